@@ -1,0 +1,659 @@
+/*
+ * vfm_oracle.c -- CPU restatement ("oracle") of the VFM-Registration
+ * correspondence-and-solve hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product path (vfm-registration_amd/) never does.
+ *
+ * Build (see oracle/Makefile):
+ *   gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -shared -fPIC
+ * -ffp-contract=off matters: every fp64 expression below is evaluated
+ * left-to-right with one rounding per operation, which is the op sequence the
+ * HIP kernels replicate to obtain bit-identical indices / masks / poses.
+ *
+ * Parity status per stage:
+ *   projection, descriptor lifting, transform_pcl, Kabsch: PINNED against the
+ *     importable reference functions through tests/golden/ fixtures
+ *     (tests/golden/make_golden.py imports /root/reference in the build
+ *     container and records inputs + the reference's outputs).
+ *   IP top-1 (faiss, unpinned git clone), RANSAC (Open3D 0.18) and DINOv2
+ *     (torch.hub FeatUp): the arithmetic lives in third-party code absent from
+ *     /root/reference and the reference holds no test for it:
+ *     PARITY UNPINNED for those stages; the restatements follow the published
+ *     algorithms and the reference's call sites cited at each function.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------ */
+/* Row A5 step (2): faiss::fvec_renorm_L2, called per row at                 */
+/* VoxelHashMap.cpp:474 and :480.  faiss computes nr = sum x^2 in fp32 (SIMD */
+/* order unspecified), inv_nr = 1.0 / sqrtf(nr) (double divide, stored as    */
+/* float) and scales the row in fp32 iff nr > 0.  The summation order is     */
+/* fixed here to: 64 partial sums, element k goes to partial (k/4) % 64 in   */
+/* ascending k, then an xor-butterfly 32,16,8,4,2,1 -- the order a 64-lane   */
+/* wavefront with float4 loads produces.                                      */
+/* ------------------------------------------------------------------------ */
+static float orc_sumsq_f32(const float *x, int d) {
+    float p[64];
+    for (int l = 0; l < 64; ++l) p[l] = 0.0f;
+    for (int k = 0; k < d; ++k) {
+        float t = x[k] * x[k];
+        int l = (k >> 2) & 63;
+        p[l] = p[l] + t;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        float q[64];
+        for (int l = 0; l < 64; ++l) q[l] = p[l] + p[l ^ off];
+        memcpy(p, q, sizeof(p));
+    }
+    return p[0];
+}
+
+ORC_API void orc_l2norm_rows_f32(const float *x, int64_t n, int d, float *xn_out,
+                                 float *inv_out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const float *xi = x + i * (int64_t)d;
+        float *yo = xn_out + i * (int64_t)d;
+        float nr = orc_sumsq_f32(xi, d);
+        float inv = 0.0f;
+        if (nr > 0.0f) {
+            inv = (float)(1.0 / (double)sqrtf(nr));
+            for (int k = 0; k < d; ++k) yo[k] = xi[k] * inv;
+        } else {
+            for (int k = 0; k < d; ++k) yo[k] = xi[k];
+        }
+        if (inv_out) inv_out[i] = inv;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Row A5 step (3): faiss::IndexFlatIP(d).search(n, xq, k=1, D, I)           */
+/* (VoxelHashMap.cpp:486-495).  faiss evaluates <q,b> with fp32 BLAS, whose   */
+/* summation order is unspecified; the oracle decides in fp64 (sequential k, */
+/* products of two fp32 are exact in fp64) on the fp32-normalised inputs,    */
+/* ties -> lowest map index, D = (float)score.                               */
+/* ------------------------------------------------------------------------ */
+static inline double orc_dot_f64(const float *a, const float *b, int d) {
+    double acc = 0.0;
+    for (int k = 0; k < d; ++k) acc = acc + (double)a[k] * (double)b[k];
+    return acc;
+}
+
+ORC_API void orc_match_ip_top1(const float *qn, int64_t n, const float *bn, int64_t m, int d,
+                               int64_t *idx_out, float *sim_out) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t i = 0; i < n; ++i) {
+        const float *q = qn + i * (int64_t)d;
+        double best = -INFINITY;
+        int64_t bj = 0;
+        for (int64_t j = 0; j < m; ++j) {
+            double s = orc_dot_f64(q, bn + j * (int64_t)d, d);
+            if (s > best) {
+                best = s;
+                bj = j;
+            }
+        }
+        idx_out[i] = (m > 0) ? bj : -1;
+        sim_out[i] = (m > 0) ? (float)best : 0.0f;
+    }
+}
+
+/* Exact re-decision restricted to per-row candidate lists (CSR).  Used by the
+ * accelerated oracle in oracle.py: a BLAS fp32 prefilter proposes every map
+ * row whose fp32 score is within a proven bound of the row maximum, this
+ * function then decides among them exactly as orc_match_ip_top1 would. */
+ORC_API void orc_match_ip_candidates(const float *qn, int64_t n, const float *bn, int d,
+                                     const int64_t *cand_ptr, const int64_t *cand_idx,
+                                     int64_t *idx_out, float *sim_out) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < n; ++i) {
+        const float *q = qn + i * (int64_t)d;
+        double best = -INFINITY;
+        int64_t bj = -1;
+        for (int64_t c = cand_ptr[i]; c < cand_ptr[i + 1]; ++c) {
+            int64_t j = cand_idx[c];
+            double s = orc_dot_f64(q, bn + j * (int64_t)d, d);
+            if (s > best || (s == best && j < bj)) {
+                best = s;
+                bj = j;
+            }
+        }
+        idx_out[i] = bj;
+        sim_out[i] = (bj >= 0) ? (float)best : 0.0f;
+    }
+}
+
+/* Row A6: find_correspondences' find_knn_cpu (registration_node.py:485-496):
+ * exact Euclidean 1-NN of every row of a among the rows of b (cKDTree.query
+ * k=1).  Decided on squared distances accumulated in fp64, sequential k,
+ * ties -> lowest index. dist_out = sqrt(d2) as cKDTree returns. */
+ORC_API void orc_nn_l2(const float *a, int64_t n, const float *b, int64_t m, int d,
+                       int64_t *idx_out, double *dist_out) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t i = 0; i < n; ++i) {
+        const float *q = a + i * (int64_t)d;
+        double best = INFINITY;
+        int64_t bj = -1;
+        for (int64_t j = 0; j < m; ++j) {
+            const float *p = b + j * (int64_t)d;
+            double acc = 0.0;
+            for (int k = 0; k < d; ++k) {
+                double t = (double)q[k] - (double)p[k];
+                acc = acc + t * t;
+            }
+            if (acc < best) {
+                best = acc;
+                bj = j;
+            }
+        }
+        idx_out[i] = bj;
+        if (dist_out) dist_out[i] = sqrt(best);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Row A5 steps (4)+(6): valid = !(D < min_cosine_similarity)                 */
+/* (VoxelHashMap.cpp:501-511, float D promoted to double), survivors emitted  */
+/* in query order (VoxelHashMap.cpp:587-600).                                 */
+/* ------------------------------------------------------------------------ */
+ORC_API int64_t orc_threshold_compact(const float *sim, int64_t n, double thr, int64_t *keep_out) {
+    int64_t c = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (!((double)sim[i] < thr)) keep_out[c++] = i;
+    }
+    return c;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Counter-based RNG replacing Open3D's global mt19937:      */
+/* Philox4x32-10 (Salmon et al., SC'11), key = seed, counter = (hyp,0,0,0).  */
+/* ------------------------------------------------------------------------ */
+static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                 uint32_t k1, uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c0;
+        uint64_t p1 = (uint64_t)M1 * c2;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n1 = lo1;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        uint32_t n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+ORC_API void orc_philox(uint32_t ctr, uint64_t seed, uint32_t out[4]) {
+    philox4x32_10(ctr, 0u, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), out);
+}
+
+/* ------------------------------------------------------------------------ */
+/* Row A9: Kabsch / Umeyama without scaling (Eigen::umeyama as used by        */
+/* Open3D's TransformationEstimationPointToPoint(False), call site            */
+/* registration_node.py:319-327; in-tree analogue pointdsc/common.py:7-47).   */
+/*   mean      = (sum_i w_i p_i) / (sum_i w_i + denom_eps)                    */
+/*   sigma     = sum_i w_i (b_i - mb)(a_i - ma)^T * (1/sum w)                 */
+/*   R         = U diag(1,1,det(U V^T)) V^T,  t = mb - R ma                   */
+/* The 3x3 SVD is replaced by a FIXED operation sequence (one-sided Jacobi,   */
+/* 6 cyclic sweeps, only + - * / sqrt) so that the HIP kernel can reproduce   */
+/* the result bit for bit.  R is assembled from the two dominant singular    */
+/* pairs and their cross products, which equals Umeyama's reflection-fixed   */
+/* solution (and is well defined for the rank-2 sigma of a 3-point sample).  */
+/* Returns 0 (invalid) when the second singular value vanishes relative to   */
+/* the first (collinear / repeated sample).                                   */
+/* ------------------------------------------------------------------------ */
+#define ORC_JACOBI_SWEEPS 6
+
+static int orc_rot_from_sigma(const double S[9], double R[9]) {
+    /* G = sigma (columns g0,g1,g2), V = I */
+    double G[3][3], V[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            G[r][c] = S[r * 3 + c];
+            V[r][c] = (r == c) ? 1.0 : 0.0;
+        }
+    static const int PP[3] = {0, 0, 1}, QQ[3] = {1, 2, 2};
+    for (int sweep = 0; sweep < ORC_JACOBI_SWEEPS; ++sweep) {
+        for (int e = 0; e < 3; ++e) {
+            const int p = PP[e], q = QQ[e];
+            double alpha = (G[0][p] * G[0][p] + G[1][p] * G[1][p]) + G[2][p] * G[2][p];
+            double beta = (G[0][q] * G[0][q] + G[1][q] * G[1][q]) + G[2][q] * G[2][q];
+            double gamma = (G[0][p] * G[0][q] + G[1][p] * G[1][q]) + G[2][p] * G[2][q];
+            if (gamma == 0.0) continue;
+            double zeta = (beta - alpha) / (2.0 * gamma);
+            double az = fabs(zeta);
+            double tt = 1.0 / (az + sqrt(1.0 + zeta * zeta));
+            if (zeta < 0.0) tt = -tt;
+            double c = 1.0 / sqrt(1.0 + tt * tt);
+            double s = c * tt;
+            for (int r = 0; r < 3; ++r) {
+                double gp = G[r][p], gq = G[r][q];
+                G[r][p] = c * gp - s * gq;
+                G[r][q] = s * gp + c * gq;
+                double vp = V[r][p], vq = V[r][q];
+                V[r][p] = c * vp - s * vq;
+                V[r][q] = s * vp + c * vq;
+            }
+        }
+    }
+    double nn[3];
+    for (int c = 0; c < 3; ++c) nn[c] = (G[0][c] * G[0][c] + G[1][c] * G[1][c]) + G[2][c] * G[2][c];
+    /* two dominant columns, ties -> lowest column index */
+    int i1 = 0;
+    if (nn[1] > nn[i1]) i1 = 1;
+    if (nn[2] > nn[i1]) i1 = 2;
+    int i2 = -1;
+    for (int c = 0; c < 3; ++c) {
+        if (c == i1) continue;
+        if (i2 < 0 || nn[c] > nn[i2]) i2 = c;
+    }
+    if (!(nn[i1] > 0.0)) return 0;
+    if (!(nn[i2] > nn[i1] * 1e-20)) return 0;
+    double s1 = sqrt(nn[i1]), s2 = sqrt(nn[i2]);
+    double u1[3], u2[3], u3[3], v1[3], v2[3], v3[3];
+    for (int r = 0; r < 3; ++r) {
+        u1[r] = G[r][i1] / s1;
+        u2[r] = G[r][i2] / s2;
+        v1[r] = V[r][i1];
+        v2[r] = V[r][i2];
+    }
+    u3[0] = u1[1] * u2[2] - u1[2] * u2[1];
+    u3[1] = u1[2] * u2[0] - u1[0] * u2[2];
+    u3[2] = u1[0] * u2[1] - u1[1] * u2[0];
+    v3[0] = v1[1] * v2[2] - v1[2] * v2[1];
+    v3[1] = v1[2] * v2[0] - v1[0] * v2[2];
+    v3[2] = v1[0] * v2[1] - v1[1] * v2[0];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) R[r * 3 + c] = (u1[r] * v1[c] + u2[r] * v2[c]) + u3[r] * v3[c];
+    return 1;
+}
+
+/* A, B: n x 3 row-major; w: n or NULL; T: 4x4 row-major. returns validity. */
+ORC_API int orc_kabsch(const double *A, const double *B, const double *w, int64_t n,
+                       double denom_eps, double *T) {
+    double ma[3] = {0, 0, 0}, mb[3] = {0, 0, 0}, sw = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        double wi = w ? w[i] : 1.0;
+        sw = sw + wi;
+        for (int c = 0; c < 3; ++c) {
+            ma[c] = ma[c] + wi * A[i * 3 + c];
+            mb[c] = mb[c] + wi * B[i * 3 + c];
+        }
+    }
+    double inv = 1.0 / (sw + denom_eps);
+    for (int c = 0; c < 3; ++c) {
+        ma[c] = ma[c] * inv;
+        mb[c] = mb[c] * inv;
+    }
+    double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = 0; i < n; ++i) {
+        double wi = w ? w[i] : 1.0;
+        double ad[3], bd[3];
+        for (int c = 0; c < 3; ++c) {
+            ad[c] = A[i * 3 + c] - ma[c];
+            bd[c] = B[i * 3 + c] - mb[c];
+        }
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) S[r * 3 + c] = S[r * 3 + c] + (wi * bd[r]) * ad[c];
+    }
+    double invs = 1.0 / sw;
+    for (int k = 0; k < 9; ++k) S[k] = S[k] * invs;
+    double R[9];
+    for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    if (!orc_rot_from_sigma(S, R)) return 0;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) T[r * 4 + c] = R[r * 3 + c];
+        T[r * 4 + 3] = mb[r] - ((R[r * 3 + 0] * ma[0] + R[r * 3 + 1] * ma[1]) + R[r * 3 + 2] * ma[2]);
+    }
+    return 1;
+}
+
+ORC_API void orc_kabsch_batched(const double *A, const double *B, const double *w, int64_t b,
+                                int64_t n, double denom_eps, double *T, int32_t *valid) {
+    for (int64_t i = 0; i < b; ++i) {
+        int v = orc_kabsch(A + i * n * 3, B + i * n * 3, w ? w + i * n : NULL, n, denom_eps,
+                           T + i * 16);
+        if (valid) valid[i] = v;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Row A8: open3d.pipelines.registration.                                    */
+/*   registration_ransac_based_on_correspondence(src, tgt, corres, max_dist, */
+/*       TransformationEstimationPointToPoint(False), ransac_n=3,             */
+/*       RANSACConvergenceCriteria(n_iter, 1.0))                              */
+/* as called at registration_node.py:319-327 (Open3D 0.18.0, Dockerfile:81). */
+/* Per iteration: draw 3 correspondences uniformly with replacement,         */
+/* estimate T (A9), transform every source point, score                       */
+/*   inlier iff |T s - t|^2 < max_dist^2, fitness = inliers / C,             */
+/*   rmse = sqrt(sum inlier err^2 / inliers),                                 */
+/* keep if fitness higher, or equal and rmse lower (IsBetterRANSACThan);     */
+/* confidence = 1 -> never exits early.  Deviations, all documented in       */
+/* RNG = Philox (Open3D's is thread-order dependent), earliest    */
+/* hypothesis wins exact ties, degenerate samples are skipped.               */
+/* ------------------------------------------------------------------------ */
+static inline int orc_sample_T(const double *src, const double *tgt, const int32_t *corres,
+                               int64_t C, uint32_t hyp, uint64_t seed, double T[16]) {
+    uint32_t r[4];
+    philox4x32_10(hyp, 0u, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    double A[9], B[9];
+    for (int j = 0; j < 3; ++j) {
+        uint64_t pick = ((uint64_t)r[j] * (uint64_t)C) >> 32;
+        const double *s = src + 3 * (int64_t)corres[2 * pick + 0];
+        const double *t = tgt + 3 * (int64_t)corres[2 * pick + 1];
+        for (int c = 0; c < 3; ++c) {
+            A[j * 3 + c] = s[c];
+            B[j * 3 + c] = t[c];
+        }
+    }
+    return orc_kabsch(A, B, NULL, 3, 0.0, T);
+}
+
+static inline double orc_err2(const double T[16], const double *s, const double *t) {
+    double x = ((T[0] * s[0] + T[1] * s[1]) + T[2] * s[2]) + T[3];
+    double y = ((T[4] * s[0] + T[5] * s[1]) + T[6] * s[2]) + T[7];
+    double z = ((T[8] * s[0] + T[9] * s[1]) + T[10] * s[2]) + T[11];
+    double dx = x - t[0], dy = y - t[1], dz = z - t[2];
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+/* hyp_fit / hyp_rmse: optional n_iter-long per-hypothesis records (NULL ok). */
+ORC_API int orc_ransac_corr(const double *src, const double *tgt, const int32_t *corres, int64_t C,
+                            double max_dist, int32_t n_iter, uint64_t seed, double *T_out,
+                            double *fitness_out, double *rmse_out, uint8_t *mask_out,
+                            int32_t *best_hyp_out, double *hyp_fit, double *hyp_rmse) {
+    for (int k = 0; k < 16; ++k) T_out[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    *fitness_out = 0.0;
+    *rmse_out = 0.0;
+    *best_hyp_out = -1;
+    if (mask_out) memset(mask_out, 0, (size_t)(C > 0 ? C : 0));
+    if (C < 3 || max_dist <= 0.0) return 0;
+    const double max_d2 = max_dist * max_dist;
+
+    double *fit = (double *)malloc(sizeof(double) * (size_t)n_iter);
+    double *rms = (double *)malloc(sizeof(double) * (size_t)n_iter);
+#pragma omp parallel for schedule(dynamic, 32)
+    for (int32_t h = 0; h < n_iter; ++h) {
+        double T[16];
+        fit[h] = -1.0;
+        rms[h] = 0.0;
+        if (!orc_sample_T(src, tgt, corres, C, (uint32_t)h, seed, T)) continue;
+        int64_t good = 0;
+        double e2 = 0.0;
+        for (int64_t i = 0; i < C; ++i) {
+            double d2 = orc_err2(T, src + 3 * (int64_t)corres[2 * i], tgt + 3 * (int64_t)corres[2 * i + 1]);
+            if (d2 < max_d2) {
+                good++;
+                e2 = e2 + d2;
+            }
+        }
+        if (good == 0) {
+            fit[h] = 0.0;
+            rms[h] = 0.0;
+        } else {
+            fit[h] = (double)good / (double)C;
+            rms[h] = sqrt(e2 / (double)good);
+        }
+    }
+    /* sequential selection == Open3D's loop run on one thread */
+    double bf = 0.0, br = 0.0;
+    int32_t bh = -1;
+    for (int32_t h = 0; h < n_iter; ++h) {
+        if (fit[h] < 0.0) continue;
+        if (fit[h] > bf || (fit[h] == bf && rms[h] < br)) {
+            bf = fit[h];
+            br = rms[h];
+            bh = h;
+        }
+    }
+    if (hyp_fit) memcpy(hyp_fit, fit, sizeof(double) * (size_t)n_iter);
+    if (hyp_rmse) memcpy(hyp_rmse, rms, sizeof(double) * (size_t)n_iter);
+    free(fit);
+    free(rms);
+    if (bh >= 0) {
+        double T[16];
+        orc_sample_T(src, tgt, corres, C, (uint32_t)bh, seed, T);
+        memcpy(T_out, T, sizeof(T));
+        *fitness_out = bf;
+        *rmse_out = br;
+        *best_hyp_out = bh;
+        if (mask_out) {
+            for (int64_t i = 0; i < C; ++i) {
+                double d2 = orc_err2(T, src + 3 * (int64_t)corres[2 * i], tgt + 3 * (int64_t)corres[2 * i + 1]);
+                mask_out[i] = (d2 < max_d2) ? 1 : 0;
+            }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Row A2: LiDAR -> image projection.  One generic pinhole core with the     */
+/* three dataset front-ends restated exactly (operation order spelled out):  */
+/*  mode 0 NCLT  (dataloader/nclt.py:311-366)                                 */
+/*     pc = T_c_body @ p (4-term dots, left-to-right), q = K @ pc[:3],       */
+/*     x = q0/q2/sub, y = q1/q2/sub, keep z=q2 > 0, trunc to int, keep        */
+/*     win_c <= x < win_c + win_w and win_r <= y < win_r + win_h, shift by    */
+/*     the window origin, keep pixels with any RGB != 0.                      */
+/*  mode 1 RobotCar (dataloader/oxford_robotcar.py:330-363)                   */
+/*     pc = Tm @ p where Tm is applied as THREE successive 4x4 products       */
+/*     (lidar_in_ego, cam_in_ego, inv(G_camera_image) via solve), keep        */
+/*     z >= 0, u = fx*x/z + cx, v = fy*y/z + cy, /= sub, keep 0<=u<=W and     */
+/*     0<=v<=H (inclusive upper bound -- reference quirk), trunc.             */
+/*  mode 2 KITTI  (dataloader/kitti_odometry.py:110-125)                      */
+/*     q = (P2 @ Tr) @ p, keep z > 0, u = q0/z/sub, v = q1/z/sub, inclusive   */
+/*     bounds, trunc.                                                         */
+/* The matrix products that numpy hands to BLAS (unspecified order for K=4)  */
+/* are restated as explicit left-to-right sums; the golden fixtures record   */
+/* that the reference's outputs agree on the committed inputs.               */
+/* ------------------------------------------------------------------------ */
+static inline double dot4(const double *r, const double *p) {
+    return ((r[0] * p[0] + r[1] * p[1]) + r[2] * p[2]) + r[3] * p[3];
+}
+static inline double dot3(const double *r, const double *p) {
+    return (r[0] * p[0] + r[1] * p[1]) + r[2] * p[2];
+}
+
+/* pcl: 4 x N column-major in the numpy sense, i.e. pcl[r*N + i].
+ * Mats: mode 0: M0 = T_c_body (4x4), M1 = K (3x3 in the first 9 entries).
+ *       mode 1: M0 = lidar_in_ego, M1 = cam_in_ego, M2 = inv(G_camera_image)
+ *               (4x4 each), fc = {fx, fy, cx, cy}.
+ *       mode 2: M0 = P2 @ Tr (3x4 in the first 12 entries).
+ * image: H x W x 3 uint8 or NULL (mode 0 only uses it).
+ * win = {row0, col0, h, w} already divided by subsample (mode 0).
+ * returns K; u,v int64, idx int64 in ascending point order. */
+ORC_API int64_t orc_project(int mode, const double *pcl, int64_t n, const double *M0,
+                            const double *M1, const double *M2, const double *fc, double subsample,
+                            const int64_t *win, const uint8_t *image, int64_t H, int64_t W,
+                            int64_t *u_out, int64_t *v_out, int64_t *idx_out) {
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double p[4] = {pcl[0 * n + i], pcl[1 * n + i], pcl[2 * n + i], pcl[3 * n + i]};
+        int64_t ui, vi;
+        if (mode == 0) {
+            double pc[3];
+            for (int r = 0; r < 3; ++r) pc[r] = dot4(M0 + 4 * r, p);
+            double q0 = dot3(M1 + 0, pc), q1 = dot3(M1 + 3, pc), q2 = dot3(M1 + 6, pc);
+            double x = q0 / q2 / subsample;
+            double y = q1 / q2 / subsample;
+            if (!(q2 > 0.0)) continue;
+            /* astype(int) of |x| >= 2^63 yields INT64_MIN in numpy, which the window test
+             * then rejects; stay clear of C's undefined conversion with an explicit range
+             * test (also rejects NaN). */
+            if (!(x > -2147483648.0 && x < 2147483648.0)) continue;
+            if (!(y > -2147483648.0 && y < 2147483648.0)) continue;
+            ui = (int64_t)x; /* astype(int): truncation toward zero */
+            vi = (int64_t)y;
+            if (ui < win[1] || ui >= win[1] + win[3]) continue;
+            if (vi < win[0] || vi >= win[0] + win[2]) continue;
+            ui -= win[1];
+            vi -= win[0];
+            if (image) {
+                const uint8_t *px = image + (vi * W + ui) * 3;
+                if (px[0] == 0 && px[1] == 0 && px[2] == 0) continue;
+            }
+        } else if (mode == 1) {
+            double a[4], b[4], c[4];
+            for (int r = 0; r < 4; ++r) a[r] = dot4(M0 + 4 * r, p);
+            for (int r = 0; r < 4; ++r) b[r] = dot4(M1 + 4 * r, a);
+            for (int r = 0; r < 4; ++r) c[r] = dot4(M2 + 4 * r, b);
+            if (!(c[2] >= 0.0)) continue;
+            double uu = fc[0] * c[0] / c[2] + fc[2];
+            double vv = fc[1] * c[1] / c[2] + fc[3];
+            uu = uu / subsample;
+            vv = vv / subsample;
+            if (uu < 0.0 || uu > (double)W) continue;
+            if (vv < 0.0 || vv > (double)H) continue;
+            if (uu != uu || vv != vv) continue; /* 0/0 at z == 0: numpy comparisons are False -> kept;
+                                                   see DESIGN.md: treated as dropped */
+            ui = (int64_t)uu;
+            vi = (int64_t)vv;
+        } else {
+            double q0 = dot4(M0 + 0, p), q1 = dot4(M0 + 4, p), q2 = dot4(M0 + 8, p);
+            if (!(q2 > 0.0)) continue;
+            double uu = q0 / q2 / subsample;
+            double vv = q1 / q2 / subsample;
+            if (uu < 0.0 || uu > (double)W) continue;
+            if (vv < 0.0 || vv > (double)H) continue;
+            ui = (int64_t)uu;
+            vi = (int64_t)vv;
+        }
+        u_out[k] = ui;
+        v_out[k] = vi;
+        idx_out[k] = i;
+        ++k;
+    }
+    return k;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Rows A1(tail)+A3: "bilinear upsample to H x W then index [v,u]"           */
+/* (image_features.py:104-110 + prepare_scenes.py:85-91) evaluated per       */
+/* point without materialising the H x W x C tensor.  PyTorch                 */
+/* upsample_bilinear2d(align_corners=False) semantics in fp32:               */
+/*   src = (dst + 0.5) * (in / out) - 0.5, clamped below at 0,               */
+/*   i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1        */
+/*   out = h0*(w0*f00 + w1*f01) + h1*(w0*f10 + w1*f11)                        */
+/* grid: gh x gw x C (channels last) fp32.  rot_mode 1 = NCLT: the feature   */
+/* map is rot90(k=1) of the upsampled map (prepare_scenes.py:80-81), i.e.    */
+/* out_rot[v,u] = up[u, W_up-1-v] where up is H_up x W_up.                    */
+/* ------------------------------------------------------------------------ */
+static inline void orc_src_index(float scale, int64_t dst, int64_t in_size, int64_t *i0, int64_t *i1,
+                                 float *l0, float *l1) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.0f) src = 0.0f;
+    int64_t a = (int64_t)src;
+    if (a > in_size - 1) a = in_size - 1;
+    int64_t b = a + ((a < in_size - 1) ? 1 : 0);
+    float lam = src - (float)a;
+    if (lam < 0.0f) lam = 0.0f;
+    if (lam > 1.0f) lam = 1.0f;
+    *i0 = a;
+    *i1 = b;
+    *l1 = lam;
+    *l0 = 1.0f - lam;
+}
+
+ORC_API void orc_gather_bilinear(const float *grid, int64_t gh, int64_t gw, int64_t C, int64_t Hup,
+                                 int64_t Wup, int rot_mode, const int64_t *u, const int64_t *v,
+                                 int64_t k, float *out) {
+    const float sh = (float)gh / (float)Hup; /* torch: area_pixel_compute_scale = in/out in fp32 */
+    const float sw = (float)gw / (float)Wup;
+    for (int64_t i = 0; i < k; ++i) {
+        int64_t row, col; /* position in the upsampled (un-rotated) map */
+        if (rot_mode == 1) {
+            row = u[i];
+            col = Wup - 1 - v[i];
+        } else {
+            row = v[i];
+            col = u[i];
+        }
+        int64_t h0, h1, w0, w1;
+        float hl0, hl1, wl0, wl1;
+        orc_src_index(sh, row, gh, &h0, &h1, &hl0, &hl1);
+        orc_src_index(sw, col, gw, &w0, &w1, &wl0, &wl1);
+        const float *f00 = grid + (h0 * gw + w0) * C;
+        const float *f01 = grid + (h0 * gw + w1) * C;
+        const float *f10 = grid + (h1 * gw + w0) * C;
+        const float *f11 = grid + (h1 * gw + w1) * C;
+        float *o = out + i * C;
+        for (int64_t c = 0; c < C; ++c) {
+            float top = wl0 * f00[c] + wl1 * f01[c];
+            float bot = wl0 * f10[c] + wl1 * f11[c];
+            o[c] = hl0 * top + hl1 * bot;
+        }
+    }
+}
+
+/* Row A4: transform_pcl (vfm_reg/utils.py:47-54): xyz' = T[:3,:] @ [xyz;1] in
+ * fp64 (4-term dot, left-to-right), descriptors carried through. */
+ORC_API void orc_transform_xyz(const double *xyz, int64_t n, const double *T, double *out) {
+    for (int64_t i = 0; i < n; ++i) {
+        double p[4] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 1.0};
+        for (int r = 0; r < 3; ++r) out[3 * i + r] = dot4(T + 4 * r, p);
+    }
+}
+
+/* Row F1: kiss_icp VoxelDownsample (Preprocessing.cpp:50-137): first point
+ * per voxel, voxel = trunc(p / voxel_size) per axis (Eigen cast<int>).  The
+ * reference emits survivors in robin_map iteration order; the build emits
+ * them in input order (documented deviation).  keep_out: indices of
+ * survivors; returns their number.  O(n log n) via sort of keys. */
+typedef struct {
+    int32_t v[3];
+    int64_t i;
+} orc_vox_t;
+static int orc_vox_cmp(const void *a, const void *b) {
+    const orc_vox_t *x = (const orc_vox_t *)a, *y = (const orc_vox_t *)b;
+    for (int c = 0; c < 3; ++c) {
+        if (x->v[c] < y->v[c]) return -1;
+        if (x->v[c] > y->v[c]) return 1;
+    }
+    return (x->i < y->i) ? -1 : (x->i > y->i);
+}
+static int orc_i64_cmp(const void *a, const void *b) {
+    int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
+    return (x < y) ? -1 : (x > y);
+}
+ORC_API int64_t orc_voxel_first(const double *pts, int64_t n, int64_t stride, double voxel_size,
+                                int64_t max_per_voxel, int64_t *keep_out) {
+    orc_vox_t *a = (orc_vox_t *)malloc(sizeof(orc_vox_t) * (size_t)(n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; ++i) {
+        for (int c = 0; c < 3; ++c) a[i].v[c] = (int32_t)(pts[i * stride + c] / voxel_size);
+        a[i].i = i;
+    }
+    qsort(a, (size_t)n, sizeof(orc_vox_t), orc_vox_cmp);
+    int64_t k = 0, run = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (i > 0 && a[i].v[0] == a[i - 1].v[0] && a[i].v[1] == a[i - 1].v[1] &&
+            a[i].v[2] == a[i - 1].v[2])
+            run++;
+        else
+            run = 0;
+        if (run < max_per_voxel) keep_out[k++] = a[i].i;
+    }
+    free(a);
+    qsort(keep_out, (size_t)k, sizeof(int64_t), orc_i64_cmp);
+    return k;
+}
+
+ORC_API int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
