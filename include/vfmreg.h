@@ -1,0 +1,174 @@
+/*
+ * vfmreg.h -- C ABI of libvfmreg_hip.so: the MI355X (gfx950) implementation of the
+ * VFM-Registration correspondence-and-solve hot path.
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types; every pointer is a DEVICE pointer unless its name ends in
+ *     _host; all matrices are row-major; sizes are element counts.
+ *   - the caller owns every buffer.  Scratch is caller-provided and sized by the matching
+ *     vfm_*_workspace_bytes(); no hidden allocation, no global state except the thread-local
+ *     last-error string.  All work is enqueued on `stream` (a hipStream_t passed as void*);
+ *     nothing synchronises the device, so calls can be chained and captured in a hipGraph.
+ *   - return 0 on success, a negative VFM_E* code otherwise; vfm_last_error() describes it.
+ *
+ * Reference interfaces replaced (paths relative to /root/reference):
+ *   RN  = src/vfm-reg/src/registration_node.py      PS  = src/vfm-reg/src/prepare_scenes.py
+ *   IF  = src/vfm-reg/src/vfm_reg/image_features.py UT  = src/vfm-reg/src/vfm_reg/utils.py
+ *   VHM = src/kiss-icp/cpp/kiss_icp/core/VoxelHashMap.cpp
+ *   PYB = src/kiss-icp/python/kiss_icp/pybind/kiss_icp_pybind.cpp
+ *   NCLT/OXF/KIT = src/vfm-reg/src/dataloader/{nclt,oxford_robotcar,kitti_odometry}.py
+ */
+#ifndef VFMREG_H
+#define VFMREG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VFM_OK 0
+#define VFM_EINVAL (-1)    /* bad argument (shape, alignment, unsupported size) */
+#define VFM_EWORKSPACE (-2) /* workspace too small */
+#define VFM_EHIP (-3)      /* HIP runtime error at launch */
+
+typedef void *vfm_stream_t; /* hipStream_t */
+
+const char *vfm_last_error(void);
+/* "gfx950" build id + version, for the loader's sanity check */
+const char *vfm_build_info(void);
+
+/* ------------------------------------------------------------------ matching (row A5) */
+
+/* faiss::fvec_renorm_L2(d, 1, row) applied to every row (VHM:474, VHM:480): in place,
+ * fp32, rows with zero norm untouched.  inv_out (nullable) receives 1/|row| (0 for zero rows).
+ * Requires d % 4 == 0. */
+int vfm_l2norm_rows_f32(float *x, int64_t n, int d, float *inv_out, vfm_stream_t stream);
+
+/* precision modes of the top-1 search */
+#define VFM_MATCH_FAST 0  /* fp16 MFMA coarse pass + exact fp64 re-decision (indices == EXACT) */
+#define VFM_MATCH_EXACT 1 /* all-pairs fp64 on the vector ALUs (small sizes / cross-check) */
+
+/* faiss::IndexFlatIP(d).add(m, xb) + .search(n, xq, k=1, D, I) on rows that are L2-normalised
+ * first (the whole of VHM:469-495).  q, b: RAW (un-normalised) fp32 descriptors, row-major
+ * n x d and m x d.  idx_out[i] = argmax_j <qn_i, bn_j> decided in fp64 on the fp32-normalised
+ * rows, ties -> lowest j; sim_out[i] = (float) of that score.  Zero-norm query rows give
+ * idx 0 / sim 0.  FAST requires d % 128 == 0 and d <= 512. */
+size_t vfm_match_ip_top1_workspace_bytes(int64_t n, int64_t m, int d, int prec_mode);
+int vfm_match_ip_top1(const float *q, int64_t n, const float *b, int64_t m, int d, int prec_mode,
+                      int64_t *idx_out, float *sim_out, void *ws, size_t ws_bytes,
+                      vfm_stream_t stream);
+
+/* Split form for a map that is searched many times (IndexFlatIP.add once, VHM:487): the
+ * prepared operand holds 1/|row| and the fp16 MFMA-fragment image of the normalised rows. */
+size_t vfm_match_prepared_bytes(int64_t rows, int d);
+int vfm_match_prepare(const float *x, int64_t rows, int d, void *prepared, vfm_stream_t stream);
+size_t vfm_match_search_workspace_bytes(int64_t n, int64_t m, int d);
+int vfm_match_search_prepared(const float *q, const void *q_prepared, int64_t n, const float *b,
+                              const void *b_prepared, int64_t m, int d, int64_t *idx_out,
+                              float *sim_out, void *ws, size_t ws_bytes, vfm_stream_t stream);
+
+/* valid = !(D < min_cosine_similarity) (VHM:501-511), survivors in query order (VHM:587-600).
+ * keep_out[k] = query index of the k-th survivor, *count_out = K.  corres_out (nullable,
+ * n x 2 int32) receives (query index, idx[query index]) per survivor -- the Vector2iVector the
+ * reference rebuilds at RN:295-317.  src_xyz_out / tgt_xyz_out (nullable, n x 3 fp64) receive
+ * the coordinate pairs GetVFMCorrespondences returns (PYB:128-129); q_xyz n x 3, b_xyz m x 3. */
+int vfm_threshold_compact(const float *sim, const int64_t *idx, int64_t n, double thr,
+                          int64_t *keep_out, int64_t *count_out, int32_t *corres_out,
+                          const double *q_xyz, const double *b_xyz, double *src_xyz_out,
+                          double *tgt_xyz_out, vfm_stream_t stream);
+
+/* find_correspondences' nearest neighbours (RN:482-538): exact Euclidean 1-NN of every row of a
+ * (n x d) among b (m x d) and, if nn_ba != NULL, of every row of b among a; fp64 decision,
+ * ties -> lowest index.  d2_ab (nullable): squared distance.  Any d >= 1. */
+int vfm_match_mutual_l2(const float *a, int64_t n, const float *b, int64_t m, int d,
+                        int64_t *nn_ab, double *d2_ab, int64_t *nn_ba, vfm_stream_t stream);
+
+/* ------------------------------------------------------------------ RANSAC (rows A8, A9) */
+
+/* open3d.pipelines.registration.registration_ransac_based_on_correspondence(src, tgt, corres,
+ * max_dist, TransformationEstimationPointToPoint(False), 3, RANSACConvergenceCriteria(n_iter, 1))
+ * as called at RN:319-327.  src ns x 3, tgt nt x 3 fp64; corres C x 2 int32.  The number of
+ * correspondences is read ON THE DEVICE from *count_dev when count_dev != NULL (<= c_max),
+ * otherwise it is c_max.  Hypothesis h draws its 3 correspondences from Philox4x32-10
+ * (key = seed, counter = h).  Outputs: T_out 4x4 fp64, fitness, rmse (1 fp64 each), inlier_mask
+ * (c_max bytes, nullable), best_hyp (int32, -1 if no hypothesis had an inlier). */
+size_t vfm_ransac_workspace_bytes(int64_t c_max, int32_t n_iter);
+int vfm_ransac_corr(const double *src, const double *tgt, const int32_t *corres,
+                    const int64_t *count_dev, int64_t c_max, double max_dist, int32_t n_iter,
+                    uint64_t seed, double *T_out, double *fitness_out, double *rmse_out,
+                    uint8_t *inlier_mask, int32_t *best_hyp_out, void *ws, size_t ws_bytes,
+                    vfm_stream_t stream);
+
+/* Eigen::umeyama(with_scaling=false) / pointdsc.common.rigid_transform_3d
+ * (src/vfm-reg/src/pointdsc/common.py:7-47), batched: A, B b x n x 3, w b x n or NULL,
+ * denom_eps added to sum(w) in the centroids (0 for Umeyama, 1e-6 for the PointDSC variant).
+ * T_out b x 16; valid (nullable) 0 where the sample is degenerate (T = identity). */
+int vfm_kabsch_batched(const double *A, const double *B, const double *w, int64_t b, int64_t n,
+                       double denom_eps, double *T_out, int32_t *valid, vfm_stream_t stream);
+
+/* ------------------------------------------------------------------ projection (rows A2-A4) */
+
+#define VFM_PROJ_NCLT 0     /* NCLT:311-366 */
+#define VFM_PROJ_ROBOTCAR 1 /* OXF:330-363  */
+#define VFM_PROJ_KITTI 2    /* KIT:110-125  */
+
+/* Dataset.project_pcl_to_image.  pcl: 4 x n fp64 (row r at pcl + r*n, device); the small
+ * calibration arrays are HOST pointers (copied into the launch).  mats_host: 48 fp64 =
+ *   NCLT:     [T_c_body 4x4 | K 3x3 (9, rest unused) | unused]
+ *   ROBOTCAR: [lidar_in_ego 4x4 | <cam>_in_ego 4x4 | inv(G_camera_image) 4x4],
+ *             fc_host = fx,fy,cx,cy
+ *   KITTI:    [P2 @ Tr_velo_to_cam 3x4 (12) | unused | unused]
+ * win = {row0, col0, h, w} // subsample (NCLT crop window), image H x W x 3 uint8 (NCLT only,
+ * nullable), outputs u, v (int32), idx (int64) in ascending point order, *count_out = K.
+ * ws: vfm_project_workspace_bytes(n). */
+size_t vfm_project_workspace_bytes(int64_t n);
+int vfm_project_pinhole_f64(int mode, const double *pcl, int64_t n, const double *mats_host,
+                            const double *fc_host, double subsample, const int64_t *win_host,
+                            const uint8_t *image, int64_t H, int64_t W, int32_t *u_out,
+                            int32_t *v_out, int64_t *idx_out, int64_t *count_out, void *ws,
+                            size_t ws_bytes, vfm_stream_t stream);
+
+/* F.interpolate(bilinear, align_corners=False) to Hup x Wup (IF:104-108), black-pixel zeroing
+ * (PS:57-62), NCLT rot90 (PS:80-81), per-point gather feat[v,u,:] (PS:85-91) and
+ * first-camera-wins scatter (PS:96-104) for ONE camera; call once per camera in priority
+ * order on the same desc_out / filled (zero-initialised by the caller).
+ * grid gh x gw x C fp32 (channels last); image Himg x Wimg x 3 uint8 = the UN-rotated image
+ * (nullable: no black test); u, v, idx, *count_dev from vfm_project_pinhole_f64. */
+int vfm_gather_bilinear_patchgrid(const float *grid, int gh, int gw, int C, int Hup, int Wup,
+                                  int rot_mode, const uint8_t *image, const int32_t *u,
+                                  const int32_t *v, const int64_t *idx, const int64_t *count_dev,
+                                  int64_t k_max, float *desc_out, uint8_t *filled,
+                                  vfm_stream_t stream);
+
+/* transform_pcl (UT:47-54): xyz' = T[:3,:] @ [xyz;1], fp64. T: 16 fp64 on the device. */
+int vfm_transform_xyz_f64(const double *xyz, int64_t n, const double *T, double *out,
+                          vfm_stream_t stream);
+
+/* ------------------------------------------------------------------ DINOv2 ViT-S/14 (row A1) */
+
+/* self.model.model(img) of IF:101 incl. the transform of IF:67-77: bilinear resize (antialias
+ * off) of B uint8 images H x W x 3 to 224 x 14*pw, ImageNet normalisation, ViT (patch 14,
+ * dim 384*k, 64-wide heads, LayerScale, exact GELU), final LayerNorm, cls dropped, FeatUp
+ * ChannelNorm.  tokens_out: B x 16 x pw x dim fp32.  weights: packed blob described by
+ * vfm_vit_weights_bytes / vfmreg/vit.py.  */
+typedef struct {
+    int dim;      /* 384 */
+    int depth;    /* 12 */
+    int heads;    /* 6 */
+    int mlp_dim;  /* 1536 */
+    int patch;    /* 14 */
+    int patch_h;  /* 16 */
+    int patch_w;  /* pw */
+} vfm_vit_config;
+size_t vfm_vit_weights_bytes(const vfm_vit_config *cfg);
+size_t vfm_vit_workspace_bytes(const vfm_vit_config *cfg, int B);
+int vfm_vit_forward(const vfm_vit_config *cfg, const void *weights, const uint8_t *img, int B,
+                    int H, int W, float *tokens_out, void *ws, size_t ws_bytes,
+                    vfm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFMREG_H */

@@ -1,0 +1,58 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports every
+symbol include/vfmreg.h declares (no compute calls: there is no GPU in this container)."""
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def built():
+    subprocess.run([sys.executable, str(ROOT / "vfm-registration_amd" / "build.py")], check=True,
+                   stdout=subprocess.DEVNULL)
+    from vfmreg import _lib
+    return _lib
+
+
+def _declared():
+    text = (ROOT / "include" / "vfmreg.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vfm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(built):
+    lib = built.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vfmreg.h but not exported"
+    assert set(names) == set(built.SIGNATURES), "ctypes signature table out of sync with the header"
+    assert b"gfx950" in lib.vfm_build_info()
+
+
+def test_library_is_gfx950_code_object(built):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(built.LIB_PATH)],
+                         capture_output=True, text=True)
+    blob = built.LIB_PATH.read_bytes()
+    assert b"gfx950" in blob
+
+
+def test_host_argument_checks_need_no_gpu(built):
+    lib = built.load()
+    # argument validation happens before any launch
+    assert lib.vfm_match_ip_top1(None, 0, None, 0, 384, 0, None, None, None, 0, None) == -1
+    assert b"empty" in lib.vfm_last_error()
+    assert lib.vfm_match_prepare(1, 10, 100, 1, None) == -1  # d not in {128,...}
+    assert lib.vfm_match_prepared_bytes(20000, 384) >= 20224 * 384 * 2
+    assert lib.vfm_ransac_workspace_bytes(20000, 50000) > 20000 * 48
+
+
+def test_ops_refuse_cpu_tensors(built):
+    import torch
+    from vfmreg import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.match_ip_top1(torch.zeros(4, 384), torch.zeros(8, 384))

@@ -1,0 +1,833 @@
+// match.hip -- descriptor matching on MI355X (gfx950): the whole of
+// VoxelHashMap::GetVFMCorrespondences' search (VoxelHashMap.cpp:469-511, 587-600) and
+// find_correspondences' nearest neighbours (registration_node.py:482-538).
+//
+// Pipeline of the FAST top-1 search (indices identical to the fp64 oracle):
+//   prep_rows_kernel      fp32 rows -> 1/|row| (faiss fvec_renorm_L2 order) + fp16 copy of the
+//                         normalised rows in MFMA-fragment ("frag-major") tiles of 32 rows
+//   match_coarse_kernel   fp16 MFMA 32x32x16, queries resident in VGPRs, map tiles streamed
+//                         through an LDS ring by LDS-DMA; per (query, 128-row chunk) top-2 of the
+//                         coarse scores, never materialising N x M
+//   match_select_kernel   per query: global coarse max, every chunk within the proven error
+//                         window becomes a candidate (single row, or whole chunk if its top-2
+//                         is inside the window too)
+//   match_rescore_kernel  exact fp64 re-decision among the candidates (sequential-k dot of the
+//                         fp32-normalised rows, ties -> lowest index)
+//   match_exact_kernel    all-pairs fp64 (EXACT mode, and fallback for candidate overflow)
+// Compiled with -ffp-contract=off (fp32 sum-of-squares order must match the oracle).
+#include "common.h"
+
+#include <type_traits>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+namespace {
+
+constexpr int TILE_ROWS = 32;     // rows per fragment tile
+constexpr int CHUNK_ROWS = 128;   // map rows per partial record (4 tiles)
+constexpr int ROW_PAD = 256;      // prepared operands are padded to a multiple of this
+constexpr int QBLOCK = 256;       // queries per workgroup of the coarse kernel (8 waves x 32)
+constexpr int NBUF = 4;           // LDS ring depth (tiles)
+constexpr int CAND_CAP = 12;      // candidate chunks kept per query before falling back
+constexpr float COARSE_OFFSET = 2.0f;   // accumulators start here: every coarse score is a
+                                        // positive normal float, so uint order == float order
+constexpr float DEFAULT_WINDOW = 2.5e-3f;  // >= 2E, E = proven |coarse - exact| bound
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ---------------------------------------------------------------------------------------------
+// prepared operand layout: [inv: rows_pad floats][tiles: rows_pad/32 x (d/16 ksteps) x 64 x 16 B]
+// unit (tile, s, h, p) = 8 fp16 = row (tile*32+p), k = 16 s + 8 h .. +7  at uint4 index
+// tile*(d/16*64) + s*64 + h*32 + p : exactly the register image of one 32x32x16 MFMA operand.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int64_t rows_padded(int64_t rows) { return (rows + ROW_PAD - 1) / ROW_PAD * ROW_PAD; }
+
+// sum of squares in the oracle's order: lane l owns the float4 chunks c with c % 64 == l
+// (ascending c, ascending element inside a chunk), then an xor butterfly.  d <= 1024.
+__device__ __forceinline__ float row_sumsq_wave(const float* __restrict__ row, int d, float4 (&v)[4]) {
+    const int lane = lane_id();
+    const int nchunks = d >> 2;
+    float p = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nchunks) {
+            x = reinterpret_cast<const float4*>(row)[c];
+            float t;
+            t = x.x * x.x; p = p + t;
+            t = x.y * x.y; p = p + t;
+            t = x.z * x.z; p = p + t;
+            t = x.w * x.w; p = p + t;
+        }
+        v[i] = x;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off);
+    return p;
+}
+
+__device__ __forceinline__ float inv_norm_from_sumsq(float nr) {
+    // faiss: const float inv_nr = 1.0 / sqrtf(nr);  (double divide, rounded to float)
+    if (!(nr > 0.0f)) return 0.0f;
+    float s = __fsqrt_rn(nr);
+    return (float)(1.0 / (double)s);
+}
+
+// one workgroup (4 waves) per 32-row tile
+__global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict__ x, int64_t rows, int d,
+                                                        float* __restrict__ inv_out,
+                                                        uint4* __restrict__ tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tile = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int ksteps = d >> 4;
+    _Float16* img = reinterpret_cast<_Float16*>(smem);
+    for (int pr = wave; pr < TILE_ROWS; pr += 4) {
+        const int64_t r = (int64_t)tile * TILE_ROWS + pr;
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float inv = 0.0f;
+        if (r < rows) {
+            float nr = row_sumsq_wave(x + r * (int64_t)d, d, v);
+            inv = inv_norm_from_sumsq(nr);
+        }
+        if (lane == 0) inv_out[r] = inv;
+        const int nchunks = d >> 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunks) {
+                const float4 xv = v[i];
+                // normalised value exactly as faiss leaves it in fp32, then rounded to fp16 (RNE)
+                half4 h;
+                h[0] = (_Float16)(xv.x * inv);
+                h[1] = (_Float16)(xv.y * inv);
+                h[2] = (_Float16)(xv.z * inv);
+                h[3] = (_Float16)(xv.w * inv);
+                const int s = c >> 2, hh = (c >> 1) & 1, sub = c & 1;
+                const int unit = (s * 2 + hh) * 32 + pr;
+                *reinterpret_cast<half4*>(img + unit * 8 + sub * 4) = h;
+            }
+        }
+    }
+    __syncthreads();
+    const int units = ksteps * 64;
+    uint4* dst = tiles + (int64_t)tile * units;
+    const uint4* src = reinterpret_cast<const uint4*>(smem);
+    for (int u = threadIdx.x; u < units; u += 256) dst[u] = src[u];
+}
+
+// in-place renorm (vfm_l2norm_rows_f32): one wave per row
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x, int64_t rows, int d,
+                                                          float* __restrict__ inv_out) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float4 v[4];
+    float* row = x + r * (int64_t)d;
+    float nr = row_sumsq_wave(row, d, v);
+    float inv = inv_norm_from_sumsq(nr);
+    if (lane_id() == 0 && inv_out) inv_out[r] = inv;
+    if (!(nr > 0.0f)) return;
+    const int nchunks = d >> 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane_id() + 64 * i;
+        if (c < nchunks) {
+            float4 xv = v[i];
+            xv.x = xv.x * inv; xv.y = xv.y * inv; xv.z = xv.z * inv; xv.w = xv.w * inv;
+            reinterpret_cast<float4*>(row)[c] = xv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// coarse pass
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else static_assert(N < 0, "unsupported vmcnt");
+}
+
+// LDS-DMA, 16 B per lane: LDS destination = wave-uniform byte address in M0 + lane * 16.
+// Issued from inline asm so that hipcc neither counts it nor drains it (it would place an
+// s_waitcnt vmcnt(0) in front of the next ds_read); completion is tracked by wait_vmcnt<N>().
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst_uniform)
+        : "memory");
+}
+
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+    return max(min(a, b), min(max(a, b), c));
+}
+
+struct CoarseArgs {
+    const uint4* Qh;     // query fragment tiles
+    const uint4* Bh;     // map fragment tiles
+    uint2* partials;     // [nchunks][npad]
+    int nq_tiles;        // valid 32-query tiles
+    int nchunks;         // map chunks (128 rows)
+    long long m_valid;   // real map rows
+    int npad;            // padded query count (row stride of partials)
+    int nqb;             // query blocks (256 queries)
+    int nslices;         // map slices
+};
+
+template <int KSTEPS>
+__global__ __launch_bounds__(512, 2) void match_coarse_kernel(CoarseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TILE_U4 = KSTEPS * 64;
+    constexpr int TILE_BYTES = TILE_U4 * 16;
+    constexpr int PASSES = KSTEPS / 8;  // 1 KiB pieces per wave per tile
+    static_assert(KSTEPS % 8 == 0, "d must be a multiple of 128");
+
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // XCD-aware unit mapping: workgroup b runs on XCD b % 8 (observed, speed only); give every
+    // XCD one contiguous range of (slice-major) units so co-resident workgroups stream the same
+    // map slice through that XCD's L2.
+    const int total = a.nqb * a.nslices;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, within = bid >> 3;
+    const int qn = total >> 3, rn = total & 7;
+    const int unit = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + within;
+    const int slice = unit / a.nqb;
+    const int qb = unit - slice * a.nqb;
+
+    const int c0 = (int)(((long long)slice * a.nchunks) / a.nslices);
+    const int c1 = (int)(((long long)(slice + 1) * a.nchunks) / a.nslices);
+    const int ntiles = (c1 - c0) * 4;
+    const int t0 = c0 * 4;
+
+    const int qt = qb * 8 + wave;
+    const bool q_ok = qt < a.nq_tiles;
+
+    const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS unsigned char*)smem;
+    auto stage = [&](int it_s) {
+        const uint4* src = a.Bh + (size_t)(t0 + it_s) * TILE_U4;
+        const unsigned dst = lds_base + (unsigned)((it_s & (NBUF - 1)) * TILE_BYTES);
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int piece = p * 8 + wave;
+            glds16(src + piece * 64 + lane, __builtin_amdgcn_readfirstlane(dst + (unsigned)piece * 1024u));
+        }
+    };
+
+    // query fragments stay in registers for the whole slice
+    half8 qf[KSTEPS];
+    {
+        const uint4* qsrc = a.Qh + (size_t)(q_ok ? qt : 0) * TILE_U4 + lane;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            uint4 v = qsrc[s * 64];
+            qf[s] = *reinterpret_cast<half8*>(&v);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+        if (i < ntiles) stage(i);
+
+    unsigned s1 = 0u, s2 = 0u;
+    const int hi = lane >> 5;
+
+    auto do_tile = [&](int it, auto TTc) {
+        constexpr int TT = decltype(TTc)::value;
+        const int rem = ntiles - 1 - it;
+        if (rem >= NBUF - 2) wait_vmcnt<PASSES*(NBUF - 2)>();
+        else if (rem == 1) wait_vmcnt<PASSES>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + NBUF - 1 < ntiles) stage(it + NBUF - 1);
+
+        const uint4* buf = reinterpret_cast<const uint4*>(smem + (it & (NBUF - 1)) * TILE_BYTES) + lane;
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = COARSE_OFFSET;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            uint4 v = buf[s * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&v), qf[s], acc, 0, 0, 0);
+        }
+        const long long tile_row0 = (long long)(t0 + it) * TILE_ROWS;
+        if (tile_row0 + TILE_ROWS > a.m_valid) {
+            // padded map rows must never win: force their packed score to 0
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                unsigned pk = (__float_as_uint(acc[r]) & 0xFFFFFFC0u) | (unsigned)(63 - (TT * 16 + r));
+                if (tile_row0 + i >= a.m_valid) pk = 0u;
+                s2 = umed3(s1, s2, pk);
+                s1 = max(s1, pk);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                unsigned pk = (__float_as_uint(acc[r]) & 0xFFFFFFC0u) | (unsigned)(63 - (TT * 16 + r));
+                s2 = umed3(s1, s2, pk);
+                s1 = max(s1, pk);
+            }
+        }
+        if constexpr (TT == 3) {
+            const unsigned o1 = __shfl_xor(s1, 32), o2 = __shfl_xor(s2, 32);
+            const bool own = (s1 > o1) || (s1 == o1 && hi == 0);
+            const unsigned w1 = own ? s1 : o1;
+            const int wh = own ? hi : (1 - hi);
+            const unsigned w2 = max(max(s2, o2), min(s1, o1));
+            const int code = 63 - (int)(w1 & 63u);
+            const int li = (code >> 4) * 32 + (code & 3) + 8 * ((code & 15) >> 2) + 4 * wh;
+            if (lane < 32 && q_ok) {
+                const int chunk = c0 + (it >> 2);
+                a.partials[(size_t)chunk * a.npad + (size_t)qt * 32 + lane] = make_uint2((w1 & ~127u) | (unsigned)li, w2);
+            }
+            s1 = 0u;
+            s2 = 0u;
+        }
+    };
+
+    for (int it = 0; it < ntiles; it += 4) {
+        do_tile(it + 0, std::integral_constant<int, 0>{});
+        do_tile(it + 1, std::integral_constant<int, 1>{});
+        do_tile(it + 2, std::integral_constant<int, 2>{});
+        do_tile(it + 3, std::integral_constant<int, 3>{});
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// selection: coarse max per query and the candidate chunks inside the error window
+// cand entry: (chunk << 8) | (rescan << 7) | local row
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void match_select_kernel(const uint2* __restrict__ partials, int nchunks, int npad,
+                                                           int64_t n, const float* __restrict__ invq, float window,
+                                                           int* __restrict__ cand_cnt,
+                                                           unsigned* __restrict__ cand, int* __restrict__ fb_count,
+                                                           int* __restrict__ fb_list) {
+    __shared__ unsigned smax[4][64];
+    __shared__ int lcnt[64];
+    __shared__ unsigned lcand[64][CAND_CAP];
+    const int qq = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 64 + qq;
+    unsigned m = 0u;
+    for (int c = g; c < nchunks; c += 4) m = max(m, partials[(size_t)c * npad + q].x);
+    smax[g][qq] = m;
+    if (g == 0) lcnt[qq] = 0;
+    __syncthreads();
+    m = max(max(smax[0][qq], smax[1][qq]), max(smax[2][qq], smax[3][qq]));
+    // the record's low 7 bits hold the row: compare on the value bits only
+    const float thr_f = __uint_as_float(m & ~127u) - window;
+    const unsigned thr = __float_as_uint(thr_f) & ~127u;
+    for (int c = g; c < nchunks; c += 4) {
+        const uint2 rec = partials[(size_t)c * npad + q];
+        if ((rec.x | 127u) >= thr) {
+            const int slot = atomicAdd(&lcnt[qq], 1);
+            if (slot < CAND_CAP) {
+                const unsigned rescan = ((rec.y | 63u) >= thr) ? 1u : 0u;
+                lcand[qq][slot] = ((unsigned)c << 8) | (rescan << 7) | (rec.x & 127u);
+            }
+        }
+    }
+    __syncthreads();
+    if (g == 0 && q < n) {
+        const int cnt = lcnt[qq];
+        if (invq[q] == 0.0f) {
+            cand_cnt[q] = 0;  // zero query row: decided directly (index 0, score 0)
+        } else if (cnt > CAND_CAP) {
+            cand_cnt[q] = -1;  // overflow: decided by the exact all-pairs kernel
+            const int slot = atomicAdd(fb_count, 1);
+            fb_list[slot] = (int)q;
+        } else {
+            cand_cnt[q] = cnt;
+            for (int e = 0; e < cnt; ++e) cand[(size_t)q * CAND_CAP + e] = lcand[qq][e];
+        }
+    }
+}
+
+// exact score of normalised rows, sequential k, fp64 (products of two fp32 are exact in fp64)
+__device__ __forceinline__ double dot_norm_f64(const float* __restrict__ qrow_n, const float* __restrict__ brow, float invb, int d) {
+    double acc = 0.0;
+    for (int k = 0; k < d; k += 4) {
+        const float4 bv = *reinterpret_cast<const float4*>(brow + k);
+        const float b0 = bv.x * invb, b1 = bv.y * invb, b2 = bv.z * invb, b3 = bv.w * invb;
+        acc = acc + (double)qrow_n[k + 0] * (double)b0;
+        acc = acc + (double)qrow_n[k + 1] * (double)b1;
+        acc = acc + (double)qrow_n[k + 2] * (double)b2;
+        acc = acc + (double)qrow_n[k + 3] * (double)b3;
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void wave_argmax(double& s, long long& j) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double so = __shfl_xor(s, off);
+        const long long jo = __shfl_xor(j, off);
+        if (jo >= 0 && (j < 0 || so > s || (so == s && jo < j))) {
+            s = so;
+            j = jo;
+        }
+    }
+}
+
+// one wave per query
+__global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restrict__ q, const float* __restrict__ invq,
+                                                            const float* __restrict__ b, const float* __restrict__ invb,
+                                                            int64_t n, int64_t m, int d, const int* __restrict__ cand_cnt,
+                                                            const unsigned* __restrict__ cand,
+                                                            int64_t* __restrict__ idx_out, float* __restrict__ sim_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    float* qn = reinterpret_cast<float*>(smem) + wave * d;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+    if (qi >= n) return;
+    const float iq = invq[qi];
+    for (int k = lane; k < d; k += 64) qn[k] = q[qi * (int64_t)d + k] * iq;
+    __builtin_amdgcn_wave_barrier();
+    if (iq == 0.0f) {  // zero query: every score is 0.0, the lowest index wins
+        if (lane == 0) {
+            idx_out[qi] = (m > 0) ? 0 : -1;
+            sim_out[qi] = 0.0f;
+        }
+        return;
+    }
+    const int cnt = cand_cnt[qi];
+    if (cnt < 0) return;  // handled by match_exact_kernel
+    double best = 0.0;
+    long long bj = -1;
+    for (int e = 0; e < cnt; ++e) {
+        const unsigned ce = cand[(size_t)qi * CAND_CAP + e];
+        const long long base = (long long)(ce >> 8) * CHUNK_ROWS;
+        if (ce & 128u) {
+            for (int li = lane; li < CHUNK_ROWS; li += 64) {
+                const long long j = base + li;
+                if (j < m) {
+                    const double s = dot_norm_f64(qn, b + j * (int64_t)d, invb[j], d);
+                    if (bj < 0 || s > best || (s == best && j < bj)) {
+                        best = s;
+                        bj = j;
+                    }
+                }
+            }
+        } else if (lane == (e & 63)) {
+            const long long j = base + (ce & 127u);
+            if (j < m) {
+                const double s = dot_norm_f64(qn, b + j * (int64_t)d, invb[j], d);
+                if (bj < 0 || s > best || (s == best && j < bj)) {
+                    best = s;
+                    bj = j;
+                }
+            }
+        }
+    }
+    wave_argmax(best, bj);
+    if (lane == 0) {
+        idx_out[qi] = bj;
+        sim_out[qi] = (float)best;
+    }
+}
+
+// all-pairs exact decision for the queries in `list` (or all queries if list == NULL)
+__global__ __launch_bounds__(256) void match_exact_kernel(const float* __restrict__ q, const float* __restrict__ invq,
+                                                          const float* __restrict__ b, const float* __restrict__ invb,
+                                                          int64_t n, int64_t m, int d, const int* __restrict__ list,
+                                                          const int* __restrict__ list_count,
+                                                          int64_t* __restrict__ idx_out, float* __restrict__ sim_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* qn = reinterpret_cast<float*>(smem);
+    double* rs = reinterpret_cast<double*>(smem + (((size_t)d * 4 + 15) & ~(size_t)15));
+    long long* rj = reinterpret_cast<long long*>(rs + 4);
+    const int64_t count = list ? (int64_t)*list_count : n;
+    for (int64_t e = blockIdx.x; e < count; e += gridDim.x) {
+        const int64_t qi = list ? (int64_t)list[e] : e;
+        const float iq = invq ? invq[qi] : 1.0f;
+        __syncthreads();
+        for (int k = threadIdx.x; k < d; k += 256) qn[k] = q[qi * (int64_t)d + k] * iq;
+        __syncthreads();
+        double best = 0.0;
+        long long bj = -1;
+        for (long long j = threadIdx.x; j < m; j += 256) {
+            const double s = dot_norm_f64(qn, b + j * (int64_t)d, invb ? invb[j] : 1.0f, d);
+            if (bj < 0 || s > best) {
+                best = s;
+                bj = j;
+            }
+        }
+        wave_argmax(best, bj);
+        if (lane_id() == 0) {
+            rs[threadIdx.x >> 6] = best;
+            rj[threadIdx.x >> 6] = bj;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (rj[w] >= 0 && (rj[0] < 0 || rs[w] > rs[0] || (rs[w] == rs[0] && rj[w] < rj[0]))) {
+                    rs[0] = rs[w];
+                    rj[0] = rj[w];
+                }
+            idx_out[qi] = (m > 0) ? rj[0] : -1;
+            sim_out[qi] = (m > 0) ? (float)rs[0] : 0.0f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// threshold + stable compaction (VoxelHashMap.cpp:501-511, 587-600), single workgroup
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void threshold_compact_kernel(const float* __restrict__ sim, const int64_t* __restrict__ idx,
+                                                                 int64_t n, double thr, int64_t* __restrict__ keep,
+                                                                 int64_t* __restrict__ count, int32_t* __restrict__ corres,
+                                                                 const double* __restrict__ qxyz, const double* __restrict__ bxyz,
+                                                                 double* __restrict__ src_out, double* __restrict__ tgt_out) {
+    __shared__ int wsum[16];
+    __shared__ int64_t base_s;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int64_t s = 0; s < n; s += 1024) {
+        const int64_t i = s + threadIdx.x;
+        const bool valid = (i < n) && !((double)sim[i] < thr);
+        const unsigned long long bal = __ballot(valid);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) woff += wsum[w];
+            tot += wsum[w];
+        }
+        const int64_t base = base_s;
+        if (valid) {
+            const int64_t k = base + woff + before;
+            keep[k] = i;
+            const int64_t j = idx ? idx[i] : 0;
+            if (corres) {
+                corres[2 * k + 0] = (int32_t)i;
+                corres[2 * k + 1] = (int32_t)j;
+            }
+            if (src_out) {
+                src_out[3 * k + 0] = qxyz[3 * i + 0];
+                src_out[3 * k + 1] = qxyz[3 * i + 1];
+                src_out[3 * k + 2] = qxyz[3 * i + 2];
+            }
+            if (tgt_out) {
+                tgt_out[3 * k + 0] = bxyz[3 * j + 0];
+                tgt_out[3 * k + 1] = bxyz[3 * j + 1];
+                tgt_out[3 * k + 2] = bxyz[3 * j + 2];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base_s = base + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = base_s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact Euclidean 1-NN (find_correspondences, registration_node.py:485-496): one workgroup per
+// query row, fp64 squared distance, sequential k, ties -> lowest index
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nn_l2_kernel(const float* __restrict__ a, int64_t n, const float* __restrict__ b,
+                                                    int64_t m, int d, int64_t* __restrict__ nn, double* __restrict__ d2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* qa = reinterpret_cast<float*>(smem);
+    double* rs = reinterpret_cast<double*>(smem + (((size_t)d * 4 + 15) & ~(size_t)15));
+    long long* rj = reinterpret_cast<long long*>(rs + 4);
+    for (int64_t qi = blockIdx.x; qi < n; qi += gridDim.x) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < d; k += 256) qa[k] = a[qi * (int64_t)d + k];
+        __syncthreads();
+        double best = 0.0;
+        long long bj = -1;
+        for (long long j = threadIdx.x; j < m; j += 256) {
+            const float* p = b + j * (int64_t)d;
+            double acc = 0.0;
+            for (int k = 0; k < d; ++k) {
+                const double t = (double)qa[k] - (double)p[k];
+                acc = acc + t * t;
+            }
+            if (bj < 0 || acc < best) {
+                best = acc;
+                bj = j;
+            }
+        }
+        // arg-min: negate so that wave_argmax applies (x -> -x is exact)
+        double neg = -best;
+        wave_argmax(neg, bj);
+        if (lane_id() == 0) {
+            rs[threadIdx.x >> 6] = neg;
+            rj[threadIdx.x >> 6] = bj;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (rj[w] >= 0 && (rj[0] < 0 || rs[w] > rs[0] || (rs[w] == rs[0] && rj[w] < rj[0]))) {
+                    rs[0] = rs[w];
+                    rj[0] = rj[w];
+                }
+            nn[qi] = rj[0];
+            if (d2) d2[qi] = -rs[0];
+        }
+    }
+}
+
+}  // namespace
+
+// =============================================================================================
+// host side: C ABI (include/vfmreg.h)
+// =============================================================================================
+namespace {
+
+struct Prepared {
+    float* inv;
+    uint4* tiles;
+};
+
+inline Prepared carve_prepared(void* p, int64_t rows, int d) {
+    VfmCarver c(p);
+    Prepared r;
+    const int64_t rp = rows_padded(rows);
+    r.inv = c.take<float>((size_t)rp);
+    r.tiles = c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(d / 16) * 64);
+    return r;
+}
+
+struct SearchWs {
+    uint2* partials;
+    int* cand_cnt;
+    unsigned* cand;
+    int* fb_count;
+    int* fb_list;
+    size_t bytes;
+};
+
+inline SearchWs carve_search(void* p, int64_t n, int64_t m) {
+    VfmCarver c(p);
+    SearchWs w;
+    const int64_t npad = rows_padded(n), mpad = rows_padded(m);
+    w.partials = c.take<uint2>((size_t)(mpad / CHUNK_ROWS) * (size_t)npad);
+    w.cand_cnt = c.take<int>((size_t)npad);
+    w.cand = c.take<unsigned>((size_t)npad * CAND_CAP);
+    w.fb_count = c.take<int>(64);
+    w.fb_list = c.take<int>((size_t)npad);
+    w.bytes = c.used();
+    return w;
+}
+
+inline int choose_slices(int nqb, int nchunks) {
+    // fill 256 CUs with whole "rounds" of workgroups; prefer fewer, longer slices on ties
+    int best_s = 1;
+    double best_eff = -1.0;
+    const int smax = nchunks < 64 ? nchunks : 64;
+    for (int s = 1; s <= smax; ++s) {
+        if (nchunks / s < 8 && s > 1) break;  // keep >= 32 tiles per workgroup
+        const long long total = (long long)nqb * s;
+        const long long rounds = (total + 255) / 256;
+        const double eff = (double)total / (double)(rounds * 256);
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best_s = s;
+        }
+    }
+    return best_s;
+}
+
+template <int KSTEPS>
+int launch_coarse(const CoarseArgs& a, hipStream_t st) {
+    const int lds = NBUF * KSTEPS * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_kernel<KSTEPS>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(match_coarse_kernel<KSTEPS>, dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
+    VFM_CHECK_LAUNCH("match_coarse_kernel");
+    return VFM_OK;
+}
+
+int do_prepare(const float* x, int64_t rows, int d, void* prepared, hipStream_t st) {
+    Prepared p = carve_prepared(prepared, rows, d);
+    const int64_t rp = rows_padded(rows);
+    hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)(rp / TILE_ROWS)), dim3(256), (size_t)d * 64, st, x, rows, d,
+                       p.inv, p.tiles);
+    VFM_CHECK_LAUNCH("prep_rows_kernel");
+    return VFM_OK;
+}
+
+int do_search(const float* q, const void* qprep, int64_t n, const float* b, const void* bprep, int64_t m, int d,
+              int64_t* idx_out, float* sim_out, void* ws, hipStream_t st) {
+    Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
+    Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
+    SearchWs w = carve_search(ws, n, m);
+    const int64_t npad = rows_padded(n), mpad = rows_padded(m);
+    CoarseArgs a;
+    a.Qh = Q.tiles;
+    a.Bh = B.tiles;
+    a.partials = w.partials;
+    a.nq_tiles = (int)((n + TILE_ROWS - 1) / TILE_ROWS);
+    a.nchunks = (int)(mpad / CHUNK_ROWS);
+    a.m_valid = m;
+    a.npad = (int)npad;
+    a.nqb = (int)(npad / QBLOCK);
+    a.nslices = choose_slices(a.nqb, a.nchunks);
+    VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, sizeof(int), st));
+    int rc;
+    switch (d / 16) {
+        case 8: rc = launch_coarse<8>(a, st); break;
+        case 16: rc = launch_coarse<16>(a, st); break;
+        case 24: rc = launch_coarse<24>(a, st); break;
+        case 32: rc = launch_coarse<32>(a, st); break;
+        default: return vfm_fail(VFM_EINVAL, "FAST matching supports d in {128,256,384,512}, got %d", d);
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, w.partials, a.nchunks,
+                       a.npad, n, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.fb_count, w.fb_list);
+    VFM_CHECK_LAUNCH("match_select_kernel");
+    hipLaunchKernelGGL(match_rescore_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)d * 4 * 4, st, q, Q.inv, b,
+                       B.inv, n, m, d, w.cand_cnt, w.cand, idx_out, sim_out);
+    VFM_CHECK_LAUNCH("match_rescore_kernel");
+    hipLaunchKernelGGL(match_exact_kernel, dim3(256), dim3(256), (((size_t)d * 4 + 15) & ~(size_t)15) + 64, st, q, Q.inv,
+                       b, B.inv, n, m, d, w.fb_list, w.fb_count, idx_out, sim_out);
+    VFM_CHECK_LAUNCH("match_exact_kernel(fallback)");
+    return VFM_OK;
+}
+
+}  // namespace
+
+VFM_EXPORT int vfm_l2norm_rows_f32(float* x, int64_t n, int d, float* inv_out, vfm_stream_t stream) {
+    VFM_CHECK_ARG(n >= 0 && d > 0 && d % 4 == 0 && d <= 1024, "l2norm: need d %% 4 == 0 and d <= 1024 (d=%d)", d);
+    if (n == 0) return VFM_OK;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n, d,
+                       inv_out);
+    VFM_CHECK_LAUNCH("l2norm_rows_kernel");
+    return VFM_OK;
+}
+
+VFM_EXPORT size_t vfm_match_prepared_bytes(int64_t rows, int d) {
+    VfmCarver c(nullptr);
+    const int64_t rp = rows_padded(rows);
+    c.take<float>((size_t)rp);
+    c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(d / 16) * 64);
+    return c.used();
+}
+
+VFM_EXPORT int vfm_match_prepare(const float* x, int64_t rows, int d, void* prepared, vfm_stream_t stream) {
+    VFM_CHECK_ARG(rows > 0 && d % 128 == 0 && d >= 128 && d <= 512, "prepare: d must be in {128,256,384,512}");
+    VFM_CHECK_ARG(x && prepared, "prepare: null pointer");
+    return do_prepare(x, rows, d, prepared, (hipStream_t)stream);
+}
+
+VFM_EXPORT size_t vfm_match_search_workspace_bytes(int64_t n, int64_t m, int d) {
+    (void)d;
+    return carve_search(nullptr, n, m).bytes;
+}
+
+VFM_EXPORT int vfm_match_search_prepared(const float* q, const void* q_prepared, int64_t n, const float* b,
+                                         const void* b_prepared, int64_t m, int d, int64_t* idx_out, float* sim_out,
+                                         void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    VFM_CHECK_ARG(n > 0 && m > 0, "search: empty operand (n=%lld m=%lld)", (long long)n, (long long)m);
+    VFM_CHECK_ARG(d % 128 == 0 && d >= 128 && d <= 512, "search: d must be in {128,256,384,512}");
+    VFM_CHECK_ARG(m < (1ll << 31) - 256 && n < (1ll << 31) - 256, "search: more than 2^31 rows");
+    if (ws_bytes < vfm_match_search_workspace_bytes(n, m, d)) return vfm_fail(VFM_EWORKSPACE, "search: workspace too small");
+    return do_search(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream);
+}
+
+VFM_EXPORT size_t vfm_match_ip_top1_workspace_bytes(int64_t n, int64_t m, int d, int prec_mode) {
+    if (prec_mode == VFM_MATCH_EXACT) return vfm_align_up((size_t)(n + m) * sizeof(float), 256) + 512;
+    return vfm_match_prepared_bytes(n, d) + vfm_match_prepared_bytes(m, d) + vfm_match_search_workspace_bytes(n, m, d);
+}
+
+namespace {
+// 1/|row| only (EXACT mode)
+__global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__ x, int64_t rows, int d,
+                                                       float* __restrict__ inv_out) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float4 v[4];
+    float nr = row_sumsq_wave(x + r * (int64_t)d, d, v);
+    float inv = inv_norm_from_sumsq(nr);
+    // faiss leaves zero rows untouched: scaling by 1 reproduces that
+    if (lane_id() == 0) inv_out[r] = (nr > 0.0f) ? inv : 1.0f;
+}
+}  // namespace
+
+VFM_EXPORT int vfm_match_ip_top1(const float* q, int64_t n, const float* b, int64_t m, int d, int prec_mode,
+                                 int64_t* idx_out, float* sim_out, void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    VFM_CHECK_ARG(n > 0 && m > 0, "match: empty operand (n=%lld m=%lld)", (long long)n, (long long)m);
+    VFM_CHECK_ARG(q && b && idx_out && sim_out && ws, "match: null pointer");
+    if (ws_bytes < vfm_match_ip_top1_workspace_bytes(n, m, d, prec_mode)) return vfm_fail(VFM_EWORKSPACE, "match: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (prec_mode == VFM_MATCH_EXACT) {
+        VFM_CHECK_ARG(d % 4 == 0 && d <= 1024, "match(EXACT): need d %% 4 == 0 and d <= 1024");
+        VfmCarver c(ws);
+        float* invq = c.take<float>((size_t)n);
+        float* invb = c.take<float>((size_t)m);
+        hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, n, d, invq);
+        hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, b, m, d, invb);
+        VFM_CHECK_LAUNCH("inv_norm_kernel");
+        const unsigned grid = (unsigned)(n < 4096 ? n : 4096);
+        hipLaunchKernelGGL(match_exact_kernel, dim3(grid), dim3(256), (((size_t)d * 4 + 15) & ~(size_t)15) + 64, st, q,
+                           invq, b, invb, n, m, d, (const int*)nullptr, (const int*)nullptr, idx_out, sim_out);
+        VFM_CHECK_LAUNCH("match_exact_kernel");
+        return VFM_OK;
+    }
+    VFM_CHECK_ARG(prec_mode == VFM_MATCH_FAST, "match: unknown prec_mode %d", prec_mode);
+    VFM_CHECK_ARG(d % 128 == 0 && d >= 128 && d <= 512, "match(FAST): d must be in {128,256,384,512}, got %d", d);
+    unsigned char* p = static_cast<unsigned char*>(ws);
+    void* qprep = p;
+    void* bprep = p + vfm_match_prepared_bytes(n, d);
+    void* sws = p + vfm_match_prepared_bytes(n, d) + vfm_match_prepared_bytes(m, d);
+    int rc = do_prepare(q, n, d, qprep, st);
+    if (rc) return rc;
+    rc = do_prepare(b, m, d, bprep, st);
+    if (rc) return rc;
+    return vfm_match_search_prepared(q, qprep, n, b, bprep, m, d, idx_out, sim_out, sws,
+                                     vfm_match_search_workspace_bytes(n, m, d), stream);
+}
+
+VFM_EXPORT int vfm_threshold_compact(const float* sim, const int64_t* idx, int64_t n, double thr, int64_t* keep_out,
+                                     int64_t* count_out, int32_t* corres_out, const double* q_xyz, const double* b_xyz,
+                                     double* src_xyz_out, double* tgt_xyz_out, vfm_stream_t stream) {
+    VFM_CHECK_ARG(n >= 0 && sim && keep_out && count_out, "threshold_compact: bad arguments");
+    VFM_CHECK_ARG(!(corres_out || tgt_xyz_out) || idx, "threshold_compact: idx required for corres / tgt output");
+    VFM_CHECK_ARG(!src_xyz_out || q_xyz, "threshold_compact: q_xyz required");
+    VFM_CHECK_ARG(!tgt_xyz_out || b_xyz, "threshold_compact: b_xyz required");
+    hipLaunchKernelGGL(threshold_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sim, idx, n, thr, keep_out,
+                       count_out, corres_out, q_xyz, b_xyz, src_xyz_out, tgt_xyz_out);
+    VFM_CHECK_LAUNCH("threshold_compact_kernel");
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_match_mutual_l2(const float* a, int64_t n, const float* b, int64_t m, int d, int64_t* nn_ab,
+                                   double* d2_ab, int64_t* nn_ba, vfm_stream_t stream) {
+    VFM_CHECK_ARG(n > 0 && m > 0 && d > 0 && a && b && nn_ab, "mutual_l2: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (((size_t)d * 4 + 15) & ~(size_t)15) + 64;
+    hipLaunchKernelGGL(nn_l2_kernel, dim3((unsigned)(n < 8192 ? n : 8192)), dim3(256), lds, st, a, n, b, m, d, nn_ab, d2_ab);
+    if (nn_ba)
+        hipLaunchKernelGGL(nn_l2_kernel, dim3((unsigned)(m < 8192 ? m : 8192)), dim3(256), lds, st, b, m, a, n, d, nn_ba,
+                           (double*)nullptr);
+    VFM_CHECK_LAUNCH("nn_l2_kernel");
+    return VFM_OK;
+}

@@ -1,0 +1,432 @@
+// ransac.hip -- correspondence RANSAC + Kabsch on MI355X (gfx950).
+//
+// Replaces open3d.pipelines.registration.registration_ransac_based_on_correspondence as called
+// at registration_node.py:319-327 (Open3D 0.18: draw 3 correspondences with replacement,
+// Eigen::umeyama without scaling, score |T s - t|^2 < d^2 over ALL correspondences, keep the
+// hypothesis with higher fitness, then lower RMSE; confidence 1 => every iteration runs) and
+// Eigen::umeyama / pointdsc.common.rigid_transform_3d (pointdsc/common.py:7-47).
+//
+// Layout: ONE THREAD PER HYPOTHESIS.  A wavefront evaluates 64 hypotheses against the same
+// correspondence at the same time, so the correspondence stream is wave-uniform (scalar loads,
+// no LDS, no cross-lane traffic) and each lane accumulates its inlier count / squared error in
+// correspondence order -- the same order Open3D's loop (and the CPU oracle) uses.
+// All arithmetic is fp64, compiled with -ffp-contract=off, written as the exact operation
+// sequence of oracle/vfm_oracle.c so that poses, masks and the winning hypothesis are
+// bit-identical to the oracle's.
+#include "common.h"
+
+namespace {
+
+constexpr int JACOBI_SWEEPS = 6;
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n1 = lo1;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        const uint32_t n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// rotation from the 3x3 cross-covariance: one-sided Jacobi, fixed sweeps, only + - * / sqrt.
+__device__ bool rot_from_sigma(const double S[9], double R[9]) {
+    double G[3][3], V[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            G[r][c] = S[r * 3 + c];
+            V[r][c] = (r == c) ? 1.0 : 0.0;
+        }
+#pragma unroll 1
+    for (int sweep = 0; sweep < JACOBI_SWEEPS; ++sweep) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int p = (e == 2) ? 1 : 0;
+            const int q = (e == 0) ? 1 : 2;
+            const double alpha = (G[0][p] * G[0][p] + G[1][p] * G[1][p]) + G[2][p] * G[2][p];
+            const double beta = (G[0][q] * G[0][q] + G[1][q] * G[1][q]) + G[2][q] * G[2][q];
+            const double gamma = (G[0][p] * G[0][q] + G[1][p] * G[1][q]) + G[2][p] * G[2][q];
+            if (gamma == 0.0) continue;
+            const double zeta = (beta - alpha) / (2.0 * gamma);
+            const double az = fabs(zeta);
+            double tt = 1.0 / (az + sqrt(1.0 + zeta * zeta));
+            if (zeta < 0.0) tt = -tt;
+            const double c = 1.0 / sqrt(1.0 + tt * tt);
+            const double s = c * tt;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double gp = G[r][p], gq = G[r][q];
+                G[r][p] = c * gp - s * gq;
+                G[r][q] = s * gp + c * gq;
+                const double vp = V[r][p], vq = V[r][q];
+                V[r][p] = c * vp - s * vq;
+                V[r][q] = s * vp + c * vq;
+            }
+        }
+    }
+    double nn[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nn[c] = (G[0][c] * G[0][c] + G[1][c] * G[1][c]) + G[2][c] * G[2][c];
+    // two dominant columns, ties -> lowest column index (static indexing only: select by value)
+    int i1 = 0;
+    if (nn[1] > nn[i1 == 0 ? 0 : 1]) i1 = 1;
+    {
+        const double cur = (i1 == 0) ? nn[0] : nn[1];
+        if (nn[2] > cur) i1 = 2;
+    }
+    int i2;
+    {
+        // candidates are the two columns != i1, scanned in ascending order, strict '>' to replace
+        const int ca = (i1 == 0) ? 1 : 0;
+        const int cb = (i1 == 2) ? 1 : 2;
+        const double na = (ca == 0) ? nn[0] : nn[1];
+        const double nb = (cb == 1) ? nn[1] : nn[2];
+        i2 = (nb > na) ? cb : ca;
+    }
+    const double n1 = (i1 == 0) ? nn[0] : ((i1 == 1) ? nn[1] : nn[2]);
+    const double n2 = (i2 == 0) ? nn[0] : ((i2 == 1) ? nn[1] : nn[2]);
+    if (!(n1 > 0.0)) return false;
+    if (!(n2 > n1 * 1e-20)) return false;
+    const double s1 = sqrt(n1), s2 = sqrt(n2);
+    double u1[3], u2[3], u3[3], v1[3], v2[3], v3[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double g1 = (i1 == 0) ? G[r][0] : ((i1 == 1) ? G[r][1] : G[r][2]);
+        const double g2 = (i2 == 0) ? G[r][0] : ((i2 == 1) ? G[r][1] : G[r][2]);
+        u1[r] = g1 / s1;
+        u2[r] = g2 / s2;
+        v1[r] = (i1 == 0) ? V[r][0] : ((i1 == 1) ? V[r][1] : V[r][2]);
+        v2[r] = (i2 == 0) ? V[r][0] : ((i2 == 1) ? V[r][1] : V[r][2]);
+    }
+    u3[0] = u1[1] * u2[2] - u1[2] * u2[1];
+    u3[1] = u1[2] * u2[0] - u1[0] * u2[2];
+    u3[2] = u1[0] * u2[1] - u1[1] * u2[0];
+    v3[0] = v1[1] * v2[2] - v1[2] * v2[1];
+    v3[1] = v1[2] * v2[0] - v1[0] * v2[2];
+    v3[2] = v1[0] * v2[1] - v1[1] * v2[0];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[r * 3 + c] = (u1[r] * v1[c] + u2[r] * v2[c]) + u3[r] * v3[c];
+    return true;
+}
+
+// Kabsch on n weighted pairs; A, B: n x 3 with the given element stride. T: 12 doubles
+// (rows of [R|t]).  Same operation order as orc_kabsch.
+__device__ bool kabsch_rows(const double* A, const double* B, const double* w, int64_t n, double denom_eps,
+                            double T[12]) {
+    double ma[3] = {0.0, 0.0, 0.0}, mb[3] = {0.0, 0.0, 0.0}, sw = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double wi = w ? w[i] : 1.0;
+        sw = sw + wi;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ma[c] = ma[c] + wi * A[i * 3 + c];
+            mb[c] = mb[c] + wi * B[i * 3 + c];
+        }
+    }
+    const double inv = 1.0 / (sw + denom_eps);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        ma[c] = ma[c] * inv;
+        mb[c] = mb[c] * inv;
+    }
+    double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = 0; i < n; ++i) {
+        const double wi = w ? w[i] : 1.0;
+        double ad[3], bd[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ad[c] = A[i * 3 + c] - ma[c];
+            bd[c] = B[i * 3 + c] - mb[c];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) S[r * 3 + c] = S[r * 3 + c] + (wi * bd[r]) * ad[c];
+    }
+    const double invs = 1.0 / sw;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) S[k] = S[k] * invs;
+    double R[9];
+    if (!rot_from_sigma(S, R)) return false;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        T[r * 4 + 0] = R[r * 3 + 0];
+        T[r * 4 + 1] = R[r * 3 + 1];
+        T[r * 4 + 2] = R[r * 3 + 2];
+        T[r * 4 + 3] = mb[r] - ((R[r * 3 + 0] * ma[0] + R[r * 3 + 1] * ma[1]) + R[r * 3 + 2] * ma[2]);
+    }
+    return true;
+}
+
+__device__ __forceinline__ double err2(const double T[12], double sx, double sy, double sz, double tx, double ty,
+                                       double tz) {
+    const double x = ((T[0] * sx + T[1] * sy) + T[2] * sz) + T[3];
+    const double y = ((T[4] * sx + T[5] * sy) + T[6] * sz) + T[7];
+    const double z = ((T[8] * sx + T[9] * sy) + T[10] * sz) + T[11];
+    const double dx = x - tx, dy = y - ty, dz = z - tz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+// pts[i] = {src[corres[i][0]], tgt[corres[i][1]]}: the wave-uniform stream of the scoring loop
+__global__ __launch_bounds__(256) void ransac_gather_kernel(const double* __restrict__ src, const double* __restrict__ tgt,
+                                                            const int32_t* __restrict__ corres,
+                                                            const int64_t* __restrict__ count_dev, int64_t c_max,
+                                                            double* __restrict__ pts) {
+    const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= C) return;
+    const int64_t a = corres[2 * i], b = corres[2 * i + 1];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        pts[6 * i + c] = src[3 * a + c];
+        pts[6 * i + 3 + c] = tgt[3 * b + c];
+    }
+}
+
+__device__ __forceinline__ bool sample_T(const double* __restrict__ pts, int64_t C, uint32_t hyp, uint64_t seed,
+                                         double T[12]) {
+    uint32_t r[4];
+    philox4x32_10(hyp, 0u, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    double A[9], B[9];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint64_t pick = ((uint64_t)r[j] * (uint64_t)C) >> 32;
+        const double* p = pts + 6 * pick;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            A[j * 3 + c] = p[c];
+            B[j * 3 + c] = p[3 + c];
+        }
+    }
+    return kabsch_rows(A, B, nullptr, 3, 0.0, T);
+}
+
+struct HypScore {
+    double fit;
+    double rmse;
+    int32_t hyp;
+};
+
+// a strictly better than b under Open3D's IsBetterRANSACThan + earliest-hypothesis tie-break;
+// entries with hyp < 0 are empty.
+__device__ __forceinline__ bool better(double af, double ar, int ah, double bf, double br, int bh) {
+    if (ah < 0) return false;
+    if (bh < 0) return true;
+    if (af > bf) return true;
+    if (af < bf) return false;
+    if (ar < br) return true;
+    if (ar > br) return false;
+    return ah < bh;
+}
+
+__global__ __launch_bounds__(64) void ransac_score_kernel(const double* __restrict__ pts,
+                                                          const int64_t* __restrict__ count_dev, int64_t c_max,
+                                                          double max_d2, int32_t n_iter, uint64_t seed,
+                                                          HypScore* __restrict__ block_best) {
+    const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
+    const int32_t h = (int32_t)(blockIdx.x * 64 + threadIdx.x);
+    double fit = 0.0, rmse = 0.0;
+    int hyp = -1;
+    if (C >= 3 && h < n_iter) {
+        double T[12];
+        if (sample_T(pts, C, (uint32_t)h, seed, T)) {
+            int64_t good = 0;
+            double e2 = 0.0;
+            for (int64_t i = 0; i < C; ++i) {
+                const double* p = pts + 6 * i;  // wave-uniform address
+                const double d2 = err2(T, p[0], p[1], p[2], p[3], p[4], p[5]);
+                if (d2 < max_d2) {
+                    good++;
+                    e2 = e2 + d2;
+                }
+            }
+            if (good > 0) {  // fitness 0 can never beat the initial (0, 0) result
+                fit = (double)good / (double)C;
+                rmse = sqrt(e2 / (double)good);
+                hyp = h;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double of = __shfl_xor(fit, off), orr = __shfl_xor(rmse, off);
+        const int oh = __shfl_xor(hyp, off);
+        if (better(of, orr, oh, fit, rmse, hyp)) {
+            fit = of;
+            rmse = orr;
+            hyp = oh;
+        }
+    }
+    if (threadIdx.x == 0) {
+        HypScore s;
+        s.fit = fit;
+        s.rmse = rmse;
+        s.hyp = hyp;
+        block_best[blockIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void ransac_final_kernel(const double* __restrict__ pts,
+                                                           const int64_t* __restrict__ count_dev, int64_t c_max,
+                                                           uint64_t seed, const HypScore* __restrict__ block_best,
+                                                           int nblocks, double* __restrict__ T_out,
+                                                           double* __restrict__ fitness_out, double* __restrict__ rmse_out,
+                                                           int32_t* __restrict__ best_hyp_out) {
+    __shared__ double sf[4], sr[4];
+    __shared__ int sh[4];
+    const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
+    double fit = 0.0, rmse = 0.0;
+    int hyp = -1;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        const HypScore s = block_best[b];
+        if (better(s.fit, s.rmse, s.hyp, fit, rmse, hyp)) {
+            fit = s.fit;
+            rmse = s.rmse;
+            hyp = s.hyp;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double of = __shfl_xor(fit, off), orr = __shfl_xor(rmse, off);
+        const int oh = __shfl_xor(hyp, off);
+        if (better(of, orr, oh, fit, rmse, hyp)) {
+            fit = of;
+            rmse = orr;
+            hyp = oh;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sf[threadIdx.x >> 6] = fit;
+        sr[threadIdx.x >> 6] = rmse;
+        sh[threadIdx.x >> 6] = hyp;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better(sf[w], sr[w], sh[w], sf[0], sr[0], sh[0])) {
+                sf[0] = sf[w];
+                sr[0] = sr[w];
+                sh[0] = sh[w];
+            }
+        double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        if (sh[0] >= 0) sample_T(pts, C, (uint32_t)sh[0], seed, T);
+        for (int k = 0; k < 12; ++k) T_out[k] = T[k];
+        T_out[12] = 0.0;
+        T_out[13] = 0.0;
+        T_out[14] = 0.0;
+        T_out[15] = 1.0;
+        *fitness_out = (sh[0] >= 0) ? sf[0] : 0.0;
+        *rmse_out = (sh[0] >= 0) ? sr[0] : 0.0;
+        *best_hyp_out = sh[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void ransac_mask_kernel(const double* __restrict__ pts,
+                                                          const int64_t* __restrict__ count_dev, int64_t c_max,
+                                                          double max_d2, const double* __restrict__ T_in,
+                                                          const int32_t* __restrict__ best_hyp,
+                                                          uint8_t* __restrict__ mask) {
+    const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= c_max) return;
+    uint8_t m = 0;
+    if (i < C && *best_hyp >= 0) {
+        double T[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) T[k] = T_in[k];
+        const double* p = pts + 6 * i;
+        m = (err2(T, p[0], p[1], p[2], p[3], p[4], p[5]) < max_d2) ? 1 : 0;
+    }
+    mask[i] = m;
+}
+
+__global__ __launch_bounds__(64) void kabsch_batched_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                            const double* __restrict__ w, int64_t b, int64_t n,
+                                                            double denom_eps, double* __restrict__ T_out,
+                                                            int32_t* __restrict__ valid) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= b) return;
+    double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    const bool ok = kabsch_rows(A + i * n * 3, B + i * n * 3, w ? w + i * n : nullptr, n, denom_eps, T);
+    if (!ok) {
+        const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        for (int k = 0; k < 12; ++k) T[k] = I[k];
+    }
+    for (int k = 0; k < 12; ++k) T_out[i * 16 + k] = T[k];
+    T_out[i * 16 + 12] = 0.0;
+    T_out[i * 16 + 13] = 0.0;
+    T_out[i * 16 + 14] = 0.0;
+    T_out[i * 16 + 15] = 1.0;
+    if (valid) valid[i] = ok ? 1 : 0;
+}
+
+struct RansacWs {
+    double* pts;
+    HypScore* block_best;
+    size_t bytes;
+};
+inline RansacWs carve_ransac(void* p, int64_t c_max, int32_t n_iter) {
+    VfmCarver c(p);
+    RansacWs w;
+    w.pts = c.take<double>((size_t)(c_max > 0 ? c_max : 1) * 6);
+    w.block_best = c.take<HypScore>((size_t)(n_iter + 63) / 64 + 1);
+    w.bytes = c.used();
+    return w;
+}
+
+}  // namespace
+
+VFM_EXPORT size_t vfm_ransac_workspace_bytes(int64_t c_max, int32_t n_iter) { return carve_ransac(nullptr, c_max, n_iter).bytes; }
+
+VFM_EXPORT int vfm_ransac_corr(const double* src, const double* tgt, const int32_t* corres, const int64_t* count_dev,
+                               int64_t c_max, double max_dist, int32_t n_iter, uint64_t seed, double* T_out,
+                               double* fitness_out, double* rmse_out, uint8_t* inlier_mask, int32_t* best_hyp_out,
+                               void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    VFM_CHECK_ARG(src && tgt && corres && T_out && fitness_out && rmse_out && best_hyp_out && ws, "ransac: null pointer");
+    VFM_CHECK_ARG(c_max >= 0 && n_iter > 0, "ransac: bad sizes (c_max=%lld n_iter=%d)", (long long)c_max, n_iter);
+    if (ws_bytes < vfm_ransac_workspace_bytes(c_max, n_iter)) return vfm_fail(VFM_EWORKSPACE, "ransac: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    RansacWs w = carve_ransac(ws, c_max, n_iter);
+    // Open3D returns a default RegistrationResult when max_correspondence_distance <= 0:
+    // a non-positive squared threshold admits no inlier, which yields exactly that here.
+    const double max_d2 = (max_dist > 0.0) ? max_dist * max_dist : -1.0;
+    const int nblocks = (n_iter + 63) / 64;
+    if (c_max > 0) {
+        hipLaunchKernelGGL(ransac_gather_kernel, dim3((unsigned)((c_max + 255) / 256)), dim3(256), 0, st, src, tgt, corres,
+                           count_dev, c_max, w.pts);
+        VFM_CHECK_LAUNCH("ransac_gather_kernel");
+    }
+    hipLaunchKernelGGL(ransac_score_kernel, dim3(nblocks), dim3(64), 0, st, w.pts, count_dev, c_max, max_d2, n_iter, seed,
+                       w.block_best);
+    VFM_CHECK_LAUNCH("ransac_score_kernel");
+    hipLaunchKernelGGL(ransac_final_kernel, dim3(1), dim3(256), 0, st, w.pts, count_dev, c_max, seed, w.block_best, nblocks,
+                       T_out, fitness_out, rmse_out, best_hyp_out);
+    VFM_CHECK_LAUNCH("ransac_final_kernel");
+    if (inlier_mask && c_max > 0) {
+        hipLaunchKernelGGL(ransac_mask_kernel, dim3((unsigned)((c_max + 255) / 256)), dim3(256), 0, st, w.pts, count_dev,
+                           c_max, max_d2, T_out, best_hyp_out, inlier_mask);
+        VFM_CHECK_LAUNCH("ransac_mask_kernel");
+    }
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_kabsch_batched(const double* A, const double* B, const double* w, int64_t b, int64_t n,
+                                  double denom_eps, double* T_out, int32_t* valid, vfm_stream_t stream) {
+    VFM_CHECK_ARG(A && B && T_out && b >= 0 && n >= 1, "kabsch: bad arguments");
+    if (b == 0) return VFM_OK;
+    hipLaunchKernelGGL(kabsch_batched_kernel, dim3((unsigned)((b + 63) / 64)), dim3(64), 0, (hipStream_t)stream, A, B, w, b,
+                       n, denom_eps, T_out, valid);
+    VFM_CHECK_LAUNCH("kabsch_batched_kernel");
+    return VFM_OK;
+}

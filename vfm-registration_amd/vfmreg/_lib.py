@@ -1,0 +1,77 @@
+"""ctypes loader for libvfmreg_hip.so (the C ABI declared in include/vfmreg.h).
+
+The product path has NO CPU fallback: if the HIP library is missing this module raises, and every
+op in ``vfmreg.ops`` refuses to run without a ROCm device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libvfmreg_hip.so"
+_lib = None
+
+c_i64 = C.c_int64
+c_vp = C.c_void_p
+
+
+class VitConfig(C.Structure):
+    _fields_ = [("dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int), ("mlp_dim", C.c_int),
+                ("patch", C.c_int), ("patch_h", C.c_int), ("patch_w", C.c_int)]
+
+
+# name -> (restype, argtypes); mirrors include/vfmreg.h one to one
+SIGNATURES = {
+    "vfm_last_error": (C.c_char_p, []),
+    "vfm_build_info": (C.c_char_p, []),
+    "vfm_l2norm_rows_f32": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, c_vp]),
+    "vfm_match_ip_top1_workspace_bytes": (C.c_size_t, [c_i64, c_i64, C.c_int, C.c_int]),
+    "vfm_match_ip_top1": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_vp, c_vp, C.c_size_t, c_vp]),
+    "vfm_match_prepared_bytes": (C.c_size_t, [c_i64, C.c_int]),
+    "vfm_match_prepare": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, c_vp]),
+    "vfm_match_search_workspace_bytes": (C.c_size_t, [c_i64, c_i64, C.c_int]),
+    "vfm_match_search_prepared": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp,
+                                            C.c_size_t, c_vp]),
+    "vfm_threshold_compact": (C.c_int, [c_vp, c_vp, c_i64, C.c_double, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vfm_match_mutual_l2": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp, c_vp]),
+    "vfm_ransac_workspace_bytes": (C.c_size_t, [c_i64, C.c_int32]),
+    "vfm_ransac_corr": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, C.c_double, C.c_int32, C.c_uint64, c_vp, c_vp, c_vp,
+                                  c_vp, c_vp, c_vp, C.c_size_t, c_vp]),
+    "vfm_kabsch_batched": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, C.c_double, c_vp, c_vp, c_vp]),
+    "vfm_project_workspace_bytes": (C.c_size_t, [c_i64]),
+    "vfm_project_pinhole_f64": (C.c_int, [C.c_int, c_vp, c_i64, c_vp, c_vp, C.c_double, c_vp, c_vp, c_i64, c_i64,
+                                          c_vp, c_vp, c_vp, c_vp, c_vp, C.c_size_t, c_vp]),
+    "vfm_gather_bilinear_patchgrid": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp,
+                                                c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "vfm_transform_xyz_f64": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "vfm_vit_weights_bytes": (C.c_size_t, [C.POINTER(VitConfig)]),
+    "vfm_vit_workspace_bytes": (C.c_size_t, [C.POINTER(VitConfig), C.c_int]),
+    "vfm_vit_forward": (C.c_int, [C.POINTER(VitConfig), c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp,
+                                  C.c_size_t, c_vp]),
+}
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (after torch, so that both share one libamdhip64 runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python vfm-registration_amd/build.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    import torch  # noqa: F401  -- loads torch's libamdhip64.so first (same soname => one runtime)
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError => the .so does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().vfm_last_error().decode()
+        raise RuntimeError(f"libvfmreg_hip {what} failed ({rc}): {msg}")
