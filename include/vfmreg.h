@@ -168,6 +168,16 @@ int vfm_vit_forward(const vfm_vit_config *cfg, const void *weights, const uint8_
                     int H, int W, float *tokens_out, void *ws, size_t ws_bytes,
                     vfm_stream_t stream);
 
+/* ------------------------------------------------------------------ measurement hooks */
+
+/* HIP events around the dominant kernel (the fp16 MFMA coarse pass of the top-1 search), recorded
+ * on the stream that kernel is launched on.  vfm_prof_arm() applies to the NEXT search issued
+ * from the calling thread (one shot).  vfm_prof_elapsed_ms() waits for `stop`. */
+int vfm_prof_events_create(void **start, void **stop);
+int vfm_prof_arm(void *start, void *stop);
+int vfm_prof_elapsed_ms(void *start, void *stop, float *ms_host);
+int vfm_prof_events_destroy(void *start, void *stop);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,7 +75,7 @@ __device__ __forceinline__ float row_sumsq_wave(const float* __restrict__ row, i
 __device__ __forceinline__ float inv_norm_from_sumsq(float nr) {
     // faiss: const float inv_nr = 1.0 / sqrtf(nr);  (double divide, rounded to float)
     if (!(nr > 0.0f)) return 0.0f;
-    float s = __fsqrt_rn(nr);
+    float s = sqrtf(nr);  // __builtin_sqrtf: correctly rounded (HIP default); __fsqrt_rn is the native approximation
     return (float)(1.0 / (double)s);
 }
 
@@ -652,6 +652,9 @@ inline int choose_slices(int nqb, int nchunks) {
     return best_s;
 }
 
+// profiling hook (vfm_prof_arm): events recorded around the next coarse launch on this thread
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+
 template <int KSTEPS>
 int launch_coarse(const CoarseArgs& a, hipStream_t st) {
     const int lds = NBUF * KSTEPS * 1024;
@@ -661,8 +664,11 @@ int launch_coarse(const CoarseArgs& a, hipStream_t st) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
+    if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
     hipLaunchKernelGGL(match_coarse_kernel<KSTEPS>, dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
     VFM_CHECK_LAUNCH("match_coarse_kernel");
+    if (g_prof_stop) VFM_CHECK_HIP(hipEventRecord(g_prof_stop, st));
+    g_prof_start = g_prof_stop = nullptr;
     return VFM_OK;
 }
 
@@ -829,5 +835,35 @@ VFM_EXPORT int vfm_match_mutual_l2(const float* a, int64_t n, const float* b, in
         hipLaunchKernelGGL(nn_l2_kernel, dim3((unsigned)(m < 8192 ? m : 8192)), dim3(256), lds, st, b, m, a, n, d, nn_ba,
                            (double*)nullptr);
     VFM_CHECK_LAUNCH("nn_l2_kernel");
+    return VFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling hooks: HIP events around the dominant kernel (match_coarse_kernel), on the stream the
+// kernel is launched on.  Used by bench.py for roofline.achieved.
+// ---------------------------------------------------------------------------------------------
+VFM_EXPORT int vfm_prof_events_create(void** start, void** stop) {
+    VFM_CHECK_ARG(start && stop, "prof: null pointer");
+    hipEvent_t a, b;
+    VFM_CHECK_HIP(hipEventCreate(&a));
+    VFM_CHECK_HIP(hipEventCreate(&b));
+    *start = a;
+    *stop = b;
+    return VFM_OK;
+}
+VFM_EXPORT int vfm_prof_arm(void* start, void* stop) {
+    g_prof_start = (hipEvent_t)start;
+    g_prof_stop = (hipEvent_t)stop;
+    return VFM_OK;
+}
+VFM_EXPORT int vfm_prof_elapsed_ms(void* start, void* stop, float* ms_host) {
+    VFM_CHECK_ARG(start && stop && ms_host, "prof: null pointer");
+    VFM_CHECK_HIP(hipEventSynchronize((hipEvent_t)stop));
+    VFM_CHECK_HIP(hipEventElapsedTime(ms_host, (hipEvent_t)start, (hipEvent_t)stop));
+    return VFM_OK;
+}
+VFM_EXPORT int vfm_prof_events_destroy(void* start, void* stop) {
+    if (start) hipEventDestroy((hipEvent_t)start);
+    if (stop) hipEventDestroy((hipEvent_t)stop);
     return VFM_OK;
 }

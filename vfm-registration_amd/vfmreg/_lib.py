@@ -45,6 +45,10 @@ SIGNATURES = {
     "vfm_gather_bilinear_patchgrid": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp,
                                                 c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "vfm_transform_xyz_f64": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "vfm_prof_events_create": (C.c_int, [C.POINTER(c_vp), C.POINTER(c_vp)]),
+    "vfm_prof_arm": (C.c_int, [c_vp, c_vp]),
+    "vfm_prof_elapsed_ms": (C.c_int, [c_vp, c_vp, C.POINTER(C.c_float)]),
+    "vfm_prof_events_destroy": (C.c_int, [c_vp, c_vp]),
     "vfm_vit_weights_bytes": (C.c_size_t, [C.POINTER(VitConfig)]),
     "vfm_vit_workspace_bytes": (C.c_size_t, [C.POINTER(VitConfig), C.c_int]),
     "vfm_vit_forward": (C.c_int, [C.POINTER(VitConfig), c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp,
