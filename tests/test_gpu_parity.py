@@ -167,6 +167,7 @@ def test_mutual_l2(ops, orc):
 # ------------------------------------------------------------------------------------- RANSAC
 def test_kabsch_batched_bit_exact(ops, orc):
     rng = np.random.default_rng(5)
+    n_invalid = 0
     for n in (3, 4, 50):
         A = rng.uniform(-20, 20, (64, n, 3))
         B = rng.uniform(-20, 20, (64, n, 3))
@@ -180,7 +181,9 @@ def test_kabsch_batched_bit_exact(ops, orc):
                 Tr, ok = orc.kabsch(A[i], B[i], None if wt is None else wt[i], eps)
                 assert bool(valid[i]) == ok
                 np.testing.assert_array_equal(T[i], Tr)
-    assert valid[60] == 0
+            if wt is None:
+                assert valid[60] == 0  # all points equal: reported invalid, T = identity
+                np.testing.assert_array_equal(T[60], np.eye(4))
 
 
 def _ransac_case(n_corr, outlier, seed, noise=0.02):

@@ -243,13 +243,20 @@ __global__ __launch_bounds__(64) void ransac_score_kernel(const double* __restri
         if (sample_T(pts, C, (uint32_t)h, seed, T)) {
             int64_t good = 0;
             double e2 = 0.0;
+            // software pipeline: the (wave-uniform, scalar) loads of correspondence i+1 are in
+            // flight while correspondence i is scored; accumulation order stays i = 0, 1, 2, ...
+            double c0 = pts[0], c1 = pts[1], c2 = pts[2], c3 = pts[3], c4 = pts[4], c5 = pts[5];
             for (int64_t i = 0; i < C; ++i) {
-                const double* p = pts + 6 * i;  // wave-uniform address
-                const double d2 = err2(T, p[0], p[1], p[2], p[3], p[4], p[5]);
+                const __attribute__((address_space(1))) double* pn =
+                    (const __attribute__((address_space(1))) double*)(pts + 6 * ((i + 1 < C) ? (i + 1) : i));
+                asm volatile("" : "+s"(pn));  // opaque: keeps the prefetch a separate, early load
+                const double n0 = pn[0], n1 = pn[1], n2 = pn[2], n3 = pn[3], n4 = pn[4], n5 = pn[5];
+                const double d2 = err2(T, c0, c1, c2, c3, c4, c5);
                 if (d2 < max_d2) {
                     good++;
                     e2 = e2 + d2;
                 }
+                c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4; c5 = n5;
             }
             if (good > 0) {  // fitness 0 can never beat the initial (0, 0) result
                 fit = (double)good / (double)C;
