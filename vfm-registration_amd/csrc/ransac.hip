@@ -230,39 +230,86 @@ __device__ __forceinline__ bool better(double af, double ar, int ah, double bf, 
     return ah < bh;
 }
 
+constexpr int SCORE_CHUNK = 128;  // correspondences staged in LDS per step (6 KiB)
+
 __global__ __launch_bounds__(64) void ransac_score_kernel(const double* __restrict__ pts,
                                                           const int64_t* __restrict__ count_dev, int64_t c_max,
                                                           double max_d2, int32_t n_iter, uint64_t seed,
                                                           HypScore* __restrict__ block_best) {
+    // one wavefront per workgroup: its private LDS double buffer holds the correspondence stream
+    __shared__ __attribute__((aligned(16))) double lbuf[2][SCORE_CHUNK * 6];
     const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
-    const int32_t h = (int32_t)(blockIdx.x * 64 + threadIdx.x);
+    const int lane = threadIdx.x;
+    const int32_t h = (int32_t)(blockIdx.x * 64 + lane);
     double fit = 0.0, rmse = 0.0;
     int hyp = -1;
-    if (C >= 3 && h < n_iter) {
-        double T[12];
-        if (sample_T(pts, C, (uint32_t)h, seed, T)) {
-            int64_t good = 0;
-            double e2 = 0.0;
-            // software pipeline: the (wave-uniform, scalar) loads of correspondence i+1 are in
-            // flight while correspondence i is scored; accumulation order stays i = 0, 1, 2, ...
-            double c0 = pts[0], c1 = pts[1], c2 = pts[2], c3 = pts[3], c4 = pts[4], c5 = pts[5];
-            for (int64_t i = 0; i < C; ++i) {
-                const __attribute__((address_space(1))) double* pn =
-                    (const __attribute__((address_space(1))) double*)(pts + 6 * ((i + 1 < C) ? (i + 1) : i));
-                asm volatile("" : "+s"(pn));  // opaque: keeps the prefetch a separate, early load
-                const double n0 = pn[0], n1 = pn[1], n2 = pn[2], n3 = pn[3], n4 = pn[4], n5 = pn[5];
-                const double d2 = err2(T, c0, c1, c2, c3, c4, c5);
+    double T[12];
+    const bool wave_has_work = (C >= 3) && ((int32_t)(blockIdx.x * 64) < n_iter);
+    bool live = false;
+    if (C >= 3 && h < n_iter) live = sample_T(pts, C, (uint32_t)h, seed, T);
+    if (!live) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) T[k] = 0.0;
+    }
+    if (wave_has_work) {
+        int64_t good = 0;
+        double e2 = 0.0;
+        // chunk c covers correspondences [c*128, c*128+128): 768 doubles = 64 lanes x 6 double2
+        const int64_t nchunks = (C + SCORE_CHUNK - 1) / SCORE_CHUNK;
+        double2 pre[6];
+        auto fetch = [&](int64_t c) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int64_t e = c * (SCORE_CHUNK * 6) + (int64_t)(j * 64 + lane) * 2;  // element index
+                pre[j] = (e + 1 < C * 6) ? *reinterpret_cast<const double2*>(pts + e) : make_double2(0.0, 0.0);
+            }
+        };
+        auto stash = [&](int b) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<double2*>(&lbuf[b][(j * 64 + lane) * 2]) = pre[j];
+        };
+        fetch(0);
+        stash(0);
+        for (int64_t c = 0; c < nchunks; ++c) {
+            const int b = (int)(c & 1);
+            if (c + 1 < nchunks) fetch(c + 1);  // global loads in flight during the scoring below
+            __builtin_amdgcn_wave_barrier();
+            const int64_t base = c * SCORE_CHUNK;
+            const int cnt = (int)min((int64_t)SCORE_CHUNK, C - base);
+            const double* lp = lbuf[b];
+            // 4 correspondences per trip: independent fp64 chains (the kernel is bound by the
+            // dependent-issue latency of the fp64 ALU at one wave per SIMD); (good, e2) are folded
+            // in the original order, so the accumulation order of the oracle / Open3D is kept.
+            int i = 0;
+            for (; i + 4 <= cnt; i += 4) {
+                double d2[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double* p = lp + 6 * (i + u);  // same address in every lane: LDS broadcast
+                    d2[u] = err2(T, p[0], p[1], p[2], p[3], p[4], p[5]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (d2[u] < max_d2) {
+                        good++;
+                        e2 = e2 + d2[u];
+                    }
+            }
+            for (; i < cnt; ++i) {
+                const double* p = lp + 6 * i;
+                const double d2 = err2(T, p[0], p[1], p[2], p[3], p[4], p[5]);
                 if (d2 < max_d2) {
                     good++;
                     e2 = e2 + d2;
                 }
-                c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4; c5 = n5;
             }
-            if (good > 0) {  // fitness 0 can never beat the initial (0, 0) result
-                fit = (double)good / (double)C;
-                rmse = sqrt(e2 / (double)good);
-                hyp = h;
-            }
+            __builtin_amdgcn_wave_barrier();
+            if (c + 1 < nchunks) stash(b ^ 1);
+        }
+        if (live && good > 0) {  // fitness 0 can never beat the initial (0, 0) result
+            fit = (double)good / (double)C;
+            rmse = sqrt(e2 / (double)good);
+            hyp = h;
         }
     }
 #pragma unroll
