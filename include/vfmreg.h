@@ -163,6 +163,12 @@ typedef struct {
     int patch_w;  /* pw */
 } vfm_vit_config;
 size_t vfm_vit_weights_bytes(const vfm_vit_config *cfg);
+/* segment table of the weights blob for the host-side packer: byte offsets / sizes of
+ * [patch_w, patch_b, cls_pos, {ln1_w, ln1_b, qkv_w, qkv_b, proj_w, proj_b, ls1, ln2_w, ln2_b, fc1_w,
+ *  fc1_b, fc2_w, fc2_b, ls2} x depth, norm_w, norm_b, channel_norm_w, channel_norm_b];
+ * *_w of the linear layers are fp16 fragment tiles, everything else fp32.  Returns the count. */
+int vfm_vit_weights_layout(const vfm_vit_config *cfg, int64_t *offsets_host, int64_t *bytes_host,
+                           int max_n);
 size_t vfm_vit_workspace_bytes(const vfm_vit_config *cfg, int B);
 int vfm_vit_forward(const vfm_vit_config *cfg, const void *weights, const uint8_t *img, int B,
                     int H, int W, float *tokens_out, void *ws, size_t ws_bytes,

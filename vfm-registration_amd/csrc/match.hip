@@ -863,7 +863,7 @@ VFM_EXPORT int vfm_prof_elapsed_ms(void* start, void* stop, float* ms_host) {
     return VFM_OK;
 }
 VFM_EXPORT int vfm_prof_events_destroy(void* start, void* stop) {
-    if (start) hipEventDestroy((hipEvent_t)start);
-    if (stop) hipEventDestroy((hipEvent_t)stop);
+    if (start) (void)hipEventDestroy((hipEvent_t)start);
+    if (stop) (void)hipEventDestroy((hipEvent_t)stop);
     return VFM_OK;
 }

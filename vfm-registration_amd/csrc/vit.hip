@@ -1,10 +1,592 @@
-// vit.hip -- DINOv2 ViT-S/14 forward (row A1). Placeholder translation unit: replaced by the MFMA
-// implementation in a later commit of this round; until then the entry points report VFM_EINVAL.
+// vit.hip -- DINOv2 ViT-S/14 (+ FeatUp ChannelNorm) forward on MI355X (gfx950), row A1.
+//
+// Replaces `self.model.model(torch_image)` of image_features.py:101 together with the transform of
+// image_features.py:67-77 (ToTensor, bilinear Resize to 224 x 14*pw without antialias, ImageNet
+// Normalize).  Architecture as in facebookresearch/dinov2 `vit_small(patch_size=14)` + FeatUp's
+// `ChannelNorm` (SURVEY.md section 8 "A1 detail"): conv patch embed, cls token, (pre-interpolated)
+// position embedding, 12 pre-norm blocks with LayerScale, final LayerNorm, cls dropped, LayerNorm
+// over channels.
+//
+// MI355X design
+//   * every GEMM operand (activations and weights) is kept in HBM as fp16 "fragment tiles":
+//     unit (rowtile, kstep, half, row%32) = 8 consecutive k of one row = exactly one lane's
+//     operand of v_mfma_f32_32x32x16_f16.  A wavefront fetches an operand with ONE coalesced
+//     1 KiB load straight into VGPRs: no LDS staging, no barriers in the GEMMs.
+//   * fp32 residual stream; fp32 accumulation; epilogues fused (bias, exact GELU, LayerScale +
+//     residual add, position embedding).
+//   * GEMMs are computed "swapped" (D = W . A^T) so a lane owns 4 consecutive output channels of
+//     one token: 8-byte fragment stores / 16-byte residual read-modify-writes.
+//   * attention: one wavefront per 32 queries of one (image, head); scores S^T = K Q^T so the
+//     softmax row lives in one lane pair (in-lane max/sum + one xor-32 exchange); P is converted
+//     to the MFMA operand layout in registers with v_permlane32_swap; K / V^T fragments come
+//     straight from HBM/L2 (337 tokens x 64: 43 KB per head, L2 resident).
+//   * all 6 cameras are batched (6 x 352 padded tokens = 66 row tiles) to fill the chip.
+// Floating point => tolerance parity (tests state it); weights are seeded-random in tests/bench.
 #include "common.h"
 
-VFM_EXPORT size_t vfm_vit_weights_bytes(const vfm_vit_config*) { return 0; }
-VFM_EXPORT size_t vfm_vit_workspace_bytes(const vfm_vit_config*, int) { return 0; }
-VFM_EXPORT int vfm_vit_forward(const vfm_vit_config*, const void*, const uint8_t*, int, int, int, float*, void*, size_t,
-                               vfm_stream_t) {
-    return vfm_fail(VFM_EINVAL, "vfm_vit_forward: not built yet");
+#include <type_traits>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// half index of element (row, k) inside a fragment-tiled matrix with `ksteps` k-steps of 16
+__device__ __forceinline__ size_t frag_index(int row, int k, int ksteps) {
+    const int tile = row >> 5, p = row & 31, s = k >> 4, h = (k >> 3) & 1, e = k & 7;
+    return ((((size_t)tile * ksteps + s) * 2 + h) * 32 + p) * 8 + e;
+}
+
+struct Dims {
+    int B, H, W;      // images
+    int Hr, Wr;       // resized image (224 x 14*pw)
+    int gh, gw;       // patch grid (16 x pw)
+    int Np, T, Tp;    // patches, tokens (Np+1), tokens padded to a multiple of 32
+    int M;            // B * Tp rows
+    int D, heads, mlp, depth;
+    int KP;           // patch-embed K padded to a multiple of 16 (3*14*14 = 588 -> 592)
+};
+
+// ---------------------------------------------------------------------------------------------
+// weights blob
+// ---------------------------------------------------------------------------------------------
+enum Seg {
+    SEG_PATCH_W = 0, SEG_PATCH_B, SEG_CLS_POS,
+    SEG_LAYER0,  // per layer: LN1_W LN1_B QKV_W QKV_B PROJ_W PROJ_B LS1 LN2_W LN2_B FC1_W FC1_B FC2_W FC2_B LS2
+};
+constexpr int SEGS_PER_LAYER = 14;
+enum LayerSeg { L_LN1_W = 0, L_LN1_B, L_QKV_W, L_QKV_B, L_PROJ_W, L_PROJ_B, L_LS1, L_LN2_W, L_LN2_B, L_FC1_W, L_FC1_B,
+                L_FC2_W, L_FC2_B, L_LS2 };
+// tail: NORM_W NORM_B CN_W CN_B
+
+struct Layout {
+    size_t off[3 + SEGS_PER_LAYER * 64 + 4];
+    size_t bytes[3 + SEGS_PER_LAYER * 64 + 4];
+    int count;
+    size_t total;
+};
+
+inline size_t frag_bytes(int rows, int k) { return (size_t)ceil_div(rows, 32) * 32 * (size_t)ceil_div(k, 16) * 16 * 2; }
+
+inline Layout make_layout(const vfm_vit_config* c) {
+    Layout L;
+    const int D = c->dim, T = c->patch_h * c->patch_w + 1;
+    const int KP = ceil_div(3 * c->patch * c->patch, 16) * 16;
+    int n = 0;
+    size_t off = 0;
+    auto add = [&](size_t b) {
+        L.off[n] = off;
+        L.bytes[n] = b;
+        off += vfm_align_up(b, 256);
+        ++n;
+    };
+    add(frag_bytes(D, KP));            // patch_w  fp16 frag [D][KP]
+    add((size_t)D * 4);                // patch_b  fp32
+    add((size_t)T * D * 4);            // cls_pos  fp32 [T][D]: row 0 = cls + pos[0], row t = pos[t]
+    for (int l = 0; l < c->depth; ++l) {
+        add((size_t)D * 4); add((size_t)D * 4);                         // ln1
+        add(frag_bytes(3 * D, D)); add((size_t)3 * D * 4);              // qkv
+        add(frag_bytes(D, D)); add((size_t)D * 4); add((size_t)D * 4);  // proj, ls1
+        add((size_t)D * 4); add((size_t)D * 4);                         // ln2
+        add(frag_bytes(c->mlp_dim, D)); add((size_t)c->mlp_dim * 4);    // fc1
+        add(frag_bytes(D, c->mlp_dim)); add((size_t)D * 4); add((size_t)D * 4);  // fc2, ls2
+    }
+    add((size_t)D * 4); add((size_t)D * 4); add((size_t)D * 4); add((size_t)D * 4);  // norm, channel norm
+    L.count = n;
+    L.total = off;
+    return L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1. preprocessing: uint8 HWC -> bilinear resize -> normalise -> im2col fragment tiles
+//    row m = b*Tp + 1 + patch (token row), k = c*196 + py*14 + px (conv weight order)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vit_preprocess_kernel(const uint8_t* __restrict__ img, Dims d,
+                                                             _Float16* __restrict__ out) {
+    const int ksteps = d.KP / 16;
+    const int units_per_row = ksteps * 2;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)d.M * units_per_row;
+    if (gid >= total) return;
+    const int m = (int)(gid / units_per_row), unit = (int)(gid % units_per_row);
+    const int b = m / d.Tp, t = m % d.Tp;
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.0f;
+    if (t >= 1 && t <= d.Np) {
+        const int patch = t - 1, pr = patch / d.gw, pc = patch % d.gw;
+        const float sh = (float)d.H / (float)d.Hr, sw = (float)d.W / (float)d.Wr;
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = unit * 8 + e;
+            if (k < 3 * 196) {
+                const int c = k / 196, py = (k % 196) / 14, px = k % 14;
+                const int oy = pr * 14 + py, ox = pc * 14 + px;
+                // torch upsample_bilinear2d, align_corners=False, antialias=False
+                float sy = sh * ((float)oy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+                float sx = sw * ((float)ox + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+                int y0 = (int)sy; if (y0 > d.H - 1) y0 = d.H - 1;
+                int x0 = (int)sx; if (x0 > d.W - 1) x0 = d.W - 1;
+                const int y1 = y0 + (y0 < d.H - 1 ? 1 : 0), x1 = x0 + (x0 < d.W - 1 ? 1 : 0);
+                const float ly = sy - (float)y0, lx = sx - (float)x0;
+                const uint8_t* base = img + (size_t)b * d.H * d.W * 3;
+                const float p00 = base[((size_t)y0 * d.W + x0) * 3 + c] * (1.0f / 255.0f);
+                const float p01 = base[((size_t)y0 * d.W + x1) * 3 + c] * (1.0f / 255.0f);
+                const float p10 = base[((size_t)y1 * d.W + x0) * 3 + c] * (1.0f / 255.0f);
+                const float p11 = base[((size_t)y1 * d.W + x1) * 3 + c] * (1.0f / 255.0f);
+                const float r = (1.f - ly) * ((1.f - lx) * p00 + lx * p01) + ly * ((1.f - lx) * p10 + lx * p11);
+                v[e] = (_Float16)((r - mean[c]) / stdv[c]);
+            }
+        }
+    }
+    const int s = unit >> 1, h = unit & 1;
+    const size_t idx = ((((size_t)(m >> 5) * ksteps + s) * 2 + h) * 32 + (m & 31)) * 8;
+    *reinterpret_cast<half8*>(out + idx) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. GEMM on fragment tiles.  out[m][n] = sum_k A[m][k] W[n][k]  (+ fused epilogue)
+//    One wavefront per (32 tokens) x (64 output channels); swapped product D = W . A^T:
+//    lane <-> token (column), registers <-> channels (rows): 4 consecutive channels per group.
+// ---------------------------------------------------------------------------------------------
+enum Epi { EPI_PATCH = 0, EPI_QKV = 1, EPI_RESID = 2, EPI_GELU = 3 };
+
+struct GemmArgs {
+    const uint4* A;    // activations, fragment tiles [M/32][KS][64]
+    const uint4* W;    // weights, fragment tiles [N/32][KS][64]
+    const float* bias; // [N]
+    int M, N, KS;
+    // epilogue operands
+    float* x;            // residual stream [M][D] fp32 (PATCH: written, RESID: read-modify-write)
+    const float* gamma;  // LayerScale [N] (RESID)
+    const float* clspos; // [T][D] (PATCH)
+    _Float16* out;       // fragment-tiled fp16 output (GELU: [M][N]; QKV: q,k,vT per head)
+    int T, Tp, D, heads;
+    _Float16* q;  // QKV outputs: per (b, head): Q frag [Tp][64], K frag [Tp][64], V^T frag [64][Tp]
+    _Float16* k;
+    _Float16* vt;
+};
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int EPI>
+__global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int ntile64 = g.N / 64;
+    const int wid = blockIdx.x * 4 + wave;
+    const int mt = wid / ntile64, nt = wid % ntile64;  // token tile, 64-channel tile
+    if (mt >= g.M / 32) return;
+    const uint4* Ap = g.A + (size_t)mt * g.KS * 64 + lane;
+    const uint4* W0 = g.W + (size_t)(nt * 2) * g.KS * 64 + lane;
+    const uint4* W1 = W0 + (size_t)g.KS * 64;
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int s = 0; s < g.KS; ++s) {
+        uint4 a = Ap[(size_t)s * 64], w0 = W0[(size_t)s * 64], w1 = W1[(size_t)s * 64];
+        const half8 av = *reinterpret_cast<half8*>(&a);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&w0), av, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&w1), av, acc1, 0, 0, 0);
+    }
+    // D layout: column = lane & 31 = token, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel in tile
+    const int m = mt * 32 + (lane & 31);
+    const int b = m / g.Tp, t = m % g.Tp;
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const floatx16& acc = half ? acc1 : acc0;
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const int n0 = nt * 64 + half * 32 + 8 * grp + 4 * hi;  // 4 consecutive channels n0..n0+3
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[grp * 4 + j] + g.bias[n0 + j];
+            if constexpr (EPI == EPI_PATCH) {
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t == 0) {
+                    o = *reinterpret_cast<const float4*>(g.clspos + n0);
+                } else if (t < g.T) {
+                    const float4 pe = *reinterpret_cast<const float4*>(g.clspos + (size_t)t * g.D + n0);
+                    o = make_float4(v[0] + pe.x, v[1] + pe.y, v[2] + pe.z, v[3] + pe.w);
+                }
+                *reinterpret_cast<float4*>(g.x + (size_t)m * g.D + n0) = o;
+            } else if constexpr (EPI == EPI_RESID) {
+                if (t < g.T) {
+                    float4* xp = reinterpret_cast<float4*>(g.x + (size_t)m * g.D + n0);
+                    const float4 ga = *reinterpret_cast<const float4*>(g.gamma + n0);
+                    float4 xv = *xp;
+                    xv.x = xv.x + ga.x * v[0]; xv.y = xv.y + ga.y * v[1];
+                    xv.z = xv.z + ga.z * v[2]; xv.w = xv.w + ga.w * v[3];
+                    *xp = xv;
+                }
+            } else if constexpr (EPI == EPI_GELU) {
+                half4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (_Float16)gelu_exact(v[j]);
+                *reinterpret_cast<half4*>(g.out + frag_index(m, n0, g.N / 16)) = o;
+            } else {  // EPI_QKV: channel n0 -> (which, head, d)
+                const int which = n0 / g.D, rem = n0 % g.D, head = rem / 64, dd = rem % 64;
+                const size_t bh = (size_t)b * g.heads + head;
+                if (which < 2) {
+                    half4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[j];
+                    _Float16* dst = (which == 0 ? g.q : g.k) + bh * (size_t)g.Tp * 64;
+                    *reinterpret_cast<half4*>(dst + frag_index(t, dd, 4)) = o;
+                } else {
+                    // V^T fragment tiles: rows = d (64), k = key index (Tp); element (d, key = t)
+                    _Float16* dst = g.vt + bh * (size_t)g.Tp * 64;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dst[frag_index(dd + j, t, g.Tp / 16)] = (_Float16)v[j];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3. LayerNorm over channels, fp32 in -> fp16 fragment tiles out.  One wavefront per token.
+// ---------------------------------------------------------------------------------------------
+// A lane owns the float4 chunks c = lane and c = lane + 64 (D <= 512): v[0..3], v[4..7].
+__device__ __forceinline__ void ln_load(const float* __restrict__ row, int D, float (&v)[8], bool (&has)[2]) {
+    const int lane = lane_id(), nchunk = D >> 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = lane + 64 * i;
+        has[i] = c < nchunk;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has[i]) t = *reinterpret_cast<const float4*>(row + c * 4);
+        v[4 * i + 0] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    }
+}
+
+__device__ __forceinline__ void wave_ln_stats(const float (&v)[8], const bool (&has)[2], int D, float& mean, float& rstd,
+                                              float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += has[i >> 2] ? v[i] : 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float c = has[i >> 2] ? v[i] - mean : 0.f;
+        q += c * c;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+    rstd = rsqrtf(q / (float)D + eps);
+}
+
+__global__ __launch_bounds__(256) void vit_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bsh, int M, int D,
+                                                            _Float16* __restrict__ out) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = lane_id();
+    float v[8];
+    bool has[2];
+    ln_load(x + (size_t)m * D, D, v, has);
+    float mean, rstd;
+    wave_ln_stats(v, has, D, mean, rstd, 1e-6f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (!has[i]) continue;
+        const int n0 = (lane + 64 * i) * 4;
+        half4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (_Float16)((v[4 * i + j] - mean) * rstd * w[n0 + j] + bsh[n0 + j]);
+        *reinterpret_cast<half4*>(out + frag_index(m, n0, D / 16)) = o;
+    }
+}
+
+// final: LayerNorm(norm, 1e-6) -> drop cls -> LayerNorm(channel norm, 1e-5) -> fp32 [B][Np][D]
+__global__ __launch_bounds__(256) void vit_final_kernel(const float* __restrict__ x, const float* __restrict__ nw,
+                                                        const float* __restrict__ nb, const float* __restrict__ cw,
+                                                        const float* __restrict__ cb, Dims d, float* __restrict__ out) {
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);  // over B * Np
+    if (tok >= d.B * d.Np) return;
+    const int b = tok / d.Np, p = tok % d.Np;
+    const int m = b * d.Tp + 1 + p;
+    const int lane = lane_id();
+    float v[8];
+    bool has[2];
+    ln_load(x + (size_t)m * d.D, d.D, v, has);
+    float mean, rstd;
+    wave_ln_stats(v, has, d.D, mean, rstd, 1e-6f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = (lane + 64 * i) * 4 + j;
+            if (has[i]) v[4 * i + j] = (v[4 * i + j] - mean) * rstd * nw[n] + nb[n];
+        }
+    wave_ln_stats(v, has, d.D, mean, rstd, 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (!has[i]) continue;
+        const int n0 = (lane + 64 * i) * 4;
+        float4 o;
+        o.x = (v[4 * i + 0] - mean) * rstd * cw[n0 + 0] + cb[n0 + 0];
+        o.y = (v[4 * i + 1] - mean) * rstd * cw[n0 + 1] + cb[n0 + 1];
+        o.z = (v[4 * i + 2] - mean) * rstd * cw[n0 + 2] + cb[n0 + 2];
+        o.w = (v[4 * i + 3] - mean) * rstd * cw[n0 + 3] + cb[n0 + 3];
+        *reinterpret_cast<float4*>(out + (size_t)tok * d.D + n0) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4. attention: one wavefront per 32 queries of one (image, head).  NKT = key tiles (Tp / 32).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    half2v h;
+    h[0] = (_Float16)a;
+    h[1] = (_Float16)b;
+    return *reinterpret_cast<unsigned*>(&h);
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256) void vit_attention_kernel(const uint4* __restrict__ Q, const uint4* __restrict__ K,
+                                                            const uint4* __restrict__ VT, int T, int Tp, int heads, int D,
+                                                            int nwork, _Float16* __restrict__ out) {
+    const int lane = lane_id();
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= nwork) return;
+    const int qtiles = Tp / 32;
+    const int bh = wid / qtiles, qt = wid % qtiles;
+    const int b = bh / heads, head = bh % heads;
+    const size_t base = (size_t)bh * Tp * 64 / 8;  // uint4 units per (b, head)
+    // Q^T as B operand: query tile qt, 4 k-steps over d
+    half8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        uint4 v = Q[base + ((size_t)qt * 4 + s) * 64 + lane];
+        qf[s] = *reinterpret_cast<half8*>(&v);
+    }
+    // S^T tiles: rows = keys, column = query (lane & 31)
+    floatx16 S[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint4 v = K[base + ((size_t)kt * 4 + s) * 64 + lane];
+            S[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&v), qf[s], S[kt], 0, 0, 0);
+        }
+    }
+    const int hi = lane >> 5;
+    // softmax over keys (scale 1/8), keys >= T masked
+    const float scale = 0.125f * 1.44269504088896340736f;  // fold log2(e): exp(x) = exp2(x*log2e)
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float s = (key < T) ? S[kt][r] * scale : -3.0e38f;
+            S[kt][r] = s;
+            mx = fmaxf(mx, s);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = exp2f(S[kt][r] - mx);
+            S[kt][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    // O^T[d][query] = sum_keys V^T[d][key] P^T[key][query]: A = V^T fragment, B = P^T in registers.
+    floatx16 O0, O1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { O0[r] = 0.f; O1[r] = 0.f; }
+    const int vks = Tp / 16;  // k-steps over keys
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            // keys 16*(2kt+s2) .. +15: register groups g = 2*s2, 2*s2+1 of tile kt.
+            // lanes 0-31 hold keys 8g..8g+3, lanes 32-63 keys 8g+4..8g+7 of each group (packed 2x fp16x2)
+            unsigned x0 = pack_f16x2(S[kt][8 * s2 + 0], S[kt][8 * s2 + 1]);
+            unsigned x1 = pack_f16x2(S[kt][8 * s2 + 2], S[kt][8 * s2 + 3]);
+            unsigned y0 = pack_f16x2(S[kt][8 * s2 + 4], S[kt][8 * s2 + 5]);
+            unsigned y1 = pack_f16x2(S[kt][8 * s2 + 6], S[kt][8 * s2 + 7]);
+            // swap upper half of x with lower half of y: lower lanes end with keys 16s..16s+7,
+            // upper lanes with keys 16s+8..16s+15 -- the B-operand layout (k = 8*(lane>>5) + e)
+            auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+            uint4 pb;
+            pb.x = r0[0]; pb.y = r1[0]; pb.z = r0[1]; pb.w = r1[1];
+            const half8 pf = *reinterpret_cast<half8*>(&pb);
+            const int ks = kt * 2 + s2;
+            uint4 v0 = VT[base + ((size_t)0 * vks + ks) * 64 + lane];
+            uint4 v1 = VT[base + ((size_t)1 * vks + ks) * 64 + lane];
+            O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&v0), pf, O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&v1), pf, O1, 0, 0, 0);
+        }
+    }
+    // write O[query][head*64 + d] as fragment tiles of the [M][D] activation for the proj GEMM
+    const int t = qt * 32 + (lane & 31);
+    const int m = b * Tp + t;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const floatx16& O = half ? O1 : O0;
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const int dd = half * 32 + 8 * grp + 4 * hi;
+            half4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (_Float16)(O[grp * 4 + j] * inv);
+            *reinterpret_cast<half4*>(out + frag_index(m, head * 64 + dd, D / 16)) = o;
+        }
+    }
+}
+
+struct VitWs {
+    float* x;          // [M][D] fp32 residual
+    _Float16* a;       // [M][max(D, KP)] fragment tiles (LN out / im2col / attention out)
+    _Float16* h;       // [M][mlp] fragment tiles
+    _Float16* q;
+    _Float16* k;
+    _Float16* vt;
+    size_t bytes;
+};
+
+inline Dims make_dims(const vfm_vit_config* c, int B, int H, int W) {
+    Dims d;
+    d.B = B; d.H = H; d.W = W;
+    d.gh = c->patch_h; d.gw = c->patch_w;
+    d.Hr = c->patch * c->patch_h; d.Wr = c->patch * c->patch_w;
+    d.Np = d.gh * d.gw; d.T = d.Np + 1; d.Tp = ceil_div(d.T, 32) * 32;
+    d.M = B * d.Tp;
+    d.D = c->dim; d.heads = c->heads; d.mlp = c->mlp_dim; d.depth = c->depth;
+    d.KP = ceil_div(3 * c->patch * c->patch, 16) * 16;
+    return d;
+}
+
+inline VitWs carve_vit(void* p, const Dims& d) {
+    VfmCarver c(p);
+    VitWs w;
+    const int kmax = d.D > d.KP ? d.D : d.KP;
+    w.x = c.take<float>((size_t)d.M * d.D);
+    w.a = c.take<_Float16>((size_t)d.M * kmax);
+    w.h = c.take<_Float16>((size_t)d.M * d.mlp);
+    w.q = c.take<_Float16>((size_t)d.M * d.D);
+    w.k = c.take<_Float16>((size_t)d.M * d.D);
+    w.vt = c.take<_Float16>((size_t)d.M * d.D);
+    w.bytes = c.used();
+    return w;
+}
+
+template <int EPI>
+int launch_gemm(const GemmArgs& g, hipStream_t st) {
+    const int waves = (g.M / 32) * (g.N / 64);
+    hipLaunchKernelGGL(vit_gemm_kernel<EPI>, dim3(ceil_div(waves, 4)), dim3(256), 0, st, g);
+    VFM_CHECK_LAUNCH("vit_gemm_kernel");
+    return VFM_OK;
+}
+
+}  // namespace
+
+VFM_EXPORT size_t vfm_vit_weights_bytes(const vfm_vit_config* cfg) { return cfg ? make_layout(cfg).total : 0; }
+
+// segment table for the host-side packer (vfmreg/vit.py): offsets / sizes in bytes, returns count
+VFM_EXPORT int vfm_vit_weights_layout(const vfm_vit_config* cfg, int64_t* offsets_host, int64_t* bytes_host, int max_n) {
+    if (!cfg) return 0;
+    const Layout L = make_layout(cfg);
+    for (int i = 0; i < L.count && i < max_n; ++i) {
+        offsets_host[i] = (int64_t)L.off[i];
+        bytes_host[i] = (int64_t)L.bytes[i];
+    }
+    return L.count;
+}
+
+VFM_EXPORT size_t vfm_vit_workspace_bytes(const vfm_vit_config* cfg, int B) {
+    if (!cfg) return 0;
+    return carve_vit(nullptr, make_dims(cfg, B, 1, 1)).bytes;
+}
+
+VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, const uint8_t* img, int B, int H, int W,
+                               float* tokens_out, void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    VFM_CHECK_ARG(cfg && weights && img && tokens_out && ws, "vit: null pointer");
+    VFM_CHECK_ARG(cfg->dim % 64 == 0 && cfg->dim == cfg->heads * 64 && cfg->dim <= 512, "vit: dim must be heads*64 and <= 512");
+    VFM_CHECK_ARG(cfg->mlp_dim % 64 == 0 && cfg->depth >= 1 && cfg->depth <= 64, "vit: bad mlp_dim / depth");
+    VFM_CHECK_ARG(cfg->patch == 14 && cfg->patch_h >= 1 && cfg->patch_w >= 1 && B >= 1, "vit: bad patch grid");
+    const Dims d = make_dims(cfg, B, H, W);
+    VFM_CHECK_ARG(d.Tp / 32 <= 16, "vit: at most 512 tokens per image supported (got %d)", d.T);
+    if (ws_bytes < carve_vit(nullptr, d).bytes) return vfm_fail(VFM_EWORKSPACE, "vit: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const Layout L = make_layout(cfg);
+    const unsigned char* wb = static_cast<const unsigned char*>(weights);
+    auto f32 = [&](int seg) { return reinterpret_cast<const float*>(wb + L.off[seg]); };
+    auto f16 = [&](int seg) { return reinterpret_cast<const uint4*>(wb + L.off[seg]); };
+    VitWs w = carve_vit(ws, d);
+
+    // padded token rows stay exactly zero in the residual stream
+    {
+        const int64_t total = (int64_t)d.M * (d.KP / 16) * 2;
+        hipLaunchKernelGGL(vit_preprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, d, w.a);
+        VFM_CHECK_LAUNCH("vit_preprocess_kernel");
+    }
+    GemmArgs g{};
+    g.T = d.T; g.Tp = d.Tp; g.D = d.D; g.heads = d.heads; g.M = d.M;
+    g.x = w.x; g.q = w.q; g.k = w.k; g.vt = w.vt;
+    // patch embedding (+ cls token + position embedding)
+    g.A = reinterpret_cast<const uint4*>(w.a); g.W = f16(SEG_PATCH_W); g.bias = f32(SEG_PATCH_B);
+    g.N = d.D; g.KS = d.KP / 16; g.clspos = f32(SEG_CLS_POS);
+    int rc = launch_gemm<EPI_PATCH>(g, st);
+    if (rc) return rc;
+    const int ln_blocks = ceil_div(d.M, 4);
+    const int att_work = d.B * d.heads * (d.Tp / 32);
+    for (int l = 0; l < d.depth; ++l) {
+        const int s0 = SEG_LAYER0 + l * SEGS_PER_LAYER;
+        hipLaunchKernelGGL(vit_layernorm_kernel, dim3(ln_blocks), dim3(256), 0, st, w.x, f32(s0 + L_LN1_W), f32(s0 + L_LN1_B),
+                           d.M, d.D, w.a);
+        g.A = reinterpret_cast<const uint4*>(w.a); g.W = f16(s0 + L_QKV_W); g.bias = f32(s0 + L_QKV_B);
+        g.N = 3 * d.D; g.KS = d.D / 16;
+        if ((rc = launch_gemm<EPI_QKV>(g, st))) return rc;
+#define VIT_ATT(NKT)                                                                                                      \
+    hipLaunchKernelGGL(vit_attention_kernel<NKT>, dim3(ceil_div(att_work, 4)), dim3(256), 0, st,                          \
+                       reinterpret_cast<const uint4*>(w.q), reinterpret_cast<const uint4*>(w.k),                          \
+                       reinterpret_cast<const uint4*>(w.vt), d.T, d.Tp, d.heads, d.D, att_work, w.a)
+        switch (d.Tp / 32) {
+            case 1: VIT_ATT(1); break;   case 2: VIT_ATT(2); break;   case 3: VIT_ATT(3); break;
+            case 4: VIT_ATT(4); break;   case 5: VIT_ATT(5); break;   case 6: VIT_ATT(6); break;
+            case 7: VIT_ATT(7); break;   case 8: VIT_ATT(8); break;   case 9: VIT_ATT(9); break;
+            case 10: VIT_ATT(10); break; case 11: VIT_ATT(11); break; case 12: VIT_ATT(12); break;
+            case 13: VIT_ATT(13); break; case 14: VIT_ATT(14); break; case 15: VIT_ATT(15); break;
+            default: VIT_ATT(16); break;
+        }
+#undef VIT_ATT
+        VFM_CHECK_LAUNCH("vit_attention_kernel");
+        g.A = reinterpret_cast<const uint4*>(w.a); g.W = f16(s0 + L_PROJ_W); g.bias = f32(s0 + L_PROJ_B);
+        g.gamma = f32(s0 + L_LS1); g.N = d.D; g.KS = d.D / 16;
+        if ((rc = launch_gemm<EPI_RESID>(g, st))) return rc;
+        hipLaunchKernelGGL(vit_layernorm_kernel, dim3(ln_blocks), dim3(256), 0, st, w.x, f32(s0 + L_LN2_W), f32(s0 + L_LN2_B),
+                           d.M, d.D, w.a);
+        g.A = reinterpret_cast<const uint4*>(w.a); g.W = f16(s0 + L_FC1_W); g.bias = f32(s0 + L_FC1_B);
+        g.N = d.mlp; g.KS = d.D / 16; g.out = w.h;
+        if ((rc = launch_gemm<EPI_GELU>(g, st))) return rc;
+        g.A = reinterpret_cast<const uint4*>(w.h); g.W = f16(s0 + L_FC2_W); g.bias = f32(s0 + L_FC2_B);
+        g.gamma = f32(s0 + L_LS2); g.N = d.D; g.KS = d.mlp / 16;
+        if ((rc = launch_gemm<EPI_RESID>(g, st))) return rc;
+    }
+    const int tail = SEG_LAYER0 + d.depth * SEGS_PER_LAYER;
+    hipLaunchKernelGGL(vit_final_kernel, dim3(ceil_div(d.B * d.Np, 4)), dim3(256), 0, st, w.x, f32(tail + 0), f32(tail + 1),
+                       f32(tail + 2), f32(tail + 3), d, tokens_out);
+    VFM_CHECK_LAUNCH("vit_final_kernel");
+    return VFM_OK;
 }

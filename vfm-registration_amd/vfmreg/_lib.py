@@ -50,6 +50,7 @@ SIGNATURES = {
     "vfm_prof_elapsed_ms": (C.c_int, [c_vp, c_vp, C.POINTER(C.c_float)]),
     "vfm_prof_events_destroy": (C.c_int, [c_vp, c_vp]),
     "vfm_vit_weights_bytes": (C.c_size_t, [C.POINTER(VitConfig)]),
+    "vfm_vit_weights_layout": (C.c_int, [C.POINTER(VitConfig), C.POINTER(c_i64), C.POINTER(c_i64), C.c_int]),
     "vfm_vit_workspace_bytes": (C.c_size_t, [C.POINTER(VitConfig), C.c_int]),
     "vfm_vit_forward": (C.c_int, [C.POINTER(VitConfig), c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp,
                                   C.c_size_t, c_vp]),

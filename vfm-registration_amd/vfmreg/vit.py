@@ -1,0 +1,152 @@
+"""DINOv2 ViT-S/14 (+ FeatUp ChannelNorm) weights and forward wrapper (row A1).
+
+The reference obtains the model with ``torch.hub.load("mhamilton723/FeatUp", "dinov2",
+use_norm=True)`` (image_features.py:39-42) -- no network here, so weights come either from a
+state dict in facebookresearch/dinov2 naming (``load_state_dict``; the FeatUp ChannelNorm is
+``channel_norm.{weight,bias}``) or from ``random_weights`` (seeded, exact ViT-S/14 shapes).
+
+Host-side work done once per (weights, input resolution): bicubic interpolation of the 37x37
+position embedding to the 16 x pw patch grid (dinov2 ``interpolate_pos_encoding``; depends only on
+the shape) and re-tiling of the linear weights into the fp16 MFMA fragment layout the HIP kernels
+read (see csrc/vit.hip).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+PATCH = 14
+PATCH_H = 16  # image_features.py:35
+
+
+def vit_s14_shapes(dim: int = 384, depth: int = 12, mlp: int = 1536, n_pos: int = 37 * 37 + 1) -> Dict[str, tuple]:
+    s = {"patch_embed.proj.weight": (dim, 3, PATCH, PATCH), "patch_embed.proj.bias": (dim,),
+         "cls_token": (1, 1, dim), "pos_embed": (1, n_pos, dim), "norm.weight": (dim,), "norm.bias": (dim,),
+         "channel_norm.weight": (dim,), "channel_norm.bias": (dim,)}
+    for i in range(depth):
+        p = f"blocks.{i}."
+        s.update({p + "norm1.weight": (dim,), p + "norm1.bias": (dim,), p + "attn.qkv.weight": (3 * dim, dim),
+                  p + "attn.qkv.bias": (3 * dim,), p + "attn.proj.weight": (dim, dim), p + "attn.proj.bias": (dim,),
+                  p + "ls1.gamma": (dim,), p + "norm2.weight": (dim,), p + "norm2.bias": (dim,),
+                  p + "mlp.fc1.weight": (mlp, dim), p + "mlp.fc1.bias": (mlp,), p + "mlp.fc2.weight": (dim, mlp),
+                  p + "mlp.fc2.bias": (dim,), p + "ls2.gamma": (dim,)})
+    return s
+
+
+def random_weights(seed: int = 0, dim: int = 384, depth: int = 12, mlp: int = 1536) -> Dict[str, np.ndarray]:
+    """Seeded stand-in for the pretrained checkpoint (no network): every branch contributes at O(1)."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for k, shp in vit_s14_shapes(dim, depth, mlp).items():
+        if k.endswith("norm1.weight") or k.endswith("norm2.weight") or k in ("norm.weight", "channel_norm.weight"):
+            v = 1.0 + 0.1 * rng.standard_normal(shp)
+        elif k.endswith(".gamma"):
+            v = rng.uniform(0.05, 0.5, shp)
+        elif k.endswith(".bias"):
+            v = 0.05 * rng.standard_normal(shp)
+        elif k in ("cls_token", "pos_embed"):
+            v = 0.2 * rng.standard_normal(shp)
+        else:
+            fan_in = int(np.prod(shp[1:]))
+            v = rng.standard_normal(shp) / math.sqrt(fan_in)
+        w[k] = v.astype(np.float32)
+    return w
+
+
+def interpolate_pos_embed(pos_embed: np.ndarray, h: int, w: int) -> np.ndarray:
+    """dinov2 interpolate_pos_encoding (bicubic, +0.1 offset trick) -> [1 + h*w, dim] fp32."""
+    import torch.nn.functional as F
+    pe = torch.as_tensor(pos_embed, dtype=torch.float32)
+    n = pe.shape[1] - 1
+    m = int(round(math.sqrt(n)))
+    dim = pe.shape[-1]
+    if h == m and w == m:
+        return pe[0].numpy()
+    patch = F.interpolate(pe[:, 1:].reshape(1, m, m, dim).permute(0, 3, 1, 2),
+                          scale_factor=((h + 0.1) / m, (w + 0.1) / m), mode="bicubic", align_corners=False)
+    assert patch.shape[-2:] == (h, w)
+    patch = patch.permute(0, 2, 3, 1).reshape(h * w, dim)
+    return torch.cat([pe[0, :1], patch], 0).numpy()
+
+
+def to_frag_f16(W: np.ndarray) -> np.ndarray:
+    """[N, K] fp32 -> fp16 fragment tiles [N/32][K/16][2][32][8] (N, K zero-padded to 32 / 16)."""
+    n, k = W.shape
+    npad, kpad = -(-n // 32) * 32, -(-k // 16) * 16
+    Wp = np.zeros((npad, kpad), dtype=np.float16)
+    Wp[:n, :k] = W.astype(np.float16)
+    return np.ascontiguousarray(Wp.reshape(npad // 32, 32, kpad // 16, 2, 8).transpose(0, 2, 3, 1, 4))
+
+
+class ViTS14:
+    """Device-resident DINOv2 ViT-S/14 + ChannelNorm for one input resolution."""
+
+    def __init__(self, weights: Dict[str, np.ndarray], img_h: int, img_w: int, device="cuda"):
+        lib = _lib.load()
+        self.device = torch.device(device)
+        self.img_h, self.img_w = img_h, img_w
+        scale = (PATCH * PATCH_H) / img_h            # image_features.py:68
+        self.patch_w = int(scale * img_w / PATCH)    # image_features.py:69
+        dim = weights["patch_embed.proj.weight"].shape[0]
+        depth = 0
+        while f"blocks.{depth}.norm1.weight" in weights:
+            depth += 1
+        mlp = weights["blocks.0.mlp.fc1.weight"].shape[0]
+        self.cfg = _lib.VitConfig(dim, depth, dim // 64, mlp, PATCH, PATCH_H, self.patch_w)
+        self.dim = dim
+        nseg = 3 + 14 * depth + 4
+        offs = (C.c_int64 * nseg)()
+        sizes = (C.c_int64 * nseg)()
+        cnt = lib.vfm_vit_weights_layout(C.byref(self.cfg), offs, sizes, nseg)
+        assert cnt == nseg
+        total = lib.vfm_vit_weights_bytes(C.byref(self.cfg))
+        blob = np.zeros(total, dtype=np.uint8)
+
+        def put(i, arr):
+            raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+            assert raw.size == sizes[i], (i, raw.size, sizes[i])
+            blob[offs[i]:offs[i] + raw.size] = raw
+
+        g = lambda k: np.asarray(weights[k], dtype=np.float32)
+        pos = interpolate_pos_embed(g("pos_embed"), PATCH_H, self.patch_w)
+        cls_pos = pos.copy()
+        cls_pos[0] += g("cls_token").reshape(-1)
+        put(0, to_frag_f16(g("patch_embed.proj.weight").reshape(dim, -1)))
+        put(1, g("patch_embed.proj.bias"))
+        put(2, cls_pos.astype(np.float32))
+        i = 3
+        for l in range(depth):
+            p = f"blocks.{l}."
+            for name, frag in (("norm1.weight", 0), ("norm1.bias", 0), ("attn.qkv.weight", 1), ("attn.qkv.bias", 0),
+                               ("attn.proj.weight", 1), ("attn.proj.bias", 0), ("ls1.gamma", 0), ("norm2.weight", 0),
+                               ("norm2.bias", 0), ("mlp.fc1.weight", 1), ("mlp.fc1.bias", 0), ("mlp.fc2.weight", 1),
+                               ("mlp.fc2.bias", 0), ("ls2.gamma", 0)):
+                put(i, to_frag_f16(g(p + name)) if frag else g(p + name))
+                i += 1
+        for name in ("norm.weight", "norm.bias", "channel_norm.weight", "channel_norm.bias"):
+            put(i, g(name))
+            i += 1
+        self.blob = torch.from_numpy(blob).to(self.device)
+        self._ws = {}
+
+    def forward(self, images: torch.Tensor) -> torch.Tensor:
+        """images: [B, H, W, 3] uint8 on the device -> [B, 16, pw, dim] fp32 patch features."""
+        ops._chk(images, torch.uint8, "images")
+        B, H, W, _ = images.shape
+        if (H, W) != (self.img_h, self.img_w):
+            raise ValueError("Invalid shape")
+        lib = _lib.load()
+        if B not in self._ws:
+            self._ws[B] = torch.empty(lib.vfm_vit_workspace_bytes(C.byref(self.cfg), B), dtype=torch.uint8,
+                                      device=self.device)
+        out = torch.empty((B, PATCH_H, self.patch_w, self.dim), dtype=torch.float32, device=self.device)
+        _lib.check(lib.vfm_vit_forward(C.byref(self.cfg), self.blob.data_ptr(), images.data_ptr(), B, H, W,
+                                       out.data_ptr(), self._ws[B].data_ptr(), self._ws[B].numel(), ops._stream()),
+                   "vit_forward")
+        return out
