@@ -1,0 +1,252 @@
+"""GPU tests of the drop-in Python API: the reference's names and call patterns (mapping.py,
+registration_node.py, prepare_scenes.py, image_features.py) on the HIP path, checked against the
+oracle and the reference-generated golden fixtures."""
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle as _orc
+    return _orc
+
+
+def _scene(n_scan=3000, n_map=20000, d=384, seed=3):
+    """map / scan clouds as registration_node.py holds them: [x, y, z, d0..d383] fp32-ish rows"""
+    from vfmreg import synth
+    p = synth.make_pair(n_scan, n_map, d, seed=seed)
+    voxel_map = np.c_[p["b_xyz"], p["b_desc"]]
+    raw_scan = np.c_[p["q_xyz"], p["q_desc"]]
+    return voxel_map, raw_scan, p
+
+
+def test_get_vfm_correspondences_like_the_reference(orc):
+    from vfmreg.config import load_config
+    from vfmreg.mapping import VoxelHashMap, get_voxel_hash_map
+    VoxelHashMap.quiet = True
+    voxel_map, raw_scan, p = _scene()
+    voxel_hash_map = get_voxel_hash_map(load_config(None, None))      # RN:402-403
+    voxel_hash_map.add_points(voxel_map)
+    src, tgt = voxel_hash_map.get_vfm_correspondences(raw_scan, .8)   # RN:418
+    m = voxel_hash_map.point_cloud_n()
+    s_ref, t_ref, qi, mi, _ = orc.get_vfm_correspondences(raw_scan, m, 0.8)
+    np.testing.assert_array_equal(src, s_ref)
+    np.testing.assert_array_equal(tgt, t_ref)
+    assert src.dtype == np.float64 and src.shape[1] == 3 and len(src) > 1000
+    q2, m2, _ = voxel_hash_map.get_vfm_correspondence_indices(raw_scan, .8)
+    np.testing.assert_array_equal(q2, qi)
+    np.testing.assert_array_equal(m2, mi)
+    with pytest.raises(RuntimeError):          # wrong width -> py::cast_error in the reference
+        voxel_hash_map.get_vfm_correspondences(raw_scan[:, :100], .8)
+    with pytest.raises(ValueError, match="Invalid shape"):
+        voxel_hash_map.add_points(np.zeros((5, 2)))
+
+
+def test_descriptor_width_outside_fast_path_uses_exact_kernel(orc):
+    from vfmreg.mapping import VoxelHashMap
+    VoxelHashMap.quiet = True
+    rng = np.random.default_rng(0)
+    d = 32  # baseline-descriptor width: not a multiple of 128
+    m = np.c_[rng.uniform(-50, 50, (800, 3)), rng.standard_normal((800, d))]
+    q = np.c_[rng.uniform(-50, 50, (200, 3)), m[rng.integers(0, 800, 200), 3:] + 0.05 * rng.standard_normal((200, d))]
+    vm = VoxelHashMap(1.0, 100.0, 20)
+    vm.add_points(m)
+    src, tgt = vm.get_vfm_correspondences(q, .8)
+    s_ref, t_ref, *_ = orc.get_vfm_correspondences(q, vm.point_cloud_n(), 0.8, bruteforce=True)
+    np.testing.assert_array_equal(src, s_ref)
+    np.testing.assert_array_equal(tgt, t_ref)
+
+
+def test_open3d_standin_ransac(orc):
+    from vfmreg import o3d
+    rng = np.random.default_rng(4)
+    from vfmreg import synth
+    T = synth.random_pose(rng)
+    src = rng.uniform(-40, 40, (900, 3))
+    tgt = src @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 0.02, src.shape)
+    corr = np.stack([np.arange(900), np.arange(900)], 1)
+    corr[::3, 1] = rng.integers(0, 900, 300)   # one third wrong
+    o3d.utility.random.seed(42)
+    pcd_src = o3d.geometry.PointCloud()
+    pcd_src.points = o3d.utility.Vector3dVector(src)
+    pcd_tgt = o3d.geometry.PointCloud()
+    pcd_tgt.points = o3d.utility.Vector3dVector(tgt)
+    result = o3d.pipelines.registration.registration_ransac_based_on_correspondence(
+        pcd_src, pcd_tgt, o3d.utility.Vector2iVector(corr), 0.5,
+        o3d.pipelines.registration.TransformationEstimationPointToPoint(False), ransac_n=3,
+        criteria=o3d.pipelines.registration.RANSACConvergenceCriteria(4000, 1))
+    ref = orc.ransac_corr(src, tgt, corr, 0.5, 4000, seed=42)
+    np.testing.assert_array_equal(np.array(result.transformation), ref.transformation)
+    assert result.fitness == ref.fitness and result.inlier_rmse == ref.inlier_rmse
+    np.testing.assert_array_equal(result.correspondence_set, corr[ref.inlier_mask.astype(bool)].astype(np.int32))
+    assert np.linalg.norm(result.transformation - T) < 0.05
+    # Open3D's default result for too few correspondences; unsupported options are loud
+    r0 = o3d.pipelines.registration.registration_ransac_based_on_correspondence(
+        pcd_src, pcd_tgt, corr[:2], 0.5, criteria=o3d.pipelines.registration.RANSACConvergenceCriteria(10, 1))
+    np.testing.assert_array_equal(r0.transformation, np.eye(4))
+    with pytest.raises(NotImplementedError):
+        o3d.pipelines.registration.registration_ransac_based_on_correspondence(
+            pcd_src, pcd_tgt, corr, 0.5, criteria=o3d.pipelines.registration.RANSACConvergenceCriteria(10, 0.999))
+
+
+def test_ransac_registration_end_to_end(orc):
+    """RegistrationNode.ransac_registration(voxel_map, raw_scan, 'vfm') (RN:273-328) against the same
+    steps assembled from the oracle."""
+    from vfmreg import o3d
+    from vfmreg.mapping import VoxelHashMap
+    from vfmreg.registration import RegistrationNode, compute_errors, orthogonalize_rotation
+    VoxelHashMap.quiet = True
+    voxel_map, raw_scan, p = _scene(n_scan=6000, n_map=30000, seed=11)
+    node = RegistrationNode(ransac_iterations=5000)
+    o3d.utility.random.seed(42)
+    pose, pose_icp = node.ransac_registration(voxel_map, raw_scan, "vfm")
+    assert pose_icp is None
+    # oracle re-enactment of RN:396-425 + 288-327
+    vs = node.config.mapping.voxel_size
+    scan = raw_scan[orc.voxel_first(raw_scan, vs * 0.5)]
+    scan = scan[orc.voxel_first(scan, vs * 1.0)]
+    mp = voxel_map[orc.voxel_first(voxel_map, vs, 20)]
+    sub = scan[orc.voxel_first(scan, 5.0)]
+    _, _, qi, mi, _ = orc.get_vfm_correspondences(sub, mp, 0.8)
+    if len(qi) < 75:
+        sub = scan[orc.voxel_first(scan, 1.0)]
+        _, _, qi, mi, _ = orc.get_vfm_correspondences(sub, mp, 0.8)
+    # indices into the voxelised clouds
+    scan_idx = orc.voxel_first(scan, 5.0 if len(sub) != len(scan[orc.voxel_first(scan, 1.0)]) or True else 1.0)
+    src_rows = np.array([np.flatnonzero((scan[:, :3] == sub[i, :3]).all(1))[0] for i in qi])
+    corres = np.stack([src_rows, mi], 1).astype(np.int32)
+    ref = orc.ransac_corr(scan[:, :3], mp[:, :3], corres, 10000.0, 5000, seed=42)
+    np.testing.assert_array_equal(pose, ref.transformation)
+    rte, rre = compute_errors(pose, p["T_gt"])
+    assert rte < 0.3 and rre < 1.5                                  # RN:973-977 tightest success threshold
+    assert compute_errors(pose, p["T_gt"]) == orc.compute_errors(pose, p["T_gt"])
+    np.testing.assert_allclose(orthogonalize_rotation(pose), orc.orthogonalize_rotation(pose), atol=0)
+    with pytest.raises(NotImplementedError):
+        node.ransac_registration(voxel_map, raw_scan, "vfm", run_icp=True)
+    with pytest.raises(ValueError, match="Invalid method"):
+        node.ransac_registration(voxel_map, raw_scan, "fpfh")
+
+
+def test_find_correspondences_mutual_filter(orc):
+    from vfmreg.registration import find_correspondences
+    rng = np.random.default_rng(6)
+    f1 = rng.standard_normal((700, 33)).astype(np.float32)
+    f0 = f1[rng.permutation(700)[:300]] + 0.01 * rng.standard_normal((300, 33)).astype(np.float32)
+    for mutual in (True, False):
+        i0, i1 = find_correspondences(f0, f1, n_points=100, mutual_filter=mutual)
+        r0, r1 = orc.find_correspondences(f0, f1, n_points=100, mutual_filter=mutual)
+        np.testing.assert_array_equal(np.sort(i0), np.sort(r0))
+        np.testing.assert_array_equal(i1[np.argsort(i0)], r1[np.argsort(r0)])
+
+
+def test_transform_pcl_mirror(golden):
+    from vfmreg.utils import transform_pcl
+    g = golden("transform_pcl.npz")
+    out = transform_pcl(g["pcl"], g["T"])
+    assert out.dtype == np.float32 and out.shape == g["pcl"].shape
+    np.testing.assert_allclose(out, g["out32"], rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(out[:, 3:], g["pcl"][:, 3:])
+
+
+# ------------------------------------------------------------------ create_descriptors (rows A2+A3)
+class _UpsampledFeatures:
+    """the reference's feature generator seen from create_descriptors: H x W x C after F.interpolate"""
+
+    def __init__(self, grids):
+        self.grids, self.calls = grids, 0
+
+    def get_image_features(self, image, upsample=False, cache_file=""):
+        g = torch.from_numpy(self.grids[self.calls]).permute(2, 0, 1).unsqueeze(0)
+        self.calls += 1
+        f = torch.nn.functional.interpolate(g, image.shape[:2], mode="bilinear", align_corners=False)
+        return f.squeeze().permute(1, 2, 0).numpy()
+
+
+class _PatchGridFeatures:
+    """fused path: hands the patch grids to the gather kernel (what ImageFeatureGenerator does)"""
+
+    def __init__(self, grids):
+        self.grids = grids
+
+    def patch_features_device(self, images):
+        return torch.from_numpy(np.stack(self.grids)).cuda()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_create_descriptors_oxford_fixture(golden, fused):
+    from vfmreg.dataloader import OxfordRobotcar
+    from vfmreg.prepare_scenes import create_descriptors
+    g = golden("lift_oxf.npz")
+    cams = ["stereo/centre", "mono_left", "mono_right"]
+    calib = {"lidar_in_ego": g["lidar_in_ego"]}
+    cm = {}
+    for i, c in enumerate(cams):
+        calib[f"{c}_in_ego"] = g["cam_in_ego"][i]
+        cm[c] = types.SimpleNamespace(G_camera_image=g["G"], focal_length=(g["fc"][0], g["fc"][1]),
+                                      principal_point=(g["fc"][2], g["fc"][3]))
+    seq = OxfordRobotcar(calib, cm, image_subsample=int(g["subsample"]), cameras=cams)
+    images = {c: g["images"][i] for i, c in enumerate(cams)}
+    seq.read_images = lambda filenames=None: images
+    fg = (_PatchGridFeatures if fused else _UpsampledFeatures)(list(g["grids"]))
+    desc = create_descriptors(None, seq, fg, g["xyz"])
+    ref = g["desc"]
+    assert desc.dtype == np.float32 and desc.shape == ref.shape
+    np.testing.assert_array_equal(np.abs(desc).sum(1) > 0, np.abs(ref).sum(1) > 0)
+    np.testing.assert_allclose(desc, ref, rtol=0, atol=1e-5)
+    if not fused:  # gathering from the already-upsampled map is a pure copy: bit-exact
+        np.testing.assert_array_equal(desc, ref)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_create_descriptors_nclt_fixture(golden, fused):
+    from vfmreg.dataloader import NCLT
+    from vfmreg.prepare_scenes import create_descriptors
+    g = golden("lift_nclt.npz")
+    cams = ["Cam1", "Cam2"]
+    seq = NCLT({c: {"K": g["K"][i], "x_lb3": g["x_lb3"][i]} for i, c in enumerate(cams)},
+               {c: {"coords": list(g["coords"])} for c in cams}, image_subsample=int(g["subsample"]), cameras=cams)
+    images = {c: g["images"][i] for i, c in enumerate(cams)}
+    seq.read_images = lambda filenames=None: images
+    fg = (_PatchGridFeatures if fused else _UpsampledFeatures)(list(g["grids"]))
+    desc = create_descriptors(None, seq, fg, g["xyz"])
+    ref = g["desc"]
+    np.testing.assert_array_equal(np.abs(desc).sum(1) > 0, np.abs(ref).sum(1) > 0)
+    np.testing.assert_allclose(desc, ref, rtol=0, atol=1e-5)
+
+
+def test_project_pcl_to_image_mirror_signature(golden):
+    from vfmreg.dataloader import KittiOdometry
+    g = golden("proj_kitti.npz")
+    ds = KittiOdometry({"P2": g["P2"], "Tr_velo_to_cam": g["Tr"]}, image_subsample=1)
+    u, v, idx = ds.project_pcl_to_image(g["pcl"], np.zeros((int(g["H"]), int(g["W"]), 3), np.uint8), "camera")
+    assert u.dtype == np.int64 and idx.dtype == np.int64
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(u, g["u"])
+    np.testing.assert_array_equal(v, g["v"])
+
+
+def test_image_feature_generator(orc):
+    from vfmreg import vit as V
+    from vfmreg.image_features import ImageFeatureGenerator
+    w = V.random_weights(seed=9, dim=128, depth=2, mlp=256)
+    gen = ImageFeatureGenerator("dinov2", use_featup=False, weights=w)
+    rng = np.random.default_rng(0)
+    image = rng.integers(0, 256, (120, 160, 3), dtype=np.uint8)
+    feats = gen.get_image_features(image)                       # 16 x pw x C
+    assert feats.shape == (16, gen.patch_w, 128) and gen.patch_w == int((224 / 120) * 160 / 14)
+    ref = orc.vit_reference(w, image[None])[0]
+    assert np.abs(feats - ref).max() < 1e-2
+    up = gen.get_image_features(image, upsample=True)           # H x W x C (IF:104-110)
+    assert up.shape == (120, 160, 128)
+    t = torch.from_numpy(feats).permute(2, 0, 1).unsqueeze(0)
+    up_ref = torch.nn.functional.interpolate(t, (120, 160), mode="bilinear", align_corners=False)
+    np.testing.assert_allclose(up, up_ref.squeeze().permute(1, 2, 0).numpy(), rtol=0, atol=1e-5)
+    with pytest.raises(ValueError, match="Unsupported foundation model"):
+        ImageFeatureGenerator("resnet", use_featup=False)
+    with pytest.raises(NotImplementedError):
+        ImageFeatureGenerator("dinov2", use_featup=True)

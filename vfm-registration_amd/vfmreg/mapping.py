@@ -1,0 +1,124 @@
+"""Mirror of kiss_icp.mapping (src/kiss-icp/python/kiss_icp/mapping.py:30-131) for the calls the
+registration path makes: ``get_voxel_hash_map``, ``VoxelHashMap.add_points``, ``.point_cloud``,
+``.point_cloud_n`` and ``.get_vfm_correspondences`` (C++: VoxelHashMap.cpp:461-626, 662-676,
+733-770; binding kiss_icp_pybind.cpp:75-129).
+
+The map keeps at most ``max_points_per_voxel`` points per voxel in insertion order
+(VoxelHashMap.hpp:55-62).  ``point_cloud*()`` return the kept points in insertion order (the
+reference: robin_map iteration order -- same set, documented deviation).  The descriptor search
+runs on the GPU through the C ABI; besides the reference's (source, target) coordinate pair the
+indices are available (``get_vfm_correspondence_indices``), which makes the KD-tree index recovery
+of registration_node.py:288-317 unnecessary.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .voxelization import voxel_keys
+
+
+def get_voxel_hash_map(config):
+    return VoxelHashMap(voxel_size=config.mapping.voxel_size, max_distance=config.data.max_range,
+                        max_points_per_voxel=config.mapping.max_points_per_voxel)
+
+
+class VoxelHashMap:
+    quiet = False  # the reference prints a stats line per search (VoxelHashMap.cpp:613-616)
+
+    def __init__(self, voxel_size: float, max_distance: float, max_points_per_voxel: int):
+        self.voxel_size = float(voxel_size)
+        self.max_distance = float(max_distance)
+        self.max_points_per_voxel = int(max_points_per_voxel)
+        self.clear()
+
+    # ------------------------------------------------------------------ container
+    def clear(self):
+        self._chunks = {}       # width -> list of arrays (3-D and N-D points live in separate maps)
+        self._counts = {}       # width -> dict voxel key -> count
+        self._dev = None        # cached device copy of the N-D map (IndexFlatIP.add)
+
+    def empty(self):
+        return not self._chunks.get(3)
+
+    def empty_n(self):
+        return not any(w > 3 for w in self._chunks)
+
+    def add_points(self, points: np.ndarray):
+        points = np.asarray(points)
+        if points.ndim != 2 or points.shape[1] < 3:
+            raise ValueError("Invalid shape")  # mapping.py:86
+        width = points.shape[1]
+        pts = np.ascontiguousarray(points, dtype=np.float64)  # pybind: forcecast to double (stl_vector_eigen.h:73-86)
+        keys = voxel_keys(pts, self.voxel_size)
+        counts = self._counts.setdefault(width, {})
+        keep = np.zeros(len(pts), dtype=bool)
+        # occurrence rank inside the batch + points already stored in the voxel < cap
+        order = np.argsort(keys, kind="stable")
+        ks = keys[order]
+        start = np.r_[True, ks[1:] != ks[:-1]] if len(ks) else np.zeros(0, bool)
+        run_start = np.maximum.accumulate(np.where(start, np.arange(len(ks)), 0)) if len(ks) else np.zeros(0, int)
+        rank = np.arange(len(ks)) - run_start
+        uniq = ks[start] if len(ks) else ks
+        prev = np.array([counts.get(int(k), 0) for k in uniq], dtype=np.int64)
+        prev_per_pt = prev[np.cumsum(start) - 1] if len(ks) else prev
+        keep[order] = (rank + prev_per_pt) < self.max_points_per_voxel
+        added = np.bincount(np.cumsum(start) - 1, weights=keep[order], minlength=len(uniq)).astype(np.int64) if len(ks) else []
+        for k, a in zip(uniq, added):
+            if a:
+                counts[int(k)] = counts.get(int(k), 0) + int(a)
+        self._chunks.setdefault(width, []).append(pts[keep])
+        self._dev = None
+
+    def _cloud(self, width_pred) -> Optional[np.ndarray]:
+        arrs = [a for w, lst in self._chunks.items() if width_pred(w) for a in lst]
+        if not arrs:
+            return None
+        return np.concatenate(arrs, axis=0)
+
+    def point_cloud(self) -> np.ndarray:
+        c = self._cloud(lambda w: w == 3)
+        return c if c is not None else np.zeros((0, 3))
+
+    def point_cloud_n(self) -> np.ndarray:
+        c = self._cloud(lambda w: w > 3)
+        return c if c is not None else np.zeros((0, 3))
+
+    # ------------------------------------------------------------------ search
+    def _device_map(self):
+        if self._dev is None:
+            m = self.point_cloud_n()
+            desc = torch.from_numpy(np.ascontiguousarray(m[:, 3:], dtype=np.float32)).cuda()  # VoxelHashMap.cpp:472-473
+            xyz = torch.from_numpy(np.ascontiguousarray(m[:, :3])).cuda()
+            self._dev = (desc, xyz)
+        return self._dev
+
+    def get_vfm_correspondence_indices(self, points: np.ndarray, min_cosine_similarity: float):
+        """(query_idx[K], map_idx[K], sim[N]) -- the indices behind get_vfm_correspondences."""
+        points = np.asarray(points)
+        b_desc, _ = self._device_map()
+        if points.ndim != 2 or points.shape[1] != b_desc.shape[1] + 3:
+            raise RuntimeError("Unable to cast Python instance to C++ type: expected %d columns"
+                               % (b_desc.shape[1] + 3))  # py::cast_error, stl_vector_eigen.h:76-78
+        q_desc = torch.from_numpy(np.ascontiguousarray(points[:, 3:], dtype=np.float32)).cuda()
+        d = q_desc.shape[1]
+        prec = ops.FAST if (d % 128 == 0 and 128 <= d <= 512) else ops.EXACT
+        idx, sim = ops.match_ip_top1(q_desc, b_desc, prec)
+        r = ops.threshold_compact(sim, idx, float(min_cosine_similarity), want_corres=True)
+        k = int(r["count"].item())
+        corres = r["corres"][:k].cpu().numpy()
+        return corres[:, 0].astype(np.int64), corres[:, 1].astype(np.int64), sim.cpu().numpy()
+
+    def get_vfm_correspondences(self, points: np.ndarray, max_correspondance_distance: float
+                                ) -> Tuple[np.ndarray, np.ndarray]:
+        """Pair of {source, target} coordinates (mapping.py:120-131); the float is the cosine
+        threshold despite its name (kiss_icp_pybind.cpp:128-129)."""
+        points = np.asarray(points)
+        qi, mi, sim = self.get_vfm_correspondence_indices(points, max_correspondance_distance)
+        m = self.point_cloud_n()
+        if not self.quiet:
+            print(f"Points: {len(points)} | Corrs.: {len(qi)} | Outliers: 0 | Mean sim.: {float(sim.mean()) if len(sim) else 0.0}")
+        return np.asarray(points[qi, :3], dtype=np.float64), np.asarray(m[mi, :3], dtype=np.float64)

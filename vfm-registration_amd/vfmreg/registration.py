@@ -1,0 +1,124 @@
+"""Mirror of the hot-path methods of ``RegistrationNode`` (src/vfm-reg/src/registration_node.py):
+
+  compute_vfm_correspondences  RN:396-425      ransac_registration('vfm')  RN:273-357
+  find_correspondences         RN:482-538      compute_errors              RN:997-1019
+  rotation re-orthogonalisation RN:331-336
+
+Same names, argument meaning and return values; numpy in / numpy out.  The ROS node, the baseline
+descriptors, TEASER / PointDSC and the ICP refinement are out of scope:
+``run_icp=True`` raises NotImplementedError rather than silently skipping the refinement.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import o3d, ops
+from .config import load_config
+from .mapping import get_voxel_hash_map
+from .utils import transform_pcl
+from .voxelization import voxel_down_sample
+
+
+def orthogonalize_rotation(pose: np.ndarray) -> np.ndarray:
+    """RN:331-336: Newton iteration towards the closest rotation (3x3 fp64, host)."""
+    pose = np.array(pose, dtype=np.float64, copy=True)
+    R = pose[:3, :3]
+    while np.abs(1 - np.linalg.det(R)) > 1e-12:
+        R = 3 / 2 * R - 1 / 2 * R @ R.T @ R
+    pose[:3, :3] = R
+    return pose
+
+
+def compute_errors(pose: np.ndarray, gt_pose: np.ndarray) -> Tuple[float, float]:
+    """RN:997-1019: (RTE in m, RRE in degrees)."""
+    rte = float(np.linalg.norm(pose[:3, 3] - gt_pose[:3, 3]))
+    c = (np.trace(pose[:3, :3].T @ gt_pose[:3, :3]) - 1) / 2
+    rre = float(np.abs(np.arccos(np.clip(c, -1, 1))) * 180 / np.pi)
+    return rte, rre
+
+
+def find_correspondences(feats0: np.ndarray, feats1: np.ndarray, n_points: int = 5000, mutual_filter: bool = True):
+    """RN:482-538 (adapted from TEASER++): exact Euclidean 1-NN on the GPU instead of cKDTree."""
+    f0 = torch.from_numpy(np.ascontiguousarray(feats0, dtype=np.float32)).cuda()
+    f1 = torch.from_numpy(np.ascontiguousarray(feats1, dtype=np.float32)).cuda()
+    nn01, d2, nn10 = ops.match_mutual_l2(f0, f1, mutual=mutual_filter)
+    nns01 = nn01.cpu().numpy()
+    idx0 = np.arange(len(nns01))
+    if not mutual_filter:
+        dists = np.sqrt(d2.cpu().numpy())
+        n = min(n_points, len(dists) - 1)
+        top = np.argpartition(dists, n)[:n]
+        return idx0[top], nns01[top]
+    nns10 = nn10.cpu().numpy()
+    mutual = nns10[nns01] == idx0
+    return idx0[mutual], nns01[mutual]
+
+
+class RegistrationNode:
+    """The registration methods of the reference's node, without ROS (RN:44-89)."""
+
+    def __init__(self, config=None, ransac_iterations: int = 50000, max_correspondence_distance: float = 10000.0,
+                 min_cosine_similarity: float = 0.8):
+        self.config = config or load_config(None, None)  # RN:85
+        self.ransac_iterations = ransac_iterations       # RN:326
+        self.max_correspondence_distance = max_correspondence_distance  # RN:323
+        self.min_cosine_similarity = min_cosine_similarity              # RN:418
+
+    def compute_vfm_correspondences(self, voxel_map, raw_scan, initial_pose=np.eye(4)):
+        # Voxelize: double-downsampling from KISS-ICP (RN:399-400)
+        downsample_scan = voxel_down_sample(raw_scan, self.config.mapping.voxel_size * 0.5)
+        voxel_scan = voxel_down_sample(downsample_scan, self.config.mapping.voxel_size * 1.0)
+        voxel_hash_map = get_voxel_hash_map(self.config)
+        voxel_hash_map.add_points(voxel_map)
+        pcl = transform_pcl(voxel_scan, initial_pose)
+        voxel_pcl = voxel_down_sample(pcl, 5.0)  # RN:414
+        correspondences = voxel_hash_map.get_vfm_correspondences(voxel_pcl, self.min_cosine_similarity)
+        if correspondences[0].shape[0] < 75:     # RN:420-423
+            print("[WARNING] Voxelized too sparse, retrying with a larger voxel size")
+            voxel_pcl = voxel_down_sample(pcl, 1.0)
+            correspondences = voxel_hash_map.get_vfm_correspondences(voxel_pcl, self.min_cosine_similarity)
+        return correspondences
+
+    def ransac_registration(self, voxel_map, raw_scan, method: str = "vfm", run_icp: bool = False):
+        if method != "vfm":
+            raise ValueError(f"Invalid method: {method}")  # baselines are out of scope
+        if run_icp:
+            raise NotImplementedError("ICP refinement (register_frame, RN:338-344) is row F2 of the scope table")
+        src, tgt = self.compute_vfm_correspondences(voxel_map, raw_scan)
+        # correspondence indices (RN:288-317): exact coordinate look-up replaces the two KD-trees
+        downsample_scan = voxel_down_sample(raw_scan[:, :3], self.config.mapping.voxel_size * 0.5)
+        voxel_scan = voxel_down_sample(downsample_scan, self.config.mapping.voxel_size * 1.0)
+        voxel_hash_map = get_voxel_hash_map(self.config)
+        voxel_hash_map.add_points(voxel_map[:, :3])
+        voxel_map_3d = voxel_hash_map.point_cloud()
+        src_indices, src_ok = _lookup_rows(voxel_scan, src)
+        tgt_indices, tgt_ok = _lookup_rows(voxel_map_3d, tgt)
+        ok = src_ok & tgt_ok                      # RN:301-309: drop pairs not found (distance >= 1e-3)
+        pcd_src = o3d.geometry.PointCloud()
+        pcd_src.points = o3d.utility.Vector3dVector(voxel_scan)
+        pcd_tgt = o3d.geometry.PointCloud()
+        pcd_tgt.points = o3d.utility.Vector3dVector(voxel_map_3d)
+        coors = o3d.utility.Vector2iVector(np.stack((src_indices[ok], tgt_indices[ok]), axis=1))
+        result = o3d.pipelines.registration.registration_ransac_based_on_correspondence(
+            pcd_src, pcd_tgt, coors, self.max_correspondence_distance,
+            o3d.pipelines.registration.TransformationEstimationPointToPoint(False), ransac_n=3,
+            criteria=o3d.pipelines.registration.RANSACConvergenceCriteria(self.ransac_iterations, 1))
+        return np.array(result.transformation), None
+
+
+def _lookup_rows(cloud: np.ndarray, pts: np.ndarray):
+    """Index in `cloud` of every row of `pts` (nearest neighbour at distance < 1e-3, RN:295-309).
+    The correspondences were copied out of these clouds, so an exact match on the raw bytes
+    exists whenever the KD-tree of the reference finds one."""
+    cloud = np.ascontiguousarray(cloud, dtype=np.float64)
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    key = lambda a: a.view(np.dtype((np.void, 24))).reshape(-1)
+    order = np.argsort(key(cloud), kind="stable")
+    sorted_keys = key(cloud)[order]
+    pos = np.searchsorted(sorted_keys, key(pts))
+    pos = np.minimum(pos, max(len(cloud) - 1, 0))
+    ok = (sorted_keys[pos] == key(pts)) if len(cloud) else np.zeros(len(pts), bool)
+    return order[pos] if len(cloud) else np.zeros(len(pts), np.int64), ok
