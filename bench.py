@@ -98,19 +98,17 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (there is no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from vfmreg import _lib, synth
+    from vfmreg import dist as vdist
     from vfmreg.pipeline import RegistrationPipeline
+
+    rank, world = vdist.init_from_env(backend="nccl", device=dev)  # "nccl" == RCCL on ROCm
 
     lib = _lib.load()
     n, m, d = args.n, args.m, DIM
@@ -122,8 +120,8 @@ def main():
         p = pairs[i % 2]
         return pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"], want_mask=True)
 
-    for i in range(args.warmup):
-        step(i)
+    # untimed warm-up of the complete step, including the sharding / gather path
+    vdist.register_sharded(world * max(args.warmup, 1), lambda p: (lambda o: (o["T"], o["count"]))(step(p)), rank, world, dev)
     torch.cuda.synchronize()
 
     events = []
@@ -131,19 +129,22 @@ def main():
         a, b = C.c_void_p(), C.c_void_p()
         _lib.check(lib.vfm_prof_events_create(C.byref(a), C.byref(b)))
         events.append((a, b))
-    poses = torch.empty((args.steps, 4, 4), dtype=torch.float64, device=dev)
+    num_pairs = world * args.steps  # global scene-pair ids; pair p runs on rank p mod world (weak scaling)
+    local_i = [0]
+
+    def register_pair(p):
+        i = local_i[0]
+        local_i[0] += 1
+        lib.vfm_prof_arm(events[i][0], events[i][1])
+        out = step(i)
+        return out["T"], out["count"]
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        lib.vfm_prof_arm(events[i][0], events[i][1])
-        out = step(i)
-        poses[i].copy_(out["T"])
-    if world > 1:
-        gathered = torch.empty((world,) + tuple(poses.shape), dtype=poses.dtype, device=dev)
-        dist.all_gather_into_tensor(gathered, poses)  # the path's only collective (RCCL over xGMI)
+    # every rank registers its pairs (no data-path collective), then ONE all_gather of the poses
+    all_poses, all_counts = vdist.register_sharded(num_pairs, register_pair, rank, world, dev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -163,8 +164,9 @@ def main():
 
     # sanity of the timed work: every pose must recover the planted transform
     import numpy as np
-    errs = [float(np.linalg.norm(poses[i].cpu().numpy() - pairs[i % 2]["T_gt"])) for i in range(args.steps)]
-    ncorr = int(out["count"].item())
+    mine = vdist.shard_pairs(num_pairs, rank, world)
+    errs = [float(np.linalg.norm(all_poses[p].cpu().numpy() - pairs[i % 2]["T_gt"])) for i, p in enumerate(mine)]
+    ncorr = int(all_counts[mine[-1]].item())
 
     if rank == 0:
         flops = 2.0 * n * m * d

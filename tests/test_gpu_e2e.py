@@ -1,0 +1,107 @@
+"""BASELINE config C3 end to end on the GPU: DINOv2 ViT-S/14 features of 6 x 1600x1200 surround
+images -> LiDAR projection into 6 pinhole cameras -> fused descriptor lifting (first camera wins)
+-> descriptor matching against a precomputed map -> RANSAC pose.  Each stage is checked against the
+oracle; the solve stages are fed the SAME (GPU-lifted) descriptors so that they compare exactly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _cameras(n_cam=6, fx=800.0, cx=800.0, cy=600.0):
+    """pinhole cameras yawed 60 degrees apart around the LiDAR"""
+    K = np.array([[fx, 0, cx], [0, fx, cy], [0, 0, 1.0]])
+    Ps = []
+    for i in range(n_cam):
+        yaw = np.deg2rad(60.0 * i)
+        fwd = np.array([np.cos(yaw), np.sin(yaw), 0.0])          # optical axis in the LiDAR frame
+        right = np.array([np.sin(yaw), -np.cos(yaw), 0.0])
+        down = np.array([0.0, 0.0, -1.0])
+        R = np.stack([right, down, fwd])                          # rows: camera x, y, z
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = -R @ np.array([0.1 * np.cos(yaw), 0.1 * np.sin(yaw), 0.3])
+        Ps.append(K @ T[:3, :])
+    return Ps
+
+
+def test_c3_end_to_end():
+    from oracle import oracle as orc
+    from tests.test_gpu_vit import _smooth_images
+    from vfmreg import synth
+    from vfmreg import vit as V
+    from vfmreg.dataloader import KittiOdometry
+    from vfmreg.image_features import ImageFeatureGenerator
+    from vfmreg.pipeline import RegistrationPipeline
+    from vfmreg.prepare_scenes import create_descriptors
+
+    rng = np.random.default_rng(7)
+    n, m, H, W = 20000, 200000, 1200, 1600
+    cams = [f"cam{i}" for i in range(6)]
+    Ps = _cameras()
+    imgs = _smooth_images(rng, 6, H, W)
+    imgs[2, 100:300, 200:900] = 0                                  # black block: zero descriptors (PS:57-62)
+    images = {c: imgs[i] for i, c in enumerate(cams)}
+
+    class Surround:                                                # duck-typed `sequence` (PS:50-76)
+        cameras = cams
+        image_subsample = 1
+
+        def __init__(self):
+            self._k = {c: KittiOdometry({"P2": Ps[i], "Tr_velo_to_cam": np.eye(4)}) for i, c in enumerate(cams)}
+
+        def read_images(self, filenames=None):
+            return images
+
+        def project_pcl_to_image(self, pcl, image, camera, _device_inputs=None):
+            return self._k[camera].project_pcl_to_image(pcl, image, "camera", _device_inputs=_device_inputs)
+
+    scan_xyz = np.c_[rng.uniform(-40, 40, n), rng.uniform(-40, 40, n), rng.uniform(-2.5, 6, n)].astype(np.float32)
+    w = V.random_weights(seed=0)
+    gen = ImageFeatureGenerator("dinov2", use_featup=False, weights=w)
+    desc = create_descriptors(None, Surround(), gen, scan_xyz)     # [n, 384] fp32, rows A1+A2+A3 on the GPU
+    assert desc.shape == (n, 384) and desc.dtype == np.float32
+
+    # ---- stage parity: projection indices exact, lifted values within the ViT tolerance
+    grids = orc.vit_reference(w, imgs)
+    pcl = np.insert(scan_xyz, 3, values=1, axis=1).T
+    ocams = []
+    for i in range(6):
+        u, v, idx = orc.project(2, pcl, [Ps[i]], None, 1.0, None, None, H, W)
+        ocams.append(dict(grid=grids[i], Hup=H, Wup=W, rot_mode=0, black=np.all(imgs[i] == 0, -1), u=u, v=v, idx=idx))
+    ref = orc.create_descriptors(n, ocams)
+    np.testing.assert_array_equal(np.abs(desc).sum(1) > 0, np.abs(ref).sum(1) > 0)
+    seen = np.abs(ref).sum(1) > 0
+    assert 0.5 < seen.mean() < 1.0 and np.abs(desc - ref).max() < 1e-2
+
+    # ---- map with precomputed descriptors: the scan's true counterparts + clutter
+    T_gt = synth.random_pose(rng)
+    pick = rng.permutation(m)[:n]
+    b_xyz = np.c_[rng.uniform(-60, 60, m), rng.uniform(-60, 60, m), rng.uniform(-3, 12, m)]
+    b_xyz[pick] = scan_xyz.astype(np.float64) @ T_gt[:3, :3].T + T_gt[:3, 3] + rng.normal(0, 0.02, (n, 3))
+    b_desc = rng.standard_normal((m, 384)).astype(np.float32)
+    b_desc[pick] = desc + 0.02 * np.abs(desc).mean() * rng.standard_normal(desc.shape).astype(np.float32)
+    b_desc[pick[~seen]] = rng.standard_normal((int((~seen).sum()), 384)).astype(np.float32)
+
+    pipe = RegistrationPipeline(n, m, 384, n_iter=50000, max_corr_dist=1.0)
+    dev = lambda a, t: torch.from_numpy(np.ascontiguousarray(a, dtype=t)).cuda()
+    out = pipe.register(dev(desc, np.float32), dev(scan_xyz, np.float64), dev(b_desc, np.float32), dev(b_xyz, np.float64))
+    torch.cuda.synchronize()
+    T = out["T"].cpu().numpy()
+    assert np.linalg.norm(T[:3, 3] - T_gt[:3, 3]) < 0.3
+
+    # ---- solve parity on identical descriptors: indices, inlier mask and pose vs the oracle
+    qn, _ = orc.l2norm_rows(desc)
+    bn, _ = orc.l2norm_rows(b_desc)
+    idx, sim = orc.match_ip_top1(qn, bn)
+    np.testing.assert_array_equal(out["idx"].cpu().numpy(), idx)
+    assert (sim[~seen] == 0).all()                                  # zero descriptors never match
+    keep = orc.threshold_compact(sim, 0.8)
+    k = int(out["count"].item())
+    assert k == len(keep) and k > 1000
+    corres = np.stack([keep, idx[keep]], 1).astype(np.int32)
+    r = orc.ransac_corr(scan_xyz.astype(np.float64), b_xyz, corres, 1.0, 50000, seed=42)
+    np.testing.assert_array_equal(out["mask"][:k].cpu().numpy(), r.inlier_mask)
+    assert np.linalg.norm(T - r.transformation) <= 1e-5
+    np.testing.assert_array_equal(T, r.transformation)

@@ -1,0 +1,82 @@
+"""Multi-GPU execution of the path.
+
+The reference has no distributed code.  A registration reads only its own scan/map pair
+(registration_node.py:587-589 iterates scans independently), so the path shards by INDEPENDENT SCENE
+PAIRS: one process per GPU (torchrun), pair p runs on rank p mod G, no data-path collective.  The
+only exchange is the final gather of the 4x4 poses (+ inlier counts): one
+``all_gather_into_tensor`` of fp64[pairs_per_rank, 4, 4] -- backend "nccl" (= RCCL over xGMI) on
+GPUs, "gloo" in the CPU tests.  256 pairs x 128 B = 32 KB: latency-bound, topology irrelevant.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] = None) -> Tuple[int, int]:
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun). Returns (rank, world)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def shard_pairs(num_pairs: int, rank: int, world: int) -> List[int]:
+    """Pair p -> rank p mod world (round robin)."""
+    return list(range(rank, num_pairs, world))
+
+
+def pairs_per_rank(num_pairs: int, world: int) -> int:
+    return (num_pairs + world - 1) // world
+
+
+def gather_poses(local_poses: torch.Tensor, local_aux: torch.Tensor, num_pairs: int, rank: int, world: int
+                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """All-gather the per-rank results and restore global pair order.
+
+    local_poses: [n_local, 4, 4] fp64, local_aux: [n_local] int64 (e.g. correspondence counts), for
+    the pairs of ``shard_pairs`` in order.  Returns ([num_pairs, 4, 4], [num_pairs]) on every rank.
+    """
+    cap = pairs_per_rank(num_pairs, world)
+    dev = local_poses.device
+    buf = torch.zeros((cap, 17), dtype=torch.float64, device=dev)
+    n_local = local_poses.shape[0]
+    if n_local:
+        buf[:n_local, :16] = local_poses.reshape(n_local, 16)
+        buf[:n_local, 16] = local_aux.to(torch.float64)
+    if world > 1:
+        out = torch.empty((world, cap, 17), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(out.view(world * cap, 17), buf)
+    else:
+        out = buf.unsqueeze(0)
+    poses = torch.empty((num_pairs, 4, 4), dtype=torch.float64, device=dev)
+    aux = torch.empty(num_pairs, dtype=torch.int64, device=dev)
+    for r in range(world):
+        ids = shard_pairs(num_pairs, r, world)
+        if ids:
+            idx = torch.tensor(ids, device=dev)
+            poses[idx] = out[r, :len(ids), :16].reshape(len(ids), 4, 4)
+            aux[idx] = out[r, :len(ids), 16].round().to(torch.int64)
+    return poses, aux
+
+
+def register_sharded(num_pairs: int, register_pair: Callable[[int], Tuple[torch.Tensor, torch.Tensor]],
+                     rank: int, world: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Run ``register_pair(p) -> (T[4,4] fp64, count int64[1])`` for this rank's pairs (enqueue
+    only, no host sync), then gather.  Config C4: 256 pairs over 8 GPUs."""
+    ids = shard_pairs(num_pairs, rank, world)
+    poses = torch.zeros((len(ids), 4, 4), dtype=torch.float64, device=device)
+    aux = torch.zeros(len(ids), dtype=torch.int64, device=device)
+    for j, p in enumerate(ids):
+        T, cnt = register_pair(p)
+        poses[j].copy_(T)
+        aux[j:j + 1].copy_(cnt.reshape(1))
+    return gather_poses(poses, aux, num_pairs, rank, world)
