@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--n", type=int, default=N_SCAN)
     ap.add_argument("--m", type=int, default=N_MAP)
     ap.add_argument("--iters", type=int, default=RANSAC_ITERS)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="2: RANSAC of pair i overlaps the matching of pair i+1 on a second HIP stream; 1: serial")
     args = ap.parse_args()
 
     import torch
@@ -114,14 +116,23 @@ def main():
     n, m, d = args.n, args.m, DIM
     # two resident scene pairs per rank, alternated; pair p uses seed 42 + p (global pair id)
     pairs = [synth.make_pair_device(n, m, d, seed=42 + rank * 2 + j, device=dev) for j in range(2)]
-    pipe = RegistrationPipeline(n, m, d, n_iter=args.iters, device=dev)
+    # --streams 2 (default): two-stage pipeline over independent scene pairs (BASELINE config C4:
+    # "one per stream"): the matching kernels of pair i+1 (matrix cores) run on the main stream while the
+    # RANSAC of pair i (fp64 vector ALU) runs on a second HIP stream.  Matching kernels never overlap
+    # each other, so the HIP-event duration of the coarse kernel stays a per-launch figure.
+    S = 2 if args.streams >= 2 else 1
+    pipe = RegistrationPipeline(n, m, d, n_iter=args.iters, device=dev, overlap_ransac=(S == 2))
 
     def step(i):
         p = pairs[i % 2]
         return pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"], want_mask=True)
 
     # untimed warm-up of the complete step, including the sharding / gather path
-    vdist.register_sharded(world * max(args.warmup, 1), lambda p: (lambda o: (o["T"], o["count"]))(step(p)), rank, world, dev)
+    for i in range(max(args.warmup, 1)):
+        step(i)
+    pipe.synchronize()
+    vdist.gather_poses(torch.zeros((1, 4, 4), dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev),
+                       world, rank, world)
     torch.cuda.synchronize()
 
     events = []
@@ -132,19 +143,29 @@ def main():
     num_pairs = world * args.steps  # global scene-pair ids; pair p runs on rank p mod world (weak scaling)
     local_i = [0]
 
+    res_T = torch.empty((args.steps, 4, 4), dtype=torch.float64, device=dev)
+    res_c = torch.empty((args.steps, 1), dtype=torch.int64, device=dev)
+
     def register_pair(p):
         i = local_i[0]
         local_i[0] += 1
         lib.vfm_prof_arm(events[i][0], events[i][1])
         out = step(i)
-        return out["T"], out["count"]
+        with torch.cuda.stream(out["result_stream"]):  # snapshot the result on the producing stream
+            res_T[i].copy_(out["T"])
+            res_c[i].copy_(out["count"])
+        return res_T[i], res_c[i]
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     # every rank registers its pairs (no data-path collective), then ONE all_gather of the poses
-    all_poses, all_counts = vdist.register_sharded(num_pairs, register_pair, rank, world, dev)
+    ids = vdist.shard_pairs(num_pairs, rank, world)
+    for p_id in ids:
+        register_pair(p_id)
+    pipe.synchronize()
+    all_poses, all_counts = vdist.gather_poses(res_T, res_c.reshape(-1), num_pairs, rank, world)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -162,6 +183,23 @@ def main():
         lib.vfm_prof_events_destroy(a, b)
     coarse_ms = sum(durs) / len(durs)
 
+    # the same kernel without the concurrent RANSAC stream (information only; not part of `value`)
+    iso = []
+    if S == 2:
+        pipe1 = RegistrationPipeline(n, m, d, n_iter=args.iters, device=dev, overlap_ransac=False)
+        a, b = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.vfm_prof_events_create(C.byref(a), C.byref(b)))
+        for i in range(6):
+            pr = pairs[i % 2]
+            lib.vfm_prof_arm(a, b)
+            pipe1.register(pr["q_desc"], pr["q_xyz"], pr["b_desc"], pr["b_xyz"])
+            _lib.check(lib.vfm_prof_elapsed_ms(a, b, C.byref(ms)))
+            if i:
+                iso.append(ms.value)
+        lib.vfm_prof_events_destroy(a, b)
+        del pipe1
+    iso_ms = (sum(iso) / len(iso)) if iso else coarse_ms
+
     # sanity of the timed work: every pose must recover the planted transform
     import numpy as np
     mine = vdist.shard_pairs(num_pairs, rank, world)
@@ -171,6 +209,10 @@ def main():
     if rank == 0:
         flops = 2.0 * n * m * d
         achieved = flops / (coarse_ms * 1e-3) / 1e12
+        traffic = None  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
+        pmc = ROOT / "profiles" / "r01_pmc_match_coarse.json"
+        if pmc.exists() and (n, m, d) == (N_SCAN, N_MAP, DIM):
+            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
         line = {
             "metric": "registrations/sec (20k<->200k pts, 384-D)", "value": world * args.steps / elapsed,
             "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -179,12 +221,16 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"C2: {n}-pt scan vs {m}-pt map, {d}-D descriptors precomputed and resident in "
                                    f"HBM, {args.iters} RANSAC iterations, cosine >= 0.8; map renormalised every step",
-                       "pairs_per_gpu": args.steps, "parallelism": f"{world} independent scene-pair shard(s)",
+                       "pairs_per_gpu": args.steps, "parallelism": f"{world} GPU shard(s) x {S} stream(s), independent scene pairs",
                        "correspondences_last_step": ncorr, "max_pose_err_vs_planted": max(errs)},
-            "roofline": {"bound": "mfma", "kernel": "match_coarse_kernel<24> (fp16 32x32x16 MFMA, fused top-2 epilogue)",
+            "roofline": {"bound": "mfma", "kernel": "match_coarse_kernel<24,1> (fp16 32x32x16 MFMA, fused top-2 epilogue)",
                          "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None,
-                         "flops_per_launch": flops, "avg_launch_ms": coarse_ms},
+                         "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_match_coarse.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
+                         "flops_per_launch": flops, "avg_launch_ms": coarse_ms,
+                         "single_stream": {"avg_launch_ms": iso_ms, "achieved": flops / (iso_ms * 1e-3) / 1e12,
+                                           "frac": flops / (iso_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                                           "note": "same kernel without the RANSAC of the previous pair running beside it"}},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(n, m, d, args.iters)

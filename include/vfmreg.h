@@ -183,6 +183,8 @@ int vfm_prof_events_create(void **start, void **stop);
 int vfm_prof_arm(void *start, void *stop);
 int vfm_prof_elapsed_ms(void *start, void *stop, float *ms_host);
 int vfm_prof_events_destroy(void *start, void *stop);
+/* tuning switch: coarse-kernel variant (0 default, 1 = 8 waves x 32 queries, 2 = 4 waves x 64) */
+int vfm_debug_set_coarse_variant(int qsets);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,19 @@
+"""Profiling driver: runs only the matching stage (prepare + coarse + select + rescore) of config C2
+a few times, so that rocprofv3 --pmc passes focus on match_coarse_kernel.
+    rocprofv3 --kernel-trace --pmc <counters> --output-format csv -d out -- python tools/prof_match.py"""
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "vfm-registration_amd"))
+import torch  # noqa: E402
+
+from vfmreg import ops, synth  # noqa: E402
+
+n, m, d = 20000, 200000, 384
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+p = synth.make_pair_device(n, m, d, seed=42)
+for _ in range(reps):
+    idx, sim = ops.match_ip_top1(p["q_desc"], p["b_desc"], ops.FAST)
+torch.cuda.synchronize()
+print("ok", int((idx == p["match"]).sum()))

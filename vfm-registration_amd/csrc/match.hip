@@ -32,7 +32,9 @@ constexpr int TILE_ROWS = 32;     // rows per fragment tile
 constexpr int CHUNK_ROWS = 128;   // map rows per partial record (4 tiles)
 constexpr int ROW_PAD = 256;      // prepared operands are padded to a multiple of this
 constexpr int QBLOCK = 256;       // queries per workgroup of the coarse kernel (8 waves x 32)
-constexpr int NBUF = 4;           // LDS ring depth (tiles)
+// LDS ring depth in tiles: a step consumes 2 tiles; 6 buffers = 2 steps in flight (d <= 384),
+// 4 buffers = 1 step in flight when a tile is 32 KiB (d = 512): 160 KiB of LDS per CU.
+constexpr int ring_depth(int ksteps) { return ksteps <= 24 ? 6 : 4; }
 constexpr int CAND_CAP = 12;      // candidate chunks kept per query before falling back
 constexpr float COARSE_OFFSET = 2.0f;   // accumulators start here: every coarse score is a
                                         // positive normal float, so uint order == float order
@@ -159,6 +161,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else static_assert(N < 0, "unsupported vmcnt");
 }
 
@@ -194,12 +197,20 @@ struct CoarseArgs {
     int nslices;         // map slices
 };
 
-template <int KSTEPS>
-__global__ __launch_bounds__(512, 2) void match_coarse_kernel(CoarseArgs a) {
+// QSETS = 32-query sets resident per wave: 1 -> 8 waves (2 per SIMD), 2 -> 4 waves (1 per SIMD,
+// every LDS fragment feeds two MFMAs: half the LDS read traffic / energy per flop).
+template <int KSTEPS, int QSETS>
+#ifdef VFM_COARSE_VGPR_CAP
+__attribute__((amdgpu_num_vgpr(VFM_COARSE_VGPR_CAP)))
+#endif
+__global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coarse_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NWAVES = 8 / QSETS;
     constexpr int TILE_U4 = KSTEPS * 64;
     constexpr int TILE_BYTES = TILE_U4 * 16;
-    constexpr int PASSES = KSTEPS / 8;  // 1 KiB pieces per wave per tile
+    constexpr int PASSES = KSTEPS / NWAVES;  // 1 KiB pieces per wave per tile
+    constexpr int NBUF = ring_depth(KSTEPS);
+    constexpr int AHEAD = NBUF / 2 - 1;  // steps of prefetch distance
     static_assert(KSTEPS % 8 == 0, "d must be a multiple of 128");
 
     const int lane = lane_id();
@@ -221,97 +232,135 @@ __global__ __launch_bounds__(512, 2) void match_coarse_kernel(CoarseArgs a) {
     const int ntiles = (c1 - c0) * 4;
     const int t0 = c0 * 4;
 
-    const int qt = qb * 8 + wave;
-    const bool q_ok = qt < a.nq_tiles;
+    const int qt0 = qb * 8 + wave * QSETS;  // first 32-query tile of this wave
 
     const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS unsigned char*)smem;
     auto stage = [&](int it_s) {
         const uint4* src = a.Bh + (size_t)(t0 + it_s) * TILE_U4;
-        const unsigned dst = lds_base + (unsigned)((it_s & (NBUF - 1)) * TILE_BYTES);
+        const unsigned dst = lds_base + (unsigned)((it_s % NBUF) * TILE_BYTES);
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int piece = p * 8 + wave;
+            const int piece = p * NWAVES + wave;
             glds16(src + piece * 64 + lane, __builtin_amdgcn_readfirstlane(dst + (unsigned)piece * 1024u));
         }
     };
 
     // query fragments stay in registers for the whole slice
-    half8 qf[KSTEPS];
-    {
-        const uint4* qsrc = a.Qh + (size_t)(q_ok ? qt : 0) * TILE_U4 + lane;
+    half8 qf[QSETS][KSTEPS];
+#pragma unroll
+    for (int j = 0; j < QSETS; ++j) {
+        const int qt = qt0 + j;
+        const uint4* qsrc = a.Qh + (size_t)(qt < a.nq_tiles ? qt : 0) * TILE_U4 + lane;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             uint4 v = qsrc[s * 64];
-            qf[s] = *reinterpret_cast<half8*>(&v);
+            qf[j][s] = *reinterpret_cast<half8*>(&v);
         }
     }
 #pragma unroll
-    for (int i = 0; i < NBUF - 1; ++i)
-        if (i < ntiles) stage(i);
+    for (int i = 0; i < 2 * AHEAD; ++i)
+        if (i < ntiles) stage(i);  // ntiles is a multiple of 4 (whole chunks)
 
-    unsigned s1 = 0u, s2 = 0u;
+    unsigned s1[QSETS], s2[QSETS];
+#pragma unroll
+    for (int j = 0; j < QSETS; ++j) s1[j] = s2[j] = 0u;
     const int hi = lane >> 5;
 
-    auto do_tile = [&](int it, auto TTc) {
+    // epilogue of one finished 32 x 32 accumulator tile: fold into the chunk's running top-2.
+    // Branch-free on purpose (3 VALU ops per element) so that the scheduler can issue it inside
+    // the next step's MFMA cluster.  Zero-padded map rows (score exactly 2.0) are NOT masked
+    // here: match_select_kernel ignores padded chunks for the maximum and rescans them exactly.
+    auto fold = [&](const floatx16& acc, int it, auto TTc, auto Jc) {
         constexpr int TT = decltype(TTc)::value;
-        const int rem = ntiles - 1 - it;
-        if (rem >= NBUF - 2) wait_vmcnt<PASSES*(NBUF - 2)>();
-        else if (rem == 1) wait_vmcnt<PASSES>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (it + NBUF - 1 < ntiles) stage(it + NBUF - 1);
-
-        const uint4* buf = reinterpret_cast<const uint4*>(smem + (it & (NBUF - 1)) * TILE_BYTES) + lane;
-        floatx16 acc;
+        constexpr int J = decltype(Jc)::value;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = COARSE_OFFSET;
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            uint4 v = buf[s * 64];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&v), qf[s], acc, 0, 0, 0);
-        }
-        const long long tile_row0 = (long long)(t0 + it) * TILE_ROWS;
-        if (tile_row0 + TILE_ROWS > a.m_valid) {
-            // padded map rows must never win: force their packed score to 0
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                unsigned pk = (__float_as_uint(acc[r]) & 0xFFFFFFC0u) | (unsigned)(63 - (TT * 16 + r));
-                if (tile_row0 + i >= a.m_valid) pk = 0u;
-                s2 = umed3(s1, s2, pk);
-                s1 = max(s1, pk);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                unsigned pk = (__float_as_uint(acc[r]) & 0xFFFFFFC0u) | (unsigned)(63 - (TT * 16 + r));
-                s2 = umed3(s1, s2, pk);
-                s1 = max(s1, pk);
-            }
+        for (int r = 0; r < 16; ++r) {
+            const unsigned pk = (__float_as_uint(acc[r]) & 0xFFFFFFC0u) | (unsigned)(63 - (TT * 16 + r));
+            s2[J] = umed3(s1[J], s2[J], pk);
+            s1[J] = max(s1[J], pk);
         }
         if constexpr (TT == 3) {
-            const unsigned o1 = __shfl_xor(s1, 32), o2 = __shfl_xor(s2, 32);
-            const bool own = (s1 > o1) || (s1 == o1 && hi == 0);
-            const unsigned w1 = own ? s1 : o1;
+            const unsigned o1 = __shfl_xor(s1[J], 32), o2 = __shfl_xor(s2[J], 32);
+            const bool own = (s1[J] > o1) || (s1[J] == o1 && hi == 0);
+            const unsigned w1 = own ? s1[J] : o1;
             const int wh = own ? hi : (1 - hi);
-            const unsigned w2 = max(max(s2, o2), min(s1, o1));
+            const unsigned w2 = max(max(s2[J], o2), min(s1[J], o1));
             const int code = 63 - (int)(w1 & 63u);
             const int li = (code >> 4) * 32 + (code & 3) + 8 * ((code & 15) >> 2) + 4 * wh;
-            if (lane < 32 && q_ok) {
+            const int qt = qt0 + J;
+            if (lane < 32 && qt < a.nq_tiles && it >= 0) {  // it < 0: the dummy fold of the very first step
                 const int chunk = c0 + (it >> 2);
                 a.partials[(size_t)chunk * a.npad + (size_t)qt * 32 + lane] = make_uint2((w1 & ~127u) | (unsigned)li, w2);
             }
-            s1 = 0u;
-            s2 = 0u;
+            s1[J] = 0u;
+            s2[J] = 0u;
+        }
+    };
+
+    // one step = 2 map tiles (64 rows): 2 * QSETS independent accumulator chains per wave, one
+    // barrier.  The top-2 fold of step i-1 (VALU) is issued inside the MFMA cluster of step i
+    // (matrix pipe), so the two pipes overlap within a wave instead of alternating in lockstep.
+    floatx16 prev[QSETS][2];
+#pragma unroll
+    for (int j = 0; j < QSETS; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            prev[j][0][r] = 0.f;
+            prev[j][1][r] = 0.f;
+        }
+    auto do_step = [&](int it, auto Hc) {
+        constexpr int H = decltype(Hc)::value;  // which half of the 4-tile chunk
+        // tiles it, it+1 must have landed; the (AHEAD-1) newer steps may stay in flight
+        if (AHEAD >= 2 && it + 2 < ntiles) wait_vmcnt<2 * PASSES>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + 2 * AHEAD < ntiles) {
+            stage(it + 2 * AHEAD);
+            stage(it + 2 * AHEAD + 1);
+        }
+        const uint4* buf0 = reinterpret_cast<const uint4*>(smem + (it % NBUF) * TILE_BYTES) + lane;
+        const uint4* buf1 = reinterpret_cast<const uint4*>(smem + ((it + 1) % NBUF) * TILE_BYTES) + lane;
+        floatx16 acc[QSETS][2];
+#pragma unroll
+        for (int j = 0; j < QSETS; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[j][0][r] = COARSE_OFFSET;
+                acc[j][1][r] = COARSE_OFFSET;
+            }
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            uint4 v0 = buf0[s * 64], v1 = buf1[s * 64];
+#pragma unroll
+            for (int j = 0; j < QSETS; ++j) {
+                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&v0), qf[j][s], acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&v1), qf[j][s], acc[j][1], 0, 0, 0);
+            }
+        }
+        // previous step = the other half (of this chunk for H == 1, of the previous chunk for H == 0);
+        // at it == 0 this folds the zero-initialised dummies (tiny packed values, store suppressed)
+        fold(prev[0][0], it - 2, std::integral_constant<int, 2 * (1 - H)>{}, std::integral_constant<int, 0>{});
+        fold(prev[0][1], it - 1, std::integral_constant<int, 2 * (1 - H) + 1>{}, std::integral_constant<int, 0>{});
+        if constexpr (QSETS == 2) {
+            fold(prev[1][0], it - 2, std::integral_constant<int, 2 * (1 - H)>{}, std::integral_constant<int, 1>{});
+            fold(prev[1][1], it - 1, std::integral_constant<int, 2 * (1 - H) + 1>{}, std::integral_constant<int, 1>{});
+        }
+#pragma unroll
+        for (int j = 0; j < QSETS; ++j) {
+            prev[j][0] = acc[j][0];
+            prev[j][1] = acc[j][1];
         }
     };
 
     for (int it = 0; it < ntiles; it += 4) {
-        do_tile(it + 0, std::integral_constant<int, 0>{});
-        do_tile(it + 1, std::integral_constant<int, 1>{});
-        do_tile(it + 2, std::integral_constant<int, 2>{});
-        do_tile(it + 3, std::integral_constant<int, 3>{});
+        do_step(it, std::integral_constant<int, 0>{});
+        do_step(it + 2, std::integral_constant<int, 1>{});
+    }
+    fold(prev[0][0], ntiles - 2, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+    fold(prev[0][1], ntiles - 1, std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
+    if constexpr (QSETS == 2) {
+        fold(prev[1][0], ntiles - 2, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+        fold(prev[1][1], ntiles - 1, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
     }
 }
 
@@ -320,7 +369,8 @@ __global__ __launch_bounds__(512, 2) void match_coarse_kernel(CoarseArgs a) {
 // cand entry: (chunk << 8) | (rescan << 7) | local row
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void match_select_kernel(const uint2* __restrict__ partials, int nchunks, int npad,
-                                                           int64_t n, const float* __restrict__ invq, float window,
+                                                           int64_t n, int first_pad_chunk,
+                                                           const float* __restrict__ invq, float window,
                                                            int* __restrict__ cand_cnt,
                                                            unsigned* __restrict__ cand, int* __restrict__ fb_count,
                                                            int* __restrict__ fb_list) {
@@ -329,8 +379,10 @@ __global__ __launch_bounds__(256) void match_select_kernel(const uint2* __restri
     __shared__ unsigned lcand[64][CAND_CAP];
     const int qq = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * 64 + qq;
+    // chunks >= first_pad_chunk contain zero-padded map rows whose coarse score (exactly 2.0) is
+    // meaningless: they do not take part in the maximum and are always rescanned exactly.
     unsigned m = 0u;
-    for (int c = g; c < nchunks; c += 4) m = max(m, partials[(size_t)c * npad + q].x);
+    for (int c = g; c < first_pad_chunk; c += 4) m = max(m, partials[(size_t)c * npad + q].x);
     smax[g][qq] = m;
     if (g == 0) lcnt[qq] = 0;
     __syncthreads();
@@ -343,7 +395,7 @@ __global__ __launch_bounds__(256) void match_select_kernel(const uint2* __restri
         if ((rec.x | 127u) >= thr) {
             const int slot = atomicAdd(&lcnt[qq], 1);
             if (slot < CAND_CAP) {
-                const unsigned rescan = ((rec.y | 63u) >= thr) ? 1u : 0u;
+                const unsigned rescan = (((rec.y | 63u) >= thr) || c >= first_pad_chunk) ? 1u : 0u;
                 lcand[qq][slot] = ((unsigned)c << 8) | (rescan << 7) | (rec.x & 127u);
             }
         }
@@ -655,17 +707,31 @@ inline int choose_slices(int nqb, int nchunks) {
 // profiling hook (vfm_prof_arm): events recorded around the next coarse launch on this thread
 thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 
-template <int KSTEPS>
-int launch_coarse(const CoarseArgs& a, hipStream_t st) {
-    const int lds = NBUF * KSTEPS * 1024;
+int g_coarse_qsets = 0;  // 0 = default per d; set through vfm_debug_set_coarse_variant for A/B runs
+
+template <int KSTEPS, int QSETS>
+int launch_coarse_v(const CoarseArgs& a, hipStream_t st) {
+    const int lds = ring_depth(KSTEPS) * KSTEPS * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_kernel<KSTEPS>),
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_kernel<KSTEPS, QSETS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
+    hipLaunchKernelGGL((match_coarse_kernel<KSTEPS, QSETS>), dim3(a.nqb * a.nslices), dim3(512 / QSETS), lds, st, a);
+    return VFM_OK;
+}
+
+template <int KSTEPS>
+int launch_coarse(const CoarseArgs& a, hipStream_t st) {
     if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
-    hipLaunchKernelGGL(match_coarse_kernel<KSTEPS>, dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
+    int rc;
+    if constexpr (KSTEPS <= 24) {
+        rc = (g_coarse_qsets == 2) ? launch_coarse_v<KSTEPS, 2>(a, st) : launch_coarse_v<KSTEPS, 1>(a, st);
+    } else {
+        rc = launch_coarse_v<KSTEPS, 1>(a, st);  // d = 512: 2 x 128 query VGPRs would not fit
+    }
+    if (rc) return rc;
     VFM_CHECK_LAUNCH("match_coarse_kernel");
     if (g_prof_stop) VFM_CHECK_HIP(hipEventRecord(g_prof_stop, st));
     g_prof_start = g_prof_stop = nullptr;
@@ -708,7 +774,7 @@ int do_search(const float* q, const void* qprep, int64_t n, const float* b, cons
     }
     if (rc) return rc;
     hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, w.partials, a.nchunks,
-                       a.npad, n, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.fb_count, w.fb_list);
+                       a.npad, n, (int)(m / CHUNK_ROWS), Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.fb_count, w.fb_list);
     VFM_CHECK_LAUNCH("match_select_kernel");
     hipLaunchKernelGGL(match_rescore_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)d * 4 * 4, st, q, Q.inv, b,
                        B.inv, n, m, d, w.cand_cnt, w.cand, idx_out, sim_out);
@@ -842,6 +908,12 @@ VFM_EXPORT int vfm_match_mutual_l2(const float* a, int64_t n, const float* b, in
 // profiling hooks: HIP events around the dominant kernel (match_coarse_kernel), on the stream the
 // kernel is launched on.  Used by bench.py for roofline.achieved.
 // ---------------------------------------------------------------------------------------------
+// A/B switch for the coarse kernel variant (1 = 8 waves x 32 queries, 2 = 4 waves x 64 queries, 0 = default)
+VFM_EXPORT int vfm_debug_set_coarse_variant(int qsets) {
+    g_coarse_qsets = qsets;
+    return VFM_OK;
+}
+
 VFM_EXPORT int vfm_prof_events_create(void** start, void** stop) {
     VFM_CHECK_ARG(start && stop, "prof: null pointer");
     hipEvent_t a, b;

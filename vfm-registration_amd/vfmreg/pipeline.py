@@ -1,13 +1,19 @@
 """Device-resident registration pipeline: the hot path of
-RegistrationNode.ransac_registration('vfm') (registration_node.py:273-328) as one stream of HIP
-kernels with no host synchronisation:
+RegistrationNode.ransac_registration('vfm') (registration_node.py:273-328) as HIP kernels with no
+host synchronisation:
 
     normalise + fp16 fragment tiles (VoxelHashMap.cpp:469-482)
  -> top-1 inner-product search        (VoxelHashMap.cpp:486-495)
  -> cosine threshold + compaction      (VoxelHashMap.cpp:501-511, 587-600)
  -> correspondence RANSAC + Kabsch     (registration_node.py:319-327)
 
-Buffers are allocated once for fixed (N, M, D); `register` only enqueues work.
+Buffers are allocated once for fixed (N, M, D); ``register`` only enqueues work.
+
+``overlap_ransac=True`` turns the chain into a two-stage pipeline over independent scene pairs: the
+matching kernels of pair i+1 (matrix cores) run on the caller's stream while the RANSAC of pair i
+(fp64 vector ALU) runs on a second HIP stream; events order the hand-off and two result sets
+ping-pong, so results of pair i stay valid until pair i+2 is enqueued.  Matching kernels never
+overlap each other.
 """
 from __future__ import annotations
 
@@ -18,19 +24,8 @@ import torch
 from . import _lib, ops
 
 
-class RegistrationPipeline:
-    def __init__(self, n: int, m: int, d: int = 384, n_iter: int = 50000, min_cosine: float = 0.8,
-                 max_corr_dist: float = 10000.0, seed: int = 42, device="cuda"):
-        lib = _lib.load()
-        self.n, self.m, self.d = n, m, d
-        self.n_iter, self.min_cosine, self.max_corr_dist, self.seed = n_iter, min_cosine, max_corr_dist, seed
-        self.device = torch.device(device)
-        dev = self.device
-        u8 = torch.uint8
-        self.qprep = torch.empty(lib.vfm_match_prepared_bytes(n, d), dtype=u8, device=dev)
-        self.bprep = torch.empty(lib.vfm_match_prepared_bytes(m, d), dtype=u8, device=dev)
-        self.sws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=u8, device=dev)
-        self.rws = torch.empty(lib.vfm_ransac_workspace_bytes(n, n_iter), dtype=u8, device=dev)
+class _ResultSet:
+    def __init__(self, n: int, dev):
         self.idx = torch.empty(n, dtype=torch.int64, device=dev)
         self.sim = torch.empty(n, dtype=torch.float32, device=dev)
         self.keep = torch.empty(n, dtype=torch.int64, device=dev)
@@ -41,6 +36,26 @@ class RegistrationPipeline:
         self.rmse = torch.empty(1, dtype=torch.float64, device=dev)
         self.best_hyp = torch.empty(1, dtype=torch.int32, device=dev)
         self.mask = torch.empty(n, dtype=torch.uint8, device=dev)
+        self.done: Optional[torch.cuda.Event] = None  # RANSAC of the pair that used this set finished
+
+
+class RegistrationPipeline:
+    def __init__(self, n: int, m: int, d: int = 384, n_iter: int = 50000, min_cosine: float = 0.8,
+                 max_corr_dist: float = 10000.0, seed: int = 42, device="cuda", overlap_ransac: bool = False):
+        lib = _lib.load()
+        self.n, self.m, self.d = n, m, d
+        self.n_iter, self.min_cosine, self.max_corr_dist, self.seed = n_iter, min_cosine, max_corr_dist, seed
+        self.device = torch.device(device)
+        dev = self.device
+        u8 = torch.uint8
+        self.qprep = torch.empty(lib.vfm_match_prepared_bytes(n, d), dtype=u8, device=dev)
+        self.bprep = torch.empty(lib.vfm_match_prepared_bytes(m, d), dtype=u8, device=dev)
+        self.sws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=u8, device=dev)
+        self.rws = torch.empty(lib.vfm_ransac_workspace_bytes(n, n_iter), dtype=u8, device=dev)
+        self.overlap = bool(overlap_ransac)
+        self.sets = [_ResultSet(n, dev) for _ in range(2 if self.overlap else 1)]
+        self.ransac_stream = torch.cuda.Stream(device=dev) if self.overlap else None
+        self._step = 0
         self._map_key: Optional[int] = None
 
     def prepare_map(self, b_desc: torch.Tensor) -> None:
@@ -51,29 +66,49 @@ class RegistrationPipeline:
                    "prepare(map)")
         self._map_key = b_desc.data_ptr()
 
+    def synchronize(self) -> None:
+        """Make the caller's current stream wait for every RANSAC issued on the side stream."""
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self.ransac_stream)
+
     def register(self, q_desc: torch.Tensor, q_xyz: torch.Tensor, b_desc: torch.Tensor, b_xyz: torch.Tensor,
                  reuse_map: bool = False, want_mask: bool = True):
         lib = _lib.load()
-        st = ops._stream()
         ops._chk(q_desc, torch.float32, "q_desc")
         ops._chk(b_desc, torch.float32, "b_desc")
         ops._chk(q_xyz, torch.float64, "q_xyz")
         ops._chk(b_xyz, torch.float64, "b_xyz")
         if q_desc.shape != (self.n, self.d) or b_desc.shape != (self.m, self.d):
             raise ValueError("Invalid shape")
+        r = self.sets[self._step % len(self.sets)]
+        self._step += 1
+        main = torch.cuda.current_stream()
+        st = main.cuda_stream
+        if self.overlap and r.done is not None:
+            main.wait_event(r.done)  # the RANSAC that last read this set has finished
         if not (reuse_map and self._map_key == b_desc.data_ptr()):
             self.prepare_map(b_desc)
         _lib.check(lib.vfm_match_prepare(q_desc.data_ptr(), self.n, self.d, self.qprep.data_ptr(), st), "prepare(scan)")
         _lib.check(lib.vfm_match_search_prepared(q_desc.data_ptr(), self.qprep.data_ptr(), self.n, b_desc.data_ptr(),
-                                                 self.bprep.data_ptr(), self.m, self.d, self.idx.data_ptr(),
-                                                 self.sim.data_ptr(), self.sws.data_ptr(), self.sws.numel(), st), "search")
-        _lib.check(lib.vfm_threshold_compact(self.sim.data_ptr(), self.idx.data_ptr(), self.n, float(self.min_cosine),
-                                             self.keep.data_ptr(), self.count.data_ptr(), self.corres.data_ptr(),
+                                                 self.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(),
+                                                 r.sim.data_ptr(), self.sws.data_ptr(), self.sws.numel(), st), "search")
+        _lib.check(lib.vfm_threshold_compact(r.sim.data_ptr(), r.idx.data_ptr(), self.n, float(self.min_cosine),
+                                             r.keep.data_ptr(), r.count.data_ptr(), r.corres.data_ptr(),
                                              None, None, None, None, st), "threshold_compact")
-        _lib.check(lib.vfm_ransac_corr(q_xyz.data_ptr(), b_xyz.data_ptr(), self.corres.data_ptr(), self.count.data_ptr(),
+        rst = st
+        if self.overlap:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.ransac_stream.wait_event(ev)
+            rst = self.ransac_stream.cuda_stream
+        _lib.check(lib.vfm_ransac_corr(q_xyz.data_ptr(), b_xyz.data_ptr(), r.corres.data_ptr(), r.count.data_ptr(),
                                        self.n, float(self.max_corr_dist), int(self.n_iter), int(self.seed),
-                                       self.T.data_ptr(), self.fitness.data_ptr(), self.rmse.data_ptr(),
-                                       self.mask.data_ptr() if want_mask else None, self.best_hyp.data_ptr(),
-                                       self.rws.data_ptr(), self.rws.numel(), st), "ransac")
-        return dict(T=self.T, fitness=self.fitness, rmse=self.rmse, best_hyp=self.best_hyp, mask=self.mask,
-                    idx=self.idx, sim=self.sim, keep=self.keep, count=self.count, corres=self.corres)
+                                       r.T.data_ptr(), r.fitness.data_ptr(), r.rmse.data_ptr(),
+                                       r.mask.data_ptr() if want_mask else None, r.best_hyp.data_ptr(),
+                                       self.rws.data_ptr(), self.rws.numel(), rst), "ransac")
+        if self.overlap:
+            r.done = torch.cuda.Event()
+            r.done.record(self.ransac_stream)
+        return dict(T=r.T, fitness=r.fitness, rmse=r.rmse, best_hyp=r.best_hyp, mask=r.mask, idx=r.idx, sim=r.sim,
+                    keep=r.keep, count=r.count, corres=r.corres, done=r.done,
+                    result_stream=self.ransac_stream if self.overlap else main)
