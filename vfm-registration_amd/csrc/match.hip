@@ -195,6 +195,8 @@ struct CoarseArgs {
     int npad;            // padded query count (row stride of partials)
     int nqb;             // query blocks (256 queries)
     int nslices;         // map slices
+    unsigned* qmax;      // [npad] running coarse maximum per query (value bits only), zeroed per search
+    int first_pad_chunk; // chunks >= this contain zero-padded map rows: excluded from qmax
 };
 
 // QSETS = 32-query sets resident per wave: 1 -> 8 waves (2 per SIMD), 2 -> 4 waves (1 per SIMD,
@@ -261,9 +263,9 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
     for (int i = 0; i < 2 * AHEAD; ++i)
         if (i < ntiles) stage(i);  // ntiles is a multiple of 4 (whole chunks)
 
-    unsigned s1[QSETS], s2[QSETS];
+    unsigned s1[QSETS], s2[QSETS], runmax[QSETS];
 #pragma unroll
-    for (int j = 0; j < QSETS; ++j) s1[j] = s2[j] = 0u;
+    for (int j = 0; j < QSETS; ++j) s1[j] = s2[j] = runmax[j] = 0u;
     const int hi = lane >> 5;
 
     // epilogue of one finished 32 x 32 accumulator tile: fold into the chunk's running top-2.
@@ -291,6 +293,7 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
             if (lane < 32 && qt < a.nq_tiles && it >= 0) {  // it < 0: the dummy fold of the very first step
                 const int chunk = c0 + (it >> 2);
                 a.partials[(size_t)chunk * a.npad + (size_t)qt * 32 + lane] = make_uint2((w1 & ~127u) | (unsigned)li, w2);
+                if (chunk < a.first_pad_chunk) runmax[J] = max(runmax[J], w1 & ~127u);
             }
             s1[J] = 0u;
             s2[J] = 0u;
@@ -362,6 +365,10 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
         fold(prev[1][0], ntiles - 2, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
         fold(prev[1][1], ntiles - 1, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
     }
+    // one atomic per (query, slice): the per-query coarse maximum match_select_kernel thresholds on
+#pragma unroll
+    for (int j = 0; j < QSETS; ++j)
+        if (lane < 32 && qt0 + j < a.nq_tiles) atomicMax(a.qmax + (size_t)(qt0 + j) * 32 + lane, runmax[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -370,33 +377,40 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void match_select_kernel(const uint2* __restrict__ partials, int nchunks, int npad,
                                                            int64_t n, int first_pad_chunk,
+                                                           const unsigned* __restrict__ qmax,
                                                            const float* __restrict__ invq, float window,
                                                            int* __restrict__ cand_cnt,
                                                            unsigned* __restrict__ cand, int* __restrict__ fb_count,
                                                            int* __restrict__ fb_list) {
-    __shared__ unsigned smax[4][64];
     __shared__ int lcnt[64];
     __shared__ unsigned lcand[64][CAND_CAP];
     const int qq = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * 64 + qq;
-    // chunks >= first_pad_chunk contain zero-padded map rows whose coarse score (exactly 2.0) is
-    // meaningless: they do not take part in the maximum and are always rescanned exactly.
-    unsigned m = 0u;
-    for (int c = g; c < first_pad_chunk; c += 4) m = max(m, partials[(size_t)c * npad + q].x);
-    smax[g][qq] = m;
     if (g == 0) lcnt[qq] = 0;
     __syncthreads();
-    m = max(max(smax[0][qq], smax[1][qq]), max(smax[2][qq], smax[3][qq]));
-    // the record's low 7 bits hold the row: compare on the value bits only
-    const float thr_f = __uint_as_float(m & ~127u) - window;
+    // qmax = best coarse score over the un-padded chunks (value bits; accumulated by the coarse
+    // kernel).  Chunks >= first_pad_chunk contain zero-padded map rows whose coarse score (exactly
+    // 2.0) is meaningless: they do not take part in the maximum and are always rescanned exactly.
+    const unsigned m = qmax[q];
+    const float thr_f = __uint_as_float(m) - window;
     const unsigned thr = __float_as_uint(thr_f) & ~127u;
-    for (int c = g; c < nchunks; c += 4) {
-        const uint2 rec = partials[(size_t)c * npad + q];
-        if ((rec.x | 127u) >= thr) {
-            const int slot = atomicAdd(&lcnt[qq], 1);
-            if (slot < CAND_CAP) {
-                const unsigned rescan = (((rec.y | 63u) >= thr) || c >= first_pad_chunk) ? 1u : 0u;
-                lcand[qq][slot] = ((unsigned)c << 8) | (rescan << 7) | (rec.x & 127u);
+    // HBM-bound sweep over this query's records: 8 independent loads in flight per thread
+    for (int cb = g; cb < nchunks; cb += 32) {
+        uint2 rec[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = cb + 4 * u;
+            rec[u] = (c < nchunks) ? partials[(size_t)c * npad + q] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = cb + 4 * u;
+            if (c < nchunks && (rec[u].x | 127u) >= thr) {
+                const int slot = atomicAdd(&lcnt[qq], 1);
+                if (slot < CAND_CAP) {
+                    const unsigned rescan = (((rec[u].y | 63u) >= thr) || c >= first_pad_chunk) ? 1u : 0u;
+                    lcand[qq][slot] = ((unsigned)c << 8) | (rescan << 7) | (rec[u].x & 127u);
+                }
             }
         }
     }
@@ -450,12 +464,11 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restr
                                                             int64_t* __restrict__ idx_out, float* __restrict__ sim_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    float* qn = reinterpret_cast<float*>(smem) + wave * d;
+    float* qn = reinterpret_cast<float*>(smem) + wave * 2 * d;  // normalised query row
+    float* bn = qn + d;                                          // normalised candidate row
     const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
     if (qi >= n) return;
     const float iq = invq[qi];
-    for (int k = lane; k < d; k += 64) qn[k] = q[qi * (int64_t)d + k] * iq;
-    __builtin_amdgcn_wave_barrier();
     if (iq == 0.0f) {  // zero query: every score is 0.0, the lowest index wins
         if (lane == 0) {
             idx_out[qi] = (m > 0) ? 0 : -1;
@@ -465,12 +478,19 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restr
     }
     const int cnt = cand_cnt[qi];
     if (cnt < 0) return;  // handled by match_exact_kernel
+    for (int k = lane * 4; k < d; k += 256) {
+        float4 v = *reinterpret_cast<const float4*>(q + qi * (int64_t)d + k);
+        v.x = v.x * iq; v.y = v.y * iq; v.z = v.z * iq; v.w = v.w * iq;
+        *reinterpret_cast<float4*>(qn + k) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
     double best = 0.0;
     long long bj = -1;
     for (int e = 0; e < cnt; ++e) {
         const unsigned ce = cand[(size_t)qi * CAND_CAP + e];
         const long long base = (long long)(ce >> 8) * CHUNK_ROWS;
         if (ce & 128u) {
+            // whole chunk: every lane scores its own rows (rare)
             for (int li = lane; li < CHUNK_ROWS; li += 64) {
                 const long long j = base + li;
                 if (j < m) {
@@ -481,12 +501,30 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restr
                     }
                 }
             }
-        } else if (lane == (e & 63)) {
+        } else {
+            // single row: the wave fetches it coalesced, every lane then runs the same sequential
+            // fp64 sum from LDS (broadcast reads) -- identical result in all lanes
             const long long j = base + (ce & 127u);
             if (j < m) {
-                const double s = dot_norm_f64(qn, b + j * (int64_t)d, invb[j], d);
-                if (bj < 0 || s > best || (s == best && j < bj)) {
-                    best = s;
+                const float ib = invb[j];
+                __builtin_amdgcn_wave_barrier();
+                for (int k = lane * 4; k < d; k += 256) {
+                    float4 v = *reinterpret_cast<const float4*>(b + j * (int64_t)d + k);
+                    v.x = v.x * ib; v.y = v.y * ib; v.z = v.z * ib; v.w = v.w * ib;
+                    *reinterpret_cast<float4*>(bn + k) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                double acc = 0.0;
+                for (int k = 0; k < d; k += 4) {
+                    const float4 qa = *reinterpret_cast<const float4*>(qn + k);
+                    const float4 bb = *reinterpret_cast<const float4*>(bn + k);
+                    acc = acc + (double)qa.x * (double)bb.x;
+                    acc = acc + (double)qa.y * (double)bb.y;
+                    acc = acc + (double)qa.z * (double)bb.z;
+                    acc = acc + (double)qa.w * (double)bb.w;
+                }
+                if (bj < 0 || acc > best || (acc == best && j < bj)) {
+                    best = acc;
                     bj = j;
                 }
             }
@@ -670,6 +708,7 @@ struct SearchWs {
     unsigned* cand;
     int* fb_count;
     int* fb_list;
+    unsigned* qmax;
     size_t bytes;
 };
 
@@ -682,6 +721,7 @@ inline SearchWs carve_search(void* p, int64_t n, int64_t m) {
     w.cand = c.take<unsigned>((size_t)npad * CAND_CAP);
     w.fb_count = c.take<int>(64);
     w.fb_list = c.take<int>((size_t)npad);
+    w.qmax = c.take<unsigned>((size_t)npad);
     w.bytes = c.used();
     return w;
 }
@@ -763,7 +803,10 @@ int do_search(const float* q, const void* qprep, int64_t n, const float* b, cons
     a.npad = (int)npad;
     a.nqb = (int)(npad / QBLOCK);
     a.nslices = choose_slices(a.nqb, a.nchunks);
+    a.qmax = w.qmax;
+    a.first_pad_chunk = (int)(m / CHUNK_ROWS);
     VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, sizeof(int), st));
+    VFM_CHECK_HIP(hipMemsetAsync(w.qmax, 0, (size_t)npad * sizeof(unsigned), st));
     int rc;
     switch (d / 16) {
         case 8: rc = launch_coarse<8>(a, st); break;
@@ -774,9 +817,9 @@ int do_search(const float* q, const void* qprep, int64_t n, const float* b, cons
     }
     if (rc) return rc;
     hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, w.partials, a.nchunks,
-                       a.npad, n, (int)(m / CHUNK_ROWS), Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.fb_count, w.fb_list);
+                       a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.fb_count, w.fb_list);
     VFM_CHECK_LAUNCH("match_select_kernel");
-    hipLaunchKernelGGL(match_rescore_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)d * 4 * 4, st, q, Q.inv, b,
+    hipLaunchKernelGGL(match_rescore_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)d * 4 * 8, st, q, Q.inv, b,
                        B.inv, n, m, d, w.cand_cnt, w.cand, idx_out, sim_out);
     VFM_CHECK_LAUNCH("match_rescore_kernel");
     hipLaunchKernelGGL(match_exact_kernel, dim3(256), dim3(256), (((size_t)d * 4 + 15) & ~(size_t)15) + 64, st, q, Q.inv,
