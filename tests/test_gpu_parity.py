@@ -72,6 +72,17 @@ def test_match_fast_equals_oracle(ops, orc, n, m, d):
     assert (idx[inl] == p["match"][inl]).mean() > 0.99  # planted matches are found
 
 
+@pytest.mark.parametrize("n,m", [(1, 1), (1, 50), (5, 127), (64, 128), (3, 129), (300, 255), (31, 257)])
+def test_match_fast_tiny_and_ragged_sizes(ops, orc, n, m):
+    """maps smaller than one 128-row chunk (everything is padding), single rows, off-by-one sizes"""
+    rng = np.random.default_rng(n * 1000 + m)
+    q = rng.standard_normal((n, 384)).astype(np.float32)
+    b = rng.standard_normal((m, 384)).astype(np.float32)
+    _check_match(ops, orc, q, b, ops.FAST)
+    _check_match(ops, orc, q, -np.abs(b), ops.FAST)   # all-negative scores vs the 2.0 of padded rows
+    _check_match(ops, orc, q, b, ops.EXACT)
+
+
 def test_match_fast_edge_cases(ops, orc):
     """zero rows (points seen by no camera), exact duplicates (ties -> lowest index), near ties
     inside the fp16 error window, negative-only scores, padding rows must never win."""

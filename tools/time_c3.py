@@ -1,0 +1,60 @@
+"""Timing of the C3 feature stages on one MI355X: ViT-S/14 on 6 x 1200x1600, 6-camera projection +
+fused lifting of 20k points.  Prints per-stage milliseconds (HIP events, median of 10)."""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "vfm-registration_amd"))
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402
+
+from vfmreg import ops  # noqa: E402
+from vfmreg import vit as V  # noqa: E402
+
+
+def timed(fn, reps=10):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    return sorted(ts)[len(ts) // 2]
+
+
+rng = np.random.default_rng(0)
+B, H, W, n = 6, 1200, 1600, 20000
+imgs = torch.from_numpy(rng.integers(1, 255, (B, H, W, 3), dtype=np.uint8)).cuda()
+model = V.ViTS14(V.random_weights(0), H, W)
+grids = model.forward(imgs)
+t_vit = timed(lambda: model.forward(imgs))
+xyz = np.c_[rng.uniform(-40, 40, n), rng.uniform(-40, 40, n), rng.uniform(-2, 6, n)]
+pcl = torch.from_numpy(np.ascontiguousarray(np.insert(xyz, 3, 1, axis=1).T)).cuda()
+K = np.array([[800.0, 0, 800], [0, 800, 600], [0, 0, 1]])
+Ps = []
+for i in range(6):
+    y = np.deg2rad(60 * i)
+    R = np.stack([[np.sin(y), -np.cos(y), 0], [0, 0, -1], [np.cos(y), np.sin(y), 0]])
+    Ps.append(K @ np.c_[R, np.zeros(3)])
+desc = torch.zeros((n, 384), dtype=torch.float32, device="cuda")
+filled = torch.zeros(n, dtype=torch.uint8, device="cuda")
+
+
+def lift():
+    desc.zero_()
+    filled.zero_()
+    for c in range(6):
+        u, v, idx, cnt = ops.project_pinhole(ops.PROJ_KITTI, pcl, [Ps[c]], None, 1.0, None, None, H, W)
+        ops.gather_bilinear(grids[c], H, W, 0, imgs[c], u, v, idx, cnt, desc, filled)
+
+
+t_lift = timed(lift)
+flops = 6 * 16.6e9
+print(f"ViT-S/14 6x{H}x{W}: {t_vit:.3f} ms ({flops / t_vit / 1e9:.1f} TFLOP/s of ~1e11 FLOP)")
+print(f"projection + lifting, 6 cameras x {n} points: {t_lift:.3f} ms; lifted {int(filled.sum())} points")

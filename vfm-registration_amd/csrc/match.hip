@@ -392,8 +392,9 @@ __global__ __launch_bounds__(256) void match_select_kernel(const uint2* __restri
     // kernel).  Chunks >= first_pad_chunk contain zero-padded map rows whose coarse score (exactly
     // 2.0) is meaningless: they do not take part in the maximum and are always rescanned exactly.
     const unsigned m = qmax[q];
+    // m == 0: no un-padded chunk exists (map smaller than one chunk) -> every chunk is a candidate
     const float thr_f = __uint_as_float(m) - window;
-    const unsigned thr = __float_as_uint(thr_f) & ~127u;
+    const unsigned thr = (m == 0u) ? 0u : (__float_as_uint(thr_f) & ~127u);
     // HBM-bound sweep over this query's records: 8 independent loads in flight per thread
     for (int cb = g; cb < nchunks; cb += 32) {
         uint2 rec[8];
