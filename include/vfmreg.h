@@ -146,6 +146,22 @@ int vfm_gather_bilinear_patchgrid(const float *grid, int gh, int gw, int C, int 
 int vfm_transform_xyz_f64(const double *xyz, int64_t n, const double *T, double *out,
                           vfm_stream_t stream);
 
+/* ------------------------------------------------------------------ ICP refinement (row F2) */
+
+/* VoxelHashMap::GetCorrespondences (src/kiss-icp/cpp/kiss_icp/core/VoxelHashMap.cpp:76-168): for
+ * each source point the nearest map point among the 27 voxels around it, valid iff its distance
+ * is < max_dist.  The map is a sorted-key CSR: keys[n_voxels] ascending
+ * (key = ((vx+2^20)<<42)|((vy+2^20)<<21)|(vz+2^20), v = trunc(xyz / voxel_size)),
+ * start[n_voxels+1], pts[start[n_voxels]][3] fp64 in (voxel, insertion) order. */
+int vfm_icp_nearest(const double *src, int64_t n, const int64_t *keys, const int32_t *start,
+                    const double *pts, int32_t n_voxels, double voxel_size, double max_dist,
+                    double *tgt_out, uint8_t *valid_out, vfm_stream_t stream);
+
+/* BuildLinearSystem (src/kiss-icp/cpp/kiss_icp/core/Registration.cpp:96-141): out43 =
+ * [J^T W J row-major 6x6 | J^T W r (6) | pair count], J = [I | -hat(s)], w = k^2/(k+|r|^2)^2. */
+int vfm_icp_build_system(const double *src, const double *tgt, const uint8_t *valid, int64_t n,
+                         double kernel, double *out43, vfm_stream_t stream);
+
 /* ------------------------------------------------------------------ DINOv2 ViT-S/14 (row A1) */
 
 /* self.model.model(img) of IF:101 incl. the transform of IF:67-77: bilinear resize (antialias

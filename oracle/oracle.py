@@ -417,3 +417,71 @@ def interpolate_pos_embed(pos_embed, h: int, w: int):
     assert patch_pe.shape[-2] == h and patch_pe.shape[-1] == w
     patch_pe = patch_pe.permute(0, 2, 3, 1).reshape(1, h * w, dim)
     return torch.cat([cls_pe, patch_pe], dim=1)
+
+
+# ----------------------------------------------------------------------------- F2 ICP
+def voxel_grid_csr(points: np.ndarray, voxel_size: float):
+    """Sorted-key CSR of a point set (keys as in vfm_oracle.c:orc_voxel_key); points of a voxel keep
+    their order (the insertion order of VoxelHashMap::AddPoints, VHM:733-770)."""
+    pts = np.ascontiguousarray(points[:, :3], dtype=np.float64)
+    v = np.trunc(pts / voxel_size).astype(np.int64) + (1 << 20)
+    keys = (v[:, 0] << 42) | (v[:, 1] << 21) | v[:, 2]
+    order = np.argsort(keys, kind="stable")
+    ks = keys[order]
+    uniq, first = np.unique(ks, return_index=True)
+    start = np.r_[first, len(ks)].astype(np.int32)
+    return np.ascontiguousarray(uniq), start, np.ascontiguousarray(pts[order])
+
+
+def se3_exp(dx: np.ndarray) -> np.ndarray:
+    """Sophus::SE3d::exp (tangent = [upsilon (translation), omega (rotation)]) as a 4x4 matrix."""
+    ups, om = np.asarray(dx[:3], np.float64), np.asarray(dx[3:], np.float64)
+    th = float(np.linalg.norm(om))
+    Om = np.array([[0, -om[2], om[1]], [om[2], 0, -om[0]], [-om[1], om[0], 0]])
+    if th < 1e-10:
+        R = np.eye(3) + Om
+        V = np.eye(3) + 0.5 * Om
+    else:
+        R = np.eye(3) + np.sin(th) / th * Om + (1 - np.cos(th)) / th ** 2 * (Om @ Om)
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * Om + (th - np.sin(th)) / th ** 3 * (Om @ Om)
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = V @ ups
+    return T
+
+
+def register_frame(points: np.ndarray, map_points: np.ndarray, voxel_size: float, initial_guess: np.ndarray,
+                   max_correspondance_distance: float, kernel: float, max_iter: int = 1000,
+                   return_history: bool = False):
+    """kiss_icp RegisterFrame (Registration.cpp:145-195) on an explicit map point set."""
+    keys, start, pts = voxel_grid_csr(map_points, voxel_size)
+    src = np.ascontiguousarray(points[:, :3], dtype=np.float64)
+    source = np.empty_like(src)
+    T0 = np.ascontiguousarray(initial_guess, dtype=np.float64)
+    lib().orc_transform_xyz(_p(src, _f64p), C.c_int64(len(src)), _p(T0, _f64p), _p(source, _f64p))
+    T_icp = np.eye(4)
+    hist = []
+    n = len(source)
+    tgt = np.empty_like(source)
+    valid = np.empty(n, dtype=np.uint8)
+    out = np.empty(43, dtype=np.float64)
+    for _ in range(max_iter):
+        lib().orc_icp_nearest(_p(source, _f64p), C.c_int64(n), _p(keys, _i64p), _p(start, _i32p), _p(pts, _f64p),
+                              C.c_int32(len(keys)), C.c_double(voxel_size), C.c_double(max_correspondance_distance),
+                              _p(tgt, _f64p), _p(valid, _u8p))
+        lib().orc_icp_system(_p(source, _f64p), _p(tgt, _f64p), _p(valid, _u8p), C.c_int64(n), C.c_double(kernel),
+                             _p(out, _f64p))
+        if out[42] == 0:
+            break
+        JTJ, JTr = out[:36].reshape(6, 6), out[36:42]
+        dx = np.linalg.solve(JTJ, -JTr)
+        est = se3_exp(dx)
+        new = np.empty_like(source)
+        lib().orc_transform_xyz(_p(source, _f64p), C.c_int64(n), _p(np.ascontiguousarray(est), _f64p), _p(new, _f64p))
+        source = new
+        T_icp = est @ T_icp
+        hist.append((out.copy(), dx.copy()))
+        if np.linalg.norm(dx) < 1e-4:
+            break
+    T = T_icp @ T0
+    return (T, hist) if return_history else T

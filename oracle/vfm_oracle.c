@@ -657,3 +657,83 @@ ORC_API int orc_num_threads(void) {
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------ */
+/* Row F2: ICP refinement, kiss_icp::RegisterFrame (Registration.cpp:145-195) */
+/* ------------------------------------------------------------------------ */
+static inline int64_t orc_voxel_key(int vx, int vy, int vz) {
+    return ((int64_t)(vx + (1 << 20)) << 42) | ((int64_t)(vy + (1 << 20)) << 21) | (int64_t)(vz + (1 << 20));
+}
+
+/* VoxelHashMap::GetCorrespondences (VoxelHashMap.cpp:76-168): nearest map point among the 27
+ * voxels around each source point; voxel loops i, j, k ascending, points of a voxel in insertion
+ * order, strict '<' (first minimum wins); valid iff sqrt(d2) < max_dist.  The map is given as
+ * sorted voxel keys + CSR offsets (the reference's hash map holds the same points per voxel). */
+ORC_API void orc_icp_nearest(const double *src, int64_t n, const int64_t *keys, const int32_t *start,
+                             const double *pts, int32_t nv, double voxel_size, double max_dist,
+                             double *tgt, uint8_t *valid) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const double px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
+        const int kx = (int)(px / voxel_size), ky = (int)(py / voxel_size), kz = (int)(pz / voxel_size);
+        double bx = 0, by = 0, bz = 0, best = 1.7976931348623157e308;
+        int found = 0;
+        for (int a = kx - 1; a <= kx + 1; ++a)
+            for (int b = ky - 1; b <= ky + 1; ++b)
+                for (int c = kz - 1; c <= kz + 1; ++c) {
+                    const int64_t key = orc_voxel_key(a, b, c);
+                    int lo = 0, hi = nv;
+                    while (lo < hi) {
+                        int mid = (lo + hi) >> 1;
+                        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+                    }
+                    if (lo < nv && keys[lo] == key) {
+                        for (int j = start[lo]; j < start[lo + 1]; ++j) {
+                            double dx = pts[3 * j] - px, dy = pts[3 * j + 1] - py, dz = pts[3 * j + 2] - pz;
+                            double d2 = (dx * dx + dy * dy) + dz * dz;
+                            if (d2 < best) {
+                                best = d2;
+                                bx = pts[3 * j]; by = pts[3 * j + 1]; bz = pts[3 * j + 2];
+                                found = 1;
+                            }
+                        }
+                    }
+                }
+        tgt[3 * i] = bx; tgt[3 * i + 1] = by; tgt[3 * i + 2] = bz;
+        valid[i] = (found && sqrt(best) < max_dist) ? 1 : 0;
+    }
+}
+
+/* BuildLinearSystem (Registration.cpp:96-141): J = [I | -hat(s)], w = k^2 / (k + |r|^2)^2,
+ * JTJ += J^T w J, JTr += J^T w r.  TBB's reduction order is unspecified; fixed here to 256
+ * interleaved partial sums (pair i -> partial i % 256, ascending i) + stride-halving tree. */
+ORC_API void orc_icp_system(const double *src, const double *tgt, const uint8_t *valid, int64_t n, double kernel,
+                            double *out43) {
+    static double red[43][256];
+    for (int t = 0; t < 256; ++t) {
+        double acc[43];
+        for (int k = 0; k < 43; ++k) acc[k] = 0.0;
+        for (int64_t i = t; i < n; i += 256) {
+            if (!valid[i]) continue;
+            const double s[3] = {src[3 * i], src[3 * i + 1], src[3 * i + 2]};
+            const double r[3] = {s[0] - tgt[3 * i], s[1] - tgt[3 * i + 1], s[2] - tgt[3 * i + 2]};
+            const double r2 = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
+            const double w = (kernel * kernel) / ((kernel + r2) * (kernel + r2));
+            const double J[3][6] = {{1.0, 0.0, 0.0, 0.0, s[2], -s[1]},
+                                    {0.0, 1.0, 0.0, -s[2], 0.0, s[0]},
+                                    {0.0, 0.0, 1.0, s[1], -s[0], 0.0}};
+            for (int a = 0; a < 6; ++a) {
+                const double jw[3] = {J[0][a] * w, J[1][a] * w, J[2][a] * w};
+                for (int b = 0; b < 6; ++b)
+                    acc[a * 6 + b] = acc[a * 6 + b] + ((jw[0] * J[0][b] + jw[1] * J[1][b]) + jw[2] * J[2][b]);
+                acc[36 + a] = acc[36 + a] + ((jw[0] * r[0] + jw[1] * r[1]) + jw[2] * r[2]);
+            }
+            acc[42] = acc[42] + 1.0;
+        }
+        for (int k = 0; k < 43; ++k) red[k][t] = acc[k];
+    }
+    for (int stride = 128; stride >= 1; stride >>= 1)
+        for (int t = 0; t < stride; ++t)
+            for (int k = 0; k < 43; ++k) red[k][t] = red[k][t] + red[k][t + stride];
+    for (int k = 0; k < 43; ++k) out43[k] = red[k][0];
+}

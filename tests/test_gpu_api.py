@@ -126,8 +126,6 @@ def test_ransac_registration_end_to_end(orc):
     assert rte < 0.3 and rre < 1.5                                  # RN:973-977 tightest success threshold
     assert compute_errors(pose, p["T_gt"]) == orc.compute_errors(pose, p["T_gt"])
     np.testing.assert_allclose(orthogonalize_rotation(pose), orc.orthogonalize_rotation(pose), atol=0)
-    with pytest.raises(NotImplementedError):
-        node.ransac_registration(voxel_map, raw_scan, "vfm", run_icp=True)
     with pytest.raises(ValueError, match="Invalid method"):
         node.ransac_registration(voxel_map, raw_scan, "fpfh")
 

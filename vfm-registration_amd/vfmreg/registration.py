@@ -5,8 +5,8 @@
   rotation re-orthogonalisation RN:331-336
 
 Same names, argument meaning and return values; numpy in / numpy out.  The ROS node, the baseline
-descriptors, TEASER / PointDSC and the ICP refinement are out of scope:
-``run_icp=True`` raises NotImplementedError rather than silently skipping the refinement.
+descriptors, TEASER and PointDSC are out of scope.  ``run_icp=True`` runs the point-to-point ICP
+refinement of registration_node.py:338-344 (row F2, vfmreg/icp.py).
 """
 from __future__ import annotations
 
@@ -17,6 +17,7 @@ import torch
 
 from . import o3d, ops
 from .config import load_config
+from .icp import register_frame
 from .mapping import get_voxel_hash_map
 from .utils import transform_pcl
 from .voxelization import voxel_down_sample
@@ -85,8 +86,6 @@ class RegistrationNode:
     def ransac_registration(self, voxel_map, raw_scan, method: str = "vfm", run_icp: bool = False):
         if method != "vfm":
             raise ValueError(f"Invalid method: {method}")  # baselines are out of scope
-        if run_icp:
-            raise NotImplementedError("ICP refinement (register_frame, RN:338-344) is row F2 of the scope table")
         src, tgt = self.compute_vfm_correspondences(voxel_map, raw_scan)
         # correspondence indices (RN:288-317): exact coordinate look-up replaces the two KD-trees
         downsample_scan = voxel_down_sample(raw_scan[:, :3], self.config.mapping.voxel_size * 0.5)
@@ -106,7 +105,14 @@ class RegistrationNode:
             pcd_src, pcd_tgt, coors, self.max_correspondence_distance,
             o3d.pipelines.registration.TransformationEstimationPointToPoint(False), ransac_n=3,
             criteria=o3d.pipelines.registration.RANSACConvergenceCriteria(self.ransac_iterations, 1))
-        return np.array(result.transformation), None
+        ransac_pose = np.array(result.transformation)
+        if run_icp:
+            ransac_pose = orthogonalize_rotation(ransac_pose)                 # RN:331-336
+            sigma = self.config.adaptive_threshold.initial_threshold          # RN:339
+            pose = register_frame(points=voxel_scan, voxel_map=voxel_hash_map, initial_guess=ransac_pose,
+                                  max_correspondance_distance=3 * sigma, kernel=sigma / 3)   # RN:340-344
+            return ransac_pose, pose
+        return ransac_pose, None
 
 
 def _lookup_rows(cloud: np.ndarray, pts: np.ndarray):
