@@ -146,6 +146,18 @@ int vfm_gather_bilinear_patchgrid(const float *grid, int gh, int gw, int C, int 
 int vfm_transform_xyz_f64(const double *xyz, int64_t n, const double *T, double *out,
                           vfm_stream_t stream);
 
+/* ------------------------------------------------------------------ voxel maps (row F1) */
+
+/* kiss_icp::VoxelDownsample (src/kiss-icp/cpp/kiss_icp/core/Preprocessing.cpp:50-137; K = 1) and
+ * the insertion rule of VoxelHashMap::AddPoints (VoxelHashMap.cpp:733-770, VoxelHashMap.hpp:55-62;
+ * K = max_points_per_voxel): keep point i iff fewer than K earlier points lie in its voxel
+ * (voxel = trunc(xyz / voxel_size)).  pts: n rows of `stride` fp64, xyz first.  keep_out: indices
+ * of the survivors in ascending (input) order, *count_out their number. */
+size_t vfm_voxel_first_workspace_bytes(int64_t n);
+int vfm_voxel_first(const double *pts, int64_t n, int64_t stride, double voxel_size,
+                    int32_t max_per_voxel, int64_t *keep_out, int64_t *count_out, void *ws,
+                    size_t ws_bytes, vfm_stream_t stream);
+
 /* ------------------------------------------------------------------ ICP refinement (row F2) */
 
 /* VoxelHashMap::GetCorrespondences (src/kiss-icp/cpp/kiss_icp/core/VoxelHashMap.cpp:76-168): for

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .voxelization import voxel_keys
+from .voxelization import first_per_voxel
 
 
 def get_voxel_hash_map(config):
@@ -38,7 +38,6 @@ class VoxelHashMap:
     # ------------------------------------------------------------------ container
     def clear(self):
         self._chunks = {}       # width -> list of arrays (3-D and N-D points live in separate maps)
-        self._counts = {}       # width -> dict voxel key -> count
         self._dev = None        # cached device copy of the N-D map (IndexFlatIP.add)
 
     def empty(self):
@@ -53,24 +52,17 @@ class VoxelHashMap:
             raise ValueError("Invalid shape")  # mapping.py:86
         width = points.shape[1]
         pts = np.ascontiguousarray(points, dtype=np.float64)  # pybind: forcecast to double (stl_vector_eigen.h:73-86)
-        keys = voxel_keys(pts, self.voxel_size)
-        counts = self._counts.setdefault(width, {})
-        keep = np.zeros(len(pts), dtype=bool)
-        # occurrence rank inside the batch + points already stored in the voxel < cap
-        order = np.argsort(keys, kind="stable")
-        ks = keys[order]
-        start = np.r_[True, ks[1:] != ks[:-1]] if len(ks) else np.zeros(0, bool)
-        run_start = np.maximum.accumulate(np.where(start, np.arange(len(ks)), 0)) if len(ks) else np.zeros(0, int)
-        rank = np.arange(len(ks)) - run_start
-        uniq = ks[start] if len(ks) else ks
-        prev = np.array([counts.get(int(k), 0) for k in uniq], dtype=np.int64)
-        prev_per_pt = prev[np.cumsum(start) - 1] if len(ks) else prev
-        keep[order] = (rank + prev_per_pt) < self.max_points_per_voxel
-        added = np.bincount(np.cumsum(start) - 1, weights=keep[order], minlength=len(uniq)).astype(np.int64) if len(ks) else []
-        for k, a in zip(uniq, added):
-            if a:
-                counts[int(k)] = counts.get(int(k), 0) + int(a)
-        self._chunks.setdefault(width, []).append(pts[keep])
+        if len(pts) == 0:
+            return
+        # VoxelBlock::AddPoint keeps a point iff its voxel holds fewer than max_points_per_voxel points
+        # (VoxelHashMap.hpp:55-62).  The points already stored come first and are all within the cap,
+        # so "first K per voxel of [stored..., new...]" restricted to the new rows is exactly that rule.
+        stored = self._chunks.get(width, [])
+        n_old = sum(len(a) for a in stored)
+        xyz = np.concatenate([a[:, :3] for a in stored] + [pts[:, :3]], axis=0) if n_old else pts[:, :3]
+        keep = first_per_voxel(xyz, self.voxel_size, self.max_points_per_voxel)
+        keep_new = keep[keep >= n_old] - n_old
+        self._chunks.setdefault(width, []).append(pts[keep_new])
         self._dev = None
 
     def _cloud(self, width_pred) -> Optional[np.ndarray]:

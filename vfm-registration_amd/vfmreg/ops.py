@@ -253,3 +253,18 @@ def transform_xyz(xyz: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
     _lib.check(lib.vfm_transform_xyz_f64(xyz.data_ptr(), xyz.shape[0], T.data_ptr(), out.data_ptr(), _stream()),
                "transform_xyz")
     return out
+
+
+# ------------------------------------------------------------------------------------ voxel maps
+def voxel_first(xyz: torch.Tensor, voxel_size: float, max_per_voxel: int = 1) -> torch.Tensor:
+    """Indices (ascending) of the points that are among the first `max_per_voxel` of their voxel:
+    VoxelDownsample (Preprocessing.cpp:50-137) for 1, VoxelHashMap::AddPoints' cap otherwise."""
+    _chk(xyz, torch.float64, "xyz")
+    lib = _lib.load()
+    n, stride = xyz.shape
+    keep = torch.empty(max(n, 1), dtype=torch.int64, device=xyz.device)
+    count = torch.empty(1, dtype=torch.int64, device=xyz.device)
+    ws = _ws(lib.vfm_voxel_first_workspace_bytes(n), xyz.device)
+    _lib.check(lib.vfm_voxel_first(xyz.data_ptr(), n, stride, float(voxel_size), int(max_per_voxel), keep.data_ptr(),
+                                   count.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "voxel_first")
+    return keep[:int(count.item())]
