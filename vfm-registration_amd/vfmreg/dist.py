@@ -52,10 +52,11 @@ def gather_poses(local_poses: torch.Tensor, local_aux: torch.Tensor, num_pairs: 
     if n_local:
         buf[:n_local, :16] = local_poses.reshape(n_local, 16)
         buf[:n_local, 16] = local_aux.to(torch.float64)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         out = torch.empty((world, cap, 17), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(out.view(world * cap, 17), buf)
+        dist.all_gather_into_tensor(out.view(world * cap, 17), buf)  # RCCL over xGMI on GPUs, gloo on CPU
     else:
+        assert world == 1, "world > 1 needs an initialised process group"
         out = buf.unsqueeze(0)
     poses = torch.empty((num_pairs, 4, 4), dtype=torch.float64, device=dev)
     aux = torch.empty(num_pairs, dtype=torch.int64, device=dev)
