@@ -175,39 +175,44 @@ struct GemmArgs {
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int EPI>
+// NT = 32-channel tiles per wave (2 for the wide GEMMs, 1 for N = dim so that 66 x 12 = 792 waves
+// cover the chip instead of 396).
+template <int EPI, int NT>
 __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
-    const int ntile64 = g.N / 64;
+    const int ntiles = g.N / (32 * NT);
     const int wid = blockIdx.x * 4 + wave;
-    const int mt = wid / ntile64, nt = wid % ntile64;  // token tile, 64-channel tile
+    const int mt = wid / ntiles, nt = wid % ntiles;  // token tile, (32*NT)-channel tile
     if (mt >= g.M / 32) return;
     const uint4* Ap = g.A + (size_t)mt * g.KS * 64 + lane;
-    const uint4* W0 = g.W + (size_t)(nt * 2) * g.KS * 64 + lane;
-    const uint4* W1 = W0 + (size_t)g.KS * 64;
-    floatx16 acc0, acc1;
+    const uint4* Wp = g.W + (size_t)(nt * NT) * g.KS * 64 + lane;
+    floatx16 acc[NT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     for (int s = 0; s < g.KS; ++s) {
-        uint4 a = Ap[(size_t)s * 64], w0 = W0[(size_t)s * 64], w1 = W1[(size_t)s * 64];
+        uint4 a = Ap[(size_t)s * 64];
         const half8 av = *reinterpret_cast<half8*>(&a);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&w0), av, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&w1), av, acc1, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            uint4 w = Wp[((size_t)j * g.KS + s) * 64];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&w), av, acc[j], 0, 0, 0);
+        }
     }
     // D layout: column = lane & 31 = token, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel in tile
     const int m = mt * 32 + (lane & 31);
     const int b = m / g.Tp, t = m % g.Tp;
     const int hi = lane >> 5;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const floatx16& acc = half ? acc1 : acc0;
+    for (int half = 0; half < NT; ++half) {
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
-            const int n0 = nt * 64 + half * 32 + 8 * grp + 4 * hi;  // 4 consecutive channels n0..n0+3
+            const int n0 = (nt * NT + half) * 32 + 8 * grp + 4 * hi;  // 4 consecutive channels n0..n0+3
             float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[grp * 4 + j] + g.bias[n0 + j];
+            for (int j = 0; j < 4; ++j) v[j] = acc[half][grp * 4 + j] + g.bias[n0 + j];
             if constexpr (EPI == EPI_PATCH) {
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (t == 0) {
@@ -493,8 +498,14 @@ inline VitWs carve_vit(void* p, const Dims& d) {
 
 template <int EPI>
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
+    if (g.N <= 512) {  // narrow output: 32-channel wave tiles so the grid covers the chip
+        const int waves = (g.M / 32) * (g.N / 32);
+        hipLaunchKernelGGL((vit_gemm_kernel<EPI, 1>), dim3(ceil_div(waves, 4)), dim3(256), 0, st, g);
+        VFM_CHECK_LAUNCH("vit_gemm_kernel");
+        return VFM_OK;
+    }
     const int waves = (g.M / 32) * (g.N / 64);
-    hipLaunchKernelGGL(vit_gemm_kernel<EPI>, dim3(ceil_div(waves, 4)), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((vit_gemm_kernel<EPI, 2>), dim3(ceil_div(waves, 4)), dim3(256), 0, st, g);
     VFM_CHECK_LAUNCH("vit_gemm_kernel");
     return VFM_OK;
 }
