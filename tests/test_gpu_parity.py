@@ -326,3 +326,32 @@ def test_transform_xyz(ops, golden, orc):
     out = ops.transform_xyz(dev(xyz), dev(g["T"])).cpu().numpy()
     np.testing.assert_array_equal(out, orc.transform_pcl(xyz, g["T"]))
     np.testing.assert_allclose(out, g["out64"][:, :3], rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------ pipeline
+def test_pipeline_overlap_equals_serial(ops):
+    """two-stage pipeline (RANSAC of pair i on a side stream, ping-pong result sets, events) must give
+    exactly the serial pipeline's results for a sequence of different pairs"""
+    from vfmreg import synth
+    from vfmreg.pipeline import RegistrationPipeline
+    n, m, d = 1500, 9000, 384
+    pairs = [synth.make_pair(n, m, d, seed=100 + i) for i in range(5)]
+    dv = [{k: dev(v) for k, v in p.items() if k != "T_gt" and k != "match"} for p in pairs]
+    serial = RegistrationPipeline(n, m, d, n_iter=3000, max_corr_dist=0.5)
+    want = []
+    for p in dv:
+        o = serial.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
+        torch.cuda.synchronize()
+        want.append({k: o[k].clone() for k in ("T", "idx", "mask", "count", "fitness", "rmse")})
+    over = RegistrationPipeline(n, m, d, n_iter=3000, max_corr_dist=0.5, overlap_ransac=True)
+    got = []
+    for p in dv:
+        o = over.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
+        with torch.cuda.stream(o["result_stream"]):
+            got.append({k: o[k].clone() for k in ("T", "idx", "mask", "count", "fitness", "rmse")})
+    over.synchronize()
+    torch.cuda.synchronize()
+    for w, g, p in zip(want, got, pairs):
+        for k in w:
+            assert torch.equal(w[k], g[k]), k
+        assert np.linalg.norm(g["T"].cpu().numpy() - p["T_gt"]) < 0.05

@@ -35,7 +35,7 @@ constexpr int QBLOCK = 256;       // queries per workgroup of the coarse kernel 
 // LDS ring depth in tiles: a step consumes 2 tiles; 6 buffers = 2 steps in flight (d <= 384),
 // 4 buffers = 1 step in flight when a tile is 32 KiB (d = 512): 160 KiB of LDS per CU.
 constexpr int ring_depth(int ksteps) { return ksteps <= 24 ? 6 : 4; }
-constexpr int CAND_CAP = 12;      // candidate chunks kept per query before falling back
+constexpr int CAND_CAP = 40;      // candidate chunks kept per query before falling back
 constexpr float COARSE_OFFSET = 2.0f;   // accumulators start here: every coarse score is a
                                         // positive normal float, so uint order == float order
 constexpr float DEFAULT_WINDOW = 2.5e-3f;  // >= 2E, E = proven |coarse - exact| bound
@@ -202,9 +202,6 @@ struct CoarseArgs {
 // QSETS = 32-query sets resident per wave: 1 -> 8 waves (2 per SIMD), 2 -> 4 waves (1 per SIMD,
 // every LDS fragment feeds two MFMAs: half the LDS read traffic / energy per flop).
 template <int KSTEPS, int QSETS>
-#ifdef VFM_COARSE_VGPR_CAP
-__attribute__((amdgpu_num_vgpr(VFM_COARSE_VGPR_CAP)))
-#endif
 __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coarse_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVES = 8 / QSETS;
