@@ -248,3 +248,44 @@ def test_image_feature_generator(orc):
         ImageFeatureGenerator("resnet", use_featup=False)
     with pytest.raises(NotImplementedError):
         ImageFeatureGenerator("dinov2", use_featup=True)
+
+
+def test_evaluation_harness_on_a_synthetic_scene(tmp_path):
+    """row F4 (+ the npz stand-in for the HDF5 scene files, row F3): build the map from posed clouds,
+    register every scan with VFM + RANSAC + ICP, recall table as RN:961-989"""
+    from vfmreg import synth
+    from vfmreg.evaluation import Evaluation, evaluate_scene, read_scenes, save_scene
+    from vfmreg.mapping import VoxelHashMap
+    from vfmreg.registration import RegistrationNode
+    VoxelHashMap.quiet = True
+    rng = np.random.default_rng(2)
+    d = 128
+    world = np.c_[rng.uniform(-40, 40, (40000, 2)), rng.uniform(-2, 6, 40000)]
+    desc = np.abs(rng.standard_normal((40000, d))).astype(np.float32)
+    desc[::50] = 0.0                                          # points without descriptor are dropped (RN:562)
+    map_poses, map_clouds = [], []
+    for j in range(3):                                        # three posed map clouds covering the world
+        T = synth.random_pose(rng)
+        sel = np.arange(j, 40000, 3)
+        local = (world[sel] - T[:3, 3]) @ T[:3, :3]           # cloud in its own sensor frame
+        map_poses.append(T)
+        map_clouds.append(np.c_[local, desc[sel]].astype(np.float32))
+    scan_poses, scan_clouds = [], []
+    for s in range(2):
+        T = synth.random_pose(rng)
+        sel = rng.permutation(40000)[:6000]
+        sel = sel[desc[sel].sum(1) > 0]
+        local = (world[sel] - T[:3, 3]) @ T[:3, :3] + rng.normal(0, 0.01, (len(sel), 3))
+        noisy = desc[sel] + 0.05 * np.abs(rng.standard_normal((len(sel), d))).astype(np.float32)
+        scan_poses.append(T)
+        scan_clouds.append(np.c_[local, noisy].astype(np.float32))
+    f = tmp_path / "scene_000.npz"
+    save_scene(f, ["mapseq", "scanA", "scanB"], map_poses, map_clouds, scan_poses, scan_clouds)
+    scene = read_scenes(f)
+    assert len(scene["map_poses"]) == 3 and scene["scene_sequences"] == ["scanA", "scanB"]
+    ev = evaluate_scene(scene, RegistrationNode(ransac_iterations=4000), Evaluation())
+    assert set(ev.rot_errors) == {"vfm_ransac", "vfm_ransac_icp"} and len(ev.rot_errors["vfm_ransac"]) == 2
+    assert ev.compute_success_rate("vfm_ransac_icp", .3, 15) == 1.0
+    assert ev.compute_success_rate("vfm_ransac_icp", .6, 1.5) == 1.0
+    assert max(ev.trans_errors["vfm_ransac_icp"]) < 0.1
+    assert "vfm_ransac_icp" in ev.summary()

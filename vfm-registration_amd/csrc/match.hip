@@ -314,10 +314,12 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
         if (AHEAD >= 2 && it + 2 < ntiles) wait_vmcnt<2 * PASSES>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifndef VFM_ABLATE_DMA
         if (it + 2 * AHEAD < ntiles) {
             stage(it + 2 * AHEAD);
             stage(it + 2 * AHEAD + 1);
         }
+#endif
         const uint4* buf0 = reinterpret_cast<const uint4*>(smem + (it % NBUF) * TILE_BYTES) + lane;
         const uint4* buf1 = reinterpret_cast<const uint4*>(smem + ((it + 1) % NBUF) * TILE_BYTES) + lane;
         floatx16 acc[QSETS][2];
@@ -337,6 +339,15 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
                 acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&v1), qf[j][s], acc[j][1], 0, 0, 0);
             }
         }
+#ifdef VFM_ABLATE_FOLD
+#pragma unroll
+        for (int j = 0; j < QSETS; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" ::"v"(acc[j][0]), "v"(acc[j][1]));
+#endif
+        }
+        if (it >= 0) return;
+#endif
         // previous step = the other half (of this chunk for H == 1, of the previous chunk for H == 0);
         // at it == 0 this folds the zero-initialised dummies (tiny packed values, store suppressed)
         fold(prev[0][0], it - 2, std::integral_constant<int, 2 * (1 - H)>{}, std::integral_constant<int, 0>{});
