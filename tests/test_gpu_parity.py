@@ -228,6 +228,32 @@ def test_ransac_bit_exact(ops, orc, n_corr, n_iter, max_dist):
         assert np.linalg.norm(ref.transformation - T_gt) < 0.05  # the planted pose is recovered
 
 
+@pytest.mark.parametrize("n_corr,outlier,noise,max_dist,n_iter", [
+    (3000, 0.5, 0.02, 0.06, 4000),    # threshold at ~1.7 sigma of the residuals: many borderline correspondences
+    (3000, 0.9, 0.02, 0.5, 6000),     # outlier-dominated: fitness decides, counts differ by a few
+    (2000, 0.0, 0.0, 10000.0, 3000),  # noise-free: thousands of equally perfect hypotheses -> candidate overflow -> fallback
+    (501, 0.3, 0.05, 1.0, 2000),      # odd count (fp32 stream tail), moderate noise
+    (40, 0.5, 0.02, 0.1, 500), (3, 0.0, 0.01, 10000.0, 50)])
+def test_ransac_two_level_equals_exact(ops, orc, n_corr, outlier, noise, max_dist, n_iter):
+    """fp32 coarse scoring + exact fp64 re-scoring of the surviving hypotheses must return exactly what
+    scoring every hypothesis in fp64 returns (= the oracle), including masks and the winner's id"""
+    from vfmreg import _lib
+    lib = _lib.load()
+    src, tgt, corres, _ = _ransac_case(n_corr, outlier, seed=n_corr + n_iter, noise=noise)
+    ref = orc.ransac_corr(src, tgt, corres, max_dist, n_iter, seed=7)
+    for exact_only in (1, 0):
+        lib.vfm_debug_set_ransac_exact_only(exact_only)
+        try:
+            out = ops.ransac_corr(dev(src), dev(tgt), dev(corres), max_dist, n_iter, seed=7)
+            torch.cuda.synchronize()
+        finally:
+            lib.vfm_debug_set_ransac_exact_only(0)
+        assert out["best_hyp"].item() == ref.best_hyp, exact_only
+        np.testing.assert_array_equal(out["T"].cpu().numpy(), ref.transformation)
+        assert out["fitness"].item() == ref.fitness and out["rmse"].item() == ref.inlier_rmse
+        np.testing.assert_array_equal(out["mask"][:n_corr].cpu().numpy(), ref.inlier_mask)
+
+
 def test_ransac_device_count_and_degenerate(ops, orc):
     src, tgt, corres, _ = _ransac_case(800, 0.3, seed=9)
     cnt = torch.tensor([500], dtype=torch.int64, device="cuda")

@@ -232,19 +232,30 @@ __device__ __forceinline__ bool better(double af, double ar, int ah, double bf, 
 
 constexpr int SCORE_CHUNK = 128;  // correspondences staged in LDS per step (6 KiB)
 
+// Exact (fp64, oracle operation order) scoring.  Two launch forms:
+//   list == NULL : hypothesis h = global thread index (all n_iter hypotheses); runs only if
+//                  gate == NULL or *gate != 0 (the fallback when the candidate list overflowed)
+//   list != NULL : hypothesis = list[global thread index] for indices < *list_count (the candidates
+//                  the fp32 coarse pass could not rule out); skipped when *gate != 0
 __global__ __launch_bounds__(64) void ransac_score_kernel(const double* __restrict__ pts,
                                                           const int64_t* __restrict__ count_dev, int64_t c_max,
                                                           double max_d2, int32_t n_iter, uint64_t seed,
+                                                          const int32_t* __restrict__ list,
+                                                          const int32_t* __restrict__ list_count,
+                                                          const int32_t* __restrict__ gate,
                                                           HypScore* __restrict__ block_best) {
     // one wavefront per workgroup: its private LDS double buffer holds the correspondence stream
     __shared__ __attribute__((aligned(16))) double lbuf[2][SCORE_CHUNK * 6];
     const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
     const int lane = threadIdx.x;
-    const int32_t h = (int32_t)(blockIdx.x * 64 + lane);
+    const int32_t slot = (int32_t)(blockIdx.x * 64 + lane);
+    const int32_t limit = list ? *list_count : n_iter;
+    const bool enabled = list ? (!gate || *gate == 0) : (!gate || *gate != 0);
+    const int32_t h = (enabled && slot < limit) ? (list ? list[slot] : slot) : n_iter;
     double fit = 0.0, rmse = 0.0;
     int hyp = -1;
     double T[12];
-    const bool wave_has_work = (C >= 3) && ((int32_t)(blockIdx.x * 64) < n_iter);
+    const bool wave_has_work = enabled && (C >= 3) && ((int32_t)(blockIdx.x * 64) < limit);
     bool live = false;
     if (C >= 3 && h < n_iter) live = sample_T(pts, C, (uint32_t)h, seed, T);
     if (!live) {
@@ -425,21 +436,415 @@ __global__ __launch_bounds__(64) void kabsch_batched_kernel(const double* __rest
     if (valid) valid[i] = ok ? 1 : 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// fp32 coarse scoring with a proven error bound (the same idea as the matcher's fp16 coarse pass):
+// every hypothesis is scored in fp32 FMA arithmetic (~6x cheaper than the fp64 no-FMA sequence),
+// together with bounds [n_lo, n_hi] on its inlier count and [r_lo, r_hi] on its inlier RMSE;
+// only hypotheses that these bounds cannot rule out are re-scored exactly by ransac_score_kernel.
+// The winner (and therefore T, fitness, rmse, mask) is the one the all-fp64 pass would return.
+//
+// Bound.  With centred clouds s' = s - cs, q' = q - cq, t' = t + R cs - cq (exact identity
+// R s + t - q = R s' + t' - q'), M = max |s'|, |q'| and u = 2^-24: every component of the fp32
+// residual d~ = fl(R~ s~' + t~' - q~') differs from the exact one by at most
+//     delta = u (19 M + 5 |t'|_inf)  <=  u (32 M + 8 |t'|_inf)      (input roundings + 4 fp32 ops),
+// hence | |d~| - |d| | <= eta = sqrt(3) delta.  A correspondence with d~^2 < (max_dist - eta)^2 is
+// certainly an inlier, one with d~^2 >= (max_dist + eta)^2 certainly is not; over a certain set
+// RMSE(d) lies within eta of RMSE(d~) (Minkowski); uncertain members (all at distance ~max_dist)
+// widen the lower bound by another 2 eta.  fp32 chunk sums (128 terms) are covered by 1e-4 slack.
+// ---------------------------------------------------------------------------------------------
+constexpr int COARSE_CHUNK = 128;
+constexpr int COARSE_WAVES = 8;
+constexpr int CAND_MAX = 2048;
+
+struct RansacStats {
+    double cs[3], cq[3];  // centroids of the gathered source / target points
+    double M;             // max |centred coordinate|
+};
+
+// one workgroup: centroids, extent, and the centred fp32 copy of the correspondence stream
+__global__ __launch_bounds__(1024) void ransac_center_kernel(const double* __restrict__ pts,
+                                                             const int64_t* __restrict__ count_dev, int64_t c_max,
+                                                             RansacStats* __restrict__ stats, float* __restrict__ pts32) {
+    __shared__ double red[6][1024];
+    __shared__ double cen[6];
+    const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
+    const int t = threadIdx.x;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t i = t; i < C; i += 1024)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[c] += pts[6 * i + c];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) red[c][t] = acc[c];
+    __syncthreads();
+    for (int stride = 512; stride >= 1; stride >>= 1) {
+        if (t < stride)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) red[c][t] += red[c][t + stride];
+        __syncthreads();
+    }
+    if (t < 6) cen[t] = (C > 0) ? red[t][0] / (double)C : 0.0;
+    __syncthreads();
+    double m = 0.0;
+    for (int64_t i = t; i < C; i += 1024)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double v = pts[6 * i + c] - cen[c];
+            pts32[6 * i + c] = (float)v;
+            m = fmax(m, fabs(v));
+        }
+    __syncthreads();
+    red[0][t] = m;
+    __syncthreads();
+    for (int stride = 512; stride >= 1; stride >>= 1) {
+        if (t < stride) red[0][t] = fmax(red[0][t], red[0][t + stride]);
+        __syncthreads();
+    }
+    if (t == 0) {
+        for (int c = 0; c < 3; ++c) {
+            stats->cs[c] = cen[c];
+            stats->cq[c] = cen[3 + c];
+        }
+        stats->M = red[0][0];
+    }
+}
+
+struct SelectState {           // zeroed per call (Rbits = +inf)
+    int F;                     // max certain inlier count
+    int count;                 // candidates appended
+    unsigned long long Rbits;  // min r_hi among hypotheses whose count is certainly F (bits of a double >= 0)
+    int overflow;              // candidate list overflowed -> score everything exactly
+    int pad;
+};
+
+__global__ void ransac_sel_init_kernel(SelectState* sel) {
+    sel->F = 0;
+    sel->count = 0;
+    sel->Rbits = 0x7FF0000000000000ull;  // +inf
+    sel->overflow = 0;
+    sel->pad = 0;
+}
+
+struct CoarseHyp {
+    int32_t n_lo, n_hi;  // certain inliers / possible inliers (n_hi < 0: degenerate sample)
+    double r_lo, r_hi;   // bounds on the inlier RMSE
+};
+
+// 512 threads = 8 waves per 64 hypotheses: wave w scores chunks w, w+8, ... of the stream (the coarse
+// sums have no prescribed order), so 6 waves share a SIMD and hide each other's issue latency (a lone
+// wave issues one instruction per ~4 cycles whatever its type).  Wave 0 derives the fp32 transform
+// and the thresholds of each hypothesis once; partial results are combined in LDS in wave order.
+__global__ __launch_bounds__(512) void ransac_coarse_kernel(const double* __restrict__ pts, const float* __restrict__ pts32,
+                                                            const RansacStats* __restrict__ stats,
+                                                            const int64_t* __restrict__ count_dev, int64_t c_max,
+                                                            double max_dist, int32_t n_iter, uint64_t seed,
+                                                            CoarseHyp* __restrict__ out, SelectState* __restrict__ sel) {
+    __shared__ __attribute__((aligned(16))) float lbuf[COARSE_WAVES][2][COARSE_CHUNK * 6];
+    __shared__ float hyp_f[14][64];  // R (9), t' (3), Lf, Hf per hypothesis
+    __shared__ double hyp_eta[64];
+    __shared__ int hyp_live[64];
+    __shared__ int all_inliers_s;  // every correspondence is certainly an inlier of every hypothesis of this block
+    __shared__ int part_n[COARSE_WAVES][2][64];
+    __shared__ double part_e[COARSE_WAVES][2][64];
+    const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t h = (int32_t)(blockIdx.x * 64 + lane);
+    if (C < 3) {
+        if (wave == 0 && h < n_iter) out[h] = CoarseHyp{0, -1, 0.0, 0.0};
+        return;
+    }
+    if (wave == 0) {
+        double T[12];
+        const bool ok = (h < n_iter) && sample_T(pts, C, (uint32_t)h, seed, T);
+        double eta = 0.0;
+        float f[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1.0f, -1.0f};
+        bool sure = true;  // degenerate / out-of-range hypotheses do not veto the fast path
+        if (ok) {
+            double tmax = 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double tr = (T[4 * r + 3] + ((T[4 * r] * stats->cs[0] + T[4 * r + 1] * stats->cs[1]) + T[4 * r + 2] * stats->cs[2])) -
+                                  stats->cq[r];
+                f[9 + r] = (float)tr;
+                tmax = fmax(tmax, fabs(tr));
+                f[3 * r] = (float)T[4 * r];
+                f[3 * r + 1] = (float)T[4 * r + 1];
+                f[3 * r + 2] = (float)T[4 * r + 2];
+            }
+            const double delta = 5.9604644775390625e-08 * (32.0 * stats->M + 8.0 * tmax);  // u = 2^-24
+            eta = 1.7321 * delta;
+            // certain / possible inlier thresholds on the fp32 squared distance (directed 1e-6 slack >> fp32 rounding)
+            if (max_dist > 0.0) {
+                const double lo = fmax(0.0, max_dist - eta), hi = max_dist + eta;
+                f[12] = (float)(lo * lo * (1.0 - 1e-6));
+                f[13] = (float)(hi * hi * (1.0 + 1e-6));
+            }
+            // |d~ component| <= sqrt(3) M + |t'| + M, so d~^2 <= 3 (3 M + |t'|)^2: if even that is below the
+            // "certain inlier" threshold (the reference calls RANSAC with max_dist = 10000 m), no test is needed
+            const double reach = 3.0 * stats->M + tmax;
+            sure = (double)f[12] > 3.0 * reach * reach * 1.001;
+        }
+        const bool all_sure = __all(sure);
+        if (lane == 0) all_inliers_s = all_sure ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) hyp_f[k][lane] = f[k];
+        hyp_eta[lane] = eta;
+        hyp_live[lane] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    float R[9], tp[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = hyp_f[k][lane];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tp[k] = hyp_f[9 + k][lane];
+    const float Lf = hyp_f[12][lane], Hf = hyp_f[13][lane];
+    const bool all_in = all_inliers_s != 0;  // block-uniform
+    int n_lo = 0, n_hi = 0;
+    double E_lo = 0.0, E_hi = 0.0;
+    const int64_t nchunks = (C + COARSE_CHUNK - 1) / COARSE_CHUNK;  // 768 floats per chunk = 64 lanes x 3 float4
+    float4 pre[3];
+    auto fetch = [&](int64_t c) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int64_t e = c * (COARSE_CHUNK * 6) + (int64_t)(j * 64 + lane) * 4;
+            // pts32 is allocated with 4 floats of slack: a float4 that STARTS inside the data may over-read
+            pre[j] = (e < C * 6) ? *reinterpret_cast<const float4*>(pts32 + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) *reinterpret_cast<float4*>(&lbuf[wave][b][(j * 64 + lane) * 4]) = pre[j];
+    };
+    int b = 0;
+    if (wave < nchunks) {
+        fetch(wave);
+        stash(0);
+    }
+    for (int64_t c = wave; c < nchunks; c += COARSE_WAVES, b ^= 1) {
+        if (c + COARSE_WAVES < nchunks) fetch(c + COARSE_WAVES);
+        __builtin_amdgcn_wave_barrier();
+        const int64_t base = c * COARSE_CHUNK;
+        const int cnt = (int)min((int64_t)COARSE_CHUNK, C - base);
+        const float* lp = lbuf[wave][b];
+        float e_lo = 0.f, e_hi = 0.f;
+        auto score = [&](const float* p, float& d2) {  // p: LDS broadcast address
+            const float dx = fmaf(R[0], p[0], fmaf(R[1], p[1], fmaf(R[2], p[2], tp[0]))) - p[3];
+            const float dy = fmaf(R[3], p[0], fmaf(R[4], p[1], fmaf(R[5], p[2], tp[1]))) - p[4];
+            const float dz = fmaf(R[6], p[0], fmaf(R[7], p[1], fmaf(R[8], p[2], tp[2]))) - p[5];
+            d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        };
+        if (all_in) {
+            // every point is a certain inlier: only the sum is needed (4 partial sums for ILP)
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int i = 0;
+            for (; i + 4 <= cnt; i += 4) {
+                float d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) score(lp + 6 * (i + u), d[u]);
+                a0 += d[0]; a1 += d[1]; a2 += d[2]; a3 += d[3];
+            }
+            for (; i < cnt; ++i) {
+                float d;
+                score(lp + 6 * i, d);
+                a0 += d;
+            }
+            e_lo = e_hi = (a0 + a1) + (a2 + a3);
+            n_lo += cnt;
+            n_hi += cnt;
+        } else {
+            auto tally = [&](float d2) {
+                const bool in_lo = d2 < Lf, in_hi = d2 < Hf;
+                n_lo += in_lo ? 1 : 0;
+                n_hi += in_hi ? 1 : 0;
+                e_lo += in_lo ? d2 : 0.f;
+                e_hi += in_hi ? d2 : 0.f;
+            };
+            int i = 0;
+            for (; i + 4 <= cnt; i += 4) {
+                float d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) score(lp + 6 * (i + u), d[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tally(d[u]);
+            }
+            for (; i < cnt; ++i) {
+                float d;
+                score(lp + 6 * i, d);
+                tally(d);
+            }
+        }
+        E_lo += (double)e_lo;
+        E_hi += (double)e_hi;
+        __builtin_amdgcn_wave_barrier();
+        if (c + COARSE_WAVES < nchunks) stash(b ^ 1);
+    }
+    part_n[wave][0][lane] = n_lo;
+    part_n[wave][1][lane] = n_hi;
+    part_e[wave][0][lane] = E_lo;
+    part_e[wave][1][lane] = E_hi;
+    __syncthreads();
+    if (wave != 0) return;
+    n_lo = n_hi = 0;
+    E_lo = E_hi = 0.0;
+#pragma unroll
+    for (int w = 0; w < COARSE_WAVES; ++w) {  // fixed order: deterministic
+        n_lo += part_n[w][0][lane];
+        n_hi += part_n[w][1][lane];
+        E_lo += part_e[w][0][lane];
+        E_hi += part_e[w][1][lane];
+    }
+    const bool live = hyp_live[lane] != 0;
+    const double eta = hyp_eta[lane];
+    if (h < n_iter) {
+        CoarseHyp o;
+        if (!live) {
+            o = CoarseHyp{0, -1, 0.0, 0.0};
+        } else {
+            o.n_lo = n_lo;
+            o.n_hi = n_hi;
+            o.r_lo = (n_lo > 0) ? fmax(0.0, sqrt(E_lo / (double)n_lo) * (1.0 - 1e-4) - 3.0 * eta) : 0.0;
+            o.r_hi = (n_hi > 0) ? sqrt(E_hi / (double)n_hi) * (1.0 + 1e-4) + eta : 1.7976931348623157e308;
+        }
+        out[h] = o;
+    }
+    // F* = max over hypotheses of the certain inlier count (one atomic per workgroup)
+    int f = (live && h < n_iter) ? n_lo : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) f = max(f, __shfl_xor(f, off));
+    if (lane == 0 && f > 0) atomicMax(&sel->F, f);
+}
+
+// which hypotheses can still be the exact winner?
+//   F* = max n_lo (some hypothesis certainly has that many inliers); a winner needs n_hi >= F*.
+//   R* = min r_hi over hypotheses whose count is certainly F* (n_lo == n_hi == F*); a hypothesis that
+//        can at best tie on the count (n_hi == F*) also needs r_lo <= R*.
+__global__ __launch_bounds__(256) void ransac_select_rmin_kernel(const CoarseHyp* __restrict__ hyps, int32_t n_iter,
+                                                                 SelectState* __restrict__ sel) {
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    const int F = sel->F;
+    double r = 1.7976931348623157e308;
+    if (h < n_iter) {
+        const CoarseHyp c = hyps[h];
+        if (c.n_hi >= 0 && c.n_lo == F && c.n_hi == F) r = c.r_hi;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) r = fmin(r, __shfl_xor(r, off));
+    if ((threadIdx.x & 63) == 0 && r < 1.7976931348623157e308)
+        atomicMin(&sel->Rbits, (unsigned long long)__double_as_longlong(r));  // r >= 0: bit order == value order
+}
+
+__global__ __launch_bounds__(256) void ransac_select_list_kernel(const CoarseHyp* __restrict__ hyps, int32_t n_iter,
+                                                                 SelectState* __restrict__ sel, int32_t* __restrict__ list) {
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= n_iter) return;
+    const int F = sel->F;
+    const double Rs = __longlong_as_double((long long)sel->Rbits);
+    const CoarseHyp c = hyps[h];
+    const bool cand = c.n_hi > 0 && c.n_hi >= F && (c.n_hi > F || c.r_lo <= Rs);
+    if (cand) {
+        const int slot = atomicAdd(&sel->count, 1);
+        if (slot < CAND_MAX) list[slot] = h;
+        else sel->overflow = 1;
+    }
+}
+
+// Exact scoring of ONE candidate per wavefront.  The 64 lanes evaluate the residuals of a 1024-point
+// chunk in parallel (same fp64 expression as the oracle), then the chunk is folded into (good, e2) in
+// correspondence order by a sequential loop over LDS -- the oracle's accumulation order -- so a
+// candidate costs ~C * (1/64 * 31 + 1) fp64 ops of latency instead of C * 31.
+constexpr int EXACT_CHUNK = 1024;
+__global__ __launch_bounds__(64) void ransac_exact_list_kernel(const double* __restrict__ pts,
+                                                               const int64_t* __restrict__ count_dev, int64_t c_max,
+                                                               double max_d2, int32_t n_iter, uint64_t seed,
+                                                               const int32_t* __restrict__ list,
+                                                               const SelectState* __restrict__ sel,
+                                                               HypScore* __restrict__ best_out) {
+    __shared__ __attribute__((aligned(16))) double d2s[EXACT_CHUNK];
+    const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
+    const int lane = threadIdx.x;
+    HypScore res;
+    res.fit = 0.0;
+    res.rmse = 0.0;
+    res.hyp = -1;
+    const int ncand = sel->overflow ? 0 : min(sel->count, CAND_MAX);
+    if ((int)blockIdx.x < ncand && C >= 3) {
+        const int32_t h = list[blockIdx.x];
+        double T[12];
+        if (sample_T(pts, C, (uint32_t)h, seed, T)) {  // wave-uniform
+            int64_t good = 0;
+            double e2 = 0.0;
+            for (int64_t base = 0; base < C; base += EXACT_CHUNK) {
+                const int cnt = (int)min((int64_t)EXACT_CHUNK, C - base);
+                __builtin_amdgcn_wave_barrier();
+                // parallel phase: residual, inlier test and inlier count (a count has no order);
+                // LDS receives "d2 if inlier else 0.0" -- adding 0.0 is the identity, so the in-order
+                // fold below is bit-identical to "if (d2 < max_d2) e2 += d2"
+                int mine = 0;
+                for (int i = lane; i < cnt; i += 64) {
+                    const double* p = pts + 6 * (base + i);
+                    const double d2 = err2(T, p[0], p[1], p[2], p[3], p[4], p[5]);
+                    const bool in = d2 < max_d2;
+                    mine += in ? 1 : 0;
+                    d2s[i] = in ? d2 : 0.0;
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
+                good += mine;
+                __builtin_amdgcn_wave_barrier();
+                // sequential phase: the oracle's accumulation order (every lane runs the same chain)
+                int i = 0;
+                for (; i + 8 <= cnt; i += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = d2s[i + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) e2 = e2 + v[u];
+                }
+                for (; i < cnt; ++i) e2 = e2 + d2s[i];
+            }
+            if (good > 0) {
+                res.fit = (double)good / (double)C;
+                res.rmse = sqrt(e2 / (double)good);
+                res.hyp = h;
+            }
+        }
+    }
+    if (lane == 0) best_out[blockIdx.x] = res;
+}
+
 struct RansacWs {
     double* pts;
-    HypScore* block_best;
+    float* pts32;
+    RansacStats* stats;
+    CoarseHyp* hyps;
+    int32_t* list;
+    SelectState* sel;
+    HypScore* block_best;  // [0, CAND_MAX): one per candidate, [CAND_MAX, CAND_MAX + nblocks): full fallback pass
     size_t bytes;
 };
 inline RansacWs carve_ransac(void* p, int64_t c_max, int32_t n_iter) {
     VfmCarver c(p);
     RansacWs w;
     w.pts = c.take<double>((size_t)(c_max > 0 ? c_max : 1) * 6);
-    w.block_best = c.take<HypScore>((size_t)(n_iter + 63) / 64 + 1);
+    w.pts32 = c.take<float>((size_t)(c_max > 0 ? c_max : 1) * 6 + 4);
+    w.stats = c.take<RansacStats>(1);
+    w.hyps = c.take<CoarseHyp>((size_t)n_iter);
+    w.list = c.take<int32_t>(CAND_MAX);
+    w.sel = c.take<SelectState>(1);
+    w.block_best = c.take<HypScore>((size_t)(n_iter + 63) / 64 + CAND_MAX + 1);
     w.bytes = c.used();
     return w;
 }
 
+int g_ransac_exact_only = 0;
+
 }  // namespace
+
+// A/B switch: 1 = score every hypothesis in fp64 (no fp32 coarse pass)
+VFM_EXPORT int vfm_debug_set_ransac_exact_only(int on) {
+    g_ransac_exact_only = on;
+    return VFM_OK;
+}
 
 VFM_EXPORT size_t vfm_ransac_workspace_bytes(int64_t c_max, int32_t n_iter) { return carve_ransac(nullptr, c_max, n_iter).bytes; }
 
@@ -461,11 +866,32 @@ VFM_EXPORT int vfm_ransac_corr(const double* src, const double* tgt, const int32
                            count_dev, c_max, w.pts);
         VFM_CHECK_LAUNCH("ransac_gather_kernel");
     }
-    hipLaunchKernelGGL(ransac_score_kernel, dim3(nblocks), dim3(64), 0, st, w.pts, count_dev, c_max, max_d2, n_iter, seed,
-                       w.block_best);
-    VFM_CHECK_LAUNCH("ransac_score_kernel");
-    hipLaunchKernelGGL(ransac_final_kernel, dim3(1), dim3(256), 0, st, w.pts, count_dev, c_max, seed, w.block_best, nblocks,
-                       T_out, fitness_out, rmse_out, best_hyp_out);
+    if (g_ransac_exact_only) {
+        // reference-order fp64 scoring of every hypothesis (A/B switch, and the semantics the
+        // two-level path below must reproduce bit for bit)
+        hipLaunchKernelGGL(ransac_score_kernel, dim3(nblocks), dim3(64), 0, st, w.pts, count_dev, c_max, max_d2, n_iter, seed,
+                           (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, w.block_best);
+        VFM_CHECK_LAUNCH("ransac_score_kernel");
+        hipLaunchKernelGGL(ransac_final_kernel, dim3(1), dim3(256), 0, st, w.pts, count_dev, c_max, seed, w.block_best,
+                           nblocks, T_out, fitness_out, rmse_out, best_hyp_out);
+    } else {
+        // fp32 coarse pass -> candidates -> exact fp64 on the candidates (or on everything if the
+        // candidate list overflowed)
+        hipLaunchKernelGGL(ransac_sel_init_kernel, dim3(1), dim3(1), 0, st, w.sel);
+        hipLaunchKernelGGL(ransac_center_kernel, dim3(1), dim3(1024), 0, st, w.pts, count_dev, c_max, w.stats, w.pts32);
+        hipLaunchKernelGGL(ransac_coarse_kernel, dim3(nblocks), dim3(64 * COARSE_WAVES), 0, st, w.pts, w.pts32, w.stats, count_dev, c_max,
+                           max_dist, n_iter, seed, w.hyps, w.sel);
+        const unsigned gsel = (unsigned)((n_iter + 255) / 256);
+        hipLaunchKernelGGL(ransac_select_rmin_kernel, dim3(gsel), dim3(256), 0, st, w.hyps, n_iter, w.sel);
+        hipLaunchKernelGGL(ransac_select_list_kernel, dim3(gsel), dim3(256), 0, st, w.hyps, n_iter, w.sel, w.list);
+        hipLaunchKernelGGL(ransac_exact_list_kernel, dim3(CAND_MAX), dim3(64), 0, st, w.pts, count_dev, c_max, max_d2, n_iter,
+                           seed, w.list, w.sel, w.block_best);
+        hipLaunchKernelGGL(ransac_score_kernel, dim3(nblocks), dim3(64), 0, st, w.pts, count_dev, c_max, max_d2, n_iter, seed,
+                           (const int32_t*)nullptr, (const int32_t*)nullptr, &w.sel->overflow, w.block_best + CAND_MAX);
+        VFM_CHECK_LAUNCH("ransac coarse/select/score kernels");
+        hipLaunchKernelGGL(ransac_final_kernel, dim3(1), dim3(256), 0, st, w.pts, count_dev, c_max, seed, w.block_best,
+                           CAND_MAX + nblocks, T_out, fitness_out, rmse_out, best_hyp_out);
+    }
     VFM_CHECK_LAUNCH("ransac_final_kernel");
     if (inlier_mask && c_max > 0) {
         hipLaunchKernelGGL(ransac_mask_kernel, dim3((unsigned)((c_max + 255) / 256)), dim3(256), 0, st, w.pts, count_dev,
