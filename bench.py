@@ -231,7 +231,7 @@ def main():
                                    f"HBM, {args.iters} RANSAC iterations, cosine >= 0.8; map renormalised every step",
                        "pairs_per_gpu": args.steps, "parallelism": f"{world} GPU shard(s) x {S} stream(s), independent scene pairs",
                        "correspondences_last_step": ncorr, "max_pose_err_vs_planted": max(errs)},
-            "roofline": {"bound": "mfma", "kernel": "match_coarse_kernel<24,1> (fp16 32x32x16 MFMA, fused top-2 epilogue)",
+            "roofline": {"bound": "mfma", "kernel": "match_coarse_pipe_kernel<24> (fp16 32x32x16 MFMA, fused top-2 epilogue)",
                          "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": "profiles/r01_pmc_match_coarse.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",

@@ -68,6 +68,16 @@ size_t vfm_match_search_workspace_bytes(int64_t n, int64_t m, int d);
 int vfm_match_search_prepared(const float *q, const void *q_prepared, int64_t n, const float *b,
                               const void *b_prepared, int64_t m, int d, int64_t *idx_out,
                               float *sim_out, void *ws, size_t ws_bytes, vfm_stream_t stream);
+/* The same search as two enqueue calls, so that a caller can run the matrix-core stage of one scan
+ * while the vector-ALU stage of the previous scan finishes on another stream (vfmreg/pipeline.py):
+ * _coarse = fp16 MFMA pass over all N x M pairs (IndexFlatIP::search's sgemm, VHM:486-495) into ws;
+ * _finish = candidate selection + exact fp64 decision from that ws.  _prepared == _coarse; _finish
+ * on one stream.  ws and both prepared operands must stay untouched between the two calls. */
+int vfm_match_search_coarse(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
+                            int d, void *ws, size_t ws_bytes, vfm_stream_t stream);
+int vfm_match_search_finish(const float *q, const void *q_prepared, int64_t n, const float *b,
+                            const void *b_prepared, int64_t m, int d, int64_t *idx_out,
+                            float *sim_out, void *ws, size_t ws_bytes, vfm_stream_t stream);
 
 /* valid = !(D < min_cosine_similarity) (VHM:501-511), survivors in query order (VHM:587-600).
  * keep_out[k] = query index of the k-th survivor, *count_out = K.  corres_out (nullable,

@@ -8,7 +8,15 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "vfm-registration_amd"))
 import torch  # noqa: E402
 
+import os  # noqa: E402
+
+from vfmreg import _lib  # noqa: E402
+
+if os.environ.get("VFM_LIB"):  # experimental build (tools/build_ablate.sh)
+    _lib.LIB_PATH = ROOT / "vfm-registration_amd" / "vfmreg" / "lib" / os.environ["VFM_LIB"]
 from vfmreg import ops, synth  # noqa: E402
+
+_lib.load().vfm_debug_set_coarse_variant(int(os.environ.get("VFM_VARIANT", "0")))
 
 n, m, d = 20000, 200000, 384
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
@@ -16,4 +24,4 @@ p = synth.make_pair_device(n, m, d, seed=42)
 for _ in range(reps):
     idx, sim = ops.match_ip_top1(p["q_desc"], p["b_desc"], ops.FAST)
 torch.cuda.synchronize()
-print("ok", int((idx == p["match"]).sum()))
+print("ok", int((idx == p["match"]).sum()))  # meaningless for ablated builds

@@ -38,6 +38,9 @@ constexpr int ring_depth(int ksteps) { return ksteps <= 24 ? 6 : 4; }
 constexpr int CAND_CAP = 40;      // candidate chunks kept per query before falling back
 constexpr float COARSE_OFFSET = 2.0f;   // accumulators start here: every coarse score is a
                                         // positive normal float, so uint order == float order
+#ifndef VFM_COARSE_PF
+#define VFM_COARSE_PF 0
+#endif
 constexpr float DEFAULT_WINDOW = 2.5e-3f;  // >= 2E, E = proven |coarse - exact| bound
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -265,6 +268,25 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
     for (int j = 0; j < QSETS; ++j) s1[j] = s2[j] = runmax[j] = 0u;
     const int hi = lane >> 5;
 
+    // end of a 128-row chunk: merge the two half-waves and emit the chunk's top-2 for 32 queries
+    auto fold_tail = [&](int it, auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        const unsigned o1 = __shfl_xor(s1[J], 32), o2 = __shfl_xor(s2[J], 32);
+        const bool own = (s1[J] > o1) || (s1[J] == o1 && hi == 0);
+        const unsigned w1 = own ? s1[J] : o1;
+        const int wh = own ? hi : (1 - hi);
+        const unsigned w2 = max(max(s2[J], o2), min(s1[J], o1));
+        const int code = 63 - (int)(w1 & 63u);
+        const int li = (code >> 4) * 32 + (code & 3) + 8 * ((code & 15) >> 2) + 4 * wh;
+        const int qt = qt0 + J;
+        if (lane < 32 && qt < a.nq_tiles && it >= 0) {  // it < 0: the dummy fold of the very first step
+            const int chunk = c0 + (it >> 2);
+            a.partials[(size_t)chunk * a.npad + (size_t)qt * 32 + lane] = make_uint2((w1 & ~127u) | (unsigned)li, w2);
+            if (chunk < a.first_pad_chunk) runmax[J] = max(runmax[J], w1 & ~127u);
+        }
+        s1[J] = 0u;
+        s2[J] = 0u;
+    };
     // epilogue of one finished 32 x 32 accumulator tile: fold into the chunk's running top-2.
     // Branch-free on purpose (3 VALU ops per element) so that the scheduler can issue it inside
     // the next step's MFMA cluster.  Zero-padded map rows (score exactly 2.0) are NOT masked
@@ -278,23 +300,7 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
             s2[J] = umed3(s1[J], s2[J], pk);
             s1[J] = max(s1[J], pk);
         }
-        if constexpr (TT == 3) {
-            const unsigned o1 = __shfl_xor(s1[J], 32), o2 = __shfl_xor(s2[J], 32);
-            const bool own = (s1[J] > o1) || (s1[J] == o1 && hi == 0);
-            const unsigned w1 = own ? s1[J] : o1;
-            const int wh = own ? hi : (1 - hi);
-            const unsigned w2 = max(max(s2[J], o2), min(s1[J], o1));
-            const int code = 63 - (int)(w1 & 63u);
-            const int li = (code >> 4) * 32 + (code & 3) + 8 * ((code & 15) >> 2) + 4 * wh;
-            const int qt = qt0 + J;
-            if (lane < 32 && qt < a.nq_tiles && it >= 0) {  // it < 0: the dummy fold of the very first step
-                const int chunk = c0 + (it >> 2);
-                a.partials[(size_t)chunk * a.npad + (size_t)qt * 32 + lane] = make_uint2((w1 & ~127u) | (unsigned)li, w2);
-                if (chunk < a.first_pad_chunk) runmax[J] = max(runmax[J], w1 & ~127u);
-            }
-            s1[J] = 0u;
-            s2[J] = 0u;
-        }
+        if constexpr (TT == 3) fold_tail(it, Jc);
     };
 
     // one step = 2 map tiles (64 rows): 2 * QSETS independent accumulator chains per wave, one
@@ -330,9 +336,47 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
                 acc[j][0][r] = COARSE_OFFSET;
                 acc[j][1][r] = COARSE_OFFSET;
             }
+        if constexpr (QSETS == 1 && VFM_COARSE_PF > 0) {
+        // pinned software pipeline (QSETS == 1): fragment reads run PF k-steps ahead of the MFMAs that
+        // consume them and the deferred fold is spread over the slots; sched_barrier keeps the slots apart
+        constexpr int PF = VFM_COARSE_PF > 0 ? VFM_COARSE_PF : 1;
+        uint4 r0[PF], r1[PF];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            r0[s] = buf0[s * 64];
+            r1[s] = buf1[s * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&r0[s % PF]), qf[0][s], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&r1[s % PF]), qf[0][s], acc[0][1], 0, 0, 0);
+            if (s + PF < KSTEPS) {
+                r0[s % PF] = buf0[(s + PF) * 64];
+                r1[s % PF] = buf1[(s + PF) * 64];
+            }
+#pragma unroll
+            for (int e = s * 32 / KSTEPS; e < (s + 1) * 32 / KSTEPS; ++e) {
+                const int TTe = 2 * (1 - H) + (e >> 4);
+                const unsigned pk = (__float_as_uint(prev[0][e >> 4][e & 15]) & 0xFFFFFFC0u) | (unsigned)(63 - (TTe * 16 + (e & 15)));
+                s2[0] = umed3(s1[0], s2[0], pk);
+                s1[0] = max(s1[0], pk);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (H == 0) fold_tail(it - 1, std::integral_constant<int, 0>{});
+        prev[0][0] = acc[0][0];
+        prev[0][1] = acc[0][1];
+        return;
+        }
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+#ifdef VFM_ABLATE_LDS
+            uint4 v0 = *reinterpret_cast<const uint4*>(&qf[0][(s + 1) % KSTEPS]), v1 = *reinterpret_cast<const uint4*>(&qf[0][(s + 2) % KSTEPS]);
+            (void)buf0; (void)buf1;
+#else
             uint4 v0 = buf0[s * 64], v1 = buf1[s * 64];
+#endif
 #pragma unroll
             for (int j = 0; j < QSETS; ++j) {
                 acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&v0), qf[j][s], acc[j][0], 0, 0, 0);
@@ -377,6 +421,177 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
 #pragma unroll
     for (int j = 0; j < QSETS; ++j)
         if (lane < 32 && qt0 + j < a.nq_tiles) atomicMax(a.qmax + (size_t)(qt0 + j) * 32 + lane, runmax[j]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// coarse pass, pipelined across the step barrier (default for d <= 384)
+//
+// Same tiles, ring, fold and results as match_coarse_kernel<KSTEPS, 1>; what changes is the order
+// of work around the one barrier per step.  PMC showed the old kernel's waves 34 % of their time
+// in s_waitcnt/s_barrier with the LDS only 34 % busy: after each barrier BOTH waves of a SIMD ran
+// the serial restart (ring arithmetic, DMA issue, first ds_read latency) while the matrix pipe
+// idled.  Here
+//   * map tiles land one step early (s_waitcnt vmcnt(0) at the top of step i covers the tiles of
+//     step i+1), so the last PF slots of step i read the first PF fragments of step i+1: the
+//     MFMAs after the barrier start from registers;
+//   * fragment reads run PF k-steps ahead of their MFMAs, the deferred top-2 fold of step i-1 is
+//     spread over the slots, the LDS-DMA of step i+2's tiles is issued from slot 1;
+//     __builtin_amdgcn_sched_barrier(0) keeps the slots apart;
+//   * ring offsets are carried incrementally (no division in the loop).
+// Ring of 6 tiles: step i computes on (i, i+1), prefetches from (i+2, i+3), DMA fills (i+4, i+5)
+// = the slots of (i-2, i-1), whose last read retired before the barrier of step i.
+// ---------------------------------------------------------------------------------------------
+template <int KSTEPS>
+__global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NWAVES = 8;
+    constexpr int TILE_U4 = KSTEPS * 64;
+    constexpr int TILE_BYTES = TILE_U4 * 16;
+    constexpr int PASSES = KSTEPS / NWAVES;
+    constexpr int NBUF = 6;
+    constexpr int PF = 4;
+    static_assert(KSTEPS % 8 == 0 && KSTEPS <= 24, "d must be a multiple of 128, at most 384");
+    static_assert(KSTEPS % PF == 0 && KSTEPS >= 2 * PF, "fragment ring must align across steps");
+
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // XCD-aware unit mapping (see match_coarse_kernel)
+    const int total = a.nqb * a.nslices;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, within = bid >> 3;
+    const int qn = total >> 3, rn = total & 7;
+    const int unit = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + within;
+    const int slice = unit / a.nqb;
+    const int qb = unit - slice * a.nqb;
+    const int c0 = (int)(((long long)slice * a.nchunks) / a.nslices);
+    const int c1 = (int)(((long long)(slice + 1) * a.nchunks) / a.nslices);
+    const int ntiles = (c1 - c0) * 4;
+    const int qt = qb * 8 + wave;  // this wave's 32-query tile
+
+    const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS unsigned char*)smem;
+    // this wave's pieces of one tile: global source of piece p = src + p * NWAVES * 64, LDS p * NWAVES KiB on
+    const uint4* gsrc = a.Bh + (size_t)c0 * 4 * TILE_U4 + wave * 64 + lane;
+    const unsigned ldst0 = lds_base + (unsigned)wave * 1024u;
+    auto stage = [&](const uint4* src, unsigned ring_byte) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p)
+            glds16(src + p * NWAVES * 64, __builtin_amdgcn_readfirstlane(ldst0 + ring_byte + (unsigned)(p * NWAVES) * 1024u));
+    };
+
+    half8 qf[KSTEPS];
+    {
+        const uint4* qsrc = a.Qh + (size_t)(qt < a.nq_tiles ? qt : 0) * TILE_U4 + lane;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            uint4 v = qsrc[s * 64];
+            qf[s] = *reinterpret_cast<half8*>(&v);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)  // ntiles >= 4 (whole chunks)
+        stage(gsrc + (size_t)i * TILE_U4, (unsigned)(i * TILE_BYTES));
+    const uint4* gnext = gsrc + (size_t)4 * TILE_U4;  // next tile to stage
+
+    unsigned s1 = 0u, s2 = 0u, runmax = 0u;
+    const int hi = lane >> 5;
+    auto fold_tail = [&](int it) {
+        const unsigned o1 = __shfl_xor(s1, 32), o2 = __shfl_xor(s2, 32);
+        const bool own = (s1 > o1) || (s1 == o1 && hi == 0);
+        const unsigned w1 = own ? s1 : o1;
+        const int wh = own ? hi : (1 - hi);
+        const unsigned w2 = max(max(s2, o2), min(s1, o1));
+        const int code = 63 - (int)(w1 & 63u);
+        const int li = (code >> 4) * 32 + (code & 3) + 8 * ((code & 15) >> 2) + 4 * wh;
+        if (lane < 32 && qt < a.nq_tiles && it >= 0) {  // it < 0: the dummy fold of the very first step
+            const int chunk = c0 + (it >> 2);
+            a.partials[(size_t)chunk * a.npad + (size_t)qt * 32 + lane] = make_uint2((w1 & ~127u) | (unsigned)li, w2);
+            if (chunk < a.first_pad_chunk) runmax = max(runmax, w1 & ~127u);
+        }
+        s1 = 0u;
+        s2 = 0u;
+    };
+    auto fold_one = [&](float v, int code) {
+        const unsigned pk = (__float_as_uint(v) & 0xFFFFFFC0u) | (unsigned)(63 - code);
+        s2 = umed3(s1, s2, pk);
+        s1 = max(s1, pk);
+    };
+
+    floatx16 prev0, prev1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) prev0[r] = prev1[r] = 0.f;
+
+    // fragment ring registers: slot s of a step consumes r0/r1[s % PF]
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    uint4 r0[PF], r1[PF];
+    {
+        const uint4* b0 = reinterpret_cast<const uint4*>(smem) + lane;
+        const uint4* b1 = reinterpret_cast<const uint4*>(smem + TILE_BYTES) + lane;
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            r0[s] = b0[s * 64];
+            r1[s] = b1[s * 64];
+        }
+    }
+    unsigned ring = 0u;  // ring slot of tile `it` (even, 0 .. NBUF - 2)
+
+    auto do_step = [&](int it, auto Hc) {
+        constexpr int H = decltype(Hc)::value;  // which half of the 4-tile chunk
+        // every wave's pieces of tiles it+2, it+3 (issued during the previous step) have landed
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned ring2 = ring + 2u >= (unsigned)NBUF ? ring + 2u - NBUF : ring + 2u;   // tiles it+2, it+3
+        const unsigned ring4 = ring2 + 2u >= (unsigned)NBUF ? ring2 + 2u - NBUF : ring2 + 2u;  // tiles it+4, it+5
+        const uint4* cur0 = reinterpret_cast<const uint4*>(smem + ring * TILE_BYTES) + lane;
+        const uint4* cur1 = cur0 + TILE_U4;
+        const uint4* nxt0 = reinterpret_cast<const uint4*>(smem + ring2 * TILE_BYTES) + lane;
+        const uint4* nxt1 = nxt0 + TILE_U4;
+        floatx16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = COARSE_OFFSET;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&r0[s % PF]), qf[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&r1[s % PF]), qf[s], acc1, 0, 0, 0);
+            if (s + PF < KSTEPS) {
+                r0[s % PF] = cur0[(s + PF) * 64];
+                r1[s % PF] = cur1[(s + PF) * 64];
+            } else {  // first fragments of the next step (stale data after the last step: unused)
+                r0[s % PF] = nxt0[(s + PF - KSTEPS) * 64];
+                r1[s % PF] = nxt1[(s + PF - KSTEPS) * 64];
+            }
+            // deferred fold of the previous step's two tiles, spread over the slots
+#pragma unroll
+            for (int e = s * 32 / KSTEPS; e < (s + 1) * 32 / KSTEPS; ++e)
+                fold_one(e < 16 ? prev0[e & 15] : prev1[e & 15], (2 * (1 - H) + (e >> 4)) * 16 + (e & 15));
+            if (s == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + 4 < ntiles) {  // uniform; ntiles is a multiple of 4
+                    stage(gnext, ring4 * TILE_BYTES);
+                    stage(gnext + TILE_U4, (ring4 + 1u) * TILE_BYTES);
+                }
+                gnext += 2 * TILE_U4;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (H == 0) fold_tail(it - 1);
+        prev0 = acc0;
+        prev1 = acc1;
+        ring = ring2;
+    };
+
+    for (int it = 0; it < ntiles; it += 4) {
+        do_step(it, std::integral_constant<int, 0>{});
+        do_step(it + 2, std::integral_constant<int, 1>{});
+    }
+#pragma unroll
+    for (int e = 0; e < 32; ++e) fold_one(e < 16 ? prev0[e & 15] : prev1[e & 15], (2 + (e >> 4)) * 16 + (e & 15));
+    fold_tail(ntiles - 1);
+    if (lane < 32 && qt < a.nq_tiles) atomicMax(a.qmax + (size_t)qt * 32 + lane, runmax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -756,7 +971,22 @@ inline int choose_slices(int nqb, int nchunks) {
 // profiling hook (vfm_prof_arm): events recorded around the next coarse launch on this thread
 thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 
-int g_coarse_qsets = 0;  // 0 = default per d; set through vfm_debug_set_coarse_variant for A/B runs
+// 0 = default (pipelined kernel for d <= 384); 1 = match_coarse_kernel<.,1>; 2 = match_coarse_kernel<.,2>;
+// set through vfm_debug_set_coarse_variant for A/B runs
+int g_coarse_qsets = 0;
+
+template <int KSTEPS>
+int launch_coarse_pipe(const CoarseArgs& a, hipStream_t st) {
+    const int lds = 6 * KSTEPS * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_pipe_kernel<KSTEPS>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((match_coarse_pipe_kernel<KSTEPS>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
+    return VFM_OK;
+}
 
 template <int KSTEPS, int QSETS>
 int launch_coarse_v(const CoarseArgs& a, hipStream_t st) {
@@ -776,7 +1006,9 @@ int launch_coarse(const CoarseArgs& a, hipStream_t st) {
     if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
     int rc;
     if constexpr (KSTEPS <= 24) {
-        rc = (g_coarse_qsets == 2) ? launch_coarse_v<KSTEPS, 2>(a, st) : launch_coarse_v<KSTEPS, 1>(a, st);
+        rc = (g_coarse_qsets == 2)   ? launch_coarse_v<KSTEPS, 2>(a, st)
+             : (g_coarse_qsets == 1) ? launch_coarse_v<KSTEPS, 1>(a, st)
+                                     : launch_coarse_pipe<KSTEPS>(a, st);
     } else {
         rc = launch_coarse_v<KSTEPS, 1>(a, st);  // d = 512: 2 x 128 query VGPRs would not fit
     }
@@ -796,11 +1028,7 @@ int do_prepare(const float* x, int64_t rows, int d, void* prepared, hipStream_t 
     return VFM_OK;
 }
 
-int do_search(const float* q, const void* qprep, int64_t n, const float* b, const void* bprep, int64_t m, int d,
-              int64_t* idx_out, float* sim_out, void* ws, hipStream_t st) {
-    Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
-    Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
-    SearchWs w = carve_search(ws, n, m);
+CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, int64_t n, int64_t m) {
     const int64_t npad = rows_padded(n), mpad = rows_padded(m);
     CoarseArgs a;
     a.Qh = Q.tiles;
@@ -814,8 +1042,17 @@ int do_search(const float* q, const void* qprep, int64_t n, const float* b, cons
     a.nslices = choose_slices(a.nqb, a.nchunks);
     a.qmax = w.qmax;
     a.first_pad_chunk = (int)(m / CHUNK_ROWS);
+    return a;
+}
+
+// stage 1 of a search: the MFMA coarse pass (fills ws: partials + per-query coarse maxima)
+int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, hipStream_t st) {
+    Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
+    Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
+    SearchWs w = carve_search(ws, n, m);
+    const CoarseArgs a = coarse_args(Q, B, w, n, m);
     VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, sizeof(int), st));
-    VFM_CHECK_HIP(hipMemsetAsync(w.qmax, 0, (size_t)npad * sizeof(unsigned), st));
+    VFM_CHECK_HIP(hipMemsetAsync(w.qmax, 0, (size_t)a.npad * sizeof(unsigned), st));
     int rc;
     switch (d / 16) {
         case 8: rc = launch_coarse<8>(a, st); break;
@@ -824,7 +1061,16 @@ int do_search(const float* q, const void* qprep, int64_t n, const float* b, cons
         case 32: rc = launch_coarse<32>(a, st); break;
         default: return vfm_fail(VFM_EINVAL, "FAST matching supports d in {128,256,384,512}, got %d", d);
     }
-    if (rc) return rc;
+    return rc;
+}
+
+// stage 2 of a search: candidate selection + exact fp64 decision (reads ws of stage 1)
+int do_search_finish(const float* q, const void* qprep, int64_t n, const float* b, const void* bprep, int64_t m, int d,
+                     int64_t* idx_out, float* sim_out, void* ws, hipStream_t st) {
+    Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
+    Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
+    SearchWs w = carve_search(ws, n, m);
+    const CoarseArgs a = coarse_args(Q, B, w, n, m);
     hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, w.partials, a.nchunks,
                        a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.fb_count, w.fb_list);
     VFM_CHECK_LAUNCH("match_select_kernel");
@@ -835,6 +1081,13 @@ int do_search(const float* q, const void* qprep, int64_t n, const float* b, cons
                        b, B.inv, n, m, d, w.fb_list, w.fb_count, idx_out, sim_out);
     VFM_CHECK_LAUNCH("match_exact_kernel(fallback)");
     return VFM_OK;
+}
+
+int do_search(const float* q, const void* qprep, int64_t n, const float* b, const void* bprep, int64_t m, int d,
+              int64_t* idx_out, float* sim_out, void* ws, hipStream_t st) {
+    const int rc = do_search_coarse(qprep, n, bprep, m, d, ws, st);
+    if (rc) return rc;
+    return do_search_finish(q, qprep, n, b, bprep, m, d, idx_out, sim_out, ws, st);
 }
 
 }  // namespace
@@ -875,6 +1128,29 @@ VFM_EXPORT int vfm_match_search_prepared(const float* q, const void* q_prepared,
     VFM_CHECK_ARG(m < (1ll << 31) - 256 && n < (1ll << 31) - 256, "search: more than 2^31 rows");
     if (ws_bytes < vfm_match_search_workspace_bytes(n, m, d)) return vfm_fail(VFM_EWORKSPACE, "search: workspace too small");
     return do_search(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream);
+}
+
+static int check_search_args(int64_t n, int64_t m, int d, size_t ws_bytes) {
+    VFM_CHECK_ARG(n > 0 && m > 0, "search: empty operand (n=%lld m=%lld)", (long long)n, (long long)m);
+    VFM_CHECK_ARG(d % 128 == 0 && d >= 128 && d <= 512, "search: d must be in {128,256,384,512}");
+    VFM_CHECK_ARG(m < (1ll << 31) - 256 && n < (1ll << 31) - 256, "search: more than 2^31 rows");
+    if (ws_bytes < vfm_match_search_workspace_bytes(n, m, d)) return vfm_fail(VFM_EWORKSPACE, "search: workspace too small");
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_match_search_coarse(const void* q_prepared, int64_t n, const void* b_prepared, int64_t m, int d,
+                                       void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
+    VFM_CHECK_ARG(q_prepared && b_prepared && ws, "search_coarse: null pointer");
+    return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream);
+}
+
+VFM_EXPORT int vfm_match_search_finish(const float* q, const void* q_prepared, int64_t n, const float* b,
+                                       const void* b_prepared, int64_t m, int d, int64_t* idx_out, float* sim_out,
+                                       void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
+    VFM_CHECK_ARG(q && b && q_prepared && b_prepared && ws && idx_out && sim_out, "search_finish: null pointer");
+    return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream);
 }
 
 VFM_EXPORT size_t vfm_match_ip_top1_workspace_bytes(int64_t n, int64_t m, int d, int prec_mode) {

@@ -9,11 +9,12 @@ host synchronisation:
 
 Buffers are allocated once for fixed (N, M, D); ``register`` only enqueues work.
 
-``overlap_ransac=True`` turns the chain into a two-stage pipeline over independent scene pairs: the
-matching kernels of pair i+1 (matrix cores) run on the caller's stream while the RANSAC of pair i
-(fp64 vector ALU) runs on a second HIP stream; events order the hand-off and two result sets
-ping-pong, so results of pair i stay valid until pair i+2 is enqueued.  Matching kernels never
-overlap each other.
+``overlap_ransac=True`` turns the chain into a two-stage pipeline over independent scene pairs:
+stage 1 (caller's stream) = normalise/convert + the fp16 MFMA coarse pass of pair i+1 -- the matrix
+cores; stage 2 (a second HIP stream) = candidate selection, exact fp64 re-decision, threshold /
+compaction and RANSAC of pair i -- vector ALU and fp64.  Events order the hand-off and two complete
+buffer sets (prepared operands, search workspace, results) ping-pong, so results of pair i stay
+valid until pair i+2 is enqueued.  Coarse passes never overlap each other.
 """
 from __future__ import annotations
 
@@ -25,7 +26,12 @@ from . import _lib, ops
 
 
 class _ResultSet:
-    def __init__(self, n: int, dev):
+    def __init__(self, n: int, dev, qprep_bytes: int, bprep_bytes: int, sws_bytes: int):
+        u8 = torch.uint8
+        self.qprep = torch.empty(qprep_bytes, dtype=u8, device=dev)
+        self.bprep = torch.empty(bprep_bytes, dtype=u8, device=dev)
+        self.sws = torch.empty(sws_bytes, dtype=u8, device=dev)
+        self.map_key: Optional[int] = None
         self.idx = torch.empty(n, dtype=torch.int64, device=dev)
         self.sim = torch.empty(n, dtype=torch.float32, device=dev)
         self.keep = torch.empty(n, dtype=torch.int64, device=dev)
@@ -48,23 +54,28 @@ class RegistrationPipeline:
         self.device = torch.device(device)
         dev = self.device
         u8 = torch.uint8
-        self.qprep = torch.empty(lib.vfm_match_prepared_bytes(n, d), dtype=u8, device=dev)
-        self.bprep = torch.empty(lib.vfm_match_prepared_bytes(m, d), dtype=u8, device=dev)
-        self.sws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=u8, device=dev)
         self.rws = torch.empty(lib.vfm_ransac_workspace_bytes(n, n_iter), dtype=u8, device=dev)
         self.overlap = bool(overlap_ransac)
-        self.sets = [_ResultSet(n, dev) for _ in range(2 if self.overlap else 1)]
+        sizes = (lib.vfm_match_prepared_bytes(n, d), lib.vfm_match_prepared_bytes(m, d),
+                 lib.vfm_match_search_workspace_bytes(n, m, d))
+        self.sets = [_ResultSet(n, dev, *sizes) for _ in range(2 if self.overlap else 1)]
         self.ransac_stream = torch.cuda.Stream(device=dev) if self.overlap else None
         self._step = 0
-        self._map_key: Optional[int] = None
 
     def prepare_map(self, b_desc: torch.Tensor) -> None:
-        """IndexFlatIP.add: normalise + convert the map once (it is immutable per scene)."""
+        """IndexFlatIP.add: normalise + convert the map once (it is immutable per scene); every buffer
+        set gets its own copy so that ``register(..., reuse_map=True)`` never re-prepares."""
         lib = _lib.load()
         ops._chk(b_desc, torch.float32, "b_desc")
-        _lib.check(lib.vfm_match_prepare(b_desc.data_ptr(), self.m, self.d, self.bprep.data_ptr(), ops._stream()),
-                   "prepare(map)")
-        self._map_key = b_desc.data_ptr()
+        if b_desc.shape != (self.m, self.d):
+            raise ValueError("Invalid shape")
+        main = torch.cuda.current_stream()
+        for r in self.sets:
+            if r.done is not None:
+                main.wait_event(r.done)
+            _lib.check(lib.vfm_match_prepare(b_desc.data_ptr(), self.m, self.d, r.bprep.data_ptr(), main.cuda_stream),
+                       "prepare(map)")
+            r.map_key = b_desc.data_ptr()
 
     def synchronize(self) -> None:
         """Make the caller's current stream wait for every RANSAC issued on the side stream."""
@@ -86,21 +97,24 @@ class RegistrationPipeline:
         st = main.cuda_stream
         if self.overlap and r.done is not None:
             main.wait_event(r.done)  # the RANSAC that last read this set has finished
-        if not (reuse_map and self._map_key == b_desc.data_ptr()):
-            self.prepare_map(b_desc)
-        _lib.check(lib.vfm_match_prepare(q_desc.data_ptr(), self.n, self.d, self.qprep.data_ptr(), st), "prepare(scan)")
-        _lib.check(lib.vfm_match_search_prepared(q_desc.data_ptr(), self.qprep.data_ptr(), self.n, b_desc.data_ptr(),
-                                                 self.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(),
-                                                 r.sim.data_ptr(), self.sws.data_ptr(), self.sws.numel(), st), "search")
-        _lib.check(lib.vfm_threshold_compact(r.sim.data_ptr(), r.idx.data_ptr(), self.n, float(self.min_cosine),
-                                             r.keep.data_ptr(), r.count.data_ptr(), r.corres.data_ptr(),
-                                             None, None, None, None, st), "threshold_compact")
+        if not (reuse_map and r.map_key == b_desc.data_ptr()):
+            _lib.check(lib.vfm_match_prepare(b_desc.data_ptr(), self.m, self.d, r.bprep.data_ptr(), st), "prepare(map)")
+            r.map_key = b_desc.data_ptr() if reuse_map else None
+        _lib.check(lib.vfm_match_prepare(q_desc.data_ptr(), self.n, self.d, r.qprep.data_ptr(), st), "prepare(scan)")
+        _lib.check(lib.vfm_match_search_coarse(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
+                                               r.sws.data_ptr(), r.sws.numel(), st), "search(coarse)")
         rst = st
-        if self.overlap:
+        if self.overlap:  # hand over to stage 2
             ev = torch.cuda.Event()
             ev.record(main)
             self.ransac_stream.wait_event(ev)
             rst = self.ransac_stream.cuda_stream
+        _lib.check(lib.vfm_match_search_finish(q_desc.data_ptr(), r.qprep.data_ptr(), self.n, b_desc.data_ptr(),
+                                               r.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(), r.sim.data_ptr(),
+                                               r.sws.data_ptr(), r.sws.numel(), rst), "search(finish)")
+        _lib.check(lib.vfm_threshold_compact(r.sim.data_ptr(), r.idx.data_ptr(), self.n, float(self.min_cosine),
+                                             r.keep.data_ptr(), r.count.data_ptr(), r.corres.data_ptr(),
+                                             None, None, None, None, rst), "threshold_compact")
         _lib.check(lib.vfm_ransac_corr(q_xyz.data_ptr(), b_xyz.data_ptr(), r.corres.data_ptr(), r.count.data_ptr(),
                                        self.n, float(self.max_corr_dist), int(self.n_iter), int(self.seed),
                                        r.T.data_ptr(), r.fitness.data_ptr(), r.rmse.data_ptr(),
