@@ -254,6 +254,28 @@ def test_ransac_two_level_equals_exact(ops, orc, n_corr, outlier, noise, max_dis
         np.testing.assert_array_equal(out["mask"][:n_corr].cpu().numpy(), ref.inlier_mask)
 
 
+@pytest.mark.parametrize("n_corr,outlier,noise,offset,max_dist,n_iter", [
+    (10000, 0.0, 0.02, 0.0, 10000.0, 20000),     # the reference's regime at C2 scale: all-inlier closed-form prefilter
+    (4000, 0.5, 0.02, 0.0, 10000.0, 8000),       # half the pairs wrong: every hypothesis still "all inliers", large E
+    (3000, 0.0, 0.02, 3.0e5, 1.0e7, 5000),       # UTM-like coordinates: heavy cancellation in the moments
+    (3000, 0.0, 1e-7, 0.0, 10000.0, 5000),       # near-perfect data: E ~ 1e-10, thousands of near-ties
+    (2500, 0.2, 0.02, 0.0, 260.0, 4000),         # threshold near the scene extent: some hypotheses provable, some not
+    (1200, 0.3, 0.05, 50.0, 10000.0, 64)])
+def test_ransac_moment_prefilter_equals_exact(ops, orc, n_corr, outlier, noise, offset, max_dist, n_iter):
+    """closed-form (second-moment) bounds on the all-inlier RMSE are only a prefilter: the result must be
+    what scoring every hypothesis in the oracle's order returns, bit for bit"""
+    src, tgt, corres, _ = _ransac_case(n_corr, outlier, seed=n_corr + n_iter, noise=noise)
+    src = src + offset
+    tgt = tgt + np.array([offset, -2.0 * offset, 0.25 * offset])
+    ref = orc.ransac_corr(src, tgt, corres, max_dist, n_iter, seed=11)
+    out = ops.ransac_corr(dev(src), dev(tgt), dev(corres), max_dist, n_iter, seed=11)
+    torch.cuda.synchronize()
+    assert out["best_hyp"].item() == ref.best_hyp
+    np.testing.assert_array_equal(out["T"].cpu().numpy(), ref.transformation)
+    assert out["fitness"].item() == ref.fitness and out["rmse"].item() == ref.inlier_rmse
+    np.testing.assert_array_equal(out["mask"][:n_corr].cpu().numpy(), ref.inlier_mask)
+
+
 def test_ransac_device_count_and_degenerate(ops, orc):
     src, tgt, corres, _ = _ransac_case(800, 0.3, seed=9)
     cnt = torch.tensor([500], dtype=torch.int64, device="cuda")

@@ -598,7 +598,8 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
 // selection: coarse max per query and the candidate chunks inside the error window
 // cand entry: (chunk << 8) | (rescan << 7) | local row
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void match_select_kernel(const uint2* __restrict__ partials, int nchunks, int npad,
+constexpr int SELECT_GROUPS = 16;  // waves per 64 queries: enough loads in flight to saturate HBM on the sweep
+__global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const uint2* __restrict__ partials, int nchunks, int npad,
                                                            int64_t n, int first_pad_chunk,
                                                            const unsigned* __restrict__ qmax,
                                                            const float* __restrict__ invq, float window,
@@ -619,16 +620,16 @@ __global__ __launch_bounds__(256) void match_select_kernel(const uint2* __restri
     const float thr_f = __uint_as_float(m) - window;
     const unsigned thr = (m == 0u) ? 0u : (__float_as_uint(thr_f) & ~127u);
     // HBM-bound sweep over this query's records: 8 independent loads in flight per thread
-    for (int cb = g; cb < nchunks; cb += 32) {
+    for (int cb = g; cb < nchunks; cb += 8 * SELECT_GROUPS) {
         uint2 rec[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int c = cb + 4 * u;
+            const int c = cb + SELECT_GROUPS * u;
             rec[u] = (c < nchunks) ? partials[(size_t)c * npad + q] : make_uint2(0u, 0u);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int c = cb + 4 * u;
+            const int c = cb + SELECT_GROUPS * u;
             if (c < nchunks && (rec[u].x | 127u) >= thr) {
                 const int slot = atomicAdd(&lcnt[qq], 1);
                 if (slot < CAND_CAP) {
@@ -1071,7 +1072,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
     SearchWs w = carve_search(ws, n, m);
     const CoarseArgs a = coarse_args(Q, B, w, n, m);
-    hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, w.partials, a.nchunks,
+    hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS), 0, st, w.partials, a.nchunks,
                        a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.fb_count, w.fb_list);
     VFM_CHECK_LAUNCH("match_select_kernel");
     hipLaunchKernelGGL(match_rescore_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)d * 4 * 8, st, q, Q.inv, b,

@@ -460,6 +460,14 @@ constexpr int CAND_MAX = 2048;
 struct RansacStats {
     double cs[3], cq[3];  // centroids of the gathered source / target points
     double M;             // max |centred coordinate|
+    // second moments of the centred stream sigma_i = s_i - cs, kappa_i = q_i - cq (closed-form score
+    // of the all-inlier regime, ransac_moment_kernel)
+    double Sss[6];         // sum sigma_b sigma_c: xx, xy, xz, yy, yz, zz
+    double K[9];           // sum kappa_a sigma_b, row-major [a][b]
+    double Akk;            // sum |kappa|^2
+    double sbar[3], kbar[3];  // sum sigma, sum kappa (~0)
+    double Xs, Xq;         // max |raw coordinate| of source / target
+    double gm;             // terms per partial sum of the moment reductions (rounding-error constant)
 };
 
 // one workgroup: centroids, extent, and the centred fp32 copy of the correspondence stream
@@ -485,27 +493,73 @@ __global__ __launch_bounds__(1024) void ransac_center_kernel(const double* __res
     }
     if (t < 6) cen[t] = (C > 0) ? red[t][0] / (double)C : 0.0;
     __syncthreads();
-    double m = 0.0;
-    for (int64_t i = t; i < C; i += 1024)
+    double m = 0.0, xs = 0.0, xq = 0.0;
+    double mom[22];  // Sss (6), K (9), Akk, sbar (3), kbar (3)
+#pragma unroll
+    for (int k = 0; k < 22; ++k) mom[k] = 0.0;
+    for (int64_t i = t; i < C; i += 1024) {
+        double v[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            const double v = pts[6 * i + c] - cen[c];
-            pts32[6 * i + c] = (float)v;
-            m = fmax(m, fabs(v));
+            const double raw = pts[6 * i + c];
+            v[c] = raw - cen[c];
+            pts32[6 * i + c] = (float)v[c];
+            m = fmax(m, fabs(v[c]));
+            if (c < 3) xs = fmax(xs, fabs(raw)); else xq = fmax(xq, fabs(raw));
         }
-    __syncthreads();
-    red[0][t] = m;
-    __syncthreads();
-    for (int stride = 512; stride >= 1; stride >>= 1) {
-        if (t < stride) red[0][t] = fmax(red[0][t], red[0][t + stride]);
-        __syncthreads();
+        mom[0] += v[0] * v[0]; mom[1] += v[0] * v[1]; mom[2] += v[0] * v[2];
+        mom[3] += v[1] * v[1]; mom[4] += v[1] * v[2]; mom[5] += v[2] * v[2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) mom[6 + 3 * a + b] += v[3 + a] * v[b];
+        mom[15] += (v[3] * v[3] + v[4] * v[4]) + v[5] * v[5];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            mom[16 + c] += v[c];
+            mom[19 + c] += v[3 + c];
+        }
     }
+    // wave butterflies (order-symmetric, deterministic), then 16 partials per quantity in LDS
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 22; ++k) mom[k] += __shfl_xor(mom[k], off);
+        m = fmax(m, __shfl_xor(m, off));
+        xs = fmax(xs, __shfl_xor(xs, off));
+        xq = fmax(xq, __shfl_xor(xq, off));
+    }
+    __syncthreads();  // red[] is free again
+    if ((t & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 22; ++k) red[0][(t >> 6) * 32 + k] = mom[k];
+        red[0][(t >> 6) * 32 + 22] = m;
+        red[0][(t >> 6) * 32 + 23] = xs;
+        red[0][(t >> 6) * 32 + 24] = xq;
+    }
+    __syncthreads();
+    if (t < 25) {
+        double acc1 = red[0][t];
+        for (int w = 1; w < 16; ++w) acc1 = (t < 22) ? acc1 + red[0][w * 32 + t] : fmax(acc1, red[0][w * 32 + t]);
+        red[1][t] = acc1;
+    }
+    __syncthreads();
     if (t == 0) {
         for (int c = 0; c < 3; ++c) {
             stats->cs[c] = cen[c];
             stats->cq[c] = cen[3 + c];
         }
-        stats->M = red[0][0];
+        stats->M = red[1][22];
+        for (int k = 0; k < 6; ++k) stats->Sss[k] = red[1][k];
+        for (int k = 0; k < 9; ++k) stats->K[k] = red[1][6 + k];
+        stats->Akk = red[1][15];
+        for (int k = 0; k < 3; ++k) {
+            stats->sbar[k] = red[1][16 + k];
+            stats->kbar[k] = red[1][19 + k];
+        }
+        stats->Xs = red[1][23];
+        stats->Xq = red[1][24];
+        stats->gm = (double)((C + 1023) / 1024) + 32.0;  // per-thread terms + butterfly (6) + partials (16) + products / centring
     }
 }
 
@@ -514,7 +568,7 @@ struct SelectState {           // zeroed per call (Rbits = +inf)
     int count;                 // candidates appended
     unsigned long long Rbits;  // min r_hi among hypotheses whose count is certainly F (bits of a double >= 0)
     int overflow;              // candidate list overflowed -> score everything exactly
-    int pad;
+    int unsure;                // some hypothesis is not certainly all-inlier -> point-wise coarse pass needed
 };
 
 __global__ void ransac_sel_init_kernel(SelectState* sel) {
@@ -522,13 +576,89 @@ __global__ void ransac_sel_init_kernel(SelectState* sel) {
     sel->count = 0;
     sel->Rbits = 0x7FF0000000000000ull;  // +inf
     sel->overflow = 0;
-    sel->pad = 0;
+    sel->unsure = 0;
 }
 
 struct CoarseHyp {
     int32_t n_lo, n_hi;  // certain inliers / possible inliers (n_hi < 0: degenerate sample)
     double r_lo, r_hi;   // bounds on the inlier RMSE
 };
+
+// Closed-form coarse score for the regime the reference actually runs (registration_node.py:319-327
+// passes max_correspondence_distance = 10000 m, so every correspondence is an inlier of every sane
+// hypothesis): with sigma_i = s_i - cs, kappa_i = q_i - cq, tau = t + R cs - cq,
+//   E(R,t) = sum_i |R sigma_i + tau - kappa_i|^2
+//          = sum_a R_a^T Sss R_a + C |tau|^2 + Akk + 2 tau.(R sbar - kbar) - 2 sum_ab R_ab K_ab
+// -- O(1) per hypothesis from the second moments of the stream instead of O(C).  It is only a
+// PREFILTER: [E - eps, E + eps] provably contains the oracle's sequentially accumulated fp64 sum
+// (derivation in DESIGN.md 4.3: moment/evaluation rounding <= u (gm + 80) B with B the sum of the
+// magnitudes of all terms; the oracle's own residual rounding <= 48 u A sqrt(C E) with A the raw
+// coordinate magnitude; its summation error <= (C + 8) u E), and the survivors are re-scored in the
+// oracle's order by ransac_exact_list_kernel.  A hypothesis for which "every point is an inlier"
+// cannot be proven (or max_dist <= 0) raises sel->unsure and the point-wise fp32 pass runs instead.
+__global__ __launch_bounds__(64) void ransac_moment_kernel(const double* __restrict__ pts, const RansacStats* __restrict__ stats,
+                                                           const int64_t* __restrict__ count_dev, int64_t c_max,
+                                                           double max_d2, int32_t n_iter, uint64_t seed,
+                                                           CoarseHyp* __restrict__ out, SelectState* __restrict__ sel) {
+    const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
+    const int lane = threadIdx.x;
+    const int32_t h = (int32_t)(blockIdx.x * 64 + lane);
+    CoarseHyp o = CoarseHyp{0, -1, 0.0, 0.0};
+    bool unsure = false, sure_live = false;
+    if (C >= 3 && h < n_iter) {
+        double T[12];
+        if (sample_T(pts, C, (uint32_t)h, seed, T)) {
+            const double u = 1.1102230246251565e-16;
+            double tau[3], taumax = 0.0, tt = 0.0, tabs = 0.0, rmax = 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                tau[r] = (T[4 * r + 3] + ((T[4 * r] * stats->cs[0] + T[4 * r + 1] * stats->cs[1]) + T[4 * r + 2] * stats->cs[2])) -
+                         stats->cq[r];
+                taumax = fmax(taumax, fabs(tau[r]));
+                tt += tau[r] * tau[r];
+                tabs = fmax(tabs, fabs(T[4 * r + 3]));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rmax = fmax(rmax, fabs(T[4 * r + c]));
+            }
+            // |residual component| <= 3 * 1.001 M + |tau| + M for every point
+            const double reach = 4.01 * stats->M + taumax;
+            const bool sure = (rmax <= 1.001) && (max_d2 > 0.0) && (3.0 * reach * reach * 1.001 < max_d2);
+            if (!sure) {
+                unsure = true;
+            } else {
+                const double* S = stats->Sss;
+                double q1 = 0.0, rk = 0.0, t4 = 0.0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double x = T[4 * a], y = T[4 * a + 1], z = T[4 * a + 2];
+                    q1 += (x * (S[0] * x + S[1] * y + S[2] * z) + y * (S[1] * x + S[3] * y + S[4] * z)) +
+                          z * (S[2] * x + S[4] * y + S[5] * z);
+                    rk += (x * stats->K[3 * a] + y * stats->K[3 * a + 1]) + z * stats->K[3 * a + 2];
+                    t4 += tau[a] * (((x * stats->sbar[0] + y * stats->sbar[1]) + z * stats->sbar[2]) - stats->kbar[a]);
+                }
+                const double Cd = (double)C;
+                const double E = (((q1 + Cd * tt) + stats->Akk) + 2.0 * t4) - 2.0 * rk;
+                const double Ass = (S[0] + S[3]) + S[5];
+                const double sbm = fmax(fmax(fabs(stats->sbar[0]), fabs(stats->sbar[1])), fabs(stats->sbar[2]));
+                const double kbm = fmax(fmax(fabs(stats->kbar[0]), fabs(stats->kbar[1])), fabs(stats->kbar[2]));
+                const double B = ((13.0 * Ass + 5.0 * stats->Akk) + 1.01 * Cd * tt) + 6.0 * taumax * (3.01 * sbm + kbm);
+                const double eps1 = u * (stats->gm + 80.0) * B;
+                const double Ep = fmax(E, 0.0) + eps1;
+                const double A = (3.01 * stats->Xs + tabs) + stats->Xq;
+                const double eps = (eps1 + (Cd + 8.0) * u * Ep) + 48.0 * u * A * sqrt(Cd * Ep);
+                const double lo = fmax(0.0, E - eps), hi = fmax(0.0, E + eps);
+                o.n_lo = (int32_t)C;
+                o.n_hi = (int32_t)C;
+                o.r_lo = sqrt(lo / Cd) * (1.0 - 1e-13);
+                o.r_hi = sqrt(hi / Cd) * (1.0 + 1e-13);
+                sure_live = true;
+            }
+        }
+    }
+    if (h < n_iter) out[h] = o;
+    if (__any(unsure) && lane == 0) atomicExch(&sel->unsure, 1);
+    if (__any(sure_live) && lane == 0) atomicMax(&sel->F, (int)C);
+}
 
 // 512 threads = 8 waves per 64 hypotheses: wave w scores chunks w, w+8, ... of the stream (the coarse
 // sums have no prescribed order), so 6 waves share a SIMD and hide each other's issue latency (a lone
@@ -546,6 +676,7 @@ __global__ __launch_bounds__(512) void ransac_coarse_kernel(const double* __rest
     __shared__ int all_inliers_s;  // every correspondence is certainly an inlier of every hypothesis of this block
     __shared__ int part_n[COARSE_WAVES][2][64];
     __shared__ double part_e[COARSE_WAVES][2][64];
+    if (sel->unsure == 0) return;  // ransac_moment_kernel bounded every hypothesis already (uniform)
     const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int32_t h = (int32_t)(blockIdx.x * 64 + lane);
@@ -875,10 +1006,13 @@ VFM_EXPORT int vfm_ransac_corr(const double* src, const double* tgt, const int32
         hipLaunchKernelGGL(ransac_final_kernel, dim3(1), dim3(256), 0, st, w.pts, count_dev, c_max, seed, w.block_best,
                            nblocks, T_out, fitness_out, rmse_out, best_hyp_out);
     } else {
-        // fp32 coarse pass -> candidates -> exact fp64 on the candidates (or on everything if the
-        // candidate list overflowed)
+        // coarse bounds (closed form from the stream's moments when every point is provably an inlier,
+        // else the point-wise fp32 pass) -> candidates -> exact fp64 on the candidates (or on everything
+        // if the candidate list overflowed)
         hipLaunchKernelGGL(ransac_sel_init_kernel, dim3(1), dim3(1), 0, st, w.sel);
         hipLaunchKernelGGL(ransac_center_kernel, dim3(1), dim3(1024), 0, st, w.pts, count_dev, c_max, w.stats, w.pts32);
+        hipLaunchKernelGGL(ransac_moment_kernel, dim3(nblocks), dim3(64), 0, st, w.pts, w.stats, count_dev, c_max, max_d2,
+                           n_iter, seed, w.hyps, w.sel);
         hipLaunchKernelGGL(ransac_coarse_kernel, dim3(nblocks), dim3(64 * COARSE_WAVES), 0, st, w.pts, w.pts32, w.stats, count_dev, c_max,
                            max_dist, n_iter, seed, w.hyps, w.sel);
         const unsigned gsel = (unsigned)((n_iter + 255) / 256);
