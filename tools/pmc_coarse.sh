@@ -1,0 +1,47 @@
+# PMC passes for the dominant kernel (match_coarse_pipe_kernel) on config C2 -> gpurun_out/pmc_coarse/
+# Separate --pmc passes, --kernel-trace only (MI355X_MICROARCH.md, HBM / rocprofv3 section).
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/pmc_coarse
+rm -rf $O && mkdir -p $O
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
+           "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
+           "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_CMD_FIFO_FULL SQ_INST_LEVEL_VMEM"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O -o p$i -- python $R/tools/prof_match.py 3 > $O/log$i.txt 2>&1
+  echo "pass $i ($set): rc=$?"
+done
+python - <<PY
+import csv, glob, collections, json
+agg = collections.defaultdict(list); dur = []
+for f in sorted(glob.glob("$O/p*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if "match_coarse" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for f in sorted(glob.glob("$O/p*_kernel_trace.csv")):
+    for r in csv.DictReader(open(f)):
+        if "match_coarse" in r["Kernel_Name"]:
+            dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+a = {k: sum(v) / len(v) for k, v in agg.items()}
+cyc = a["GRBM_GUI_ACTIVE"] / 8
+d = sorted(dur)[len(dur) // 2]
+out = {
+    "kernel": "match_coarse_pipe_kernel<24>", "workload": "C2 20000x200000x384, one launch",
+    "counters_avg_per_launch": a,
+    "FETCH_SIZE_KB": a["FETCH_SIZE"], "WRITE_SIZE_KB": a["WRITE_SIZE"],
+    "hbm_bytes_per_launch": (2 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024,
+    "note": "FETCH_SIZE doubled (gfx950 reports 1/2 of a wide coalesced stream, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported (matches the 253 MB of partial records); separate --pmc passes with --kernel-trace only",
+    "TCC_hit_rate": a["TCC_HIT_sum"] / (a["TCC_HIT_sum"] + a["TCC_MISS_sum"]),
+    "median_duration_us_under_pmc": d, "cycles_per_xcd": cyc, "clock_GHz": cyc / d / 1e3,
+    "mfma_busy_fraction": a["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024),
+    "lds_array_busy_fraction": a["SQ_LDS_IDX_ACTIVE"] / (cyc * 256),
+    "wave_time_shares": {k: a[k] / a["SQ_WAVE_CYCLES"] for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS")},
+    "per_mfma": {"salu": a["SQ_INSTS_SALU"] / a["SQ_INSTS_MFMA"], "valu_incl_mfma": a["SQ_INSTS_VALU"] / a["SQ_INSTS_MFMA"], "lds": a["SQ_INSTS_LDS"] / a["SQ_INSTS_MFMA"]},
+    "command": "bash tools/pmc_coarse.sh  (7 x rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python tools/prof_match.py 3)",
+}
+json.dump(out, open("$O/pmc_match_coarse.json", "w"), indent=1)
+print(json.dumps({k: out[k] for k in ("hbm_bytes_per_launch", "TCC_hit_rate", "clock_GHz", "mfma_busy_fraction", "lds_array_busy_fraction", "wave_time_shares", "per_mfma")}, indent=1))
+PY
