@@ -54,7 +54,8 @@ int vfm_l2norm_rows_f32(float *x, int64_t n, int d, float *inv_out, vfm_stream_t
  * first (the whole of VHM:469-495).  q, b: RAW (un-normalised) fp32 descriptors, row-major
  * n x d and m x d.  idx_out[i] = argmax_j <qn_i, bn_j> decided in fp64 on the fp32-normalised
  * rows, ties -> lowest j; sim_out[i] = (float) of that score.  Zero-norm query rows give
- * idx 0 / sim 0.  FAST requires d % 128 == 0 and d <= 512. */
+ * idx 0 / sim 0.  FAST requires d % 128 == 0 and d <= 768
+ * (d = 640, 768 -- config C5's ViT-B/14 descriptors -- run a 4-wave kernel with 192 query registers). */
 size_t vfm_match_ip_top1_workspace_bytes(int64_t n, int64_t m, int d, int prec_mode);
 int vfm_match_ip_top1(const float *q, int64_t n, const float *b, int64_t m, int d, int prec_mode,
                       int64_t *idx_out, float *sim_out, void *ws, size_t ws_bytes,
@@ -188,7 +189,7 @@ int vfm_icp_build_system(const double *src, const double *tgt, const uint8_t *va
 
 /* self.model.model(img) of IF:101 incl. the transform of IF:67-77: bilinear resize (antialias
  * off) of B uint8 images H x W x 3 to 224 x 14*pw, ImageNet normalisation, ViT (patch 14,
- * dim 384*k, 64-wide heads, LayerScale, exact GELU), final LayerNorm, cls dropped, FeatUp
+ * dim = 64 * heads <= 1024 (ViT-S/14: 384, ViT-B/14: 768), 64-wide heads, LayerScale, exact GELU), final LayerNorm, cls dropped, FeatUp
  * ChannelNorm.  tokens_out: B x 16 x pw x dim fp32.  weights: packed blob described by
  * vfm_vit_weights_bytes / vfmreg/vit.py.  */
 typedef struct {

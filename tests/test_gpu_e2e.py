@@ -105,3 +105,46 @@ def test_c3_end_to_end():
     np.testing.assert_array_equal(out["mask"][:k].cpu().numpy(), r.inlier_mask)
     assert np.linalg.norm(T - r.transformation) <= 1e-5
     np.testing.assert_array_equal(T, r.transformation)
+
+
+def test_c5_solve_at_full_size():
+    """BASELINE config C5 (stretch): 50k-point scan vs 1M-point map, 768-D descriptors, fp16 coarse
+    distances + exact decision, RANSAC.  Matching indices are checked against the oracle on a row sample,
+    the solve against the oracle on the GPU's own correspondence set (bit-exact mask and pose), the pose
+    against the planted one; the two-stage pipeline must return what the serial one returns."""
+    from oracle import oracle as orc
+    from vfmreg import synth
+    from vfmreg.pipeline import RegistrationPipeline
+
+    n, m, d, iters = 50000, 1000000, 768, 20000
+    p = synth.make_pair_device(n, m, d, seed=77)
+    outs = []
+    for overlap in (False, True):
+        pipe = RegistrationPipeline(n, m, d, n_iter=iters, overlap_ransac=overlap)
+        out = pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        outs.append({k: out[k].clone() for k in ("T", "idx", "sim", "count", "mask", "corres", "best_hyp")})
+        del pipe
+    out = outs[0]
+    k = int(out["count"].item())
+    assert k > 20000
+    for key in outs[0]:  # rows past the correspondence count are never written
+        a, b = (outs[0][key][:k], outs[1][key][:k]) if key in ("corres", "mask") else (outs[0][key], outs[1][key])
+        assert torch.equal(a, b), key
+    T = out["T"].cpu().numpy()
+    T_gt = p["T_gt"].cpu().numpy() if hasattr(p["T_gt"], "cpu") else np.asarray(p["T_gt"])
+    assert np.linalg.norm(T - T_gt) < 0.05
+    # matching parity on a row sample (BLAS prefilter + exact fp64 decision)
+    rows = torch.arange(0, n, 1000, device="cuda")
+    qn, _ = orc.l2norm_rows(p["q_desc"][rows].cpu().numpy())
+    bn, _ = orc.l2norm_rows(p["b_desc"].cpu().numpy())
+    idx_ref, sim_ref = orc.match_ip_top1(qn, bn)
+    np.testing.assert_array_equal(out["idx"][rows].cpu().numpy(), idx_ref)
+    np.testing.assert_array_equal(out["sim"][rows].cpu().numpy(), sim_ref)
+    # solve parity on the GPU's correspondences
+    corres = out["corres"][:k].cpu().numpy()
+    r = orc.ransac_corr(p["q_xyz"].cpu().numpy(), p["b_xyz"].cpu().numpy(), corres, 10000.0, iters, seed=42)
+    assert out["best_hyp"].item() == r.best_hyp
+    np.testing.assert_array_equal(T, r.transformation)
+    np.testing.assert_array_equal(out["mask"][:k].cpu().numpy(), r.inlier_mask)

@@ -60,7 +60,7 @@ def test_match_exact_mode_small(ops, orc):
 
 
 @pytest.mark.parametrize("n,m,d", [(2000, 10000, 384), (33, 129, 384), (257, 4097, 128), (1000, 3000, 256),
-                                   (500, 2000, 512)])
+                                   (500, 2000, 512), (700, 5000, 768), (129, 1300, 640), (3, 129, 768)])
 def test_match_fast_equals_oracle(ops, orc, n, m, d):
     from vfmreg import synth
     p = synth.make_pair(n, m, d, seed=42)
@@ -136,6 +136,39 @@ def test_match_fast_full_size_property(ops, orc):
     idx_ref, sim_ref = orc.match_ip_top1(qn, bn)
     np.testing.assert_array_equal(idx[rows].cpu().numpy(), idx_ref)
     np.testing.assert_array_equal(sim[rows].cpu().numpy(), sim_ref)
+
+
+def test_match_fast_c5_size_property(ops, orc):
+    """BASELINE config C5 (stretch): 50k x 1M x 768.  Planted-match recovery on all rows, exactness against
+    the accelerated oracle on a row sample, and the edge cases of the wide-descriptor kernel at small size."""
+    from vfmreg import synth
+    n, m, d = 50000, 1000000, 768
+    p = synth.make_pair_device(n, m, d, seed=5)
+    idx, sim = ops.match_ip_top1(p["q_desc"], p["b_desc"], ops.FAST)
+    torch.cuda.synchronize()
+    match = p["match"]
+    inl = match >= 0
+    assert (idx[inl] == match[inl]).float().mean().item() > 0.999
+    assert (sim[inl] > 0.8).float().mean().item() > 0.999 and (sim[~inl] < 0.8).all()
+    rows = torch.arange(0, n, 500, device="cuda")
+    q = p["q_desc"][rows].cpu().numpy()
+    b = p["b_desc"].cpu().numpy()
+    qn, _ = orc.l2norm_rows(q)
+    bn, _ = orc.l2norm_rows(b)
+    idx_ref, sim_ref = orc.match_ip_top1(qn, bn)
+    np.testing.assert_array_equal(idx[rows].cpu().numpy(), idx_ref)
+    np.testing.assert_array_equal(sim[rows].cpu().numpy(), sim_ref)
+    # duplicates / zero rows / all-negative scores at d = 768
+    rng = np.random.default_rng(11)
+    b2 = rng.standard_normal((900, d)).astype(np.float32)
+    b2[10] = 0.0
+    b2[500] = b2[20]
+    q2 = rng.standard_normal((70, d)).astype(np.float32)
+    q2[0] = 0.0
+    q2[1] = b2[500]
+    idx2, sim2 = _check_match(ops, orc, q2, b2, ops.FAST)
+    assert idx2[1] == 20 and idx2[0] == 0 and sim2[0] == 0.0
+    _check_match(ops, orc, q2, -np.abs(b2), ops.FAST)
 
 
 def test_threshold_compact(ops, orc):

@@ -57,3 +57,12 @@ def test_vit_nclt_resolution_padding():
     w = V.random_weights(seed=2, dim=384, depth=3, mlp=1536)
     imgs = _smooth_images(np.random.default_rng(2), 1, 700, 820)
     _check(w, imgs, atol=1e-2, cos_min=0.99999)
+
+
+def test_vit_b14_config_c5():
+    """BASELINE config C5's feature extractor: ViT-B/14 (dim 768, 12 heads, MLP 3072) -> 768-D descriptors.
+    4 blocks keep the CPU reference within seconds; every kernel shape of the 12-block model is exercised."""
+    from vfmreg import vit as V
+    w = V.random_weights(seed=3, dim=768, depth=4, mlp=3072)
+    imgs = _smooth_images(np.random.default_rng(3), 2, 600, 800)
+    _check(w, imgs, atol=1e-2, cos_min=0.99999)

@@ -165,6 +165,8 @@ __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     else static_assert(N < 0, "unsupported vmcnt");
 }
 
@@ -595,6 +597,192 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// coarse pass, 4 waves per workgroup with QSETS x 32 resident queries each ("register-heavy")
+//
+// One wave per SIMD and the unified 512-register budget: a wave keeps QSETS x 32 queries resident
+// (QSETS * d/4 registers) and every map fragment read from LDS feeds QSETS MFMAs -- LDS operand
+// traffic per flop / QSETS, and with QSETS = 3 a workgroup covers 384 queries, so the L2 -> LDS staging
+// per flop drops to 2/3 as well (the two costs the ablations of the 8-wave kernel measured).
+// Measured at d = 384 (C2): QSETS = 2 -> 3.26 ms, QSETS = 3 -> register spills, vs 2.6 ms for the 8-wave
+// kernel: one wave per SIMD cannot slot the fold / LDS / scalar stream between its own MFMAs as well as
+// two waves hide each other, so this shape is instantiated only where it is the only one that fits:
+// wide descriptors (d = 640, 768: config C5, QSETS = 1, 192 query registers), 1.04-1.06 PFLOP/s.  A step is ONE 32-row map tile (d/16 KiB in LDS): tile i in use, i+1 landed (its first
+// fragments are prefetched across the barrier), i+2 .. i+NBUF-2 in flight, the slot of i-1 is being
+// refilled.  QSETS = 1 alternates the k-steps between two accumulator chains (added before the fold);
+// QSETS >= 2 has one chain per query set.  Same packed top-2 records, select / rescore as every other
+// variant.  Error bound of the coarse score at d = 768: 48 instead of 24 accumulation steps add
+// < 5e-5, E < 1.15e-3, window 2.5e-3 >= 2E still holds.
+// ---------------------------------------------------------------------------------------------
+template <int KSTEPS, int QSETS, int NBUF>
+__global__ __launch_bounds__(256, 1) void match_coarse_r_kernel(CoarseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NWAVES = 4;
+    constexpr int TILE_U4 = KSTEPS * 64;
+    constexpr int TILE_BYTES = TILE_U4 * 16;
+    constexpr int PASSES = KSTEPS / NWAVES;
+    constexpr int PF = 4;
+    constexpr int SPLIT = (QSETS == 1) ? 2 : 1;  // accumulator chains per query set
+    constexpr int FOLD = 16 * QSETS;             // accumulator elements folded per step
+    static_assert(KSTEPS % 8 == 0 && KSTEPS % PF == 0, "d must be a multiple of 128");
+    static_assert(NBUF >= 3 && NBUF * TILE_BYTES <= 160 * 1024, "ring must fit the LDS");
+    static_assert(QSETS * KSTEPS * 4 <= 320, "resident queries must leave registers for the accumulators");
+
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int total = a.nqb * a.nslices;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, within = bid >> 3;
+    const int qn = total >> 3, rn = total & 7;
+    const int unit = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + within;
+    const int slice = unit / a.nqb;
+    const int qb = unit - slice * a.nqb;
+    const int c0 = (int)(((long long)slice * a.nchunks) / a.nslices);
+    const int c1 = (int)(((long long)(slice + 1) * a.nchunks) / a.nslices);
+    const int ntiles = (c1 - c0) * 4;
+    const int qt0 = (qb * NWAVES + wave) * QSETS;  // first 32-query tile of this wave
+
+    const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS unsigned char*)smem;
+    const uint4* gsrc = a.Bh + (size_t)c0 * 4 * TILE_U4 + wave * 64 + lane;
+    const unsigned ldst0 = lds_base + (unsigned)wave * 1024u;
+    auto stage = [&](const uint4* src, unsigned ring_byte) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p)
+            glds16(src + p * NWAVES * 64, __builtin_amdgcn_readfirstlane(ldst0 + ring_byte + (unsigned)(p * NWAVES) * 1024u));
+    };
+
+    half8 qf[QSETS][KSTEPS];
+#pragma unroll
+    for (int j = 0; j < QSETS; ++j) {
+        const int qt = qt0 + j;
+        const uint4* qsrc = a.Qh + (size_t)(qt < a.nq_tiles ? qt : 0) * TILE_U4 + lane;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            uint4 v = qsrc[s * 64];
+            qf[j][s] = *reinterpret_cast<half8*>(&v);
+        }
+    }
+    // tiles 0 .. NBUF-2 go out before the loop (a slice has >= 4 tiles; clamp for tiny ones)
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+        if (i < ntiles) stage(gsrc + (size_t)i * TILE_U4, (unsigned)(i * TILE_BYTES));
+    const uint4* gnext = gsrc + (size_t)(NBUF - 1) * TILE_U4;
+
+    unsigned s1[QSETS], s2[QSETS], runmax[QSETS];
+#pragma unroll
+    for (int j = 0; j < QSETS; ++j) s1[j] = s2[j] = runmax[j] = 0u;
+    const int hi = lane >> 5;
+    auto fold_tail = [&](int it, auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        const unsigned o1 = __shfl_xor(s1[J], 32), o2 = __shfl_xor(s2[J], 32);
+        const bool own = (s1[J] > o1) || (s1[J] == o1 && hi == 0);
+        const unsigned w1 = own ? s1[J] : o1;
+        const int wh = own ? hi : (1 - hi);
+        const unsigned w2 = max(max(s2[J], o2), min(s1[J], o1));
+        const int code = 63 - (int)(w1 & 63u);
+        const int li = (code >> 4) * 32 + (code & 3) + 8 * ((code & 15) >> 2) + 4 * wh;
+        const int qt = qt0 + J;
+        if (lane < 32 && qt < a.nq_tiles && it >= 0) {
+            const int chunk = c0 + (it >> 2);
+            a.partials[(size_t)chunk * a.npad + (size_t)qt * 32 + lane] = make_uint2((w1 & ~127u) | (unsigned)li, w2);
+            if (chunk < a.first_pad_chunk) runmax[J] = max(runmax[J], w1 & ~127u);
+        }
+        s1[J] = 0u;
+        s2[J] = 0u;
+    };
+
+    floatx16 prev[QSETS];
+#pragma unroll
+    for (int j = 0; j < QSETS; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prev[j][r] = 0.f;
+
+    // all of tile 0 and this wave's pieces of tile 1 .. : wait for everything once
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    uint4 rf[PF];
+    {
+        const uint4* b0 = reinterpret_cast<const uint4*>(smem) + lane;
+#pragma unroll
+        for (int s = 0; s < PF; ++s) rf[s] = b0[s * 64];
+    }
+    unsigned ring = 0u;  // ring slot of tile `it`
+
+    auto do_step = [&](int it, auto Pc) {
+        constexpr int P = decltype(Pc)::value;  // tile index inside the 4-tile chunk
+        // tile it+1 must have landed; tiles it+2 .. it+NBUF-2 may stay in flight
+        if (NBUF > 3 && it + 2 < ntiles) wait_vmcnt<(NBUF - 3) * PASSES>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned ring1 = ring + 1u >= (unsigned)NBUF ? 0u : ring + 1u;
+        const unsigned ringf = ring == 0u ? (unsigned)NBUF - 1u : ring - 1u;  // slot of tile it-1 = tile it+NBUF-1
+        const uint4* cur = reinterpret_cast<const uint4*>(smem + ring * TILE_BYTES) + lane;
+        const uint4* nxt = reinterpret_cast<const uint4*>(smem + ring1 * TILE_BYTES) + lane;
+        floatx16 acc[QSETS][SPLIT];
+#pragma unroll
+        for (int j = 0; j < QSETS; ++j)
+#pragma unroll
+            for (int c = 0; c < SPLIT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][c][r] = (c == 0) ? COARSE_OFFSET : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+#pragma unroll
+            for (int j = 0; j < QSETS; ++j)
+                acc[j][s % SPLIT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&rf[s % PF]), qf[j][s],
+                                                                           acc[j][s % SPLIT], 0, 0, 0);
+            rf[s % PF] = (s + PF < KSTEPS) ? cur[(s + PF) * 64] : nxt[(s + PF - KSTEPS) * 64];
+            // deferred fold of the previous tile (tile (P + 3) % 4 of its chunk), spread over the slots
+#pragma unroll
+            for (int e = s * FOLD / KSTEPS; e < (s + 1) * FOLD / KSTEPS; ++e) {
+                const int j = e >> 4, r = e & 15;
+                const unsigned pk = (__float_as_uint(prev[j][r]) & 0xFFFFFFC0u) | (unsigned)(63 - (((P + 3) & 3) * 16 + r));
+                s2[j] = umed3(s1[j], s2[j], pk);
+                s1[j] = max(s1[j], pk);
+            }
+            if (s == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + NBUF - 1 < ntiles) stage(gnext, ringf * TILE_BYTES);  // uniform
+                gnext += TILE_U4;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (P == 0) {
+            fold_tail(it - 1, std::integral_constant<int, 0>{});
+            if constexpr (QSETS > 1) fold_tail(it - 1, std::integral_constant<int, 1>{});
+            if constexpr (QSETS > 2) fold_tail(it - 1, std::integral_constant<int, 2>{});
+        }
+#pragma unroll
+        for (int j = 0; j < QSETS; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) prev[j][r] = (SPLIT == 2) ? acc[j][0][r] + acc[j][SPLIT - 1][r] : acc[j][0][r];
+        ring = ring1;
+    };
+
+    for (int it = 0; it < ntiles; it += 4) {
+        do_step(it, std::integral_constant<int, 0>{});
+        do_step(it + 1, std::integral_constant<int, 1>{});
+        do_step(it + 2, std::integral_constant<int, 2>{});
+        do_step(it + 3, std::integral_constant<int, 3>{});
+    }
+#pragma unroll
+    for (int j = 0; j < QSETS; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned pk = (__float_as_uint(prev[j][r]) & 0xFFFFFFC0u) | (unsigned)(63 - (3 * 16 + r));
+            s2[j] = umed3(s1[j], s2[j], pk);
+            s1[j] = max(s1[j], pk);
+        }
+    fold_tail(ntiles - 1, std::integral_constant<int, 0>{});
+    if constexpr (QSETS > 1) fold_tail(ntiles - 1, std::integral_constant<int, 1>{});
+    if constexpr (QSETS > 2) fold_tail(ntiles - 1, std::integral_constant<int, 2>{});
+#pragma unroll
+    for (int j = 0; j < QSETS; ++j)
+        if (lane < 32 && qt0 + j < a.nq_tiles) atomicMax(a.qmax + (size_t)(qt0 + j) * 32 + lane, runmax[j]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // selection: coarse max per query and the candidate chunks inside the error window
 // cand entry: (chunk << 8) | (rescan << 7) | local row
 // ---------------------------------------------------------------------------------------------
@@ -976,6 +1164,9 @@ thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 // set through vfm_debug_set_coarse_variant for A/B runs
 int g_coarse_qsets = 0;
 
+// queries per workgroup of the coarse kernel that do_search_coarse will launch
+int coarse_qblock(int d) { return d > 512 ? 128 : QBLOCK; }
+
 template <int KSTEPS>
 int launch_coarse_pipe(const CoarseArgs& a, hipStream_t st) {
     const int lds = 6 * KSTEPS * 1024;
@@ -1002,6 +1193,23 @@ int launch_coarse_v(const CoarseArgs& a, hipStream_t st) {
     return VFM_OK;
 }
 
+template <int KSTEPS, int QSETS, int NBUF>
+int launch_coarse_r(const CoarseArgs& a, hipStream_t st) {
+    const int lds = NBUF * KSTEPS * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_r_kernel<KSTEPS, QSETS, NBUF>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
+    hipLaunchKernelGGL((match_coarse_r_kernel<KSTEPS, QSETS, NBUF>), dim3(a.nqb * a.nslices), dim3(256), lds, st, a);
+    VFM_CHECK_LAUNCH("match_coarse_r_kernel");
+    if (g_prof_stop) VFM_CHECK_HIP(hipEventRecord(g_prof_stop, st));
+    g_prof_start = g_prof_stop = nullptr;
+    return VFM_OK;
+}
+
 template <int KSTEPS>
 int launch_coarse(const CoarseArgs& a, hipStream_t st) {
     if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
@@ -1009,7 +1217,7 @@ int launch_coarse(const CoarseArgs& a, hipStream_t st) {
     if constexpr (KSTEPS <= 24) {
         rc = (g_coarse_qsets == 2)   ? launch_coarse_v<KSTEPS, 2>(a, st)
              : (g_coarse_qsets == 1) ? launch_coarse_v<KSTEPS, 1>(a, st)
-                                     : launch_coarse_pipe<KSTEPS>(a, st);
+                                     : launch_coarse_pipe<KSTEPS>(a, st);  // 0, 3
     } else {
         rc = launch_coarse_v<KSTEPS, 1>(a, st);  // d = 512: 2 x 128 query VGPRs would not fit
     }
@@ -1029,7 +1237,7 @@ int do_prepare(const float* x, int64_t rows, int d, void* prepared, hipStream_t 
     return VFM_OK;
 }
 
-CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, int64_t n, int64_t m) {
+CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, int64_t n, int64_t m, int qblock = QBLOCK) {
     const int64_t npad = rows_padded(n), mpad = rows_padded(m);
     CoarseArgs a;
     a.Qh = Q.tiles;
@@ -1039,7 +1247,7 @@ CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, 
     a.nchunks = (int)(mpad / CHUNK_ROWS);
     a.m_valid = m;
     a.npad = (int)npad;
-    a.nqb = (int)(npad / QBLOCK);
+    a.nqb = (int)(npad / qblock);
     a.nslices = choose_slices(a.nqb, a.nchunks);
     a.qmax = w.qmax;
     a.first_pad_chunk = (int)(m / CHUNK_ROWS);
@@ -1051,7 +1259,7 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
     Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
     Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
     SearchWs w = carve_search(ws, n, m);
-    const CoarseArgs a = coarse_args(Q, B, w, n, m);
+    const CoarseArgs a = coarse_args(Q, B, w, n, m, coarse_qblock(d));
     VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, sizeof(int), st));
     VFM_CHECK_HIP(hipMemsetAsync(w.qmax, 0, (size_t)a.npad * sizeof(unsigned), st));
     int rc;
@@ -1060,7 +1268,9 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
         case 16: rc = launch_coarse<16>(a, st); break;
         case 24: rc = launch_coarse<24>(a, st); break;
         case 32: rc = launch_coarse<32>(a, st); break;
-        default: return vfm_fail(VFM_EINVAL, "FAST matching supports d in {128,256,384,512}, got %d", d);
+        case 40: rc = launch_coarse_r<40, 1, 3>(a, st); break;
+        case 48: rc = launch_coarse_r<48, 1, 3>(a, st); break;
+        default: return vfm_fail(VFM_EINVAL, "FAST matching supports d in {128,256,384,512,640,768}, got %d", d);
     }
     return rc;
 }
@@ -1071,7 +1281,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
     Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
     SearchWs w = carve_search(ws, n, m);
-    const CoarseArgs a = coarse_args(Q, B, w, n, m);
+    const CoarseArgs a = coarse_args(Q, B, w, n, m, coarse_qblock(d));
     hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS), 0, st, w.partials, a.nchunks,
                        a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.fb_count, w.fb_list);
     VFM_CHECK_LAUNCH("match_select_kernel");
@@ -1111,7 +1321,7 @@ VFM_EXPORT size_t vfm_match_prepared_bytes(int64_t rows, int d) {
 }
 
 VFM_EXPORT int vfm_match_prepare(const float* x, int64_t rows, int d, void* prepared, vfm_stream_t stream) {
-    VFM_CHECK_ARG(rows > 0 && d % 128 == 0 && d >= 128 && d <= 512, "prepare: d must be in {128,256,384,512}");
+    VFM_CHECK_ARG(rows > 0 && d % 128 == 0 && d >= 128 && d <= 768, "prepare: d must be in {128,256,384,512,640,768}");
     VFM_CHECK_ARG(x && prepared, "prepare: null pointer");
     return do_prepare(x, rows, d, prepared, (hipStream_t)stream);
 }
@@ -1125,7 +1335,7 @@ VFM_EXPORT int vfm_match_search_prepared(const float* q, const void* q_prepared,
                                          const void* b_prepared, int64_t m, int d, int64_t* idx_out, float* sim_out,
                                          void* ws, size_t ws_bytes, vfm_stream_t stream) {
     VFM_CHECK_ARG(n > 0 && m > 0, "search: empty operand (n=%lld m=%lld)", (long long)n, (long long)m);
-    VFM_CHECK_ARG(d % 128 == 0 && d >= 128 && d <= 512, "search: d must be in {128,256,384,512}");
+    VFM_CHECK_ARG(d % 128 == 0 && d >= 128 && d <= 768, "search: d must be in {128,256,384,512,640,768}");
     VFM_CHECK_ARG(m < (1ll << 31) - 256 && n < (1ll << 31) - 256, "search: more than 2^31 rows");
     if (ws_bytes < vfm_match_search_workspace_bytes(n, m, d)) return vfm_fail(VFM_EWORKSPACE, "search: workspace too small");
     return do_search(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream);
@@ -1133,7 +1343,7 @@ VFM_EXPORT int vfm_match_search_prepared(const float* q, const void* q_prepared,
 
 static int check_search_args(int64_t n, int64_t m, int d, size_t ws_bytes) {
     VFM_CHECK_ARG(n > 0 && m > 0, "search: empty operand (n=%lld m=%lld)", (long long)n, (long long)m);
-    VFM_CHECK_ARG(d % 128 == 0 && d >= 128 && d <= 512, "search: d must be in {128,256,384,512}");
+    VFM_CHECK_ARG(d % 128 == 0 && d >= 128 && d <= 768, "search: d must be in {128,256,384,512,640,768}");
     VFM_CHECK_ARG(m < (1ll << 31) - 256 && n < (1ll << 31) - 256, "search: more than 2^31 rows");
     if (ws_bytes < vfm_match_search_workspace_bytes(n, m, d)) return vfm_fail(VFM_EWORKSPACE, "search: workspace too small");
     return VFM_OK;
@@ -1194,7 +1404,7 @@ VFM_EXPORT int vfm_match_ip_top1(const float* q, int64_t n, const float* b, int6
         return VFM_OK;
     }
     VFM_CHECK_ARG(prec_mode == VFM_MATCH_FAST, "match: unknown prec_mode %d", prec_mode);
-    VFM_CHECK_ARG(d % 128 == 0 && d >= 128 && d <= 512, "match(FAST): d must be in {128,256,384,512}, got %d", d);
+    VFM_CHECK_ARG(d % 128 == 0 && d >= 128 && d <= 768, "match(FAST): d must be in {128,256,384,512,640,768}, got %d", d);
     unsigned char* p = static_cast<unsigned char*>(ws);
     void* qprep = p;
     void* bprep = p + vfm_match_prepared_bytes(n, d);

@@ -259,11 +259,12 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
 // ---------------------------------------------------------------------------------------------
 // 3. LayerNorm over channels, fp32 in -> fp16 fragment tiles out.  One wavefront per token.
 // ---------------------------------------------------------------------------------------------
-// A lane owns the float4 chunks c = lane and c = lane + 64 (D <= 512): v[0..3], v[4..7].
-__device__ __forceinline__ void ln_load(const float* __restrict__ row, int D, float (&v)[8], bool (&has)[2]) {
+// A lane owns the float4 chunks c = lane + 64 i, i < LN_CH (D <= 1024): v[4 i .. 4 i + 3].
+constexpr int LN_CH = 4;
+__device__ __forceinline__ void ln_load(const float* __restrict__ row, int D, float (&v)[4 * LN_CH], bool (&has)[LN_CH]) {
     const int lane = lane_id(), nchunk = D >> 2;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < LN_CH; ++i) {
         const int c = lane + 64 * i;
         has[i] = c < nchunk;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -272,17 +273,17 @@ __device__ __forceinline__ void ln_load(const float* __restrict__ row, int D, fl
     }
 }
 
-__device__ __forceinline__ void wave_ln_stats(const float (&v)[8], const bool (&has)[2], int D, float& mean, float& rstd,
+__device__ __forceinline__ void wave_ln_stats(const float (&v)[4 * LN_CH], const bool (&has)[LN_CH], int D, float& mean, float& rstd,
                                               float eps) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += has[i >> 2] ? v[i] : 0.f;
+    for (int i = 0; i < 4 * LN_CH; ++i) s += has[i >> 2] ? v[i] : 0.f;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     mean = s / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 4 * LN_CH; ++i) {
         const float c = has[i >> 2] ? v[i] - mean : 0.f;
         q += c * c;
     }
@@ -297,13 +298,13 @@ __global__ __launch_bounds__(256) void vit_layernorm_kernel(const float* __restr
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const int lane = lane_id();
-    float v[8];
-    bool has[2];
+    float v[4 * LN_CH];
+    bool has[LN_CH];
     ln_load(x + (size_t)m * D, D, v, has);
     float mean, rstd;
     wave_ln_stats(v, has, D, mean, rstd, 1e-6f);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < LN_CH; ++i) {
         if (!has[i]) continue;
         const int n0 = (lane + 64 * i) * 4;
         half4 o;
@@ -322,13 +323,13 @@ __global__ __launch_bounds__(256) void vit_final_kernel(const float* __restrict_
     const int b = tok / d.Np, p = tok % d.Np;
     const int m = b * d.Tp + 1 + p;
     const int lane = lane_id();
-    float v[8];
-    bool has[2];
+    float v[4 * LN_CH];
+    bool has[LN_CH];
     ln_load(x + (size_t)m * d.D, d.D, v, has);
     float mean, rstd;
     wave_ln_stats(v, has, d.D, mean, rstd, 1e-6f);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < LN_CH; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = (lane + 64 * i) * 4 + j;
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(256) void vit_final_kernel(const float* __restrict_
         }
     wave_ln_stats(v, has, d.D, mean, rstd, 1e-5f);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < LN_CH; ++i) {
         if (!has[i]) continue;
         const int n0 = (lane + 64 * i) * 4;
         float4 o;
@@ -533,7 +534,7 @@ VFM_EXPORT size_t vfm_vit_workspace_bytes(const vfm_vit_config* cfg, int B) {
 VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, const uint8_t* img, int B, int H, int W,
                                float* tokens_out, void* ws, size_t ws_bytes, vfm_stream_t stream) {
     VFM_CHECK_ARG(cfg && weights && img && tokens_out && ws, "vit: null pointer");
-    VFM_CHECK_ARG(cfg->dim % 64 == 0 && cfg->dim == cfg->heads * 64 && cfg->dim <= 512, "vit: dim must be heads*64 and <= 512");
+    VFM_CHECK_ARG(cfg->dim % 64 == 0 && cfg->dim == cfg->heads * 64 && cfg->dim <= 1024, "vit: dim must be heads*64 and <= 1024");
     VFM_CHECK_ARG(cfg->mlp_dim % 64 == 0 && cfg->depth >= 1 && cfg->depth <= 64, "vit: bad mlp_dim / depth");
     VFM_CHECK_ARG(cfg->patch == 14 && cfg->patch_h >= 1 && cfg->patch_w >= 1 && B >= 1, "vit: bad patch grid");
     const Dims d = make_dims(cfg, B, H, W);

@@ -97,7 +97,7 @@ class VoxelHashMap:
                                % (b_desc.shape[1] + 3))  # py::cast_error, stl_vector_eigen.h:76-78
         q_desc = torch.from_numpy(np.ascontiguousarray(points[:, 3:], dtype=np.float32)).cuda()
         d = q_desc.shape[1]
-        prec = ops.FAST if (d % 128 == 0 and 128 <= d <= 512) else ops.EXACT
+        prec = ops.FAST if (d % 128 == 0 and 128 <= d <= 768) else ops.EXACT
         idx, sim = ops.match_ip_top1(q_desc, b_desc, prec)
         r = ops.threshold_compact(sim, idx, float(min_cosine_similarity), want_corres=True)
         k = int(r["count"].item())
