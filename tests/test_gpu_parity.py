@@ -193,40 +193,57 @@ def test_threshold_compact(ops, orc):
     assert int(r["count"].item()) == 0
 
 
+def _check_l2(ops, orc, a, b):
+    i_ref, dist_ref = orc.nn_l2(a, b)
+    j_ref, _ = orc.nn_l2(b, a)
+    for prec in (ops.FAST, ops.EXACT):
+        nn_ab, d2, nn_ba = ops.match_mutual_l2(dev(a), dev(b), prec=prec)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(nn_ab.cpu().numpy(), i_ref, err_msg=f"prec {prec}")
+        np.testing.assert_array_equal(nn_ba.cpu().numpy(), j_ref, err_msg=f"prec {prec}")
+        np.testing.assert_array_equal(np.sqrt(d2.cpu().numpy()), dist_ref)
+    return i_ref
+
+
 def test_mutual_l2(ops, orc):
     rng = np.random.default_rng(3)
     a = rng.standard_normal((400, 33)).astype(np.float32)
     b = rng.standard_normal((900, 33)).astype(np.float32)
     b[100] = b[50]
     a[7] = b[100]
-    nn_ab, d2, nn_ba = ops.match_mutual_l2(dev(a), dev(b))
-    i_ref, dist_ref = orc.nn_l2(a, b)
-    j_ref, _ = orc.nn_l2(b, a)
-    np.testing.assert_array_equal(nn_ab.cpu().numpy(), i_ref)
-    np.testing.assert_array_equal(nn_ba.cpu().numpy(), j_ref)
-    np.testing.assert_array_equal(np.sqrt(d2.cpu().numpy()), dist_ref)
-    assert nn_ab[7].item() == 50
+    i_ref = _check_l2(ops, orc, a, b)
+    assert i_ref[7] == 50
 
 
-# ------------------------------------------------------------------------------------- RANSAC
-def test_kabsch_batched_bit_exact(ops, orc):
-    rng = np.random.default_rng(5)
-    n_invalid = 0
-    for n in (3, 4, 50):
-        A = rng.uniform(-20, 20, (64, n, 3))
-        B = rng.uniform(-20, 20, (64, n, 3))
-        B[:32] = A[:32] @ np.linalg.qr(rng.standard_normal((3, 3)))[0] + 1.5
-        A[60] = A[60, 0]  # degenerate: all points equal
-        w = rng.uniform(0.1, 1, (64, n))
-        for wt, eps in ((None, 0.0), (w, 1e-6)):
-            T, valid = ops.kabsch_batched(dev(A), dev(B), None if wt is None else dev(wt), eps)
-            T, valid = T.cpu().numpy(), valid.cpu().numpy()
-            for i in range(64):
-                Tr, ok = orc.kabsch(A[i], B[i], None if wt is None else wt[i], eps)
-                assert bool(valid[i]) == ok
-                np.testing.assert_array_equal(T[i], Tr)
-                n_invalid += int(not ok)
-    assert n_invalid >= 2  # the all-points-equal sample is reported invalid (T = identity)
+@pytest.mark.parametrize("n,m,d", [(1500, 4000, 384), (700, 300, 32), (5, 1, 7), (1, 130, 126), (260, 1000, 200)])
+def test_mutual_l2_fast_equals_oracle(ops, orc, n, m, d):
+    """row A6 on the matrix cores: un-normalised descriptors, wildly different row norms (one huge row sets
+    the common scale, some rows are ~0), exact duplicates and near ties"""
+    rng = np.random.default_rng(n + m + d)
+    a = (rng.standard_normal((n, d)) * rng.uniform(0.2, 3.0, (n, 1))).astype(np.float32)
+    b = (rng.standard_normal((m, d)) * rng.uniform(0.2, 3.0, (m, 1))).astype(np.float32)
+    if m > 200:
+        b[3] *= 40.0                       # dominates the common scale
+        b[10] = 0.0                        # zero row: nearest neighbour of every tiny query
+        b[120] = b[20]                     # duplicate: index 20 must win
+        b[150] = b[20] + 1e-4 * rng.standard_normal(d).astype(np.float32)   # near tie inside the window
+    if n > 200:
+        a[0] = 0.0
+        a[1] = b[min(120, m - 1)]
+        a[2] *= 1e-3                       # tiny norm: distances differ only through |b|^2
+        a[3] = b[3]
+    _check_l2(ops, orc, a, b)
+
+
+def test_mutual_l2_fpfh_like(ops, orc):
+    """non-negative histogram descriptors (FPFH: 33 bins, three sub-histograms summing to 100 each)"""
+    rng = np.random.default_rng(12)
+    def fpfh(k):
+        h = rng.gamma(0.6, 1.0, (k, 3, 11))
+        return (100.0 * h / h.sum(-1, keepdims=True)).reshape(k, 33).astype(np.float32)
+    a, b = fpfh(3000), fpfh(5000)
+    b[::500] = b[0]                        # many exact duplicates across chunks
+    _check_l2(ops, orc, a, b)
 
 
 def _ransac_case(n_corr, outlier, seed, noise=0.02):

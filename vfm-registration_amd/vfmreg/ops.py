@@ -130,18 +130,21 @@ def threshold_compact(sim: torch.Tensor, idx: Optional[torch.Tensor], thr: float
     return dict(keep=keep, count=count, corres=corres, src=src, tgt=tgt)
 
 
-def match_mutual_l2(a: torch.Tensor, b: torch.Tensor, mutual: bool = True):
-    """Exact Euclidean 1-NN a->b (and b->a) (registration_node.py:485-496)."""
+def match_mutual_l2(a: torch.Tensor, b: torch.Tensor, mutual: bool = True, prec: int = FAST):
+    """Exact Euclidean 1-NN a->b (and b->a) (registration_node.py:485-496).  FAST and EXACT return the same
+    indices and distances; FAST runs the all-pairs part on the matrix cores."""
     _chk(a, torch.float32, "a")
     _chk(b, torch.float32, "b")
     if a.shape[1] != b.shape[1]:
         raise ValueError("Invalid shape")
     lib = _lib.load()
-    nn_ab = torch.empty(a.shape[0], dtype=torch.int64, device=a.device)
-    d2 = torch.empty(a.shape[0], dtype=torch.float64, device=a.device)
-    nn_ba = torch.empty(b.shape[0], dtype=torch.int64, device=a.device) if mutual else None
-    _lib.check(lib.vfm_match_mutual_l2(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], a.shape[1],
-                                       nn_ab.data_ptr(), d2.data_ptr(), _ptr(nn_ba), _stream()), "match_mutual_l2")
+    n, m, d = a.shape[0], b.shape[0], a.shape[1]
+    nn_ab = torch.empty(n, dtype=torch.int64, device=a.device)
+    d2 = torch.empty(n, dtype=torch.float64, device=a.device)
+    nn_ba = torch.empty(m, dtype=torch.int64, device=a.device) if mutual else None
+    ws = torch.empty(lib.vfm_match_mutual_l2_workspace_bytes(n, m, d, prec, int(mutual)), dtype=torch.uint8, device=a.device)
+    _lib.check(lib.vfm_match_mutual_l2(a.data_ptr(), n, b.data_ptr(), m, d, prec, nn_ab.data_ptr(), d2.data_ptr(),
+                                       _ptr(nn_ba), ws.data_ptr(), ws.numel(), _stream()), "match_mutual_l2")
     return nn_ab, d2, nn_ba
 
 
