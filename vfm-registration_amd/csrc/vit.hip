@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void vit_preprocess_kernel(const uint8_t* __re
 //    lane <-> token (column), registers <-> channels (rows): 4 consecutive channels per group.
 // ---------------------------------------------------------------------------------------------
 enum Epi { EPI_PATCH = 0, EPI_QKV = 1, EPI_RESID = 2, EPI_GELU = 3 };
+constexpr int GEMM_PF = 8;  // k-steps of operand fragments in flight per wave
 
 struct GemmArgs {
     const uint4* A;    // activations, fragment tiles [M/32][KS][64]
@@ -192,13 +193,32 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    for (int s = 0; s < g.KS; ++s) {
-        uint4 a = Ap[(size_t)s * 64];
-        const half8 av = *reinterpret_cast<half8*>(&a);
+    // The grid is ~1 wave per SIMD, so nothing hides a load's L2 round trip except the wave itself:
+    // keep GEMM_PF k-steps of operand fragments in flight in a register ring.
+    constexpr int PF = GEMM_PF;
+    uint4 ra[PF], rw[NT][PF];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            uint4 w = Wp[((size_t)j * g.KS + s) * 64];
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&w), av, acc[j], 0, 0, 0);
+    for (int i = 0; i < PF; ++i)
+        if (i < g.KS) {
+            ra[i] = Ap[(size_t)i * 64];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) rw[j][i] = Wp[((size_t)j * g.KS + i) * 64];
+        }
+    for (int s0 = 0; s0 < g.KS; s0 += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int s = s0 + i;
+            if (s < g.KS) {
+                const half8 av = *reinterpret_cast<half8*>(&ra[i]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&rw[j][i]), av, acc[j], 0, 0, 0);
+                if (s + PF < g.KS) {
+                    ra[i] = Ap[(size_t)(s + PF) * 64];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) rw[j][i] = Wp[((size_t)j * g.KS + s + PF) * 64];
+                }
+            }
         }
     }
     // D layout: column = lane & 31 = token, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel in tile
