@@ -10,7 +10,8 @@ import torch  # noqa: E402
 from vfmreg import _lib, ops, synth  # noqa: E402
 
 lib = _lib.load()
-n, m, d = 20000, 200000, 384
+import os  # noqa: E402
+n, m, d = 20000, 200000, int(os.environ.get("D", "384"))
 p = synth.make_pair_device(n, m, d, seed=42)
 variants = [int(v) for v in sys.argv[1:]] or [1, 2]
 a, b = C.c_void_p(), C.c_void_p()
