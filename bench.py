@@ -116,20 +116,25 @@ def main():
     n, m, d = args.n, args.m, DIM
     # two resident scene pairs per rank, alternated; pair p uses seed 42 + p (global pair id)
     pairs = [synth.make_pair_device(n, m, d, seed=42 + rank * 2 + j, device=dev) for j in range(2)]
-    # --streams 2 (default): two-stage pipeline over independent scene pairs (BASELINE config C4:
-    # "one per stream"): the matching kernels of pair i+1 (matrix cores) run on the main stream while the
-    # RANSAC of pair i (fp64 vector ALU) runs on a second HIP stream.  Matching kernels never overlap
-    # each other, so the HIP-event duration of the coarse kernel stays a per-launch figure.
+    # --streams 2 (default): pipeline over independent scene pairs (BASELINE config C4: "one per stream"):
+    # the MFMA coarse pass of pair i+1 runs on the main stream while the operand preparation of pair i+2 and
+    # the select / exact decision / RANSAC of pair i run on two side streams (vfmreg/pipeline.py).  Coarse
+    # passes never overlap each other, so the HIP-event duration of the coarse kernel stays a per-launch figure.
     S = 2 if args.streams >= 2 else 1
     pipe = RegistrationPipeline(n, m, d, n_iter=args.iters, device=dev, overlap_ransac=(S == 2))
 
     # (a high-priority matching stream was tried: no measurable difference)
     match_stream = torch.cuda.current_stream()
 
+    torch.cuda.synchronize()
+    inputs_ready = torch.cuda.Event()  # the resident scene pairs are complete from here on
+    inputs_ready.record(match_stream)
+
     def step(i):
         p = pairs[i % 2]
         with torch.cuda.stream(match_stream):
-            return pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"], want_mask=True)
+            return pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"], want_mask=True,
+                                 inputs_ready=inputs_ready if S == 2 else None)
 
     # untimed warm-up of the complete step, including the sharding / gather path
     for i in range(max(args.warmup, 1)):

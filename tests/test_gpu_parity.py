@@ -441,15 +441,21 @@ def test_pipeline_overlap_equals_serial(ops):
         o = serial.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
         torch.cuda.synchronize()
         want.append({k: o[k].clone() for k in ("T", "idx", "mask", "count", "fitness", "rmse")})
-    over = RegistrationPipeline(n, m, d, n_iter=3000, max_corr_dist=0.5, overlap_ransac=True)
-    got = []
-    for p in dv:
-        o = over.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
-        with torch.cuda.stream(o["result_stream"]):
-            got.append({k: o[k].clone() for k in ("T", "idx", "mask", "count", "fitness", "rmse")})
-    over.synchronize()
     torch.cuda.synchronize()
-    for w, g, p in zip(want, got, pairs):
-        for k in w:
-            assert torch.equal(w[k], g[k]), k
-        assert np.linalg.norm(g["T"].cpu().numpy() - p["T_gt"]) < 0.05
+    ready = torch.cuda.Event()
+    ready.record()
+    for ev in (None, ready):  # without / with the explicit "inputs are complete" event (stage 0 on its own stream)
+        over = RegistrationPipeline(n, m, d, n_iter=3000, max_corr_dist=0.5, overlap_ransac=True)
+        got = []
+        for rep in range(2):  # 10 registrations: every buffer set is reused several times
+            for p in dv:
+                o = over.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"], inputs_ready=ev)
+                with torch.cuda.stream(o["result_stream"]):
+                    got.append({k: o[k].clone() for k in ("T", "idx", "mask", "count", "fitness", "rmse")})
+        over.synchronize()
+        torch.cuda.synchronize()
+        for i, g in enumerate(got):
+            w, p = want[i % len(want)], pairs[i % len(pairs)]
+            for k in w:
+                assert torch.equal(w[k], g[k]), (k, i)
+            assert np.linalg.norm(g["T"].cpu().numpy() - p["T_gt"]) < 0.05

@@ -9,12 +9,14 @@ host synchronisation:
 
 Buffers are allocated once for fixed (N, M, D); ``register`` only enqueues work.
 
-``overlap_ransac=True`` turns the chain into a two-stage pipeline over independent scene pairs:
-stage 1 (caller's stream) = normalise/convert + the fp16 MFMA coarse pass of pair i+1 -- the matrix
-cores; stage 2 (a second HIP stream) = candidate selection, exact fp64 re-decision, threshold /
-compaction and RANSAC of pair i -- vector ALU and fp64.  Events order the hand-off and two complete
-buffer sets (prepared operands, search workspace, results) ping-pong, so results of pair i stay
-valid until pair i+2 is enqueued.  Coarse passes never overlap each other.
+``overlap_ransac=True`` turns the chain into a pipeline over independent scene pairs:
+stage 0 (a "prepare" HIP stream) = normalise + fp16 fragment conversion of pair i+1 (HBM-bound);
+stage 1 (caller's stream) = the fp16 MFMA coarse pass of pair i+1 -- the matrix cores;
+stage 2 (a "solve" HIP stream) = candidate selection, exact fp64 re-decision, threshold / compaction
+and RANSAC of pair i -- vector ALU and fp64.  Events order the hand-offs and two complete buffer sets
+(prepared operands, search workspace, results) ping-pong, so results of pair i stay valid until pair
+i+2 is enqueued.  Coarse passes never overlap each other; the inputs of a pair must stay untouched
+until its ``done`` event.
 """
 from __future__ import annotations
 
@@ -60,6 +62,7 @@ class RegistrationPipeline:
                  lib.vfm_match_search_workspace_bytes(n, m, d))
         self.sets = [_ResultSet(n, dev, *sizes) for _ in range(2 if self.overlap else 1)]
         self.ransac_stream = torch.cuda.Stream(device=dev) if self.overlap else None
+        self.prep_stream = torch.cuda.Stream(device=dev) if self.overlap else None
         self._step = 0
 
     def prepare_map(self, b_desc: torch.Tensor) -> None:
@@ -83,7 +86,10 @@ class RegistrationPipeline:
             torch.cuda.current_stream().wait_stream(self.ransac_stream)
 
     def register(self, q_desc: torch.Tensor, q_xyz: torch.Tensor, b_desc: torch.Tensor, b_xyz: torch.Tensor,
-                 reuse_map: bool = False, want_mask: bool = True):
+                 reuse_map: bool = False, want_mask: bool = True, inputs_ready: Optional[torch.cuda.Event] = None):
+        """Enqueue one registration.  ``inputs_ready`` (overlap mode): an event after which the four input
+        tensors are complete; with it the prepare stage does not have to queue behind the coarse pass of
+        the previous pair on the caller's stream (without it, it conservatively does)."""
         lib = _lib.load()
         ops._chk(q_desc, torch.float32, "q_desc")
         ops._chk(b_desc, torch.float32, "b_desc")
@@ -95,12 +101,22 @@ class RegistrationPipeline:
         self._step += 1
         main = torch.cuda.current_stream()
         st = main.cuda_stream
-        if self.overlap and r.done is not None:
-            main.wait_event(r.done)  # the RANSAC that last read this set has finished
+        pst = st
+        if self.overlap:
+            # stage 0 on its own stream: it may run beside the coarse pass of the previous pair
+            if inputs_ready is not None:
+                self.prep_stream.wait_event(inputs_ready)
+            else:
+                self.prep_stream.wait_stream(main)      # inputs produced on the caller's stream are ready
+            if r.done is not None:
+                self.prep_stream.wait_event(r.done)     # the solve stage that last read this set has finished
+            pst = self.prep_stream.cuda_stream
         if not (reuse_map and r.map_key == b_desc.data_ptr()):
-            _lib.check(lib.vfm_match_prepare(b_desc.data_ptr(), self.m, self.d, r.bprep.data_ptr(), st), "prepare(map)")
+            _lib.check(lib.vfm_match_prepare(b_desc.data_ptr(), self.m, self.d, r.bprep.data_ptr(), pst), "prepare(map)")
             r.map_key = b_desc.data_ptr() if reuse_map else None
-        _lib.check(lib.vfm_match_prepare(q_desc.data_ptr(), self.n, self.d, r.qprep.data_ptr(), st), "prepare(scan)")
+        _lib.check(lib.vfm_match_prepare(q_desc.data_ptr(), self.n, self.d, r.qprep.data_ptr(), pst), "prepare(scan)")
+        if self.overlap:
+            main.wait_stream(self.prep_stream)
         _lib.check(lib.vfm_match_search_coarse(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
                                                r.sws.data_ptr(), r.sws.numel(), st), "search(coarse)")
         rst = st
