@@ -55,6 +55,35 @@ def lift():
 
 
 t_lift = timed(lift)
+
+# registration of the lifted scan against a 200k-point map (C2 solve) and the whole chain back to back
+from vfmreg.pipeline import RegistrationPipeline  # noqa: E402
+m = 200000
+g = torch.Generator(device="cuda").manual_seed(3)
+b_desc = torch.randn(m, 384, device="cuda", generator=g)
+lift()
+pick = torch.randperm(m, device="cuda", generator=g)[:n]
+b_desc[pick] = desc + 0.02 * desc.abs().mean() * torch.randn(n, 384, device="cuda", generator=g)
+b_xyz = torch.rand(m, 3, device="cuda", generator=g, dtype=torch.float64) * 100.0
+q_xyz = torch.from_numpy(np.ascontiguousarray(xyz)).cuda()
+b_xyz[pick] = q_xyz + 0.02 * torch.randn(n, 3, device="cuda", generator=g, dtype=torch.float64)
+pipe = RegistrationPipeline(n, m, 384, n_iter=50000)
+t_reg = timed(lambda: pipe.register(desc, q_xyz, b_desc, b_xyz))
+
+
+def chain():
+    global grids
+    grids = model.forward(imgs)
+    lift()
+    return pipe.register(desc, q_xyz, b_desc, b_xyz)
+
+
+t_all = timed(chain)
+out = chain()
+torch.cuda.synchronize()
 flops = 6 * 16.6e9
 print(f"ViT-S/14 6x{H}x{W}: {t_vit:.3f} ms ({flops / t_vit / 1e9:.1f} TFLOP/s of ~1e11 FLOP)")
 print(f"projection + lifting, 6 cameras x {n} points: {t_lift:.3f} ms; lifted {int(filled.sum())} points")
+print(f"registration of the lifted scan vs {m}-point map (50k RANSAC iterations): {t_reg:.3f} ms; "
+      f"{int(out['count'].item())} correspondences, |t| = {float(out['T'][:3, 3].norm()):.3f} m")
+print(f"C3 end to end, device resident (ViT -> project/lift -> match -> RANSAC), one pair: {t_all:.3f} ms")
