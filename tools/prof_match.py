@@ -17,6 +17,7 @@ if os.environ.get("VFM_LIB"):  # experimental build (tools/build_ablate.sh)
 from vfmreg import ops, synth  # noqa: E402
 
 _lib.load().vfm_debug_set_coarse_variant(int(os.environ.get("VFM_VARIANT", "0")))
+_lib.load().vfm_debug_set_coarse_slices(int(os.environ.get("VFM_SLICES", "0")))
 
 n, m, d = 20000, 200000, 384
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3

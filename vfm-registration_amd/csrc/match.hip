@@ -1281,8 +1281,16 @@ inline SearchWs carve_search(void* p, int64_t n, int64_t m) {
     return w;
 }
 
+int g_force_slices = 0;  // experiment knob (vfm_debug_set_coarse_slices): 0 = heuristic below
+
 inline int choose_slices(int nqb, int nchunks) {
-    // fill 256 CUs with whole "rounds" of workgroups; prefer fewer, longer slices on ties
+    if (g_force_slices > 0) return g_force_slices < nchunks ? g_force_slices : nchunks;
+    // Fill 256 CUs with whole "rounds" of workgroups (best tail efficiency; fewer, longer slices on ties).
+    // Trade-off measured at C2: every (query block, slice) unit re-reads its 256 queries (196 KB), so HBM
+    // traffic grows with the slice count (16 slices: 0.89 GB, 55 slices: 1.52 GB per launch) and the kernel
+    // alone is ~1 % faster with 16; but in the registration pipeline short workgroups hand compute units to
+    // the side stages more often -- 55 slices: 334 / 361 registrations/s vs 16 slices: 320 (two boxes;
+    // 81: 360, 107: 358, 133: 355).  Throughput wins, so the efficiency-maximising count stays.
     int best_s = 1;
     double best_eff = -1.0;
     const int smax = nchunks < 64 ? nchunks : 64;
@@ -1676,6 +1684,10 @@ VFM_EXPORT int vfm_match_mutual_l2(const float* a, int64_t n, const float* b, in
 // kernel is launched on.  Used by bench.py for roofline.achieved.
 // ---------------------------------------------------------------------------------------------
 // A/B switch for the coarse kernel variant (1 = 8 waves x 32 queries, 2 = 4 waves x 64 queries, 0 = default)
+VFM_EXPORT int vfm_debug_set_coarse_slices(int slices) {
+    g_force_slices = slices;
+    return VFM_OK;
+}
 VFM_EXPORT int vfm_debug_set_coarse_variant(int qsets) {
     g_coarse_qsets = qsets;
     return VFM_OK;

@@ -59,6 +59,7 @@ SIGNATURES = {
     "vfm_prof_elapsed_ms": (C.c_int, [c_vp, c_vp, C.POINTER(C.c_float)]),
     "vfm_prof_events_destroy": (C.c_int, [c_vp, c_vp]),
     "vfm_debug_set_coarse_variant": (C.c_int, [C.c_int]),
+    "vfm_debug_set_coarse_slices": (C.c_int, [C.c_int]),
     "vfm_debug_set_ransac_exact_only": (C.c_int, [C.c_int]),
     "vfm_vit_weights_bytes": (C.c_size_t, [C.POINTER(VitConfig)]),
     "vfm_vit_weights_layout": (C.c_int, [C.POINTER(VitConfig), C.POINTER(c_i64), C.POINTER(c_i64), C.c_int]),
