@@ -5,15 +5,20 @@
 // Pipeline of the FAST top-1 search (indices identical to the fp64 oracle):
 //   prep_rows_kernel      fp32 rows -> 1/|row| (faiss fvec_renorm_L2 order) + fp16 copy of the
 //                         normalised rows in MFMA-fragment ("frag-major") tiles of 32 rows
-//   match_coarse_kernel   fp16 MFMA 32x32x16, queries resident in VGPRs, map tiles streamed
-//                         through an LDS ring by LDS-DMA; per (query, 128-row chunk) top-2 of the
-//                         coarse scores, never materialising N x M
+//   coarse pass           fp16 MFMA 32x32x16, queries resident in VGPRs, map tiles streamed through an
+//                         LDS ring by LDS-DMA; per (query, 128-row chunk) top-2 of the coarse scores,
+//                         never materialising N x M.  Three shapes of the same pass:
+//                           match_coarse_pipe_kernel  d <= 384 (default): 8 waves, fragment pipeline
+//                                                     carried across the step barrier
+//                           match_coarse_kernel       d = 512 (ring of 4), and the A/B + ablation base
+//                           match_coarse_r_kernel     d = 640 / 768: 4 waves, 192 query registers
 //   match_select_kernel   per query: global coarse max, every chunk within the proven error
 //                         window becomes a candidate (single row, or whole chunk if its top-2
 //                         is inside the window too)
 //   match_rescore_kernel  exact fp64 re-decision among the candidates (sequential-k dot of the
 //                         fp32-normalised rows, ties -> lowest index)
 //   match_exact_kernel    all-pairs fp64 (EXACT mode, and fallback for candidate overflow)
+// Euclidean 1-NN (row A6) reuses the coarse pass and select: l2_maxnorm / l2_prep / l2_rescore kernels.
 // Compiled with -ffp-contract=off (fp32 sum-of-squares order must match the oracle).
 #include "common.h"
 
@@ -38,9 +43,6 @@ constexpr int ring_depth(int ksteps) { return ksteps <= 24 ? 6 : 4; }
 constexpr int CAND_CAP = 40;      // candidate chunks kept per query before falling back
 constexpr float COARSE_OFFSET = 2.0f;   // accumulators start here: every coarse score is a
                                         // positive normal float, so uint order == float order
-#ifndef VFM_COARSE_PF
-#define VFM_COARSE_PF 0
-#endif
 constexpr float DEFAULT_WINDOW = 2.5e-3f;  // >= 2E, E = proven |coarse - exact| bound
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -204,6 +206,56 @@ struct CoarseArgs {
     int first_pad_chunk; // chunks >= this contain zero-padded map rows: excluded from qmax
 };
 
+// XCD-aware unit mapping shared by the coarse kernels: workgroup b runs on XCD b % 8 (observed, speed
+// only); every XCD gets one contiguous range of (slice-major) units so that co-resident workgroups stream
+// the same map slice through that XCD's L2.  Unit = (query block qb, map slice); tiles [4 c0, 4 c1).
+struct CoarseUnit {
+    int qb, c0, ntiles;
+};
+__device__ __forceinline__ CoarseUnit coarse_unit(const CoarseArgs& a) {
+    const int total = a.nqb * a.nslices;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, within = bid >> 3;
+    const int qn = total >> 3, rn = total & 7;
+    const int unit = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + within;
+    const int slice = unit / a.nqb;
+    CoarseUnit u;
+    u.qb = unit - slice * a.nqb;
+    u.c0 = (int)(((long long)slice * a.nchunks) / a.nslices);
+    const int c1 = (int)(((long long)(slice + 1) * a.nchunks) / a.nslices);
+    u.ntiles = (c1 - u.c0) * 4;
+    return u;
+}
+
+// One accumulator element into the running top-2 of its chunk: 3 VALU ops, branch-free.  code = 16 * tile
+// in chunk + accumulator register; zero-padded map rows (score exactly 2.0) are NOT masked here:
+// match_select_kernel ignores padded chunks for the maximum and rescans them exactly.
+__device__ __forceinline__ void coarse_fold(unsigned& s1, unsigned& s2, float v, int code) {
+    const unsigned pk = (__float_as_uint(v) & 0xFFFFFFC0u) | (unsigned)(63 - code);
+    s2 = umed3(s1, s2, pk);
+    s1 = max(s1, pk);
+}
+
+// End of a 128-row chunk: merge the two half-waves and emit the chunk's top-2 for the 32 queries of tile
+// qt (chunk < 0: the dummy fold of the very first step, nothing is stored); resets the running pair.
+__device__ __forceinline__ void coarse_emit_chunk(const CoarseArgs& a, unsigned& s1, unsigned& s2, unsigned& runmax,
+                                                  int qt, int chunk) {
+    const int lane = lane_id(), hi = lane >> 5;
+    const unsigned o1 = __shfl_xor(s1, 32), o2 = __shfl_xor(s2, 32);
+    const bool own = (s1 > o1) || (s1 == o1 && hi == 0);
+    const unsigned w1 = own ? s1 : o1;
+    const int wh = own ? hi : (1 - hi);
+    const unsigned w2 = max(max(s2, o2), min(s1, o1));
+    const int code = 63 - (int)(w1 & 63u);
+    const int li = (code >> 4) * 32 + (code & 3) + 8 * ((code & 15) >> 2) + 4 * wh;  // row inside the chunk
+    if (lane < 32 && qt < a.nq_tiles && chunk >= 0) {
+        a.partials[(size_t)chunk * a.npad + (size_t)qt * 32 + lane] = make_uint2((w1 & ~127u) | (unsigned)li, w2);
+        if (chunk < a.first_pad_chunk) runmax = max(runmax, w1 & ~127u);
+    }
+    s1 = 0u;
+    s2 = 0u;
+}
+
 // QSETS = 32-query sets resident per wave: 1 -> 8 waves (2 per SIMD), 2 -> 4 waves (1 per SIMD,
 // every LDS fragment feeds two MFMAs: half the LDS read traffic / energy per flop).
 template <int KSTEPS, int QSETS>
@@ -220,20 +272,8 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    // XCD-aware unit mapping: workgroup b runs on XCD b % 8 (observed, speed only); give every
-    // XCD one contiguous range of (slice-major) units so co-resident workgroups stream the same
-    // map slice through that XCD's L2.
-    const int total = a.nqb * a.nslices;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, within = bid >> 3;
-    const int qn = total >> 3, rn = total & 7;
-    const int unit = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + within;
-    const int slice = unit / a.nqb;
-    const int qb = unit - slice * a.nqb;
-
-    const int c0 = (int)(((long long)slice * a.nchunks) / a.nslices);
-    const int c1 = (int)(((long long)(slice + 1) * a.nchunks) / a.nslices);
-    const int ntiles = (c1 - c0) * 4;
+    const CoarseUnit cu = coarse_unit(a);
+    const int qb = cu.qb, c0 = cu.c0, ntiles = cu.ntiles;
     const int t0 = c0 * 4;
 
     const int qt0 = qb * 8 + wave * QSETS;  // first 32-query tile of this wave
@@ -268,41 +308,15 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
     unsigned s1[QSETS], s2[QSETS], runmax[QSETS];
 #pragma unroll
     for (int j = 0; j < QSETS; ++j) s1[j] = s2[j] = runmax[j] = 0u;
-    const int hi = lane >> 5;
 
-    // end of a 128-row chunk: merge the two half-waves and emit the chunk's top-2 for 32 queries
-    auto fold_tail = [&](int it, auto Jc) {
-        constexpr int J = decltype(Jc)::value;
-        const unsigned o1 = __shfl_xor(s1[J], 32), o2 = __shfl_xor(s2[J], 32);
-        const bool own = (s1[J] > o1) || (s1[J] == o1 && hi == 0);
-        const unsigned w1 = own ? s1[J] : o1;
-        const int wh = own ? hi : (1 - hi);
-        const unsigned w2 = max(max(s2[J], o2), min(s1[J], o1));
-        const int code = 63 - (int)(w1 & 63u);
-        const int li = (code >> 4) * 32 + (code & 3) + 8 * ((code & 15) >> 2) + 4 * wh;
-        const int qt = qt0 + J;
-        if (lane < 32 && qt < a.nq_tiles && it >= 0) {  // it < 0: the dummy fold of the very first step
-            const int chunk = c0 + (it >> 2);
-            a.partials[(size_t)chunk * a.npad + (size_t)qt * 32 + lane] = make_uint2((w1 & ~127u) | (unsigned)li, w2);
-            if (chunk < a.first_pad_chunk) runmax[J] = max(runmax[J], w1 & ~127u);
-        }
-        s1[J] = 0u;
-        s2[J] = 0u;
-    };
-    // epilogue of one finished 32 x 32 accumulator tile: fold into the chunk's running top-2.
-    // Branch-free on purpose (3 VALU ops per element) so that the scheduler can issue it inside
-    // the next step's MFMA cluster.  Zero-padded map rows (score exactly 2.0) are NOT masked
-    // here: match_select_kernel ignores padded chunks for the maximum and rescans them exactly.
+    // epilogue of one finished 32 x 32 accumulator tile: fold into the chunk's running top-2 (branch-free
+    // so that the scheduler can issue it inside the next step's MFMA cluster); tile 3 closes the chunk
     auto fold = [&](const floatx16& acc, int it, auto TTc, auto Jc) {
         constexpr int TT = decltype(TTc)::value;
         constexpr int J = decltype(Jc)::value;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned pk = (__float_as_uint(acc[r]) & 0xFFFFFFC0u) | (unsigned)(63 - (TT * 16 + r));
-            s2[J] = umed3(s1[J], s2[J], pk);
-            s1[J] = max(s1[J], pk);
-        }
-        if constexpr (TT == 3) fold_tail(it, Jc);
+        for (int r = 0; r < 16; ++r) coarse_fold(s1[J], s2[J], acc[r], TT * 16 + r);
+        if constexpr (TT == 3) coarse_emit_chunk(a, s1[J], s2[J], runmax[J], qt0 + J, it >= 0 ? c0 + (it >> 2) : -1);
     };
 
     // one step = 2 map tiles (64 rows): 2 * QSETS independent accumulator chains per wave, one
@@ -338,39 +352,6 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
                 acc[j][0][r] = COARSE_OFFSET;
                 acc[j][1][r] = COARSE_OFFSET;
             }
-        if constexpr (QSETS == 1 && VFM_COARSE_PF > 0) {
-        // pinned software pipeline (QSETS == 1): fragment reads run PF k-steps ahead of the MFMAs that
-        // consume them and the deferred fold is spread over the slots; sched_barrier keeps the slots apart
-        constexpr int PF = VFM_COARSE_PF > 0 ? VFM_COARSE_PF : 1;
-        uint4 r0[PF], r1[PF];
-#pragma unroll
-        for (int s = 0; s < PF; ++s) {
-            r0[s] = buf0[s * 64];
-            r1[s] = buf1[s * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&r0[s % PF]), qf[0][s], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&r1[s % PF]), qf[0][s], acc[0][1], 0, 0, 0);
-            if (s + PF < KSTEPS) {
-                r0[s % PF] = buf0[(s + PF) * 64];
-                r1[s % PF] = buf1[(s + PF) * 64];
-            }
-#pragma unroll
-            for (int e = s * 32 / KSTEPS; e < (s + 1) * 32 / KSTEPS; ++e) {
-                const int TTe = 2 * (1 - H) + (e >> 4);
-                const unsigned pk = (__float_as_uint(prev[0][e >> 4][e & 15]) & 0xFFFFFFC0u) | (unsigned)(63 - (TTe * 16 + (e & 15)));
-                s2[0] = umed3(s1[0], s2[0], pk);
-                s1[0] = max(s1[0], pk);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (H == 0) fold_tail(it - 1, std::integral_constant<int, 0>{});
-        prev[0][0] = acc[0][0];
-        prev[0][1] = acc[0][1];
-        return;
-        }
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
 #ifdef VFM_ABLATE_LDS
@@ -458,17 +439,8 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    // XCD-aware unit mapping (see match_coarse_kernel)
-    const int total = a.nqb * a.nslices;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, within = bid >> 3;
-    const int qn = total >> 3, rn = total & 7;
-    const int unit = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + within;
-    const int slice = unit / a.nqb;
-    const int qb = unit - slice * a.nqb;
-    const int c0 = (int)(((long long)slice * a.nchunks) / a.nslices);
-    const int c1 = (int)(((long long)(slice + 1) * a.nchunks) / a.nslices);
-    const int ntiles = (c1 - c0) * 4;
+    const CoarseUnit cu = coarse_unit(a);
+    const int qb = cu.qb, c0 = cu.c0, ntiles = cu.ntiles;
     const int qt = qb * 8 + wave;  // this wave's 32-query tile
 
     const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS unsigned char*)smem;
@@ -496,28 +468,8 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
     const uint4* gnext = gsrc + (size_t)4 * TILE_U4;  // next tile to stage
 
     unsigned s1 = 0u, s2 = 0u, runmax = 0u;
-    const int hi = lane >> 5;
-    auto fold_tail = [&](int it) {
-        const unsigned o1 = __shfl_xor(s1, 32), o2 = __shfl_xor(s2, 32);
-        const bool own = (s1 > o1) || (s1 == o1 && hi == 0);
-        const unsigned w1 = own ? s1 : o1;
-        const int wh = own ? hi : (1 - hi);
-        const unsigned w2 = max(max(s2, o2), min(s1, o1));
-        const int code = 63 - (int)(w1 & 63u);
-        const int li = (code >> 4) * 32 + (code & 3) + 8 * ((code & 15) >> 2) + 4 * wh;
-        if (lane < 32 && qt < a.nq_tiles && it >= 0) {  // it < 0: the dummy fold of the very first step
-            const int chunk = c0 + (it >> 2);
-            a.partials[(size_t)chunk * a.npad + (size_t)qt * 32 + lane] = make_uint2((w1 & ~127u) | (unsigned)li, w2);
-            if (chunk < a.first_pad_chunk) runmax = max(runmax, w1 & ~127u);
-        }
-        s1 = 0u;
-        s2 = 0u;
-    };
-    auto fold_one = [&](float v, int code) {
-        const unsigned pk = (__float_as_uint(v) & 0xFFFFFFC0u) | (unsigned)(63 - code);
-        s2 = umed3(s1, s2, pk);
-        s1 = max(s1, pk);
-    };
+    auto fold_tail = [&](int it) { coarse_emit_chunk(a, s1, s2, runmax, qt, it >= 0 ? c0 + (it >> 2) : -1); };
+    auto fold_one = [&](float v, int code) { coarse_fold(s1, s2, v, code); };
 
     floatx16 prev0, prev1;
 #pragma unroll
@@ -629,16 +581,8 @@ __global__ __launch_bounds__(256, 1) void match_coarse_r_kernel(CoarseArgs a) {
 
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int total = a.nqb * a.nslices;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, within = bid >> 3;
-    const int qn = total >> 3, rn = total & 7;
-    const int unit = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + within;
-    const int slice = unit / a.nqb;
-    const int qb = unit - slice * a.nqb;
-    const int c0 = (int)(((long long)slice * a.nchunks) / a.nslices);
-    const int c1 = (int)(((long long)(slice + 1) * a.nchunks) / a.nslices);
-    const int ntiles = (c1 - c0) * 4;
+    const CoarseUnit cu = coarse_unit(a);
+    const int qb = cu.qb, c0 = cu.c0, ntiles = cu.ntiles;
     const int qt0 = (qb * NWAVES + wave) * QSETS;  // first 32-query tile of this wave
 
     const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS unsigned char*)smem;
@@ -670,24 +614,9 @@ __global__ __launch_bounds__(256, 1) void match_coarse_r_kernel(CoarseArgs a) {
     unsigned s1[QSETS], s2[QSETS], runmax[QSETS];
 #pragma unroll
     for (int j = 0; j < QSETS; ++j) s1[j] = s2[j] = runmax[j] = 0u;
-    const int hi = lane >> 5;
     auto fold_tail = [&](int it, auto Jc) {
         constexpr int J = decltype(Jc)::value;
-        const unsigned o1 = __shfl_xor(s1[J], 32), o2 = __shfl_xor(s2[J], 32);
-        const bool own = (s1[J] > o1) || (s1[J] == o1 && hi == 0);
-        const unsigned w1 = own ? s1[J] : o1;
-        const int wh = own ? hi : (1 - hi);
-        const unsigned w2 = max(max(s2[J], o2), min(s1[J], o1));
-        const int code = 63 - (int)(w1 & 63u);
-        const int li = (code >> 4) * 32 + (code & 3) + 8 * ((code & 15) >> 2) + 4 * wh;
-        const int qt = qt0 + J;
-        if (lane < 32 && qt < a.nq_tiles && it >= 0) {
-            const int chunk = c0 + (it >> 2);
-            a.partials[(size_t)chunk * a.npad + (size_t)qt * 32 + lane] = make_uint2((w1 & ~127u) | (unsigned)li, w2);
-            if (chunk < a.first_pad_chunk) runmax[J] = max(runmax[J], w1 & ~127u);
-        }
-        s1[J] = 0u;
-        s2[J] = 0u;
+        coarse_emit_chunk(a, s1[J], s2[J], runmax[J], qt0 + J, it >= 0 ? c0 + (it >> 2) : -1);
     };
 
     floatx16 prev[QSETS];
@@ -737,9 +666,7 @@ __global__ __launch_bounds__(256, 1) void match_coarse_r_kernel(CoarseArgs a) {
 #pragma unroll
             for (int e = s * FOLD / KSTEPS; e < (s + 1) * FOLD / KSTEPS; ++e) {
                 const int j = e >> 4, r = e & 15;
-                const unsigned pk = (__float_as_uint(prev[j][r]) & 0xFFFFFFC0u) | (unsigned)(63 - (((P + 3) & 3) * 16 + r));
-                s2[j] = umed3(s1[j], s2[j], pk);
-                s1[j] = max(s1[j], pk);
+                coarse_fold(s1[j], s2[j], prev[j][r], ((P + 3) & 3) * 16 + r);
             }
             if (s == 1) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -769,11 +696,7 @@ __global__ __launch_bounds__(256, 1) void match_coarse_r_kernel(CoarseArgs a) {
 #pragma unroll
     for (int j = 0; j < QSETS; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned pk = (__float_as_uint(prev[j][r]) & 0xFFFFFFC0u) | (unsigned)(63 - (3 * 16 + r));
-            s2[j] = umed3(s1[j], s2[j], pk);
-            s1[j] = max(s1[j], pk);
-        }
+        for (int r = 0; r < 16; ++r) coarse_fold(s1[j], s2[j], prev[j][r], 3 * 16 + r);
     fold_tail(ntiles - 1, std::integral_constant<int, 0>{});
     if constexpr (QSETS > 1) fold_tail(ntiles - 1, std::integral_constant<int, 1>{});
     if constexpr (QSETS > 2) fold_tail(ntiles - 1, std::integral_constant<int, 2>{});
