@@ -6,13 +6,17 @@
 // hypothesis with higher fitness, then lower RMSE; confidence 1 => every iteration runs) and
 // Eigen::umeyama / pointdsc.common.rigid_transform_3d (pointdsc/common.py:7-47).
 //
-// Layout: ONE THREAD PER HYPOTHESIS.  A wavefront evaluates 64 hypotheses against the same
-// correspondence at the same time, so the correspondence stream is wave-uniform (scalar loads,
-// no LDS, no cross-lane traffic) and each lane accumulates its inlier count / squared error in
-// correspondence order -- the same order Open3D's loop (and the CPU oracle) uses.
-// All arithmetic is fp64, compiled with -ffp-contract=off, written as the exact operation
-// sequence of oracle/vfm_oracle.c so that poses, masks and the winning hypothesis are
-// bit-identical to the oracle's.
+// Structure: cheap, PROVEN bounds on every hypothesis' inlier count and RMSE
+//   ransac_center_kernel + ransac_moment_kernel   closed form from the stream's second moments when every
+//                                                 correspondence is provably an inlier (the reference's
+//                                                 max_correspondence_distance = 10000 m)
+//   ransac_coarse_kernel                          point-wise fp32 otherwise
+// -> ransac_select_{rmin,list}_kernel: the hypotheses the bounds cannot rule out
+// -> ransac_exact_list_kernel: those are re-scored in fp64 in the oracle's operation and summation order
+//    (ransac_score_kernel does that for ALL hypotheses: reference semantics, A/B switch, overflow fallback)
+// -> ransac_final_kernel: total order (fitness desc, rmse asc, id asc), pose of the winner; ransac_mask_kernel.
+// Exact arithmetic is fp64, compiled with -ffp-contract=off, written as the exact operation sequence of
+// oracle/vfm_oracle.c so that poses, masks and the winning hypothesis are bit-identical to the oracle's.
 #include "common.h"
 
 namespace {
@@ -232,16 +236,12 @@ __device__ __forceinline__ bool better(double af, double ar, int ah, double bf, 
 
 constexpr int SCORE_CHUNK = 128;  // correspondences staged in LDS per step (6 KiB)
 
-// Exact (fp64, oracle operation order) scoring.  Two launch forms:
-//   list == NULL : hypothesis h = global thread index (all n_iter hypotheses); runs only if
-//                  gate == NULL or *gate != 0 (the fallback when the candidate list overflowed)
-//   list != NULL : hypothesis = list[global thread index] for indices < *list_count (the candidates
-//                  the fp32 coarse pass could not rule out); skipped when *gate != 0
+// Exact (fp64, oracle operation order) scoring of ALL n_iter hypotheses, one lane per hypothesis: the
+// semantics every other path must reproduce (vfm_debug_set_ransac_exact_only), and the fallback when the
+// candidate list overflowed (gate != NULL: runs only if *gate != 0).
 __global__ __launch_bounds__(64) void ransac_score_kernel(const double* __restrict__ pts,
                                                           const int64_t* __restrict__ count_dev, int64_t c_max,
                                                           double max_d2, int32_t n_iter, uint64_t seed,
-                                                          const int32_t* __restrict__ list,
-                                                          const int32_t* __restrict__ list_count,
                                                           const int32_t* __restrict__ gate,
                                                           HypScore* __restrict__ block_best) {
     // one wavefront per workgroup: its private LDS double buffer holds the correspondence stream
@@ -249,9 +249,9 @@ __global__ __launch_bounds__(64) void ransac_score_kernel(const double* __restri
     const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
     const int lane = threadIdx.x;
     const int32_t slot = (int32_t)(blockIdx.x * 64 + lane);
-    const int32_t limit = list ? *list_count : n_iter;
-    const bool enabled = list ? (!gate || *gate == 0) : (!gate || *gate != 0);
-    const int32_t h = (enabled && slot < limit) ? (list ? list[slot] : slot) : n_iter;
+    const int32_t limit = n_iter;
+    const bool enabled = !gate || *gate != 0;  // gate: run only if the flag is set (candidate-list overflow)
+    const int32_t h = (enabled && slot < limit) ? slot : n_iter;
     double fit = 0.0, rmse = 0.0;
     int hyp = -1;
     double T[12];
@@ -1001,7 +1001,7 @@ VFM_EXPORT int vfm_ransac_corr(const double* src, const double* tgt, const int32
         // reference-order fp64 scoring of every hypothesis (A/B switch, and the semantics the
         // two-level path below must reproduce bit for bit)
         hipLaunchKernelGGL(ransac_score_kernel, dim3(nblocks), dim3(64), 0, st, w.pts, count_dev, c_max, max_d2, n_iter, seed,
-                           (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, w.block_best);
+                           (const int32_t*)nullptr, w.block_best);
         VFM_CHECK_LAUNCH("ransac_score_kernel");
         hipLaunchKernelGGL(ransac_final_kernel, dim3(1), dim3(256), 0, st, w.pts, count_dev, c_max, seed, w.block_best,
                            nblocks, T_out, fitness_out, rmse_out, best_hyp_out);
@@ -1021,7 +1021,7 @@ VFM_EXPORT int vfm_ransac_corr(const double* src, const double* tgt, const int32
         hipLaunchKernelGGL(ransac_exact_list_kernel, dim3(CAND_MAX), dim3(64), 0, st, w.pts, count_dev, c_max, max_d2, n_iter,
                            seed, w.list, w.sel, w.block_best);
         hipLaunchKernelGGL(ransac_score_kernel, dim3(nblocks), dim3(64), 0, st, w.pts, count_dev, c_max, max_d2, n_iter, seed,
-                           (const int32_t*)nullptr, (const int32_t*)nullptr, &w.sel->overflow, w.block_best + CAND_MAX);
+                           &w.sel->overflow, w.block_best + CAND_MAX);
         VFM_CHECK_LAUNCH("ransac coarse/select/score kernels");
         hipLaunchKernelGGL(ransac_final_kernel, dim3(1), dim3(256), 0, st, w.pts, count_dev, c_max, seed, w.block_best,
                            CAND_MAX + nblocks, T_out, fitness_out, rmse_out, best_hyp_out);
