@@ -159,6 +159,26 @@ int vfm_gather_bilinear_patchgrid(const float *grid, int gh, int gw, int C, int 
                                   int64_t k_max, float *desc_out, uint8_t *filled,
                                   vfm_stream_t stream);
 
+/* create_descriptors (PS:50-107) for up to 6 cameras in ONE launch: per LiDAR point the cameras are tried
+ * in array order (= the reference's dict order = priority; the first camera that sees the point wins,
+ * PS:96-101), projected with the arithmetic of vfm_project_pinhole_f64, and the winning camera's patch
+ * grid is sampled as in vfm_gather_bilinear_patchgrid.  desc_out (n x C) must be zero-initialised;
+ * filled[i] = 1 iff some camera saw point i.  The struct array is HOST memory, its pointers DEVICE. */
+typedef struct {
+    int mode;                  /* VFM_PROJ_NCLT / _ROBOTCAR / _KITTI */
+    double mats[48];           /* as vfm_project_pinhole_f64 */
+    double fc[4];
+    double subsample;
+    int64_t win[4];
+    int64_t H, W;              /* size of the image the projection addresses */
+    const uint8_t *proj_image; /* NCLT: image of the projection's non-black test (nullable) */
+    const float *grid;         /* patch grid gh x gw x C of this camera */
+    const uint8_t *raw_image;  /* raw image for the black-pixel zeroing of PS:57-62 (nullable) */
+    int gh, gw, Hup, Wup, rot_mode;
+} vfm_lift_camera;
+int vfm_lift_multicam(const double *pcl_4xn, int64_t n, int ncam, const vfm_lift_camera *cams_host,
+                      int C, float *desc_out, uint8_t *filled, vfm_stream_t stream);
+
 /* transform_pcl (UT:47-54): xyz' = T[:3,:] @ [xyz;1], fp64. T: 16 fp64 on the device. */
 int vfm_transform_xyz_f64(const double *xyz, int64_t n, const double *T, double *out,
                           vfm_stream_t stream);

@@ -152,6 +152,16 @@ def test_transform_pcl_mirror(golden):
 
 
 # ------------------------------------------------------------------ create_descriptors (rows A2+A3)
+@pytest.fixture(params=["one_launch", "per_camera"])
+def lift_path(request):
+    """create_descriptors has two device paths: projection fused with the gather for all cameras in one launch
+    (vfm_lift_multicam) and project -> compact -> gather per camera; both must reproduce the reference fixtures"""
+    from vfmreg import prepare_scenes as PS
+    PS._FORCE_PER_CAMERA = request.param == "per_camera"
+    yield request.param
+    PS._FORCE_PER_CAMERA = False
+
+
 class _UpsampledFeatures:
     """the reference's feature generator seen from create_descriptors: H x W x C after F.interpolate"""
 
@@ -176,7 +186,7 @@ class _PatchGridFeatures:
 
 
 @pytest.mark.parametrize("fused", [False, True])
-def test_create_descriptors_oxford_fixture(golden, fused):
+def test_create_descriptors_oxford_fixture(golden, fused, lift_path):
     from vfmreg.dataloader import OxfordRobotcar
     from vfmreg.prepare_scenes import create_descriptors
     g = golden("lift_oxf.npz")
@@ -201,7 +211,7 @@ def test_create_descriptors_oxford_fixture(golden, fused):
 
 
 @pytest.mark.parametrize("fused", [False, True])
-def test_create_descriptors_nclt_fixture(golden, fused):
+def test_create_descriptors_nclt_fixture(golden, fused, lift_path):
     from vfmreg.dataloader import NCLT
     from vfmreg.prepare_scenes import create_descriptors
     g = golden("lift_nclt.npz")

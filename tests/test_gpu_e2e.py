@@ -57,11 +57,22 @@ def test_c3_end_to_end():
         def project_pcl_to_image(self, pcl, image, camera, _device_inputs=None):
             return self._k[camera].project_pcl_to_image(pcl, image, "camera", _device_inputs=_device_inputs)
 
+        def projection_params(self, camera, image_shape):       # enables the fused multi-camera lift
+            return self._k[camera].projection_params("camera", image_shape)
+
     scan_xyz = np.c_[rng.uniform(-40, 40, n), rng.uniform(-40, 40, n), rng.uniform(-2.5, 6, n)].astype(np.float32)
     w = V.random_weights(seed=0)
     gen = ImageFeatureGenerator("dinov2", use_featup=False, weights=w)
     desc = create_descriptors(None, Surround(), gen, scan_xyz)     # [n, 384] fp32, rows A1+A2+A3 on the GPU
     assert desc.shape == (n, 384) and desc.dtype == np.float32
+    # the fused "projection + gather, all cameras in one launch" path must equal the per-camera path bit for bit
+    from vfmreg import prepare_scenes as PS
+    PS._FORCE_PER_CAMERA = True
+    try:
+        desc_loop = create_descriptors(None, Surround(), gen, scan_xyz)
+    finally:
+        PS._FORCE_PER_CAMERA = False
+    np.testing.assert_array_equal(desc, desc_loop)
 
     # ---- stage parity: projection indices exact, lifted values within the ViT tolerance
     grids = orc.vit_reference(w, imgs)

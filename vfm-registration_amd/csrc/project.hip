@@ -5,6 +5,8 @@
 //   vfm_gather_bilinear_patchgrid  image_features.py:104-110 (bilinear upsample) fused with
 //                                  prepare_scenes.py:57-62, 80-104 (black-pixel zeroing, NCLT
 //                                  rot90, per-point gather, first-camera-wins scatter)
+//   vfm_lift_multicam              the two above for all cameras of a scan in ONE launch (projection
+//                                  fused with the gather; no compaction, no per-camera round trip)
 //   vfm_transform_xyz_f64          vfm_reg/utils.py:47-54
 //
 // HBM-bound integer / fp64 work: one thread per point, coalesced SoA reads, a single-workgroup
@@ -12,6 +14,9 @@
 // in the oracle's order and the file is compiled with -ffp-contract=off, so pixel coordinates
 // and surviving point indices are bit-identical to the reference's on the golden fixtures.
 #include "common.h"
+
+#include <string.h>
+#include "../../include/vfmreg.h"
 
 namespace {
 
@@ -31,17 +36,15 @@ struct ProjArgs {
     int mode;
 };
 
-__global__ __launch_bounds__(256) void project_points_kernel(const double* __restrict__ pcl, int64_t n, ProjArgs a,
-                                                             const uint8_t* __restrict__ image,
-                                                             int32_t* __restrict__ ucand, int32_t* __restrict__ vcand,
-                                                             uint8_t* __restrict__ flag) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const double p[4] = {pcl[i], pcl[n + i], pcl[2 * n + i], pcl[3 * n + i]};
+// projection of ONE point (homogeneous p) by one camera: the reference's three project_pcl_to_image
+// variants, fp64, oracle operation order.  Returns "point survives"; (ui, vi) = integer pixel.
+__device__ __forceinline__ bool project_one(const ProjArgs& a, const uint8_t* __restrict__ image, const double p[4],
+                                            long long& ui, long long& vi) {
     const double* M0 = a.mats;
     const double* M1 = a.mats + 16;
     const double* M2 = a.mats + 32;
-    long long ui = 0, vi = 0;
+    ui = 0;
+    vi = 0;
     bool keep = false;
     if (a.mode == VFM_PROJ_NCLT) {
         double pc[3];
@@ -95,6 +98,18 @@ __global__ __launch_bounds__(256) void project_points_kernel(const double* __res
             }
         }
     }
+    return keep;
+}
+
+__global__ __launch_bounds__(256) void project_points_kernel(const double* __restrict__ pcl, int64_t n, ProjArgs a,
+                                                             const uint8_t* __restrict__ image,
+                                                             int32_t* __restrict__ ucand, int32_t* __restrict__ vcand,
+                                                             uint8_t* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double p[4] = {pcl[i], pcl[n + i], pcl[2 * n + i], pcl[3 * n + i]};
+    long long ui, vi;
+    const bool keep = project_one(a, image, p, ui, vi);
     ucand[i] = (int32_t)ui;
     vcand[i] = (int32_t)vi;
     flag[i] = keep ? 1 : 0;
@@ -153,7 +168,56 @@ __device__ __forceinline__ void src_index(float scale, int dst, int in_size, int
     l0 = 1.0f - lam;
 }
 
-// one wavefront per projected point; lanes stride over channels (float4 when C % 4 == 0)
+// descriptor of ONE projected point (pixel u, v of the image the projection addressed), written by one
+// wavefront: bilinear sample of the patch grid at the pixel (image_features.py:104-108 without the
+// full-resolution tensor), zero if the raw image is black there (prepare_scenes.py:57-62).
+__device__ __forceinline__ void gather_point(const float* __restrict__ grid, int gh, int gw, int C, int Hup, int Wup,
+                                             int rot_mode, const uint8_t* __restrict__ image, int u, int v,
+                                             float* __restrict__ o, int lane) {
+    int row, col;
+    if (rot_mode == 1) {
+        row = u;
+        col = Wup - 1 - v;
+    } else {
+        row = v;
+        col = u;
+    }
+    bool black = false;
+    if (image) {
+        const uint8_t* px = image + ((int64_t)row * Wup + col) * 3;
+        black = (px[0] == 0 && px[1] == 0 && px[2] == 0);
+    }
+    if (black) return;  // the descriptor stays zero
+    const float sh = (float)gh / (float)Hup;
+    const float sw = (float)gw / (float)Wup;
+    int h0, h1, w0, w1;
+    float hl0, hl1, wl0, wl1;
+    src_index(sh, row, gh, h0, h1, hl0, hl1);
+    src_index(sw, col, gw, w0, w1, wl0, wl1);
+    const float* f00 = grid + ((int64_t)h0 * gw + w0) * C;
+    const float* f01 = grid + ((int64_t)h0 * gw + w1) * C;
+    const float* f10 = grid + ((int64_t)h1 * gw + w0) * C;
+    const float* f11 = grid + ((int64_t)h1 * gw + w1) * C;
+    if ((C & 3) == 0) {
+        for (int c4 = lane; c4 < (C >> 2); c4 += 64) {
+            const float4 a = reinterpret_cast<const float4*>(f00)[c4];
+            const float4 b = reinterpret_cast<const float4*>(f01)[c4];
+            const float4 c = reinterpret_cast<const float4*>(f10)[c4];
+            const float4 d = reinterpret_cast<const float4*>(f11)[c4];
+            float4 r;
+            r.x = hl0 * (wl0 * a.x + wl1 * b.x) + hl1 * (wl0 * c.x + wl1 * d.x);
+            r.y = hl0 * (wl0 * a.y + wl1 * b.y) + hl1 * (wl0 * c.y + wl1 * d.y);
+            r.z = hl0 * (wl0 * a.z + wl1 * b.z) + hl1 * (wl0 * c.z + wl1 * d.z);
+            r.w = hl0 * (wl0 * a.w + wl1 * b.w) + hl1 * (wl0 * c.w + wl1 * d.w);
+            reinterpret_cast<float4*>(o)[c4] = r;
+        }
+    } else {
+        for (int c = lane; c < C; c += 64)
+            o[c] = hl0 * (wl0 * f00[c] + wl1 * f01[c]) + hl1 * (wl0 * f10[c] + wl1 * f11[c]);
+    }
+}
+
+// one wavefront per projected point of ONE camera; cameras are launched in priority order
 __global__ __launch_bounds__(256) void gather_bilinear_kernel(const float* __restrict__ grid, int gh, int gw, int C,
                                                               int Hup, int Wup, int rot_mode,
                                                               const uint8_t* __restrict__ image,
@@ -167,52 +231,49 @@ __global__ __launch_bounds__(256) void gather_bilinear_kernel(const float* __res
     const int lane = threadIdx.x & 63;
     const int64_t pt = idx[i];
     if (filled[pt]) return;  // an earlier (higher-priority) camera already owns this point
-    int row, col;
-    if (rot_mode == 1) {
-        row = u[i];
-        col = Wup - 1 - v[i];
-    } else {
-        row = v[i];
-        col = u[i];
-    }
-    bool black = false;
-    if (image) {
-        const uint8_t* px = image + ((int64_t)row * Wup + col) * 3;
-        black = (px[0] == 0 && px[1] == 0 && px[2] == 0);
-    }
-    float* o = desc + pt * (int64_t)C;
-    if (!black) {
-        const float sh = (float)gh / (float)Hup;
-        const float sw = (float)gw / (float)Wup;
-        int h0, h1, w0, w1;
-        float hl0, hl1, wl0, wl1;
-        src_index(sh, row, gh, h0, h1, hl0, hl1);
-        src_index(sw, col, gw, w0, w1, wl0, wl1);
-        const float* f00 = grid + ((int64_t)h0 * gw + w0) * C;
-        const float* f01 = grid + ((int64_t)h0 * gw + w1) * C;
-        const float* f10 = grid + ((int64_t)h1 * gw + w0) * C;
-        const float* f11 = grid + ((int64_t)h1 * gw + w1) * C;
-        if ((C & 3) == 0) {
-            for (int c4 = lane; c4 < (C >> 2); c4 += 64) {
-                const float4 a = reinterpret_cast<const float4*>(f00)[c4];
-                const float4 b = reinterpret_cast<const float4*>(f01)[c4];
-                const float4 c = reinterpret_cast<const float4*>(f10)[c4];
-                const float4 d = reinterpret_cast<const float4*>(f11)[c4];
-                float4 r;
-                r.x = hl0 * (wl0 * a.x + wl1 * b.x) + hl1 * (wl0 * c.x + wl1 * d.x);
-                r.y = hl0 * (wl0 * a.y + wl1 * b.y) + hl1 * (wl0 * c.y + wl1 * d.y);
-                r.z = hl0 * (wl0 * a.z + wl1 * b.z) + hl1 * (wl0 * c.z + wl1 * d.z);
-                r.w = hl0 * (wl0 * a.w + wl1 * b.w) + hl1 * (wl0 * c.w + wl1 * d.w);
-                reinterpret_cast<float4*>(o)[c4] = r;
-            }
-        } else {
-            for (int c = lane; c < C; c += 64)
-                o[c] = hl0 * (wl0 * f00[c] + wl1 * f01[c]) + hl1 * (wl0 * f10[c] + wl1 * f11[c]);
-        }
-    }
+    gather_point(grid, gh, gw, C, Hup, Wup, rot_mode, image, u[i], v[i], desc + pt * (int64_t)C, lane);
     // black pixel: descriptor stays zero but the point is still claimed (prepare_scenes.py:57-62
     // zeroes the feature, np.unique at :96-101 still keeps this camera's entry)
     if (lane == 0) filled[pt] = 1;
+}
+
+// create_descriptors (prepare_scenes.py:50-107) for ALL cameras in one launch -- the projection fused with
+// the gather.  One wavefront per LiDAR point: lane c projects the point into camera c (same device code as
+// project_points_kernel), the first surviving camera in priority order wins (np.unique(return_index=True)
+// at :96-101 keeps the first camera's entry), and the whole wavefront samples that camera's patch grid.
+// Points seen by no camera keep their (zero-initialised) descriptor; `filled` reports which were seen.
+constexpr int LIFT_MAX_CAMS = 6;  // kernel arguments are limited to 4 KiB
+struct LiftCam {
+    ProjArgs proj;
+    const uint8_t* proj_image;
+    const float* grid;
+    const uint8_t* raw_image;
+    int gh, gw, Hup, Wup, rot_mode;
+};
+struct LiftArgs {
+    LiftCam cam[LIFT_MAX_CAMS];
+    int ncam;
+};
+
+__global__ __launch_bounds__(256) void lift_multicam_kernel(const double* __restrict__ pcl, int64_t n, LiftArgs a, int C,
+                                                            float* __restrict__ desc, uint8_t* __restrict__ filled) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    const double p[4] = {pcl[i], pcl[n + i], pcl[2 * n + i], pcl[3 * n + i]};
+    long long ui = 0, vi = 0;
+    bool keep = false;
+    if (lane < a.ncam) keep = project_one(a.cam[lane].proj, a.cam[lane].proj_image, p, ui, vi);
+    const unsigned long long seen = __ballot(keep);
+    if (seen == 0ull) {
+        if (lane == 0) filled[i] = 0;
+        return;
+    }
+    const int c = __builtin_ctzll(seen);  // first camera in priority order
+    const int u = __shfl((int)ui, c), v = __shfl((int)vi, c);
+    const LiftCam& cam = a.cam[c];
+    gather_point(cam.grid, cam.gh, cam.gw, C, cam.Hup, cam.Wup, cam.rot_mode, cam.raw_image, u, v, desc + i * (int64_t)C, lane);
+    if (lane == 0) filled[i] = 1;
 }
 
 __global__ __launch_bounds__(256) void transform_xyz_kernel(const double* __restrict__ xyz, int64_t n,
@@ -286,5 +347,36 @@ VFM_EXPORT int vfm_transform_xyz_f64(const double* xyz, int64_t n, const double*
     hipLaunchKernelGGL(transform_xyz_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xyz, n,
                        T, out);
     VFM_CHECK_LAUNCH("transform_xyz_kernel");
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_lift_multicam(const double* pcl, int64_t n, int ncam, const vfm_lift_camera* cams_host, int C,
+                                 float* desc_out, uint8_t* filled, vfm_stream_t stream) {
+    VFM_CHECK_ARG(pcl && cams_host && desc_out && filled && n >= 0 && C > 0, "lift: bad arguments");
+    VFM_CHECK_ARG(ncam >= 1 && ncam <= LIFT_MAX_CAMS, "lift: 1..%d cameras per call (got %d)", LIFT_MAX_CAMS, ncam);
+    LiftArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ncam = ncam;
+    for (int c = 0; c < ncam; ++c) {
+        const vfm_lift_camera& h = cams_host[c];
+        VFM_CHECK_ARG(h.mode >= 0 && h.mode <= 2 && h.subsample > 0.0 && h.grid, "lift: camera %d: bad mode / subsample / grid", c);
+        VFM_CHECK_ARG(h.gh > 0 && h.gw > 0 && h.Hup > 0 && h.Wup > 0, "lift: camera %d: bad sizes", c);
+        LiftCam& d = a.cam[c];
+        for (int k = 0; k < 48; ++k) d.proj.mats[k] = h.mats[k];
+        for (int k = 0; k < 4; ++k) d.proj.fc[k] = h.fc[k];
+        for (int k = 0; k < 4; ++k) d.proj.win[k] = h.win[k];
+        d.proj.subsample = h.subsample;
+        d.proj.H = h.H;
+        d.proj.W = h.W;
+        d.proj.mode = h.mode;
+        d.proj_image = h.proj_image;
+        d.grid = h.grid;
+        d.raw_image = h.raw_image;
+        d.gh = h.gh; d.gw = h.gw; d.Hup = h.Hup; d.Wup = h.Wup; d.rot_mode = h.rot_mode;
+    }
+    if (n == 0) return VFM_OK;
+    hipLaunchKernelGGL(lift_multicam_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pcl, n, a, C,
+                       desc_out, filled);
+    VFM_CHECK_LAUNCH("lift_multicam_kernel");
     return VFM_OK;
 }

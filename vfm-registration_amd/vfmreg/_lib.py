@@ -21,6 +21,13 @@ class VitConfig(C.Structure):
                 ("patch", C.c_int), ("patch_h", C.c_int), ("patch_w", C.c_int)]
 
 
+class LiftCamera(C.Structure):  # vfm_lift_camera
+    _fields_ = [("mode", C.c_int), ("mats", C.c_double * 48), ("fc", C.c_double * 4), ("subsample", C.c_double),
+                ("win", C.c_int64 * 4), ("H", C.c_int64), ("W", C.c_int64), ("proj_image", C.c_void_p),
+                ("grid", C.c_void_p), ("raw_image", C.c_void_p), ("gh", C.c_int), ("gw", C.c_int), ("Hup", C.c_int),
+                ("Wup", C.c_int), ("rot_mode", C.c_int)]
+
+
 # name -> (restype, argtypes); mirrors include/vfmreg.h one to one
 SIGNATURES = {
     "vfm_last_error": (C.c_char_p, []),
@@ -47,6 +54,7 @@ SIGNATURES = {
     "vfm_project_workspace_bytes": (C.c_size_t, [c_i64]),
     "vfm_project_pinhole_f64": (C.c_int, [C.c_int, c_vp, c_i64, c_vp, c_vp, C.c_double, c_vp, c_vp, c_i64, c_i64,
                                           c_vp, c_vp, c_vp, c_vp, c_vp, C.c_size_t, c_vp]),
+    "vfm_lift_multicam": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, C.c_int, c_vp, c_vp, c_vp]),
     "vfm_gather_bilinear_patchgrid": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp,
                                                 c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "vfm_transform_xyz_f64": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),

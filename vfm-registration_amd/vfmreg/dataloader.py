@@ -56,14 +56,19 @@ class NCLT(_Base):
         T_c_lb3 = np.linalg.inv(self.camera_parameters[camera]["x_lb3"])
         return T_c_lb3 @ T_lb3_body  # nclt.py:323-325
 
-    def project_pcl_to_image(self, pcl, image, camera: str, _device_inputs=None):
+    def projection_params(self, camera: str, image_shape) -> dict:
+        """what project_pcl_to_image feeds the projection kernel (also used by the fused multi-camera lift)"""
         assert camera in self.cameras, f"Camera {camera} not available"
         K = np.asarray(self.camera_parameters[camera]["K"], dtype=np.float64)
         win = np.array(self.undistortion_masks[camera]["coords"]) // self.image_subsample
+        return dict(mode=ops.PROJ_NCLT, mats=[self.extrinsic(camera), K], fc=None, subsample=float(self.image_subsample),
+                    win=win, H=image_shape[0], W=image_shape[1], needs_image=True)
+
+    def project_pcl_to_image(self, pcl, image, camera: str, _device_inputs=None):
+        q = self.projection_params(camera, image.shape)
         pcl_d = _device_inputs[0] if _device_inputs else _to_dev(pcl, np.float64)
         img_d = _device_inputs[1] if _device_inputs else _to_dev(image, np.uint8)
-        r = ops.project_pinhole(ops.PROJ_NCLT, pcl_d, [self.extrinsic(camera), K], None, float(self.image_subsample),
-                                win, img_d)
+        r = ops.project_pinhole(q["mode"], pcl_d, q["mats"], None, q["subsample"], q["win"], img_d)
         return r if _device_inputs else self._finish(*r)
 
 
@@ -79,15 +84,19 @@ class OxfordRobotcar(_Base):
         self.image_subsample = image_subsample
         self.cameras = cameras or list(camera_model.keys())
 
-    def project_pcl_to_image(self, pcl, image, camera: str, _device_inputs=None):
+    def projection_params(self, camera: str, image_shape) -> dict:
         assert camera in self.cameras, f"Camera {camera} not available"
         cm = self.camera_model[camera]
         G = np.asarray(cm.G_camera_image, dtype=np.float64)
         Ginv = np.linalg.solve(G, np.eye(4))  # the reference solves per call (oxford_robotcar.py:341)
         fc = [cm.focal_length[0], cm.focal_length[1], cm.principal_point[0], cm.principal_point[1]]
+        return dict(mode=ops.PROJ_ROBOTCAR, mats=[self.calib["lidar_in_ego"], self.calib[f"{camera}_in_ego"], Ginv], fc=fc,
+                    subsample=float(self.image_subsample), win=None, H=image_shape[0], W=image_shape[1], needs_image=False)
+
+    def project_pcl_to_image(self, pcl, image, camera: str, _device_inputs=None):
+        q = self.projection_params(camera, image.shape)
         pcl_d = _device_inputs[0] if _device_inputs else _to_dev(pcl, np.float64)
-        r = ops.project_pinhole(ops.PROJ_ROBOTCAR, pcl_d, [self.calib["lidar_in_ego"], self.calib[f"{camera}_in_ego"], Ginv],
-                                fc, float(self.image_subsample), None, None, image.shape[0], image.shape[1])
+        r = ops.project_pinhole(q["mode"], pcl_d, q["mats"], q["fc"], q["subsample"], None, None, q["H"], q["W"])
         return r if _device_inputs else self._finish(*r)
 
 
@@ -99,9 +108,13 @@ class KittiOdometry(_Base):
         self.image_subsample = image_subsample
         self.cameras = ["camera"]
 
-    def project_pcl_to_image(self, pcl, image, camera: str = "camera", _device_inputs=None):
+    def projection_params(self, camera: str, image_shape) -> dict:
         P = np.asarray(self.calib["P2"], dtype=np.float64) @ np.asarray(self.calib["Tr_velo_to_cam"], dtype=np.float64)
+        return dict(mode=ops.PROJ_KITTI, mats=[P], fc=None, subsample=float(self.image_subsample), win=None,
+                    H=image_shape[0], W=image_shape[1], needs_image=False)
+
+    def project_pcl_to_image(self, pcl, image, camera: str = "camera", _device_inputs=None):
+        q = self.projection_params(camera, image.shape)
         pcl_d = _device_inputs[0] if _device_inputs else _to_dev(pcl, np.float64)
-        r = ops.project_pinhole(ops.PROJ_KITTI, pcl_d, [P], None, float(self.image_subsample), None, None,
-                                image.shape[0], image.shape[1])
+        r = ops.project_pinhole(q["mode"], pcl_d, q["mats"], None, q["subsample"], None, None, q["H"], q["W"])
         return r if _device_inputs else self._finish(*r)

@@ -227,6 +227,52 @@ def project_pinhole(mode: int, pcl4xn: torch.Tensor, mats, fc=None, subsample: f
     return u, v, idx, count
 
 
+LIFT_MAX_CAMS = 6
+
+
+def lift_multicam(pcl4xn: torch.Tensor, cams: list, desc: torch.Tensor, filled: torch.Tensor) -> None:
+    """create_descriptors (prepare_scenes.py:50-107) for all cameras in one launch.  ``cams``: list (priority
+    order) of dicts with the projection parameters of ``project_pinhole`` (mode, mats, fc, subsample, win, H, W,
+    proj_image) and of ``gather_bilinear`` (grid [gh, gw, C], Hup, Wup, rot_mode, raw_image).  ``desc`` must be
+    zero-initialised; ``filled`` receives 1 for every point some camera saw."""
+    import ctypes as C
+    _chk(pcl4xn, torch.float64, "pcl")
+    _chk(desc, torch.float32, "desc")
+    _chk(filled, torch.uint8, "filled")
+    if pcl4xn.dim() != 2 or pcl4xn.shape[0] != 4 or not 1 <= len(cams) <= LIFT_MAX_CAMS:
+        raise ValueError("Invalid shape")
+    lib = _lib.load()
+    arr = (_lib.LiftCamera * len(cams))()
+    keep = []
+    for k, c in enumerate(cams):
+        g = c["grid"]
+        _chk(g, torch.float32, "grid")
+        if g.shape[-1] != desc.shape[1]:
+            raise ValueError("Invalid shape")
+        a = arr[k]
+        a.mode = int(c["mode"])
+        flat = [0.0] * 48
+        for j, m in enumerate(list(c["mats"])[:3]):
+            vals = [float(x) for x in (m.reshape(-1).tolist() if hasattr(m, "reshape") else m)]
+            flat[16 * j:16 * j + len(vals)] = vals
+        a.mats[:] = flat
+        a.fc[:] = [float(x) for x in c["fc"]] if c.get("fc") is not None else [0.0] * 4
+        a.subsample = float(c.get("subsample", 1.0))
+        a.win[:] = [int(x) for x in c["win"]] if c.get("win") is not None else [0] * 4
+        a.H, a.W = int(c["H"]), int(c["W"])
+        for name in ("proj_image", "raw_image"):
+            t = c.get(name)
+            if t is not None:
+                _chk(t, torch.uint8, name)
+                keep.append(t)
+            setattr(a, name, _ptr(t))
+        a.grid = g.data_ptr()
+        a.gh, a.gw = int(g.shape[0]), int(g.shape[1])
+        a.Hup, a.Wup, a.rot_mode = int(c["Hup"]), int(c["Wup"]), int(c.get("rot_mode", 0))
+    _lib.check(lib.vfm_lift_multicam(pcl4xn.data_ptr(), pcl4xn.shape[1], len(cams), C.cast(arr, C.c_void_p),
+                                     desc.shape[1], desc.data_ptr(), filled.data_ptr(), _stream()), "lift_multicam")
+
+
 def gather_bilinear(grid: torch.Tensor, Hup: int, Wup: int, rot_mode: int, image: Optional[torch.Tensor],
                     u: torch.Tensor, v: torch.Tensor, idx: torch.Tensor, count: Optional[torch.Tensor],
                     desc: torch.Tensor, filled: torch.Tensor) -> None:

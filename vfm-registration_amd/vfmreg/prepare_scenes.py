@@ -22,6 +22,9 @@ from . import ops
 from .dataloader import NCLT
 
 
+_FORCE_PER_CAMERA = False  # tests: run the per-camera path (project -> compact -> gather per camera)
+
+
 def create_descriptors(image_files, sequence, feature_generator, pcl, images=None) -> np.ndarray:
     images = images if images is not None else sequence.read_images(filenames=image_files)
     cams = list(images.keys())  # the reference iterates images.items() (PS:70): dict order = camera priority
@@ -46,6 +49,18 @@ def create_descriptors(image_files, sequence, feature_generator, pcl, images=Non
     desc = torch.zeros((n, C), dtype=torch.float32, device=dev)
     filled = torch.zeros(n, dtype=torch.uint8, device=dev)
     is_nclt = isinstance(sequence, NCLT) or getattr(sequence, "rotate_images", False)
+    if hasattr(sequence, "projection_params") and len(cams) <= ops.LIFT_MAX_CAMS and not _FORCE_PER_CAMERA:
+        # projection fused with the gather, all cameras in one launch (same device code as the loop below)
+        specs = []
+        for c in cams:
+            raw = img_d[c]
+            proj_img = torch.rot90(raw, 1, (0, 1)).contiguous() if is_nclt else raw  # PS:73-74
+            q = dict(sequence.projection_params(c, proj_img.shape))
+            q.update(proj_image=proj_img if q.pop("needs_image", False) else None, grid=grid[c].contiguous(),
+                     Hup=raw.shape[0], Wup=raw.shape[1], rot_mode=1 if is_nclt else 0, raw_image=raw)
+            specs.append(q)
+        ops.lift_multicam(pcl_d, specs, desc, filled)
+        return desc.cpu().numpy()
     for c in cams:
         raw = img_d[c]
         H, W = raw.shape[0], raw.shape[1]
