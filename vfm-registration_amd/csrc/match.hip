@@ -792,82 +792,171 @@ __device__ __forceinline__ void wave_argmax(double& s, long long& j) {
     }
 }
 
-// one wave per query
+// Exact decision among the candidates: one workgroup (4 waves) owns 64 queries; thread t < 64 = query t.
+//   single-row candidates (the common case, ~1.3 per query): the block's (query, candidate) pairs are
+//   flattened and taken 64 at a time; per batch and per 96-wide k chunk the four waves compute the fp64
+//   products of the 64 pairs k-parallel (coalesced row segments, 16 pairs per wave; fp32 normalisation as
+//   faiss leaves it, products of two fp32 are exact in fp64) into LDS, then wave 0 adds every pair's 96
+//   products in ascending k -- 64 different in-order chains at once instead of one chain per wavefront.
+//   whole-chunk candidates (rare): per flagged query, the lanes of wave 0 score their own rows of the chunk.
+// The accumulation order is the oracle's (sequential k), ties -> lowest index, sim = (float)score.
+constexpr int RS_KC = 96;             // k values per chunk (24 float4 per row)
+constexpr int RS_STRIDE = RS_KC + 1;  // doubles per LDS row: 194 words == 2 (mod 64) -> conflict-free ds_read_b64
+constexpr int RS_MAX_PAIRS = 64 * CAND_CAP;
 __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restrict__ q, const float* __restrict__ invq,
                                                             const float* __restrict__ b, const float* __restrict__ invb,
                                                             int64_t n, int64_t m, int d, const int* __restrict__ cand_cnt,
                                                             const unsigned* __restrict__ cand,
                                                             int64_t* __restrict__ idx_out, float* __restrict__ sim_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int wave = threadIdx.x >> 6, lane = lane_id();
-    float* qn = reinterpret_cast<float*>(smem) + wave * 2 * d;  // normalised query row
-    float* bn = qn + d;                                          // normalised candidate row
-    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
-    if (qi >= n) return;
-    const float iq = invq[qi];
-    if (iq == 0.0f) {  // zero query: every score is 0.0, the lowest index wins
-        if (lane == 0) {
-            idx_out[qi] = (m > 0) ? 0 : -1;
-            sim_out[qi] = 0.0f;
+    double* P = reinterpret_cast<double*>(smem);               // [64][RS_STRIDE] products
+    double* pscore = P + 64 * RS_STRIDE;                       // [RS_MAX_PAIRS] exact score per pair
+    float* qn = reinterpret_cast<float*>(pscore + RS_MAX_PAIRS);  // [d] normalised query row (chunk rescans)
+    __shared__ unsigned short p_slot[RS_MAX_PAIRS];            // pair -> (query lane << 8) | candidate slot e
+    __shared__ long long s_j[64];
+    __shared__ float s_iq[64], s_ib[64];
+    __shared__ int s_ql[64];
+    __shared__ int s_total;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int64_t q0 = (int64_t)blockIdx.x * 64;
+    // per-query state lives in wave 0 (lane = query)
+    const int64_t qi = q0 + lane;
+    const bool owner = wave == 0;
+    const bool have = owner && qi < n;
+    const float iq = have ? invq[qi] : 0.0f;
+    int cnt = have ? cand_cnt[qi] : 0;
+    if (iq == 0.0f || cnt < 0) cnt = 0;  // zero query: decided below; overflow (-1): match_exact_kernel's
+    bool any_rescan = false;
+    int my_off = 0, my_pairs = 0;
+    if (owner) {
+        // flatten: single-row candidates of query `lane` become pairs [my_off, my_off + my_pairs)
+        for (int e = 0; e < cnt; ++e) {
+            const unsigned ce = cand[(size_t)qi * CAND_CAP + e];
+            if (ce & 128u) any_rescan = true;
+            else if ((long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u) < m) ++my_pairs;
         }
-        return;
+        int incl = my_pairs;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        my_off = incl - my_pairs;
+        if (lane == 63) s_total = incl;
+        int k = my_off;
+        for (int e = 0; e < cnt; ++e) {
+            const unsigned ce = cand[(size_t)qi * CAND_CAP + e];
+            if (!(ce & 128u) && (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u) < m) p_slot[k++] = (unsigned short)((lane << 8) | e);
+        }
     }
-    const int cnt = cand_cnt[qi];
-    if (cnt < 0) return;  // handled by match_exact_kernel
-    for (int k = lane * 4; k < d; k += 256) {
-        float4 v = *reinterpret_cast<const float4*>(q + qi * (int64_t)d + k);
-        v.x = v.x * iq; v.y = v.y * iq; v.z = v.z * iq; v.w = v.w * iq;
-        *reinterpret_cast<float4*>(qn + k) = v;
+    __syncthreads();
+    const int total = s_total;
+    for (int p0 = 0; p0 < total; p0 += 64) {
+        // slot `lane` of this batch = pair p0 + lane
+        long long j = -1;
+        if (owner) {
+            const int pid = p0 + lane;
+            const unsigned ps = (pid < total) ? p_slot[pid] : 0u;
+            const int ql = (int)(ps >> 8);
+            const float iqq = __shfl(iq, ql);  // all lanes of wave 0 take part
+            float ibb = 0.f;
+            if (pid < total) {
+                const unsigned ce = cand[(size_t)(q0 + ql) * CAND_CAP + (ps & 255u)];
+                j = (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u);
+                ibb = invb[j];
+            }
+            s_j[lane] = j;
+            s_ql[lane] = ql;
+            s_iq[lane] = iqq;
+            s_ib[lane] = ibb;
+        }
+        __syncthreads();
+        double acc = 0.0;
+        for (int k0 = 0; k0 < d; k0 += RS_KC) {
+            const int kn = min(RS_KC, d - k0);  // d % 4 == 0
+            // products: wave w takes slots 16 w .. 16 w + 15, two per pass (lanes 0..23 and 32..55: one float4 each)
+            const int sub = lane >> 5, l4 = lane & 31;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int sl = 16 * wave + 2 * it + sub;
+                const long long jj = s_j[sl];
+                if (jj >= 0 && 4 * l4 < kn) {
+                    const float iqq = s_iq[sl], ibb = s_ib[sl];
+                    const float4 qv = *reinterpret_cast<const float4*>(q + (q0 + s_ql[sl]) * (int64_t)d + k0 + 4 * l4);
+                    const float4 bv = *reinterpret_cast<const float4*>(b + jj * (int64_t)d + k0 + 4 * l4);
+                    double* dst = P + sl * RS_STRIDE + 4 * l4;
+                    dst[0] = (double)(qv.x * iqq) * (double)(bv.x * ibb);
+                    dst[1] = (double)(qv.y * iqq) * (double)(bv.y * ibb);
+                    dst[2] = (double)(qv.z * iqq) * (double)(bv.z * ibb);
+                    dst[3] = (double)(qv.w * iqq) * (double)(bv.w * ibb);
+                }
+            }
+            __syncthreads();
+            if (owner && j >= 0) {
+                const double* src = P + lane * RS_STRIDE;
+                for (int k = 0; k < kn; ++k) acc = acc + src[k];
+            }
+            __syncthreads();
+        }
+        if (owner && j >= 0) pscore[p0 + lane] = acc;
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    if (!owner) return;
+    // every query folds its own pairs: best score, ties -> lowest index
     double best = 0.0;
     long long bj = -1;
-    for (int e = 0; e < cnt; ++e) {
-        const unsigned ce = cand[(size_t)qi * CAND_CAP + e];
-        const long long base = (long long)(ce >> 8) * CHUNK_ROWS;
-        if (ce & 128u) {
-            // whole chunk: every lane scores its own rows (rare)
-            for (int li = lane; li < CHUNK_ROWS; li += 64) {
-                const long long j = base + li;
-                if (j < m) {
-                    const double s = dot_norm_f64(qn, b + j * (int64_t)d, invb[j], d);
-                    if (bj < 0 || s > best || (s == best && j < bj)) {
-                        best = s;
-                        bj = j;
+    for (int k = my_off; k < my_off + my_pairs; ++k) {
+        const unsigned ce = cand[(size_t)qi * CAND_CAP + (p_slot[k] & 255u)];
+        const long long j = (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u);
+        const double sc = pscore[k];
+        if (bj < 0 || sc > best || (sc == best && j < bj)) {
+            best = sc;
+            bj = j;
+        }
+    }
+    // whole-chunk candidates: wave 0 takes the flagged queries one by one
+    if (__any(any_rescan)) {
+        for (int ql = 0; ql < 64; ++ql) {
+            if (!__shfl((int)any_rescan, ql)) continue;  // wave-uniform
+            const int64_t qq = q0 + ql;
+            const float iqq = __shfl(iq, ql);
+            const int cq = __shfl(cnt, ql);
+            __builtin_amdgcn_wave_barrier();
+            for (int k = lane * 4; k < d; k += 256) {
+                float4 v = *reinterpret_cast<const float4*>(q + qq * (int64_t)d + k);
+                v.x = v.x * iqq; v.y = v.y * iqq; v.z = v.z * iqq; v.w = v.w * iqq;
+                *reinterpret_cast<float4*>(qn + k) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            double rbest = 0.0;
+            long long rj = -1;
+            for (int e = 0; e < cq; ++e) {
+                const unsigned ce = cand[(size_t)qq * CAND_CAP + e];
+                if (!(ce & 128u)) continue;
+                const long long base = (long long)(ce >> 8) * CHUNK_ROWS;
+                for (int li = lane; li < CHUNK_ROWS; li += 64) {
+                    const long long j = base + li;
+                    if (j < m) {
+                        const double sc = dot_norm_f64(qn, b + j * (int64_t)d, invb[j], d);
+                        if (rj < 0 || sc > rbest || (sc == rbest && j < rj)) {
+                            rbest = sc;
+                            rj = j;
+                        }
                     }
                 }
             }
-        } else {
-            // single row: the wave fetches it coalesced, every lane then runs the same sequential
-            // fp64 sum from LDS (broadcast reads) -- identical result in all lanes
-            const long long j = base + (ce & 127u);
-            if (j < m) {
-                const float ib = invb[j];
-                __builtin_amdgcn_wave_barrier();
-                for (int k = lane * 4; k < d; k += 256) {
-                    float4 v = *reinterpret_cast<const float4*>(b + j * (int64_t)d + k);
-                    v.x = v.x * ib; v.y = v.y * ib; v.z = v.z * ib; v.w = v.w * ib;
-                    *reinterpret_cast<float4*>(bn + k) = v;
-                }
-                __builtin_amdgcn_wave_barrier();
-                double acc = 0.0;
-                for (int k = 0; k < d; k += 4) {
-                    const float4 qa = *reinterpret_cast<const float4*>(qn + k);
-                    const float4 bb = *reinterpret_cast<const float4*>(bn + k);
-                    acc = acc + (double)qa.x * (double)bb.x;
-                    acc = acc + (double)qa.y * (double)bb.y;
-                    acc = acc + (double)qa.z * (double)bb.z;
-                    acc = acc + (double)qa.w * (double)bb.w;
-                }
-                if (bj < 0 || acc > best || (acc == best && j < bj)) {
-                    best = acc;
-                    bj = j;
-                }
+            wave_argmax(rbest, rj);
+            if (lane == ql && rj >= 0 && (bj < 0 || rbest > best || (rbest == best && rj < bj))) {
+                best = rbest;
+                bj = rj;
             }
         }
     }
-    wave_argmax(best, bj);
-    if (lane == 0) {
+    if (!have) return;
+    if (iq == 0.0f) {  // zero query: every score is 0.0, the lowest index wins
+        idx_out[qi] = (m > 0) ? 0 : -1;
+        sim_out[qi] = 0.0f;
+    } else if (cand_cnt[qi] >= 0) {
         idx_out[qi] = bj;
         sim_out[qi] = (float)best;
     }
@@ -1358,8 +1447,17 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS), 0, st, w.partials, a.nchunks,
                        a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.fb_count, w.fb_list);
     VFM_CHECK_LAUNCH("match_select_kernel");
-    hipLaunchKernelGGL(match_rescore_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)d * 4 * 8, st, q, Q.inv, b,
-                       B.inv, n, m, d, w.cand_cnt, w.cand, idx_out, sim_out);
+    {
+        const size_t lds = (size_t)(64 * RS_STRIDE + RS_MAX_PAIRS) * sizeof(double) + (size_t)d * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_rescore_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(match_rescore_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), lds, st, q, Q.inv, b, B.inv, n, m,
+                           d, w.cand_cnt, w.cand, idx_out, sim_out);
+    }
     VFM_CHECK_LAUNCH("match_rescore_kernel");
     hipLaunchKernelGGL(match_exact_kernel, dim3(256), dim3(256), (((size_t)d * 4 + 15) & ~(size_t)15) + 64, st, q, Q.inv,
                        b, B.inv, n, m, d, w.fb_list, w.fb_count, idx_out, sim_out);
