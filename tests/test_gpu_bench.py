@@ -1,0 +1,47 @@
+"""bench.py contract on the GPU box: the plain form and the torch.distributed.run form the driver uses for
+N > 1 (here with one rank: backend "nccl" = RCCL, rendezvous on 127.0.0.1), both must print ONE JSON line
+with the contract's keys."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _check(out: str, steps: int):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    d = json.loads(lines[0])
+    assert KEYS <= set(d), sorted(KEYS - set(d))
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["value"] > 50 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and 0.05 < r["frac"] < 1.0 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
+    assert "workload" in d["config"] and d["config"]["max_pose_err_vs_planted"] < 0.05
+    return d
+
+
+def test_bench_plain_small_run():
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    _check(r.stdout, 4)
+
+
+def test_bench_under_torch_distributed_run_world1():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", str(ROOT / "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _check(r.stdout, 4)
+    assert d["cpu_baseline"] is not None and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
