@@ -117,6 +117,31 @@ def test_match_fast_edge_cases(ops, orc):
     assert idx2[5] == 0
 
 
+def test_match_fast_randomised_shapes_and_candidate_mixes(ops, orc):
+    """ragged (n, m) with data that exercises every branch of select / rescore at once: exact duplicates
+    (ties -> lowest index, whole-chunk rescans), clusters of near-duplicates inside the coarse window (many
+    single-row candidates per query, several 64-pair batches per block), zero rows, padded last chunks,
+    queries with > 40 candidate chunks (overflow -> all-pairs fallback)"""
+    rng = np.random.default_rng(2024)
+    for trial in range(12):
+        d = int(rng.choice([128, 256, 384]))
+        n = int(rng.integers(1, 700))
+        m = int(rng.integers(1, 6000))
+        b = rng.standard_normal((m, d)).astype(np.float32)
+        q = rng.standard_normal((n, d)).astype(np.float32)
+        if m > 10:
+            base = rng.standard_normal(d).astype(np.float32)
+            k = min(m, int(rng.integers(2, 90)))
+            rows = rng.choice(m, k, replace=False)
+            b[rows] = base + np.float32(rng.choice([0.0, 1e-4, 3e-3])) * rng.standard_normal((k, d)).astype(np.float32)
+            b[rng.integers(0, m)] = 0.0
+            hit = rng.choice(n, min(n, 40), replace=False)
+            q[hit] = base + 1e-3 * rng.standard_normal((len(hit), d)).astype(np.float32)
+            q[rng.integers(0, n)] = 0.0
+            q[rng.integers(0, n)] = b[rng.integers(0, m)]
+        _check_match(ops, orc, q, b, ops.FAST)
+
+
 def test_match_fast_full_size_property(ops, orc):
     """BASELINE config C2 (20k x 200k x 384): exactness via the accelerated oracle (BLAS prefilter
     + fp64 decision) on a row sample, and planted-match recovery on all rows."""
