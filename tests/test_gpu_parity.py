@@ -142,6 +142,22 @@ def test_match_fast_randomised_shapes_and_candidate_mixes(ops, orc):
         _check_match(ops, orc, q, b, ops.FAST)
 
 
+def test_match_fast_many_single_row_candidates(ops, orc):
+    """35 near-duplicates of one direction, one per 128-row chunk, and 100 queries pointing at them: every
+    query gets 35 single-row candidates inside the coarse window (under the cap of 40) -> a 64-query block of
+    the rescore kernel holds 2240 (query, candidate) pairs = three epochs of its pair table"""
+    rng = np.random.default_rng(99)
+    d, m, n = 384, 40 * 128, 100
+    b = rng.standard_normal((m, d)).astype(np.float32)
+    base = rng.standard_normal(d).astype(np.float32)
+    rows = np.arange(35) * 128 + rng.integers(0, 128, 35)
+    b[rows] = base + 2e-4 * rng.standard_normal((35, d)).astype(np.float32)
+    q = rng.standard_normal((n, d)).astype(np.float32)
+    q[:90] = base + 1e-3 * rng.standard_normal((90, d)).astype(np.float32)
+    idx, _ = _check_match(ops, orc, q, b, ops.FAST)
+    assert np.isin(idx[:90], rows).all()
+
+
 def test_match_fast_full_size_property(ops, orc):
     """BASELINE config C2 (20k x 200k x 384): exactness via the accelerated oracle (BLAS prefilter
     + fp64 decision) on a row sample, and planted-match recovery on all rows."""

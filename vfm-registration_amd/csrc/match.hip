@@ -802,7 +802,7 @@ __device__ __forceinline__ void wave_argmax(double& s, long long& j) {
 // The accumulation order is the oracle's (sequential k), ties -> lowest index, sim = (float)score.
 constexpr int RS_KC = 96;             // k values per chunk (24 float4 per row)
 constexpr int RS_STRIDE = RS_KC + 1;  // doubles per LDS row: 194 words == 2 (mod 64) -> conflict-free ds_read_b64
-constexpr int RS_MAX_PAIRS = 64 * CAND_CAP;
+constexpr int RS_PAIRS = 1024;        // pair slots per epoch (a block has ~80 pairs; 64 * CAND_CAP at most)
 __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restrict__ q, const float* __restrict__ invq,
                                                             const float* __restrict__ b, const float* __restrict__ invb,
                                                             int64_t n, int64_t m, int d, const int* __restrict__ cand_cnt,
@@ -810,9 +810,10 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restr
                                                             int64_t* __restrict__ idx_out, float* __restrict__ sim_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* P = reinterpret_cast<double*>(smem);               // [64][RS_STRIDE] products
-    double* pscore = P + 64 * RS_STRIDE;                       // [RS_MAX_PAIRS] exact score per pair
-    float* qn = reinterpret_cast<float*>(pscore + RS_MAX_PAIRS);  // [d] normalised query row (chunk rescans)
-    __shared__ unsigned short p_slot[RS_MAX_PAIRS];            // pair -> (query lane << 8) | candidate slot e
+    double* pscore = P + 64 * RS_STRIDE;                       // [RS_PAIRS] exact score per pair of the epoch
+    float* qn = reinterpret_cast<float*>(pscore + RS_PAIRS);   // [d] normalised query row (chunk rescans)
+    __shared__ unsigned p_j[RS_PAIRS];                         // pair -> map row
+    __shared__ unsigned char p_q[RS_PAIRS];                    // pair -> query lane
     __shared__ long long s_j[64];
     __shared__ float s_iq[64], s_ib[64];
     __shared__ int s_ql[64];
@@ -828,12 +829,14 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restr
     if (iq == 0.0f || cnt < 0) cnt = 0;  // zero query: decided below; overflow (-1): match_exact_kernel's
     bool any_rescan = false;
     int my_off = 0, my_pairs = 0;
+    const unsigned* mycand = cand + (size_t)(have ? qi : 0) * CAND_CAP;
+    auto row_of = [&](unsigned ce) { return (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u); };
     if (owner) {
-        // flatten: single-row candidates of query `lane` become pairs [my_off, my_off + my_pairs)
+        // flatten: the single-row candidates of query `lane` become pairs [my_off, my_off + my_pairs)
         for (int e = 0; e < cnt; ++e) {
-            const unsigned ce = cand[(size_t)qi * CAND_CAP + e];
+            const unsigned ce = mycand[e];
             if (ce & 128u) any_rescan = true;
-            else if ((long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u) < m) ++my_pairs;
+            else if (row_of(ce) < m) ++my_pairs;
         }
         int incl = my_pairs;
 #pragma unroll
@@ -843,77 +846,109 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restr
         }
         my_off = incl - my_pairs;
         if (lane == 63) s_total = incl;
-        int k = my_off;
-        for (int e = 0; e < cnt; ++e) {
-            const unsigned ce = cand[(size_t)qi * CAND_CAP + e];
-            if (!(ce & 128u) && (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u) < m) p_slot[k++] = (unsigned short)((lane << 8) | e);
-        }
     }
     __syncthreads();
     const int total = s_total;
-    for (int p0 = 0; p0 < total; p0 += 64) {
-        // slot `lane` of this batch = pair p0 + lane
-        long long j = -1;
-        if (owner) {
-            const int pid = p0 + lane;
-            const unsigned ps = (pid < total) ? p_slot[pid] : 0u;
-            const int ql = (int)(ps >> 8);
-            const float iqq = __shfl(iq, ql);  // all lanes of wave 0 take part
-            float ibb = 0.f;
-            if (pid < total) {
-                const unsigned ce = cand[(size_t)(q0 + ql) * CAND_CAP + (ps & 255u)];
-                j = (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u);
-                ibb = invb[j];
-            }
-            s_j[lane] = j;
-            s_ql[lane] = ql;
-            s_iq[lane] = iqq;
-            s_ib[lane] = ibb;
-        }
-        __syncthreads();
-        double acc = 0.0;
-        for (int k0 = 0; k0 < d; k0 += RS_KC) {
-            const int kn = min(RS_KC, d - k0);  // d % 4 == 0
-            // products: wave w takes slots 16 w .. 16 w + 15, two per pass (lanes 0..23 and 32..55: one float4 each)
-            const int sub = lane >> 5, l4 = lane & 31;
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int sl = 16 * wave + 2 * it + sub;
-                const long long jj = s_j[sl];
-                if (jj >= 0 && 4 * l4 < kn) {
-                    const float iqq = s_iq[sl], ibb = s_ib[sl];
-                    const float4 qv = *reinterpret_cast<const float4*>(q + (q0 + s_ql[sl]) * (int64_t)d + k0 + 4 * l4);
-                    const float4 bv = *reinterpret_cast<const float4*>(b + jj * (int64_t)d + k0 + 4 * l4);
-                    double* dst = P + sl * RS_STRIDE + 4 * l4;
-                    dst[0] = (double)(qv.x * iqq) * (double)(bv.x * ibb);
-                    dst[1] = (double)(qv.y * iqq) * (double)(bv.y * ibb);
-                    dst[2] = (double)(qv.z * iqq) * (double)(bv.z * ibb);
-                    dst[3] = (double)(qv.w * iqq) * (double)(bv.w * ibb);
-                }
-            }
-            __syncthreads();
-            if (owner && j >= 0) {
-                const double* src = P + lane * RS_STRIDE;
-                for (int k = 0; k < kn; ++k) acc = acc + src[k];
-            }
-            __syncthreads();
-        }
-        if (owner && j >= 0) pscore[p0 + lane] = acc;
-    }
-    __syncthreads();
-    if (!owner) return;
-    // every query folds its own pairs: best score, ties -> lowest index
     double best = 0.0;
     long long bj = -1;
-    for (int k = my_off; k < my_off + my_pairs; ++k) {
-        const unsigned ce = cand[(size_t)qi * CAND_CAP + (p_slot[k] & 255u)];
-        const long long j = (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u);
-        const double sc = pscore[k];
-        if (bj < 0 || sc > best || (sc == best && j < bj)) {
-            best = sc;
-            bj = j;
+    for (int E0 = 0; E0 < total; E0 += RS_PAIRS) {  // one epoch unless a block has > RS_PAIRS pairs
+        const int ecount = min(RS_PAIRS, total - E0);
+        if (owner) {
+            int k = my_off;
+            for (int e = 0; e < cnt; ++e) {
+                const unsigned ce = mycand[e];
+                if ((ce & 128u) || row_of(ce) >= m) continue;
+                if (k >= E0 && k < E0 + RS_PAIRS) {
+                    p_j[k - E0] = (unsigned)row_of(ce);
+                    p_q[k - E0] = (unsigned char)lane;
+                }
+                ++k;
+            }
         }
+        __syncthreads();
+        for (int p0 = 0; p0 < ecount; p0 += 64) {
+            // slot `lane` of this batch = pair p0 + lane of the epoch
+            long long j = -1;
+            if (owner) {
+                const int pid = p0 + lane;
+                const int ql = (pid < ecount) ? (int)p_q[pid] : 0;
+                const float iqq = __shfl(iq, ql);  // all lanes of wave 0 take part
+                float ibb = 0.f;
+                if (pid < ecount) {
+                    j = (long long)p_j[pid];
+                    ibb = invb[j];
+                }
+                s_j[lane] = j;
+                s_ql[lane] = ql;
+                s_iq[lane] = iqq;
+                s_ib[lane] = ibb;
+            }
+            __syncthreads();
+            double acc = 0.0;
+            // wave w takes slots 16 w .. 16 w + 15, two per pass (lanes 0..23 and 32..55: one float4 of k each);
+            // the row segments of chunk c+1 are fetched while wave 0 runs the chains of chunk c
+            const int sub = lane >> 5, l4 = lane & 31;
+            float4 qv[8], bv[8];
+            auto fetch = [&](int k0) {
+                const int kn = min(RS_KC, d - k0);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int sl = 16 * wave + 2 * it + sub;
+                    const long long jj = s_j[sl];
+                    if (jj >= 0 && 4 * l4 < kn) {
+                        qv[it] = *reinterpret_cast<const float4*>(q + (q0 + s_ql[sl]) * (int64_t)d + k0 + 4 * l4);
+                        bv[it] = *reinterpret_cast<const float4*>(b + jj * (int64_t)d + k0 + 4 * l4);
+                    }
+                }
+            };
+            fetch(0);
+            for (int k0 = 0; k0 < d; k0 += RS_KC) {
+                const int kn = min(RS_KC, d - k0);  // d % 4 == 0
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int sl = 16 * wave + 2 * it + sub;
+                    if (s_j[sl] >= 0 && 4 * l4 < kn) {
+                        const float iqq = s_iq[sl], ibb = s_ib[sl];
+                        double* dst = P + sl * RS_STRIDE + 4 * l4;
+                        dst[0] = (double)(qv[it].x * iqq) * (double)(bv[it].x * ibb);
+                        dst[1] = (double)(qv[it].y * iqq) * (double)(bv[it].y * ibb);
+                        dst[2] = (double)(qv[it].z * iqq) * (double)(bv[it].z * ibb);
+                        dst[3] = (double)(qv[it].w * iqq) * (double)(bv[it].w * ibb);
+                    }
+                }
+                __syncthreads();
+                if (k0 + RS_KC < d) fetch(k0 + RS_KC);
+                if (owner && j >= 0) {
+                    const double* src = P + lane * RS_STRIDE;
+                    int k = 0;
+                    for (; k + 8 <= kn; k += 8) {  // reads first, then the in-order chain
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = src[k + u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc = acc + v[u];
+                    }
+                    for (; k < kn; ++k) acc = acc + src[k];
+                }
+                __syncthreads();
+            }
+            if (owner && j >= 0) pscore[p0 + lane] = acc;
+        }
+        __syncthreads();
+        if (owner) {  // every query folds its own pairs of this epoch: best score, ties -> lowest index
+            const int lo = max(my_off, E0), hi = min(my_off + my_pairs, E0 + RS_PAIRS);
+            for (int k = lo; k < hi; ++k) {
+                const long long j = (long long)p_j[k - E0];
+                const double sc = pscore[k - E0];
+                if (bj < 0 || sc > best || (sc == best && j < bj)) {
+                    best = sc;
+                    bj = j;
+                }
+            }
+        }
+        __syncthreads();
     }
+    if (!owner) return;
     // whole-chunk candidates: wave 0 takes the flagged queries one by one
     if (__any(any_rescan)) {
         for (int ql = 0; ql < 64; ++ql) {
@@ -1448,7 +1483,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                        a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.fb_count, w.fb_list);
     VFM_CHECK_LAUNCH("match_select_kernel");
     {
-        const size_t lds = (size_t)(64 * RS_STRIDE + RS_MAX_PAIRS) * sizeof(double) + (size_t)d * sizeof(float);
+        const size_t lds = (size_t)(64 * RS_STRIDE + RS_PAIRS) * sizeof(double) + (size_t)d * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {
             VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_rescore_kernel),
