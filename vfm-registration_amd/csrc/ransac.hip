@@ -923,13 +923,26 @@ __global__ __launch_bounds__(64) void ransac_exact_list_kernel(const double* __r
                 good += mine;
                 __builtin_amdgcn_wave_barrier();
                 // sequential phase: the oracle's accumulation order (every lane runs the same chain)
+                // two register batches: the LDS reads of the next 16 values are in flight while the
+                // dependent add chain consumes the current 16 (the sum stays strictly in order)
                 int i = 0;
-                for (; i + 8 <= cnt; i += 8) {
-                    double v[8];
+                if (cnt >= 32) {
+                    double va[16], vb[16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = d2s[i + u];
+                    for (int u = 0; u < 16; ++u) va[u] = d2s[u];
+                    for (; i + 48 <= cnt; i += 32) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) e2 = e2 + v[u];
+                        for (int u = 0; u < 16; ++u) vb[u] = d2s[i + 16 + u];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) e2 = e2 + va[u];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) va[u] = d2s[i + 32 + u];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) e2 = e2 + vb[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) e2 = e2 + va[u];  // va holds d2s[i .. i + 15]
+                    i += 16;
                 }
                 for (; i < cnt; ++i) e2 = e2 + d2s[i];
             }
