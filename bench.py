@@ -234,7 +234,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"C2: {n}-pt scan vs {m}-pt map, {d}-D descriptors precomputed and resident in "
                                    f"HBM, {args.iters} RANSAC iterations, cosine >= 0.8; map renormalised every step",
-                       "pairs_per_gpu": args.steps, "parallelism": f"{world} GPU shard(s) x {S} stream(s), independent scene pairs",
+                       "registrations_per_gpu": args.steps, "resident_scene_pairs_per_gpu": 2,
+                       "parallelism": f"{world} GPU shard(s) x {S} stream(s), independent scene pairs",
                        "correspondences_last_step": ncorr, "max_pose_err_vs_planted": max(errs)},
             "roofline": {"bound": "mfma", "kernel": "match_coarse_pipe_kernel<24> (fp16 32x32x16 MFMA, fused top-2 epilogue)",
                          "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
