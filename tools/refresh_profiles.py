@@ -12,6 +12,8 @@ shutil.copy(SRC / "prof1" / "bench1_kernel_stats.csv", DST / "r01_bench_streams1
 (DST / "r01_bench.json").write_text((SRC / "bench.json").read_text().strip().splitlines()[-1] + "\n")
 (DST / "r01_bench_streams1.json").write_text((SRC / "bench_prof1.json").read_text().strip().splitlines()[-1] + "\n")
 shutil.copy(SRC / "pytest_gpu.txt", DST / "r01_pytest_gpu.txt")
+if (ROOT / "gpurun_out" / "other_rows.txt").exists():
+    shutil.copy(ROOT / "gpurun_out" / "other_rows.txt", DST / "r01_other_rows.txt")
 if (PMC / "pmc_match_coarse.json").exists():
     shutil.copy(PMC / "pmc_match_coarse.json", DST / "r01_pmc_match_coarse.json")
     for i in range(1, 8):
@@ -81,7 +83,7 @@ Ablations of the same kernel (timing only; `tools/build_ablate.sh` + `tools/abla
 baseline): no fold 2.69 ms, no LDS-DMA 2.42 ms, no LDS fragment reads 2.47 ms, no fold + no DMA 2.31 ms, MFMA + barrier
 skeleton only 1.98 ms (1.55 PFLOP/s at 1.66 GHz, MFMA busy 0.88) -- the power-limited ceiling of this tile structure.
 
-## Other rows (tools/time_*.py)
+## Other rows (tools/time_*.py via tools/other_rows.sh; raw output: profiles/r01_other_rows.txt)
 
 C5 coarse pass 50 000 x 1 000 000 x 768: 72.4 ms (1.06 PFLOP/s).  Mutual Euclidean NN (A6) 20k x 200k x 384: 17.4 ms.
 ViT-S/14 on 6 x 1200x1600: 0.83 ms; 6-camera lift of 20 000 points: 0.10 ms; C3 one pair end to end: 4.33 ms
