@@ -49,6 +49,23 @@ def test_host_argument_checks_need_no_gpu(built):
     assert lib.vfm_match_prepare(1, 10, 100, 1, None) == -1  # d not in {128,...}
     assert lib.vfm_match_prepared_bytes(20000, 384) >= 20224 * 384 * 2
     assert lib.vfm_ransac_workspace_bytes(20000, 50000) > 20000 * 48
+    # descriptor widths of the FAST search: 128 .. 768 in steps of 128
+    assert lib.vfm_match_prepare(1, 10, 896, 1, None) == -1 and b"d must be in" in lib.vfm_last_error()
+    assert lib.vfm_match_prepared_bytes(50000, 768) >= 50176 * 768 * 2
+    # split search: both halves validate like the fused call
+    assert lib.vfm_match_search_coarse(1, 0, 1, 10, 384, 1, 0, None) == -1
+    assert lib.vfm_match_search_finish(1, 1, 10, 1, 1, 10, 384, 1, 1, 1, 0, None) != 0 and b"workspace" in lib.vfm_last_error()
+    # mutual L2: precision mode and workspace are checked on the host
+    assert lib.vfm_match_mutual_l2(1, 10, 1, 10, 33, 7, 1, None, None, None, 0, None) == -1
+    assert b"prec_mode" in lib.vfm_last_error()
+    assert lib.vfm_match_mutual_l2(1, 10, 1, 10, 33, 0, 1, None, None, 1, 16, None) != 0
+    assert lib.vfm_match_mutual_l2_workspace_bytes(20000, 200000, 384, 0, 1) > lib.vfm_match_mutual_l2_workspace_bytes(20000, 200000, 384, 0, 0) > 0
+    assert lib.vfm_match_mutual_l2_workspace_bytes(20000, 200000, 768, 0, 1) == 256  # wider than 510: EXACT path, no workspace
+    # fused lift: at most 6 cameras per launch
+    import ctypes as C
+    cams = (built.LiftCamera * 7)()
+    assert lib.vfm_lift_multicam(1, 10, 7, C.cast(cams, C.c_void_p), 384, 1, 1, None) == -1
+    assert b"cameras" in lib.vfm_last_error()
 
 
 def test_ops_refuse_cpu_tensors(built):
