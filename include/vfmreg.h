@@ -94,9 +94,10 @@ int vfm_threshold_compact(const float *sim, const int64_t *idx, int64_t n, doubl
  * exact Euclidean 1-NN of every row of a (n x d) among b (m x d) and, if nn_ba != NULL, of every row
  * of b among a; the decision is the fp64 squared distance accumulated in ascending k, ties -> lowest
  * index.  d2_ab (nullable): that squared distance.  Any d >= 1.
- * prec_mode VFM_MATCH_FAST (d <= 510): fp16 MFMA coarse pass on a commonly scaled copy with the norm
- * term in two appended columns, then the fp64 decision among the candidates inside the proven error
- * window -- same results as VFM_MATCH_EXACT (all-pairs fp64), which wider descriptors fall back to. */
+ * prec_mode VFM_MATCH_FAST (d <= 768): fp16 MFMA coarse pass on a commonly scaled copy with the norm
+ * term in two appended columns (d <= 510) or in the accumulator start of each map row (wider), then the
+ * fp64 decision among the candidates inside the proven error window -- same results as VFM_MATCH_EXACT
+ * (all-pairs fp64), which descriptors wider than 768 fall back to. */
 size_t vfm_match_mutual_l2_workspace_bytes(int64_t n, int64_t m, int d, int prec_mode, int mutual);
 int vfm_match_mutual_l2(const float *a, int64_t n, const float *b, int64_t m, int d, int prec_mode,
                         int64_t *nn_ab, double *d2_ab, int64_t *nn_ba, void *ws, size_t ws_bytes,

@@ -60,7 +60,8 @@ def test_host_argument_checks_need_no_gpu(built):
     assert b"prec_mode" in lib.vfm_last_error()
     assert lib.vfm_match_mutual_l2(1, 10, 1, 10, 33, 0, 1, None, None, 1, 16, None) != 0
     assert lib.vfm_match_mutual_l2_workspace_bytes(20000, 200000, 384, 0, 1) > lib.vfm_match_mutual_l2_workspace_bytes(20000, 200000, 384, 0, 0) > 0
-    assert lib.vfm_match_mutual_l2_workspace_bytes(20000, 200000, 768, 0, 1) == 256  # wider than 510: EXACT path, no workspace
+    assert lib.vfm_match_mutual_l2_workspace_bytes(20000, 200000, 768, 0, 1) > 256   # 510 < d <= 768: row-bias form
+    assert lib.vfm_match_mutual_l2_workspace_bytes(20000, 200000, 1024, 0, 1) == 256  # wider: EXACT path, no workspace
     # fused lift: at most 6 cameras per launch
     import ctypes as C
     cams = (built.LiftCamera * 7)()

@@ -256,7 +256,8 @@ def test_mutual_l2(ops, orc):
     assert i_ref[7] == 50
 
 
-@pytest.mark.parametrize("n,m,d", [(1500, 4000, 384), (700, 300, 32), (5, 1, 7), (1, 130, 126), (260, 1000, 200)])
+@pytest.mark.parametrize("n,m,d", [(1500, 4000, 384), (700, 300, 32), (5, 1, 7), (1, 130, 126), (260, 1000, 200),
+                                   (600, 2500, 768), (300, 900, 640), (250, 1100, 700), (300, 3000, 511), (260, 2600, 512)])
 def test_mutual_l2_fast_equals_oracle(ops, orc, n, m, d):
     """row A6 on the matrix cores: un-normalised descriptors, wildly different row norms (one huge row sets
     the common scale, some rows are ~0), exact duplicates and near ties"""
@@ -274,6 +275,21 @@ def test_mutual_l2_fast_equals_oracle(ops, orc, n, m, d):
         a[2] *= 1e-3                       # tiny norm: distances differ only through |b|^2
         a[3] = b[3]
     _check_l2(ops, orc, a, b)
+
+
+@pytest.mark.parametrize("d", [384, 511, 640, 768])
+def test_mutual_l2_norm_term_matters(ops, orc, d):
+    """rows of strongly varying norm and no dominating row: the nearest neighbour in Euclidean distance differs
+    from the best inner product for most queries, so the result is only right if the -|b|^2/2 term reaches the
+    coarse pass (appended columns for d <= 510, accumulator start per map row above) -- and candidates stay
+    sparse (32+ chunks), so the exact stage cannot paper over a wrong coarse ranking"""
+    rng = np.random.default_rng(d)
+    n, m = 400, 5000
+    a = (rng.standard_normal((n, d)) * rng.uniform(0.5, 1.5, (n, 1))).astype(np.float32)
+    b = (rng.standard_normal((m, d)) * rng.uniform(0.5, 1.5, (m, 1))).astype(np.float32)
+    i_ref = _check_l2(ops, orc, a, b)
+    ip_best = (a.astype(np.float64) @ b.astype(np.float64).T).argmax(1)
+    assert (ip_best != i_ref).mean() > 0.5
 
 
 def test_mutual_l2_fpfh_like(ops, orc):

@@ -204,6 +204,8 @@ struct CoarseArgs {
     int nslices;         // map slices
     unsigned* qmax;      // [npad] running coarse maximum per query (value bits only), zeroed per search
     int first_pad_chunk; // chunks >= this contain zero-padded map rows: excluded from qmax
+    const float* row_bias;  // [padded map rows] added to the accumulator start of that row, or NULL
+                            // (Euclidean search for d > 510: -|b~|^2 / 2; match_coarse_r_kernel only)
 };
 
 // XCD-aware unit mapping shared by the coarse kernels: workgroup b runs on XCD b % 8 (observed, speed
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
 // variant.  Error bound of the coarse score at d = 768: 48 instead of 24 accumulation steps add
 // < 5e-5, E < 1.15e-3, window 2.5e-3 >= 2E still holds.
 // ---------------------------------------------------------------------------------------------
-template <int KSTEPS, int QSETS, int NBUF>
+template <int KSTEPS, int QSETS, int NBUF, bool BIAS>
 __global__ __launch_bounds__(256, 1) void match_coarse_r_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVES = 4;
@@ -654,6 +656,21 @@ __global__ __launch_bounds__(256, 1) void match_coarse_r_kernel(CoarseArgs a) {
             for (int c = 0; c < SPLIT; ++c)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][c][r] = (c == 0) ? COARSE_OFFSET : 0.f;
+        if constexpr (BIAS) {
+            // accumulator register r of a lane holds map row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the tile
+            const float* bt = a.row_bias + ((size_t)c0 * 4 + (size_t)it) * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4*>(bt + 8 * g);
+#pragma unroll
+                for (int j = 0; j < QSETS; ++j) {
+                    acc[j][0][4 * g + 0] += bv.x;
+                    acc[j][0][4 * g + 1] += bv.y;
+                    acc[j][0][4 * g + 2] += bv.z;
+                    acc[j][0][4 * g + 3] += bv.w;
+                }
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
@@ -1181,8 +1198,11 @@ __device__ __forceinline__ float l2_scale(const unsigned* max_bits) {
 }
 
 // one workgroup (4 waves) per 32-row tile; role 0 = query (extra columns 1, 1), 1 = map (-hi, -lo)
+// aug = 1: the norm term travels in two appended columns (d + 2 <= kp); aug = 0 (d > 510, kp = d rounded up
+// to 128): no extra columns, the MAP role stores -|b~|^2 / 2 per row in inv_out instead -- the coarse kernel
+// adds it to the accumulator start of that row (CoarseArgs::row_bias)
 __global__ __launch_bounds__(256) void l2_prep_kernel(const float* __restrict__ x, int64_t rows, int d, int kp,
-                                                      const unsigned* __restrict__ max_bits, int role,
+                                                      const unsigned* __restrict__ max_bits, int role, int aug,
                                                       float* __restrict__ inv_out, uint4* __restrict__ tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tile = blockIdx.x;
@@ -1199,11 +1219,11 @@ __global__ __launch_bounds__(256) void l2_prep_kernel(const float* __restrict__ 
                 v = x[r * (int64_t)d + k] * scale;
                 nb2 += v * v;
             }
-            if (k < d || k >= d + 2) img[(((k >> 4) * 2 + ((k >> 3) & 1)) * 32 + pr) * 8 + (k & 7)] = (_Float16)v;
+            if (!aug || k < d || k >= d + 2) img[(((k >> 4) * 2 + ((k >> 3) & 1)) * 32 + pr) * 8 + (k & 7)] = (_Float16)v;
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) nb2 += __shfl_xor(nb2, off);
-        if (lane < 2) {
+        if (aug && lane < 2) {
             const float h = 0.5f * nb2;
             const _Float16 hi = (_Float16)h;
             const _Float16 lo = (_Float16)(h - (float)hi);
@@ -1212,7 +1232,8 @@ __global__ __launch_bounds__(256) void l2_prep_kernel(const float* __restrict__ 
             const int k = d + lane;
             img[(((k >> 4) * 2 + ((k >> 3) & 1)) * 32 + pr) * 8 + (k & 7)] = e;
         }
-        if (lane == 0) inv_out[r] = 1.0f;  // "not a zero row" for match_select_kernel
+        // query role: "not a zero row" for match_select_kernel; map role without columns: the row bias
+        if (lane == 0) inv_out[r] = (!aug && role == 1) ? (valid ? -0.5f * nb2 : 0.0f) : 1.0f;
     }
     __syncthreads();
     const int units = (kp >> 4) * 64;
@@ -1390,17 +1411,17 @@ int launch_coarse_v(const CoarseArgs& a, hipStream_t st) {
     return VFM_OK;
 }
 
-template <int KSTEPS, int QSETS, int NBUF>
+template <int KSTEPS, int QSETS, int NBUF, bool BIAS>
 int launch_coarse_r(const CoarseArgs& a, hipStream_t st) {
     const int lds = NBUF * KSTEPS * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_r_kernel<KSTEPS, QSETS, NBUF>),
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_r_kernel<KSTEPS, QSETS, NBUF, BIAS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
-    hipLaunchKernelGGL((match_coarse_r_kernel<KSTEPS, QSETS, NBUF>), dim3(a.nqb * a.nslices), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((match_coarse_r_kernel<KSTEPS, QSETS, NBUF, BIAS>), dim3(a.nqb * a.nslices), dim3(256), lds, st, a);
     VFM_CHECK_LAUNCH("match_coarse_r_kernel");
     if (g_prof_stop) VFM_CHECK_HIP(hipEventRecord(g_prof_stop, st));
     g_prof_start = g_prof_stop = nullptr;
@@ -1448,15 +1469,21 @@ CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, 
     a.nslices = choose_slices(a.nqb, a.nchunks);
     a.qmax = w.qmax;
     a.first_pad_chunk = (int)(m / CHUNK_ROWS);
+    a.row_bias = nullptr;
     return a;
 }
 
 // stage 1 of a search: the MFMA coarse pass (fills ws: partials + per-query coarse maxima)
-int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, hipStream_t st) {
+int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, hipStream_t st,
+                     bool bias_from_map_inv = false) {
     Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
     Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
     SearchWs w = carve_search(ws, n, m);
-    const CoarseArgs a = coarse_args(Q, B, w, n, m, coarse_qblock(d));
+    CoarseArgs a = coarse_args(Q, B, w, n, m, coarse_qblock(d));
+    if (bias_from_map_inv) {  // Euclidean search, d > 510: the map's "inv" array holds -|b~|^2 / 2
+        if (d != 640 && d != 768) return vfm_fail(VFM_EINVAL, "row bias needs the 4-wave coarse kernel (K = 640 / 768), got %d", d);
+        a.row_bias = B.inv;
+    }
     VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, sizeof(int), st));
     VFM_CHECK_HIP(hipMemsetAsync(w.qmax, 0, (size_t)a.npad * sizeof(unsigned), st));
     int rc;
@@ -1465,8 +1492,8 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
         case 16: rc = launch_coarse<16>(a, st); break;
         case 24: rc = launch_coarse<24>(a, st); break;
         case 32: rc = launch_coarse<32>(a, st); break;  // 8-wave kernel, ring of 4: 3.45 ms at C2 x 512 (4-wave kernel: 4.42 ms)
-        case 40: rc = launch_coarse_r<40, 1, 3>(a, st); break;
-        case 48: rc = launch_coarse_r<48, 1, 3>(a, st); break;
+        case 40: rc = a.row_bias ? launch_coarse_r<40, 1, 3, true>(a, st) : launch_coarse_r<40, 1, 3, false>(a, st); break;
+        case 48: rc = a.row_bias ? launch_coarse_r<48, 1, 3, true>(a, st) : launch_coarse_r<48, 1, 3, false>(a, st); break;
         default: return vfm_fail(VFM_EINVAL, "FAST matching supports d in {128,256,384,512,640,768}, got %d", d);
     }
     return rc;
@@ -1637,7 +1664,10 @@ VFM_EXPORT int vfm_threshold_compact(const float* sim, const int64_t* idx, int64
 }
 
 namespace {
-inline int l2_padded_k(int d) { return (d + 2 + 127) / 128 * 128; }
+// d <= 510: two appended columns; 510 < d <= 768: row bias, no extra columns; wider: 0 (all-pairs fp64)
+inline bool l2_aug(int d) { return d + 2 <= 512; }
+// (the row-bias form exists in match_coarse_r_kernel only, i.e. for K = 640 and 768: d = 511, 512 pad to 640)
+inline int l2_padded_k(int d) { return l2_aug(d) ? (d + 2 + 127) / 128 * 128 : (d <= 640 ? 640 : (d <= 768 ? 768 : 0)); }
 
 struct L2Ws {
     unsigned* max_bits;
@@ -1667,7 +1697,7 @@ inline L2Ws carve_l2(void* p, int64_t n, int64_t m, int d, bool mutual) {
 int l2_prepare(const float* x, int64_t rows, int d, int kp, const unsigned* max_bits, int role, void* prepared, hipStream_t st) {
     Prepared p = carve_prepared(prepared, rows, kp);
     hipLaunchKernelGGL(l2_prep_kernel, dim3((unsigned)(rows_padded(rows) / TILE_ROWS)), dim3(256), (size_t)kp * 64, st, x, rows, d, kp,
-                       max_bits, role, p.inv, p.tiles);
+                       max_bits, role, l2_aug(d) ? 1 : 0, p.inv, p.tiles);
     VFM_CHECK_LAUNCH("l2_prep_kernel");
     return VFM_OK;
 }
@@ -1675,7 +1705,7 @@ int l2_prepare(const float* x, int64_t rows, int d, int kp, const unsigned* max_
 // one direction: every row of q (n x d) among b (m x d)
 int l2_search(const float* q, void* qprep, int64_t n, const float* b, void* bprep, int64_t m, int d, int kp, int64_t* nn,
               double* d2, void* ws, hipStream_t st) {
-    if (int rc = do_search_coarse(qprep, n, bprep, m, kp, ws, st)) return rc;
+    if (int rc = do_search_coarse(qprep, n, bprep, m, kp, ws, st, !l2_aug(d))) return rc;
     Prepared Q = carve_prepared(qprep, n, kp);
     SearchWs w = carve_search(ws, n, m);
     const CoarseArgs a = coarse_args(Q, carve_prepared(bprep, m, kp), w, n, m, coarse_qblock(kp));
@@ -1693,7 +1723,7 @@ int l2_search(const float* q, void* qprep, int64_t n, const float* b, void* bpre
 }  // namespace
 
 VFM_EXPORT size_t vfm_match_mutual_l2_workspace_bytes(int64_t n, int64_t m, int d, int prec_mode, int mutual) {
-    if (prec_mode == VFM_MATCH_EXACT || l2_padded_k(d) > 512 || n <= 0 || m <= 0) return 256;
+    if (prec_mode == VFM_MATCH_EXACT || l2_padded_k(d) == 0 || n <= 0 || m <= 0) return 256;
     return carve_l2(nullptr, n, m, d, mutual != 0).bytes;
 }
 
@@ -1705,8 +1735,8 @@ VFM_EXPORT int vfm_match_mutual_l2(const float* a, int64_t n, const float* b, in
     VFM_CHECK_ARG(m < (1ll << 31) - 256 && n < (1ll << 31) - 256, "mutual_l2: more than 2^31 rows");
     hipStream_t st = (hipStream_t)stream;
     const int kp = l2_padded_k(d);
-    if (prec_mode == VFM_MATCH_EXACT || kp > 512) {
-        // all-pairs fp64 (also the path for descriptors wider than 510)
+    if (prec_mode == VFM_MATCH_EXACT || kp == 0) {
+        // all-pairs fp64 (also the path for descriptors wider than 768)
         const size_t lds = (((size_t)d * 4 + 15) & ~(size_t)15) + 64;
         hipLaunchKernelGGL(nn_l2_kernel, dim3((unsigned)(n < 8192 ? n : 8192)), dim3(256), lds, st, a, n, b, m, d,
                            (const int*)nullptr, (const int*)nullptr, nn_ab, d2_ab);
