@@ -86,7 +86,7 @@ skeleton only 1.98 ms (1.55 PFLOP/s at 1.66 GHz, MFMA busy 0.88) -- the power-li
 ## Other rows (tools/time_*.py via tools/other_rows.sh; raw output: profiles/r01_other_rows.txt)
 
 C5 coarse pass 50 000 x 1 000 000 x 768: 72.4 ms (1.06 PFLOP/s).  Mutual Euclidean NN (A6) 20k x 200k x 384: 17.4 ms.
-ViT-S/14 on 6 x 1200x1600: 0.83 ms; 6-camera lift of 20 000 points: 0.10 ms; C3 one pair end to end: 4.33 ms
+ViT-S/14 on 6 x 1200x1600: 0.83 ms; 6-camera lift of 20 000 points: 0.07 ms; C3 one pair end to end: 4.21 ms
 (`profiles/r01_c3_features_kernel_stats.csv`).  Real-data regime (1500 x 100k): 0.33 ms per registration.
 
 ## GPU test-suite
