@@ -292,6 +292,28 @@ def test_mutual_l2_norm_term_matters(ops, orc, d):
     assert (ip_best != i_ref).mean() > 0.5
 
 
+def test_mutual_l2_full_size_property(ops, orc):
+    """row A6 at config C2's size (20k x 200k x 384, un-normalised rows): planted neighbours recovered in
+    both directions, and exactness against the oracle on a row sample of each direction"""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n, m, d = 20000, 200000, 384
+    b = torch.randn(m, d, device="cuda", generator=g) * (0.5 + torch.rand(m, 1, device="cuda", generator=g))
+    pick = torch.randperm(m, device="cuda", generator=g)[:n]
+    a = b[pick] + 0.05 * torch.randn(n, d, device="cuda", generator=g)
+    nn_ab, d2, nn_ba = ops.match_mutual_l2(a, b)
+    torch.cuda.synchronize()
+    assert (nn_ab == pick).float().mean().item() > 0.999
+    assert (nn_ba[pick] == torch.arange(n, device="cuda")).float().mean().item() > 0.999
+    ah, bh = a.cpu().numpy(), b.cpu().numpy()
+    rows = np.arange(0, n, 400)
+    i_ref, dist_ref = orc.nn_l2(ah[rows], bh)
+    np.testing.assert_array_equal(nn_ab[rows].cpu().numpy(), i_ref)
+    np.testing.assert_array_equal(np.sqrt(d2[rows].cpu().numpy()), dist_ref)
+    cols = np.arange(0, m, 4000)
+    j_ref, _ = orc.nn_l2(bh[cols], ah)
+    np.testing.assert_array_equal(nn_ba[cols].cpu().numpy(), j_ref)
+
+
 def test_mutual_l2_fpfh_like(ops, orc):
     """non-negative histogram descriptors (FPFH: 33 bins, three sub-histograms summing to 100 each)"""
     rng = np.random.default_rng(12)
