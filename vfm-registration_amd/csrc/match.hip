@@ -687,10 +687,12 @@ __global__ __launch_bounds__(256, 1) void match_coarse_r_kernel(CoarseArgs a) {
                 const int j = e >> 4, r = e & 15;
                 coarse_fold(s1[j], s2[j], prev[j][r], ((P + 3) & 3) * 16 + r);
             }
-            if (s == 1) {
+            if (s >= 1 && s <= PASSES) {  // one 1 KiB piece of tile it+NBUF-1 per slot (no burst after the barrier)
                 __builtin_amdgcn_sched_barrier(0);
-                if (it + NBUF - 1 < ntiles) stage(gnext, ringf * TILE_BYTES);  // uniform
-                gnext += TILE_U4;
+                if (it + NBUF - 1 < ntiles)  // uniform
+                    glds16(gnext + (s - 1) * NWAVES * 64,
+                           __builtin_amdgcn_readfirstlane(ldst0 + ringf * TILE_BYTES + (unsigned)((s - 1) * NWAVES) * 1024u));
+                if (s == PASSES) gnext += TILE_U4;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
