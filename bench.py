@@ -167,7 +167,8 @@ def main():
             res_c[i].copy_(out["count"])
         return res_T[i], res_c[i]
 
-    if world > 1:
+    grouped = dist.is_available() and dist.is_initialized()  # launched through torch.distributed.run
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -180,10 +181,10 @@ def main():
     torch.cuda.current_stream().wait_stream(match_stream)
     all_poses, all_counts = vdist.gather_poses(res_T, res_c.reshape(-1), num_pairs, rank, world)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -236,6 +237,8 @@ def main():
                                    f"HBM, {args.iters} RANSAC iterations, cosine >= 0.8; map renormalised every step",
                        "registrations_per_gpu": args.steps, "resident_scene_pairs_per_gpu": 2,
                        "parallelism": f"{world} GPU shard(s) x {S} stream(s), independent scene pairs",
+                       "collective": (f"one all_gather_into_tensor of the poses ({dist.get_backend()} = RCCL)" if grouped
+                                      else "none (single process, no launcher)"),
                        "correspondences_last_step": ncorr, "max_pose_err_vs_planted": max(errs)},
             "roofline": {"bound": "mfma", "kernel": "match_coarse_pipe_kernel<24> (fp16 32x32x16 MFMA, fused top-2 epilogue)",
                          "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -251,7 +254,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -33,7 +33,8 @@ def test_bench_plain_small_run():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-3000:]
-    _check(r.stdout, 4)
+    d = _check(r.stdout, 4)
+    assert d["config"]["collective"].startswith("none")
 
 
 def test_bench_under_torch_distributed_run_world1():
@@ -44,4 +45,5 @@ def test_bench_under_torch_distributed_run_world1():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-3000:]
     d = _check(r.stdout, 4)
+    assert "nccl" in d["config"]["collective"]  # the RCCL process group was created and used
     assert d["cpu_baseline"] is not None and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1

@@ -17,10 +17,13 @@ import torch.distributed as dist
 
 
 def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] = None) -> Tuple[int, int]:
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun). Returns (rank, world)."""
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun). Returns (rank, world).
+    Under a launcher (RANK and WORLD_SIZE set) the group is created even for one rank, so that a
+    single-GPU run exercises the same RCCL calls as an 8-GPU run."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
