@@ -196,6 +196,27 @@ int vfm_voxel_first(const double *pts, int64_t n, int64_t stride, double voxel_s
                     int32_t max_per_voxel, int64_t *keep_out, int64_t *count_out, void *ws,
                     size_t ws_bytes, vfm_stream_t stream);
 
+/* The same survivors in the ORDER the reference emits them: the iteration order of the
+ * tsl::robin_map<Voxel, ., VoxelHash> (Tessil robin-map v1.2.1, 3rdparty/tsl_robin/tsl_robin.cmake:24)
+ * that VoxelDownsample fills and walks (Preprocessing.cpp:55-69) and that VoxelHashMap::Pointcloud /
+ * PointcloudN / GetVFMCorrespondences walk (VoxelHashMap.cpp:465, 640-676); per voxel block the points
+ * in insertion order.  hash_mul_y: the middle multiplier of VoxelHash -- 19349663 for
+ * Preprocessing.cpp:44, 19349669 for VoxelHashMap.hpp:75.  reserve_n >= 0: the container was
+ * `reserve(reserve_n)`-ed first (VoxelDownsample passes frame.size() = n); reserve_n < 0: a
+ * default-constructed map that grows by doubling (VoxelHashMap::map_ / map_n_).  The chained
+ * voxelisations of registration_node.py:399-414 need this order: the next level keeps the first point
+ * per voxel OF THIS ORDER.  info_host (nullable, HOST int64[4]): final bucket count, number of voxels,
+ * largest probe distance, generations that needed the wrap-around path.  This entry point reads the
+ * voxel count back (it synchronises `stream`); it fails with VFM_EINVAL where the reference container
+ * would exceed its probe-distance limit (8192; 20-bit hash saturated). */
+#define VFM_VOXEL_HASH_DOWNSAMPLE 19349663u
+#define VFM_VOXEL_HASH_MAP 19349669u
+size_t vfm_voxel_robin_workspace_bytes(int64_t n);
+int vfm_voxel_robin(const double *pts, int64_t n, int64_t stride, double voxel_size,
+                    int32_t max_per_voxel, uint32_t hash_mul_y, int64_t reserve_n, int64_t *keep_out,
+                    int64_t *count_out, int64_t *info_host, void *ws, size_t ws_bytes,
+                    vfm_stream_t stream);
+
 /* ------------------------------------------------------------------ ICP refinement (row F2) */
 
 /* VoxelHashMap::GetCorrespondences (src/kiss-icp/cpp/kiss_icp/core/VoxelHashMap.cpp:76-168): for

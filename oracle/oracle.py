@@ -344,6 +344,117 @@ def voxel_first(points: np.ndarray, voxel_size: float, max_per_voxel: int = 1) -
     return keep[:k].copy()
 
 
+HASH_MUL_DOWNSAMPLE = 19349663  # Preprocessing.cpp:44
+HASH_MUL_MAP = 19349669         # VoxelHashMap.hpp:75
+
+
+def voxel_robin(points: np.ndarray, voxel_size: float, max_per_voxel: int = 1, reserve: bool = True,
+                hash_mul: int = HASH_MUL_DOWNSAMPLE, return_info: bool = False):
+    """Point indices in the order the reference emits them: tsl::robin_map iteration order
+    (restated operation by operation in vfm_oracle.c, v1.2.1; parity unpinned -- the header is not in
+    the tree).  ``reserve=True, max_per_voxel=1, HASH_MUL_DOWNSAMPLE`` = VoxelDownsample
+    (Preprocessing.cpp:50-69); ``reserve=False, max_per_voxel=K, HASH_MUL_MAP`` = a fresh
+    VoxelHashMap after AddPoints, as Pointcloud()/PointcloudN() iterate it (VHM:640-676, 733-770)."""
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    out = np.empty(max(len(pts), 1), dtype=np.int64)
+    info = np.zeros(4, dtype=np.int64)
+    f = lib().orc_voxel_robin
+    f.restype = C.c_int64
+    k = f(_p(pts, _f64p), C.c_int64(len(pts)), C.c_int64(pts.shape[1] if pts.ndim == 2 else 3),
+          C.c_double(voxel_size), C.c_int64(max_per_voxel), C.c_uint32(hash_mul),
+          C.c_int64(len(pts) if reserve else -1), _p(out, _i64p), _p(info, _i64p))
+    return (out[:k].copy(), info) if return_info else out[:k].copy()
+
+
+def voxel_down_sample(points: np.ndarray, voxel_size: float) -> np.ndarray:
+    """kiss_icp.voxelization.voxel_down_sample as the reference returns it (rows in robin_map order)."""
+    points = np.asarray(points)
+    return np.asarray(points[voxel_robin(points[:, :3], voxel_size)], dtype=np.float64)
+
+
+def voxel_hash_map_points(points: np.ndarray, voxel_size: float, max_per_voxel: int) -> np.ndarray:
+    """get_voxel_hash_map(); add_points(points); point_cloud*(): indices of the rows, in map order."""
+    return voxel_robin(np.asarray(points)[:, :3], voxel_size, max_per_voxel, reserve=False, hash_mul=HASH_MUL_MAP)
+
+
+def voxel_hash(vox: np.ndarray, hash_mul: int) -> np.ndarray:
+    v = vox.astype(np.int32).view(np.uint32).astype(np.uint64)
+    h = (v[:, 0] * 73856093) ^ (v[:, 1] * hash_mul) ^ (v[:, 2] * 83492791)
+    return (h & 0xFFFFF).astype(np.int64)
+
+
+def robin_order_by_clusters(hashes: np.ndarray, reserve_n: Optional[int]) -> np.ndarray:
+    """Second derivation of the robin_map iteration order of distinct keys inserted in sequence (argument:
+    their 20-bit hashes), structured like csrc/voxel.hip so that the decomposition the GPU uses is checked
+    on the CPU against the bucket-level container simulation of vfm_oracle.c:
+      * a robin-hood table with linear probing holds, cyclically, its keys sorted by home bucket, so the
+        occupied bucket runs ("clusters") follow from a stable sort by ``hash & mask`` and a running maximum
+        (bucket of sorted entry i = i + max_{j<=i}(home_j - j));
+      * clusters never interact: replaying the insertions of one cluster's keys (arrival order, tsl's swap
+        rule) inside its own window gives the container's layout there;
+      * arrival order at a rehash is the old table's iteration order; a growing map is one such step per
+        table generation; entries wrapping past the last bucket: redo in coordinates rotated to an empty bucket."""
+    n = len(hashes)
+    hashes = np.asarray(hashes, dtype=np.int64)
+    order = np.zeros(0, dtype=np.int64)
+    if reserve_n is not None:
+        c = int(np.ceil(np.float32(reserve_n) / np.float32(0.5)))
+        B = 0 if c == 0 else 1 << max(0, int(c - 1).bit_length())
+    else:
+        B = 0
+    s = 0
+    while s < n:
+        thr = int(np.float32(B) * np.float32(0.5))
+        if s >= thr:
+            B = 2 * B if B else 2
+            thr = int(np.float32(B) * np.float32(0.5))
+        m = min(n, thr)
+        seq = np.concatenate([order, np.arange(s, m)])
+        z = 0
+        for attempt in range(2):
+            home = (hashes[seq] - z) & (B - 1)
+            perm = np.argsort(home, kind="stable")
+            hs = home[perm]
+            d = hs - np.arange(m)
+            cm = np.maximum.accumulate(d)
+            w = int(np.count_nonzero(np.arange(m) + cm >= B))
+            if w > 0:
+                assert attempt == 0
+                a = int(np.argmax(cm >= w + 1))
+                z = a + int(cm[a]) - 1
+                continue
+            start = np.r_[True, d[1:] > cm[:-1]]
+            cidx = np.cumsum(start) - 1
+            cl_of_pos = np.empty(m, dtype=np.int64)
+            cl_of_pos[perm] = cidx
+            arr = seq[np.argsort(cl_of_pos, kind="stable")]           # per cluster, in arrival order
+            starts = np.r_[np.nonzero(start)[0], m]
+            tab = np.empty(m, dtype=np.int64)
+            for c in range(len(starts) - 1):
+                i0, i1 = int(starts[c]), int(starts[c + 1])
+                L, base = i1 - i0, int(hs[i0])
+                D = [-1] * L
+                I = [0] * L
+                for v in arr[i0:i1]:
+                    v = int(v)
+                    ib, dist = ((int(hashes[v]) - z) & (B - 1)) - base, 0
+                    while True:
+                        if dist > D[ib]:
+                            if D[ib] < 0:
+                                D[ib], I[ib] = dist, v
+                                break
+                            D[ib], dist = dist, D[ib]
+                            I[ib], v = v, I[ib]
+                        dist += 1
+                        ib += 1
+                tab[i0:i1] = I
+            r = int(np.argmax(np.arange(m) + cm >= B - z)) if (z > 0 and np.any(np.arange(m) + cm >= B - z)) else 0
+            order = np.concatenate([tab[r:], tab[:r]])
+            break
+        s = m
+    return order
+
+
 # ----------------------------------------------------------------------------- A1 ViT (torch fp32)
 def vit_reference(weights: dict, img_u8: np.ndarray, patch_h: int = 16):
     """ImageFeatureGenerator.get_image_features(upsample=False) for 'dinov2', use_featup=False

@@ -650,6 +650,217 @@ ORC_API int64_t orc_voxel_first(const double *pts, int64_t n, int64_t stride, do
     return k;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Row F1, container ORDER: tsl::robin_map iteration order.                   */
+/*                                                                            */
+/* kiss_icp::VoxelDownsample (Preprocessing.cpp:50-69) and                    */
+/* VoxelHashMap::Pointcloud / PointcloudN / GetVFMCorrespondences             */
+/* (VoxelHashMap.cpp:465, 640-676) emit their points by iterating a           */
+/* tsl::robin_map<Voxel, ., VoxelHash>.  The next voxelisation level          */
+/* (registration_node.py:399-414: 0.5 -> 1.0 -> 5.0 m) keeps the FIRST point   */
+/* per voxel of THAT order, and the map's row order decides faiss' tie-break   */
+/* and the indices RANSAC samples, so the order is part of the result.        */
+/*                                                                            */
+/* tsl::robin_map is a third-party header absent from /root/reference         */
+/* (3rdparty/tsl_robin/tsl_robin.cmake:24 fetches Tessil/robin-map v1.2.1)    */
+/* and from this image: PARITY UNPINNED.  What follows restates the           */
+/* published container (include/tsl/robin_hash.h, robin_growth_policy.h of    */
+/* v1.2.1) operation by operation:                                            */
+/*   - power_of_two_growth_policy<2>: bucket_count rounded up to a power of    */
+/*     two, bucket_for_hash = hash & mask, next_bucket_count = 2*(mask+1);    */
+/*   - default-constructed map: 0 buckets (one static empty sentinel),        */
+/*     max_load_factor 0.5, load_threshold = size_t(float(buckets) * 0.5f);   */
+/*   - insert_impl: probe while dist <= bucket.dist (key compare on the way), */
+/*     then `while (rehash_on_extreme_load(dist))` re-probe, then place:      */
+/*     empty bucket -> store; else robin-hood swap chain (insert_value_impl), */
+/*     which sets grow_on_next_insert when a displaced entry's distance       */
+/*     exceeds DIST_FROM_IDEAL_BUCKET_LIMIT (8192);                           */
+/*   - rehash_on_extreme_load: grow_on_next_insert || dist > LIMIT ||         */
+/*     size >= load_threshold  ->  rehash_impl(next_bucket_count());          */
+/*   - rehash_impl(count): new table, old buckets walked in index order,      */
+/*     each re-inserted with insert_value_on_rehash;                          */
+/*   - reserve(n) = rehash(size_t(ceil(float(n) / 0.5f)));                    */
+/*   - iteration = buckets in index order, empty ones skipped.                */
+/* VoxelHash (Preprocessing.cpp:41-46 with 19349663; VoxelHashMap.hpp:72-77   */
+/* with 19349669): ((1<<20)-1) & (x*73856093 ^ y*C ^ z*83492791) on uint32.   */
+/* KeyEqual = Eigen operator== (all three coefficients).                      */
+/* ------------------------------------------------------------------------ */
+#define ORC_RH_LIMIT 8192
+typedef struct {
+    int16_t dist; /* dist_from_ideal_bucket, -1 = empty */
+    int64_t id;   /* value: index of the voxel's record */
+} orc_rh_bucket;
+typedef struct {
+    orc_rh_bucket *b; /* NULL <=> bucket_count == 0 (static empty sentinel) */
+    uint64_t bucket_count, mask, nb, load_threshold;
+    int grow_on_next_insert;
+    int64_t max_dist_seen;
+    int64_t n_rehash;
+    const int32_t *vox; /* [id][3] keys */
+    const uint32_t *hash; /* [id] VoxelHash */
+} orc_rh;
+
+static uint64_t orc_rh_round_pow2(uint64_t v) {
+    if (v == 0) return 1;
+    if ((v & (v - 1)) == 0) return v;
+    uint64_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+static void orc_rh_construct(orc_rh *m, uint64_t bucket_count) {
+    if (bucket_count > 0) {
+        bucket_count = orc_rh_round_pow2(bucket_count);
+        m->mask = bucket_count - 1;
+        m->b = (orc_rh_bucket *)malloc(sizeof(orc_rh_bucket) * bucket_count);
+        for (uint64_t i = 0; i < bucket_count; ++i) { m->b[i].dist = -1; m->b[i].id = -1; }
+    } else {
+        m->mask = 0;
+        m->b = NULL;
+    }
+    m->bucket_count = bucket_count;
+    m->nb = 0;
+    m->grow_on_next_insert = 0;
+    m->load_threshold = (uint64_t)((float)bucket_count * 0.5f);
+}
+static inline int16_t orc_rh_dist(const orc_rh *m, uint64_t i) { return m->b ? m->b[i].dist : (int16_t)-1; }
+
+static void orc_rh_insert_on_rehash(orc_rh *m, uint64_t ib, int16_t dist, int64_t id) {
+    for (;;) {
+        if (dist > m->b[ib].dist) {
+            if (m->b[ib].dist < 0) { m->b[ib].dist = dist; m->b[ib].id = id; return; }
+            int16_t td = m->b[ib].dist; int64_t ti = m->b[ib].id;
+            m->b[ib].dist = dist; m->b[ib].id = id;
+            dist = td; id = ti;
+        }
+        dist++;
+        ib = (ib + 1) & m->mask;
+    }
+}
+static void orc_rh_rehash_impl(orc_rh *m, uint64_t count) {
+    orc_rh t = *m;
+    orc_rh_construct(&t, count);
+    for (uint64_t i = 0; i < m->bucket_count; ++i) {
+        if (!m->b || m->b[i].dist < 0) continue;
+        const int64_t id = m->b[i].id;
+        orc_rh_insert_on_rehash(&t, (uint64_t)m->hash[id] & t.mask, 0, id);
+    }
+    t.nb = m->nb;
+    t.max_dist_seen = m->max_dist_seen;
+    t.n_rehash = m->n_rehash + 1;
+    free(m->b);
+    *m = t;
+}
+static void orc_rh_reserve(orc_rh *m, uint64_t count) {
+    uint64_t c = (uint64_t)ceilf((float)count / 0.5f);
+    uint64_t c2 = (uint64_t)ceilf((float)m->nb / 0.5f);
+    orc_rh_rehash_impl(m, c > c2 ? c : c2);
+}
+static int orc_rh_rehash_on_extreme_load(orc_rh *m, int16_t dist) {
+    if (m->grow_on_next_insert || dist > ORC_RH_LIMIT || m->nb >= m->load_threshold) {
+        orc_rh_rehash_impl(m, (m->mask + 1) * 2);
+        m->grow_on_next_insert = 0;
+        return 1;
+    }
+    return 0;
+}
+/* find: id of the stored record with the same voxel, or -1 */
+static int64_t orc_rh_find(const orc_rh *m, const int32_t *key, uint32_t hash) {
+    uint64_t ib = (uint64_t)hash & m->mask;
+    int16_t dist = 0;
+    while (dist <= orc_rh_dist(m, ib)) {
+        const int32_t *k = m->vox + 3 * m->b[ib].id;
+        if (k[0] == key[0] && k[1] == key[1] && k[2] == key[2]) return m->b[ib].id;
+        ib = (ib + 1) & m->mask;
+        dist++;
+    }
+    return -1;
+}
+/* insert of a key known to be absent (the callers test contains()/find() first) */
+static void orc_rh_insert_new(orc_rh *m, int64_t id) {
+    const uint32_t hash = m->hash[id];
+    uint64_t ib = (uint64_t)hash & m->mask;
+    int16_t dist = 0;
+    while (dist <= orc_rh_dist(m, ib)) { ib = (ib + 1) & m->mask; dist++; }
+    while (orc_rh_rehash_on_extreme_load(m, dist)) {
+        ib = (uint64_t)hash & m->mask;
+        dist = 0;
+        while (dist <= orc_rh_dist(m, ib)) { ib = (ib + 1) & m->mask; dist++; }
+    }
+    if (m->b[ib].dist < 0) {
+        m->b[ib].dist = dist; m->b[ib].id = id;
+        if (dist > m->max_dist_seen) m->max_dist_seen = dist;
+    } else { /* insert_value_impl */
+        int16_t td = m->b[ib].dist; int64_t ti = m->b[ib].id;
+        m->b[ib].dist = dist; m->b[ib].id = id;
+        if (dist > m->max_dist_seen) m->max_dist_seen = dist;
+        dist = td; id = ti;
+        ib = (ib + 1) & m->mask;
+        dist++;
+        while (m->b[ib].dist >= 0) {
+            if (dist > m->b[ib].dist) {
+                if (dist > ORC_RH_LIMIT) m->grow_on_next_insert = 1;
+                td = m->b[ib].dist; ti = m->b[ib].id;
+                m->b[ib].dist = dist; m->b[ib].id = id;
+                if (dist > m->max_dist_seen) m->max_dist_seen = dist;
+                dist = td; id = ti;
+            }
+            ib = (ib + 1) & m->mask;
+            dist++;
+        }
+        m->b[ib].dist = dist; m->b[ib].id = id;
+        if (dist > m->max_dist_seen) m->max_dist_seen = dist;
+    }
+    m->nb++;
+}
+
+/* The reference loop itself.  reserve_n >= 0: `grid.reserve(reserve_n)` first
+ * (VoxelDownsample passes frame.size(), Preprocessing.cpp:56); reserve_n < 0: a
+ * default-constructed map that grows (VoxelHashMap::map_, VoxelHashMap.hpp:117).
+ * max_per_voxel = 1 restates VoxelDownsample (contains -> continue, else insert),
+ * max_per_voxel = K restates AddPoints + VoxelBlock::AddPoint (VoxelHashMap.cpp:733-770,
+ * VoxelHashMap.hpp:55-62).  out_idx: point indices in ITERATION order (per voxel block the
+ * points in insertion order, as Pointcloud()/PointcloudN() emit them).  info[0] = final
+ * bucket count, info[1] = number of voxels, info[2] = largest probe distance stored,
+ * info[3] = number of rehashes.  Returns the number of emitted points. */
+ORC_API int64_t orc_voxel_robin(const double *pts, int64_t n, int64_t stride, double voxel_size,
+                                int64_t max_per_voxel, uint32_t hash_mul_y, int64_t reserve_n,
+                                int64_t *out_idx, int64_t *info) {
+    const size_t cap = (size_t)(n > 0 ? n : 1);
+    int32_t *vox = (int32_t *)malloc(sizeof(int32_t) * 3 * cap);   /* per voxel record */
+    uint32_t *hash = (uint32_t *)malloc(sizeof(uint32_t) * cap);
+    int64_t *head = (int64_t *)malloc(sizeof(int64_t) * cap), *tail = (int64_t *)malloc(sizeof(int64_t) * cap);
+    int64_t *cnt = (int64_t *)malloc(sizeof(int64_t) * cap), *next = (int64_t *)malloc(sizeof(int64_t) * cap);
+    orc_rh m;
+    memset(&m, 0, sizeof(m));
+    m.vox = vox; m.hash = hash;
+    orc_rh_construct(&m, 0);
+    if (reserve_n >= 0) orc_rh_reserve(&m, (uint64_t)reserve_n);
+    int64_t nv = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int32_t key[3];
+        for (int c = 0; c < 3; ++c) key[c] = (int32_t)(pts[i * stride + c] / voxel_size);
+        const uint32_t h = ((1u << 20) - 1u) & (((uint32_t)key[0] * 73856093u) ^ ((uint32_t)key[1] * hash_mul_y) ^
+                                                ((uint32_t)key[2] * 83492791u));
+        const int64_t id = orc_rh_find(&m, key, h);
+        if (id >= 0) {
+            if (cnt[id] < max_per_voxel) { next[tail[id]] = i; tail[id] = i; next[i] = -1; cnt[id]++; }
+            continue;
+        }
+        vox[3 * nv] = key[0]; vox[3 * nv + 1] = key[1]; vox[3 * nv + 2] = key[2];
+        hash[nv] = h; head[nv] = tail[nv] = i; cnt[nv] = 1; next[i] = -1;
+        orc_rh_insert_new(&m, nv);
+        nv++;
+    }
+    int64_t k = 0;
+    for (uint64_t b = 0; b < m.bucket_count; ++b) {
+        if (m.b[b].dist < 0) continue;
+        for (int64_t p = head[m.b[b].id]; p >= 0; p = next[p]) out_idx[k++] = p;
+    }
+    if (info) { info[0] = (int64_t)m.bucket_count; info[1] = nv; info[2] = m.max_dist_seen; info[3] = m.n_rehash; }
+    free(m.b); free(vox); free(hash); free(head); free(tail); free(cnt); free(next);
+    return k;
+}
+
 ORC_API int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -108,16 +108,14 @@ def test_ransac_registration_end_to_end(orc):
     assert pose_icp is None
     # oracle re-enactment of RN:396-425 + 288-327
     vs = node.config.mapping.voxel_size
-    scan = raw_scan[orc.voxel_first(raw_scan, vs * 0.5)]
-    scan = scan[orc.voxel_first(scan, vs * 1.0)]
-    mp = voxel_map[orc.voxel_first(voxel_map, vs, 20)]
-    sub = scan[orc.voxel_first(scan, 5.0)]
+    scan = orc.voxel_down_sample(orc.voxel_down_sample(raw_scan, vs * 0.5), vs * 1.0)   # RN:399-400, container order
+    mp = voxel_map[orc.voxel_hash_map_points(voxel_map, vs, 20)]                         # RN:402-403 -> PointcloudN()
+    sub = orc.voxel_down_sample(scan, 5.0)                                               # RN:414
     _, _, qi, mi, _ = orc.get_vfm_correspondences(sub, mp, 0.8)
     if len(qi) < 75:
-        sub = scan[orc.voxel_first(scan, 1.0)]
+        sub = orc.voxel_down_sample(scan, 1.0)
         _, _, qi, mi, _ = orc.get_vfm_correspondences(sub, mp, 0.8)
-    # indices into the voxelised clouds
-    scan_idx = orc.voxel_first(scan, 5.0 if len(sub) != len(scan[orc.voxel_first(scan, 1.0)]) or True else 1.0)
+    # indices into the voxelised clouds (RN:288-309)
     src_rows = np.array([np.flatnonzero((scan[:, :3] == sub[i, :3]).all(1))[0] for i in qi])
     corres = np.stack([src_rows, mi], 1).astype(np.int32)
     ref = orc.ransac_corr(scan[:, :3], mp[:, :3], corres, 10000.0, 5000, seed=42)

@@ -1,5 +1,7 @@
-"""Row F1 on the GPU: voxel down-sampling / voxel-hash-map insertion (csrc/voxel.hip) against the oracle
-(sort-based restatement of Preprocessing.cpp:50-137 and VoxelHashMap.cpp:733-770)."""
+"""Row F1 on the GPU: voxel down-sampling / voxel-hash-map insertion (csrc/voxel.hip) against the oracle:
+the survivor set (Preprocessing.cpp:50-137, VoxelHashMap.cpp:733-770) AND the reference's emission order
+(tsl::robin_map iteration order, Preprocessing.cpp:64-69 / VoxelHashMap.cpp:628-676; oracle:
+``orc_voxel_robin``), including the chained voxelisations of registration_node.py:399-414 and 556-580."""
 import numpy as np
 import pytest
 
@@ -19,6 +21,71 @@ def test_voxel_first_matches_oracle(n, extent, vs, K):
     np.testing.assert_array_equal(keep, orc.voxel_first(pts, vs, K))
 
 
+def test_voxel_keys_do_not_alias_at_large_coordinates():
+    """Absolute / UTM coordinates: |xyz / voxel_size| beyond 2^20 (the old packed 21-bit key aliased there)."""
+    from oracle import oracle as orc
+    from vfmreg import ops
+    rng = np.random.default_rng(5)
+    base = np.array([3.2e5, 4.7e6, 120.0])
+    pts = base + rng.uniform(-20, 20, (20000, 3))
+    for vs in (0.1, 0.25):
+        assert np.abs(pts / vs).max() > 2 ** 20
+        keep = ops.voxel_first(torch.from_numpy(pts).cuda(), vs, 1).cpu().numpy()
+        np.testing.assert_array_equal(keep, orc.voxel_first(pts, vs, 1))
+        got = ops.voxel_robin(torch.from_numpy(pts).cuda(), vs).cpu().numpy()
+        np.testing.assert_array_equal(got, orc.voxel_robin(pts, vs))
+
+
+@pytest.mark.parametrize("n,extent,vs", [(1, 1.0, 1.0), (7, 3.0, 1.0), (700, 10.0, 0.5), (5000, 30.0, 1.0), (5000, 30.0, 0.25),
+                                         (120000, 60.0, 0.25), (400000, 80.0, 0.5)])
+def test_downsample_order_is_the_containers(n, extent, vs):
+    from oracle import oracle as orc
+    from vfmreg import ops
+    rng = np.random.default_rng(n)
+    pts = rng.uniform(-extent, extent, (n, 3)) * [1, 1, 0.15]
+    got, info = ops.voxel_robin(torch.from_numpy(pts).cuda(), vs, return_info=True)
+    ref, rinfo = orc.voxel_robin(pts, vs, return_info=True)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    assert info[0] == rinfo[0] and info[1] == rinfo[1]        # bucket count, voxel count
+
+
+def test_downsample_order_with_wrapping_clusters():
+    """Voxels whose home buckets are the last ones of the table: the cluster wraps to bucket 0."""
+    from oracle import oracle as orc
+    from vfmreg import ops
+    rng = np.random.default_rng(11)
+    wrapped = 0
+    for trial in range(12):
+        n = int(rng.integers(50, 3000))
+        c = int(np.ceil(np.float32(n) / np.float32(0.5)))
+        B = 1 << int(c - 1).bit_length()
+        cand = rng.integers(-300, 300, (200000, 3)).astype(np.int32)
+        h = orc.voxel_hash(cand, orc.HASH_MUL_DOWNSAMPLE) & (B - 1)
+        near, low = cand[h >= B - 3][:int(rng.integers(4, 12))], cand[h <= 2][:int(rng.integers(0, 6))]
+        rest = cand[rng.integers(0, len(cand), n - len(near) - len(low))]
+        vox = np.concatenate([near, low, rest])
+        vox = vox[rng.permutation(len(vox))]
+        pts = (vox.astype(np.float64) + np.where(vox >= 0, 0.5, -0.5)) * 0.5
+        got, info = ops.voxel_robin(torch.from_numpy(pts).cuda(), 0.5, return_info=True)
+        np.testing.assert_array_equal(got.cpu().numpy(), orc.voxel_robin(pts, 0.5))
+        wrapped += int(info[3] > 0)
+    assert wrapped >= 6
+
+
+@pytest.mark.parametrize("n,extent,K", [(3, 2.0, 20), (300, 6.0, 20), (513, 30.0, 20), (8000, 3.0, 20), (8000, 40.0, 2),
+                                        (200000, 60.0, 20)])
+def test_growing_map_order_is_the_containers(n, extent, K):
+    """A default-constructed VoxelHashMap that doubles as it fills (VoxelHashMap.hpp:117, AddPoints)."""
+    from oracle import oracle as orc
+    from vfmreg import ops
+    rng = np.random.default_rng(n + K)
+    pts = rng.uniform(-extent, extent, (n, 3)) * [1, 1, 0.15]
+    got, info = ops.voxel_robin(torch.from_numpy(pts).cuda(), 1.0, K, reserve=False, hash_mul=ops.HASH_MAP, return_info=True)
+    ref, rinfo = orc.voxel_robin(pts, 1.0, K, False, orc.HASH_MUL_MAP, return_info=True)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    assert info[0] == rinfo[0] and info[1] == rinfo[1]
+
+
 def test_voxel_down_sample_mirror():
     from oracle import oracle as orc
     from vfmreg.voxelization import voxel_down_sample
@@ -26,7 +93,9 @@ def test_voxel_down_sample_mirror():
     pts = rng.uniform(-30, 30, (5000, 7))
     for vs in (0.25, 1.0, 5.0):
         out = voxel_down_sample(pts, vs)                                   # voxelization.py:27
-        np.testing.assert_array_equal(out, pts[orc.voxel_first(pts, vs, 1)])
+        np.testing.assert_array_equal(out, orc.voxel_down_sample(pts, vs))
+        np.testing.assert_array_equal(np.sort(out.view(np.dtype((np.void, 56))).ravel()),
+                                      np.sort(pts[orc.voxel_first(pts, vs, 1)].view(np.dtype((np.void, 56))).ravel()))
         v = np.trunc(out[:, :3] / vs).astype(int)
         assert len(np.unique(v, axis=0)) == len(v)
     # truncation toward zero (Preprocessing.cpp:58): -0.3 and 0.3 share voxel 0
@@ -35,6 +104,31 @@ def test_voxel_down_sample_mirror():
     assert voxel_down_sample(np.zeros((0, 3)), 1.0).shape == (0, 3)
     with pytest.raises(ValueError, match="Invalid shape"):
         voxel_down_sample(np.zeros((4, 2)), 1.0)
+
+
+def test_chained_voxelisation_equals_reference_chain():
+    """registration_node.py:399-414 (0.5 -> 1.0 -> [transform] -> 5.0 m, retry 1.0) and 556-580 (0.25 m per cloud,
+    then 0.25 m on the concatenation): every level keeps the first point per voxel of the previous level's
+    CONTAINER order, so the chain only matches if each level's order does."""
+    from oracle import oracle as orc
+    from vfmreg.voxelization import voxel_down_sample
+    rng = np.random.default_rng(3)
+    scan = np.c_[rng.uniform(-50, 50, (60000, 3)) * [1, 1, 0.1], rng.standard_normal((60000, 5))]
+    a = voxel_down_sample(voxel_down_sample(scan, 0.5), 1.0)
+    b = orc.voxel_down_sample(orc.voxel_down_sample(scan, 0.5), 1.0)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(voxel_down_sample(a, 5.0), orc.voxel_down_sample(b, 5.0))
+    np.testing.assert_array_equal(voxel_down_sample(a, 1.0), orc.voxel_down_sample(b, 1.0))
+    # and the input-order chain (what round 1 shipped) is a different point set
+    c = scan
+    for vs in (0.5, 1.0, 5.0):
+        c = c[orc.voxel_first(c, vs, 1)]
+    assert set(map(tuple, c[:, :3])) != set(map(tuple, voxel_down_sample(a, 5.0)[:, :3]))
+    # map accumulation: per-cloud 0.25 m, concatenate, 0.25 m again
+    clouds = [rng.uniform(-30, 30, (20000, 3)) * [1, 1, 0.1] + [5.0 * k, 0, 0] for k in range(4)]
+    got = voxel_down_sample(np.concatenate([voxel_down_sample(c, 0.25) for c in clouds]), 0.25)
+    ref = orc.voxel_down_sample(np.concatenate([orc.voxel_down_sample(c, 0.25) for c in clouds]), 0.25)
+    np.testing.assert_array_equal(got, ref)
 
 
 def test_voxel_hash_map_caps_points_per_voxel():
@@ -47,9 +141,17 @@ def test_voxel_hash_map_caps_points_per_voxel():
     m = get_voxel_hash_map(cfg)
     m.add_points(pts[:5000])
     m.add_points(pts[5000:])                 # incremental insertion honours the earlier counts
-    np.testing.assert_array_equal(m.point_cloud(), pts[orc.voxel_first(pts, 1.0, 20)])
+    np.testing.assert_array_equal(m.point_cloud(), pts[orc.voxel_hash_map_points(pts, 1.0, 20)])
+    np.testing.assert_array_equal(np.sort(orc.voxel_hash_map_points(pts, 1.0, 20)), orc.voxel_first(pts, 1.0, 20))
     assert m.empty_n() and not m.empty()
     with pytest.raises(ValueError, match="Invalid shape"):
         m.add_points(np.zeros((3, 2)))
     m.clear()
     assert m.empty()
+    # 387-column points live in map_n_; point_cloud() falls back to their heads (VoxelHashMap.cpp:641-649)
+    wide = np.c_[rng.uniform(-30, 30, (3000, 3)), rng.standard_normal((3000, 384))]
+    m.add_points(wide)
+    order = orc.voxel_hash_map_points(wide, 1.0, 20)
+    np.testing.assert_array_equal(m.point_cloud_n(), wide[order])
+    np.testing.assert_array_equal(m.point_cloud(), wide[order][:, :3])
+    assert m.empty() and not m.empty_n()

@@ -3,6 +3,9 @@
 max_points_per_voxel = 20, max_range = 100, initial_threshold = 2.0."""
 from types import SimpleNamespace
 
+DESCRIPTOR_SIZE = 384             # descriptor_size.hpp:7
+POINT_SIZE = 3 + DESCRIPTOR_SIZE  # descriptor_size.hpp:13, kiss_icp_pybind._point_size()
+
 
 def load_config(config_file=None, deskew=None, max_range=None):
     max_range = 100.0 if max_range is None else float(max_range)

@@ -43,7 +43,12 @@ class VoxelGridDevice:
 
     def __init__(self, points: np.ndarray, voxel_size: float):
         pts = np.ascontiguousarray(points[:, :3], dtype=np.float64)
-        v = np.trunc(pts / voxel_size).astype(np.int64) + (1 << 20)
+        v = np.trunc(pts / voxel_size).astype(np.int64)
+        # the CSR key packs 21 bits per axis (csrc/icp.hip voxel_key); the 27-neighbour scan reaches v +- 1
+        if len(v) and (np.abs(v).max() >= (1 << 20) - 1):
+            raise ValueError("voxel coordinate outside +-2^20 voxels: shift the clouds towards the origin "
+                             "(the ICP grid key holds 21 bits per axis)")
+        v = v + (1 << 20)
         keys = (v[:, 0] << 42) | (v[:, 1] << 21) | v[:, 2]
         order = np.argsort(keys, kind="stable")   # points of a voxel keep their insertion order
         ks = keys[order]

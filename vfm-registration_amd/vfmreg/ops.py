@@ -317,3 +317,27 @@ def voxel_first(xyz: torch.Tensor, voxel_size: float, max_per_voxel: int = 1) ->
     _lib.check(lib.vfm_voxel_first(xyz.data_ptr(), n, stride, float(voxel_size), int(max_per_voxel), keep.data_ptr(),
                                    count.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "voxel_first")
     return keep[:int(count.item())]
+
+
+HASH_DOWNSAMPLE = 19349663  # VoxelHash of Preprocessing.cpp:44
+HASH_MAP = 19349669         # VoxelHash of VoxelHashMap.hpp:75
+
+
+def voxel_robin(xyz: torch.Tensor, voxel_size: float, max_per_voxel: int = 1, reserve: bool = True,
+                hash_mul: int = HASH_DOWNSAMPLE, return_info: bool = False):
+    """The survivors of ``voxel_first`` in the order the reference emits them (tsl::robin_map iteration
+    order): ``reserve=True, HASH_DOWNSAMPLE`` = VoxelDownsample (Preprocessing.cpp:50-69);
+    ``reserve=False, HASH_MAP`` = a fresh VoxelHashMap after AddPoints, as Pointcloud*() walk it."""
+    import ctypes as C
+    _chk(xyz, torch.float64, "xyz")
+    lib = _lib.load()
+    n, stride = xyz.shape
+    keep = torch.empty(max(n, 1), dtype=torch.int64, device=xyz.device)
+    count = torch.empty(1, dtype=torch.int64, device=xyz.device)
+    info = (C.c_int64 * 4)()
+    ws = _ws(lib.vfm_voxel_robin_workspace_bytes(n), xyz.device)
+    _lib.check(lib.vfm_voxel_robin(xyz.data_ptr(), n, stride, float(voxel_size), int(max_per_voxel), int(hash_mul),
+                                   n if reserve else -1, keep.data_ptr(), count.data_ptr(), C.cast(info, C.c_void_p),
+                                   ws.data_ptr(), ws.numel(), _stream()), "voxel_robin")
+    out = keep[:int(count.item())]
+    return (out, list(info)) if return_info else out

@@ -119,8 +119,8 @@ def _lookup_rows(cloud: np.ndarray, pts: np.ndarray):
     """Index in `cloud` of every row of `pts` (nearest neighbour at distance < 1e-3, RN:295-309).
     The correspondences were copied out of these clouds, so an exact match on the raw bytes
     exists whenever the KD-tree of the reference finds one."""
-    cloud = np.ascontiguousarray(cloud, dtype=np.float64)
-    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    cloud = np.ascontiguousarray(cloud, dtype=np.float64) + 0.0   # -0.0 -> +0.0: the KD-tree sees them at distance 0
+    pts = np.ascontiguousarray(pts, dtype=np.float64) + 0.0
     key = lambda a: a.view(np.dtype((np.void, 24))).reshape(-1)
     order = np.argsort(key(cloud), kind="stable")
     sorted_keys = key(cloud)[order]

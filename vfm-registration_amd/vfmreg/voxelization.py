@@ -1,10 +1,12 @@
 """Mirror of kiss_icp.voxelization (src/kiss-icp/python/kiss_icp/voxelization.py:27-39).
 
 ``voxel_down_sample(points, voxel_size)`` keeps the FIRST point of every voxel,
-voxel = trunc(xyz / voxel_size) per axis (Eigen ``cast<int>``, Preprocessing.cpp:58), computed on the
-GPU (csrc/voxel.hip, row F1).  The reference emits survivors in tsl::robin_map iteration order
-(Preprocessing.cpp:64-69); this build emits them in input order (documented deviation):
-the SET of survivors is identical.
+voxel = trunc(xyz / voxel_size) per axis (Eigen ``cast<int>``, Preprocessing.cpp:58), and returns the
+survivors in the order the reference does: the iteration order of the ``tsl::robin_map`` that
+``VoxelDownsample`` fills (``reserve(frame.size())``, Preprocessing.cpp:55-69).  The order matters
+because the path chains the call (registration_node.py:399-414: 0.5 m -> 1.0 m -> 5.0 m): each level
+keeps the first point per voxel OF THE PREVIOUS LEVEL'S OUTPUT ORDER.  Both parts run on the GPU
+(csrc/voxel.hip, row F1).
 """
 from __future__ import annotations
 
@@ -20,10 +22,17 @@ def first_per_voxel(points: np.ndarray, voxel_size: float, max_per_voxel: int = 
     return ops.voxel_first(xyz, voxel_size, max_per_voxel).cpu().numpy()
 
 
+def robin_order(points: np.ndarray, voxel_size: float, max_per_voxel: int = 1, reserve: bool = True,
+                hash_mul: int = ops.HASH_DOWNSAMPLE) -> np.ndarray:
+    """Indices of the kept points in the reference's container iteration order."""
+    xyz = torch.from_numpy(np.ascontiguousarray(points[:, :3], dtype=np.float64)).cuda()
+    return ops.voxel_robin(xyz, voxel_size, max_per_voxel, reserve, hash_mul).cpu().numpy()
+
+
 def voxel_down_sample(points: np.ndarray, voxel_size: float) -> np.ndarray:
     points = np.asarray(points)
     if points.ndim != 2 or points.shape[1] < 3:
         raise ValueError("Invalid shape")  # voxelization.py:37
     if len(points) == 0:
         return np.zeros((0, points.shape[1]), dtype=np.float64)
-    return np.asarray(points[first_per_voxel(points, voxel_size, 1)], dtype=np.float64)
+    return np.asarray(points[robin_order(points, voxel_size)], dtype=np.float64)
