@@ -273,6 +273,9 @@ int vfm_prof_events_destroy(void *start, void *stop);
 /* tuning switch: coarse-kernel variant (0 default, 1 = 8 waves x 32 queries, 2 = 4 waves x 64) */
 int vfm_debug_set_coarse_variant(int qsets);
 /* tuning switch: force the number of map slices of the coarse pass (0 = heuristic) */
+/* counters of the last FAST search that used workspace `ws` (candidate histogram, refined / fallback queries;
+ * see csrc/match.hip).  out64_host: HOST int32[64].  Synchronises the device. */
+int vfm_debug_match_stats(void *ws, int64_t n, int64_t m, int32_t *out64_host);
 int vfm_debug_set_coarse_slices(int slices);
 /* tuning switch: 1 = RANSAC scores every hypothesis in fp64 (skips the fp32 coarse pass) */
 int vfm_debug_set_ransac_exact_only(int on);

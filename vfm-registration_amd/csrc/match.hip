@@ -40,7 +40,11 @@ constexpr int QBLOCK = 256;       // queries per workgroup of the coarse kernel 
 // LDS ring depth in tiles: a step consumes 2 tiles; 6 buffers = 2 steps in flight (d <= 384),
 // 4 buffers = 1 step in flight when a tile is 32 KiB (d = 512): 160 KiB of LDS per CU.
 constexpr int ring_depth(int ksteps) { return ksteps <= 24 ? 6 : 4; }
-constexpr int CAND_CAP = 40;      // candidate chunks kept per query before falling back
+constexpr int CAND_CAP_MAX = 2048;  // candidate entries a query can hold = min(#chunks, this), a multiple of 64 (cand_cap());
+                                    // beyond it the query is decided by the all-pairs kernel.  At C2 (1563 chunks) the cap
+                                    // cannot be exceeded: every chunk fits in the list.
+constexpr int REFINE_MIN = 3;     // queries with this many candidate entries (or a whole-chunk entry) go through the fp32 refinement
+constexpr int REFINE_KEEP = 64;   // rows a query may keep after the refinement
 constexpr float COARSE_OFFSET = 2.0f;   // accumulators start here: every coarse score is a
                                         // positive normal float, so uint order == float order
 constexpr float DEFAULT_WINDOW = 2.5e-3f;  // >= 2E, E = proven |coarse - exact| bound
@@ -52,6 +56,10 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // unit (tile, s, h, p) = 8 fp16 = row (tile*32+p), k = 16 s + 8 h .. +7  at uint4 index
 // tile*(d/16*64) + s*64 + h*32 + p : exactly the register image of one 32x32x16 MFMA operand.
 // ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int cand_cap(int64_t map_rows_padded) {
+    int64_t c = (map_rows_padded / 128 + 63) / 64 * 64;
+    return (int)(c < 64 ? 64 : (c > CAND_CAP_MAX ? CAND_CAP_MAX : c));
+}
 __host__ __device__ inline int64_t rows_padded(int64_t rows) { return (rows + ROW_PAD - 1) / ROW_PAD * ROW_PAD; }
 
 // sum of squares in the oracle's order: lane l owns the float4 chunks c with c % 64 == l
@@ -736,10 +744,9 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
                                                            const unsigned* __restrict__ qmax,
                                                            const float* __restrict__ invq, float window,
                                                            int* __restrict__ cand_cnt,
-                                                           unsigned* __restrict__ cand, int* __restrict__ fb_count,
+                                                           unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count,
                                                            int* __restrict__ fb_list) {
     __shared__ int lcnt[64];
-    __shared__ unsigned lcand[64][CAND_CAP];
     const int qq = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * 64 + qq;
     if (g == 0) lcnt[qq] = 0;
@@ -764,9 +771,9 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
             const int c = cb + SELECT_GROUPS * u;
             if (c < nchunks && (rec[u].x | 127u) >= thr) {
                 const int slot = atomicAdd(&lcnt[qq], 1);
-                if (slot < CAND_CAP) {
+                if (slot < cap && q < n) {  // sparse: straight to the query's global list
                     const unsigned rescan = (((rec[u].y | 63u) >= thr) || c >= first_pad_chunk) ? 1u : 0u;
-                    lcand[qq][slot] = ((unsigned)c << 8) | (rescan << 7) | (rec[u].x & 127u);
+                    cand[(size_t)q * cap + slot] = ((unsigned)c << 8) | (rescan << 7) | (rec[u].x & 127u);
                 }
             }
         }
@@ -774,17 +781,176 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
     __syncthreads();
     if (g == 0 && q < n) {
         const int cnt = lcnt[qq];
+        // statistics (vfm_debug_match_stats): [2] candidate entries, [8 + b] queries with 2^(b-1) < entries <= 2^b
+        if (invq[q] != 0.0f) {
+            atomicAdd(fb_count + 2, cnt);
+            int bin = 0;
+            while ((1 << bin) < cnt && bin < 15) ++bin;
+            atomicAdd(fb_count + 8 + bin, 1);
+        }
         if (invq[q] == 0.0f) {
             cand_cnt[q] = 0;  // zero query row: decided directly (index 0, score 0)
-        } else if (cnt > CAND_CAP) {
+        } else if (cnt > cap) {
             cand_cnt[q] = -1;  // overflow: decided by the exact all-pairs kernel
             const int slot = atomicAdd(fb_count, 1);
             fb_list[slot] = (int)q;
         } else {
             cand_cnt[q] = cnt;
-            for (int e = 0; e < cnt; ++e) cand[(size_t)q * CAND_CAP + e] = lcand[qq][e];
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 refinement of crowded candidate lists (near-duplicate map rows).
+//
+// Real lifted descriptors are bilinear interpolations of a 16 x 21 patch grid (image_features.py:104-110,
+// prepare_scenes.py:85-104): neighbouring map points differ by less than the fp16 window (2.5e-3), so a query
+// can have dozens of candidate chunks, and chunks whose two best rows are both inside the window.  Deciding
+// all of them in fp64 (or, past the old 40-entry cap, all M rows) was a cliff.  Here one wavefront per such
+// query scores every candidate row in fp32 -- 16 lanes per row, 4 rows per pass, each lane a sequential fma
+// chain over d/16 elements followed by a 4-level xor tree -- and keeps only the rows within
+//     w2 = 2 * (d/16 + 4 + 2) * 2^-24      (3.6e-6 at d = 384)
+// of the fp32 maximum.  Proof that the oracle's arg-max survives: the fp32 value s of a row differs from the
+// exact dot product t of the same fp32-normalised rows (the oracle's definition) by at most
+// gamma = (d/16 + 4) u * sum|q_k b_k| <= (d/16 + 4) u (1 + 1e-6), u = 2^-24 (one rounding per fma / add along the
+// longest path of the summation tree; Cauchy-Schwarz on unit rows).  With j* the exact arg-max and j' the fp32
+// arg-max: s(j*) >= t(j*) - gamma >= t(j') - gamma >= s(j') - 2 gamma; every row that ties with j* exactly is
+// inside the same margin, so the fp64 decision (ties -> lowest index) sees them all.  The surviving rows
+// replace the query's list as single-row entries: match_rescore_kernel is unchanged.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void match_refine_kernel(const float* __restrict__ q, const float* __restrict__ invq,
+                                                           const float* __restrict__ b, const float* __restrict__ invb,
+                                                           int64_t n, int64_t m, int d, float w2, int* __restrict__ cand_cnt,
+                                                           unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count,
+                                                           int* __restrict__ fb_list) {
+    __shared__ unsigned l_row[4][REFINE_KEEP];
+    __shared__ float l_sc[4][REFINE_KEEP];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+    if (qi >= n) return;
+    const int cnt = cand_cnt[qi];
+    if (cnt <= 0) return;  // zero query / nothing / overflow (-1: the all-pairs kernel decides)
+    unsigned* mycand = cand + (size_t)qi * cap;
+    // wave-uniform: is this list crowded?
+    bool flagged = false;
+    for (int e = lane; e < cnt; e += 64) flagged |= (mycand[e] & 128u) != 0u;
+    if (cnt < REFINE_MIN && !__any(flagged)) return;
+    const int g = lane >> 4, l = lane & 15;  // row slot of the pass, k-slice
+    const int nt = d >> 6;                   // float4 per lane (d % 64 == 0)
+    const float iq = invq[qi];
+    float4 qv[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+        if (t < nt) {
+            float4 v = *reinterpret_cast<const float4*>(q + qi * (int64_t)d + 4 * (l + 16 * t));
+            v.x = v.x * iq; v.y = v.y * iq; v.z = v.z * iq; v.w = v.w * iq;  // the fp32-normalised query (faiss' xq)
+            qv[t] = v;
+        }
+    }
+    unsigned* lrow = l_row[wave];
+    float* lsc = l_sc[wave];
+    int kept = 0;            // wave-uniform
+    float runmax = -3.0e38f;  // wave-uniform
+    bool overflow = false;
+    auto score4 = [&](long long row) -> float {  // rows of the 4 lane groups; row < 0: none
+        float acc = 0.0f;
+        if (row >= 0) {
+            const float ib = invb[row];
+            const float* br = b + row * (int64_t)d + 4 * l;
+#pragma unroll
+            for (int t = 0; t < 12; ++t) {
+                if (t < nt) {
+                    const float4 bv = *reinterpret_cast<const float4*>(br + 64 * t);
+                    acc = __builtin_fmaf(qv[t].x, bv.x * ib, acc);
+                    acc = __builtin_fmaf(qv[t].y, bv.y * ib, acc);
+                    acc = __builtin_fmaf(qv[t].z, bv.z * ib, acc);
+                    acc = __builtin_fmaf(qv[t].w, bv.w * ib, acc);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
+        return acc;
+    };
+    auto consider = [&](long long row, float sc) {  // called by all lanes; (row, sc) of this lane's group
+        // new running maximum over the pass
+        float pm = (row >= 0) ? sc : -3.0e38f;
+        pm = fmaxf(pm, __shfl_xor(pm, 16));
+        pm = fmaxf(pm, __shfl_xor(pm, 32));
+        if (pm > runmax) {  // prune the kept list against the new maximum
+            runmax = pm;
+            const float thr = runmax - w2;
+            const bool mine = lane < kept && lsc[lane] >= thr;
+            const unsigned r = lane < kept ? lrow[lane] : 0u;
+            const float sv = lane < kept ? lsc[lane] : 0.f;
+            const unsigned long long bal = __ballot(mine);
+            __builtin_amdgcn_wave_barrier();
+            if (mine) {
+                const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+                lrow[pos] = r;
+                lsc[pos] = sv;
+            }
+            __builtin_amdgcn_wave_barrier();
+            kept = __popcll(bal);
+        }
+        const float thr = runmax - w2;
+        const bool add = (l == 0) && row >= 0 && sc >= thr;
+        const unsigned long long bal = __ballot(add);
+        if (add) {
+            const int pos = kept + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < REFINE_KEEP) {
+                lrow[pos] = (unsigned)row;
+                lsc[pos] = sc;
+            }
+        }
+        kept += __popcll(bal);
+        if (kept > REFINE_KEEP) {
+            overflow = true;
+            kept = REFINE_KEEP;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // single-row entries: 4 per pass
+    for (int e0 = 0; e0 < cnt; e0 += 4) {
+        long long row = -1;
+        if (e0 + g < cnt) {
+            const unsigned ce = mycand[e0 + g];
+            if (!(ce & 128u)) {
+                row = (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u);
+                if (row >= m) row = -1;
+            }
+        }
+        if (__any(row >= 0)) consider(row, score4(row));
+    }
+    // whole-chunk entries: all 128 rows of the chunk
+    for (int e = 0; e < cnt; ++e) {
+        const unsigned ce = mycand[e];  // wave-uniform
+        if (!(ce & 128u)) continue;
+        const long long base = (long long)(ce >> 8) * CHUNK_ROWS;
+        for (int r0 = 0; r0 < CHUNK_ROWS; r0 += 4) {
+            long long row = base + r0 + g;
+            if (row >= m) row = -1;
+            if (__any(row >= 0)) consider(row, score4(row));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (overflow) {  // > REFINE_KEEP rows tie within 4e-6: the all-pairs kernel decides
+        if (lane == 0) {
+            cand_cnt[qi] = -1;
+            const int slot = atomicAdd(fb_count, 1);
+            fb_list[slot] = (int)qi;
+        }
+        return;
+    }
+    if (lane == 0) {  // statistics: [1] queries refined, [3] rows they keep
+        atomicAdd(fb_count + 1, 1);
+        atomicAdd(fb_count + 3, kept);
+    }
+    if (lane < kept) {
+        const unsigned row = lrow[lane];
+        mycand[lane] = ((row / CHUNK_ROWS) << 8) | (row % CHUNK_ROWS);
+    }
+    if (lane == 0) cand_cnt[qi] = kept;
 }
 
 // exact score of normalised rows, sequential k, fp64 (products of two fp32 are exact in fp64)
@@ -823,11 +989,11 @@ __device__ __forceinline__ void wave_argmax(double& s, long long& j) {
 // The accumulation order is the oracle's (sequential k), ties -> lowest index, sim = (float)score.
 constexpr int RS_KC = 96;             // k values per chunk (24 float4 per row)
 constexpr int RS_STRIDE = RS_KC + 1;  // doubles per LDS row: 194 words == 2 (mod 64) -> conflict-free ds_read_b64
-constexpr int RS_PAIRS = 1024;        // pair slots per epoch (a block has ~80 pairs; 64 * CAND_CAP at most)
+constexpr int RS_PAIRS = 1024;        // pair slots per epoch (a block has ~80 pairs; more run in further epochs)
 __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restrict__ q, const float* __restrict__ invq,
                                                             const float* __restrict__ b, const float* __restrict__ invb,
                                                             int64_t n, int64_t m, int d, const int* __restrict__ cand_cnt,
-                                                            const unsigned* __restrict__ cand,
+                                                            const unsigned* __restrict__ cand, int cap,
                                                             int64_t* __restrict__ idx_out, float* __restrict__ sim_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* P = reinterpret_cast<double*>(smem);               // [64][RS_STRIDE] products
@@ -850,7 +1016,7 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restr
     if (iq == 0.0f || cnt < 0) cnt = 0;  // zero query: decided below; overflow (-1): match_exact_kernel's
     bool any_rescan = false;
     int my_off = 0, my_pairs = 0;
-    const unsigned* mycand = cand + (size_t)(have ? qi : 0) * CAND_CAP;
+    const unsigned* mycand = cand + (size_t)(have ? qi : 0) * cap;
     auto row_of = [&](unsigned ce) { return (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u); };
     if (owner) {
         // flatten: the single-row candidates of query `lane` become pairs [my_off, my_off + my_pairs)
@@ -987,7 +1153,7 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restr
             double rbest = 0.0;
             long long rj = -1;
             for (int e = 0; e < cq; ++e) {
-                const unsigned ce = cand[(size_t)qq * CAND_CAP + e];
+                const unsigned ce = cand[(size_t)qq * cap + e];
                 if (!(ce & 128u)) continue;
                 const long long base = (long long)(ce >> 8) * CHUNK_ROWS;
                 for (int li = lane; li < CHUNK_ROWS; li += 64) {
@@ -1259,7 +1425,7 @@ __device__ __forceinline__ double l2_dist_f64(const float* __restrict__ qa, cons
 // exact decision among the candidates of match_select_kernel: one wave per query
 __global__ __launch_bounds__(256) void l2_rescore_kernel(const float* __restrict__ q, const float* __restrict__ b, int64_t n,
                                                          int64_t m, int d, const int* __restrict__ cand_cnt,
-                                                         const unsigned* __restrict__ cand, int64_t* __restrict__ nn_out,
+                                                         const unsigned* __restrict__ cand, int cap, int64_t* __restrict__ nn_out,
                                                          double* __restrict__ d2_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -1274,7 +1440,7 @@ __global__ __launch_bounds__(256) void l2_rescore_kernel(const float* __restrict
     double best = 0.0;  // negated distance: wave_argmax picks the smallest distance, ties -> lowest index
     long long bj = -1;
     for (int e = 0; e < cnt; ++e) {
-        const unsigned ce = cand[(size_t)qi * CAND_CAP + e];
+        const unsigned ce = cand[(size_t)qi * cap + e];
         const long long base = (long long)(ce >> 8) * CHUNK_ROWS;
         if (ce & 128u) {
             for (int li = lane; li < CHUNK_ROWS; li += 64) {
@@ -1333,6 +1499,7 @@ struct SearchWs {
     uint2* partials;
     int* cand_cnt;
     unsigned* cand;
+    int cap;  // entries per query in `cand`
     int* fb_count;
     int* fb_list;
     unsigned* qmax;
@@ -1345,7 +1512,8 @@ inline SearchWs carve_search(void* p, int64_t n, int64_t m) {
     const int64_t npad = rows_padded(n), mpad = rows_padded(m);
     w.partials = c.take<uint2>((size_t)(mpad / CHUNK_ROWS) * (size_t)npad);
     w.cand_cnt = c.take<int>((size_t)npad);
-    w.cand = c.take<unsigned>((size_t)npad * CAND_CAP);
+    w.cap = cand_cap(mpad);
+    w.cand = c.take<unsigned>((size_t)npad * (size_t)w.cap);
     w.fb_count = c.take<int>(64);
     w.fb_list = c.take<int>((size_t)npad);
     w.qmax = c.take<unsigned>((size_t)npad);
@@ -1488,7 +1656,7 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
         if (d != 640 && d != 768) return vfm_fail(VFM_EINVAL, "row bias needs the 4-wave coarse kernel (K = 640 / 768), got %d", d);
         a.row_bias = B.inv;
     }
-    VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, sizeof(int), st));
+    VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, 64 * sizeof(int), st));
     VFM_CHECK_HIP(hipMemsetAsync(w.qmax, 0, (size_t)a.npad * sizeof(unsigned), st));
     int rc;
     switch (d / 16) {
@@ -1511,8 +1679,14 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     SearchWs w = carve_search(ws, n, m);
     const CoarseArgs a = coarse_args(Q, B, w, n, m, coarse_qblock(d));
     hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS), 0, st, w.partials, a.nchunks,
-                       a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.fb_count, w.fb_list);
+                       a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list);
     VFM_CHECK_LAUNCH("match_select_kernel");
+    {
+        const float w2 = 2.0f * (float)(d / 16 + 4 + 2) * 5.9604645e-8f;
+        hipLaunchKernelGGL(match_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2,
+                           w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list);
+        VFM_CHECK_LAUNCH("match_refine_kernel");
+    }
     {
         const size_t lds = (size_t)(64 * RS_STRIDE + RS_PAIRS) * sizeof(double) + (size_t)d * sizeof(float);
         static bool attr_set = false;
@@ -1522,7 +1696,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
             attr_set = true;
         }
         hipLaunchKernelGGL(match_rescore_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), lds, st, q, Q.inv, b, B.inv, n, m,
-                           d, w.cand_cnt, w.cand, idx_out, sim_out);
+                           d, w.cand_cnt, w.cand, w.cap, idx_out, sim_out);
     }
     VFM_CHECK_LAUNCH("match_rescore_kernel");
     hipLaunchKernelGGL(match_exact_kernel, dim3(256), dim3(256), (((size_t)d * 4 + 15) & ~(size_t)15) + 64, st, q, Q.inv,
@@ -1714,10 +1888,10 @@ int l2_search(const float* q, void* qprep, int64_t n, const float* b, void* bpre
     SearchWs w = carve_search(ws, n, m);
     const CoarseArgs a = coarse_args(Q, carve_prepared(bprep, m, kp), w, n, m, coarse_qblock(kp));
     hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS), 0, st, w.partials, a.nchunks,
-                       a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.fb_count, w.fb_list);
+                       a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list);
     VFM_CHECK_LAUNCH("match_select_kernel");
     hipLaunchKernelGGL(l2_rescore_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)d * 4 * 8, st, q, b, n, m, d, w.cand_cnt,
-                       w.cand, nn, d2);
+                       w.cand, w.cap, nn, d2);
     VFM_CHECK_LAUNCH("l2_rescore_kernel");
     const size_t lds = (((size_t)d * 4 + 15) & ~(size_t)15) + 64;
     hipLaunchKernelGGL(nn_l2_kernel, dim3(256), dim3(256), lds, st, q, n, b, m, d, w.fb_list, w.fb_count, nn, d2);
@@ -1774,6 +1948,17 @@ VFM_EXPORT int vfm_match_mutual_l2(const float* a, int64_t n, const float* b, in
 // kernel is launched on.  Used by bench.py for roofline.achieved.
 // ---------------------------------------------------------------------------------------------
 // A/B switch for the coarse kernel variant (1 = 8 waves x 32 queries, 2 = 4 waves x 64 queries, 0 = default)
+// Counters of the last search that used workspace `ws` (sizes as passed to that search): out64_host[0] queries
+// decided by the all-pairs fallback, [1] queries refined in fp32, [2] candidate entries after select, [3] rows kept
+// by the refinement, [8 + b] queries with 2^(b-1) < entries <= 2^b.  Synchronises the device.
+VFM_EXPORT int vfm_debug_match_stats(void* ws, int64_t n, int64_t m, int32_t* out64_host) {
+    VFM_CHECK_ARG(ws && out64_host, "match_stats: bad arguments");
+    SearchWs w = carve_search(ws, n, m);
+    VFM_CHECK_HIP(hipDeviceSynchronize());
+    VFM_CHECK_HIP(hipMemcpy(out64_host, w.fb_count, 64 * sizeof(int), hipMemcpyDeviceToHost));
+    return VFM_OK;
+}
+
 VFM_EXPORT int vfm_debug_set_coarse_slices(int slices) {
     g_force_slices = slices;
     return VFM_OK;
