@@ -113,6 +113,8 @@ def main():
     rank, world = vdist.init_from_env(backend="nccl", device=dev)  # "nccl" == RCCL on ROCm
 
     lib = _lib.load()
+    if os.environ.get("VFM_VARIANT"):  # A/B runs (tools/r02_prof.sh): 4 = dense per-chunk records + select kernel
+        lib.vfm_debug_set_coarse_variant(int(os.environ["VFM_VARIANT"]))
     n, m, d = args.n, args.m, DIM
     # two resident scene pairs per rank, alternated; pair p uses seed 42 + p (global pair id)
     pairs = [synth.make_pair_device(n, m, d, seed=42 + rank * 2 + j, device=dev) for j in range(2)]

@@ -276,6 +276,10 @@ int vfm_debug_set_coarse_variant(int qsets);
 /* counters of the last FAST search that used workspace `ws` (candidate histogram, refined / fallback queries;
  * see csrc/match.hip).  out64_host: HOST int32[64].  Synchronises the device. */
 int vfm_debug_match_stats(void *ws, int64_t n, int64_t m, int32_t *out64_host);
+/* the counters are collected only while this switch is on (they cost same-address atomics) */
+int vfm_debug_set_match_stats(int on);
+/* timing experiments only: overrides the coarse window of the sparse kernel (0 = default); results become wrong */
+int vfm_debug_set_coarse_window(float w);
 int vfm_debug_set_coarse_slices(int slices);
 /* tuning switch: 1 = RANSAC scores every hypothesis in fp64 (skips the fp32 coarse pass) */
 int vfm_debug_set_ransac_exact_only(int on);

@@ -27,11 +27,13 @@ def _stats(ops, q, b):
     """run the split search on explicit buffers so that the counters of the workspace can be read"""
     from vfmreg import _lib
     lib = _lib.load()
+    lib.vfm_debug_set_match_stats(1)
     Q, B = ops.PreparedRows(q), ops.PreparedRows(b)
     ws = torch.empty(lib.vfm_match_search_workspace_bytes(Q.rows, B.rows, Q.d), dtype=torch.uint8, device="cuda")
     idx, sim = ops.match_search(Q, B, ws=ws)
     out = (C.c_int32 * 64)()
     _lib.check(lib.vfm_debug_match_stats(ws.data_ptr(), Q.rows, B.rows, C.cast(out, C.c_void_p)))
+    lib.vfm_debug_set_match_stats(0)
     return idx, sim, list(out)
 
 

@@ -63,6 +63,11 @@ def run(pipe, p, steps, lib, n, m):
     pipe.synchronize()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    lib.vfm_debug_set_match_stats(1)  # one more registration with the counters on (they cost atomics: not timed)
+    pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"], inputs_ready=ev)
+    pipe.synchronize()
+    torch.cuda.synchronize()
+    lib.vfm_debug_set_match_stats(0)
     st = (C.c_int32 * 64)()
     r = pipe.sets[(pipe._step - 1) % len(pipe.sets)]
     _lib.check(lib.vfm_debug_match_stats(r.sws.data_ptr(), n, m, C.cast(st, C.c_void_p)))
@@ -107,7 +112,7 @@ def main():
             key = name + (" | pipelined" if overlap else " | serial")
             hist = {f"<= {1 << bnum}": st[8 + bnum] for bnum in range(16) if st[8 + bnum]}
             res[key] = dict(ms_per_registration=1e3 * dt, registrations_per_s=1.0 / dt, correspondences=k, pose_err_vs_planted=err,
-                            fallback_queries=st[0], refined_queries=st[1], candidate_entries_per_query=st[2] / n,
+                            fallback_queries=st[0], refined_queries=st[1], coarse_records_per_query=st[4] / n, candidate_entries_per_query=st[2] / n,
                             rows_kept_per_refined_query=(st[3] / st[1]) if st[1] else 0.0, candidate_entry_histogram=hist)
             print(key, json.dumps(res[key]), flush=True)
             del pipe

@@ -45,6 +45,7 @@ constexpr int CAND_CAP_MAX = 2048;  // candidate entries a query can hold = min(
                                     // cannot be exceeded: every chunk fits in the list.
 constexpr int REFINE_MIN = 3;     // queries with this many candidate entries (or a whole-chunk entry) go through the fp32 refinement
 constexpr int REFINE_KEEP = 64;   // rows a query may keep after the refinement
+constexpr int SPARSE_LREC_CAP = 1536;  // records a workgroup of the sparse coarse kernel buffers in LDS (12 KiB)
 constexpr float COARSE_OFFSET = 2.0f;   // accumulators start here: every coarse score is a
                                         // positive normal float, so uint order == float order
 constexpr float DEFAULT_WINDOW = 2.5e-3f;  // >= 2E, E = proven |coarse - exact| bound
@@ -214,6 +215,13 @@ struct CoarseArgs {
     int first_pad_chunk; // chunks >= this contain zero-padded map rows: excluded from qmax
     const float* row_bias;  // [padded map rows] added to the accumulator start of that row, or NULL
                             // (Euclidean search for d > 510: -|b~|^2 / 2; match_coarse_r_kernel only)
+    // sparse row-level records (match_coarse_pipe_kernel<., true>): every (query, map row) whose coarse score is
+    // within `window` of the query's running maximum at that time -- a superset of the rows within `window` of the
+    // final maximum, which is all the exact decision needs
+    unsigned* rec_cnt;   // [npad] records appended per query (may exceed rcap: overflow)
+    uint2* rec;          // [npad][rcap] (map row, score bits)
+    int rcap;
+    float window;
 };
 
 // XCD-aware unit mapping shared by the coarse kernels: workgroup b runs on XCD b % 8 (observed, speed
@@ -435,7 +443,15 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
 // Ring of 6 tiles: step i computes on (i, i+1), prefetches from (i+2, i+3), DMA fills (i+4, i+5)
 // = the slots of (i-2, i-1), whose last read retired before the barrier of step i.
 // ---------------------------------------------------------------------------------------------
-template <int KSTEPS>
+//
+// SPARSE = true (inner-product search, the default): instead of one top-2 record per (query, 128-row chunk) -- 253 MB
+// at C2, swept again by match_select_kernel, and ambiguous whenever two rows of a chunk are both inside the window --
+// the epilogue keeps ONE running maximum per lane (1 VALU op per accumulator element instead of 3) and, once per step,
+// tests the step's maximum against `running maximum - window`; only then (rare: a lane's query meets a near-best row)
+// are the 32 accumulators of the previous step compared one by one and the hits appended to the query's record list
+// (atomic slot counter).  The running maximum starts from the maxima earlier workgroups published for the query
+// (a.qmax), so only the first units of a query see the record-breaking phase of a fresh maximum.
+template <int KSTEPS, bool SPARSE>
 __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVES = 8;
@@ -479,8 +495,63 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
     const uint4* gnext = gsrc + (size_t)4 * TILE_U4;  // next tile to stage
 
     unsigned s1 = 0u, s2 = 0u, runmax = 0u;
-    auto fold_tail = [&](int it) { coarse_emit_chunk(a, s1, s2, runmax, qt, it >= 0 ? c0 + (it >> 2) : -1); };
-    auto fold_one = [&](float v, int code) { coarse_fold(s1, s2, v, code); };
+    constexpr int LREC_CAP = SPARSE_LREC_CAP;
+    uint2* lrec = reinterpret_cast<uint2*>(smem + NBUF * TILE_BYTES);        // [LREC_CAP] (query in block << 24 | row, score bits)
+    unsigned* lrec_count = reinterpret_cast<unsigned*>(lrec + LREC_CAP);
+    if constexpr (SPARSE) {
+        if (qt < a.nq_tiles) runmax = a.qmax[(size_t)qt * 32 + (lane & 31)];  // published by earlier units (any stale value is valid)
+        if (threadIdx.x == 0) *lrec_count = 0u;  // visible after the first barrier below
+    }
+    auto fold_tail = [&](int it) {
+        if constexpr (!SPARSE) coarse_emit_chunk(a, s1, s2, runmax, qt, it >= 0 ? c0 + (it >> 2) : -1);
+    };
+    auto fold_one = [&](float v, int code) {
+        if constexpr (SPARSE) s1 = max(s1, __float_as_uint(v));  // s1 = maximum of the step being folded
+        else coarse_fold(s1, s2, v, code);
+    };
+    // SPARSE: end of the fold of tiles (t0, t0 + 1) of this unit, whose accumulators are still in p0 / p1
+    auto step_tail = [&](int t0, const floatx16& p0, const floatx16& p1) __attribute__((always_inline)) {
+        const long long row0 = ((long long)c0 * 4 + t0) * TILE_ROWS;
+        const int half4 = 4 * (lane >> 5);
+        if (row0 + 2 * TILE_ROWS > a.m_valid) {  // wave-uniform, last tiles of the map only: zero-padded rows score exactly
+            s1 = 0u;                                // 2.0 and must neither raise the maximum nor be recorded
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long ra = row0 + (r & 3) + 8 * (r >> 2) + half4;
+                if (ra < a.m_valid) s1 = max(s1, __float_as_uint(p0[r]));
+                if (ra + TILE_ROWS < a.m_valid) s1 = max(s1, __float_as_uint(p1[r]));
+            }
+        }
+        runmax = max(runmax, s1);
+        {   // the other half-wave folds the other 16 rows per tile: v_permlane32_swap (VALU; a ds_bpermute would make the
+            // wave wait on lgkmcnt(0), i.e. on the fragment prefetches of the next step)
+            const auto sw = __builtin_amdgcn_permlane32_swap(runmax, runmax, false, false);
+            runmax = max((unsigned)sw[0], (unsigned)sw[1]);
+        }
+        const unsigned thr = __float_as_uint(__uint_as_float(runmax) - a.window);
+        if (s1 >= thr && qt < a.nq_tiles) {  // rare
+            // Hits go to a workgroup buffer in LDS (slot from an LDS atomic: waits on lgkmcnt only).  A returning
+            // GLOBAL atomic here would make the wave wait on vmcnt(0), i.e. on every LDS-DMA tile in flight: measured
+            // +9 % kernel time.  The buffer is flushed to the per-query lists after the last step.
+            const unsigned ql = (unsigned)(wave * 32 + (lane & 31));
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const unsigned x = __float_as_uint(r < 16 ? p0[r & 15] : p1[r & 15]);
+                const long long row = row0 + (r >> 4) * TILE_ROWS + (r & 3) + 8 * ((r & 15) >> 2) + half4;
+                if (x >= thr && row < a.m_valid) {
+                    const unsigned slot = atomicAdd(lrec_count, 1u);
+                    if (slot < (unsigned)LREC_CAP) {
+                        lrec[slot] = make_uint2((ql << 24) | (unsigned)row, x);
+                    } else {  // buffer full (a fresh maximum meeting a duplicate-rich map): straight to the list
+                        const size_t qi = (size_t)qt * 32 + (lane & 31);
+                        const unsigned gs = atomicAdd(a.rec_cnt + qi, 1u);
+                        if (gs < (unsigned)a.rcap) a.rec[qi * (size_t)a.rcap + gs] = make_uint2((unsigned)row, x);
+                    }
+                }
+            }
+        }
+        s1 = 0u;
+    };
 
     floatx16 prev0, prev1;
 #pragma unroll
@@ -544,7 +615,12 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (H == 0) fold_tail(it - 1);
+        if constexpr (SPARSE) {
+            if (it >= 2) step_tail(it - 2, prev0, prev1);
+            else s1 = 0u;
+        } else {
+            if constexpr (H == 0) fold_tail(it - 1);
+        }
         prev0 = acc0;
         prev1 = acc1;
         ring = ring2;
@@ -556,8 +632,19 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
     }
 #pragma unroll
     for (int e = 0; e < 32; ++e) fold_one(e < 16 ? prev0[e & 15] : prev1[e & 15], (2 + (e >> 4)) * 16 + (e & 15));
-    fold_tail(ntiles - 1);
+    if constexpr (SPARSE) step_tail(ntiles - 2, prev0, prev1);
+    else fold_tail(ntiles - 1);
     if (lane < 32 && qt < a.nq_tiles) atomicMax(a.qmax + (size_t)qt * 32 + lane, runmax);
+    if constexpr (SPARSE) {  // flush the workgroup's records to the per-query lists (no DMA in flight any more)
+        __syncthreads();
+        const unsigned cnt = min(*lrec_count, (unsigned)LREC_CAP);
+        for (unsigned i = threadIdx.x; i < cnt; i += 512) {
+            const uint2 r = lrec[i];
+            const size_t qi = (size_t)qb * QBLOCK + (r.x >> 24);
+            const unsigned gs = atomicAdd(a.rec_cnt + qi, 1u);
+            if (gs < (unsigned)a.rcap) a.rec[qi * (size_t)a.rcap + gs] = make_uint2(r.x & 0xFFFFFFu, r.y);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -745,7 +832,7 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
                                                            const float* __restrict__ invq, float window,
                                                            int* __restrict__ cand_cnt,
                                                            unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count,
-                                                           int* __restrict__ fb_list) {
+                                                           int* __restrict__ fb_list, int stats) {
     __shared__ int lcnt[64];
     const int qq = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * 64 + qq;
@@ -782,7 +869,7 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
     if (g == 0 && q < n) {
         const int cnt = lcnt[qq];
         // statistics (vfm_debug_match_stats): [2] candidate entries, [8 + b] queries with 2^(b-1) < entries <= 2^b
-        if (invq[q] != 0.0f) {
+        if (stats && invq[q] != 0.0f) {
             atomicAdd(fb_count + 2, cnt);
             int bin = 0;
             while ((1 << bin) < cnt && bin < 15) ++bin;
@@ -818,41 +905,40 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
 // inside the same margin, so the fp64 decision (ties -> lowest index) sees them all.  The surviving rows
 // replace the query's list as single-row entries: match_rescore_kernel is unchanged.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void match_refine_kernel(const float* __restrict__ q, const float* __restrict__ invq,
-                                                           const float* __restrict__ b, const float* __restrict__ invb,
-                                                           int64_t n, int64_t m, int d, float w2, int* __restrict__ cand_cnt,
-                                                           unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count,
-                                                           int* __restrict__ fb_list) {
-    __shared__ unsigned l_row[4][REFINE_KEEP];
-    __shared__ float l_sc[4][REFINE_KEEP];
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
-    if (qi >= n) return;
-    const int cnt = cand_cnt[qi];
-    if (cnt <= 0) return;  // zero query / nothing / overflow (-1: the all-pairs kernel decides)
-    unsigned* mycand = cand + (size_t)qi * cap;
-    // wave-uniform: is this list crowded?
-    bool flagged = false;
-    for (int e = lane; e < cnt; e += 64) flagged |= (mycand[e] & 128u) != 0u;
-    if (cnt < REFINE_MIN && !__any(flagged)) return;
-    const int g = lane >> 4, l = lane & 15;  // row slot of the pass, k-slice
-    const int nt = d >> 6;                   // float4 per lane (d % 64 == 0)
-    const float iq = invq[qi];
+// state of one wavefront refining one query: the fp32-normalised query in registers, the kept rows in LDS
+struct RefineWave {
+    const float* b;
+    const float* invb;
+    int d, nt, g, l, lane;
+    float w2;
     float4 qv[12];
+    unsigned* lrow;
+    float* lsc;
+    int kept;        // wave-uniform
+    float runmax;    // wave-uniform
+    bool overflow;
+
+    __device__ __forceinline__ void init(const float* q, float iq, int64_t qi, const float* b_, const float* invb_, int d_, float w2_,
+                                         unsigned* lrow_, float* lsc_) {
+        b = b_; invb = invb_; d = d_; w2 = w2_; lrow = lrow_; lsc = lsc_;
+        lane = lane_id();
+        g = lane >> 4;   // row slot of the pass
+        l = lane & 15;   // k-slice
+        nt = d >> 6;     // float4 per lane (d % 64 == 0)
+        kept = 0;
+        runmax = -3.0e38f;
+        overflow = false;
 #pragma unroll
-    for (int t = 0; t < 12; ++t) {
-        if (t < nt) {
-            float4 v = *reinterpret_cast<const float4*>(q + qi * (int64_t)d + 4 * (l + 16 * t));
-            v.x = v.x * iq; v.y = v.y * iq; v.z = v.z * iq; v.w = v.w * iq;  // the fp32-normalised query (faiss' xq)
-            qv[t] = v;
+        for (int t = 0; t < 12; ++t) {
+            if (t < nt) {
+                float4 v = *reinterpret_cast<const float4*>(q + qi * (int64_t)d + 4 * (l + 16 * t));
+                v.x = v.x * iq; v.y = v.y * iq; v.z = v.z * iq; v.w = v.w * iq;  // the fp32-normalised query (faiss' xq)
+                qv[t] = v;
+            }
         }
     }
-    unsigned* lrow = l_row[wave];
-    float* lsc = l_sc[wave];
-    int kept = 0;            // wave-uniform
-    float runmax = -3.0e38f;  // wave-uniform
-    bool overflow = false;
-    auto score4 = [&](long long row) -> float {  // rows of the 4 lane groups; row < 0: none
+    // fp32 score of this lane group's row (row < 0: none); identical in the 16 lanes of the group
+    __device__ __forceinline__ float score4(long long row) const {
         float acc = 0.0f;
         if (row >= 0) {
             const float ib = invb[row];
@@ -871,9 +957,9 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
         return acc;
-    };
-    auto consider = [&](long long row, float sc) {  // called by all lanes; (row, sc) of this lane's group
-        // new running maximum over the pass
+    }
+    // one pass: (row, sc) of the four lane groups; keeps the rows within w2 of the running fp32 maximum
+    __device__ __forceinline__ void consider(long long row, float sc) {
         float pm = (row >= 0) ? sc : -3.0e38f;
         pm = fmaxf(pm, __shfl_xor(pm, 16));
         pm = fmaxf(pm, __shfl_xor(pm, 32));
@@ -909,18 +995,61 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
             kept = REFINE_KEEP;
         }
         __builtin_amdgcn_wave_barrier();
-    };
+    }
+    // result: the kept rows become the query's single-row candidate list (or the query goes to the all-pairs kernel)
+    __device__ __forceinline__ void finish(int64_t qi, unsigned* mycand, int* cand_cnt, int* fb_count, int* fb_list, int stats) {
+        __builtin_amdgcn_wave_barrier();
+        if (overflow) {  // > REFINE_KEEP rows tie within the fp32 margin: the all-pairs kernel decides
+            if (lane == 0) {
+                cand_cnt[qi] = -1;
+                const int slot = atomicAdd(fb_count, 1);
+                fb_list[slot] = (int)qi;
+            }
+            return;
+        }
+        if (stats && lane == 0) {  // statistics: [1] queries refined, [3] rows they keep
+            atomicAdd(fb_count + 1, 1);
+            atomicAdd(fb_count + 3, kept);
+        }
+        if (lane < kept) {
+            const unsigned row = lrow[lane];
+            mycand[lane] = ((row / CHUNK_ROWS) << 8) | (row % CHUNK_ROWS);
+        }
+        if (lane == 0) cand_cnt[qi] = kept;
+    }
+};
+
+// dense records: the candidate entries of match_select_kernel
+__global__ __launch_bounds__(256) void match_refine_kernel(const float* __restrict__ q, const float* __restrict__ invq,
+                                                           const float* __restrict__ b, const float* __restrict__ invb,
+                                                           int64_t n, int64_t m, int d, float w2, int* __restrict__ cand_cnt,
+                                                           unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count,
+                                                           int* __restrict__ fb_list, int stats) {
+    __shared__ unsigned l_row[4][REFINE_KEEP];
+    __shared__ float l_sc[4][REFINE_KEEP];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+    if (qi >= n) return;
+    const int cnt = cand_cnt[qi];
+    if (cnt <= 0) return;  // zero query / nothing / overflow (-1: the all-pairs kernel decides)
+    unsigned* mycand = cand + (size_t)qi * cap;
+    // wave-uniform: is this list crowded?
+    bool flagged = false;
+    for (int e = lane; e < cnt; e += 64) flagged |= (mycand[e] & 128u) != 0u;
+    if (cnt < REFINE_MIN && !__any(flagged)) return;
+    RefineWave R;
+    R.init(q, invq[qi], qi, b, invb, d, w2, l_row[wave], l_sc[wave]);
     // single-row entries: 4 per pass
     for (int e0 = 0; e0 < cnt; e0 += 4) {
         long long row = -1;
-        if (e0 + g < cnt) {
-            const unsigned ce = mycand[e0 + g];
+        if (e0 + R.g < cnt) {
+            const unsigned ce = mycand[e0 + R.g];
             if (!(ce & 128u)) {
                 row = (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u);
                 if (row >= m) row = -1;
             }
         }
-        if (__any(row >= 0)) consider(row, score4(row));
+        if (__any(row >= 0)) R.consider(row, R.score4(row));
     }
     // whole-chunk entries: all 128 rows of the chunk
     for (int e = 0; e < cnt; ++e) {
@@ -928,13 +1057,41 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
         if (!(ce & 128u)) continue;
         const long long base = (long long)(ce >> 8) * CHUNK_ROWS;
         for (int r0 = 0; r0 < CHUNK_ROWS; r0 += 4) {
-            long long row = base + r0 + g;
+            long long row = base + r0 + R.g;
             if (row >= m) row = -1;
-            if (__any(row >= 0)) consider(row, score4(row));
+            if (__any(row >= 0)) R.consider(row, R.score4(row));
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    if (overflow) {  // > REFINE_KEEP rows tie within 4e-6: the all-pairs kernel decides
+    R.finish(qi, mycand, cand_cnt, fb_count, fb_list, stats);
+}
+
+// sparse records (match_coarse_pipe_kernel<., true>): filter the query's records against its FINAL coarse maximum, then
+// refine in fp32 if more than two rows remain.  Replaces match_select_kernel + match_refine_kernel; one wave per query.
+constexpr int FILTER_LDS_ROWS = 1024;  // >= rcap
+__global__ __launch_bounds__(256) void match_filter_refine_kernel(const float* __restrict__ q, const float* __restrict__ invq,
+                                                                  const float* __restrict__ b, const float* __restrict__ invb,
+                                                                  int64_t n, int64_t m, int d, float window, float w2,
+                                                                  const unsigned* __restrict__ qmax,
+                                                                  const unsigned* __restrict__ rec_cnt, const uint2* __restrict__ rec,
+                                                                  int rcap, int* __restrict__ cand_cnt, unsigned* __restrict__ cand,
+                                                                  int cap, int* __restrict__ fb_count, int* __restrict__ fb_list, int stats) {
+    __shared__ unsigned l_row[4][REFINE_KEEP];
+    __shared__ float l_sc[4][REFINE_KEEP];
+    __shared__ unsigned l_cand[4][FILTER_LDS_ROWS];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+    if (qi >= n) return;
+    unsigned* mycand = cand + (size_t)qi * cap;
+    const float iq = invq[qi];
+    if (iq == 0.0f) {  // zero query row: decided directly by match_rescore_kernel (index 0, score 0)
+        if (lane == 0) cand_cnt[qi] = 0;
+        return;
+    }
+    const unsigned total = rec_cnt[qi];
+    if (stats && lane == 0) {  // statistics: [4] records written by the coarse pass
+        atomicAdd(fb_count + 4, (int)total);
+    }
+    if (total > (unsigned)rcap || m <= 0) {  // record overflow: the all-pairs kernel decides
         if (lane == 0) {
             cand_cnt[qi] = -1;
             const int slot = atomicAdd(fb_count, 1);
@@ -942,15 +1099,41 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
         }
         return;
     }
-    if (lane == 0) {  // statistics: [1] queries refined, [3] rows they keep
-        atomicAdd(fb_count + 1, 1);
-        atomicAdd(fb_count + 3, kept);
+    const unsigned thr = __float_as_uint(__uint_as_float(qmax[qi]) - window);
+    const uint2* myrec = rec + (size_t)qi * rcap;
+    unsigned* lc = l_cand[wave];
+    int ncand = 0;  // wave-uniform
+    for (unsigned e0 = 0; e0 < total; e0 += 64) {
+        const unsigned e = e0 + lane;
+        uint2 r = make_uint2(0u, 0u);
+        if (e < total) r = myrec[e];
+        const bool in = e < total && r.y >= thr;
+        const unsigned long long bal = __ballot(in);
+        if (in) lc[ncand + __popcll(bal & ((1ull << lane) - 1ull))] = r.x;
+        ncand += __popcll(bal);
     }
-    if (lane < kept) {
-        const unsigned row = lrow[lane];
-        mycand[lane] = ((row / CHUNK_ROWS) << 8) | (row % CHUNK_ROWS);
+    __builtin_amdgcn_wave_barrier();
+    if (stats && lane == 0) {  // statistics: [2] candidate rows, [8 + b] queries with 2^(b-1) < rows <= 2^b
+        atomicAdd(fb_count + 2, ncand);
+        int bin = 0;
+        while ((1 << bin) < ncand && bin < 15) ++bin;
+        atomicAdd(fb_count + 8 + bin, 1);
     }
-    if (lane == 0) cand_cnt[qi] = kept;
+    if (ncand < REFINE_MIN) {
+        if (lane < ncand) {
+            const unsigned row = lc[lane];
+            mycand[lane] = ((row / CHUNK_ROWS) << 8) | (row % CHUNK_ROWS);
+        }
+        if (lane == 0) cand_cnt[qi] = ncand;
+        return;
+    }
+    RefineWave R;
+    R.init(q, iq, qi, b, invb, d, w2, l_row[wave], l_sc[wave]);
+    for (int e0 = 0; e0 < ncand; e0 += 4) {
+        const long long row = (e0 + R.g < ncand) ? (long long)lc[e0 + R.g] : -1;
+        R.consider(row, R.score4(row));
+    }
+    R.finish(qi, mycand, cand_cnt, fb_count, fb_list, stats);
 }
 
 // exact score of normalised rows, sequential k, fp64 (products of two fp32 are exact in fp64)
@@ -1500,6 +1683,9 @@ struct SearchWs {
     int* cand_cnt;
     unsigned* cand;
     int cap;  // entries per query in `cand`
+    unsigned* rec_cnt;  // sparse records of the coarse pass (see CoarseArgs)
+    uint2* rec;
+    int rcap;
     int* fb_count;
     int* fb_list;
     unsigned* qmax;
@@ -1517,6 +1703,9 @@ inline SearchWs carve_search(void* p, int64_t n, int64_t m) {
     w.fb_count = c.take<int>(64);
     w.fb_list = c.take<int>((size_t)npad);
     w.qmax = c.take<unsigned>((size_t)npad);
+    w.rcap = FILTER_LDS_ROWS;
+    w.rec_cnt = c.take<unsigned>((size_t)npad);
+    w.rec = c.take<uint2>((size_t)npad * (size_t)w.rcap);
     w.bytes = c.used();
     return w;
 }
@@ -1553,20 +1742,28 @@ thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 // 0 = default (pipelined kernel for d <= 384); 1 = match_coarse_kernel<.,1>; 2 = match_coarse_kernel<.,2>;
 // set through vfm_debug_set_coarse_variant for A/B runs
 int g_coarse_qsets = 0;
+float g_window_override = 0.0f;  // vfm_debug_set_coarse_window: timing experiments only (results are wrong)
+int g_match_stats = 0;  // vfm_debug_set_match_stats: per-query counters cost ~0.5 ms of same-address atomics per search
+// 4 = pipelined kernel with the DENSE per-chunk records + match_select_kernel (round-1 path; A/B reference)
+
+// inner-product searches with d <= 384 use the sparse row-level records of match_coarse_pipe_kernel<., true>
+inline bool use_sparse(int d, int64_t m) {
+    return d <= 384 && d % 128 == 0 && m < (1ll << 24) && (g_coarse_qsets == 0 || g_coarse_qsets == 3);
+}
 
 // queries per workgroup of the coarse kernel that do_search_coarse will launch
 int coarse_qblock(int d) { return d > 512 ? 128 : QBLOCK; }
 
-template <int KSTEPS>
+template <int KSTEPS, bool SPARSE>
 int launch_coarse_pipe(const CoarseArgs& a, hipStream_t st) {
-    const int lds = 6 * KSTEPS * 1024;
+    const int lds = 6 * KSTEPS * 1024 + (SPARSE ? SPARSE_LREC_CAP * 8 + 16 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_pipe_kernel<KSTEPS>),
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_pipe_kernel<KSTEPS, SPARSE>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((match_coarse_pipe_kernel<KSTEPS>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((match_coarse_pipe_kernel<KSTEPS, SPARSE>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
     return VFM_OK;
 }
 
@@ -1607,7 +1804,7 @@ int launch_coarse(const CoarseArgs& a, hipStream_t st) {
     if constexpr (KSTEPS <= 24) {
         rc = (g_coarse_qsets == 2)   ? launch_coarse_v<KSTEPS, 2>(a, st)
              : (g_coarse_qsets == 1) ? launch_coarse_v<KSTEPS, 1>(a, st)
-                                     : launch_coarse_pipe<KSTEPS>(a, st);  // 0, 3
+                                     : (a.rec ? launch_coarse_pipe<KSTEPS, true>(a, st) : launch_coarse_pipe<KSTEPS, false>(a, st));  // 0, 3
     } else {
         rc = launch_coarse_v<KSTEPS, 1>(a, st);  // d = 512: 2 x 128 query VGPRs would not fit
     }
@@ -1642,12 +1839,16 @@ CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, 
     a.qmax = w.qmax;
     a.first_pad_chunk = (int)(m / CHUNK_ROWS);
     a.row_bias = nullptr;
+    a.rec_cnt = nullptr;
+    a.rec = nullptr;
+    a.rcap = 0;
+    a.window = g_window_override != 0.0f ? g_window_override : DEFAULT_WINDOW;
     return a;
 }
 
 // stage 1 of a search: the MFMA coarse pass (fills ws: partials + per-query coarse maxima)
 int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, hipStream_t st,
-                     bool bias_from_map_inv = false) {
+                     bool bias_from_map_inv = false, bool inner_product = false) {
     Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
     Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
     SearchWs w = carve_search(ws, n, m);
@@ -1655,6 +1856,12 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
     if (bias_from_map_inv) {  // Euclidean search, d > 510: the map's "inv" array holds -|b~|^2 / 2
         if (d != 640 && d != 768) return vfm_fail(VFM_EINVAL, "row bias needs the 4-wave coarse kernel (K = 640 / 768), got %d", d);
         a.row_bias = B.inv;
+    }
+    if (inner_product && use_sparse(d, m)) {
+        a.rec_cnt = w.rec_cnt;
+        a.rec = w.rec;
+        a.rcap = w.rcap;
+        VFM_CHECK_HIP(hipMemsetAsync(w.rec_cnt, 0, (size_t)a.npad * sizeof(unsigned), st));
     }
     VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, 64 * sizeof(int), st));
     VFM_CHECK_HIP(hipMemsetAsync(w.qmax, 0, (size_t)a.npad * sizeof(unsigned), st));
@@ -1678,13 +1885,17 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
     SearchWs w = carve_search(ws, n, m);
     const CoarseArgs a = coarse_args(Q, B, w, n, m, coarse_qblock(d));
-    hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS), 0, st, w.partials, a.nchunks,
-                       a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list);
-    VFM_CHECK_LAUNCH("match_select_kernel");
-    {
-        const float w2 = 2.0f * (float)(d / 16 + 4 + 2) * 5.9604645e-8f;
+    const float w2 = 2.0f * (float)(d / 16 + 4 + 2) * 5.9604645e-8f;
+    if (use_sparse(d, m)) {
+        hipLaunchKernelGGL(match_filter_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d,
+                           DEFAULT_WINDOW, w2, w.qmax, w.rec_cnt, w.rec, w.rcap, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
+        VFM_CHECK_LAUNCH("match_filter_refine_kernel");
+    } else {
+        hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS), 0, st, w.partials, a.nchunks,
+                           a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
+        VFM_CHECK_LAUNCH("match_select_kernel");
         hipLaunchKernelGGL(match_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2,
-                           w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list);
+                           w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
         VFM_CHECK_LAUNCH("match_refine_kernel");
     }
     {
@@ -1707,7 +1918,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
 
 int do_search(const float* q, const void* qprep, int64_t n, const float* b, const void* bprep, int64_t m, int d,
               int64_t* idx_out, float* sim_out, void* ws, hipStream_t st) {
-    const int rc = do_search_coarse(qprep, n, bprep, m, d, ws, st);
+    const int rc = do_search_coarse(qprep, n, bprep, m, d, ws, st, false, true);
     if (rc) return rc;
     return do_search_finish(q, qprep, n, b, bprep, m, d, idx_out, sim_out, ws, st);
 }
@@ -1764,7 +1975,7 @@ VFM_EXPORT int vfm_match_search_coarse(const void* q_prepared, int64_t n, const 
                                        void* ws, size_t ws_bytes, vfm_stream_t stream) {
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q_prepared && b_prepared && ws, "search_coarse: null pointer");
-    return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream);
+    return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream, false, true);
 }
 
 VFM_EXPORT int vfm_match_search_finish(const float* q, const void* q_prepared, int64_t n, const float* b,
@@ -1888,7 +2099,7 @@ int l2_search(const float* q, void* qprep, int64_t n, const float* b, void* bpre
     SearchWs w = carve_search(ws, n, m);
     const CoarseArgs a = coarse_args(Q, carve_prepared(bprep, m, kp), w, n, m, coarse_qblock(kp));
     hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS), 0, st, w.partials, a.nchunks,
-                       a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list);
+                       a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
     VFM_CHECK_LAUNCH("match_select_kernel");
     hipLaunchKernelGGL(l2_rescore_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)d * 4 * 8, st, q, b, n, m, d, w.cand_cnt,
                        w.cand, w.cap, nn, d2);
@@ -1956,6 +2167,16 @@ VFM_EXPORT int vfm_debug_match_stats(void* ws, int64_t n, int64_t m, int32_t* ou
     SearchWs w = carve_search(ws, n, m);
     VFM_CHECK_HIP(hipDeviceSynchronize());
     VFM_CHECK_HIP(hipMemcpy(out64_host, w.fb_count, 64 * sizeof(int), hipMemcpyDeviceToHost));
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_debug_set_coarse_window(float w) {
+    g_window_override = w;
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_debug_set_match_stats(int on) {
+    g_match_stats = on;
     return VFM_OK;
 }
 
