@@ -596,3 +596,78 @@ def register_frame(points: np.ndarray, map_points: np.ndarray, voxel_size: float
             break
     T = T_icp @ T0
     return (T, hist) if return_history else T
+
+
+# ----------------------------------------------------------------------------- F4 evaluation harness
+def build_local_map(map_poses, map_point_clouds, voxel_size: float = .25, n_descriptors: int = 384) -> np.ndarray:
+    """RN:556-580: rows with descriptor sum <= 0 dropped, every cloud voxelised (container order), moved into the map
+    frame, concatenated as float32, voxelised again (in two halves about the mean x above 1e6 rows)."""
+    local = []
+    for pose, pcl in zip(map_poses, map_point_clouds):
+        pcl = pcl[np.sum(pcl[:, 3:], axis=1) > 0]
+        pcl = voxel_down_sample(pcl, voxel_size).astype(pcl.dtype)
+        local.append(transform_pcl(pcl, pose))
+    m = np.concatenate(local, axis=0).astype(np.float32)
+    if m.shape[0] > 1000000:
+        mean_3d = np.mean(m[:, :3], axis=0)
+        a = voxel_down_sample(m[m[:, 0] > mean_3d[0]], voxel_size).astype(m.dtype)
+        b = voxel_down_sample(m[m[:, 0] <= mean_3d[0]], voxel_size).astype(m.dtype)
+        m = np.concatenate([a, b], axis=0)
+    else:
+        m = voxel_down_sample(m, voxel_size).astype(m.dtype)
+    return m[:, :3 + n_descriptors]
+
+
+def ransac_registration_vfm(voxel_map: np.ndarray, raw_scan: np.ndarray, n_iter: int = 50000, seed: int = 42,
+                            run_icp: bool = False, voxel_size: float = 1.0, max_points_per_voxel: int = 20,
+                            sigma: float = 2.0, min_cosine: float = 0.8):
+    """RegistrationNode.ransac_registration(voxel_map, raw_scan, 'vfm', run_icp) (RN:273-357 + 396-425) assembled
+    from the oracle's pieces; returns (ransac_pose, icp_pose | None, correspondences)."""
+    scan = voxel_down_sample(voxel_down_sample(raw_scan, voxel_size * 0.5), voxel_size * 1.0)     # RN:399-400
+    mp = np.asarray(voxel_map, dtype=np.float64)[voxel_hash_map_points(voxel_map, voxel_size, max_points_per_voxel)]
+    pcl = transform_pcl(scan, np.eye(4))                                                            # RN:408
+    sub = voxel_down_sample(pcl, 5.0)                                                               # RN:414
+    _, _, qi, mi, _ = get_vfm_correspondences(sub, mp, min_cosine)
+    if len(qi) < 75:                                                                                # RN:420-423
+        sub = voxel_down_sample(pcl, 1.0)
+        _, _, qi, mi, _ = get_vfm_correspondences(sub, mp, min_cosine)
+    # RN:288-309: rows of the correspondences inside the re-voxelised clouds (exact coordinates)
+    key = lambda a: (np.ascontiguousarray(a, dtype=np.float64) + 0.0).view(np.dtype((np.void, 24))).reshape(-1)
+    order = np.argsort(key(scan[:, :3]), kind="stable")
+    pos = np.searchsorted(key(scan[:, :3])[order], key(sub[qi, :3]))
+    src_rows = order[pos]
+    corres = np.stack([src_rows, mi], 1).astype(np.int32)
+    res = ransac_corr(scan[:, :3], mp[:, :3], corres, 10000.0, n_iter, seed=seed)
+    pose = res.transformation
+    if not run_icp:
+        return pose, None, corres
+    guess = orthogonalize_rotation(pose)                                                            # RN:331-336
+    icp = register_frame(scan[:, :3], mp[:, :3], voxel_size, guess, 3 * sigma, sigma / 3)           # RN:338-344
+    return guess, icp, corres
+
+
+def success_rate(trans_errors, rot_errors, translation_threshold, rotation_threshold) -> float:
+    """RN:1021-1025 / print_errors.py:8-13."""
+    return float(np.mean((np.array(trans_errors) < translation_threshold) & (np.array(rot_errors) < rotation_threshold)))
+
+
+def evaluate_scene(scene: dict, n_iter: int = 50000, run_icp: bool = True, n_descriptors: Optional[int] = None):
+    """The VFM + RANSAC (+ ICP) branch of make_step for one scene (RN:556-593, 858-882, 943-951)."""
+    n_desc = n_descriptors or scene["map_point_clouds"][0].shape[1] - 3
+    local_map = build_local_map(scene["map_poses"], scene["map_point_clouds"], n_descriptors=n_desc)
+    rot, trans, poses = {}, {}, []
+    for gt_pose, cloud in zip(scene["scene_poses"], scene["scene_point_clouds"]):
+        cloud = voxel_down_sample(cloud, .1).astype(cloud.dtype)                                    # RN:593
+        cloud = transform_pcl(cloud, np.eye(4))                                                     # RN:863
+        p0, p1, _ = ransac_registration_vfm(local_map, cloud, n_iter=n_iter, run_icp=run_icp)
+        for k, v in (("vfm_ransac", p0), ("vfm_ransac_icp", p1)):
+            if v is None:
+                continue
+            # RN:997-1011 literally (called as compute_errors(gt_pose, v, k) at RN:947)
+            R, R_gt = np.asarray(gt_pose)[:3, :3], (v @ np.eye(4))[:3, :3]
+            rre = float(np.rad2deg(abs(np.arccos(min(max(((R.T @ R_gt).trace() - 1) / 2, -1.0), 1.0)))))
+            rte = float(np.linalg.norm(np.asarray(gt_pose)[:3, 3] - (v @ np.eye(4))[:3, 3]))
+            trans.setdefault(k, []).append(rte)
+            rot.setdefault(k, []).append(rre)
+        poses.append((p0, p1))
+    return dict(local_map=local_map, rot_errors=rot, trans_errors=trans, poses=poses)

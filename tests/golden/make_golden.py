@@ -12,6 +12,7 @@ Importable reference callables:
   prepare_scenes.create_descriptors                         -> lift_oxf.npz, lift_nclt.npz
   vfm_reg.utils.transform_pcl                               -> transform_pcl.npz
   pointdsc.common.rigid_transform_3d                        -> kabsch_dsc.npz
+  print_errors.compute_success_rate / print_errors.main     -> print_errors.npz (recall + the paper-table rows)
 
 Libraries the reference imports at module level but that are absent here are replaced by
 ``MagicMock`` (they are never touched by the functions above) with one exception:
@@ -270,6 +271,39 @@ def gen_kabsch(rng):
     print("kabsch ok; planted-vs-recovered max err", np.abs(T_unw - Ts).max())
 
 
+def gen_print_errors():
+    """print_errors.py:8-36 + the rows main() writes (print_errors.py:38-56).  main() writes `error.txt` next to the script
+    (inside the read-only reference tree): the write is redirected to a temporary file, nothing else is changed."""
+    import builtins
+    import pickle
+    import tempfile
+    import print_errors as PE
+    rng = np.random.default_rng(77)
+    methods = ["fpfh_ransac", "fpfh_ransac_icp", "vfm_ransac", "vfm_ransac_icp", "vfm_teaser", "vfm_teaser_icp", "icp"]
+    rot = {m: np.abs(rng.standard_cauchy(23)) * (0.4 if "vfm" in m else 3.0) for m in methods}
+    trans = {m: np.abs(rng.standard_cauchy(23)) * (0.2 if "vfm" in m else 1.5) for m in methods}
+    thresholds = [(.3, 15), (.6, 1.5), (2, 5)]
+    rates = np.array([[PE.compute_success_rate(trans[m], rot[m], *t) for t in thresholds] for m in methods])
+    with tempfile.TemporaryDirectory() as td:
+        src = Path(td) / "errors.pkl"
+        with open(src, "wb") as f:
+            pickle.dump({"rot": {k: list(v) for k, v in rot.items()}, "trans": {k: list(v) for k, v in trans.items()}}, f)
+        real_open = builtins.open
+        out = Path(td) / "error.txt"
+
+        def redirected(file, *a, **k):
+            return real_open(out if str(file).endswith("error.txt") else file, *a, **k)
+        builtins.open = redirected
+        try:
+            PE.main(src)
+        finally:
+            builtins.open = real_open
+        text = out.read_text()
+    np.savez(OUT / "print_errors.npz", methods=np.array(methods), rot=np.stack([rot[m] for m in methods]),
+             trans=np.stack([trans[m] for m in methods]), thresholds=np.array(thresholds), rates=rates, error_txt=np.array(text))
+    print("print_errors.npz", rates.shape, len(text))
+
+
 def main():
     _install_stubs()
     rng = np.random.default_rng(20250620)
@@ -280,6 +314,7 @@ def main():
     gen_lift_nclt(rng)
     gen_transform_pcl(rng)
     gen_kabsch(rng)
+    gen_print_errors()
 
 
 if __name__ == "__main__":

@@ -287,7 +287,7 @@ def test_evaluation_harness_on_a_synthetic_scene(tmp_path):
         noisy = desc[sel] + 0.05 * np.abs(rng.standard_normal((len(sel), d))).astype(np.float32)
         scan_poses.append(T)
         scan_clouds.append(np.c_[local, noisy].astype(np.float32))
-    f = tmp_path / "scene_000.npz"
+    f = tmp_path / "scene_000.h5"
     save_scene(f, ["mapseq", "scanA", "scanB"], map_poses, map_clouds, scan_poses, scan_clouds)
     scene = read_scenes(f)
     assert len(scene["map_poses"]) == 3 and scene["scene_sequences"] == ["scanA", "scanB"]
@@ -297,3 +297,13 @@ def test_evaluation_harness_on_a_synthetic_scene(tmp_path):
     assert ev.compute_success_rate("vfm_ransac_icp", .6, 1.5) == 1.0
     assert max(ev.trans_errors["vfm_ransac_icp"]) < 0.1
     assert "vfm_ransac_icp" in ev.summary()
+    # ---- parity with the oracle's restatement of the same harness (RN:556-593, 858-882, 943-951, 997-1025):
+    # the accumulated map (two voxelisation levels in CONTAINER order, fp32 round trips), every pose, every error
+    from oracle import oracle as orc
+    from vfmreg.evaluation import build_local_map
+    ref = orc.evaluate_scene(scene, n_iter=4000)
+    np.testing.assert_array_equal(build_local_map(scene["map_poses"], scene["map_point_clouds"], n_descriptors=d), ref["local_map"])
+    assert ev.points_in_map == [len(ref["local_map"])] * 2
+    for k in ("vfm_ransac", "vfm_ransac_icp"):
+        assert ev.rot_errors[k] == ref["rot_errors"][k] and ev.trans_errors[k] == ref["trans_errors"][k], k
+    assert ev.error_string().startswith("vfm_ransac\t")

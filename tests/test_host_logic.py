@@ -20,3 +20,23 @@ def test_synth_pair_statistics():
     assert 0.85 < cos.mean() < 0.95 and 0.4 < inl.mean() < 0.6
     back = p["q_xyz"][inl] @ p["T_gt"][:3, :3].T + p["T_gt"][:3, 3]
     assert np.abs(back - p["b_xyz"][p["match"][inl]]).max() < 0.15
+
+
+def test_error_table_matches_reference_print_errors(golden):
+    """Row F4: recall (registration_node.py:1021-1025 == print_errors.py:8-13) and the paper-table rows of
+    print_errors.main (print_errors.py:27-56) against OUTPUTS OF THE REFERENCE's print_errors.py
+    (tests/golden/make_golden.py::gen_print_errors)."""
+    import numpy as np
+    from oracle import oracle as orc
+    from vfmreg.evaluation import Evaluation
+    g = golden("print_errors.npz")
+    ev = Evaluation()
+    for m, rot, trans in zip(g["methods"], g["rot"], g["trans"]):
+        ev.rot_errors[str(m)] = list(rot)
+        ev.trans_errors[str(m)] = list(trans)
+    for i, m in enumerate(g["methods"]):
+        for j, (t, r) in enumerate(g["thresholds"]):
+            assert ev.compute_success_rate(str(m), t, r) == g["rates"][i, j]
+            assert orc.success_rate(g["trans"][i], g["rot"][i], t, r) == g["rates"][i, j]
+    assert ev.error_string() == str(g["error_txt"])
+    assert "vfm_ransac_icp" in ev.summary()

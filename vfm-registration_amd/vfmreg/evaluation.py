@@ -4,10 +4,11 @@ bookkeeping of ``RegistrationNode.make_step`` (registration_node.py:548-989), ``
 orchestration (as in the reference); the heavy steps it calls (voxel_down_sample, transform_pcl,
 ransac_registration, register_frame) run on the GPU.
 
-Scenes: the reference stores processed scenes as HDF5 (prepare_scenes.py:16-47, read_h5.py:17-49);
-h5py is not available in this environment, so ``save_scene`` / ``read_scenes`` keep the same logical
-layout (``map/<seq>/pose/<jjj>``, ``map/<seq>/point_cloud/<jjj>``, ``scans/<seq>/{pose,point_cloud}``,
-rows = [x, y, z, d0..dC-1] fp32) in a ``.npz`` container (row F3 stand-in, documented in DESIGN.md).
+Scenes (row F3): the reference stores processed scenes as HDF5 (prepare_scenes.py:16-47, read_h5.py:17-49):
+``/map/<seq>/pose/<jjj>`` f64[4,4], ``/map/<seq>/point_cloud/<jjj>`` f32[n, 3+C], ``/scans/<seq>/{pose, point_cloud}``,
+rows = [x, y, z, d0..dC-1].  ``save_scene`` / ``read_scenes`` write and read that file format itself (``vfmreg.h5lite``:
+h5py is not installed; the subset of HDF5 those h5py calls produce, verified against libhdf5's own tools and files);
+a path ending in ``.npz`` selects a numpy container with the same key paths instead (cache format of round 1).
 """
 from __future__ import annotations
 
@@ -16,6 +17,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
+from . import h5lite
 from .registration import RegistrationNode
 from .utils import transform_pcl
 from .voxelization import voxel_down_sample
@@ -24,7 +26,7 @@ SUCCESS_THRESHOLDS = [(.3, 15), (.6, 1.5), (2, 5)]  # (RTE m, RRE deg): PointDSC
 
 
 def save_scene(filename, sequences: List[str], map_poses, map_point_clouds, seq_poses, seq_point_clouds) -> None:
-    """prepare_scenes.save_scene (PS:16-47) with the HDF5 group paths as npz keys."""
+    """prepare_scenes.save_scene (PS:16-47): the same groups and datasets, as an HDF5 file."""
     filename = Path(filename)
     filename.parent.mkdir(parents=True, exist_ok=True)
     data = {}
@@ -36,23 +38,50 @@ def save_scene(filename, sequences: List[str], map_poses, map_point_clouds, seq_
             continue
         data[f"scans/{sequences[j + 1]}/pose"] = np.asarray(seq_poses[j])
         data[f"scans/{sequences[j + 1]}/point_cloud"] = np.asarray(seq_point_clouds[j])
-    np.savez(filename, **data)
+    if filename.suffix == ".npz":
+        np.savez(filename, **data)
+        return
+    tree: dict = {"map": {sequences[0]: {"pose": {}, "point_cloud": {}}}, "scans": {}}   # PS:30-38: groups exist even when empty
+    for key, arr in data.items():
+        node = tree
+        parts = key.split("/")
+        for part in parts[:-1]:
+            node = node.setdefault(part, {})
+        node[parts[-1]] = arr
+    h5lite.write_h5(filename, tree)
 
 
 def read_scenes(filename) -> Dict[str, list]:
-    """read_h5.read_scenes (read_h5.py:17-49): dict(map_poses, map_point_clouds, scene_poses,
-    scene_point_clouds, scene_sequences)."""
-    z = np.load(filename)
-    keys = sorted(z.files)
-    map_ids = sorted({k.split("/")[3] for k in keys if k.startswith("map/") and "/pose/" in k})
-    seq0 = next(k.split("/")[1] for k in keys if k.startswith("map/"))
-    scans = sorted({k.split("/")[1] for k in keys if k.startswith("scans/")})
+    """read_h5.read_scenes (read_h5.py:17-49): dict(map_poses, map_point_clouds, map_clip, scene_poses,
+    scene_point_clouds) + scene_sequences (the scan group names, in the order the arrays are listed)."""
+    filename = Path(filename)
+    if filename.suffix == ".npz":
+        z = np.load(filename)
+        tree: dict = {}
+        for key in sorted(z.files):
+            node = tree
+            parts = key.split("/")
+            for part in parts[:-1]:
+                node = node.setdefault(part, {})
+            node[parts[-1]] = z[key]
+    else:
+        tree = h5lite.read_h5(filename)
+    map_poses, map_point_clouds, map_clip = [], [], []
+    for key in tree["map"]:  # there should be only one key corresponding to the sequence name (read_h5.py:22-24)
+        g = tree["map"][key]
+        for pose, cloud in zip(g["pose"].values(), g["point_cloud"].values()):
+            map_poses.append(pose)
+            map_point_clouds.append(cloud)
+        if "clip" in g:
+            map_clip.extend(g["clip"].values())
+    scans = tree.get("scans", {})
     return {
-        "map_poses": [z[f"map/{seq0}/pose/{j}"] for j in map_ids],
-        "map_point_clouds": [z[f"map/{seq0}/point_cloud/{j}"] for j in map_ids],
-        "scene_poses": [z[f"scans/{s}/pose"] for s in scans],
-        "scene_point_clouds": [z[f"scans/{s}/point_cloud"] for s in scans],
-        "scene_sequences": scans,
+        "map_poses": map_poses,
+        "map_point_clouds": map_point_clouds,
+        "map_clip": map_clip,
+        "scene_poses": [scans[s]["pose"] for s in scans],
+        "scene_point_clouds": [scans[s]["point_cloud"] for s in scans],
+        "scene_sequences": list(scans),
     }
 
 
@@ -96,6 +125,27 @@ class Evaluation:
         ok_t = np.array(self.trans_errors[method]) < translation_threshold
         ok_r = np.array(self.rot_errors[method]) < rotation_threshold
         return float(np.mean(ok_t & ok_r))
+
+    def error_string(self) -> str:
+        """The rows print_errors.main writes to error.txt (print_errors.py:27-56): per method
+        ``RTE mean+-std & RRE mean+-std & recall & recall after ICP`` at the (0.6 m, 1.5 deg) threshold; ``*_icp`` rows
+        are listed only for the vfm methods."""
+        rot = {k: np.array(v) for k, v in self.rot_errors.items()}
+        trans = {k: np.array(v) for k, v in self.trans_errors.items()}
+        success = {m: np.logical_and(trans[m] < .6, rot[m] < 1.5) for m in rot}
+        out = ""
+        for method, rot_error in rot.items():
+            if 'icp' in method and 'vfm' not in method:
+                continue
+            trans_error = trans[method]
+            recall = success[method]
+            out += f"{method}\t{np.round(np.mean(trans_error), 2):.2f}$\\pm${np.round(np.std(trans_error), 2):.2f}"
+            out += f" & {np.round(np.mean(rot_error), 2):.2f}$\\pm${np.round(np.std(rot_error), 2):.2f}"
+            out += f" & {np.round(np.mean(recall) * 100, 2):.2f}"
+            recall = success.get(f"{method}_icp", recall)
+            out += f" & {np.round(np.mean(recall) * 100, 2):.2f}"
+            out += "\n"
+        return out
 
     def summary(self) -> str:
         lines = ["=" * 80]

@@ -1,0 +1,414 @@
+"""Minimal HDF5 reader / writer for the processed-scene files of the reference (row F3).
+
+The reference writes scenes with h5py (prepare_scenes.py:16-47: ``create_group`` / ``create_dataset(data=...)``, default
+``libver='earliest'``) and reads them back with ``dataset[()]`` (vfm_reg/read_h5.py:17-49).  h5py is not installed here,
+so this module implements exactly the subset of the HDF5 file format (HDF5 File Format Specification, version 2.0)
+those calls produce and a little more of what other writers emit for the same logical content:
+
+reader   superblock versions 0-3; object headers version 1 and 2 (incl. continuation blocks); old-style groups
+         (symbol-table message -> v1 B-tree of SNOD nodes + local heap) and new-style groups with compact storage
+         (link messages); datasets with contiguous, compact or chunked (v1 B-tree index; optional shuffle + deflate
+         filters) layout; fixed-point and IEEE floating-point types of either byte order, scalar and N-d simple spaces.
+writer   superblock 0, version-1 object headers, symbol-table groups, contiguous little-endian datasets -- byte-level the
+         same structures libhdf5 1.10 produces for the reference's calls (checked with h5dump / h5ls / h5debug in
+         tests/test_h5lite.py when the HDF5 command-line tools are present).
+
+Anything outside that subset raises ``NotImplementedError`` naming the structure -- never a silent mis-read.
+"""
+from __future__ import annotations
+
+import struct
+import zlib
+from pathlib import Path
+from typing import Dict, Union
+
+import numpy as np
+
+SIG = b"\x89HDF\r\n\x1a\n"
+UNDEF = 0xFFFFFFFFFFFFFFFF
+Tree = Dict[str, Union["Tree", np.ndarray]]
+
+
+# ============================================================================================= reader
+class _Reader:
+    def __init__(self, buf: bytes):
+        self.b = buf
+        base = 0
+        while True:  # the superblock may sit at 0, 512, 1024, ...
+            if buf[base:base + 8] == SIG:
+                break
+            base = 512 if base == 0 else base * 2
+            if base + 8 > len(buf):
+                raise ValueError("not an HDF5 file (no superblock signature)")
+        ver = buf[base + 8]
+        if ver in (0, 1):
+            self.so, self.sl = buf[base + 13], buf[base + 14]
+            p = base + 24 + (4 if ver == 1 else 0)
+            self.base_addr = self._u(p, self.so)
+            p += 4 * self.so  # base address, free-space info, end of file, driver info
+            self.root_header = self._u(p + self.so, self.so)  # symbol table entry: name offset, header address
+        elif ver in (2, 3):
+            self.so, self.sl = buf[base + 9], buf[base + 10]
+            p = base + 12
+            self.base_addr = self._u(p, self.so)
+            self.root_header = self._u(p + 3 * self.so, self.so)
+        else:
+            raise NotImplementedError(f"HDF5 superblock version {ver}")
+        if self.so != 8 or self.sl != 8:
+            raise NotImplementedError(f"HDF5 offsets/lengths of {self.so}/{self.sl} bytes")
+
+    def _u(self, p: int, n: int) -> int:
+        return int.from_bytes(self.b[p:p + n], "little")
+
+    # ---- object headers -> list of (type, flags, payload bytes)
+    def messages(self, addr: int):
+        b = self.b
+        addr += self.base_addr
+        out = []
+        if b[addr:addr + 4] == b"OHDR":  # version 2
+            flags = b[addr + 5]
+            p = addr + 6
+            if flags & 0x20:
+                p += 16  # access, modification, change, birth times
+            if flags & 0x10:
+                p += 4   # max compact / min dense attributes
+            nsz = 1 << (flags & 3)
+            chunk = self._u(p, nsz)
+            p += nsz
+            track = bool(flags & 0x04)
+            blocks = [(p, p + chunk)]
+            while blocks:
+                p, end = blocks.pop(0)
+                while p + 4 <= end:
+                    mtype, msize, mflags = b[p], self._u(p + 1, 2), b[p + 3]
+                    p += 4 + (2 if track else 0)
+                    payload = b[p:p + msize]
+                    if mtype == 0x10:  # continuation: "OCHK" block
+                        off, ln = self._u(p, 8) + self.base_addr, self._u(p + 8, 8)
+                        blocks.append((off + 4, off + ln - 4))
+                    else:
+                        out.append((mtype, mflags, payload))
+                    p += msize
+            return out
+        if b[addr] != 1:
+            raise NotImplementedError(f"object header version {b[addr]} at {addr}")
+        size = self._u(addr + 8, 4)
+        blocks = [(addr + 16, addr + 16 + size)]
+        while blocks:
+            p, end = blocks.pop(0)
+            while p + 8 <= end:
+                mtype, msize, mflags = self._u(p, 2), self._u(p + 2, 2), b[p + 4]
+                payload = b[p + 8:p + 8 + msize]
+                if mtype == 0x10:
+                    off, ln = self._u(p + 8, 8) + self.base_addr, self._u(p + 16, 8)
+                    blocks.append((off, off + ln))
+                else:
+                    out.append((mtype, mflags, payload))
+                p += 8 + msize
+        return out
+
+    # ---- old-style group: walk the B-tree of symbol nodes
+    def _heap_string(self, heap_addr: int, off: int) -> str:
+        h = heap_addr + self.base_addr
+        if self.b[h:h + 4] != b"HEAP":
+            raise ValueError("local heap signature missing")
+        data = self._u(h + 8 + 2 * self.sl, self.so) + self.base_addr
+        end = self.b.index(b"\0", data + off)
+        return self.b[data + off:end].decode()
+
+    def _symbols(self, btree: int, heap: int):
+        p = btree + self.base_addr
+        sig = self.b[p:p + 4]
+        if sig == b"TREE":
+            if self.b[p + 4] != 0:
+                raise ValueError("group B-tree node of the wrong type")
+            n = self._u(p + 6, 2)
+            q = p + 8 + 2 * self.so
+            for i in range(n):
+                child = self._u(q + self.sl + i * (self.sl + self.so), self.so)
+                yield from self._symbols(child, heap)
+        elif sig == b"SNOD":
+            n = self._u(p + 6, 2)
+            for i in range(n):
+                e = p + 8 + i * (2 * self.so + 24)
+                yield self._heap_string(heap, self._u(e, self.so)), self._u(e + self.so, self.so)
+        else:
+            raise ValueError(f"unexpected node signature {sig!r} in a group B-tree")
+
+    def children(self, msgs):
+        for mtype, _, pl in msgs:
+            if mtype == 0x11:  # symbol table message: B-tree address, local heap address
+                yield from self._symbols(int.from_bytes(pl[0:8], "little"), int.from_bytes(pl[8:16], "little"))
+                return
+        links = [pl for mtype, _, pl in msgs if mtype == 0x06]
+        for pl in links:  # compact new-style group: link messages
+            flags = pl[1]
+            p = 2
+            ltype = 0
+            if flags & 0x08:
+                ltype = pl[p]
+                p += 1
+            if flags & 0x04:
+                p += 8
+            if flags & 0x10:
+                p += 1
+            nsz = 1 << (flags & 3)
+            nlen = int.from_bytes(pl[p:p + nsz], "little")
+            p += nsz
+            name = pl[p:p + nlen].decode()
+            p += nlen
+            if ltype != 0:
+                raise NotImplementedError("soft / external links")
+            yield name, int.from_bytes(pl[p:p + 8], "little")
+        if not links:
+            for mtype, _, pl in msgs:
+                if mtype == 0x02:  # link info: version, flags, [max creation index], fractal heap address, ...
+                    q = 2 + (8 if pl[1] & 1 else 0)
+                    if int.from_bytes(pl[q:q + 8], "little") != UNDEF:
+                        raise NotImplementedError("dense link storage (fractal heap): repack the file with "
+                                                  "`h5repack --low=0 --high=0` (symbol-table groups)")
+
+    # ---- datasets
+    @staticmethod
+    def _dtype(pl: bytes) -> np.dtype:
+        cls, bits0 = pl[0] & 0x0F, pl[1]
+        size = int.from_bytes(pl[4:8], "little")
+        order = ">" if (bits0 & 1) else "<"
+        if cls == 0:
+            return np.dtype(f"{order}{'i' if bits0 & 0x08 else 'u'}{size}")
+        if cls == 1:
+            if size not in (2, 4, 8):
+                raise NotImplementedError(f"{size}-byte floating point type")
+            return np.dtype(f"{order}f{size}")
+        raise NotImplementedError(f"HDF5 datatype class {cls}")
+
+    @staticmethod
+    def _shape(pl: bytes):
+        ver, rank = pl[0], pl[1]
+        if ver == 1:
+            p = 8
+        elif ver == 2:
+            if pl[3] == 2:
+                return None  # null dataspace
+            p = 4
+        else:
+            raise NotImplementedError(f"dataspace version {ver}")
+        return tuple(int.from_bytes(pl[p + 8 * i:p + 8 * i + 8], "little") for i in range(rank))
+
+    def _chunks(self, btree: int, rank: int):
+        p = btree + self.base_addr
+        if self.b[p:p + 4] != b"TREE" or self.b[p + 4] != 1:
+            raise NotImplementedError("chunk index other than a version-1 B-tree")
+        level, n = self.b[p + 5], self._u(p + 6, 2)
+        q = p + 8 + 2 * self.so
+        ksz = 8 + 8 * (rank + 1)
+        for i in range(n):
+            k = q + i * (ksz + self.so)
+            child = self._u(k + ksz, self.so)
+            if level > 0:
+                yield from self._chunks(child, rank)
+            else:
+                yield (self._u(k, 4), self._u(k + 4, 4),
+                       tuple(self._u(k + 8 + 8 * j, 8) for j in range(rank)), child)
+
+    def dataset(self, msgs) -> np.ndarray:
+        dt = shape = layout = None
+        filters = []
+        for mtype, _, pl in msgs:
+            if mtype == 0x03:
+                dt = self._dtype(pl)
+            elif mtype == 0x01:
+                shape = self._shape(pl)
+            elif mtype == 0x08:
+                layout = pl
+            elif mtype == 0x0B:  # filter pipeline
+                ver, nf = pl[0], pl[1]
+                p = 8 if ver == 1 else 2
+                for _ in range(nf):
+                    fid = int.from_bytes(pl[p:p + 2], "little")
+                    p += 2
+                    if ver == 1 or fid >= 256:
+                        nlen = int.from_bytes(pl[p:p + 2], "little")
+                        p += 2
+                    else:
+                        nlen = 0
+                    ncv = int.from_bytes(pl[p + 2:p + 4], "little")
+                    p += 4 + nlen + 4 * ncv
+                    if ver == 1 and ncv % 2:
+                        p += 4
+                    filters.append(fid)
+        if dt is None or shape is None or layout is None:
+            raise ValueError("dataset without datatype / dataspace / layout message")
+        count = int(np.prod(shape)) if shape else 1
+        ver, cls = layout[0], layout[1]
+        if ver != 3:
+            raise NotImplementedError(f"data layout message version {ver}")
+        if cls == 0:
+            n = int.from_bytes(layout[2:4], "little")
+            raw = layout[4:4 + n]
+        elif cls == 1:
+            addr, n = int.from_bytes(layout[2:10], "little"), int.from_bytes(layout[10:18], "little")
+            raw = b"" if addr == UNDEF else self.b[addr + self.base_addr:addr + self.base_addr + n]
+            if addr == UNDEF:
+                return np.zeros(shape, dtype=dt.newbyteorder("="))
+        elif cls == 2:
+            rank1 = layout[2]
+            btree = int.from_bytes(layout[3:11], "little")
+            cdims = tuple(int.from_bytes(layout[11 + 4 * i:15 + 4 * i], "little") for i in range(rank1 - 1))
+            out = np.zeros(shape, dtype=dt)
+            if btree != UNDEF:
+                for csize, mask, offs, addr in self._chunks(btree, rank1 - 1):
+                    raw = self.b[addr + self.base_addr:addr + self.base_addr + csize]
+                    for k, fid in reversed(list(enumerate(filters))):
+                        if mask & (1 << k):
+                            continue
+                        if fid == 1:
+                            raw = zlib.decompress(raw)
+                        elif fid == 2:
+                            es = dt.itemsize
+                            raw = np.frombuffer(raw, np.uint8).reshape(es, -1).T.tobytes()
+                        else:
+                            raise NotImplementedError(f"HDF5 filter {fid}")
+                    chunk = np.frombuffer(raw, dtype=dt, count=int(np.prod(cdims))).reshape(cdims)
+                    sl = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, cdims, shape))
+                    out[sl] = chunk[tuple(slice(0, s.stop - s.start) for s in sl)]
+            return out.astype(dt.newbyteorder("="))
+        else:
+            raise NotImplementedError(f"data layout class {cls}")
+        return np.frombuffer(raw, dtype=dt, count=count).reshape(shape if shape else ()).astype(dt.newbyteorder("="))
+
+    def node(self, addr: int):
+        msgs = self.messages(addr)
+        types = {m[0] for m in msgs}
+        if 0x08 in types:
+            return self.dataset(msgs)
+        if types & {0x11, 0x06, 0x02, 0x0A}:
+            return {name: self.node(child) for name, child in self.children(msgs)}
+        return {}  # an empty new-style group
+
+
+def read_h5(path) -> Tree:
+    """The whole file as nested dicts (groups, in the order the file's index yields them = sorted by name for
+    symbol-table groups, which is what ``h5py.Group.keys()`` / ``.values()`` iterate) of numpy arrays."""
+    r = _Reader(Path(path).read_bytes())
+    return r.node(r.root_header)
+
+
+# ============================================================================================= writer
+class _Writer:
+    LEAF_K, INTERNAL_K = 4, 16
+
+    def __init__(self):
+        self.buf = bytearray(96)  # superblock placeholder
+
+    def alloc(self, data: bytes) -> int:
+        while len(self.buf) % 8:
+            self.buf.append(0)
+        addr = len(self.buf)
+        self.buf += data
+        return addr
+
+    @staticmethod
+    def _msg(mtype: int, payload: bytes, flags: int = 0) -> bytes:
+        pad = (-len(payload)) % 8
+        return struct.pack("<HHB3x", mtype, len(payload) + pad, flags) + payload + b"\0" * pad
+
+    def _header(self, msgs) -> int:
+        body = b"".join(msgs)
+        return self.alloc(struct.pack("<BxHII4x", 1, len(msgs), 1, len(body)) + body)
+
+    def dataset(self, a: np.ndarray) -> int:
+        a = np.ascontiguousarray(a)
+        dt = a.dtype.newbyteorder("<") if a.dtype.byteorder == ">" else a.dtype
+        a = a.astype(dt, copy=False)
+        if dt.kind == "f" and dt.itemsize in (4, 8):
+            e, m = (8, 23) if dt.itemsize == 4 else (11, 52)
+            dtype_msg = struct.pack("<BBBBI", 0x11, 0x20, 8 * dt.itemsize - 1, 0, dt.itemsize) + \
+                struct.pack("<HHBBBBI", 0, 8 * dt.itemsize, m, e, 0, m, (1 << (e - 1)) - 1)
+        elif dt.kind in "iu":
+            dtype_msg = struct.pack("<BBBBI", 0x10, 0x08 if dt.kind == "i" else 0, 0, 0, dt.itemsize) + \
+                struct.pack("<HH", 0, 8 * dt.itemsize)
+        else:
+            raise NotImplementedError(f"dtype {a.dtype}")
+        space = struct.pack("<BBB5x", 1, a.ndim, 1) + b"".join(struct.pack("<Q", s) for s in a.shape) * 2 if a.ndim else \
+            struct.pack("<BBB5x", 1, 0, 0)
+        raw = a.tobytes()
+        data_addr = self.alloc(raw) if raw else UNDEF
+        fill = struct.pack("<BBBBI", 2, 2, 2, 1, 0)  # version 2, late allocation, fill if set, default value
+        layout = struct.pack("<BBQQ", 3, 1, data_addr, len(raw))
+        return self._header([self._msg(1, space), self._msg(3, dtype_msg, 1), self._msg(5, fill, 1), self._msg(8, layout)])
+
+    def group(self, tree: Tree):
+        """returns (object header address, B-tree address, heap address)"""
+        kids = []
+        for name in sorted(tree, key=lambda s: s.encode()):
+            v = tree[name]
+            if isinstance(v, dict):
+                kids.append((name, *self.group(v)))
+            else:
+                kids.append((name, self.dataset(np.asarray(v)), None, None))
+        # local heap: "" at offset 0, then the names (8-byte aligned)
+        seg = bytearray(8)
+        offs = []
+        for name, *_ in kids:
+            offs.append(len(seg))
+            nb = name.encode() + b"\0"
+            seg += nb + b"\0" * ((-len(nb)) % 8)
+        free = len(seg)
+        seg += struct.pack("<QQ", 1, 16)  # one free block at the end: (next = H5HL_FREE_NULL, size)
+        seg_addr = self.alloc(bytes(seg))
+        heap = self.alloc(b"HEAP" + struct.pack("<B3xQQQ", 0, len(seg), free, seg_addr))
+        # symbol nodes of up to 2 * LEAF_K entries, sorted by name
+        per = 2 * self.LEAF_K
+        level_nodes = []  # (address, heap offset of the largest name below)
+        if not kids:  # empty group: a B-tree node without entries (what H5Gcreate leaves)
+            btree = self.alloc(b"TREE" + struct.pack("<BBHQQ", 0, 0, 0, UNDEF, UNDEF) + b"\0" * (8 + 16 * 2 * self.INTERNAL_K))
+            return self._header([self._msg(0x11, struct.pack("<QQ", btree, heap))]), btree, heap
+        for i in range(0, len(kids), per):
+            part = list(zip(kids[i:i + per], offs[i:i + per]))
+            body = b"".join(struct.pack("<QQII", off, hdr, 1 if bt is not None else 0, 0) +
+                            (struct.pack("<QQ", bt, hp) if bt is not None else b"\0" * 16)
+                            for (_, hdr, bt, hp), off in part)
+            body += b"\0" * (40 * (per - len(part)))
+            addr = self.alloc(b"SNOD" + struct.pack("<BxH", 1, len(part)) + body)
+            level_nodes.append((addr, part[-1][1] if part else 0))
+        level = 0
+        fan = 2 * self.INTERNAL_K
+        while True:
+            nodes = []
+            for i in range(0, len(level_nodes), fan):
+                part = level_nodes[i:i + fan]
+                body = struct.pack("<Q", 0)
+                for addr, key in part:
+                    body += struct.pack("<QQ", addr, key)
+                body += b"\0" * (16 * (fan - len(part)))
+                nodes.append([self.alloc(b"TREE" + struct.pack("<BBHQQ", 0, level, len(part), UNDEF, UNDEF) + body), part[-1][1]])
+            for j, (addr, _) in enumerate(nodes):  # sibling links
+                left = nodes[j - 1][0] if j else UNDEF
+                right = nodes[j + 1][0] if j + 1 < len(nodes) else UNDEF
+                self.buf[addr + 8:addr + 24] = struct.pack("<QQ", left, right)
+            if len(nodes) == 1:
+                btree = nodes[0][0]
+                break
+            level_nodes = [tuple(x) for x in nodes]
+            level += 1
+        hdr = self._header([self._msg(0x11, struct.pack("<QQ", btree, heap))])
+        return hdr, btree, heap
+
+    def finish(self, root) -> bytes:
+        hdr, btree, heap = root
+        while len(self.buf) % 8:
+            self.buf.append(0)
+        sb = SIG + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, self.LEAF_K, self.INTERNAL_K, 0)
+        sb += struct.pack("<QQQQ", 0, UNDEF, len(self.buf), UNDEF)
+        sb += struct.pack("<QQII", 0, hdr, 1, 0) + struct.pack("<QQ", btree, heap)
+        assert len(sb) == 96
+        self.buf[0:96] = sb
+        return bytes(self.buf)
+
+
+def write_h5(path, tree: Tree) -> None:
+    """Write nested dicts of arrays as groups / contiguous datasets (the structures libhdf5 emits for
+    ``create_group`` + ``create_dataset(data=...)`` with ``libver='earliest'``)."""
+    w = _Writer()
+    Path(path).write_bytes(w.finish(w.group(tree)))
