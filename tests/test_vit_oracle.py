@@ -75,3 +75,52 @@ def test_fragment_tiling_roundtrip():
     for (n, k) in ((0, 0), (33, 17), (69, 49), (31, 15)):
         assert F[n // 32, k // 16, (k // 8) % 2, n % 32, k % 8] == np.float16(W[n, k])
     assert F[2, 3, 1, 31, 7] == 0  # padding
+
+
+def test_load_state_dict_from_three_checkpoint_layouts():
+    """vit.load_state_dict (the loader image_features.py:39-44 needs offline): a transformers.Dinov2Model state dict
+    (seeded weights), the same weights in facebookresearch/dinov2 naming (flat and chunked blocks) and inside the FeatUp
+    wrapper's naming all convert to the same arrays, and the converted weights reproduce the HF model's tokens."""
+    dim, depth, mlp = 128, 3, 512
+    w = V.random_weights(seed=5, dim=dim, depth=depth, mlp=mlp)
+    m = _hf_model(w, dim, depth, mlp)
+    hf = V.load_state_dict(m.state_dict())                       # Hugging Face naming, no ChannelNorm -> identity
+    for k, v in w.items():
+        if k.startswith("channel_norm"):
+            continue
+        np.testing.assert_array_equal(hf[k], v, err_msg=k)
+    assert (hf["channel_norm.weight"] == 1).all() and (hf["channel_norm.bias"] == 0).all()
+    with pytest.raises(KeyError, match="ChannelNorm"):
+        V.load_state_dict(m.state_dict(), channel_norm="require")
+    # facebookresearch/dinov2 naming (+ mask_token, chunked blocks) and the FeatUp wrapper around it
+    fb = {k: torch.from_numpy(v) for k, v in w.items() if not k.startswith("channel_norm")}
+    fb["mask_token"] = torch.zeros(1, dim)
+    chunked = {(k.replace("blocks.", "blocks.0.", 1) if k.startswith("blocks.") else k): v for k, v in fb.items()}
+    featup = {"model.0.model." + k: v for k, v in fb.items()}
+    featup["model.1.norm.weight"] = torch.from_numpy(w["channel_norm.weight"])
+    featup["model.1.norm.bias"] = torch.from_numpy(w["channel_norm.bias"])
+    featup["upsampler.up1.range_temp"] = torch.zeros(1)
+    for sd, has_cn in ((fb, False), (chunked, False), (featup, True)):
+        got = V.load_state_dict(sd)
+        assert set(got) == set(w)
+        for k, v in w.items():
+            if k.startswith("channel_norm") and not has_cn:
+                continue
+            np.testing.assert_array_equal(got[k], v, err_msg=k)
+    # the converted HF checkpoint drives the oracle ViT to the HF model's own output
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (1, 518, 518, 3), dtype=np.uint8)
+    feats = orc.vit_reference(hf, img, patch_h=37)               # identity ChannelNorm = plain LayerNorm over channels
+    x = torch.from_numpy(img).permute(0, 3, 1, 2).float() / 255.0
+    x = (x - torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    with torch.no_grad():
+        tok = m(pixel_values=x).last_hidden_state[:, 1:]
+        ref = torch.nn.functional.layer_norm(tok, (dim,), None, None, 1e-5)
+    np.testing.assert_allclose(feats.reshape(1, -1, dim), ref.numpy(), rtol=0, atol=2e-4)
+    # malformed inputs are loud
+    bad = dict(fb)
+    del bad["blocks.1.attn.proj.bias"]
+    with pytest.raises(KeyError, match="lacks"):
+        V.load_state_dict(bad)
+    with pytest.raises(NotImplementedError, match="register"):
+        V.load_state_dict({**fb, "register_tokens": torch.zeros(1, 4, dim)})

@@ -8,8 +8,8 @@ numpy) computed by the HIP ViT (csrc/vit.hip); ``upsample=True`` reproduces the 
 ``create_descriptors`` never materialises that 2.9 GB tensor: it calls ``patch_features_device``
 and lets the gather kernel interpolate per projected point.
 
-No network: pass ``weights`` (state dict in facebookresearch/dinov2 naming + channel_norm.*);
-without it a seeded random ViT-S/14 is used and a warning is printed.
+No network: pass ``weights`` -- a checkpoint path or a state dict in facebookresearch/dinov2, FeatUp-wrapper or
+transformers naming (``vit.load_state_dict``); without it a seeded random ViT-S/14 is used and a warning is printed.
 """
 from __future__ import annotations
 
@@ -40,6 +40,11 @@ class ImageFeatureGenerator:
         if use_featup:
             raise NotImplementedError("the FeatUp JBU upsampler is not on the hot path: the reference builds the "
                                       "generator with use_featup=False (registration_node.py:57)")
+        if isinstance(weights, (str, Path)):  # a checkpoint file: dinov2 / FeatUp / transformers key layouts
+            sd = torch.load(weights, map_location="cpu", weights_only=True)
+            weights = V.load_state_dict(sd.get("state_dict", sd) if isinstance(sd, dict) else sd)
+        elif weights is not None and "patch_embed.proj.weight" not in weights:
+            weights = V.load_state_dict(weights)  # a raw state dict in one of the supported layouts
         if weights is None:
             print("[WARNING] no DINOv2 weights given: using seeded random ViT-S/14 weights")
             weights = V.random_weights(seed=0)

@@ -1,9 +1,9 @@
 """DINOv2 ViT-S/14 (+ FeatUp ChannelNorm) weights and forward wrapper (row A1).
 
 The reference obtains the model with ``torch.hub.load("mhamilton723/FeatUp", "dinov2",
-use_norm=True)`` (image_features.py:39-42) -- no network here, so weights come either from a
-state dict in facebookresearch/dinov2 naming (``load_state_dict``; the FeatUp ChannelNorm is
-``channel_norm.{weight,bias}``) or from ``random_weights`` (seeded, exact ViT-S/14 shapes).
+use_norm=True)`` (image_features.py:39-42) -- no network here, so weights come either from a checkpoint's
+state dict (``load_state_dict``: facebookresearch/dinov2, FeatUp-wrapper or transformers key layouts; the FeatUp
+ChannelNorm becomes ``channel_norm.{weight,bias}``) or from ``random_weights`` (seeded, exact ViT-S/14 shapes).
 
 Host-side work done once per (weights, input resolution): bicubic interpolation of the 37x37
 position embedding to the 16 x pw patch grid (dinov2 ``interpolate_pos_encoding``; depends only on
@@ -57,6 +57,84 @@ def random_weights(seed: int = 0, dim: int = 384, depth: int = 12, mlp: int = 15
             v = rng.standard_normal(shp) / math.sqrt(fan_in)
         w[k] = v.astype(np.float32)
     return w
+
+
+def load_state_dict(state_dict, channel_norm: str = "identity") -> Dict[str, np.ndarray]:
+    """Weights dict for ``ViTS14`` / ``ImageFeatureGenerator(weights=...)`` from a checkpoint's state dict
+    (torch tensors or numpy arrays).  Accepted key layouts:
+
+    * facebookresearch/dinov2 (``torch.hub.load('facebookresearch/dinov2', 'dinov2_vits14').state_dict()``):
+      ``cls_token, pos_embed, patch_embed.proj.*, blocks.<i>.{norm1, attn.qkv, attn.proj, ls1.gamma, norm2, mlp.fc1,
+      mlp.fc2, ls2.gamma}, norm.*`` -- also with chunked blocks (``blocks.<chunk>.<i>.``); ``mask_token`` is ignored;
+    * the FeatUp wrapper the reference loads (image_features.py:39-42): ``model.0.model.<dinov2 key>`` for the
+      featurizer and ``model.1.norm.{weight,bias}`` for ``ChannelNorm(384)`` (``use_norm=True``); ``upsampler.*`` (the JBU
+      stack, unused with ``use_featup=False``) is ignored;
+    * Hugging Face ``transformers.Dinov2Model``: ``embeddings.*, encoder.layer.<i>.*, layernorm.*`` (separate
+      query / key / value projections are concatenated into the fused qkv).
+
+    A plain DINOv2 checkpoint has no ChannelNorm: ``channel_norm='identity'`` then uses LayerNorm's initial affine
+    (weight 1, bias 0), ``'require'`` raises instead.  Register tokens (dinov2 ``*_reg`` models) are not supported."""
+    sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in state_dict.items()}
+    sd = {k: v.astype(np.float32) for k, v in sd.items() if v.dtype.kind == "f"}
+    out: Dict[str, np.ndarray] = {}
+    if any(k.startswith("model.0.model.") for k in sd):  # FeatUp UpsampledBackbone
+        for k, v in sd.items():
+            if k.startswith("model.0.model."):
+                out[k[len("model.0.model."):]] = v
+            elif k in ("model.1.norm.weight", "model.1.norm.bias"):
+                out["channel_norm." + k.rsplit(".", 1)[1]] = v
+    elif any(k.startswith("embeddings.") or k.startswith("dinov2.embeddings.") for k in sd):  # transformers
+        sd = {(k[len("dinov2."):] if k.startswith("dinov2.") else k): v for k, v in sd.items()}
+        ren = {"embeddings.cls_token": "cls_token", "embeddings.position_embeddings": "pos_embed",
+               "embeddings.patch_embeddings.projection.weight": "patch_embed.proj.weight",
+               "embeddings.patch_embeddings.projection.bias": "patch_embed.proj.bias",
+               "layernorm.weight": "norm.weight", "layernorm.bias": "norm.bias"}
+        for a, b in ren.items():
+            if a in sd:
+                out[b] = sd[a]
+        i = 0
+        while f"encoder.layer.{i}.norm1.weight" in sd:
+            q, p = f"encoder.layer.{i}.", f"blocks.{i}."
+            for wb in ("weight", "bias"):
+                out[p + "attn.qkv." + wb] = np.concatenate([sd[q + f"attention.attention.{n}.{wb}"]
+                                                            for n in ("query", "key", "value")], axis=0)
+                out[p + "attn.proj." + wb] = sd[q + "attention.output.dense." + wb]
+                for n in ("norm1", "norm2", "mlp.fc1", "mlp.fc2"):
+                    out[p + n + "." + wb] = sd[q + n + "." + wb]
+            out[p + "ls1.gamma"] = sd[q + "layer_scale1.lambda1"]
+            out[p + "ls2.gamma"] = sd[q + "layer_scale2.lambda1"]
+            i += 1
+        for k in ("channel_norm.weight", "channel_norm.bias"):
+            if k in sd:
+                out[k] = sd[k]
+    else:  # facebookresearch/dinov2
+        import re
+        for k, v in sd.items():
+            out[re.sub(r"^blocks\.\d+\.(\d+)\.", r"blocks.\1.", k)] = v
+    if "register_tokens" in out or any("register_tokens" in k for k in sd):
+        raise NotImplementedError("DINOv2 checkpoints with register tokens")
+    out.pop("mask_token", None)
+    if "channel_norm.weight" not in out:
+        if channel_norm == "require":
+            raise KeyError("the state dict has no ChannelNorm (FeatUp `model.1.norm.*` / `channel_norm.*`)")
+        dim = out["patch_embed.proj.weight"].shape[0]
+        out["channel_norm.weight"] = np.ones(dim, np.float32)
+        out["channel_norm.bias"] = np.zeros(dim, np.float32)
+    dim = out["patch_embed.proj.weight"].shape[0]
+    depth = 0
+    while f"blocks.{depth}.norm1.weight" in out:
+        depth += 1
+    mlp = out["blocks.0.mlp.fc1.weight"].shape[0]
+    want = vit_s14_shapes(dim, depth, mlp, n_pos=out["pos_embed"].shape[1])
+    missing = [k for k in want if k not in out]
+    if missing:
+        raise KeyError(f"state dict lacks {missing[:4]}{'...' if len(missing) > 4 else ''}")
+    for k, shp in want.items():
+        if tuple(out[k].shape) != tuple(shp):
+            raise ValueError(f"{k}: shape {tuple(out[k].shape)}, expected {tuple(shp)}")
+    if out["patch_embed.proj.weight"].shape[2:] != (PATCH, PATCH) or dim % 64:
+        raise ValueError("not a patch-14 ViT with 64-wide heads")
+    return {k: np.ascontiguousarray(out[k]) for k in want}
 
 
 def interpolate_pos_embed(pos_embed: np.ndarray, h: int, w: int) -> np.ndarray:
