@@ -18,7 +18,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
                   / average launch duration measured with HIP events on its stream, vs the dense
                   fp16 MFMA peak of MI355X_MICROARCH.md (2.5 PFLOP/s);
   cpu_baseline -- the CPU oracle (oracle/, a port: faiss and Open3D are absent) timed on this
-                  box's host cores on a bounded sample of the same workload.
+                  box's host cores on a bounded sample of the same workload;
+  extra        -- outside the timed region: |T_gpu - T_oracle|_F of one pair ("pose delta vs ref"), config C3
+                  end to end (+ the ViT's roofline entry) and config C5 (+ its coarse kernel's roofline entry).
+--pairs P (config C4): P independent scene pairs, pair p generated from seed 42 + p on rank p mod N and registered
+there; every rank prints its own rate to stderr before the gather.
 """
 from __future__ import annotations
 
@@ -39,17 +43,19 @@ N_SCAN, N_MAP, DIM, RANSAC_ITERS = 20000, 200000, 384, 50000
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/fp16 MFMA ~2.5 PFLOP/s
 
 
-def cpu_baseline(n=N_SCAN, m=N_MAP, d=DIM, iters=RANSAC_ITERS):
+def cpu_baseline(p, iters=RANSAC_ITERS, T_gpu=None):
     """Reference-CPU-path stand-in (kind 'port'): the oracle's restatement -- fp32 BLAS Q.B^T + exact
-    fp64 decision, threshold, OpenMP RANSAC -- on a bounded sample, extrapolated linearly."""
+    fp64 decision, threshold, OpenMP RANSAC -- on the SAME scene pair the GPU registered (host copies `p`),
+    on a bounded sample, extrapolated linearly.  When the whole registration fits the time budget it is run
+    completely, which also yields the metric's "pose delta vs ref": |T_gpu - T_oracle|_F."""
     import numpy as np
     from oracle import oracle as orc
-    from vfmreg import synth
 
+    n, d = p["q_desc"].shape
+    m = p["b_desc"].shape[0]
     # 1) probe on a small sample to size the run: the whole registration is timed when it fits in
     #    ~40 s of host time, otherwise a bounded sample is extrapolated linearly (stated in `sample`).
     rows = 512
-    p = synth.make_pair(n, m, d, seed=42)
     t0 = time.perf_counter()
     bn, _ = orc.l2norm_rows(p["b_desc"])
     t_norm_map = time.perf_counter() - t0
@@ -73,7 +79,7 @@ def cpu_baseline(n=N_SCAN, m=N_MAP, d=DIM, iters=RANSAC_ITERS):
     t_ransac = time.perf_counter() - t0
     total = t_norm_map + t_match * (n / rows_used) + t_ransac * (iters / it_used)
     what = "the WHOLE registration (no extrapolation)" if full else "a bounded sample, extrapolated linearly"
-    return {
+    out = {
         "value": 1.0 / total, "unit": "registrations/s", "cores": orc.num_threads(), "kind": "port",
         "sample": (f"CPU oracle (numpy BLAS fp32 Q.B^T prefilter + C/OpenMP fp64 decision and RANSAC) on {what}: "
                    f"map renorm {m}x{d} {t_norm_map:.2f}s, search of {rows_used}/{n} scan rows vs the full map "
@@ -82,14 +88,132 @@ def cpu_baseline(n=N_SCAN, m=N_MAP, d=DIM, iters=RANSAC_ITERS):
                    f"{float(np.linalg.norm(res.transformation - p['T_gt'])):.4f}"),
         "host_cpu_count": os.cpu_count(),
     }
+    delta = None
+    if full and T_gpu is not None:
+        delta = {"pose_delta_vs_oracle_frobenius": float(np.linalg.norm(np.asarray(T_gpu) - res.transformation)),
+                 "correspondences_oracle": int(len(keep)),
+                 "note": "GPU pose of global pair 0 vs the CPU oracle's pose on identical inputs (same seed, same RANSAC stream)"}
+    return out, delta
+
+
+def extra_configs(dev):
+    """Other BASELINE configs, measured OUTSIDE the timed region (information only; the headline stays C2):
+    C3 = C2 + DINOv2 ViT-S/14 on 6 x 1200 x 1600 + 6-camera projection/lifting, one pair end to end (latency);
+    C5 = 50k x 1M x 768 (stretch)."""
+    import numpy as np
+    import torch
+    from vfmreg import _lib, ops, synth
+    from vfmreg import vit as V
+    from vfmreg.pipeline import RegistrationPipeline
+    lib = _lib.load()
+
+    def timed(fn, reps=7):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b))
+        return sorted(ts)[len(ts) // 2]
+
+    out = {}
+    # ---- C3
+    rng = np.random.default_rng(0)
+    B, H, W, n, m = 6, 1200, 1600, N_SCAN, N_MAP
+    imgs = torch.from_numpy(rng.integers(1, 255, (B, H, W, 3), dtype=np.uint8)).to(dev)
+    model = V.ViTS14(V.random_weights(0), H, W, device=dev)
+    grids = model.forward(imgs)
+    t_vit = timed(lambda: model.forward(imgs))
+    xyz = np.c_[rng.uniform(-40, 40, n), rng.uniform(-40, 40, n), rng.uniform(-2, 6, n)]
+    pcl = torch.from_numpy(np.ascontiguousarray(np.insert(xyz, 3, 1, axis=1).T)).to(dev)
+    K = np.array([[800.0, 0, 800], [0, 800, 600], [0, 0, 1]])
+    Ps = []
+    for i in range(6):
+        y = np.deg2rad(60 * i)
+        R = np.stack([[np.sin(y), -np.cos(y), 0], [0, 0, -1], [np.cos(y), np.sin(y), 0]])
+        Ps.append(K @ np.c_[R, np.zeros(3)])
+    desc = torch.zeros((n, 384), dtype=torch.float32, device=dev)
+    filled = torch.zeros(n, dtype=torch.uint8, device=dev)
+
+    def lift():
+        desc.zero_()
+        ops.lift_multicam(pcl, [dict(mode=ops.PROJ_KITTI, mats=[Ps[c]], fc=None, subsample=1.0, win=None, H=H, W=W,
+                                     proj_image=None, grid=grids[c], Hup=H, Wup=W, rot_mode=0, raw_image=imgs[c])
+                                for c in range(6)], desc, filled)
+    t_lift = timed(lift)
+    g = torch.Generator(device=dev).manual_seed(3)
+    b_desc = torch.randn(m, 384, device=dev, generator=g)
+    pick = torch.randperm(m, device=dev, generator=g)[:n]
+    b_desc[pick] = desc + 0.02 * desc.abs().mean() * torch.randn(n, 384, device=dev, generator=g)
+    b_xyz = torch.rand(m, 3, device=dev, generator=g, dtype=torch.float64) * 100.0
+    q_xyz = torch.from_numpy(np.ascontiguousarray(xyz)).to(dev)
+    b_xyz[pick] = q_xyz + 0.02 * torch.randn(n, 3, device=dev, generator=g, dtype=torch.float64)
+    pipe = RegistrationPipeline(n, m, 384, n_iter=RANSAC_ITERS, device=dev)
+    t_reg = timed(lambda: pipe.register(desc, q_xyz, b_desc, b_xyz))
+
+    def chain():
+        nonlocal grids
+        grids = model.forward(imgs)
+        lift()
+        return pipe.register(desc, q_xyz, b_desc, b_xyz)
+    t_all = timed(chain)
+    r = chain()
+    torch.cuda.synchronize()
+    vit_flops = 6 * 16.6e9  # SURVEY.md 8 D.3: 16.6 GFLOP per 224 x 294 image
+    out["C3"] = {"workload": "one pair end to end, device resident: ViT-S/14 on 6 x 1200x1600 -> 6-camera projection + lifting "
+                             "of 20000 points -> match vs 200000-point map -> 50000-iteration RANSAC (latency, no pipelining)",
+                 "ms_end_to_end": t_all, "ms_vit": t_vit, "ms_project_lift": t_lift, "ms_registration": t_reg,
+                 "correspondences": int(r["count"].item()),
+                 "vit_roofline": {"bound": "mfma", "flops": vit_flops, "achieved": vit_flops / (t_vit * 1e-3) / 1e12,
+                                  "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": vit_flops / (t_vit * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS}}
+    del pipe, model, imgs, b_desc
+    # ---- C5
+    n5, m5, d5 = 50000, 1000000, 768
+    p5 = synth.make_pair_device(n5, m5, d5, seed=1, device=dev)
+    a, b = C.c_void_p(), C.c_void_p()
+    lib.vfm_prof_events_create(C.byref(a), C.byref(b))
+    ts = []
+    ms = C.c_float()
+    for k in range(4):
+        lib.vfm_prof_arm(a, b)
+        ops.match_ip_top1(p5["q_desc"], p5["b_desc"], ops.FAST)
+        lib.vfm_prof_elapsed_ms(a, b, C.byref(ms))
+        if k:
+            ts.append(ms.value)
+    lib.vfm_prof_events_destroy(a, b)
+    t5 = sorted(ts)[len(ts) // 2]
+    pipe5 = RegistrationPipeline(n5, m5, d5, n_iter=RANSAC_ITERS, device=dev)
+    t5_reg = timed(lambda: pipe5.register(p5["q_desc"], p5["q_xyz"], p5["b_desc"], p5["b_xyz"]), reps=3)
+    r5 = pipe5.register(p5["q_desc"], p5["q_xyz"], p5["b_desc"], p5["b_xyz"])
+    torch.cuda.synchronize()
+    f5 = 2.0 * n5 * m5 * d5
+    out["C5"] = {"workload": "50000-pt scan vs 1000000-pt map, 768-D, 50000 RANSAC iterations (one registration, serial)",
+                 "ms_registration": t5_reg, "ms_coarse_kernel": t5, "correspondences": int(r5["count"].item()),
+                 "pose_err_vs_planted": float(np.linalg.norm(r5["T"].cpu().numpy() - p5["T_gt"])),
+                 "roofline": {"bound": "mfma", "kernel": "match_coarse_r_kernel<48,1,3> (fp16 32x32x16 MFMA)", "flops": f5,
+                              "achieved": f5 / (t5 * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": f5 / (t5 * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS}}
+    return out
+
+
+RESIDENT_MAX = 32  # distinct scene pairs kept in HBM per rank (338 MB each); longer runs cycle through them
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20, help="timed registrations per GPU")
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=0,
+                    help="config C4: total number of independent scene pairs of the job, sharded pair p -> rank p mod N "
+                         "(overrides --steps: every rank registers its ceil(pairs / N) pairs once)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C5 measurements reported under `extra`")
     ap.add_argument("--n", type=int, default=N_SCAN)
     ap.add_argument("--m", type=int, default=N_MAP)
     ap.add_argument("--iters", type=int, default=RANSAC_ITERS)
@@ -97,6 +221,7 @@ def main():
                     help="2: RANSAC of pair i overlaps the matching of pair i+1 on a second HIP stream; 1: serial")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -116,11 +241,16 @@ def main():
     if os.environ.get("VFM_VARIANT"):  # A/B runs (tools/r02_prof.sh): 4 = dense per-chunk records + select kernel
         lib.vfm_debug_set_coarse_variant(int(os.environ["VFM_VARIANT"]))
     n, m, d = args.n, args.m, DIM
-    # two resident scene pairs per rank, alternated; pair p uses seed 42 + p (global pair id)
-    pairs = [synth.make_pair_device(n, m, d, seed=42 + rank * 2 + j, device=dev) for j in range(2)]
+    # Global scene pairs: pair p runs on rank p mod world and is generated ON ITS OWNER from
+    # seed 42 + p (D.2).  They are resident in HBM before the timed region starts.
+    num_pairs = args.pairs if args.pairs > 0 else world * args.steps
+    mine = vdist.shard_pairs(num_pairs, rank, world)
+    steps = len(mine) if args.pairs > 0 else args.steps
+    n_res = max(1, min(len(mine), RESIDENT_MAX))
+    pairs = [synth.make_pair_device(n, m, d, seed=42 + mine[j], device=dev) for j in range(n_res)]
     # --streams 2 (default): pipeline over independent scene pairs (BASELINE config C4: "one per stream"):
     # the MFMA coarse pass of pair i+1 runs on the main stream while the operand preparation of pair i+2 and
-    # the select / exact decision / RANSAC of pair i run on two side streams (vfmreg/pipeline.py).  Coarse
+    # the filter / exact decision / RANSAC of pair i run on two side streams (vfmreg/pipeline.py).  Coarse
     # passes never overlap each other, so the HIP-event duration of the coarse kernel stays a per-launch figure.
     S = 2 if args.streams >= 2 else 1
     pipe = RegistrationPipeline(n, m, d, n_iter=args.iters, device=dev, overlap_ransac=(S == 2))
@@ -133,7 +263,7 @@ def main():
     inputs_ready.record(match_stream)
 
     def step(i):
-        p = pairs[i % 2]
+        p = pairs[i % n_res]
         with torch.cuda.stream(match_stream):
             return pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"], want_mask=True,
                                  inputs_ready=inputs_ready if S == 2 else None)
@@ -149,25 +279,20 @@ def main():
     torch.cuda.synchronize()
 
     events = []
-    for _ in range(args.steps):
+    for _ in range(steps):
         a, b = C.c_void_p(), C.c_void_p()
         _lib.check(lib.vfm_prof_events_create(C.byref(a), C.byref(b)))
         events.append((a, b))
-    num_pairs = world * args.steps  # global scene-pair ids; pair p runs on rank p mod world (weak scaling)
-    local_i = [0]
 
-    res_T = torch.empty((args.steps, 4, 4), dtype=torch.float64, device=dev)
-    res_c = torch.empty((args.steps, 1), dtype=torch.int64, device=dev)
+    res_T = torch.empty((steps, 4, 4), dtype=torch.float64, device=dev)
+    res_c = torch.empty((steps, 1), dtype=torch.int64, device=dev)
 
-    def register_pair(p):
-        i = local_i[0]
-        local_i[0] += 1
+    def register_pair(i):
         lib.vfm_prof_arm(events[i][0], events[i][1])
         out = step(i)
         with torch.cuda.stream(out["result_stream"]):  # snapshot the result on the producing stream
             res_T[i].copy_(out["T"])
             res_c[i].copy_(out["count"])
-        return res_T[i], res_c[i]
 
     grouped = dist.is_available() and dist.is_initialized()  # launched through torch.distributed.run
     if grouped:
@@ -175,21 +300,29 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     # every rank registers its pairs (no data-path collective), then ONE all_gather of the poses
-    ids = vdist.shard_pairs(num_pairs, rank, world)
-    for p_id in ids:
-        register_pair(p_id)
+    for i in range(steps):
+        register_pair(i)
     with torch.cuda.stream(match_stream):
         pipe.synchronize()
     torch.cuda.current_stream().wait_stream(match_stream)
-    all_poses, all_counts = vdist.gather_poses(res_T, res_c.reshape(-1), num_pairs, rank, world)
+    torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0   # this rank's own work, before the gather (stragglers show up here)
+    gather_pairs = world * steps               # ranks with one pair less (ragged --pairs) pad with their last pose
+    all_poses, all_counts = vdist.gather_poses(res_T, res_c.reshape(-1), gather_pairs, rank, world)
     torch.cuda.synchronize()
     if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = [steps / local_elapsed]
     if grouped:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        rates = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(rates, torch.tensor([steps / local_elapsed], dtype=torch.float64, device=dev))
+        per_rank = [float(x) for x in rates.cpu()]
+    print(f"[rank {rank}] {steps} registrations in {local_elapsed * 1e3:.1f} ms = {steps / local_elapsed:.1f} registrations/s "
+          f"(before the gather)", file=sys.stderr, flush=True)
 
     ms = C.c_float()
     durs = []
@@ -206,7 +339,7 @@ def main():
         a, b = C.c_void_p(), C.c_void_p()
         _lib.check(lib.vfm_prof_events_create(C.byref(a), C.byref(b)))
         for i in range(6):
-            pr = pairs[i % 2]
+            pr = pairs[i % n_res]
             lib.vfm_prof_arm(a, b)
             pipe1.register(pr["q_desc"], pr["q_xyz"], pr["b_desc"], pr["b_xyz"])
             _lib.check(lib.vfm_prof_elapsed_ms(a, b, C.byref(ms)))
@@ -216,47 +349,65 @@ def main():
         del pipe1
     iso_ms = (sum(iso) / len(iso)) if iso else coarse_ms
 
-    # sanity of the timed work: every pose must recover the planted transform
-    import numpy as np
-    mine = vdist.shard_pairs(num_pairs, rank, world)
-    errs = [float(np.linalg.norm(all_poses[p].cpu().numpy() - pairs[i % 2]["T_gt"])) for i, p in enumerate(mine)]
-    ncorr = int(all_counts[mine[-1]].item())
+    # sanity of the timed work: every pose of this rank must recover the planted transform of ITS pair
+    local_ids = [rank + world * i for i in range(steps)]
+    errs = [float(np.linalg.norm(all_poses[g].cpu().numpy() - pairs[i % n_res]["T_gt"])) for i, g in enumerate(local_ids)]
+    ncorr = int(all_counts[local_ids[-1]].item())
+    T0 = all_poses[0].cpu().numpy()  # global pair 0 lives on rank 0
 
     if rank == 0:
         flops = 2.0 * n * m * d
         achieved = flops / (coarse_ms * 1e-3) / 1e12
-        traffic = None  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
-        pmc = ROOT / "profiles" / "r01_pmc_match_coarse.json"
-        if pmc.exists() and (n, m, d) == (N_SCAN, N_MAP, DIM):
-            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+        traffic, traffic_src = None, None  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
+        for name in ("r02_pmc_match_coarse.json", "r01_pmc_match_coarse.json"):
+            pmc = ROOT / "profiles" / name
+            if pmc.exists() and (n, m, d) == (N_SCAN, N_MAP, DIM):
+                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+                traffic_src = f"profiles/{name} (FETCH_SIZE / WRITE_SIZE from separate --pmc passes, corrected per MI355X_MICROARCH.md)"
+                break
         line = {
-            "metric": "registrations/sec (20k<->200k pts, 384-D)", "value": world * args.steps / elapsed,
-            "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16 coarse pass (MFMA) + f64 exact decision / f64 RANSAC",
+            "metric": "registrations/sec (20k<->200k pts, 384-D)", "value": world * steps / elapsed,
+            "unit": "registrations/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16 coarse pass (MFMA) + f32 refinement + f64 exact decision / f64 RANSAC",
             "data": "synthetic",
             "config": {"workload": f"C2: {n}-pt scan vs {m}-pt map, {d}-D descriptors precomputed and resident in "
                                    f"HBM, {args.iters} RANSAC iterations, cosine >= 0.8; map renormalised every step",
-                       "registrations_per_gpu": args.steps, "resident_scene_pairs_per_gpu": 2,
-                       "parallelism": f"{world} GPU shard(s) x {S} stream(s), independent scene pairs",
+                       "registrations_per_gpu": steps, "scene_pairs_total": world * steps,
+                       "resident_scene_pairs_per_gpu": n_res, "pair_seed": "42 + global pair id, generated on the owning rank",
+                       "parallelism": f"{world} GPU shard(s) x {S} stream(s), independent scene pairs (pair p -> rank p mod N)",
                        "collective": (f"one all_gather_into_tensor of the poses ({dist.get_backend()} = RCCL)" if grouped
                                       else "none (single process, no launcher)"),
                        "correspondences_last_step": ncorr, "max_pose_err_vs_planted": max(errs)},
-            "roofline": {"bound": "mfma", "kernel": "match_coarse_pipe_kernel<24> (fp16 32x32x16 MFMA, fused top-2 epilogue)",
+            "per_rank_registrations_per_s": per_rank,
+            "roofline": {"bound": "mfma", "kernel": "match_coarse_pipe_kernel<24, true> (fp16 32x32x16 MFMA, sparse row-level records)",
                          "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_source": "profiles/r01_pmc_match_coarse.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
+                         "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "flops_per_launch": flops, "avg_launch_ms": coarse_ms,
                          "single_stream": {"avg_launch_ms": iso_ms, "achieved": flops / (iso_ms * 1e-3) / 1e12,
                                            "frac": flops / (iso_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
                                            "note": "same kernel without the RANSAC of the previous pair running beside it"}},
         }
+        extra = {"note": "measured outside the timed region; the headline `value` is C2 only"}
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(n, m, d, args.iters)
+            host = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in pairs[0].items()}
+            line["cpu_baseline"], delta = cpu_baseline(host, args.iters, T_gpu=T0)
+            if delta is not None:
+                extra["pose_delta_vs_oracle"] = delta
         else:
             line["cpu_baseline"] = None
+        if not args.no_extra and (n, m) == (N_SCAN, N_MAP):
+            del pipe
+            pairs.clear()
+            torch.cuda.empty_cache()
+            try:
+                extra.update(extra_configs(dev))
+            except Exception as e:  # never lose the headline line to an auxiliary measurement
+                extra["error"] = f"{type(e).__name__}: {e}"
+        line["extra"] = extra
         print(json.dumps(line), flush=True)
     if grouped:
+        dist.barrier()
         dist.destroy_process_group()
 
 

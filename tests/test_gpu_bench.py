@@ -30,7 +30,7 @@ def _check(out: str, steps: int):
 
 def test_bench_plain_small_run():
     env = dict(os.environ)
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extra"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-3000:]
     d = _check(r.stdout, 4)
@@ -47,3 +47,25 @@ def test_bench_under_torch_distributed_run_world1():
     d = _check(r.stdout, 4)
     assert "nccl" in d["config"]["collective"]  # the RCCL process group was created and used
     assert d["cpu_baseline"] is not None and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    # the metric's "pose delta vs ref" and the other configs ride on the same line, outside the timed region
+    ex = d["extra"]
+    assert "error" not in ex, ex
+    if "pose_delta_vs_oracle" in ex:   # present whenever the host finishes the whole oracle registration in the time budget
+        assert ex["pose_delta_vs_oracle"]["pose_delta_vs_oracle_frobenius"] <= 1e-5
+    assert ex["C3"]["ms_end_to_end"] > ex["C3"]["ms_vit"] > 0 and 0 < ex["C3"]["vit_roofline"]["frac"] < 1
+    assert ex["C5"]["pose_err_vs_planted"] < 0.05 and 0.05 < ex["C5"]["roofline"]["frac"] < 1
+
+
+def test_bench_pairs_form_for_config_c4():
+    """`--pairs P`: pair p is generated from seed 42 + p on rank p mod N and registered there; per-rank rates are reported."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", str(ROOT / "bench.py"), "--gpus", "1", "--pairs", "32", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extra"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _check(r.stdout, 32)
+    assert d["config"]["scene_pairs_total"] == 32 and d["config"]["resident_scene_pairs_per_gpu"] == 32
+    assert len(d["per_rank_registrations_per_s"]) == 1 and d["per_rank_registrations_per_s"][0] >= d["value"] * 0.99
+    assert "[rank 0] 32 registrations" in r.stderr

@@ -105,3 +105,26 @@ def test_select_overflow_beyond_list_capacity_falls_back_exactly():
     np.testing.assert_array_equal(idx.cpu().numpy(), idx_ref)
     np.testing.assert_array_equal(sim.cpu().numpy(), sim_ref)
     assert st[0] == 6, st
+
+
+def test_zero_rows_do_not_flood_the_record_lists():
+    """points seen by no camera carry an all-zero descriptor (prepare_scenes.py:102-104): such a query scores exactly
+    2.0 against every map row in the coarse pass and must not record anything (index 0, similarity 0 as the oracle gives);
+    zero MAP rows must not disturb the others either."""
+    from oracle import oracle as orc
+    from vfmreg import ops
+    rng = np.random.default_rng(8)
+    n, m, d = 3000, 40000, 384
+    b = rng.standard_normal((m, d)).astype(np.float32)
+    b[rng.choice(m, 2000, replace=False)] = 0.0
+    q = b[rng.permutation(m)[:n]] + 0.1 * rng.standard_normal((n, d)).astype(np.float32)
+    zero_q = rng.choice(n, n // 2, replace=False)
+    q[zero_q] = 0.0
+    idx, sim, st = _stats(ops, torch.from_numpy(q).cuda(), torch.from_numpy(b).cuda())
+    qn, _ = orc.l2norm_rows(q)
+    bn, _ = orc.l2norm_rows(b)
+    idx_ref, sim_ref = orc.match_ip_top1(qn, bn)
+    np.testing.assert_array_equal(idx.cpu().numpy(), idx_ref)
+    np.testing.assert_array_equal(sim.cpu().numpy(), sim_ref)
+    assert (idx[zero_q].cpu().numpy() == 0).all() and (sim[zero_q].cpu().numpy() == 0).all()
+    assert st[0] == 0 and st[4] < 60 * n, st      # a few dozen records per non-zero query, none for the zero ones

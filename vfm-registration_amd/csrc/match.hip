@@ -218,6 +218,7 @@ struct CoarseArgs {
     // sparse row-level records (match_coarse_pipe_kernel<., true>): every (query, map row) whose coarse score is
     // within `window` of the query's running maximum at that time -- a superset of the rows within `window` of the
     // final maximum, which is all the exact decision needs
+    const float* qinv;   // [npad] 1/|query row| (0 for zero rows: they record nothing, match_rescore_kernel decides them)
     unsigned* rec_cnt;   // [npad] records appended per query (may exceed rcap: overflow)
     uint2* rec;          // [npad][rcap] (map row, score bits)
     int rcap;
@@ -499,7 +500,12 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
     uint2* lrec = reinterpret_cast<uint2*>(smem + NBUF * TILE_BYTES);        // [LREC_CAP] (query in block << 24 | row, score bits)
     unsigned* lrec_count = reinterpret_cast<unsigned*>(lrec + LREC_CAP);
     if constexpr (SPARSE) {
-        if (qt < a.nq_tiles) runmax = a.qmax[(size_t)qt * 32 + (lane & 31)];  // published by earlier units (any stale value is valid)
+        if (qt < a.nq_tiles) {
+            runmax = a.qmax[(size_t)qt * 32 + (lane & 31)];  // published by earlier units (any stale value is valid)
+            // a zero query row scores exactly 2.0 against every map row: it would record all of them.  Its answer is
+            // fixed (index 0, score 0): park its maximum at the largest float so that nothing passes the threshold.
+            if (a.qinv[(size_t)qt * 32 + (lane & 31)] == 0.0f) runmax = 0x7F7FFFFFu;
+        }
         if (threadIdx.x == 0) *lrec_count = 0u;  // visible after the first barrier below
     }
     auto fold_tail = [&](int it) {
@@ -1839,6 +1845,7 @@ CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, 
     a.qmax = w.qmax;
     a.first_pad_chunk = (int)(m / CHUNK_ROWS);
     a.row_bias = nullptr;
+    a.qinv = Q.inv;
     a.rec_cnt = nullptr;
     a.rec = nullptr;
     a.rcap = 0;

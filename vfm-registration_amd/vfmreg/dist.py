@@ -74,13 +74,24 @@ def gather_poses(local_poses: torch.Tensor, local_aux: torch.Tensor, num_pairs: 
 
 def register_sharded(num_pairs: int, register_pair: Callable[[int], Tuple[torch.Tensor, torch.Tensor]],
                      rank: int, world: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Run ``register_pair(p) -> (T[4,4] fp64, count int64[1])`` for this rank's pairs (enqueue
-    only, no host sync), then gather.  Config C4: 256 pairs over 8 GPUs."""
+    """Run ``register_pair(p) -> (T[4,4] fp64, count int64[1][, ready])`` for this rank's pairs (enqueue
+    only, no host sync), then gather.  ``ready`` (optional) is the ``torch.cuda.Event`` or ``torch.cuda.Stream`` after
+    which T and count are complete -- e.g. ``out["done"]`` / ``out["result_stream"]`` of a
+    ``RegistrationPipeline(overlap_ransac=True)``, whose results are produced on a side stream; without it the
+    results must be ordered on the caller's current stream.  Config C4: 256 pairs over 8 GPUs."""
     ids = shard_pairs(num_pairs, rank, world)
     poses = torch.zeros((len(ids), 4, 4), dtype=torch.float64, device=device)
     aux = torch.zeros(len(ids), dtype=torch.int64, device=device)
     for j, p in enumerate(ids):
-        T, cnt = register_pair(p)
+        res = register_pair(p)
+        T, cnt = res[0], res[1]
+        ready = res[2] if len(res) > 2 else None
+        if ready is not None and T.is_cuda:
+            cur = torch.cuda.current_stream(T.device)
+            if isinstance(ready, torch.cuda.Event):
+                cur.wait_event(ready)
+            else:
+                cur.wait_stream(ready)
         poses[j].copy_(T)
         aux[j:j + 1].copy_(cnt.reshape(1))
     return gather_poses(poses, aux, num_pairs, rank, world)
