@@ -65,6 +65,7 @@ __host__ __device__ inline int64_t rows_padded(int64_t rows) { return (rows + RO
 
 // sum of squares in the oracle's order: lane l owns the float4 chunks c with c % 64 == l
 // (ascending c, ascending element inside a chunk), then an xor butterfly.  d <= 1024.
+template <bool STREAM = false>
 __device__ __forceinline__ float row_sumsq_wave(const float* __restrict__ row, int d, float4 (&v)[4]) {
     const int lane = lane_id();
     const int nchunks = d >> 2;
@@ -74,7 +75,15 @@ __device__ __forceinline__ float row_sumsq_wave(const float* __restrict__ row, i
         const int c = lane + 64 * i;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < nchunks) {
-            x = reinterpret_cast<const float4*>(row)[c];
+            if constexpr (STREAM) {  // read-once data: do not displace the coarse pass' map slice from L2
+                const float* pc = row + 4 * c;
+                x.x = __builtin_nontemporal_load(pc);
+                x.y = __builtin_nontemporal_load(pc + 1);
+                x.z = __builtin_nontemporal_load(pc + 2);
+                x.w = __builtin_nontemporal_load(pc + 3);
+            } else {
+                x = reinterpret_cast<const float4*>(row)[c];
+            }
             float t;
             t = x.x * x.x; p = p + t;
             t = x.y * x.y; p = p + t;
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
         for (int i = 0; i < 4; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         float inv = 0.0f;
         if (r < rows) {
-            float nr = row_sumsq_wave(x + r * (int64_t)d, d, v);
+            float nr = row_sumsq_wave<true>(x + r * (int64_t)d, d, v);
             inv = inv_norm_from_sumsq(nr);
         }
         if (lane == 0) inv_out[r] = inv;
@@ -137,7 +146,14 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
     const int units = ksteps * 64;
     uint4* dst = tiles + (int64_t)tile * units;
     const uint4* src = reinterpret_cast<const uint4*>(smem);
-    for (int u = threadIdx.x; u < units; u += 256) dst[u] = src[u];
+    for (int u = threadIdx.x; u < units; u += 256) {
+        const uint4 t = src[u];
+        unsigned* o = reinterpret_cast<unsigned*>(dst + u);
+        __builtin_nontemporal_store(t.x, o);
+        __builtin_nontemporal_store(t.y, o + 1);
+        __builtin_nontemporal_store(t.z, o + 2);
+        __builtin_nontemporal_store(t.w, o + 3);
+    }
 }
 
 // in-place renorm (vfm_l2norm_rows_f32): one wave per row
@@ -1598,7 +1614,14 @@ __global__ __launch_bounds__(256) void l2_prep_kernel(const float* __restrict__ 
     const int units = (kp >> 4) * 64;
     uint4* dst = tiles + (int64_t)tile * units;
     const uint4* src = reinterpret_cast<const uint4*>(smem);
-    for (int u = threadIdx.x; u < units; u += 256) dst[u] = src[u];
+    for (int u = threadIdx.x; u < units; u += 256) {
+        const uint4 t = src[u];
+        unsigned* o = reinterpret_cast<unsigned*>(dst + u);
+        __builtin_nontemporal_store(t.x, o);
+        __builtin_nontemporal_store(t.y, o + 1);
+        __builtin_nontemporal_store(t.z, o + 2);
+        __builtin_nontemporal_store(t.w, o + 3);
+    }
 }
 
 // oracle order: acc += (double(a_k) - double(b_k))^2, k ascending

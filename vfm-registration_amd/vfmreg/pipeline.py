@@ -10,13 +10,16 @@ host synchronisation:
 Buffers are allocated once for fixed (N, M, D); ``register`` only enqueues work.
 
 ``overlap_ransac=True`` turns the chain into a pipeline over independent scene pairs:
-stage 0 (a "prepare" HIP stream) = normalise + fp16 fragment conversion of pair i+1 (HBM-bound);
-stage 1 (caller's stream) = the fp16 MFMA coarse pass of pair i+1 -- the matrix cores;
-stage 2 (a "solve" HIP stream) = candidate selection, exact fp64 re-decision, threshold / compaction
-and RANSAC of pair i -- vector ALU and fp64.  Events order the hand-offs and two complete buffer sets
-(prepared operands, search workspace, results) ping-pong, so results of pair i stay valid until pair
-i+2 is enqueued.  Coarse passes never overlap each other; the inputs of a pair must stay untouched
-until its ``done`` event.
+stage 1 (caller's stream) = normalise + fp16 fragment conversion (HBM-bound) and the fp16 MFMA coarse pass of pair i+1;
+stage 2 (a "solve" HIP stream) = record filtering + fp32 refinement, exact fp64 re-decision, threshold / compaction
+and RANSAC of pair i -- vector ALU and fp64, a few hundred short waves that share compute units with the coarse pass at
+no measurable cost to it.  Events order the hand-offs and two complete buffer sets (prepared operands, search
+workspace, results) ping-pong, so results of pair i stay valid until pair i+2 is enqueued.  Coarse passes never overlap
+each other; the inputs of a pair must stay untouched until its ``done`` event.
+``overlap_prepare=True`` additionally moves the operand preparation of pair i+1 to a third stream beside the coarse pass
+of pair i (round 1's default).  Measured in round 2: the 0.5 GB it streams cost the coarse pass 5-7 % (2.71-2.77 vs
+2.57-2.59 ms; power and L2, not LDS: an LDS-free version of the kernel taxed it the same), more than the 0.11 ms it
+hides -- 360 vs 365 registrations/s -- so it is off by default.
 """
 from __future__ import annotations
 
@@ -49,7 +52,8 @@ class _ResultSet:
 
 class RegistrationPipeline:
     def __init__(self, n: int, m: int, d: int = 384, n_iter: int = 50000, min_cosine: float = 0.8,
-                 max_corr_dist: float = 10000.0, seed: int = 42, device="cuda", overlap_ransac: bool = False):
+                 max_corr_dist: float = 10000.0, seed: int = 42, device="cuda", overlap_ransac: bool = False,
+                 overlap_prepare: bool = False):
         lib = _lib.load()
         self.n, self.m, self.d = n, m, d
         self.n_iter, self.min_cosine, self.max_corr_dist, self.seed = n_iter, min_cosine, max_corr_dist, seed
@@ -58,6 +62,7 @@ class RegistrationPipeline:
         u8 = torch.uint8
         self.rws = torch.empty(lib.vfm_ransac_workspace_bytes(n, n_iter), dtype=u8, device=dev)
         self.overlap = bool(overlap_ransac)
+        self.overlap_prepare = bool(overlap_prepare)
         sizes = (lib.vfm_match_prepared_bytes(n, d), lib.vfm_match_prepared_bytes(m, d),
                  lib.vfm_match_search_workspace_bytes(n, m, d))
         self.sets = [_ResultSet(n, dev, *sizes) for _ in range(2 if self.overlap else 1)]
@@ -102,7 +107,10 @@ class RegistrationPipeline:
         main = torch.cuda.current_stream()
         st = main.cuda_stream
         pst = st
-        if self.overlap:
+        if self.overlap and not self.overlap_prepare:
+            if r.done is not None:
+                main.wait_event(r.done)                 # the solve stage that last read this set has finished
+        elif self.overlap:
             # stage 0 on its own stream: it may run beside the coarse pass of the previous pair
             if inputs_ready is not None:
                 self.prep_stream.wait_event(inputs_ready)
@@ -115,7 +123,7 @@ class RegistrationPipeline:
             _lib.check(lib.vfm_match_prepare(b_desc.data_ptr(), self.m, self.d, r.bprep.data_ptr(), pst), "prepare(map)")
             r.map_key = b_desc.data_ptr() if reuse_map else None
         _lib.check(lib.vfm_match_prepare(q_desc.data_ptr(), self.n, self.d, r.qprep.data_ptr(), pst), "prepare(scan)")
-        if self.overlap:
+        if self.overlap and pst != st:
             main.wait_stream(self.prep_stream)
         _lib.check(lib.vfm_match_search_coarse(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
                                                r.sws.data_ptr(), r.sws.numel(), st), "search(coarse)")
