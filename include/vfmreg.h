@@ -278,6 +278,8 @@ int vfm_debug_set_coarse_variant(int qsets);
 int vfm_debug_match_stats(void *ws, int64_t n, int64_t m, int32_t *out64_host);
 /* the counters are collected only while this switch is on (they cost same-address atomics) */
 int vfm_debug_set_match_stats(int on);
+/* ViT GEMM wave tile / prefetch depth for A/B runs: NT * 100 + PF for N <= 512 and N > 512 (see csrc/vit.hip) */
+int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
 /* timing experiments only: overrides the coarse window of the sparse kernel (0 = default); results become wrong */
 int vfm_debug_set_coarse_window(float w);
 int vfm_debug_set_coarse_slices(int slices);

@@ -156,7 +156,6 @@ __global__ __launch_bounds__(256) void vit_preprocess_kernel(const uint8_t* __re
 //    lane <-> token (column), registers <-> channels (rows): 4 consecutive channels per group.
 // ---------------------------------------------------------------------------------------------
 enum Epi { EPI_PATCH = 0, EPI_QKV = 1, EPI_RESID = 2, EPI_GELU = 3 };
-constexpr int GEMM_PF = 8;  // k-steps of operand fragments in flight per wave
 
 struct GemmArgs {
     const uint4* A;    // activations, fragment tiles [M/32][KS][64]
@@ -178,7 +177,7 @@ __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f +
 
 // NT = 32-channel tiles per wave (2 for the wide GEMMs, 1 for N = dim so that 66 x 12 = 792 waves
 // cover the chip instead of 396).
-template <int EPI, int NT>
+template <int EPI, int NT, int PF>
 __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -194,8 +193,7 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     // The grid is ~1 wave per SIMD, so nothing hides a load's L2 round trip except the wave itself:
-    // keep GEMM_PF k-steps of operand fragments in flight in a register ring.
-    constexpr int PF = GEMM_PF;
+    // keep PF k-steps of operand fragments in flight in a register ring.
     uint4 ra[PF], rw[NT][PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i)
@@ -517,21 +515,38 @@ inline VitWs carve_vit(void* p, const Dims& d) {
     return w;
 }
 
-template <int EPI>
-int launch_gemm(const GemmArgs& g, hipStream_t st) {
-    if (g.N <= 512) {  // narrow output: 32-channel wave tiles so the grid covers the chip
-        const int waves = (g.M / 32) * (g.N / 32);
-        hipLaunchKernelGGL((vit_gemm_kernel<EPI, 1>), dim3(ceil_div(waves, 4)), dim3(256), 0, st, g);
-        VFM_CHECK_LAUNCH("vit_gemm_kernel");
-        return VFM_OK;
-    }
-    const int waves = (g.M / 32) * (g.N / 64);
-    hipLaunchKernelGGL((vit_gemm_kernel<EPI, 2>), dim3(ceil_div(waves, 4)), dim3(256), 0, st, g);
+int g_vit_cfg_narrow = 108, g_vit_cfg_wide = 108;  // (NT * 100 + PF) for N <= 512 / N > 512 (vfm_debug_set_vit_gemm)
+
+template <int EPI, int NT, int PF>
+int launch_gemm_cfg(const GemmArgs& g, hipStream_t st) {
+    const int waves = (g.M / 32) * (g.N / (32 * NT));
+    hipLaunchKernelGGL((vit_gemm_kernel<EPI, NT, PF>), dim3(ceil_div(waves, 4)), dim3(256), 0, st, g);
     VFM_CHECK_LAUNCH("vit_gemm_kernel");
     return VFM_OK;
 }
 
+// Wave tile (NT x 32 channels) and prefetch depth (PF k-steps).  Round 2 measurements on 6 x 1200 x 1600 (tools/ab_vit.py,
+// profiles/r02_pmc_vit.json): a wave lives ~2.5 us inside kernels that take 10-17 us -- the forward is bound by the
+// ~5 us floor of each of its 87 launches, not by L2 latency or bandwidth: PF = 8 / 16 / 24 make no difference, 32-channel
+// tiles everywhere (twice the waves) give 0.76 instead of 0.82 ms, 64 x 64 wave tiles and row-complete workgroups with the
+// LayerNorm fused into the epilogue (63 launches, but 66 workgroups per GEMM) gave 1.04 ms and were removed again.
+template <int EPI>
+int launch_gemm(const GemmArgs& g, hipStream_t st) {
+    const int cfg = g.N <= 512 ? g_vit_cfg_narrow : g_vit_cfg_wide;
+    switch (cfg) {
+        case 116: return launch_gemm_cfg<EPI, 1, 16>(g, st);
+        case 208: return launch_gemm_cfg<EPI, 2, 8>(g, st);
+        default: return launch_gemm_cfg<EPI, 1, 8>(g, st);
+    }
+}
+
 }  // namespace
+
+VFM_EXPORT int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg) {
+    g_vit_cfg_narrow = narrow_cfg ? narrow_cfg : 108;
+    g_vit_cfg_wide = wide_cfg ? wide_cfg : 108;
+    return VFM_OK;
+}
 
 VFM_EXPORT size_t vfm_vit_weights_bytes(const vfm_vit_config* cfg) { return cfg ? make_layout(cfg).total : 0; }
 

@@ -72,6 +72,7 @@ SIGNATURES = {
     "vfm_debug_match_stats": (C.c_int, [c_vp, c_i64, c_i64, c_vp]),
     "vfm_debug_set_match_stats": (C.c_int, [C.c_int]),
     "vfm_debug_set_coarse_window": (C.c_int, [C.c_float]),
+    "vfm_debug_set_vit_gemm": (C.c_int, [C.c_int, C.c_int]),
     "vfm_debug_set_coarse_variant": (C.c_int, [C.c_int]),
     "vfm_debug_set_coarse_slices": (C.c_int, [C.c_int]),
     "vfm_debug_set_ransac_exact_only": (C.c_int, [C.c_int]),
