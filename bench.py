@@ -240,6 +240,8 @@ def main():
     lib = _lib.load()
     if os.environ.get("VFM_VARIANT"):  # A/B runs (tools/r02_prof.sh): 4 = dense per-chunk records + select kernel
         lib.vfm_debug_set_coarse_variant(int(os.environ["VFM_VARIANT"]))
+    if os.environ.get("VFM_SLICES"):   # A/B runs: number of map slices of the coarse pass (0 = heuristic)
+        lib.vfm_debug_set_coarse_slices(int(os.environ["VFM_SLICES"]))
     n, m, d = args.n, args.m, DIM
     # Global scene pairs: pair p runs on rank p mod world and is generated ON ITS OWNER from
     # seed 42 + p (D.2).  They are resident in HBM before the timed region starts.

@@ -38,7 +38,8 @@ def run(label, variant, window):
 
 for rep in range(2):
     run("dense records (variant 4)", 4, 0.0)
-    run("sparse records (default)", 0, 0.0)
+    run("sparse records + seed units (default)", 0, 0.0)
+    run("sparse records, no seed units (variant 7)", 7, 0.0)
     run("sparse, rare path never taken (window -1: timing only)", 0, -1.0)
     run("sparse, window 1e-4 (timing only)", 0, 1e-4)
 lib.vfm_debug_set_coarse_variant(0)

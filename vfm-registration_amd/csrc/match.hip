@@ -235,6 +235,11 @@ struct CoarseArgs {
     // within `window` of the query's running maximum at that time -- a superset of the rows within `window` of the
     // final maximum, which is all the exact decision needs
     const float* qinv;   // [npad] 1/|query row| (0 for zero rows: they record nothing, match_rescore_kernel decides them)
+    // seed units (sparse path): the first seed_parts * seed_chunks chunks of the map are taken by short workgroups at the
+    // head of the grid, seed_parts per query block, so that every later unit of a query block starts from a published
+    // maximum (a fresh running maximum breaks records at rate ~1/k per row; with 55 slices, 15 % of the units used to
+    // start unseeded and the record-breaking phase cost the kernel 5 %)
+    int seed_parts, seed_chunks, nseed_pad;
     unsigned* rec_cnt;   // [npad] records appended per query (may exceed rcap: overflow)
     uint2* rec;          // [npad][rcap] (map row, score bits)
     int rcap;
@@ -249,15 +254,25 @@ struct CoarseUnit {
 };
 __device__ __forceinline__ CoarseUnit coarse_unit(const CoarseArgs& a) {
     const int total = a.nqb * a.nslices;
-    const int bid = blockIdx.x;
+    int bid = blockIdx.x;
+    const int seed_total = a.seed_parts * a.seed_chunks;  // chunks [0, seed_total) belong to the seed units
+    if (bid < a.nseed_pad) {  // nseed_pad is a multiple of 8: the XCD phase of the remaining grid is unchanged
+        CoarseUnit u;
+        u.qb = bid / a.seed_parts;
+        u.c0 = (bid - u.qb * a.seed_parts) * a.seed_chunks;
+        u.ntiles = (u.qb < a.nqb) ? a.seed_chunks * 4 : 0;  // padding workgroups of the seed round: nothing to do
+        return u;
+    }
+    bid -= a.nseed_pad;
     const int xcd = bid & 7, within = bid >> 3;
     const int qn = total >> 3, rn = total & 7;
     const int unit = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + within;
     const int slice = unit / a.nqb;
     CoarseUnit u;
     u.qb = unit - slice * a.nqb;
-    u.c0 = (int)(((long long)slice * a.nchunks) / a.nslices);
-    const int c1 = (int)(((long long)(slice + 1) * a.nchunks) / a.nslices);
+    const int rest = a.nchunks - seed_total;
+    u.c0 = seed_total + (int)(((long long)slice * rest) / a.nslices);
+    const int c1 = seed_total + (int)(((long long)(slice + 1) * rest) / a.nslices);
     u.ntiles = (c1 - u.c0) * 4;
     return u;
 }
@@ -485,6 +500,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
 
     const CoarseUnit cu = coarse_unit(a);
     const int qb = cu.qb, c0 = cu.c0, ntiles = cu.ntiles;
+    if (ntiles == 0) return;  // uniform: padding workgroup of the seed round
     const int qt = qb * 8 + wave;  // this wave's 32-query tile
 
     const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS unsigned char*)smem;
@@ -517,7 +533,10 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
     unsigned* lrec_count = reinterpret_cast<unsigned*>(lrec + LREC_CAP);
     if constexpr (SPARSE) {
         if (qt < a.nq_tiles) {
-            runmax = a.qmax[(size_t)qt * 32 + (lane & 31)];  // published by earlier units (any stale value is valid)
+            // published by earlier units (any stale value is valid).  Device-scope load: the publishing atomicMax is
+            // performed at device scope, but a plain load could be served from this XCD's own (non-coherent) L2 and
+            // keep returning the zero it cached at the start of the launch.
+            runmax = __hip_atomic_load(a.qmax + (size_t)qt * 32 + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // a zero query row scores exactly 2.0 against every map row: it would record all of them.  Its answer is
             // fixed (index 0, score 0): park its maximum at the largest float so that nothing passes the threshold.
             if (a.qinv[(size_t)qt * 32 + (lane & 31)] == 0.0f) runmax = 0x7F7FFFFFu;
@@ -535,7 +554,8 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
     auto step_tail = [&](int t0, const floatx16& p0, const floatx16& p1) __attribute__((always_inline)) {
         const long long row0 = ((long long)c0 * 4 + t0) * TILE_ROWS;
         const int half4 = 4 * (lane >> 5);
-        if (row0 + 2 * TILE_ROWS > a.m_valid) {  // wave-uniform, last tiles of the map only: zero-padded rows score exactly
+        const bool pad = row0 + 2 * TILE_ROWS > a.m_valid;
+        if (pad) {  // wave-uniform, last tiles of the map only: zero-padded rows score exactly
             s1 = 0u;                                // 2.0 and must neither raise the maximum nor be recorded
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -555,19 +575,30 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
             // Hits go to a workgroup buffer in LDS (slot from an LDS atomic: waits on lgkmcnt only).  A returning
             // GLOBAL atomic here would make the wave wait on vmcnt(0), i.e. on every LDS-DMA tile in flight: measured
             // +9 % kernel time.  The buffer is flushed to the per-query lists after the last step.
+            // The 32 accumulators are searched in groups of four (3 max + 1 test per group, element tests only inside a
+            // group that holds a hit): an entry costs ~70 instead of ~250 instructions -- the whole wave pays for it.
             const unsigned ql = (unsigned)(wave * 32 + (lane & 31));
+            auto emit = [&](unsigned x, long long row) __attribute__((always_inline)) {
+                const unsigned slot = atomicAdd(lrec_count, 1u);
+                if (slot < (unsigned)LREC_CAP) {
+                    lrec[slot] = make_uint2((ql << 24) | (unsigned)row, x);
+                } else {  // buffer full (a fresh maximum meeting a duplicate-rich map): straight to the list
+                    const size_t qi = (size_t)qt * 32 + (lane & 31);
+                    const unsigned gs = atomicAdd(a.rec_cnt + qi, 1u);
+                    if (gs < (unsigned)a.rcap) a.rec[qi * (size_t)a.rcap + gs] = make_uint2((unsigned)row, x);
+                }
+            };
 #pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const unsigned x = __float_as_uint(r < 16 ? p0[r & 15] : p1[r & 15]);
-                const long long row = row0 + (r >> 4) * TILE_ROWS + (r & 3) + 8 * ((r & 15) >> 2) + half4;
-                if (x >= thr && row < a.m_valid) {
-                    const unsigned slot = atomicAdd(lrec_count, 1u);
-                    if (slot < (unsigned)LREC_CAP) {
-                        lrec[slot] = make_uint2((ql << 24) | (unsigned)row, x);
-                    } else {  // buffer full (a fresh maximum meeting a duplicate-rich map): straight to the list
-                        const size_t qi = (size_t)qt * 32 + (lane & 31);
-                        const unsigned gs = atomicAdd(a.rec_cnt + qi, 1u);
-                        if (gs < (unsigned)a.rcap) a.rec[qi * (size_t)a.rcap + gs] = make_uint2((unsigned)row, x);
+            for (int g4 = 0; g4 < 8; ++g4) {
+                unsigned x[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = __float_as_uint(g4 < 4 ? p0[4 * g4 + e] : p1[4 * (g4 - 4) + e]);
+                if (max(max(x[0], x[1]), max(x[2], x[3])) >= thr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // accumulator register r = 4 (g4 & 3) + e of tile (g4 >> 2): row (r & 3) + 8 (r >> 2) + 4 * half
+                        const long long row = row0 + (g4 >> 2) * TILE_ROWS + e + 8 * (g4 & 3) + half4;
+                        if (x[e] >= thr && (!pad || row < a.m_valid)) emit(x[e], row);
                     }
                 }
             }
@@ -1772,6 +1803,7 @@ thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 // set through vfm_debug_set_coarse_variant for A/B runs
 int g_coarse_qsets = 0;
 float g_window_override = 0.0f;  // vfm_debug_set_coarse_window: timing experiments only (results are wrong)
+int g_seed_units = 1;   // vfm_debug_set_coarse_variant(7): no seed units (A/B)
 int g_match_stats = 0;  // vfm_debug_set_match_stats: per-query counters cost ~0.5 ms of same-address atomics per search
 // 4 = pipelined kernel with the DENSE per-chunk records + match_select_kernel (round-1 path; A/B reference)
 
@@ -1792,7 +1824,7 @@ int launch_coarse_pipe(const CoarseArgs& a, hipStream_t st) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((match_coarse_pipe_kernel<KSTEPS, SPARSE>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((match_coarse_pipe_kernel<KSTEPS, SPARSE>), dim3(a.nseed_pad + a.nqb * a.nslices), dim3(512), lds, st, a);
     return VFM_OK;
 }
 
@@ -1869,6 +1901,7 @@ CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, 
     a.first_pad_chunk = (int)(m / CHUNK_ROWS);
     a.row_bias = nullptr;
     a.qinv = Q.inv;
+    a.seed_parts = a.seed_chunks = a.nseed_pad = 0;
     a.rec_cnt = nullptr;
     a.rec = nullptr;
     a.rcap = 0;
@@ -1891,6 +1924,12 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
         a.rec_cnt = w.rec_cnt;
         a.rec = w.rec;
         a.rcap = w.rcap;
+        if (g_seed_units && a.nchunks >= 256 && a.nqb <= 256) {  // seed units: one short round at the head of the grid
+            a.seed_parts = 256 / a.nqb < 4 ? 256 / a.nqb : 4;
+            a.seed_chunks = 5;
+            a.nseed_pad = (a.nqb * a.seed_parts + 7) / 8 * 8;
+            a.nslices = choose_slices(a.nqb, a.nchunks - a.seed_parts * a.seed_chunks);
+        }
         VFM_CHECK_HIP(hipMemsetAsync(w.rec_cnt, 0, (size_t)a.npad * sizeof(unsigned), st));
     }
     VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, 64 * sizeof(int), st));
@@ -2215,6 +2254,8 @@ VFM_EXPORT int vfm_debug_set_coarse_slices(int slices) {
     return VFM_OK;
 }
 VFM_EXPORT int vfm_debug_set_coarse_variant(int qsets) {
+    g_seed_units = qsets == 7 ? 0 : 1;
+    if (qsets == 7) qsets = 0;
     g_coarse_qsets = qsets;
     return VFM_OK;
 }
