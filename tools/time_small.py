@@ -4,7 +4,9 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "vfm-registration_amd"))
 import torch
-from vfmreg import synth
+from vfmreg import synth, _lib
+import os
+_lib.load().vfm_debug_set_coarse_variant(int(os.environ.get('VFM_VARIANT', '0')))
 from vfmreg.pipeline import RegistrationPipeline
 for (n, m) in ((300, 50000), (1500, 100000), (2000, 200000), (20000, 200000)):
     p = synth.make_pair_device(n, m, 384, seed=1)

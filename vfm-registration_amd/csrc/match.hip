@@ -1760,11 +1760,13 @@ inline SearchWs carve_search(void* p, int64_t n, int64_t m) {
     w.cand_cnt = c.take<int>((size_t)npad);
     w.cap = cand_cap(mpad);
     w.cand = c.take<unsigned>((size_t)npad * (size_t)w.cap);
-    w.fb_count = c.take<int>(64);
     w.fb_list = c.take<int>((size_t)npad);
+    // zeroed before every search by ONE memset: [fb_count (64, padded to 256 B) | qmax (npad) | rec_cnt (npad)]; npad is a
+    // multiple of 256, so the three arrays are contiguous under the carver's 256-byte alignment
+    w.fb_count = c.take<int>(64);
     w.qmax = c.take<unsigned>((size_t)npad);
-    w.rcap = FILTER_LDS_ROWS;
     w.rec_cnt = c.take<unsigned>((size_t)npad);
+    w.rcap = FILTER_LDS_ROWS;
     w.rec = c.take<uint2>((size_t)npad * (size_t)w.rcap);
     w.bytes = c.used();
     return w;
@@ -1808,8 +1810,10 @@ int g_match_stats = 0;  // vfm_debug_set_match_stats: per-query counters cost ~0
 // 4 = pipelined kernel with the DENSE per-chunk records + match_select_kernel (round-1 path; A/B reference)
 
 // inner-product searches with d <= 384 use the sparse row-level records of match_coarse_pipe_kernel<., true>
-inline bool use_sparse(int d, int64_t m) {
-    return d <= 384 && d % 128 == 0 && m < (1ll << 24) && (g_coarse_qsets == 0 || g_coarse_qsets == 3);
+// (from 3 query blocks on: with 1-2 blocks every unit of the grid runs at once, none is seeded, and the dense records
+// measured faster -- 244 vs 282 us per registration at 300 x 50000)
+inline bool use_sparse(int d, int64_t n, int64_t m) {
+    return d <= 384 && d % 128 == 0 && m < (1ll << 24) && n > 2 * QBLOCK && (g_coarse_qsets == 0 || g_coarse_qsets == 3);
 }
 
 // queries per workgroup of the coarse kernel that do_search_coarse will launch
@@ -1920,7 +1924,7 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
         if (d != 640 && d != 768) return vfm_fail(VFM_EINVAL, "row bias needs the 4-wave coarse kernel (K = 640 / 768), got %d", d);
         a.row_bias = B.inv;
     }
-    if (inner_product && use_sparse(d, m)) {
+    if (inner_product && use_sparse(d, n, m)) {
         a.rec_cnt = w.rec_cnt;
         a.rec = w.rec;
         a.rcap = w.rcap;
@@ -1930,10 +1934,8 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
             a.nseed_pad = (a.nqb * a.seed_parts + 7) / 8 * 8;
             a.nslices = choose_slices(a.nqb, a.nchunks - a.seed_parts * a.seed_chunks);
         }
-        VFM_CHECK_HIP(hipMemsetAsync(w.rec_cnt, 0, (size_t)a.npad * sizeof(unsigned), st));
     }
-    VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, 64 * sizeof(int), st));
-    VFM_CHECK_HIP(hipMemsetAsync(w.qmax, 0, (size_t)a.npad * sizeof(unsigned), st));
+    VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, 256 + 2 * (size_t)a.npad * sizeof(unsigned), st));  // fb_count | qmax | rec_cnt
     int rc;
     switch (d / 16) {
         case 8: rc = launch_coarse<8>(a, st); break;
@@ -1955,7 +1957,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     SearchWs w = carve_search(ws, n, m);
     const CoarseArgs a = coarse_args(Q, B, w, n, m, coarse_qblock(d));
     const float w2 = 2.0f * (float)(d / 16 + 4 + 2) * 5.9604645e-8f;
-    if (use_sparse(d, m)) {
+    if (use_sparse(d, n, m)) {
         hipLaunchKernelGGL(match_filter_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d,
                            DEFAULT_WINDOW, w2, w.qmax, w.rec_cnt, w.rec, w.rcap, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
         VFM_CHECK_LAUNCH("match_filter_refine_kernel");
