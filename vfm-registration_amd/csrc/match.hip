@@ -1776,24 +1776,32 @@ int g_force_slices = 0;  // experiment knob (vfm_debug_set_coarse_slices): 0 = h
 
 inline int choose_slices(int nqb, int nchunks) {
     if (g_force_slices > 0) return g_force_slices < nchunks ? g_force_slices : nchunks;
-    // Fill 256 CUs with whole "rounds" of workgroups (best tail efficiency; fewer, longer slices on ties).
-    // Trade-off measured at C2: every (query block, slice) unit re-reads its 256 queries (196 KB), so HBM
-    // traffic grows with the slice count (16 slices: 0.89 GB, 55 slices: 1.52 GB per launch) and the kernel
-    // alone is ~1 % faster with 16; but in the registration pipeline short workgroups hand compute units to
-    // the side stages more often -- 55 slices: 334 / 361 registrations/s vs 16 slices: 320 (two boxes;
-    // 81: 360, 107: 358, 133: 355).  Throughput wins, so the efficiency-maximising count stays.
+    // Fill 256 CUs with whole "rounds" of workgroups (tail efficiency).  Every (query block, slice) unit re-reads its 256
+    // queries (196 KB), so HBM / Infinity-Cache traffic grows with the slice count (C2: 55 slices 1.45 GB per launch).
+    // Round 2 sweep at C2 with the seeded sparse kernel (registrations/s in the pipeline): 14-16 slices 349, 21: 367,
+    // 29: 366, 35: 367, 42: 365, 48: 364, 55: 364 -- flat from ~8 rounds on.  So: among the counts within 1 % of the best
+    // tail efficiency take the SMALLEST that still gives >= 8 rounds (29 at C2); without such a count, the most efficient.
     int best_s = 1;
     double best_eff = -1.0;
     const int smax = nchunks < 64 ? nchunks : 64;
-    for (int s = 1; s <= smax; ++s) {
-        if (nchunks / s < 8 && s > 1) break;  // keep >= 32 tiles per workgroup
+    auto eff_of = [&](int s, long long* rounds_out) {
         const long long total = (long long)nqb * s;
         const long long rounds = (total + 255) / 256;
-        const double eff = (double)total / (double)(rounds * 256);
+        if (rounds_out) *rounds_out = rounds;
+        return (double)total / (double)(rounds * 256);
+    };
+    for (int s = 1; s <= smax; ++s) {
+        if (nchunks / s < 8 && s > 1) break;  // keep >= 32 tiles per workgroup
+        const double eff = eff_of(s, nullptr);
         if (eff > best_eff + 1e-9) {
             best_eff = eff;
             best_s = s;
         }
+    }
+    for (int s = 1; s < best_s; ++s) {
+        long long rounds;
+        const double eff = eff_of(s, &rounds);
+        if (rounds >= 8 && eff >= best_eff - 0.01) return s;
     }
     return best_s;
 }
