@@ -8,7 +8,8 @@
  *   - the caller owns every buffer.  Scratch is caller-provided and sized by the matching
  *     vfm_*_workspace_bytes(); no hidden allocation, no global state except the thread-local
  *     last-error string.  All work is enqueued on `stream` (a hipStream_t passed as void*);
- *     nothing synchronises the device, so calls can be chained and captured in a hipGraph.
+ *     nothing synchronises the device unless its comment says so (vfm_voxel_robin, vfm_debug_*), so the
+ *     registration path can be chained and captured in a hipGraph.
  *   - return 0 on success, a negative VFM_E* code otherwise; vfm_last_error() describes it.
  *
  * Reference interfaces replaced (paths relative to /root/reference):

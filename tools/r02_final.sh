@@ -13,3 +13,4 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -o 
 cd $R && bash tools/pmc_coarse.sh 2>&1 | tail -30
 cp $R/gpurun_out/pmc_coarse/pmc_match_coarse.json $O/ 2>/dev/null
 for i in 1 2 3 4 5 6 7; do cp $R/gpurun_out/pmc_coarse/p${i}_counter_collection.csv $O/pmc_pass${i}_counter_collection.csv 2>/dev/null; done
+cd $R && python tools/time_neardup.py --steps 20 --out $O/neardup.json > $O/neardup.log 2>&1
