@@ -1827,14 +1827,26 @@ inline bool use_sparse(int d, int64_t n, int64_t m) {
 // queries per workgroup of the coarse kernel that do_search_coarse will launch
 int coarse_qblock(int d) { return d > 512 ? 128 : QBLOCK; }
 
+// hipFuncSetAttribute is per device: remember which devices have been configured (one bit each)
+inline bool attr_done(unsigned long long mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return (mask >> (dev & 63)) & 1ull;
+}
+inline void attr_mark(unsigned long long& mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    mask |= 1ull << (dev & 63);
+}
+
 template <int KSTEPS, bool SPARSE>
 int launch_coarse_pipe(const CoarseArgs& a, hipStream_t st) {
     const int lds = 6 * KSTEPS * 1024 + (SPARSE ? SPARSE_LREC_CAP * 8 + 16 : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0ull;  // one bit per device
+    if (!attr_done(attr_set)) {
         VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_pipe_kernel<KSTEPS, SPARSE>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        attr_mark(attr_set);
     }
     hipLaunchKernelGGL((match_coarse_pipe_kernel<KSTEPS, SPARSE>), dim3(a.nseed_pad + a.nqb * a.nslices), dim3(512), lds, st, a);
     return VFM_OK;
@@ -1843,11 +1855,11 @@ int launch_coarse_pipe(const CoarseArgs& a, hipStream_t st) {
 template <int KSTEPS, int QSETS>
 int launch_coarse_v(const CoarseArgs& a, hipStream_t st) {
     const int lds = ring_depth(KSTEPS) * KSTEPS * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0ull;  // one bit per device
+    if (!attr_done(attr_set)) {
         VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_kernel<KSTEPS, QSETS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        attr_mark(attr_set);
     }
     hipLaunchKernelGGL((match_coarse_kernel<KSTEPS, QSETS>), dim3(a.nqb * a.nslices), dim3(512 / QSETS), lds, st, a);
     return VFM_OK;
@@ -1856,11 +1868,11 @@ int launch_coarse_v(const CoarseArgs& a, hipStream_t st) {
 template <int KSTEPS, int QSETS, int NBUF, bool BIAS>
 int launch_coarse_r(const CoarseArgs& a, hipStream_t st) {
     const int lds = NBUF * KSTEPS * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0ull;  // one bit per device
+    if (!attr_done(attr_set)) {
         VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_r_kernel<KSTEPS, QSETS, NBUF, BIAS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        attr_mark(attr_set);
     }
     if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
     hipLaunchKernelGGL((match_coarse_r_kernel<KSTEPS, QSETS, NBUF, BIAS>), dim3(a.nqb * a.nslices), dim3(256), lds, st, a);
@@ -1979,11 +1991,11 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     }
     {
         const size_t lds = (size_t)(64 * RS_STRIDE + RS_PAIRS) * sizeof(double) + (size_t)d * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static unsigned long long attr_set = 0ull;  // one bit per device
+        if (!attr_done(attr_set)) {
             VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_rescore_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            attr_set = true;
+            attr_mark(attr_set);
         }
         hipLaunchKernelGGL(match_rescore_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), lds, st, q, Q.inv, b, B.inv, n, m,
                            d, w.cand_cnt, w.cand, w.cap, idx_out, sim_out);

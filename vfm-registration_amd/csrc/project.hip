@@ -182,6 +182,10 @@ __device__ __forceinline__ void gather_point(const float* __restrict__ grid, int
         row = v;
         col = u;
     }
+    // The RobotCar / KITTI projections keep the reference's inclusive bound (u == W or v == H can be emitted,
+    // oxford_robotcar.py:356-357); the reference's `feat[v, u, :]` raises IndexError there.  Here such a point keeps a
+    // zero descriptor instead of reading past the image / the patch grid.
+    if (row < 0 || row >= Hup || col < 0 || col >= Wup) return;
     bool black = false;
     if (image) {
         const uint8_t* px = image + ((int64_t)row * Wup + col) * 3;
