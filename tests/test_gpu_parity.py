@@ -523,8 +523,10 @@ def test_pipeline_overlap_equals_serial(ops):
     torch.cuda.synchronize()
     ready = torch.cuda.Event()
     ready.record()
-    for ev in (None, ready):  # without / with the explicit "inputs are complete" event (stage 0 on its own stream)
-        over = RegistrationPipeline(n, m, d, n_iter=3000, max_corr_dist=0.5, overlap_ransac=True)
+    # default pipeline (prepare + coarse on the caller's stream, solve on a side stream) and round 1's three-stream form
+    # (prepare on its own stream), the latter without / with the explicit "inputs are complete" event
+    for ev, prep in ((None, False), (None, True), (ready, True)):
+        over = RegistrationPipeline(n, m, d, n_iter=3000, max_corr_dist=0.5, overlap_ransac=True, overlap_prepare=prep)
         got = []
         for rep in range(2):  # 10 registrations: every buffer set is reused several times
             for p in dv:
@@ -538,3 +540,37 @@ def test_pipeline_overlap_equals_serial(ops):
             for k in w:
                 assert torch.equal(w[k], g[k]), (k, i)
             assert np.linalg.norm(g["T"].cpu().numpy() - p["T_gt"]) < 0.05
+
+
+def test_register_sharded_with_the_overlapped_pipeline(ops):
+    """dist.register_sharded must wait for the side stream that produces a pipelined registration's results
+    (ADVICE r1): poses gathered through it equal the serial pipeline's, pair for pair."""
+    from vfmreg import dist as vdist
+    from vfmreg import synth
+    from vfmreg.pipeline import RegistrationPipeline
+    n, m, d = 1500, 9000, 384
+    pairs = [synth.make_pair(n, m, d, seed=300 + i) for i in range(6)]
+    dv = [{k: dev(v) for k, v in p.items() if k != "T_gt" and k != "match"} for p in pairs]
+    serial = RegistrationPipeline(n, m, d, n_iter=3000, max_corr_dist=0.5)
+    want = []
+    for p in dv:
+        o = serial.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
+        torch.cuda.synchronize()
+        want.append((o["T"].clone(), int(o["count"].item())))
+    over = RegistrationPipeline(n, m, d, n_iter=3000, max_corr_dist=0.5, overlap_ransac=True)
+    snaps = []
+
+    def register_pair(p):
+        o = over.register(dv[p]["q_desc"], dv[p]["q_xyz"], dv[p]["b_desc"], dv[p]["b_xyz"])
+        # the result buffers are reused two registrations later: snapshot them on the producing stream
+        with torch.cuda.stream(o["result_stream"]):
+            T, c = o["T"].clone(), o["count"].clone()
+            ev = torch.cuda.Event()
+            ev.record(o["result_stream"])
+        snaps.append((T, c))
+        return T, c, ev
+
+    poses, counts = vdist.register_sharded(len(pairs), register_pair, 0, 1, torch.device("cuda"))
+    torch.cuda.synchronize()
+    for i, (T, c) in enumerate(want):
+        assert torch.equal(poses[i], T) and int(counts[i].item()) == c, i
