@@ -128,6 +128,33 @@ def test_ransac_registration_end_to_end(orc):
         node.ransac_registration(voxel_map, raw_scan, "fpfh")
 
 
+def test_ransac_registration_retries_with_the_1m_subset(orc):
+    """RN:420-423: fewer than 75 correspondences from the 5 m voxel subset -> the 1 m subset is matched instead.  A small
+    scan (so that the 5 m subset holds < 75 inlier rows) drives product and oracle re-enactment through the retry; both
+    must take it and end with the same pose.  Also runs the ICP refinement of RN:331-344 on the result."""
+    from vfmreg import o3d
+    from vfmreg.mapping import VoxelHashMap
+    from vfmreg.registration import RegistrationNode
+    VoxelHashMap.quiet = True
+    voxel_map, raw_scan, p = _scene(n_scan=20000, n_map=30000, seed=21)
+    # a scan confined to a 24 m ball: a few dozen 5 m voxels, but a thousand 1 m voxels
+    raw_scan = raw_scan[np.linalg.norm(raw_scan[:, :3] - raw_scan[0, :3], axis=1) < 12.0]
+    assert 300 < len(raw_scan) < 4000
+    node = RegistrationNode(ransac_iterations=3000)
+    o3d.utility.random.seed(42)
+    pose, pose_icp = node.ransac_registration(voxel_map, raw_scan, "vfm", run_icp=True)
+    # did the first attempt really fall short?  (oracle pieces, container order)
+    scan = orc.voxel_down_sample(orc.voxel_down_sample(raw_scan, 0.5), 1.0)
+    mp = voxel_map[orc.voxel_hash_map_points(voxel_map, 1.0, 20)]
+    _, _, qi, _, _ = orc.get_vfm_correspondences(orc.voxel_down_sample(scan, 5.0), mp, 0.8)
+    assert 3 <= len(qi) < 75
+    ref_pose, ref_icp, corres = orc.ransac_registration_vfm(voxel_map, raw_scan, n_iter=3000, run_icp=True)
+    assert len(corres) >= 75
+    np.testing.assert_array_equal(pose, ref_pose)
+    np.testing.assert_array_equal(pose_icp, ref_icp)
+    assert np.linalg.norm(pose_icp - p["T_gt"]) < 0.05
+
+
 def test_find_correspondences_mutual_filter(orc):
     from vfmreg.registration import find_correspondences
     rng = np.random.default_rng(6)

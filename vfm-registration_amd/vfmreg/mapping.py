@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .voxelization import first_per_voxel, robin_order
+from .voxelization import to_device_rows
 
 
 def get_voxel_hash_map(config):
@@ -40,9 +40,11 @@ class VoxelHashMap:
 
     # ------------------------------------------------------------------ container
     def clear(self):
-        self._chunks = {}       # kind -> list of arrays, in insertion order (3-D and N-D points live in separate maps)
-        self._ordered = {}      # kind -> rows in container iteration order (cache)
-        self._dev = None        # cached device copy of the N-D map (IndexFlatIP.add)
+        # kind -> list of (rows, xyz64) device tensors in insertion order (3-D and N-D points live in separate maps);
+        # the rows keep the dtype they were given in (see voxelization.to_device_rows)
+        self._chunks = {}
+        self._ordered = {}      # kind -> (rows, xyz64) in container iteration order (cache)
+        self._dev = None        # cached (descriptors fp32, xyz fp64) of the N-D map (IndexFlatIP.add)
 
     @staticmethod
     def _kind(width: int) -> str:
@@ -62,73 +64,102 @@ class VoxelHashMap:
         points = np.asarray(points)
         if points.ndim != 2 or points.shape[1] < 3:
             raise ValueError("Invalid shape")  # mapping.py:86
-        kind = self._kind(points.shape[1])
-        pts = np.ascontiguousarray(points, dtype=np.float64)  # pybind: forcecast to double (stl_vector_eigen.h:73-86)
-        if len(pts) == 0:
+        if len(points) == 0:
             return
+        self.add_points_device(*to_device_rows(points))
+
+    def add_points_device(self, rows: torch.Tensor, xyz64: torch.Tensor):
+        """add_points on rows that are already on the device (rows [n, w] fp32 / fp64, xyz64 [n, 3] fp64)."""
+        kind = self._kind(rows.shape[1])
         # VoxelBlock::AddPoint keeps a point iff its voxel holds fewer than max_points_per_voxel points
         # (VoxelHashMap.hpp:55-62).  The points already stored come first and are all within the cap,
         # so "first K per voxel of [stored..., new...]" restricted to the new rows is exactly that rule.
         stored = self._chunks.get(kind, [])
-        if stored and stored[0].shape[1] != pts.shape[1]:
+        if stored and stored[0][0].shape[1] != rows.shape[1]:
             raise ValueError("Invalid shape")
-        n_old = sum(len(a) for a in stored)
-        xyz = np.concatenate([a[:, :3] for a in stored] + [pts[:, :3]], axis=0) if n_old else pts[:, :3]
-        keep = first_per_voxel(xyz, self.voxel_size, self.max_points_per_voxel)
+        n_old = sum(len(r) for r, _ in stored)
+        cat = torch.cat([x for _, x in stored] + [xyz64], dim=0) if n_old else xyz64
+        keep = ops.voxel_first(cat, self.voxel_size, self.max_points_per_voxel)
         keep_new = keep[keep >= n_old] - n_old
-        self._chunks.setdefault(kind, []).append(pts[keep_new])
+        if stored and stored[0][0].dtype != rows.dtype:   # mixed precisions: everything to double, as pybind would
+            stored[:] = [(r.double(), x) for r, x in stored]
+            rows = rows.double()
+        self._chunks.setdefault(kind, []).append((rows[keep_new], xyz64[keep_new]))
         self._ordered.pop(kind, None)
         self._dev = None
 
-    def _cloud(self, kind: str) -> Optional[np.ndarray]:
-        """Rows of one of the three maps as the reference walks it (VoxelHashMap.cpp:628-676)."""
-        arrs = self._chunks.get(kind)
-        if not arrs:
+    def _cloud(self, kind: str):
+        """(rows, xyz64) of one of the maps as the reference walks it (VoxelHashMap.cpp:628-676), on the device."""
+        chunks = self._chunks.get(kind)
+        if not chunks:
             return None
         if kind not in self._ordered:
-            rows = np.concatenate(arrs, axis=0)
+            rows = torch.cat([r for r, _ in chunks], dim=0) if len(chunks) > 1 else chunks[0][0]
+            xyz = torch.cat([x for _, x in chunks], dim=0) if len(chunks) > 1 else chunks[0][1]
             # every stored row is a kept one: replaying them reproduces the container (voxels are created
             # by their first point, which is always kept)
-            order = robin_order(rows, self.voxel_size, self.max_points_per_voxel, reserve=False, hash_mul=ops.HASH_MAP)
+            order = ops.voxel_robin(xyz, self.voxel_size, self.max_points_per_voxel, reserve=False, hash_mul=ops.HASH_MAP)
             assert len(order) == len(rows)
-            self._ordered[kind] = rows[order]
+            self._ordered[kind] = (rows[order], xyz[order])
         return self._ordered[kind]
 
-    def point_cloud(self) -> np.ndarray:
+    def xyz_map(self) -> "VoxelHashMap":
+        """The 3-D map ``add_points(points[:, :3])`` would build from the same rows (registration_node.py:290-293 builds
+        it next to the N-D one): same voxels, same kept points, same container order -- shared, not recomputed."""
+        m = VoxelHashMap(self.voxel_size, self.max_distance, self.max_points_per_voxel)
+        m._chunks["3"] = [(x, x) for _, x in self._chunks.get("n", [])]
+        if "n" in self._ordered:
+            m._ordered["3"] = (self._ordered["n"][1], self._ordered["n"][1])
+        return m
+
+    def point_cloud_device(self) -> Optional[torch.Tensor]:
         for kind in ("3", "n"):  # VoxelHashMap.cpp:631-659: map_, else map_n_ (else map_x_)
             c = self._cloud(kind)
             if c is not None:
-                return np.ascontiguousarray(c[:, :3])
-        return np.zeros((0, 3))
+                return c[1]
+        return None
+
+    def point_cloud(self) -> np.ndarray:
+        x = self.point_cloud_device()
+        return x.cpu().numpy() if x is not None else np.zeros((0, 3))
 
     def point_cloud_n(self) -> np.ndarray:
         c = self._cloud("n")  # VoxelHashMap.cpp:664-676
-        return c if c is not None else np.zeros((0, 3))
+        if c is None:
+            return np.zeros((0, 3))
+        out = c[0].double().cpu().numpy()
+        out[:, :3] = c[1].cpu().numpy()
+        return out
 
     # ------------------------------------------------------------------ search
     def _device_map(self):
         if self._dev is None:
-            m = self.point_cloud_n()
-            desc = torch.from_numpy(np.ascontiguousarray(m[:, 3:], dtype=np.float32)).cuda()  # VoxelHashMap.cpp:472-473
-            xyz = torch.from_numpy(np.ascontiguousarray(m[:, :3])).cuda()
-            self._dev = (desc, xyz)
+            rows, xyz = self._cloud("n")
+            self._dev = (rows[:, 3:].float().contiguous(), xyz)   # VoxelHashMap.cpp:472-473: static_cast<float>
         return self._dev
 
-    def get_vfm_correspondence_indices(self, points: np.ndarray, min_cosine_similarity: float):
-        """(query_idx[K], map_idx[K], sim[N]) -- the indices behind get_vfm_correspondences."""
-        points = np.asarray(points)
+    def search_device(self, q_rows: torch.Tensor, min_cosine_similarity: float):
+        """Device form of the search: (query_idx int64[K], map_idx int64[K], sim fp32[N]) as device tensors."""
         b_desc, _ = self._device_map()
-        if points.ndim != 2 or points.shape[1] != b_desc.shape[1] + 3:
+        if q_rows.dim() != 2 or q_rows.shape[1] != b_desc.shape[1] + 3:
             raise RuntimeError("Unable to cast Python instance to C++ type: expected %d columns"
                                % (b_desc.shape[1] + 3))  # py::cast_error, stl_vector_eigen.h:76-78
-        q_desc = torch.from_numpy(np.ascontiguousarray(points[:, 3:], dtype=np.float32)).cuda()
+        q_desc = q_rows[:, 3:].float().contiguous()            # VoxelHashMap.cpp:478-481
         d = q_desc.shape[1]
         prec = ops.FAST if (d % 128 == 0 and 128 <= d <= 768) else ops.EXACT
         idx, sim = ops.match_ip_top1(q_desc, b_desc, prec)
         r = ops.threshold_compact(sim, idx, float(min_cosine_similarity), want_corres=True)
         k = int(r["count"].item())
-        corres = r["corres"][:k].cpu().numpy()
-        return corres[:, 0].astype(np.int64), corres[:, 1].astype(np.int64), sim.cpu().numpy()
+        corres = r["corres"][:k]
+        return corres[:, 0].long(), corres[:, 1].long(), sim
+
+    def get_vfm_correspondence_indices(self, points: np.ndarray, min_cosine_similarity: float):
+        """(query_idx[K], map_idx[K], sim[N]) -- the indices behind get_vfm_correspondences."""
+        points = np.asarray(points)
+        if self._cloud("n") is None or points.ndim != 2:
+            raise RuntimeError("Unable to cast Python instance to C++ type")
+        qi, mi, sim = self.search_device(to_device_rows(points)[0], min_cosine_similarity)
+        return qi.cpu().numpy(), mi.cpu().numpy(), sim.cpu().numpy()
 
     def get_vfm_correspondences(self, points: np.ndarray, max_correspondance_distance: float
                                 ) -> Tuple[np.ndarray, np.ndarray]:
@@ -136,7 +167,8 @@ class VoxelHashMap:
         threshold despite its name (kiss_icp_pybind.cpp:128-129)."""
         points = np.asarray(points)
         qi, mi, sim = self.get_vfm_correspondence_indices(points, max_correspondance_distance)
-        m = self.point_cloud_n()
+        m_xyz = self._device_map()[1]
         if not self.quiet:
             print(f"Points: {len(points)} | Corrs.: {len(qi)} | Outliers: 0 | Mean sim.: {float(sim.mean()) if len(sim) else 0.0}")
-        return np.asarray(points[qi, :3], dtype=np.float64), np.asarray(m[mi, :3], dtype=np.float64)
+        return (np.asarray(points[qi, :3], dtype=np.float64),
+                m_xyz[torch.from_numpy(mi).to(m_xyz.device)].cpu().numpy())

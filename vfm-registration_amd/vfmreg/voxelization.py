@@ -16,6 +16,22 @@ import torch
 from . import ops
 
 
+def to_device_rows(points: np.ndarray):
+    """One upload of a point block in its own dtype + the fp64 coordinates the containers key on (the pybind layer
+    force-casts every input to double, stl_vector_eigen.h:73-86; fp32 -> fp64 is exact, so the descriptors can stay in
+    the given dtype until they are cast to float for the search, VoxelHashMap.cpp:472-481)."""
+    rows = torch.from_numpy(np.ascontiguousarray(points)).cuda()
+    if rows.dtype not in (torch.float32, torch.float64):
+        rows = rows.double()
+    return rows, rows[:, :3].double().contiguous()
+
+
+def down_sample_device(rows: torch.Tensor, xyz64: torch.Tensor, voxel_size: float):
+    """voxel_down_sample on device-resident rows: (rows[order], xyz64[order], order) in the container's order."""
+    order = ops.voxel_robin(xyz64, voxel_size)
+    return rows[order], xyz64[order], order
+
+
 def first_per_voxel(points: np.ndarray, voxel_size: float, max_per_voxel: int = 1) -> np.ndarray:
     """Indices (ascending = input order) of the first ``max_per_voxel`` points of every voxel."""
     xyz = torch.from_numpy(np.ascontiguousarray(points[:, :3], dtype=np.float64)).cuda()
@@ -35,4 +51,6 @@ def voxel_down_sample(points: np.ndarray, voxel_size: float) -> np.ndarray:
         raise ValueError("Invalid shape")  # voxelization.py:37
     if len(points) == 0:
         return np.zeros((0, points.shape[1]), dtype=np.float64)
-    return np.asarray(points[robin_order(points, voxel_size)], dtype=np.float64)
+    rows, xyz64 = to_device_rows(points)
+    kept, _, _ = down_sample_device(rows, xyz64, voxel_size)   # gather on the device: only the survivors come back
+    return kept.cpu().numpy().astype(np.float64, copy=False)
