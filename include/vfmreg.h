@@ -209,7 +209,8 @@ int vfm_voxel_first(const double *pts, int64_t n, int64_t stride, double voxel_s
  * per voxel OF THIS ORDER.  info_host (nullable, HOST int64[4]): final bucket count, number of voxels,
  * largest probe distance, generations that needed the wrap-around path.  This entry point reads the
  * voxel count back (it synchronises `stream`); it fails with VFM_EINVAL where the reference container
- * would exceed its probe-distance limit (8192; 20-bit hash saturated). */
+ * would exceed its probe-distance limit (8192) or holds a run of more than 4096 occupied buckets (its 20-bit
+ * VoxelHash saturated: about 2^20 voxels and more -- the reference keeps doubling / overflows there). */
 #define VFM_VOXEL_HASH_DOWNSAMPLE 19349663u
 #define VFM_VOXEL_HASH_MAP 19349669u
 size_t vfm_voxel_robin_workspace_bytes(int64_t n);

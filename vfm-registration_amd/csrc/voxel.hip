@@ -30,6 +30,7 @@ namespace {
 
 constexpr int EMPTY_OWNER = -1;
 constexpr int RH_DIST_LIMIT = 8192;  // tsl::detail_robin_hash::bucket_entry::DIST_FROM_IDEAL_BUCKET_LIMIT (v1.2.1)
+constexpr int RH_MAX_CLUSTER = 4096;  // longest run of occupied buckets the per-cluster replay accepts
 constexpr int SMALL_CAP = 512;       // generations up to 1024 buckets are replayed by one thread in LDS
 
 struct Vox {
@@ -228,6 +229,15 @@ __global__ __launch_bounds__(256) void robin_cluster_kernel(const int* __restric
     }
     if (i == m - 1) cl_start[c + 1] = (int)m;
 }
+// longest cluster of the generation (geninfo[4]): a saturated table (20-bit VoxelHash with ~2^20 voxels) has clusters of
+// thousands of entries, which one thread per cluster would replay for seconds -- the host refuses those instead
+__global__ __launch_bounds__(256) void robin_maxlen_kernel(const int* __restrict__ cl_start, const int* __restrict__ cidx, int64_t m,
+                                                           int64_t* __restrict__ geninfo) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cidx[m - 1]) return;
+    const int len = cl_start[c + 1] - cl_start[c];
+    if (len > 64) atomicMax((unsigned long long*)(geninfo + 4), (unsigned long long)len);
+}
 // wrap analysis (one thread): w = entries whose bucket would be >= B; z = a bucket that stays empty once the w
 // wrapped entries have filled the first w free buckets; r = first entry whose rotated bucket is >= B - z_used.
 // geninfo: [0] w, [1] z, [2] rotation r for the CURRENT coordinates (z_used), [3] max dist (atomicMax by replay)
@@ -262,6 +272,7 @@ __global__ void robin_wrap_kernel(const int* __restrict__ cm, int64_t m, int64_t
     geninfo[1] = z;
     geninfo[2] = r;
     geninfo[3] = 0;
+    geninfo[4] = 0;
 }
 // one thread per cluster replays the insertions of its entries (arrival order) inside its own window
 __global__ __launch_bounds__(64) void robin_replay_kernel(const int* __restrict__ cl_start, const int* __restrict__ cl_base,
@@ -398,7 +409,7 @@ inline VoxelWs carve_voxel(void* p, int64_t n, bool robin) {
     w.counts = c.take<int64_t>(4);
     if (robin) {
         w.vfirst = c.take<int64_t>(nn);
-        w.geninfo = c.take<int64_t>(4);
+        w.geninfo = c.take<int64_t>(8);
         w.smallinfo = c.take<int64_t>(4);
         w.vhash = c.take<unsigned>(nn);
         w.slot_vid = c.take<int>((size_t)h);
@@ -555,6 +566,16 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
             hipLaunchKernelGGL(robin_cluster_kernel, dim3(gm), dim3(256), 0, st, w.flag, w.cidx, w.key_s, w.pos_s, m,
                                w.cl_of_pos, w.cl_start, w.cl_base, w.tab_dist);
             hipLaunchKernelGGL(robin_wrap_kernel, dim3(1), dim3(1), 0, st, w.cm, m, B, (int64_t)z, w.geninfo);
+            hipLaunchKernelGGL(robin_maxlen_kernel, dim3(gm), dim3(256), 0, st, w.cl_start, w.cidx, m, w.geninfo);
+            {
+                int64_t gl[5];
+                VFM_CHECK_HIP(hipMemcpyAsync(gl, w.geninfo, sizeof(gl), hipMemcpyDeviceToHost, st));
+                VFM_CHECK_HIP(hipStreamSynchronize(st));
+                if (gl[4] > RH_MAX_CLUSTER)
+                    return vfm_fail(VFM_EINVAL, "voxel_robin: a run of %lld occupied buckets -- the reference container's 20-bit "
+                                    "VoxelHash is saturated (%lld voxels in %lld buckets); not reproduced", (long long)gl[4],
+                                    (long long)m, (long long)B);
+            }
             int cbits = 1;
             while ((1ll << cbits) < m) ++cbits;
             tb = w.cub_bytes;
