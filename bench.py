@@ -245,15 +245,17 @@ def main():
     n, m, d = args.n, args.m, DIM
     # Global scene pairs: pair p runs on rank p mod world and is generated ON ITS OWNER from
     # seed 42 + p (D.2).  They are resident in HBM before the timed region starts.
+    if 0 < args.pairs < world:
+        raise SystemExit(f"--pairs {args.pairs} is smaller than the number of GPUs ({world})")
     num_pairs = args.pairs if args.pairs > 0 else world * args.steps
     mine = vdist.shard_pairs(num_pairs, rank, world)
     steps = len(mine) if args.pairs > 0 else args.steps
     n_res = max(1, min(len(mine), RESIDENT_MAX))
     pairs = [synth.make_pair_device(n, m, d, seed=42 + mine[j], device=dev) for j in range(n_res)]
     # --streams 2 (default): pipeline over independent scene pairs (BASELINE config C4: "one per stream"):
-    # the MFMA coarse pass of pair i+1 runs on the main stream while the operand preparation of pair i+2 and
-    # the filter / exact decision / RANSAC of pair i run on two side streams (vfmreg/pipeline.py).  Coarse
-    # passes never overlap each other, so the HIP-event duration of the coarse kernel stays a per-launch figure.
+    # operand preparation + the MFMA coarse pass of pair i+1 run on the main stream while the filter / exact decision /
+    # RANSAC of pair i run on a side stream (vfmreg/pipeline.py).  Coarse passes never overlap each other, so the
+    # HIP-event duration of the coarse kernel stays a per-launch figure.
     S = 2 if args.streams >= 2 else 1
     pipe = RegistrationPipeline(n, m, d, n_iter=args.iters, device=dev, overlap_ransac=(S == 2))
 
@@ -309,8 +311,8 @@ def main():
     torch.cuda.current_stream().wait_stream(match_stream)
     torch.cuda.synchronize()
     local_elapsed = time.perf_counter() - t0   # this rank's own work, before the gather (stragglers show up here)
-    gather_pairs = world * steps               # ranks with one pair less (ragged --pairs) pad with their last pose
-    all_poses, all_counts = vdist.gather_poses(res_T, res_c.reshape(-1), gather_pairs, rank, world)
+    # ragged --pairs (not a multiple of N): gather_poses pads the shorter ranks to ceil(pairs / N) rows
+    all_poses, all_counts = vdist.gather_poses(res_T[:steps], res_c[:steps].reshape(-1), num_pairs, rank, world)
     torch.cuda.synchronize()
     if grouped:
         dist.barrier()
@@ -332,7 +334,7 @@ def main():
         _lib.check(lib.vfm_prof_elapsed_ms(a, b, C.byref(ms)))
         durs.append(ms.value)
         lib.vfm_prof_events_destroy(a, b)
-    coarse_ms = sum(durs) / len(durs)
+    coarse_ms = sum(durs) / max(len(durs), 1)
 
     # the same kernel without the concurrent RANSAC stream (information only; not part of `value`)
     iso = []
@@ -352,7 +354,7 @@ def main():
     iso_ms = (sum(iso) / len(iso)) if iso else coarse_ms
 
     # sanity of the timed work: every pose of this rank must recover the planted transform of ITS pair
-    local_ids = [rank + world * i for i in range(steps)]
+    local_ids = mine[:steps] if args.pairs > 0 else [rank + world * i for i in range(steps)]
     errs = [float(np.linalg.norm(all_poses[g].cpu().numpy() - pairs[i % n_res]["T_gt"])) for i, g in enumerate(local_ids)]
     ncorr = int(all_counts[local_ids[-1]].item())
     T0 = all_poses[0].cpu().numpy()  # global pair 0 lives on rank 0
@@ -368,14 +370,14 @@ def main():
                 traffic_src = f"profiles/{name} (FETCH_SIZE / WRITE_SIZE from separate --pmc passes, corrected per MI355X_MICROARCH.md)"
                 break
         line = {
-            "metric": "registrations/sec (20k<->200k pts, 384-D)", "value": world * steps / elapsed,
-            "unit": "registrations/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak",
+            "metric": "registrations/sec (20k<->200k pts, 384-D)", "value": num_pairs / elapsed,
+            "unit": "registrations/s", "n_gpus": world, "steps": vdist.pairs_per_rank(num_pairs, world), "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / vdist.pairs_per_rank(num_pairs, world), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16 coarse pass (MFMA) + f32 refinement + f64 exact decision / f64 RANSAC",
             "data": "synthetic",
             "config": {"workload": f"C2: {n}-pt scan vs {m}-pt map, {d}-D descriptors precomputed and resident in "
                                    f"HBM, {args.iters} RANSAC iterations, cosine >= 0.8; map renormalised every step",
-                       "registrations_per_gpu": steps, "scene_pairs_total": world * steps,
+                       "registrations_per_gpu": vdist.pairs_per_rank(num_pairs, world), "scene_pairs_total": num_pairs,
                        "resident_scene_pairs_per_gpu": n_res, "pair_seed": "42 + global pair id, generated on the owning rank",
                        "parallelism": f"{world} GPU shard(s) x {S} stream(s), independent scene pairs (pair p -> rank p mod N)",
                        "collective": (f"one all_gather_into_tensor of the poses ({dist.get_backend()} = RCCL)" if grouped

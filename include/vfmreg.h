@@ -66,6 +66,9 @@ int vfm_match_ip_top1(const float *q, int64_t n, const float *b, int64_t m, int 
  * prepared operand holds 1/|row| and the fp16 MFMA-fragment image of the normalised rows. */
 size_t vfm_match_prepared_bytes(int64_t rows, int d);
 int vfm_match_prepare(const float *x, int64_t rows, int d, void *prepared, vfm_stream_t stream);
+/* two operands (the map and the scan of one registration, VHM:469-482) in ONE launch */
+int vfm_match_prepare2(const float *x1, int64_t rows1, void *prepared1, const float *x2, int64_t rows2,
+                       void *prepared2, int d, vfm_stream_t stream);
 size_t vfm_match_search_workspace_bytes(int64_t n, int64_t m, int d);
 int vfm_match_search_prepared(const float *q, const void *q_prepared, int64_t n, const float *b,
                               const void *b_prepared, int64_t m, int d, int64_t *idx_out,

@@ -108,7 +108,7 @@ class RegistrationPipeline:
         st = main.cuda_stream
         pst = st
         if self.overlap and not self.overlap_prepare:
-            if r.done is not None:
+            if r.done is not None and not r.done.query():
                 main.wait_event(r.done)                 # the solve stage that last read this set has finished
         elif self.overlap:
             # stage 0 on its own stream: it may run beside the coarse pass of the previous pair
@@ -120,9 +120,11 @@ class RegistrationPipeline:
                 self.prep_stream.wait_event(r.done)     # the solve stage that last read this set has finished
             pst = self.prep_stream.cuda_stream
         if not (reuse_map and r.map_key == b_desc.data_ptr()):
-            _lib.check(lib.vfm_match_prepare(b_desc.data_ptr(), self.m, self.d, r.bprep.data_ptr(), pst), "prepare(map)")
+            _lib.check(lib.vfm_match_prepare2(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
+                                              r.qprep.data_ptr(), self.d, pst), "prepare(map + scan)")
             r.map_key = b_desc.data_ptr() if reuse_map else None
-        _lib.check(lib.vfm_match_prepare(q_desc.data_ptr(), self.n, self.d, r.qprep.data_ptr(), pst), "prepare(scan)")
+        else:
+            _lib.check(lib.vfm_match_prepare(q_desc.data_ptr(), self.n, self.d, r.qprep.data_ptr(), pst), "prepare(scan)")
         if self.overlap and pst != st:
             main.wait_stream(self.prep_stream)
         _lib.check(lib.vfm_match_search_coarse(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
