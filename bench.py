@@ -400,7 +400,7 @@ def main():
                 extra["pose_delta_vs_oracle"] = delta
         else:
             line["cpu_baseline"] = None
-        if not args.no_extra and (n, m) == (N_SCAN, N_MAP):
+        if not args.no_extra and world == 1 and (n, m) == (N_SCAN, N_MAP):  # N > 1: the other ranks would idle at the barrier
             del pipe
             pairs.clear()
             torch.cuda.empty_cache()
