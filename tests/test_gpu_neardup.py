@@ -55,10 +55,11 @@ def test_manifold_map_equals_oracle(n, m, G, jitter):
     assert st[0] <= n // 50, st        # ... and the all-pairs fallback stayed the exception
 
 
-def test_refinement_overflow_falls_back_exactly_and_long_lists_do_not():
-    """> 64 rows tying within the fp32 margin (exact duplicates) end in the all-pairs kernel; ~290 candidate chunks in
-    the window (beyond round 1's cap of 40, below the list capacity min(#chunks, 2048)) are refined, not fallen back.
-    Both give the oracle's answer (ties -> lowest index)."""
+def test_many_exact_duplicates_and_long_lists_need_no_all_pairs_fallback():
+    """> 64 rows tying within the fp32 margin (100 exact duplicates): the refinement cannot thin them, the whole list goes
+    to the fp64 decision; ~290 candidate chunks in the window (beyond round 1's cap of 40, below the list capacity
+    min(#chunks, 2048)) are refined.  Neither needs the all-pairs kernel; both give the oracle's answer (ties -> lowest
+    index)."""
     from oracle import oracle as orc
     from vfmreg import ops
     rng = np.random.default_rng(3)
@@ -82,7 +83,7 @@ def test_refinement_overflow_falls_back_exactly_and_long_lists_do_not():
     np.testing.assert_array_equal(idx.cpu().numpy(), idx_ref)
     np.testing.assert_array_equal(sim.cpu().numpy(), sim_ref)
     assert (idx[:20].cpu().numpy() == dup_rows[0]).all()
-    assert st[0] == 20, st                                        # only the 20 queries of the duplicated row
+    assert st[0] == 0, st                                         # no all-pairs fallback
     assert st[8 + 9] >= 20, st                                    # 20 queries with 257..512 candidate entries
 
 

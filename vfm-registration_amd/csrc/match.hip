@@ -1126,6 +1126,8 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
             if (__any(row >= 0)) R.consider(row, R.score4(row));
         }
     }
+    if (R.overflow) return;  // > REFINE_KEEP rows tie within the fp32 margin (exact duplicates): the list stays as
+                             // match_select_kernel wrote it and match_rescore_kernel decides all of it in fp64
     R.finish(qi, mycand, cand_cnt, fb_count, fb_list, stats);
 }
 
@@ -1196,6 +1198,14 @@ __global__ __launch_bounds__(256) void match_filter_refine_kernel(const float* _
     for (int e0 = 0; e0 < ncand; e0 += 4) {
         const long long row = (e0 + R.g < ncand) ? (long long)lc[e0 + R.g] : -1;
         R.consider(row, R.score4(row));
+    }
+    if (R.overflow && ncand <= cap) {  // > REFINE_KEEP rows tie within the fp32 margin (exact duplicates): hand ALL
+        for (int e = lane; e < ncand; e += 64) {  // candidates to the fp64 decision instead of the all-pairs kernel
+            const unsigned row = lc[e];
+            mycand[e] = ((row / CHUNK_ROWS) << 8) | (row % CHUNK_ROWS);
+        }
+        if (lane == 0) cand_cnt[qi] = ncand;
+        return;
     }
     R.finish(qi, mycand, cand_cnt, fb_count, fb_list, stats);
 }
