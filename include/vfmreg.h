@@ -83,6 +83,15 @@ int vfm_match_search_coarse(const void *q_prepared, int64_t n, const void *b_pre
 int vfm_match_search_finish(const float *q, const void *q_prepared, int64_t n, const float *b,
                             const void *b_prepared, int64_t m, int d, int64_t *idx_out,
                             float *sim_out, void *ws, size_t ws_bytes, vfm_stream_t stream);
+/* _finish for a caller that keeps only matches with similarity >= gate (the cosine gate of
+ * GetVFMCorrespondences, VHM:501-511): a query whose best similarity is PROVABLY below `gate` is
+ * not resolved -- idx_out = -1, sim_out = -2.0 -- every other query gets the oracle's answer.  The
+ * proof comes from the int8 coarse pass' bounds (d = 256, 384 and n > 512); elsewhere the gate is
+ * ignored and every query is resolved. */
+int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_t n, const float *b,
+                                  const void *b_prepared, int64_t m, int d, int64_t *idx_out,
+                                  float *sim_out, void *ws, size_t ws_bytes, float gate,
+                                  vfm_stream_t stream);
 
 /* valid = !(D < min_cosine_similarity) (VHM:501-511), survivors in query order (VHM:587-600).
  * keep_out[k] = query index of the k-th survivor, *count_out = K.  corres_out (nullable,

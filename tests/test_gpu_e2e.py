@@ -106,7 +106,10 @@ def test_c3_end_to_end():
     qn, _ = orc.l2norm_rows(desc)
     bn, _ = orc.l2norm_rows(b_desc)
     idx, sim = orc.match_ip_top1(qn, bn)
-    np.testing.assert_array_equal(out["idx"].cpu().numpy(), idx)
+    got = out["idx"].cpu().numpy()
+    solved = got >= 0   # the pipeline leaves queries that provably cannot reach the cosine gate unresolved (-1, -2.0)
+    np.testing.assert_array_equal(got[solved], idx[solved])
+    assert (sim[~solved] < 0.8).all() and (out["sim"].cpu().numpy()[~solved] == -2.0).all()
     assert (sim[~seen] == 0).all()                                  # zero descriptors never match
     keep = orc.threshold_compact(sim, 0.8)
     k = int(out["count"].item())
@@ -151,8 +154,12 @@ def test_c5_solve_at_full_size():
     qn, _ = orc.l2norm_rows(p["q_desc"][rows].cpu().numpy())
     bn, _ = orc.l2norm_rows(p["b_desc"].cpu().numpy())
     idx_ref, sim_ref = orc.match_ip_top1(qn, bn)
-    np.testing.assert_array_equal(out["idx"][rows].cpu().numpy(), idx_ref)
-    np.testing.assert_array_equal(out["sim"][rows].cpu().numpy(), sim_ref)
+    got_i, got_s = out["idx"][rows].cpu().numpy(), out["sim"][rows].cpu().numpy()
+    solved = got_i >= 0   # unresolved rows (-1, -2.0): provably below the cosine gate
+    assert solved.sum() >= 5
+    np.testing.assert_array_equal(got_i[solved], idx_ref[solved])
+    np.testing.assert_array_equal(got_s[solved], sim_ref[solved])
+    assert (sim_ref[~solved] < 0.8).all() and (got_s[~solved] == -2.0).all()
     # solve parity on the GPU's correspondences
     corres = out["corres"][:k].cpu().numpy()
     r = orc.ransac_corr(p["q_xyz"].cpu().numpy(), p["b_xyz"].cpu().numpy(), corres, 10000.0, iters, seed=42)

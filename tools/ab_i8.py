@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""int8 coarse pass (variant 8) vs the fp16 one (variant 0): coarse-kernel time, record / candidate counts, finish time,
+and equality of the answers."""
+import ctypes as C
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "vfm-registration_amd"))
+from vfmreg import _lib, ops, synth  # noqa: E402
+
+lib = _lib.load()
+n, m, d = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (20000, 200000, 384)))
+p = synth.make_pair_device(n, m, d, seed=42)
+Q, B = ops.PreparedRows(p["q_desc"]), ops.PreparedRows(p["b_desc"])
+ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=torch.uint8, device="cuda")
+a, b = C.c_void_p(), C.c_void_p()
+_lib.check(lib.vfm_prof_events_create(C.byref(a), C.byref(b)))
+ms = C.c_float()
+st = torch.cuda.current_stream().cuda_stream
+res = {}
+import os
+VARIANTS = tuple(int(v) for v in os.environ.get("VFM_AB_VARIANTS", "0,9,8,0,9").split(","))
+for variant in VARIANTS:
+    lib.vfm_debug_set_coarse_variant(variant)
+    t, tf = [], []
+    idx = torch.empty(n, dtype=torch.int64, device="cuda")
+    sim = torch.empty(n, dtype=torch.float32, device="cuda")
+    for i in range(12):
+        lib.vfm_prof_arm(a, b)
+        _lib.check(lib.vfm_match_search_coarse(Q.buf.data_ptr(), n, B.buf.data_ptr(), m, d, ws.data_ptr(), ws.numel(), st))
+        torch.cuda.synchronize()
+        _lib.check(lib.vfm_prof_elapsed_ms(a, b, C.byref(ms)))
+        t0 = time.perf_counter()
+        _lib.check(lib.vfm_match_search_finish(p["q_desc"].data_ptr(), Q.buf.data_ptr(), n, p["b_desc"].data_ptr(), B.buf.data_ptr(), m, d,
+                                               idx.data_ptr(), sim.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        torch.cuda.synchronize()
+        if i >= 2:
+            t.append(ms.value)
+            tf.append(1e3 * (time.perf_counter() - t0))
+    lib.vfm_debug_set_match_stats(1)
+    _lib.check(lib.vfm_match_search_coarse(Q.buf.data_ptr(), n, B.buf.data_ptr(), m, d, ws.data_ptr(), ws.numel(), st))
+    _lib.check(lib.vfm_match_search_finish(p["q_desc"].data_ptr(), Q.buf.data_ptr(), n, p["b_desc"].data_ptr(), B.buf.data_ptr(), m, d,
+                                           idx.data_ptr(), sim.data_ptr(), ws.data_ptr(), ws.numel(), st))
+    stats = (C.c_int32 * 64)()
+    _lib.check(lib.vfm_debug_match_stats(ws.data_ptr(), n, m, stats))
+    lib.vfm_debug_set_match_stats(0)
+    s = list(stats)
+    print(f"variant {variant}: coarse {sum(t) / len(t):.3f} ms (min {min(t):.3f}), finish {sum(tf) / len(tf):.3f} ms; fallbacks {s[0]}, "
+          f"refined {s[1]}, candidates/query {s[2] / n:.2f}, kept {s[3]}, records/query {s[4] / n:.1f}, histogram {s[8:24]}", flush=True)
+    res[variant] = (idx.clone(), sim.clone())
+lib.vfm_debug_set_coarse_variant(0)
+if 0 in res and 9 in res:
+    print("idx equal:", bool((res[0][0] == res[9][0]).all()), " sim equal:", bool((res[0][1] == res[9][1]).all()),
+          " mismatches:", int((res[0][0] != res[9][0]).sum()))

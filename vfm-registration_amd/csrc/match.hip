@@ -27,6 +27,8 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef int intx16 __attribute__((ext_vector_type(16)));
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
@@ -49,6 +51,9 @@ constexpr int SPARSE_LREC_CAP = 1536;  // records a workgroup of the sparse coar
 constexpr float COARSE_OFFSET = 2.0f;   // accumulators start here: every coarse score is a
                                         // positive normal float, so uint order == float order
 constexpr float DEFAULT_WINDOW = 2.5e-3f;  // >= 2E, E = proven |coarse - exact| bound
+constexpr int I8_OFFSET = 1 << 30;  // int8 coarse pass: accumulators start here (scores positive: uint order == int order)
+constexpr int I8_GROUP = 128;       // rows that share one quantisation step (= CHUNK_ROWS: a record never mixes two steps)
+static_assert(I8_GROUP == 128, "match_select_kernel and the coarse records assume 128-row groups");
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
@@ -167,6 +172,184 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// int8 image of the rows (d = 256, 384) for the int8 coarse pass, plus (F16) the fp16 image above.
+// One workgroup (8 waves) per GROUP of 128 rows = one record chunk of the coarse pass.  The rows of a group share one
+// quantisation step  s = max|v| / 127  over the group's fp32-normalised elements v (no clipping, no tuning constant):
+//     q_k = rint(v_k / s) in [-127, 127],   e = v - s q  (measured in fp32, not assumed),   E = |e|_2 rounded up.
+// The integer score S = q_a . q_b of the MFMA is exact, so for rows a (step s_a) and b (step s_b)
+//     | v_a . v_b - s_a s_b S |  =  | (s_a q_a) . e_b + e_a . v_b |  <=  (|v_a| + E_a) E_b + E_a |v_b|     (Cauchy-Schwarz)
+// with |v| <= 1 + 2^-13 for fp32-normalised rows: match_select_kernel turns this into per-(query, chunk) bounds.
+// 16 waves x 8 rows: the group's rows stay in registers between phase 1 (1/|row|, group maximum) and phase 2 (quantise).
+// Layout: int8 fragment tiles of the 32x32x32 MFMA: unit (tile, s, h, p) = 16 int8 = row tile*32+p, k = 32 s + 16 h .. +15,
+// at uint4 index tile*(d/32*64) + s*64 + h*32 + p.
+// ---------------------------------------------------------------------------------------------
+struct PrepOut {
+    float* inv;       // [rows_pad]
+    uint4* tiles;     // fp16 fragment tiles
+    float* err;       // [rows_pad] E per row
+    unsigned* emax;   // bits of the operand's maximum E (atomicMax; zeroed by the host before the launch)
+    float* gstep;     // [rows_pad / 128] quantisation step of the group
+    float* gerr;      // [rows_pad / 128] maximum E of the group
+    uint4* tiles8;    // int8 fragment tiles
+};
+template <bool F16>
+__global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restrict__ x, int64_t rows, int d, PrepOut o, int groups1,
+                                                          const float* __restrict__ x2, int64_t rows2, PrepOut o2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned amax_bits, emax_bits;
+    constexpr int RPW = I8_GROUP / 16;  // rows per wave: 16 waves x 8 rows, all of them in registers between the two phases
+    int grp = blockIdx.x;
+    if (grp >= groups1) {  // uniform per workgroup: the second operand rides in the same grid
+        grp -= groups1;
+        x = x2;
+        rows = rows2;
+        o = o2;
+    }
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int nchunks = d >> 2;  // float4 chunks per row (<= 96): lane l owns chunks l and l + 64
+    unsigned char* img8 = smem;                                                  // [4 tiles][d/32 * 64 units][16]
+    _Float16* img16 = reinterpret_cast<_Float16*>(smem + (size_t)I8_GROUP * d);  // F16: [4 tiles][d/16 * 64 units][8]
+    if (threadIdx.x == 0) {
+        amax_bits = 0u;
+        emax_bits = 0u;
+    }
+    // phase 1: the rows (read once), 1/|row| in the oracle's order, the group's largest normalised magnitude
+    float4 v[RPW][2];
+    float inv[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int64_t r = (int64_t)grp * I8_GROUP + wave * RPW + j;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = lane + 64 * i;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows && c < nchunks) {
+                const float* pc = x + r * (int64_t)d + 4 * c;
+                t.x = __builtin_nontemporal_load(pc);
+                t.y = __builtin_nontemporal_load(pc + 1);
+                t.z = __builtin_nontemporal_load(pc + 2);
+                t.w = __builtin_nontemporal_load(pc + 3);
+            }
+            v[j][i] = t;
+        }
+    }
+    float lmax = 0.0f;
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        // sum of squares as row_sumsq_wave: lane-sequential over its chunks and elements, then an xor butterfly
+        float p = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (lane + 64 * i < nchunks) {
+                float t;
+                t = v[j][i].x * v[j][i].x; p = p + t;
+                t = v[j][i].y * v[j][i].y; p = p + t;
+                t = v[j][i].z * v[j][i].z; p = p + t;
+                t = v[j][i].w * v[j][i].w; p = p + t;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off);
+        const float iv = inv_norm_from_sumsq(p);
+        inv[j] = iv;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {  // normalised values exactly as faiss leaves them in fp32 (zero in the unused slots)
+            v[j][i].x = v[j][i].x * iv;
+            v[j][i].y = v[j][i].y * iv;
+            v[j][i].z = v[j][i].z * iv;
+            v[j][i].w = v[j][i].w * iv;
+            lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(v[j][i].x), fabsf(v[j][i].y)), fmaxf(fabsf(v[j][i].z), fabsf(v[j][i].w))));
+        }
+        if (lane == 0) o.inv[(int64_t)grp * I8_GROUP + wave * RPW + j] = iv;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    __syncthreads();  // amax_bits / emax_bits initialised
+    if (lane == 0 && lmax > 0.0f) atomicMax(&amax_bits, __float_as_uint(lmax));  // finite or +Inf: uint order == float order
+    __syncthreads();
+    const float amax = __uint_as_float(amax_bits);
+    const bool usable = amax > 0.0f && amax < 3.0e38f;
+    const float qstep = usable ? amax / 127.0f : 1.0f;
+    const float inv_qstep = usable ? 127.0f / amax : 0.0f;
+    // phase 2: quantise from the registers
+    float wmax = 0.0f;
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int pr = wave * RPW + j;
+        const int64_t r = (int64_t)grp * I8_GROUP + pr;
+        const int t = pr >> 5, p = pr & 31;
+        float e2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunks) {
+                const float nv[4] = {v[j][i].x, v[j][i].y, v[j][i].z, v[j][i].w};
+                unsigned packed = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float qf = rintf(nv[e] * inv_qstep);
+                    qf = fminf(fmaxf(qf, -127.0f), 127.0f);                // (a NaN becomes -127: any integer is valid,
+                    const float res = __builtin_fmaf(-qstep, qf, nv[e]);   //  the residual is measured: it turns E into Inf)
+                    e2 = __builtin_fmaf(res, res, e2);
+                    packed |= ((unsigned)(int)qf & 0xFFu) << (8 * e);
+                }
+                *reinterpret_cast<unsigned*>(img8 + (size_t)t * (d * 32) + (((c >> 3) * 2 + ((c >> 2) & 1)) * 32 + p) * 16 + (c & 3) * 4) = packed;
+                if constexpr (F16) {
+                    half4 h;
+                    h[0] = (_Float16)nv[0];
+                    h[1] = (_Float16)nv[1];
+                    h[2] = (_Float16)nv[2];
+                    h[3] = (_Float16)nv[3];
+                    const int s = c >> 2, hh = (c >> 1) & 1, sub = c & 1;
+                    *reinterpret_cast<half4*>(img16 + (size_t)t * (d * 32) + ((s * 2 + hh) * 32 + p) * 8 + sub * 4) = h;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) e2 = e2 + __shfl_xor(e2, off);
+        // |e|_2 rounded up: the fp32 sum of d non-negative terms is within (d + 8) 2^-24 of exact, sqrtf within 2^-24
+        float en = sqrtf(e2) * 1.000244140625f + 1.0e-30f;
+        if (!(en == en)) en = __builtin_inff();
+        if (r >= rows) en = 0.0f;
+        if (lane == 0) o.err[r] = en;
+        wmax = fmaxf(wmax, en);
+    }
+    if (lane == 0 && wmax > 0.0f) atomicMax(&emax_bits, __float_as_uint(wmax));
+    __syncthreads();
+    {
+        const int u8n = (d >> 5) * 64 * 4;  // uint4 units of the group's four int8 tiles
+        uint4* dst = o.tiles8 + (int64_t)grp * u8n;
+        const uint4* src = reinterpret_cast<const uint4*>(img8);
+        for (int u = threadIdx.x; u < u8n; u += 1024) {
+            const uint4 tq = src[u];
+            unsigned* po = reinterpret_cast<unsigned*>(dst + u);
+            __builtin_nontemporal_store(tq.x, po);
+            __builtin_nontemporal_store(tq.y, po + 1);
+            __builtin_nontemporal_store(tq.z, po + 2);
+            __builtin_nontemporal_store(tq.w, po + 3);
+        }
+    }
+    if constexpr (F16) {
+        const int u16n = (d >> 4) * 64 * 4;
+        uint4* dst = o.tiles + (int64_t)grp * u16n;
+        const uint4* src = reinterpret_cast<const uint4*>(img16);
+        for (int u = threadIdx.x; u < u16n; u += 1024) {
+            const uint4 tq = src[u];
+            unsigned* po = reinterpret_cast<unsigned*>(dst + u);
+            __builtin_nontemporal_store(tq.x, po);
+            __builtin_nontemporal_store(tq.y, po + 1);
+            __builtin_nontemporal_store(tq.z, po + 2);
+            __builtin_nontemporal_store(tq.w, po + 3);
+        }
+    }
+    if (threadIdx.x == 0) {
+        o.gstep[grp] = qstep;
+        o.gerr[grp] = __uint_as_float(emax_bits);
+        if (emax_bits > 0u) atomicMax(o.emax, emax_bits);
+    }
+}
+
 // in-place renorm (vfm_l2norm_rows_f32): one wave per row
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x, int64_t rows, int d,
                                                           float* __restrict__ inv_out) {
@@ -228,6 +411,24 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
     return max(min(a, b), min(max(a, b), c));
 }
 
+// per-row / per-group quantisation data of the two operands of an int8 pass (qerr == NULL: fp16 records)
+struct I8Bounds {
+    const float* qerr;   // [npad] E of every query row
+    const float* qstep;  // [npad / 128] step of the query's group
+    const float* bstep;  // [nchunks] step of the map chunk
+    const float* berr;   // [nchunks] maximum E of the map chunk
+};
+// float <-> unsigned key with the same order (0 = below every float: the memset value of "nothing published")
+__device__ __forceinline__ unsigned float_key(float f) {
+    const int k = __float_as_int(f);
+    return (unsigned)(k >= 0 ? k : k ^ 0x7FFFFFFF) ^ 0x80000000u;
+}
+__device__ __forceinline__ float key_float(unsigned u) {
+    if (u == 0u) return -__builtin_inff();
+    const int k = (int)(u ^ 0x80000000u);
+    return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF);
+}
+
 struct CoarseArgs {
     const uint4* Qh;     // query fragment tiles
     const uint4* Bh;     // map fragment tiles
@@ -255,6 +456,7 @@ struct CoarseArgs {
     uint2* rec;          // [npad][rcap] (map row, score bits)
     int rcap;
     float window;
+    I8Bounds ib;         // int8 pass: qmax receives float_key(lower bound of the query's exact maximum) instead of score bits
 };
 
 // XCD-aware unit mapping shared by the coarse kernels: workgroup b runs on XCD b % 8 (observed, speed
@@ -291,16 +493,20 @@ __device__ __forceinline__ CoarseUnit coarse_unit(const CoarseArgs& a) {
 // One accumulator element into the running top-2 of its chunk: 3 VALU ops, branch-free.  code = 16 * tile
 // in chunk + accumulator register; zero-padded map rows (score exactly 2.0) are NOT masked here:
 // match_select_kernel ignores padded chunks for the maximum and rescans them exactly.
-__device__ __forceinline__ void coarse_fold(unsigned& s1, unsigned& s2, float v, int code) {
-    const unsigned pk = (__float_as_uint(v) & 0xFFFFFFC0u) | (unsigned)(63 - code);
+__device__ __forceinline__ void coarse_fold_bits(unsigned& s1, unsigned& s2, unsigned bits, int code) {
+    const unsigned pk = (bits & 0xFFFFFFC0u) | (unsigned)(63 - code);
     s2 = umed3(s1, s2, pk);
     s1 = max(s1, pk);
 }
+__device__ __forceinline__ void coarse_fold(unsigned& s1, unsigned& s2, float v, int code) { coarse_fold_bits(s1, s2, __float_as_uint(v), code); }
+__device__ __forceinline__ void coarse_fold(unsigned& s1, unsigned& s2, int v, int code) { coarse_fold_bits(s1, s2, (unsigned)v, code); }
+__device__ __forceinline__ unsigned score_bits(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ unsigned score_bits(int v) { return (unsigned)v; }
 
 // End of a 128-row chunk: merge the two half-waves and emit the chunk's top-2 for the 32 queries of tile
 // qt (chunk < 0: the dummy fold of the very first step, nothing is stored); resets the running pair.
-__device__ __forceinline__ void coarse_emit_chunk(const CoarseArgs& a, unsigned& s1, unsigned& s2, unsigned& runmax,
-                                                  int qt, int chunk) {
+__device__ __forceinline__ unsigned coarse_emit_chunk(const CoarseArgs& a, unsigned& s1, unsigned& s2, unsigned& runmax,
+                                                      int qt, int chunk) {
     const int lane = lane_id(), hi = lane >> 5;
     const unsigned o1 = __shfl_xor(s1, 32), o2 = __shfl_xor(s2, 32);
     const bool own = (s1 > o1) || (s1 == o1 && hi == 0);
@@ -315,6 +521,7 @@ __device__ __forceinline__ void coarse_emit_chunk(const CoarseArgs& a, unsigned&
     }
     s1 = 0u;
     s2 = 0u;
+    return w1 & ~127u;  // the chunk's best score, low 7 bits dropped (all lanes)
 }
 
 // QSETS = 32-query sets resident per wave: 1 -> 8 waves (2 per SIMD), 2 -> 4 waves (1 per SIMD,
@@ -494,17 +701,25 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
 // are the 32 accumulators of the previous step compared one by one and the hits appended to the query's record list
 // (atomic slot counter).  The running maximum starts from the maxima earlier workgroups published for the query
 // (a.qmax), so only the first units of a query see the record-breaking phase of a fresh maximum.
-template <int KSTEPS, bool SPARSE>
+// I8 = true: the same schedule on the int8 MFMA (32x32x32: twice the k per instruction, so KSTEPS = d/32 and a tile is
+// d/32 KiB) over the int8 image of the rows (prep_chunk_kernel); integer scores offset by 2^30, DENSE records only: the
+// rigorous int8 window is ~15x the fp16 one, and row-level records against a running maximum cost 4.3 us of kernel time
+// per record and query (measured: 410 records per query at C2, 2.98 ms), while the per-chunk top-2 is window-independent.
+template <int KSTEPS, bool SPARSE, bool I8 = false>
 __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVES = 8;
     constexpr int TILE_U4 = KSTEPS * 64;
     constexpr int TILE_BYTES = TILE_U4 * 16;
-    constexpr int PASSES = KSTEPS / NWAVES;
+    constexpr int PIECES = 2 * KSTEPS / NWAVES;  // 1 KiB pieces per wave per PAIR of tiles (one step)
     constexpr int NBUF = 6;
     constexpr int PF = 4;
-    static_assert(KSTEPS % 8 == 0 && KSTEPS <= 24, "d must be a multiple of 128, at most 384");
+    static_assert((2 * KSTEPS) % NWAVES == 0 && KSTEPS <= 24 && PIECES < KSTEPS, "a pair of tiles must split evenly over the waves");
     static_assert(KSTEPS % PF == 0 && KSTEPS >= 2 * PF, "fragment ring must align across steps");
+    static_assert(!(I8 && SPARSE), "the int8 pass writes the dense per-chunk records");
+    using frag_t = std::conditional_t<I8, intx4, half8>;
+    using acc_t = std::conditional_t<I8, intx16, floatx16>;
+    using accel_t = std::conditional_t<I8, int, float>;
 
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -518,24 +733,24 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
     // this wave's pieces of one tile: global source of piece p = src + p * NWAVES * 64, LDS p * NWAVES KiB on
     const uint4* gsrc = a.Bh + (size_t)c0 * 4 * TILE_U4 + wave * 64 + lane;
     const unsigned ldst0 = lds_base + (unsigned)wave * 1024u;
-    auto stage = [&](const uint4* src, unsigned ring_byte) {
+    auto stage_pair = [&](const uint4* src, unsigned ring_byte) {  // two consecutive tiles: contiguous in memory and in the ring
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p)
+        for (int p = 0; p < PIECES; ++p)
             glds16(src + p * NWAVES * 64, __builtin_amdgcn_readfirstlane(ldst0 + ring_byte + (unsigned)(p * NWAVES) * 1024u));
     };
 
-    half8 qf[KSTEPS];
+    frag_t qf[KSTEPS];
     {
         const uint4* qsrc = a.Qh + (size_t)(qt < a.nq_tiles ? qt : 0) * TILE_U4 + lane;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             uint4 v = qsrc[s * 64];
-            qf[s] = *reinterpret_cast<half8*>(&v);
+            qf[s] = *reinterpret_cast<frag_t*>(&v);
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)  // ntiles >= 4 (whole chunks)
-        stage(gsrc + (size_t)i * TILE_U4, (unsigned)(i * TILE_BYTES));
+    for (int i = 0; i < 2; ++i)  // ntiles >= 4 (whole chunks)
+        stage_pair(gsrc + (size_t)i * 2 * TILE_U4, (unsigned)(i * 2 * TILE_BYTES));
     const uint4* gnext = gsrc + (size_t)4 * TILE_U4;  // next tile to stage
 
     unsigned s1 = 0u, s2 = 0u, runmax = 0u;
@@ -554,15 +769,33 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
         }
         if (threadIdx.x == 0) *lrec_count = 0u;  // visible after the first barrier below
     }
+    // I8: per-lane constants of the query's bound and the running lower bound of its exact maximum (match_select_kernel)
+    float i8_sq = 0.f, i8_A = 0.f, i8_mult = 0.f, i8_low = -__builtin_inff();
+    if constexpr (I8) {
+        const size_t qi = (size_t)(qt < a.nq_tiles ? qt : 0) * 32 + (lane & 31);
+        const float eq = a.ib.qerr[qi];
+        i8_sq = a.ib.qstep[qi >> 7];
+        i8_A = eq * 1.0001220703125f + 1.0e-6f;
+        i8_mult = 1.0001220703125f + eq;
+    }
     auto fold_tail = [&](int it) {
-        if constexpr (!SPARSE) coarse_emit_chunk(a, s1, s2, runmax, qt, it >= 0 ? c0 + (it >> 2) : -1);
+        if constexpr (!SPARSE) {
+            const int chunk = it >= 0 ? c0 + (it >> 2) : -1;
+            const unsigned best = coarse_emit_chunk(a, s1, s2, runmax, qt, chunk);
+            if constexpr (I8) {
+                if (chunk >= 0 && chunk < a.first_pad_chunk) {  // wave-uniform
+                    const float sb = a.ib.bstep[chunk], be = a.ib.berr[chunk];
+                    i8_low = fmaxf(i8_low, __builtin_fmaf(i8_sq * sb, (float)((int)best - I8_OFFSET), -(i8_A + i8_mult * be)));
+                }
+            }
+        }
     };
-    auto fold_one = [&](float v, int code) {
-        if constexpr (SPARSE) s1 = max(s1, __float_as_uint(v));  // s1 = maximum of the step being folded
+    auto fold_one = [&](accel_t v, int code) {
+        if constexpr (SPARSE) s1 = max(s1, score_bits(v));  // s1 = maximum of the step being folded
         else coarse_fold(s1, s2, v, code);
     };
     // SPARSE: end of the fold of tiles (t0, t0 + 1) of this unit, whose accumulators are still in p0 / p1
-    auto step_tail = [&](int t0, const floatx16& p0, const floatx16& p1) __attribute__((always_inline)) {
+    auto step_tail = [&](int t0, const acc_t& p0, const acc_t& p1) __attribute__((always_inline)) {
         const long long row0 = ((long long)c0 * 4 + t0) * TILE_ROWS;
         const int half4 = 4 * (lane >> 5);
         const bool pad = row0 + 2 * TILE_ROWS > a.m_valid;
@@ -571,8 +804,8 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long long ra = row0 + (r & 3) + 8 * (r >> 2) + half4;
-                if (ra < a.m_valid) s1 = max(s1, __float_as_uint(p0[r]));
-                if (ra + TILE_ROWS < a.m_valid) s1 = max(s1, __float_as_uint(p1[r]));
+                if (ra < a.m_valid) s1 = max(s1, score_bits(p0[r]));
+                if (ra + TILE_ROWS < a.m_valid) s1 = max(s1, score_bits(p1[r]));
             }
         }
         runmax = max(runmax, s1);
@@ -603,7 +836,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
             for (int g4 = 0; g4 < 8; ++g4) {
                 unsigned x[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = __float_as_uint(g4 < 4 ? p0[4 * g4 + e] : p1[4 * (g4 - 4) + e]);
+                for (int e = 0; e < 4; ++e) x[e] = score_bits(g4 < 4 ? p0[4 * g4 + e] : p1[4 * (g4 - 4) + e]);
                 if (max(max(x[0], x[1]), max(x[2], x[3])) >= thr) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -617,9 +850,9 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
         s1 = 0u;
     };
 
-    floatx16 prev0, prev1;
+    acc_t prev0, prev1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) prev0[r] = prev1[r] = 0.f;
+    for (int r = 0; r < 16; ++r) prev0[r] = prev1[r] = 0;
 
     // fragment ring registers: slot s of a step consumes r0/r1[s % PF]
     wait_vmcnt<0>();
@@ -649,14 +882,19 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
         const uint4* cur1 = cur0 + TILE_U4;
         const uint4* nxt0 = reinterpret_cast<const uint4*>(smem + ring2 * TILE_BYTES) + lane;
         const uint4* nxt1 = nxt0 + TILE_U4;
-        floatx16 acc0, acc1;
+        acc_t acc0, acc1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = COARSE_OFFSET;
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = I8 ? (accel_t)I8_OFFSET : (accel_t)COARSE_OFFSET;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&r0[s % PF]), qf[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&r1[s % PF]), qf[s], acc1, 0, 0, 0);
+            if constexpr (I8) {
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<intx4*>(&r0[s % PF]), qf[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<intx4*>(&r1[s % PF]), qf[s], acc1, 0, 0, 0);
+            } else {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&r0[s % PF]), qf[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&r1[s % PF]), qf[s], acc1, 0, 0, 0);
+            }
             if (s + PF < KSTEPS) {
                 r0[s % PF] = cur0[(s + PF) * 64];
                 r1[s % PF] = cur1[(s + PF) * 64];
@@ -668,14 +906,14 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
 #pragma unroll
             for (int e = s * 32 / KSTEPS; e < (s + 1) * 32 / KSTEPS; ++e)
                 fold_one(e < 16 ? prev0[e & 15] : prev1[e & 15], (2 * (1 - H) + (e >> 4)) * 16 + (e & 15));
-            if (s >= 1 && s <= 2 * PASSES) {  // one 1 KiB piece per slot instead of a burst in slot 1
+            if (s >= 1 && s <= PIECES) {  // one 1 KiB piece per slot instead of a burst in slot 1
                 __builtin_amdgcn_sched_barrier(0);
                 if (it + 4 < ntiles) {
-                    const int p = (s - 1) % PASSES, tl = (s - 1) / PASSES;
-                    glds16(gnext + (size_t)tl * TILE_U4 + p * NWAVES * 64,
-                           __builtin_amdgcn_readfirstlane(ldst0 + (ring4 + (unsigned)tl) * TILE_BYTES + (unsigned)(p * NWAVES) * 1024u));
+                    const int p = s - 1;
+                    glds16(gnext + p * NWAVES * 64,
+                           __builtin_amdgcn_readfirstlane(ldst0 + ring4 * TILE_BYTES + (unsigned)(p * NWAVES) * 1024u));
                 }
-                if (s == 2 * PASSES) gnext += 2 * TILE_U4;
+                if (s == PIECES) gnext += 2 * TILE_U4;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -698,7 +936,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
     for (int e = 0; e < 32; ++e) fold_one(e < 16 ? prev0[e & 15] : prev1[e & 15], (2 + (e >> 4)) * 16 + (e & 15));
     if constexpr (SPARSE) step_tail(ntiles - 2, prev0, prev1);
     else fold_tail(ntiles - 1);
-    if (lane < 32 && qt < a.nq_tiles) atomicMax(a.qmax + (size_t)qt * 32 + lane, runmax);
+    if (lane < 32 && qt < a.nq_tiles) atomicMax(a.qmax + (size_t)qt * 32 + lane, I8 ? float_key(i8_low) : runmax);
     if constexpr (SPARSE) {  // flush the workgroup's records to the per-query lists (no DMA in flight any more)
         __syncthreads();
         const unsigned cnt = min(*lrec_count, (unsigned)LREC_CAP);
@@ -894,14 +1132,57 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
                                                            int64_t n, int first_pad_chunk,
                                                            const unsigned* __restrict__ qmax,
                                                            const float* __restrict__ invq, float window,
-                                                           int* __restrict__ cand_cnt,
+                                                           I8Bounds ib, float gate, int* __restrict__ cand_cnt,
                                                            unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count,
                                                            int* __restrict__ fb_list, int stats) {
     __shared__ int lcnt[64];
+    __shared__ unsigned lub[64];  // int8 records: float_key of the largest upper bound over the query's chunks
     const int qq = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * 64 + qq;
-    if (g == 0) lcnt[qq] = 0;
+    if (g == 0) {
+        lcnt[qq] = 0;
+        lub[qq] = 0u;
+    }
     __syncthreads();
+    if (ib.qerr) {
+        // Records of the int8 pass: integer scores in the units of (query group step) x (map chunk step).  In exact score
+        // units, with A = (1 + 2^-13) E_q and B_c = (1 + 2^-13 + E_q) max E of chunk c (prep_chunk_kernel):
+        //     lower_c = s_q s_c S_lo(c) - A - B_c  <=  best exact score of chunk c  <=  s_q s_c S_hi(c) + A + B_c = upper_c
+        // (S_lo / S_hi: the packed record drops the low 7 bits of the best and the low 6 bits of the second-best score).
+        // qlow = max over the un-padded chunks of lower_c, a lower bound of the query's exact maximum, comes from the coarse
+        // kernel (qmax holds its float_key).  Every chunk with upper_c >= qlow is a candidate (its best row; the whole chunk if the second-best's upper
+        // bound reaches qlow too): the oracle's arg-max row is the best row of its chunk or inside a rescanned chunk.
+        // fp32 evaluation of the bounds: three roundings on magnitudes <= 2 -- 1e-6 of slack covers them.
+        const float eq = ib.qerr[q], sq = ib.qstep[q >> 7];
+        const float A = eq * 1.0001220703125f, mult = 1.0001220703125f + eq, slack = 1.0e-6f;
+        const float qlow = key_float(qmax[q]);  // -Inf: no un-padded chunk exists -> every chunk is a candidate
+        float maxup = -__builtin_inff();
+        for (int cb = g; cb < nchunks; cb += 8 * SELECT_GROUPS) {
+            uint2 rec[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = cb + SELECT_GROUPS * u;
+                rec[u] = (c < nchunks) ? partials[(size_t)c * npad + q] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = cb + SELECT_GROUPS * u;
+                if (c >= nchunks) continue;
+                const float sc = sq * ib.bstep[c], bound = A + mult * ib.berr[c] + slack;
+                const float up1 = sc * (float)((int)(rec[u].x | 127u) - I8_OFFSET) + bound;
+                maxup = fmaxf(maxup, up1);
+                if (up1 >= qlow) {  // (zero-padded rows score exactly 0: a padded chunk is a candidate only if 0 is inside the window)
+                    const int slot = atomicAdd(&lcnt[qq], 1);
+                    if (slot < cap && q < n) {
+                        const float up2 = sc * (float)((int)(rec[u].y | 63u) - I8_OFFSET) + bound;
+                        const unsigned rescan = (up2 >= qlow || c >= first_pad_chunk) ? 1u : 0u;
+                        cand[(size_t)q * cap + slot] = ((unsigned)c << 8) | (rescan << 7) | (rec[u].x & 127u);
+                    }
+                }
+            }
+        }
+        atomicMax(&lub[qq], float_key(maxup));
+    } else {
     // qmax = best coarse score over the un-padded chunks (value bits; accumulated by the coarse
     // kernel).  Chunks >= first_pad_chunk contain zero-padded map rows whose coarse score (exactly
     // 2.0) is meaningless: they do not take part in the maximum and are always rescanned exactly.
@@ -929,6 +1210,7 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
             }
         }
     }
+    }
     __syncthreads();
     if (g == 0 && q < n) {
         const int cnt = lcnt[qq];
@@ -941,6 +1223,10 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
         }
         if (invq[q] == 0.0f) {
             cand_cnt[q] = 0;  // zero query row: decided directly (index 0, score 0)
+        } else if (ib.qerr && key_float(lub[qq]) < gate) {
+            // no row of the map can reach the caller's similarity gate (VoxelHashMap.cpp:501-511 drops such queries):
+            // the query is not resolved further -- match_rescore_kernel reports (index -1, similarity -2)
+            cand_cnt[q] = -2;
         } else if (cnt > cap) {
             cand_cnt[q] = -1;  // overflow: decided by the exact all-pairs kernel
             const int slot = atomicAdd(fb_count, 1);
@@ -1083,14 +1369,21 @@ struct RefineWave {
     }
 };
 
-// dense records: the candidate entries of match_select_kernel
+// dense records: the candidate entries of match_select_kernel.
+// int8 pass (ib.qerr != NULL): a whole-chunk entry is first rescanned in int8 -- the exact integer scores of the chunk's 128
+// rows against this query (v_dot4 over the int8 tiles: 48 KB, contiguous, L2 / Infinity-Cache resident, instead of 196 KB of
+// fp32 rows) -- and only the rows whose upper bound reaches the query's lower bound go on to the fp32 scoring.
 __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restrict__ q, const float* __restrict__ invq,
                                                            const float* __restrict__ b, const float* __restrict__ invb,
                                                            int64_t n, int64_t m, int d, float w2, int* __restrict__ cand_cnt,
                                                            unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count,
-                                                           int* __restrict__ fb_list, int stats) {
+                                                           int* __restrict__ fb_list, int stats, I8Bounds ib,
+                                                           const uint4* __restrict__ q8, const uint4* __restrict__ b8,
+                                                           const unsigned* __restrict__ qmax) {
     __shared__ unsigned l_row[4][REFINE_KEEP];
     __shared__ float l_sc[4][REFINE_KEEP];
+    __shared__ uint4 l_q8[4][24];       // the query's int8 row, unit by unit
+    __shared__ unsigned l_hit[4][CHUNK_ROWS];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
     if (qi >= n) return;
@@ -1103,6 +1396,17 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
     if (cnt < REFINE_MIN && !__any(flagged)) return;
     RefineWave R;
     R.init(q, invq[qi], qi, b, invb, d, w2, l_row[wave], l_sc[wave]);
+    const int units8 = d >> 4;  // 16-byte units per int8 row
+    float i8_sq = 0.f, i8_A = 0.f, i8_mult = 0.f, i8_qlow = 0.f;
+    if (ib.qerr && __any(flagged)) {
+        if (lane < units8) l_q8[wave][lane] = q8[(size_t)(qi >> 5) * (units8 * 32) + (size_t)lane * 32 + (qi & 31)];
+        const float eq = ib.qerr[qi];
+        i8_sq = ib.qstep[qi >> 7];
+        i8_A = eq * 1.0001220703125f + 1.0e-6f;
+        i8_mult = 1.0001220703125f + eq;
+        i8_qlow = key_float(qmax[qi]);
+        __builtin_amdgcn_wave_barrier();
+    }
     // single-row entries: 4 per pass
     for (int e0 = 0; e0 < cnt; e0 += 4) {
         long long row = -1;
@@ -1120,6 +1424,36 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
         const unsigned ce = mycand[e];  // wave-uniform
         if (!(ce & 128u)) continue;
         const long long base = (long long)(ce >> 8) * CHUNK_ROWS;
+        if (ib.qerr) {
+            const int c = (int)(ce >> 8);
+            const float sc = i8_sq * ib.bstep[c], bound = i8_A + i8_mult * ib.berr[c];
+            int nhit = 0;  // wave-uniform
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int rr = lane + 64 * half;  // row of the chunk: tile rr >> 5, position rr & 31
+                const uint4* src = b8 + ((size_t)c * 4 + (rr >> 5)) * (size_t)(units8 * 32) + (rr & 31);
+                int acc = 0;
+                for (int u = 0; u < units8; ++u) {
+                    const uint4 bv = src[u * 32];
+                    const uint4 qv = l_q8[wave][u];
+                    acc = __builtin_amdgcn_sdot4((int)bv.x, (int)qv.x, acc, false);
+                    acc = __builtin_amdgcn_sdot4((int)bv.y, (int)qv.y, acc, false);
+                    acc = __builtin_amdgcn_sdot4((int)bv.z, (int)qv.z, acc, false);
+                    acc = __builtin_amdgcn_sdot4((int)bv.w, (int)qv.w, acc, false);
+                }
+                const bool hit = base + rr < m && sc * (float)acc + bound >= i8_qlow;
+                const unsigned long long bal = __ballot(hit);
+                if (hit) l_hit[wave][nhit + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned)rr;
+                nhit += __popcll(bal);
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int h0 = 0; h0 < nhit; h0 += 4) {
+                const long long row = (h0 + R.g < nhit) ? base + l_hit[wave][h0 + R.g] : -1;
+                R.consider(row, R.score4(row));
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         for (int r0 = 0; r0 < CHUNK_ROWS; r0 += 4) {
             long long row = base + r0 + R.g;
             if (row >= m) row = -1;
@@ -1438,6 +1772,9 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restr
     } else if (cand_cnt[qi] >= 0) {
         idx_out[qi] = bj;
         sim_out[qi] = (float)best;
+    } else if (cand_cnt[qi] == -2) {  // below the caller's gate (match_select_kernel)
+        idx_out[qi] = -1;
+        sim_out[qi] = -2.0f;
     }
 }
 
@@ -1748,7 +2085,17 @@ namespace {
 struct Prepared {
     float* inv;
     uint4* tiles;
+    // int8 image (i8_capable(d); prep_chunk_kernel)
+    float* err;       // E per row
+    unsigned* emax;   // bits of the operand's maximum E (256 B slot)
+    float* gstep;     // quantisation step per group of 128 rows
+    float* gerr;      // maximum E per group
+    uint4* tiles8;    // int8 fragment tiles
+    size_t bytes;
 };
+
+// widths the int8 coarse pass exists for (match_coarse_pipe_kernel<d/32, false, true>)
+inline bool i8_capable(int d) { return d == 256 || d == 384; }
 
 inline Prepared carve_prepared(void* p, int64_t rows, int d) {
     VfmCarver c(p);
@@ -1756,6 +2103,18 @@ inline Prepared carve_prepared(void* p, int64_t rows, int d) {
     const int64_t rp = rows_padded(rows);
     r.inv = c.take<float>((size_t)rp);
     r.tiles = c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(d / 16) * 64);
+    r.err = nullptr;
+    r.emax = nullptr;
+    r.gstep = r.gerr = nullptr;
+    r.tiles8 = nullptr;
+    if (i8_capable(d)) {  // behind the fp16 image: the Euclidean path carves the same layout and ignores the rest
+        r.err = c.take<float>((size_t)rp);
+        r.emax = c.take<unsigned>(64);
+        r.gstep = c.take<float>((size_t)rp / I8_GROUP);
+        r.gerr = c.take<float>((size_t)rp / I8_GROUP);
+        r.tiles8 = c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(d / 32) * 64);
+    }
+    r.bytes = c.used();
     return r;
 }
 
@@ -1842,7 +2201,16 @@ int g_match_stats = 0;  // vfm_debug_set_match_stats: per-query counters cost ~0
 // (from 3 query blocks on: with 1-2 blocks every unit of the grid runs at once, none is seeded, and the dense records
 // measured faster -- 244 vs 282 us per registration at 300 x 50000)
 inline bool use_sparse(int d, int64_t n, int64_t m) {
-    return d <= 384 && d % 128 == 0 && m < (1ll << 24) && n > 2 * QBLOCK && (g_coarse_qsets == 0 || g_coarse_qsets == 3);
+    return d <= 384 && d % 128 == 0 && m < (1ll << 24) && n > 2 * QBLOCK &&
+           (g_coarse_qsets == 0 || g_coarse_qsets == 3 || g_coarse_qsets == 5);
+}
+
+// ... and before those, for d = 256 / 384, the int8 coarse pass with dense per-chunk records (variant 5 = the fp16 pass, A/B)
+inline bool use_i8(int d, int64_t n, int64_t m) {
+    return i8_capable(d) && m < (1ll << 24) && n > 2 * QBLOCK && (g_coarse_qsets == 0 || g_coarse_qsets == 9);
+}
+inline I8Bounds i8_bounds(const Prepared& Q, const Prepared& B, bool on) {
+    return on ? I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr} : I8Bounds{nullptr, nullptr, nullptr, nullptr};
 }
 
 // queries per workgroup of the coarse kernel that do_search_coarse will launch
@@ -1860,16 +2228,16 @@ inline void attr_mark(unsigned long long& mask) {
     mask |= 1ull << (dev & 63);
 }
 
-template <int KSTEPS, bool SPARSE>
+template <int KSTEPS, bool SPARSE, bool I8 = false>
 int launch_coarse_pipe(const CoarseArgs& a, hipStream_t st) {
     const int lds = 6 * KSTEPS * 1024 + (SPARSE ? SPARSE_LREC_CAP * 8 + 16 : 0);
     static unsigned long long attr_set = 0ull;  // one bit per device
     if (!attr_done(attr_set)) {
-        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_pipe_kernel<KSTEPS, SPARSE>),
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_pipe_kernel<KSTEPS, SPARSE, I8>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_mark(attr_set);
     }
-    hipLaunchKernelGGL((match_coarse_pipe_kernel<KSTEPS, SPARSE>), dim3(a.nseed_pad + a.nqb * a.nslices), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((match_coarse_pipe_kernel<KSTEPS, SPARSE, I8>), dim3(a.nseed_pad + a.nqb * a.nslices), dim3(512), lds, st, a);
     return VFM_OK;
 }
 
@@ -1921,23 +2289,42 @@ int launch_coarse(const CoarseArgs& a, hipStream_t st) {
     return VFM_OK;
 }
 
-int do_prepare(const float* x, int64_t rows, int d, void* prepared, hipStream_t st) {
-    Prepared p = carve_prepared(prepared, rows, d);
-    const int64_t rp = rows_padded(rows);
-    hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)(rp / TILE_ROWS)), dim3(256), (size_t)d * 64, st, x, rows, d,
-                       p.inv, p.tiles, (int)(rp / TILE_ROWS), (const float*)nullptr, (int64_t)0, (float*)nullptr, (uint4*)nullptr);
-    VFM_CHECK_LAUNCH("prep_rows_kernel");
-    return VFM_OK;
-}
+inline PrepOut prep_out(const Prepared& p) { return PrepOut{p.inv, p.tiles, p.err, p.emax, p.gstep, p.gerr, p.tiles8}; }
 
+// one or two operands (x2 may be NULL) in one launch.  want_f16 = false: only the int8 image (d = 256, 384), for operands that
+// will meet in an int8 search (use_i8): a third of the bytes written, a third of the LDS.
 int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2, int64_t rows2, void* prepared2, int d,
-                hipStream_t st) {
-    Prepared p1 = carve_prepared(prepared1, rows1, d), p2 = carve_prepared(prepared2, rows2, d);
-    const int t1 = (int)(rows_padded(rows1) / TILE_ROWS), t2 = (int)(rows_padded(rows2) / TILE_ROWS);
+                hipStream_t st, bool want_f16 = true) {
+    Prepared p1 = carve_prepared(prepared1, rows1, d);
+    Prepared p2 = x2 ? carve_prepared(prepared2, rows2, d) : Prepared{};
+    if (i8_capable(d)) {  // int8 tiles + group data (+ fp16 tiles)
+        const int g1 = (int)(rows_padded(rows1) / I8_GROUP), g2 = x2 ? (int)(rows_padded(rows2) / I8_GROUP) : 0;
+        static unsigned long long attr_set = 0ull;  // one bit per device
+        if (!attr_done(attr_set)) {
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_chunk_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * 384 * 3));
+            attr_mark(attr_set);
+        }
+        VFM_CHECK_HIP(hipMemsetAsync(p1.emax, 0, sizeof(unsigned), st));
+        if (x2) VFM_CHECK_HIP(hipMemsetAsync(p2.emax, 0, sizeof(unsigned), st));
+        if (want_f16)
+            hipLaunchKernelGGL(prep_chunk_kernel<true>, dim3((unsigned)(g1 + g2)), dim3(1024), (size_t)I8_GROUP * d * 3, st, x1, rows1, d,
+                               prep_out(p1), g1, x2, rows2, prep_out(p2));
+        else
+            hipLaunchKernelGGL(prep_chunk_kernel<false>, dim3((unsigned)(g1 + g2)), dim3(1024), (size_t)I8_GROUP * d, st, x1, rows1, d,
+                               prep_out(p1), g1, x2, rows2, prep_out(p2));
+        VFM_CHECK_LAUNCH("prep_chunk_kernel");
+        return VFM_OK;
+    }
+    const int t1 = (int)(rows_padded(rows1) / TILE_ROWS), t2 = x2 ? (int)(rows_padded(rows2) / TILE_ROWS) : 0;
     hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)(t1 + t2)), dim3(256), (size_t)d * 64, st, x1, rows1, d, p1.inv, p1.tiles,
                        t1, x2, rows2, p2.inv, p2.tiles);
     VFM_CHECK_LAUNCH("prep_rows_kernel");
     return VFM_OK;
+}
+
+int do_prepare(const float* x, int64_t rows, int d, void* prepared, hipStream_t st) {
+    return do_prepare2(x, rows, prepared, nullptr, 0, nullptr, d, st);
 }
 
 CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, int64_t n, int64_t m, int qblock = QBLOCK) {
@@ -1961,6 +2348,7 @@ CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, 
     a.rec = nullptr;
     a.rcap = 0;
     a.window = g_window_override != 0.0f ? g_window_override : DEFAULT_WINDOW;
+    a.ib = I8Bounds{nullptr, nullptr, nullptr, nullptr};
     return a;
 }
 
@@ -1975,7 +2363,7 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
         if (d != 640 && d != 768) return vfm_fail(VFM_EINVAL, "row bias needs the 4-wave coarse kernel (K = 640 / 768), got %d", d);
         a.row_bias = B.inv;
     }
-    if (inner_product && use_sparse(d, n, m)) {
+    if (inner_product && !use_i8(d, n, m) && use_sparse(d, n, m)) {
         a.rec_cnt = w.rec_cnt;
         a.rec = w.rec;
         a.rcap = w.rcap;
@@ -1987,6 +2375,18 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
         }
     }
     VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, 256 + 2 * (size_t)a.npad * sizeof(unsigned), st));  // fb_count | qmax | rec_cnt
+    if (inner_product && use_i8(d, n, m)) {
+        a.Qh = Q.tiles8;
+        a.Bh = B.tiles8;
+        a.ib = I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr};
+        if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
+        const int rc8 = d == 384 ? launch_coarse_pipe<12, false, true>(a, st) : launch_coarse_pipe<8, false, true>(a, st);
+        if (rc8) return rc8;
+        VFM_CHECK_LAUNCH("match_coarse_pipe_kernel(int8)");
+        if (g_prof_stop) VFM_CHECK_HIP(hipEventRecord(g_prof_stop, st));
+        g_prof_start = g_prof_stop = nullptr;
+        return VFM_OK;
+    }
     int rc;
     switch (d / 16) {
         case 8: rc = launch_coarse<8>(a, st); break;
@@ -2001,23 +2401,28 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
 }
 
 // stage 2 of a search: candidate selection + exact fp64 decision (reads ws of stage 1)
+// gate: queries whose best similarity is provably below it are reported as (-1, -2.0) instead of being resolved (int8 pass
+// only; -Inf = resolve every query)
 int do_search_finish(const float* q, const void* qprep, int64_t n, const float* b, const void* bprep, int64_t m, int d,
-                     int64_t* idx_out, float* sim_out, void* ws, hipStream_t st) {
+                     int64_t* idx_out, float* sim_out, void* ws, hipStream_t st, float gate = -__builtin_inff()) {
     Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
     Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
     SearchWs w = carve_search(ws, n, m);
     const CoarseArgs a = coarse_args(Q, B, w, n, m, coarse_qblock(d));
     const float w2 = 2.0f * (float)(d / 16 + 4 + 2) * 5.9604645e-8f;
-    if (use_sparse(d, n, m)) {
+    const bool i8 = use_i8(d, n, m);
+    if (!i8 && use_sparse(d, n, m)) {
         hipLaunchKernelGGL(match_filter_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d,
                            DEFAULT_WINDOW, w2, w.qmax, w.rec_cnt, w.rec, w.rcap, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
         VFM_CHECK_LAUNCH("match_filter_refine_kernel");
     } else {
         hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS), 0, st, w.partials, a.nchunks,
-                           a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
+                           a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, i8_bounds(Q, B, i8), gate, w.cand_cnt, w.cand, w.cap,
+                           w.fb_count, w.fb_list, g_match_stats);
         VFM_CHECK_LAUNCH("match_select_kernel");
         hipLaunchKernelGGL(match_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2,
-                           w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
+                           w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats, i8_bounds(Q, B, i8),
+                           (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax);
         VFM_CHECK_LAUNCH("match_refine_kernel");
     }
     {
@@ -2056,13 +2461,7 @@ VFM_EXPORT int vfm_l2norm_rows_f32(float* x, int64_t n, int d, float* inv_out, v
     return VFM_OK;
 }
 
-VFM_EXPORT size_t vfm_match_prepared_bytes(int64_t rows, int d) {
-    VfmCarver c(nullptr);
-    const int64_t rp = rows_padded(rows);
-    c.take<float>((size_t)rp);
-    c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(d / 16) * 64);
-    return c.used();
-}
+VFM_EXPORT size_t vfm_match_prepared_bytes(int64_t rows, int d) { return carve_prepared(nullptr, rows, d).bytes; }
 
 VFM_EXPORT int vfm_match_prepare(const float* x, int64_t rows, int d, void* prepared, vfm_stream_t stream) {
     VFM_CHECK_ARG(rows > 0 && d % 128 == 0 && d >= 128 && d <= 768, "prepare: d must be in {128,256,384,512,640,768}");
@@ -2074,7 +2473,9 @@ VFM_EXPORT int vfm_match_prepare2(const float* x1, int64_t rows1, void* prepared
                                   int d, vfm_stream_t stream) {
     VFM_CHECK_ARG(rows1 > 0 && rows2 > 0 && d % 128 == 0 && d >= 128 && d <= 768, "prepare2: d must be in {128,256,384,512,640,768}");
     VFM_CHECK_ARG(x1 && x2 && prepared1 && prepared2, "prepare2: null pointer");
-    return do_prepare2(x1, rows1, prepared1, x2, rows2, prepared2, d, (hipStream_t)stream);
+    // (map, scan): when the two will meet in an int8 search, the fp16 image is not needed
+    const bool want_f16 = !use_i8(d, rows2, rows1) || g_coarse_qsets != 0;
+    return do_prepare2(x1, rows1, prepared1, x2, rows2, prepared2, d, (hipStream_t)stream, want_f16);
 }
 
 VFM_EXPORT size_t vfm_match_search_workspace_bytes(int64_t n, int64_t m, int d) {
@@ -2113,6 +2514,15 @@ VFM_EXPORT int vfm_match_search_finish(const float* q, const void* q_prepared, i
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q && b && q_prepared && b_prepared && ws && idx_out && sim_out, "search_finish: null pointer");
     return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream);
+}
+
+VFM_EXPORT int vfm_match_search_finish_gated(const float* q, const void* q_prepared, int64_t n, const float* b,
+                                             const void* b_prepared, int64_t m, int d, int64_t* idx_out, float* sim_out,
+                                             void* ws, size_t ws_bytes, float gate, vfm_stream_t stream) {
+    if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
+    VFM_CHECK_ARG(q && b && q_prepared && b_prepared && ws && idx_out && sim_out, "search_finish: null pointer");
+    VFM_CHECK_ARG(gate == gate, "search_finish: gate is NaN");
+    return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream, gate);
 }
 
 VFM_EXPORT size_t vfm_match_ip_top1_workspace_bytes(int64_t n, int64_t m, int d, int prec_mode) {
@@ -2228,7 +2638,8 @@ int l2_search(const float* q, void* qprep, int64_t n, const float* b, void* bpre
     SearchWs w = carve_search(ws, n, m);
     const CoarseArgs a = coarse_args(Q, carve_prepared(bprep, m, kp), w, n, m, coarse_qblock(kp));
     hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS), 0, st, w.partials, a.nchunks,
-                       a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
+                       a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, i8_bounds(Q, Q, false), -__builtin_inff(), w.cand_cnt, w.cand,
+                       w.cap, w.fb_count, w.fb_list, g_match_stats);
     VFM_CHECK_LAUNCH("match_select_kernel");
     hipLaunchKernelGGL(l2_rescore_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)d * 4 * 8, st, q, b, n, m, d, w.cand_cnt,
                        w.cand, w.cap, nn, d2);

@@ -44,6 +44,8 @@ SIGNATURES = {
     "vfm_match_search_coarse": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, c_vp, C.c_size_t, c_vp]),
     "vfm_match_search_finish": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp,
                                           C.c_size_t, c_vp]),
+    "vfm_match_search_finish_gated": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp,
+                                                C.c_size_t, C.c_float, c_vp]),
     "vfm_threshold_compact": (C.c_int, [c_vp, c_vp, c_i64, C.c_double, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vfm_match_mutual_l2_workspace_bytes": (C.c_size_t, [c_i64, c_i64, C.c_int, C.c_int, C.c_int]),
     "vfm_match_mutual_l2": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, C.c_size_t,

@@ -25,6 +25,7 @@ from __future__ import annotations
 
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import _lib, ops
@@ -53,20 +54,27 @@ class _ResultSet:
 class RegistrationPipeline:
     def __init__(self, n: int, m: int, d: int = 384, n_iter: int = 50000, min_cosine: float = 0.8,
                  max_corr_dist: float = 10000.0, seed: int = 42, device="cuda", overlap_ransac: bool = False,
-                 overlap_prepare: bool = False):
+                 overlap_prepare: bool = False, solve_streams: int = 1, gate: bool = True):
         lib = _lib.load()
         self.n, self.m, self.d = n, m, d
         self.n_iter, self.min_cosine, self.max_corr_dist, self.seed = n_iter, min_cosine, max_corr_dist, seed
         self.device = torch.device(device)
         dev = self.device
         u8 = torch.uint8
-        self.rws = torch.empty(lib.vfm_ransac_workspace_bytes(n, n_iter), dtype=u8, device=dev)
         self.overlap = bool(overlap_ransac)
         self.overlap_prepare = bool(overlap_prepare)
+        self.gate = bool(gate)
+        # solve_streams = K: the solve stages of K consecutive pairs may run beside each other (and beside the coarse pass
+        # of a later pair) on K side streams, with K + 1 buffer sets
+        self.n_solve = max(1, int(solve_streams)) if self.overlap else 0
         sizes = (lib.vfm_match_prepared_bytes(n, d), lib.vfm_match_prepared_bytes(m, d),
                  lib.vfm_match_search_workspace_bytes(n, m, d))
-        self.sets = [_ResultSet(n, dev, *sizes) for _ in range(2 if self.overlap else 1)]
-        self.ransac_stream = torch.cuda.Stream(device=dev) if self.overlap else None
+        self.sets = [_ResultSet(n, dev, *sizes) for _ in range(self.n_solve + 1)]
+        self.solve_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_solve)]
+        self.rws_list = [torch.empty(lib.vfm_ransac_workspace_bytes(n, n_iter), dtype=u8, device=dev)
+                         for _ in range(max(1, self.n_solve))]
+        self.rws = self.rws_list[0]
+        self.ransac_stream = self.solve_streams[0] if self.overlap else None
         self.prep_stream = torch.cuda.Stream(device=dev) if self.overlap else None
         self._step = 0
 
@@ -87,8 +95,8 @@ class RegistrationPipeline:
 
     def synchronize(self) -> None:
         """Make the caller's current stream wait for every RANSAC issued on the side stream."""
-        if self.overlap:
-            torch.cuda.current_stream().wait_stream(self.ransac_stream)
+        for s in self.solve_streams:
+            torch.cuda.current_stream().wait_stream(s)
 
     def register(self, q_desc: torch.Tensor, q_xyz: torch.Tensor, b_desc: torch.Tensor, b_xyz: torch.Tensor,
                  reuse_map: bool = False, want_mask: bool = True, inputs_ready: Optional[torch.cuda.Event] = None):
@@ -103,6 +111,8 @@ class RegistrationPipeline:
         if q_desc.shape != (self.n, self.d) or b_desc.shape != (self.m, self.d):
             raise ValueError("Invalid shape")
         r = self.sets[self._step % len(self.sets)]
+        solve = self.solve_streams[self._step % self.n_solve] if self.overlap else None
+        rws = self.rws_list[self._step % self.n_solve] if self.overlap else self.rws
         self._step += 1
         main = torch.cuda.current_stream()
         st = main.cuda_stream
@@ -133,11 +143,13 @@ class RegistrationPipeline:
         if self.overlap:  # hand over to stage 2
             ev = torch.cuda.Event()
             ev.record(main)
-            self.ransac_stream.wait_event(ev)
-            rst = self.ransac_stream.cuda_stream
-        _lib.check(lib.vfm_match_search_finish(q_desc.data_ptr(), r.qprep.data_ptr(), self.n, b_desc.data_ptr(),
-                                               r.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(), r.sim.data_ptr(),
-                                               r.sws.data_ptr(), r.sws.numel(), rst), "search(finish)")
+            solve.wait_event(ev)
+            rst = solve.cuda_stream
+        # only matches with cosine >= min_cosine are kept below: queries that provably cannot reach it stay unresolved
+        gate = float(np.nextafter(np.float32(self.min_cosine), np.float32(-np.inf))) if self.gate else float("-inf")
+        _lib.check(lib.vfm_match_search_finish_gated(q_desc.data_ptr(), r.qprep.data_ptr(), self.n, b_desc.data_ptr(),
+                                                     r.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(), r.sim.data_ptr(),
+                                                     r.sws.data_ptr(), r.sws.numel(), gate, rst), "search(finish)")
         _lib.check(lib.vfm_threshold_compact(r.sim.data_ptr(), r.idx.data_ptr(), self.n, float(self.min_cosine),
                                              r.keep.data_ptr(), r.count.data_ptr(), r.corres.data_ptr(),
                                              None, None, None, None, rst), "threshold_compact")
@@ -145,10 +157,10 @@ class RegistrationPipeline:
                                        self.n, float(self.max_corr_dist), int(self.n_iter), int(self.seed),
                                        r.T.data_ptr(), r.fitness.data_ptr(), r.rmse.data_ptr(),
                                        r.mask.data_ptr() if want_mask else None, r.best_hyp.data_ptr(),
-                                       self.rws.data_ptr(), self.rws.numel(), rst), "ransac")
+                                       rws.data_ptr(), rws.numel(), rst), "ransac")
         if self.overlap:
             r.done = torch.cuda.Event()
-            r.done.record(self.ransac_stream)
+            r.done.record(solve)
         return dict(T=r.T, fitness=r.fitness, rmse=r.rmse, best_hyp=r.best_hyp, mask=r.mask, idx=r.idx, sim=r.sim,
                     keep=r.keep, count=r.count, corres=r.corres, done=r.done,
-                    result_stream=self.ransac_stream if self.overlap else main)
+                    result_stream=solve if self.overlap else main)
