@@ -6,17 +6,19 @@
 
 Workload = BASELINE.json configs[1] ("C2"): one step = one registration of a 20 000-point scan
 against a 200 000-point map with 384-D descriptors (precomputed, resident in HBM) and 50 000 RANSAC
-iterations: normalise + fp16 fragment conversion of BOTH clouds (the reference renormalises the map
-on every call, VoxelHashMap.cpp:469-482), exact top-1 inner-product search, cosine >= 0.8 threshold
+iterations: normalise + int8 fragment conversion of BOTH clouds (the reference renormalises the map
+on every call, VoxelHashMap.cpp:469-482), exact top-1 inner-product search (int8 MFMA coarse pass with
+proven bounds -> fp32 refinement -> fp64 decision: the oracle's indices), cosine >= 0.8 threshold
 and compaction, correspondence RANSAC with 3-point Kabsch.  Synthetic inputs of SURVEY.md 8 D.2.
 
 Multi-GPU: independent scene pairs are sharded across ranks, no data-path
 collective; one all_gather of the 4x4 poses (RCCL) closes the timed region.  Weak scaling.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline     -- the dominant kernel (fp16 MFMA coarse pass): algorithmic flops 2*N*M*D per launch
-                  / average launch duration measured with HIP events on its stream, vs the dense
-                  fp16 MFMA peak of MI355X_MICROARCH.md (2.5 PFLOP/s);
+  roofline     -- the dominant kernel (int8 MFMA coarse pass): algorithmic operations 2*N*M*D per launch
+                  / average launch duration measured with HIP events on its stream, vs the dense int8
+                  MFMA peak (5 POP/s = 2 x the 2.5 PFLOP/s fp16 figure of MI355X_MICROARCH.md: the
+                  32x32x32 i8 instruction has twice the k of 32x32x16 f16 at the same issue rate);
   cpu_baseline -- the CPU oracle (oracle/, a port: faiss and Open3D are absent) timed on this
                   box's host cores on a bounded sample of the same workload;
   extra        -- outside the timed region: |T_gpu - T_oracle|_F of one pair ("pose delta vs ref"), config C3
@@ -41,6 +43,7 @@ for p in (ROOT, ROOT / "vfm-registration_amd"):
 
 N_SCAN, N_MAP, DIM, RANSAC_ITERS = 20000, 200000, 384, 50000
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/fp16 MFMA ~2.5 PFLOP/s
+MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 MFMA: 2 x the fp16 rate (same table: "I8 ~2x bf16 rate (2xK)", ubench >= 4404)
 
 
 def cpu_baseline(p, iters=RANSAC_ITERS, T_gpu=None):
@@ -364,8 +367,13 @@ def main():
     if rank == 0:
         flops = 2.0 * n * m * d
         achieved = flops / (coarse_ms * 1e-3) / 1e12
+        # which coarse pass ran: the int8 one for d = 256 / 384 unless an A/B variant forces the fp16 pass
+        i8 = d in (256, 384) and n > 512 and os.environ.get("VFM_VARIANT", "0") in ("0", "9")
+        peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS
+        kernel = ("match_coarse_pipe_kernel<12, false, true> (int8 32x32x32 MFMA, exact integer scores, per-chunk top-2 records)" if i8
+                  else "match_coarse_pipe_kernel<24, true> (fp16 32x32x16 MFMA, sparse row-level records)")
         traffic, traffic_src = None, None  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
-        for name in ("r02_pmc_match_coarse.json", "r01_pmc_match_coarse.json"):
+        for name in (("r02_pmc_match_coarse_i8.json",) if i8 else ("r02_pmc_match_coarse.json", "r01_pmc_match_coarse.json")):
             pmc = ROOT / "profiles" / name
             if pmc.exists() and (n, m, d) == (N_SCAN, N_MAP, DIM):
                 traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
@@ -375,7 +383,9 @@ def main():
             "metric": "registrations/sec (20k<->200k pts, 384-D)", "value": num_pairs / elapsed,
             "unit": "registrations/s", "n_gpus": world, "steps": vdist.pairs_per_rank(num_pairs, world), "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / vdist.pairs_per_rank(num_pairs, world), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16 coarse pass (MFMA) + f32 refinement + f64 exact decision / f64 RANSAC",
+            "vs_baseline": None,
+            "dtype": ("int8 coarse pass (MFMA, exact integer scores + proven quantisation bounds)" if i8 else "f16 coarse pass (MFMA)")
+                     + " + f32 refinement + f64 exact decision / f64 RANSAC",
             "data": "synthetic",
             "config": {"workload": f"C2: {n}-pt scan vs {m}-pt map, {d}-D descriptors precomputed and resident in "
                                    f"HBM, {args.iters} RANSAC iterations, cosine >= 0.8; map renormalised every step",
@@ -386,12 +396,14 @@ def main():
                                       else "none (single process, no launcher)"),
                        "correspondences_last_step": ncorr, "max_pose_err_vs_planted": max(errs)},
             "per_rank_registrations_per_s": per_rank,
-            "roofline": {"bound": "mfma", "kernel": "match_coarse_pipe_kernel<24, true> (fp16 32x32x16 MFMA, sparse row-level records)",
-                         "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "roofline": {"bound": "mfma", "kernel": kernel,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "peak_note": ("dense int8 MFMA, integer multiply-adds counted as 2 operations each" if i8
+                                       else "dense fp16 MFMA"),
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "flops_per_launch": flops, "avg_launch_ms": coarse_ms,
                          "single_stream": {"avg_launch_ms": iso_ms, "achieved": flops / (iso_ms * 1e-3) / 1e12,
-                                           "frac": flops / (iso_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                                           "frac": flops / (iso_ms * 1e-3) / 1e12 / peak,
                                            "note": "same kernel without the RANSAC of the previous pair running beside it"}},
         }
         extra = {"note": "measured outside the timed region; the headline `value` is C2 only"}

@@ -61,6 +61,10 @@ size_t vfm_match_ip_top1_workspace_bytes(int64_t n, int64_t m, int d, int prec_m
 int vfm_match_ip_top1(const float *q, int64_t n, const float *b, int64_t m, int d, int prec_mode,
                       int64_t *idx_out, float *sim_out, void *ws, size_t ws_bytes,
                       vfm_stream_t stream);
+/* one-shot form of the gated family (same workspace size) */
+int vfm_match_ip_top1_gated(const float *q, int64_t n, const float *b, int64_t m, int d, int prec_mode,
+                            float gate, int64_t *idx_out, float *sim_out, void *ws, size_t ws_bytes,
+                            vfm_stream_t stream);
 
 /* Split form for a map that is searched many times (IndexFlatIP.add once, VHM:487): the
  * prepared operand holds 1/|row| and the fp16 MFMA-fragment image of the normalised rows. */
@@ -83,11 +87,20 @@ int vfm_match_search_coarse(const void *q_prepared, int64_t n, const void *b_pre
 int vfm_match_search_finish(const float *q, const void *q_prepared, int64_t n, const float *b,
                             const void *b_prepared, int64_t m, int d, int64_t *idx_out,
                             float *sim_out, void *ws, size_t ws_bytes, vfm_stream_t stream);
-/* _finish for a caller that keeps only matches with similarity >= gate (the cosine gate of
- * GetVFMCorrespondences, VHM:501-511): a query whose best similarity is PROVABLY below `gate` is
- * not resolved -- idx_out = -1, sim_out = -2.0 -- every other query gets the oracle's answer.  The
- * proof comes from the int8 coarse pass' bounds (d = 256, 384 and n > 512); elsewhere the gate is
- * ignored and every query is resolved. */
+/* ---- the GATED family: for a caller that keeps only matches with similarity >= gate (the cosine gate of
+ * GetVFMCorrespondences, VHM:501-511).  A query whose best similarity is PROVABLY below `gate` is not resolved --
+ * idx_out = -1, sim_out = -2.0 -- every other query gets the oracle's answer; gate = -INFINITY resolves every query.
+ * For d = 256 / 384 and n > 512 this family runs the int8 coarse pass (int8 MFMA over rows quantised per 128-row group,
+ * exact integer scores, proven per-(query, chunk) bounds): twice the matrix rate of the fp16 pass, and
+ * the proof that a query stays below the gate comes from the same bounds.  Elsewhere it is the ungated path and the gate
+ * is ignored (every query resolved).  The three calls of one search must come from the same family:
+ *   _prepare2_gated (x1 = map, x2 = scan: writes what the gated search of x2 in x1 reads -- the int8 image alone where
+ *                    the int8 pass runs)  ->  _search_coarse_gated  ->  _search_finish_gated;
+ * operands prepared by vfm_match_prepare / vfm_match_prepare2 carry both images and serve either family. */
+int vfm_match_prepare2_gated(const float *x1, int64_t rows1, void *prepared1, const float *x2, int64_t rows2,
+                             void *prepared2, int d, vfm_stream_t stream);
+int vfm_match_search_coarse_gated(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
+                                  int d, void *ws, size_t ws_bytes, vfm_stream_t stream);
 int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_t n, const float *b,
                                   const void *b_prepared, int64_t m, int d, int64_t *idx_out,
                                   float *sim_out, void *ws, size_t ws_bytes, float gate,
@@ -284,7 +297,9 @@ int vfm_prof_events_create(void **start, void **stop);
 int vfm_prof_arm(void *start, void *stop);
 int vfm_prof_elapsed_ms(void *start, void *stop, float *ms_host);
 int vfm_prof_events_destroy(void *start, void *stop);
-/* tuning switch: coarse-kernel variant (0 default, 1 = 8 waves x 32 queries, 2 = 4 waves x 64) */
+/* tuning switch: coarse-kernel variant (0 default: int8 pass for d = 256 / 384 with n > 512, sparse fp16 records for the
+ * other d <= 384, dense fp16 records elsewhere; 1 = 8 waves x 32 queries, 2 = 4 waves x 64, 4 = pipelined kernel with dense
+ * fp16 records, 5 = the fp16 pass with sparse records where 0 would take the int8 pass, 7 = 5 without seed units) */
 int vfm_debug_set_coarse_variant(int qsets);
 /* tuning switch: force the number of map slices of the coarse pass (0 = heuristic) */
 /* counters of the last FAST search that used workspace `ws` (candidate histogram, refined / fallback queries;
@@ -294,6 +309,10 @@ int vfm_debug_match_stats(void *ws, int64_t n, int64_t m, int32_t *out64_host);
 int vfm_debug_set_match_stats(int on);
 /* ViT GEMM wave tile / prefetch depth for A/B runs: NT * 100 + PF for N <= 512 and N > 512 (see csrc/vit.hip) */
 int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
+/* tests: the int8 image of a prepared operand (d = 256, 384) unpacked on the host -- q8_host[rows][d], and per row the
+ * quantisation step of its 128-row group, its residual norm E and the group's maximum E.  Synchronises the device. */
+int vfm_debug_i8_rows(const void *prepared, int64_t rows, int d, int8_t *q8_host, float *step_host,
+                      float *err_host, float *gerr_host);
 /* timing experiments only: overrides the coarse window of the sparse kernel (0 = default); results become wrong */
 int vfm_debug_set_coarse_window(float w);
 int vfm_debug_set_coarse_slices(int slices);

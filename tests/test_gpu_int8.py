@@ -1,0 +1,119 @@
+"""The int8 coarse pass (d = 256 / 384, more than 512 queries): its quantisation bound checked pair by pair against fp64
+scores, oracle-identical answers on inputs that stress the quantisation, and the contract of the similarity gate."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle as orc  # noqa: E402
+from vfmreg import _lib, ops, synth  # noqa: E402
+from vfmreg.pipeline import RegistrationPipeline  # noqa: E402
+
+
+def _i8_rows(P):
+    lib = _lib.load()
+    q8 = np.empty((P.rows, P.d), np.int8)
+    step, err, gerr = (np.empty(P.rows, np.float32) for _ in range(3))
+    _lib.check(lib.vfm_debug_i8_rows(P.buf.data_ptr(), P.rows, P.d, q8.ctypes.data, step.ctypes.data, err.ctypes.data, gerr.ctypes.data))
+    return q8, step, err, gerr
+
+
+def _heavy_tailed(rng, rows, d):
+    x = rng.standard_normal((rows, d)).astype(np.float32)
+    x[rng.random((rows, d)) < 0.002] *= 12.0            # outlier elements
+    x[::97] = 0.0
+    x[::97, rng.integers(0, d, len(x[::97]))] = 1.0     # one-hot rows
+    x[5::131] *= 1e-18                                  # tiny norms
+    x[7::89] = x[6::89][: len(x[7::89])]                # exact duplicates
+    return x
+
+
+@pytest.mark.parametrize("d", [256, 384])
+def test_quantisation_bound_holds_for_every_pair(d):
+    """| v_a . v_b - s_a s_b (q_a . q_b) | <= (1 + 2^-13 + E_a) E_b + (1 + 2^-13) E_a for every pair, with the kernel's own
+    steps, integers and measured residual norms (csrc/match.hip, prep_chunk_kernel): Gaussian and heavy-tailed rows."""
+    rng = np.random.default_rng(d)
+    n, m = 700, 3000
+    gens = ((lambda r: rng.standard_normal((r, d)).astype(np.float32), 0.03), (lambda r: _heavy_tailed(rng, r, d), 0.2))
+    for gen, typical in gens:
+        q, b = gen(n), gen(m)
+        Q, B = ops.PreparedRows(torch.from_numpy(q).cuda()), ops.PreparedRows(torch.from_numpy(b).cuda())
+        q8, sq, eq, _ = _i8_rows(Q)
+        b8, sb, eb, gb = _i8_rows(B)
+        vq, _ = orc.l2norm_rows(q)
+        vb, _ = orc.l2norm_rows(b)
+        # the measured E really bounds the residual of the oracle's normalised rows
+        for v8, s, e, v in ((q8, sq, eq, vq), (b8, sb, eb, vb)):
+            res = np.linalg.norm(v.astype(np.float64) - s[:, None].astype(np.float64) * v8.astype(np.float64), axis=1)
+            assert (e.astype(np.float64) >= res).all()
+            assert (np.abs(v8.astype(np.int32)) <= 127).all()
+        assert (gb >= eb).all()
+        t = vq.astype(np.float64) @ vb.astype(np.float64).T
+        S = q8.astype(np.float64) @ b8.astype(np.float64).T
+        dev = np.abs(t - sq[:, None].astype(np.float64) * sb[None, :].astype(np.float64) * S)
+        bound = (1 + 2.0 ** -13 + eq[:, None].astype(np.float64)) * gb[None, :] + (1 + 2.0 ** -13) * eq[:, None].astype(np.float64)
+        assert (dev <= bound).all()
+        # ... and is not vacuous: ~2e-2 on Gaussian unit rows; a one-hot row coarsens the step of its whole 128-row group
+        assert np.median(bound) < typical
+
+
+@pytest.mark.parametrize("d,n,m", [(384, 1500, 9000), (256, 2050, 5003), (384, 777, 130)])
+def test_int8_search_equals_the_oracle_on_stress_inputs(d, n, m):
+    rng = np.random.default_rng(n + m)
+    cases = {
+        "heavy": (_heavy_tailed(rng, n, d), _heavy_tailed(rng, m, d)),
+        "anticorrelated": (None, None),
+        "duplicates": (None, None),
+    }
+    base = rng.standard_normal((1, d)).astype(np.float32)
+    bq = -base + 0.3 * rng.standard_normal((n, d)).astype(np.float32)            # every similarity negative
+    bb = base + 0.3 * rng.standard_normal((m, d)).astype(np.float32)
+    cases["anticorrelated"] = (bq, bb)
+    few = rng.standard_normal((16, d)).astype(np.float32)
+    cases["duplicates"] = (few[rng.integers(0, 16, n)] + 0.0, few[rng.integers(0, 16, m)] + 0.0)  # m rows, 16 distinct
+    for name, (q, b) in cases.items():
+        # the gated family with gate = -inf: the int8 pass, every query resolved
+        idx, sim = ops.match_ip_top1(torch.from_numpy(q).cuda(), torch.from_numpy(b).cuda(), ops.FAST, gate=float("-inf"))
+        torch.cuda.synchronize()
+        qn, _ = orc.l2norm_rows(q)
+        bn, _ = orc.l2norm_rows(b)
+        ridx, rsim = orc.match_ip_top1(qn, bn)
+        np.testing.assert_array_equal(idx.cpu().numpy(), ridx, err_msg=name)
+        np.testing.assert_array_equal(sim.cpu().numpy(), rsim, err_msg=name)
+
+
+def test_gate_leaves_only_provably_rejected_queries_unresolved():
+    n, m, d = 4000, 30000, 384
+    p = synth.make_pair_device(n, m, d, seed=5)
+    outs = {}
+    for gate in (True, False):
+        pipe = RegistrationPipeline(n, m, d, n_iter=20000, gate=gate)
+        out = pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
+        torch.cuda.synchronize()
+        outs[gate] = {k: out[k].clone() for k in ("T", "idx", "sim", "count", "corres", "mask", "best_hyp")}
+    g, f = outs[True], outs[False]
+    k = int(f["count"].item())
+    assert k == int(g["count"].item()) > 1000
+    for key in ("T", "best_hyp"):
+        assert torch.equal(g[key], f[key]), key
+    for key in ("corres", "mask"):
+        assert torch.equal(g[key][:k], f[key][:k]), key
+    unresolved = g["idx"] < 0
+    assert int(unresolved.sum()) > n // 4                      # the planted outliers (50 %) mostly end here
+    assert torch.equal(g["idx"][~unresolved], f["idx"][~unresolved]) and torch.equal(g["sim"][~unresolved], f["sim"][~unresolved])
+    assert bool((f["sim"][unresolved] < 0.8).all()) and bool((g["sim"][unresolved] == -2.0).all())
+    # the ungated one-shot call (fp16 pass) and the gated one with a real gate agree wherever the latter resolves
+    i0, s0 = ops.match_ip_top1(p["q_desc"], p["b_desc"], ops.FAST)
+    i1, s1 = ops.match_ip_top1(p["q_desc"], p["b_desc"], ops.FAST, gate=0.5)
+    ok = i1 >= 0
+    assert torch.equal(i0[ok], i1[ok]) and torch.equal(s0[ok], s1[ok]) and bool((s0[~ok] < 0.5).all()) and int((~ok).sum()) > n // 4
+    assert torch.equal(i0, f["idx"]) and torch.equal(s0, f["sim"])
+    # and the fully resolved run is the oracle's
+    qn, _ = orc.l2norm_rows(p["q_desc"].cpu().numpy())
+    bn, _ = orc.l2norm_rows(p["b_desc"].cpu().numpy())
+    ridx, rsim = orc.match_ip_top1(qn, bn)
+    np.testing.assert_array_equal(f["idx"].cpu().numpy(), ridx)
+    np.testing.assert_array_equal(f["sim"].cpu().numpy(), rsim)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""int8 coarse pass (variant 8) vs the fp16 one (variant 0): coarse-kernel time, record / candidate counts, finish time,
+"""int8 coarse pass (gated family, variant 0) vs the fp16 one (variant 5): coarse-kernel time, record / candidate counts, finish time,
 and equality of the answers."""
 import ctypes as C
+import os
 import sys
 import time
 from pathlib import Path
@@ -22,8 +23,9 @@ _lib.check(lib.vfm_prof_events_create(C.byref(a), C.byref(b)))
 ms = C.c_float()
 st = torch.cuda.current_stream().cuda_stream
 res = {}
+GATE = C.c_float(float(os.environ.get("VFM_GATE", "-inf")))
 import os
-VARIANTS = tuple(int(v) for v in os.environ.get("VFM_AB_VARIANTS", "0,9,8,0,9").split(","))
+VARIANTS = tuple(int(v) for v in os.environ.get("VFM_AB_VARIANTS", "0,5,0,5").split(","))
 for variant in VARIANTS:
     lib.vfm_debug_set_coarse_variant(variant)
     t, tf = [], []
@@ -31,20 +33,20 @@ for variant in VARIANTS:
     sim = torch.empty(n, dtype=torch.float32, device="cuda")
     for i in range(12):
         lib.vfm_prof_arm(a, b)
-        _lib.check(lib.vfm_match_search_coarse(Q.buf.data_ptr(), n, B.buf.data_ptr(), m, d, ws.data_ptr(), ws.numel(), st))
+        _lib.check(lib.vfm_match_search_coarse_gated(Q.buf.data_ptr(), n, B.buf.data_ptr(), m, d, ws.data_ptr(), ws.numel(), st))
         torch.cuda.synchronize()
         _lib.check(lib.vfm_prof_elapsed_ms(a, b, C.byref(ms)))
         t0 = time.perf_counter()
-        _lib.check(lib.vfm_match_search_finish(p["q_desc"].data_ptr(), Q.buf.data_ptr(), n, p["b_desc"].data_ptr(), B.buf.data_ptr(), m, d,
-                                               idx.data_ptr(), sim.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        _lib.check(lib.vfm_match_search_finish_gated(p["q_desc"].data_ptr(), Q.buf.data_ptr(), n, p["b_desc"].data_ptr(), B.buf.data_ptr(), m, d,
+                                                     idx.data_ptr(), sim.data_ptr(), ws.data_ptr(), ws.numel(), GATE, st))
         torch.cuda.synchronize()
         if i >= 2:
             t.append(ms.value)
             tf.append(1e3 * (time.perf_counter() - t0))
     lib.vfm_debug_set_match_stats(1)
-    _lib.check(lib.vfm_match_search_coarse(Q.buf.data_ptr(), n, B.buf.data_ptr(), m, d, ws.data_ptr(), ws.numel(), st))
-    _lib.check(lib.vfm_match_search_finish(p["q_desc"].data_ptr(), Q.buf.data_ptr(), n, p["b_desc"].data_ptr(), B.buf.data_ptr(), m, d,
-                                           idx.data_ptr(), sim.data_ptr(), ws.data_ptr(), ws.numel(), st))
+    _lib.check(lib.vfm_match_search_coarse_gated(Q.buf.data_ptr(), n, B.buf.data_ptr(), m, d, ws.data_ptr(), ws.numel(), st))
+    _lib.check(lib.vfm_match_search_finish_gated(p["q_desc"].data_ptr(), Q.buf.data_ptr(), n, p["b_desc"].data_ptr(), B.buf.data_ptr(), m, d,
+                                                 idx.data_ptr(), sim.data_ptr(), ws.data_ptr(), ws.numel(), GATE, st))
     stats = (C.c_int32 * 64)()
     _lib.check(lib.vfm_debug_match_stats(ws.data_ptr(), n, m, stats))
     lib.vfm_debug_set_match_stats(0)
@@ -53,6 +55,6 @@ for variant in VARIANTS:
           f"refined {s[1]}, candidates/query {s[2] / n:.2f}, kept {s[3]}, records/query {s[4] / n:.1f}, histogram {s[8:24]}", flush=True)
     res[variant] = (idx.clone(), sim.clone())
 lib.vfm_debug_set_coarse_variant(0)
-if 0 in res and 9 in res:
-    print("idx equal:", bool((res[0][0] == res[9][0]).all()), " sim equal:", bool((res[0][1] == res[9][1]).all()),
-          " mismatches:", int((res[0][0] != res[9][0]).sum()))
+if 0 in res and 5 in res:
+    print("idx equal:", bool((res[0][0] == res[5][0]).all()), " sim equal:", bool((res[0][1] == res[5][1]).all()),
+          " mismatches:", int((res[0][0] != res[5][0]).sum()))

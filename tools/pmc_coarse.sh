@@ -16,10 +16,11 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
 done
 python - <<PY
 import csv, glob, collections, json
-agg = collections.defaultdict(list); dur = []
+agg = collections.defaultdict(list); dur = []; kname = ""
 for f in sorted(glob.glob("$O/p*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         if "match_coarse" in r["Kernel_Name"]:
+            kname = r["Kernel_Name"]
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in sorted(glob.glob("$O/p*_kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
@@ -29,11 +30,13 @@ a = {k: sum(v) / len(v) for k, v in agg.items()}
 cyc = a["GRBM_GUI_ACTIVE"] / 8
 d = sorted(dur)[len(dur) // 2]
 out = {
-    "kernel": "match_coarse_pipe_kernel<24, true> (sparse row-level records)", "workload": "C2 20000x200000x384, one launch",
+    "kernel": kname.split("(")[0].replace("void (anonymous namespace)::", "").strip()
+              + (" (int8 32x32x32 MFMA, dense per-chunk records)" if "false, true" in kname else " (fp16 32x32x16 MFMA)"),
+    "workload": "C2 20000x200000x384, one launch",
     "counters_avg_per_launch": a,
     "FETCH_SIZE_KB": a["FETCH_SIZE"], "WRITE_SIZE_KB": a["WRITE_SIZE"],
     "hbm_bytes_per_launch": (2 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024,
-    "note": "FETCH_SIZE doubled (gfx950 reports 1/2 of a wide coalesced stream, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported (round 1: it matched the 253 MB of per-chunk records that no longer exist); separate --pmc passes with --kernel-trace only",
+    "note": "FETCH_SIZE doubled (gfx950 reports 1/2 of a wide coalesced stream, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported (it matches the 253 MB of per-chunk records where the kernel writes them); separate --pmc passes with --kernel-trace only",
     "TCC_hit_rate": a["TCC_HIT_sum"] / (a["TCC_HIT_sum"] + a["TCC_MISS_sum"]),
     "median_duration_us_under_pmc": d, "cycles_per_xcd": cyc, "clock_GHz": cyc / d / 1e3,
     "mfma_busy_fraction": a["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024),

@@ -23,6 +23,7 @@
 #include "common.h"
 
 #include <type_traits>
+#include <vector>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -188,7 +189,6 @@ struct PrepOut {
     float* inv;       // [rows_pad]
     uint4* tiles;     // fp16 fragment tiles
     float* err;       // [rows_pad] E per row
-    unsigned* emax;   // bits of the operand's maximum E (atomicMax; zeroed by the host before the launch)
     float* gstep;     // [rows_pad / 128] quantisation step of the group
     float* gerr;      // [rows_pad / 128] maximum E of the group
     uint4* tiles8;    // int8 fragment tiles
@@ -346,7 +346,6 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
     if (threadIdx.x == 0) {
         o.gstep[grp] = qstep;
         o.gerr[grp] = __uint_as_float(emax_bits);
-        if (emax_bits > 0u) atomicMax(o.emax, emax_bits);
     }
 }
 
@@ -522,6 +521,18 @@ __device__ __forceinline__ unsigned coarse_emit_chunk(const CoarseArgs& a, unsig
     s1 = 0u;
     s2 = 0u;
     return w1 & ~127u;  // the chunk's best score, low 7 bits dropped (all lanes)
+}
+
+// int8 pass: the chunk's BEST VALUE only -- one VALU op per accumulator element instead of three (with the packed top-2 the
+// fold had become the kernel's limiter: the int8 MFMA halves the matrix time per element -- 5 VALU ops per MFMA, matrix pipe
+// 56 % busy) and a 4-byte record.  Which rows of a candidate chunk matter is found by match_refine_kernel's int8 rescan.
+__device__ __forceinline__ unsigned coarse_emit_chunk_best(const CoarseArgs& a, unsigned& s1, int qt, int chunk) {
+    const int lane = lane_id();
+    const unsigned w1 = max(s1, (unsigned)__shfl_xor(s1, 32));
+    if (lane < 32 && qt < a.nq_tiles && chunk >= 0)
+        reinterpret_cast<unsigned*>(a.partials)[(size_t)chunk * a.npad + (size_t)qt * 32 + lane] = w1;
+    s1 = 0u;
+    return w1;
 }
 
 // QSETS = 32-query sets resident per wave: 1 -> 8 waves (2 per SIMD), 2 -> 4 waves (1 per SIMD,
@@ -781,7 +792,9 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
     auto fold_tail = [&](int it) {
         if constexpr (!SPARSE) {
             const int chunk = it >= 0 ? c0 + (it >> 2) : -1;
-            const unsigned best = coarse_emit_chunk(a, s1, s2, runmax, qt, chunk);
+            unsigned best;
+            if constexpr (I8) best = coarse_emit_chunk_best(a, s1, qt, chunk);
+            else best = coarse_emit_chunk(a, s1, s2, runmax, qt, chunk);
             if constexpr (I8) {
                 if (chunk >= 0 && chunk < a.first_pad_chunk) {  // wave-uniform
                     const float sb = a.ib.bstep[chunk], be = a.ib.berr[chunk];
@@ -791,8 +804,13 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
         }
     };
     auto fold_one = [&](accel_t v, int code) {
-        if constexpr (SPARSE) s1 = max(s1, score_bits(v));  // s1 = maximum of the step being folded
-        else coarse_fold(s1, s2, v, code);
+        if constexpr (SPARSE) {
+            s1 = max(s1, score_bits(v));  // s1 = maximum of the step being folded
+        } else if constexpr (I8) {
+            s1 = max(s1, score_bits(v));
+        } else {
+            coarse_fold(s1, s2, v, code);
+        }
     };
     // SPARSE: end of the fold of tiles (t0, t0 + 1) of this unit, whose accumulators are still in p0 / p1
     auto step_tail = [&](int t0, const acc_t& p0, const acc_t& p1) __attribute__((always_inline)) {
@@ -1147,37 +1165,36 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
     if (ib.qerr) {
         // Records of the int8 pass: integer scores in the units of (query group step) x (map chunk step).  In exact score
         // units, with A = (1 + 2^-13) E_q and B_c = (1 + 2^-13 + E_q) max E of chunk c (prep_chunk_kernel):
-        //     lower_c = s_q s_c S_lo(c) - A - B_c  <=  best exact score of chunk c  <=  s_q s_c S_hi(c) + A + B_c = upper_c
-        // (S_lo / S_hi: the packed record drops the low 7 bits of the best and the low 6 bits of the second-best score).
+        //     lower_c = s_q s_c S(c) - A - B_c  <=  best exact score of chunk c  <=  s_q s_c S(c) + A + B_c = upper_c
+        // (S(c): the chunk's best integer score, exact).
         // qlow = max over the un-padded chunks of lower_c, a lower bound of the query's exact maximum, comes from the coarse
-        // kernel (qmax holds its float_key).  Every chunk with upper_c >= qlow is a candidate (its best row; the whole chunk if the second-best's upper
-        // bound reaches qlow too): the oracle's arg-max row is the best row of its chunk or inside a rescanned chunk.
+        // kernel (qmax holds its float_key).  Every chunk with upper_c >= qlow is a candidate:
+        // the oracle's arg-max row is inside one of them, and match_refine_kernel finds the rows (int8 rescan, then fp32).
         // fp32 evaluation of the bounds: three roundings on magnitudes <= 2 -- 1e-6 of slack covers them.
         const float eq = ib.qerr[q], sq = ib.qstep[q >> 7];
         const float A = eq * 1.0001220703125f, mult = 1.0001220703125f + eq, slack = 1.0e-6f;
         const float qlow = key_float(qmax[q]);  // -Inf: no un-padded chunk exists -> every chunk is a candidate
         float maxup = -__builtin_inff();
+        const unsigned* best = reinterpret_cast<const unsigned*>(partials);  // [nchunks][npad] best integer score (+ 2^30)
         for (int cb = g; cb < nchunks; cb += 8 * SELECT_GROUPS) {
-            uint2 rec[8];
+            unsigned rec[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = cb + SELECT_GROUPS * u;
-                rec[u] = (c < nchunks) ? partials[(size_t)c * npad + q] : make_uint2(0u, 0u);
+                rec[u] = (c < nchunks) ? best[(size_t)c * npad + q] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = cb + SELECT_GROUPS * u;
                 if (c >= nchunks) continue;
                 const float sc = sq * ib.bstep[c], bound = A + mult * ib.berr[c] + slack;
-                const float up1 = sc * (float)((int)(rec[u].x | 127u) - I8_OFFSET) + bound;
+                const float up1 = sc * (float)((int)rec[u] - I8_OFFSET) + bound;
                 maxup = fmaxf(maxup, up1);
                 if (up1 >= qlow) {  // (zero-padded rows score exactly 0: a padded chunk is a candidate only if 0 is inside the window)
                     const int slot = atomicAdd(&lcnt[qq], 1);
-                    if (slot < cap && q < n) {
-                        const float up2 = sc * (float)((int)(rec[u].y | 63u) - I8_OFFSET) + bound;
-                        const unsigned rescan = (up2 >= qlow || c >= first_pad_chunk) ? 1u : 0u;
-                        cand[(size_t)q * cap + slot] = ((unsigned)c << 8) | (rescan << 7) | (rec[u].x & 127u);
-                    }
+                    // (the records hold values only: which rows of the chunk reach qlow is found by match_refine_kernel's
+                    // int8 rescan -- every entry is a whole-chunk entry)
+                    if (slot < cap && q < n) cand[(size_t)q * cap + slot] = ((unsigned)c << 8) | 128u;
                 }
             }
         }
@@ -1433,13 +1450,18 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
                 const int rr = lane + 64 * half;  // row of the chunk: tile rr >> 5, position rr & 31
                 const uint4* src = b8 + ((size_t)c * 4 + (rr >> 5)) * (size_t)(units8 * 32) + (rr & 31);
                 int acc = 0;
-                for (int u = 0; u < units8; ++u) {
-                    const uint4 bv = src[u * 32];
-                    const uint4 qv = l_q8[wave][u];
-                    acc = __builtin_amdgcn_sdot4((int)bv.x, (int)qv.x, acc, false);
-                    acc = __builtin_amdgcn_sdot4((int)bv.y, (int)qv.y, acc, false);
-                    acc = __builtin_amdgcn_sdot4((int)bv.z, (int)qv.z, acc, false);
-                    acc = __builtin_amdgcn_sdot4((int)bv.w, (int)qv.w, acc, false);
+                for (int u0 = 0; u0 < units8; u0 += 8) {  // units8 = 16 or 24: eight 16-byte loads in flight per lane
+                    uint4 bv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bv[j] = src[(u0 + j) * 32];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint4 qv = l_q8[wave][u0 + j];
+                        acc = __builtin_amdgcn_sdot4((int)bv[j].x, (int)qv.x, acc, false);
+                        acc = __builtin_amdgcn_sdot4((int)bv[j].y, (int)qv.y, acc, false);
+                        acc = __builtin_amdgcn_sdot4((int)bv[j].z, (int)qv.z, acc, false);
+                        acc = __builtin_amdgcn_sdot4((int)bv[j].w, (int)qv.w, acc, false);
+                    }
                 }
                 const bool hit = base + rr < m && sc * (float)acc + bound >= i8_qlow;
                 const unsigned long long bal = __ballot(hit);
@@ -2087,7 +2109,6 @@ struct Prepared {
     uint4* tiles;
     // int8 image (i8_capable(d); prep_chunk_kernel)
     float* err;       // E per row
-    unsigned* emax;   // bits of the operand's maximum E (256 B slot)
     float* gstep;     // quantisation step per group of 128 rows
     float* gerr;      // maximum E per group
     uint4* tiles8;    // int8 fragment tiles
@@ -2104,12 +2125,10 @@ inline Prepared carve_prepared(void* p, int64_t rows, int d) {
     r.inv = c.take<float>((size_t)rp);
     r.tiles = c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(d / 16) * 64);
     r.err = nullptr;
-    r.emax = nullptr;
     r.gstep = r.gerr = nullptr;
     r.tiles8 = nullptr;
     if (i8_capable(d)) {  // behind the fp16 image: the Euclidean path carves the same layout and ignores the rest
         r.err = c.take<float>((size_t)rp);
-        r.emax = c.take<unsigned>(64);
         r.gstep = c.take<float>((size_t)rp / I8_GROUP);
         r.gerr = c.take<float>((size_t)rp / I8_GROUP);
         r.tiles8 = c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(d / 32) * 64);
@@ -2205,9 +2224,12 @@ inline bool use_sparse(int d, int64_t n, int64_t m) {
            (g_coarse_qsets == 0 || g_coarse_qsets == 3 || g_coarse_qsets == 5);
 }
 
-// ... and before those, for d = 256 / 384, the int8 coarse pass with dense per-chunk records (variant 5 = the fp16 pass, A/B)
-inline bool use_i8(int d, int64_t n, int64_t m) {
-    return i8_capable(d) && m < (1ll << 24) && n > 2 * QBLOCK && (g_coarse_qsets == 0 || g_coarse_qsets == 9);
+// ... and before those, in the GATED family of entry points (callers that keep only matches above a similarity gate), for
+// d = 256 / 384: the int8 coarse pass with one best-score record per (query, chunk).  Its exact re-decision costs an int8
+// rescan per candidate chunk, cheap when most unmatched queries stop at the gate and slower than the fp16 pass when every
+// query must be resolved -- so the ungated entry points keep the fp16 pass.  (variant 5 = fp16 pass everywhere, A/B)
+inline bool use_i8(int d, int64_t n, int64_t m, bool gated) {
+    return gated && i8_capable(d) && m < (1ll << 24) && n > 2 * QBLOCK && (g_coarse_qsets == 0 || g_coarse_qsets == 9);
 }
 inline I8Bounds i8_bounds(const Prepared& Q, const Prepared& B, bool on) {
     return on ? I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr} : I8Bounds{nullptr, nullptr, nullptr, nullptr};
@@ -2289,7 +2311,7 @@ int launch_coarse(const CoarseArgs& a, hipStream_t st) {
     return VFM_OK;
 }
 
-inline PrepOut prep_out(const Prepared& p) { return PrepOut{p.inv, p.tiles, p.err, p.emax, p.gstep, p.gerr, p.tiles8}; }
+inline PrepOut prep_out(const Prepared& p) { return PrepOut{p.inv, p.tiles, p.err, p.gstep, p.gerr, p.tiles8}; }
 
 // one or two operands (x2 may be NULL) in one launch.  want_f16 = false: only the int8 image (d = 256, 384), for operands that
 // will meet in an int8 search (use_i8): a third of the bytes written, a third of the LDS.
@@ -2305,8 +2327,6 @@ int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2
                                               hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * 384 * 3));
             attr_mark(attr_set);
         }
-        VFM_CHECK_HIP(hipMemsetAsync(p1.emax, 0, sizeof(unsigned), st));
-        if (x2) VFM_CHECK_HIP(hipMemsetAsync(p2.emax, 0, sizeof(unsigned), st));
         if (want_f16)
             hipLaunchKernelGGL(prep_chunk_kernel<true>, dim3((unsigned)(g1 + g2)), dim3(1024), (size_t)I8_GROUP * d * 3, st, x1, rows1, d,
                                prep_out(p1), g1, x2, rows2, prep_out(p2));
@@ -2354,7 +2374,7 @@ CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, 
 
 // stage 1 of a search: the MFMA coarse pass (fills ws: partials + per-query coarse maxima)
 int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, hipStream_t st,
-                     bool bias_from_map_inv = false, bool inner_product = false) {
+                     bool bias_from_map_inv = false, bool inner_product = false, bool gated = false) {
     Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
     Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
     SearchWs w = carve_search(ws, n, m);
@@ -2363,7 +2383,7 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
         if (d != 640 && d != 768) return vfm_fail(VFM_EINVAL, "row bias needs the 4-wave coarse kernel (K = 640 / 768), got %d", d);
         a.row_bias = B.inv;
     }
-    if (inner_product && !use_i8(d, n, m) && use_sparse(d, n, m)) {
+    if (inner_product && !use_i8(d, n, m, gated) && use_sparse(d, n, m)) {
         a.rec_cnt = w.rec_cnt;
         a.rec = w.rec;
         a.rcap = w.rcap;
@@ -2375,7 +2395,7 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
         }
     }
     VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, 256 + 2 * (size_t)a.npad * sizeof(unsigned), st));  // fb_count | qmax | rec_cnt
-    if (inner_product && use_i8(d, n, m)) {
+    if (inner_product && use_i8(d, n, m, gated)) {
         a.Qh = Q.tiles8;
         a.Bh = B.tiles8;
         a.ib = I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr};
@@ -2401,16 +2421,17 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
 }
 
 // stage 2 of a search: candidate selection + exact fp64 decision (reads ws of stage 1)
-// gate: queries whose best similarity is provably below it are reported as (-1, -2.0) instead of being resolved (int8 pass
-// only; -Inf = resolve every query)
+// gated: the search was started by the gated family (do_search_coarse(..., gated)); gate: queries whose best similarity is
+// provably below it are reported as (-1, -2.0) instead of being resolved (int8 pass only; -Inf = resolve every query)
 int do_search_finish(const float* q, const void* qprep, int64_t n, const float* b, const void* bprep, int64_t m, int d,
-                     int64_t* idx_out, float* sim_out, void* ws, hipStream_t st, float gate = -__builtin_inff()) {
+                     int64_t* idx_out, float* sim_out, void* ws, hipStream_t st, bool gated = false,
+                     float gate = -__builtin_inff()) {
     Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
     Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
     SearchWs w = carve_search(ws, n, m);
     const CoarseArgs a = coarse_args(Q, B, w, n, m, coarse_qblock(d));
     const float w2 = 2.0f * (float)(d / 16 + 4 + 2) * 5.9604645e-8f;
-    const bool i8 = use_i8(d, n, m);
+    const bool i8 = use_i8(d, n, m, gated);
     if (!i8 && use_sparse(d, n, m)) {
         hipLaunchKernelGGL(match_filter_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d,
                            DEFAULT_WINDOW, w2, w.qmax, w.rec_cnt, w.rec, w.rcap, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
@@ -2473,8 +2494,15 @@ VFM_EXPORT int vfm_match_prepare2(const float* x1, int64_t rows1, void* prepared
                                   int d, vfm_stream_t stream) {
     VFM_CHECK_ARG(rows1 > 0 && rows2 > 0 && d % 128 == 0 && d >= 128 && d <= 768, "prepare2: d must be in {128,256,384,512,640,768}");
     VFM_CHECK_ARG(x1 && x2 && prepared1 && prepared2, "prepare2: null pointer");
-    // (map, scan): when the two will meet in an int8 search, the fp16 image is not needed
-    const bool want_f16 = !use_i8(d, rows2, rows1) || g_coarse_qsets != 0;
+    return do_prepare2(x1, rows1, prepared1, x2, rows2, prepared2, d, (hipStream_t)stream);
+}
+
+VFM_EXPORT int vfm_match_prepare2_gated(const float* x1, int64_t rows1, void* prepared1, const float* x2, int64_t rows2,
+                                        void* prepared2, int d, vfm_stream_t stream) {
+    VFM_CHECK_ARG(rows1 > 0 && rows2 > 0 && d % 128 == 0 && d >= 128 && d <= 768, "prepare2: d must be in {128,256,384,512,640,768}");
+    VFM_CHECK_ARG(x1 && x2 && prepared1 && prepared2, "prepare2: null pointer");
+    // (map, scan): where the gated search of x2 in x1 runs the int8 pass, the fp16 image is never read
+    const bool want_f16 = !use_i8(d, rows2, rows1, true);
     return do_prepare2(x1, rows1, prepared1, x2, rows2, prepared2, d, (hipStream_t)stream, want_f16);
 }
 
@@ -2516,13 +2544,20 @@ VFM_EXPORT int vfm_match_search_finish(const float* q, const void* q_prepared, i
     return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream);
 }
 
+VFM_EXPORT int vfm_match_search_coarse_gated(const void* q_prepared, int64_t n, const void* b_prepared, int64_t m, int d,
+                                             void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
+    VFM_CHECK_ARG(q_prepared && b_prepared && ws, "search_coarse: null pointer");
+    return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream, false, true, true);
+}
+
 VFM_EXPORT int vfm_match_search_finish_gated(const float* q, const void* q_prepared, int64_t n, const float* b,
                                              const void* b_prepared, int64_t m, int d, int64_t* idx_out, float* sim_out,
                                              void* ws, size_t ws_bytes, float gate, vfm_stream_t stream) {
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q && b && q_prepared && b_prepared && ws && idx_out && sim_out, "search_finish: null pointer");
     VFM_CHECK_ARG(gate == gate, "search_finish: gate is NaN");
-    return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream, gate);
+    return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream, true, gate);
 }
 
 VFM_EXPORT size_t vfm_match_ip_top1_workspace_bytes(int64_t n, int64_t m, int d, int prec_mode) {
@@ -2544,8 +2579,22 @@ __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__
 }
 }  // namespace
 
+namespace {
+int ip_top1(const float* q, int64_t n, const float* b, int64_t m, int d, int prec_mode, bool gated, float gate, int64_t* idx_out,
+            float* sim_out, void* ws, size_t ws_bytes, vfm_stream_t stream);
+}
 VFM_EXPORT int vfm_match_ip_top1(const float* q, int64_t n, const float* b, int64_t m, int d, int prec_mode,
                                  int64_t* idx_out, float* sim_out, void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    return ip_top1(q, n, b, m, d, prec_mode, false, 0.0f, idx_out, sim_out, ws, ws_bytes, stream);
+}
+VFM_EXPORT int vfm_match_ip_top1_gated(const float* q, int64_t n, const float* b, int64_t m, int d, int prec_mode, float gate,
+                                       int64_t* idx_out, float* sim_out, void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    VFM_CHECK_ARG(gate == gate, "match: gate is NaN");
+    return ip_top1(q, n, b, m, d, prec_mode, true, gate, idx_out, sim_out, ws, ws_bytes, stream);
+}
+namespace {
+int ip_top1(const float* q, int64_t n, const float* b, int64_t m, int d, int prec_mode, bool gated, float gate, int64_t* idx_out,
+            float* sim_out, void* ws, size_t ws_bytes, vfm_stream_t stream) {
     VFM_CHECK_ARG(n > 0 && m > 0, "match: empty operand (n=%lld m=%lld)", (long long)n, (long long)m);
     VFM_CHECK_ARG(q && b && idx_out && sim_out && ws, "match: null pointer");
     if (ws_bytes < vfm_match_ip_top1_workspace_bytes(n, m, d, prec_mode)) return vfm_fail(VFM_EWORKSPACE, "match: workspace too small");
@@ -2570,13 +2619,14 @@ VFM_EXPORT int vfm_match_ip_top1(const float* q, int64_t n, const float* b, int6
     void* qprep = p;
     void* bprep = p + vfm_match_prepared_bytes(n, d);
     void* sws = p + vfm_match_prepared_bytes(n, d) + vfm_match_prepared_bytes(m, d);
-    int rc = do_prepare(q, n, d, qprep, st);
+    VFM_CHECK_ARG(m < (1ll << 31) - 256 && n < (1ll << 31) - 256, "match: more than 2^31 rows");
+    int rc = do_prepare2(b, m, bprep, q, n, qprep, d, st, !use_i8(d, n, m, gated));
     if (rc) return rc;
-    rc = do_prepare(b, m, d, bprep, st);
+    rc = do_search_coarse(qprep, n, bprep, m, d, sws, st, false, true, gated);
     if (rc) return rc;
-    return vfm_match_search_prepared(q, qprep, n, b, bprep, m, d, idx_out, sim_out, sws,
-                                     vfm_match_search_workspace_bytes(n, m, d), stream);
+    return do_search_finish(q, qprep, n, b, bprep, m, d, idx_out, sim_out, sws, st, gated, gated ? gate : -__builtin_inff());
 }
+}  // namespace
 
 VFM_EXPORT int vfm_threshold_compact(const float* sim, const int64_t* idx, int64_t n, double thr, int64_t* keep_out,
                                      int64_t* count_out, int32_t* corres_out, const double* q_xyz, const double* b_xyz,
@@ -2707,6 +2757,35 @@ VFM_EXPORT int vfm_debug_match_stats(void* ws, int64_t n, int64_t m, int32_t* ou
     SearchWs w = carve_search(ws, n, m);
     VFM_CHECK_HIP(hipDeviceSynchronize());
     VFM_CHECK_HIP(hipMemcpy(out64_host, w.fb_count, 64 * sizeof(int), hipMemcpyDeviceToHost));
+    return VFM_OK;
+}
+
+// The int8 image of a prepared operand, unpacked on the host: q8_host[rows][d] (int8), step_host[rows] (the row's group
+// step), err_host[rows] (E), gerr_host[rows] (its group's maximum E).  Tests only (the bound of prep_chunk_kernel is checked
+// pair by pair against fp64 scores).  Synchronises the device.
+VFM_EXPORT int vfm_debug_i8_rows(const void* prepared, int64_t rows, int d, int8_t* q8_host, float* step_host, float* err_host,
+                                 float* gerr_host) {
+    VFM_CHECK_ARG(prepared && rows > 0 && i8_capable(d) && q8_host && step_host && err_host && gerr_host, "i8_rows: bad arguments");
+    Prepared p = carve_prepared(const_cast<void*>(prepared), rows, d);
+    const int64_t rp = rows_padded(rows);
+    const size_t units = (size_t)rp / TILE_ROWS * (size_t)(d / 32) * 64;
+    std::vector<uint4> tiles(units);
+    std::vector<float> gstep((size_t)rp / I8_GROUP), gerr((size_t)rp / I8_GROUP);
+    VFM_CHECK_HIP(hipDeviceSynchronize());
+    VFM_CHECK_HIP(hipMemcpy(tiles.data(), p.tiles8, units * sizeof(uint4), hipMemcpyDeviceToHost));
+    VFM_CHECK_HIP(hipMemcpy(gstep.data(), p.gstep, gstep.size() * sizeof(float), hipMemcpyDeviceToHost));
+    VFM_CHECK_HIP(hipMemcpy(gerr.data(), p.gerr, gerr.size() * sizeof(float), hipMemcpyDeviceToHost));
+    VFM_CHECK_HIP(hipMemcpy(err_host, p.err, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost));
+    const int upt = (d / 32) * 64;  // units per tile
+    for (int64_t r = 0; r < rows; ++r) {
+        const int64_t tile = r / TILE_ROWS, pp = r % TILE_ROWS;
+        for (int u = 0; u < d / 16; ++u) {  // unit u = 2 s + h holds k = 16 u .. 16 u + 15
+            const int8_t* src = reinterpret_cast<const int8_t*>(&tiles[(size_t)tile * upt + (size_t)u * 32 + pp]);
+            for (int k = 0; k < 16; ++k) q8_host[r * (int64_t)d + 16 * u + k] = src[k];
+        }
+        step_host[r] = gstep[(size_t)(r / I8_GROUP)];
+        gerr_host[r] = gerr[(size_t)(r / I8_GROUP)];
+    }
     return VFM_OK;
 }
 

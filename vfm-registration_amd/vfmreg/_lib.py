@@ -35,13 +35,17 @@ SIGNATURES = {
     "vfm_l2norm_rows_f32": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, c_vp]),
     "vfm_match_ip_top1_workspace_bytes": (C.c_size_t, [c_i64, c_i64, C.c_int, C.c_int]),
     "vfm_match_ip_top1": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_vp, c_vp, C.c_size_t, c_vp]),
+    "vfm_match_ip_top1_gated": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, C.c_float, c_vp, c_vp, c_vp, C.c_size_t,
+                                          c_vp]),
     "vfm_match_prepared_bytes": (C.c_size_t, [c_i64, C.c_int]),
     "vfm_match_prepare": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, c_vp]),
     "vfm_match_prepare2": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, C.c_int, c_vp]),
+    "vfm_match_prepare2_gated": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, C.c_int, c_vp]),
     "vfm_match_search_workspace_bytes": (C.c_size_t, [c_i64, c_i64, C.c_int]),
     "vfm_match_search_prepared": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp,
                                             C.c_size_t, c_vp]),
     "vfm_match_search_coarse": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, c_vp, C.c_size_t, c_vp]),
+    "vfm_match_search_coarse_gated": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, c_vp, C.c_size_t, c_vp]),
     "vfm_match_search_finish": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp,
                                           C.c_size_t, c_vp]),
     "vfm_match_search_finish_gated": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp,
@@ -74,6 +78,7 @@ SIGNATURES = {
     "vfm_prof_events_destroy": (C.c_int, [c_vp, c_vp]),
     "vfm_debug_match_stats": (C.c_int, [c_vp, c_i64, c_i64, c_vp]),
     "vfm_debug_set_match_stats": (C.c_int, [C.c_int]),
+    "vfm_debug_i8_rows": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp, c_vp]),
     "vfm_debug_set_coarse_window": (C.c_int, [C.c_float]),
     "vfm_debug_set_vit_gemm": (C.c_int, [C.c_int, C.c_int]),
     "vfm_debug_set_coarse_variant": (C.c_int, [C.c_int]),

@@ -50,8 +50,10 @@ def l2norm_rows_(x: torch.Tensor, inv_out: Optional[torch.Tensor] = None) -> tor
 
 
 def match_ip_top1(q: torch.Tensor, b: torch.Tensor, prec: int = FAST,
-                  ws: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Normalise + IndexFlatIP top-1 (VoxelHashMap.cpp:469-495). Returns (idx int64[N], sim fp32[N])."""
+                  ws: Optional[torch.Tensor] = None, gate: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Normalise + IndexFlatIP top-1 (VoxelHashMap.cpp:469-495). Returns (idx int64[N], sim fp32[N]).
+    ``gate`` (the gated family of include/vfmreg.h): for a caller that keeps only matches with similarity >= gate
+    (VoxelHashMap.cpp:501-511) -- queries that provably cannot reach it come back as (-1, -2.0); ``-inf`` resolves all."""
     _chk(q, torch.float32, "q")
     _chk(b, torch.float32, "b")
     if q.dim() != 2 or b.dim() != 2 or q.shape[1] != b.shape[1]:
@@ -64,8 +66,12 @@ def match_ip_top1(q: torch.Tensor, b: torch.Tensor, prec: int = FAST,
         ws = _ws(need, q.device)
     idx = torch.empty(n, dtype=torch.int64, device=q.device)
     sim = torch.empty(n, dtype=torch.float32, device=q.device)
-    _lib.check(lib.vfm_match_ip_top1(q.data_ptr(), n, b.data_ptr(), m, d, prec, idx.data_ptr(), sim.data_ptr(),
-                                     ws.data_ptr(), ws.numel(), _stream()), "match_ip_top1")
+    if gate is None:
+        _lib.check(lib.vfm_match_ip_top1(q.data_ptr(), n, b.data_ptr(), m, d, prec, idx.data_ptr(), sim.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), _stream()), "match_ip_top1")
+    else:
+        _lib.check(lib.vfm_match_ip_top1_gated(q.data_ptr(), n, b.data_ptr(), m, d, prec, float(gate), idx.data_ptr(),
+                                               sim.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "match_ip_top1")
     return idx, sim
 
 

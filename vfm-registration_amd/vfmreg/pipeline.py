@@ -130,15 +130,15 @@ class RegistrationPipeline:
                 self.prep_stream.wait_event(r.done)     # the solve stage that last read this set has finished
             pst = self.prep_stream.cuda_stream
         if not (reuse_map and r.map_key == b_desc.data_ptr()):
-            _lib.check(lib.vfm_match_prepare2(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
-                                              r.qprep.data_ptr(), self.d, pst), "prepare(map + scan)")
+            _lib.check(lib.vfm_match_prepare2_gated(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
+                                                    r.qprep.data_ptr(), self.d, pst), "prepare(map + scan)")
             r.map_key = b_desc.data_ptr() if reuse_map else None
         else:
             _lib.check(lib.vfm_match_prepare(q_desc.data_ptr(), self.n, self.d, r.qprep.data_ptr(), pst), "prepare(scan)")
         if self.overlap and pst != st:
             main.wait_stream(self.prep_stream)
-        _lib.check(lib.vfm_match_search_coarse(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
-                                               r.sws.data_ptr(), r.sws.numel(), st), "search(coarse)")
+        _lib.check(lib.vfm_match_search_coarse_gated(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
+                                                     r.sws.data_ptr(), r.sws.numel(), st), "search(coarse)")
         rst = st
         if self.overlap:  # hand over to stage 2
             ev = torch.cuda.Event()
