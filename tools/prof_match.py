@@ -23,6 +23,8 @@ n, m, d = 20000, 200000, 384
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 p = synth.make_pair_device(n, m, d, seed=42)
 for _ in range(reps):
-    idx, sim = ops.match_ip_top1(p["q_desc"], p["b_desc"], ops.FAST)
+    # the gated family (int8 pass for d = 256 / 384) with the pipeline's gate; VFM_GATE=none -> the ungated call (fp16 pass)
+    g = os.environ.get("VFM_GATE", "0.8")
+    idx, sim = ops.match_ip_top1(p["q_desc"], p["b_desc"], ops.FAST, gate=None if g == "none" else float(g))
 torch.cuda.synchronize()
-print("ok", int((idx == p["match"]).sum()))  # meaningless for ablated builds
+print("ok", int((idx == p["match"]).sum()), "unresolved", int((idx < 0).sum()))  # meaningless for ablated builds

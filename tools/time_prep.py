@@ -16,13 +16,11 @@ p = synth.make_pair_device(n, m, d, seed=1)
 qb = torch.empty(lib.vfm_match_prepared_bytes(n, d), dtype=torch.uint8, device="cuda")
 bb = torch.empty(lib.vfm_match_prepared_bytes(m, d), dtype=torch.uint8, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
-for variant, label in ((0, "int8 image only"), (5, "int8 + fp16 images")):
-    lib.vfm_debug_set_coarse_variant(variant)
+for fn, label in ((lib.vfm_match_prepare2_gated, "gated family: int8 image only"), (lib.vfm_match_prepare2, "ungated: int8 + fp16 images")):
     for rep in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(20):
-            _lib.check(lib.vfm_match_prepare2(p["b_desc"].data_ptr(), m, bb.data_ptr(), p["q_desc"].data_ptr(), n, qb.data_ptr(), d, st))
+            _lib.check(fn(p["b_desc"].data_ptr(), m, bb.data_ptr(), p["q_desc"].data_ptr(), n, qb.data_ptr(), d, st))
         torch.cuda.synchronize()
         print(f"{label}: {1e3 * (time.perf_counter() - t0) / 20:.3f} ms per call", flush=True)
-lib.vfm_debug_set_coarse_variant(0)

@@ -216,7 +216,6 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
     }
     // phase 1: the rows (read once), 1/|row| in the oracle's order, the group's largest normalised magnitude
     float4 v[RPW][2];
-    float inv[RPW];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         const int64_t r = (int64_t)grp * I8_GROUP + wave * RPW + j;
@@ -234,10 +233,26 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
             v[j][i] = t;
         }
     }
-    float lmax = 0.0f;
+    // Eight per-row sums per lane -> one per lane: a reduce-scatter over the xor-32 / 16 / 8 levels (the lane keeps half of
+    // its rows at every level and adds the partner's partial of those rows), then the xor-4 / 2 / 1 levels on the single
+    // value.  Every addition pairs the same two partials as row_sumsq_wave's butterfly (which computes each of them in both
+    // lanes), so the sum is bit-identical to the oracle's; 10 shuffles instead of 48.  Afterwards lane l holds row l >> 3.
+    auto scatter8 = [&](float (&p)[RPW]) __attribute__((always_inline)) {
+        const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+        float q4[4], q2[2];
 #pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        // sum of squares as row_sumsq_wave: lane-sequential over its chunks and elements, then an xor butterfly
+        for (int j = 0; j < 4; ++j) q4[j] = (b5 ? p[j + 4] : p[j]) + __shfl_xor(b5 ? p[j] : p[j + 4], 32);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) q2[j] = (b4 ? q4[j + 2] : q4[j]) + __shfl_xor(b4 ? q4[j] : q4[j + 2], 16);
+        float q1 = (b3 ? q2[1] : q2[0]) + __shfl_xor(b3 ? q2[0] : q2[1], 8);
+        q1 = q1 + __shfl_xor(q1, 4);
+        q1 = q1 + __shfl_xor(q1, 2);
+        q1 = q1 + __shfl_xor(q1, 1);
+        return q1;
+    };
+    float part[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {  // lane-sequential over its chunks and elements, as row_sumsq_wave
         float p = 0.0f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -249,10 +264,14 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
                 t = v[j][i].w * v[j][i].w; p = p + t;
             }
         }
+        part[j] = p;
+    }
+    const float my_inv = inv_norm_from_sumsq(scatter8(part));  // of row lane >> 3: eight rows in one evaluation
+    if ((lane & 7) == 0) o.inv[(int64_t)grp * I8_GROUP + wave * RPW + (lane >> 3)] = my_inv;
+    float lmax = 0.0f;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off);
-        const float iv = inv_norm_from_sumsq(p);
-        inv[j] = iv;
+    for (int j = 0; j < RPW; ++j) {
+        const float iv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_inv), 8 * j));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {  // normalised values exactly as faiss leaves them in fp32 (zero in the unused slots)
             v[j][i].x = v[j][i].x * iv;
@@ -261,7 +280,6 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
             v[j][i].w = v[j][i].w * iv;
             lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(v[j][i].x), fabsf(v[j][i].y)), fmaxf(fabsf(v[j][i].z), fabsf(v[j][i].w))));
         }
-        if (lane == 0) o.inv[(int64_t)grp * I8_GROUP + wave * RPW + j] = iv;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
@@ -273,11 +291,9 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
     const float qstep = usable ? amax / 127.0f : 1.0f;
     const float inv_qstep = usable ? 127.0f / amax : 0.0f;
     // phase 2: quantise from the registers
-    float wmax = 0.0f;
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         const int pr = wave * RPW + j;
-        const int64_t r = (int64_t)grp * I8_GROUP + pr;
         const int t = pr >> 5, p = pr & 31;
         float e2 = 0.0f;
 #pragma unroll
@@ -285,15 +301,18 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
             const int c = lane + 64 * i;
             if (c < nchunks) {
                 const float nv[4] = {v[j][i].x, v[j][i].y, v[j][i].z, v[j][i].w};
-                unsigned packed = 0u;
+                int qi[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float qf = rintf(nv[e] * inv_qstep);
                     qf = fminf(fmaxf(qf, -127.0f), 127.0f);                // (a NaN becomes -127: any integer is valid,
                     const float res = __builtin_fmaf(-qstep, qf, nv[e]);   //  the residual is measured: it turns E into Inf)
                     e2 = __builtin_fmaf(res, res, e2);
-                    packed |= ((unsigned)(int)qf & 0xFFu) << (8 * e);
+                    qi[e] = (int)qf;
                 }
+                // low bytes of the four integers: two byte permutes and an or
+                const unsigned packed = __builtin_amdgcn_perm((unsigned)qi[1], (unsigned)qi[0], 0x0c0c0400u) |
+                                        __builtin_amdgcn_perm((unsigned)qi[3], (unsigned)qi[2], 0x04000c0cu);
                 *reinterpret_cast<unsigned*>(img8 + (size_t)t * (d * 32) + (((c >> 3) * 2 + ((c >> 2) & 1)) * 32 + p) * 16 + (c & 3) * 4) = packed;
                 if constexpr (F16) {
                     half4 h;
@@ -306,16 +325,20 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
                 }
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) e2 = e2 + __shfl_xor(e2, off);
-        // |e|_2 rounded up: the fp32 sum of d non-negative terms is within (d + 8) 2^-24 of exact, sqrtf within 2^-24
-        float en = sqrtf(e2) * 1.000244140625f + 1.0e-30f;
-        if (!(en == en)) en = __builtin_inff();
-        if (r >= rows) en = 0.0f;
-        if (lane == 0) o.err[r] = en;
-        wmax = fmaxf(wmax, en);
+        part[j] = e2;
     }
-    if (lane == 0 && wmax > 0.0f) atomicMax(&emax_bits, __float_as_uint(wmax));
+    {
+        // |e|_2 of row lane >> 3, rounded up: the fp32 sum of d non-negative terms is within (d + 8) 2^-24 of exact, sqrtf
+        // within 2^-24
+        float en = sqrtf(scatter8(part)) * 1.000244140625f + 1.0e-30f;
+        if (!(en == en)) en = __builtin_inff();
+        const int64_t r = (int64_t)grp * I8_GROUP + wave * RPW + (lane >> 3);
+        if (r >= rows) en = 0.0f;
+        if ((lane & 7) == 0) {
+            o.err[r] = en;
+            if (en > 0.0f) atomicMax(&emax_bits, __float_as_uint(en));
+        }
+    }
     __syncthreads();
     {
         const int u8n = (d >> 5) * 64 * 4;  // uint4 units of the group's four int8 tiles
@@ -716,15 +739,17 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
 // d/32 KiB) over the int8 image of the rows (prep_chunk_kernel); integer scores offset by 2^30, DENSE records only: the
 // rigorous int8 window is ~15x the fp16 one, and row-level records against a running maximum cost 4.3 us of kernel time
 // per record and query (measured: 410 records per query at C2, 2.98 ms), while the per-chunk top-2 is window-independent.
-template <int KSTEPS, bool SPARSE, bool I8 = false>
-__global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a) {
+// NWAVES = 12 (int8 pass only: its 48 query registers leave room for 3 waves per SIMD): 384 queries per workgroup -- the
+// map is staged 2/3 as often -- and a third wave to issue while two wait.
+template <int KSTEPS, bool SPARSE, bool I8 = false, int NWAVES = 8>
+__global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void match_coarse_pipe_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NWAVES = 8;
+    static_assert(NWAVES == 8 || (NWAVES == 12 && I8), "8 waves, or 12 for the int8 pass");
     constexpr int TILE_U4 = KSTEPS * 64;
     constexpr int TILE_BYTES = TILE_U4 * 16;
     constexpr int PIECES = 2 * KSTEPS / NWAVES;  // 1 KiB pieces per wave per PAIR of tiles (one step)
     constexpr int NBUF = 6;
-    constexpr int PF = 4;
+    constexpr int PF = NWAVES == 12 ? 3 : 4;  // fragment look-ahead in k-steps (12 waves: 170-register budget)
     static_assert((2 * KSTEPS) % NWAVES == 0 && KSTEPS <= 24 && PIECES < KSTEPS, "a pair of tiles must split evenly over the waves");
     static_assert(KSTEPS % PF == 0 && KSTEPS >= 2 * PF, "fragment ring must align across steps");
     static_assert(!(I8 && SPARSE), "the int8 pass writes the dense per-chunk records");
@@ -738,7 +763,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
     const CoarseUnit cu = coarse_unit(a);
     const int qb = cu.qb, c0 = cu.c0, ntiles = cu.ntiles;
     if (ntiles == 0) return;  // uniform: padding workgroup of the seed round
-    const int qt = qb * 8 + wave;  // this wave's 32-query tile
+    const int qt = qb * NWAVES + wave;  // this wave's 32-query tile
 
     const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS unsigned char*)smem;
     // this wave's pieces of one tile: global source of piece p = src + p * NWAVES * 64, LDS p * NWAVES KiB on
@@ -2250,16 +2275,17 @@ inline void attr_mark(unsigned long long& mask) {
     mask |= 1ull << (dev & 63);
 }
 
-template <int KSTEPS, bool SPARSE, bool I8 = false>
+template <int KSTEPS, bool SPARSE, bool I8 = false, int NWAVES = 8>
 int launch_coarse_pipe(const CoarseArgs& a, hipStream_t st) {
     const int lds = 6 * KSTEPS * 1024 + (SPARSE ? SPARSE_LREC_CAP * 8 + 16 : 0);
     static unsigned long long attr_set = 0ull;  // one bit per device
     if (!attr_done(attr_set)) {
-        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_pipe_kernel<KSTEPS, SPARSE, I8>),
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_pipe_kernel<KSTEPS, SPARSE, I8, NWAVES>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_mark(attr_set);
     }
-    hipLaunchKernelGGL((match_coarse_pipe_kernel<KSTEPS, SPARSE, I8>), dim3(a.nseed_pad + a.nqb * a.nslices), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((match_coarse_pipe_kernel<KSTEPS, SPARSE, I8, NWAVES>), dim3(a.nseed_pad + a.nqb * a.nslices), dim3(64 * NWAVES),
+                       lds, st, a);
     return VFM_OK;
 }
 
@@ -2400,7 +2426,16 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
         a.Bh = B.tiles8;
         a.ib = I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr};
         if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
-        const int rc8 = d == 384 ? launch_coarse_pipe<12, false, true>(a, st) : launch_coarse_pipe<8, false, true>(a, st);
+        int rc8;
+        if (d == 384 && g_coarse_qsets == 9) {  // variant 9 (A/B): 12 waves x 32 queries.  Alone 1-3 % faster (1.17-1.21 vs
+            // 1.20-1.21 ms), but 3 x 167 registers per SIMD leave no room for the solve stage's waves beside it: the pipeline
+            // measured 558 vs 567 registrations/s, so 8 waves stay the default
+            a.nqb = (a.nq_tiles + 11) / 12;
+            a.nslices = choose_slices(a.nqb, a.nchunks);
+            rc8 = launch_coarse_pipe<12, false, true, 12>(a, st);
+        } else {
+            rc8 = d == 384 ? launch_coarse_pipe<12, false, true>(a, st) : launch_coarse_pipe<8, false, true>(a, st);
+        }
         if (rc8) return rc8;
         VFM_CHECK_LAUNCH("match_coarse_pipe_kernel(int8)");
         if (g_prof_stop) VFM_CHECK_HIP(hipEventRecord(g_prof_stop, st));
