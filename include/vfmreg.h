@@ -105,6 +105,12 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
                                   const void *b_prepared, int64_t m, int d, int64_t *idx_out,
                                   float *sim_out, void *ws, size_t ws_bytes, float gate,
                                   vfm_stream_t stream);
+/* Feedback for a caller that registers many scans: the number of candidate chunks the last gated search in `ws` had to
+ * rescan (0 where the int8 pass did not run), copied to out_host (pinned memory) asynchronously on `stream`, after the
+ * _finish_gated call on that stream.  Duplicate-rich maps put hundreds of rows inside the int8 bounds of every query;
+ * beyond ~60 chunks per resolved query the ungated family (fp16 pass, 20x tighter window) is the faster one
+ * (vfmreg/pipeline.py switches on this figure). */
+int vfm_match_search_rescans_async(const void *ws, int64_t n, int64_t m, int32_t *out_host, vfm_stream_t stream);
 
 /* valid = !(D < min_cosine_similarity) (VHM:501-511), survivors in query order (VHM:587-600).
  * keep_out[k] = query index of the k-th survivor, *count_out = K.  corres_out (nullable,

@@ -104,14 +104,22 @@ def main():
             is_out = base["match"] < 0
             q = torch.where(is_out[:, None], torch.randn((n, d), generator=g, device=dev), q)
             p["b_desc"], p["q_desc"] = b.contiguous(), q.contiguous()
-        for overlap in (True, False):
-            pipe = RegistrationPipeline(n, m, d, n_iter=50000, overlap_ransac=overlap)
+        ref = None
+        for coarse in ("auto", "int8", "fp16"):  # the bench's pipeline: prepare on its own stream, two solve streams
+            pipe = RegistrationPipeline(n, m, d, n_iter=50000, overlap_ransac=True, overlap_prepare=True, solve_streams=2, coarse=coarse)
             dt, st, out = run(pipe, p, a.steps, lib, n, m)
             k = int(out["count"].item())
             err = float(np.linalg.norm(out["T"].cpu().numpy() - base["T_gt"]))
-            key = name + (" | pipelined" if overlap else " | serial")
+            same = True
+            if ref is None:
+                ref = (out["T"].clone(), out["corres"][:k].clone())
+            else:  # the three passes must agree on the correspondences and the pose
+                same = bool(torch.equal(ref[0], out["T"]) and torch.equal(ref[1], out["corres"][:k]))
+            key = name + " | " + coarse
             hist = {f"<= {1 << bnum}": st[8 + bnum] for bnum in range(16) if st[8 + bnum]}
             res[key] = dict(ms_per_registration=1e3 * dt, registrations_per_s=1.0 / dt, correspondences=k, pose_err_vs_planted=err,
+                            pass_in_use=("int8" if pipe.use_i8 else "fp16"), same_result_as_auto=same,
+                            rescanned_chunks_per_query=(pipe.last_rescans / n) if pipe.last_rescans is not None else None,
                             fallback_queries=st[0], refined_queries=st[1], coarse_records_per_query=st[4] / n, candidate_entries_per_query=st[2] / n,
                             rows_kept_per_refined_query=(st[3] / st[1]) if st[1] else 0.0, candidate_entry_histogram=hist)
             print(key, json.dumps(res[key]), flush=True)

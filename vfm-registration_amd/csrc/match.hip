@@ -1254,6 +1254,16 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
     }
     }
     __syncthreads();
+    if (g == 0 && ib.qerr) {
+        // load figure of the int8 pass: candidate chunks that match_refine_kernel will rescan (the caller's feedback for
+        // choosing between this pass and the fp16 one on duplicate-rich maps: vfm_match_search_rescans_async); one atomic
+        // per workgroup
+        int mine = 0;
+        if (q < n && invq[q] != 0.0f && !(key_float(lub[qq]) < gate) && lcnt[qq] <= cap) mine = lcnt[qq];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
+        if (qq == 0 && mine > 0) atomicAdd(fb_count + 5, mine);
+    }
     if (g == 0 && q < n) {
         const int cnt = lcnt[qq];
         // statistics (vfm_debug_match_stats): [2] candidate entries, [8 + b] queries with 2^(b-1) < entries <= 2^b
@@ -2593,6 +2603,13 @@ VFM_EXPORT int vfm_match_search_finish_gated(const float* q, const void* q_prepa
     VFM_CHECK_ARG(q && b && q_prepared && b_prepared && ws && idx_out && sim_out, "search_finish: null pointer");
     VFM_CHECK_ARG(gate == gate, "search_finish: gate is NaN");
     return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream, true, gate);
+}
+
+VFM_EXPORT int vfm_match_search_rescans_async(const void* ws, int64_t n, int64_t m, int32_t* out_host, vfm_stream_t stream) {
+    VFM_CHECK_ARG(ws && out_host && n > 0 && m > 0, "search_rescans: bad arguments");
+    SearchWs w = carve_search(const_cast<void*>(ws), n, m);
+    VFM_CHECK_HIP(hipMemcpyAsync(out_host, w.fb_count + 5, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return VFM_OK;
 }
 
 VFM_EXPORT size_t vfm_match_ip_top1_workspace_bytes(int64_t n, int64_t m, int d, int prec_mode) {

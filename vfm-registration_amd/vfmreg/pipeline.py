@@ -54,7 +54,7 @@ class _ResultSet:
 class RegistrationPipeline:
     def __init__(self, n: int, m: int, d: int = 384, n_iter: int = 50000, min_cosine: float = 0.8,
                  max_corr_dist: float = 10000.0, seed: int = 42, device="cuda", overlap_ransac: bool = False,
-                 overlap_prepare: bool = False, solve_streams: int = 1, gate: bool = True):
+                 overlap_prepare: bool = False, solve_streams: int = 1, gate: bool = True, coarse: str = "auto"):
         lib = _lib.load()
         self.n, self.m, self.d = n, m, d
         self.n_iter, self.min_cosine, self.max_corr_dist, self.seed = n_iter, min_cosine, max_corr_dist, seed
@@ -64,6 +64,16 @@ class RegistrationPipeline:
         self.overlap = bool(overlap_ransac)
         self.overlap_prepare = bool(overlap_prepare)
         self.gate = bool(gate)
+        # which coarse pass: "int8" = the gated family of include/vfmreg.h (int8 MFMA pass where it exists), "fp16" = the
+        # ungated family, "auto" = int8 until a registration reports more than RESCAN_LIMIT candidate chunks per query
+        # (duplicate-rich maps: hundreds of rows inside the int8 bounds), then fp16 for REPROBE registrations
+        if coarse not in ("auto", "int8", "fp16"):
+            raise ValueError("coarse must be 'auto', 'int8' or 'fp16'")
+        self.coarse = coarse
+        self.use_i8 = coarse != "fp16"
+        self.last_rescans: Optional[int] = None
+        self._fp16_left = 0
+        self._pending = []  # (event, pinned int32[1]) of gated searches whose rescan count is on its way to the host
         # solve_streams = K: the solve stages of K consecutive pairs may run beside each other (and beside the coarse pass
         # of a later pair) on K side streams, with K + 1 buffer sets
         self.n_solve = max(1, int(solve_streams)) if self.overlap else 0
@@ -93,6 +103,21 @@ class RegistrationPipeline:
                        "prepare(map)")
             r.map_key = b_desc.data_ptr()
 
+    # rescanned candidate chunks per query (over all queries of the scan) beyond which the fp16 pass is the faster one:
+    # measured at C2 on duplicate-rich maps (tools/time_neardup.py) -- 7.7 per query: int8 2.40 ms vs fp16 2.73; 12.4: 3.31 vs
+    # 3.06; 99: 14.5 vs 4.5
+    RESCAN_LIMIT = 10
+    REPROBE = 256       # registrations in fp16 mode before the int8 pass is tried again
+
+    def _poll_feedback(self) -> None:
+        """Non-blocking: consume the rescan counts that have arrived and pick the coarse pass of the next registrations."""
+        while self._pending and self._pending[0][0].query():
+            _, slot = self._pending.pop(0)
+            self.last_rescans = int(slot.item())
+            if self.coarse == "auto" and self.use_i8 and self.last_rescans > self.RESCAN_LIMIT * self.n:
+                self.use_i8 = False
+                self._fp16_left = self.REPROBE
+
     def synchronize(self) -> None:
         """Make the caller's current stream wait for every RANSAC issued on the side stream."""
         for s in self.solve_streams:
@@ -110,6 +135,12 @@ class RegistrationPipeline:
         ops._chk(b_xyz, torch.float64, "b_xyz")
         if q_desc.shape != (self.n, self.d) or b_desc.shape != (self.m, self.d):
             raise ValueError("Invalid shape")
+        self._poll_feedback()
+        i8 = self.use_i8
+        if not i8 and self.coarse == "auto":
+            self._fp16_left -= 1
+            if self._fp16_left <= 0:
+                self.use_i8 = True  # probe the int8 pass again with the next registration
         r = self.sets[self._step % len(self.sets)]
         solve = self.solve_streams[self._step % self.n_solve] if self.overlap else None
         rws = self.rws_list[self._step % self.n_solve] if self.overlap else self.rws
@@ -130,15 +161,18 @@ class RegistrationPipeline:
                 self.prep_stream.wait_event(r.done)     # the solve stage that last read this set has finished
             pst = self.prep_stream.cuda_stream
         if not (reuse_map and r.map_key == b_desc.data_ptr()):
-            _lib.check(lib.vfm_match_prepare2_gated(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
-                                                    r.qprep.data_ptr(), self.d, pst), "prepare(map + scan)")
+            # (a map that will be reused keeps both images: the coarse pass may change between registrations)
+            prep2 = lib.vfm_match_prepare2_gated if (i8 and not reuse_map) else lib.vfm_match_prepare2
+            _lib.check(prep2(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
+                             r.qprep.data_ptr(), self.d, pst), "prepare(map + scan)")
             r.map_key = b_desc.data_ptr() if reuse_map else None
         else:
             _lib.check(lib.vfm_match_prepare(q_desc.data_ptr(), self.n, self.d, r.qprep.data_ptr(), pst), "prepare(scan)")
         if self.overlap and pst != st:
             main.wait_stream(self.prep_stream)
-        _lib.check(lib.vfm_match_search_coarse_gated(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
-                                                     r.sws.data_ptr(), r.sws.numel(), st), "search(coarse)")
+        coarse = lib.vfm_match_search_coarse_gated if i8 else lib.vfm_match_search_coarse
+        _lib.check(coarse(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d, r.sws.data_ptr(), r.sws.numel(), st),
+                   "search(coarse)")
         rst = st
         if self.overlap:  # hand over to stage 2
             ev = torch.cuda.Event()
@@ -147,9 +181,20 @@ class RegistrationPipeline:
             rst = solve.cuda_stream
         # only matches with cosine >= min_cosine are kept below: queries that provably cannot reach it stay unresolved
         gate = float(np.nextafter(np.float32(self.min_cosine), np.float32(-np.inf))) if self.gate else float("-inf")
-        _lib.check(lib.vfm_match_search_finish_gated(q_desc.data_ptr(), r.qprep.data_ptr(), self.n, b_desc.data_ptr(),
-                                                     r.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(), r.sim.data_ptr(),
-                                                     r.sws.data_ptr(), r.sws.numel(), gate, rst), "search(finish)")
+        if i8:
+            _lib.check(lib.vfm_match_search_finish_gated(q_desc.data_ptr(), r.qprep.data_ptr(), self.n, b_desc.data_ptr(),
+                                                         r.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(), r.sim.data_ptr(),
+                                                         r.sws.data_ptr(), r.sws.numel(), gate, rst), "search(finish)")
+            if self.coarse == "auto" and len(self._pending) < 8:  # feedback: candidate chunks this search rescans
+                slot = torch.zeros(1, dtype=torch.int32).pin_memory()
+                _lib.check(lib.vfm_match_search_rescans_async(r.sws.data_ptr(), self.n, self.m, slot.data_ptr(), rst), "rescans")
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.ExternalStream(rst, device=self.device))
+                self._pending.append((ev, slot))
+        else:
+            _lib.check(lib.vfm_match_search_finish(q_desc.data_ptr(), r.qprep.data_ptr(), self.n, b_desc.data_ptr(),
+                                                   r.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(), r.sim.data_ptr(),
+                                                   r.sws.data_ptr(), r.sws.numel(), rst), "search(finish)")
         _lib.check(lib.vfm_threshold_compact(r.sim.data_ptr(), r.idx.data_ptr(), self.n, float(self.min_cosine),
                                              r.keep.data_ptr(), r.count.data_ptr(), r.corres.data_ptr(),
                                              None, None, None, None, rst), "threshold_compact")
