@@ -373,7 +373,7 @@ def main():
         kernel = ("match_coarse_pipe_kernel<12, false, true> (int8 32x32x32 MFMA, exact integer scores, per-chunk top-2 records)" if i8
                   else "match_coarse_pipe_kernel<24, true> (fp16 32x32x16 MFMA, sparse row-level records)")
         traffic, traffic_src = None, None  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
-        for name in (("r02_pmc_match_coarse_i8.json",) if i8 else ("r02_pmc_match_coarse.json", "r01_pmc_match_coarse.json")):
+        for name in (("r02_pmc_match_coarse_i8.json",) if i8 else ("r02_pmc_match_coarse_f16.json", "r01_pmc_match_coarse.json")):
             pmc = ROOT / "profiles" / name
             if pmc.exists() and (n, m, d) == (N_SCAN, N_MAP, DIM):
                 traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")

@@ -117,3 +117,33 @@ def test_gate_leaves_only_provably_rejected_queries_unresolved():
     ridx, rsim = orc.match_ip_top1(qn, bn)
     np.testing.assert_array_equal(f["idx"].cpu().numpy(), ridx)
     np.testing.assert_array_equal(f["sim"].cpu().numpy(), rsim)
+
+
+def test_pipeline_leaves_the_int8_pass_on_a_duplicate_rich_map_and_results_do_not_change():
+    """auto mode: the first gated search reports how many candidate chunks it had to rescan; on a map where every point has
+    hundreds of near-copies the pipeline switches to the fp16 pass.  Poses and correspondences are those of both fixed modes."""
+    n, m, d = 2000, 40000, 384
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    p = synth.make_pair_device(n, m, d, seed=9)
+    phys = torch.randn((100, d), generator=g, device="cuda")
+    owner = torch.randint(0, 100, (m,), generator=g, device="cuda")
+    b = phys[owner] + 0.01 * torch.randn((m, d), generator=g, device="cuda") / d ** 0.5
+    q = b[p["match"].clamp(min=0)] + 0.02 * torch.randn((n, d), generator=g, device="cuda") / d ** 0.5
+    q = torch.where((p["match"] < 0)[:, None], torch.randn((n, d), generator=g, device="cuda"), q)
+    b, q = b.contiguous(), q.contiguous()
+    outs = {}
+    for coarse in ("auto", "int8", "fp16"):
+        pipe = RegistrationPipeline(n, m, d, n_iter=5000, overlap_ransac=True, coarse=coarse)
+        for _ in range(4):
+            out = pipe.register(q, p["q_xyz"], b, p["b_xyz"])
+            pipe.synchronize()
+            torch.cuda.synchronize()
+        k = int(out["count"].item())
+        outs[coarse] = (out["T"].clone(), out["corres"][:k].clone(), pipe.use_i8, pipe.last_rescans)
+        del pipe
+    assert outs["auto"][2] is False and outs["auto"][3] > RegistrationPipeline.RESCAN_LIMIT * n
+    assert outs["int8"][2] is True and outs["fp16"][2] is False
+    for coarse in ("int8", "fp16"):
+        assert torch.equal(outs["auto"][0], outs[coarse][0]) and torch.equal(outs["auto"][1], outs[coarse][1])
+    assert outs["auto"][1].shape[0] > 500

@@ -1,12 +1,14 @@
-# Round-2 evidence run: GPU tests, smoke, bench (plain + under rocprofv3), PMC passes of the coarse kernel.
+# Round-2 evidence run: GPU tests, smoke, bench (default int8 pass, fp16 pass on the same box, serial, under rocprofv3),
+# PMC passes of the coarse kernel, duplicate-rich maps.  -> gpurun_out/r02final/, collected by tools/refresh_profiles_r02.py
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02final
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | cut -c1-300
 timeout 600 python bench.py --streams 1 --no-cpu-baseline --no-extra > $O/bench_streams1.json 2>> $O/bench.err
+VFM_VARIANT=5 timeout 600 python bench.py --no-cpu-baseline --no-extra > $O/bench_f16_same_box.json 2>> $O/bench.err; tail -1 $O/bench_f16_same_box.json | cut -c1-200
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --no-cpu-baseline --no-extra > $O/bench_prof.json 2> $O/prof.err; tail -1 $O/bench_prof.json | cut -c1-200
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -o bench1 -- python $R/bench.py --streams 1 --no-cpu-baseline --no-extra > $O/bench_prof1.json 2> $O/prof1.err
@@ -14,3 +16,4 @@ cd $R && bash tools/pmc_coarse.sh 2>&1 | tail -30
 cp $R/gpurun_out/pmc_coarse/pmc_match_coarse.json $O/ 2>/dev/null
 for i in 1 2 3 4 5 6 7; do cp $R/gpurun_out/pmc_coarse/p${i}_counter_collection.csv $O/pmc_pass${i}_counter_collection.csv 2>/dev/null; done
 cd $R && python tools/time_neardup.py --steps 20 --out $O/neardup.json > $O/neardup.log 2>&1
+python tools/time_prep.py > $O/time_prep.txt 2>&1; cat $O/time_prep.txt
