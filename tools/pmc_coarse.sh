@@ -30,7 +30,7 @@ a = {k: sum(v) / len(v) for k, v in agg.items()}
 cyc = a["GRBM_GUI_ACTIVE"] / 8
 d = sorted(dur)[len(dur) // 2]
 out = {
-    "kernel": kname.split("(")[0].replace("void (anonymous namespace)::", "").strip()
+    "kernel": kname.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip()
               + (" (int8 32x32x32 MFMA, dense per-chunk records)" if "false, true" in kname else " (fp16 32x32x16 MFMA)"),
     "workload": "C2 20000x200000x384, one launch",
     "counters_avg_per_launch": a,
