@@ -1421,21 +1421,95 @@ struct RefineWave {
     }
 };
 
-// dense records: the candidate entries of match_select_kernel.
-// int8 pass (ib.qerr != NULL): a whole-chunk entry is first rescanned in int8 -- the exact integer scores of the chunk's 128
-// rows against this query (v_dot4 over the int8 tiles: 48 KB, contiguous, L2 / Infinity-Cache resident, instead of 196 KB of
-// fp32 rows) -- and only the rows whose upper bound reaches the query's lower bound go on to the fp32 scoring.
+// int8 pass: which rows of a query's candidate chunks matter.  One wave per query; per candidate chunk the exact integer
+// scores of its 128 rows against the query (v_dot4 over the chunk's four int8 tiles: 48 KB, contiguous, L2 / Infinity-Cache
+// resident -- the whole int8 map is 77 MB at C2 -- instead of 196 KB of fp32 rows); every row whose upper bound reaches the
+// query's lower bound replaces the chunk entries as a single-row entry.  Few registers on purpose (the loop is latency-bound:
+// 8 x 16 bytes per lane in flight, 8 waves per SIMD); match_refine_kernel / match_rescore_kernel then see the lists the fp16
+// pass would have produced.
+__global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m, int d, I8Bounds ib, const uint4* __restrict__ q8,
+                                                           const uint4* __restrict__ b8, const unsigned* __restrict__ qmax,
+                                                           int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
+                                                           unsigned* __restrict__ hits, int hcap, int* __restrict__ fb_count,
+                                                           int* __restrict__ fb_list) {
+    __shared__ uint4 l_q8[4][24];  // the query's int8 row, unit by unit
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+    if (qi >= n) return;
+    const int cnt = cand_cnt[qi];
+    if (cnt <= 0) return;  // zero query / below the gate (-2) / overflow (-1)
+    unsigned* mycand = cand + (size_t)qi * cap;
+    unsigned* myhits = hits + (size_t)qi * hcap;
+    const int units8 = d >> 4;  // 16-byte units per int8 row
+    if (lane < units8) l_q8[wave][lane] = q8[(size_t)(qi >> 5) * (units8 * 32) + (size_t)lane * 32 + (qi & 31)];
+    const float eq = ib.qerr[qi];
+    const float sq = ib.qstep[qi >> 7], A = eq * 1.0001220703125f + 1.0e-6f, mult = 1.0001220703125f + eq;
+    const float qlow = key_float(qmax[qi]);
+    __builtin_amdgcn_wave_barrier();
+    int nhit = 0;  // wave-uniform
+    // Up to 64 entries (nearly every query): they sit in registers, one per lane, before the first hit is written, so the
+    // hits go straight into the query's list.  Longer lists collect their hits in the scratch list and copy them back.
+    const bool direct = cnt <= 64;
+    unsigned* out = direct ? mycand : myhits;
+    const int ocap = direct ? cap : hcap;
+    for (int e0 = 0; e0 < cnt; e0 += 64) {
+        const unsigned batch = (e0 + lane < cnt) ? mycand[e0 + lane] : 0u;
+        const int nb = cnt - e0 < 64 ? cnt - e0 : 64;
+        for (int j = 0; j < nb; ++j) {
+            const int c = (int)(__shfl(batch, j) >> 8);  // wave-uniform
+            const long long base = (long long)c * CHUNK_ROWS;
+            const float sc = sq * ib.bstep[c], bound = A + mult * ib.berr[c];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int rr = lane + 64 * half;  // row of the chunk: tile rr >> 5, position rr & 31
+                const uint4* src = b8 + ((size_t)c * 4 + (rr >> 5)) * (size_t)(units8 * 32) + (rr & 31);
+                int acc = 0;
+                for (int u0 = 0; u0 < units8; u0 += 8) {  // units8 = 16 or 24
+                    uint4 bv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) bv[k] = src[(u0 + k) * 32];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint4 qv = l_q8[wave][u0 + k];
+                        acc = __builtin_amdgcn_sdot4((int)bv[k].x, (int)qv.x, acc, false);
+                        acc = __builtin_amdgcn_sdot4((int)bv[k].y, (int)qv.y, acc, false);
+                        acc = __builtin_amdgcn_sdot4((int)bv[k].z, (int)qv.z, acc, false);
+                        acc = __builtin_amdgcn_sdot4((int)bv[k].w, (int)qv.w, acc, false);
+                    }
+                }
+                const bool hit = base + rr < m && sc * (float)acc + bound >= qlow;
+                const unsigned long long bal = __ballot(hit);
+                if (hit) {
+                    const int pos = nhit + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (pos < ocap) out[pos] = ((unsigned)c << 8) | (unsigned)rr;
+                }
+                nhit += __popcll(bal);
+            }
+        }
+    }
+    if (nhit > ocap || nhit > cap) {  // more rows inside the bounds than a list holds: the all-pairs kernel decides
+        if (lane == 0) {
+            cand_cnt[qi] = -1;
+            const int slot = atomicAdd(fb_count, 1);
+            fb_list[slot] = (int)qi;
+        }
+        return;
+    }
+    if (!direct) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the hits written above are read back by other lanes
+        for (int i = lane; i < nhit; i += 64) mycand[i] = myhits[i];
+    }
+    if (lane == 0) cand_cnt[qi] = nhit;
+}
+
+// dense records: the candidate entries of match_select_kernel (int8 pass: as rewritten by match_rescan_kernel)
 __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restrict__ q, const float* __restrict__ invq,
                                                            const float* __restrict__ b, const float* __restrict__ invb,
                                                            int64_t n, int64_t m, int d, float w2, int* __restrict__ cand_cnt,
                                                            unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count,
-                                                           int* __restrict__ fb_list, int stats, I8Bounds ib,
-                                                           const uint4* __restrict__ q8, const uint4* __restrict__ b8,
-                                                           const unsigned* __restrict__ qmax) {
+                                                           int* __restrict__ fb_list, int stats) {
     __shared__ unsigned l_row[4][REFINE_KEEP];
     __shared__ float l_sc[4][REFINE_KEEP];
-    __shared__ uint4 l_q8[4][24];       // the query's int8 row, unit by unit
-    __shared__ unsigned l_hit[4][CHUNK_ROWS];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
     if (qi >= n) return;
@@ -1448,17 +1522,6 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
     if (cnt < REFINE_MIN && !__any(flagged)) return;
     RefineWave R;
     R.init(q, invq[qi], qi, b, invb, d, w2, l_row[wave], l_sc[wave]);
-    const int units8 = d >> 4;  // 16-byte units per int8 row
-    float i8_sq = 0.f, i8_A = 0.f, i8_mult = 0.f, i8_qlow = 0.f;
-    if (ib.qerr && __any(flagged)) {
-        if (lane < units8) l_q8[wave][lane] = q8[(size_t)(qi >> 5) * (units8 * 32) + (size_t)lane * 32 + (qi & 31)];
-        const float eq = ib.qerr[qi];
-        i8_sq = ib.qstep[qi >> 7];
-        i8_A = eq * 1.0001220703125f + 1.0e-6f;
-        i8_mult = 1.0001220703125f + eq;
-        i8_qlow = key_float(qmax[qi]);
-        __builtin_amdgcn_wave_barrier();
-    }
     // single-row entries: 4 per pass
     for (int e0 = 0; e0 < cnt; e0 += 4) {
         long long row = -1;
@@ -1476,41 +1539,6 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
         const unsigned ce = mycand[e];  // wave-uniform
         if (!(ce & 128u)) continue;
         const long long base = (long long)(ce >> 8) * CHUNK_ROWS;
-        if (ib.qerr) {
-            const int c = (int)(ce >> 8);
-            const float sc = i8_sq * ib.bstep[c], bound = i8_A + i8_mult * ib.berr[c];
-            int nhit = 0;  // wave-uniform
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int rr = lane + 64 * half;  // row of the chunk: tile rr >> 5, position rr & 31
-                const uint4* src = b8 + ((size_t)c * 4 + (rr >> 5)) * (size_t)(units8 * 32) + (rr & 31);
-                int acc = 0;
-                for (int u0 = 0; u0 < units8; u0 += 8) {  // units8 = 16 or 24: eight 16-byte loads in flight per lane
-                    uint4 bv[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bv[j] = src[(u0 + j) * 32];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const uint4 qv = l_q8[wave][u0 + j];
-                        acc = __builtin_amdgcn_sdot4((int)bv[j].x, (int)qv.x, acc, false);
-                        acc = __builtin_amdgcn_sdot4((int)bv[j].y, (int)qv.y, acc, false);
-                        acc = __builtin_amdgcn_sdot4((int)bv[j].z, (int)qv.z, acc, false);
-                        acc = __builtin_amdgcn_sdot4((int)bv[j].w, (int)qv.w, acc, false);
-                    }
-                }
-                const bool hit = base + rr < m && sc * (float)acc + bound >= i8_qlow;
-                const unsigned long long bal = __ballot(hit);
-                if (hit) l_hit[wave][nhit + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned)rr;
-                nhit += __popcll(bal);
-            }
-            __builtin_amdgcn_wave_barrier();
-            for (int h0 = 0; h0 < nhit; h0 += 4) {
-                const long long row = (h0 + R.g < nhit) ? base + l_hit[wave][h0 + R.g] : -1;
-                R.consider(row, R.score4(row));
-            }
-            __builtin_amdgcn_wave_barrier();
-            continue;
-        }
         for (int r0 = 0; r0 < CHUNK_ROWS; r0 += 4) {
             long long row = base + r0 + R.g;
             if (row >= m) row = -1;
@@ -2486,9 +2514,14 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                            a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, i8_bounds(Q, B, i8), gate, w.cand_cnt, w.cand, w.cap,
                            w.fb_count, w.fb_list, g_match_stats);
         VFM_CHECK_LAUNCH("match_select_kernel");
+        if (i8) {  // candidate chunks -> candidate rows (the record buffer of the fp16 pass is free: it holds the hit lists)
+            hipLaunchKernelGGL(match_rescan_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, m, d, i8_bounds(Q, B, true),
+                               (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt, w.cand, w.cap,
+                               reinterpret_cast<unsigned*>(w.rec), 2 * w.rcap, w.fb_count, w.fb_list);
+            VFM_CHECK_LAUNCH("match_rescan_kernel");
+        }
         hipLaunchKernelGGL(match_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2,
-                           w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats, i8_bounds(Q, B, i8),
-                           (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax);
+                           w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
         VFM_CHECK_LAUNCH("match_refine_kernel");
     }
     {
