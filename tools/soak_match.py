@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Randomised soak of the FAST inner-product search against the oracle at sizes where every mechanism of the sparse path is
-active at once (seed units: >= 256 map chunks; ragged n / m; LDS record buffer overflow; duplicate-rich rows; zero rows)."""
+active at once (seed units: >= 256 map chunks; ragged n / m; LDS record buffer overflow; duplicate-rich rows; zero rows).
+Every trial runs three calls: ungated (fp16 pass), gated with gate = -inf (int8 pass for d = 256 / 384, every query
+resolved) and gated at 0.8 (unresolved rows must score below 0.8 in the oracle, the others must equal it)."""
 import sys
 import time
 from pathlib import Path
@@ -43,15 +45,23 @@ for t in range(trials):
         b[rows] = rng.random((3000, 8)).astype(np.float32) @ A
         hit = rng.choice(n, n // 4, replace=False)
         q[hit] = rng.random((len(hit), 8)).astype(np.float32) @ A
-    t0 = time.perf_counter()
-    idx, sim = ops.match_ip_top1(torch.from_numpy(q).cuda(), torch.from_numpy(b).cuda(), ops.FAST)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
+    qd, bd = torch.from_numpy(q).cuda(), torch.from_numpy(b).cuda()
     qn, _ = orc.l2norm_rows(q)
     bn, _ = orc.l2norm_rows(b)
     ir, sr = orc.match_ip_top1(qn, bn)
-    ok = np.array_equal(idx.cpu().numpy(), ir) and np.array_equal(sim.cpu().numpy(), sr)
+    ok, ms = True, []
+    for gate in (None, float("-inf"), 0.8):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idx, sim = ops.match_ip_top1(qd, bd, ops.FAST, gate=gate)
+        torch.cuda.synchronize()
+        ms.append(1e3 * (time.perf_counter() - t0))
+        gi, gs = idx.cpu().numpy(), sim.cpu().numpy()
+        solved = gi >= 0
+        ok &= np.array_equal(gi[solved], ir[solved]) and np.array_equal(gs[solved], sr[solved])
+        ok &= bool(solved.all()) if gate != 0.8 else bool((sr[~solved] < 0.8).all())
     bad += not ok
-    print(f"trial {t:2d} kind {kind} n={n:5d} m={m:6d} d={d}: {'ok' if ok else 'MISMATCH'}  gpu {1e3 * (t1 - t0):7.1f} ms", flush=True)
+    print(f"trial {t:2d} kind {kind} n={n:5d} m={m:6d} d={d}: {'ok' if ok else 'MISMATCH'}  gpu ungated / gate -inf / gate 0.8: "
+          f"{ms[0]:7.1f} {ms[1]:7.1f} {ms[2]:7.1f} ms", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
