@@ -184,7 +184,7 @@ def extra_configs(dev):
     ms = C.c_float()
     for k in range(4):
         lib.vfm_prof_arm(a, b)
-        ops.match_ip_top1(p5["q_desc"], p5["b_desc"], ops.FAST)
+        ops.match_ip_top1(p5["q_desc"], p5["b_desc"], ops.FAST, gate=0.8)  # the gated family, as the pipeline below
         lib.vfm_prof_elapsed_ms(a, b, C.byref(ms))
         if k:
             ts.append(ms.value)
@@ -198,9 +198,9 @@ def extra_configs(dev):
     out["C5"] = {"workload": "50000-pt scan vs 1000000-pt map, 768-D, 50000 RANSAC iterations (one registration, serial)",
                  "ms_registration": t5_reg, "ms_coarse_kernel": t5, "correspondences": int(r5["count"].item()),
                  "pose_err_vs_planted": float(np.linalg.norm(r5["T"].cpu().numpy() - p5["T_gt"])),
-                 "roofline": {"bound": "mfma", "kernel": "match_coarse_r_kernel<48,1,3> (fp16 32x32x16 MFMA)", "flops": f5,
-                              "achieved": f5 / (t5 * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": f5 / (t5 * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS}}
+                 "roofline": {"bound": "mfma", "kernel": "match_coarse_pipe_kernel<24, false, true> (int8 32x32x32 MFMA)", "flops": f5,
+                              "achieved": f5 / (t5 * 1e-3) / 1e12, "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s",
+                              "frac": f5 / (t5 * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS}}
     return out
 
 
@@ -368,7 +368,7 @@ def main():
         flops = 2.0 * n * m * d
         achieved = flops / (coarse_ms * 1e-3) / 1e12
         # which coarse pass ran: the int8 one for d = 256 / 384 unless an A/B variant forces the fp16 pass
-        i8 = d in (256, 384) and n > 512 and os.environ.get("VFM_VARIANT", "0") in ("0", "9")
+        i8 = d in (256, 384, 512, 640, 768) and n > 512 and os.environ.get("VFM_VARIANT", "0") in ("0", "9")
         peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS
         kernel = ("match_coarse_pipe_kernel<12, false, true> (int8 32x32x32 MFMA, exact integer scores, per-chunk top-2 records)" if i8
                   else "match_coarse_pipe_kernel<24, true> (fp16 32x32x16 MFMA, sparse row-level records)")

@@ -1,4 +1,4 @@
-"""The int8 coarse pass (d = 256 / 384, more than 512 queries): its quantisation bound checked pair by pair against fp64
+"""The int8 coarse pass (d = 256 ... 768, more than 512 queries): its quantisation bound checked pair by pair against fp64
 scores, oracle-identical answers on inputs that stress the quantisation, and the contract of the similarity gate."""
 import ctypes as C
 
@@ -31,7 +31,7 @@ def _heavy_tailed(rng, rows, d):
     return x
 
 
-@pytest.mark.parametrize("d", [256, 384])
+@pytest.mark.parametrize("d", [256, 384, 512, 640, 768])
 def test_quantisation_bound_holds_for_every_pair(d):
     """| v_a . v_b - s_a s_b (q_a . q_b) | <= (1 + 2^-13 + E_a) E_b + (1 + 2^-13) E_a for every pair, with the kernel's own
     steps, integers and measured residual norms (csrc/match.hip, prep_chunk_kernel): Gaussian and heavy-tailed rows."""
@@ -60,7 +60,8 @@ def test_quantisation_bound_holds_for_every_pair(d):
         assert np.median(bound) < typical
 
 
-@pytest.mark.parametrize("d,n,m", [(384, 1500, 9000), (256, 2050, 5003), (384, 777, 130)])
+@pytest.mark.parametrize("d,n,m", [(384, 1500, 9000), (256, 2050, 5003), (384, 777, 130), (512, 900, 4100), (640, 1030, 3000),
+                                   (768, 1300, 6000)])
 def test_int8_search_equals_the_oracle_on_stress_inputs(d, n, m):
     rng = np.random.default_rng(n + m)
     cases = {

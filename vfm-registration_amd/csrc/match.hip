@@ -2,19 +2,28 @@
 // VoxelHashMap::GetVFMCorrespondences' search (VoxelHashMap.cpp:469-511, 587-600) and
 // find_correspondences' nearest neighbours (registration_node.py:482-538).
 //
-// Pipeline of the FAST top-1 search (indices identical to the fp64 oracle):
-//   prep_rows_kernel      fp32 rows -> 1/|row| (faiss fvec_renorm_L2 order) + fp16 copy of the
-//                         normalised rows in MFMA-fragment ("frag-major") tiles of 32 rows
-//   coarse pass           fp16 MFMA 32x32x16, queries resident in VGPRs, map tiles streamed through an
-//                         LDS ring by LDS-DMA; per (query, 128-row chunk) top-2 of the coarse scores,
-//                         never materialising N x M.  Three shapes of the same pass:
-//                           match_coarse_pipe_kernel  d <= 384 (default): 8 waves, fragment pipeline
-//                                                     carried across the step barrier
+// Two coarse passes feed one exact decision (indices identical to the fp64 oracle either way):
+//
+// (a) the int8 pass -- the GATED entry points (a caller that keeps only matches above a similarity gate,
+//     VoxelHashMap.cpp:501-511), d = 256 ... 768, more than 512 queries:
+//   prep_chunk_kernel       fp32 rows -> 1/|row| (faiss fvec_renorm_L2 order), int8 image of the normalised rows with one
+//                           quantisation step per 128-row group, the measured residual norm of every row
+//   match_coarse_i8_kernel  int8 MFMA 32x32x32 (exact integer scores), queries resident in VGPRs, map tiles streamed through
+//                           an LDS ring by LDS-DMA; per (query, 128-row chunk) the best score; per query a lower bound of its
+//                           exact maximum
+//   match_select_kernel     per query: chunks whose upper bound reaches the lower bound; queries that cannot reach the gate
+//                           are closed
+//   match_rescan_kernel     candidate chunks -> candidate rows (exact integer scores of the chunk's rows, v_dot4)
+// (b) the fp16 pass -- ungated entry points, d = 128, Euclidean search, duplicate-rich maps:
+//   prep_rows_kernel      fp32 rows -> 1/|row| + fp16 copy of the normalised rows in MFMA-fragment ("frag-major") tiles
+//   coarse pass           fp16 MFMA 32x32x16, same streaming; sparse row-level records against a running maximum
+//                         (match_coarse_pipe_kernel<., true> + match_filter_refine_kernel) or per (query, 128-row chunk)
+//                         top-2 records (+ match_select_kernel).  Three shapes:
+//                           match_coarse_pipe_kernel  d <= 384: 8 waves, fragment pipeline carried across the step barrier
 //                           match_coarse_kernel       d = 512 (ring of 4), and the A/B + ablation base
 //                           match_coarse_r_kernel     d = 640 / 768: 4 waves, 192 query registers
-//   match_select_kernel   per query: global coarse max, every chunk within the proven error
-//                         window becomes a candidate (single row, or whole chunk if its top-2
-//                         is inside the window too)
+// then, common:
+//   match_refine_kernel   fp32 scores of crowded candidate lists, rows within the fp32 margin survive
 //   match_rescore_kernel  exact fp64 re-decision among the candidates (sequential-k dot of the
 //                         fp32-normalised rows, ties -> lowest index)
 //   match_exact_kernel    all-pairs fp64 (EXACT mode, and fallback for candidate overflow)
@@ -193,7 +202,7 @@ struct PrepOut {
     float* gerr;      // [rows_pad / 128] maximum E of the group
     uint4* tiles8;    // int8 fragment tiles
 };
-template <bool F16>
+template <bool F16, int NC = 2>
 __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restrict__ x, int64_t rows, int d, PrepOut o, int groups1,
                                                           const float* __restrict__ x2, int64_t rows2, PrepOut o2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
         o = o2;
     }
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    const int nchunks = d >> 2;  // float4 chunks per row (<= 96): lane l owns chunks l and l + 64
+    const int nchunks = d >> 2;  // float4 chunks per row (<= 64 NC): lane l owns chunks l, l + 64 (, l + 128)
     unsigned char* img8 = smem;                                                  // [4 tiles][d/32 * 64 units][16]
     _Float16* img16 = reinterpret_cast<_Float16*>(smem + (size_t)I8_GROUP * d);  // F16: [4 tiles][d/16 * 64 units][8]
     if (threadIdx.x == 0) {
@@ -215,12 +224,12 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
         emax_bits = 0u;
     }
     // phase 1: the rows (read once), 1/|row| in the oracle's order, the group's largest normalised magnitude
-    float4 v[RPW][2];
+    float4 v[RPW][NC];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         const int64_t r = (int64_t)grp * I8_GROUP + wave * RPW + j;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < rows && c < nchunks) {
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
     for (int j = 0; j < RPW; ++j) {  // lane-sequential over its chunks and elements, as row_sumsq_wave
         float p = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NC; ++i) {
             if (lane + 64 * i < nchunks) {
                 float t;
                 t = v[j][i].x * v[j][i].x; p = p + t;
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
     for (int j = 0; j < RPW; ++j) {
         const float iv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_inv), 8 * j));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {  // normalised values exactly as faiss leaves them in fp32 (zero in the unused slots)
+        for (int i = 0; i < NC; ++i) {  // normalised values exactly as faiss leaves them in fp32 (zero in the unused slots)
             v[j][i].x = v[j][i].x * iv;
             v[j][i].y = v[j][i].y * iv;
             v[j][i].z = v[j][i].z * iv;
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
         const int t = pr >> 5, p = pr & 31;
         float e2 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunks) {
                 const float nv[4] = {v[j][i].x, v[j][i].y, v[j][i].z, v[j][i].w};
@@ -735,27 +744,20 @@ __global__ __launch_bounds__(512 / QSETS, (QSETS == 1) ? 2 : 1) void match_coars
 // are the 32 accumulators of the previous step compared one by one and the hits appended to the query's record list
 // (atomic slot counter).  The running maximum starts from the maxima earlier workgroups published for the query
 // (a.qmax), so only the first units of a query see the record-breaking phase of a fresh maximum.
-// I8 = true: the same schedule on the int8 MFMA (32x32x32: twice the k per instruction, so KSTEPS = d/32 and a tile is
-// d/32 KiB) over the int8 image of the rows (prep_chunk_kernel); integer scores offset by 2^30, DENSE records only: the
-// rigorous int8 window is ~15x the fp16 one, and row-level records against a running maximum cost 4.3 us of kernel time
-// per record and query (measured: 410 records per query at C2, 2.98 ms), while the per-chunk top-2 is window-independent.
-// NWAVES = 12 (int8 pass only: its 48 query registers leave room for 3 waves per SIMD): 384 queries per workgroup -- the
-// map is staged 2/3 as often -- and a third wave to issue while two wait.
-template <int KSTEPS, bool SPARSE, bool I8 = false, int NWAVES = 8>
-__global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void match_coarse_pipe_kernel(CoarseArgs a) {
+template <int KSTEPS, bool SPARSE>
+__global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    static_assert(NWAVES == 8 || (NWAVES == 12 && I8), "8 waves, or 12 for the int8 pass");
+    constexpr int NWAVES = 8;
     constexpr int TILE_U4 = KSTEPS * 64;
     constexpr int TILE_BYTES = TILE_U4 * 16;
     constexpr int PIECES = 2 * KSTEPS / NWAVES;  // 1 KiB pieces per wave per PAIR of tiles (one step)
     constexpr int NBUF = 6;
-    constexpr int PF = NWAVES == 12 ? 3 : 4;  // fragment look-ahead in k-steps (12 waves: 170-register budget)
+    constexpr int PF = 4;
     static_assert((2 * KSTEPS) % NWAVES == 0 && KSTEPS <= 24 && PIECES < KSTEPS, "a pair of tiles must split evenly over the waves");
     static_assert(KSTEPS % PF == 0 && KSTEPS >= 2 * PF, "fragment ring must align across steps");
-    static_assert(!(I8 && SPARSE), "the int8 pass writes the dense per-chunk records");
-    using frag_t = std::conditional_t<I8, intx4, half8>;
-    using acc_t = std::conditional_t<I8, intx16, floatx16>;
-    using accel_t = std::conditional_t<I8, int, float>;
+    using frag_t = half8;
+    using acc_t = floatx16;
+    using accel_t = float;
 
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -805,34 +807,12 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void match_coarse_pipe_ker
         }
         if (threadIdx.x == 0) *lrec_count = 0u;  // visible after the first barrier below
     }
-    // I8: per-lane constants of the query's bound and the running lower bound of its exact maximum (match_select_kernel)
-    float i8_sq = 0.f, i8_A = 0.f, i8_mult = 0.f, i8_low = -__builtin_inff();
-    if constexpr (I8) {
-        const size_t qi = (size_t)(qt < a.nq_tiles ? qt : 0) * 32 + (lane & 31);
-        const float eq = a.ib.qerr[qi];
-        i8_sq = a.ib.qstep[qi >> 7];
-        i8_A = eq * 1.0001220703125f + 1.0e-6f;
-        i8_mult = 1.0001220703125f + eq;
-    }
     auto fold_tail = [&](int it) {
-        if constexpr (!SPARSE) {
-            const int chunk = it >= 0 ? c0 + (it >> 2) : -1;
-            unsigned best;
-            if constexpr (I8) best = coarse_emit_chunk_best(a, s1, qt, chunk);
-            else best = coarse_emit_chunk(a, s1, s2, runmax, qt, chunk);
-            if constexpr (I8) {
-                if (chunk >= 0 && chunk < a.first_pad_chunk) {  // wave-uniform
-                    const float sb = a.ib.bstep[chunk], be = a.ib.berr[chunk];
-                    i8_low = fmaxf(i8_low, __builtin_fmaf(i8_sq * sb, (float)((int)best - I8_OFFSET), -(i8_A + i8_mult * be)));
-                }
-            }
-        }
+        if constexpr (!SPARSE) coarse_emit_chunk(a, s1, s2, runmax, qt, it >= 0 ? c0 + (it >> 2) : -1);
     };
     auto fold_one = [&](accel_t v, int code) {
         if constexpr (SPARSE) {
             s1 = max(s1, score_bits(v));  // s1 = maximum of the step being folded
-        } else if constexpr (I8) {
-            s1 = max(s1, score_bits(v));
         } else {
             coarse_fold(s1, s2, v, code);
         }
@@ -927,17 +907,12 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void match_coarse_pipe_ker
         const uint4* nxt1 = nxt0 + TILE_U4;
         acc_t acc0, acc1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = I8 ? (accel_t)I8_OFFSET : (accel_t)COARSE_OFFSET;
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = COARSE_OFFSET;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
-            if constexpr (I8) {
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<intx4*>(&r0[s % PF]), qf[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<intx4*>(&r1[s % PF]), qf[s], acc1, 0, 0, 0);
-            } else {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&r0[s % PF]), qf[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&r1[s % PF]), qf[s], acc1, 0, 0, 0);
-            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&r0[s % PF]), qf[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&r1[s % PF]), qf[s], acc1, 0, 0, 0);
             if (s + PF < KSTEPS) {
                 r0[s % PF] = cur0[(s + PF) * 64];
                 r1[s % PF] = cur1[(s + PF) * 64];
@@ -979,7 +954,7 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void match_coarse_pipe_ker
     for (int e = 0; e < 32; ++e) fold_one(e < 16 ? prev0[e & 15] : prev1[e & 15], (2 + (e >> 4)) * 16 + (e & 15));
     if constexpr (SPARSE) step_tail(ntiles - 2, prev0, prev1);
     else fold_tail(ntiles - 1);
-    if (lane < 32 && qt < a.nq_tiles) atomicMax(a.qmax + (size_t)qt * 32 + lane, I8 ? float_key(i8_low) : runmax);
+    if (lane < 32 && qt < a.nq_tiles) atomicMax(a.qmax + (size_t)qt * 32 + lane, runmax);
     if constexpr (SPARSE) {  // flush the workgroup's records to the per-query lists (no DMA in flight any more)
         __syncthreads();
         const unsigned cnt = min(*lrec_count, (unsigned)LREC_CAP);
@@ -990,6 +965,143 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void match_coarse_pipe_ker
             if (gs < (unsigned)a.rcap) a.rec[qi * (size_t)a.rcap + gs] = make_uint2(r.x & 0xFFFFFFu, r.y);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// int8 coarse pass with T map tiles per step (the schedule of match_coarse_pipe_kernel<., false, true>, generalised).
+// One barrier and one staging round per T * KSTEPS MFMAs: at d = 768 (KSTEPS = 24, T = 2: 48 MFMAs per step) the int8
+// kernel measured 0.53 of the int8 peak, at d = 384 (KSTEPS = 12, T = 2: 24 per step) 0.49 -- the per-step cost is fixed,
+// so d = 384 / 256 take T = 4 here (one whole 128-row chunk per step, 48 / 32 MFMAs).  Ring = 3 steps of T tiles
+// (in use | landed | in flight), fragment look-ahead PF = 2 k-steps for T = 4 (4 tiles x 2 x 4 registers), 4 for T = 2.
+// ---------------------------------------------------------------------------------------------
+template <int KSTEPS, int T>
+__global__ __launch_bounds__(512, 2) void match_coarse_i8_kernel(CoarseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NWAVES = 8;
+    constexpr int TILE_U4 = KSTEPS * 64;
+    constexpr int TILE_BYTES = TILE_U4 * 16;
+    constexpr int PIECES = T * KSTEPS / NWAVES;  // 1 KiB pieces per wave per step
+    constexpr int NBUF = 3 * T;
+    constexpr int PF = T == 4 ? 2 : 4;
+    static_assert(T == 2 || T == 4, "a 128-row chunk is 4 tiles");
+    static_assert((T * KSTEPS) % NWAVES == 0 && PIECES < KSTEPS, "a step's tiles must split evenly over the waves");
+    static_assert(KSTEPS % PF == 0 && KSTEPS >= 2 * PF, "fragment ring must align across steps");
+    static_assert(NBUF * TILE_BYTES <= 160 * 1024, "ring exceeds the LDS");
+
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const CoarseUnit cu = coarse_unit(a);
+    const int qb = cu.qb, c0 = cu.c0, ntiles = cu.ntiles;  // ntiles: a multiple of 4 (whole chunks)
+    if (ntiles == 0) return;
+    const int qt = qb * NWAVES + wave;  // this wave's 32-query tile
+
+    const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS unsigned char*)smem;
+    const uint4* gsrc = a.Bh + (size_t)c0 * 4 * TILE_U4 + wave * 64 + lane;  // piece p of a step: + p * NWAVES * 64
+    const unsigned ldst0 = lds_base + (unsigned)wave * 1024u;
+    auto stage_step = [&](const uint4* src, unsigned ring_byte) {  // T consecutive tiles: contiguous in memory and in the ring
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p)
+            glds16(src + p * NWAVES * 64, __builtin_amdgcn_readfirstlane(ldst0 + ring_byte + (unsigned)(p * NWAVES) * 1024u));
+    };
+
+    intx4 qf[KSTEPS];
+    {
+        const uint4* qsrc = a.Qh + (size_t)(qt < a.nq_tiles ? qt : 0) * TILE_U4 + lane;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            uint4 v = qsrc[s * 64];
+            qf[s] = *reinterpret_cast<intx4*>(&v);
+        }
+    }
+    stage_step(gsrc, 0u);
+    if (ntiles > T) stage_step(gsrc + (size_t)T * TILE_U4, (unsigned)(T * TILE_BYTES));
+    const uint4* gnext = gsrc + (size_t)2 * T * TILE_U4;  // next step to stage
+
+    // per-lane constants of the query's bound and the running lower bound of its exact maximum (match_select_kernel)
+    float i8_sq, i8_A, i8_mult, i8_low = -__builtin_inff();
+    {
+        const size_t qi = (size_t)(qt < a.nq_tiles ? qt : 0) * 32 + (lane & 31);
+        const float eq = a.ib.qerr[qi];
+        i8_sq = a.ib.qstep[qi >> 7];
+        i8_A = eq * 1.0001220703125f + 1.0e-6f;
+        i8_mult = 1.0001220703125f + eq;
+    }
+    unsigned s1 = 0u;
+    auto emit_chunk = [&](int chunk) __attribute__((always_inline)) {  // chunk < 0: nothing folded yet
+        const unsigned best = coarse_emit_chunk_best(a, s1, qt, chunk);
+        if (chunk >= 0 && chunk < a.first_pad_chunk) {  // wave-uniform
+            const float sb = a.ib.bstep[chunk], be = a.ib.berr[chunk];
+            i8_low = fmaxf(i8_low, __builtin_fmaf(i8_sq * sb, (float)((int)best - I8_OFFSET), -(i8_A + i8_mult * be)));
+        }
+    };
+
+    intx16 prev[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prev[t][r] = 0;
+
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    uint4 fr[T][PF];  // fragment ring registers: slot s of a step consumes fr[t][s % PF]
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const uint4* b0 = reinterpret_cast<const uint4*>(smem + t * TILE_BYTES) + lane;
+#pragma unroll
+        for (int s = 0; s < PF; ++s) fr[t][s] = b0[s * 64];
+    }
+    unsigned ring = 0u;  // ring slot of the step's first tile (0, T, 2T)
+
+    for (int it = 0; it < ntiles; it += T) {
+        // every wave's pieces of the next step (issued during the previous step) have landed
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned ring1 = ring + T >= (unsigned)NBUF ? ring + T - NBUF : ring + T;      // next step
+        const unsigned ring2 = ring1 + T >= (unsigned)NBUF ? ring1 + T - NBUF : ring1 + T;   // the step after: being refilled
+        const uint4* cur = reinterpret_cast<const uint4*>(smem + ring * TILE_BYTES) + lane;
+        const uint4* nxt = reinterpret_cast<const uint4*>(smem + ring1 * TILE_BYTES) + lane;
+        intx16 acc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = I8_OFFSET;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<intx4*>(&fr[t][s % PF]), qf[s], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                if (s + PF < KSTEPS) fr[t][s % PF] = cur[t * TILE_U4 + (s + PF) * 64];
+                else fr[t][s % PF] = nxt[t * TILE_U4 + (s + PF - KSTEPS) * 64];  // first fragments of the next step (stale after the last)
+            }
+            // deferred fold of the previous step's tiles, spread over the slots
+#pragma unroll
+            for (int e = s * 16 * T / KSTEPS; e < (s + 1) * 16 * T / KSTEPS; ++e) s1 = max(s1, (unsigned)prev[e >> 4][e & 15]);
+            if (s >= 1 && s <= PIECES) {  // one 1 KiB piece per slot instead of a burst
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + 2 * T < ntiles) {
+                    const int p = s - 1;
+                    glds16(gnext + p * NWAVES * 64,
+                           __builtin_amdgcn_readfirstlane(ldst0 + ring2 * TILE_BYTES + (unsigned)(p * NWAVES) * 1024u));
+                }
+                if (s == PIECES) gnext += T * TILE_U4;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the tiles folded in this step were it - T .. it - 1: a chunk is complete when `it` is a multiple of 4
+        if ((it & 3) == 0) emit_chunk(it >= 4 ? c0 + (it >> 2) - 1 : -1);
+#pragma unroll
+        for (int t = 0; t < T; ++t) prev[t] = acc[t];
+        ring = ring1;
+    }
+#pragma unroll
+    for (int e = 0; e < 16 * T; ++e) s1 = max(s1, (unsigned)prev[e >> 4][e & 15]);
+    emit_chunk(c0 + (ntiles >> 2) - 1);
+    if (lane < 32 && qt < a.nq_tiles) atomicMax(a.qmax + (size_t)qt * 32 + lane, float_key(i8_low));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1432,7 +1544,7 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
                                                            int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
                                                            unsigned* __restrict__ hits, int hcap, int* __restrict__ fb_count,
                                                            int* __restrict__ fb_list) {
-    __shared__ uint4 l_q8[4][24];  // the query's int8 row, unit by unit
+    __shared__ uint4 l_q8[4][48];  // the query's int8 row, unit by unit (d <= 768)
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
     if (qi >= n) return;
@@ -1464,7 +1576,7 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
                 const int rr = lane + 64 * half;  // row of the chunk: tile rr >> 5, position rr & 31
                 const uint4* src = b8 + ((size_t)c * 4 + (rr >> 5)) * (size_t)(units8 * 32) + (rr & 31);
                 int acc = 0;
-                for (int u0 = 0; u0 < units8; u0 += 8) {  // units8 = 16 or 24
+                for (int u0 = 0; u0 < units8; u0 += 8) {  // units8 = 16, 24, 32, 40 or 48
                     uint4 bv[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) bv[k] = src[(u0 + k) * 32];
@@ -2178,8 +2290,9 @@ struct Prepared {
     size_t bytes;
 };
 
-// widths the int8 coarse pass exists for (match_coarse_pipe_kernel<d/32, false, true>)
-inline bool i8_capable(int d) { return d == 256 || d == 384; }
+// widths the int8 coarse pass exists for (match_coarse_pipe_kernel<d/32, false, true>; d = 128 has too few k-steps for the
+// fragment ring)
+inline bool i8_capable(int d) { return d == 256 || d == 384 || d == 512 || d == 640 || d == 768; }
 
 inline Prepared carve_prepared(void* p, int64_t rows, int d) {
     VfmCarver c(p);
@@ -2292,7 +2405,8 @@ inline bool use_sparse(int d, int64_t n, int64_t m) {
 // rescan per candidate chunk, cheap when most unmatched queries stop at the gate and slower than the fp16 pass when every
 // query must be resolved -- so the ungated entry points keep the fp16 pass.  (variant 5 = fp16 pass everywhere, A/B)
 inline bool use_i8(int d, int64_t n, int64_t m, bool gated) {
-    return gated && i8_capable(d) && m < (1ll << 24) && n > 2 * QBLOCK && (g_coarse_qsets == 0 || g_coarse_qsets == 9);
+    return gated && i8_capable(d) && m < (1ll << 24) && n > 2 * QBLOCK &&
+           (g_coarse_qsets == 0 || g_coarse_qsets == 10);
 }
 inline I8Bounds i8_bounds(const Prepared& Q, const Prepared& B, bool on) {
     return on ? I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr} : I8Bounds{nullptr, nullptr, nullptr, nullptr};
@@ -2313,17 +2427,29 @@ inline void attr_mark(unsigned long long& mask) {
     mask |= 1ull << (dev & 63);
 }
 
-template <int KSTEPS, bool SPARSE, bool I8 = false, int NWAVES = 8>
+template <int KSTEPS, bool SPARSE>
 int launch_coarse_pipe(const CoarseArgs& a, hipStream_t st) {
     const int lds = 6 * KSTEPS * 1024 + (SPARSE ? SPARSE_LREC_CAP * 8 + 16 : 0);
     static unsigned long long attr_set = 0ull;  // one bit per device
     if (!attr_done(attr_set)) {
-        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_pipe_kernel<KSTEPS, SPARSE, I8, NWAVES>),
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_pipe_kernel<KSTEPS, SPARSE>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_mark(attr_set);
     }
-    hipLaunchKernelGGL((match_coarse_pipe_kernel<KSTEPS, SPARSE, I8, NWAVES>), dim3(a.nseed_pad + a.nqb * a.nslices), dim3(64 * NWAVES),
-                       lds, st, a);
+    hipLaunchKernelGGL((match_coarse_pipe_kernel<KSTEPS, SPARSE>), dim3(a.nseed_pad + a.nqb * a.nslices), dim3(512), lds, st, a);
+    return VFM_OK;
+}
+
+template <int KSTEPS, int T>
+int launch_coarse_i8(const CoarseArgs& a, hipStream_t st) {
+    const int lds = 3 * T * KSTEPS * 1024;
+    static unsigned long long attr_set = 0ull;  // one bit per device
+    if (!attr_done(attr_set)) {
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_i8_kernel<KSTEPS, T>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_mark(attr_set);
+    }
+    hipLaunchKernelGGL((match_coarse_i8_kernel<KSTEPS, T>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
     return VFM_OK;
 }
 
@@ -2383,24 +2509,38 @@ int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2
                 hipStream_t st, bool want_f16 = true) {
     Prepared p1 = carve_prepared(prepared1, rows1, d);
     Prepared p2 = x2 ? carve_prepared(prepared2, rows2, d) : Prepared{};
+    const int t1 = (int)(rows_padded(rows1) / TILE_ROWS), t2 = x2 ? (int)(rows_padded(rows2) / TILE_ROWS) : 0;
     if (i8_capable(d)) {  // int8 tiles + group data (+ fp16 tiles)
         const int g1 = (int)(rows_padded(rows1) / I8_GROUP), g2 = x2 ? (int)(rows_padded(rows2) / I8_GROUP) : 0;
         static unsigned long long attr_set = 0ull;  // one bit per device
         if (!attr_done(attr_set)) {
-            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_chunk_kernel<true>),
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_chunk_kernel<true, 2>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * 384 * 3));
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_chunk_kernel<false, 2>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * 512));
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_chunk_kernel<false, 3>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * 768));
             attr_mark(attr_set);
         }
-        if (want_f16)
-            hipLaunchKernelGGL(prep_chunk_kernel<true>, dim3((unsigned)(g1 + g2)), dim3(1024), (size_t)I8_GROUP * d * 3, st, x1, rows1, d,
-                               prep_out(p1), g1, x2, rows2, prep_out(p2));
-        else
-            hipLaunchKernelGGL(prep_chunk_kernel<false>, dim3((unsigned)(g1 + g2)), dim3(1024), (size_t)I8_GROUP * d, st, x1, rows1, d,
-                               prep_out(p1), g1, x2, rows2, prep_out(p2));
+        const dim3 grid((unsigned)(g1 + g2)), block(1024);
+        if (want_f16 && d <= 384) {  // both images from one read of the rows (144 KB of LDS at d = 384)
+            hipLaunchKernelGGL((prep_chunk_kernel<true, 2>), grid, block, (size_t)I8_GROUP * d * 3, st, x1, rows1, d, prep_out(p1), g1, x2,
+                               rows2, prep_out(p2));
+        } else {
+            if (d <= 512)
+                hipLaunchKernelGGL((prep_chunk_kernel<false, 2>), grid, block, (size_t)I8_GROUP * d, st, x1, rows1, d, prep_out(p1), g1, x2,
+                                   rows2, prep_out(p2));
+            else
+                hipLaunchKernelGGL((prep_chunk_kernel<false, 3>), grid, block, (size_t)I8_GROUP * d, st, x1, rows1, d, prep_out(p1), g1, x2,
+                                   rows2, prep_out(p2));
+            if (want_f16) {  // wider rows: the fp16 image by its own kernel (both images would not fit the LDS)
+                hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)(t1 + t2)), dim3(256), (size_t)d * 64, st, x1, rows1, d, p1.inv,
+                                   p1.tiles, t1, x2, rows2, p2.inv, p2.tiles);
+            }
+        }
         VFM_CHECK_LAUNCH("prep_chunk_kernel");
         return VFM_OK;
     }
-    const int t1 = (int)(rows_padded(rows1) / TILE_ROWS), t2 = x2 ? (int)(rows_padded(rows2) / TILE_ROWS) : 0;
     hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)(t1 + t2)), dim3(256), (size_t)d * 64, st, x1, rows1, d, p1.inv, p1.tiles,
                        t1, x2, rows2, p2.inv, p2.tiles);
     VFM_CHECK_LAUNCH("prep_rows_kernel");
@@ -2464,18 +2604,21 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
         a.Bh = B.tiles8;
         a.ib = I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr};
         if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
+        a.nqb = (int)(rows_padded(n) / QBLOCK);  // 8 waves x 32 queries at every width
+        a.nslices = choose_slices(a.nqb, a.nchunks);
         int rc8;
-        if (d == 384 && g_coarse_qsets == 9) {  // variant 9 (A/B): 12 waves x 32 queries.  Alone 1-3 % faster (1.17-1.21 vs
-            // 1.20-1.21 ms), but 3 x 167 registers per SIMD leave no room for the solve stage's waves beside it: the pipeline
-            // measured 558 vs 567 registrations/s, so 8 waves stay the default
-            a.nqb = (a.nq_tiles + 11) / 12;
-            a.nslices = choose_slices(a.nqb, a.nchunks);
-            rc8 = launch_coarse_pipe<12, false, true, 12>(a, st);
-        } else {
-            rc8 = d == 384 ? launch_coarse_pipe<12, false, true>(a, st) : launch_coarse_pipe<8, false, true>(a, st);
+        {
+            const bool t2 = g_coarse_qsets == 10;  // variant 10 (A/B): 2 tiles per step at every width
+            switch (d / 32) {
+                case 8: rc8 = t2 ? launch_coarse_i8<8, 2>(a, st) : launch_coarse_i8<8, 4>(a, st); break;
+                case 12: rc8 = t2 ? launch_coarse_i8<12, 2>(a, st) : launch_coarse_i8<12, 4>(a, st); break;
+                case 16: rc8 = launch_coarse_i8<16, 2>(a, st); break;
+                case 20: rc8 = launch_coarse_i8<20, 2>(a, st); break;
+                default: rc8 = launch_coarse_i8<24, 2>(a, st); break;
+            }
         }
         if (rc8) return rc8;
-        VFM_CHECK_LAUNCH("match_coarse_pipe_kernel(int8)");
+        VFM_CHECK_LAUNCH("match_coarse_i8_kernel");
         if (g_prof_stop) VFM_CHECK_HIP(hipEventRecord(g_prof_stop, st));
         g_prof_start = g_prof_stop = nullptr;
         return VFM_OK;
