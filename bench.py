@@ -198,7 +198,7 @@ def extra_configs(dev):
     out["C5"] = {"workload": "50000-pt scan vs 1000000-pt map, 768-D, 50000 RANSAC iterations (one registration, serial)",
                  "ms_registration": t5_reg, "ms_coarse_kernel": t5, "correspondences": int(r5["count"].item()),
                  "pose_err_vs_planted": float(np.linalg.norm(r5["T"].cpu().numpy() - p5["T_gt"])),
-                 "roofline": {"bound": "mfma", "kernel": "match_coarse_pipe_kernel<24, false, true> (int8 32x32x32 MFMA)", "flops": f5,
+                 "roofline": {"bound": "mfma", "kernel": "match_coarse_i8_kernel<24, 2> (int8 32x32x32 MFMA)", "flops": f5,
                               "achieved": f5 / (t5 * 1e-3) / 1e12, "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s",
                               "frac": f5 / (t5 * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS}}
     return out
@@ -370,7 +370,7 @@ def main():
         # which coarse pass ran: the int8 one for d = 256 / 384 unless an A/B variant forces the fp16 pass
         i8 = d in (256, 384, 512, 640, 768) and n > 512 and os.environ.get("VFM_VARIANT", "0") in ("0", "9")
         peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS
-        kernel = ("match_coarse_pipe_kernel<12, false, true> (int8 32x32x32 MFMA, exact integer scores, per-chunk top-2 records)" if i8
+        kernel = ("match_coarse_i8_kernel<12, 4> (int8 32x32x32 MFMA, exact integer scores, one best-score record per (query, chunk))" if i8
                   else "match_coarse_pipe_kernel<24, true> (fp16 32x32x16 MFMA, sparse row-level records)")
         traffic, traffic_src = None, None  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
         for name in (("r02_pmc_match_coarse_i8.json",) if i8 else ("r02_pmc_match_coarse_f16.json", "r01_pmc_match_coarse.json")):
