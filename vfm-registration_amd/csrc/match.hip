@@ -536,8 +536,8 @@ __device__ __forceinline__ unsigned score_bits(int v) { return (unsigned)v; }
 
 // End of a 128-row chunk: merge the two half-waves and emit the chunk's top-2 for the 32 queries of tile
 // qt (chunk < 0: the dummy fold of the very first step, nothing is stored); resets the running pair.
-__device__ __forceinline__ unsigned coarse_emit_chunk(const CoarseArgs& a, unsigned& s1, unsigned& s2, unsigned& runmax,
-                                                      int qt, int chunk) {
+__device__ __forceinline__ void coarse_emit_chunk(const CoarseArgs& a, unsigned& s1, unsigned& s2, unsigned& runmax,
+                                                  int qt, int chunk) {
     const int lane = lane_id(), hi = lane >> 5;
     const unsigned o1 = __shfl_xor(s1, 32), o2 = __shfl_xor(s2, 32);
     const bool own = (s1 > o1) || (s1 == o1 && hi == 0);
@@ -552,7 +552,6 @@ __device__ __forceinline__ unsigned coarse_emit_chunk(const CoarseArgs& a, unsig
     }
     s1 = 0u;
     s2 = 0u;
-    return w1 & ~127u;  // the chunk's best score, low 7 bits dropped (all lanes)
 }
 
 // int8 pass: the chunk's BEST VALUE only -- one VALU op per accumulator element instead of three (with the packed top-2 the
@@ -1543,7 +1542,7 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
                                                            const uint4* __restrict__ b8, const unsigned* __restrict__ qmax,
                                                            int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
                                                            unsigned* __restrict__ hits, int hcap, int* __restrict__ fb_count,
-                                                           int* __restrict__ fb_list) {
+                                                           int* __restrict__ fb_list, int* __restrict__ todo) {
     __shared__ uint4 l_q8[4][48];  // the query's int8 row, unit by unit (d <= 768)
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
@@ -1611,7 +1610,10 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the hits written above are read back by other lanes
         for (int i = lane; i < nhit; i += 64) mycand[i] = myhits[i];
     }
-    if (lane == 0) cand_cnt[qi] = nhit;
+    if (lane == 0) {
+        cand_cnt[qi] = nhit;
+        if (nhit >= REFINE_MIN) todo[atomicAdd(fb_count + 6, 1)] = (int)qi;  // crowded: match_refine_kernel's work list
+    }
 }
 
 // dense records: the candidate entries of match_select_kernel (int8 pass: as rewritten by match_rescan_kernel)
@@ -1619,19 +1621,25 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
                                                            const float* __restrict__ b, const float* __restrict__ invb,
                                                            int64_t n, int64_t m, int d, float w2, int* __restrict__ cand_cnt,
                                                            unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count,
-                                                           int* __restrict__ fb_list, int stats) {
+                                                           int* __restrict__ fb_list, int stats, const int* __restrict__ todo,
+                                                           const int* __restrict__ todo_count) {
     __shared__ unsigned l_row[4][REFINE_KEEP];
     __shared__ float l_sc[4][REFINE_KEEP];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+    // todo != NULL (int8 pass): the queries match_rescan_kernel found crowded, a short list walked by a small grid;
+    // otherwise one wave per query
+    const int64_t slot0 = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t nslots = todo ? (int64_t)*todo_count : n;
+  for (int64_t slot = slot0; slot < nslots; slot += (int64_t)gridDim.x * 4) {
+    const int64_t qi = todo ? (int64_t)todo[slot] : slot;
     if (qi >= n) return;
     const int cnt = cand_cnt[qi];
-    if (cnt <= 0) return;  // zero query / nothing / overflow (-1: the all-pairs kernel decides)
+    if (cnt <= 0) continue;  // zero query / nothing / overflow (-1: the all-pairs kernel decides)
     unsigned* mycand = cand + (size_t)qi * cap;
     // wave-uniform: is this list crowded?
     bool flagged = false;
     for (int e = lane; e < cnt; e += 64) flagged |= (mycand[e] & 128u) != 0u;
-    if (cnt < REFINE_MIN && !__any(flagged)) return;
+    if (cnt < REFINE_MIN && !__any(flagged)) continue;
     RefineWave R;
     R.init(q, invq[qi], qi, b, invb, d, w2, l_row[wave], l_sc[wave]);
     // single-row entries: 4 per pass
@@ -1657,9 +1665,11 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
             if (__any(row >= 0)) R.consider(row, R.score4(row));
         }
     }
-    if (R.overflow) return;  // > REFINE_KEEP rows tie within the fp32 margin (exact duplicates): the list stays as
-                             // match_select_kernel wrote it and match_rescore_kernel decides all of it in fp64
+    if (R.overflow) continue;  // > REFINE_KEEP rows tie within the fp32 margin (exact duplicates): the list stays as
+                               // match_select_kernel wrote it and match_rescore_kernel decides all of it in fp64
     R.finish(qi, mycand, cand_cnt, fb_count, fb_list, stats);
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // sparse records (match_coarse_pipe_kernel<., true>): filter the query's records against its FINAL coarse maximum, then
@@ -2660,11 +2670,17 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
         if (i8) {  // candidate chunks -> candidate rows (the record buffer of the fp16 pass is free: it holds the hit lists)
             hipLaunchKernelGGL(match_rescan_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, m, d, i8_bounds(Q, B, true),
                                (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt, w.cand, w.cap,
-                               reinterpret_cast<unsigned*>(w.rec), 2 * w.rcap, w.fb_count, w.fb_list);
+                               reinterpret_cast<unsigned*>(w.rec), 2 * w.rcap, w.fb_count, w.fb_list,
+                               reinterpret_cast<int*>(w.rec_cnt));
             VFM_CHECK_LAUNCH("match_rescan_kernel");
+            // (rec_cnt, unused by the int8 pass, holds the list of crowded queries; fb_count[6] its length)
+            const unsigned grid = (unsigned)((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024);
+            hipLaunchKernelGGL(match_refine_kernel, dim3(grid), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2, w.cand_cnt, w.cand,
+                               w.cap, w.fb_count, w.fb_list, g_match_stats, (const int*)w.rec_cnt, (const int*)(w.fb_count + 6));
+        } else {
+            hipLaunchKernelGGL(match_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2,
+                               w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats, (const int*)nullptr, (const int*)nullptr);
         }
-        hipLaunchKernelGGL(match_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2,
-                           w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
         VFM_CHECK_LAUNCH("match_refine_kernel");
     }
     {
