@@ -72,7 +72,7 @@ alone on the GPU {r['single_stream']['avg_launch_ms']:.3f} ms = {r['single_strea
 {r['single_stream']['frac']:.3f}.  CPU oracle on the same box ({b['cpu_baseline']['cores']} threads): {b['cpu_baseline']['value']:.3f} registrations/s.
 Pose delta vs the oracle on identical inputs (`extra.pose_delta_vs_oracle`): {ex.get('pose_delta_vs_oracle', {}).get('pose_delta_vs_oracle_frobenius')}.
 `extra.C3`: {ex['C3']['ms_end_to_end']:.2f} ms end to end (ViT {ex['C3']['ms_vit']:.2f}, project + lift {ex['C3']['ms_project_lift']:.2f}, registration {ex['C3']['ms_registration']:.2f}; ViT at {ex['C3']['vit_roofline']['frac']:.3f} of the MFMA peak).
-`extra.C5`: coarse kernel {ex['C5']['ms_coarse_kernel']:.1f} ms = {ex['C5']['roofline']['frac']:.3f} of the fp16 peak, registration {ex['C5']['ms_registration']:.1f} ms.
+`extra.C5` (50k x 1M x 768, int8 pass): coarse kernel {ex['C5']['ms_coarse_kernel']:.1f} ms = {ex['C5']['roofline']['frac']:.3f} of the int8 peak, registration {ex['C5']['ms_registration']:.1f} ms.
 
 Same box, `VFM_VARIANT=5 python bench.py` (the fp16 coarse pass with sparse records, round 2's earlier default) ->
 `profiles/r02_bench_f16_same_box.json`: {bf['value']:.1f} registrations/s, kernel {bf['roofline']['avg_launch_ms']:.3f} ms
