@@ -55,6 +55,11 @@ for variant in VARIANTS:
           f"refined {s[1]}, candidates/query {s[2] / n:.2f}, kept {s[3]}, records/query {s[4] / n:.1f}, histogram {s[8:24]}", flush=True)
     res[variant] = (idx.clone(), sim.clone())
 lib.vfm_debug_set_coarse_variant(0)
-if 0 in res and 5 in res:
-    print("idx equal:", bool((res[0][0] == res[5][0]).all()), " sim equal:", bool((res[0][1] == res[5][1]).all()),
-          " mismatches:", int((res[0][0] != res[5][0]).sum()))
+first = VARIANTS[0]
+for v in res:
+    if v != first:
+        ok = res[v][0] >= 0
+        ok0 = res[first][0] >= 0
+        both = ok & ok0
+        print(f"variant {v} vs {first}: resolved sets equal {bool((ok == ok0).all())}, idx equal {bool((res[first][0][both] == res[v][0][both]).all())}, "
+              f"sim equal {bool((res[first][1][both] == res[v][1][both]).all())}")
