@@ -23,6 +23,7 @@ _lib.check(lib.vfm_prof_events_create(C.byref(a), C.byref(b)))
 ms = C.c_float()
 st = torch.cuda.current_stream().cuda_stream
 res = {}
+lib.vfm_debug_set_coarse_slices(int(os.environ.get("VFM_SLICES", "0")))
 GATE = C.c_float(float(os.environ.get("VFM_GATE", "-inf")))
 import os
 VARIANTS = tuple(int(v) for v in os.environ.get("VFM_AB_VARIANTS", "0,5,0,5").split(","))
