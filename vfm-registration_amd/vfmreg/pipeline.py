@@ -74,6 +74,7 @@ class RegistrationPipeline:
         self.last_rescans: Optional[int] = None
         self._fp16_left = 0
         self._pending = []  # (event, pinned int32[1]) of gated searches whose rescan count is on its way to the host
+        self._slots = []    # pinned slots ready for reuse
         # solve_streams = K: the solve stages of K consecutive pairs may run beside each other (and beside the coarse pass
         # of a later pair) on K side streams, with K + 1 buffer sets
         self.n_solve = max(1, int(solve_streams)) if self.overlap else 0
@@ -114,6 +115,7 @@ class RegistrationPipeline:
         while self._pending and self._pending[0][0].query():
             _, slot = self._pending.pop(0)
             self.last_rescans = int(slot.item())
+            self._slots.append(slot)
             if self.coarse == "auto" and self.use_i8 and self.last_rescans > self.RESCAN_LIMIT * self.n:
                 self.use_i8 = False
                 self._fp16_left = self.REPROBE
@@ -186,10 +188,10 @@ class RegistrationPipeline:
                                                          r.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(), r.sim.data_ptr(),
                                                          r.sws.data_ptr(), r.sws.numel(), gate, rst), "search(finish)")
             if self.coarse == "auto" and len(self._pending) < 8:  # feedback: candidate chunks this search rescans
-                slot = torch.zeros(1, dtype=torch.int32).pin_memory()
+                slot = self._slots.pop() if self._slots else torch.zeros(1, dtype=torch.int32).pin_memory()
                 _lib.check(lib.vfm_match_search_rescans_async(r.sws.data_ptr(), self.n, self.m, slot.data_ptr(), rst), "rescans")
                 ev = torch.cuda.Event()
-                ev.record(torch.cuda.ExternalStream(rst, device=self.device))
+                ev.record(solve if self.overlap else main)
                 self._pending.append((ev, slot))
         else:
             _lib.check(lib.vfm_match_search_finish(q_desc.data_ptr(), r.qprep.data_ptr(), self.n, b_desc.data_ptr(),
