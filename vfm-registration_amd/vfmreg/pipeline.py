@@ -2,7 +2,7 @@
 RegistrationNode.ransac_registration('vfm') (registration_node.py:273-328) as HIP kernels with no
 host synchronisation:
 
-    normalise + fp16 fragment tiles (VoxelHashMap.cpp:469-482)
+    normalise + MFMA fragment tiles   (VoxelHashMap.cpp:469-482; int8 image for the int8 coarse pass, fp16 for the fp16 one)
  -> top-1 inner-product search        (VoxelHashMap.cpp:486-495)
  -> cosine threshold + compaction      (VoxelHashMap.cpp:501-511, 587-600)
  -> correspondence RANSAC + Kabsch     (registration_node.py:319-327)
@@ -10,16 +10,21 @@ host synchronisation:
 Buffers are allocated once for fixed (N, M, D); ``register`` only enqueues work.
 
 ``overlap_ransac=True`` turns the chain into a pipeline over independent scene pairs:
-stage 1 (caller's stream) = normalise + fp16 fragment conversion (HBM-bound) and the fp16 MFMA coarse pass of pair i+1;
-stage 2 (a "solve" HIP stream) = record filtering + fp32 refinement, exact fp64 re-decision, threshold / compaction
-and RANSAC of pair i -- vector ALU and fp64, a few hundred short waves that share compute units with the coarse pass at
-no measurable cost to it.  Events order the hand-offs and two complete buffer sets (prepared operands, search
-workspace, results) ping-pong, so results of pair i stay valid until pair i+2 is enqueued.  Coarse passes never overlap
-each other; the inputs of a pair must stay untouched until its ``done`` event.
-``overlap_prepare=True`` additionally moves the operand preparation of pair i+1 to a third stream beside the coarse pass
-of pair i (round 1's default).  Measured in round 2: the 0.5 GB it streams cost the coarse pass 5-7 % (2.71-2.77 vs
-2.57-2.59 ms; power and L2, not LDS: an LDS-free version of the kernel taxed it the same), more than the 0.11 ms it
-hides -- 360 vs 365 registrations/s -- so it is off by default.
+stage 1 (caller's stream) = operand preparation (HBM-bound) and the MFMA coarse pass of pair i+1;
+stage 2 (``solve_streams`` side streams, round-robin) = candidate selection / rescan / fp32 refinement, exact fp64
+re-decision, threshold / compaction and RANSAC of pairs i, i-1, ...  Events order the hand-offs and ``solve_streams + 1``
+complete buffer sets (prepared operands, search workspace, results) rotate, so results of a pair stay valid until
+``solve_streams + 1`` further pairs have been enqueued.  Coarse passes never overlap each other; the inputs of a pair must
+stay untouched until its ``done`` event.
+``overlap_prepare=True`` moves the operand preparation to a stream of its own, beside the coarse pass of the previous
+pair.  With the fp16 pass it cost the coarse kernel more than it hid (round 2, first half: 360 vs 365 registrations/s);
+with the int8 pass, whose kernel is half as long, prepare stream + two solve streams is the best arrangement measured
+(604-665 registrations/s against 558-574 for one solve stream with prepare on the caller's stream) and is what bench.py runs.
+
+``coarse``: which coarse pass -- "int8" = the gated family of include/vfmreg.h (queries that provably miss ``min_cosine``
+stay unresolved: idx -1, sim -2.0; correspondences and pose are unaffected), "fp16" = the ungated family, "auto" (default)
+= int8 until a search reports more than ``RESCAN_LIMIT`` rescanned chunks per query (duplicate-rich maps), then fp16 with a
+re-probe every ``REPROBE`` registrations.  ``gate=False`` keeps the int8 pass but resolves every query.
 """
 from __future__ import annotations
 
