@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_i8
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-VFM_AB_VARIANTS=${1:-9} timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o i8 -- python $R/tools/ab_i8.py > $O/out.txt 2> $O/err.txt
+VFM_AB_VARIANTS=${1:-0} timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o i8 -- python $R/tools/ab_i8.py > $O/out.txt 2> $O/err.txt
 tail -3 $O/out.txt
 python - <<PY
 import csv, glob

@@ -560,8 +560,10 @@ __device__ __forceinline__ void coarse_emit_chunk(const CoarseArgs& a, unsigned&
 __device__ __forceinline__ unsigned coarse_emit_chunk_best(const CoarseArgs& a, unsigned& s1, int qt, int chunk) {
     const int lane = lane_id();
     const unsigned w1 = max(s1, (unsigned)__shfl_xor(s1, 32));
+    // layout [query tile][chunk][32]: a wave's records of consecutive chunks are consecutive 128-byte lines, and
+    // match_select_kernel reads each query tile as one contiguous stream
     if (lane < 32 && qt < a.nq_tiles && chunk >= 0)
-        reinterpret_cast<unsigned*>(a.partials)[(size_t)chunk * a.npad + (size_t)qt * 32 + lane] = w1;
+        reinterpret_cast<unsigned*>(a.partials)[((size_t)qt * a.nchunks + (size_t)chunk) * 32 + lane] = w1;
     s1 = 0u;
     return w1;
 }
@@ -1430,9 +1432,10 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
                                                            int64_t n, int first_pad_chunk,
                                                            const unsigned* __restrict__ qmax,
                                                            const float* __restrict__ invq, float window,
-                                                           I8Bounds ib, float gate, int* __restrict__ cand_cnt,
+                                                           I8Bounds ib, float gate, int chunk_lds, int* __restrict__ cand_cnt,
                                                            unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count,
                                                            int* __restrict__ fb_list, int stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char select_smem[];  // int8 records: the chunks' (step, max E)
     __shared__ int lcnt[64];
     __shared__ unsigned lub[64];  // int8 records: float_key of the largest upper bound over the query's chunks
     const int qq = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -1441,6 +1444,9 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
         lcnt[qq] = 0;
         lub[qq] = 0u;
     }
+    float2* lchunk = reinterpret_cast<float2*>(select_smem);
+    if (ib.qerr && chunk_lds)  // every thread walks ~nchunks / 16 chunks: their (step, max E) once per workgroup into LDS
+        for (int c = threadIdx.x; c < nchunks; c += 64 * SELECT_GROUPS) lchunk[c] = make_float2(ib.bstep[c], ib.berr[c]);
     __syncthreads();
     if (ib.qerr) {
         // Records of the int8 pass: integer scores in the units of (query group step) x (map chunk step).  In exact score
@@ -1455,19 +1461,21 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
         const float A = eq * 1.0001220703125f, mult = 1.0001220703125f + eq, slack = 1.0e-6f;
         const float qlow = key_float(qmax[q]);  // -Inf: no un-padded chunk exists -> every chunk is a candidate
         float maxup = -__builtin_inff();
-        const unsigned* best = reinterpret_cast<const unsigned*>(partials);  // [nchunks][npad] best integer score (+ 2^30)
+        // [query tile][chunk][32]: best integer score (+ 2^30) of the chunk for the tile's 32 queries
+        const unsigned* best = reinterpret_cast<const unsigned*>(partials) + (size_t)(q >> 5) * nchunks * 32 + (q & 31);
         for (int cb = g; cb < nchunks; cb += 8 * SELECT_GROUPS) {
             unsigned rec[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = cb + SELECT_GROUPS * u;
-                rec[u] = (c < nchunks) ? best[(size_t)c * npad + q] : 0u;
+                rec[u] = (c < nchunks) ? best[(size_t)c * 32] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = cb + SELECT_GROUPS * u;
                 if (c >= nchunks) continue;
-                const float sc = sq * ib.bstep[c], bound = A + mult * ib.berr[c] + slack;
+                const float2 cb2 = chunk_lds ? lchunk[c] : make_float2(ib.bstep[c], ib.berr[c]);
+                const float sc = sq * cb2.x, bound = A + mult * cb2.y + slack;
                 const float up1 = sc * (float)((int)rec[u] - I8_OFFSET) + bound;
                 maxup = fmaxf(maxup, up1);
                 if (up1 >= qlow) {  // (zero-padded rows score exactly 0: a padded chunk is a candidate only if 0 is inside the window)
@@ -2826,9 +2834,11 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                            DEFAULT_WINDOW, w2, w.qmax, w.rec_cnt, w.rec, w.rcap, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
         VFM_CHECK_LAUNCH("match_filter_refine_kernel");
     } else {
-        hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS), 0, st, w.partials, a.nchunks,
-                           a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, i8_bounds(Q, B, i8), gate, w.cand_cnt, w.cand, w.cap,
-                           w.fb_count, w.fb_list, g_match_stats);
+        const int chunk_lds = i8 && (size_t)a.nchunks * sizeof(float2) <= 63 * 1024;  // (step, max E) of every chunk in LDS
+        hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS),
+                           chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, w.partials, a.nchunks, a.npad, n, a.first_pad_chunk, w.qmax,
+                           Q.inv, DEFAULT_WINDOW, i8_bounds(Q, B, i8), gate, chunk_lds, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list,
+                           g_match_stats);
         VFM_CHECK_LAUNCH("match_select_kernel");
         if (i8) {  // candidate chunks -> candidate rows (the record buffer of the fp16 pass is free: it holds the hit lists)
             hipLaunchKernelGGL(match_rescan_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, m, d, i8_bounds(Q, B, true),
@@ -3095,7 +3105,7 @@ int l2_search(const float* q, void* qprep, int64_t n, const float* b, void* bpre
     SearchWs w = carve_search(ws, n, m);
     const CoarseArgs a = coarse_args(Q, carve_prepared(bprep, m, kp), w, n, m, coarse_qblock(kp));
     hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS), 0, st, w.partials, a.nchunks,
-                       a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, i8_bounds(Q, Q, false), -__builtin_inff(), w.cand_cnt, w.cand,
+                       a.npad, n, a.first_pad_chunk, w.qmax, Q.inv, DEFAULT_WINDOW, i8_bounds(Q, Q, false), -__builtin_inff(), 0, w.cand_cnt, w.cand,
                        w.cap, w.fb_count, w.fb_list, g_match_stats);
     VFM_CHECK_LAUNCH("match_select_kernel");
     hipLaunchKernelGGL(l2_rescore_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)d * 4 * 8, st, q, b, n, m, d, w.cand_cnt,
