@@ -368,7 +368,7 @@ def main():
         flops = 2.0 * n * m * d
         achieved = flops / (coarse_ms * 1e-3) / 1e12
         # which coarse pass ran: the int8 one for d = 256 / 384 unless an A/B variant forces the fp16 pass
-        i8 = d in (256, 384, 512, 640, 768) and n > 512 and os.environ.get("VFM_VARIANT", "0") in ("0", "10", "12")
+        i8 = d in (256, 384, 512, 640, 768) and os.environ.get("VFM_VARIANT", "0") in ("0", "10", "12")
         peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS
         kernel = ("match_coarse_i8q2_kernel<12> (int8 32x32x32 MFMA, 64 resident queries per wave, exact integer scores, one best-score record "
                   "per (query, chunk))" if i8

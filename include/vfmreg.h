@@ -90,7 +90,7 @@ int vfm_match_search_finish(const float *q, const void *q_prepared, int64_t n, c
 /* ---- the GATED family: for a caller that keeps only matches with similarity >= gate (the cosine gate of
  * GetVFMCorrespondences, VHM:501-511).  A query whose best similarity is PROVABLY below `gate` is not resolved --
  * idx_out = -1, sim_out = -2.0 -- every other query gets the oracle's answer; gate = -INFINITY resolves every query.
- * For d = 256 / 384 and n > 512 this family runs the int8 coarse pass (int8 MFMA over rows quantised per 128-row group,
+ * For d = 256 ... 768 this family runs the int8 coarse pass (int8 MFMA over rows quantised per 128-row group,
  * exact integer scores, proven per-(query, chunk) bounds): twice the matrix rate of the fp16 pass, and
  * the proof that a query stays below the gate comes from the same bounds.  Elsewhere it is the ungated path and the gate
  * is ignored (every query resolved).  The three calls of one search must come from the same family:
@@ -303,7 +303,7 @@ int vfm_prof_events_create(void **start, void **stop);
 int vfm_prof_arm(void *start, void *stop);
 int vfm_prof_elapsed_ms(void *start, void *stop, float *ms_host);
 int vfm_prof_events_destroy(void *start, void *stop);
-/* tuning switch: coarse-kernel variant (0 default: gated family = int8 pass for d = 256 ... 768 with n > 512; ungated family =
+/* tuning switch: coarse-kernel variant (0 default: gated family = int8 pass for d = 256 ... 768; ungated family =
  * sparse fp16 records for d <= 384, dense fp16 records elsewhere; 1 = 8 waves x 32 queries, 2 = 4 waves x 64, 4 = pipelined
  * kernel with dense fp16 records, 5 = the fp16 pass in the gated family too, 7 = 5 without seed units, 12 = int8 kernel with
  * 32 resident queries per wave at every size, 10 = 12 with two tiles per step at every width) */
@@ -320,6 +320,8 @@ int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
  * quantisation step of its 128-row group, its residual norm E and the group's maximum E.  Synchronises the device. */
 int vfm_debug_i8_rows(const void *prepared, int64_t rows, int d, int8_t *q8_host, float *step_host,
                       float *err_host, float *gerr_host);
+/* tuning switch: the gated family takes the int8 pass for more than this many query rows (default 0: always) */
+int vfm_debug_set_i8_min_queries(int n);
 /* timing experiments only: overrides the coarse window of the sparse kernel (0 = default); results become wrong */
 int vfm_debug_set_coarse_window(float w);
 int vfm_debug_set_coarse_slices(int slices);

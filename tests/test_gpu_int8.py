@@ -1,4 +1,4 @@
-"""The int8 coarse pass (d = 256 ... 768, more than 512 queries): its quantisation bound checked pair by pair against fp64
+"""The int8 coarse pass (d = 256 ... 768, the gated family of entry points): its quantisation bound checked pair by pair against fp64
 scores, oracle-identical answers on inputs that stress the quantisation, and the contract of the similarity gate."""
 import ctypes as C
 
@@ -61,7 +61,7 @@ def test_quantisation_bound_holds_for_every_pair(d):
 
 
 @pytest.mark.parametrize("d,n,m", [(384, 1500, 9000), (256, 2050, 5003), (384, 777, 130), (512, 900, 4100), (640, 1030, 3000),
-                                   (768, 1300, 6000)])
+                                   (768, 1300, 6000), (384, 1, 200), (256, 37, 1000), (384, 300, 20011), (384, 2049, 129)])
 def test_int8_search_equals_the_oracle_on_stress_inputs(d, n, m):
     rng = np.random.default_rng(n + m)
     cases = {

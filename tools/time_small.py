@@ -7,6 +7,8 @@ import torch
 from vfmreg import synth, _lib
 import os
 _lib.load().vfm_debug_set_coarse_variant(int(os.environ.get('VFM_VARIANT', '0')))
+if os.environ.get('VFM_I8_MIN'):
+    _lib.load().vfm_debug_set_i8_min_queries(int(os.environ['VFM_I8_MIN']))
 from vfmreg.pipeline import RegistrationPipeline
 for (n, m) in ((300, 50000), (1500, 100000), (2000, 200000), (20000, 200000)):
     p = synth.make_pair_device(n, m, 384, seed=1)

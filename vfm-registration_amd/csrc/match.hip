@@ -5,7 +5,7 @@
 // Two coarse passes feed one exact decision (indices identical to the fp64 oracle either way):
 //
 // (a) the int8 pass -- the GATED entry points (a caller that keeps only matches above a similarity gate,
-//     VoxelHashMap.cpp:501-511), d = 256 ... 768, more than 512 queries:
+//     VoxelHashMap.cpp:501-511), d = 256 ... 768:
 //   prep_chunk_kernel       fp32 rows -> 1/|row| (faiss fvec_renorm_L2 order), int8 image of the normalised rows with one
 //                           quantisation step per 128-row group, the measured residual norm of every row
 //   match_coarse_i8_kernel  int8 MFMA 32x32x32 (exact integer scores), queries resident in VGPRs, map tiles streamed through
@@ -2566,8 +2566,9 @@ inline bool use_sparse(int d, int64_t n, int64_t m) {
 // d = 256 / 384: the int8 coarse pass with one best-score record per (query, chunk).  Its exact re-decision costs an int8
 // rescan per candidate chunk, cheap when most unmatched queries stop at the gate and slower than the fp16 pass when every
 // query must be resolved -- so the ungated entry points keep the fp16 pass.  (variant 5 = fp16 pass everywhere, A/B)
+int g_i8_min_queries = 0;  // vfm_debug_set_i8_min_queries (A/B knob): the int8 pass wins at every size measured (300 x 50 000: 209 vs 244 us)
 inline bool use_i8(int d, int64_t n, int64_t m, bool gated) {
-    return gated && i8_capable(d) && m < (1ll << 24) && n > 2 * QBLOCK &&
+    return gated && i8_capable(d) && m < (1ll << 24) && n > g_i8_min_queries &&
            (g_coarse_qsets == 0 || g_coarse_qsets == 10 || g_coarse_qsets == 12);
 }
 inline I8Bounds i8_bounds(const Prepared& Q, const Prepared& B, bool on) {
@@ -3203,6 +3204,11 @@ VFM_EXPORT int vfm_debug_i8_rows(const void* prepared, int64_t rows, int d, int8
         step_host[r] = gstep[(size_t)(r / I8_GROUP)];
         gerr_host[r] = gerr[(size_t)(r / I8_GROUP)];
     }
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_debug_set_i8_min_queries(int n) {
+    g_i8_min_queries = n;
     return VFM_OK;
 }
 
