@@ -1722,24 +1722,35 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
             const int c = (int)(__shfl(batch, j) >> 8);  // wave-uniform
             const long long base = (long long)c * CHUNK_ROWS;
             const float sc = sq * ib.bstep[c], bound = A + mult * ib.berr[c];
+            // rows `lane` and `lane + 64` of the chunk (tile rr >> 5, position rr & 31); the loads of both go out together:
+            // 16 x 16 bytes per lane in flight, three round trips per chunk at d = 384 (the loop is latency-bound)
+            const uint4* src0 = b8 + ((size_t)c * 4 + (lane >> 5)) * (size_t)(units8 * 32) + (lane & 31);
+            const uint4* src1 = src0 + 2 * (size_t)(units8 * 32);
+            int acc2[2] = {0, 0};
+            for (int u0 = 0; u0 < units8; u0 += 8) {  // units8 = 16, 24, 32, 40 or 48
+                uint4 bv0[8], bv1[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    bv0[k] = src0[(u0 + k) * 32];
+                    bv1[k] = src1[(u0 + k) * 32];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint4 qv = l_q8[wave][u0 + k];
+                    acc2[0] = __builtin_amdgcn_sdot4((int)bv0[k].x, (int)qv.x, acc2[0], false);
+                    acc2[0] = __builtin_amdgcn_sdot4((int)bv0[k].y, (int)qv.y, acc2[0], false);
+                    acc2[0] = __builtin_amdgcn_sdot4((int)bv0[k].z, (int)qv.z, acc2[0], false);
+                    acc2[0] = __builtin_amdgcn_sdot4((int)bv0[k].w, (int)qv.w, acc2[0], false);
+                    acc2[1] = __builtin_amdgcn_sdot4((int)bv1[k].x, (int)qv.x, acc2[1], false);
+                    acc2[1] = __builtin_amdgcn_sdot4((int)bv1[k].y, (int)qv.y, acc2[1], false);
+                    acc2[1] = __builtin_amdgcn_sdot4((int)bv1[k].z, (int)qv.z, acc2[1], false);
+                    acc2[1] = __builtin_amdgcn_sdot4((int)bv1[k].w, (int)qv.w, acc2[1], false);
+                }
+            }
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                const int rr = lane + 64 * half;  // row of the chunk: tile rr >> 5, position rr & 31
-                const uint4* src = b8 + ((size_t)c * 4 + (rr >> 5)) * (size_t)(units8 * 32) + (rr & 31);
-                int acc = 0;
-                for (int u0 = 0; u0 < units8; u0 += 8) {  // units8 = 16, 24, 32, 40 or 48
-                    uint4 bv[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) bv[k] = src[(u0 + k) * 32];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const uint4 qv = l_q8[wave][u0 + k];
-                        acc = __builtin_amdgcn_sdot4((int)bv[k].x, (int)qv.x, acc, false);
-                        acc = __builtin_amdgcn_sdot4((int)bv[k].y, (int)qv.y, acc, false);
-                        acc = __builtin_amdgcn_sdot4((int)bv[k].z, (int)qv.z, acc, false);
-                        acc = __builtin_amdgcn_sdot4((int)bv[k].w, (int)qv.w, acc, false);
-                    }
-                }
+                const int rr = lane + 64 * half;
+                const int acc = acc2[half];
                 const bool hit = base + rr < m && sc * (float)acc + bound >= qlow;
                 const unsigned long long bal = __ballot(hit);
                 if (hit) {
