@@ -56,6 +56,7 @@ constexpr int CAND_CAP_MAX = 2048;  // candidate entries a query can hold = min(
                                     // beyond it the query is decided by the all-pairs kernel.  At C2 (1563 chunks) the cap
                                     // cannot be exceeded: every chunk fits in the list.
 constexpr int REFINE_MIN = 3;     // queries with this many candidate entries (or a whole-chunk entry) go through the fp32 refinement
+constexpr int REFINE_MIN_I8 = 8;  // the same threshold for the row lists of the int8 pass (match_rescan_kernel)
 constexpr int REFINE_KEEP = 64;   // rows a query may keep after the refinement
 constexpr int SPARSE_LREC_CAP = 1536;  // records a workgroup of the sparse coarse kernel buffers in LDS (12 KiB)
 constexpr float COARSE_OFFSET = 2.0f;   // accumulators start here: every coarse score is a
@@ -1775,7 +1776,9 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
     }
     if (lane == 0) {
         cand_cnt[qi] = nhit;
-        if (nhit >= REFINE_MIN) todo[atomicAdd(fb_count + 6, 1)] = (int)qi;  // crowded: match_refine_kernel's work list
+        // crowded: match_refine_kernel's work list (up to seven rows go straight to the fp64 decision: a handful of fp64
+        // dot products costs less than the latency of one refinement wave)
+        if (nhit >= REFINE_MIN_I8) todo[atomicAdd(fb_count + 6, 1)] = (int)qi;
     }
 }
 
