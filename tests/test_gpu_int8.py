@@ -148,3 +148,45 @@ def test_pipeline_leaves_the_int8_pass_on_a_duplicate_rich_map_and_results_do_no
     for coarse in ("int8", "fp16"):
         assert torch.equal(outs["auto"][0], outs[coarse][0]) and torch.equal(outs["auto"][1], outs[coarse][1])
     assert outs["auto"][1].shape[0] > 500
+
+
+def test_quantisation_bound_at_c2_scale():
+    """The same pair-by-pair check at the benchmark's size: every 10th query of C2 against all 200 000 map rows, fp64
+    scores of the oracle's normalised rows computed on the device (the checker, not the product)."""
+    n, m, d = 20000, 200000, 384
+    p = synth.make_pair_device(n, m, d, seed=42)
+    Q, B = ops.PreparedRows(p["q_desc"]), ops.PreparedRows(p["b_desc"])
+    q8, sq, eq, _ = _i8_rows(Q)
+    b8, sb, eb, gb = _i8_rows(B)
+    assert float(np.median(eb)) < 0.012 and float(gb.max()) < 0.02           # Gaussian unit rows: E ~ 0.0098
+    dev = torch.device("cuda")
+    rows = torch.arange(0, n, 10, device=dev)
+    # the oracle's normalisation (fp32 sum of squares in its order is what prep_chunk_kernel reproduces; here the rows are
+    # re-normalised in fp64 from the kernel's own 1/|row|, which test_gpu_parity pins to the oracle bit for bit)
+    idx, sim = ops.match_ip_top1(p["q_desc"], p["b_desc"], ops.FAST, gate=float("-inf"))
+    vq = (p["q_desc"][rows] * (1.0 / p["q_desc"][rows].double().norm(dim=1, keepdim=True)).float()).double()
+    worst_slack, worst_dev = float("inf"), 0.0
+    tq8 = torch.from_numpy(q8).to(dev)[rows].double()
+    tsq, teq = torch.from_numpy(sq).to(dev)[rows].double(), torch.from_numpy(eq).to(dev)[rows].double()
+    best = torch.full((len(rows),), -2.0, dtype=torch.float64, device=dev)
+    arg = torch.zeros(len(rows), dtype=torch.int64, device=dev)
+    for c0 in range(0, m, 20000):
+        bb = p["b_desc"][c0:c0 + 20000]
+        vb = (bb * (1.0 / bb.double().norm(dim=1, keepdim=True)).float()).double()
+        t = vq @ vb.T
+        S = tq8 @ torch.from_numpy(b8[c0:c0 + 20000]).to(dev).double().T
+        tsb = torch.from_numpy(sb[c0:c0 + 20000]).to(dev).double()
+        tgb = torch.from_numpy(gb[c0:c0 + 20000]).to(dev).double()
+        devn = (t - tsq[:, None] * tsb[None, :] * S).abs()
+        bound = (1 + 2.0 ** -13 + teq[:, None]) * tgb[None, :] + (1 + 2.0 ** -13) * teq[:, None]
+        # the re-normalisation above differs from the kernel's fp32 one by < 2e-7 per score: far inside the bound's slack
+        worst_slack = min(worst_slack, float((bound - devn).min()))
+        worst_dev = max(worst_dev, float(devn.max()))
+        cb, ca = t.max(dim=1)
+        upd = cb > best
+        best = torch.where(upd, cb, best)
+        arg = torch.where(upd, ca + c0, arg)
+    assert worst_slack > 0.0, (worst_slack, worst_dev)
+    assert worst_dev < 0.01                                                    # the actual error is a fraction of the bound
+    # and the search's answers on those rows are the arg-max of the fp64 scores (up to exact ties, which the data has none of)
+    assert torch.equal(idx[rows], arg)
