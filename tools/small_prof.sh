@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for v in 0 4 7; do echo "== variant $v"; VFM_VARIANT=$v python $R/tools/time_small.py 2>&1 | grep "fresh"; done
+for v in 0 5; do echo "== variant $v"; VFM_VARIANT=$v python $R/tools/time_small.py 2>&1 | grep "fresh"; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/small -o s -- python $R/tools/time_small.py > /dev/null 2>&1
 python - <<PY
 import csv
