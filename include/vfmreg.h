@@ -105,6 +105,20 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
                                   const void *b_prepared, int64_t m, int d, int64_t *idx_out,
                                   float *sim_out, void *ws, size_t ws_bytes, float gate,
                                   vfm_stream_t stream);
+/* The same two calls with the kind of record the int8 pass keeps per (query, 128-row chunk) -- the same value in both:
+ *   VFM_RECORDS_BEST  the best score only (the default above): the cheapest coarse kernel; every candidate chunk of a
+ *                     resolved query is rescanned in int8 (48 KB) to find its rows;
+ *   VFM_RECORDS_TOP2  best and second-best score plus the best row's index: ~15 % more coarse-kernel time, but a candidate
+ *                     chunk with one row inside the bounds is a single 1.5 KB row -- the choice for duplicate-rich maps,
+ *                     where a query has tens of candidate chunks (vfm_match_search_rescans_async reports the load). */
+#define VFM_RECORDS_BEST 0
+#define VFM_RECORDS_TOP2 1
+int vfm_match_search_coarse_gated_r(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
+                                    int d, void *ws, size_t ws_bytes, int records, vfm_stream_t stream);
+int vfm_match_search_finish_gated_r(const float *q, const void *q_prepared, int64_t n, const float *b,
+                                    const void *b_prepared, int64_t m, int d, int64_t *idx_out,
+                                    float *sim_out, void *ws, size_t ws_bytes, float gate, int records,
+                                    vfm_stream_t stream);
 /* Feedback for a caller that registers many scans: the number of candidate chunks the last gated search in `ws` had to
  * rescan (0 where the int8 pass did not run), copied to out_host (pinned memory) asynchronously on `stream`, after the
  * _finish_gated call on that stream.  Duplicate-rich maps put hundreds of rows inside the int8 bounds of every query;

@@ -21,6 +21,23 @@ def _i8_rows(P):
     return q8, step, err, gerr
 
 
+def _search_gated(q, b, gate, records):
+    """prepare -> coarse -> finish of the gated family with an explicit record kind (0 = best score, 1 = packed top-2)."""
+    lib = _lib.load()
+    n, d = q.shape
+    m = b.shape[0]
+    Q, B = ops.PreparedRows(q), ops.PreparedRows(b)
+    ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=torch.uint8, device="cuda")
+    idx = torch.empty(n, dtype=torch.int64, device="cuda")
+    sim = torch.empty(n, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.vfm_match_search_coarse_gated_r(Q.buf.data_ptr(), n, B.buf.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, st))
+    _lib.check(lib.vfm_match_search_finish_gated_r(q.data_ptr(), Q.buf.data_ptr(), n, b.data_ptr(), B.buf.data_ptr(), m, d, idx.data_ptr(),
+                                                   sim.data_ptr(), ws.data_ptr(), ws.numel(), gate, records, st))
+    torch.cuda.synchronize()
+    return idx, sim
+
+
 def _heavy_tailed(rng, rows, d):
     x = rng.standard_normal((rows, d)).astype(np.float32)
     x[rng.random((rows, d)) < 0.002] *= 12.0            # outlier elements
@@ -76,14 +93,16 @@ def test_int8_search_equals_the_oracle_on_stress_inputs(d, n, m):
     few = rng.standard_normal((16, d)).astype(np.float32)
     cases["duplicates"] = (few[rng.integers(0, 16, n)] + 0.0, few[rng.integers(0, 16, m)] + 0.0)  # m rows, 16 distinct
     for name, (q, b) in cases.items():
-        # the gated family with gate = -inf: the int8 pass, every query resolved
-        idx, sim = ops.match_ip_top1(torch.from_numpy(q).cuda(), torch.from_numpy(b).cuda(), ops.FAST, gate=float("-inf"))
-        torch.cuda.synchronize()
         qn, _ = orc.l2norm_rows(q)
         bn, _ = orc.l2norm_rows(b)
         ridx, rsim = orc.match_ip_top1(qn, bn)
-        np.testing.assert_array_equal(idx.cpu().numpy(), ridx, err_msg=name)
-        np.testing.assert_array_equal(sim.cpu().numpy(), rsim, err_msg=name)
+        qd, bd = torch.from_numpy(q).cuda(), torch.from_numpy(b).cuda()
+        # the gated family with gate = -inf: the int8 pass, every query resolved -- one-shot call, then both record kinds
+        results = [ops.match_ip_top1(qd, bd, ops.FAST, gate=float("-inf")), _search_gated(qd, bd, float("-inf"), 0),
+                   _search_gated(qd, bd, float("-inf"), 1)]
+        for kind, (idx, sim) in enumerate(results):
+            np.testing.assert_array_equal(idx.cpu().numpy(), ridx, err_msg=f"{name} / call {kind}")
+            np.testing.assert_array_equal(sim.cpu().numpy(), rsim, err_msg=f"{name} / call {kind}")
 
 
 def test_gate_leaves_only_provably_rejected_queries_unresolved():
@@ -120,33 +139,39 @@ def test_gate_leaves_only_provably_rejected_queries_unresolved():
     np.testing.assert_array_equal(f["sim"].cpu().numpy(), rsim)
 
 
-def test_pipeline_leaves_the_int8_pass_on_a_duplicate_rich_map_and_results_do_not_change():
+def test_pipeline_changes_records_on_a_duplicate_rich_map_and_results_do_not_change():
     """auto mode: the first gated search reports how many candidate chunks it had to rescan; on a map where every point has
-    hundreds of near-copies the pipeline switches to the fp16 pass.  Poses and correspondences are those of both fixed modes."""
+    about twenty near-copies the pipeline moves to the packed top-2 records (a chunk with one row inside the bounds then costs
+    one fp32 row instead of a 48 KB rescan).  Poses and correspondences are those of every fixed mode."""
     n, m, d = 2000, 40000, 384
     g = torch.Generator(device="cuda")
     g.manual_seed(3)
     p = synth.make_pair_device(n, m, d, seed=9)
-    phys = torch.randn((100, d), generator=g, device="cuda")
-    owner = torch.randint(0, 100, (m,), generator=g, device="cuda")
+    phys = torch.randn((2000, d), generator=g, device="cuda")      # every physical point ~20 times in the map
+    owner = torch.randint(0, 2000, (m,), generator=g, device="cuda")
     b = phys[owner] + 0.01 * torch.randn((m, d), generator=g, device="cuda") / d ** 0.5
     q = b[p["match"].clamp(min=0)] + 0.02 * torch.randn((n, d), generator=g, device="cuda") / d ** 0.5
     q = torch.where((p["match"] < 0)[:, None], torch.randn((n, d), generator=g, device="cuda"), q)
     b, q = b.contiguous(), q.contiguous()
     outs = {}
-    for coarse in ("auto", "int8", "fp16"):
+    for coarse in ("auto", "int8", "int8-top2", "fp16"):
         pipe = RegistrationPipeline(n, m, d, n_iter=5000, overlap_ransac=True, coarse=coarse)
-        for _ in range(4):
+        first_rescans = None
+        for _ in range(5):
             out = pipe.register(q, p["q_xyz"], b, p["b_xyz"])
             pipe.synchronize()
             torch.cuda.synchronize()
+            pipe._poll_feedback()
+            if first_rescans is None:
+                first_rescans = pipe.last_rescans
         k = int(out["count"].item())
-        outs[coarse] = (out["T"].clone(), out["corres"][:k].clone(), pipe.use_i8, pipe.last_rescans)
+        outs[coarse] = (out["T"].clone(), out["corres"][:k].clone(), pipe.use_i8, pipe.top2, first_rescans)
         del pipe
-    assert outs["auto"][2] is False and outs["auto"][3] > RegistrationPipeline.RESCAN_LIMIT * n
-    assert outs["int8"][2] is True and outs["fp16"][2] is False
-    for coarse in ("int8", "fp16"):
-        assert torch.equal(outs["auto"][0], outs[coarse][0]) and torch.equal(outs["auto"][1], outs[coarse][1])
+    assert outs["auto"][2] is True and outs["auto"][3] is True            # int8 pass, top-2 records
+    assert outs["auto"][4] > RegistrationPipeline.RESCAN_LIMIT * n         # what the first (best-score) search reported
+    assert outs["int8"][2:4] == (True, False) and outs["int8-top2"][2:4] == (True, True) and outs["fp16"][2] is False
+    for coarse in ("int8", "int8-top2", "fp16"):
+        assert torch.equal(outs["auto"][0], outs[coarse][0]) and torch.equal(outs["auto"][1], outs[coarse][1]), coarse
     assert outs["auto"][1].shape[0] > 500
 
 

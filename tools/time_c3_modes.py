@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Config C3's registration (lifted ViT descriptors: duplicate-rich) with the coarse pass chosen by feedback / pinned to
+int8 / fp16: milliseconds per registration (serial), rescanned chunks per query."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "vfm-registration_amd"))
+from vfmreg import ops  # noqa: E402
+from vfmreg import vit as V  # noqa: E402
+from vfmreg.pipeline import RegistrationPipeline  # noqa: E402
+
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(0)
+B, H, W, n, m = 6, 1200, 1600, 20000, 200000
+imgs = torch.from_numpy(rng.integers(1, 255, (B, H, W, 3), dtype=np.uint8)).to(dev)
+model = V.ViTS14(V.random_weights(0), H, W, device=dev)
+grids = model.forward(imgs)
+xyz = np.c_[rng.uniform(-40, 40, n), rng.uniform(-40, 40, n), rng.uniform(-2, 6, n)]
+pcl = torch.from_numpy(np.ascontiguousarray(np.insert(xyz, 3, 1, axis=1).T)).to(dev)
+K = np.array([[800.0, 0, 800], [0, 800, 600], [0, 0, 1]])
+Ps = []
+for i in range(6):
+    y = np.deg2rad(60 * i)
+    R = np.stack([[np.sin(y), -np.cos(y), 0], [0, 0, -1], [np.cos(y), np.sin(y), 0]])
+    Ps.append(K @ np.c_[R, np.zeros(3)])
+desc = torch.zeros((n, 384), dtype=torch.float32, device=dev)
+filled = torch.zeros(n, dtype=torch.uint8, device=dev)
+ops.lift_multicam(pcl, [dict(mode=ops.PROJ_KITTI, mats=[Ps[c]], fc=None, subsample=1.0, win=None, H=H, W=W, proj_image=None,
+                             grid=grids[c], Hup=H, Wup=W, rot_mode=0, raw_image=imgs[c]) for c in range(6)], desc, filled)
+g = torch.Generator(device=dev).manual_seed(3)
+b_desc = torch.randn(m, 384, device=dev, generator=g)
+pick = torch.randperm(m, device=dev, generator=g)[:n]
+b_desc[pick] = desc + 0.02 * desc.abs().mean() * torch.randn(n, 384, device=dev, generator=g)
+b_xyz = torch.rand(m, 3, device=dev, generator=g, dtype=torch.float64) * 100.0
+q_xyz = torch.from_numpy(np.ascontiguousarray(xyz)).to(dev)
+b_xyz[pick] = q_xyz + 0.02 * torch.randn(n, 3, device=dev, generator=g, dtype=torch.float64)
+ref = None
+for coarse in ("auto", "int8", "int8-top2", "fp16"):
+    pipe = RegistrationPipeline(n, m, 384, n_iter=50000, device=dev, coarse=coarse)
+    ts = []
+    for r in range(8):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = pipe.register(desc, q_xyz, b_desc, b_xyz)
+        b.record()
+        b.synchronize()
+        if r >= 3:
+            ts.append(a.elapsed_time(b))
+    k = int(out["count"].item())
+    same = True
+    if ref is None:
+        ref = (out["T"].clone(), out["corres"][:k].clone())
+    else:
+        same = bool(torch.equal(ref[0], out["T"]) and torch.equal(ref[1], out["corres"][:k]))
+    print(f"{coarse}: {sorted(ts)[len(ts) // 2]:.2f} ms per registration, pass in use {'int8' if pipe.use_i8 else 'fp16'}, "
+          f"rescanned chunks per query {'-' if pipe.last_rescans is None else round(pipe.last_rescans / n, 1)}, {k} correspondences, "
+          f"same result {same}", flush=True)

@@ -449,6 +449,7 @@ struct I8Bounds {
     const float* qstep;  // [npad / 128] step of the query's group
     const float* bstep;  // [nchunks] step of the map chunk
     const float* berr;   // [nchunks] maximum E of the map chunk
+    int top2;            // records: 0 = best score per (query, chunk), 1 = packed top-2 with the best row's index
 };
 // float <-> unsigned key with the same order (0 = below every float: the memset value of "nothing published")
 __device__ __forceinline__ unsigned float_key(float f) {
@@ -537,8 +538,8 @@ __device__ __forceinline__ unsigned score_bits(int v) { return (unsigned)v; }
 
 // End of a 128-row chunk: merge the two half-waves and emit the chunk's top-2 for the 32 queries of tile
 // qt (chunk < 0: the dummy fold of the very first step, nothing is stored); resets the running pair.
-__device__ __forceinline__ void coarse_emit_chunk(const CoarseArgs& a, unsigned& s1, unsigned& s2, unsigned& runmax,
-                                                  int qt, int chunk) {
+__device__ __forceinline__ unsigned coarse_emit_chunk(const CoarseArgs& a, unsigned& s1, unsigned& s2, unsigned& runmax,
+                                                      int qt, int chunk) {
     const int lane = lane_id(), hi = lane >> 5;
     const unsigned o1 = __shfl_xor(s1, 32), o2 = __shfl_xor(s2, 32);
     const bool own = (s1 > o1) || (s1 == o1 && hi == 0);
@@ -553,6 +554,7 @@ __device__ __forceinline__ void coarse_emit_chunk(const CoarseArgs& a, unsigned&
     }
     s1 = 0u;
     s2 = 0u;
+    return w1 & ~127u;  // the chunk's best score, low 7 bits dropped (all lanes)
 }
 
 // int8 pass: the chunk's BEST VALUE only -- one VALU op per accumulator element instead of three (with the packed top-2 the
@@ -976,7 +978,9 @@ __global__ __launch_bounds__(512, 2) void match_coarse_pipe_kernel(CoarseArgs a)
 // so d = 384 / 256 take T = 4 here (one whole 128-row chunk per step, 48 / 32 MFMAs).  Ring = 3 steps of T tiles
 // (in use | landed | in flight), fragment look-ahead PF = 2 k-steps for T = 4 (4 tiles x 2 x 4 registers), 4 for T = 2.
 // ---------------------------------------------------------------------------------------------
-template <int KSTEPS, int T>
+// TOP2: the packed per-chunk top-2 records of the fp16 pass (best row index included, 3 VALU ops per element) instead of the
+// best value alone: candidate chunks with one row inside the bounds need no rescan -- the choice for duplicate-rich maps.
+template <int KSTEPS, int T, bool TOP2 = false>
 __global__ __launch_bounds__(512, 2) void match_coarse_i8_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVES = 8;
@@ -1028,9 +1032,9 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8_kernel(CoarseArgs a) {
         i8_A = eq * 1.0001220703125f + 1.0e-6f;
         i8_mult = 1.0001220703125f + eq;
     }
-    unsigned s1 = 0u;
+    unsigned s1 = 0u, s2 = 0u, unused_max = 0u;
     auto emit_chunk = [&](int chunk) __attribute__((always_inline)) {  // chunk < 0: nothing folded yet
-        const unsigned best = coarse_emit_chunk_best(a, s1, qt, chunk);
+        const unsigned best = TOP2 ? coarse_emit_chunk(a, s1, s2, unused_max, qt, chunk) : coarse_emit_chunk_best(a, s1, qt, chunk);
         if (chunk >= 0 && chunk < a.first_pad_chunk) {  // wave-uniform
             const float sb = a.ib.bstep[chunk], be = a.ib.berr[chunk];
             i8_low = fmaxf(i8_low, __builtin_fmaf(i8_sq * sb, (float)((int)best - I8_OFFSET), -(i8_A + i8_mult * be)));
@@ -1082,7 +1086,10 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8_kernel(CoarseArgs a) {
             }
             // deferred fold of the previous step's tiles, spread over the slots
 #pragma unroll
-            for (int e = s * 16 * T / KSTEPS; e < (s + 1) * 16 * T / KSTEPS; ++e) s1 = max(s1, (unsigned)prev[e >> 4][e & 15]);
+            for (int e = s * 16 * T / KSTEPS; e < (s + 1) * 16 * T / KSTEPS; ++e) {
+                if constexpr (TOP2) coarse_fold(s1, s2, prev[e >> 4][e & 15], (((it - T) & 3) + (e >> 4)) * 16 + (e & 15));
+                else s1 = max(s1, (unsigned)prev[e >> 4][e & 15]);
+            }
             if (s >= 1 && s <= PIECES) {  // one 1 KiB piece per slot instead of a burst
                 __builtin_amdgcn_sched_barrier(0);
                 if (it + 2 * T < ntiles) {
@@ -1101,7 +1108,10 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8_kernel(CoarseArgs a) {
         ring = ring1;
     }
 #pragma unroll
-    for (int e = 0; e < 16 * T; ++e) s1 = max(s1, (unsigned)prev[e >> 4][e & 15]);
+    for (int e = 0; e < 16 * T; ++e) {
+        if constexpr (TOP2) coarse_fold(s1, s2, prev[e >> 4][e & 15], ((4 - T) + (e >> 4)) * 16 + (e & 15));
+        else s1 = max(s1, (unsigned)prev[e >> 4][e & 15]);
+    }
     emit_chunk(c0 + (ntiles >> 2) - 1);
     if (lane < 32 && qt < a.nq_tiles) atomicMax(a.qmax + (size_t)qt * 32 + lane, float_key(i8_low));
 }
@@ -1114,7 +1124,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8_kernel(CoarseArgs a) {
 // query set, sharing the fragment); the accumulators of a finished tile are folded in the slots of the next one, and two
 // accumulator pairs alternate, so nothing is copied.  One barrier per 8 * KSTEPS MFMAs.
 // ---------------------------------------------------------------------------------------------
-template <int KSTEPS>
+template <int KSTEPS, bool TOP2 = false>
 __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVES = 8, T = 4;
@@ -1164,7 +1174,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a)
     if (ntiles > T) stage_step(gsrc + (size_t)T * TILE_U4, (unsigned)(T * TILE_BYTES));
     const uint4* gnext = gsrc + (size_t)2 * T * TILE_U4;
 
-    unsigned s1[2] = {0u, 0u};
+    unsigned s1[2] = {0u, 0u}, s2[2] = {0u, 0u}, unused_max = 0u;
     auto emit_chunk = [&](int chunk) __attribute__((always_inline)) {  // chunk < 0: nothing folded yet
         float sb = 0.f, be = 0.f;
         const bool counted = chunk >= 0 && chunk < a.first_pad_chunk;  // wave-uniform
@@ -1174,7 +1184,8 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a)
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const unsigned best = coarse_emit_chunk_best(a, s1[j], qt0 + j, chunk);
+            const unsigned best = TOP2 ? coarse_emit_chunk(a, s1[j], s2[j], unused_max, qt0 + j, chunk)
+                                       : coarse_emit_chunk_best(a, s1[j], qt0 + j, chunk);
             if (counted)
                 i8_low[j] = fmaxf(i8_low[j], __builtin_fmaf(i8_sq[j] * sb, (float)((int)best - I8_OFFSET), -(i8_A[j] + i8_mult[j] * be)));
         }
@@ -1222,7 +1233,10 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a)
                 acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<intx4*>(&fr[s % PF]), qf[1][s], acc[1], 0, 0, 0);
                 fr[s % PF] = (s + PF < KSTEPS) ? tb[(s + PF) * 64] : tn[(s + PF - KSTEPS) * 64];
 #pragma unroll
-                for (int e = s * 32 / KSTEPS; e < (s + 1) * 32 / KSTEPS; ++e) s1[e >> 4] = max(s1[e >> 4], (unsigned)done[e >> 4][e & 15]);
+                for (int e = s * 32 / KSTEPS; e < (s + 1) * 32 / KSTEPS; ++e) {  // `done` is tile (J + 3) & 3 of its chunk
+                    if constexpr (TOP2) coarse_fold(s1[e >> 4], s2[e >> 4], done[e >> 4][e & 15], ((J + 3) & 3) * 16 + (e & 15));
+                    else s1[e >> 4] = max(s1[e >> 4], (unsigned)done[e >> 4][e & 15]);
+                }
                 if (s >= 1 && s <= 2 && J * 2 + s - 1 < PIECES) {  // two 1 KiB pieces per tile
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) {
@@ -1243,7 +1257,10 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a)
         ring = ring1;
     }
 #pragma unroll
-    for (int e = 0; e < 32; ++e) s1[e >> 4] = max(s1[e >> 4], (unsigned)accB[e >> 4][e & 15]);
+    for (int e = 0; e < 32; ++e) {
+        if constexpr (TOP2) coarse_fold(s1[e >> 4], s2[e >> 4], accB[e >> 4][e & 15], 3 * 16 + (e & 15));
+        else s1[e >> 4] = max(s1[e >> 4], (unsigned)accB[e >> 4][e & 15]);
+    }
     emit_chunk(c0 + (ntiles >> 2) - 1);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1438,11 +1455,13 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
                                                            int* __restrict__ fb_list, int stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char select_smem[];  // int8 records: the chunks' (step, max E)
     __shared__ int lcnt[64];
+    __shared__ int lresc[64];     // int8 top-2 records: whole-chunk entries among them
     __shared__ unsigned lub[64];  // int8 records: float_key of the largest upper bound over the query's chunks
     const int qq = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * 64 + qq;
     if (g == 0) {
         lcnt[qq] = 0;
+        lresc[qq] = 0;
         lub[qq] = 0u;
     }
     float2* lchunk = reinterpret_cast<float2*>(select_smem);
@@ -1462,6 +1481,34 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
         const float A = eq * 1.0001220703125f, mult = 1.0001220703125f + eq, slack = 1.0e-6f;
         const float qlow = key_float(qmax[q]);  // -Inf: no un-padded chunk exists -> every chunk is a candidate
         float maxup = -__builtin_inff();
+        if (ib.top2) {
+            // packed top-2 records (uint2 [chunk][npad], as the fp16 pass writes them): the best row's index rides in the low
+            // 7 bits, so a candidate chunk whose SECOND-best score cannot reach qlow is a single-row entry and needs no rescan
+            for (int cb = g; cb < nchunks; cb += 8 * SELECT_GROUPS) {
+                uint2 rec[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = cb + SELECT_GROUPS * u;
+                    rec[u] = (c < nchunks) ? partials[(size_t)c * npad + q] : make_uint2(0u, 0u);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = cb + SELECT_GROUPS * u;
+                    if (c >= nchunks) continue;
+                    const float2 cb2 = chunk_lds ? lchunk[c] : make_float2(ib.bstep[c], ib.berr[c]);
+                    const float sc = sq * cb2.x, bound = A + mult * cb2.y + slack;
+                    const float up1 = sc * (float)((int)(rec[u].x | 127u) - I8_OFFSET) + bound;
+                    maxup = fmaxf(maxup, up1);
+                    if (up1 >= qlow) {
+                        const int slot = atomicAdd(&lcnt[qq], 1);
+                        const float up2 = sc * (float)((int)(rec[u].y | 63u) - I8_OFFSET) + bound;
+                        const unsigned rescan = (up2 >= qlow || c >= first_pad_chunk) ? 1u : 0u;
+                        if (rescan) atomicAdd(&lresc[qq], 1);
+                        if (slot < cap && q < n) cand[(size_t)q * cap + slot] = ((unsigned)c << 8) | (rescan << 7) | (rec[u].x & 127u);
+                    }
+                }
+            }
+        } else {
         // [query tile][chunk][32]: best integer score (+ 2^30) of the chunk for the tile's 32 queries
         const unsigned* best = reinterpret_cast<const unsigned*>(partials) + (size_t)(q >> 5) * nchunks * 32 + (q & 31);
         for (int cb = g; cb < nchunks; cb += 8 * SELECT_GROUPS) {
@@ -1486,6 +1533,7 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
                     if (slot < cap && q < n) cand[(size_t)q * cap + slot] = ((unsigned)c << 8) | 128u;
                 }
             }
+        }
         }
         atomicMax(&lub[qq], float_key(maxup));
     } else {
@@ -1523,7 +1571,9 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
         // choosing between this pass and the fp16 one on duplicate-rich maps: vfm_match_search_rescans_async); one atomic
         // per workgroup
         int mine = 0;
-        if (q < n && invq[q] != 0.0f && !(key_float(lub[qq]) < gate) && lcnt[qq] <= cap) mine = lcnt[qq];
+        // (top-2 records: whole-chunk entries count 1, single-row entries 1/32 -- 48 KB of int8 tiles against 1.5 KB of fp32 row)
+        if (q < n && invq[q] != 0.0f && !(key_float(lub[qq]) < gate) && lcnt[qq] <= cap)
+            mine = ib.top2 ? lresc[qq] + ((lcnt[qq] - lresc[qq]) >> 5) : lcnt[qq];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
         if (qq == 0 && mine > 0) atomicAdd(fb_count + 5, mine);
@@ -1720,7 +1770,13 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
         const unsigned batch = (e0 + lane < cnt) ? mycand[e0 + lane] : 0u;
         const int nb = cnt - e0 < 64 ? cnt - e0 : 64;
         for (int j = 0; j < nb; ++j) {
-            const int c = (int)(__shfl(batch, j) >> 8);  // wave-uniform
+            const unsigned entry = __shfl(batch, j);  // wave-uniform
+            const int c = (int)(entry >> 8);
+            if (!(entry & 128u)) {  // a single-row entry (top-2 records: the chunk's second-best cannot reach the bound)
+                if (lane == 0 && nhit < ocap) out[nhit] = entry;
+                ++nhit;
+                continue;
+            }
             const long long base = (long long)c * CHUNK_ROWS;
             const float sc = sq * ib.bstep[c], bound = A + mult * ib.berr[c];
             // rows `lane` and `lane + 64` of the chunk (tile rr >> 5, position rr & 31); the loads of both go out together:
@@ -2585,8 +2641,8 @@ inline bool use_i8(int d, int64_t n, int64_t m, bool gated) {
     return gated && i8_capable(d) && m < (1ll << 24) && n > g_i8_min_queries &&
            (g_coarse_qsets == 0 || g_coarse_qsets == 10 || g_coarse_qsets == 12);
 }
-inline I8Bounds i8_bounds(const Prepared& Q, const Prepared& B, bool on) {
-    return on ? I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr} : I8Bounds{nullptr, nullptr, nullptr, nullptr};
+inline I8Bounds i8_bounds(const Prepared& Q, const Prepared& B, bool on, int top2 = 0) {
+    return on ? I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr, top2} : I8Bounds{nullptr, nullptr, nullptr, nullptr, 0};
 }
 
 // queries per workgroup of the coarse kernel that do_search_coarse will launch
@@ -2617,29 +2673,29 @@ int launch_coarse_pipe(const CoarseArgs& a, hipStream_t st) {
     return VFM_OK;
 }
 
-template <int KSTEPS, int T>
+template <int KSTEPS, int T, bool TOP2 = false>
 int launch_coarse_i8(const CoarseArgs& a, hipStream_t st) {
     const int lds = 3 * T * KSTEPS * 1024;
     static unsigned long long attr_set = 0ull;  // one bit per device
     if (!attr_done(attr_set)) {
-        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_i8_kernel<KSTEPS, T>),
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_i8_kernel<KSTEPS, T, TOP2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_mark(attr_set);
     }
-    hipLaunchKernelGGL((match_coarse_i8_kernel<KSTEPS, T>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((match_coarse_i8_kernel<KSTEPS, T, TOP2>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
     return VFM_OK;
 }
 
-template <int KSTEPS>
+template <int KSTEPS, bool TOP2>
 int launch_coarse_i8q2(const CoarseArgs& a, hipStream_t st) {
     const int lds = 12 * KSTEPS * 1024;
     static unsigned long long attr_set = 0ull;  // one bit per device
     if (!attr_done(attr_set)) {
-        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_i8q2_kernel<KSTEPS>),
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_i8q2_kernel<KSTEPS, TOP2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_mark(attr_set);
     }
-    hipLaunchKernelGGL((match_coarse_i8q2_kernel<KSTEPS>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((match_coarse_i8q2_kernel<KSTEPS, TOP2>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
     return VFM_OK;
 }
 
@@ -2762,13 +2818,14 @@ CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, 
     a.rec = nullptr;
     a.rcap = 0;
     a.window = g_window_override != 0.0f ? g_window_override : DEFAULT_WINDOW;
-    a.ib = I8Bounds{nullptr, nullptr, nullptr, nullptr};
+    a.ib = I8Bounds{nullptr, nullptr, nullptr, nullptr, 0};
     return a;
 }
 
 // stage 1 of a search: the MFMA coarse pass (fills ws: partials + per-query coarse maxima)
+// records (int8 pass): 0 = best score per (query, chunk), 1 = packed top-2 with the best row's index (VFM_RECORDS_*)
 int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, hipStream_t st,
-                     bool bias_from_map_inv = false, bool inner_product = false, bool gated = false) {
+                     bool bias_from_map_inv = false, bool inner_product = false, bool gated = false, int records = 0) {
     Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
     Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
     SearchWs w = carve_search(ws, n, m);
@@ -2792,25 +2849,27 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
     if (inner_product && use_i8(d, n, m, gated)) {
         a.Qh = Q.tiles8;
         a.Bh = B.tiles8;
-        a.ib = I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr};
+        a.ib = I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr, records};
         if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
         a.nqb = (int)(rows_padded(n) / QBLOCK);  // 8 waves x 32 queries at every width
         a.nslices = choose_slices(a.nqb, a.nchunks);
         int rc8;
+        const bool top2 = records != 0;
         if (d <= 384 && n > 2048 && g_coarse_qsets == 0) {
             // 64 resident queries per wave: 11-15 % faster than the one-set kernel from ~3000 queries on (C2: 1.09 vs 1.23 ms;
             // 1500 x 100 000: 0.059 vs 0.056 ms -- half as many, twice as large workgroups); variants 10 / 12 = one set, A/B
             a.nqb = (a.nq_tiles + 15) / 16;
             a.nslices = choose_slices(a.nqb, a.nchunks);
-            rc8 = d == 384 ? launch_coarse_i8q2<12>(a, st) : launch_coarse_i8q2<8>(a, st);
+            rc8 = d == 384 ? (top2 ? launch_coarse_i8q2<12, true>(a, st) : launch_coarse_i8q2<12, false>(a, st))
+                           : (top2 ? launch_coarse_i8q2<8, true>(a, st) : launch_coarse_i8q2<8, false>(a, st));
         } else {
             const bool t2 = g_coarse_qsets == 10;  // variant 10 (A/B): 2 tiles per step at every width
             switch (d / 32) {
-                case 8: rc8 = t2 ? launch_coarse_i8<8, 2>(a, st) : launch_coarse_i8<8, 4>(a, st); break;
-                case 12: rc8 = t2 ? launch_coarse_i8<12, 2>(a, st) : launch_coarse_i8<12, 4>(a, st); break;
-                case 16: rc8 = launch_coarse_i8<16, 2>(a, st); break;
-                case 20: rc8 = launch_coarse_i8<20, 2>(a, st); break;
-                default: rc8 = launch_coarse_i8<24, 2>(a, st); break;
+                case 8: rc8 = top2 ? launch_coarse_i8<8, 4, true>(a, st) : t2 ? launch_coarse_i8<8, 2>(a, st) : launch_coarse_i8<8, 4>(a, st); break;
+                case 12: rc8 = top2 ? launch_coarse_i8<12, 4, true>(a, st) : t2 ? launch_coarse_i8<12, 2>(a, st) : launch_coarse_i8<12, 4>(a, st); break;
+                case 16: rc8 = top2 ? launch_coarse_i8<16, 2, true>(a, st) : launch_coarse_i8<16, 2>(a, st); break;
+                case 20: rc8 = top2 ? launch_coarse_i8<20, 2, true>(a, st) : launch_coarse_i8<20, 2>(a, st); break;
+                default: rc8 = top2 ? launch_coarse_i8<24, 2, true>(a, st) : launch_coarse_i8<24, 2>(a, st); break;
             }
         }
         if (rc8) return rc8;
@@ -2837,7 +2896,7 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
 // provably below it are reported as (-1, -2.0) instead of being resolved (int8 pass only; -Inf = resolve every query)
 int do_search_finish(const float* q, const void* qprep, int64_t n, const float* b, const void* bprep, int64_t m, int d,
                      int64_t* idx_out, float* sim_out, void* ws, hipStream_t st, bool gated = false,
-                     float gate = -__builtin_inff()) {
+                     float gate = -__builtin_inff(), int records = 0) {
     Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
     Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
     SearchWs w = carve_search(ws, n, m);
@@ -2852,11 +2911,11 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
         const int chunk_lds = i8 && (size_t)a.nchunks * sizeof(float2) <= 63 * 1024;  // (step, max E) of every chunk in LDS
         hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS),
                            chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, w.partials, a.nchunks, a.npad, n, a.first_pad_chunk, w.qmax,
-                           Q.inv, DEFAULT_WINDOW, i8_bounds(Q, B, i8), gate, chunk_lds, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list,
+                           Q.inv, DEFAULT_WINDOW, i8_bounds(Q, B, i8, records), gate, chunk_lds, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list,
                            g_match_stats);
         VFM_CHECK_LAUNCH("match_select_kernel");
         if (i8) {  // candidate chunks -> candidate rows (the record buffer of the fp16 pass is free: it holds the hit lists)
-            hipLaunchKernelGGL(match_rescan_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, m, d, i8_bounds(Q, B, true),
+            hipLaunchKernelGGL(match_rescan_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, m, d, i8_bounds(Q, B, true, records),
                                (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt, w.cand, w.cap,
                                reinterpret_cast<unsigned*>(w.rec), 2 * w.rcap, w.fb_count, w.fb_list,
                                reinterpret_cast<int*>(w.rec_cnt));
@@ -2971,18 +3030,32 @@ VFM_EXPORT int vfm_match_search_finish(const float* q, const void* q_prepared, i
 
 VFM_EXPORT int vfm_match_search_coarse_gated(const void* q_prepared, int64_t n, const void* b_prepared, int64_t m, int d,
                                              void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    return vfm_match_search_coarse_gated_r(q_prepared, n, b_prepared, m, d, ws, ws_bytes, VFM_RECORDS_BEST, stream);
+}
+
+VFM_EXPORT int vfm_match_search_coarse_gated_r(const void* q_prepared, int64_t n, const void* b_prepared, int64_t m, int d,
+                                               void* ws, size_t ws_bytes, int records, vfm_stream_t stream) {
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q_prepared && b_prepared && ws, "search_coarse: null pointer");
-    return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream, false, true, true);
+    VFM_CHECK_ARG(records == VFM_RECORDS_BEST || records == VFM_RECORDS_TOP2, "search_coarse: unknown record kind %d", records);
+    return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream, false, true, true, records);
 }
 
 VFM_EXPORT int vfm_match_search_finish_gated(const float* q, const void* q_prepared, int64_t n, const float* b,
                                              const void* b_prepared, int64_t m, int d, int64_t* idx_out, float* sim_out,
                                              void* ws, size_t ws_bytes, float gate, vfm_stream_t stream) {
+    return vfm_match_search_finish_gated_r(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, ws_bytes, gate,
+                                           VFM_RECORDS_BEST, stream);
+}
+
+VFM_EXPORT int vfm_match_search_finish_gated_r(const float* q, const void* q_prepared, int64_t n, const float* b,
+                                               const void* b_prepared, int64_t m, int d, int64_t* idx_out, float* sim_out,
+                                               void* ws, size_t ws_bytes, float gate, int records, vfm_stream_t stream) {
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q && b && q_prepared && b_prepared && ws && idx_out && sim_out, "search_finish: null pointer");
     VFM_CHECK_ARG(gate == gate, "search_finish: gate is NaN");
-    return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream, true, gate);
+    VFM_CHECK_ARG(records == VFM_RECORDS_BEST || records == VFM_RECORDS_TOP2, "search_finish: unknown record kind %d", records);
+    return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream, true, gate, records);
 }
 
 VFM_EXPORT int vfm_match_search_rescans_async(const void* ws, int64_t n, int64_t m, int32_t* out_host, vfm_stream_t stream) {

@@ -21,10 +21,11 @@ pair.  With the fp16 pass it cost the coarse kernel more than it hid (round 2, f
 with the int8 pass, whose kernel is half as long, prepare stream + two solve streams is the best arrangement measured
 (604-665 registrations/s against 558-574 for one solve stream with prepare on the caller's stream) and is what bench.py runs.
 
-``coarse``: which coarse pass -- "int8" = the gated family of include/vfmreg.h (queries that provably miss ``min_cosine``
-stay unresolved: idx -1, sim -2.0; correspondences and pose are unaffected), "fp16" = the ungated family, "auto" (default)
-= int8 until a search reports more than ``RESCAN_LIMIT`` rescanned chunks per query (duplicate-rich maps), then fp16 with a
-re-probe every ``REPROBE`` registrations.  ``gate=False`` keeps the int8 pass but resolves every query.
+``coarse``: which coarse pass -- "int8" / "int8-top2" = the gated family of include/vfmreg.h with best-score / packed top-2
+records (queries that provably miss ``min_cosine`` stay unresolved: idx -1, sim -2.0; correspondences and pose are
+unaffected), "fp16" = the ungated family, "auto" (default) = best-score records until a search reports more than
+``RESCAN_LIMIT`` rescanned chunks per query (duplicate-rich maps), then top-2 records, then -- above ``TOP2_LIMIT`` -- the fp16
+pass, with a probe one step back every ``REPROBE`` registrations.  ``gate=False`` keeps the int8 pass but resolves every query.
 """
 from __future__ import annotations
 
@@ -69,15 +70,17 @@ class RegistrationPipeline:
         self.overlap = bool(overlap_ransac)
         self.overlap_prepare = bool(overlap_prepare)
         self.gate = bool(gate)
-        # which coarse pass: "int8" = the gated family of include/vfmreg.h (int8 MFMA pass where it exists), "fp16" = the
-        # ungated family, "auto" = int8 until a registration reports more than RESCAN_LIMIT candidate chunks per query
-        # (duplicate-rich maps: hundreds of rows inside the int8 bounds), then fp16 for REPROBE registrations
-        if coarse not in ("auto", "int8", "fp16"):
-            raise ValueError("coarse must be 'auto', 'int8' or 'fp16'")
+        # which coarse pass: "int8" = the gated family of include/vfmreg.h with best-score records (the cheapest kernel; every
+        # candidate chunk of a resolved query is rescanned), "int8-top2" = the same with packed top-2 records (+ ~0.15 ms of
+        # kernel at C2; a chunk with one row inside the bounds costs one fp32 row instead of a 48 KB rescan), "fp16" = the
+        # ungated family, "auto" = chosen from the searches' own feedback (_poll_feedback)
+        if coarse not in ("auto", "int8", "int8-top2", "fp16"):
+            raise ValueError("coarse must be 'auto', 'int8', 'int8-top2' or 'fp16'")
         self.coarse = coarse
         self.use_i8 = coarse != "fp16"
+        self.top2 = coarse == "int8-top2"   # int8 pass with packed top-2 records (VFM_RECORDS_TOP2)
         self.last_rescans: Optional[int] = None
-        self._fp16_left = 0
+        self._since_switch = 0
         self._pending = []  # (event, pinned int32[1]) of gated searches whose rescan count is on its way to the host
         self._slots = []    # pinned slots ready for reuse
         # solve_streams = K: the solve stages of K consecutive pairs may run beside each other (and beside the coarse pass
@@ -109,21 +112,28 @@ class RegistrationPipeline:
                        "prepare(map)")
             r.map_key = b_desc.data_ptr()
 
-    # rescanned candidate chunks per query (over all queries of the scan) beyond which the fp16 pass is the faster one:
-    # measured at C2 on duplicate-rich maps (tools/time_neardup.py) -- 7.7 per query: int8 2.40 ms vs fp16 2.73; 12.4: 3.31 vs
-    # 3.06; 99: 14.5 vs 4.5
-    RESCAN_LIMIT = 10
-    REPROBE = 256       # registrations in fp16 mode before the int8 pass is tried again
+    # Feedback thresholds, in rescanned chunks per query over all queries of the scan (tools/time_neardup.py, C2 size):
+    # best-score records -> top-2 records above RESCAN_LIMIT (0.5 per query: 1.50 vs 1.67 ms; 1.2: 1.57 vs 1.65; 6.2: 2.18 vs
+    # 1.84; 12.4: 3.38 vs 2.05; 99: 14.2 vs 3.6); top-2 records -> fp16 pass above TOP2_LIMIT (whole-chunk rescans + 1/32 per
+    # single row; never reached on the maps measured: the fp16 pass takes 4.4 ms where top-2 records take 3.6)
+    RESCAN_LIMIT = 2.5
+    TOP2_LIMIT = 40
+    REPROBE = 256       # registrations before one step back towards the cheaper kernel is probed
 
     def _poll_feedback(self) -> None:
         """Non-blocking: consume the rescan counts that have arrived and pick the coarse pass of the next registrations."""
         while self._pending and self._pending[0][0].query():
-            _, slot = self._pending.pop(0)
+            _, slot, records = self._pending.pop(0)
             self.last_rescans = int(slot.item())
             self._slots.append(slot)
-            if self.coarse == "auto" and self.use_i8 and self.last_rescans > self.RESCAN_LIMIT * self.n:
+            if self.coarse != "auto" or not self.use_i8 or records != (1 if self.top2 else 0):
+                continue  # feedback of a mode that has been left already
+            if not self.top2 and self.last_rescans > self.RESCAN_LIMIT * self.n:
+                self.top2 = True
+                self._since_switch = 0
+            elif self.top2 and self.last_rescans > self.TOP2_LIMIT * self.n:
                 self.use_i8 = False
-                self._fp16_left = self.REPROBE
+                self._since_switch = 0
 
     def synchronize(self) -> None:
         """Make the caller's current stream wait for every RANSAC issued on the side stream."""
@@ -143,11 +153,14 @@ class RegistrationPipeline:
         if q_desc.shape != (self.n, self.d) or b_desc.shape != (self.m, self.d):
             raise ValueError("Invalid shape")
         self._poll_feedback()
-        i8 = self.use_i8
-        if not i8 and self.coarse == "auto":
-            self._fp16_left -= 1
-            if self._fp16_left <= 0:
-                self.use_i8 = True  # probe the int8 pass again with the next registration
+        i8, records = self.use_i8, (1 if self.top2 else 0)
+        if self.coarse == "auto":
+            self._since_switch += 1
+            if self._since_switch >= self.REPROBE and (not self.use_i8 or self.top2):
+                # every REPROBE registrations one step back towards the cheaper kernel (fp16 -> top-2 records -> best-score
+                # records); the feedback of that probe decides whether it stays
+                self.use_i8, self.top2 = True, not self.use_i8
+                self._since_switch = 0
         r = self.sets[self._step % len(self.sets)]
         solve = self.solve_streams[self._step % self.n_solve] if self.overlap else None
         rws = self.rws_list[self._step % self.n_solve] if self.overlap else self.rws
@@ -177,9 +190,12 @@ class RegistrationPipeline:
             _lib.check(lib.vfm_match_prepare(q_desc.data_ptr(), self.n, self.d, r.qprep.data_ptr(), pst), "prepare(scan)")
         if self.overlap and pst != st:
             main.wait_stream(self.prep_stream)
-        coarse = lib.vfm_match_search_coarse_gated if i8 else lib.vfm_match_search_coarse
-        _lib.check(coarse(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d, r.sws.data_ptr(), r.sws.numel(), st),
-                   "search(coarse)")
+        if i8:
+            _lib.check(lib.vfm_match_search_coarse_gated_r(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
+                                                           r.sws.data_ptr(), r.sws.numel(), records, st), "search(coarse)")
+        else:
+            _lib.check(lib.vfm_match_search_coarse(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
+                                                   r.sws.data_ptr(), r.sws.numel(), st), "search(coarse)")
         rst = st
         if self.overlap:  # hand over to stage 2
             ev = torch.cuda.Event()
@@ -189,15 +205,15 @@ class RegistrationPipeline:
         # only matches with cosine >= min_cosine are kept below: queries that provably cannot reach it stay unresolved
         gate = float(np.nextafter(np.float32(self.min_cosine), np.float32(-np.inf))) if self.gate else float("-inf")
         if i8:
-            _lib.check(lib.vfm_match_search_finish_gated(q_desc.data_ptr(), r.qprep.data_ptr(), self.n, b_desc.data_ptr(),
-                                                         r.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(), r.sim.data_ptr(),
-                                                         r.sws.data_ptr(), r.sws.numel(), gate, rst), "search(finish)")
+            _lib.check(lib.vfm_match_search_finish_gated_r(q_desc.data_ptr(), r.qprep.data_ptr(), self.n, b_desc.data_ptr(),
+                                                           r.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(), r.sim.data_ptr(),
+                                                           r.sws.data_ptr(), r.sws.numel(), gate, records, rst), "search(finish)")
             if self.coarse == "auto" and len(self._pending) < 8:  # feedback: candidate chunks this search rescans
                 slot = self._slots.pop() if self._slots else torch.zeros(1, dtype=torch.int32).pin_memory()
                 _lib.check(lib.vfm_match_search_rescans_async(r.sws.data_ptr(), self.n, self.m, slot.data_ptr(), rst), "rescans")
                 ev = torch.cuda.Event()
                 ev.record(solve if self.overlap else main)
-                self._pending.append((ev, slot))
+                self._pending.append((ev, slot, records))
         else:
             _lib.check(lib.vfm_match_search_finish(q_desc.data_ptr(), r.qprep.data_ptr(), self.n, b_desc.data_ptr(),
                                                    r.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(), r.sim.data_ptr(),
