@@ -118,7 +118,8 @@ def main():
             key = name + " | " + coarse
             hist = {f"<= {1 << bnum}": st[8 + bnum] for bnum in range(16) if st[8 + bnum]}
             res[key] = dict(ms_per_registration=1e3 * dt, registrations_per_s=1.0 / dt, correspondences=k, pose_err_vs_planted=err,
-                            pass_in_use=("int8" if pipe.use_i8 else "fp16"), same_result_as_auto=same,
+                            pass_in_use=("int8" if pipe.use_i8 else "fp16"), records_in_use=("top-2" if pipe.top2 else "best score"),
+                            same_result_as_auto=same,
                             rescanned_chunks_per_query=(pipe.last_rescans / n) if pipe.last_rescans is not None else None,
                             fallback_queries=st[0], refined_queries=st[1], coarse_records_per_query=st[4] / n, candidate_entries_per_query=st[2] / n,
                             rows_kept_per_refined_query=(st[3] / st[1]) if st[1] else 0.0, candidate_entry_histogram=hist)
