@@ -182,15 +182,15 @@ def extra_configs(dev):
     lib.vfm_prof_events_create(C.byref(a), C.byref(b))
     ts = []
     ms = C.c_float()
-    for k in range(4):
+    pipe5 = RegistrationPipeline(n5, m5, d5, n_iter=RANSAC_ITERS, device=dev)
+    for k in range(4):  # the coarse kernel of the pipeline's own search (gated family, best-score records on this data)
         lib.vfm_prof_arm(a, b)
-        ops.match_ip_top1(p5["q_desc"], p5["b_desc"], ops.FAST, gate=0.8)  # the gated family, as the pipeline below
+        pipe5.register(p5["q_desc"], p5["q_xyz"], p5["b_desc"], p5["b_xyz"])
         lib.vfm_prof_elapsed_ms(a, b, C.byref(ms))
         if k:
             ts.append(ms.value)
     lib.vfm_prof_events_destroy(a, b)
     t5 = sorted(ts)[len(ts) // 2]
-    pipe5 = RegistrationPipeline(n5, m5, d5, n_iter=RANSAC_ITERS, device=dev)
     t5_reg = timed(lambda: pipe5.register(p5["q_desc"], p5["q_xyz"], p5["b_desc"], p5["b_xyz"]), reps=3)
     r5 = pipe5.register(p5["q_desc"], p5["q_xyz"], p5["b_desc"], p5["b_xyz"])
     torch.cuda.synchronize()

@@ -61,7 +61,7 @@ size_t vfm_match_ip_top1_workspace_bytes(int64_t n, int64_t m, int d, int prec_m
 int vfm_match_ip_top1(const float *q, int64_t n, const float *b, int64_t m, int d, int prec_mode,
                       int64_t *idx_out, float *sim_out, void *ws, size_t ws_bytes,
                       vfm_stream_t stream);
-/* one-shot form of the gated family (same workspace size) */
+/* one-shot form of the gated family (same workspace size; VFM_RECORDS_TOP2, the robust record kind, see below) */
 int vfm_match_ip_top1_gated(const float *q, int64_t n, const float *b, int64_t m, int d, int prec_mode,
                             float gate, int64_t *idx_out, float *sim_out, void *ws, size_t ws_bytes,
                             vfm_stream_t stream);

@@ -3127,9 +3127,11 @@ int ip_top1(const float* q, int64_t n, const float* b, int64_t m, int d, int pre
     VFM_CHECK_ARG(m < (1ll << 31) - 256 && n < (1ll << 31) - 256, "match: more than 2^31 rows");
     int rc = do_prepare2(b, m, bprep, q, n, qprep, d, st, !use_i8(d, n, m, gated));
     if (rc) return rc;
-    rc = do_search_coarse(qprep, n, bprep, m, d, sws, st, false, true, gated);
+    // one-shot calls have no feedback loop: packed top-2 records, the robust kind (real lifted descriptors are duplicate-rich)
+    rc = do_search_coarse(qprep, n, bprep, m, d, sws, st, false, true, gated, VFM_RECORDS_TOP2);
     if (rc) return rc;
-    return do_search_finish(q, qprep, n, b, bprep, m, d, idx_out, sim_out, sws, st, gated, gated ? gate : -__builtin_inff());
+    return do_search_finish(q, qprep, n, b, bprep, m, d, idx_out, sim_out, sws, st, gated, gated ? gate : -__builtin_inff(),
+                            VFM_RECORDS_TOP2);
 }
 }  // namespace
 

@@ -139,7 +139,8 @@ class VoxelHashMap:
         return self._dev
 
     def search_device(self, q_rows: torch.Tensor, min_cosine_similarity: float):
-        """Device form of the search: (query_idx int64[K], map_idx int64[K], sim fp32[N]) as device tensors."""
+        """Device form of the search: (query_idx int64[K], map_idx int64[K], sim fp32[N]) as device tensors; sim is the best
+        cosine of every query that can reach ``min_cosine_similarity`` and -2.0 for the others."""
         b_desc, _ = self._device_map()
         if q_rows.dim() != 2 or q_rows.shape[1] != b_desc.shape[1] + 3:
             raise RuntimeError("Unable to cast Python instance to C++ type: expected %d columns"
@@ -147,7 +148,10 @@ class VoxelHashMap:
         q_desc = q_rows[:, 3:].float().contiguous()            # VoxelHashMap.cpp:478-481
         d = q_desc.shape[1]
         prec = ops.FAST if (d % 128 == 0 and 128 <= d <= 768) else ops.EXACT
-        idx, sim = ops.match_ip_top1(q_desc, b_desc, prec)
+        # only matches with cosine >= min_cosine_similarity leave this function (VoxelHashMap.cpp:501-511): the gated search
+        # leaves queries that provably cannot reach it unresolved (sim = -2.0 in the returned array)
+        gate = float(np.nextafter(np.float32(min_cosine_similarity), np.float32(-np.inf)))
+        idx, sim = ops.match_ip_top1(q_desc, b_desc, prec, gate=gate if prec == ops.FAST else None)
         r = ops.threshold_compact(sim, idx, float(min_cosine_similarity), want_corres=True)
         k = int(r["count"].item())
         corres = r["corres"][:k]
