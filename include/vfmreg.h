@@ -324,7 +324,7 @@ int vfm_prof_events_destroy(void *start, void *stop);
 int vfm_debug_set_coarse_variant(int qsets);
 /* tuning switch: force the number of map slices of the coarse pass (0 = heuristic) */
 /* counters of the last FAST search that used workspace `ws` (candidate histogram, refined / fallback queries;
- * see csrc/match.hip).  out64_host: HOST int32[64].  Synchronises the device. */
+ * see csrc/match_finish.hip).  out64_host: HOST int32[64].  Synchronises the device. */
 int vfm_debug_match_stats(void *ws, int64_t n, int64_t m, int32_t *out64_host);
 /* the counters are collected only while this switch is on (they cost same-address atomics) */
 int vfm_debug_set_match_stats(int on);

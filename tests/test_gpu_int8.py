@@ -51,7 +51,7 @@ def _heavy_tailed(rng, rows, d):
 @pytest.mark.parametrize("d", [256, 384, 512, 640, 768])
 def test_quantisation_bound_holds_for_every_pair(d):
     """| v_a . v_b - s_a s_b (q_a . q_b) | <= (1 + 2^-13 + E_a) E_b + (1 + 2^-13) E_a for every pair, with the kernel's own
-    steps, integers and measured residual norms (csrc/match.hip, prep_chunk_kernel): Gaussian and heavy-tailed rows."""
+    steps, integers and measured residual norms (csrc/match_prep.hip, prep_chunk_kernel): Gaussian and heavy-tailed rows."""
     rng = np.random.default_rng(d)
     n, m = 700, 3000
     gens = ((lambda r: rng.standard_normal((r, d)).astype(np.float32), 0.03), (lambda r: _heavy_tailed(rng, r, d), 0.2))

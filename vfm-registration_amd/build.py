@@ -23,7 +23,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the fp64 / fp32 parity kernels must not fuse a*b+c
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
-SOURCES = ["error.cpp", "match.hip", "ransac.hip", "project.hip", "vit.hip", "icp.hip", "voxel.hip"]
+SOURCES = ["error.cpp", "match_api.hip", "match_prep.hip", "match_coarse_f16.hip", "match_coarse_i8.hip", "match_finish.hip",
+           "match_l2.hip", "ransac.hip", "project.hip", "vit.hip", "icp.hip", "voxel.hip"]
 
 
 def _stale(target: Path, deps) -> bool:
@@ -49,7 +50,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(compile_one, zip(srcs, objs)))
     if force or _stale(SO, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(SO)] + [str(o) for o in objs]

@@ -1,0 +1,380 @@
+// match_api.hip -- the matcher's C ABI (include/vfmreg.h): which coarse pass and record kind a search takes, the argument
+// block of the coarse kernels, workspace layout queries, the one-shot and split entry points, experiment knobs and the
+// profiling hook.  Kernels: match_prep.hip, match_coarse_f16.hip, match_coarse_i8.hip, match_finish.hip, match_l2.hip.
+#include "match_internal.h"
+
+namespace vfmm {
+
+int g_force_slices = 0;  // experiment knob (vfm_debug_set_coarse_slices): 0 = heuristic below
+
+int choose_slices(int nqb, int nchunks) {
+    if (g_force_slices > 0) return g_force_slices < nchunks ? g_force_slices : nchunks;
+    // Fill 256 CUs with whole "rounds" of workgroups (tail efficiency).  Every (query block, slice) unit re-reads its 256
+    // queries (196 KB), so HBM / Infinity-Cache traffic grows with the slice count (C2: 55 slices 1.45 GB per launch).
+    // Round 2 sweep at C2 with the seeded sparse kernel (registrations/s in the pipeline): 14-16 slices 349, 21: 367,
+    // 29: 366, 35: 367, 42: 365, 48: 364, 55: 364 -- flat from ~8 rounds on.  So: among the counts within 1 % of the best
+    // tail efficiency take the SMALLEST that still gives >= 8 rounds (29 at C2); without such a count, the most efficient.
+    int best_s = 1;
+    double best_eff = -1.0;
+    const int smax = nchunks < 64 ? nchunks : 64;
+    auto eff_of = [&](int s, long long* rounds_out) {
+        const long long total = (long long)nqb * s;
+        const long long rounds = (total + 255) / 256;
+        if (rounds_out) *rounds_out = rounds;
+        return (double)total / (double)(rounds * 256);
+    };
+    for (int s = 1; s <= smax; ++s) {
+        if (nchunks / s < 8 && s > 1) break;  // keep >= 32 tiles per workgroup
+        const double eff = eff_of(s, nullptr);
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best_s = s;
+        }
+    }
+    for (int s = 1; s < best_s; ++s) {
+        long long rounds;
+        const double eff = eff_of(s, &rounds);
+        if (rounds >= 8 && eff >= best_eff - 0.01) return s;
+    }
+    return best_s;
+}
+
+// profiling hook (vfm_prof_arm): events recorded around the next coarse launch on this thread
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+
+// 0 = default (pipelined kernel for d <= 384); 1 = match_coarse_kernel<.,1>; 2 = match_coarse_kernel<.,2>;
+// set through vfm_debug_set_coarse_variant for A/B runs
+int g_coarse_qsets = 0;
+float g_window_override = 0.0f;  // vfm_debug_set_coarse_window: timing experiments only (results are wrong)
+int g_seed_units = 1;   // vfm_debug_set_coarse_variant(7): no seed units (A/B)
+int g_match_stats = 0;  // vfm_debug_set_match_stats: per-query counters cost ~0.5 ms of same-address atomics per search
+// 4 = pipelined kernel with the DENSE per-chunk records + match_select_kernel (round-1 path; A/B reference)
+
+// inner-product searches with d <= 384 use the sparse row-level records of match_coarse_pipe_kernel<., true>
+// (from 3 query blocks on: with 1-2 blocks every unit of the grid runs at once, none is seeded, and the dense records
+// measured faster -- 244 vs 282 us per registration at 300 x 50000)
+bool use_sparse(int d, int64_t n, int64_t m) {
+    return d <= 384 && d % 128 == 0 && m < (1ll << 24) && n > 2 * QBLOCK &&
+           (g_coarse_qsets == 0 || g_coarse_qsets == 3 || g_coarse_qsets == 5);
+}
+
+// ... and before those, in the GATED family of entry points (callers that keep only matches above a similarity gate), for
+// d = 256 / 384: the int8 coarse pass with one best-score record per (query, chunk).  Its exact re-decision costs an int8
+// rescan per candidate chunk, cheap when most unmatched queries stop at the gate and slower than the fp16 pass when every
+// query must be resolved -- so the ungated entry points keep the fp16 pass.  (variant 5 = fp16 pass everywhere, A/B)
+int g_i8_min_queries = 0;  // vfm_debug_set_i8_min_queries (A/B knob): the int8 pass wins at every size measured (300 x 50 000: 209 vs 244 us)
+bool use_i8(int d, int64_t n, int64_t m, bool gated) {
+    return gated && i8_capable(d) && m < (1ll << 24) && n > g_i8_min_queries &&
+           (g_coarse_qsets == 0 || g_coarse_qsets == 10 || g_coarse_qsets == 12);
+}
+
+// queries per workgroup of the coarse kernel that do_search_coarse will launch
+int coarse_qblock(int d) { return d > 512 ? 128 : QBLOCK; }
+
+CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, int64_t n, int64_t m, int qblock) {
+    const int64_t npad = rows_padded(n), mpad = rows_padded(m);
+    CoarseArgs a;
+    a.Qh = Q.tiles;
+    a.Bh = B.tiles;
+    a.partials = w.partials;
+    a.nq_tiles = (int)((n + TILE_ROWS - 1) / TILE_ROWS);
+    a.nchunks = (int)(mpad / CHUNK_ROWS);
+    a.m_valid = m;
+    a.npad = (int)npad;
+    a.nqb = (int)(npad / qblock);
+    a.nslices = choose_slices(a.nqb, a.nchunks);
+    a.qmax = w.qmax;
+    a.first_pad_chunk = (int)(m / CHUNK_ROWS);
+    a.row_bias = nullptr;
+    a.qinv = Q.inv;
+    a.seed_parts = a.seed_chunks = a.nseed_pad = 0;
+    a.rec_cnt = nullptr;
+    a.rec = nullptr;
+    a.rcap = 0;
+    a.window = g_window_override != 0.0f ? g_window_override : DEFAULT_WINDOW;
+    a.ib = I8Bounds{nullptr, nullptr, nullptr, nullptr, 0};
+    return a;
+}
+
+// stage 1 of a search: the MFMA coarse pass (fills ws: partials + per-query coarse maxima)
+// records (int8 pass): 0 = best score per (query, chunk), 1 = packed top-2 with the best row's index (VFM_RECORDS_*)
+int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, hipStream_t st,
+                     bool bias_from_map_inv, bool inner_product, bool gated, int records) {
+    Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
+    Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
+    SearchWs w = carve_search(ws, n, m);
+    CoarseArgs a = coarse_args(Q, B, w, n, m, coarse_qblock(d));
+    if (bias_from_map_inv) {  // Euclidean search, d > 510: the map's "inv" array holds -|b~|^2 / 2
+        if (d != 640 && d != 768) return vfm_fail(VFM_EINVAL, "row bias needs the 4-wave coarse kernel (K = 640 / 768), got %d", d);
+        a.row_bias = B.inv;
+    }
+    if (inner_product && !use_i8(d, n, m, gated) && use_sparse(d, n, m)) {
+        a.rec_cnt = w.rec_cnt;
+        a.rec = w.rec;
+        a.rcap = w.rcap;
+        if (g_seed_units && a.nchunks >= 256 && a.nqb <= 256) {  // seed units: one short round at the head of the grid
+            a.seed_parts = 256 / a.nqb < 4 ? 256 / a.nqb : 4;
+            a.seed_chunks = 5;
+            a.nseed_pad = (a.nqb * a.seed_parts + 7) / 8 * 8;
+            a.nslices = choose_slices(a.nqb, a.nchunks - a.seed_parts * a.seed_chunks);
+        }
+    }
+    VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, 256 + 2 * (size_t)a.npad * sizeof(unsigned), st));  // fb_count | qmax | rec_cnt
+    if (inner_product && use_i8(d, n, m, gated)) {
+        a.Qh = Q.tiles8;
+        a.Bh = B.tiles8;
+        a.ib = I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr, records};
+        return launch_coarse_int8(a, d, n, records, st);
+    }
+    return launch_coarse_f16(a, d, st);
+}
+
+int do_search(const float* q, const void* qprep, int64_t n, const float* b, const void* bprep, int64_t m, int d,
+              int64_t* idx_out, float* sim_out, void* ws, hipStream_t st) {
+    const int rc = do_search_coarse(qprep, n, bprep, m, d, ws, st, false, true);
+    if (rc) return rc;
+    return do_search_finish(q, qprep, n, b, bprep, m, d, idx_out, sim_out, ws, st);
+}
+
+
+}  // namespace vfmm
+
+using namespace vfmm;
+
+VFM_EXPORT size_t vfm_match_prepared_bytes(int64_t rows, int d) { return carve_prepared(nullptr, rows, d).bytes; }
+
+VFM_EXPORT int vfm_match_prepare(const float* x, int64_t rows, int d, void* prepared, vfm_stream_t stream) {
+    VFM_CHECK_ARG(rows > 0 && d % 128 == 0 && d >= 128 && d <= 768, "prepare: d must be in {128,256,384,512,640,768}");
+    VFM_CHECK_ARG(x && prepared, "prepare: null pointer");
+    return do_prepare(x, rows, d, prepared, (hipStream_t)stream);
+}
+
+VFM_EXPORT int vfm_match_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2, int64_t rows2, void* prepared2,
+                                  int d, vfm_stream_t stream) {
+    VFM_CHECK_ARG(rows1 > 0 && rows2 > 0 && d % 128 == 0 && d >= 128 && d <= 768, "prepare2: d must be in {128,256,384,512,640,768}");
+    VFM_CHECK_ARG(x1 && x2 && prepared1 && prepared2, "prepare2: null pointer");
+    return do_prepare2(x1, rows1, prepared1, x2, rows2, prepared2, d, (hipStream_t)stream);
+}
+
+VFM_EXPORT int vfm_match_prepare2_gated(const float* x1, int64_t rows1, void* prepared1, const float* x2, int64_t rows2,
+                                        void* prepared2, int d, vfm_stream_t stream) {
+    VFM_CHECK_ARG(rows1 > 0 && rows2 > 0 && d % 128 == 0 && d >= 128 && d <= 768, "prepare2: d must be in {128,256,384,512,640,768}");
+    VFM_CHECK_ARG(x1 && x2 && prepared1 && prepared2, "prepare2: null pointer");
+    // (map, scan): where the gated search of x2 in x1 runs the int8 pass, the fp16 image is never read
+    const bool want_f16 = !use_i8(d, rows2, rows1, true);
+    return do_prepare2(x1, rows1, prepared1, x2, rows2, prepared2, d, (hipStream_t)stream, want_f16);
+}
+
+VFM_EXPORT size_t vfm_match_search_workspace_bytes(int64_t n, int64_t m, int d) {
+    (void)d;
+    return carve_search(nullptr, n, m).bytes;
+}
+
+VFM_EXPORT int vfm_match_search_prepared(const float* q, const void* q_prepared, int64_t n, const float* b,
+                                         const void* b_prepared, int64_t m, int d, int64_t* idx_out, float* sim_out,
+                                         void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    VFM_CHECK_ARG(n > 0 && m > 0, "search: empty operand (n=%lld m=%lld)", (long long)n, (long long)m);
+    VFM_CHECK_ARG(d % 128 == 0 && d >= 128 && d <= 768, "search: d must be in {128,256,384,512,640,768}");
+    VFM_CHECK_ARG(m < (1ll << 31) - 256 && n < (1ll << 31) - 256, "search: more than 2^31 rows");
+    if (ws_bytes < vfm_match_search_workspace_bytes(n, m, d)) return vfm_fail(VFM_EWORKSPACE, "search: workspace too small");
+    return do_search(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream);
+}
+
+static int check_search_args(int64_t n, int64_t m, int d, size_t ws_bytes) {
+    VFM_CHECK_ARG(n > 0 && m > 0, "search: empty operand (n=%lld m=%lld)", (long long)n, (long long)m);
+    VFM_CHECK_ARG(d % 128 == 0 && d >= 128 && d <= 768, "search: d must be in {128,256,384,512,640,768}");
+    VFM_CHECK_ARG(m < (1ll << 31) - 256 && n < (1ll << 31) - 256, "search: more than 2^31 rows");
+    if (ws_bytes < vfm_match_search_workspace_bytes(n, m, d)) return vfm_fail(VFM_EWORKSPACE, "search: workspace too small");
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_match_search_coarse(const void* q_prepared, int64_t n, const void* b_prepared, int64_t m, int d,
+                                       void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
+    VFM_CHECK_ARG(q_prepared && b_prepared && ws, "search_coarse: null pointer");
+    return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream, false, true);
+}
+
+VFM_EXPORT int vfm_match_search_finish(const float* q, const void* q_prepared, int64_t n, const float* b,
+                                       const void* b_prepared, int64_t m, int d, int64_t* idx_out, float* sim_out,
+                                       void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
+    VFM_CHECK_ARG(q && b && q_prepared && b_prepared && ws && idx_out && sim_out, "search_finish: null pointer");
+    return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream);
+}
+
+VFM_EXPORT int vfm_match_search_coarse_gated(const void* q_prepared, int64_t n, const void* b_prepared, int64_t m, int d,
+                                             void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    return vfm_match_search_coarse_gated_r(q_prepared, n, b_prepared, m, d, ws, ws_bytes, VFM_RECORDS_BEST, stream);
+}
+
+VFM_EXPORT int vfm_match_search_coarse_gated_r(const void* q_prepared, int64_t n, const void* b_prepared, int64_t m, int d,
+                                               void* ws, size_t ws_bytes, int records, vfm_stream_t stream) {
+    if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
+    VFM_CHECK_ARG(q_prepared && b_prepared && ws, "search_coarse: null pointer");
+    VFM_CHECK_ARG(records == VFM_RECORDS_BEST || records == VFM_RECORDS_TOP2, "search_coarse: unknown record kind %d", records);
+    return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream, false, true, true, records);
+}
+
+VFM_EXPORT int vfm_match_search_finish_gated(const float* q, const void* q_prepared, int64_t n, const float* b,
+                                             const void* b_prepared, int64_t m, int d, int64_t* idx_out, float* sim_out,
+                                             void* ws, size_t ws_bytes, float gate, vfm_stream_t stream) {
+    return vfm_match_search_finish_gated_r(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, ws_bytes, gate,
+                                           VFM_RECORDS_BEST, stream);
+}
+
+VFM_EXPORT int vfm_match_search_finish_gated_r(const float* q, const void* q_prepared, int64_t n, const float* b,
+                                               const void* b_prepared, int64_t m, int d, int64_t* idx_out, float* sim_out,
+                                               void* ws, size_t ws_bytes, float gate, int records, vfm_stream_t stream) {
+    if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
+    VFM_CHECK_ARG(q && b && q_prepared && b_prepared && ws && idx_out && sim_out, "search_finish: null pointer");
+    VFM_CHECK_ARG(gate == gate, "search_finish: gate is NaN");
+    VFM_CHECK_ARG(records == VFM_RECORDS_BEST || records == VFM_RECORDS_TOP2, "search_finish: unknown record kind %d", records);
+    return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream, true, gate, records);
+}
+
+VFM_EXPORT int vfm_match_search_rescans_async(const void* ws, int64_t n, int64_t m, int32_t* out_host, vfm_stream_t stream) {
+    VFM_CHECK_ARG(ws && out_host && n > 0 && m > 0, "search_rescans: bad arguments");
+    SearchWs w = carve_search(const_cast<void*>(ws), n, m);
+    VFM_CHECK_HIP(hipMemcpyAsync(out_host, w.fb_count + 5, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return VFM_OK;
+}
+
+VFM_EXPORT size_t vfm_match_ip_top1_workspace_bytes(int64_t n, int64_t m, int d, int prec_mode) {
+    if (prec_mode == VFM_MATCH_EXACT) return vfm_align_up((size_t)(n + m) * sizeof(float), 256) + 512;
+    return vfm_match_prepared_bytes(n, d) + vfm_match_prepared_bytes(m, d) + vfm_match_search_workspace_bytes(n, m, d);
+}
+
+static int ip_top1(const float* q, int64_t n, const float* b, int64_t m, int d, int prec_mode, bool gated, float gate, int64_t* idx_out,
+            float* sim_out, void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    VFM_CHECK_ARG(n > 0 && m > 0, "match: empty operand (n=%lld m=%lld)", (long long)n, (long long)m);
+    VFM_CHECK_ARG(q && b && idx_out && sim_out && ws, "match: null pointer");
+    if (ws_bytes < vfm_match_ip_top1_workspace_bytes(n, m, d, prec_mode)) return vfm_fail(VFM_EWORKSPACE, "match: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (prec_mode == VFM_MATCH_EXACT) {
+        VFM_CHECK_ARG(d % 4 == 0 && d <= 1024, "match(EXACT): need d %% 4 == 0 and d <= 1024");
+        return exact_ip_top1(q, n, b, m, d, idx_out, sim_out, ws, st);
+    }
+    VFM_CHECK_ARG(prec_mode == VFM_MATCH_FAST, "match: unknown prec_mode %d", prec_mode);
+    VFM_CHECK_ARG(d % 128 == 0 && d >= 128 && d <= 768, "match(FAST): d must be in {128,256,384,512,640,768}, got %d", d);
+    unsigned char* p = static_cast<unsigned char*>(ws);
+    void* qprep = p;
+    void* bprep = p + vfm_match_prepared_bytes(n, d);
+    void* sws = p + vfm_match_prepared_bytes(n, d) + vfm_match_prepared_bytes(m, d);
+    VFM_CHECK_ARG(m < (1ll << 31) - 256 && n < (1ll << 31) - 256, "match: more than 2^31 rows");
+    int rc = do_prepare2(b, m, bprep, q, n, qprep, d, st, !use_i8(d, n, m, gated));
+    if (rc) return rc;
+    // one-shot calls have no feedback loop: packed top-2 records, the robust kind (real lifted descriptors are duplicate-rich)
+    rc = do_search_coarse(qprep, n, bprep, m, d, sws, st, false, true, gated, VFM_RECORDS_TOP2);
+    if (rc) return rc;
+    return do_search_finish(q, qprep, n, b, bprep, m, d, idx_out, sim_out, sws, st, gated, gated ? gate : -__builtin_inff(),
+                            VFM_RECORDS_TOP2);
+}
+
+VFM_EXPORT int vfm_match_ip_top1(const float* q, int64_t n, const float* b, int64_t m, int d, int prec_mode,
+                                 int64_t* idx_out, float* sim_out, void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    return ip_top1(q, n, b, m, d, prec_mode, false, 0.0f, idx_out, sim_out, ws, ws_bytes, stream);
+}
+VFM_EXPORT int vfm_match_ip_top1_gated(const float* q, int64_t n, const float* b, int64_t m, int d, int prec_mode, float gate,
+                                       int64_t* idx_out, float* sim_out, void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    VFM_CHECK_ARG(gate == gate, "match: gate is NaN");
+    return ip_top1(q, n, b, m, d, prec_mode, true, gate, idx_out, sim_out, ws, ws_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling hooks: HIP events around the dominant kernel (match_coarse_kernel), on the stream the
+// kernel is launched on.  Used by bench.py for roofline.achieved.
+// ---------------------------------------------------------------------------------------------
+// A/B switch for the coarse kernel variant (1 = 8 waves x 32 queries, 2 = 4 waves x 64 queries, 0 = default)
+// Counters of the last search that used workspace `ws` (sizes as passed to that search): out64_host[0] queries
+// decided by the all-pairs fallback, [1] queries refined in fp32, [2] candidate entries after select, [3] rows kept
+// by the refinement, [8 + b] queries with 2^(b-1) < entries <= 2^b.  Synchronises the device.
+VFM_EXPORT int vfm_debug_match_stats(void* ws, int64_t n, int64_t m, int32_t* out64_host) {
+    VFM_CHECK_ARG(ws && out64_host, "match_stats: bad arguments");
+    SearchWs w = carve_search(ws, n, m);
+    VFM_CHECK_HIP(hipDeviceSynchronize());
+    VFM_CHECK_HIP(hipMemcpy(out64_host, w.fb_count, 64 * sizeof(int), hipMemcpyDeviceToHost));
+    return VFM_OK;
+}
+
+// The int8 image of a prepared operand, unpacked on the host: q8_host[rows][d] (int8), step_host[rows] (the row's group
+// step), err_host[rows] (E), gerr_host[rows] (its group's maximum E).  Tests only (the bound of prep_chunk_kernel is checked
+// pair by pair against fp64 scores).  Synchronises the device.
+VFM_EXPORT int vfm_debug_i8_rows(const void* prepared, int64_t rows, int d, int8_t* q8_host, float* step_host, float* err_host,
+                                 float* gerr_host) {
+    VFM_CHECK_ARG(prepared && rows > 0 && i8_capable(d) && q8_host && step_host && err_host && gerr_host, "i8_rows: bad arguments");
+    Prepared p = carve_prepared(const_cast<void*>(prepared), rows, d);
+    const int64_t rp = rows_padded(rows);
+    const size_t units = (size_t)rp / TILE_ROWS * (size_t)(d / 32) * 64;
+    std::vector<uint4> tiles(units);
+    std::vector<float> gstep((size_t)rp / I8_GROUP), gerr((size_t)rp / I8_GROUP);
+    VFM_CHECK_HIP(hipDeviceSynchronize());
+    VFM_CHECK_HIP(hipMemcpy(tiles.data(), p.tiles8, units * sizeof(uint4), hipMemcpyDeviceToHost));
+    VFM_CHECK_HIP(hipMemcpy(gstep.data(), p.gstep, gstep.size() * sizeof(float), hipMemcpyDeviceToHost));
+    VFM_CHECK_HIP(hipMemcpy(gerr.data(), p.gerr, gerr.size() * sizeof(float), hipMemcpyDeviceToHost));
+    VFM_CHECK_HIP(hipMemcpy(err_host, p.err, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost));
+    const int upt = (d / 32) * 64;  // units per tile
+    for (int64_t r = 0; r < rows; ++r) {
+        const int64_t tile = r / TILE_ROWS, pp = r % TILE_ROWS;
+        for (int u = 0; u < d / 16; ++u) {  // unit u = 2 s + h holds k = 16 u .. 16 u + 15
+            const int8_t* src = reinterpret_cast<const int8_t*>(&tiles[(size_t)tile * upt + (size_t)u * 32 + pp]);
+            for (int k = 0; k < 16; ++k) q8_host[r * (int64_t)d + 16 * u + k] = src[k];
+        }
+        step_host[r] = gstep[(size_t)(r / I8_GROUP)];
+        gerr_host[r] = gerr[(size_t)(r / I8_GROUP)];
+    }
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_debug_set_i8_min_queries(int n) {
+    g_i8_min_queries = n;
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_debug_set_coarse_window(float w) {
+    g_window_override = w;
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_debug_set_match_stats(int on) {
+    g_match_stats = on;
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_debug_set_coarse_slices(int slices) {
+    g_force_slices = slices;
+    return VFM_OK;
+}
+VFM_EXPORT int vfm_debug_set_coarse_variant(int qsets) {
+    g_seed_units = qsets == 7 ? 0 : 1;
+    if (qsets == 7) qsets = 0;
+    g_coarse_qsets = qsets;
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_prof_events_create(void** start, void** stop) {
+    VFM_CHECK_ARG(start && stop, "prof: null pointer");
+    hipEvent_t a, b;
+    VFM_CHECK_HIP(hipEventCreate(&a));
+    VFM_CHECK_HIP(hipEventCreate(&b));
+    *start = a;
+    *stop = b;
+    return VFM_OK;
+}
+VFM_EXPORT int vfm_prof_arm(void* start, void* stop) {
+    g_prof_start = (hipEvent_t)start;
+    g_prof_stop = (hipEvent_t)stop;
+    return VFM_OK;
+}
+VFM_EXPORT int vfm_prof_elapsed_ms(void* start, void* stop, float* ms_host) {
+    VFM_CHECK_ARG(start && stop && ms_host, "prof: null pointer");
+    VFM_CHECK_HIP(hipEventSynchronize((hipEvent_t)stop));
+    VFM_CHECK_HIP(hipEventElapsedTime(ms_host, (hipEvent_t)start, (hipEvent_t)stop));
+    return VFM_OK;
+}
+VFM_EXPORT int vfm_prof_events_destroy(void* start, void* stop) {
+    if (start) (void)hipEventDestroy((hipEvent_t)start);
+    if (stop) (void)hipEventDestroy((hipEvent_t)stop);
+    return VFM_OK;
+}
+

@@ -1,0 +1,971 @@
+// match_finish.hip -- from coarse records to the oracle's answer: candidate selection
+// (match_select_kernel), int8 rescan of candidate chunks (match_rescan_kernel), fp32 refinement of crowded lists
+// (match_refine_kernel, match_filter_refine_kernel), the exact fp64 decision (match_rescore_kernel), the all-pairs fp64
+// kernel (EXACT mode and overflow fallback) and the cosine threshold + compaction (VoxelHashMap.cpp:501-511, 587-600).
+#include "match_internal.h"
+
+namespace vfmm {
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// selection: coarse max per query and the candidate chunks inside the error window
+// cand entry: (chunk << 8) | (rescan << 7) | local row
+// ---------------------------------------------------------------------------------------------
+constexpr int SELECT_GROUPS = 16;  // waves per 64 queries: enough loads in flight to saturate HBM on the sweep
+__global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const uint2* __restrict__ partials, int nchunks, int npad,
+                                                           int64_t n, int first_pad_chunk,
+                                                           const unsigned* __restrict__ qmax,
+                                                           const float* __restrict__ invq, float window,
+                                                           I8Bounds ib, float gate, int chunk_lds, int* __restrict__ cand_cnt,
+                                                           unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count,
+                                                           int* __restrict__ fb_list, int stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char select_smem[];  // int8 records: the chunks' (step, max E)
+    __shared__ int lcnt[64];
+    __shared__ int lresc[64];     // int8 top-2 records: whole-chunk entries among them
+    __shared__ unsigned lub[64];  // int8 records: float_key of the largest upper bound over the query's chunks
+    const int qq = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 64 + qq;
+    if (g == 0) {
+        lcnt[qq] = 0;
+        lresc[qq] = 0;
+        lub[qq] = 0u;
+    }
+    float2* lchunk = reinterpret_cast<float2*>(select_smem);
+    if (ib.qerr && chunk_lds)  // every thread walks ~nchunks / 16 chunks: their (step, max E) once per workgroup into LDS
+        for (int c = threadIdx.x; c < nchunks; c += 64 * SELECT_GROUPS) lchunk[c] = make_float2(ib.bstep[c], ib.berr[c]);
+    __syncthreads();
+    if (ib.qerr) {
+        // Records of the int8 pass: integer scores in the units of (query group step) x (map chunk step).  In exact score
+        // units, with A = (1 + 2^-13) E_q and B_c = (1 + 2^-13 + E_q) max E of chunk c (prep_chunk_kernel):
+        //     lower_c = s_q s_c S(c) - A - B_c  <=  best exact score of chunk c  <=  s_q s_c S(c) + A + B_c = upper_c
+        // (S(c): the chunk's best integer score, exact).
+        // qlow = max over the un-padded chunks of lower_c, a lower bound of the query's exact maximum, comes from the coarse
+        // kernel (qmax holds its float_key).  Every chunk with upper_c >= qlow is a candidate:
+        // the oracle's arg-max row is inside one of them, and match_refine_kernel finds the rows (int8 rescan, then fp32).
+        // fp32 evaluation of the bounds: three roundings on magnitudes <= 2 -- 1e-6 of slack covers them.
+        const float eq = ib.qerr[q], sq = ib.qstep[q >> 7];
+        const float A = eq * 1.0001220703125f, mult = 1.0001220703125f + eq, slack = 1.0e-6f;
+        const float qlow = key_float(qmax[q]);  // -Inf: no un-padded chunk exists -> every chunk is a candidate
+        float maxup = -__builtin_inff();
+        if (ib.top2) {
+            // packed top-2 records (uint2 [chunk][npad], as the fp16 pass writes them): the best row's index rides in the low
+            // 7 bits, so a candidate chunk whose SECOND-best score cannot reach qlow is a single-row entry and needs no rescan
+            for (int cb = g; cb < nchunks; cb += 8 * SELECT_GROUPS) {
+                uint2 rec[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = cb + SELECT_GROUPS * u;
+                    rec[u] = (c < nchunks) ? partials[(size_t)c * npad + q] : make_uint2(0u, 0u);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = cb + SELECT_GROUPS * u;
+                    if (c >= nchunks) continue;
+                    const float2 cb2 = chunk_lds ? lchunk[c] : make_float2(ib.bstep[c], ib.berr[c]);
+                    const float sc = sq * cb2.x, bound = A + mult * cb2.y + slack;
+                    const float up1 = sc * (float)((int)(rec[u].x | 127u) - I8_OFFSET) + bound;
+                    maxup = fmaxf(maxup, up1);
+                    if (up1 >= qlow) {
+                        const int slot = atomicAdd(&lcnt[qq], 1);
+                        const float up2 = sc * (float)((int)(rec[u].y | 63u) - I8_OFFSET) + bound;
+                        const unsigned rescan = (up2 >= qlow || c >= first_pad_chunk) ? 1u : 0u;
+                        if (rescan) atomicAdd(&lresc[qq], 1);
+                        if (slot < cap && q < n) cand[(size_t)q * cap + slot] = ((unsigned)c << 8) | (rescan << 7) | (rec[u].x & 127u);
+                    }
+                }
+            }
+        } else {
+        // [query tile][chunk][32]: best integer score (+ 2^30) of the chunk for the tile's 32 queries
+        const unsigned* best = reinterpret_cast<const unsigned*>(partials) + (size_t)(q >> 5) * nchunks * 32 + (q & 31);
+        for (int cb = g; cb < nchunks; cb += 8 * SELECT_GROUPS) {
+            unsigned rec[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = cb + SELECT_GROUPS * u;
+                rec[u] = (c < nchunks) ? best[(size_t)c * 32] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = cb + SELECT_GROUPS * u;
+                if (c >= nchunks) continue;
+                const float2 cb2 = chunk_lds ? lchunk[c] : make_float2(ib.bstep[c], ib.berr[c]);
+                const float sc = sq * cb2.x, bound = A + mult * cb2.y + slack;
+                const float up1 = sc * (float)((int)rec[u] - I8_OFFSET) + bound;
+                maxup = fmaxf(maxup, up1);
+                if (up1 >= qlow) {  // (zero-padded rows score exactly 0: a padded chunk is a candidate only if 0 is inside the window)
+                    const int slot = atomicAdd(&lcnt[qq], 1);
+                    // (the records hold values only: which rows of the chunk reach qlow is found by match_refine_kernel's
+                    // int8 rescan -- every entry is a whole-chunk entry)
+                    if (slot < cap && q < n) cand[(size_t)q * cap + slot] = ((unsigned)c << 8) | 128u;
+                }
+            }
+        }
+        }
+        atomicMax(&lub[qq], float_key(maxup));
+    } else {
+    // qmax = best coarse score over the un-padded chunks (value bits; accumulated by the coarse
+    // kernel).  Chunks >= first_pad_chunk contain zero-padded map rows whose coarse score (exactly
+    // 2.0) is meaningless: they do not take part in the maximum and are always rescanned exactly.
+    const unsigned m = qmax[q];
+    // m == 0: no un-padded chunk exists (map smaller than one chunk) -> every chunk is a candidate
+    const float thr_f = __uint_as_float(m) - window;
+    const unsigned thr = (m == 0u) ? 0u : (__float_as_uint(thr_f) & ~127u);
+    // HBM-bound sweep over this query's records: 8 independent loads in flight per thread
+    for (int cb = g; cb < nchunks; cb += 8 * SELECT_GROUPS) {
+        uint2 rec[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = cb + SELECT_GROUPS * u;
+            rec[u] = (c < nchunks) ? partials[(size_t)c * npad + q] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = cb + SELECT_GROUPS * u;
+            if (c < nchunks && (rec[u].x | 127u) >= thr) {
+                const int slot = atomicAdd(&lcnt[qq], 1);
+                if (slot < cap && q < n) {  // sparse: straight to the query's global list
+                    const unsigned rescan = (((rec[u].y | 63u) >= thr) || c >= first_pad_chunk) ? 1u : 0u;
+                    cand[(size_t)q * cap + slot] = ((unsigned)c << 8) | (rescan << 7) | (rec[u].x & 127u);
+                }
+            }
+        }
+    }
+    }
+    __syncthreads();
+    if (g == 0 && ib.qerr) {
+        // load figure of the int8 pass: candidate chunks that match_refine_kernel will rescan (the caller's feedback for
+        // choosing between this pass and the fp16 one on duplicate-rich maps: vfm_match_search_rescans_async); one atomic
+        // per workgroup
+        int mine = 0;
+        // (top-2 records: whole-chunk entries count 1, single-row entries 1/32 -- 48 KB of int8 tiles against 1.5 KB of fp32 row)
+        if (q < n && invq[q] != 0.0f && !(key_float(lub[qq]) < gate) && lcnt[qq] <= cap)
+            mine = ib.top2 ? lresc[qq] + ((lcnt[qq] - lresc[qq]) >> 5) : lcnt[qq];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
+        if (qq == 0 && mine > 0) atomicAdd(fb_count + 5, mine);
+    }
+    if (g == 0 && q < n) {
+        const int cnt = lcnt[qq];
+        // statistics (vfm_debug_match_stats): [2] candidate entries, [8 + b] queries with 2^(b-1) < entries <= 2^b
+        if (stats && invq[q] != 0.0f) {
+            atomicAdd(fb_count + 2, cnt);
+            int bin = 0;
+            while ((1 << bin) < cnt && bin < 15) ++bin;
+            atomicAdd(fb_count + 8 + bin, 1);
+        }
+        if (invq[q] == 0.0f) {
+            cand_cnt[q] = 0;  // zero query row: decided directly (index 0, score 0)
+        } else if (ib.qerr && key_float(lub[qq]) < gate) {
+            // no row of the map can reach the caller's similarity gate (VoxelHashMap.cpp:501-511 drops such queries):
+            // the query is not resolved further -- match_rescore_kernel reports (index -1, similarity -2)
+            cand_cnt[q] = -2;
+        } else if (cnt > cap) {
+            cand_cnt[q] = -1;  // overflow: decided by the exact all-pairs kernel
+            const int slot = atomicAdd(fb_count, 1);
+            fb_list[slot] = (int)q;
+        } else {
+            cand_cnt[q] = cnt;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 refinement of crowded candidate lists (near-duplicate map rows).
+//
+// Real lifted descriptors are bilinear interpolations of a 16 x 21 patch grid (image_features.py:104-110,
+// prepare_scenes.py:85-104): neighbouring map points differ by less than the fp16 window (2.5e-3), so a query
+// can have dozens of candidate chunks, and chunks whose two best rows are both inside the window.  Deciding
+// all of them in fp64 (or, past the old 40-entry cap, all M rows) was a cliff.  Here one wavefront per such
+// query scores every candidate row in fp32 -- 16 lanes per row, 4 rows per pass, each lane a sequential fma
+// chain over d/16 elements followed by a 4-level xor tree -- and keeps only the rows within
+//     w2 = 2 * (d/16 + 4 + 2) * 2^-24      (3.6e-6 at d = 384)
+// of the fp32 maximum.  Proof that the oracle's arg-max survives: the fp32 value s of a row differs from the
+// exact dot product t of the same fp32-normalised rows (the oracle's definition) by at most
+// gamma = (d/16 + 4) u * sum|q_k b_k| <= (d/16 + 4) u (1 + 1e-6), u = 2^-24 (one rounding per fma / add along the
+// longest path of the summation tree; Cauchy-Schwarz on unit rows).  With j* the exact arg-max and j' the fp32
+// arg-max: s(j*) >= t(j*) - gamma >= t(j') - gamma >= s(j') - 2 gamma; every row that ties with j* exactly is
+// inside the same margin, so the fp64 decision (ties -> lowest index) sees them all.  The surviving rows
+// replace the query's list as single-row entries: match_rescore_kernel is unchanged.
+// ---------------------------------------------------------------------------------------------
+// state of one wavefront refining one query: the fp32-normalised query in registers, the kept rows in LDS
+struct RefineWave {
+    const float* b;
+    const float* invb;
+    int d, nt, g, l, lane;
+    float w2;
+    float4 qv[12];
+    unsigned* lrow;
+    float* lsc;
+    int kept;        // wave-uniform
+    float runmax;    // wave-uniform
+    bool overflow;
+
+    __device__ __forceinline__ void init(const float* q, float iq, int64_t qi, const float* b_, const float* invb_, int d_, float w2_,
+                                         unsigned* lrow_, float* lsc_) {
+        b = b_; invb = invb_; d = d_; w2 = w2_; lrow = lrow_; lsc = lsc_;
+        lane = lane_id();
+        g = lane >> 4;   // row slot of the pass
+        l = lane & 15;   // k-slice
+        nt = d >> 6;     // float4 per lane (d % 64 == 0)
+        kept = 0;
+        runmax = -3.0e38f;
+        overflow = false;
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            if (t < nt) {
+                float4 v = *reinterpret_cast<const float4*>(q + qi * (int64_t)d + 4 * (l + 16 * t));
+                v.x = v.x * iq; v.y = v.y * iq; v.z = v.z * iq; v.w = v.w * iq;  // the fp32-normalised query (faiss' xq)
+                qv[t] = v;
+            }
+        }
+    }
+    // fp32 score of this lane group's row (row < 0: none); identical in the 16 lanes of the group
+    __device__ __forceinline__ float score4(long long row) const {
+        float acc = 0.0f;
+        if (row >= 0) {
+            const float ib = invb[row];
+            const float* br = b + row * (int64_t)d + 4 * l;
+#pragma unroll
+            for (int t = 0; t < 12; ++t) {
+                if (t < nt) {
+                    const float4 bv = *reinterpret_cast<const float4*>(br + 64 * t);
+                    acc = __builtin_fmaf(qv[t].x, bv.x * ib, acc);
+                    acc = __builtin_fmaf(qv[t].y, bv.y * ib, acc);
+                    acc = __builtin_fmaf(qv[t].z, bv.z * ib, acc);
+                    acc = __builtin_fmaf(qv[t].w, bv.w * ib, acc);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
+        return acc;
+    }
+    // one pass: (row, sc) of the four lane groups; keeps the rows within w2 of the running fp32 maximum
+    __device__ __forceinline__ void consider(long long row, float sc) {
+        float pm = (row >= 0) ? sc : -3.0e38f;
+        pm = fmaxf(pm, __shfl_xor(pm, 16));
+        pm = fmaxf(pm, __shfl_xor(pm, 32));
+        if (pm > runmax) {  // prune the kept list against the new maximum
+            runmax = pm;
+            const float thr = runmax - w2;
+            const bool mine = lane < kept && lsc[lane] >= thr;
+            const unsigned r = lane < kept ? lrow[lane] : 0u;
+            const float sv = lane < kept ? lsc[lane] : 0.f;
+            const unsigned long long bal = __ballot(mine);
+            __builtin_amdgcn_wave_barrier();
+            if (mine) {
+                const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+                lrow[pos] = r;
+                lsc[pos] = sv;
+            }
+            __builtin_amdgcn_wave_barrier();
+            kept = __popcll(bal);
+        }
+        const float thr = runmax - w2;
+        const bool add = (l == 0) && row >= 0 && sc >= thr;
+        const unsigned long long bal = __ballot(add);
+        if (add) {
+            const int pos = kept + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < REFINE_KEEP) {
+                lrow[pos] = (unsigned)row;
+                lsc[pos] = sc;
+            }
+        }
+        kept += __popcll(bal);
+        if (kept > REFINE_KEEP) {
+            overflow = true;
+            kept = REFINE_KEEP;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // result: the kept rows become the query's single-row candidate list (or the query goes to the all-pairs kernel)
+    __device__ __forceinline__ void finish(int64_t qi, unsigned* mycand, int* cand_cnt, int* fb_count, int* fb_list, int stats) {
+        __builtin_amdgcn_wave_barrier();
+        if (overflow) {  // > REFINE_KEEP rows tie within the fp32 margin: the all-pairs kernel decides
+            if (lane == 0) {
+                cand_cnt[qi] = -1;
+                const int slot = atomicAdd(fb_count, 1);
+                fb_list[slot] = (int)qi;
+            }
+            return;
+        }
+        if (stats && lane == 0) {  // statistics: [1] queries refined, [3] rows they keep
+            atomicAdd(fb_count + 1, 1);
+            atomicAdd(fb_count + 3, kept);
+        }
+        if (lane < kept) {
+            const unsigned row = lrow[lane];
+            mycand[lane] = ((row / CHUNK_ROWS) << 8) | (row % CHUNK_ROWS);
+        }
+        if (lane == 0) cand_cnt[qi] = kept;
+    }
+};
+
+// int8 pass: which rows of a query's candidate chunks matter.  One wave per query; per candidate chunk the exact integer
+// scores of its 128 rows against the query (v_dot4 over the chunk's four int8 tiles: 48 KB, contiguous, L2 / Infinity-Cache
+// resident -- the whole int8 map is 77 MB at C2 -- instead of 196 KB of fp32 rows); every row whose upper bound reaches the
+// query's lower bound replaces the chunk entries as a single-row entry.  Few registers on purpose (the loop is latency-bound:
+// 8 x 16 bytes per lane in flight, 8 waves per SIMD); match_refine_kernel / match_rescore_kernel then see the lists the fp16
+// pass would have produced.
+__global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m, int d, I8Bounds ib, const uint4* __restrict__ q8,
+                                                           const uint4* __restrict__ b8, const unsigned* __restrict__ qmax,
+                                                           int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
+                                                           unsigned* __restrict__ hits, int hcap, int* __restrict__ fb_count,
+                                                           int* __restrict__ fb_list, int* __restrict__ todo) {
+    __shared__ uint4 l_q8[4][48];  // the query's int8 row, unit by unit (d <= 768)
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+    if (qi >= n) return;
+    const int cnt = cand_cnt[qi];
+    if (cnt <= 0) return;  // zero query / below the gate (-2) / overflow (-1)
+    unsigned* mycand = cand + (size_t)qi * cap;
+    unsigned* myhits = hits + (size_t)qi * hcap;
+    const int units8 = d >> 4;  // 16-byte units per int8 row
+    if (lane < units8) l_q8[wave][lane] = q8[(size_t)(qi >> 5) * (units8 * 32) + (size_t)lane * 32 + (qi & 31)];
+    const float eq = ib.qerr[qi];
+    const float sq = ib.qstep[qi >> 7], A = eq * 1.0001220703125f + 1.0e-6f, mult = 1.0001220703125f + eq;
+    const float qlow = key_float(qmax[qi]);
+    __builtin_amdgcn_wave_barrier();
+    int nhit = 0;  // wave-uniform
+    // Up to 64 entries (nearly every query): they sit in registers, one per lane, before the first hit is written, so the
+    // hits go straight into the query's list.  Longer lists collect their hits in the scratch list and copy them back.
+    const bool direct = cnt <= 64;
+    unsigned* out = direct ? mycand : myhits;
+    const int ocap = direct ? cap : hcap;
+    for (int e0 = 0; e0 < cnt; e0 += 64) {
+        const unsigned batch = (e0 + lane < cnt) ? mycand[e0 + lane] : 0u;
+        const int nb = cnt - e0 < 64 ? cnt - e0 : 64;
+        for (int j = 0; j < nb; ++j) {
+            const unsigned entry = __shfl(batch, j);  // wave-uniform
+            const int c = (int)(entry >> 8);
+            if (!(entry & 128u)) {  // a single-row entry (top-2 records: the chunk's second-best cannot reach the bound)
+                if (lane == 0 && nhit < ocap) out[nhit] = entry;
+                ++nhit;
+                continue;
+            }
+            const long long base = (long long)c * CHUNK_ROWS;
+            const float sc = sq * ib.bstep[c], bound = A + mult * ib.berr[c];
+            // rows `lane` and `lane + 64` of the chunk (tile rr >> 5, position rr & 31); the loads of both go out together:
+            // 16 x 16 bytes per lane in flight, three round trips per chunk at d = 384 (the loop is latency-bound)
+            const uint4* src0 = b8 + ((size_t)c * 4 + (lane >> 5)) * (size_t)(units8 * 32) + (lane & 31);
+            const uint4* src1 = src0 + 2 * (size_t)(units8 * 32);
+            int acc2[2] = {0, 0};
+            for (int u0 = 0; u0 < units8; u0 += 8) {  // units8 = 16, 24, 32, 40 or 48
+                uint4 bv0[8], bv1[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    bv0[k] = src0[(u0 + k) * 32];
+                    bv1[k] = src1[(u0 + k) * 32];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint4 qv = l_q8[wave][u0 + k];
+                    acc2[0] = __builtin_amdgcn_sdot4((int)bv0[k].x, (int)qv.x, acc2[0], false);
+                    acc2[0] = __builtin_amdgcn_sdot4((int)bv0[k].y, (int)qv.y, acc2[0], false);
+                    acc2[0] = __builtin_amdgcn_sdot4((int)bv0[k].z, (int)qv.z, acc2[0], false);
+                    acc2[0] = __builtin_amdgcn_sdot4((int)bv0[k].w, (int)qv.w, acc2[0], false);
+                    acc2[1] = __builtin_amdgcn_sdot4((int)bv1[k].x, (int)qv.x, acc2[1], false);
+                    acc2[1] = __builtin_amdgcn_sdot4((int)bv1[k].y, (int)qv.y, acc2[1], false);
+                    acc2[1] = __builtin_amdgcn_sdot4((int)bv1[k].z, (int)qv.z, acc2[1], false);
+                    acc2[1] = __builtin_amdgcn_sdot4((int)bv1[k].w, (int)qv.w, acc2[1], false);
+                }
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int rr = lane + 64 * half;
+                const int acc = acc2[half];
+                const bool hit = base + rr < m && sc * (float)acc + bound >= qlow;
+                const unsigned long long bal = __ballot(hit);
+                if (hit) {
+                    const int pos = nhit + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (pos < ocap) out[pos] = ((unsigned)c << 8) | (unsigned)rr;
+                }
+                nhit += __popcll(bal);
+            }
+        }
+    }
+    if (nhit > ocap || nhit > cap) {  // more rows inside the bounds than a list holds: the all-pairs kernel decides
+        if (lane == 0) {
+            cand_cnt[qi] = -1;
+            const int slot = atomicAdd(fb_count, 1);
+            fb_list[slot] = (int)qi;
+        }
+        return;
+    }
+    if (!direct) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the hits written above are read back by other lanes
+        for (int i = lane; i < nhit; i += 64) mycand[i] = myhits[i];
+    }
+    if (lane == 0) {
+        cand_cnt[qi] = nhit;
+        // crowded: match_refine_kernel's work list (up to seven rows go straight to the fp64 decision: a handful of fp64
+        // dot products costs less than the latency of one refinement wave)
+        if (nhit >= REFINE_MIN_I8) todo[atomicAdd(fb_count + 6, 1)] = (int)qi;
+    }
+}
+
+// dense records: the candidate entries of match_select_kernel (int8 pass: as rewritten by match_rescan_kernel)
+__global__ __launch_bounds__(256) void match_refine_kernel(const float* __restrict__ q, const float* __restrict__ invq,
+                                                           const float* __restrict__ b, const float* __restrict__ invb,
+                                                           int64_t n, int64_t m, int d, float w2, int* __restrict__ cand_cnt,
+                                                           unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count,
+                                                           int* __restrict__ fb_list, int stats, const int* __restrict__ todo,
+                                                           const int* __restrict__ todo_count) {
+    __shared__ unsigned l_row[4][REFINE_KEEP];
+    __shared__ float l_sc[4][REFINE_KEEP];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    // todo != NULL (int8 pass): the queries match_rescan_kernel found crowded, a short list walked by a small grid;
+    // otherwise one wave per query
+    const int64_t slot0 = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t nslots = todo ? (int64_t)*todo_count : n;
+  for (int64_t slot = slot0; slot < nslots; slot += (int64_t)gridDim.x * 4) {
+    const int64_t qi = todo ? (int64_t)todo[slot] : slot;
+    if (qi >= n) return;
+    const int cnt = cand_cnt[qi];
+    if (cnt <= 0) continue;  // zero query / nothing / overflow (-1: the all-pairs kernel decides)
+    unsigned* mycand = cand + (size_t)qi * cap;
+    // wave-uniform: is this list crowded?
+    bool flagged = false;
+    for (int e = lane; e < cnt; e += 64) flagged |= (mycand[e] & 128u) != 0u;
+    if (cnt < REFINE_MIN && !__any(flagged)) continue;
+    RefineWave R;
+    R.init(q, invq[qi], qi, b, invb, d, w2, l_row[wave], l_sc[wave]);
+    // single-row entries: 4 per pass
+    for (int e0 = 0; e0 < cnt; e0 += 4) {
+        long long row = -1;
+        if (e0 + R.g < cnt) {
+            const unsigned ce = mycand[e0 + R.g];
+            if (!(ce & 128u)) {
+                row = (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u);
+                if (row >= m) row = -1;
+            }
+        }
+        if (__any(row >= 0)) R.consider(row, R.score4(row));
+    }
+    // whole-chunk entries: all 128 rows of the chunk
+    for (int e = 0; e < cnt; ++e) {
+        const unsigned ce = mycand[e];  // wave-uniform
+        if (!(ce & 128u)) continue;
+        const long long base = (long long)(ce >> 8) * CHUNK_ROWS;
+        for (int r0 = 0; r0 < CHUNK_ROWS; r0 += 4) {
+            long long row = base + r0 + R.g;
+            if (row >= m) row = -1;
+            if (__any(row >= 0)) R.consider(row, R.score4(row));
+        }
+    }
+    if (R.overflow) continue;  // > REFINE_KEEP rows tie within the fp32 margin (exact duplicates): the list stays as
+                               // match_select_kernel wrote it and match_rescore_kernel decides all of it in fp64
+    R.finish(qi, mycand, cand_cnt, fb_count, fb_list, stats);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// sparse records (match_coarse_pipe_kernel<., true>): filter the query's records against its FINAL coarse maximum, then
+// refine in fp32 if more than two rows remain.  Replaces match_select_kernel + match_refine_kernel; one wave per query.
+__global__ __launch_bounds__(256) void match_filter_refine_kernel(const float* __restrict__ q, const float* __restrict__ invq,
+                                                                  const float* __restrict__ b, const float* __restrict__ invb,
+                                                                  int64_t n, int64_t m, int d, float window, float w2,
+                                                                  const unsigned* __restrict__ qmax,
+                                                                  const unsigned* __restrict__ rec_cnt, const uint2* __restrict__ rec,
+                                                                  int rcap, int* __restrict__ cand_cnt, unsigned* __restrict__ cand,
+                                                                  int cap, int* __restrict__ fb_count, int* __restrict__ fb_list, int stats) {
+    __shared__ unsigned l_row[4][REFINE_KEEP];
+    __shared__ float l_sc[4][REFINE_KEEP];
+    __shared__ unsigned l_cand[4][FILTER_LDS_ROWS];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+    if (qi >= n) return;
+    unsigned* mycand = cand + (size_t)qi * cap;
+    const float iq = invq[qi];
+    if (iq == 0.0f) {  // zero query row: decided directly by match_rescore_kernel (index 0, score 0)
+        if (lane == 0) cand_cnt[qi] = 0;
+        return;
+    }
+    const unsigned total = rec_cnt[qi];
+    if (stats && lane == 0) {  // statistics: [4] records written by the coarse pass
+        atomicAdd(fb_count + 4, (int)total);
+    }
+    if (total > (unsigned)rcap || m <= 0) {  // record overflow: the all-pairs kernel decides
+        if (lane == 0) {
+            cand_cnt[qi] = -1;
+            const int slot = atomicAdd(fb_count, 1);
+            fb_list[slot] = (int)qi;
+        }
+        return;
+    }
+    const unsigned thr = __float_as_uint(__uint_as_float(qmax[qi]) - window);
+    const uint2* myrec = rec + (size_t)qi * rcap;
+    unsigned* lc = l_cand[wave];
+    int ncand = 0;  // wave-uniform
+    for (unsigned e0 = 0; e0 < total; e0 += 64) {
+        const unsigned e = e0 + lane;
+        uint2 r = make_uint2(0u, 0u);
+        if (e < total) r = myrec[e];
+        const bool in = e < total && r.y >= thr;
+        const unsigned long long bal = __ballot(in);
+        if (in) lc[ncand + __popcll(bal & ((1ull << lane) - 1ull))] = r.x;
+        ncand += __popcll(bal);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (stats && lane == 0) {  // statistics: [2] candidate rows, [8 + b] queries with 2^(b-1) < rows <= 2^b
+        atomicAdd(fb_count + 2, ncand);
+        int bin = 0;
+        while ((1 << bin) < ncand && bin < 15) ++bin;
+        atomicAdd(fb_count + 8 + bin, 1);
+    }
+    if (ncand < REFINE_MIN) {
+        if (lane < ncand) {
+            const unsigned row = lc[lane];
+            mycand[lane] = ((row / CHUNK_ROWS) << 8) | (row % CHUNK_ROWS);
+        }
+        if (lane == 0) cand_cnt[qi] = ncand;
+        return;
+    }
+    RefineWave R;
+    R.init(q, iq, qi, b, invb, d, w2, l_row[wave], l_sc[wave]);
+    for (int e0 = 0; e0 < ncand; e0 += 4) {
+        const long long row = (e0 + R.g < ncand) ? (long long)lc[e0 + R.g] : -1;
+        R.consider(row, R.score4(row));
+    }
+    if (R.overflow && ncand <= cap) {  // > REFINE_KEEP rows tie within the fp32 margin (exact duplicates): hand ALL
+        for (int e = lane; e < ncand; e += 64) {  // candidates to the fp64 decision instead of the all-pairs kernel
+            const unsigned row = lc[e];
+            mycand[e] = ((row / CHUNK_ROWS) << 8) | (row % CHUNK_ROWS);
+        }
+        if (lane == 0) cand_cnt[qi] = ncand;
+        return;
+    }
+    R.finish(qi, mycand, cand_cnt, fb_count, fb_list, stats);
+}
+
+// exact score of normalised rows, sequential k, fp64 (products of two fp32 are exact in fp64)
+__device__ __forceinline__ double dot_norm_f64(const float* __restrict__ qrow_n, const float* __restrict__ brow, float invb, int d) {
+    double acc = 0.0;
+    for (int k = 0; k < d; k += 4) {
+        const float4 bv = *reinterpret_cast<const float4*>(brow + k);
+        const float b0 = bv.x * invb, b1 = bv.y * invb, b2 = bv.z * invb, b3 = bv.w * invb;
+        acc = acc + (double)qrow_n[k + 0] * (double)b0;
+        acc = acc + (double)qrow_n[k + 1] * (double)b1;
+        acc = acc + (double)qrow_n[k + 2] * (double)b2;
+        acc = acc + (double)qrow_n[k + 3] * (double)b3;
+    }
+    return acc;
+}
+
+
+// Exact decision among the candidates: one workgroup (4 waves) owns 64 queries; thread t < 64 = query t.
+//   single-row candidates (the common case, ~1.3 per query): the block's (query, candidate) pairs are
+//   flattened and taken 64 at a time; per batch and per 96-wide k chunk the four waves compute the fp64
+//   products of the 64 pairs k-parallel (coalesced row segments, 16 pairs per wave; fp32 normalisation as
+//   faiss leaves it, products of two fp32 are exact in fp64) into LDS, then wave 0 adds every pair's 96
+//   products in ascending k -- 64 different in-order chains at once instead of one chain per wavefront.
+//   whole-chunk candidates (rare): per flagged query, the lanes of wave 0 score their own rows of the chunk.
+// The accumulation order is the oracle's (sequential k), ties -> lowest index, sim = (float)score.
+constexpr int RS_KC = 96;             // k values per chunk (24 float4 per row)
+constexpr int RS_STRIDE = RS_KC + 1;  // doubles per LDS row: 194 words == 2 (mod 64) -> conflict-free ds_read_b64
+constexpr int RS_PAIRS = 1024;        // pair slots per epoch (a block has ~80 pairs; more run in further epochs)
+__global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restrict__ q, const float* __restrict__ invq,
+                                                            const float* __restrict__ b, const float* __restrict__ invb,
+                                                            int64_t n, int64_t m, int d, const int* __restrict__ cand_cnt,
+                                                            const unsigned* __restrict__ cand, int cap,
+                                                            int64_t* __restrict__ idx_out, float* __restrict__ sim_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* P = reinterpret_cast<double*>(smem);               // [64][RS_STRIDE] products
+    double* pscore = P + 64 * RS_STRIDE;                       // [RS_PAIRS] exact score per pair of the epoch
+    float* qn = reinterpret_cast<float*>(pscore + RS_PAIRS);   // [d] normalised query row (chunk rescans)
+    __shared__ unsigned p_j[RS_PAIRS];                         // pair -> map row
+    __shared__ unsigned char p_q[RS_PAIRS];                    // pair -> query lane
+    __shared__ long long s_j[64];
+    __shared__ float s_iq[64], s_ib[64];
+    __shared__ int s_ql[64];
+    __shared__ int s_total;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int64_t q0 = (int64_t)blockIdx.x * 64;
+    // per-query state lives in wave 0 (lane = query)
+    const int64_t qi = q0 + lane;
+    const bool owner = wave == 0;
+    const bool have = owner && qi < n;
+    const float iq = have ? invq[qi] : 0.0f;
+    int cnt = have ? cand_cnt[qi] : 0;
+    if (iq == 0.0f || cnt < 0) cnt = 0;  // zero query: decided below; overflow (-1): match_exact_kernel's
+    bool any_rescan = false;
+    int my_off = 0, my_pairs = 0;
+    const unsigned* mycand = cand + (size_t)(have ? qi : 0) * cap;
+    auto row_of = [&](unsigned ce) { return (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u); };
+    if (owner) {
+        // flatten: the single-row candidates of query `lane` become pairs [my_off, my_off + my_pairs)
+        for (int e = 0; e < cnt; ++e) {
+            const unsigned ce = mycand[e];
+            if (ce & 128u) any_rescan = true;
+            else if (row_of(ce) < m) ++my_pairs;
+        }
+        int incl = my_pairs;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        my_off = incl - my_pairs;
+        if (lane == 63) s_total = incl;
+    }
+    __syncthreads();
+    const int total = s_total;
+    double best = 0.0;
+    long long bj = -1;
+    for (int E0 = 0; E0 < total; E0 += RS_PAIRS) {  // one epoch unless a block has > RS_PAIRS pairs
+        const int ecount = min(RS_PAIRS, total - E0);
+        if (owner) {
+            int k = my_off;
+            for (int e = 0; e < cnt; ++e) {
+                const unsigned ce = mycand[e];
+                if ((ce & 128u) || row_of(ce) >= m) continue;
+                if (k >= E0 && k < E0 + RS_PAIRS) {
+                    p_j[k - E0] = (unsigned)row_of(ce);
+                    p_q[k - E0] = (unsigned char)lane;
+                }
+                ++k;
+            }
+        }
+        __syncthreads();
+        for (int p0 = 0; p0 < ecount; p0 += 64) {
+            // slot `lane` of this batch = pair p0 + lane of the epoch
+            long long j = -1;
+            if (owner) {
+                const int pid = p0 + lane;
+                const int ql = (pid < ecount) ? (int)p_q[pid] : 0;
+                const float iqq = __shfl(iq, ql);  // all lanes of wave 0 take part
+                float ibb = 0.f;
+                if (pid < ecount) {
+                    j = (long long)p_j[pid];
+                    ibb = invb[j];
+                }
+                s_j[lane] = j;
+                s_ql[lane] = ql;
+                s_iq[lane] = iqq;
+                s_ib[lane] = ibb;
+            }
+            __syncthreads();
+            double acc = 0.0;
+            // wave w takes slots 16 w .. 16 w + 15, two per pass (lanes 0..23 and 32..55: one float4 of k each);
+            // the row segments of chunk c+1 are fetched while wave 0 runs the chains of chunk c
+            const int sub = lane >> 5, l4 = lane & 31;
+            float4 qv[8], bv[8];
+            auto fetch = [&](int k0) {
+                const int kn = min(RS_KC, d - k0);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int sl = 16 * wave + 2 * it + sub;
+                    const long long jj = s_j[sl];
+                    if (jj >= 0 && 4 * l4 < kn) {
+                        qv[it] = *reinterpret_cast<const float4*>(q + (q0 + s_ql[sl]) * (int64_t)d + k0 + 4 * l4);
+                        bv[it] = *reinterpret_cast<const float4*>(b + jj * (int64_t)d + k0 + 4 * l4);
+                    }
+                }
+            };
+            fetch(0);
+            for (int k0 = 0; k0 < d; k0 += RS_KC) {
+                const int kn = min(RS_KC, d - k0);  // d % 4 == 0
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int sl = 16 * wave + 2 * it + sub;
+                    if (s_j[sl] >= 0 && 4 * l4 < kn) {
+                        const float iqq = s_iq[sl], ibb = s_ib[sl];
+                        double* dst = P + sl * RS_STRIDE + 4 * l4;
+                        dst[0] = (double)(qv[it].x * iqq) * (double)(bv[it].x * ibb);
+                        dst[1] = (double)(qv[it].y * iqq) * (double)(bv[it].y * ibb);
+                        dst[2] = (double)(qv[it].z * iqq) * (double)(bv[it].z * ibb);
+                        dst[3] = (double)(qv[it].w * iqq) * (double)(bv[it].w * ibb);
+                    }
+                }
+                __syncthreads();
+                if (k0 + RS_KC < d) fetch(k0 + RS_KC);
+                if (owner && j >= 0) {
+                    const double* src = P + lane * RS_STRIDE;
+                    int k = 0;
+                    for (; k + 8 <= kn; k += 8) {  // reads first, then the in-order chain
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = src[k + u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc = acc + v[u];
+                    }
+                    for (; k < kn; ++k) acc = acc + src[k];
+                }
+                __syncthreads();
+            }
+            if (owner && j >= 0) pscore[p0 + lane] = acc;
+        }
+        __syncthreads();
+        if (owner) {  // every query folds its own pairs of this epoch: best score, ties -> lowest index
+            const int lo = max(my_off, E0), hi = min(my_off + my_pairs, E0 + RS_PAIRS);
+            for (int k = lo; k < hi; ++k) {
+                const long long j = (long long)p_j[k - E0];
+                const double sc = pscore[k - E0];
+                if (bj < 0 || sc > best || (sc == best && j < bj)) {
+                    best = sc;
+                    bj = j;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!owner) return;
+    // whole-chunk candidates: wave 0 takes the flagged queries one by one
+    if (__any(any_rescan)) {
+        for (int ql = 0; ql < 64; ++ql) {
+            if (!__shfl((int)any_rescan, ql)) continue;  // wave-uniform
+            const int64_t qq = q0 + ql;
+            const float iqq = __shfl(iq, ql);
+            const int cq = __shfl(cnt, ql);
+            __builtin_amdgcn_wave_barrier();
+            for (int k = lane * 4; k < d; k += 256) {
+                float4 v = *reinterpret_cast<const float4*>(q + qq * (int64_t)d + k);
+                v.x = v.x * iqq; v.y = v.y * iqq; v.z = v.z * iqq; v.w = v.w * iqq;
+                *reinterpret_cast<float4*>(qn + k) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            double rbest = 0.0;
+            long long rj = -1;
+            for (int e = 0; e < cq; ++e) {
+                const unsigned ce = cand[(size_t)qq * cap + e];
+                if (!(ce & 128u)) continue;
+                const long long base = (long long)(ce >> 8) * CHUNK_ROWS;
+                for (int li = lane; li < CHUNK_ROWS; li += 64) {
+                    const long long j = base + li;
+                    if (j < m) {
+                        const double sc = dot_norm_f64(qn, b + j * (int64_t)d, invb[j], d);
+                        if (rj < 0 || sc > rbest || (sc == rbest && j < rj)) {
+                            rbest = sc;
+                            rj = j;
+                        }
+                    }
+                }
+            }
+            wave_argmax(rbest, rj);
+            if (lane == ql && rj >= 0 && (bj < 0 || rbest > best || (rbest == best && rj < bj))) {
+                best = rbest;
+                bj = rj;
+            }
+        }
+    }
+    if (!have) return;
+    if (iq == 0.0f) {  // zero query: every score is 0.0, the lowest index wins
+        idx_out[qi] = (m > 0) ? 0 : -1;
+        sim_out[qi] = 0.0f;
+    } else if (cand_cnt[qi] >= 0) {
+        idx_out[qi] = bj;
+        sim_out[qi] = (float)best;
+    } else if (cand_cnt[qi] == -2) {  // below the caller's gate (match_select_kernel)
+        idx_out[qi] = -1;
+        sim_out[qi] = -2.0f;
+    }
+}
+
+// all-pairs exact decision for the queries in `list` (or all queries if list == NULL)
+__global__ __launch_bounds__(256) void match_exact_kernel(const float* __restrict__ q, const float* __restrict__ invq,
+                                                          const float* __restrict__ b, const float* __restrict__ invb,
+                                                          int64_t n, int64_t m, int d, const int* __restrict__ list,
+                                                          const int* __restrict__ list_count,
+                                                          int64_t* __restrict__ idx_out, float* __restrict__ sim_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* qn = reinterpret_cast<float*>(smem);
+    double* rs = reinterpret_cast<double*>(smem + (((size_t)d * 4 + 15) & ~(size_t)15));
+    long long* rj = reinterpret_cast<long long*>(rs + 4);
+    const int64_t count = list ? (int64_t)*list_count : n;
+    for (int64_t e = blockIdx.x; e < count; e += gridDim.x) {
+        const int64_t qi = list ? (int64_t)list[e] : e;
+        const float iq = invq ? invq[qi] : 1.0f;
+        __syncthreads();
+        for (int k = threadIdx.x; k < d; k += 256) qn[k] = q[qi * (int64_t)d + k] * iq;
+        __syncthreads();
+        double best = 0.0;
+        long long bj = -1;
+        for (long long j = threadIdx.x; j < m; j += 256) {
+            const double s = dot_norm_f64(qn, b + j * (int64_t)d, invb ? invb[j] : 1.0f, d);
+            if (bj < 0 || s > best) {
+                best = s;
+                bj = j;
+            }
+        }
+        wave_argmax(best, bj);
+        if (lane_id() == 0) {
+            rs[threadIdx.x >> 6] = best;
+            rj[threadIdx.x >> 6] = bj;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (rj[w] >= 0 && (rj[0] < 0 || rs[w] > rs[0] || (rs[w] == rs[0] && rj[w] < rj[0]))) {
+                    rs[0] = rs[w];
+                    rj[0] = rj[w];
+                }
+            idx_out[qi] = (m > 0) ? rj[0] : -1;
+            sim_out[qi] = (m > 0) ? (float)rs[0] : 0.0f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// threshold + stable compaction (VoxelHashMap.cpp:501-511, 587-600), single workgroup
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void threshold_compact_kernel(const float* __restrict__ sim, const int64_t* __restrict__ idx,
+                                                                 int64_t n, double thr, int64_t* __restrict__ keep,
+                                                                 int64_t* __restrict__ count, int32_t* __restrict__ corres,
+                                                                 const double* __restrict__ qxyz, const double* __restrict__ bxyz,
+                                                                 double* __restrict__ src_out, double* __restrict__ tgt_out) {
+    __shared__ int wsum[16];
+    __shared__ int64_t base_s;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int64_t s = 0; s < n; s += 1024) {
+        const int64_t i = s + threadIdx.x;
+        const bool valid = (i < n) && !((double)sim[i] < thr);
+        const unsigned long long bal = __ballot(valid);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) woff += wsum[w];
+            tot += wsum[w];
+        }
+        const int64_t base = base_s;
+        if (valid) {
+            const int64_t k = base + woff + before;
+            keep[k] = i;
+            const int64_t j = idx ? idx[i] : 0;
+            if (corres) {
+                corres[2 * k + 0] = (int32_t)i;
+                corres[2 * k + 1] = (int32_t)j;
+            }
+            if (src_out) {
+                src_out[3 * k + 0] = qxyz[3 * i + 0];
+                src_out[3 * k + 1] = qxyz[3 * i + 1];
+                src_out[3 * k + 2] = qxyz[3 * i + 2];
+            }
+            if (tgt_out) {
+                tgt_out[3 * k + 0] = bxyz[3 * j + 0];
+                tgt_out[3 * k + 1] = bxyz[3 * j + 1];
+                tgt_out[3 * k + 2] = bxyz[3 * j + 2];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base_s = base + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = base_s;
+}
+
+
+// 1/|row| only (EXACT mode)
+__global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__ x, int64_t rows, int d,
+                                                       float* __restrict__ inv_out) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float4 v[4];
+    float nr = row_sumsq_wave(x + r * (int64_t)d, d, v);
+    float inv = inv_norm_from_sumsq(nr);
+    // faiss leaves zero rows untouched: scaling by 1 reproduces that
+    if (lane_id() == 0) inv_out[r] = (nr > 0.0f) ? inv : 1.0f;
+}
+
+}  // namespace
+
+// stage 2 of a search: candidate selection + exact fp64 decision (reads ws of stage 1)
+// gated: the search was started by the gated family (do_search_coarse(..., gated)); gate: queries whose best similarity is
+// provably below it are reported as (-1, -2.0) instead of being resolved (int8 pass only; -Inf = resolve every query)
+int do_search_finish(const float* q, const void* qprep, int64_t n, const float* b, const void* bprep, int64_t m, int d,
+                     int64_t* idx_out, float* sim_out, void* ws, hipStream_t st, bool gated, float gate, int records) {
+    Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
+    Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
+    SearchWs w = carve_search(ws, n, m);
+    const CoarseArgs a = coarse_args(Q, B, w, n, m, coarse_qblock(d));
+    const float w2 = 2.0f * (float)(d / 16 + 4 + 2) * 5.9604645e-8f;
+    const bool i8 = use_i8(d, n, m, gated);
+    if (!i8 && use_sparse(d, n, m)) {
+        hipLaunchKernelGGL(match_filter_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d,
+                           DEFAULT_WINDOW, w2, w.qmax, w.rec_cnt, w.rec, w.rcap, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
+        VFM_CHECK_LAUNCH("match_filter_refine_kernel");
+    } else {
+        const int chunk_lds = i8 && (size_t)a.nchunks * sizeof(float2) <= 63 * 1024;  // (step, max E) of every chunk in LDS
+        hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS),
+                           chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, w.partials, a.nchunks, a.npad, n, a.first_pad_chunk, w.qmax,
+                           Q.inv, DEFAULT_WINDOW, i8_bounds(Q, B, i8, records), gate, chunk_lds, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list,
+                           g_match_stats);
+        VFM_CHECK_LAUNCH("match_select_kernel");
+        if (i8) {  // candidate chunks -> candidate rows (the record buffer of the fp16 pass is free: it holds the hit lists)
+            hipLaunchKernelGGL(match_rescan_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, m, d, i8_bounds(Q, B, true, records),
+                               (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt, w.cand, w.cap,
+                               reinterpret_cast<unsigned*>(w.rec), 2 * w.rcap, w.fb_count, w.fb_list,
+                               reinterpret_cast<int*>(w.rec_cnt));
+            VFM_CHECK_LAUNCH("match_rescan_kernel");
+            // (rec_cnt, unused by the int8 pass, holds the list of crowded queries; fb_count[6] its length)
+            const unsigned grid = (unsigned)((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024);
+            hipLaunchKernelGGL(match_refine_kernel, dim3(grid), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2, w.cand_cnt, w.cand,
+                               w.cap, w.fb_count, w.fb_list, g_match_stats, (const int*)w.rec_cnt, (const int*)(w.fb_count + 6));
+        } else {
+            hipLaunchKernelGGL(match_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2,
+                               w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats, (const int*)nullptr, (const int*)nullptr);
+        }
+        VFM_CHECK_LAUNCH("match_refine_kernel");
+    }
+    {
+        const size_t lds = (size_t)(64 * RS_STRIDE + RS_PAIRS) * sizeof(double) + (size_t)d * sizeof(float);
+        static unsigned long long attr_set = 0ull;  // one bit per device
+        if (!attr_done(attr_set)) {
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_rescore_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr_mark(attr_set);
+        }
+        hipLaunchKernelGGL(match_rescore_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), lds, st, q, Q.inv, b, B.inv, n, m,
+                           d, w.cand_cnt, w.cand, w.cap, idx_out, sim_out);
+    }
+    VFM_CHECK_LAUNCH("match_rescore_kernel");
+    hipLaunchKernelGGL(match_exact_kernel, dim3(256), dim3(256), (((size_t)d * 4 + 15) & ~(size_t)15) + 64, st, q, Q.inv,
+                       b, B.inv, n, m, d, w.fb_list, w.fb_count, idx_out, sim_out);
+    VFM_CHECK_LAUNCH("match_exact_kernel(fallback)");
+    return VFM_OK;
+}
+
+// dense fp16 records -> candidate lists (the Euclidean search's use of match_select_kernel)
+int launch_select_dense(const SearchWs& w, const CoarseArgs& a, const float* qinv, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS), 0, st, w.partials, a.nchunks,
+                       a.npad, n, a.first_pad_chunk, w.qmax, qinv, DEFAULT_WINDOW, i8_bounds(Prepared{}, Prepared{}, false),
+                       -__builtin_inff(), 0, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
+    VFM_CHECK_LAUNCH("match_select_kernel");
+    return VFM_OK;
+}
+
+// EXACT mode of vfm_match_ip_top1: all-pairs fp64; ws holds 1/|row| of both operands
+int exact_ip_top1(const float* q, int64_t n, const float* b, int64_t m, int d, int64_t* idx_out, float* sim_out, void* ws,
+                  hipStream_t st) {
+    VfmCarver c(ws);
+    float* invq = c.take<float>((size_t)n);
+    float* invb = c.take<float>((size_t)m);
+    hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, n, d, invq);
+    hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, b, m, d, invb);
+    VFM_CHECK_LAUNCH("inv_norm_kernel");
+    const unsigned grid = (unsigned)(n < 4096 ? n : 4096);
+    hipLaunchKernelGGL(match_exact_kernel, dim3(grid), dim3(256), (((size_t)d * 4 + 15) & ~(size_t)15) + 64, st, q,
+                       invq, b, invb, n, m, d, (const int*)nullptr, (const int*)nullptr, idx_out, sim_out);
+    VFM_CHECK_LAUNCH("match_exact_kernel");
+    return VFM_OK;
+}
+
+}  // namespace vfmm
+
+using namespace vfmm;
+
+VFM_EXPORT int vfm_threshold_compact(const float* sim, const int64_t* idx, int64_t n, double thr, int64_t* keep_out,
+                                     int64_t* count_out, int32_t* corres_out, const double* q_xyz, const double* b_xyz,
+                                     double* src_xyz_out, double* tgt_xyz_out, vfm_stream_t stream) {
+    VFM_CHECK_ARG(n >= 0 && sim && keep_out && count_out, "threshold_compact: bad arguments");
+    VFM_CHECK_ARG(!(corres_out || tgt_xyz_out) || idx, "threshold_compact: idx required for corres / tgt output");
+    VFM_CHECK_ARG(!src_xyz_out || q_xyz, "threshold_compact: q_xyz required");
+    VFM_CHECK_ARG(!tgt_xyz_out || b_xyz, "threshold_compact: b_xyz required");
+    hipLaunchKernelGGL(threshold_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sim, idx, n, thr, keep_out,
+                       count_out, corres_out, q_xyz, b_xyz, src_xyz_out, tgt_xyz_out);
+    VFM_CHECK_LAUNCH("threshold_compact_kernel");
+    return VFM_OK;
+}

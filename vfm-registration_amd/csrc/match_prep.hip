@@ -1,0 +1,356 @@
+// match_prep.hip -- operand preparation of the matcher (VoxelHashMap.cpp:469-482): 1/|row| in faiss' fvec_renorm_L2 order,
+// the fp16 MFMA-fragment image of the normalised rows (prep_rows_kernel) and the int8 image with per-128-row quantisation
+// steps and measured residual norms (prep_chunk_kernel).  Compiled with -ffp-contract=off.
+#include "match_internal.h"
+
+namespace vfmm {
+namespace {
+
+// (a second operand -- x2, rows2, ... -- may ride in the same grid: workgroups >= tiles1 prepare it; the scan and the map
+// of a registration go out as ONE launch instead of two, 25 us less on the stream the coarse pass waits on)
+__global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict__ x, int64_t rows, int d,
+                                                        float* __restrict__ inv_out,
+                                                        uint4* __restrict__ tiles, int tiles1,
+                                                        const float* __restrict__ x2, int64_t rows2,
+                                                        float* __restrict__ inv_out2, uint4* __restrict__ tiles2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tile = blockIdx.x;
+    if (tile >= tiles1) {  // uniform per workgroup
+        tile -= tiles1;
+        x = x2;
+        rows = rows2;
+        inv_out = inv_out2;
+        tiles = tiles2;
+    }
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int ksteps = d >> 4;
+    _Float16* img = reinterpret_cast<_Float16*>(smem);
+    for (int pr = wave; pr < TILE_ROWS; pr += 4) {
+        const int64_t r = (int64_t)tile * TILE_ROWS + pr;
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float inv = 0.0f;
+        if (r < rows) {
+            float nr = row_sumsq_wave<true>(x + r * (int64_t)d, d, v);
+            inv = inv_norm_from_sumsq(nr);
+        }
+        if (lane == 0) inv_out[r] = inv;
+        const int nchunks = d >> 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunks) {
+                const float4 xv = v[i];
+                // normalised value exactly as faiss leaves it in fp32, then rounded to fp16 (RNE)
+                half4 h;
+                h[0] = (_Float16)(xv.x * inv);
+                h[1] = (_Float16)(xv.y * inv);
+                h[2] = (_Float16)(xv.z * inv);
+                h[3] = (_Float16)(xv.w * inv);
+                const int s = c >> 2, hh = (c >> 1) & 1, sub = c & 1;
+                const int unit = (s * 2 + hh) * 32 + pr;
+                *reinterpret_cast<half4*>(img + unit * 8 + sub * 4) = h;
+            }
+        }
+    }
+    __syncthreads();
+    const int units = ksteps * 64;
+    uint4* dst = tiles + (int64_t)tile * units;
+    const uint4* src = reinterpret_cast<const uint4*>(smem);
+    for (int u = threadIdx.x; u < units; u += 256) {
+        const uint4 t = src[u];
+        unsigned* o = reinterpret_cast<unsigned*>(dst + u);
+        __builtin_nontemporal_store(t.x, o);
+        __builtin_nontemporal_store(t.y, o + 1);
+        __builtin_nontemporal_store(t.z, o + 2);
+        __builtin_nontemporal_store(t.w, o + 3);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// int8 image of the rows (d = 256, 384) for the int8 coarse pass, plus (F16) the fp16 image above.
+// One workgroup (8 waves) per GROUP of 128 rows = one record chunk of the coarse pass.  The rows of a group share one
+// quantisation step  s = max|v| / 127  over the group's fp32-normalised elements v (no clipping, no tuning constant):
+//     q_k = rint(v_k / s) in [-127, 127],   e = v - s q  (measured in fp32, not assumed),   E = |e|_2 rounded up.
+// The integer score S = q_a . q_b of the MFMA is exact, so for rows a (step s_a) and b (step s_b)
+//     | v_a . v_b - s_a s_b S |  =  | (s_a q_a) . e_b + e_a . v_b |  <=  (|v_a| + E_a) E_b + E_a |v_b|     (Cauchy-Schwarz)
+// with |v| <= 1 + 2^-13 for fp32-normalised rows: match_select_kernel turns this into per-(query, chunk) bounds.
+// 16 waves x 8 rows: the group's rows stay in registers between phase 1 (1/|row|, group maximum) and phase 2 (quantise).
+// Layout: int8 fragment tiles of the 32x32x32 MFMA: unit (tile, s, h, p) = 16 int8 = row tile*32+p, k = 32 s + 16 h .. +15,
+// at uint4 index tile*(d/32*64) + s*64 + h*32 + p.
+// ---------------------------------------------------------------------------------------------
+struct PrepOut {
+    float* inv;       // [rows_pad]
+    uint4* tiles;     // fp16 fragment tiles
+    float* err;       // [rows_pad] E per row
+    float* gstep;     // [rows_pad / 128] quantisation step of the group
+    float* gerr;      // [rows_pad / 128] maximum E of the group
+    uint4* tiles8;    // int8 fragment tiles
+};
+template <bool F16, int NC = 2>
+__global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restrict__ x, int64_t rows, int d, PrepOut o, int groups1,
+                                                          const float* __restrict__ x2, int64_t rows2, PrepOut o2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned amax_bits, emax_bits;
+    constexpr int RPW = I8_GROUP / 16;  // rows per wave: 16 waves x 8 rows, all of them in registers between the two phases
+    int grp = blockIdx.x;
+    if (grp >= groups1) {  // uniform per workgroup: the second operand rides in the same grid
+        grp -= groups1;
+        x = x2;
+        rows = rows2;
+        o = o2;
+    }
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int nchunks = d >> 2;  // float4 chunks per row (<= 64 NC): lane l owns chunks l, l + 64 (, l + 128)
+    unsigned char* img8 = smem;                                                  // [4 tiles][d/32 * 64 units][16]
+    _Float16* img16 = reinterpret_cast<_Float16*>(smem + (size_t)I8_GROUP * d);  // F16: [4 tiles][d/16 * 64 units][8]
+    if (threadIdx.x == 0) {
+        amax_bits = 0u;
+        emax_bits = 0u;
+    }
+    // phase 1: the rows (read once), 1/|row| in the oracle's order, the group's largest normalised magnitude
+    float4 v[RPW][NC];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int64_t r = (int64_t)grp * I8_GROUP + wave * RPW + j;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + 64 * i;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows && c < nchunks) {
+                const float* pc = x + r * (int64_t)d + 4 * c;
+                t.x = __builtin_nontemporal_load(pc);
+                t.y = __builtin_nontemporal_load(pc + 1);
+                t.z = __builtin_nontemporal_load(pc + 2);
+                t.w = __builtin_nontemporal_load(pc + 3);
+            }
+            v[j][i] = t;
+        }
+    }
+    // Eight per-row sums per lane -> one per lane: a reduce-scatter over the xor-32 / 16 / 8 levels (the lane keeps half of
+    // its rows at every level and adds the partner's partial of those rows), then the xor-4 / 2 / 1 levels on the single
+    // value.  Every addition pairs the same two partials as row_sumsq_wave's butterfly (which computes each of them in both
+    // lanes), so the sum is bit-identical to the oracle's; 10 shuffles instead of 48.  Afterwards lane l holds row l >> 3.
+    auto scatter8 = [&](float (&p)[RPW]) __attribute__((always_inline)) {
+        const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+        float q4[4], q2[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q4[j] = (b5 ? p[j + 4] : p[j]) + __shfl_xor(b5 ? p[j] : p[j + 4], 32);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) q2[j] = (b4 ? q4[j + 2] : q4[j]) + __shfl_xor(b4 ? q4[j] : q4[j + 2], 16);
+        float q1 = (b3 ? q2[1] : q2[0]) + __shfl_xor(b3 ? q2[0] : q2[1], 8);
+        q1 = q1 + __shfl_xor(q1, 4);
+        q1 = q1 + __shfl_xor(q1, 2);
+        q1 = q1 + __shfl_xor(q1, 1);
+        return q1;
+    };
+    float part[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {  // lane-sequential over its chunks and elements, as row_sumsq_wave
+        float p = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            if (lane + 64 * i < nchunks) {
+                float t;
+                t = v[j][i].x * v[j][i].x; p = p + t;
+                t = v[j][i].y * v[j][i].y; p = p + t;
+                t = v[j][i].z * v[j][i].z; p = p + t;
+                t = v[j][i].w * v[j][i].w; p = p + t;
+            }
+        }
+        part[j] = p;
+    }
+    const float my_inv = inv_norm_from_sumsq(scatter8(part));  // of row lane >> 3: eight rows in one evaluation
+    if ((lane & 7) == 0) o.inv[(int64_t)grp * I8_GROUP + wave * RPW + (lane >> 3)] = my_inv;
+    float lmax = 0.0f;
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const float iv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_inv), 8 * j));
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {  // normalised values exactly as faiss leaves them in fp32 (zero in the unused slots)
+            v[j][i].x = v[j][i].x * iv;
+            v[j][i].y = v[j][i].y * iv;
+            v[j][i].z = v[j][i].z * iv;
+            v[j][i].w = v[j][i].w * iv;
+            lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(v[j][i].x), fabsf(v[j][i].y)), fmaxf(fabsf(v[j][i].z), fabsf(v[j][i].w))));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    __syncthreads();  // amax_bits / emax_bits initialised
+    if (lane == 0 && lmax > 0.0f) atomicMax(&amax_bits, __float_as_uint(lmax));  // finite or +Inf: uint order == float order
+    __syncthreads();
+    const float amax = __uint_as_float(amax_bits);
+    const bool usable = amax > 0.0f && amax < 3.0e38f;
+    const float qstep = usable ? amax / 127.0f : 1.0f;
+    const float inv_qstep = usable ? 127.0f / amax : 0.0f;
+    // phase 2: quantise from the registers
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int pr = wave * RPW + j;
+        const int t = pr >> 5, p = pr & 31;
+        float e2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunks) {
+                const float nv[4] = {v[j][i].x, v[j][i].y, v[j][i].z, v[j][i].w};
+                int qi[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float qf = rintf(nv[e] * inv_qstep);
+                    qf = fminf(fmaxf(qf, -127.0f), 127.0f);                // (a NaN becomes -127: any integer is valid,
+                    const float res = __builtin_fmaf(-qstep, qf, nv[e]);   //  the residual is measured: it turns E into Inf)
+                    e2 = __builtin_fmaf(res, res, e2);
+                    qi[e] = (int)qf;
+                }
+                // low bytes of the four integers: two byte permutes and an or
+                const unsigned packed = __builtin_amdgcn_perm((unsigned)qi[1], (unsigned)qi[0], 0x0c0c0400u) |
+                                        __builtin_amdgcn_perm((unsigned)qi[3], (unsigned)qi[2], 0x04000c0cu);
+                *reinterpret_cast<unsigned*>(img8 + (size_t)t * (d * 32) + (((c >> 3) * 2 + ((c >> 2) & 1)) * 32 + p) * 16 + (c & 3) * 4) = packed;
+                if constexpr (F16) {
+                    half4 h;
+                    h[0] = (_Float16)nv[0];
+                    h[1] = (_Float16)nv[1];
+                    h[2] = (_Float16)nv[2];
+                    h[3] = (_Float16)nv[3];
+                    const int s = c >> 2, hh = (c >> 1) & 1, sub = c & 1;
+                    *reinterpret_cast<half4*>(img16 + (size_t)t * (d * 32) + ((s * 2 + hh) * 32 + p) * 8 + sub * 4) = h;
+                }
+            }
+        }
+        part[j] = e2;
+    }
+    {
+        // |e|_2 of row lane >> 3, rounded up: the fp32 sum of d non-negative terms is within (d + 8) 2^-24 of exact, sqrtf
+        // within 2^-24
+        float en = sqrtf(scatter8(part)) * 1.000244140625f + 1.0e-30f;
+        if (!(en == en)) en = __builtin_inff();
+        const int64_t r = (int64_t)grp * I8_GROUP + wave * RPW + (lane >> 3);
+        if (r >= rows) en = 0.0f;
+        if ((lane & 7) == 0) {
+            o.err[r] = en;
+            if (en > 0.0f) atomicMax(&emax_bits, __float_as_uint(en));
+        }
+    }
+    __syncthreads();
+    {
+        const int u8n = (d >> 5) * 64 * 4;  // uint4 units of the group's four int8 tiles
+        uint4* dst = o.tiles8 + (int64_t)grp * u8n;
+        const uint4* src = reinterpret_cast<const uint4*>(img8);
+        for (int u = threadIdx.x; u < u8n; u += 1024) {
+            const uint4 tq = src[u];
+            unsigned* po = reinterpret_cast<unsigned*>(dst + u);
+            __builtin_nontemporal_store(tq.x, po);
+            __builtin_nontemporal_store(tq.y, po + 1);
+            __builtin_nontemporal_store(tq.z, po + 2);
+            __builtin_nontemporal_store(tq.w, po + 3);
+        }
+    }
+    if constexpr (F16) {
+        const int u16n = (d >> 4) * 64 * 4;
+        uint4* dst = o.tiles + (int64_t)grp * u16n;
+        const uint4* src = reinterpret_cast<const uint4*>(img16);
+        for (int u = threadIdx.x; u < u16n; u += 1024) {
+            const uint4 tq = src[u];
+            unsigned* po = reinterpret_cast<unsigned*>(dst + u);
+            __builtin_nontemporal_store(tq.x, po);
+            __builtin_nontemporal_store(tq.y, po + 1);
+            __builtin_nontemporal_store(tq.z, po + 2);
+            __builtin_nontemporal_store(tq.w, po + 3);
+        }
+    }
+    if (threadIdx.x == 0) {
+        o.gstep[grp] = qstep;
+        o.gerr[grp] = __uint_as_float(emax_bits);
+    }
+}
+
+// in-place renorm (vfm_l2norm_rows_f32): one wave per row
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x, int64_t rows, int d,
+                                                          float* __restrict__ inv_out) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float4 v[4];
+    float* row = x + r * (int64_t)d;
+    float nr = row_sumsq_wave(row, d, v);
+    float inv = inv_norm_from_sumsq(nr);
+    if (lane_id() == 0 && inv_out) inv_out[r] = inv;
+    if (!(nr > 0.0f)) return;
+    const int nchunks = d >> 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane_id() + 64 * i;
+        if (c < nchunks) {
+            float4 xv = v[i];
+            xv.x = xv.x * inv; xv.y = xv.y * inv; xv.z = xv.z * inv; xv.w = xv.w * inv;
+            reinterpret_cast<float4*>(row)[c] = xv;
+        }
+    }
+}
+
+}  // namespace
+
+inline PrepOut prep_out(const Prepared& p) { return PrepOut{p.inv, p.tiles, p.err, p.gstep, p.gerr, p.tiles8}; }
+
+// one or two operands (x2 may be NULL) in one launch.  want_f16 = false: only the int8 image (d = 256, 384), for operands that
+// will meet in an int8 search (use_i8): a third of the bytes written, a third of the LDS.
+int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2, int64_t rows2, void* prepared2, int d,
+                hipStream_t st, bool want_f16) {
+    Prepared p1 = carve_prepared(prepared1, rows1, d);
+    Prepared p2 = x2 ? carve_prepared(prepared2, rows2, d) : Prepared{};
+    const int t1 = (int)(rows_padded(rows1) / TILE_ROWS), t2 = x2 ? (int)(rows_padded(rows2) / TILE_ROWS) : 0;
+    if (i8_capable(d)) {  // int8 tiles + group data (+ fp16 tiles)
+        const int g1 = (int)(rows_padded(rows1) / I8_GROUP), g2 = x2 ? (int)(rows_padded(rows2) / I8_GROUP) : 0;
+        static unsigned long long attr_set = 0ull;  // one bit per device
+        if (!attr_done(attr_set)) {
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_chunk_kernel<true, 2>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * 384 * 3));
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_chunk_kernel<false, 2>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * 512));
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_chunk_kernel<false, 3>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * 768));
+            attr_mark(attr_set);
+        }
+        const dim3 grid((unsigned)(g1 + g2)), block(1024);
+        if (want_f16 && d <= 384) {  // both images from one read of the rows (144 KB of LDS at d = 384)
+            hipLaunchKernelGGL((prep_chunk_kernel<true, 2>), grid, block, (size_t)I8_GROUP * d * 3, st, x1, rows1, d, prep_out(p1), g1, x2,
+                               rows2, prep_out(p2));
+        } else {
+            if (d <= 512)
+                hipLaunchKernelGGL((prep_chunk_kernel<false, 2>), grid, block, (size_t)I8_GROUP * d, st, x1, rows1, d, prep_out(p1), g1, x2,
+                                   rows2, prep_out(p2));
+            else
+                hipLaunchKernelGGL((prep_chunk_kernel<false, 3>), grid, block, (size_t)I8_GROUP * d, st, x1, rows1, d, prep_out(p1), g1, x2,
+                                   rows2, prep_out(p2));
+            if (want_f16) {  // wider rows: the fp16 image by its own kernel (both images would not fit the LDS)
+                hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)(t1 + t2)), dim3(256), (size_t)d * 64, st, x1, rows1, d, p1.inv,
+                                   p1.tiles, t1, x2, rows2, p2.inv, p2.tiles);
+            }
+        }
+        VFM_CHECK_LAUNCH("prep_chunk_kernel");
+        return VFM_OK;
+    }
+    hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)(t1 + t2)), dim3(256), (size_t)d * 64, st, x1, rows1, d, p1.inv, p1.tiles,
+                       t1, x2, rows2, p2.inv, p2.tiles);
+    VFM_CHECK_LAUNCH("prep_rows_kernel");
+    return VFM_OK;
+}
+
+int do_prepare(const float* x, int64_t rows, int d, void* prepared, hipStream_t st) {
+    return do_prepare2(x, rows, prepared, nullptr, 0, nullptr, d, st);
+}
+
+}  // namespace vfmm
+
+using namespace vfmm;
+
+VFM_EXPORT int vfm_l2norm_rows_f32(float* x, int64_t n, int d, float* inv_out, vfm_stream_t stream) {
+    VFM_CHECK_ARG(n >= 0 && d > 0 && d % 4 == 0 && d <= 1024, "l2norm: need d %% 4 == 0 and d <= 1024 (d=%d)", d);
+    if (n == 0) return VFM_OK;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n, d,
+                       inv_out);
+    VFM_CHECK_LAUNCH("l2norm_rows_kernel");
+    return VFM_OK;
+}
