@@ -320,7 +320,8 @@ int vfm_prof_events_destroy(void *start, void *stop);
 /* tuning switch: coarse-kernel variant (0 default: gated family = int8 pass for d = 256 ... 768; ungated family =
  * sparse fp16 records for d <= 384, dense fp16 records elsewhere; 1 = 8 waves x 32 queries, 2 = 4 waves x 64, 4 = pipelined
  * kernel with dense fp16 records, 5 = the fp16 pass in the gated family too, 7 = 5 without seed units, 12 = int8 kernel with
- * 32 resident queries per wave at every size, 10 = 12 with two tiles per step at every width) */
+ * 32 resident queries per wave at every size, 10 = 12 with two tiles per step at every width, 20 = default kernels with the
+ * general selection kernel on best-score records too, 21 = default kernels without the chunk-major rescan) */
 int vfm_debug_set_coarse_variant(int qsets);
 /* tuning switch: force the number of map slices of the coarse pass (0 = heuristic) */
 /* counters of the last FAST search that used workspace `ws` (candidate histogram, refined / fallback queries;

@@ -53,7 +53,7 @@ for variant in VARIANTS:
     lib.vfm_debug_set_match_stats(0)
     s = list(stats)
     print(f"variant {variant}: coarse {sum(t) / len(t):.3f} ms (min {min(t):.3f}), finish {sum(tf) / len(tf):.3f} ms; fallbacks {s[0]}, "
-          f"refined {s[1]}, candidates/query {s[2] / n:.2f}, kept {s[3]}, records/query {s[4] / n:.1f}, histogram {s[8:24]}", flush=True)
+          f"refined {s[1]}, candidates/query {s[2] / n:.2f}, kept {s[3]}, records/query {s[4] / n:.1f}, rescans {s[5]}, crowded queries {s[6]}, histogram {s[8:24]}", flush=True)
     res[variant] = (idx.clone(), sim.clone())
 lib.vfm_debug_set_coarse_variant(0)
 first = VARIANTS[0]

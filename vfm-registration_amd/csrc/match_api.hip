@@ -47,6 +47,7 @@ thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 int g_coarse_qsets = 0;
 float g_window_override = 0.0f;  // vfm_debug_set_coarse_window: timing experiments only (results are wrong)
 int g_seed_units = 1;   // vfm_debug_set_coarse_variant(7): no seed units (A/B)
+int g_select_variant = 0;  // vfm_debug_set_coarse_variant(20 / 21): general select kernel / no chunk-major rescan (A/B)
 int g_match_stats = 0;  // vfm_debug_set_match_stats: per-query counters cost ~0.5 ms of same-address atomics per search
 // 4 = pipelined kernel with the DENSE per-chunk records + match_select_kernel (round-1 path; A/B reference)
 
@@ -119,7 +120,7 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
             a.nslices = choose_slices(a.nqb, a.nchunks - a.seed_parts * a.seed_chunks);
         }
     }
-    VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, 256 + 2 * (size_t)a.npad * sizeof(unsigned), st));  // fb_count | qmax | rec_cnt
+    VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, search_zero_bytes(n, m), st));  // fb_count | qmax | rec_cnt | bin_cnt
     if (inner_product && use_i8(d, n, m, gated)) {
         a.Qh = Q.tiles8;
         a.Bh = B.tiles8;
@@ -348,6 +349,9 @@ VFM_EXPORT int vfm_debug_set_coarse_slices(int slices) {
 VFM_EXPORT int vfm_debug_set_coarse_variant(int qsets) {
     g_seed_units = qsets == 7 ? 0 : 1;
     if (qsets == 7) qsets = 0;
+    // 20: the general select kernel on best-score records too, 21: best-score select kernel, query-major rescan only (A/B)
+    g_select_variant = qsets == 20 ? 1 : (qsets == 21 ? 2 : 0);
+    if (qsets == 20 || qsets == 21) qsets = 0;
     g_coarse_qsets = qsets;
     return VFM_OK;
 }

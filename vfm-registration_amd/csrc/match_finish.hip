@@ -169,6 +169,246 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
     }
 }
 
+// Best-score records of the int8 pass ([query tile][chunk][32], 4 bytes each): the same decision as the int8 branch of
+// match_select_kernel, laid out for the sweep.  One workgroup per query tile; a lane owns four consecutive queries of the
+// tile and one chunk of a block of eight, so a wave's load instruction covers 8 chunks x 32 queries = 1 KiB of consecutive
+// record bytes (the general kernel reads two 128-byte pieces per instruction: 103 us for the 125 MB of C2's records; this
+// one is bound by the sweep itself).
+constexpr int SELECT_BEST_WAVES = 8;
+__global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kernel(
+    const unsigned* __restrict__ best, int nchunks, int64_t n, const unsigned* __restrict__ qmax, const float* __restrict__ invq,
+    I8Bounds ib, float gate, int chunk_lds, int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
+    int* __restrict__ fb_count, int* __restrict__ fb_list, int stats, unsigned* __restrict__ bin_cnt, int* __restrict__ bins,
+    int first_pad_chunk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char select_smem[];  // the chunks' (step, max E)
+    __shared__ int lcnt[32];      // candidate chunks of the query
+    __shared__ int lov[32];       // bins != NULL: those of them that did not fit their chunk's bin (they go to the query's own list)
+    __shared__ unsigned lub[32];  // float_key of the largest upper bound over the query's chunks
+    __shared__ unsigned lmaxe;    // float_key of the largest max E over the chunks
+    __shared__ int ldead[32];     // the query records nothing (see below)
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int qt = blockIdx.x;
+    if (threadIdx.x < 32) {
+        lcnt[threadIdx.x] = 0;
+        lov[threadIdx.x] = 0;
+        lub[threadIdx.x] = 0u;
+    }
+    if (threadIdx.x == 0) lmaxe = 0u;
+    __syncthreads();
+    float2* lchunk = reinterpret_cast<float2*>(select_smem);
+    if (chunk_lds) {
+        float me = 0.0f;
+        for (int c = threadIdx.x; c < nchunks; c += 64 * SELECT_BEST_WAVES) {
+            const float2 v = make_float2(ib.bstep[c], ib.berr[c]);
+            lchunk[c] = v;
+            me = fmaxf(me, v.y);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) me = fmaxf(me, __shfl_xor(me, off));
+        if (lane == 0) atomicMax(&lmaxe, float_key(me));
+    }
+    __syncthreads();
+    const int lq = (lane & 7) * 4, lc = lane >> 3;
+    const int64_t q0 = (int64_t)qt * 32 + lq;   // the lane's four queries (rows of the padded tile always exist)
+    const float sq = ib.qstep[q0 >> 7], slack = 1.0e-6f;
+    float A[4], mult[4], qlow[4], maxup[4];
+    // "dead": the query provably ends below the gate, so its candidates are not even recorded (at C2 the unmatched half of
+    // the scan would write sixteen entries per query).  Every un-padded chunk has upper_c = lower_c + 2 (A + mult E_c) up
+    // to roundings of 1e-6 and lower_c <= qlow, so the largest upper bound over them is below qlow + 2 (A + mult max E)
+    // + 1e-5; the (at most two) padded chunks are not covered by qlow: their records are looked at here.  Should the sweep
+    // find the largest upper bound at or above the gate after all, the query goes to the all-pairs kernel (epilogue).
+    // Zero query rows (decided directly) and the rows that pad the last tile record nothing either.
+    unsigned deadmask = 0u;
+    const float maxe = chunk_lds ? key_float(lmaxe) : __builtin_inff();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float eq = ib.qerr[q0 + j];
+        A[j] = eq * 1.0001220703125f;
+        mult[j] = 1.0001220703125f + eq;
+        qlow[j] = key_float(qmax[q0 + j]);  // -Inf: no un-padded chunk exists -> every chunk is a candidate
+        maxup[j] = -__builtin_inff();
+        const bool dead = qlow[j] + 2.0f * (A[j] + mult[j] * maxe) + 1.0e-5f < gate;
+        deadmask |= dead ? (1u << j) : 0u;
+    }
+    for (int c = first_pad_chunk; c < nchunks && deadmask; ++c) {
+        const uint4 r = reinterpret_cast<const uint4*>(best + ((size_t)qt * nchunks + c) * 32)[lane & 7];
+        const unsigned r4[4] = {r.x, r.y, r.z, r.w};
+        const float sc = sq * ib.bstep[c], be = ib.berr[c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (!(sc * (float)((int)r4[j] - I8_OFFSET) + (A[j] + mult[j] * be + slack) < gate)) deadmask &= ~(1u << j);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (q0 + j >= n || invq[q0 + j] == 0.0f) deadmask |= 1u << j;
+        if (threadIdx.x < 8) ldead[lq + j] = (deadmask >> j) & 1u;
+    }
+    const uint4* src = reinterpret_cast<const uint4*>(best + (size_t)qt * nchunks * 32) + lane;
+    const int nblocks = (nchunks + 7) >> 3;
+    for (int cb0 = wave; cb0 < nblocks; cb0 += 8 * SELECT_BEST_WAVES) {
+        uint4 rec[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int cb = cb0 + SELECT_BEST_WAVES * u;
+            rec[u] = (cb * 8 + lc < nchunks) ? src[(size_t)cb * 64] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = (cb0 + SELECT_BEST_WAVES * u) * 8 + lc;
+            if (c >= nchunks) continue;
+            const float2 cb2 = chunk_lds ? lchunk[c] : make_float2(ib.bstep[c], ib.berr[c]);
+            const float sc = sq * cb2.x;
+            const unsigned r4[4] = {rec[u].x, rec[u].y, rec[u].z, rec[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float bound = A[j] + mult[j] * cb2.y + slack;
+                const float up1 = sc * (float)((int)r4[j] - I8_OFFSET) + bound;
+                maxup[j] = fmaxf(maxup[j], up1);
+                // (zero-padded rows score exactly 0: a padded chunk is a candidate only if 0 is inside the bounds)
+                if (up1 >= qlow[j] && !((deadmask >> j) & 1u)) {
+                    int slot = atomicAdd(&lcnt[lq + j], 1);
+                    if (bins) {  // chunk-major rescan: the query joins the chunk's bin; a full bin leaves the entry with the query
+                        const unsigned pos = atomicAdd(&bin_cnt[c], 1u);
+                        if (pos < (unsigned)RESCAN_BIN_CAP) {
+                            bins[(size_t)c * RESCAN_BIN_CAP + pos] = (int)(q0 + j);
+                            slot = cap;
+                        } else {
+                            slot = atomicAdd(&lov[lq + j], 1);
+                        }
+                    }
+                    if (slot < cap) cand[(size_t)(q0 + j) * cap + slot] = ((unsigned)c << 8) | 128u;  // whole-chunk entry
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = maxup[j];
+        v = fmaxf(v, __shfl_xor(v, 8));
+        v = fmaxf(v, __shfl_xor(v, 16));
+        v = fmaxf(v, __shfl_xor(v, 32));
+        if (lane < 8) atomicMax(&lub[lq + j], float_key(v));
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {   // one wave: the tile's 32 queries
+        const int qq = lane & 31;
+        const int64_t q = (int64_t)qt * 32 + qq;
+        const bool live = lane < 32 && q < n;
+        const int cnt = lcnt[qq];
+        // load figure of the int8 pass (vfm_match_search_rescans_async): candidate chunks match_rescan_kernel will rescan
+        int mine = 0;
+        if (live && invq[q] != 0.0f && !(key_float(lub[qq]) < gate) && cnt <= cap) mine = cnt;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
+        if (lane == 0 && mine > 0) atomicAdd(fb_count + 5, mine);
+        if (live) {
+            if (stats && invq[q] != 0.0f) {
+                atomicAdd(fb_count + 2, cnt);
+                int bin = 0;
+                while ((1 << bin) < cnt && bin < 15) ++bin;
+                atomicAdd(fb_count + 8 + bin, 1);
+            }
+            const bool dead = ldead[qq] != 0;
+            if (invq[q] == 0.0f) {
+                cand_cnt[q] = 0;  // zero query row: decided directly (index 0, score 0)
+            } else if (key_float(lub[qq]) < gate) {
+                cand_cnt[q] = -2;  // no row of the map can reach the caller's similarity gate
+            } else if (cnt > cap || dead) {
+                // overflow, or a padded chunk lifted a query past the gate whose candidates were not recorded: decided by the
+                // exact all-pairs kernel
+                cand_cnt[q] = -1;
+                const int slot = atomicAdd(fb_count, 1);
+                fb_list[slot] = (int)q;
+            } else {
+                // chunk-major rescan: the list holds only the entries that missed their bins; match_rescan_chunk_kernel
+                // appends the rows it finds behind what match_rescan_kernel makes of these
+                cand_cnt[q] = bins ? lov[qq] : cnt;
+            }
+        }
+    }
+}
+
+// int8 pass, chunk-major rescan (best-score records, many queries per chunk): one workgroup per map chunk scores the chunk's
+// 128 rows against every query of the chunk's bin.  The query-major kernel below reads 48 KB per (query, chunk) pair --
+// 0.5 GB per registration at C2, from the Infinity Cache / HBM because the 77 MB int8 map does not fit the L2s; here the map
+// is read once.  Wave w holds tile w of the chunk in registers, lanes l and l + 32 one half of row l each; the bin's
+// queries (int8 rows, bounds) are staged in LDS; a row inside the query's bounds is appended to the query's list.
+template <int UH>  // 16-byte units per half row (d / 32)
+__global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int64_t m, I8Bounds ib, const uint4* __restrict__ q8,
+                                                                 const uint4* __restrict__ b8, const unsigned* __restrict__ qmax,
+                                                                 int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
+                                                                 const unsigned* __restrict__ bin_cnt, const int* __restrict__ bins) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rescan_smem[];
+    uint4* l_q8 = reinterpret_cast<uint4*>(rescan_smem);  // [RESCAN_BIN_CAP][2 UH]
+    __shared__ int l_q[RESCAN_BIN_CAP];
+    __shared__ float l_sc[RESCAN_BIN_CAP], l_bound[RESCAN_BIN_CAP], l_qlow[RESCAN_BIN_CAP];
+    const int c = blockIdx.x;
+    const unsigned filled = bin_cnt[c];
+    if (filled == 0u) return;
+    const int nq = filled < (unsigned)RESCAN_BIN_CAP ? (int)filled : RESCAN_BIN_CAP;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    constexpr int UNITS = 2 * UH;
+    // the chunk's rows: tile `wave`, position lane & 31, half lane >> 5
+    uint4 bv[UH];
+    {
+        const uint4* src = b8 + ((size_t)c * 4 + wave) * (size_t)(UNITS * 32) + (size_t)(lane >> 5) * (UH * 32) + (lane & 31);
+#pragma unroll
+        for (int k = 0; k < UH; ++k) bv[k] = src[k * 32];
+    }
+    if (threadIdx.x < nq) {
+        const int qi = bins[(size_t)c * RESCAN_BIN_CAP + threadIdx.x];
+        const bool live = cand_cnt[qi] >= 0;   // (-2: below the gate, -1: already with the all-pairs kernel)
+        l_q[threadIdx.x] = live ? qi : -1;
+        const float eq = ib.qerr[qi];
+        const float sq = ib.qstep[qi >> 7], A = eq * 1.0001220703125f + 1.0e-6f, mult = 1.0001220703125f + eq;
+        l_sc[threadIdx.x] = sq * ib.bstep[c];       // the same expressions as match_rescan_kernel: the same rows pass
+        l_bound[threadIdx.x] = A + mult * ib.berr[c];
+        l_qlow[threadIdx.x] = key_float(qmax[qi]);
+    }
+    for (int i = threadIdx.x; i < nq * UNITS; i += 256) {
+        const int j = i / UNITS, u = i % UNITS;
+        const int qi = bins[(size_t)c * RESCAN_BIN_CAP + j];
+        l_q8[i] = q8[(size_t)(qi >> 5) * (UNITS * 32) + (size_t)u * 32 + (qi & 31)];
+    }
+    __syncthreads();
+    const long long base = (long long)c * CHUNK_ROWS;
+    const int rr = wave * 32 + (lane & 31);
+    for (int j = 0; j < nq; ++j) {
+        const int qi = l_q[j];
+        if (qi < 0) continue;
+        const uint4* qv8 = l_q8 + j * UNITS + (lane >> 5) * UH;
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < UH; ++k) {
+            const uint4 qv = qv8[k];
+            acc = __builtin_amdgcn_sdot4((int)bv[k].x, (int)qv.x, acc, false);
+            acc = __builtin_amdgcn_sdot4((int)bv[k].y, (int)qv.y, acc, false);
+            acc = __builtin_amdgcn_sdot4((int)bv[k].z, (int)qv.z, acc, false);
+            acc = __builtin_amdgcn_sdot4((int)bv[k].w, (int)qv.w, acc, false);
+        }
+        acc += __shfl_xor(acc, 32);
+        if (lane < 32 && base + rr < m && l_sc[j] * (float)acc + l_bound[j] >= l_qlow[j]) {
+            const int pos = atomicAdd(&cand_cnt[qi], 1);
+            if (pos < cap) cand[(size_t)qi * cap + pos] = ((unsigned)c << 8) | (unsigned)rr;
+        }
+    }
+}
+
+// after both rescans: lists longer than their capacity go to the all-pairs kernel, crowded ones to the fp32 refinement
+__global__ __launch_bounds__(256) void match_rescan_close_kernel(int64_t n, int* __restrict__ cand_cnt, int cap,
+                                                                 int* __restrict__ fb_count, int* __restrict__ fb_list,
+                                                                 int* __restrict__ todo) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const int cnt = cand_cnt[q];
+    if (cnt > cap) {
+        cand_cnt[q] = -1;
+        fb_list[atomicAdd(fb_count, 1)] = (int)q;
+    } else if (cnt >= REFINE_MIN_I8) {
+        todo[atomicAdd(fb_count + 6, 1)] = (int)q;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // fp32 refinement of crowded candidate lists (near-duplicate map rows).
 //
@@ -311,7 +551,7 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
                                                            const uint4* __restrict__ b8, const unsigned* __restrict__ qmax,
                                                            int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
                                                            unsigned* __restrict__ hits, int hcap, int* __restrict__ fb_count,
-                                                           int* __restrict__ fb_list, int* __restrict__ todo) {
+                                                           int* __restrict__ fb_list, int* __restrict__ todo, int defer_todo) {
     __shared__ uint4 l_q8[4][48];  // the query's int8 row, unit by unit (d <= 768)
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
@@ -400,7 +640,8 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
         cand_cnt[qi] = nhit;
         // crowded: match_refine_kernel's work list (up to seven rows go straight to the fp64 decision: a handful of fp64
         // dot products costs less than the latency of one refinement wave)
-        if (nhit >= REFINE_MIN_I8) todo[atomicAdd(fb_count + 6, 1)] = (int)qi;
+        // (defer_todo: match_rescan_chunk_kernel still appends to the lists; match_rescan_close_kernel builds the work list)
+        if (nhit >= REFINE_MIN_I8 && !defer_todo) todo[atomicAdd(fb_count + 6, 1)] = (int)qi;
     }
 }
 
@@ -889,6 +1130,17 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
         VFM_CHECK_LAUNCH("match_filter_refine_kernel");
     } else {
         const int chunk_lds = i8 && (size_t)a.nchunks * sizeof(float2) <= 63 * 1024;  // (step, max E) of every chunk in LDS
+        bool use_bins = false;
+        // best-score records with many queries per map chunk: the rescan runs chunk-major (match_rescan_chunk_kernel)
+        const bool best = i8 && records == VFM_RECORDS_BEST && g_select_variant != 1;
+        use_bins = best && g_select_variant != 2 && n >= 4 * (int64_t)a.nchunks;
+        if (best) {
+            hipLaunchKernelGGL(match_select_best_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * SELECT_BEST_WAVES),
+                               chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, reinterpret_cast<const unsigned*>(w.partials),
+                               a.nchunks, n, (const unsigned*)w.qmax, Q.inv, i8_bounds(Q, B, true, records), gate, chunk_lds, w.cand_cnt,
+                               w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats, use_bins ? w.bin_cnt : (unsigned*)nullptr,
+                               use_bins ? w.bins : (int*)nullptr, a.first_pad_chunk);
+        } else
         hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS),
                            chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, w.partials, a.nchunks, a.npad, n, a.first_pad_chunk, w.qmax,
                            Q.inv, DEFAULT_WINDOW, i8_bounds(Q, B, i8, records), gate, chunk_lds, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list,
@@ -898,8 +1150,27 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
             hipLaunchKernelGGL(match_rescan_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, m, d, i8_bounds(Q, B, true, records),
                                (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt, w.cand, w.cap,
                                reinterpret_cast<unsigned*>(w.rec), 2 * w.rcap, w.fb_count, w.fb_list,
-                               reinterpret_cast<int*>(w.rec_cnt));
+                               reinterpret_cast<int*>(w.rec_cnt), use_bins ? 1 : 0);
             VFM_CHECK_LAUNCH("match_rescan_kernel");
+            if (use_bins) {
+                const size_t lds = (size_t)RESCAN_BIN_CAP * (size_t)(d / 16) * sizeof(uint4);
+#define VFM_RESCAN_CHUNK(UH)                                                                                                  \
+    hipLaunchKernelGGL(match_rescan_chunk_kernel<UH>, dim3((unsigned)a.nchunks), dim3(256), lds, st, n, m,                      \
+                       i8_bounds(Q, B, true, records), (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, \
+                       w.cand_cnt, w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins)
+                switch (d / 32) {
+                    case 8: VFM_RESCAN_CHUNK(8); break;
+                    case 12: VFM_RESCAN_CHUNK(12); break;
+                    case 16: VFM_RESCAN_CHUNK(16); break;
+                    case 20: VFM_RESCAN_CHUNK(20); break;
+                    default: VFM_RESCAN_CHUNK(24); break;
+                }
+#undef VFM_RESCAN_CHUNK
+                VFM_CHECK_LAUNCH("match_rescan_chunk_kernel");
+                hipLaunchKernelGGL(match_rescan_close_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, w.cand_cnt, w.cap,
+                                   w.fb_count, w.fb_list, reinterpret_cast<int*>(w.rec_cnt));
+                VFM_CHECK_LAUNCH("match_rescan_close_kernel");
+            }
             // (rec_cnt, unused by the int8 pass, holds the list of crowded queries; fb_count[6] its length)
             const unsigned grid = (unsigned)((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024);
             hipLaunchKernelGGL(match_refine_kernel, dim3(grid), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2, w.cand_cnt, w.cand,

@@ -32,6 +32,7 @@ constexpr int CAND_CAP_MAX = 2048;  // candidate entries a query can hold = min(
 constexpr int REFINE_MIN = 3;     // queries with this many candidate entries (or a whole-chunk entry) go through the fp32 refinement
 constexpr int REFINE_MIN_I8 = 8;  // the same threshold for the row lists of the int8 pass (match_rescan_kernel)
 constexpr int REFINE_KEEP = 64;   // rows a query may keep after the refinement
+constexpr int RESCAN_BIN_CAP = 64;  // candidate queries a map chunk can collect for the chunk-major int8 rescan (the rest: query-major)
 constexpr int FILTER_LDS_ROWS = 1024;  // sparse fp16 records a query can hold (= SearchWs::rcap; match_filter_refine_kernel keeps them in LDS)
 constexpr int SPARSE_LREC_CAP = 1536;  // records a workgroup of the sparse coarse kernel buffers in LDS (12 KiB)
 constexpr float COARSE_OFFSET = 2.0f;   // accumulators start here: every coarse score is a
@@ -325,6 +326,8 @@ struct SearchWs {
     int* fb_count;
     int* fb_list;
     unsigned* qmax;
+    unsigned* bin_cnt;  // int8 pass, best-score records: candidate queries per map chunk ...
+    int* bins;          // ... and the queries themselves, RESCAN_BIN_CAP per chunk (match_rescan_chunk_kernel)
     size_t bytes;
 };
 
@@ -337,15 +340,23 @@ inline SearchWs carve_search(void* p, int64_t n, int64_t m) {
     w.cap = cand_cap(mpad);
     w.cand = c.take<unsigned>((size_t)npad * (size_t)w.cap);
     w.fb_list = c.take<int>((size_t)npad);
-    // zeroed before every search by ONE memset: [fb_count (64, padded to 256 B) | qmax (npad) | rec_cnt (npad)]; npad is a
-    // multiple of 256, so the three arrays are contiguous under the carver's 256-byte alignment
+    // zeroed before every search by ONE memset (search_zero_bytes): [fb_count (64, padded to 256 B) | qmax (npad) |
+    // rec_cnt (npad) | bin_cnt (chunks, padded to 64)]; npad is a multiple of 256, so the arrays are contiguous under the
+    // carver's 256-byte alignment
     w.fb_count = c.take<int>(64);
     w.qmax = c.take<unsigned>((size_t)npad);
     w.rec_cnt = c.take<unsigned>((size_t)npad);
+    w.bin_cnt = c.take<unsigned>((size_t)((mpad / CHUNK_ROWS + 63) / 64 * 64));
+    w.bins = c.take<int>((size_t)(mpad / CHUNK_ROWS) * RESCAN_BIN_CAP);
     w.rcap = FILTER_LDS_ROWS;
     w.rec = c.take<uint2>((size_t)npad * (size_t)w.rcap);
     w.bytes = c.used();
     return w;
+}
+
+inline size_t search_zero_bytes(int64_t n, int64_t m) {
+    const int64_t npad = rows_padded(n), mpad = rows_padded(m);
+    return 256 + 2 * (size_t)npad * sizeof(unsigned) + (size_t)((mpad / CHUNK_ROWS + 63) / 64 * 64) * sizeof(unsigned);
 }
 
 // hipFuncSetAttribute is per device: remember which devices have been configured (one bit each)
@@ -361,7 +372,7 @@ inline void attr_mark(unsigned long long& mask) {
 }
 
 // experiment knobs and profiling hook (match_api.hip)
-extern int g_force_slices, g_coarse_qsets, g_seed_units, g_match_stats, g_i8_min_queries;
+extern int g_force_slices, g_coarse_qsets, g_seed_units, g_match_stats, g_i8_min_queries, g_select_variant;
 extern float g_window_override;
 extern thread_local hipEvent_t g_prof_start, g_prof_stop;  // vfm_prof_arm: events around the next coarse launch of this thread
 
