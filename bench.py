@@ -262,7 +262,8 @@ def main():
     S = 2 if args.streams >= 2 else 1
     pipe = RegistrationPipeline(n, m, d, n_iter=args.iters, device=dev, overlap_ransac=(S == 2),
                                 overlap_prepare=(S == 2 and os.environ.get("VFM_OVERLAP_PREPARE", "1") == "1"),
-                                solve_streams=int(os.environ.get("VFM_SOLVE_STREAMS", "2")))
+                                solve_streams=int(os.environ.get("VFM_SOLVE_STREAMS", "2")),
+                                coarse=os.environ.get("VFM_COARSE", "auto"))  # A/B: "int8" / "int8-top2" / "fp16" fix the pass
 
     # (a high-priority matching stream was tried: no measurable difference)
     match_stream = torch.cuda.current_stream()

@@ -215,3 +215,53 @@ def test_quantisation_bound_at_c2_scale():
     assert worst_dev < 0.01                                                    # the actual error is a fraction of the bound
     # and the search's answers on those rows are the arg-max of the fp64 scores (up to exact ties, which the data has none of)
     assert torch.equal(idx[rows], arg)
+
+
+def _gate_contract(idx, sim, ridx, rsim, gate):
+    idx, sim = idx.cpu().numpy(), sim.cpu().numpy()
+    solved = idx >= 0
+    np.testing.assert_array_equal(idx[solved], ridx[solved])
+    np.testing.assert_array_equal(sim[solved], rsim[solved])
+    assert (rsim[~solved] < gate).all() and (sim[~solved] == -2.0).all()
+    return solved
+
+
+@pytest.mark.parametrize("d", [384, 768])
+def test_chunk_major_rescan_full_bins_and_padded_chunks(d):
+    """Best-score records with many queries per map chunk take the chunk-major rescan (match_rescan_chunk_kernel): bins that
+    overflow (the rest of the chunk's queries stay query-major), matches inside the partly padded last chunk (not covered by
+    the running lower bound: the "provably below the gate" shortcut of match_select_best_kernel must not drop them), gate
+    off / on, and the same answers with the chunk-major path switched off (variant 21) and from the general selection
+    kernel (variant 20)."""
+    lib = _lib.load()
+    rng = np.random.default_rng(d)
+    gate = float(np.nextafter(np.float32(0.8), np.float32(-np.inf)))
+    # (a) 8 chunks, 6000 matched queries: 750 per chunk against a bin of 512
+    m, n = 1000, 6000
+    b = rng.standard_normal((m, d)).astype(np.float32)
+    q = b[rng.integers(0, m, n)] + 0.25 * rng.standard_normal((n, d)).astype(np.float32)
+    q[::7] = rng.standard_normal((len(q[::7]), d)).astype(np.float32)       # unmatched queries
+    # (b) 20 full chunks + 40 rows: half of the queries match rows of the padded chunk
+    m2, n2 = 128 * 20 + 40, 600
+    b2 = rng.standard_normal((m2, d)).astype(np.float32)
+    q2 = rng.standard_normal((n2, d)).astype(np.float32)
+    q2[::2] = b2[rng.integers(128 * 20, m2, len(q2[::2]))] + 0.2 * rng.standard_normal((len(q2[::2]), d)).astype(np.float32)
+    for name, (qq, bb) in {"full bins": (q, b), "padded chunk": (q2, b2)}.items():
+        qn, _ = orc.l2norm_rows(qq)
+        bn, _ = orc.l2norm_rows(bb)
+        ridx, rsim = orc.match_ip_top1(qn, bn)
+        qd, bd = torch.from_numpy(qq).cuda(), torch.from_numpy(bb).cuda()
+        ref = {}
+        for variant in (0, 21, 20):
+            lib.vfm_debug_set_coarse_variant(variant)
+            try:
+                i0, s0 = _search_gated(qd, bd, float("-inf"), 0)
+                i1, s1 = _search_gated(qd, bd, gate, 0)
+            finally:
+                lib.vfm_debug_set_coarse_variant(0)
+            np.testing.assert_array_equal(i0.cpu().numpy(), ridx, err_msg=f"{name} / variant {variant}")
+            np.testing.assert_array_equal(s0.cpu().numpy(), rsim, err_msg=f"{name} / variant {variant}")
+            solved = _gate_contract(i1, s1, ridx, rsim, gate)
+            assert solved[rsim >= 0.8].all() and solved.sum() > len(solved) // 3 and (~solved).sum() > 0
+            ref.setdefault("solved", solved)
+            np.testing.assert_array_equal(solved, ref["solved"], err_msg=f"{name} / variant {variant}")

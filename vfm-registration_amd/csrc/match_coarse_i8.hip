@@ -72,9 +72,13 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8_kernel(CoarseArgs a) {
     unsigned s1 = 0u, s2 = 0u, unused_max = 0u;
     auto emit_chunk = [&](int chunk) __attribute__((always_inline)) {  // chunk < 0: nothing folded yet
         const unsigned best = TOP2 ? coarse_emit_chunk(a, s1, s2, unused_max, qt, chunk) : coarse_emit_chunk_best(a, s1, qt, chunk);
-        if (chunk >= 0 && chunk < a.first_pad_chunk) {  // wave-uniform
+        if (chunk >= 0) {  // wave-uniform
+            // a chunk with zero-padded rows (they score exactly 0) counts only where its best score is positive: that score
+            // belongs to a real row
             const float sb = a.ib.bstep[chunk], be = a.ib.berr[chunk];
-            i8_low = fmaxf(i8_low, __builtin_fmaf(i8_sq * sb, (float)((int)best - I8_OFFSET), -(i8_A + i8_mult * be)));
+            const int sbest = (int)best - I8_OFFSET;
+            const float low = __builtin_fmaf(i8_sq * sb, (float)sbest, -(i8_A + i8_mult * be));
+            i8_low = fmaxf(i8_low, (chunk < a.first_pad_chunk || sbest > 0) ? low : -__builtin_inff());
         }
     };
 
@@ -214,17 +218,23 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a)
     unsigned s1[2] = {0u, 0u}, s2[2] = {0u, 0u}, unused_max = 0u;
     auto emit_chunk = [&](int chunk) __attribute__((always_inline)) {  // chunk < 0: nothing folded yet
         float sb = 0.f, be = 0.f;
-        const bool counted = chunk >= 0 && chunk < a.first_pad_chunk;  // wave-uniform
+        const bool counted = chunk >= 0;  // wave-uniform
         if (counted) {
             sb = a.ib.bstep[chunk];
             be = a.ib.berr[chunk];
         }
+        // a chunk with zero-padded rows (they score exactly 0) counts only where its best score is positive: that score
+        // belongs to a real row
+        const bool padded = chunk >= a.first_pad_chunk;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const unsigned best = TOP2 ? coarse_emit_chunk(a, s1[j], s2[j], unused_max, qt0 + j, chunk)
                                        : coarse_emit_chunk_best(a, s1[j], qt0 + j, chunk);
-            if (counted)
-                i8_low[j] = fmaxf(i8_low[j], __builtin_fmaf(i8_sq[j] * sb, (float)((int)best - I8_OFFSET), -(i8_A[j] + i8_mult[j] * be)));
+            if (counted) {
+                const int sbest = (int)best - I8_OFFSET;
+                const float low = __builtin_fmaf(i8_sq[j] * sb, (float)sbest, -(i8_A[j] + i8_mult[j] * be));
+                i8_low[j] = fmaxf(i8_low[j], (!padded || sbest > 0) ? low : -__builtin_inff());
+            }
         }
     };
 

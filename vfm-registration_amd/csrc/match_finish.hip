@@ -332,16 +332,17 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
 // 128 rows against every query of the chunk's bin.  The query-major kernel below reads 48 KB per (query, chunk) pair --
 // 0.5 GB per registration at C2, from the Infinity Cache / HBM because the 77 MB int8 map does not fit the L2s; here the map
 // is read once.  Wave w holds tile w of the chunk in registers, lanes l and l + 32 one half of row l each; the bin's
-// queries (int8 rows, bounds) are staged in LDS; a row inside the query's bounds is appended to the query's list.
+// queries (int8 rows, bounds) are staged in LDS, RESCAN_BATCH at a time; a row inside the query's bounds is appended to the
+// query's list.
 template <int UH>  // 16-byte units per half row (d / 32)
 __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int64_t m, I8Bounds ib, const uint4* __restrict__ q8,
                                                                  const uint4* __restrict__ b8, const unsigned* __restrict__ qmax,
                                                                  int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
                                                                  const unsigned* __restrict__ bin_cnt, const int* __restrict__ bins) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rescan_smem[];
-    uint4* l_q8 = reinterpret_cast<uint4*>(rescan_smem);  // [RESCAN_BIN_CAP][2 UH]
-    __shared__ int l_q[RESCAN_BIN_CAP];
-    __shared__ float l_sc[RESCAN_BIN_CAP], l_bound[RESCAN_BIN_CAP], l_qlow[RESCAN_BIN_CAP];
+    uint4* l_q8 = reinterpret_cast<uint4*>(rescan_smem);  // [RESCAN_BATCH][2 UH]
+    __shared__ int l_q[RESCAN_BATCH];
+    __shared__ float l_sc[RESCAN_BATCH], l_bound[RESCAN_BATCH], l_qlow[RESCAN_BATCH];
     const int c = blockIdx.x;
     const unsigned filled = bin_cnt[c];
     if (filled == 0u) return;
@@ -355,41 +356,47 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
 #pragma unroll
         for (int k = 0; k < UH; ++k) bv[k] = src[k * 32];
     }
-    if (threadIdx.x < nq) {
-        const int qi = bins[(size_t)c * RESCAN_BIN_CAP + threadIdx.x];
-        const bool live = cand_cnt[qi] >= 0;   // (-2: below the gate, -1: already with the all-pairs kernel)
-        l_q[threadIdx.x] = live ? qi : -1;
-        const float eq = ib.qerr[qi];
-        const float sq = ib.qstep[qi >> 7], A = eq * 1.0001220703125f + 1.0e-6f, mult = 1.0001220703125f + eq;
-        l_sc[threadIdx.x] = sq * ib.bstep[c];       // the same expressions as match_rescan_kernel: the same rows pass
-        l_bound[threadIdx.x] = A + mult * ib.berr[c];
-        l_qlow[threadIdx.x] = key_float(qmax[qi]);
-    }
-    for (int i = threadIdx.x; i < nq * UNITS; i += 256) {
-        const int j = i / UNITS, u = i % UNITS;
-        const int qi = bins[(size_t)c * RESCAN_BIN_CAP + j];
-        l_q8[i] = q8[(size_t)(qi >> 5) * (UNITS * 32) + (size_t)u * 32 + (qi & 31)];
-    }
-    __syncthreads();
+    const int* bin = bins + (size_t)c * RESCAN_BIN_CAP;
+    const float bstep = ib.bstep[c], berr = ib.berr[c];
     const long long base = (long long)c * CHUNK_ROWS;
     const int rr = wave * 32 + (lane & 31);
-    for (int j = 0; j < nq; ++j) {
-        const int qi = l_q[j];
-        if (qi < 0) continue;
-        const uint4* qv8 = l_q8 + j * UNITS + (lane >> 5) * UH;
-        int acc = 0;
-#pragma unroll
-        for (int k = 0; k < UH; ++k) {
-            const uint4 qv = qv8[k];
-            acc = __builtin_amdgcn_sdot4((int)bv[k].x, (int)qv.x, acc, false);
-            acc = __builtin_amdgcn_sdot4((int)bv[k].y, (int)qv.y, acc, false);
-            acc = __builtin_amdgcn_sdot4((int)bv[k].z, (int)qv.z, acc, false);
-            acc = __builtin_amdgcn_sdot4((int)bv[k].w, (int)qv.w, acc, false);
+    for (int j0 = 0; j0 < nq; j0 += RESCAN_BATCH) {   // the bin, RESCAN_BATCH queries at a time
+        const int nb = nq - j0 < RESCAN_BATCH ? nq - j0 : RESCAN_BATCH;
+        if (j0) __syncthreads();
+        if (threadIdx.x < nb) {
+            const int qi = bin[j0 + threadIdx.x];
+            const bool live = cand_cnt[qi] >= 0;   // (-2: below the gate, -1: already with the all-pairs kernel)
+            l_q[threadIdx.x] = live ? qi : -1;
+            const float eq = ib.qerr[qi];
+            const float sq = ib.qstep[qi >> 7], A = eq * 1.0001220703125f + 1.0e-6f, mult = 1.0001220703125f + eq;
+            l_sc[threadIdx.x] = sq * bstep;          // the same expressions as match_rescan_kernel: the same rows pass
+            l_bound[threadIdx.x] = A + mult * berr;
+            l_qlow[threadIdx.x] = key_float(qmax[qi]);
         }
-        acc += __shfl_xor(acc, 32);
-        if (lane < 32 && base + rr < m && l_sc[j] * (float)acc + l_bound[j] >= l_qlow[j]) {
-            const int pos = atomicAdd(&cand_cnt[qi], 1);
-            if (pos < cap) cand[(size_t)qi * cap + pos] = ((unsigned)c << 8) | (unsigned)rr;
+        for (int i = threadIdx.x; i < nb * UNITS; i += 256) {
+            const int j = i / UNITS, u = i % UNITS;
+            const int qi = bin[j0 + j];
+            l_q8[i] = q8[(size_t)(qi >> 5) * (UNITS * 32) + (size_t)u * 32 + (qi & 31)];
+        }
+        __syncthreads();
+        for (int j = 0; j < nb; ++j) {
+            const int qi = l_q[j];
+            if (qi < 0) continue;
+            const uint4* qv8 = l_q8 + j * UNITS + (lane >> 5) * UH;
+            int acc = 0;
+#pragma unroll
+            for (int k = 0; k < UH; ++k) {
+                const uint4 qv = qv8[k];
+                acc = __builtin_amdgcn_sdot4((int)bv[k].x, (int)qv.x, acc, false);
+                acc = __builtin_amdgcn_sdot4((int)bv[k].y, (int)qv.y, acc, false);
+                acc = __builtin_amdgcn_sdot4((int)bv[k].z, (int)qv.z, acc, false);
+                acc = __builtin_amdgcn_sdot4((int)bv[k].w, (int)qv.w, acc, false);
+            }
+            acc += __shfl_xor(acc, 32);
+            if (lane < 32 && base + rr < m && l_sc[j] * (float)acc + l_bound[j] >= l_qlow[j]) {
+                const int pos = atomicAdd(&cand_cnt[qi], 1);
+                if (pos < cap) cand[(size_t)qi * cap + pos] = ((unsigned)c << 8) | (unsigned)rr;
+            }
         }
     }
 }
@@ -1153,7 +1160,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                                reinterpret_cast<int*>(w.rec_cnt), use_bins ? 1 : 0);
             VFM_CHECK_LAUNCH("match_rescan_kernel");
             if (use_bins) {
-                const size_t lds = (size_t)RESCAN_BIN_CAP * (size_t)(d / 16) * sizeof(uint4);
+                const size_t lds = (size_t)RESCAN_BATCH * (size_t)(d / 16) * sizeof(uint4);
 #define VFM_RESCAN_CHUNK(UH)                                                                                                  \
     hipLaunchKernelGGL(match_rescan_chunk_kernel<UH>, dim3((unsigned)a.nchunks), dim3(256), lds, st, n, m,                      \
                        i8_bounds(Q, B, true, records), (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, \

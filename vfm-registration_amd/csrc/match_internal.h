@@ -32,7 +32,8 @@ constexpr int CAND_CAP_MAX = 2048;  // candidate entries a query can hold = min(
 constexpr int REFINE_MIN = 3;     // queries with this many candidate entries (or a whole-chunk entry) go through the fp32 refinement
 constexpr int REFINE_MIN_I8 = 8;  // the same threshold for the row lists of the int8 pass (match_rescan_kernel)
 constexpr int REFINE_KEEP = 64;   // rows a query may keep after the refinement
-constexpr int RESCAN_BIN_CAP = 64;  // candidate queries a map chunk can collect for the chunk-major int8 rescan (the rest: query-major)
+constexpr int RESCAN_BIN_CAP = 512;  // candidate queries a map chunk can collect for the chunk-major int8 rescan (the rest: query-major)
+constexpr int RESCAN_BATCH = 64;     // ... of which match_rescan_chunk_kernel stages this many in LDS at a time
 constexpr int FILTER_LDS_ROWS = 1024;  // sparse fp16 records a query can hold (= SearchWs::rcap; match_filter_refine_kernel keeps them in LDS)
 constexpr int SPARSE_LREC_CAP = 1536;  // records a workgroup of the sparse coarse kernel buffers in LDS (12 KiB)
 constexpr float COARSE_OFFSET = 2.0f;   // accumulators start here: every coarse score is a

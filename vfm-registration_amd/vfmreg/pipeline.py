@@ -112,11 +112,12 @@ class RegistrationPipeline:
                        "prepare(map)")
             r.map_key = b_desc.data_ptr()
 
-    # Feedback thresholds, in rescanned chunks per query over all queries of the scan (tools/time_neardup.py, C2 size):
-    # best-score records -> top-2 records above RESCAN_LIMIT (0.5 per query: 1.50 vs 1.67 ms; 1.2: 1.57 vs 1.65; 6.2: 2.18 vs
-    # 1.84; 12.4: 3.38 vs 2.05; 99: 14.2 vs 3.6); top-2 records -> fp16 pass above TOP2_LIMIT (whole-chunk rescans + 1/32 per
-    # single row; never reached on the maps measured: the fp16 pass takes 4.4 ms where top-2 records take 3.6)
-    RESCAN_LIMIT = 2.5
+    # Feedback thresholds, in rescanned chunks per query over all queries of the scan (tools/time_neardup.py, C2 size, ms per
+    # registration with best-score vs top-2 records): 0.5 per query: 1.28 vs 1.53; 1.2: 1.33 vs 1.51; 6.2: 1.50 vs 1.73; 7.7: 1.81
+    # vs 1.85; 12.4: 2.01 vs 1.94; 31.6: 2.57 vs 2.28; 99: 10.8 vs 3.4 (the chunk-major rescan, match_rescan_chunk_kernel, moved
+    # the crossover from ~2.5 to ~10); top-2 records -> fp16 pass above TOP2_LIMIT (whole-chunk rescans + 1/32 per single row;
+    # never reached on the maps measured: the fp16 pass takes 4.2 ms where top-2 records take 3.4)
+    RESCAN_LIMIT = 10.0
     TOP2_LIMIT = 40
     REPROBE = 256       # registrations before one step back towards the cheaper kernel is probed
 
