@@ -96,7 +96,10 @@ int vfm_match_search_finish(const float *q, const void *q_prepared, int64_t n, c
  * is ignored (every query resolved).  The three calls of one search must come from the same family:
  *   _prepare2_gated (x1 = map, x2 = scan: writes what the gated search of x2 in x1 reads -- the int8 image alone where
  *                    the int8 pass runs)  ->  _search_coarse_gated  ->  _search_finish_gated;
- * operands prepared by vfm_match_prepare / vfm_match_prepare2 carry both images and serve either family. */
+ * operands prepared by vfm_match_prepare / vfm_match_prepare2 carry both images and serve either family.
+ * (The ungated calls above resolve every query and take the fp16 coarse pass, except for large searches -- from 8192 queries
+ * x 1e9 pairs on, where the int8 pass with packed top-2 records is the faster one even without a gate; the answers are the
+ * same either way.) */
 int vfm_match_prepare2_gated(const float *x1, int64_t rows1, void *prepared1, const float *x2, int64_t rows2,
                              void *prepared2, int d, vfm_stream_t stream);
 int vfm_match_search_coarse_gated(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
@@ -107,7 +110,8 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
                                   vfm_stream_t stream);
 /* The same two calls with the kind of record the int8 pass keeps per (query, 128-row chunk) -- the same value in both:
  *   VFM_RECORDS_BEST  the best score only (the default above): the cheapest coarse kernel; every candidate chunk of a
- *                     resolved query is rescanned in int8 (48 KB) to find its rows;
+ *                     resolved query is rescanned in int8 to find its rows (chunk-major where a map chunk collects many
+ *                     queries: the int8 map is then read once; otherwise 48 KB per candidate);
  *   VFM_RECORDS_TOP2  best and second-best score plus the best row's index: ~15 % more coarse-kernel time, but a candidate
  *                     chunk with one row inside the bounds is a single 1.5 KB row -- the choice for duplicate-rich maps,
  *                     where a query has tens of candidate chunks (vfm_match_search_rescans_async reports the load). */

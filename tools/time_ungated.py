@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Every query resolved (no gate): the fp16 pass (ungated call) against the int8 pass with best-score / packed top-2 records
-and gate = -inf.  Milliseconds for coarse + finish at C2 size, answers compared."""
+"""Every query resolved (no gate): the fp16 pass (ungated call with variant 5 = fp16 everywhere), the ungated call as the
+library routes it (int8 pass with top-2 records from 8192 queries x 1e9 pairs on), and the int8 pass with best-score / packed
+top-2 records and gate = -inf.  Milliseconds for coarse + finish, answers compared."""
 import ctypes as C
 import sys
 import time
@@ -20,7 +21,11 @@ Q, B = ops.PreparedRows(q), ops.PreparedRows(b)
 ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=torch.uint8, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 ref = None
-for label, records in (("fp16 pass (ungated)", None), ("int8, best-score records, gate -inf", 0), ("int8, top-2 records, gate -inf", 1)):
+for label, records in (("fp16 pass (ungated call, variant 5)", -5), ("ungated call, default routing", None),
+                       ("int8, best-score records, gate -inf", 0), ("int8, top-2 records, gate -inf", 1)):
+    lib.vfm_debug_set_coarse_variant(5 if records == -5 else 0)
+    if records == -5:
+        records = None
     idx = torch.empty(n, dtype=torch.int64, device="cuda")
     sim = torch.empty(n, dtype=torch.float32, device="cuda")
     ts = []
@@ -42,3 +47,4 @@ for label, records in (("fp16 pass (ungated)", None), ("int8, best-score records
     if ref is None:
         ref = (idx.clone(), sim.clone())
     print(f"{label}: {sorted(ts)[len(ts) // 2]:.2f} ms (coarse + finish), same answers {same}", flush=True)
+lib.vfm_debug_set_coarse_variant(0)

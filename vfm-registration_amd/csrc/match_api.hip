@@ -64,8 +64,12 @@ bool use_sparse(int d, int64_t n, int64_t m) {
 // rescan per candidate chunk, cheap when most unmatched queries stop at the gate and slower than the fp16 pass when every
 // query must be resolved -- so the ungated entry points keep the fp16 pass.  (variant 5 = fp16 pass everywhere, A/B)
 int g_i8_min_queries = 0;  // vfm_debug_set_i8_min_queries (A/B knob): the int8 pass wins at every size measured (300 x 50 000: 209 vs 244 us)
+// Ungated calls (every query resolved) take the int8 pass, with packed top-2 records, from 8192 queries x 1e9 pairs on
+// (tools/time_ungated.py, coarse + finish: 20 000 x 200 000 x 384 1.98 vs 2.69 ms, 20 000 x 50 000 x 256 0.55 vs 0.65,
+// 50 000 x 1 000 000 x 768 41.8 vs 74.2; below that the fp16 pass wins: 2000 x 200 000 0.39 vs 0.45, 300 x 50 000 0.15 vs 0.22).
 bool use_i8(int d, int64_t n, int64_t m, bool gated) {
-    return gated && i8_capable(d) && m < (1ll << 24) && n > g_i8_min_queries &&
+    const bool large = n >= 8192 && n * m >= 1000000000ll;
+    return (gated || large) && i8_capable(d) && m < (1ll << 24) && n > g_i8_min_queries &&
            (g_coarse_qsets == 0 || g_coarse_qsets == 10 || g_coarse_qsets == 12);
 }
 
@@ -122,6 +126,7 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
     }
     VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, search_zero_bytes(n, m), st));  // fb_count | qmax | rec_cnt | bin_cnt
     if (inner_product && use_i8(d, n, m, gated)) {
+        if (!gated) records = VFM_RECORDS_TOP2;  // no feedback loop behind an ungated call: the robust record kind
         a.Qh = Q.tiles8;
         a.Bh = B.tiles8;
         a.ib = I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr, records};

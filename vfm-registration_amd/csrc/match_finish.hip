@@ -1131,6 +1131,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     const CoarseArgs a = coarse_args(Q, B, w, n, m, coarse_qblock(d));
     const float w2 = 2.0f * (float)(d / 16 + 4 + 2) * 5.9604645e-8f;
     const bool i8 = use_i8(d, n, m, gated);
+    if (i8 && !gated) records = VFM_RECORDS_TOP2;  // as do_search_coarse chose
     if (!i8 && use_sparse(d, n, m)) {
         hipLaunchKernelGGL(match_filter_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d,
                            DEFAULT_WINDOW, w2, w.qmax, w.rec_cnt, w.rec, w.rcap, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
