@@ -243,6 +243,8 @@ def main():
     lib = _lib.load()
     if os.environ.get("VFM_VARIANT"):  # A/B runs (tools/r02_prof.sh): 4 = dense per-chunk records + select kernel
         lib.vfm_debug_set_coarse_variant(int(os.environ["VFM_VARIANT"]))
+    if os.environ.get("VFM_PREP_GRID"):  # A/B runs: workgroups of the operand-preparation kernel (-1 = one per 128-row group)
+        lib.vfm_debug_set_prep_grid(int(os.environ["VFM_PREP_GRID"]))
     if os.environ.get("VFM_SLICES"):   # A/B runs: number of map slices of the coarse pass (0 = heuristic)
         lib.vfm_debug_set_coarse_slices(int(os.environ["VFM_SLICES"]))
     n, m, d = args.n, args.m, DIM

@@ -335,6 +335,10 @@ int vfm_debug_match_stats(void *ws, int64_t n, int64_t m, int32_t *out64_host);
 int vfm_debug_set_match_stats(int on);
 /* ViT GEMM wave tile / prefetch depth for A/B runs: NT * 100 + PF for N <= 512 and N > 512 (see csrc/vit.hip) */
 int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
+/* A/B: workgroups of the int8 operand-preparation kernel (-1, default = one per 128-row group; 0 = one per compute unit, each
+ * walking several groups with the next group's rows read under the current group's quantisation and store: faster alone,
+ * slower beside the coarse kernel; n > 0 = n workgroups) */
+int vfm_debug_set_prep_grid(int workgroups);
 /* tests: the int8 image of a prepared operand (d = 256, 384) unpacked on the host -- q8_host[rows][d], and per row the
  * quantisation step of its 128-row group, its residual norm E and the group's maximum E.  Synchronises the device. */
 int vfm_debug_i8_rows(const void *prepared, int64_t rows, int d, int8_t *q8_host, float *step_host,

@@ -89,18 +89,11 @@ struct PrepOut {
     uint4* tiles8;    // int8 fragment tiles
 };
 template <bool F16, int NC = 2>
-__global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restrict__ x, int64_t rows, int d, PrepOut o, int groups1,
-                                                          const float* __restrict__ x2, int64_t rows2, PrepOut o2) {
+__global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restrict__ x1, int64_t rows1, int d, PrepOut o1, int groups1,
+                                                          const float* __restrict__ x2, int64_t rows2, PrepOut o2, int groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned amax_bits, emax_bits;
     constexpr int RPW = I8_GROUP / 16;  // rows per wave: 16 waves x 8 rows, all of them in registers between the two phases
-    int grp = blockIdx.x;
-    if (grp >= groups1) {  // uniform per workgroup: the second operand rides in the same grid
-        grp -= groups1;
-        x = x2;
-        rows = rows2;
-        o = o2;
-    }
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int nchunks = d >> 2;  // float4 chunks per row (<= 64 NC): lane l owns chunks l, l + 64 (, l + 128)
     unsigned char* img8 = smem;                                                  // [4 tiles][d/32 * 64 units][16]
@@ -109,11 +102,16 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
         amax_bits = 0u;
         emax_bits = 0u;
     }
-    // phase 1: the rows (read once), 1/|row| in the oracle's order, the group's largest normalised magnitude
+    // The kernel's registers allow one workgroup per compute unit, so a workgroup walks several groups (grid = compute
+    // units) and reads row j of its NEXT group as soon as row j of the current one has been quantised: the read of the next
+    // 196 KB runs under the quantisation, the LDS transpose and the store of the current group instead of after them.
+    // (a second operand -- x2, rows2, o2 -- rides in the same grid: groups >= groups1 are its groups)
     float4 v[RPW][NC];
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const int64_t r = (int64_t)grp * I8_GROUP + wave * RPW + j;
+    auto load_row = [&](int grp, int j) __attribute__((always_inline)) {
+        const bool second = grp >= groups1;
+        const float* x = second ? x2 : x1;
+        const int64_t rows = second ? rows2 : rows1;
+        const int64_t r = (int64_t)(second ? grp - groups1 : grp) * I8_GROUP + wave * RPW + j;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
@@ -127,7 +125,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
             }
             v[j][i] = t;
         }
-    }
+    };
     // Eight per-row sums per lane -> one per lane: a reduce-scatter over the xor-32 / 16 / 8 levels (the lane keeps half of
     // its rows at every level and adds the partner's partial of those rows), then the xor-4 / 2 / 1 levels on the single
     // value.  Every addition pairs the same two partials as row_sumsq_wave's butterfly (which computes each of them in both
@@ -145,125 +143,140 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
         q1 = q1 + __shfl_xor(q1, 1);
         return q1;
     };
-    float part[RPW];
+    if ((int)blockIdx.x < groups) {
 #pragma unroll
-    for (int j = 0; j < RPW; ++j) {  // lane-sequential over its chunks and elements, as row_sumsq_wave
-        float p = 0.0f;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            if (lane + 64 * i < nchunks) {
-                float t;
-                t = v[j][i].x * v[j][i].x; p = p + t;
-                t = v[j][i].y * v[j][i].y; p = p + t;
-                t = v[j][i].z * v[j][i].z; p = p + t;
-                t = v[j][i].w * v[j][i].w; p = p + t;
-            }
-        }
-        part[j] = p;
+        for (int j = 0; j < RPW; ++j) load_row(blockIdx.x, j);
     }
-    const float my_inv = inv_norm_from_sumsq(scatter8(part));  // of row lane >> 3: eight rows in one evaluation
-    if ((lane & 7) == 0) o.inv[(int64_t)grp * I8_GROUP + wave * RPW + (lane >> 3)] = my_inv;
-    float lmax = 0.0f;
+    for (int gidx = blockIdx.x; gidx < groups; gidx += gridDim.x) {
+        const bool second = gidx >= groups1;
+        const int grp = second ? gidx - groups1 : gidx;
+        const int64_t rows = second ? rows2 : rows1;
+        const PrepOut& o = second ? o2 : o1;
+        const int gnext = gidx + gridDim.x;
+        // phase 1: 1/|row| in the oracle's order, the group's largest normalised magnitude
+        float part[RPW];
 #pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const float iv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_inv), 8 * j));
+        for (int j = 0; j < RPW; ++j) {  // lane-sequential over its chunks and elements, as row_sumsq_wave
+            float p = 0.0f;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {  // normalised values exactly as faiss leaves them in fp32 (zero in the unused slots)
-            v[j][i].x = v[j][i].x * iv;
-            v[j][i].y = v[j][i].y * iv;
-            v[j][i].z = v[j][i].z * iv;
-            v[j][i].w = v[j][i].w * iv;
-            lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(v[j][i].x), fabsf(v[j][i].y)), fmaxf(fabsf(v[j][i].z), fabsf(v[j][i].w))));
-        }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
-    __syncthreads();  // amax_bits / emax_bits initialised
-    if (lane == 0 && lmax > 0.0f) atomicMax(&amax_bits, __float_as_uint(lmax));  // finite or +Inf: uint order == float order
-    __syncthreads();
-    const float amax = __uint_as_float(amax_bits);
-    const bool usable = amax > 0.0f && amax < 3.0e38f;
-    const float qstep = usable ? amax / 127.0f : 1.0f;
-    const float inv_qstep = usable ? 127.0f / amax : 0.0f;
-    // phase 2: quantise from the registers
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const int pr = wave * RPW + j;
-        const int t = pr >> 5, p = pr & 31;
-        float e2 = 0.0f;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nchunks) {
-                const float nv[4] = {v[j][i].x, v[j][i].y, v[j][i].z, v[j][i].w};
-                int qi[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float qf = rintf(nv[e] * inv_qstep);
-                    qf = fminf(fmaxf(qf, -127.0f), 127.0f);                // (a NaN becomes -127: any integer is valid,
-                    const float res = __builtin_fmaf(-qstep, qf, nv[e]);   //  the residual is measured: it turns E into Inf)
-                    e2 = __builtin_fmaf(res, res, e2);
-                    qi[e] = (int)qf;
-                }
-                // low bytes of the four integers: two byte permutes and an or
-                const unsigned packed = __builtin_amdgcn_perm((unsigned)qi[1], (unsigned)qi[0], 0x0c0c0400u) |
-                                        __builtin_amdgcn_perm((unsigned)qi[3], (unsigned)qi[2], 0x04000c0cu);
-                *reinterpret_cast<unsigned*>(img8 + (size_t)t * (d * 32) + (((c >> 3) * 2 + ((c >> 2) & 1)) * 32 + p) * 16 + (c & 3) * 4) = packed;
-                if constexpr (F16) {
-                    half4 h;
-                    h[0] = (_Float16)nv[0];
-                    h[1] = (_Float16)nv[1];
-                    h[2] = (_Float16)nv[2];
-                    h[3] = (_Float16)nv[3];
-                    const int s = c >> 2, hh = (c >> 1) & 1, sub = c & 1;
-                    *reinterpret_cast<half4*>(img16 + (size_t)t * (d * 32) + ((s * 2 + hh) * 32 + p) * 8 + sub * 4) = h;
+            for (int i = 0; i < NC; ++i) {
+                if (lane + 64 * i < nchunks) {
+                    float t;
+                    t = v[j][i].x * v[j][i].x; p = p + t;
+                    t = v[j][i].y * v[j][i].y; p = p + t;
+                    t = v[j][i].z * v[j][i].z; p = p + t;
+                    t = v[j][i].w * v[j][i].w; p = p + t;
                 }
             }
+            part[j] = p;
         }
-        part[j] = e2;
-    }
-    {
-        // |e|_2 of row lane >> 3, rounded up: the fp32 sum of d non-negative terms is within (d + 8) 2^-24 of exact, sqrtf
-        // within 2^-24
-        float en = sqrtf(scatter8(part)) * 1.000244140625f + 1.0e-30f;
-        if (!(en == en)) en = __builtin_inff();
-        const int64_t r = (int64_t)grp * I8_GROUP + wave * RPW + (lane >> 3);
-        if (r >= rows) en = 0.0f;
-        if ((lane & 7) == 0) {
-            o.err[r] = en;
-            if (en > 0.0f) atomicMax(&emax_bits, __float_as_uint(en));
+        const float my_inv = inv_norm_from_sumsq(scatter8(part));  // of row lane >> 3: eight rows in one evaluation
+        if ((lane & 7) == 0) o.inv[(int64_t)grp * I8_GROUP + wave * RPW + (lane >> 3)] = my_inv;
+        float lmax = 0.0f;
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const float iv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_inv), 8 * j));
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {  // normalised values exactly as faiss leaves them in fp32 (zero in the unused slots)
+                v[j][i].x = v[j][i].x * iv;
+                v[j][i].y = v[j][i].y * iv;
+                v[j][i].z = v[j][i].z * iv;
+                v[j][i].w = v[j][i].w * iv;
+                lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(v[j][i].x), fabsf(v[j][i].y)), fmaxf(fabsf(v[j][i].z), fabsf(v[j][i].w))));
+            }
         }
-    }
-    __syncthreads();
-    {
-        const int u8n = (d >> 5) * 64 * 4;  // uint4 units of the group's four int8 tiles
-        uint4* dst = o.tiles8 + (int64_t)grp * u8n;
-        const uint4* src = reinterpret_cast<const uint4*>(img8);
-        for (int u = threadIdx.x; u < u8n; u += 1024) {
-            const uint4 tq = src[u];
-            unsigned* po = reinterpret_cast<unsigned*>(dst + u);
-            __builtin_nontemporal_store(tq.x, po);
-            __builtin_nontemporal_store(tq.y, po + 1);
-            __builtin_nontemporal_store(tq.z, po + 2);
-            __builtin_nontemporal_store(tq.w, po + 3);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+        __syncthreads();  // amax_bits / emax_bits initialised; the previous group's image has left the LDS
+        if (lane == 0 && lmax > 0.0f) atomicMax(&amax_bits, __float_as_uint(lmax));  // finite or +Inf: uint order == float order
+        __syncthreads();
+        const float amax = __uint_as_float(amax_bits);
+        const bool usable = amax > 0.0f && amax < 3.0e38f;
+        const float qstep = usable ? amax / 127.0f : 1.0f;
+        const float inv_qstep = usable ? 127.0f / amax : 0.0f;
+        // phase 2: quantise from the registers; each row's registers then take the same row of the next group
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int pr = wave * RPW + j;
+            const int t = pr >> 5, p = pr & 31;
+            float e2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nchunks) {
+                    const float nv[4] = {v[j][i].x, v[j][i].y, v[j][i].z, v[j][i].w};
+                    int qi[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float qf = rintf(nv[e] * inv_qstep);
+                        qf = fminf(fmaxf(qf, -127.0f), 127.0f);                // (a NaN becomes -127: any integer is valid,
+                        const float res = __builtin_fmaf(-qstep, qf, nv[e]);   //  the residual is measured: it turns E into Inf)
+                        e2 = __builtin_fmaf(res, res, e2);
+                        qi[e] = (int)qf;
+                    }
+                    // low bytes of the four integers: two byte permutes and an or
+                    const unsigned packed = __builtin_amdgcn_perm((unsigned)qi[1], (unsigned)qi[0], 0x0c0c0400u) |
+                                            __builtin_amdgcn_perm((unsigned)qi[3], (unsigned)qi[2], 0x04000c0cu);
+                    *reinterpret_cast<unsigned*>(img8 + (size_t)t * (d * 32) + (((c >> 3) * 2 + ((c >> 2) & 1)) * 32 + p) * 16 + (c & 3) * 4) = packed;
+                    if constexpr (F16) {
+                        half4 h;
+                        h[0] = (_Float16)nv[0];
+                        h[1] = (_Float16)nv[1];
+                        h[2] = (_Float16)nv[2];
+                        h[3] = (_Float16)nv[3];
+                        const int s = c >> 2, hh = (c >> 1) & 1, sub = c & 1;
+                        *reinterpret_cast<half4*>(img16 + (size_t)t * (d * 32) + ((s * 2 + hh) * 32 + p) * 8 + sub * 4) = h;
+                    }
+                }
+            }
+            part[j] = e2;
+            if (gnext < groups) load_row(gnext, j);
         }
-    }
-    if constexpr (F16) {
-        const int u16n = (d >> 4) * 64 * 4;
-        uint4* dst = o.tiles + (int64_t)grp * u16n;
-        const uint4* src = reinterpret_cast<const uint4*>(img16);
-        for (int u = threadIdx.x; u < u16n; u += 1024) {
-            const uint4 tq = src[u];
-            unsigned* po = reinterpret_cast<unsigned*>(dst + u);
-            __builtin_nontemporal_store(tq.x, po);
-            __builtin_nontemporal_store(tq.y, po + 1);
-            __builtin_nontemporal_store(tq.z, po + 2);
-            __builtin_nontemporal_store(tq.w, po + 3);
+        {
+            // |e|_2 of row lane >> 3, rounded up: the fp32 sum of d non-negative terms is within (d + 8) 2^-24 of exact, sqrtf
+            // within 2^-24
+            float en = sqrtf(scatter8(part)) * 1.000244140625f + 1.0e-30f;
+            if (!(en == en)) en = __builtin_inff();
+            const int64_t r = (int64_t)grp * I8_GROUP + wave * RPW + (lane >> 3);
+            if (r >= rows) en = 0.0f;
+            if ((lane & 7) == 0) {
+                o.err[r] = en;
+                if (en > 0.0f) atomicMax(&emax_bits, __float_as_uint(en));
+            }
         }
-    }
-    if (threadIdx.x == 0) {
-        o.gstep[grp] = qstep;
-        o.gerr[grp] = __uint_as_float(emax_bits);
+        __syncthreads();
+        {
+            const int u8n = (d >> 5) * 64 * 4;  // uint4 units of the group's four int8 tiles
+            uint4* dst = o.tiles8 + (int64_t)grp * u8n;
+            const uint4* src = reinterpret_cast<const uint4*>(img8);
+            for (int u = threadIdx.x; u < u8n; u += 1024) {
+                const uint4 tq = src[u];
+                unsigned* po = reinterpret_cast<unsigned*>(dst + u);
+                __builtin_nontemporal_store(tq.x, po);
+                __builtin_nontemporal_store(tq.y, po + 1);
+                __builtin_nontemporal_store(tq.z, po + 2);
+                __builtin_nontemporal_store(tq.w, po + 3);
+            }
+        }
+        if constexpr (F16) {
+            const int u16n = (d >> 4) * 64 * 4;
+            uint4* dst = o.tiles + (int64_t)grp * u16n;
+            const uint4* src = reinterpret_cast<const uint4*>(img16);
+            for (int u = threadIdx.x; u < u16n; u += 1024) {
+                const uint4 tq = src[u];
+                unsigned* po = reinterpret_cast<unsigned*>(dst + u);
+                __builtin_nontemporal_store(tq.x, po);
+                __builtin_nontemporal_store(tq.y, po + 1);
+                __builtin_nontemporal_store(tq.z, po + 2);
+                __builtin_nontemporal_store(tq.w, po + 3);
+            }
+        }
+        if (threadIdx.x == 0) {
+            o.gstep[grp] = qstep;
+            o.gerr[grp] = __uint_as_float(emax_bits);
+            amax_bits = 0u;   // for the next group (read again only behind the next two barriers)
+            emax_bits = 0u;
+        }
     }
 }
 
@@ -294,6 +307,24 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x,
 
 inline PrepOut prep_out(const Prepared& p) { return PrepOut{p.inv, p.tiles, p.err, p.gstep, p.gerr, p.tiles8}; }
 
+// Workgroups of prep_chunk_kernel (vfm_debug_set_prep_grid): -1 (default) = one per 128-row group; 0 = one per compute unit,
+// each walking ceil(groups / grid) groups with the next group's rows read under the current group's quantisation and store
+// (the kernel's registers admit one workgroup per compute unit, so nothing else overlaps them); n > 0 = n workgroups.
+// Alone on the GPU the persistent form is the faster one (C2: 81 vs 109 us, 5.2 vs 3.9 TB/s); beside the coarse kernel of the
+// previous registration -- whose workgroups need a whole compute unit each -- the short workgroups interleave better
+// (791 vs 783 registrations/s over 300 steps, same box), and that is where the pipeline runs it.
+int g_prep_grid = -1;
+inline int prep_grid(int groups) {
+    static thread_local int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    int g = g_prep_grid > 0 ? g_prep_grid : (g_prep_grid < 0 ? groups : cus);
+    return g < groups ? g : groups;
+}
+
 // one or two operands (x2 may be NULL) in one launch.  want_f16 = false: only the int8 image (d = 256, 384), for operands that
 // will meet in an int8 search (use_i8): a third of the bytes written, a third of the LDS.
 int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2, int64_t rows2, void* prepared2, int d,
@@ -313,17 +344,19 @@ int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2
                                               hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * 768));
             attr_mark(attr_set);
         }
-        const dim3 grid((unsigned)(g1 + g2)), block(1024);
+        const int groups = g1 + g2;
+        int pg = prep_grid(groups);
+        const dim3 grid((unsigned)pg), block(1024);
         if (want_f16 && d <= 384) {  // both images from one read of the rows (144 KB of LDS at d = 384)
             hipLaunchKernelGGL((prep_chunk_kernel<true, 2>), grid, block, (size_t)I8_GROUP * d * 3, st, x1, rows1, d, prep_out(p1), g1, x2,
-                               rows2, prep_out(p2));
+                               rows2, prep_out(p2), groups);
         } else {
             if (d <= 512)
                 hipLaunchKernelGGL((prep_chunk_kernel<false, 2>), grid, block, (size_t)I8_GROUP * d, st, x1, rows1, d, prep_out(p1), g1, x2,
-                                   rows2, prep_out(p2));
+                                   rows2, prep_out(p2), groups);
             else
                 hipLaunchKernelGGL((prep_chunk_kernel<false, 3>), grid, block, (size_t)I8_GROUP * d, st, x1, rows1, d, prep_out(p1), g1, x2,
-                                   rows2, prep_out(p2));
+                                   rows2, prep_out(p2), groups);
             if (want_f16) {  // wider rows: the fp16 image by its own kernel (both images would not fit the LDS)
                 hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)(t1 + t2)), dim3(256), (size_t)d * 64, st, x1, rows1, d, p1.inv,
                                    p1.tiles, t1, x2, rows2, p2.inv, p2.tiles);
@@ -352,5 +385,10 @@ VFM_EXPORT int vfm_l2norm_rows_f32(float* x, int64_t n, int d, float* inv_out, v
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n, d,
                        inv_out);
     VFM_CHECK_LAUNCH("l2norm_rows_kernel");
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_debug_set_prep_grid(int workgroups) {
+    g_prep_grid = workgroups;
     return VFM_OK;
 }

@@ -86,6 +86,7 @@ SIGNATURES = {
     "vfm_debug_set_i8_min_queries": (C.c_int, [C.c_int]),
     "vfm_debug_set_coarse_window": (C.c_int, [C.c_float]),
     "vfm_debug_set_vit_gemm": (C.c_int, [C.c_int, C.c_int]),
+    "vfm_debug_set_prep_grid": (C.c_int, [C.c_int]),
     "vfm_debug_set_coarse_variant": (C.c_int, [C.c_int]),
     "vfm_debug_set_coarse_slices": (C.c_int, [C.c_int]),
     "vfm_debug_set_ransac_exact_only": (C.c_int, [C.c_int]),
