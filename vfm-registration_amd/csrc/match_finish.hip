@@ -401,19 +401,26 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
     }
 }
 
-// after both rescans: lists longer than their capacity go to the all-pairs kernel, crowded ones to the fp32 refinement
+// after the rescans: lists longer than their capacity go to the all-pairs kernel, crowded ones to the fp32 refinement's work
+// list -- appended with ONE atomic per wavefront (on duplicate-rich maps every query is crowded: 20 000 same-address atomics
+// took 190 us)
 __global__ __launch_bounds__(256) void match_rescan_close_kernel(int64_t n, int* __restrict__ cand_cnt, int cap,
                                                                  int* __restrict__ fb_count, int* __restrict__ fb_list,
                                                                  int* __restrict__ todo) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (q >= n) return;
-    const int cnt = cand_cnt[q];
+    const int lane = lane_id();
+    const int cnt = q < n ? cand_cnt[q] : 0;
     if (cnt > cap) {
         cand_cnt[q] = -1;
         fb_list[atomicAdd(fb_count, 1)] = (int)q;
-    } else if (cnt >= REFINE_MIN_I8) {
-        todo[atomicAdd(fb_count + 6, 1)] = (int)q;
     }
+    const bool crowded = cnt >= REFINE_MIN_I8 && cnt <= cap;
+    const unsigned long long bal = __ballot(crowded);
+    if (bal == 0ull) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(fb_count + 6, __popcll(bal));
+    base = __shfl(base, 0);
+    if (crowded) todo[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int)q;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
                                                            const uint4* __restrict__ b8, const unsigned* __restrict__ qmax,
                                                            int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
                                                            unsigned* __restrict__ hits, int hcap, int* __restrict__ fb_count,
-                                                           int* __restrict__ fb_list, int* __restrict__ todo, int defer_todo) {
+                                                           int* __restrict__ fb_list) {
     __shared__ uint4 l_q8[4][48];  // the query's int8 row, unit by unit (d <= 768)
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
@@ -645,10 +652,9 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
     }
     if (lane == 0) {
         cand_cnt[qi] = nhit;
-        // crowded: match_refine_kernel's work list (up to seven rows go straight to the fp64 decision: a handful of fp64
-        // dot products costs less than the latency of one refinement wave)
-        // (defer_todo: match_rescan_chunk_kernel still appends to the lists; match_rescan_close_kernel builds the work list)
-        if (nhit >= REFINE_MIN_I8 && !defer_todo) todo[atomicAdd(fb_count + 6, 1)] = (int)qi;
+        // (match_rescan_close_kernel builds the refinement's work list from the final counts: lists of eight rows or more;
+        // up to seven rows go straight to the fp64 decision -- a handful of fp64 dot products costs less than the latency
+        // of one refinement wave)
     }
 }
 
@@ -1157,8 +1163,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
         if (i8) {  // candidate chunks -> candidate rows (the record buffer of the fp16 pass is free: it holds the hit lists)
             hipLaunchKernelGGL(match_rescan_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, m, d, i8_bounds(Q, B, true, records),
                                (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt, w.cand, w.cap,
-                               reinterpret_cast<unsigned*>(w.rec), 2 * w.rcap, w.fb_count, w.fb_list,
-                               reinterpret_cast<int*>(w.rec_cnt), use_bins ? 1 : 0);
+                               reinterpret_cast<unsigned*>(w.rec), 2 * w.rcap, w.fb_count, w.fb_list);
             VFM_CHECK_LAUNCH("match_rescan_kernel");
             if (use_bins) {
                 const size_t lds = (size_t)RESCAN_BATCH * (size_t)(d / 16) * sizeof(uint4);
@@ -1175,10 +1180,10 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                 }
 #undef VFM_RESCAN_CHUNK
                 VFM_CHECK_LAUNCH("match_rescan_chunk_kernel");
-                hipLaunchKernelGGL(match_rescan_close_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, w.cand_cnt, w.cap,
-                                   w.fb_count, w.fb_list, reinterpret_cast<int*>(w.rec_cnt));
-                VFM_CHECK_LAUNCH("match_rescan_close_kernel");
             }
+            hipLaunchKernelGGL(match_rescan_close_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, w.cand_cnt, w.cap,
+                               w.fb_count, w.fb_list, reinterpret_cast<int*>(w.rec_cnt));
+            VFM_CHECK_LAUNCH("match_rescan_close_kernel");
             // (rec_cnt, unused by the int8 pass, holds the list of crowded queries; fb_count[6] its length)
             const unsigned grid = (unsigned)((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024);
             hipLaunchKernelGGL(match_refine_kernel, dim3(grid), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2, w.cand_cnt, w.cand,
