@@ -114,9 +114,13 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
  *                     queries: the int8 map is then read once; otherwise 48 KB per candidate);
  *   VFM_RECORDS_TOP2  best and second-best score plus the best row's index: ~15 % more coarse-kernel time, but a candidate
  *                     chunk with one row inside the bounds is a single 1.5 KB row -- the choice for duplicate-rich maps,
- *                     where a query has tens of candidate chunks (vfm_match_search_rescans_async reports the load). */
+ *                     where a query has tens of candidate chunks (vfm_match_search_rescans_async reports the load);
+ *   VFM_RECORDS_F16   not an int8 record kind: the fp16 coarse pass at every size, every query resolved (gate ignored) -- what
+ *                     a caller falls back to on maps so duplicate-rich that the int8 bounds admit hundreds of rows per query
+ *                     (operands must then carry the fp16 image: vfm_match_prepare / vfm_match_prepare2). */
 #define VFM_RECORDS_BEST 0
 #define VFM_RECORDS_TOP2 1
+#define VFM_RECORDS_F16 2
 int vfm_match_search_coarse_gated_r(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
                                     int d, void *ws, size_t ws_bytes, int records, vfm_stream_t stream);
 int vfm_match_search_finish_gated_r(const float *q, const void *q_prepared, int64_t n, const float *b,

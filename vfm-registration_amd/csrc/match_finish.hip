@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int c = cb + SELECT_GROUPS * u;
-                    rec[u] = (c < nchunks) ? partials[(size_t)c * npad + q] : make_uint2(0u, 0u);
+                    rec[u] = (c < nchunks) ? partials[((size_t)(q >> 5) * nchunks + c) * 32 + (q & 31)] : make_uint2(0u, 0u);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -165,6 +165,148 @@ __global__ __launch_bounds__(64 * SELECT_GROUPS) void match_select_kernel(const 
             fb_list[slot] = (int)q;
         } else {
             cand_cnt[q] = cnt;
+        }
+    }
+}
+
+// Packed top-2 records of the int8 pass ([query tile][chunk][32], 8 bytes each): the int8 / top-2 branch of
+// match_select_kernel laid out for the sweep, as match_select_best_kernel below.  A lane owns two consecutive queries of the
+// tile and one chunk of a block of four: a wave's load instruction covers 4 chunks x 32 queries = 1 KiB of consecutive
+// record bytes.  Queries that provably end below the gate record nothing (see match_select_best_kernel).
+constexpr int SELECT_TOP2_WAVES = 8;
+__global__ __launch_bounds__(64 * SELECT_TOP2_WAVES) void match_select_top2_kernel(
+    const uint2* __restrict__ recs, int nchunks, int64_t n, int first_pad_chunk, const unsigned* __restrict__ qmax,
+    const float* __restrict__ invq, I8Bounds ib, float gate, int chunk_lds, int* __restrict__ cand_cnt, unsigned* __restrict__ cand,
+    int cap, int* __restrict__ fb_count, int* __restrict__ fb_list, int stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char select_smem[];  // the chunks' (step, max E)
+    __shared__ int lcnt[32];
+    __shared__ int lresc[32];     // whole-chunk entries among them
+    __shared__ unsigned lub[32];  // float_key of the largest upper bound over the query's chunks
+    __shared__ unsigned lmaxe;
+    __shared__ int ldead[32];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int qt = blockIdx.x;
+    if (threadIdx.x < 32) {
+        lcnt[threadIdx.x] = 0;
+        lresc[threadIdx.x] = 0;
+        lub[threadIdx.x] = 0u;
+    }
+    if (threadIdx.x == 0) lmaxe = 0u;
+    __syncthreads();
+    float2* lchunk = reinterpret_cast<float2*>(select_smem);
+    if (chunk_lds) {
+        float me = 0.0f;
+        for (int c = threadIdx.x; c < nchunks; c += 64 * SELECT_TOP2_WAVES) {
+            const float2 v = make_float2(ib.bstep[c], ib.berr[c]);
+            lchunk[c] = v;
+            me = fmaxf(me, v.y);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) me = fmaxf(me, __shfl_xor(me, off));
+        if (lane == 0) atomicMax(&lmaxe, float_key(me));
+    }
+    __syncthreads();
+    const int lq = (lane & 15) * 2, lc = lane >> 4;
+    const int64_t q0 = (int64_t)qt * 32 + lq;   // the lane's two queries
+    const float sq = ib.qstep[q0 >> 7], slack = 1.0e-6f;
+    float A[2], mult[2], qlow[2], maxup[2];
+    unsigned deadmask = 0u;
+    const float maxe = chunk_lds ? key_float(lmaxe) : __builtin_inff();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float eq = ib.qerr[q0 + j];
+        A[j] = eq * 1.0001220703125f;
+        mult[j] = 1.0001220703125f + eq;
+        qlow[j] = key_float(qmax[q0 + j]);
+        maxup[j] = -__builtin_inff();
+        const bool dead = qlow[j] + 2.0f * (A[j] + mult[j] * maxe) + 1.0e-5f < gate;
+        deadmask |= dead ? (1u << j) : 0u;
+    }
+    const uint4* src = reinterpret_cast<const uint4*>(recs + (size_t)qt * nchunks * 32) + (lane & 15);
+    for (int c = first_pad_chunk; c < nchunks && deadmask; ++c) {  // padded chunks are not covered by qlow
+        const uint4 r = src[(size_t)c * 16];
+        const unsigned r1[2] = {r.x, r.z};
+        const float sc = sq * ib.bstep[c], be = ib.berr[c];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (!(sc * (float)((int)(r1[j] | 127u) - I8_OFFSET) + (A[j] + mult[j] * be + slack) < gate)) deadmask &= ~(1u << j);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (q0 + j >= n || invq[q0 + j] == 0.0f) deadmask |= 1u << j;
+        if (threadIdx.x < 16) ldead[lq + j] = (deadmask >> j) & 1u;
+    }
+    const int nblocks = (nchunks + 3) >> 2;
+    for (int cb0 = wave; cb0 < nblocks; cb0 += 8 * SELECT_TOP2_WAVES) {
+        uint4 rec[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int cb = cb0 + SELECT_TOP2_WAVES * u;
+            rec[u] = (cb * 4 + lc < nchunks) ? src[((size_t)cb * 4 + lc) * 16] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = (cb0 + SELECT_TOP2_WAVES * u) * 4 + lc;
+            if (c >= nchunks) continue;
+            const float2 cb2 = chunk_lds ? lchunk[c] : make_float2(ib.bstep[c], ib.berr[c]);
+            const float sc = sq * cb2.x;
+            const unsigned r1[2] = {rec[u].x, rec[u].z}, r2[2] = {rec[u].y, rec[u].w};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float bound = A[j] + mult[j] * cb2.y + slack;
+                const float up1 = sc * (float)((int)(r1[j] | 127u) - I8_OFFSET) + bound;
+                maxup[j] = fmaxf(maxup[j], up1);
+                if (up1 >= qlow[j] && !((deadmask >> j) & 1u)) {
+                    const int slot = atomicAdd(&lcnt[lq + j], 1);
+                    // the best row's index rides in the low 7 bits: a candidate chunk whose SECOND-best score cannot reach
+                    // qlow is a single-row entry and needs no rescan
+                    const float up2 = sc * (float)((int)(r2[j] | 63u) - I8_OFFSET) + bound;
+                    const unsigned rescan = (up2 >= qlow[j] || c >= first_pad_chunk) ? 1u : 0u;
+                    if (rescan) atomicAdd(&lresc[lq + j], 1);
+                    if (slot < cap) cand[(size_t)(q0 + j) * cap + slot] = ((unsigned)c << 8) | (rescan << 7) | (r1[j] & 127u);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float v = maxup[j];
+        v = fmaxf(v, __shfl_xor(v, 16));
+        v = fmaxf(v, __shfl_xor(v, 32));
+        if (lane < 16) atomicMax(&lub[lq + j], float_key(v));
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {   // one wave: the tile's 32 queries
+        const int qq = lane & 31;
+        const int64_t q = (int64_t)qt * 32 + qq;
+        const bool live = lane < 32 && q < n;
+        const int cnt = lcnt[qq];
+        // load figure (vfm_match_search_rescans_async): whole-chunk entries count 1, single-row entries 1/32 -- 48 KB of int8
+        // tiles against 1.5 KB of fp32 row
+        int mine = 0;
+        if (live && invq[q] != 0.0f && !(key_float(lub[qq]) < gate) && cnt <= cap) mine = lresc[qq] + ((cnt - lresc[qq]) >> 5);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
+        if (lane == 0 && mine > 0) atomicAdd(fb_count + 5, mine);
+        if (live) {
+            if (stats && invq[q] != 0.0f) {
+                atomicAdd(fb_count + 2, cnt);
+                int bin = 0;
+                while ((1 << bin) < cnt && bin < 15) ++bin;
+                atomicAdd(fb_count + 8 + bin, 1);
+            }
+            const bool dead = ldead[qq] != 0;
+            if (invq[q] == 0.0f) {
+                cand_cnt[q] = 0;  // zero query row: decided directly (index 0, score 0)
+            } else if (key_float(lub[qq]) < gate) {
+                cand_cnt[q] = -2;  // no row of the map can reach the caller's similarity gate
+            } else if (cnt > cap || dead) {
+                cand_cnt[q] = -1;  // overflow (or a "dead" query lifted past the gate after all): the all-pairs kernel decides
+                const int slot = atomicAdd(fb_count, 1);
+                fb_list[slot] = (int)q;
+            } else {
+                cand_cnt[q] = cnt;
+            }
         }
     }
 }
@@ -1136,7 +1278,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     SearchWs w = carve_search(ws, n, m);
     const CoarseArgs a = coarse_args(Q, B, w, n, m, coarse_qblock(d));
     const float w2 = 2.0f * (float)(d / 16 + 4 + 2) * 5.9604645e-8f;
-    const bool i8 = use_i8(d, n, m, gated);
+    const bool i8 = records != VFM_RECORDS_F16 && use_i8(d, n, m, gated);
     if (i8 && !gated) records = VFM_RECORDS_TOP2;  // as do_search_coarse chose
     if (!i8 && use_sparse(d, n, m)) {
         hipLaunchKernelGGL(match_filter_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d,
@@ -1148,7 +1290,12 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
         // best-score records with many queries per map chunk: the rescan runs chunk-major (match_rescan_chunk_kernel)
         const bool best = i8 && records == VFM_RECORDS_BEST && g_select_variant != 1;
         use_bins = best && g_select_variant != 2 && n >= 4 * (int64_t)a.nchunks;
-        if (best) {
+        if (i8 && records == VFM_RECORDS_TOP2 && g_select_variant != 1) {
+            hipLaunchKernelGGL(match_select_top2_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * SELECT_TOP2_WAVES),
+                               chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, (const uint2*)w.partials, a.nchunks, n,
+                               a.first_pad_chunk, (const unsigned*)w.qmax, Q.inv, i8_bounds(Q, B, true, records), gate, chunk_lds,
+                               w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
+        } else if (best) {
             hipLaunchKernelGGL(match_select_best_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * SELECT_BEST_WAVES),
                                chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, reinterpret_cast<const unsigned*>(w.partials),
                                a.nchunks, n, (const unsigned*)w.qmax, Q.inv, i8_bounds(Q, B, true, records), gate, chunk_lds, w.cand_cnt,

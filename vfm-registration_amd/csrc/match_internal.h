@@ -242,7 +242,10 @@ __device__ __forceinline__ unsigned coarse_emit_chunk(const CoarseArgs& a, unsig
     const int code = 63 - (int)(w1 & 63u);
     const int li = (code >> 4) * 32 + (code & 3) + 8 * ((code & 15) >> 2) + 4 * wh;  // row inside the chunk
     if (lane < 32 && qt < a.nq_tiles && chunk >= 0) {
-        a.partials[(size_t)chunk * a.npad + (size_t)qt * 32 + lane] = make_uint2((w1 & ~127u) | (unsigned)li, w2);
+        // int8 pass: [query tile][chunk][32] (a query tile's records are one contiguous stream for match_select_top2_kernel);
+        // fp16 pass: [chunk][npad]
+        const size_t at = a.ib.qerr ? ((size_t)qt * a.nchunks + (size_t)chunk) * 32 + lane : (size_t)chunk * a.npad + (size_t)qt * 32 + lane;
+        a.partials[at] = make_uint2((w1 & ~127u) | (unsigned)li, w2);
         if (chunk < a.first_pad_chunk) runmax = max(runmax, w1 & ~127u);
     }
     s1 = 0u;

@@ -23,7 +23,7 @@ with the int8 pass, whose kernel is half as long, prepare stream + two solve str
 
 ``coarse``: which coarse pass -- "int8" / "int8-top2" = the gated family of include/vfmreg.h with best-score / packed top-2
 records (queries that provably miss ``min_cosine`` stay unresolved: idx -1, sim -2.0; correspondences and pose are
-unaffected), "fp16" = the ungated family, "auto" (default) = best-score records until a search reports more than
+unaffected), "fp16" = the fp16 pass (VFM_RECORDS_F16: every query resolved), "auto" (default) = best-score records until a search reports more than
 ``RESCAN_LIMIT`` rescanned chunks per query (duplicate-rich maps), then top-2 records, then -- above ``TOP2_LIMIT`` -- the fp16
 pass, with a probe one step back every ``REPROBE`` registrations.  ``gate=False`` keeps the int8 pass but resolves every query.
 """
@@ -195,8 +195,9 @@ class RegistrationPipeline:
             _lib.check(lib.vfm_match_search_coarse_gated_r(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
                                                            r.sws.data_ptr(), r.sws.numel(), records, st), "search(coarse)")
         else:
-            _lib.check(lib.vfm_match_search_coarse(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
-                                                   r.sws.data_ptr(), r.sws.numel(), st), "search(coarse)")
+            # (VFM_RECORDS_F16 = 2: the fp16 pass explicitly -- the ungated calls route large searches to the int8 pass)
+            _lib.check(lib.vfm_match_search_coarse_gated_r(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
+                                                           r.sws.data_ptr(), r.sws.numel(), 2, st), "search(coarse)")
         rst = st
         if self.overlap:  # hand over to stage 2
             ev = torch.cuda.Event()
@@ -216,9 +217,9 @@ class RegistrationPipeline:
                 ev.record(solve if self.overlap else main)
                 self._pending.append((ev, slot, records))
         else:
-            _lib.check(lib.vfm_match_search_finish(q_desc.data_ptr(), r.qprep.data_ptr(), self.n, b_desc.data_ptr(),
-                                                   r.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(), r.sim.data_ptr(),
-                                                   r.sws.data_ptr(), r.sws.numel(), rst), "search(finish)")
+            _lib.check(lib.vfm_match_search_finish_gated_r(q_desc.data_ptr(), r.qprep.data_ptr(), self.n, b_desc.data_ptr(),
+                                                           r.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(), r.sim.data_ptr(),
+                                                           r.sws.data_ptr(), r.sws.numel(), float("-inf"), 2, rst), "search(finish)")
         _lib.check(lib.vfm_threshold_compact(r.sim.data_ptr(), r.idx.data_ptr(), self.n, float(self.min_cosine),
                                              r.keep.data_ptr(), r.count.data_ptr(), r.corres.data_ptr(),
                                              None, None, None, None, rst), "threshold_compact")
