@@ -22,9 +22,24 @@ _lib.load().vfm_debug_set_coarse_slices(int(os.environ.get("VFM_SLICES", "0")))
 n, m, d = 20000, 200000, 384
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 p = synth.make_pair_device(n, m, d, seed=42)
-for _ in range(reps):
-    # the gated family (int8 pass for d = 256 / 384) with the pipeline's gate; VFM_GATE=none -> the ungated call (fp16 pass)
-    g = os.environ.get("VFM_GATE", "0.8")
-    idx, sim = ops.match_ip_top1(p["q_desc"], p["b_desc"], ops.FAST, gate=None if g == "none" else float(g))
+lib = _lib.load()
+records = int(os.environ.get("VFM_RECORDS", "0"))   # 0 = best-score records (what bench.py's pipeline runs), 1 = packed top-2
+g = os.environ.get("VFM_GATE", "0.8")
+if g == "none":   # the ungated one-shot call
+    for _ in range(reps):
+        idx, sim = ops.match_ip_top1(p["q_desc"], p["b_desc"], ops.FAST)
+else:             # the gated family, split form, as vfmreg/pipeline.py calls it
+    q, b = p["q_desc"], p["b_desc"]
+    qb = torch.empty(lib.vfm_match_prepared_bytes(n, d), dtype=torch.uint8, device="cuda")
+    bb = torch.empty(lib.vfm_match_prepared_bytes(m, d), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=torch.uint8, device="cuda")
+    idx = torch.empty(n, dtype=torch.int64, device="cuda")
+    sim = torch.empty(n, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(reps):
+        _lib.check(lib.vfm_match_prepare2_gated(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, st))
+        _lib.check(lib.vfm_match_search_coarse_gated_r(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, st))
+        _lib.check(lib.vfm_match_search_finish_gated_r(q.data_ptr(), qb.data_ptr(), n, b.data_ptr(), bb.data_ptr(), m, d, idx.data_ptr(),
+                                                       sim.data_ptr(), ws.data_ptr(), ws.numel(), float(g), records, st))
 torch.cuda.synchronize()
 print("ok", int((idx == p["match"]).sum()), "unresolved", int((idx < 0).sum()))  # meaningless for ablated builds

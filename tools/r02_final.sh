@@ -17,3 +17,15 @@ cp $R/gpurun_out/pmc_coarse/pmc_match_coarse.json $O/ 2>/dev/null
 for i in 1 2 3 4 5 6 7; do cp $R/gpurun_out/pmc_coarse/p${i}_counter_collection.csv $O/pmc_pass${i}_counter_collection.csv 2>/dev/null; done
 cd $R && python tools/time_neardup.py --steps 20 --out $O/neardup.json > $O/neardup.log 2>&1
 python tools/time_prep.py > $O/time_prep.txt 2>&1; cat $O/time_prep.txt
+# second half of round 2: the timed region against its length, power / clock under load, ViT batch scaling, ungated routing,
+# C3 per coarse mode, what each side stage costs the steady state, CU-masked side streams
+bash tools/steps_sweep.sh > /dev/null 2>&1; cp $R/gpurun_out/steps_sweep.txt $O/steps_sweep.txt
+bash tools/power_probe.sh > /dev/null 2>&1; cp $R/gpurun_out/power_probe.txt $O/power_probe.txt
+timeout 300 python tools/time_vit_batch.py > $O/time_vit_batch.txt 2>/dev/null
+{ for s in "20000 200000 384" "2000 200000 384" "300 50000 384" "20000 50000 256" "50000 1000000 768"; do echo "## $s"; timeout 200 python tools/time_ungated.py $s 2>/dev/null; done; } > $O/time_ungated.txt
+timeout 300 python tools/time_c3_modes.py 2>/dev/null | tail -5 > $O/time_c3_modes.txt
+timeout 300 python tools/tax_probe.py 2>/dev/null > $O/tax_probe.txt
+{ for c in "0 0" "64 0" "0 64" "64 64" "0 0"; do timeout 100 python tools/cu_mask_probe.py $c 2>/dev/null; done; } > $O/cu_mask_probe.txt
+VFM_GATE=0.7999999 bash tools/prof_i8.sh 0 > $O/prof_search_c2.txt 2>&1
+bash tools/prof_c3.sh > $O/prof_c3.txt 2>&1
+tail -3 $O/steps_sweep.txt | cut -c1-200; cat $O/time_c3_modes.txt

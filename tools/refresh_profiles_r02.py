@@ -32,7 +32,12 @@ def main():
               "prof/bench_kernel_stats.csv": "r02_bench_kernel_stats.csv",
               "prof1/bench1_kernel_stats.csv": "r02_bench_streams1_kernel_stats.csv",
               "pmc_match_coarse.json": "r02_pmc_match_coarse_i8.json", "pytest_gpu.txt": "r02_pytest_gpu.txt",
-              "neardup.json": "r02_neardup.json", "time_prep.txt": "r02_time_prep.txt"}
+              "neardup.json": "r02_neardup.json", "time_prep.txt": "r02_time_prep.txt",
+              "steps_sweep.txt": "r02_steps_sweep.txt", "power_probe.txt": "r02_power_probe.txt",
+              "time_vit_batch.txt": "r02_time_vit_batch.txt", "time_ungated.txt": "r02_time_ungated.txt",
+              "time_c3_modes.txt": "r02_time_c3_modes.txt", "tax_probe.txt": "r02_tax_probe.txt",
+              "cu_mask_probe.txt": "r02_cu_mask_probe.txt", "prof_search_c2.txt": "r02_prof_search_c2.txt",
+              "prof_c3.txt": "r02_prof_c3.txt"}
     for i in range(1, 8):
         copies[f"pmc_pass{i}_counter_collection.csv"] = f"r02_pmc_pass{i}_counter_collection.csv"
     for a, b in copies.items():
@@ -111,6 +116,15 @@ warm-up in brackets), and with each mode forced (int8 = best-score records, int8
 | map | auto | int8 | int8-top2 | fp16 | same correspondences + pose | all-pairs fallbacks |
 |---|---|---|---|---|---|---|
 {nd_rows}
+
+## Second half of the round (files next to this one)
+
+`r02_steps_sweep.txt` (registrations/s against the number of timed steps, with the coarse kernel's duration per step: the
+first ~15 launches after the synchronise run slower), `r02_power_probe.txt` (rocm-smi power / clocks under an 8000-step
+run), `r02_tax_probe.txt` (steady state with side stages replaced by no-ops), `r02_cu_mask_probe.txt` (side stages on
+CU-masked streams: slower in every split), `r02_prof_search_c2.txt` (kernels of one gated C2 search), `r02_prof_c3.txt` +
+`r02_time_c3_modes.txt` (C3's registration per coarse mode), `r02_time_ungated.txt` (ungated calls: fp16 pass vs the
+routing by size), `r02_time_vit_batch.txt` (ViT forward against the number of images per call).
 
 ## Other evidence files
 
