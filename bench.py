@@ -352,10 +352,12 @@ def main():
         print("[trace] host time after each step's launches, ms: " + " ".join(f"{x * 1e3:.2f}" for x in host_t[:64]),
               file=sys.stderr, flush=True)
 
+    mode_i8, mode_half, mode_top2 = bool(pipe.use_i8), bool(pipe.use_i8 and pipe.half), bool(pipe.use_i8 and pipe.top2 and not pipe.half)
     # the same kernel without the concurrent RANSAC stream (information only; not part of `value`)
     iso = []
     if S == 2:
-        pipe1 = RegistrationPipeline(n, m, d, n_iter=args.iters, device=dev, overlap_ransac=False)
+        pipe1 = RegistrationPipeline(n, m, d, n_iter=args.iters, device=dev, overlap_ransac=False,
+                                     coarse=("int8-half" if mode_half else "int8-top2" if mode_top2 else "int8" if mode_i8 else "fp16"))
         a, b = C.c_void_p(), C.c_void_p()
         _lib.check(lib.vfm_prof_events_create(C.byref(a), C.byref(b)))
         for i in range(6):
@@ -376,16 +378,24 @@ def main():
     T0 = all_poses[0].cpu().numpy()  # global pair 0 lives on rank 0
 
     if rank == 0:
-        flops = 2.0 * n * m * d
+        # which coarse pass ran: the int8 one for d = 256 ... 768 unless an A/B variant forces the fp16 pass; of the int8 pass the
+        # kind the pipeline ended the timed region in (vfmreg/pipeline.py: the half-width pass over the first d / 2 columns while
+        # few chunks survive it -- D.2 descriptors -- else best-score / packed top-2 records over all d)
+        i8 = d in (256, 384, 512, 640, 768) and os.environ.get("VFM_VARIANT", "0") in ("0", "10", "12") and mode_i8
+        half = i8 and mode_half
+        kcols = d // 2 if half else d
+        flops = 2.0 * n * m * kcols   # what the dominant kernel computes per launch
         achieved = flops / (coarse_ms * 1e-3) / 1e12
-        # which coarse pass ran: the int8 one for d = 256 / 384 unless an A/B variant forces the fp16 pass
-        i8 = d in (256, 384, 512, 640, 768) and os.environ.get("VFM_VARIANT", "0") in ("0", "10", "12")
         peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS
-        kernel = ("match_coarse_i8q2_kernel<12> (int8 32x32x32 MFMA, 64 resident queries per wave, exact integer scores, one best-score record "
-                  "per (query, chunk))" if i8
+        kernel = ((f"match_coarse_i8q2_kernel<{kcols // 32}> (int8 32x32x32 MFMA over the first {kcols} of {d} columns -- the half-width pass: the "
+                   "other half is bounded by Cauchy-Schwarz against the cosine gate and only surviving chunks are scored over all columns -- "
+                   "64 resident queries per wave, exact integer scores, one best-score record per (query, chunk))") if half
+                  else ("match_coarse_i8q2_kernel<12> (int8 32x32x32 MFMA, 64 resident queries per wave, exact integer scores, "
+                        + ("packed top-2 records" if mode_top2 else "one best-score record per (query, chunk)") + ")") if i8
                   else "match_coarse_pipe_kernel<24, true> (fp16 32x32x16 MFMA, sparse row-level records)")
         traffic, traffic_src = None, None  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
-        for name in (("r02_pmc_match_coarse_i8.json",) if i8 else ("r02_pmc_match_coarse_f16.json", "r01_pmc_match_coarse.json")):
+        for name in ((("r02_pmc_match_coarse_i8half.json",) if half else ("r02_pmc_match_coarse_i8.json",)) if i8
+                     else ("r02_pmc_match_coarse_f16.json", "r01_pmc_match_coarse.json")):
             pmc = ROOT / "profiles" / name
             if pmc.exists() and (n, m, d) == (N_SCAN, N_MAP, DIM):
                 traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
@@ -406,7 +416,9 @@ def main():
                        "parallelism": f"{world} GPU shard(s) x {S} stream(s), independent scene pairs (pair p -> rank p mod N)",
                        "collective": (f"one all_gather_into_tensor of the poses ({dist.get_backend()} = RCCL)" if grouped
                                       else "none (single process, no launcher)"),
-                       "correspondences_last_step": ncorr, "max_pose_err_vs_planted": max(errs)},
+                       "correspondences_last_step": ncorr, "max_pose_err_vs_planted": max(errs),
+                       "coarse_pass": ("int8, half-width (VFM_RECORDS_HALF)" if half else "int8, packed top-2 records" if (i8 and mode_top2)
+                                       else "int8, best-score records" if i8 else "fp16")},
             "per_rank_registrations_per_s": per_rank,
             "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

@@ -121,6 +121,18 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
 #define VFM_RECORDS_BEST 0
 #define VFM_RECORDS_TOP2 1
 #define VFM_RECORDS_F16 2
+/*   VFM_RECORDS_HALF  the half-width pass (needs a finite gate and operands from vfm_match_prepare2_gated): the int8 coarse
+ *                     pass over the FIRST d / 2 columns only -- half the matrix work -- with best-score records.  A (query,
+ *                     chunk) pair survives if  partial score + quantisation bound + |rest of the query| * max |rest of a row
+ *                     of the chunk|  can reach the gate (Cauchy-Schwarz on the other half of the columns); the survivors'
+ *                     rows are scored over all d columns by the int8 rescan, and a query is resolved iff its exact best
+ *                     similarity reaches the gate (every other query: idx -1, sim -2.0 -- it provably has no match).  On
+ *                     descriptors whose matches stand clear of the background (the benchmark's D.2 data: 0.9 against <= 0.3)
+ *                     almost nothing survives; on descriptors that are all alike everything does, and the call is slower
+ *                     than VFM_RECORDS_BEST: vfm_match_search_rescans_async reports the survivors for that decision.
+ *                     Exists for d = 256 / 384 with more than 2048 queries and for d = 512 / 768; elsewhere the call
+ *                     behaves as VFM_RECORDS_BEST. */
+#define VFM_RECORDS_HALF 3
 int vfm_match_search_coarse_gated_r(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
                                     int d, void *ws, size_t ws_bytes, int records, vfm_stream_t stream);
 int vfm_match_search_finish_gated_r(const float *q, const void *q_prepared, int64_t n, const float *b,

@@ -128,9 +128,11 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
     VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, search_zero_bytes(n, m), st));  // fb_count | qmax | rec_cnt | bin_cnt
     if (i8) {
         if (!gated) records = VFM_RECORDS_TOP2;  // no feedback loop behind an ungated call: the robust record kind
-        a.Qh = Q.tiles8;
-        a.Bh = B.tiles8;
-        a.ib = I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr, records};
+        records = effective_records(records, d, n);
+        const bool half = records == VFM_RECORDS_HALF;   // the image of the first d / 2 columns
+        a.Qh = half ? Q.tiles8h : Q.tiles8;
+        a.Bh = half ? B.tiles8h : B.tiles8;
+        a.ib = I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr, records == VFM_RECORDS_TOP2 ? 1 : 0};
         return launch_coarse_int8(a, d, n, records, st);
     }
     return launch_coarse_f16(a, d, st);
@@ -219,7 +221,7 @@ VFM_EXPORT int vfm_match_search_coarse_gated_r(const void* q_prepared, int64_t n
                                                void* ws, size_t ws_bytes, int records, vfm_stream_t stream) {
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q_prepared && b_prepared && ws, "search_coarse: null pointer");
-    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_F16, "search_coarse: unknown record kind %d", records);
+    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_HALF, "search_coarse: unknown record kind %d", records);
     return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream, false, true, true, records);
 }
 
@@ -236,7 +238,7 @@ VFM_EXPORT int vfm_match_search_finish_gated_r(const float* q, const void* q_pre
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q && b && q_prepared && b_prepared && ws && idx_out && sim_out, "search_finish: null pointer");
     VFM_CHECK_ARG(gate == gate, "search_finish: gate is NaN");
-    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_F16, "search_finish: unknown record kind %d", records);
+    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_HALF, "search_finish: unknown record kind %d", records);
     return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream, true, gate, records);
 }
 

@@ -173,8 +173,8 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a)
     constexpr int TILE_BYTES = TILE_U4 * 16;
     constexpr int PIECES = T * KSTEPS / NWAVES;  // 1 KiB pieces per wave per step: 6 (d = 384) or 4 (d = 256)
     constexpr int NBUF = 3 * T;
-    constexpr int PF = 4;
-    static_assert(KSTEPS % PF == 0 && KSTEPS >= 2 * PF && PIECES <= 2 * T, "shape");
+    constexpr int PF = (KSTEPS % 4 == 0 && KSTEPS >= 8) ? 4 : (KSTEPS % 3 == 0 ? 3 : 2);  // fragment look-ahead in k-steps
+    static_assert(KSTEPS % PF == 0 && KSTEPS >= 2 * PF && PIECES <= 2 * T && (T * KSTEPS) % NWAVES == 0, "shape");
     static_assert(NBUF * TILE_BYTES <= 160 * 1024, "ring exceeds the LDS");
 
     const int lane = lane_id();
@@ -349,9 +349,18 @@ int launch_coarse_int8(CoarseArgs& a, int d, int64_t n, int records, hipStream_t
     a.nqb = (int)(rows_padded(n) / QBLOCK);  // 8 waves x 32 queries at every width
     a.nslices = choose_slices(a.nqb, a.nchunks);
     if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
-    const bool top2 = records != 0;
+    const bool top2 = records == VFM_RECORDS_TOP2;
     int rc8;
-    if (d <= 384 && n > 2048 && g_coarse_qsets == 0) {
+    if (records == VFM_RECORDS_HALF) {
+        // the half-width pass: the same kernels on the image of the first d / 2 columns (a.Qh / a.Bh = tiles8h), best-score records
+        if (d <= 384) {
+            a.nqb = (a.nq_tiles + 15) / 16;
+            a.nslices = choose_slices(a.nqb, a.nchunks);
+            rc8 = d == 384 ? launch_coarse_i8q2<6, false>(a, st) : launch_coarse_i8q2<4, false>(a, st);
+        } else {
+            rc8 = d == 768 ? launch_coarse_i8<12, 4>(a, st) : launch_coarse_i8<8, 4>(a, st);
+        }
+    } else if (d <= 384 && n > 2048 && g_coarse_qsets == 0) {
         // 64 resident queries per wave: 11-15 % faster than the one-set kernel from ~3000 queries on (C2: 1.09 vs 1.23 ms;
         // 1500 x 100 000: 0.059 vs 0.056 ms -- half as many, twice as large workgroups); variants 10 / 12 = one set, A/B
         a.nqb = (a.nq_tiles + 15) / 16;

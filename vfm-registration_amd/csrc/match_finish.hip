@@ -311,6 +311,117 @@ __global__ __launch_bounds__(64 * SELECT_TOP2_WAVES) void match_select_top2_kern
     }
 }
 
+// Half-width pass (VFM_RECORDS_HALF): the records hold the best integer score of every (query, chunk) over the FIRST d / 2
+// columns.  With r_q = |second half of the normalised query|, R_c = max over the chunk's rows of |second half of the row|
+// (both rounded up, prep_chunk_kernel) and the quantisation bound A + B_c of the full rows (an upper bound for any subset of
+// columns):      best exact score of chunk c  <=  s_q s_c S_half(c) + A + B_c + r_q R_c       (Cauchy-Schwarz on the other half)
+// A chunk survives for a query iff that bound reaches the gate; the survivors are binned per chunk (or left in the query's
+// list) for the full-width int8 rescan, whose hit test is then the gate itself.  A query without survivors provably has no
+// match (cand_cnt = -2).  Same sweep layout as match_select_best_kernel.
+__global__ __launch_bounds__(64 * 8) void match_select_half_kernel(
+    const unsigned* __restrict__ best, int nchunks, int64_t n, const float* __restrict__ invq, I8Bounds ib,
+    const float* __restrict__ qrest, const float* __restrict__ grest, float gate, int chunk_lds, int* __restrict__ cand_cnt,
+    unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count, int* __restrict__ fb_list, int stats,
+    unsigned* __restrict__ bin_cnt, int* __restrict__ bins) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char select_smem[];  // the chunks' (step, max E) and max |rest|
+    __shared__ int lcnt[32];
+    __shared__ int lov[32];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int qt = blockIdx.x;
+    if (threadIdx.x < 32) {
+        lcnt[threadIdx.x] = 0;
+        lov[threadIdx.x] = 0;
+    }
+    float2* lchunk = reinterpret_cast<float2*>(select_smem);
+    float* lrest = reinterpret_cast<float*>(lchunk + nchunks);
+    if (chunk_lds)
+        for (int c = threadIdx.x; c < nchunks; c += 64 * 8) {
+            lchunk[c] = make_float2(ib.bstep[c], ib.berr[c]);
+            lrest[c] = grest[c];
+        }
+    __syncthreads();
+    const int lq = (lane & 7) * 4, lc = lane >> 3;
+    const int64_t q0 = (int64_t)qt * 32 + lq;   // the lane's four queries (rows of the padded tile always exist)
+    const float sq = ib.qstep[q0 >> 7], slack = 1.0e-6f;
+    float A[4], mult[4], rq[4];
+    unsigned livemask = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float eq = ib.qerr[q0 + j];
+        A[j] = eq * 1.0001220703125f;
+        mult[j] = 1.0001220703125f + eq;
+        rq[j] = qrest[q0 + j];
+        if (q0 + j < n && invq[q0 + j] != 0.0f) livemask |= 1u << j;
+    }
+    const uint4* src = reinterpret_cast<const uint4*>(best + (size_t)qt * nchunks * 32) + lane;
+    const int nblocks = (nchunks + 7) >> 3;
+    for (int cb0 = wave; cb0 < nblocks; cb0 += 8 * 8) {
+        uint4 rec[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int cb = cb0 + 8 * u;
+            rec[u] = (cb * 8 + lc < nchunks) ? src[(size_t)cb * 64] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = (cb0 + 8 * u) * 8 + lc;
+            if (c >= nchunks) continue;
+            const float2 cb2 = chunk_lds ? lchunk[c] : make_float2(ib.bstep[c], ib.berr[c]);
+            const float rb = chunk_lds ? lrest[c] : grest[c];
+            const float sc = sq * cb2.x;
+            const unsigned r4[4] = {rec[u].x, rec[u].y, rec[u].z, rec[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // fp32 evaluation: five roundings on magnitudes <= 2 -- 2e-6 of slack covers them
+                const float up = sc * (float)((int)r4[j] - I8_OFFSET) + (A[j] + mult[j] * cb2.y + slack) + (rq[j] * rb + slack);
+                if (!(up < gate) && ((livemask >> j) & 1u)) {
+                    int slot = atomicAdd(&lcnt[lq + j], 1);
+                    if (bins) {
+                        const unsigned pos = atomicAdd(&bin_cnt[c], 1u);
+                        if (pos < (unsigned)RESCAN_BIN_CAP) {
+                            bins[(size_t)c * RESCAN_BIN_CAP + pos] = (int)(q0 + j);
+                            slot = cap;
+                        } else {
+                            slot = atomicAdd(&lov[lq + j], 1);
+                        }
+                    }
+                    if (slot < cap) cand[(size_t)(q0 + j) * cap + slot] = ((unsigned)c << 8) | 128u;  // whole-chunk entry
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {   // one wave: the tile's 32 queries
+        const int qq = lane & 31;
+        const int64_t q = (int64_t)qt * 32 + qq;
+        const bool live = lane < 32 && q < n;
+        const int cnt = lcnt[qq];
+        int mine = (live && cnt <= cap) ? cnt : 0;   // load figure (vfm_match_search_rescans_async): surviving chunks
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
+        if (lane == 0 && mine > 0) atomicAdd(fb_count + 5, mine);
+        if (live) {
+            if (stats && invq[q] != 0.0f) {
+                atomicAdd(fb_count + 2, cnt);
+                int bin = 0;
+                while ((1 << bin) < cnt && bin < 15) ++bin;
+                atomicAdd(fb_count + 8 + bin, 1);
+            }
+            if (invq[q] == 0.0f) {
+                cand_cnt[q] = 0;  // zero query row: decided directly (index 0, score 0)
+            } else if (cnt == 0) {
+                cand_cnt[q] = -2;  // no chunk can hold a row at the gate
+            } else if (cnt > cap) {
+                cand_cnt[q] = -1;  // more surviving chunks than a list holds: the all-pairs kernel decides
+                const int slot = atomicAdd(fb_count, 1);
+                fb_list[slot] = (int)q;
+            } else {
+                cand_cnt[q] = bins ? lov[qq] : cnt;
+            }
+        }
+    }
+}
+
 // Best-score records of the int8 pass ([query tile][chunk][32], 4 bytes each): the same decision as the int8 branch of
 // match_select_kernel, laid out for the sweep.  One workgroup per query tile; a lane owns four consecutive queries of the
 // tile and one chunk of a block of eight, so a wave's load instruction covers 8 chunks x 32 queries = 1 KiB of consecutive
@@ -480,7 +591,8 @@ template <int UH>  // 16-byte units per half row (d / 32)
 __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int64_t m, I8Bounds ib, const uint4* __restrict__ q8,
                                                                  const uint4* __restrict__ b8, const unsigned* __restrict__ qmax,
                                                                  int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
-                                                                 const unsigned* __restrict__ bin_cnt, const int* __restrict__ bins) {
+                                                                 const unsigned* __restrict__ bin_cnt, const int* __restrict__ bins,
+                                                                 int use_gate, float gate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rescan_smem[];
     uint4* l_q8 = reinterpret_cast<uint4*>(rescan_smem);  // [RESCAN_BATCH][2 UH]
     __shared__ int l_q[RESCAN_BATCH];
@@ -513,7 +625,7 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
             const float sq = ib.qstep[qi >> 7], A = eq * 1.0001220703125f + 1.0e-6f, mult = 1.0001220703125f + eq;
             l_sc[threadIdx.x] = sq * bstep;          // the same expressions as match_rescan_kernel: the same rows pass
             l_bound[threadIdx.x] = A + mult * berr;
-            l_qlow[threadIdx.x] = key_float(qmax[qi]);
+            l_qlow[threadIdx.x] = use_gate ? gate : key_float(qmax[qi]);   // half-width pass: the hit test is the gate itself
         }
         for (int i = threadIdx.x; i < nb * UNITS; i += 256) {
             const int j = i / UNITS, u = i % UNITS;
@@ -548,10 +660,12 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
 // took 190 us)
 __global__ __launch_bounds__(256) void match_rescan_close_kernel(int64_t n, int* __restrict__ cand_cnt, int cap,
                                                                  int* __restrict__ fb_count, int* __restrict__ fb_list,
-                                                                 int* __restrict__ todo) {
+                                                                 int* __restrict__ todo, const float* __restrict__ invq_half) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = lane_id();
     const int cnt = q < n ? cand_cnt[q] : 0;
+    // half-width pass (invq_half != NULL): a live query whose surviving chunks held no row at the gate has no match
+    if (invq_half && q < n && cnt == 0 && invq_half[q] != 0.0f) cand_cnt[q] = -2;
     if (cnt > cap) {
         cand_cnt[q] = -1;
         fb_list[atomicAdd(fb_count, 1)] = (int)q;
@@ -707,7 +821,7 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
                                                            const uint4* __restrict__ b8, const unsigned* __restrict__ qmax,
                                                            int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
                                                            unsigned* __restrict__ hits, int hcap, int* __restrict__ fb_count,
-                                                           int* __restrict__ fb_list) {
+                                                           int* __restrict__ fb_list, int use_gate, float gate) {
     __shared__ uint4 l_q8[4][48];  // the query's int8 row, unit by unit (d <= 768)
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
@@ -720,7 +834,7 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
     if (lane < units8) l_q8[wave][lane] = q8[(size_t)(qi >> 5) * (units8 * 32) + (size_t)lane * 32 + (qi & 31)];
     const float eq = ib.qerr[qi];
     const float sq = ib.qstep[qi >> 7], A = eq * 1.0001220703125f + 1.0e-6f, mult = 1.0001220703125f + eq;
-    const float qlow = key_float(qmax[qi]);
+    const float qlow = use_gate ? gate : key_float(qmax[qi]);   // half-width pass: the hit test is the gate itself
     __builtin_amdgcn_wave_barrier();
     int nhit = 0;  // wave-uniform
     // Up to 64 entries (nearly every query): they sit in registers, one per lane, before the first hit is written, so the
@@ -964,7 +1078,7 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restr
                                                             const float* __restrict__ b, const float* __restrict__ invb,
                                                             int64_t n, int64_t m, int d, const int* __restrict__ cand_cnt,
                                                             const unsigned* __restrict__ cand, int cap,
-                                                            int64_t* __restrict__ idx_out, float* __restrict__ sim_out) {
+                                                            int64_t* __restrict__ idx_out, float* __restrict__ sim_out, float min_sim) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* P = reinterpret_cast<double*>(smem);               // [64][RS_STRIDE] products
     double* pscore = P + 64 * RS_STRIDE;                       // [RS_PAIRS] exact score per pair of the epoch
@@ -1149,8 +1263,11 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restr
         idx_out[qi] = (m > 0) ? 0 : -1;
         sim_out[qi] = 0.0f;
     } else if (cand_cnt[qi] >= 0) {
-        idx_out[qi] = bj;
-        sim_out[qi] = (float)best;
+        // (half-width pass: min_sim = the gate -- the lists hold only rows of chunks that could reach it, so a best below it
+        // is not the oracle's arg-max but the proof that the query has no match; otherwise min_sim = -Inf)
+        const bool ok = !((float)best < min_sim) && bj >= 0;
+        idx_out[qi] = ok ? bj : -1;
+        sim_out[qi] = ok ? (float)best : -2.0f;
     } else if (cand_cnt[qi] == -2) {  // below the caller's gate (match_select_kernel)
         idx_out[qi] = -1;
         sim_out[qi] = -2.0f;
@@ -1280,6 +1397,9 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     const float w2 = 2.0f * (float)(d / 16 + 4 + 2) * 5.9604645e-8f;
     const bool i8 = records != VFM_RECORDS_F16 && use_i8(d, n, m, gated);
     if (i8 && !gated) records = VFM_RECORDS_TOP2;  // as do_search_coarse chose
+    records = effective_records(records, d, n);
+    const bool half = i8 && records == VFM_RECORDS_HALF;
+    if (half && !(gate > -__builtin_inff())) return vfm_fail(VFM_EINVAL, "search_finish: VFM_RECORDS_HALF needs a finite gate");
     if (!i8 && use_sparse(d, n, m)) {
         hipLaunchKernelGGL(match_filter_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d,
                            DEFAULT_WINDOW, w2, w.qmax, w.rec_cnt, w.rec, w.rcap, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
@@ -1289,8 +1409,14 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
         bool use_bins = false;
         // best-score records with many queries per map chunk: the rescan runs chunk-major (match_rescan_chunk_kernel)
         const bool best = i8 && records == VFM_RECORDS_BEST && g_select_variant != 1;
-        use_bins = best && g_select_variant != 2 && n >= 4 * (int64_t)a.nchunks;
-        if (i8 && records == VFM_RECORDS_TOP2 && g_select_variant != 1) {
+        use_bins = (best || half) && g_select_variant != 2 && n >= 4 * (int64_t)a.nchunks;
+        if (half) {
+            const int half_lds = (size_t)a.nchunks * 12 <= 63 * 1024;  // (step, max E, max |rest|) of every chunk in LDS
+            hipLaunchKernelGGL(match_select_half_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * 8), half_lds ? (size_t)a.nchunks * 12 : 0,
+                               st, reinterpret_cast<const unsigned*>(w.partials), a.nchunks, n, Q.inv, i8_bounds(Q, B, true, records),
+                               (const float*)Q.rest, (const float*)B.grest, gate, half_lds, w.cand_cnt, w.cand, w.cap, w.fb_count,
+                               w.fb_list, g_match_stats, use_bins ? w.bin_cnt : (unsigned*)nullptr, use_bins ? w.bins : (int*)nullptr);
+        } else if (i8 && records == VFM_RECORDS_TOP2 && g_select_variant != 1) {
             hipLaunchKernelGGL(match_select_top2_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * SELECT_TOP2_WAVES),
                                chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, (const uint2*)w.partials, a.nchunks, n,
                                a.first_pad_chunk, (const unsigned*)w.qmax, Q.inv, i8_bounds(Q, B, true, records), gate, chunk_lds,
@@ -1310,14 +1436,14 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
         if (i8) {  // candidate chunks -> candidate rows (the record buffer of the fp16 pass is free: it holds the hit lists)
             hipLaunchKernelGGL(match_rescan_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, m, d, i8_bounds(Q, B, true, records),
                                (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt, w.cand, w.cap,
-                               reinterpret_cast<unsigned*>(w.rec), 2 * w.rcap, w.fb_count, w.fb_list);
+                               reinterpret_cast<unsigned*>(w.rec), 2 * w.rcap, w.fb_count, w.fb_list, half ? 1 : 0, gate);
             VFM_CHECK_LAUNCH("match_rescan_kernel");
             if (use_bins) {
                 const size_t lds = (size_t)RESCAN_BATCH * (size_t)(d / 16) * sizeof(uint4);
 #define VFM_RESCAN_CHUNK(UH)                                                                                                  \
     hipLaunchKernelGGL(match_rescan_chunk_kernel<UH>, dim3((unsigned)a.nchunks), dim3(256), lds, st, n, m,                      \
                        i8_bounds(Q, B, true, records), (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, \
-                       w.cand_cnt, w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins)
+                       w.cand_cnt, w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, half ? 1 : 0, gate)
                 switch (d / 32) {
                     case 8: VFM_RESCAN_CHUNK(8); break;
                     case 12: VFM_RESCAN_CHUNK(12); break;
@@ -1329,7 +1455,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                 VFM_CHECK_LAUNCH("match_rescan_chunk_kernel");
             }
             hipLaunchKernelGGL(match_rescan_close_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, w.cand_cnt, w.cap,
-                               w.fb_count, w.fb_list, reinterpret_cast<int*>(w.rec_cnt));
+                               w.fb_count, w.fb_list, reinterpret_cast<int*>(w.rec_cnt), half ? (const float*)Q.inv : (const float*)nullptr);
             VFM_CHECK_LAUNCH("match_rescan_close_kernel");
             // (rec_cnt, unused by the int8 pass, holds the list of crowded queries; fb_count[6] its length)
             const unsigned grid = (unsigned)((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024);
@@ -1350,7 +1476,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
             attr_mark(attr_set);
         }
         hipLaunchKernelGGL(match_rescore_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), lds, st, q, Q.inv, b, B.inv, n, m,
-                           d, w.cand_cnt, w.cand, w.cap, idx_out, sim_out);
+                           d, w.cand_cnt, w.cand, w.cap, idx_out, sim_out, half ? gate : -__builtin_inff());
     }
     VFM_CHECK_LAUNCH("match_rescore_kernel");
     hipLaunchKernelGGL(match_exact_kernel, dim3(256), dim3(256), (((size_t)d * 4 + 15) & ~(size_t)15) + 64, st, q, Q.inv,

@@ -293,12 +293,20 @@ struct Prepared {
     float* gstep;     // quantisation step per group of 128 rows
     float* gerr;      // maximum E per group
     uint4* tiles8;    // int8 fragment tiles
+    uint4* tiles8h;   // int8 fragment tiles of the first d / 2 columns (written by the gated prepare only)
+    float* rest;      // per row: |second half of the normalised row|_2, rounded up
+    float* grest;     // its maximum per group
     size_t bytes;
 };
 
 // widths the int8 coarse pass exists for (match_coarse_pipe_kernel<d/32, false, true>; d = 128 has too few k-steps for the
 // fragment ring)
 inline bool i8_capable(int d) { return d == 256 || d == 384 || d == 512 || d == 640 || d == 768; }
+// shapes the half-width pass (VFM_RECORDS_HALF) has a kernel for; elsewhere the record kind falls back to best-score records
+inline bool half_capable(int d, int64_t n) { return ((d == 256 || d == 384) && n > 2048) || d == 512 || d == 768; }
+inline int effective_records(int records, int d, int64_t n) {
+    return (records == VFM_RECORDS_HALF && !half_capable(d, n)) ? VFM_RECORDS_BEST : records;
+}
 
 inline Prepared carve_prepared(void* p, int64_t rows, int d) {
     VfmCarver c(p);
@@ -309,11 +317,18 @@ inline Prepared carve_prepared(void* p, int64_t rows, int d) {
     r.err = nullptr;
     r.gstep = r.gerr = nullptr;
     r.tiles8 = nullptr;
+    r.tiles8h = nullptr;
+    r.rest = r.grest = nullptr;
     if (i8_capable(d)) {  // behind the fp16 image: the Euclidean path carves the same layout and ignores the rest
         r.err = c.take<float>((size_t)rp);
         r.gstep = c.take<float>((size_t)rp / I8_GROUP);
         r.gerr = c.take<float>((size_t)rp / I8_GROUP);
         r.tiles8 = c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(d / 32) * 64);
+        // half-width pass (VFM_RECORDS_HALF): the int8 image of the first d / 2 columns as tiles of their own, the norm of
+        // the OTHER half of every normalised row (rounded up) and its maximum per 128-row group
+        r.tiles8h = c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(d / 64) * 64);
+        r.rest = c.take<float>((size_t)rp);
+        r.grest = c.take<float>((size_t)rp / I8_GROUP);
     }
     r.bytes = c.used();
     return r;
@@ -386,7 +401,7 @@ bool use_i8(int d, int64_t n, int64_t m, bool gated);
 int coarse_qblock(int d);
 int choose_slices(int nqb, int nchunks);
 inline I8Bounds i8_bounds(const Prepared& Q, const Prepared& B, bool on, int top2 = 0) {
-    return on ? I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr, top2} : I8Bounds{nullptr, nullptr, nullptr, nullptr, 0};
+    return on ? I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr, top2 == VFM_RECORDS_TOP2 ? 1 : 0} : I8Bounds{nullptr, nullptr, nullptr, nullptr, 0};
 }
 CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, int64_t n, int64_t m, int qblock = QBLOCK);
 

@@ -87,12 +87,15 @@ struct PrepOut {
     float* gstep;     // [rows_pad / 128] quantisation step of the group
     float* gerr;      // [rows_pad / 128] maximum E of the group
     uint4* tiles8;    // int8 fragment tiles
+    uint4* tiles8h;   // !F16: int8 fragment tiles of the first d / 2 columns
+    float* rest;      // !F16: |second half of the normalised row|_2, rounded up
+    float* grest;     // !F16: its maximum over the group
 };
 template <bool F16, int NC = 2>
 __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restrict__ x1, int64_t rows1, int d, PrepOut o1, int groups1,
                                                           const float* __restrict__ x2, int64_t rows2, PrepOut o2, int groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ unsigned amax_bits, emax_bits;
+    __shared__ unsigned amax_bits, emax_bits, rmax_bits;
     constexpr int RPW = I8_GROUP / 16;  // rows per wave: 16 waves x 8 rows, all of them in registers between the two phases
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int nchunks = d >> 2;  // float4 chunks per row (<= 64 NC): lane l owns chunks l, l + 64 (, l + 128)
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
     if (threadIdx.x == 0) {
         amax_bits = 0u;
         emax_bits = 0u;
+        rmax_bits = 0u;
     }
     // The kernel's registers allow one workgroup per compute unit, so a workgroup walks several groups (grid = compute
     // units) and reads row j of its NEXT group as soon as row j of the current one has been quantised: the read of the next
@@ -195,16 +199,19 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
         const float qstep = usable ? amax / 127.0f : 1.0f;
         const float inv_qstep = usable ? 127.0f / amax : 0.0f;
         // phase 2: quantise from the registers; each row's registers then take the same row of the next group
+        float rpart[RPW];
 #pragma unroll
         for (int j = 0; j < RPW; ++j) {
             const int pr = wave * RPW + j;
             const int t = pr >> 5, p = pr & 31;
-            float e2 = 0.0f;
+            float e2 = 0.0f, r2 = 0.0f;
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
                 const int c = lane + 64 * i;
                 if (c < nchunks) {
                     const float nv[4] = {v[j][i].x, v[j][i].y, v[j][i].z, v[j][i].w};
+                    if constexpr (!F16)
+                        if (8 * c >= d) r2 = r2 + (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] + nv[3] * nv[3]);  // columns >= d / 2
                     int qi[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -230,6 +237,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
                 }
             }
             part[j] = e2;
+            rpart[j] = r2;
             if (gnext < groups) load_row(gnext, j);
         }
         {
@@ -243,6 +251,17 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
                 o.err[r] = en;
                 if (en > 0.0f) atomicMax(&emax_bits, __float_as_uint(en));
             }
+            if constexpr (!F16) {
+                // |second half of the row|_2, rounded up like E (d / 2 + 8 roundings of 2^-24 on non-negative terms, one sqrtf);
+                // NaN / Inf elements -> Inf: nothing is ever pruned against such a row
+                float rn = sqrtf(scatter8(rpart)) * 1.000244140625f + 1.0e-30f;
+                if (!(rn == rn)) rn = __builtin_inff();
+                if (r >= rows) rn = 0.0f;
+                if ((lane & 7) == 0) {
+                    o.rest[r] = rn;
+                    if (rn > 0.0f) atomicMax(&rmax_bits, __float_as_uint(rn));
+                }
+            }
         }
         __syncthreads();
         {
@@ -251,6 +270,20 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
             const uint4* src = reinterpret_cast<const uint4*>(img8);
             for (int u = threadIdx.x; u < u8n; u += 1024) {
                 const uint4 tq = src[u];
+                unsigned* po = reinterpret_cast<unsigned*>(dst + u);
+                __builtin_nontemporal_store(tq.x, po);
+                __builtin_nontemporal_store(tq.y, po + 1);
+                __builtin_nontemporal_store(tq.z, po + 2);
+                __builtin_nontemporal_store(tq.w, po + 3);
+            }
+        }
+        if constexpr (!F16) {  // the first d / 2 columns again, as tiles of their own (the first half of every tile's units)
+            const int uh = (d >> 6) * 64;  // uint4 units per half tile
+            uint4* dst = o.tiles8h + (int64_t)grp * (uh * 4);
+            const uint4* src = reinterpret_cast<const uint4*>(img8);
+            for (int u = threadIdx.x; u < uh * 4; u += 1024) {
+                const int t = u / uh, w = u % uh;
+                const uint4 tq = src[t * (2 * uh) + w];
                 unsigned* po = reinterpret_cast<unsigned*>(dst + u);
                 __builtin_nontemporal_store(tq.x, po);
                 __builtin_nontemporal_store(tq.y, po + 1);
@@ -274,8 +307,10 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
         if (threadIdx.x == 0) {
             o.gstep[grp] = qstep;
             o.gerr[grp] = __uint_as_float(emax_bits);
+            if constexpr (!F16) o.grest[grp] = __uint_as_float(rmax_bits);
             amax_bits = 0u;   // for the next group (read again only behind the next two barriers)
             emax_bits = 0u;
+            rmax_bits = 0u;
         }
     }
 }
@@ -305,7 +340,7 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x,
 
 }  // namespace
 
-inline PrepOut prep_out(const Prepared& p) { return PrepOut{p.inv, p.tiles, p.err, p.gstep, p.gerr, p.tiles8}; }
+inline PrepOut prep_out(const Prepared& p) { return PrepOut{p.inv, p.tiles, p.err, p.gstep, p.gerr, p.tiles8, p.tiles8h, p.rest, p.grest}; }
 
 // Workgroups of prep_chunk_kernel (vfm_debug_set_prep_grid): -1 (default) = one per 128-row group; 0 = one per compute unit,
 // each walking ceil(groups / grid) groups with the next group's rows read under the current group's quantisation and store

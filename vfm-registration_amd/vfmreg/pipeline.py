@@ -21,9 +21,11 @@ pair.  With the fp16 pass it cost the coarse kernel more than it hid (round 2, f
 with the int8 pass, whose kernel is half as long, prepare stream + two solve streams is the best arrangement measured
 (604-665 registrations/s against 558-574 for one solve stream with prepare on the caller's stream) and is what bench.py runs.
 
-``coarse``: which coarse pass -- "int8" / "int8-top2" = the gated family of include/vfmreg.h with best-score / packed top-2
-records (queries that provably miss ``min_cosine`` stay unresolved: idx -1, sim -2.0; correspondences and pose are
-unaffected), "fp16" = the fp16 pass (VFM_RECORDS_F16: every query resolved), "auto" (default) = best-score records until a search reports more than
+``coarse``: which coarse pass -- "int8-half" = the half-width pass of the gated family (VFM_RECORDS_HALF: int8 MFMA over the
+first d / 2 columns, the other half bounded by Cauchy-Schwarz against the gate; needs the gate), "int8" / "int8-top2" = the
+gated family of include/vfmreg.h with best-score / packed top-2 records (queries that provably miss ``min_cosine`` stay unresolved: idx -1, sim -2.0; correspondences and pose are
+unaffected), "fp16" = the fp16 pass (VFM_RECORDS_F16: every query resolved), "auto" (default) = the half-width pass while a search reports at most
+``HALF_LIMIT`` surviving chunks per query, then best-score records until a search reports more than
 ``RESCAN_LIMIT`` rescanned chunks per query (duplicate-rich maps), then top-2 records, then -- above ``TOP2_LIMIT`` -- the fp16
 pass, with a probe one step back every ``REPROBE`` registrations.  ``gate=False`` keeps the int8 pass but resolves every query.
 """
@@ -74,11 +76,15 @@ class RegistrationPipeline:
         # candidate chunk of a resolved query is rescanned), "int8-top2" = the same with packed top-2 records (+ ~0.15 ms of
         # kernel at C2; a chunk with one row inside the bounds costs one fp32 row instead of a 48 KB rescan), "fp16" = the
         # ungated family, "auto" = chosen from the searches' own feedback (_poll_feedback)
-        if coarse not in ("auto", "int8", "int8-top2", "fp16"):
-            raise ValueError("coarse must be 'auto', 'int8', 'int8-top2' or 'fp16'")
+        if coarse not in ("auto", "int8-half", "int8", "int8-top2", "fp16"):
+            raise ValueError("coarse must be 'auto', 'int8-half', 'int8', 'int8-top2' or 'fp16'")
+        if coarse == "int8-half" and not gate:
+            raise ValueError("the half-width pass needs the gate")
         self.coarse = coarse
         self.use_i8 = coarse != "fp16"
         self.top2 = coarse == "int8-top2"   # int8 pass with packed top-2 records (VFM_RECORDS_TOP2)
+        # half-width pass (VFM_RECORDS_HALF): where the library has no kernel for it the call behaves as best-score records
+        self.half = coarse == "int8-half" or (coarse == "auto" and self.gate)
         self.last_rescans: Optional[int] = None
         self._since_switch = 0
         self._pending = []  # (event, pinned int32[1]) of gated searches whose rescan count is on its way to the host
@@ -117,6 +123,9 @@ class RegistrationPipeline:
     # vs 1.85; 12.4: 2.01 vs 1.94; 31.6: 2.57 vs 2.28; 99: 10.8 vs 3.4 (the chunk-major rescan, match_rescan_chunk_kernel, moved
     # the crossover from ~2.5 to ~10); top-2 records -> fp16 pass above TOP2_LIMIT (whole-chunk rescans + 1/32 per single row;
     # never reached on the maps measured: the fp16 pass takes 4.2 ms where top-2 records take 3.4)
+    # half-width pass -> best-score records above HALF_LIMIT surviving chunks per query (D.2 descriptors: 0.5 -- the planted
+    # matches and nothing else; lifted descriptors that are all alike: hundreds)
+    HALF_LIMIT = 4.0
     RESCAN_LIMIT = 10.0
     TOP2_LIMIT = 40
     REPROBE = 256       # registrations before one step back towards the cheaper kernel is probed
@@ -127,14 +136,21 @@ class RegistrationPipeline:
             _, slot, records = self._pending.pop(0)
             self.last_rescans = int(slot.item())
             self._slots.append(slot)
-            if self.coarse != "auto" or not self.use_i8 or records != (1 if self.top2 else 0):
+            if self.coarse != "auto" or not self.use_i8 or records != self._records():
                 continue  # feedback of a mode that has been left already
-            if not self.top2 and self.last_rescans > self.RESCAN_LIMIT * self.n:
+            if self.half:
+                if self.last_rescans > self.HALF_LIMIT * self.n:
+                    self.half = False
+                    self._since_switch = 0
+            elif not self.top2 and self.last_rescans > self.RESCAN_LIMIT * self.n:
                 self.top2 = True
                 self._since_switch = 0
             elif self.top2 and self.last_rescans > self.TOP2_LIMIT * self.n:
                 self.use_i8 = False
                 self._since_switch = 0
+
+    def _records(self) -> int:
+        return 3 if self.half else (1 if self.top2 else 0)
 
     def synchronize(self) -> None:
         """Make the caller's current stream wait for every RANSAC issued on the side stream."""
@@ -154,14 +170,21 @@ class RegistrationPipeline:
         if q_desc.shape != (self.n, self.d) or b_desc.shape != (self.m, self.d):
             raise ValueError("Invalid shape")
         self._poll_feedback()
-        i8, records = self.use_i8, (1 if self.top2 else 0)
         if self.coarse == "auto":
             self._since_switch += 1
-            if self._since_switch >= self.REPROBE and (not self.use_i8 or self.top2):
+            if self._since_switch >= self.REPROBE and (not self.use_i8 or self.top2 or (not self.half and self.gate)):
                 # every REPROBE registrations one step back towards the cheaper kernel (fp16 -> top-2 records -> best-score
-                # records); the feedback of that probe decides whether it stays
-                self.use_i8, self.top2 = True, not self.use_i8
+                # records -> half-width pass); the feedback of that probe decides whether it stays
+                if not self.use_i8:
+                    self.use_i8, self.top2 = True, True
+                elif self.top2:
+                    self.top2 = False
+                else:
+                    self.half = True
                 self._since_switch = 0
+        i8, records = self.use_i8, self._records()
+        if records == 3 and reuse_map:
+            records = 0   # a map kept across registrations carries both images but not the half-width one
         r = self.sets[self._step % len(self.sets)]
         solve = self.solve_streams[self._step % self.n_solve] if self.overlap else None
         rws = self.rws_list[self._step % self.n_solve] if self.overlap else self.rws
