@@ -194,11 +194,14 @@ def extra_configs(dev):
     t5_reg = timed(lambda: pipe5.register(p5["q_desc"], p5["q_xyz"], p5["b_desc"], p5["b_xyz"]), reps=3)
     r5 = pipe5.register(p5["q_desc"], p5["q_xyz"], p5["b_desc"], p5["b_xyz"])
     torch.cuda.synchronize()
-    f5 = 2.0 * n5 * m5 * d5
+    half5 = bool(pipe5.use_i8 and pipe5.half)   # the half-width pass: the kernel runs over the first 384 of the 768 columns
+    f5 = 2.0 * n5 * m5 * (d5 // 2 if half5 else d5)
     out["C5"] = {"workload": "50000-pt scan vs 1000000-pt map, 768-D, 50000 RANSAC iterations (one registration, serial)",
                  "ms_registration": t5_reg, "ms_coarse_kernel": t5, "correspondences": int(r5["count"].item()),
                  "pose_err_vs_planted": float(np.linalg.norm(r5["T"].cpu().numpy() - p5["T_gt"])),
-                 "roofline": {"bound": "mfma", "kernel": "match_coarse_i8_kernel<24, 2> (int8 32x32x32 MFMA)", "flops": f5,
+                 "coarse_pass": "int8, half-width (VFM_RECORDS_HALF)" if half5 else ("int8, packed top-2 records" if pipe5.top2 else "int8, best-score records"),
+                 "roofline": {"bound": "mfma", "kernel": ("match_coarse_i8_kernel<12, 4> (int8 32x32x32 MFMA over the first 384 of 768 columns)" if half5
+                                                          else "match_coarse_i8_kernel<24, 2> (int8 32x32x32 MFMA)"), "flops": f5,
                               "achieved": f5 / (t5 * 1e-3) / 1e12, "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s",
                               "frac": f5 / (t5 * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS}}
     return out

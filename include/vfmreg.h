@@ -145,6 +145,14 @@ int vfm_match_search_finish_gated_r(const float *q, const void *q_prepared, int6
  * beyond ~60 chunks per resolved query the ungated family (fp16 pass, 20x tighter window) is the faster one
  * (vfmreg/pipeline.py switches on this figure). */
 int vfm_match_search_rescans_async(const void *ws, int64_t n, int64_t m, int32_t *out_host, vfm_stream_t stream);
+/* Probe for VFM_RECORDS_HALF: runs the half-width coarse pass of this (scan, map) pair into `ws` and counts the (query, chunk)
+ * pairs that survive its bound against `gate` -- nothing else is computed; the count goes to out_host (pinned memory)
+ * asynchronously on `stream` (INT32_MAX, written at once, where the shape has no half-width kernel).  A half-width search
+ * whose survivors run into the hundreds per query is far slower than any other mode (every survivor is a 128-row rescan), so a
+ * caller probes before switching to it (vfmreg/pipeline.py: on the first registration and at every re-probe interval); `ws`
+ * is free for the real search of the same pair afterwards.  Operands from vfm_match_prepare2_gated. */
+int vfm_match_search_probe_half(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m, int d,
+                                void *ws, size_t ws_bytes, float gate, int32_t *out_host, vfm_stream_t stream);
 
 /* valid = !(D < min_cosine_similarity) (VHM:501-511), survivors in query order (VHM:587-600).
  * keep_out[k] = query index of the k-th survivor, *count_out = K.  corres_out (nullable,

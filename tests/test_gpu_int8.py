@@ -265,3 +265,104 @@ def test_chunk_major_rescan_full_bins_and_padded_chunks(d):
             assert solved[rsim >= 0.8].all() and solved.sum() > len(solved) // 3 and (~solved).sum() > 0
             ref.setdefault("solved", solved)
             np.testing.assert_array_equal(solved, ref["solved"], err_msg=f"{name} / variant {variant}")
+
+
+def _search_gated_split(q, b, gate, records):
+    """The gated family exactly as the pipeline calls it: vfm_match_prepare2_gated (the only prepare that writes the half-width
+    image) -> coarse_gated_r -> finish_gated_r."""
+    lib = _lib.load()
+    n, d = q.shape
+    m = b.shape[0]
+    qb = torch.empty(lib.vfm_match_prepared_bytes(n, d), dtype=torch.uint8, device="cuda")
+    bb = torch.empty(lib.vfm_match_prepared_bytes(m, d), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=torch.uint8, device="cuda")
+    idx = torch.empty(n, dtype=torch.int64, device="cuda")
+    sim = torch.empty(n, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.vfm_match_prepare2_gated(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, st))
+    _lib.check(lib.vfm_match_search_coarse_gated_r(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, st))
+    _lib.check(lib.vfm_match_search_finish_gated_r(q.data_ptr(), qb.data_ptr(), n, b.data_ptr(), bb.data_ptr(), m, d, idx.data_ptr(),
+                                                   sim.data_ptr(), ws.data_ptr(), ws.numel(), gate, records, st))
+    torch.cuda.synchronize()
+    return idx, sim
+
+
+@pytest.mark.parametrize("d,n,m", [(384, 2500, 9000), (256, 3000, 5003), (384, 2100, 130), (512, 900, 4100), (768, 1300, 6000),
+                                   (384, 300, 20011), (640, 1030, 3000)])
+def test_half_width_pass_keeps_the_gate_contract(d, n, m):
+    """VFM_RECORDS_HALF: int8 scores over the first d / 2 columns + |rest of the query| * max |rest of a row of the chunk| decide
+    which chunks can hold a row at the gate.  The contract: every query resolved has the oracle's index and similarity, every
+    query left unresolved has an oracle similarity below the gate, and every match at or above min_cosine is resolved -- on
+    planted matches, on descriptors whose energy sits entirely in one half of the columns (the bound is then exact on one side
+    and vacuous on the other), on heavy-tailed rows, on rows that are all alike (everything survives) and on exact duplicates.
+    (384, 300, .) and (640, ., .) have no half-width kernel: the call must behave as best-score records.)"""
+    rng = np.random.default_rng(d + n)
+    gate = float(np.nextafter(np.float32(0.8), np.float32(-np.inf)))
+    cases = {}
+    b = rng.standard_normal((m, d)).astype(np.float32)
+    q = b[rng.integers(0, m, n)] + 0.3 * rng.standard_normal((n, d)).astype(np.float32)
+    q[::3] = rng.standard_normal((len(q[::3]), d)).astype(np.float32)
+    cases["planted"] = (q, b)
+    b2, q2 = b.copy(), q.copy()
+    b2[: m // 2, : d // 2] *= 1e-3      # half of the map lives in the second half of the columns ...
+    b2[m // 2:, d // 2:] *= 1e-3        # ... the other half in the first
+    q2[::2, : d // 2] *= 1e-3
+    q2[1::2, d // 2:] *= 1e-3
+    cases["energy in one half"] = (q2, b2)
+    cases["heavy-tailed"] = (_heavy_tailed(rng, n, d), _heavy_tailed(rng, m, d))
+    base = rng.standard_normal((1, d)).astype(np.float32)
+    cases["all alike"] = (base + 0.2 * rng.standard_normal((n, d)).astype(np.float32), base + 0.2 * rng.standard_normal((m, d)).astype(np.float32))
+    few = rng.standard_normal((16, d)).astype(np.float32)
+    cases["duplicates"] = (few[rng.integers(0, 16, n)] + 0.0, few[rng.integers(0, 16, m)] + 0.0)
+    for name, (qq, bb) in cases.items():
+        qn, _ = orc.l2norm_rows(qq)
+        bn, _ = orc.l2norm_rows(bb)
+        ridx, rsim = orc.match_ip_top1(qn, bn)
+        qd, bd = torch.from_numpy(qq).cuda(), torch.from_numpy(bb).cuda()
+        idx, sim = _search_gated_split(qd, bd, gate, 3)
+        solved = _gate_contract(idx, sim, ridx, rsim, gate)
+        assert solved[rsim >= 0.8].all(), name
+        # ... and the correspondences a caller keeps (similarity >= min_cosine) are those of best-score records
+        i0, s0 = _search_gated_split(qd, bd, gate, 0)
+        keep3, keep0 = (sim >= 0.8).cpu().numpy(), (s0 >= 0.8).cpu().numpy()
+        np.testing.assert_array_equal(keep3, keep0, err_msg=name)
+        np.testing.assert_array_equal(idx.cpu().numpy()[keep3], i0.cpu().numpy()[keep0], err_msg=name)
+
+
+def test_half_width_pass_needs_a_gate_and_the_pipeline_leaves_it_on_descriptors_that_are_all_alike():
+    lib = _lib.load()
+    n, m, d = 2200, 20000, 384
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    q = torch.randn((n, d), generator=g, device="cuda")
+    b = torch.randn((m, d), generator=g, device="cuda")
+    with pytest.raises(RuntimeError, match="finite gate"):
+        _search_gated_split(q, b, float("-inf"), 3)
+    # D.2-like pair: the pipeline stays on the half-width pass; a map whose rows are all alike (cosine ~0.96 to everything):
+    # every chunk survives the half-width bound, the feedback moves the pipeline on, results unchanged
+    p = synth.make_pair_device(n, m, d, seed=21)
+    pipe = RegistrationPipeline(n, m, d, n_iter=4000, overlap_ransac=True)
+    for _ in range(4):
+        out = pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        pipe._poll_feedback()
+    assert pipe.half and pipe.use_i8 and int(out["count"].item()) > 500
+    base = torch.randn((1, d), generator=g, device="cuda")
+    b2 = (base + 0.2 * torch.randn((m, d), generator=g, device="cuda")).contiguous()
+    q2 = b2[p["match"].clamp(min=0)] + 0.05 * torch.randn((n, d), generator=g, device="cuda")
+    q2 = torch.where((p["match"] < 0)[:, None], base + 0.2 * torch.randn((n, d), generator=g, device="cuda"), q2).contiguous()
+    outs = {}
+    for coarse in ("auto", "int8-half", "int8", "fp16"):
+        pipe = RegistrationPipeline(n, m, d, n_iter=4000, overlap_ransac=True, coarse=coarse)
+        for _ in range(4):
+            out = pipe.register(q2, p["q_xyz"], b2, p["b_xyz"])
+            pipe.synchronize()
+            torch.cuda.synchronize()
+            pipe._poll_feedback()
+        k = int(out["count"].item())
+        outs[coarse] = (out["T"].clone(), out["corres"][:k].clone(), pipe.half)
+    assert outs["auto"][2] is False and outs["int8-half"][2] is True     # the feedback left the half-width pass
+    for coarse in ("int8-half", "int8", "fp16"):
+        assert torch.equal(outs["auto"][0], outs[coarse][0]) and torch.equal(outs["auto"][1], outs[coarse][1]), coarse
+    assert outs["auto"][1].shape[0] > 500

@@ -58,10 +58,11 @@ def main():
     nd_rows = "\n".join(
         f"| {name} | {nd[name + ' | auto']['ms_per_registration']:.2f} ({nd[name + ' | auto']['pass_in_use']}"
         f"{'' if nd[name + ' | auto']['pass_in_use'] == 'fp16' else ', ' + nd[name + ' | auto'].get('records_in_use', '?')}) | "
+        f"{nd[name + ' | int8-half']['ms_per_registration']:.2f} | "
         f"{nd[name + ' | int8']['ms_per_registration']:.2f} | {nd[name + ' | int8-top2']['ms_per_registration']:.2f} | "
         f"{nd[name + ' | fp16']['ms_per_registration']:.2f} | "
-        f"{all(nd[name + ' | ' + c]['same_result_as_auto'] for c in ('int8', 'int8-top2', 'fp16'))} | "
-        f"{sum(nd[name + ' | ' + c]['fallback_queries'] for c in ('auto', 'int8', 'int8-top2', 'fp16'))} |" for name in maps)
+        f"{all(nd[name + ' | ' + c]['same_result_as_auto'] for c in ('int8-half', 'int8', 'int8-top2', 'fp16'))} | "
+        f"{sum(nd[name + ' | ' + c]['fallback_queries'] for c in ('auto', 'int8-half', 'int8', 'int8-top2', 'fp16'))} |" for name in maps)
     md = f"""# Round 2 -- measurements on one MI355X (config C2: 20 000 x 200 000 x 384, 50 000 RANSAC iterations)
 
 Produced by `bash tools/r02_final.sh` (GPU tests, smoke, bench default / fp16 pass / serial / under rocprofv3, PMC passes of
@@ -111,10 +112,11 @@ L2 hit rate {pmc['TCC_hit_rate']:.3f}; clock {pmc['clock_GHz']:.2f} GHz; MFMA pi
 ## Duplicate-rich maps (`python tools/time_neardup.py`, C2 size, the bench's pipeline; `r02_neardup.json`)
 
 ms per registration with the coarse pass chosen by the pipeline's feedback (`auto`: the pass and record kind in use after the
-warm-up in brackets), and with each mode forced (int8 = best-score records, int8-top2 = packed top-2 records):
+warm-up in brackets), and with each mode forced (int8-half = the half-width pass, int8 = best-score records, int8-top2 = packed
+top-2 records):
 
-| map | auto | int8 | int8-top2 | fp16 | same correspondences + pose | all-pairs fallbacks |
-|---|---|---|---|---|---|---|
+| map | auto | int8-half | int8 | int8-top2 | fp16 | same correspondences + pose | all-pairs fallbacks |
+|---|---|---|---|---|---|---|---|
 {nd_rows}
 
 ## Second half of the round (files next to this one)

@@ -105,7 +105,7 @@ def main():
             q = torch.where(is_out[:, None], torch.randn((n, d), generator=g, device=dev), q)
             p["b_desc"], p["q_desc"] = b.contiguous(), q.contiguous()
         ref = None
-        for coarse in ("auto", "int8", "int8-top2", "fp16"):  # the bench's pipeline: prepare on its own stream, two solve streams
+        for coarse in ("auto", "int8-half", "int8", "int8-top2", "fp16"):  # the bench's pipeline: prepare on its own stream, two solve streams
             pipe = RegistrationPipeline(n, m, d, n_iter=50000, overlap_ransac=True, overlap_prepare=True, solve_streams=2, coarse=coarse)
             dt, st, out = run(pipe, p, a.steps, lib, n, m)
             k = int(out["count"].item())
@@ -118,7 +118,7 @@ def main():
             key = name + " | " + coarse
             hist = {f"<= {1 << bnum}": st[8 + bnum] for bnum in range(16) if st[8 + bnum]}
             res[key] = dict(ms_per_registration=1e3 * dt, registrations_per_s=1.0 / dt, correspondences=k, pose_err_vs_planted=err,
-                            pass_in_use=("int8" if pipe.use_i8 else "fp16"), records_in_use=("top-2" if pipe.top2 else "best score"),
+                            pass_in_use=("int8" if pipe.use_i8 else "fp16"), records_in_use=("half-width" if (pipe.use_i8 and pipe.half) else "top-2" if pipe.top2 else "best score"),
                             same_result_as_auto=same,
                             rescanned_chunks_per_query=(pipe.last_rescans / n) if pipe.last_rescans is not None else None,
                             fallback_queries=st[0], refined_queries=st[1], coarse_records_per_query=st[4] / n, candidate_entries_per_query=st[2] / n,

@@ -249,6 +249,23 @@ VFM_EXPORT int vfm_match_search_rescans_async(const void* ws, int64_t n, int64_t
     return VFM_OK;
 }
 
+VFM_EXPORT int vfm_match_search_probe_half(const void* q_prepared, int64_t n, const void* b_prepared, int64_t m, int d, void* ws,
+                                           size_t ws_bytes, float gate, int32_t* out_host, vfm_stream_t stream) {
+    if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
+    VFM_CHECK_ARG(q_prepared && b_prepared && ws && out_host, "probe_half: null pointer");
+    VFM_CHECK_ARG(gate > -__builtin_inff(), "probe_half: needs a finite gate");
+    if (!(use_i8(d, n, m, true) && half_capable(d, n))) {  // no half-width kernel for this shape: "everything survives"
+        *out_host = INT32_MAX;
+        return VFM_OK;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = do_search_coarse(q_prepared, n, b_prepared, m, d, ws, st, false, true, true, VFM_RECORDS_HALF)) return rc;
+    if (int rc = probe_half_select(q_prepared, n, b_prepared, m, d, ws, gate, st)) return rc;
+    SearchWs w = carve_search(ws, n, m);
+    VFM_CHECK_HIP(hipMemcpyAsync(out_host, w.fb_count + 5, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    return VFM_OK;
+}
+
 VFM_EXPORT size_t vfm_match_ip_top1_workspace_bytes(int64_t n, int64_t m, int d, int prec_mode) {
     if (prec_mode == VFM_MATCH_EXACT) return vfm_align_up((size_t)(n + m) * sizeof(float), 256) + 512;
     return vfm_match_prepared_bytes(n, d) + vfm_match_prepared_bytes(m, d) + vfm_match_search_workspace_bytes(n, m, d);

@@ -376,6 +376,7 @@ __global__ __launch_bounds__(64 * 8) void match_select_half_kernel(
                 const float up = sc * (float)((int)r4[j] - I8_OFFSET) + (A[j] + mult[j] * cb2.y + slack) + (rq[j] * rb + slack);
                 if (!(up < gate) && ((livemask >> j) & 1u)) {
                     int slot = atomicAdd(&lcnt[lq + j], 1);
+                    if (!cand) continue;  // probe (vfm_match_search_probe_half): the survivors are only counted
                     if (bins) {
                         const unsigned pos = atomicAdd(&bin_cnt[c], 1u);
                         if (pos < (unsigned)RESCAN_BIN_CAP) {
@@ -396,11 +397,11 @@ __global__ __launch_bounds__(64 * 8) void match_select_half_kernel(
         const int64_t q = (int64_t)qt * 32 + qq;
         const bool live = lane < 32 && q < n;
         const int cnt = lcnt[qq];
-        int mine = (live && cnt <= cap) ? cnt : 0;   // load figure (vfm_match_search_rescans_async): surviving chunks
+        int mine = (live && (cnt <= cap || !cand)) ? cnt : 0;   // load figure (vfm_match_search_rescans_async): surviving chunks
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
         if (lane == 0 && mine > 0) atomicAdd(fb_count + 5, mine);
-        if (live) {
+        if (live && cand) {
             if (stats && invq[q] != 0.0f) {
                 atomicAdd(fb_count + 2, cnt);
                 int bin = 0;
@@ -1482,6 +1483,22 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     hipLaunchKernelGGL(match_exact_kernel, dim3(256), dim3(256), (((size_t)d * 4 + 15) & ~(size_t)15) + 64, st, q, Q.inv,
                        b, B.inv, n, m, d, w.fb_list, w.fb_count, idx_out, sim_out);
     VFM_CHECK_LAUNCH("match_exact_kernel(fallback)");
+    return VFM_OK;
+}
+
+// vfm_match_search_probe_half: how many (query, chunk) pairs the half-width pass would leave for the rescan -- its coarse
+// pass has just run into ws (do_search_coarse(..., VFM_RECORDS_HALF)); only fb_count[5] is written
+int probe_half_select(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, float gate, hipStream_t st) {
+    Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
+    Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
+    SearchWs w = carve_search(ws, n, m);
+    const CoarseArgs a = coarse_args(Q, B, w, n, m, coarse_qblock(d));
+    const int half_lds = (size_t)a.nchunks * 12 <= 63 * 1024;
+    hipLaunchKernelGGL(match_select_half_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * 8), half_lds ? (size_t)a.nchunks * 12 : 0, st,
+                       reinterpret_cast<const unsigned*>(w.partials), a.nchunks, n, Q.inv, i8_bounds(Q, B, true, VFM_RECORDS_HALF),
+                       (const float*)Q.rest, (const float*)B.grest, gate, half_lds, w.cand_cnt, (unsigned*)nullptr, w.cap, w.fb_count,
+                       w.fb_list, 0, (unsigned*)nullptr, (int*)nullptr);
+    VFM_CHECK_LAUNCH("match_select_half_kernel(probe)");
     return VFM_OK;
 }
 

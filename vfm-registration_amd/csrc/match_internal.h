@@ -420,6 +420,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                      int64_t* idx_out, float* sim_out, void* ws, hipStream_t st, bool gated = false,
                      float gate = -__builtin_inff(), int records = 0);
 int launch_select_dense(const SearchWs& w, const CoarseArgs& a, const float* qinv, int64_t n, hipStream_t st);
+int probe_half_select(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, float gate, hipStream_t st);
 int exact_ip_top1(const float* q, int64_t n, const float* b, int64_t m, int d, int64_t* idx_out, float* sim_out, void* ws,
                   hipStream_t st);
 

@@ -46,6 +46,7 @@ SIGNATURES = {
                                             C.c_size_t, c_vp]),
     "vfm_match_search_coarse": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, c_vp, C.c_size_t, c_vp]),
     "vfm_match_search_rescans_async": (C.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "vfm_match_search_probe_half": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, c_vp, C.c_size_t, C.c_float, c_vp, c_vp]),
     "vfm_match_search_coarse_gated": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, c_vp, C.c_size_t, c_vp]),
     "vfm_match_search_coarse_gated_r": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, c_vp, C.c_size_t, C.c_int, c_vp]),
     "vfm_match_search_finish_gated_r": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp,

@@ -24,8 +24,9 @@ with the int8 pass, whose kernel is half as long, prepare stream + two solve str
 ``coarse``: which coarse pass -- "int8-half" = the half-width pass of the gated family (VFM_RECORDS_HALF: int8 MFMA over the
 first d / 2 columns, the other half bounded by Cauchy-Schwarz against the gate; needs the gate), "int8" / "int8-top2" = the
 gated family of include/vfmreg.h with best-score / packed top-2 records (queries that provably miss ``min_cosine`` stay unresolved: idx -1, sim -2.0; correspondences and pose are
-unaffected), "fp16" = the fp16 pass (VFM_RECORDS_F16: every query resolved), "auto" (default) = the half-width pass while a search reports at most
-``HALF_LIMIT`` surviving chunks per query, then best-score records until a search reports more than
+unaffected), "fp16" = the fp16 pass (VFM_RECORDS_F16: every query resolved), "auto" (default) = the half-width pass if a probe of it (first registration,
+then every ``REPROBE``) and every search after that report at most ``HALF_LIMIT`` surviving chunks per query, else best-score
+records until a search reports more than
 ``RESCAN_LIMIT`` rescanned chunks per query (duplicate-rich maps), then top-2 records, then -- above ``TOP2_LIMIT`` -- the fp16
 pass, with a probe one step back every ``REPROBE`` registrations.  ``gate=False`` keeps the int8 pass but resolves every query.
 """
@@ -84,8 +85,13 @@ class RegistrationPipeline:
         self.use_i8 = coarse != "fp16"
         self.top2 = coarse == "int8-top2"   # int8 pass with packed top-2 records (VFM_RECORDS_TOP2)
         # half-width pass (VFM_RECORDS_HALF): where the library has no kernel for it the call behaves as best-score records
-        self.half = coarse == "int8-half" or (coarse == "auto" and self.gate)
+        # ... and where almost every chunk survives its bound (descriptors that are all alike) it is two orders of magnitude slower
+        # than any other mode: "auto" therefore PROBES it (vfm_match_search_probe_half: its coarse pass + a count of the survivors,
+        # +0.7 ms once) on the first registration and at every re-probe interval, and switches to it only on a good count
+        self.half = coarse == "int8-half"
+        self._probe_due = coarse == "auto" and self.gate
         self.last_rescans: Optional[int] = None
+        self.last_probe: Optional[int] = None
         self._since_switch = 0
         self._pending = []  # (event, pinned int32[1]) of gated searches whose rescan count is on its way to the host
         self._slots = []    # pinned slots ready for reuse
@@ -134,6 +140,13 @@ class RegistrationPipeline:
         """Non-blocking: consume the rescan counts that have arrived and pick the coarse pass of the next registrations."""
         while self._pending and self._pending[0][0].query():
             _, slot, records = self._pending.pop(0)
+            if records == "probe":  # survivors the half-width pass would leave (vfm_match_search_probe_half)
+                self.last_probe = int(slot.item())
+                self._slots.append(slot)
+                if self.coarse == "auto" and self.use_i8 and not self.half and self.last_probe <= self.HALF_LIMIT * self.n:
+                    self.half, self.top2 = True, False
+                    self._since_switch = 0
+                continue
             self.last_rescans = int(slot.item())
             self._slots.append(slot)
             if self.coarse != "auto" or not self.use_i8 or records != self._records():
@@ -172,15 +185,14 @@ class RegistrationPipeline:
         self._poll_feedback()
         if self.coarse == "auto":
             self._since_switch += 1
-            if self._since_switch >= self.REPROBE and (not self.use_i8 or self.top2 or (not self.half and self.gate)):
+            if self._since_switch >= self.REPROBE and not self.half:
                 # every REPROBE registrations one step back towards the cheaper kernel (fp16 -> top-2 records -> best-score
-                # records -> half-width pass); the feedback of that probe decides whether it stays
+                # records); the feedback of that search decides whether it stays.  The half-width pass is probed, not tried.
                 if not self.use_i8:
                     self.use_i8, self.top2 = True, True
                 elif self.top2:
                     self.top2 = False
-                else:
-                    self.half = True
+                self._probe_due = self.gate
                 self._since_switch = 0
         i8, records = self.use_i8, self._records()
         if records == 3 and reuse_map:
@@ -214,6 +226,15 @@ class RegistrationPipeline:
             _lib.check(lib.vfm_match_prepare(q_desc.data_ptr(), self.n, self.d, r.qprep.data_ptr(), pst), "prepare(scan)")
         if self.overlap and pst != st:
             main.wait_stream(self.prep_stream)
+        gate = float(np.nextafter(np.float32(self.min_cosine), np.float32(-np.inf))) if self.gate else float("-inf")
+        if i8 and self._probe_due and not self.half and not reuse_map and len(self._pending) < 8:
+            self._probe_due = False
+            slot = self._slots.pop() if self._slots else torch.zeros(1, dtype=torch.int32).pin_memory()
+            _lib.check(lib.vfm_match_search_probe_half(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d, r.sws.data_ptr(),
+                                                       r.sws.numel(), gate, slot.data_ptr(), st), "probe(half)")
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._pending.append((ev, slot, "probe"))
         if i8:
             _lib.check(lib.vfm_match_search_coarse_gated_r(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
                                                            r.sws.data_ptr(), r.sws.numel(), records, st), "search(coarse)")
@@ -227,8 +248,7 @@ class RegistrationPipeline:
             ev.record(main)
             solve.wait_event(ev)
             rst = solve.cuda_stream
-        # only matches with cosine >= min_cosine are kept below: queries that provably cannot reach it stay unresolved
-        gate = float(np.nextafter(np.float32(self.min_cosine), np.float32(-np.inf))) if self.gate else float("-inf")
+        # only matches with cosine >= min_cosine are kept below: queries that provably cannot reach it stay unresolved (gate)
         if i8:
             _lib.check(lib.vfm_match_search_finish_gated_r(q_desc.data_ptr(), r.qprep.data_ptr(), self.n, b_desc.data_ptr(),
                                                            r.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(), r.sim.data_ptr(),
