@@ -9,10 +9,15 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | cut -c1-300
 timeout 600 python bench.py --streams 1 --no-cpu-baseline --no-extra > $O/bench_streams1.json 2>> $O/bench.err
 VFM_VARIANT=5 timeout 600 python bench.py --no-cpu-baseline --no-extra > $O/bench_f16_same_box.json 2>> $O/bench.err; tail -1 $O/bench_f16_same_box.json | cut -c1-200
+VFM_COARSE=int8 timeout 600 python bench.py --no-cpu-baseline --no-extra > $O/bench_int8_full_same_box.json 2>> $O/bench.err; tail -1 $O/bench_int8_full_same_box.json | cut -c1-200
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --no-cpu-baseline --no-extra > $O/bench_prof.json 2> $O/prof.err; tail -1 $O/bench_prof.json | cut -c1-200
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -o bench1 -- python $R/bench.py --streams 1 --no-cpu-baseline --no-extra > $O/bench_prof1.json 2> $O/prof1.err
-cd $R && bash tools/pmc_coarse.sh 2>&1 | tail -30
+# PMC passes: the half-width kernel the bench runs on D.2 data (VFM_RECORDS=3), then the full-width best-score kernel (0)
+cd $R && VFM_RECORDS=3 bash tools/pmc_coarse.sh 2>&1 | tail -22
+cp $R/gpurun_out/pmc_coarse/pmc_match_coarse.json $O/pmc_match_coarse_half.json 2>/dev/null
+for i in 1 2 3 4 5 6 7; do cp $R/gpurun_out/pmc_coarse/p${i}_counter_collection.csv $O/pmc_half_pass${i}_counter_collection.csv 2>/dev/null; done
+cd $R && VFM_RECORDS=0 bash tools/pmc_coarse.sh 2>&1 | tail -22
 cp $R/gpurun_out/pmc_coarse/pmc_match_coarse.json $O/ 2>/dev/null
 for i in 1 2 3 4 5 6 7; do cp $R/gpurun_out/pmc_coarse/p${i}_counter_collection.csv $O/pmc_pass${i}_counter_collection.csv 2>/dev/null; done
 cd $R && python tools/time_neardup.py --steps 20 --out $O/neardup.json > $O/neardup.log 2>&1
@@ -27,5 +32,6 @@ timeout 300 python tools/time_c3_modes.py 2>/dev/null | tail -5 > $O/time_c3_mod
 timeout 300 python tools/tax_probe.py 2>/dev/null > $O/tax_probe.txt
 { for c in "0 0" "64 0" "0 64" "64 64" "0 0"; do timeout 100 python tools/cu_mask_probe.py $c 2>/dev/null; done; } > $O/cu_mask_probe.txt
 VFM_GATE=0.7999999 bash tools/prof_i8.sh 0 > $O/prof_search_c2.txt 2>&1
+{ for s in "20000 200000 384" "50000 1000000 768" "20000 50000 256" "3000 100000 384"; do echo "## $s"; VFM_AB_RECORDS=0,3,1,0,3 timeout 200 python tools/ab_half.py $s 2>/dev/null; done; } > $O/ab_half.txt
 bash tools/prof_c3.sh > $O/prof_c3.txt 2>&1
 tail -3 $O/steps_sweep.txt | cut -c1-200; cat $O/time_c3_modes.txt

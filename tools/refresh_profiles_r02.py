@@ -37,15 +37,20 @@ def main():
               "time_vit_batch.txt": "r02_time_vit_batch.txt", "time_ungated.txt": "r02_time_ungated.txt",
               "time_c3_modes.txt": "r02_time_c3_modes.txt", "tax_probe.txt": "r02_tax_probe.txt",
               "cu_mask_probe.txt": "r02_cu_mask_probe.txt", "prof_search_c2.txt": "r02_prof_search_c2.txt",
-              "prof_c3.txt": "r02_prof_c3.txt"}
+              "prof_c3.txt": "r02_prof_c3.txt", "ab_half.txt": "r02_ab_half.txt",
+              "pmc_match_coarse_half.json": "r02_pmc_match_coarse_i8half.json",
+              "bench_int8_full_same_box.json": "r02_bench_int8_full_same_box.json"}
     for i in range(1, 8):
         copies[f"pmc_pass{i}_counter_collection.csv"] = f"r02_pmc_pass{i}_counter_collection.csv"
+        copies[f"pmc_half_pass{i}_counter_collection.csv"] = f"r02_pmc_half_pass{i}_counter_collection.csv"
     for a, b in copies.items():
         if (SRC / a).exists():
             shutil.copy(SRC / a, DST / b)
     b = last_json(DST / "r02_bench.json")
     b1 = last_json(DST / "r02_bench_streams1.json")
     bf = last_json(DST / "r02_bench_f16_same_box.json")
+    bi = last_json(DST / "r02_bench_int8_full_same_box.json")
+    pmh = json.loads((DST / "r02_pmc_match_coarse_i8half.json").read_text())
     pmc = json.loads((DST / "r02_pmc_match_coarse_i8.json").read_text())
     r = b["roofline"]
     ex = b["extra"]
@@ -70,16 +75,20 @@ the coarse kernel, duplicate-rich maps) through `gpurun` (a fresh box per call; 
 collected by `python tools/refresh_profiles_r02.py`.  Raw files are next to this one (`r02_*`); the same set for the fp16
 coarse pass as it stood before the int8 pass is in `r02_*_f16*` (summary: `r02_bench_summary_f16.md`).
 
-## bench.py (default: int8 coarse pass; operand preparation | coarse pass | two solve streams)
+## bench.py (default: int8 coarse pass -- on D.2 descriptors the half-width pass; operand preparation | coarse pass | two solve streams)
 
 `python bench.py` -> `profiles/r02_bench.json`: **{b['value']:.1f} registrations/s** ({b['ms_per_step']:.3f} ms per
 registration), dominant kernel `{r['kernel'].split(' (')[0]}` {r['avg_launch_ms']:.3f} ms per launch inside the timed region =
-{r['achieved']:.0f} TOP/s = {r['frac']:.3f} of the {r['peak'] / 1000:.1f} POP/s dense int8 MFMA peak;
+{r['achieved']:.0f} TOP/s = {r['frac']:.3f} of the {r['peak'] / 1000:.1f} POP/s dense int8 MFMA peak (operations of the kernel as launched:
+{r['flops_per_launch'] / 1e12:.3f} TOP -- coarse pass in use: {b['config'].get('coarse_pass', '?')});
 alone on the GPU {r['single_stream']['avg_launch_ms']:.3f} ms = {r['single_stream']['achieved']:.0f} TOP/s =
 {r['single_stream']['frac']:.3f}.  CPU oracle on the same box ({b['cpu_baseline']['cores']} threads): {b['cpu_baseline']['value']:.3f} registrations/s.
 Pose delta vs the oracle on identical inputs (`extra.pose_delta_vs_oracle`): {ex.get('pose_delta_vs_oracle', {}).get('pose_delta_vs_oracle_frobenius')}.
 `extra.C3`: {ex['C3']['ms_end_to_end']:.2f} ms end to end (ViT {ex['C3']['ms_vit']:.2f}, project + lift {ex['C3']['ms_project_lift']:.2f}, registration {ex['C3']['ms_registration']:.2f}; ViT at {ex['C3']['vit_roofline']['frac']:.3f} of the MFMA peak).
 `extra.C5` (50k x 1M x 768, int8 pass): coarse kernel {ex['C5']['ms_coarse_kernel']:.1f} ms = {ex['C5']['roofline']['frac']:.3f} of the int8 peak, registration {ex['C5']['ms_registration']:.1f} ms.
+
+Same box, `VFM_COARSE=int8 python bench.py` (full-width int8 pass, best-score records) -> `profiles/r02_bench_int8_full_same_box.json`:
+{bi['value']:.1f} registrations/s, kernel {bi['roofline']['avg_launch_ms']:.3f} ms ({bi['roofline']['frac']:.3f} of the int8 peak).
 
 Same box, `VFM_VARIANT=5 python bench.py` (the fp16 coarse pass with sparse records, round 2's earlier default) ->
 `profiles/r02_bench_f16_same_box.json`: {bf['value']:.1f} registrations/s, kernel {bf['roofline']['avg_launch_ms']:.3f} ms
@@ -102,6 +111,13 @@ Serial (`--streams 1`), `profiles/r02_bench_streams1_kernel_stats.csv`:
 {stats_table(DST / 'r02_bench_streams1_kernel_stats.csv', 16)}
 
 ## PMC passes of the coarse kernel (`bash tools/pmc_coarse.sh`, separate --pmc passes, --kernel-trace only)
+
+Half-width kernel (`VFM_RECORDS=3`; `profiles/r02_pmc_match_coarse_i8half.json` + `profiles/r02_pmc_half_pass*_counter_collection.csv`,
+{pmh['kernel']}): **{pmh['hbm_bytes_per_launch'] / 1e9:.2f} GB per launch** (`roofline.traffic` of the default bench line), L2 hit rate
+{pmh['TCC_hit_rate']:.3f}, clock {pmh['clock_GHz']:.2f} GHz, MFMA pipe busy {pmh['mfma_busy_fraction']:.3f}, LDS array busy {pmh['lds_array_busy_fraction']:.3f},
+per MFMA {pmh['per_mfma']['valu_incl_mfma']:.2f} VALU (incl. the MFMA) / {pmh['per_mfma']['salu']:.2f} SALU / {pmh['per_mfma']['lds']:.2f} LDS.
+
+Full-width kernel (`VFM_RECORDS=0`):
 
 `profiles/r02_pmc_match_coarse_i8.json` + `profiles/r02_pmc_pass*_counter_collection.csv` ({pmc['kernel']}): FETCH_SIZE {pmc['FETCH_SIZE_KB'] / 1024:.0f} MB (x2 per the
 guide's gfx950 correction), WRITE_SIZE {pmc['WRITE_SIZE_KB'] / 1024:.0f} MB -> **{pmc['hbm_bytes_per_launch'] / 1e9:.2f} GB per launch** (`roofline.traffic`; fp16 pass: 1.05 GB);
@@ -126,7 +142,8 @@ first ~15 launches after the synchronise run slower), `r02_power_probe.txt` (roc
 run), `r02_tax_probe.txt` (steady state with side stages replaced by no-ops), `r02_cu_mask_probe.txt` (side stages on
 CU-masked streams: slower in every split), `r02_prof_search_c2.txt` (kernels of one gated C2 search), `r02_prof_c3.txt` +
 `r02_time_c3_modes.txt` (C3's registration per coarse mode), `r02_time_ungated.txt` (ungated calls: fp16 pass vs the
-routing by size), `r02_time_vit_batch.txt` (ViT forward against the number of images per call).
+routing by size), `r02_time_vit_batch.txt` (ViT forward against the number of images per call), `r02_ab_half.txt` (half-width pass vs
+best-score / top-2 records at four sizes: coarse kernel, finish stage, survivors, agreement of the answers).
 
 ## Other evidence files
 
