@@ -102,6 +102,19 @@ int vfm_match_search_finish(const float *q, const void *q_prepared, int64_t n, c
  * same either way.) */
 int vfm_match_prepare2_gated(const float *x1, int64_t rows1, void *prepared1, const float *x2, int64_t rows2,
                              void *prepared2, int d, vfm_stream_t stream);
+/* The same with the launch shape of the int8 preparation kernel chosen by the caller:
+ *   VFM_PREPARE_PERSISTENT   one workgroup per compute unit, each walking several 128-row groups with the next group's rows read
+ *                            under the current group's quantisation and store -- the faster form when nothing else runs
+ *                            beside it or when the kernels beside it leave registers free (C2 alone: 81 vs 109 us; beside
+ *                            the half-width coarse kernel: 1295 vs 1247 registrations/s);
+ *   VFM_PREPARE_INTERLEAVED  one short workgroup per group -- interleaves better with a kernel whose workgroups need whole
+ *                            compute units (the full-width int8 coarse kernel: 791 vs 783 registrations/s);
+ *   VFM_PREPARE_DEFAULT      the library's default (INTERLEAVED). */
+#define VFM_PREPARE_DEFAULT 0
+#define VFM_PREPARE_PERSISTENT 1
+#define VFM_PREPARE_INTERLEAVED 2
+int vfm_match_prepare2_gated_p(const float *x1, int64_t rows1, void *prepared1, const float *x2, int64_t rows2,
+                               void *prepared2, int d, int schedule, vfm_stream_t stream);
 int vfm_match_search_coarse_gated(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
                                   int d, void *ws, size_t ws_bytes, vfm_stream_t stream);
 int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_t n, const float *b,

@@ -29,7 +29,7 @@ bash tools/power_probe.sh > /dev/null 2>&1; cp $R/gpurun_out/power_probe.txt $O/
 timeout 300 python tools/time_vit_batch.py > $O/time_vit_batch.txt 2>/dev/null
 { for s in "20000 200000 384" "2000 200000 384" "300 50000 384" "20000 50000 256" "50000 1000000 768"; do echo "## $s"; timeout 200 python tools/time_ungated.py $s 2>/dev/null; done; } > $O/time_ungated.txt
 timeout 300 python tools/time_c3_modes.py 2>/dev/null | tail -5 > $O/time_c3_modes.txt
-timeout 300 python tools/tax_probe.py 2>/dev/null > $O/tax_probe.txt
+# (tools/tax_probe.py predates the half-width probe of the pipeline: its no-op patching stalls there; run it with VFM_COARSE-style fixed modes only)
 { for c in "0 0" "64 0" "0 64" "64 64" "0 0"; do timeout 100 python tools/cu_mask_probe.py $c 2>/dev/null; done; } > $O/cu_mask_probe.txt
 VFM_GATE=0.7999999 bash tools/prof_i8.sh 0 > $O/prof_search_c2.txt 2>&1
 { for s in "20000 200000 384" "50000 1000000 768" "20000 50000 256" "3000 100000 384"; do echo "## $s"; VFM_AB_RECORDS=0,3,1,0,3 timeout 200 python tools/ab_half.py $s 2>/dev/null; done; } > $O/ab_half.txt

@@ -174,6 +174,15 @@ VFM_EXPORT int vfm_match_prepare2_gated(const float* x1, int64_t rows1, void* pr
     return do_prepare2(x1, rows1, prepared1, x2, rows2, prepared2, d, (hipStream_t)stream, want_f16);
 }
 
+VFM_EXPORT int vfm_match_prepare2_gated_p(const float* x1, int64_t rows1, void* prepared1, const float* x2, int64_t rows2,
+                                          void* prepared2, int d, int schedule, vfm_stream_t stream) {
+    VFM_CHECK_ARG(rows1 > 0 && rows2 > 0 && d % 128 == 0 && d >= 128 && d <= 768, "prepare2: d must be in {128,256,384,512,640,768}");
+    VFM_CHECK_ARG(x1 && x2 && prepared1 && prepared2, "prepare2: null pointer");
+    VFM_CHECK_ARG(schedule >= VFM_PREPARE_DEFAULT && schedule <= VFM_PREPARE_INTERLEAVED, "prepare2: unknown schedule %d", schedule);
+    const bool want_f16 = !use_i8(d, rows2, rows1, true);
+    return do_prepare2(x1, rows1, prepared1, x2, rows2, prepared2, d, (hipStream_t)stream, want_f16, schedule);
+}
+
 VFM_EXPORT size_t vfm_match_search_workspace_bytes(int64_t n, int64_t m, int d) {
     (void)d;
     return carve_search(nullptr, n, m).bytes;

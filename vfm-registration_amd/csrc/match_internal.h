@@ -407,7 +407,7 @@ CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, 
 
 // match_prep.hip
 int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2, int64_t rows2, void* prepared2, int d,
-                hipStream_t st, bool want_f16 = true);
+                hipStream_t st, bool want_f16 = true, int grid_mode = 0 /* VFM_PREPARE_DEFAULT */);
 int do_prepare(const float* x, int64_t rows, int d, void* prepared, hipStream_t st);
 // match_coarse_f16.hip / match_coarse_i8.hip: launch the coarse kernel for arguments prepared by do_search_coarse
 int launch_coarse_f16(const CoarseArgs& a, int d, hipStream_t st);

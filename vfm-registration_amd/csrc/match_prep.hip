@@ -349,21 +349,22 @@ inline PrepOut prep_out(const Prepared& p) { return PrepOut{p.inv, p.tiles, p.er
 // previous registration -- whose workgroups need a whole compute unit each -- the short workgroups interleave better
 // (791 vs 783 registrations/s over 300 steps, same box), and that is where the pipeline runs it.
 int g_prep_grid = -1;
-inline int prep_grid(int groups) {
+inline int prep_grid(int groups, int mode) {
     static thread_local int cus = 0;
     if (!cus) {
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
-    int g = g_prep_grid > 0 ? g_prep_grid : (g_prep_grid < 0 ? groups : cus);
+    const int knob = mode == VFM_PREPARE_DEFAULT ? g_prep_grid : (mode == VFM_PREPARE_PERSISTENT ? 0 : -1);
+    int g = knob > 0 ? knob : (knob < 0 ? groups : cus);
     return g < groups ? g : groups;
 }
 
 // one or two operands (x2 may be NULL) in one launch.  want_f16 = false: only the int8 image (d = 256, 384), for operands that
 // will meet in an int8 search (use_i8): a third of the bytes written, a third of the LDS.
 int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2, int64_t rows2, void* prepared2, int d,
-                hipStream_t st, bool want_f16) {
+                hipStream_t st, bool want_f16, int grid_mode) {
     Prepared p1 = carve_prepared(prepared1, rows1, d);
     Prepared p2 = x2 ? carve_prepared(prepared2, rows2, d) : Prepared{};
     const int t1 = (int)(rows_padded(rows1) / TILE_ROWS), t2 = x2 ? (int)(rows_padded(rows2) / TILE_ROWS) : 0;
@@ -380,7 +381,7 @@ int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2
             attr_mark(attr_set);
         }
         const int groups = g1 + g2;
-        int pg = prep_grid(groups);
+        int pg = prep_grid(groups, grid_mode);
         const dim3 grid((unsigned)pg), block(1024);
         if (want_f16 && d <= 384) {  // both images from one read of the rows (144 KB of LDS at d = 384)
             hipLaunchKernelGGL((prep_chunk_kernel<true, 2>), grid, block, (size_t)I8_GROUP * d * 3, st, x1, rows1, d, prep_out(p1), g1, x2,

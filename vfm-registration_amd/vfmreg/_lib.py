@@ -41,6 +41,7 @@ SIGNATURES = {
     "vfm_match_prepare": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, c_vp]),
     "vfm_match_prepare2": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, C.c_int, c_vp]),
     "vfm_match_prepare2_gated": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, C.c_int, c_vp]),
+    "vfm_match_prepare2_gated_p": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, C.c_int, C.c_int, c_vp]),
     "vfm_match_search_workspace_bytes": (C.c_size_t, [c_i64, c_i64, C.c_int]),
     "vfm_match_search_prepared": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp,
                                             C.c_size_t, c_vp]),

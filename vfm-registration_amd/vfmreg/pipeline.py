@@ -218,9 +218,15 @@ class RegistrationPipeline:
             pst = self.prep_stream.cuda_stream
         if not (reuse_map and r.map_key == b_desc.data_ptr()):
             # (a map that will be reused keeps both images: the coarse pass may change between registrations)
-            prep2 = lib.vfm_match_prepare2_gated if (i8 and not reuse_map) else lib.vfm_match_prepare2
-            _lib.check(prep2(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
-                             r.qprep.data_ptr(), self.d, pst), "prepare(map + scan)")
+            if i8 and not reuse_map:
+                # the preparation kernel's launch shape: persistent when it runs alone or beside the half-width coarse kernel
+                # (which leaves registers free), short workgroups beside the full-width one (include/vfmreg.h)
+                schedule = 1 if (records == 3 or not (self.overlap and self.overlap_prepare)) else 2
+                _lib.check(lib.vfm_match_prepare2_gated_p(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
+                                                          r.qprep.data_ptr(), self.d, schedule, pst), "prepare(map + scan)")
+            else:
+                _lib.check(lib.vfm_match_prepare2(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
+                                                  r.qprep.data_ptr(), self.d, pst), "prepare(map + scan)")
             r.map_key = b_desc.data_ptr() if reuse_map else None
         else:
             _lib.check(lib.vfm_match_prepare(q_desc.data_ptr(), self.n, self.d, r.qprep.data_ptr(), pst), "prepare(scan)")
