@@ -53,10 +53,11 @@ def lifted_map(m, d, clouds, cams, gh, gw, seed, view_noise, dev, revisit=0):
 def run(pipe, p, steps, lib, n, m):
     ev = torch.cuda.Event()
     ev.record()
-    for i in range(3):
+    for i in range(8):   # warm-up, one registration at a time: the "auto" policy settles (probe -> records by feedback)
         pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"], inputs_ready=ev)
-    pipe.synchronize()
-    torch.cuda.synchronize()
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        pipe._poll_feedback()
     t0 = time.perf_counter()
     for i in range(steps):
         out = pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"], inputs_ready=ev)
