@@ -132,9 +132,11 @@ class RegistrationPipeline:
     # vs 1.85; 12.4: 2.01 vs 1.94; 31.6: 2.57 vs 2.28; 99: 10.8 vs 3.4 (the chunk-major rescan, match_rescan_chunk_kernel, moved
     # the crossover from ~2.5 to ~10); top-2 records -> fp16 pass above TOP2_LIMIT (whole-chunk rescans + 1/32 per single row;
     # never reached on the maps measured: the fp16 pass takes 4.2 ms where top-2 records take 3.4)
-    # half-width pass -> best-score records above HALF_LIMIT surviving chunks per query (D.2 descriptors: 0.5 -- the planted
-    # matches and nothing else; lifted descriptors that are all alike: hundreds)
-    HALF_LIMIT = 4.0
+    # half-width pass -> best-score records above HALF_LIMIT surviving chunks per query (tools/time_neardup.py, ms per
+    # registration, half-width vs best-score records: D.2 descriptors, 0.5 survivors per query -- the planted matches and nothing
+    # else: 0.87 vs 1.48; lifted, independent views, 20 per query: 1.23 vs 1.60; lifted, shared scene, 96: 8.3 vs 1.8; descriptors
+    # that are all alike (C3): every chunk, 195 vs 2.4)
+    HALF_LIMIT = 24.0
     RESCAN_LIMIT = 10.0
     TOP2_LIMIT = 40
     REPROBE = 256       # registrations before one step back towards the cheaper kernel is probed
