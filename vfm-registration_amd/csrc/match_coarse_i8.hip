@@ -165,7 +165,9 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8_kernel(CoarseArgs a) {
 // query set, sharing the fragment); the accumulators of a finished tile are folded in the slots of the next one, and two
 // accumulator pairs alternate, so nothing is copied.  One barrier per 8 * KSTEPS MFMAs.
 // ---------------------------------------------------------------------------------------------
-template <int KSTEPS, bool TOP2 = false>
+// LOW = false (half-width pass): the running lower bound of the query's exact maximum is not kept -- its selection tests
+// against the gate alone
+template <int KSTEPS, bool TOP2 = false, bool LOW = true>
 __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVES = 8, T = 4;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a)
     unsigned s1[2] = {0u, 0u}, s2[2] = {0u, 0u}, unused_max = 0u;
     auto emit_chunk = [&](int chunk) __attribute__((always_inline)) {  // chunk < 0: nothing folded yet
         float sb = 0.f, be = 0.f;
-        const bool counted = chunk >= 0;  // wave-uniform
+        const bool counted = LOW && chunk >= 0;  // wave-uniform
         if (counted) {
             sb = a.ib.bstep[chunk];
             be = a.ib.berr[chunk];
@@ -309,9 +311,11 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a)
         else s1[e >> 4] = max(s1[e >> 4], (unsigned)accB[e >> 4][e & 15]);
     }
     emit_chunk(c0 + (ntiles >> 2) - 1);
+    if constexpr (LOW) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-        if (lane < 32 && qt0 + j < a.nq_tiles) atomicMax(a.qmax + (size_t)(qt0 + j) * 32 + lane, float_key(i8_low[j]));
+        for (int j = 0; j < 2; ++j)
+            if (lane < 32 && qt0 + j < a.nq_tiles) atomicMax(a.qmax + (size_t)(qt0 + j) * 32 + lane, float_key(i8_low[j]));
+    }
 }
 
 
@@ -330,16 +334,16 @@ int launch_coarse_i8(const CoarseArgs& a, hipStream_t st) {
     return VFM_OK;
 }
 
-template <int KSTEPS, bool TOP2>
+template <int KSTEPS, bool TOP2, bool LOW = true>
 int launch_coarse_i8q2(const CoarseArgs& a, hipStream_t st) {
     const int lds = 12 * KSTEPS * 1024;
     static unsigned long long attr_set = 0ull;  // one bit per device
     if (!attr_done(attr_set)) {
-        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_i8q2_kernel<KSTEPS, TOP2>),
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_i8q2_kernel<KSTEPS, TOP2, LOW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_mark(attr_set);
     }
-    hipLaunchKernelGGL((match_coarse_i8q2_kernel<KSTEPS, TOP2>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((match_coarse_i8q2_kernel<KSTEPS, TOP2, LOW>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
     return VFM_OK;
 }
 
@@ -356,7 +360,7 @@ int launch_coarse_int8(CoarseArgs& a, int d, int64_t n, int records, hipStream_t
         if (d <= 384) {
             a.nqb = (a.nq_tiles + 15) / 16;
             a.nslices = choose_slices(a.nqb, a.nchunks);
-            rc8 = d == 384 ? launch_coarse_i8q2<6, false>(a, st) : launch_coarse_i8q2<4, false>(a, st);
+            rc8 = d == 384 ? launch_coarse_i8q2<6, false, false>(a, st) : launch_coarse_i8q2<4, false, false>(a, st);
         } else {
             rc8 = d == 768 ? launch_coarse_i8<12, 4>(a, st) : launch_coarse_i8<8, 4>(a, st);
         }
