@@ -17,7 +17,8 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // TOP2: the packed per-chunk top-2 records of the fp16 pass (best row index included, 3 VALU ops per element) instead of the
 // best value alone: candidate chunks with one row inside the bounds need no rescan -- the choice for duplicate-rich maps.
-template <int KSTEPS, int T, bool TOP2 = false>
+// LOW = false (half-width pass): no running lower bound of the query's exact maximum (see match_coarse_i8q2_kernel)
+template <int KSTEPS, int T, bool TOP2 = false, bool LOW = true>
 __global__ __launch_bounds__(512, 2) void match_coarse_i8_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVES = 8;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8_kernel(CoarseArgs a) {
     unsigned s1 = 0u, s2 = 0u, unused_max = 0u;
     auto emit_chunk = [&](int chunk) __attribute__((always_inline)) {  // chunk < 0: nothing folded yet
         const unsigned best = TOP2 ? coarse_emit_chunk(a, s1, s2, unused_max, qt, chunk) : coarse_emit_chunk_best(a, s1, qt, chunk);
-        if (chunk >= 0) {  // wave-uniform
+        if (LOW && chunk >= 0) {  // wave-uniform
             // a chunk with zero-padded rows (they score exactly 0) counts only where its best score is positive: that score
             // belongs to a real row
             const float sb = a.ib.bstep[chunk], be = a.ib.berr[chunk];
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8_kernel(CoarseArgs a) {
         else s1 = max(s1, (unsigned)prev[e >> 4][e & 15]);
     }
     emit_chunk(c0 + (ntiles >> 2) - 1);
-    if (lane < 32 && qt < a.nq_tiles) atomicMax(a.qmax + (size_t)qt * 32 + lane, float_key(i8_low));
+    if (LOW && lane < 32 && qt < a.nq_tiles) atomicMax(a.qmax + (size_t)qt * 32 + lane, float_key(i8_low));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -321,16 +322,16 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a)
 
 }  // namespace
 
-template <int KSTEPS, int T, bool TOP2 = false>
+template <int KSTEPS, int T, bool TOP2 = false, bool LOW = true>
 int launch_coarse_i8(const CoarseArgs& a, hipStream_t st) {
     const int lds = 3 * T * KSTEPS * 1024;
     static unsigned long long attr_set = 0ull;  // one bit per device
     if (!attr_done(attr_set)) {
-        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_i8_kernel<KSTEPS, T, TOP2>),
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_i8_kernel<KSTEPS, T, TOP2, LOW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_mark(attr_set);
     }
-    hipLaunchKernelGGL((match_coarse_i8_kernel<KSTEPS, T, TOP2>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((match_coarse_i8_kernel<KSTEPS, T, TOP2, LOW>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
     return VFM_OK;
 }
 
@@ -362,7 +363,7 @@ int launch_coarse_int8(CoarseArgs& a, int d, int64_t n, int records, hipStream_t
             a.nslices = choose_slices(a.nqb, a.nchunks);
             rc8 = d == 384 ? launch_coarse_i8q2<6, false, false>(a, st) : launch_coarse_i8q2<4, false, false>(a, st);
         } else {
-            rc8 = d == 768 ? launch_coarse_i8<12, 4>(a, st) : launch_coarse_i8<8, 4>(a, st);
+            rc8 = d == 768 ? launch_coarse_i8<12, 4, false, false>(a, st) : launch_coarse_i8<8, 4, false, false>(a, st);
         }
     } else if (d <= 384 && n > 2048 && g_coarse_qsets == 0) {
         // 64 resident queries per wave: 11-15 % faster than the one-set kernel from ~3000 queries on (C2: 1.09 vs 1.23 ms;

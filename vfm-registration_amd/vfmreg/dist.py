@@ -48,6 +48,9 @@ def gather_poses(local_poses: torch.Tensor, local_aux: torch.Tensor, num_pairs: 
     local_poses: [n_local, 4, 4] fp64, local_aux: [n_local] int64 (e.g. correspondence counts), for
     the pairs of ``shard_pairs`` in order.  Returns ([num_pairs, 4, 4], [num_pairs]) on every rank.
     """
+    if world == 1 and local_poses.shape[0] == num_pairs:
+        # one rank owns every pair, in order: nothing to gather or to reorder
+        return local_poses.clone(), local_aux.to(torch.int64).clone()
     cap = pairs_per_rank(num_pairs, world)
     dev = local_poses.device
     buf = torch.zeros((cap, 17), dtype=torch.float64, device=dev)
