@@ -146,8 +146,18 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
  *                     Exists for d = 256 / 384 with more than 2048 queries and for d = 512 / 768; elsewhere the call
  *                     behaves as VFM_RECORDS_BEST. */
 #define VFM_RECORDS_HALF 3
+/*   VFM_RECORDS_HALF_FUSED  the half-width pass with its selection inside the coarse kernel: the gate is known when the coarse
+ *                     pass runs (vfm_match_search_coarse_gated_g), so a (query, chunk) pair is tested the moment its best score
+ *                     exists and a survivor goes straight into the chunk's rescan bin -- no records are written or read back,
+ *                     no selection kernel.  The matching _finish call takes the same gate and this record kind.  Exists for
+ *                     d = 256 / 384 with more than 2048 queries and at least four queries per map chunk; elsewhere it behaves
+ *                     as VFM_RECORDS_HALF. */
+#define VFM_RECORDS_HALF_FUSED 4
 int vfm_match_search_coarse_gated_r(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
                                     int d, void *ws, size_t ws_bytes, int records, vfm_stream_t stream);
+/* _coarse_gated_r with the gate of the search (needed by VFM_RECORDS_HALF_FUSED; ignored by the other kinds) */
+int vfm_match_search_coarse_gated_g(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
+                                    int d, void *ws, size_t ws_bytes, int records, float gate, vfm_stream_t stream);
 int vfm_match_search_finish_gated_r(const float *q, const void *q_prepared, int64_t n, const float *b,
                                     const void *b_prepared, int64_t m, int d, int64_t *idx_out,
                                     float *sim_out, void *ws, size_t ws_bytes, float gate, int records,

@@ -280,7 +280,7 @@ def _search_gated_split(q, b, gate, records):
     sim = torch.empty(n, dtype=torch.float32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     _lib.check(lib.vfm_match_prepare2_gated(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, st))
-    _lib.check(lib.vfm_match_search_coarse_gated_r(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, st))
+    _lib.check(lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, gate, st))
     _lib.check(lib.vfm_match_search_finish_gated_r(q.data_ptr(), qb.data_ptr(), n, b.data_ptr(), bb.data_ptr(), m, d, idx.data_ptr(),
                                                    sim.data_ptr(), ws.data_ptr(), ws.numel(), gate, records, st))
     torch.cuda.synchronize()
@@ -319,14 +319,16 @@ def test_half_width_pass_keeps_the_gate_contract(d, n, m):
         bn, _ = orc.l2norm_rows(bb)
         ridx, rsim = orc.match_ip_top1(qn, bn)
         qd, bd = torch.from_numpy(qq).cuda(), torch.from_numpy(bb).cuda()
-        idx, sim = _search_gated_split(qd, bd, gate, 3)
-        solved = _gate_contract(idx, sim, ridx, rsim, gate)
-        assert solved[rsim >= 0.8].all(), name
-        # ... and the correspondences a caller keeps (similarity >= min_cosine) are those of best-score records
         i0, s0 = _search_gated_split(qd, bd, gate, 0)
-        keep3, keep0 = (sim >= 0.8).cpu().numpy(), (s0 >= 0.8).cpu().numpy()
-        np.testing.assert_array_equal(keep3, keep0, err_msg=name)
-        np.testing.assert_array_equal(idx.cpu().numpy()[keep3], i0.cpu().numpy()[keep0], err_msg=name)
+        keep0 = (s0 >= 0.8).cpu().numpy()
+        for records in (3, 4):   # 4 = the selection fused into the coarse kernel (where that kernel exists; else as 3)
+            idx, sim = _search_gated_split(qd, bd, gate, records)
+            solved = _gate_contract(idx, sim, ridx, rsim, gate)
+            assert solved[rsim >= 0.8].all(), (name, records)
+            # ... and the correspondences a caller keeps (similarity >= min_cosine) are those of best-score records
+            keep3 = (sim >= 0.8).cpu().numpy()
+            np.testing.assert_array_equal(keep3, keep0, err_msg=f"{name} / {records}")
+            np.testing.assert_array_equal(idx.cpu().numpy()[keep3], i0.cpu().numpy()[keep0], err_msg=f"{name} / {records}")
 
 
 def test_half_width_pass_needs_a_gate_and_the_pipeline_leaves_it_on_descriptors_that_are_all_alike():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Half-width pass (VFM_RECORDS_HALF = 3) against best-score records (0) and packed top-2 records (1) of the gated family:
+"""Half-width pass (VFM_RECORDS_HALF = 3; 4 = the same with the selection fused into the coarse kernel) against best-score records (0) and packed top-2 records (1) of the gated family:
 coarse-kernel time, finish time, surviving chunks, and agreement of the answers under the gate contract (a query resolved by
 both has the same index and similarity; a query left unresolved by either has a best-score-records similarity below the gate)."""
 import ctypes as C
@@ -28,13 +28,13 @@ a, e = C.c_void_p(), C.c_void_p()
 _lib.check(lib.vfm_prof_events_create(C.byref(a), C.byref(e)))
 ms = C.c_float()
 res = {}
-for records in tuple(int(v) for v in os.environ.get("VFM_AB_RECORDS", "0,3,1,0,3").split(",")):
+for records in tuple(int(v) for v in os.environ.get("VFM_AB_RECORDS", "0,3,4,1,0,3,4").split(",")):
     idx = torch.empty(n, dtype=torch.int64, device="cuda")
     sim = torch.empty(n, dtype=torch.float32, device="cuda")
     tc, tf = [], []
     for i in range(10):
         lib.vfm_prof_arm(a, e)
-        _lib.check(lib.vfm_match_search_coarse_gated_r(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, st))
+        _lib.check(lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, gate, st))
         torch.cuda.synchronize()
         _lib.check(lib.vfm_prof_elapsed_ms(a, e, C.byref(ms)))
         t0 = time.perf_counter()
@@ -45,7 +45,7 @@ for records in tuple(int(v) for v in os.environ.get("VFM_AB_RECORDS", "0,3,1,0,3
             tc.append(ms.value)
             tf.append(1e3 * (time.perf_counter() - t0))
     lib.vfm_debug_set_match_stats(1)
-    _lib.check(lib.vfm_match_search_coarse_gated_r(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, st))
+    _lib.check(lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, gate, st))
     _lib.check(lib.vfm_match_search_finish_gated_r(q.data_ptr(), qb.data_ptr(), n, b.data_ptr(), bb.data_ptr(), m, d, idx.data_ptr(),
                                                    sim.data_ptr(), ws.data_ptr(), ws.numel(), gate, records, st))
     stats = (C.c_int32 * 64)()

@@ -104,7 +104,7 @@ CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, 
 // stage 1 of a search: the MFMA coarse pass (fills ws: partials + per-query coarse maxima)
 // records (int8 pass): 0 = best score per (query, chunk), 1 = packed top-2 with the best row's index (VFM_RECORDS_*)
 int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, hipStream_t st,
-                     bool bias_from_map_inv, bool inner_product, bool gated, int records) {
+                     bool bias_from_map_inv, bool inner_product, bool gated, int records, float gate) {
     Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
     Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);
     SearchWs w = carve_search(ws, n, m);
@@ -128,8 +128,22 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
     VFM_CHECK_HIP(hipMemsetAsync(w.fb_count, 0, search_zero_bytes(n, m), st));  // fb_count | qmax | rec_cnt | bin_cnt
     if (i8) {
         if (!gated) records = VFM_RECORDS_TOP2;  // no feedback loop behind an ungated call: the robust record kind
-        records = effective_records(records, d, n);
-        const bool half = records == VFM_RECORDS_HALF;   // the image of the first d / 2 columns
+        records = effective_records(records, d, n, m);
+        if (records == VFM_RECORDS_HALF_FUSED) {
+            if (!(gate > -__builtin_inff())) return vfm_fail(VFM_EINVAL, "search_coarse: VFM_RECORDS_HALF_FUSED needs a finite gate");
+            a.gate = gate;
+            a.n_valid = n;
+            a.qrest = Q.rest;
+            a.grest = B.grest;
+            a.bin_cnt = w.bin_cnt;
+            a.bins = w.bins;
+            a.cand_cnt = w.cand_cnt;
+            a.cand = w.cand;
+            a.cap = w.cap;
+            a.survivors = w.fb_count + 5;
+            VFM_CHECK_HIP(hipMemsetAsync(w.cand_cnt, 0, (size_t)a.npad * sizeof(int), st));  // lengths of the queries' own lists
+        }
+        const bool half = records == VFM_RECORDS_HALF || records == VFM_RECORDS_HALF_FUSED;   // the image of the first d / 2 columns
         a.Qh = half ? Q.tiles8h : Q.tiles8;
         a.Bh = half ? B.tiles8h : B.tiles8;
         a.ib = I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr, records == VFM_RECORDS_TOP2 ? 1 : 0};
@@ -234,6 +248,15 @@ VFM_EXPORT int vfm_match_search_coarse_gated_r(const void* q_prepared, int64_t n
     return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream, false, true, true, records);
 }
 
+VFM_EXPORT int vfm_match_search_coarse_gated_g(const void* q_prepared, int64_t n, const void* b_prepared, int64_t m, int d,
+                                               void* ws, size_t ws_bytes, int records, float gate, vfm_stream_t stream) {
+    if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
+    VFM_CHECK_ARG(q_prepared && b_prepared && ws, "search_coarse: null pointer");
+    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_HALF_FUSED, "search_coarse: unknown record kind %d", records);
+    VFM_CHECK_ARG(gate == gate, "search_coarse: gate is NaN");
+    return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream, false, true, true, records, gate);
+}
+
 VFM_EXPORT int vfm_match_search_finish_gated(const float* q, const void* q_prepared, int64_t n, const float* b,
                                              const void* b_prepared, int64_t m, int d, int64_t* idx_out, float* sim_out,
                                              void* ws, size_t ws_bytes, float gate, vfm_stream_t stream) {
@@ -247,7 +270,7 @@ VFM_EXPORT int vfm_match_search_finish_gated_r(const float* q, const void* q_pre
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q && b && q_prepared && b_prepared && ws && idx_out && sim_out, "search_finish: null pointer");
     VFM_CHECK_ARG(gate == gate, "search_finish: gate is NaN");
-    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_HALF, "search_finish: unknown record kind %d", records);
+    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_HALF_FUSED, "search_finish: unknown record kind %d", records);
     return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream, true, gate, records);
 }
 

@@ -168,7 +168,9 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8_kernel(CoarseArgs a) {
 // ---------------------------------------------------------------------------------------------
 // LOW = false (half-width pass): the running lower bound of the query's exact maximum is not kept -- its selection tests
 // against the gate alone
-template <int KSTEPS, bool TOP2 = false, bool LOW = true>
+// FUSE (half-width pass, VFM_RECORDS_HALF_FUSED): no records -- the chunk's best score is tested against the gate as soon as
+// it exists (the bound of match_select_half_kernel) and a survivor goes straight into the chunk's rescan bin
+template <int KSTEPS, bool TOP2 = false, bool LOW = true, bool FUSE = false>
 __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVES = 8, T = 4;
@@ -198,6 +200,8 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a)
 
     intx4 qf[2][KSTEPS];
     float i8_sq[2], i8_A[2], i8_mult[2], i8_low[2];
+    float fuse_rq[2] = {0.f, 0.f};
+    bool fuse_live[2] = {false, false};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int qt = qt0 + j < a.nq_tiles ? qt0 + j : 0;
@@ -213,6 +217,10 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a)
         i8_A[j] = eq * 1.0001220703125f + 1.0e-6f;
         i8_mult[j] = 1.0001220703125f + eq;
         i8_low[j] = -__builtin_inff();
+        if constexpr (FUSE) {
+            fuse_rq[j] = a.qrest[qi];
+            fuse_live[j] = qt0 + j < a.nq_tiles && (int64_t)qi < a.n_valid && a.qinv[qi] != 0.0f;
+        }
     }
     stage_step(gsrc, 0u);
     if (ntiles > T) stage_step(gsrc + (size_t)T * TILE_U4, (unsigned)(T * TILE_BYTES));
@@ -220,17 +228,38 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a)
 
     unsigned s1[2] = {0u, 0u}, s2[2] = {0u, 0u}, unused_max = 0u;
     auto emit_chunk = [&](int chunk) __attribute__((always_inline)) {  // chunk < 0: nothing folded yet
-        float sb = 0.f, be = 0.f;
-        const bool counted = LOW && chunk >= 0;  // wave-uniform
+        float sb = 0.f, be = 0.f, rb = 0.f;
+        const bool counted = (LOW || FUSE) && chunk >= 0;  // wave-uniform
         if (counted) {
             sb = a.ib.bstep[chunk];
             be = a.ib.berr[chunk];
+            if constexpr (FUSE) rb = a.grest[chunk];
         }
         // a chunk with zero-padded rows (they score exactly 0) counts only where its best score is positive: that score
         // belongs to a real row
         const bool padded = chunk >= a.first_pad_chunk;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+            if constexpr (FUSE) {
+                const unsigned w1 = max(s1[j], (unsigned)__shfl_xor(s1[j], 32));   // the chunk's best score (all lanes)
+                s1[j] = 0u;
+                if (counted && lane < 32 && fuse_live[j]) {
+                    // the bound of match_select_half_kernel: best exact score of the chunk <= s_q s_c S_half + A + B_c + r_q R_c
+                    const float up = (i8_sq[j] * sb) * (float)((int)w1 - I8_OFFSET) + (i8_A[j] + i8_mult[j] * be) + (fuse_rq[j] * rb + 1.0e-6f);
+                    if (!(up < a.gate)) {   // rare: a handful per query where the pass is used at all
+                        const int64_t q = (int64_t)(qt0 + j) * 32 + lane;
+                        atomicAdd(a.survivors, 1);
+                        const unsigned pos = atomicAdd(&a.bin_cnt[chunk], 1u);
+                        if (pos < (unsigned)RESCAN_BIN_CAP) {
+                            a.bins[(size_t)chunk * RESCAN_BIN_CAP + pos] = (int)q;
+                        } else {   // a full bin leaves the entry in the query's own list (match_rescan_kernel)
+                            const int slot = atomicAdd(&a.cand_cnt[q], 1);
+                            if (slot < a.cap) a.cand[(size_t)q * a.cap + slot] = ((unsigned)chunk << 8) | 128u;
+                        }
+                    }
+                }
+                continue;
+            }
             const unsigned best = TOP2 ? coarse_emit_chunk(a, s1[j], s2[j], unused_max, qt0 + j, chunk)
                                        : coarse_emit_chunk_best(a, s1[j], qt0 + j, chunk);
             if (counted) {
@@ -335,16 +364,16 @@ int launch_coarse_i8(const CoarseArgs& a, hipStream_t st) {
     return VFM_OK;
 }
 
-template <int KSTEPS, bool TOP2, bool LOW = true>
+template <int KSTEPS, bool TOP2, bool LOW = true, bool FUSE = false>
 int launch_coarse_i8q2(const CoarseArgs& a, hipStream_t st) {
     const int lds = 12 * KSTEPS * 1024;
     static unsigned long long attr_set = 0ull;  // one bit per device
     if (!attr_done(attr_set)) {
-        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_i8q2_kernel<KSTEPS, TOP2, LOW>),
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_i8q2_kernel<KSTEPS, TOP2, LOW, FUSE>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_mark(attr_set);
     }
-    hipLaunchKernelGGL((match_coarse_i8q2_kernel<KSTEPS, TOP2, LOW>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((match_coarse_i8q2_kernel<KSTEPS, TOP2, LOW, FUSE>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
     return VFM_OK;
 }
 
@@ -356,7 +385,11 @@ int launch_coarse_int8(CoarseArgs& a, int d, int64_t n, int records, hipStream_t
     if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
     const bool top2 = records == VFM_RECORDS_TOP2;
     int rc8;
-    if (records == VFM_RECORDS_HALF) {
+    if (records == VFM_RECORDS_HALF_FUSED) {   // d = 256 / 384, more than 2048 queries (effective_records)
+        a.nqb = (a.nq_tiles + 15) / 16;
+        a.nslices = choose_slices(a.nqb, a.nchunks);
+        rc8 = d == 384 ? launch_coarse_i8q2<6, false, false, true>(a, st) : launch_coarse_i8q2<4, false, false, true>(a, st);
+    } else if (records == VFM_RECORDS_HALF) {
         // the half-width pass: the same kernels on the image of the first d / 2 columns (a.Qh / a.Bh = tiles8h), best-score records
         if (d <= 384) {
             a.nqb = (a.nq_tiles + 15) / 16;

@@ -829,6 +829,13 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
     if (qi >= n) return;
     const int cnt = cand_cnt[qi];
     if (cnt <= 0) return;  // zero query / below the gate (-2) / overflow (-1)
+    if (cnt > cap) {       // (fused half-width pass: more bin overflows than the list holds) the all-pairs kernel decides
+        if (lane == 0) {
+            cand_cnt[qi] = -1;
+            fb_list[atomicAdd(fb_count, 1)] = (int)qi;
+        }
+        return;
+    }
     unsigned* mycand = cand + (size_t)qi * cap;
     unsigned* myhits = hits + (size_t)qi * hcap;
     const int units8 = d >> 4;  // 16-byte units per int8 row
@@ -1398,8 +1405,9 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     const float w2 = 2.0f * (float)(d / 16 + 4 + 2) * 5.9604645e-8f;
     const bool i8 = records != VFM_RECORDS_F16 && use_i8(d, n, m, gated);
     if (i8 && !gated) records = VFM_RECORDS_TOP2;  // as do_search_coarse chose
-    records = effective_records(records, d, n);
-    const bool half = i8 && records == VFM_RECORDS_HALF;
+    records = effective_records(records, d, n, m);
+    const bool fused = i8 && records == VFM_RECORDS_HALF_FUSED;   // the coarse kernel has filled the bins already
+    const bool half = i8 && (records == VFM_RECORDS_HALF || fused);
     if (half && !(gate > -__builtin_inff())) return vfm_fail(VFM_EINVAL, "search_finish: VFM_RECORDS_HALF needs a finite gate");
     if (!i8 && use_sparse(d, n, m)) {
         hipLaunchKernelGGL(match_filter_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d,
@@ -1411,7 +1419,9 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
         // best-score records with many queries per map chunk: the rescan runs chunk-major (match_rescan_chunk_kernel)
         const bool best = i8 && records == VFM_RECORDS_BEST && g_select_variant != 1;
         use_bins = (best || half) && g_select_variant != 2 && n >= 4 * (int64_t)a.nchunks;
-        if (half) {
+        if (fused) {
+            // (nothing to select)
+        } else if (half) {
             const int half_lds = (size_t)a.nchunks * 12 <= 63 * 1024;  // (step, max E, max |rest|) of every chunk in LDS
             hipLaunchKernelGGL(match_select_half_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * 8), half_lds ? (size_t)a.nchunks * 12 : 0,
                                st, reinterpret_cast<const unsigned*>(w.partials), a.nchunks, n, Q.inv, i8_bounds(Q, B, true, records),

@@ -183,6 +183,18 @@ struct CoarseArgs {
     int rcap;
     float window;
     I8Bounds ib;         // int8 pass: qmax receives float_key(lower bound of the query's exact maximum) instead of score bits
+    // half-width pass with the selection fused into the coarse kernel (VFM_RECORDS_HALF_FUSED): no records are written --
+    // a (query, chunk) pair whose bound reaches `gate` goes straight into the chunk's bin (or, past the bin, the query's list)
+    float gate;
+    int64_t n_valid;        // real queries
+    const float* qrest;     // [npad] |second half of the normalised query|, rounded up
+    const float* grest;     // [nchunks] its maximum over the chunk's rows
+    unsigned* bin_cnt;      // [nchunks], zeroed per search
+    int* bins;              // [nchunks][RESCAN_BIN_CAP]
+    int* cand_cnt;          // [npad], zeroed per search (entries of the query's own list)
+    unsigned* cand;         // [npad][cap]
+    int cap;
+    int* survivors;         // fb_count + 5: the search's load figure
 };
 
 // XCD-aware unit mapping shared by the coarse kernels: workgroup b runs on XCD b % 8 (observed, speed
@@ -304,7 +316,10 @@ struct Prepared {
 inline bool i8_capable(int d) { return d == 256 || d == 384 || d == 512 || d == 640 || d == 768; }
 // shapes the half-width pass (VFM_RECORDS_HALF) has a kernel for; elsewhere the record kind falls back to best-score records
 inline bool half_capable(int d, int64_t n) { return ((d == 256 || d == 384) && n > 2048) || d == 512 || d == 768; }
-inline int effective_records(int records, int d, int64_t n) {
+// the fused form exists where the 64-queries-per-wave kernel runs and a map chunk collects several queries (chunk-major rescan)
+inline int effective_records(int records, int d, int64_t n, int64_t m) {
+    if (records == VFM_RECORDS_HALF_FUSED && !((d == 256 || d == 384) && n > 2048 && n >= 4 * ((m + CHUNK_ROWS - 1) / CHUNK_ROWS)))
+        records = VFM_RECORDS_HALF;
     return (records == VFM_RECORDS_HALF && !half_capable(d, n)) ? VFM_RECORDS_BEST : records;
 }
 
@@ -414,7 +429,8 @@ int launch_coarse_f16(const CoarseArgs& a, int d, hipStream_t st);
 int launch_coarse_int8(CoarseArgs& a, int d, int64_t n, int records, hipStream_t st);
 // match_api.hip
 int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, hipStream_t st,
-                     bool bias_from_map_inv = false, bool inner_product = false, bool gated = false, int records = 0);
+                     bool bias_from_map_inv = false, bool inner_product = false, bool gated = false, int records = 0,
+                     float gate = -__builtin_inff());
 // match_finish.hip
 int do_search_finish(const float* q, const void* qprep, int64_t n, const float* b, const void* bprep, int64_t m, int d,
                      int64_t* idx_out, float* sim_out, void* ws, hipStream_t st, bool gated = false,

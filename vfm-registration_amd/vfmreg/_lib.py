@@ -50,6 +50,7 @@ SIGNATURES = {
     "vfm_match_search_probe_half": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, c_vp, C.c_size_t, C.c_float, c_vp, c_vp]),
     "vfm_match_search_coarse_gated": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, c_vp, C.c_size_t, c_vp]),
     "vfm_match_search_coarse_gated_r": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, c_vp, C.c_size_t, C.c_int, c_vp]),
+    "vfm_match_search_coarse_gated_g": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, c_vp, C.c_size_t, C.c_int, C.c_float, c_vp]),
     "vfm_match_search_finish_gated_r": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp,
                                                   C.c_size_t, C.c_float, C.c_int, c_vp]),
     "vfm_match_search_finish": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp,

@@ -90,6 +90,12 @@ class RegistrationPipeline:
         # +0.7 ms once) on the first registration and at every re-probe interval, and switches to it only on a good count
         self.half = coarse == "int8-half"
         self._probe_due = coarse == "auto" and self.gate
+        # which form of the half-width pass: with the selection fused into the coarse kernel (VFM_RECORDS_HALF_FUSED = 4: no
+        # records, no selection kernel) a serial registration is 1.5 % faster (1017 vs 1002 registrations/s), but in the
+        # overlapped pipeline it is 1-2 % slower (1363 vs 1378; 1190 vs 1211 in 20-step runs): the selection kernel ran on a side
+        # stream for free, the fused form adds a memset and the bin atomics to the stream everything waits for
+        import os
+        self._half_kind = int(os.environ.get("VFM_HALF_RECORDS", "3" if self.overlap else "4"))
         self.last_rescans: Optional[int] = None
         self.last_probe: Optional[int] = None
         self._since_switch = 0
@@ -168,7 +174,7 @@ class RegistrationPipeline:
                 self._since_switch = 0
 
     def _records(self) -> int:
-        return 3 if self.half else (1 if self.top2 else 0)
+        return self._half_kind if self.half else (1 if self.top2 else 0)   # 4 = VFM_RECORDS_HALF_FUSED (falls back to 3 / 0 inside the library)
 
     def synchronize(self) -> None:
         """Make the caller's current stream wait for every RANSAC issued on the side stream."""
@@ -200,7 +206,7 @@ class RegistrationPipeline:
                 self._probe_due = self.gate
                 self._since_switch = 0
         i8, records = self.use_i8, self._records()
-        if records == 3 and reuse_map:
+        if records in (3, 4) and reuse_map:
             records = 0   # a map kept across registrations carries both images but not the half-width one
         r = self.sets[self._step % len(self.sets)]
         solve = self.solve_streams[self._step % self.n_solve] if self.overlap else None
@@ -226,7 +232,7 @@ class RegistrationPipeline:
             if i8 and not reuse_map:
                 # the preparation kernel's launch shape: persistent when it runs alone or beside the half-width coarse kernel
                 # (which leaves registers free), short workgroups beside the full-width one (include/vfmreg.h)
-                schedule = 1 if (records == 3 or not (self.overlap and self.overlap_prepare)) else 2
+                schedule = 1 if (records in (3, 4) or not (self.overlap and self.overlap_prepare)) else 2
                 _lib.check(lib.vfm_match_prepare2_gated_p(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
                                                           r.qprep.data_ptr(), self.d, schedule, pst), "prepare(map + scan)")
             else:
@@ -247,8 +253,8 @@ class RegistrationPipeline:
             ev.record(main)
             self._pending.append((ev, slot, "probe"))
         if i8:
-            _lib.check(lib.vfm_match_search_coarse_gated_r(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
-                                                           r.sws.data_ptr(), r.sws.numel(), records, st), "search(coarse)")
+            _lib.check(lib.vfm_match_search_coarse_gated_g(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
+                                                           r.sws.data_ptr(), r.sws.numel(), records, gate, st), "search(coarse)")
         else:
             # (VFM_RECORDS_F16 = 2: the fp16 pass explicitly -- the ungated calls route large searches to the int8 pass)
             _lib.check(lib.vfm_match_search_coarse_gated_r(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d,
