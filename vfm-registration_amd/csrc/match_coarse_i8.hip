@@ -248,7 +248,8 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a)
                     const float up = (i8_sq[j] * sb) * (float)((int)w1 - I8_OFFSET) + (i8_A[j] + i8_mult[j] * be) + (fuse_rq[j] * rb + 1.0e-6f);
                     if (!(up < a.gate)) {   // rare: a handful per query where the pass is used at all
                         const int64_t q = (int64_t)(qt0 + j) * 32 + lane;
-                        atomicAdd(a.survivors, 1);
+                        // (the search's load figure is summed from the bin counts by match_rescan_chunk_kernel: ten thousand
+                        // same-address atomics from inside this kernel cost it more than the selection kernel it replaces)
                         const unsigned pos = atomicAdd(&a.bin_cnt[chunk], 1u);
                         if (pos < (unsigned)RESCAN_BIN_CAP) {
                             a.bins[(size_t)chunk * RESCAN_BIN_CAP + pos] = (int)q;

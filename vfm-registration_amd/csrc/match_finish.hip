@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
                                                                  const uint4* __restrict__ b8, const unsigned* __restrict__ qmax,
                                                                  int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
                                                                  const unsigned* __restrict__ bin_cnt, const int* __restrict__ bins,
-                                                                 int use_gate, float gate) {
+                                                                 int use_gate, float gate, int* __restrict__ survivors) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rescan_smem[];
     uint4* l_q8 = reinterpret_cast<uint4*>(rescan_smem);  // [RESCAN_BATCH][2 UH]
     __shared__ int l_q[RESCAN_BATCH];
@@ -601,6 +601,8 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
     const int c = blockIdx.x;
     const unsigned filled = bin_cnt[c];
     if (filled == 0u) return;
+    // fused half-width pass: the coarse kernel did not count its survivors (one atomic per chunk here instead)
+    if (survivors && threadIdx.x == 0) atomicAdd(survivors, (int)filled);
     const int nq = filled < (unsigned)RESCAN_BIN_CAP ? (int)filled : RESCAN_BIN_CAP;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     constexpr int UNITS = 2 * UH;
@@ -1454,7 +1456,8 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
 #define VFM_RESCAN_CHUNK(UH)                                                                                                  \
     hipLaunchKernelGGL(match_rescan_chunk_kernel<UH>, dim3((unsigned)a.nchunks), dim3(256), lds, st, n, m,                      \
                        i8_bounds(Q, B, true, records), (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, \
-                       w.cand_cnt, w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, half ? 1 : 0, gate)
+                       w.cand_cnt, w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, half ? 1 : 0, gate,                     \
+                       fused ? w.fb_count + 5 : (int*)nullptr)
                 switch (d / 32) {
                     case 8: VFM_RESCAN_CHUNK(8); break;
                     case 12: VFM_RESCAN_CHUNK(12); break;
