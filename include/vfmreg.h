@@ -134,7 +134,7 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
 #define VFM_RECORDS_BEST 0
 #define VFM_RECORDS_TOP2 1
 #define VFM_RECORDS_F16 2
-/*   VFM_RECORDS_HALF  the half-width pass (needs a finite gate and operands from vfm_match_prepare2_gated): the int8 coarse
+/*   VFM_RECORDS_HALF  the half-width pass (needs a finite gate): the int8 coarse
  *                     pass over the FIRST d / 2 columns only -- half the matrix work -- with best-score records.  A (query,
  *                     chunk) pair survives if  partial score + quantisation bound + |rest of the query| * max |rest of a row
  *                     of the chunk|  can reach the gate (Cauchy-Schwarz on the other half of the columns); the survivors'
@@ -143,8 +143,7 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
  *                     descriptors whose matches stand clear of the background (the benchmark's D.2 data: 0.9 against <= 0.3)
  *                     almost nothing survives; on descriptors that are all alike everything does, and the call is slower
  *                     than VFM_RECORDS_BEST: vfm_match_search_rescans_async reports the survivors for that decision.
- *                     Exists for d = 256 / 384 with more than 2048 queries and for d = 512 / 768; elsewhere the call
- *                     behaves as VFM_RECORDS_BEST. */
+ *                     Exists wherever the int8 pass does (d = 256 ... 768). */
 #define VFM_RECORDS_HALF 3
 /*   VFM_RECORDS_HALF_FUSED  the half-width pass with its selection inside the coarse kernel: the gate is known when the coarse
  *                     pass runs (vfm_match_search_coarse_gated_g), so a (query, chunk) pair is tested the moment its best score
@@ -173,7 +172,7 @@ int vfm_match_search_rescans_async(const void *ws, int64_t n, int64_t m, int32_t
  * asynchronously on `stream` (INT32_MAX, written at once, where the shape has no half-width kernel).  A half-width search
  * whose survivors run into the hundreds per query is far slower than any other mode (every survivor is a 128-row rescan), so a
  * caller probes before switching to it (vfmreg/pipeline.py: on the first registration and at every re-probe interval); `ws`
- * is free for the real search of the same pair afterwards.  Operands from vfm_match_prepare2_gated. */
+ * is free for the real search of the same pair afterwards. */
 int vfm_match_search_probe_half(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m, int d,
                                 void *ws, size_t ws_bytes, float gate, int32_t *out_host, vfm_stream_t stream);
 

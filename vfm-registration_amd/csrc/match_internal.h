@@ -305,7 +305,7 @@ struct Prepared {
     float* gstep;     // quantisation step per group of 128 rows
     float* gerr;      // maximum E per group
     uint4* tiles8;    // int8 fragment tiles
-    uint4* tiles8h;   // int8 fragment tiles of the first d / 2 columns (written by the gated prepare only)
+    uint4* tiles8h;   // int8 fragment tiles of the first d / 2 columns
     float* rest;      // per row: |second half of the normalised row|_2, rounded up
     float* grest;     // its maximum per group
     size_t bytes;
@@ -314,8 +314,12 @@ struct Prepared {
 // widths the int8 coarse pass exists for (match_coarse_pipe_kernel<d/32, false, true>; d = 128 has too few k-steps for the
 // fragment ring)
 inline bool i8_capable(int d) { return d == 256 || d == 384 || d == 512 || d == 640 || d == 768; }
-// shapes the half-width pass (VFM_RECORDS_HALF) has a kernel for; elsewhere the record kind falls back to best-score records
-inline bool half_capable(int d, int64_t n) { return ((d == 256 || d == 384) && n > 2048) || d == 512 || d == 768; }
+// shapes the half-width pass (VFM_RECORDS_HALF) has a kernel for (every int8 width: the 64-queries-per-wave kernel for d <= 384
+// with more than 2048 queries, the one-set kernel with four tiles per step elsewhere)
+inline bool half_capable(int d, int64_t n) {
+    (void)n;
+    return i8_capable(d);
+}
 // the fused form exists where the 64-queries-per-wave kernel runs and a map chunk collects several queries (chunk-major rescan)
 inline int effective_records(int records, int d, int64_t n, int64_t m) {
     if (records == VFM_RECORDS_HALF_FUSED && !((d == 256 || d == 384) && n > 2048 && n >= 4 * ((m + CHUNK_ROWS - 1) / CHUNK_ROWS)))

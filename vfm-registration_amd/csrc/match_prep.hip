@@ -87,9 +87,9 @@ struct PrepOut {
     float* gstep;     // [rows_pad / 128] quantisation step of the group
     float* gerr;      // [rows_pad / 128] maximum E of the group
     uint4* tiles8;    // int8 fragment tiles
-    uint4* tiles8h;   // !F16: int8 fragment tiles of the first d / 2 columns
-    float* rest;      // !F16: |second half of the normalised row|_2, rounded up
-    float* grest;     // !F16: its maximum over the group
+    uint4* tiles8h;   // int8 fragment tiles of the first d / 2 columns
+    float* rest;      // |second half of the normalised row|_2, rounded up
+    float* grest;     // its maximum over the group
 };
 template <bool F16, int NC = 2>
 __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restrict__ x1, int64_t rows1, int d, PrepOut o1, int groups1,
@@ -210,8 +210,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
                 const int c = lane + 64 * i;
                 if (c < nchunks) {
                     const float nv[4] = {v[j][i].x, v[j][i].y, v[j][i].z, v[j][i].w};
-                    if constexpr (!F16)
-                        if (8 * c >= d) r2 = r2 + (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] + nv[3] * nv[3]);  // columns >= d / 2
+                    if (8 * c >= d) r2 = r2 + (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] + nv[3] * nv[3]);  // columns >= d / 2
                     int qi[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -251,7 +250,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
                 o.err[r] = en;
                 if (en > 0.0f) atomicMax(&emax_bits, __float_as_uint(en));
             }
-            if constexpr (!F16) {
+            {
                 // |second half of the row|_2, rounded up like E (d / 2 + 8 roundings of 2^-24 on non-negative terms, one sqrtf);
                 // NaN / Inf elements -> Inf: nothing is ever pruned against such a row
                 float rn = sqrtf(scatter8(rpart)) * 1.000244140625f + 1.0e-30f;
@@ -277,7 +276,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
                 __builtin_nontemporal_store(tq.w, po + 3);
             }
         }
-        if constexpr (!F16) {  // the first d / 2 columns again, as tiles of their own (the first half of every tile's units)
+        {  // the first d / 2 columns again, as tiles of their own (the first half of every tile's units)
             const int uh = (d >> 6) * 64;  // uint4 units per half tile
             uint4* dst = o.tiles8h + (int64_t)grp * (uh * 4);
             const uint4* src = reinterpret_cast<const uint4*>(img8);
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
         if (threadIdx.x == 0) {
             o.gstep[grp] = qstep;
             o.gerr[grp] = __uint_as_float(emax_bits);
-            if constexpr (!F16) o.grest[grp] = __uint_as_float(rmax_bits);
+            o.grest[grp] = __uint_as_float(rmax_bits);
             amax_bits = 0u;   // for the next group (read again only behind the next two barriers)
             emax_bits = 0u;
             rmax_bits = 0u;

@@ -206,8 +206,6 @@ class RegistrationPipeline:
                 self._probe_due = self.gate
                 self._since_switch = 0
         i8, records = self.use_i8, self._records()
-        if records in (3, 4) and reuse_map:
-            records = 0   # a map kept across registrations carries both images but not the half-width one
         r = self.sets[self._step % len(self.sets)]
         solve = self.solve_streams[self._step % self.n_solve] if self.overlap else None
         rws = self.rws_list[self._step % self.n_solve] if self.overlap else self.rws
@@ -244,7 +242,7 @@ class RegistrationPipeline:
         if self.overlap and pst != st:
             main.wait_stream(self.prep_stream)
         gate = float(np.nextafter(np.float32(self.min_cosine), np.float32(-np.inf))) if self.gate else float("-inf")
-        if i8 and self._probe_due and not self.half and not reuse_map and len(self._pending) < 8:
+        if i8 and self._probe_due and not self.half and len(self._pending) < 8:
             self._probe_due = False
             slot = self._slots.pop() if self._slots else torch.zeros(1, dtype=torch.int32).pin_memory()
             _lib.check(lib.vfm_match_search_probe_half(r.qprep.data_ptr(), self.n, r.bprep.data_ptr(), self.m, self.d, r.sws.data_ptr(),
