@@ -370,3 +370,51 @@ def test_half_width_pass_needs_a_gate_and_the_pipeline_leaves_it_on_descriptors_
     for coarse in ("int8-half", "int8", "fp16"):
         assert torch.equal(outs["auto"][0], outs[coarse][0]) and torch.equal(outs["auto"][1], outs[coarse][1]), coarse
     assert outs["auto"][1].shape[0] > 500
+
+
+def test_half_width_probe_counts_the_survivors_and_prepare_schedules_write_the_same_bytes():
+    """vfm_match_search_probe_half reports exactly the load figure the half-width search itself reports afterwards
+    (vfm_match_search_rescans_async); the prepare kernel's launch shapes (vfm_match_prepare2_gated_p) and the plain gated prepare
+    write identical bytes; unknown record kinds / schedules are refused."""
+    lib = _lib.load()
+    n, m, d = 3000, 30000, 384
+    p = synth.make_pair_device(n, m, d, seed=3)
+    q, b = p["q_desc"], p["b_desc"]
+    st = torch.cuda.current_stream().cuda_stream
+    bufs = {}
+    for schedule in (None, 0, 1, 2):
+        qb = torch.zeros(lib.vfm_match_prepared_bytes(n, d), dtype=torch.uint8, device="cuda")
+        bb = torch.zeros(lib.vfm_match_prepared_bytes(m, d), dtype=torch.uint8, device="cuda")
+        if schedule is None:
+            _lib.check(lib.vfm_match_prepare2_gated(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, st))
+        else:
+            _lib.check(lib.vfm_match_prepare2_gated_p(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, schedule, st))
+        torch.cuda.synchronize()
+        bufs[schedule] = (qb, bb)
+    for schedule in (0, 1, 2):
+        assert torch.equal(bufs[schedule][0], bufs[None][0]) and torch.equal(bufs[schedule][1], bufs[None][1]), schedule
+    assert lib.vfm_match_prepare2_gated_p(b.data_ptr(), m, bufs[0][1].data_ptr(), q.data_ptr(), n, bufs[0][0].data_ptr(), d, 7, st) != 0
+    qb, bb = bufs[None]
+    ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=torch.uint8, device="cuda")
+    gate = float(np.nextafter(np.float32(0.8), np.float32(-np.inf)))
+    probe = torch.zeros(1, dtype=torch.int32).pin_memory()
+    _lib.check(lib.vfm_match_search_probe_half(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), gate, probe.data_ptr(), st))
+    torch.cuda.synchronize()
+    idx = torch.empty(n, dtype=torch.int64, device="cuda")
+    sim = torch.empty(n, dtype=torch.float32, device="cuda")
+    counts = {}
+    for records in (3, 4):
+        _lib.check(lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, gate, st))
+        _lib.check(lib.vfm_match_search_finish_gated_r(q.data_ptr(), qb.data_ptr(), n, b.data_ptr(), bb.data_ptr(), m, d, idx.data_ptr(),
+                                                       sim.data_ptr(), ws.data_ptr(), ws.numel(), gate, records, st))
+        slot = torch.zeros(1, dtype=torch.int32).pin_memory()
+        _lib.check(lib.vfm_match_search_rescans_async(ws.data_ptr(), n, m, slot.data_ptr(), st))
+        torch.cuda.synchronize()
+        counts[records] = int(slot.item())
+    matched = int((p["match"] >= 0).sum())
+    assert int(probe.item()) == counts[3] == counts[4] and matched <= counts[3] <= matched + n // 20
+    assert int((sim >= 0.8).sum()) == matched
+    assert lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), 9, gate, st) != 0
+    with pytest.raises(RuntimeError, match="finite gate"):
+        _lib.check(lib.vfm_match_search_probe_half(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), float("-inf"),
+                                                   probe.data_ptr(), st))
