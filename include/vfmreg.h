@@ -142,7 +142,10 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
  *                     similarity reaches the gate (every other query: idx -1, sim -2.0 -- it provably has no match).  On
  *                     descriptors whose matches stand clear of the background (the benchmark's D.2 data: 0.9 against <= 0.3)
  *                     almost nothing survives; on descriptors that are all alike everything does, and the call is slower
- *                     than VFM_RECORDS_BEST: vfm_match_search_rescans_async reports the survivors for that decision.
+ *                     than VFM_RECORDS_BEST -- by orders of magnitude at scale: every survivor is a 128-row rescan, and a query
+ *                     with more survivors than its list holds falls back to the all-pairs kernel.  It is an expert mode:
+ *                     probe first (vfm_match_search_probe_half), and watch vfm_match_search_rescans_async, which reports
+ *                     the survivors of every search, as vfmreg/pipeline.py does.
  *                     Exists wherever the int8 pass does (d = 256 ... 768). */
 #define VFM_RECORDS_HALF 3
 /*   VFM_RECORDS_HALF_FUSED  the half-width pass with its selection inside the coarse kernel: the gate is known when the coarse
