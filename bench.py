@@ -429,6 +429,10 @@ def main():
                                        else "dense fp16 MFMA"),
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "flops_per_launch": flops, "avg_launch_ms": coarse_ms,
+                         "flops_note": ("operations this kernel performs: 2 N M D/2 -- the reference's all-pairs product is 2 N M D = "
+                                        f"{2.0 * n * m * d:.4g}; the half-width pass computes half of it and bounds the rest (DESIGN.md 4.15); "
+                                        "achieved / frac count the operations performed, not the product avoided") if half else
+                                       "2 N M D, the reference's all-pairs product",
                          "single_stream": {"avg_launch_ms": iso_ms, "achieved": flops / (iso_ms * 1e-3) / 1e12,
                                            "frac": flops / (iso_ms * 1e-3) / 1e12 / peak,
                                            "note": "same kernel without the RANSAC of the previous pair running beside it"}},
