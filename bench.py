@@ -200,7 +200,7 @@ def extra_configs(dev):
                  "ms_registration": t5_reg, "ms_coarse_kernel": t5, "correspondences": int(r5["count"].item()),
                  "pose_err_vs_planted": float(np.linalg.norm(r5["T"].cpu().numpy() - p5["T_gt"])),
                  "coarse_pass": "int8, half-width (VFM_RECORDS_HALF)" if half5 else ("int8, packed top-2 records" if pipe5.top2 else "int8, best-score records"),
-                 "roofline": {"bound": "mfma", "kernel": ("match_coarse_i8_kernel<12, 4> (int8 32x32x32 MFMA over the first 384 of 768 columns)" if half5
+                 "roofline": {"bound": "mfma", "kernel": ("match_coarse_i8q2_kernel<12> (int8 32x32x32 MFMA over the first 384 of 768 columns, 64 resident queries per wave)" if half5
                                                           else "match_coarse_i8_kernel<24, 2> (int8 32x32x32 MFMA)"), "flops": f5,
                               "achieved": f5 / (t5 * 1e-3) / 1e12, "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s",
                               "frac": f5 / (t5 * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS}}

@@ -392,11 +392,17 @@ int launch_coarse_int8(CoarseArgs& a, int d, int64_t n, int records, hipStream_t
         rc8 = d == 384 ? launch_coarse_i8q2<6, false, false, true>(a, st) : launch_coarse_i8q2<4, false, false, true>(a, st);
     } else if (records == VFM_RECORDS_HALF) {
         // the half-width pass: the same kernels on the image of the first d / 2 columns (a.Qh / a.Bh = tiles8h), best-score records
-        if (d <= 384 && n > 2048) {
+        if (n > 2048 && g_coarse_qsets == 0) {   // 64 resident queries per wave at every width: d / 2 columns are at most 384
             a.nqb = (a.nq_tiles + 15) / 16;
             a.nslices = choose_slices(a.nqb, a.nchunks);
-            rc8 = d == 384 ? launch_coarse_i8q2<6, false, false>(a, st) : launch_coarse_i8q2<4, false, false>(a, st);
-        } else {   // one query set per wave: the other widths, and few queries
+            switch (d / 64) {
+                case 4: rc8 = launch_coarse_i8q2<4, false, false>(a, st); break;
+                case 6: rc8 = launch_coarse_i8q2<6, false, false>(a, st); break;
+                case 8: rc8 = launch_coarse_i8q2<8, false, false>(a, st); break;
+                case 10: rc8 = launch_coarse_i8q2<10, false, false>(a, st); break;
+                default: rc8 = launch_coarse_i8q2<12, false, false>(a, st); break;
+            }
+        } else {   // one query set per wave: few queries (variants 10 / 12: every size, A/B)
             switch (d / 64) {
                 case 4: rc8 = launch_coarse_i8<4, 4, false, false>(a, st); break;
                 case 6: rc8 = launch_coarse_i8<6, 4, false, false>(a, st); break;
