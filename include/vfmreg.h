@@ -8,8 +8,10 @@
  *   - the caller owns every buffer.  Scratch is caller-provided and sized by the matching
  *     vfm_*_workspace_bytes(); no hidden allocation, no global state except the thread-local
  *     last-error string.  All work is enqueued on `stream` (a hipStream_t passed as void*);
- *     nothing synchronises the device unless its comment says so (vfm_voxel_robin, vfm_debug_*), so the
+ *     nothing synchronises the device unless its comment says so (vfm_voxel_robin), so the
  *     registration path can be chained and captured in a hipGraph.
+ *   - nothing declared here has a process-global effect.  The measurement hooks and tuning switches of the test and
+ *     bench tooling (vfm_prof_*, vfm_debug_*) are NOT part of the drop-in contract: include/vfmreg_debug.h.
  *   - return 0 on success, a negative VFM_E* code otherwise; vfm_last_error() describes it.
  *
  * Reference interfaces replaced (paths relative to /root/reference):
@@ -360,45 +362,6 @@ size_t vfm_vit_workspace_bytes(const vfm_vit_config *cfg, int B);
 int vfm_vit_forward(const vfm_vit_config *cfg, const void *weights, const uint8_t *img, int B,
                     int H, int W, float *tokens_out, void *ws, size_t ws_bytes,
                     vfm_stream_t stream);
-
-/* ------------------------------------------------------------------ measurement hooks */
-
-/* HIP events around the dominant kernel (the fp16 MFMA coarse pass of the top-1 search), recorded
- * on the stream that kernel is launched on.  vfm_prof_arm() applies to the NEXT search issued
- * from the calling thread (one shot).  vfm_prof_elapsed_ms() waits for `stop`. */
-int vfm_prof_events_create(void **start, void **stop);
-int vfm_prof_arm(void *start, void *stop);
-int vfm_prof_elapsed_ms(void *start, void *stop, float *ms_host);
-int vfm_prof_events_destroy(void *start, void *stop);
-/* tuning switch: coarse-kernel variant (0 default: gated family = int8 pass for d = 256 ... 768; ungated family =
- * sparse fp16 records for d <= 384, dense fp16 records elsewhere; 1 = 8 waves x 32 queries, 2 = 4 waves x 64, 4 = pipelined
- * kernel with dense fp16 records, 5 = the fp16 pass in the gated family too, 7 = 5 without seed units, 12 = int8 kernel with
- * 32 resident queries per wave at every size, 10 = 12 with two tiles per step at every width, 20 = default kernels with the
- * general selection kernel on best-score records too, 21 = default kernels without the chunk-major rescan) */
-int vfm_debug_set_coarse_variant(int qsets);
-/* tuning switch: force the number of map slices of the coarse pass (0 = heuristic) */
-/* counters of the last FAST search that used workspace `ws` (candidate histogram, refined / fallback queries;
- * see csrc/match_finish.hip).  out64_host: HOST int32[64].  Synchronises the device. */
-int vfm_debug_match_stats(void *ws, int64_t n, int64_t m, int32_t *out64_host);
-/* the counters are collected only while this switch is on (they cost same-address atomics) */
-int vfm_debug_set_match_stats(int on);
-/* ViT GEMM wave tile / prefetch depth for A/B runs: NT * 100 + PF for N <= 512 and N > 512 (see csrc/vit.hip) */
-int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
-/* A/B: workgroups of the int8 operand-preparation kernel (-1, default = one per 128-row group; 0 = one per compute unit, each
- * walking several groups with the next group's rows read under the current group's quantisation and store: faster alone,
- * slower beside the coarse kernel; n > 0 = n workgroups) */
-int vfm_debug_set_prep_grid(int workgroups);
-/* tests: the int8 image of a prepared operand (d = 256, 384) unpacked on the host -- q8_host[rows][d], and per row the
- * quantisation step of its 128-row group, its residual norm E and the group's maximum E.  Synchronises the device. */
-int vfm_debug_i8_rows(const void *prepared, int64_t rows, int d, int8_t *q8_host, float *step_host,
-                      float *err_host, float *gerr_host);
-/* tuning switch: the gated family takes the int8 pass for more than this many query rows (default 0: always) */
-int vfm_debug_set_i8_min_queries(int n);
-/* timing experiments only: overrides the coarse window of the sparse kernel (0 = default); results become wrong */
-int vfm_debug_set_coarse_window(float w);
-int vfm_debug_set_coarse_slices(int slices);
-/* tuning switch: 1 = RANSAC scores every hypothesis in fp64 (skips the fp32 coarse pass) */
-int vfm_debug_set_ransac_exact_only(int on);
 
 #ifdef __cplusplus
 }

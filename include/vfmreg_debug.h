@@ -1,0 +1,63 @@
+/*
+ * vfmreg_debug.h -- measurement hooks and tuning switches of libvfmreg_hip.so used by bench.py, tools/ and tests/.
+ *
+ * NOT part of the drop-in contract (include/vfmreg.h, SURVEY.md 8 B.5: "no global state except the last-error string").
+ * Everything declared here either keeps state outside the caller's buffers or synchronises the device:
+ *   - vfm_prof_*      THREAD-LOCAL, one shot: vfm_prof_arm() stores two HIP events in thread-local storage of the calling
+ *                     thread; the next coarse launch issued FROM THAT THREAD (vfm_match_search_coarse* / vfm_match_ip_top1* /
+ *                     vfm_match_search_prepared / vfm_match_search_probe_half) records them around its dominant kernel on the
+ *                     stream it is launched on and clears the slot.  No other thread and no later search sees them.
+ *   - vfm_debug_set_* PROCESS-GLOBAL A/B switches: kernel variants and launch shapes; every setting returns the same
+ *                     results (tests run the stress inputs through them), only the time changes.  Not thread-safe against
+ *                     concurrent searches; a product integration never calls them.
+ *   - vfm_debug_match_stats / vfm_debug_i8_rows  read-backs for tests; they synchronise the device.
+ */
+#ifndef VFMREG_DEBUG_H
+#define VFMREG_DEBUG_H
+
+#include "vfmreg.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HIP events around the dominant kernel (the MFMA coarse pass of the top-1 search), recorded on the stream that kernel is
+ * launched on.  vfm_prof_arm() applies to the NEXT search issued from the calling thread (one shot, thread-local).
+ * vfm_prof_elapsed_ms() waits for `stop`. */
+int vfm_prof_events_create(void **start, void **stop);
+int vfm_prof_arm(void *start, void *stop);
+int vfm_prof_elapsed_ms(void *start, void *stop, float *ms_host);
+int vfm_prof_events_destroy(void *start, void *stop);
+
+/* A/B: coarse-kernel variant (0 default: gated family = int8 pass for d = 256 ... 768; ungated family =
+ * sparse fp16 records for d <= 384, dense fp16 records elsewhere; 1 = 8 waves x 32 queries, 2 = 4 waves x 64, 4 = pipelined
+ * kernel with dense fp16 records, 5 = the fp16 pass in the gated family too, 7 = 5 without seed units, 12 = int8 kernel with
+ * 32 resident queries per wave at every size, 10 = 12 with two tiles per step at every width, 20 = default kernels with the
+ * general selection kernel on best-score records too, 21 = default kernels without the chunk-major rescan) */
+int vfm_debug_set_coarse_variant(int qsets);
+/* A/B: force the number of map slices of the coarse pass (0 = heuristic) */
+int vfm_debug_set_coarse_slices(int slices);
+/* counters of the last FAST search that used workspace `ws` (candidate histogram, refined / fallback queries;
+ * see csrc/match_finish.hip).  out64_host: HOST int32[64].  Synchronises the device. */
+int vfm_debug_match_stats(void *ws, int64_t n, int64_t m, int32_t *out64_host);
+/* the counters are collected only while this switch is on (they cost same-address atomics) */
+int vfm_debug_set_match_stats(int on);
+/* A/B: ViT GEMM wave tile / prefetch depth: NT * 100 + PF for N <= 512 and N > 512 (see csrc/vit.hip) */
+int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
+/* A/B: workgroups of the int8 operand-preparation kernel (-1, default = one per 128-row group; 0 = one per compute unit, each
+ * walking several groups with the next group's rows read under the current group's quantisation and store: faster alone,
+ * slower beside the coarse kernel; n > 0 = n workgroups) */
+int vfm_debug_set_prep_grid(int workgroups);
+/* tests: the int8 image of a prepared operand (d = 256, 384) unpacked on the host -- q8_host[rows][d], and per row the
+ * quantisation step of its 128-row group, its residual norm E and the group's maximum E.  Synchronises the device. */
+int vfm_debug_i8_rows(const void *prepared, int64_t rows, int d, int8_t *q8_host, float *step_host,
+                      float *err_host, float *gerr_host);
+/* A/B: the gated family takes the int8 pass for more than this many query rows (default 0: always) */
+int vfm_debug_set_i8_min_queries(int n);
+/* A/B: 1 = RANSAC scores every hypothesis in fp64 (skips the bounds) */
+int vfm_debug_set_ransac_exact_only(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFMREG_DEBUG_H */

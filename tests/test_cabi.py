@@ -18,8 +18,8 @@ def built():
     return _lib
 
 
-def _declared():
-    text = (ROOT / "include" / "vfmreg.h").read_text()
+def _declared(header="vfmreg.h"):
+    text = (ROOT / "include" / header).read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(vfm_[a-z0-9_]+)\s*\(", text)))
 
@@ -32,6 +32,27 @@ def test_header_symbols_are_exported(built):
         assert hasattr(lib, n), f"{n} declared in include/vfmreg.h but not exported"
     assert set(names) == set(built.SIGNATURES), "ctypes signature table out of sync with the header"
     assert b"gfx950" in lib.vfm_build_info()
+
+
+def test_contract_header_declares_nothing_with_process_global_effect(built):
+    """no global state except the last-error string.  The measurement hooks / A-B switches live in
+    include/vfmreg_debug.h; vfmreg.h must not declare any of them, and the library must not export a vfm_ symbol that
+    neither header declares."""
+    lib = built.load()
+    contract, debug = _declared(), _declared("vfmreg_debug.h")
+    assert not [n for n in contract if n.startswith(("vfm_debug_", "vfm_prof_"))]
+    assert debug and all(n.startswith(("vfm_debug_", "vfm_prof_")) for n in debug)
+    assert set(debug) == set(built.DEBUG_SIGNATURES)
+    for n in debug:
+        assert hasattr(lib, n), f"{n} declared in include/vfmreg_debug.h but not exported"
+    out = subprocess.run(["nm", "-D", "--defined-only", str(built.LIB_PATH)],
+                         capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("vfm_")}
+    assert exported == set(contract) | set(debug), sorted(exported ^ (set(contract) | set(debug)))
+    # the product's Python side reads no tuning switch from the environment (the launcher's RANK / WORLD_SIZE / MASTER_* in
+    # vfmreg/dist.py are the torch.distributed contract, not switches)
+    for py in (ROOT / "vfm-registration_amd" / "vfmreg").glob("*.py"):
+        assert not re.search(r"environ[^\n]*VFM_", py.read_text()), py.name
 
 
 def test_library_is_gfx950_code_object(built):

@@ -1,0 +1,189 @@
+"""The configuration bench.py times, compared with the oracle at ITS size, and the randomised soak of
+the half-width pass (was tools/soak_half.py) with a fixed seed.
+
+bench.py builds RegistrationPipeline(20000, 200000, 384, n_iter=50000, overlap_ransac=True, overlap_prepare=True,
+solve_streams=2) with coarse="auto"; on SURVEY D.2 data the policy settles on the half-width int8 pass.  Here that very
+construction registers three D.2 pairs (seeds 42 + p) in the overlapped form and every output a caller reads --
+correspondence list, inlier mask, pose, winning hypothesis, and the per-query index / similarity of every resolved query --
+is compared with the CPU oracle's registration of the same inputs (registration_node.py:273-328; VoxelHashMap.cpp:469-511).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+N, M, D, ITERS = 20000, 200000, 384, 50000
+
+
+def _oracle_registration(orc, p, iters):
+    qn, _ = orc.l2norm_rows(p["q_desc"])
+    bn, _ = orc.l2norm_rows(p["b_desc"])
+    idx, sim = orc.match_ip_top1(qn, bn)
+    keep = orc.threshold_compact(sim, 0.8)
+    corres = np.stack([keep, idx[keep]], 1).astype(np.int32)
+    ref = orc.ransac_corr(p["q_xyz"], p["b_xyz"], corres, 10000.0, iters, seed=42)
+    return idx, sim, corres, ref
+
+
+def _snapshot(out):
+    """copies of a registration's results, taken on the stream that produces them (the buffer sets rotate)"""
+    with torch.cuda.stream(out["result_stream"]):
+        return {k: out[k].clone() for k in ("T", "fitness", "rmse", "best_hyp", "mask", "idx", "sim", "count", "corres")}
+
+
+def _compare(orc, snap, host, iters, what):
+    idx_ref, sim_ref, corres_ref, ref = _oracle_registration(orc, host, iters)
+    k = int(snap["count"].item())
+    assert k == len(corres_ref), (what, k, len(corres_ref))
+    np.testing.assert_array_equal(snap["corres"][:k].cpu().numpy(), corres_ref, err_msg=what)
+    got_idx, got_sim = snap["idx"].cpu().numpy(), snap["sim"].cpu().numpy()
+    solved = got_idx >= 0
+    np.testing.assert_array_equal(got_idx[solved], idx_ref[solved], err_msg=what)
+    np.testing.assert_array_equal(got_sim[solved], sim_ref[solved], err_msg=what)
+    assert (sim_ref[~solved] < 0.8).all(), what          # an unresolved query provably misses the gate
+    assert (got_sim[~solved] == -2.0).all(), what
+    np.testing.assert_array_equal(snap["mask"][:k].cpu().numpy(), ref.inlier_mask, err_msg=what)
+    np.testing.assert_array_equal(snap["T"].cpu().numpy(), ref.transformation, err_msg=what)
+    assert int(snap["best_hyp"].item()) == ref.best_hyp, what
+    assert float(snap["fitness"].item()) == ref.fitness and float(snap["rmse"].item()) == ref.inlier_rmse, what
+    assert np.linalg.norm(ref.transformation - host["T_gt"]) < 0.05
+
+
+def test_the_pipeline_bench_times_equals_the_oracle_at_c2_size():
+    from oracle import oracle as orc
+    from vfmreg import synth
+    from vfmreg.pipeline import RegistrationPipeline
+
+    pairs = [synth.make_pair_device(N, M, D, seed=42 + p) for p in range(3)]
+    pipe = RegistrationPipeline(N, M, D, n_iter=ITERS, overlap_ransac=True, overlap_prepare=True, solve_streams=2)  # bench.py's
+    main = torch.cuda.current_stream()
+    torch.cuda.synchronize()
+    ready = torch.cuda.Event()
+    ready.record(main)
+
+    def reg(i):
+        p = pairs[i % 3]
+        return pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"], want_mask=True, inputs_ready=ready)
+
+    # let the policy settle (probe on the first registration, feedback arrives asynchronously)
+    for i in range(12):
+        reg(i)
+        if i % 3 == 2:
+            pipe.synchronize()
+            torch.cuda.synchronize()
+        if pipe.half:
+            break
+    assert pipe.use_i8 and pipe.half, "the auto policy did not settle on the half-width pass on D.2 data"
+    # the timed form: registrations back to back, no host synchronisation, results snapshotted on their streams
+    snaps, modes = [], []
+    for i in range(6):
+        out = reg(i)
+        modes.append((pipe.use_i8, pipe.half, pipe._records()))
+        snaps.append(_snapshot(out))
+    pipe.synchronize()
+    torch.cuda.synchronize()
+    assert all(m[0] and m[1] for m in modes), modes       # every compared registration ran the half-width pass
+    assert pipe.last_rescans is not None and pipe.last_rescans <= pipe.HALF_LIMIT * N
+    hosts = [{k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in p.items()} for p in pairs]
+    for i in range(3, 6):                                 # one registration of each pair, from the steady state
+        _compare(orc, snaps[i], hosts[i % 3], ITERS, f"registration {i} (pair {i % 3}, records {modes[i][2]})")
+    # the same pair registered twice in the overlapped form gives the same bits
+    for k in ("T", "corres", "mask", "idx", "sim", "best_hyp"):
+        assert torch.equal(snaps[0][k], snaps[3][k]), k
+
+
+def test_full_width_modes_equal_the_oracle_at_c2_size_too():
+    """the data-independent passes of the same pipeline (what lifted descriptors run): best-score and top-2 records"""
+    from oracle import oracle as orc
+    from vfmreg import synth
+    from vfmreg.pipeline import RegistrationPipeline
+
+    p = synth.make_pair_device(N, M, D, seed=45)
+    host = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in p.items()}
+    ref = None
+    for coarse in ("int8", "int8-top2"):
+        pipe = RegistrationPipeline(N, M, D, n_iter=ITERS, overlap_ransac=True, overlap_prepare=True, solve_streams=2, coarse=coarse)
+        out = None
+        for _ in range(2):
+            out = pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
+        snap = _snapshot(out)
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        if ref is None:
+            _compare(orc, snap, host, ITERS, coarse)
+            ref = snap
+        else:
+            for k in ("T", "corres", "mask", "best_hyp", "count"):
+                assert torch.equal(snap[k], ref[k]), (coarse, k)
+        del pipe
+
+
+# ----------------------------------------------------------------------------------------------------------------- soak
+def soak_trial(lib, rng, st):
+    """one random trial of the half-width pass (VFM_RECORDS_HALF = 3, fused = 4) against best-score records (0): random shape,
+    width, gate and data kind; returns (ok, description).  Gate contract, pairwise: the same answer where both resolve;
+    whatever only one resolves lies below the gate; the matches a caller keeps (similarity >= gate) are identical."""
+    from vfmreg import _lib
+    d = int(rng.choice([256, 384, 384, 512, 768]))
+    n = int(rng.integers(1, 7000))
+    m = int(rng.integers(1, 60000))
+    gate = float(np.nextafter(np.float32(rng.choice([0.5, 0.8, 0.8, 0.95])), np.float32(-np.inf)))
+    kind = rng.choice(["planted", "alike", "duplicates", "halves"])
+    g = torch.Generator(device="cuda")
+    g.manual_seed(int(rng.integers(1 << 30)))
+    b = torch.randn((m, d), generator=g, device="cuda")
+    pick = torch.randint(0, m, (n,), generator=g, device="cuda")
+    q = b[pick] + float(rng.choice([0.1, 0.3, 0.6])) * torch.randn((n, d), generator=g, device="cuda")
+    if kind == "alike":
+        base = torch.randn((1, d), generator=g, device="cuda")
+        b = base + 0.3 * b
+        q = base + 0.3 * q
+    elif kind == "duplicates":
+        b = b[torch.randint(0, max(1, m // 50), (m,), generator=g, device="cuda")].clone()
+        q = b[pick].clone()
+    elif kind == "halves":
+        b[: m // 2, : d // 2] *= 1e-3
+        q[::2, d // 2:] *= 1e-3
+    q[torch.rand(n, generator=g, device="cuda") < 0.3] = torch.randn((d,), generator=g, device="cuda")
+    q, b = q.contiguous(), b.contiguous()
+    qb = torch.empty(lib.vfm_match_prepared_bytes(n, d), dtype=torch.uint8, device="cuda")
+    bb = torch.empty(lib.vfm_match_prepared_bytes(m, d), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.vfm_match_prepare2_gated(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, st))
+    res = {}
+    for records in (0, 3, 4):
+        idx = torch.empty(n, dtype=torch.int64, device="cuda")
+        sim = torch.empty(n, dtype=torch.float32, device="cuda")
+        _lib.check(lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, gate, st))
+        _lib.check(lib.vfm_match_search_finish_gated_r(q.data_ptr(), qb.data_ptr(), n, b.data_ptr(), bb.data_ptr(), m, d, idx.data_ptr(),
+                                                       sim.data_ptr(), ws.data_ptr(), ws.numel(), gate, records, st))
+        torch.cuda.synchronize()
+        res[records] = (idx, sim)
+    i0, s0 = res[0]
+    ok = True
+    for r in (3, 4):
+        i, s = res[r]
+        both = (i >= 0) & (i0 >= 0)
+        ok &= bool(torch.equal(i[both], i0[both]) and torch.equal(s[both], s0[both]))
+        ok &= bool((s0[(i0 >= 0) & (i < 0)] < gate).all())          # what only best-score records resolve lies below the gate
+        ok &= int(((i >= 0) & (i0 < 0)).sum()) == 0                 # the half-width pass never resolves more
+        keep, keep0 = s >= gate, s0 >= gate
+        ok &= bool(torch.equal(keep, keep0) and torch.equal(i[keep], i0[keep0]))
+    desc = (f"d {d} n {n} m {m} gate {gate:.3f} {kind}: kept {int((s0 >= gate).sum())}, resolved 0/3/4 "
+            f"{int((i0 >= 0).sum())}/{int((res[3][0] >= 0).sum())}/{int((res[4][0] >= 0).sum())}")
+    return ok, desc
+
+
+def test_half_width_pass_randomised_soak_fixed_seed():
+    from vfmreg import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(20260929)
+    st = torch.cuda.current_stream().cuda_stream
+    bad = []
+    for t in range(10):
+        ok, desc = soak_trial(lib, rng, st)
+        print(f"trial {t}: {desc} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+        if not ok:
+            bad.append(desc)
+    assert not bad, bad

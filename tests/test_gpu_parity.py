@@ -420,6 +420,46 @@ def test_ransac_device_count_and_degenerate(ops, orc):
         assert out["fitness"].item() == 0.0 and out["best_hyp"].item() == -1
 
 
+# ------------------------------------------------------------------------------- Kabsch (row A9)
+def test_kabsch_batched_bit_exact(ops, orc):
+    """vfm_kabsch_batched (Eigen::umeyama / pointdsc/common.py:7-47) against the oracle's fixed operation sequence:
+    n = 3 (RANSAC's sample), 4 and 50 points, unweighted (denom_eps 0) and weighted (PointDSC's 1e-6), degenerate batches"""
+    rng = np.random.default_rng(5)
+    n_invalid = 0
+    for n in (3, 4, 50):
+        A = rng.uniform(-20, 20, (64, n, 3))
+        B = rng.uniform(-20, 20, (64, n, 3))
+        B[:32] = A[:32] @ np.linalg.qr(rng.standard_normal((3, 3)))[0] + 1.5
+        A[60] = A[60, 0]  # degenerate: all points equal
+        w = rng.uniform(0.1, 1, (64, n))
+        for wt, eps in ((None, 0.0), (w, 1e-6), (None, 1e-6), (w, 0.0)):
+            T, valid = ops.kabsch_batched(dev(A), dev(B), None if wt is None else dev(wt), eps)
+            T, valid = T.cpu().numpy(), valid.cpu().numpy()
+            for i in range(64):
+                Tr, ok = orc.kabsch(A[i], B[i], None if wt is None else wt[i], eps)
+                assert bool(valid[i]) == ok
+                np.testing.assert_array_equal(T[i], Tr)
+                n_invalid += int(not ok)
+    assert n_invalid >= 2  # the all-points-equal sample is reported invalid (T = identity)
+
+
+def test_kabsch_batched_matches_reference_rigid_transform_3d(ops, golden):
+    """the fixture tests/golden/kabsch_dsc.npz holds outputs of the reference's own pointdsc.common.rigid_transform_3d
+    (fp32 torch.svd): the HIP kernel must meet them within the tolerances the CPU oracle is held to
+    (tests/test_oracle_golden.py::test_kabsch_matches_reference_rigid_transform_3d)"""
+    g = golden("kabsch_dsc.npz")
+    A, B, w = g["A"].astype(np.float64), g["B"].astype(np.float64), g["w"].astype(np.float64)
+    T, valid = ops.kabsch_batched(dev(A), dev(B), None, 1e-6)
+    assert valid.cpu().numpy().all()
+    np.testing.assert_allclose(T.cpu().numpy(), g["T_unw"], rtol=0, atol=2e-4)
+    Tw, valid = ops.kabsch_batched(dev(A), dev(B), dev(w), 1e-6)
+    assert valid.cpu().numpy().all()
+    np.testing.assert_allclose(Tw.cpu().numpy(), g["T_w"], rtol=0, atol=2e-4)
+    T3, valid = ops.kabsch_batched(dev(g["A3"].astype(np.float64)), dev(g["B3"].astype(np.float64)), None, 1e-6)
+    assert valid.cpu().numpy().all()
+    np.testing.assert_allclose(T3.cpu().numpy(), g["T_3"], rtol=0, atol=5e-3)  # 3-point, fp32 SVD of a rank-2 H
+
+
 # --------------------------------------------------------------------------------- projection
 def test_projection_matches_reference_fixtures(ops, golden):
     g = golden("proj_nclt.npz")

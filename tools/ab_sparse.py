@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""A/B of the coarse kernel alone (no side streams): sparse records (default) vs dense per-chunk records (variant 4),
-and the sparse kernel with the rare path disabled (negative window: timing only)."""
+"""A/B of the coarse kernel alone (no side streams): sparse records (default) vs dense per-chunk records (variant 4).
+(Round 2 also timed the sparse kernel with its rare path disabled through a window override; that switch made results wrong
+and was removed from the library in round 3 -- the figures are in DESIGN.md 4.1.)"""
 import ctypes as C
 import sys
 from pathlib import Path
@@ -21,9 +22,8 @@ _lib.check(lib.vfm_prof_events_create(C.byref(a), C.byref(b)))
 ms = C.c_float()
 
 
-def run(label, variant, window):
+def run(label, variant):
     lib.vfm_debug_set_coarse_variant(variant)
-    lib.vfm_debug_set_coarse_window(C.c_float(window))
     t = []
     for i in range(12):
         lib.vfm_prof_arm(a, b)
@@ -37,10 +37,7 @@ def run(label, variant, window):
 
 
 for rep in range(2):
-    run("dense records (variant 4)", 4, 0.0)
-    run("sparse records + seed units (default)", 0, 0.0)
-    run("sparse records, no seed units (variant 7)", 7, 0.0)
-    run("sparse, rare path never taken (window -1: timing only)", 0, -1.0)
-    run("sparse, window 1e-4 (timing only)", 0, 1e-4)
+    run("dense records (variant 4)", 4)
+    run("sparse records + seed units (default)", 0)
+    run("sparse records, no seed units (variant 7)", 7)
 lib.vfm_debug_set_coarse_variant(0)
-lib.vfm_debug_set_coarse_window(C.c_float(0.0))

@@ -22,32 +22,7 @@ from vfmreg import _lib, synth  # noqa: E402
 from vfmreg.pipeline import RegistrationPipeline  # noqa: E402
 
 
-def lifted_map(m, d, clouds, cams, gh, gw, seed, view_noise, dev, revisit=0):
-    """m map rows; row r belongs to (cloud, camera) image k = r % (clouds * cams) and takes the bilinear sample of that
-    image's gh x gw patch grid at a random position.  Images of different clouds that look at the same place are
-    modelled by sharing a smooth scene field: grid(k) = scene_grid(camera) + view_noise * randn."""
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    scene = torch.randn((cams, gh, gw, d), generator=g, device=dev)
-    K = clouds * cams
-    img = torch.randint(0, K, (m,), generator=g, device=dev)
-    cam = img % cams
-    noise_seed = torch.randn((K, gh, gw, d), generator=g, device=dev) * view_noise
-    if revisit:  # the same physical points are seen again by every cloud: `revisit` distinct pixel positions per camera
-        py = torch.rand((cams, revisit), generator=g, device=dev) * (gh - 1 - 1e-3)
-        px = torch.rand((cams, revisit), generator=g, device=dev) * (gw - 1 - 1e-3)
-        which = torch.randint(0, revisit, (m,), generator=g, device=dev)
-        y, x = py[cam, which], px[cam, which]
-    else:
-        y = torch.rand(m, generator=g, device=dev) * (gh - 1 - 1e-3)
-        x = torch.rand(m, generator=g, device=dev) * (gw - 1 - 1e-3)
-    i, j = y.long(), x.long()
-    fy, fx = (y - i)[:, None], (x - j)[:, None]
-
-    def at(ii, jj):
-        return scene[cam, ii, jj] + noise_seed[img, ii, jj]
-    out = at(i, j) * (1 - fy) * (1 - fx) + at(i + 1, j) * fy * (1 - fx) + at(i, j + 1) * (1 - fy) * fx + at(i + 1, j + 1) * fy * fx
-    return out.float().contiguous()
+lifted_map = synth.lifted_map   # moved into the package (bench.py's C2_lifted uses it too)
 
 
 def run(pipe, p, steps, lib, n, m):

@@ -45,7 +45,6 @@ thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 // 0 = default (pipelined kernel for d <= 384); 1 = match_coarse_kernel<.,1>; 2 = match_coarse_kernel<.,2>;
 // set through vfm_debug_set_coarse_variant for A/B runs
 int g_coarse_qsets = 0;
-float g_window_override = 0.0f;  // vfm_debug_set_coarse_window: timing experiments only (results are wrong)
 int g_seed_units = 1;   // vfm_debug_set_coarse_variant(7): no seed units (A/B)
 int g_select_variant = 0;  // vfm_debug_set_coarse_variant(20 / 21): general select kernel / no chunk-major rescan (A/B)
 int g_match_stats = 0;  // vfm_debug_set_match_stats: per-query counters cost ~0.5 ms of same-address atomics per search
@@ -96,7 +95,7 @@ CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, 
     a.rec_cnt = nullptr;
     a.rec = nullptr;
     a.rcap = 0;
-    a.window = g_window_override != 0.0f ? g_window_override : DEFAULT_WINDOW;
+    a.window = DEFAULT_WINDOW;
     a.ib = I8Bounds{nullptr, nullptr, nullptr, nullptr, 0};
     return a;
 }
@@ -389,10 +388,6 @@ VFM_EXPORT int vfm_debug_set_i8_min_queries(int n) {
     return VFM_OK;
 }
 
-VFM_EXPORT int vfm_debug_set_coarse_window(float w) {
-    g_window_override = w;
-    return VFM_OK;
-}
 
 VFM_EXPORT int vfm_debug_set_match_stats(int on) {
     g_match_stats = on;

@@ -411,7 +411,6 @@ inline void attr_mark(unsigned long long& mask) {
 
 // experiment knobs and profiling hook (match_api.hip)
 extern int g_force_slices, g_coarse_qsets, g_seed_units, g_match_stats, g_i8_min_queries, g_select_variant;
-extern float g_window_override;
 extern thread_local hipEvent_t g_prof_start, g_prof_stop;  // vfm_prof_arm: events around the next coarse launch of this thread
 
 // which coarse pass / record kind a search takes (match_api.hip)

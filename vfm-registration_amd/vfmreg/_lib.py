@@ -79,6 +79,16 @@ SIGNATURES = {
                                   C.c_size_t, c_vp]),
     "vfm_icp_nearest": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, C.c_int32, C.c_double, C.c_double, c_vp, c_vp, c_vp]),
     "vfm_icp_build_system": (C.c_int, [c_vp, c_vp, c_vp, c_i64, C.c_double, c_vp, c_vp]),
+    "vfm_vit_weights_bytes": (C.c_size_t, [C.POINTER(VitConfig)]),
+    "vfm_vit_weights_layout": (C.c_int, [C.POINTER(VitConfig), C.POINTER(c_i64), C.POINTER(c_i64), C.c_int]),
+    "vfm_vit_workspace_bytes": (C.c_size_t, [C.POINTER(VitConfig), C.c_int]),
+    "vfm_vit_forward": (C.c_int, [C.POINTER(VitConfig), c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp,
+                                  C.c_size_t, c_vp]),
+}
+
+
+# include/vfmreg_debug.h: measurement hooks and A/B switches (not part of the drop-in contract)
+DEBUG_SIGNATURES = {
     "vfm_prof_events_create": (C.c_int, [C.POINTER(c_vp), C.POINTER(c_vp)]),
     "vfm_prof_arm": (C.c_int, [c_vp, c_vp]),
     "vfm_prof_elapsed_ms": (C.c_int, [c_vp, c_vp, C.POINTER(C.c_float)]),
@@ -87,17 +97,11 @@ SIGNATURES = {
     "vfm_debug_set_match_stats": (C.c_int, [C.c_int]),
     "vfm_debug_i8_rows": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp, c_vp]),
     "vfm_debug_set_i8_min_queries": (C.c_int, [C.c_int]),
-    "vfm_debug_set_coarse_window": (C.c_int, [C.c_float]),
     "vfm_debug_set_vit_gemm": (C.c_int, [C.c_int, C.c_int]),
     "vfm_debug_set_prep_grid": (C.c_int, [C.c_int]),
     "vfm_debug_set_coarse_variant": (C.c_int, [C.c_int]),
     "vfm_debug_set_coarse_slices": (C.c_int, [C.c_int]),
     "vfm_debug_set_ransac_exact_only": (C.c_int, [C.c_int]),
-    "vfm_vit_weights_bytes": (C.c_size_t, [C.POINTER(VitConfig)]),
-    "vfm_vit_weights_layout": (C.c_int, [C.POINTER(VitConfig), C.POINTER(c_i64), C.POINTER(c_i64), C.c_int]),
-    "vfm_vit_workspace_bytes": (C.c_size_t, [C.POINTER(VitConfig), C.c_int]),
-    "vfm_vit_forward": (C.c_int, [C.POINTER(VitConfig), c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp,
-                                  C.c_size_t, c_vp]),
 }
 
 
@@ -112,7 +116,7 @@ def load() -> C.CDLL:
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     import torch  # noqa: F401  -- loads torch's libamdhip64.so first (same soname => one runtime)
     lib = C.CDLL(str(LIB_PATH))
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
         fn = getattr(lib, name)  # AttributeError => the .so does not export what the header declares
         fn.restype = res
         fn.argtypes = args

@@ -138,9 +138,11 @@ class VoxelHashMap:
             self._dev = (rows[:, 3:].float().contiguous(), xyz)   # VoxelHashMap.cpp:472-473: static_cast<float>
         return self._dev
 
-    def search_device(self, q_rows: torch.Tensor, min_cosine_similarity: float):
-        """Device form of the search: (query_idx int64[K], map_idx int64[K], sim fp32[N]) as device tensors; sim is the best
-        cosine of every query that can reach ``min_cosine_similarity`` and -2.0 for the others."""
+    def search_device(self, q_rows: torch.Tensor, min_cosine_similarity: float, resolve_all: bool = False):
+        """Device form of the search: (query_idx int64[K], map_idx int64[K], sim fp32[N]) as device tensors.  ``sim`` is the
+        best cosine of every query that can reach ``min_cosine_similarity`` and the sentinel -2.0 for queries that provably
+        cannot (the gated search does not resolve them; the correspondences are unaffected).  ``resolve_all=True`` runs the
+        ungated search instead: ``sim`` is then the reference's D array (VoxelHashMap.cpp:486-495) for every query."""
         b_desc, _ = self._device_map()
         if q_rows.dim() != 2 or q_rows.shape[1] != b_desc.shape[1] + 3:
             raise RuntimeError("Unable to cast Python instance to C++ type: expected %d columns"
@@ -151,18 +153,19 @@ class VoxelHashMap:
         # only matches with cosine >= min_cosine_similarity leave this function (VoxelHashMap.cpp:501-511): the gated search
         # leaves queries that provably cannot reach it unresolved (sim = -2.0 in the returned array)
         gate = float(np.nextafter(np.float32(min_cosine_similarity), np.float32(-np.inf)))
-        idx, sim = ops.match_ip_top1(q_desc, b_desc, prec, gate=gate if prec == ops.FAST else None)
+        idx, sim = ops.match_ip_top1(q_desc, b_desc, prec, gate=gate if (prec == ops.FAST and not resolve_all) else None)
         r = ops.threshold_compact(sim, idx, float(min_cosine_similarity), want_corres=True)
         k = int(r["count"].item())
         corres = r["corres"][:k]
         return corres[:, 0].long(), corres[:, 1].long(), sim
 
-    def get_vfm_correspondence_indices(self, points: np.ndarray, min_cosine_similarity: float):
-        """(query_idx[K], map_idx[K], sim[N]) -- the indices behind get_vfm_correspondences."""
+    def get_vfm_correspondence_indices(self, points: np.ndarray, min_cosine_similarity: float, resolve_all: bool = False):
+        """(query_idx[K], map_idx[K], sim[N]) -- the indices behind get_vfm_correspondences.  ``sim[i]`` = -2.0 marks a query
+        that provably has no match at the threshold (see ``search_device``); ``resolve_all=True`` returns every best cosine."""
         points = np.asarray(points)
         if self._cloud("n") is None or points.ndim != 2:
             raise RuntimeError("Unable to cast Python instance to C++ type")
-        qi, mi, sim = self.search_device(to_device_rows(points)[0], min_cosine_similarity)
+        qi, mi, sim = self.search_device(to_device_rows(points)[0], min_cosine_similarity, resolve_all)
         return qi.cpu().numpy(), mi.cpu().numpy(), sim.cpu().numpy()
 
     def get_vfm_correspondences(self, points: np.ndarray, max_correspondance_distance: float
@@ -170,7 +173,9 @@ class VoxelHashMap:
         """Pair of {source, target} coordinates (mapping.py:120-131); the float is the cosine
         threshold despite its name (kiss_icp_pybind.cpp:128-129)."""
         points = np.asarray(points)
-        qi, mi, sim = self.get_vfm_correspondence_indices(points, max_correspondance_distance)
+        # the stats line of VoxelHashMap.cpp:613-616 prints the mean of the best cosine over ALL queries (VoxelHashMap.cpp:588-602),
+        # so the printing form resolves every query; ``quiet`` callers take the gated search (same correspondences)
+        qi, mi, sim = self.get_vfm_correspondence_indices(points, max_correspondance_distance, resolve_all=not self.quiet)
         m_xyz = self._device_map()[1]
         if not self.quiet:
             print(f"Points: {len(points)} | Corrs.: {len(qi)} | Outliers: 0 | Mean sim.: {float(sim.mean()) if len(sim) else 0.0}")

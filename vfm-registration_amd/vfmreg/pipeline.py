@@ -63,7 +63,8 @@ class _ResultSet:
 class RegistrationPipeline:
     def __init__(self, n: int, m: int, d: int = 384, n_iter: int = 50000, min_cosine: float = 0.8,
                  max_corr_dist: float = 10000.0, seed: int = 42, device="cuda", overlap_ransac: bool = False,
-                 overlap_prepare: bool = False, solve_streams: int = 1, gate: bool = True, coarse: str = "auto"):
+                 overlap_prepare: bool = False, solve_streams: int = 1, gate: bool = True, coarse: str = "auto",
+                 half_fused: Optional[bool] = None):
         lib = _lib.load()
         self.n, self.m, self.d = n, m, d
         self.n_iter, self.min_cosine, self.max_corr_dist, self.seed = n_iter, min_cosine, max_corr_dist, seed
@@ -94,8 +95,8 @@ class RegistrationPipeline:
         # records, no selection kernel) a serial registration is 1.5 % faster (1017 vs 1002 registrations/s), but in the
         # overlapped pipeline it is 1-2 % slower (1363 vs 1378; 1190 vs 1211 in 20-step runs): the selection kernel ran on a side
         # stream for free, the fused form adds a memset and the bin atomics to the stream everything waits for
-        import os
-        self._half_kind = int(os.environ.get("VFM_HALF_RECORDS", "3" if self.overlap else "4"))
+        # (``half_fused``: None = that rule; True / False force VFM_RECORDS_HALF_FUSED / VFM_RECORDS_HALF -- A/B runs)
+        self._half_kind = (3 if self.overlap else 4) if half_fused is None else (4 if half_fused else 3)
         self.last_rescans: Optional[int] = None
         self.last_probe: Optional[int] = None
         self._since_switch = 0
@@ -183,9 +184,10 @@ class RegistrationPipeline:
 
     def register(self, q_desc: torch.Tensor, q_xyz: torch.Tensor, b_desc: torch.Tensor, b_xyz: torch.Tensor,
                  reuse_map: bool = False, want_mask: bool = True, inputs_ready: Optional[torch.cuda.Event] = None):
-        """Enqueue one registration.  ``inputs_ready`` (overlap mode): an event after which the four input
-        tensors are complete; with it the prepare stage does not have to queue behind the coarse pass of
-        the previous pair on the caller's stream (without it, it conservatively does)."""
+        """Enqueue one registration.  ``inputs_ready``: an event after which the four input tensors are complete (inputs
+        produced on a stream other than the caller's current one).  Every mode waits for it before the first kernel that
+        reads an input; with ``overlap_prepare`` it also spares the prepare stage from queueing behind the coarse pass of the
+        previous pair on the caller's stream (without the event, it conservatively does)."""
         lib = _lib.load()
         ops._chk(q_desc, torch.float32, "q_desc")
         ops._chk(b_desc, torch.float32, "b_desc")
@@ -213,6 +215,8 @@ class RegistrationPipeline:
         main = torch.cuda.current_stream()
         st = main.cuda_stream
         pst = st
+        if not (self.overlap and self.overlap_prepare) and inputs_ready is not None:
+            main.wait_event(inputs_ready)               # inputs produced on another stream (was ignored here)
         if self.overlap and not self.overlap_prepare:
             if r.done is not None and not r.done.query():
                 main.wait_event(r.done)                 # the solve stage that last read this set has finished

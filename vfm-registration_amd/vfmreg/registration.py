@@ -127,17 +127,3 @@ class RegistrationNode:
             return ransac_pose, pose
         return ransac_pose, None
 
-
-def _lookup_rows(cloud: np.ndarray, pts: np.ndarray):
-    """Index in `cloud` of every row of `pts` (nearest neighbour at distance < 1e-3, RN:295-309).
-    The correspondences were copied out of these clouds, so an exact match on the raw bytes
-    exists whenever the KD-tree of the reference finds one."""
-    cloud = np.ascontiguousarray(cloud, dtype=np.float64) + 0.0   # -0.0 -> +0.0: the KD-tree sees them at distance 0
-    pts = np.ascontiguousarray(pts, dtype=np.float64) + 0.0
-    key = lambda a: a.view(np.dtype((np.void, 24))).reshape(-1)
-    order = np.argsort(key(cloud), kind="stable")
-    sorted_keys = key(cloud)[order]
-    pos = np.searchsorted(sorted_keys, key(pts))
-    pos = np.minimum(pos, max(len(cloud) - 1, 0))
-    ok = (sorted_keys[pos] == key(pts)) if len(cloud) else np.zeros(len(pts), bool)
-    return order[pos] if len(cloud) else np.zeros(len(pts), np.int64), ok

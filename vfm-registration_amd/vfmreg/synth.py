@@ -78,3 +78,55 @@ def make_pair_device(n: int, m: int, d: int = 384, seed: int = 42, device="cuda"
     match = torch.where(is_out, torch.full_like(pick, -1), pick)
     return dict(q_desc=q_desc.contiguous(), q_xyz=q_xyz.contiguous(), b_desc=b_desc.contiguous(),
                 b_xyz=b_xyz.double().contiguous(), T_gt=T, match=match)
+
+
+def lifted_map(m: int, d: int, clouds: int, cams: int, gh: int, gw: int, seed: int, view_noise: float, device="cuda",
+               revisit: int = 0):
+    """Map descriptors that look like LIFTED ones (prepare_scenes.py:50-107 + image_features.py:104-108): row r belongs to
+    (cloud, camera) image k and is the bilinear sample of that image's gh x gw patch grid at a random position.  Images of
+    different clouds that look at the same place share a smooth scene field: grid(k) = scene_grid(camera) + view_noise *
+    randn.  ``revisit`` > 0: the same physical points are seen again by every cloud (that many pixel positions per camera)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    scene = torch.randn((cams, gh, gw, d), generator=g, device=device)
+    K = clouds * cams
+    img = torch.randint(0, K, (m,), generator=g, device=device)
+    cam = img % cams
+    noise_seed = torch.randn((K, gh, gw, d), generator=g, device=device) * view_noise
+    if revisit:
+        py = torch.rand((cams, revisit), generator=g, device=device) * (gh - 1 - 1e-3)
+        px = torch.rand((cams, revisit), generator=g, device=device) * (gw - 1 - 1e-3)
+        which = torch.randint(0, revisit, (m,), generator=g, device=device)
+        y, x = py[cam, which], px[cam, which]
+    else:
+        y = torch.rand(m, generator=g, device=device) * (gh - 1 - 1e-3)
+        x = torch.rand(m, generator=g, device=device) * (gw - 1 - 1e-3)
+    i, j = y.long(), x.long()
+    fy, fx = (y - i)[:, None], (x - j)[:, None]
+
+    def at(ii, jj):
+        return scene[cam, ii, jj] + noise_seed[img, ii, jj]
+    out = at(i, j) * (1 - fy) * (1 - fx) + at(i + 1, j) * fy * (1 - fx) + at(i, j + 1) * (1 - fy) * fx + at(i + 1, j + 1) * fy * fx
+    return out.float().contiguous()
+
+
+def make_lifted_pair_device(n: int, m: int, d: int = 384, seed: int = 42, device="cuda", clouds: int = 10,
+                            view_noise: float = 0.1, common: float = 0.0, revisit: int = 0):
+    """A D.2 pair (same geometry, same planted matches, same outlier rows) whose MAP descriptors are lifted ones
+    (``lifted_map``) and whose scan descriptors are the matched map rows + 0.3 rms noise.  ``common`` > 0 adds one shared
+    vector of that many rms to every row (scan and map): descriptors that are all alike, as a ViT's patch tokens are."""
+    import torch
+    base = make_pair_device(n, m, d, seed=seed, device=device)
+    b = lifted_map(m, d, clouds, 6, 16, 21, seed + 7, view_noise, device, revisit)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + 1)
+    rms = b.pow(2).mean().sqrt()
+    pick = base["match"].clamp(min=0)
+    q = b[pick] + 0.3 * rms * torch.randn((n, d), generator=g, device=device)
+    q = torch.where((base["match"] < 0)[:, None], rms * torch.randn((n, d), generator=g, device=device), q)
+    if common > 0:
+        mu = common * rms * torch.randn((1, d), generator=g, device=device)
+        b, q = b + mu, q + mu
+    base["b_desc"], base["q_desc"] = b.contiguous(), q.contiguous()
+    return base
