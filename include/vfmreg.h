@@ -143,12 +143,14 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
  *                     rows are scored over all d columns by the int8 rescan, and a query is resolved iff its exact best
  *                     similarity reaches the gate (every other query: idx -1, sim -2.0 -- it provably has no match).  On
  *                     descriptors whose matches stand clear of the background (the benchmark's D.2 data: 0.9 against <= 0.3)
- *                     almost nothing survives; on descriptors that are all alike everything does, and the call is slower
- *                     than VFM_RECORDS_BEST -- by orders of magnitude at scale: every survivor is a 128-row rescan, and a query
- *                     with more survivors than its list holds falls back to the all-pairs kernel.  It is an expert mode:
- *                     probe first (vfm_match_search_probe_half), and watch vfm_match_search_rescans_async, which reports
- *                     the survivors of every search, as vfmreg/pipeline.py does.
- *                     Exists wherever the int8 pass does (d = 256 ... 768). */
+ *                     almost nothing survives; on descriptors that are all alike everything does, and rescanning every survivor
+ *                     would cost orders of magnitude more than any other mode (round 2: 171 ms at 20 000 x 200 000).  The search
+ *                     guards against that ON THE DEVICE: when its bound leaves more than 48 surviving chunks per query, the same
+ *                     _finish call falls through to one full-width int8 pass with the gate as hit test (match_gatepass_kernel:
+ *                     6.8 ms for the whole registration at that size) -- slower than VFM_RECORDS_BEST / _TOP2 there (1.9 ms),
+ *                     never a cliff, same results.  A caller that registers many scans should still probe first
+ *                     (vfm_match_search_probe_half) and watch vfm_match_search_rescans_async, which reports the survivors of
+ *                     every search, as vfmreg/pipeline.py does.  Exists wherever the int8 pass does (d = 256 ... 768). */
 #define VFM_RECORDS_HALF 3
 /*   VFM_RECORDS_HALF_FUSED  the half-width pass with its selection inside the coarse kernel: the gate is known when the coarse
  *                     pass runs (vfm_match_search_coarse_gated_g), so a (query, chunk) pair is tested the moment its best score

@@ -269,9 +269,9 @@ def test_chunk_major_rescan_full_bins_and_padded_chunks(d):
             np.testing.assert_array_equal(solved, ref["solved"], err_msg=f"{name} / variant {variant}")
 
 
-def _search_gated_split(q, b, gate, records):
+def _search_gated_split(q, b, gate, records, want_stats=False):
     """The gated family exactly as the pipeline calls it: vfm_match_prepare2_gated (the only prepare that writes the half-width
-    image) -> coarse_gated_r -> finish_gated_r."""
+    image) -> coarse_gated_r -> finish_gated_r.  ``want_stats``: also the search's 64 counters (fb_count)."""
     lib = _lib.load()
     n, d = q.shape
     m = b.shape[0]
@@ -286,6 +286,10 @@ def _search_gated_split(q, b, gate, records):
     _lib.check(lib.vfm_match_search_finish_gated_r(q.data_ptr(), qb.data_ptr(), n, b.data_ptr(), bb.data_ptr(), m, d, idx.data_ptr(),
                                                    sim.data_ptr(), ws.data_ptr(), ws.numel(), gate, records, st))
     torch.cuda.synchronize()
+    if want_stats:
+        st64 = (C.c_int32 * 64)()
+        _lib.check(lib.vfm_debug_match_stats(ws.data_ptr(), n, m, C.cast(st64, C.c_void_p)))
+        return idx, sim, list(st64)
     return idx, sim
 
 
@@ -418,3 +422,68 @@ def test_half_width_probe_counts_the_survivors_and_prepare_schedules_write_the_s
     with pytest.raises(RuntimeError, match="finite gate"):
         _lib.check(lib.vfm_match_search_probe_half(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), float("-inf"),
                                                    probe.data_ptr(), st))
+
+
+@pytest.mark.parametrize("d,n,m", [(384, 3000, 20011), (256, 2600, 9000), (768, 1300, 12000), (384, 300, 20011)])
+def test_half_width_guard_falls_through_to_the_gate_pass(d, n, m):
+    """The device-side guard of the half-width pass (csrc/match_finish.hip: half_guard_kernel, match_gatepass_kernel): on
+    descriptors that are all alike every (query, chunk) pair survives the half-width bound; the search must not rescan them
+    (31 million 128-row rescans at C2 size: 171 ms in round 2) but fall through, inside the same _finish call, to one full-width
+    pass with the gate as hit test -- flag raised, same gate contract, same kept matches as best-score records.  On planted
+    matches the flag stays down."""
+    rng = np.random.default_rng(d + n + m)
+    gate = float(np.nextafter(np.float32(0.8), np.float32(-np.inf)))
+    base = rng.standard_normal((1, d)).astype(np.float32)
+    b = base + 0.25 * rng.standard_normal((m, d)).astype(np.float32)
+    pick = rng.integers(0, m, n)
+    q = b[pick] + 0.05 * rng.standard_normal((n, d)).astype(np.float32)
+    q[::4] = base + 0.25 * rng.standard_normal((len(q[::4]), d)).astype(np.float32)
+    q[5] = 0.0                                        # a zero row (no camera saw the point): index 0, similarity 0
+    b[7] = 0.0
+    qn, _ = orc.l2norm_rows(q)
+    bn, _ = orc.l2norm_rows(b)
+    ridx, rsim = orc.match_ip_top1(qn, bn)
+    qd, bd = torch.from_numpy(q).cuda(), torch.from_numpy(b).cuda()
+    i0, s0 = _search_gated_split(qd, bd, gate, 0)
+    keep0 = (s0 >= 0.8).cpu().numpy()
+    assert keep0.sum() > n // 3
+    for records in (3, 4):
+        idx, sim, st = _search_gated_split(qd, bd, gate, records, want_stats=True)
+        assert st[7] == 1, (records, st[:8])          # the guard flag: the search fell through
+        assert st[5] > 48 * n, (records, st[5])       # the load figure the host policy reads still says "everything survives"
+        solved = _gate_contract(idx, sim, ridx, rsim, gate)
+        assert solved[rsim >= 0.8].all()
+        keep = (sim >= 0.8).cpu().numpy()
+        np.testing.assert_array_equal(keep, keep0)
+        np.testing.assert_array_equal(idx.cpu().numpy()[keep], i0.cpu().numpy()[keep0])
+    # planted matches on isotropic descriptors: nothing but the matches survives, the flag stays down
+    p = synth.make_pair(n, m, d, seed=9)
+    for records in (3, 4):
+        _, sim, st = _search_gated_split(torch.from_numpy(p["q_desc"]).cuda(), torch.from_numpy(p["b_desc"]).cuda(), gate, records, want_stats=True)
+        assert st[7] == 0 and st[5] < 2 * n, (records, st[:8])
+        assert int((sim >= 0.8).sum()) == int((p["match"] >= 0).sum())
+
+
+def test_forced_half_width_registration_on_alike_descriptors_is_bounded_at_c2_size():
+    """C2 size, descriptors that are all alike, the pipeline PINNED to the half-width pass (the state a pipeline is in when the
+    data change under it): round 2 measured 171-195 ms per registration there; with the device-side guard the search costs one
+    full-width pass.  Same correspondences and pose as the full-width int8 pass."""
+    n, m, d = 20000, 200000, 384
+    p = synth.make_lifted_pair_device(n, m, d, seed=43, clouds=10, view_noise=0.1, common=1.0)
+    outs = {}
+    for coarse in ("int8-top2", "int8-half"):
+        pipe = RegistrationPipeline(n, m, d, n_iter=50000, coarse=coarse)
+        ts = []
+        for r in range(4):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
+            b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b))
+        k = int(out["count"].item())
+        outs[coarse] = (out["T"].clone(), out["corres"][:k].clone(), min(ts[1:]))
+    print("ms per registration:", {c: round(v[2], 2) for c, v in outs.items()})
+    assert torch.equal(outs["int8-half"][0], outs["int8-top2"][0]) and torch.equal(outs["int8-half"][1], outs["int8-top2"][1])
+    assert outs["int8-half"][1].shape[0] > 5000
+    assert outs["int8-half"][2] < 12.0, outs["int8-half"][2]     # milliseconds (round 2: 171)

@@ -378,7 +378,10 @@ __global__ __launch_bounds__(64 * 8) void match_select_half_kernel(
                     int slot = atomicAdd(&lcnt[lq + j], 1);
                     if (!cand) continue;  // probe (vfm_match_search_probe_half): the survivors are only counted
                     if (bins) {
-                        const unsigned pos = atomicAdd(&bin_cnt[c], 1u);
+                        // (a full bin is not touched again: on descriptors that are all alike every query survives in every
+                        // chunk, and 31 million atomics on 1563 addresses were most of this kernel's time there)
+                        const unsigned seen = __hip_atomic_load(&bin_cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned pos = seen >= (unsigned)RESCAN_BIN_CAP ? seen : atomicAdd(&bin_cnt[c], 1u);
                         if (pos < (unsigned)RESCAN_BIN_CAP) {
                             bins[(size_t)c * RESCAN_BIN_CAP + pos] = (int)(q0 + j);
                             slot = cap;
@@ -593,16 +596,15 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
                                                                  const uint4* __restrict__ b8, const unsigned* __restrict__ qmax,
                                                                  int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
                                                                  const unsigned* __restrict__ bin_cnt, const int* __restrict__ bins,
-                                                                 int use_gate, float gate, int* __restrict__ survivors) {
+                                                                 int use_gate, float gate, const int* __restrict__ guard) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rescan_smem[];
     uint4* l_q8 = reinterpret_cast<uint4*>(rescan_smem);  // [RESCAN_BATCH][2 UH]
     __shared__ int l_q[RESCAN_BATCH];
     __shared__ float l_sc[RESCAN_BATCH], l_bound[RESCAN_BATCH], l_qlow[RESCAN_BATCH];
     const int c = blockIdx.x;
+    if (guard && *guard) return;   // half-width pass, too many survivors: match_gatepass_kernel has decided every query
     const unsigned filled = bin_cnt[c];
     if (filled == 0u) return;
-    // fused half-width pass: the coarse kernel did not count its survivors (one atomic per chunk here instead)
-    if (survivors && threadIdx.x == 0) atomicAdd(survivors, (int)filled);
     const int nq = filled < (unsigned)RESCAN_BIN_CAP ? (int)filled : RESCAN_BIN_CAP;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     constexpr int UNITS = 2 * UH;
@@ -653,6 +655,109 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
             if (lane < 32 && base + rr < m && l_sc[j] * (float)acc + l_bound[j] >= l_qlow[j]) {
                 const int pos = atomicAdd(&cand_cnt[qi], 1);
                 if (pos < cap) cand[(size_t)qi * cap + pos] = ((unsigned)c << 8) | (unsigned)rr;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Half-width pass: the device-side guard (VERDICT r2 / ADVICE r2: "no 171 ms registration, ever").
+// half_guard_kernel (one workgroup, after the selection): the search's survivor count -- fb_count[5] from match_select_half_kernel,
+// or the sum of the bin counts in the fused form, which it stores there -- against HALF_GUARD_PER_QUERY * n; above it (or where the
+// fused coarse kernel saturated a bin) fb_count[HALF_GUARD_FLAG] = 1 and the selection's all-pairs fallbacks are withdrawn.
+// Then match_rescan_kernel empties every list, match_rescan_chunk_kernel returns at once, and match_gatepass_kernel resolves
+// the search: one workgroup per map chunk, wave w holds tile w of the chunk as the MFMA's first operand (48 registers at
+// d = 384), the scan's int8 tiles stream past it (next tile's fragments loaded under the current tile's MFMAs), and every row
+// whose full-width upper bound  s_q s_c S + A + B_c  reaches the gate -- the hit test of the rescans -- is appended to its
+// query's list.  The matrix work of the full-width pass in a kernel light enough to sit beside anything (no LDS, <= 2 waves
+// per SIMD), launched behind every half-width selection and returning at once unless the flag is up.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void half_guard_kernel(int* __restrict__ fb_count, const unsigned* __restrict__ bin_cnt, int nchunks,
+                                                         int fused, long long limit) {
+    __shared__ long long part[4];
+    long long s = 0;
+    if (fused)
+        for (int c = threadIdx.x; c < nchunks; c += 256) s += (long long)bin_cnt[c];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane_id() == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long total = fused ? part[0] + part[1] + part[2] + part[3] : (long long)fb_count[5];
+        if (fused) fb_count[5] = (int)(total > 0x7FFFFFFFll ? 0x7FFFFFFFll : total);   // the search's load figure
+        if (total > limit || fb_count[HALF_GUARD_FLAG] != 0) {
+            fb_count[HALF_GUARD_FLAG] = 1;
+            fb_count[0] = 0;   // queries the selection sent to the all-pairs kernel: the gate pass decides them too
+        }
+    }
+}
+
+template <int KS>  // k-steps of 32 columns (d / 32)
+__global__ __launch_bounds__(256, 2) void match_gatepass_kernel(int64_t n, int64_t m, int nq_tiles, I8Bounds ib,
+                                                                const float* __restrict__ invq, const uint4* __restrict__ q8,
+                                                                const uint4* __restrict__ b8, float gate, int* __restrict__ cand_cnt,
+                                                                unsigned* __restrict__ cand, int cap, const int* __restrict__ guard) {
+    if (*guard == 0) return;
+    constexpr int TILE_U4 = KS * 64;
+    const int c = blockIdx.x, lane = lane_id(), wave = threadIdx.x >> 6;
+    intx4 af[KS];
+    {
+        const uint4* asrc = b8 + ((size_t)c * 4 + wave) * TILE_U4 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const uint4 v = asrc[s * 64];
+            af[s] = *reinterpret_cast<const intx4*>(&v);
+        }
+    }
+    const float sb = ib.bstep[c], be = ib.berr[c];
+    const long long row0 = (long long)c * CHUNK_ROWS + wave * 32 + 4 * (lane >> 5);   // + (e & 3) + 8 (e >> 2): accumulator element e
+    constexpr bool AHEAD = KS <= 12;   // 3 x 4 KS fragment registers fit two waves per SIMD up to d = 384
+    uint4 qn[AHEAD ? KS : 1];
+    if constexpr (AHEAD) {
+        const uint4* qsrc = q8 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qn[s] = qsrc[s * 64];
+    }
+    for (int qt = 0; qt < nq_tiles; ++qt) {
+        intx4 qf[KS];
+        if constexpr (AHEAD) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const intx4*>(&qn[s]);
+            if (qt + 1 < nq_tiles) {   // the next tile's fragments, under this tile's MFMAs
+                const uint4* qsrc = q8 + (size_t)(qt + 1) * TILE_U4 + lane;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) qn[s] = qsrc[s * 64];
+            }
+        } else {
+            const uint4* qsrc = q8 + (size_t)qt * TILE_U4 + lane;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const uint4 v = qsrc[s * 64];
+                qf[s] = *reinterpret_cast<const intx4*>(&v);
+            }
+        }
+        const int64_t q = (int64_t)qt * 32 + (lane & 31);
+        const float eq = ib.qerr[q], sq = ib.qstep[q >> 7];
+        const bool live = q < n && invq[q] != 0.0f;
+        intx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s], qf[s], acc, 0, 0, 0);
+        int mx = acc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = max(mx, acc[r]);
+        // the expressions of match_rescan_chunk_kernel / match_rescan_kernel: the same rows pass
+        const float sc = sq * sb, bound = (eq * 1.0001220703125f + 1.0e-6f) + (1.0001220703125f + eq) * be;
+        const bool any = live && (sc * (float)mx + bound >= gate);
+        if (__ballot(any) != 0ull && any) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long long row = row0 + (e & 3) + 8 * (e >> 2);
+                if (row < m && sc * (float)acc[e] + bound >= gate) {
+                    const int pos = atomicAdd(&cand_cnt[q], 1);
+                    if (pos < cap) cand[(size_t)q * cap + pos] = ((unsigned)c << 8) | (unsigned)(row - (long long)c * CHUNK_ROWS);
+                }
             }
         }
     }
@@ -824,11 +929,16 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
                                                            const uint4* __restrict__ b8, const unsigned* __restrict__ qmax,
                                                            int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
                                                            unsigned* __restrict__ hits, int hcap, int* __restrict__ fb_count,
-                                                           int* __restrict__ fb_list, int use_gate, float gate) {
+                                                           int* __restrict__ fb_list, int use_gate, float gate,
+                                                           const int* __restrict__ guard) {
     __shared__ uint4 l_q8[4][48];  // the query's int8 row, unit by unit (d <= 768)
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
     if (qi >= n) return;
+    if (guard && *guard) {   // half-width pass, too many survivors: the lists start empty for match_gatepass_kernel's row hits
+        if (lane == 0) cand_cnt[qi] = 0;
+        return;
+    }
     const int cnt = cand_cnt[qi];
     if (cnt <= 0) return;  // zero query / below the gate (-2) / overflow (-1)
     if (cnt > cap) {       // (fused half-width pass: more bin overflows than the list holds) the all-pairs kernel decides
@@ -1447,17 +1557,37 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                            g_match_stats);
         VFM_CHECK_LAUNCH("match_select_kernel");
         if (i8) {  // candidate chunks -> candidate rows (the record buffer of the fp16 pass is free: it holds the hit lists)
+            const int* guard = half ? w.fb_count + HALF_GUARD_FLAG : (const int*)nullptr;
+            if (half) {   // the device-side guard of the half-width pass (see half_guard_kernel)
+                hipLaunchKernelGGL(half_guard_kernel, dim3(1), dim3(256), 0, st, w.fb_count, (const unsigned*)w.bin_cnt, a.nchunks,
+                                   fused ? 1 : 0, (long long)HALF_GUARD_PER_QUERY * (long long)n);
+                VFM_CHECK_LAUNCH("half_guard_kernel");
+            }
             hipLaunchKernelGGL(match_rescan_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, m, d, i8_bounds(Q, B, true, records),
                                (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt, w.cand, w.cap,
-                               reinterpret_cast<unsigned*>(w.rec), 2 * w.rcap, w.fb_count, w.fb_list, half ? 1 : 0, gate);
+                               reinterpret_cast<unsigned*>(w.rec), 2 * w.rcap, w.fb_count, w.fb_list, half ? 1 : 0, gate, guard);
             VFM_CHECK_LAUNCH("match_rescan_kernel");
+            if (half) {
+#define VFM_GATEPASS(KS)                                                                                                        \
+    hipLaunchKernelGGL(match_gatepass_kernel<KS>, dim3((unsigned)a.nchunks), dim3(256), 0, st, n, m, a.nq_tiles,                  \
+                       i8_bounds(Q, B, true, records), (const float*)Q.inv, (const uint4*)Q.tiles8, (const uint4*)B.tiles8, gate, \
+                       w.cand_cnt, w.cand, w.cap, guard)
+                switch (d / 32) {
+                    case 8: VFM_GATEPASS(8); break;
+                    case 12: VFM_GATEPASS(12); break;
+                    case 16: VFM_GATEPASS(16); break;
+                    case 20: VFM_GATEPASS(20); break;
+                    default: VFM_GATEPASS(24); break;
+                }
+#undef VFM_GATEPASS
+                VFM_CHECK_LAUNCH("match_gatepass_kernel");
+            }
             if (use_bins) {
                 const size_t lds = (size_t)RESCAN_BATCH * (size_t)(d / 16) * sizeof(uint4);
 #define VFM_RESCAN_CHUNK(UH)                                                                                                  \
     hipLaunchKernelGGL(match_rescan_chunk_kernel<UH>, dim3((unsigned)a.nchunks), dim3(256), lds, st, n, m,                      \
                        i8_bounds(Q, B, true, records), (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, \
-                       w.cand_cnt, w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, half ? 1 : 0, gate,                     \
-                       fused ? w.fb_count + 5 : (int*)nullptr)
+                       w.cand_cnt, w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, half ? 1 : 0, gate, guard)
                 switch (d / 32) {
                     case 8: VFM_RESCAN_CHUNK(8); break;
                     case 12: VFM_RESCAN_CHUNK(12); break;

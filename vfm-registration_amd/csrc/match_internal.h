@@ -34,6 +34,13 @@ constexpr int REFINE_MIN_I8 = 8;  // the same threshold for the row lists of the
 constexpr int REFINE_KEEP = 64;   // rows a query may keep after the refinement
 constexpr int RESCAN_BIN_CAP = 512;  // candidate queries a map chunk can collect for the chunk-major int8 rescan (the rest: query-major)
 constexpr int RESCAN_BATCH = 64;     // ... of which match_rescan_chunk_kernel stages this many in LDS at a time
+// Half-width pass, device-side guard: a search whose bound leaves more than this many (query, chunk) pairs per query -- descriptors
+// that are all alike: every chunk survives -- does not rescan them (31 million 128-row rescans at C2: 171 ms) but falls through,
+// inside the same _finish call, to match_gatepass_kernel: one full-width int8 MFMA pass with the gate as hit test (2-3 ms).
+// SearchWs::fb_count[7] is the flag (half_guard_kernel); the host policy (vfmreg/pipeline.py) leaves the mode on the same figure.
+constexpr int HALF_GUARD_PER_QUERY = 48;
+constexpr int HALF_GUARD_FLAG = 7;   // index into fb_count
+constexpr int FUSE_BIN_SATURATE = 8 * RESCAN_BIN_CAP;  // fused form: a chunk that collected this many survivors stops recording (and raises the flag)
 constexpr int FILTER_LDS_ROWS = 1024;  // sparse fp16 records a query can hold (= SearchWs::rcap; match_filter_refine_kernel keeps them in LDS)
 constexpr int SPARSE_LREC_CAP = 1536;  // records a workgroup of the sparse coarse kernel buffers in LDS (12 KiB)
 constexpr float COARSE_OFFSET = 2.0f;   // accumulators start here: every coarse score is a

@@ -86,8 +86,10 @@ class RegistrationPipeline:
         self.use_i8 = coarse != "fp16"
         self.top2 = coarse == "int8-top2"   # int8 pass with packed top-2 records (VFM_RECORDS_TOP2)
         # half-width pass (VFM_RECORDS_HALF): where the library has no kernel for it the call behaves as best-score records
-        # ... and where almost every chunk survives its bound (descriptors that are all alike) it is two orders of magnitude slower
-        # than any other mode: "auto" therefore PROBES it (vfm_match_search_probe_half: its coarse pass + a count of the survivors,
+        # ... and where almost every chunk survives its bound (descriptors that are all alike) it is slower than the full-width
+        # modes -- bounded by the library's device-side guard (csrc/match_finish.hip: above 48 survivors per query the search falls
+        # through to one full-width pass with the gate as hit test: 6.8 ms per C2-size registration against 1.9; before the
+        # guard: 171 ms): "auto" therefore PROBES it (vfm_match_search_probe_half: its coarse pass + a count of the survivors,
         # +0.7 ms once) on the first registration and at every re-probe interval, and switches to it only on a good count
         self.half = coarse == "int8-half"
         self._probe_due = coarse == "auto" and self.gate
