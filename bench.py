@@ -314,6 +314,32 @@ def c2_variants(dev, lib, pairs, steps, warmup, iters, streams):
                         "rescanned_chunks_per_query": (pipe.last_rescans / n) if pipe.last_rescans is not None else None}
     del pipe, lifted
     torch.cuda.empty_cache()
+    # row A6 (north_star's "all-pairs L2 + mutual-NN", registration_node.py:482-538) at C2 size on pair 0's descriptors
+    from vfmreg import ops
+
+    def ms_of(fn, reps=5):
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return sorted(ts[1:])[len(ts[1:]) // 2], r
+    a, b = pairs[0]["q_desc"], pairs[0]["b_desc"]
+    t_pairs, r = ms_of(lambda: ops.match_mutual_pairs(a, b))
+    t_full, _ = ms_of(lambda: ops.match_mutual_l2(a, b), reps=3)
+    flops = 2.0 * n * m * d + 2.0 * n * n * d      # the forward all-pairs product + the reverse one restricted to the matched rows
+    out["A6_mutual_l2"] = {"workload": "find_correspondences(mutual_filter=True) (registration_node.py:482-538) at C2 size: exact Euclidean 1-NN of "
+                                       "every scan row among the map, reverse direction at the matched map rows, mutual pairs; int8 MFMA "
+                                       "coarse pass on the norm-sorted map, fp64 decision on the original rows",
+                           "ms_mutual_pairs": t_pairs, "mutual_pairs": int(r[2].item()), "registrations_per_s_equivalent": 1e3 / t_pairs,
+                           "ms_both_directions_all_rows": t_full,
+                           "roofline": {"bound": "mfma", "flops": flops, "achieved": flops / (t_pairs * 1e-3) / 1e12, "peak": MFMA_I8_PEAK_TOPS,
+                                        "unit": "TFLOP/s", "frac": flops / (t_pairs * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
+                                        "note": "whole call (norms, sort, operand preparation, both coarse passes, selection, rescans, fp64 decision) "
+                                                "over the int8 peak"}}
     return out
 
 

@@ -200,11 +200,24 @@ int vfm_threshold_compact(const float *sim, const int64_t *idx, int64_t n, doubl
  * prec_mode VFM_MATCH_FAST (d <= 768): fp16 MFMA coarse pass on a commonly scaled copy with the norm
  * term in two appended columns (d <= 510) or in the accumulator start of each map row (wider), then the
  * fp64 decision among the candidates inside the proven error window -- same results as VFM_MATCH_EXACT
- * (all-pairs fp64), which descriptors wider than 768 fall back to. */
+ * (all-pairs fp64), which descriptors wider than 768 fall back to.  For d = 256 ... 768 in steps of 128 the a -> b direction
+ * runs the int8 coarse pass instead (map rows sorted by norm; csrc/match_l2.hip), the full b -> a direction the fp16 pass. */
 size_t vfm_match_mutual_l2_workspace_bytes(int64_t n, int64_t m, int d, int prec_mode, int mutual);
 int vfm_match_mutual_l2(const float *a, int64_t n, const float *b, int64_t m, int d, int prec_mode,
                         int64_t *nn_ab, double *d2_ab, int64_t *nn_ba, void *ws, size_t ws_bytes,
                         vfm_stream_t stream);
+
+/* find_correspondences(feats0, feats1, mutual_filter=True) in ONE call (RN:482-538): the pairs (i, nn_ab[i]) whose map row's
+ * nearest neighbour among a is i again (RN:520-532: `nns10[nns01] == idx0`), in ascending i.  idx0_out / idx1_out: n entries
+ * each, the first *count_out valid.  nn_ab_out / d2_ab_out (nullable): the forward nearest neighbours of every row of a, as
+ * vfm_match_mutual_l2 returns them.  The filter reads the reverse direction only at the matched map rows, so the reverse search
+ * runs on n gathered queries instead of all m rows.  d = 256 ... 768 in steps of 128 run the int8 coarse pass both ways (map
+ * rows sorted by norm, exact fp64 decision on the original rows: same pairs as the all-pairs fp64 search) -- 20 000 x 200 000 x
+ * 384: see DESIGN.md 4.1 "Row A6"; other widths take vfm_match_mutual_l2's path and filter its result. */
+size_t vfm_match_mutual_pairs_workspace_bytes(int64_t n, int64_t m, int d);
+int vfm_match_mutual_pairs(const float *a, int64_t n, const float *b, int64_t m, int d, int64_t *idx0_out,
+                           int64_t *idx1_out, int64_t *count_out, int64_t *nn_ab_out, double *d2_ab_out, void *ws,
+                           size_t ws_bytes, vfm_stream_t stream);
 
 /* ------------------------------------------------------------------ RANSAC (rows A8, A9) */
 

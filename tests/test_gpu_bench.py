@@ -61,6 +61,7 @@ def test_bench_under_torch_distributed_run_world1():
     assert ex["C2_sustained"]["steps"] == 200 and ex["C2_sustained"]["value"] > 100
     lf = ex["C2_lifted"]
     assert lf["value"] > 100 and lf["pose_err_vs_planted"] < 0.05 and lf["correspondences"] > 5000
+    assert 0 < ex["A6_mutual_l2"]["ms_mutual_pairs"] < 6.0 and ex["A6_mutual_l2"]["mutual_pairs"] > 9000
     assert ex["C3"]["ms_end_to_end"] > ex["C3"]["ms_vit"] > 0 and 0 < ex["C3"]["vit_roofline"]["frac"] < 1
     assert ex["C5"]["pose_err_vs_planted"] < 0.05 and 0.05 < ex["C5"]["roofline"]["frac"] < 1
 

@@ -588,73 +588,91 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
 // int8 pass, chunk-major rescan (best-score records, many queries per chunk): one workgroup per map chunk scores the chunk's
 // 128 rows against every query of the chunk's bin.  The query-major kernel below reads 48 KB per (query, chunk) pair --
 // 0.5 GB per registration at C2, from the Infinity Cache / HBM because the 77 MB int8 map does not fit the L2s; here the map
-// is read once.  Wave w holds tile w of the chunk in registers, lanes l and l + 32 one half of row l each; the bin's
-// queries (int8 rows, bounds) are staged in LDS, RESCAN_BATCH at a time; a row inside the query's bounds is appended to the
-// query's list.
-template <int UH>  // 16-byte units per half row (d / 32)
+// is read once.  Round 3: on the matrix cores.  Wave w holds tile w of the chunk as the MFMA's first operand (its int8
+// fragments: 4 KS registers), the bin's queries are taken 32 at a time -- the workgroup gathers their fragment units from the
+// scan's int8 tiles into one operand image in the LDS (16 bytes per unit) -- and KS MFMAs per wave give the exact integer
+// scores of 32 rows x 32 queries; a row inside the query's bounds is appended to the query's list (one atomic per lane and
+// block for all of its hits).  Same integers, same hit test, hence the same rows as the v_dot4 loop it replaces (24 LDS reads +
+// 96 dot4 per query and wave: 26 us at C2's 9891 candidates but 0.7 ms at the 220 000 of an ungated Euclidean search).
+template <int KS>  // k-steps of 32 columns (d / 32)
 __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int64_t m, I8Bounds ib, const uint4* __restrict__ q8,
                                                                  const uint4* __restrict__ b8, const unsigned* __restrict__ qmax,
                                                                  int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
                                                                  const unsigned* __restrict__ bin_cnt, const int* __restrict__ bins,
-                                                                 int use_gate, float gate, const int* __restrict__ guard) {
+                                                                 int use_gate, float gate, const int* __restrict__ guard, L2Terms l2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rescan_smem[];
-    uint4* l_q8 = reinterpret_cast<uint4*>(rescan_smem);  // [RESCAN_BATCH][2 UH]
-    __shared__ int l_q[RESCAN_BATCH];
-    __shared__ float l_sc[RESCAN_BATCH], l_bound[RESCAN_BATCH], l_qlow[RESCAN_BATCH];
+    uint4* l_qf = reinterpret_cast<uint4*>(rescan_smem);   // [KS][64]: the 32 queries of a block as ONE MFMA operand image
     const int c = blockIdx.x;
     if (guard && *guard) return;   // half-width pass, too many survivors: match_gatepass_kernel has decided every query
     const unsigned filled = bin_cnt[c];
     if (filled == 0u) return;
     const int nq = filled < (unsigned)RESCAN_BIN_CAP ? (int)filled : RESCAN_BIN_CAP;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    constexpr int UNITS = 2 * UH;
-    // the chunk's rows: tile `wave`, position lane & 31, half lane >> 5
-    uint4 bv[UH];
+    constexpr int TILE_U4 = KS * 64;
+    intx4 af[KS];
     {
-        const uint4* src = b8 + ((size_t)c * 4 + wave) * (size_t)(UNITS * 32) + (size_t)(lane >> 5) * (UH * 32) + (lane & 31);
+        const uint4* asrc = b8 + ((size_t)c * 4 + wave) * TILE_U4 + lane;
 #pragma unroll
-        for (int k = 0; k < UH; ++k) bv[k] = src[k * 32];
+        for (int s = 0; s < KS; ++s) {
+            const uint4 v = asrc[s * 64];
+            af[s] = *reinterpret_cast<const intx4*>(&v);
+        }
     }
     const int* bin = bins + (size_t)c * RESCAN_BIN_CAP;
     const float bstep = ib.bstep[c], berr = ib.berr[c];
     const long long base = (long long)c * CHUNK_ROWS;
-    const int rr = wave * 32 + (lane & 31);
-    for (int j0 = 0; j0 < nq; j0 += RESCAN_BATCH) {   // the bin, RESCAN_BATCH queries at a time
-        const int nb = nq - j0 < RESCAN_BATCH ? nq - j0 : RESCAN_BATCH;
-        if (j0) __syncthreads();
-        if (threadIdx.x < nb) {
-            const int qi = bin[j0 + threadIdx.x];
-            const bool live = cand_cnt[qi] >= 0;   // (-2: below the gate, -1: already with the all-pairs kernel)
-            l_q[threadIdx.x] = live ? qi : -1;
-            const float eq = ib.qerr[qi];
-            const float sq = ib.qstep[qi >> 7], A = eq * 1.0001220703125f + 1.0e-6f, mult = 1.0001220703125f + eq;
-            l_sc[threadIdx.x] = sq * bstep;          // the same expressions as match_rescan_kernel: the same rows pass
-            l_bound[threadIdx.x] = A + mult * berr;
-            l_qlow[threadIdx.x] = use_gate ? gate : key_float(qmax[qi]);   // half-width pass: the hit test is the gate itself
-        }
-        for (int i = threadIdx.x; i < nb * UNITS; i += 256) {
-            const int j = i / UNITS, u = i % UNITS;
-            const int qi = bin[j0 + j];
-            l_q8[i] = q8[(size_t)(qi >> 5) * (UNITS * 32) + (size_t)u * 32 + (qi & 31)];
-        }
-        __syncthreads();
-        for (int j = 0; j < nb; ++j) {
-            const int qi = l_q[j];
-            if (qi < 0) continue;
-            const uint4* qv8 = l_q8 + j * UNITS + (lane >> 5) * UH;
-            int acc = 0;
+    const int rr0 = wave * 32 + 4 * (lane >> 5);   // + (e & 3) + 8 (e >> 2): the chunk row of accumulator element e
+    float bn16[16];                                // Euclidean mode: |b~| of the lane's sixteen rows
 #pragma unroll
-            for (int k = 0; k < UH; ++k) {
-                const uint4 qv = qv8[k];
-                acc = __builtin_amdgcn_sdot4((int)bv[k].x, (int)qv.x, acc, false);
-                acc = __builtin_amdgcn_sdot4((int)bv[k].y, (int)qv.y, acc, false);
-                acc = __builtin_amdgcn_sdot4((int)bv[k].z, (int)qv.z, acc, false);
-                acc = __builtin_amdgcn_sdot4((int)bv[k].w, (int)qv.w, acc, false);
+    for (int e = 0; e < 16; ++e) bn16[e] = l2.qn ? l2.bn[base + rr0 + (e & 3) + 8 * (e >> 2)] : 0.0f;
+    int qnext = (lane & 31) < nq ? bin[lane & 31] : 0;
+    for (int j0 = 0; j0 < nq; j0 += 32) {          // the bin, one MFMA column block at a time
+        const int j = j0 + (lane & 31);
+        const int qi = qnext;
+        if (j + 32 < nq) qnext = bin[j + 32];
+        // The block's fragment units are gathered ONCE per workgroup into the LDS (a unit shares its 512-byte line of the scan's
+        // tiles with 31 other queries: four waves gathering for themselves moved 100 KB through the L2 per block and wave).
+        // Unit u = (k-step s, half h, column p) comes from query bin[j0 + p]; thread t takes units t, t + 256, ...
+        if (j0) __syncthreads();                   // the previous block's image has been read
+#pragma unroll
+        for (int u = threadIdx.x; u < TILE_U4; u += 256) {
+            // (u & 31 == lane & 31 for every u of this thread: the unit belongs to its own column's query)
+            l_qf[u] = q8[(size_t)(qi >> 5) * TILE_U4 + (size_t)(u >> 5) * 32 + (qi & 31)];
+        }
+        const bool live = j < nq && cand_cnt[qi] >= 0;   // (-2: below the gate, -1: already with the all-pairs kernel)
+        const float eq = ib.qerr[qi];
+        const float sc = ib.qstep[qi >> 7] * bstep;                    // the same expressions as match_rescan_kernel: the same rows pass
+        const float bound = (eq * 1.0001220703125f + 1.0e-6f) + (1.0001220703125f + eq) * berr;
+        const float qlow = use_gate ? gate : key_float(qmax[qi]);     // half-width pass: the hit test is the gate itself
+        const float qn = l2.qn ? l2.qn[qi] : 0.0f;
+        __syncthreads();
+        intx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const uint4 v = l_qf[s * 64 + lane];
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s], *reinterpret_cast<const intx4*>(&v), acc, 0, 0, 0);
+        }
+        // the lane's hits first (a bit per accumulator element), then ONE atomic for all of them: a returning atomic per hit
+        // stalled the wave once per element slot
+        unsigned hits = 0u;
+        if (live) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = rr0 + (e & 3) + 8 * (e >> 2);
+                float up = sc * (float)acc[e] + bound;
+                if (l2.qn) up = l2_upper_row(qn, bn16[e], up, l2.slack);
+                if (base + rr < m && up >= qlow) hits |= 1u << e;
             }
-            acc += __shfl_xor(acc, 32);
-            if (lane < 32 && base + rr < m && l_sc[j] * (float)acc + l_bound[j] >= l_qlow[j]) {
-                const int pos = atomicAdd(&cand_cnt[qi], 1);
-                if (pos < cap) cand[(size_t)qi * cap + pos] = ((unsigned)c << 8) | (unsigned)rr;
+        }
+        if (hits) {
+            int pos = atomicAdd(&cand_cnt[qi], __popc(hits));
+            while (hits) {
+                const int e = __ffs(hits) - 1;
+                hits &= hits - 1u;
+                if (pos < cap) cand[(size_t)qi * cap + pos] = ((unsigned)c << 8) | (unsigned)(rr0 + (e & 3) + 8 * (e >> 2));
+                ++pos;
             }
         }
     }
@@ -930,7 +948,7 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
                                                            int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
                                                            unsigned* __restrict__ hits, int hcap, int* __restrict__ fb_count,
                                                            int* __restrict__ fb_list, int use_gate, float gate,
-                                                           const int* __restrict__ guard) {
+                                                           const int* __restrict__ guard, L2Terms l2) {
     __shared__ uint4 l_q8[4][48];  // the query's int8 row, unit by unit (d <= 768)
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
@@ -955,6 +973,7 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
     const float eq = ib.qerr[qi];
     const float sq = ib.qstep[qi >> 7], A = eq * 1.0001220703125f + 1.0e-6f, mult = 1.0001220703125f + eq;
     const float qlow = use_gate ? gate : key_float(qmax[qi]);   // half-width pass: the hit test is the gate itself
+    const float qn_l2 = l2.qn ? l2.qn[qi] : 0.0f;
     __builtin_amdgcn_wave_barrier();
     int nhit = 0;  // wave-uniform
     // Up to 64 entries (nearly every query): they sit in registers, one per lane, before the first hit is written, so the
@@ -1004,7 +1023,9 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
             for (int half = 0; half < 2; ++half) {
                 const int rr = lane + 64 * half;
                 const int acc = acc2[half];
-                const bool hit = base + rr < m && sc * (float)acc + bound >= qlow;
+                float up = sc * (float)acc + bound;
+                if (l2.qn) up = l2_upper_row(qn_l2, l2.bn[base + rr], up, l2.slack);
+                const bool hit = base + rr < m && up >= qlow;
                 const unsigned long long bal = __ballot(hit);
                 if (hit) {
                     const int pos = nhit + __popcll(bal & ((1ull << lane) - 1ull));
@@ -1565,7 +1586,8 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
             }
             hipLaunchKernelGGL(match_rescan_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, m, d, i8_bounds(Q, B, true, records),
                                (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt, w.cand, w.cap,
-                               reinterpret_cast<unsigned*>(w.rec), 2 * w.rcap, w.fb_count, w.fb_list, half ? 1 : 0, gate, guard);
+                               reinterpret_cast<unsigned*>(w.rec), 2 * w.rcap, w.fb_count, w.fb_list, half ? 1 : 0, gate, guard,
+                               L2Terms{nullptr, nullptr, 0.0f});
             VFM_CHECK_LAUNCH("match_rescan_kernel");
             if (half) {
 #define VFM_GATEPASS(KS)                                                                                                        \
@@ -1583,11 +1605,12 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                 VFM_CHECK_LAUNCH("match_gatepass_kernel");
             }
             if (use_bins) {
-                const size_t lds = (size_t)RESCAN_BATCH * (size_t)(d / 16) * sizeof(uint4);
+                const size_t lds = (size_t)(d / 32) * 64 * sizeof(uint4);
 #define VFM_RESCAN_CHUNK(UH)                                                                                                  \
     hipLaunchKernelGGL(match_rescan_chunk_kernel<UH>, dim3((unsigned)a.nchunks), dim3(256), lds, st, n, m,                      \
                        i8_bounds(Q, B, true, records), (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, \
-                       w.cand_cnt, w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, half ? 1 : 0, gate, guard)
+                       w.cand_cnt, w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, half ? 1 : 0, gate, guard, \
+                       L2Terms{nullptr, nullptr, 0.0f})
                 switch (d / 32) {
                     case 8: VFM_RESCAN_CHUNK(8); break;
                     case 12: VFM_RESCAN_CHUNK(12); break;
@@ -1626,6 +1649,35 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     hipLaunchKernelGGL(match_exact_kernel, dim3(256), dim3(256), (((size_t)d * 4 + 15) & ~(size_t)15) + 64, st, q, Q.inv,
                        b, B.inv, n, m, d, w.fb_list, w.fb_count, idx_out, sim_out);
     VFM_CHECK_LAUNCH("match_exact_kernel(fallback)");
+    return VFM_OK;
+}
+
+int launch_i8_rescans(const SearchWs& w, const CoarseArgs& a, const Prepared& Q, const Prepared& B, int64_t n, int64_t m, int d,
+                      bool use_bins, L2Terms l2, hipStream_t st) {
+    const I8Bounds ib = i8_bounds(Q, B, true, VFM_RECORDS_BEST);
+    hipLaunchKernelGGL(match_rescan_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, m, d, ib, (const uint4*)Q.tiles8,
+                       (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt, w.cand, w.cap, reinterpret_cast<unsigned*>(w.rec),
+                       2 * w.rcap, w.fb_count, w.fb_list, 0, 0.0f, (const int*)nullptr, l2);
+    VFM_CHECK_LAUNCH("match_rescan_kernel");
+    if (use_bins) {
+        const size_t lds = (size_t)(d / 32) * 64 * sizeof(uint4);
+#define VFM_RESCAN_CHUNK(UH)                                                                                                       \
+    hipLaunchKernelGGL(match_rescan_chunk_kernel<UH>, dim3((unsigned)a.nchunks), dim3(256), lds, st, n, m, ib, (const uint4*)Q.tiles8, \
+                       (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt, w.cand, w.cap, (const unsigned*)w.bin_cnt,     \
+                       (const int*)w.bins, 0, 0.0f, (const int*)nullptr, l2)
+        switch (d / 32) {
+            case 8: VFM_RESCAN_CHUNK(8); break;
+            case 12: VFM_RESCAN_CHUNK(12); break;
+            case 16: VFM_RESCAN_CHUNK(16); break;
+            case 20: VFM_RESCAN_CHUNK(20); break;
+            default: VFM_RESCAN_CHUNK(24); break;
+        }
+#undef VFM_RESCAN_CHUNK
+        VFM_CHECK_LAUNCH("match_rescan_chunk_kernel");
+    }
+    hipLaunchKernelGGL(match_rescan_close_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, w.cand_cnt, w.cap, w.fb_count,
+                       w.fb_list, reinterpret_cast<int*>(w.rec_cnt), (const float*)nullptr);
+    VFM_CHECK_LAUNCH("match_rescan_close_kernel");
     return VFM_OK;
 }
 

@@ -151,6 +151,19 @@ struct I8Bounds {
     const float* berr;   // [nchunks] maximum E of the map chunk
     int top2;            // records: 0 = best score per (query, chunk), 1 = packed top-2 with the best row's index
 };
+// Euclidean mode of the int8 finish stage (row A6, match_l2i8.hip; qn == NULL: inner-product mode).  The int8 image holds the
+// NORMALISED rows, so the proven bound  cosU = s_q s_c S + A + B_c  bounds the cosine; with the commonly scaled norms |a~|, |b~|
+// (<= 1) the Euclidean score  a~.b~ - |b~|^2 / 2  of a row is at most  qn * bn * max(cosU, 0) - bn^2 / 2 + slack  (slack covers
+// the fp32 roundings of the norms: (d + 16) 2^-22).  Map rows are SORTED by norm, so a chunk's norms span a narrow [lo, hi].
+struct L2Terms {
+    const float* qn;   // [npad] |a~| per query
+    const float* bn;   // [mpad] |b~| per map row, in the (sorted) row order of the int8 image
+    float slack;
+};
+__device__ __forceinline__ float l2_upper_row(float qn, float bn, float cosU, float slack) {
+    return __builtin_fmaf(qn * bn, fmaxf(cosU, 0.0f), -0.5f * bn * bn) + slack;
+}
+
 // float <-> unsigned key with the same order (0 = below every float: the memset value of "nothing published")
 __device__ __forceinline__ unsigned float_key(float f) {
     const int k = __float_as_int(f);
@@ -434,6 +447,9 @@ CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, 
 int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2, int64_t rows2, void* prepared2, int d,
                 hipStream_t st, bool want_f16 = true, int grid_mode = 0 /* VFM_PREPARE_DEFAULT */);
 int do_prepare(const float* x, int64_t rows, int d, void* prepared, hipStream_t st);
+// int8 image alone of ONE operand whose row r is x[perm[r]] (perm == NULL: identity) -- the Euclidean search prepares its map
+// sorted by norm and the queries of its reverse direction gathered by the forward result
+int do_prepare_perm(const float* x, int64_t rows, const int* perm, int d, void* prepared, hipStream_t st);
 // match_coarse_f16.hip / match_coarse_i8.hip: launch the coarse kernel for arguments prepared by do_search_coarse
 int launch_coarse_f16(const CoarseArgs& a, int d, hipStream_t st);
 int launch_coarse_int8(CoarseArgs& a, int d, int64_t n, int records, hipStream_t st);
@@ -446,6 +462,10 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                      int64_t* idx_out, float* sim_out, void* ws, hipStream_t st, bool gated = false,
                      float gate = -__builtin_inff(), int records = 0);
 int launch_select_dense(const SearchWs& w, const CoarseArgs& a, const float* qinv, int64_t n, hipStream_t st);
+// candidate chunks (bins / lists of a selection kernel) -> candidate rows: query-major + chunk-major int8 rescans and the
+// closing pass (over-long lists to the all-pairs fallback); l2.qn != NULL: the Euclidean hit test, qmax = float_key(qlow)
+int launch_i8_rescans(const SearchWs& w, const CoarseArgs& a, const Prepared& Q, const Prepared& B, int64_t n, int64_t m, int d,
+                      bool use_bins, L2Terms l2, hipStream_t st);
 int probe_half_select(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, float gate, hipStream_t st);
 int exact_ip_top1(const float* q, int64_t n, const float* b, int64_t m, int d, int64_t* idx_out, float* sim_out, void* ws,
                   hipStream_t st);

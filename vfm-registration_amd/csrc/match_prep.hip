@@ -90,6 +90,7 @@ struct PrepOut {
     uint4* tiles8h;   // int8 fragment tiles of the first d / 2 columns
     float* rest;      // |second half of the normalised row|_2, rounded up
     float* grest;     // its maximum over the group
+    const int* perm;  // row r of the image is row perm[r] of x (NULL: identity)
 };
 template <bool F16, int NC = 2>
 __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restrict__ x1, int64_t rows1, int d, PrepOut o1, int groups1,
@@ -116,12 +117,14 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
         const float* x = second ? x2 : x1;
         const int64_t rows = second ? rows2 : rows1;
         const int64_t r = (int64_t)(second ? grp - groups1 : grp) * I8_GROUP + wave * RPW + j;
+        const int* perm = second ? o2.perm : o1.perm;
+        const int64_t rsrc = (perm && r < rows) ? (int64_t)perm[r] : r;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < rows && c < nchunks) {
-                const float* pc = x + r * (int64_t)d + 4 * c;
+                const float* pc = x + rsrc * (int64_t)d + 4 * c;
                 t.x = __builtin_nontemporal_load(pc);
                 t.y = __builtin_nontemporal_load(pc + 1);
                 t.z = __builtin_nontemporal_load(pc + 2);
@@ -339,7 +342,9 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x,
 
 }  // namespace
 
-inline PrepOut prep_out(const Prepared& p) { return PrepOut{p.inv, p.tiles, p.err, p.gstep, p.gerr, p.tiles8, p.tiles8h, p.rest, p.grest}; }
+inline PrepOut prep_out(const Prepared& p, const int* perm = nullptr) {
+    return PrepOut{p.inv, p.tiles, p.err, p.gstep, p.gerr, p.tiles8, p.tiles8h, p.rest, p.grest, perm};
+}
 
 // Workgroups of prep_chunk_kernel (vfm_debug_set_prep_grid): -1 (default) = one per 128-row group; 0 = one per compute unit,
 // each walking ceil(groups / grid) groups with the next group's rows read under the current group's quantisation and store
@@ -408,6 +413,29 @@ int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2
 
 int do_prepare(const float* x, int64_t rows, int d, void* prepared, hipStream_t st) {
     return do_prepare2(x, rows, prepared, nullptr, 0, nullptr, d, st);
+}
+
+int do_prepare_perm(const float* x, int64_t rows, const int* perm, int d, void* prepared, hipStream_t st) {
+    if (!i8_capable(d)) return vfm_fail(VFM_EINVAL, "prepare(perm): no int8 image for d = %d", d);
+    Prepared p1 = carve_prepared(prepared, rows, d);
+    const int g1 = (int)(rows_padded(rows) / I8_GROUP);
+    static unsigned long long attr_set = 0ull;  // one bit per device
+    if (!attr_done(attr_set)) {
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_chunk_kernel<false, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * 512));
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_chunk_kernel<false, 3>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * 768));
+        attr_mark(attr_set);
+    }
+    const dim3 grid((unsigned)prep_grid(g1, VFM_PREPARE_DEFAULT)), block(1024);
+    if (d <= 512)
+        hipLaunchKernelGGL((prep_chunk_kernel<false, 2>), grid, block, (size_t)I8_GROUP * d, st, x, rows, d, prep_out(p1, perm), g1,
+                           (const float*)nullptr, (int64_t)0, prep_out(Prepared{}), g1);
+    else
+        hipLaunchKernelGGL((prep_chunk_kernel<false, 3>), grid, block, (size_t)I8_GROUP * d, st, x, rows, d, prep_out(p1, perm), g1,
+                           (const float*)nullptr, (int64_t)0, prep_out(Prepared{}), g1);
+    VFM_CHECK_LAUNCH("prep_chunk_kernel(perm)");
+    return VFM_OK;
 }
 
 }  // namespace vfmm

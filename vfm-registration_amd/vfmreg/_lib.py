@@ -61,6 +61,8 @@ SIGNATURES = {
     "vfm_match_mutual_l2_workspace_bytes": (C.c_size_t, [c_i64, c_i64, C.c_int, C.c_int, C.c_int]),
     "vfm_match_mutual_l2": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, C.c_size_t,
                                       c_vp]),
+    "vfm_match_mutual_pairs_workspace_bytes": (C.c_size_t, [c_i64, c_i64, C.c_int]),
+    "vfm_match_mutual_pairs": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_size_t, c_vp]),
     "vfm_ransac_workspace_bytes": (C.c_size_t, [c_i64, C.c_int32]),
     "vfm_ransac_corr": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, C.c_double, C.c_int32, C.c_uint64, c_vp, c_vp, c_vp,
                                   c_vp, c_vp, c_vp, C.c_size_t, c_vp]),

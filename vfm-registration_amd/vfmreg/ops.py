@@ -154,6 +154,27 @@ def match_mutual_l2(a: torch.Tensor, b: torch.Tensor, mutual: bool = True, prec:
     return nn_ab, d2, nn_ba
 
 
+def match_mutual_pairs(a: torch.Tensor, b: torch.Tensor, want_nn: bool = False):
+    """find_correspondences(mutual_filter=True) in one call (registration_node.py:482-538): (idx0, idx1, count[, nn_ab, d2_ab]);
+    idx0 / idx1 hold ``count`` valid pairs in ascending idx0 (device tensors, count is a 1-element int64 tensor: no host sync)."""
+    _chk(a, torch.float32, "a")
+    _chk(b, torch.float32, "b")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
+        raise ValueError("Invalid shape")
+    lib = _lib.load()
+    n, m, d = a.shape[0], b.shape[0], a.shape[1]
+    dev = a.device
+    idx0 = torch.empty(n, dtype=torch.int64, device=dev)
+    idx1 = torch.empty(n, dtype=torch.int64, device=dev)
+    count = torch.empty(1, dtype=torch.int64, device=dev)
+    nn_ab = torch.empty(n, dtype=torch.int64, device=dev) if want_nn else None
+    d2 = torch.empty(n, dtype=torch.float64, device=dev) if want_nn else None
+    ws = _ws(lib.vfm_match_mutual_pairs_workspace_bytes(n, m, d), dev)
+    _lib.check(lib.vfm_match_mutual_pairs(a.data_ptr(), n, b.data_ptr(), m, d, idx0.data_ptr(), idx1.data_ptr(), count.data_ptr(),
+                                          _ptr(nn_ab), _ptr(d2), ws.data_ptr(), ws.numel(), _stream()), "match_mutual_pairs")
+    return (idx0, idx1, count, nn_ab, d2) if want_nn else (idx0, idx1, count)
+
+
 # --------------------------------------------------------------------------------------- RANSAC
 def ransac_corr(src: torch.Tensor, tgt: torch.Tensor, corres: torch.Tensor, max_dist: float, n_iter: int,
                 seed: int = 42, count: Optional[torch.Tensor] = None, want_mask: bool = True,

@@ -45,7 +45,11 @@ def find_correspondences(feats0: np.ndarray, feats1: np.ndarray, n_points: int =
     """RN:482-538 (adapted from TEASER++): exact Euclidean 1-NN on the GPU instead of cKDTree."""
     f0 = torch.from_numpy(np.ascontiguousarray(feats0, dtype=np.float32)).cuda()
     f1 = torch.from_numpy(np.ascontiguousarray(feats1, dtype=np.float32)).cuda()
-    nn01, d2, nn10 = ops.match_mutual_l2(f0, f1, mutual=mutual_filter)
+    if mutual_filter:   # RN:520-532 in one call: the reverse direction is searched only at the matched rows of feats1
+        i0, i1, count = ops.match_mutual_pairs(f0, f1)
+        k = int(count.item())
+        return i0[:k].cpu().numpy(), i1[:k].cpu().numpy()
+    nn01, d2, nn10 = ops.match_mutual_l2(f0, f1, mutual=False)
     nns01 = nn01.cpu().numpy()
     idx0 = np.arange(len(nns01))
     if not mutual_filter:
