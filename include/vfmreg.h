@@ -279,8 +279,9 @@ int vfm_gather_bilinear_patchgrid(const float *grid, int gh, int gw, int C, int 
 /* create_descriptors (PS:50-107) for up to 6 cameras in ONE launch: per LiDAR point the cameras are tried
  * in array order (= the reference's dict order = priority; the first camera that sees the point wins,
  * PS:96-101), projected with the arithmetic of vfm_project_pinhole_f64, and the winning camera's patch
- * grid is sampled as in vfm_gather_bilinear_patchgrid.  desc_out (n x C) must be zero-initialised;
- * filled[i] = 1 iff some camera saw point i.  The struct array is HOST memory, its pointers DEVICE. */
+ * grid is sampled as in vfm_gather_bilinear_patchgrid.  Every row of desc_out (n x C) is written: zeros for a point no camera
+ * sees or whose pixel is black (PS:57-62, 102-104) -- the caller need not clear it.  filled[i] = 1 iff some camera saw point i.
+ * The struct array is HOST memory, its pointers DEVICE. */
 typedef struct {
     int mode;                  /* VFM_PROJ_NCLT / _ROBOTCAR / _KITTI */
     double mats[48];           /* as vfm_project_pinhole_f64 */

@@ -47,7 +47,7 @@ filled = torch.zeros(n, dtype=torch.uint8, device="cuda")
 
 
 def lift():
-    desc.zero_()
+    desc.zero_()   # (the per-camera API writes only the points it claims)
     filled.zero_()
     for c in range(6):
         u, v, idx, cnt = ops.project_pinhole(ops.PROJ_KITTI, pcl, [Ps[c]], None, 1.0, None, None, H, W)
@@ -60,11 +60,12 @@ t_lift_loop = timed(lift)
 lift_per_camera = lift
 
 
-def lift():  # projection fused with the gather, all six cameras in one launch
-    desc.zero_()
-    ops.lift_multicam(pcl, [dict(mode=ops.PROJ_KITTI, mats=[Ps[c]], fc=None, subsample=1.0, win=None, H=H, W=W,
-                                 proj_image=None, grid=grids[c], Hup=H, Wup=W, rot_mode=0, raw_image=imgs[c])
-                            for c in range(6)], desc, filled)
+plan = ops.LiftPlan([dict(mode=ops.PROJ_KITTI, mats=[Ps[c]], fc=None, subsample=1.0, win=None, H=H, W=W, proj_image=None,
+                          grid=grids[c], Hup=H, Wup=W, rot_mode=0, raw_image=imgs[c]) for c in range(6)], 384)
+
+
+def lift():  # projection fused with the gather, all six cameras in one launch (camera records marshalled once)
+    plan(pcl, desc, filled)
 
 
 t_lift = timed(lift)
@@ -85,8 +86,7 @@ t_reg = timed(lambda: pipe.register(desc, q_xyz, b_desc, b_xyz))
 
 
 def chain():
-    global grids
-    grids = model.forward(imgs)
+    model.forward(imgs, out=grids)
     lift()
     return pipe.register(desc, q_xyz, b_desc, b_xyz)
 

@@ -171,6 +171,9 @@ __device__ __forceinline__ void src_index(float scale, int dst, int in_size, int
 // descriptor of ONE projected point (pixel u, v of the image the projection addressed), written by one
 // wavefront: bilinear sample of the patch grid at the pixel (image_features.py:104-108 without the
 // full-resolution tensor), zero if the raw image is black there (prepare_scenes.py:57-62).
+// lanes sub = 0 .. nsub - 1 share the row (nsub = 64: one wavefront per point; 16: four points per wavefront).  ZERO: a point
+// whose pixel is out of range or black gets its zeros written here (the caller need not clear the row beforehand).
+template <int NSUB = 64, bool ZERO = false>
 __device__ __forceinline__ void gather_point(const float* __restrict__ grid, int gh, int gw, int C, int Hup, int Wup,
                                              int rot_mode, const uint8_t* __restrict__ image, int u, int v,
                                              float* __restrict__ o, int lane) {
@@ -185,13 +188,20 @@ __device__ __forceinline__ void gather_point(const float* __restrict__ grid, int
     // The RobotCar / KITTI projections keep the reference's inclusive bound (u == W or v == H can be emitted,
     // oxford_robotcar.py:356-357); the reference's `feat[v, u, :]` raises IndexError there.  Here such a point keeps a
     // zero descriptor instead of reading past the image / the patch grid.
-    if (row < 0 || row >= Hup || col < 0 || col >= Wup) return;
-    bool black = false;
-    if (image) {
+    bool black = row < 0 || row >= Hup || col < 0 || col >= Wup;
+    if (!black && image) {
         const uint8_t* px = image + ((int64_t)row * Wup + col) * 3;
         black = (px[0] == 0 && px[1] == 0 && px[2] == 0);
     }
-    if (black) return;  // the descriptor stays zero
+    if (black) {  // the descriptor is (stays) zero
+        if constexpr (ZERO) {
+            if ((C & 3) == 0)
+                for (int c4 = lane; c4 < (C >> 2); c4 += NSUB) reinterpret_cast<float4*>(o)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            else
+                for (int c = lane; c < C; c += NSUB) o[c] = 0.0f;
+        }
+        return;
+    }
     const float sh = (float)gh / (float)Hup;
     const float sw = (float)gw / (float)Wup;
     int h0, h1, w0, w1;
@@ -203,7 +213,7 @@ __device__ __forceinline__ void gather_point(const float* __restrict__ grid, int
     const float* f10 = grid + ((int64_t)h1 * gw + w0) * C;
     const float* f11 = grid + ((int64_t)h1 * gw + w1) * C;
     if ((C & 3) == 0) {
-        for (int c4 = lane; c4 < (C >> 2); c4 += 64) {
+        for (int c4 = lane; c4 < (C >> 2); c4 += NSUB) {
             const float4 a = reinterpret_cast<const float4*>(f00)[c4];
             const float4 b = reinterpret_cast<const float4*>(f01)[c4];
             const float4 c = reinterpret_cast<const float4*>(f10)[c4];
@@ -216,7 +226,7 @@ __device__ __forceinline__ void gather_point(const float* __restrict__ grid, int
             reinterpret_cast<float4*>(o)[c4] = r;
         }
     } else {
-        for (int c = lane; c < C; c += 64)
+        for (int c = lane; c < C; c += NSUB)
             o[c] = hl0 * (wl0 * f00[c] + wl1 * f01[c]) + hl1 * (wl0 * f10[c] + wl1 * f11[c]);
     }
 }
@@ -259,25 +269,48 @@ struct LiftArgs {
     int ncam;
 };
 
+// Round 3: FOUR points per wavefront.  A point's work is a chain of dependent memory round trips (coordinates -> camera
+// parameters -> pixel -> four grid rows -> store) that one wavefront per point ran once per 1.5 KB of output: 20 000 waves,
+// 0.07 of the HBM rate.  Now lanes 0 .. 23 project (point j = lane / 6, camera lane % 6), the first surviving camera of each
+// point comes out of one ballot, and lane group g = lane >> 4 samples point g's grid with 16 lanes (6 float4 per row and lane);
+// the four chains of a wave run side by side.  Rows of points no camera sees (or whose pixel is black) are written as zeros
+// here: desc_out no longer has to be cleared by the caller.
 __global__ __launch_bounds__(256) void lift_multicam_kernel(const double* __restrict__ pcl, int64_t n, LiftArgs a, int C,
                                                             float* __restrict__ desc, uint8_t* __restrict__ filled) {
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n) return;
     const int lane = threadIdx.x & 63;
-    const double p[4] = {pcl[i], pcl[n + i], pcl[2 * n + i], pcl[3 * n + i]};
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;   // the wave's first point
+    if (i0 >= n) return;
     long long ui = 0, vi = 0;
     bool keep = false;
-    if (lane < a.ncam) keep = project_one(a.cam[lane].proj, a.cam[lane].proj_image, p, ui, vi);
-    const unsigned long long seen = __ballot(keep);
-    if (seen == 0ull) {
-        if (lane == 0) filled[i] = 0;
+    {
+        const int j = lane / 6, cam = lane - 6 * j;
+        const int64_t i = i0 + j;
+        if (lane < 24 && cam < a.ncam && i < n) {
+            const double p[4] = {pcl[i], pcl[n + i], pcl[2 * n + i], pcl[3 * n + i]};
+            keep = project_one(a.cam[cam].proj, a.cam[cam].proj_image, p, ui, vi);
+        }
+    }
+    const unsigned long long seen_all = __ballot(keep);
+    const int g = lane >> 4, sub = lane & 15;
+    const int64_t i = i0 + g;
+    const unsigned seen = (unsigned)((seen_all >> (6 * g)) & 63ull);
+    // (every lane takes part in the shuffles; the source lane of a point without a camera is arbitrary)
+    const int c = seen ? __builtin_ctz(seen) : 0;   // first camera in priority order
+    const int u = __shfl((int)ui, 6 * g + c), v = __shfl((int)vi, 6 * g + c);
+    if (i >= n) return;
+    float* o = desc + i * (int64_t)C;
+    if (seen == 0u) {
+        if ((C & 3) == 0)
+            for (int c4 = sub; c4 < (C >> 2); c4 += 16) reinterpret_cast<float4*>(o)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        else
+            for (int cc = sub; cc < C; cc += 16) o[cc] = 0.0f;
+        if (sub == 0) filled[i] = 0;
         return;
     }
-    const int c = __builtin_ctzll(seen);  // first camera in priority order
-    const int u = __shfl((int)ui, c), v = __shfl((int)vi, c);
+    // the four points of a wave may have chosen different cameras: lane-indexed camera record
     const LiftCam& cam = a.cam[c];
-    gather_point(cam.grid, cam.gh, cam.gw, C, cam.Hup, cam.Wup, cam.rot_mode, cam.raw_image, u, v, desc + i * (int64_t)C, lane);
-    if (lane == 0) filled[i] = 1;
+    gather_point<16, true>(cam.grid, cam.gh, cam.gw, C, cam.Hup, cam.Wup, cam.rot_mode, cam.raw_image, u, v, o, sub);
+    if (sub == 0) filled[i] = 1;
 }
 
 __global__ __launch_bounds__(256) void transform_xyz_kernel(const double* __restrict__ xyz, int64_t n,
@@ -379,7 +412,7 @@ VFM_EXPORT int vfm_lift_multicam(const double* pcl, int64_t n, int ncam, const v
         d.gh = h.gh; d.gw = h.gw; d.Hup = h.Hup; d.Wup = h.Wup; d.rot_mode = h.rot_mode;
     }
     if (n == 0) return VFM_OK;
-    hipLaunchKernelGGL(lift_multicam_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pcl, n, a, C,
+    hipLaunchKernelGGL(lift_multicam_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, pcl, n, a, C,
                        desc_out, filled);
     VFM_CHECK_LAUNCH("lift_multicam_kernel");
     return VFM_OK;

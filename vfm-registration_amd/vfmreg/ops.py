@@ -257,47 +257,64 @@ def project_pinhole(mode: int, pcl4xn: torch.Tensor, mats, fc=None, subsample: f
 LIFT_MAX_CAMS = 6
 
 
+class LiftPlan:
+    """The camera records of ``lift_multicam`` marshalled once (mode, matrices, image / grid pointers): a caller that lifts
+    scan after scan with the same rig -- prepare_scenes.py:50-107 walks a sequence -- pays the Python-side packing once, and a
+    call is one kernel launch.  The tensors named in ``cams`` are kept alive by the plan; their CONTENTS may change between
+    calls (new images, new patch grids in the same buffers)."""
+
+    def __init__(self, cams: list, C: int):
+        if not 1 <= len(cams) <= LIFT_MAX_CAMS:
+            raise ValueError("Invalid shape")
+        self.C = int(C)
+        self.arr = (_lib.LiftCamera * len(cams))()
+        self.keep = []
+        for k, c in enumerate(cams):
+            g = c["grid"]
+            _chk(g, torch.float32, "grid")
+            if g.shape[-1] != self.C:
+                raise ValueError("Invalid shape")
+            a = self.arr[k]
+            a.mode = int(c["mode"])
+            flat = [0.0] * 48
+            for j, m in enumerate(list(c["mats"])[:3]):
+                vals = [float(x) for x in (m.reshape(-1).tolist() if hasattr(m, "reshape") else m)]
+                flat[16 * j:16 * j + len(vals)] = vals
+            a.mats[:] = flat
+            a.fc[:] = [float(x) for x in c["fc"]] if c.get("fc") is not None else [0.0] * 4
+            a.subsample = float(c.get("subsample", 1.0))
+            a.win[:] = [int(x) for x in c["win"]] if c.get("win") is not None else [0] * 4
+            a.H, a.W = int(c["H"]), int(c["W"])
+            for name in ("proj_image", "raw_image"):
+                t = c.get(name)
+                if t is not None:
+                    _chk(t, torch.uint8, name)
+                    self.keep.append(t)
+                setattr(a, name, _ptr(t))
+            self.keep.append(g)
+            a.grid = g.data_ptr()
+            a.gh, a.gw = int(g.shape[0]), int(g.shape[1])
+            a.Hup, a.Wup, a.rot_mode = int(c["Hup"]), int(c["Wup"]), int(c.get("rot_mode", 0))
+        import ctypes as C_
+        self._ptr = C_.cast(self.arr, C_.c_void_p)
+        self._lib = _lib.load()
+
+    def __call__(self, pcl4xn: torch.Tensor, desc: torch.Tensor, filled: torch.Tensor) -> None:
+        _chk(pcl4xn, torch.float64, "pcl")
+        _chk(desc, torch.float32, "desc")
+        _chk(filled, torch.uint8, "filled")
+        if pcl4xn.dim() != 2 or pcl4xn.shape[0] != 4 or desc.shape[1] != self.C:
+            raise ValueError("Invalid shape")
+        _lib.check(self._lib.vfm_lift_multicam(pcl4xn.data_ptr(), pcl4xn.shape[1], len(self.arr), self._ptr, self.C,
+                                               desc.data_ptr(), filled.data_ptr(), _stream()), "lift_multicam")
+
+
 def lift_multicam(pcl4xn: torch.Tensor, cams: list, desc: torch.Tensor, filled: torch.Tensor) -> None:
     """create_descriptors (prepare_scenes.py:50-107) for all cameras in one launch.  ``cams``: list (priority
     order) of dicts with the projection parameters of ``project_pinhole`` (mode, mats, fc, subsample, win, H, W,
-    proj_image) and of ``gather_bilinear`` (grid [gh, gw, C], Hup, Wup, rot_mode, raw_image).  ``desc`` must be
-    zero-initialised; ``filled`` receives 1 for every point some camera saw."""
-    import ctypes as C
-    _chk(pcl4xn, torch.float64, "pcl")
-    _chk(desc, torch.float32, "desc")
-    _chk(filled, torch.uint8, "filled")
-    if pcl4xn.dim() != 2 or pcl4xn.shape[0] != 4 or not 1 <= len(cams) <= LIFT_MAX_CAMS:
-        raise ValueError("Invalid shape")
-    lib = _lib.load()
-    arr = (_lib.LiftCamera * len(cams))()
-    keep = []
-    for k, c in enumerate(cams):
-        g = c["grid"]
-        _chk(g, torch.float32, "grid")
-        if g.shape[-1] != desc.shape[1]:
-            raise ValueError("Invalid shape")
-        a = arr[k]
-        a.mode = int(c["mode"])
-        flat = [0.0] * 48
-        for j, m in enumerate(list(c["mats"])[:3]):
-            vals = [float(x) for x in (m.reshape(-1).tolist() if hasattr(m, "reshape") else m)]
-            flat[16 * j:16 * j + len(vals)] = vals
-        a.mats[:] = flat
-        a.fc[:] = [float(x) for x in c["fc"]] if c.get("fc") is not None else [0.0] * 4
-        a.subsample = float(c.get("subsample", 1.0))
-        a.win[:] = [int(x) for x in c["win"]] if c.get("win") is not None else [0] * 4
-        a.H, a.W = int(c["H"]), int(c["W"])
-        for name in ("proj_image", "raw_image"):
-            t = c.get(name)
-            if t is not None:
-                _chk(t, torch.uint8, name)
-                keep.append(t)
-            setattr(a, name, _ptr(t))
-        a.grid = g.data_ptr()
-        a.gh, a.gw = int(g.shape[0]), int(g.shape[1])
-        a.Hup, a.Wup, a.rot_mode = int(c["Hup"]), int(c["Wup"]), int(c.get("rot_mode", 0))
-    _lib.check(lib.vfm_lift_multicam(pcl4xn.data_ptr(), pcl4xn.shape[1], len(cams), C.cast(arr, C.c_void_p),
-                                     desc.shape[1], desc.data_ptr(), filled.data_ptr(), _stream()), "lift_multicam")
+    proj_image) and of ``gather_bilinear`` (grid [gh, gw, C], Hup, Wup, rot_mode, raw_image).  Every row of ``desc`` is
+    written (zeros for points no camera sees / black pixels); ``filled`` receives 1 for every point some camera saw."""
+    LiftPlan(cams, desc.shape[1])(pcl4xn, desc, filled)
 
 
 def gather_bilinear(grid: torch.Tensor, Hup: int, Wup: int, rot_mode: int, image: Optional[torch.Tensor],

@@ -46,6 +46,7 @@ def create_descriptors(image_files, sequence, feature_generator, pcl, images=Non
         grid = {c: torch.from_numpy(np.ascontiguousarray(feature_generator.get_image_features(images[c], upsample=True),
                                                          dtype=np.float32)).to(dev) for c in cams}
     C = next(iter(grid.values())).shape[-1]
+    # (vfm_lift_multicam writes every row -- zeros where nothing is seen --; the per-camera path below writes only what it claims)
     desc = torch.zeros((n, C), dtype=torch.float32, device=dev)
     filled = torch.zeros(n, dtype=torch.uint8, device=dev)
     is_nclt = isinstance(sequence, NCLT) or getattr(sequence, "rotate_images", False)

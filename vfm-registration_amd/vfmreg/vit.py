@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Dict
+from typing import Dict, Optional
 
 import numpy as np
 import torch
@@ -213,8 +213,9 @@ class ViTS14:
         self.blob = torch.from_numpy(blob).to(self.device)
         self._ws = {}
 
-    def forward(self, images: torch.Tensor) -> torch.Tensor:
-        """images: [B, H, W, 3] uint8 on the device -> [B, 16, pw, dim] fp32 patch features."""
+    def forward(self, images: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """images: [B, H, W, 3] uint8 on the device -> [B, 16, pw, dim] fp32 patch features (written into ``out`` when given:
+        a consumer that holds pointers into it -- ops.LiftPlan -- then needs no re-marshalling)."""
         ops._chk(images, torch.uint8, "images")
         B, H, W, _ = images.shape
         if (H, W) != (self.img_h, self.img_w):
@@ -223,7 +224,12 @@ class ViTS14:
         if B not in self._ws:
             self._ws[B] = torch.empty(lib.vfm_vit_workspace_bytes(C.byref(self.cfg), B), dtype=torch.uint8,
                                       device=self.device)
-        out = torch.empty((B, PATCH_H, self.patch_w, self.dim), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((B, PATCH_H, self.patch_w, self.dim), dtype=torch.float32, device=self.device)
+        else:
+            ops._chk(out, torch.float32, "out")
+            if tuple(out.shape) != (B, PATCH_H, self.patch_w, self.dim):
+                raise ValueError("Invalid shape")
         _lib.check(lib.vfm_vit_forward(C.byref(self.cfg), self.blob.data_ptr(), images.data_ptr(), B, H, W,
                                        out.data_ptr(), self._ws[B].data_ptr(), self._ws[B].numel(), ops._stream()),
                    "vit_forward")
