@@ -346,6 +346,13 @@ int vfm_icp_nearest(const double *src, int64_t n, const int64_t *keys, const int
                     const double *pts, int32_t n_voxels, double voxel_size, double max_dist,
                     double *tgt_out, uint8_t *valid_out, vfm_stream_t stream);
 
+/* One Gauss-Newton iteration's device work in one launch: src_out = T[:3,:] @ [src; 1] (Registration.cpp:178-179 -- the
+ * arithmetic of vfm_transform_xyz_f64; T_host: 16 fp64 in HOST memory, row-major, read at the call) followed by
+ * vfm_icp_nearest on the moved points.  src_out may equal src. */
+int vfm_icp_step_nearest(const double *src, int64_t n, const double *T_host, double *src_out, const int64_t *keys,
+                         const int32_t *start, const double *pts, int32_t n_voxels, double voxel_size, double max_dist,
+                         double *tgt_out, uint8_t *valid_out, vfm_stream_t stream);
+
 /* BuildLinearSystem (src/kiss-icp/cpp/kiss_icp/core/Registration.cpp:96-141): out43 =
  * [J^T W J row-major 6x6 | J^T W r (6) | pair count], J = [I | -hat(s)], w = k^2/(k+|r|^2)^2. */
 int vfm_icp_build_system(const double *src, const double *tgt, const uint8_t *valid, int64_t n,

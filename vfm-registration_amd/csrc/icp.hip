@@ -23,15 +23,32 @@ __device__ __forceinline__ long long voxel_key(int vx, int vy, int vz) {
     return ((long long)(vx + (1 << 20)) << 42) | ((long long)(vy + (1 << 20)) << 21) | (long long)(vz + (1 << 20));
 }
 
+// step: the Gauss-Newton update of the previous iteration (Registration.cpp:178-179, "Equation (12)") applied in the same
+// launch -- T by value, the arithmetic of vfm_transform_xyz_f64 -- and the moved points written to src_out
+struct IcpStep {
+    double T[12];
+    int apply;
+};
 __global__ __launch_bounds__(256) void icp_nearest_kernel(const double* __restrict__ src, int64_t n,
                                                           const long long* __restrict__ keys,
                                                           const int* __restrict__ start,
                                                           const double* __restrict__ pts, int nv, double voxel_size,
                                                           double max_dist, double* __restrict__ tgt,
-                                                          uint8_t* __restrict__ valid) {
+                                                          uint8_t* __restrict__ valid, IcpStep step,
+                                                          double* __restrict__ src_out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
+    double px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
+    if (step.apply) {
+        const double* T = step.T;
+        const double qx = ((T[0] * px + T[1] * py) + T[2] * pz) + T[3] * 1.0;
+        const double qy = ((T[4] * px + T[5] * py) + T[6] * pz) + T[7] * 1.0;
+        const double qz = ((T[8] * px + T[9] * py) + T[10] * pz) + T[11] * 1.0;
+        px = qx; py = qy; pz = qz;
+        src_out[3 * i] = px;
+        src_out[3 * i + 1] = py;
+        src_out[3 * i + 2] = pz;
+    }
     const int kx = (int)(px / voxel_size), ky = (int)(py / voxel_size), kz = (int)(pz / voxel_size);
     double bx = 0.0, by = 0.0, bz = 0.0, best = 1.7976931348623157e308;
     bool found = false;
@@ -114,10 +131,28 @@ VFM_EXPORT int vfm_icp_nearest(const double* src, int64_t n, const int64_t* keys
     VFM_CHECK_ARG(src && keys && start && pts && tgt_out && valid_out && n >= 0 && n_voxels >= 0 && voxel_size > 0.0,
                   "icp_nearest: bad arguments");
     if (n == 0) return VFM_OK;
+    IcpStep step;
+    step.apply = 0;
     hipLaunchKernelGGL(icp_nearest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, n,
                        reinterpret_cast<const long long*>(keys), start, pts, n_voxels, voxel_size, max_dist, tgt_out,
-                       valid_out);
+                       valid_out, step, (double*)nullptr);
     VFM_CHECK_LAUNCH("icp_nearest_kernel");
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_icp_step_nearest(const double* src, int64_t n, const double* T_host, double* src_out, const int64_t* keys,
+                                    const int32_t* start, const double* pts, int32_t n_voxels, double voxel_size, double max_dist,
+                                    double* tgt_out, uint8_t* valid_out, vfm_stream_t stream) {
+    VFM_CHECK_ARG(src && T_host && src_out && keys && start && pts && tgt_out && valid_out && n >= 0 && n_voxels >= 0 && voxel_size > 0.0,
+                  "icp_step_nearest: bad arguments");
+    if (n == 0) return VFM_OK;
+    IcpStep step;
+    for (int k = 0; k < 12; ++k) step.T[k] = T_host[k];
+    step.apply = 1;
+    hipLaunchKernelGGL(icp_nearest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, n,
+                       reinterpret_cast<const long long*>(keys), start, pts, n_voxels, voxel_size, max_dist, tgt_out,
+                       valid_out, step, src_out);
+    VFM_CHECK_LAUNCH("icp_nearest_kernel(step)");
     return VFM_OK;
 }
 

@@ -3,9 +3,9 @@ for 3-D point clouds: robust point-to-point Gauss-Newton ICP against a VoxelHash
 (kiss_icp::RegisterFrame, Registration.cpp:145-195; called at registration_node.py:338-344 with
 max_correspondance_distance = 3 sigma, kernel = sigma / 3).
 
-Per iteration the GPU finds the nearest map point of every source point in the 27 surrounding voxels
-(csrc/icp.hip: icp_nearest_kernel) and reduces the 6x6 normal equations (icp_system_kernel); the
-host solves the 6x6 system and applies Sophus' SE3 exponential, exactly as Registration.cpp:176-181.
+Per iteration the GPU moves the source points by the previous update and finds the nearest map point of each in the 27
+surrounding voxels (csrc/icp.hip: icp_nearest_kernel, one launch) and reduces the 6x6 normal equations
+(icp_system_kernel); the host solves the 6x6 system and applies Sophus' SE3 exponential, as Registration.cpp:176-181.
 Termination: |dx| < 1e-4 or 1000 iterations (Registration.cpp:92-93, 183).
 The VFM-seeded 387-column variant (Registration.cpp:197-382) is not used by the headline evaluation
 (every call site passes [:, :3], registration_node.py:646, 929) and is not built.
@@ -78,25 +78,36 @@ def register_frame(points: np.ndarray, voxel_map, initial_guess: np.ndarray, max
         voxel_map._icp_grid = grid
     g = grid[1]
     src = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float64)).cuda()
-    source = ops.transform_xyz(src, torch.from_numpy(initial_guess).cuda())  # Equation (9)
-    n = source.shape[0]
-    tgt = torch.empty_like(source)
+    n = src.shape[0]
+    source = torch.empty_like(src)
+    tgt = torch.empty_like(src)
     valid = torch.empty(n, dtype=torch.uint8, device="cuda")
     out = torch.empty(43, dtype=torch.float64, device="cuda")
+    out_h = torch.empty(43, dtype=torch.float64).pin_memory()
+    # An iteration = ONE launch that moves the points by the previous update (Equation (12); the first one by the initial guess,
+    # Equation (9)) and finds their nearest map points (Equation (10)), ONE that reduces the normal equations (Equation (11)),
+    # and one 344-byte read-back into pinned memory; the 6x6 solve and SE3::exp stay host code as in Registration.cpp:176-177.
+    # (Round 2 ran three launches, a blocking .cpu() and an upload of the 4x4 per iteration.)
+    step = initial_guess
+    cur = src
     T_icp = np.eye(4)
     for _ in range(MAX_NUM_ITERATIONS):
-        _lib.check(lib.vfm_icp_nearest(source.data_ptr(), n, g.keys.data_ptr(), g.start.data_ptr(), g.pts.data_ptr(),
-                                       g.n_voxels, g.voxel_size, float(max_correspondance_distance), tgt.data_ptr(),
-                                       valid.data_ptr(), st), "icp_nearest")          # Equation (10)
+        Th = np.ascontiguousarray(step, dtype=np.float64)
+        _lib.check(lib.vfm_icp_step_nearest(cur.data_ptr(), n, Th.ctypes.data, source.data_ptr(), g.keys.data_ptr(),
+                                            g.start.data_ptr(), g.pts.data_ptr(), g.n_voxels, g.voxel_size,
+                                            float(max_correspondance_distance), tgt.data_ptr(), valid.data_ptr(), st), "icp_step_nearest")
+        cur = source
         _lib.check(lib.vfm_icp_build_system(source.data_ptr(), tgt.data_ptr(), valid.data_ptr(), n, float(kernel),
                                             out.data_ptr(), st), "icp_build_system")  # Equation (11)
-        o = out.cpu().numpy()
+        out_h.copy_(out, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        o = out_h.numpy()
         if o[42] == 0:
             print("[3D] No correspondences found")  # Registration.cpp:166
             break
         dx = np.linalg.solve(o[:36].reshape(6, 6), -o[36:42])  # JTJ.ldlt().solve(-JTr)
         estimation = se3_exp(dx)
-        source = ops.transform_xyz(source, torch.from_numpy(np.ascontiguousarray(estimation)).cuda())  # Equation (12)
+        step = estimation                                       # applied by the next iteration's launch
         T_icp = estimation @ T_icp
         if np.linalg.norm(dx) < ESTIMATION_THRESHOLD:
             break
