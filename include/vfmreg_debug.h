@@ -42,7 +42,8 @@ int vfm_debug_set_coarse_slices(int slices);
 int vfm_debug_match_stats(void *ws, int64_t n, int64_t m, int32_t *out64_host);
 /* the counters are collected only while this switch is on (they cost same-address atomics) */
 int vfm_debug_set_match_stats(int on);
-/* A/B: ViT GEMM wave tile / prefetch depth: NT * 100 + PF for N <= 512 and N > 512 (see csrc/vit.hip) */
+/* A/B: ViT GEMM wave tile / prefetch depth: NT * 100 + PF for N <= 512 and N > 512 (see csrc/vit.hip); narrow_cfg = -3 / -4:
+ * XCD-consistent tile mapping of the ViT kernels on (default) / off */
 int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
 /* A/B: workgroups of the int8 operand-preparation kernel (-1, default = one per 128-row group; 0 = one per compute unit, each
  * walking several groups with the next group's rows read under the current group's quantisation and store: faster alone,

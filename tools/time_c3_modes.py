@@ -39,7 +39,8 @@ b_xyz = torch.rand(m, 3, device=dev, generator=g, dtype=torch.float64) * 100.0
 q_xyz = torch.from_numpy(np.ascontiguousarray(xyz)).to(dev)
 b_xyz[pick] = q_xyz + 0.02 * torch.randn(n, 3, device=dev, generator=g, dtype=torch.float64)
 ref = None
-for coarse in ("auto", "int8-half", "int8", "int8-top2", "fp16"):
+import os
+for coarse in os.environ.get("C3_MODES", "auto,int8-half,int8,int8-top2,fp16").split(","):
     pipe = RegistrationPipeline(n, m, 384, n_iter=50000, device=dev, coarse=coarse)
     ts = []
     for r in range(8):

@@ -171,7 +171,26 @@ struct GemmArgs {
     _Float16* q;  // QKV outputs: per (b, head): Q frag [Tp][64], K frag [Tp][64], V^T frag [64][Tp]
     _Float16* k;
     _Float16* vt;
+    int xcd_map;  // 1: token tile mt is worked on by workgroups with blockIdx % 8 == mt % 8 (see xcd_item)
 };
+
+// XCD-consistent work mapping (round 3): workgroup b runs on XCD b % 8 (observed placement, speed only).  Every kernel of a block
+// gives token tile mt to workgroups of XCD mt % 8, so a tile's activations are produced and consumed through the same 4 MiB L2
+// instead of crossing the fabric at every kernel boundary: 0.742 instead of 0.774 ms for 6 x 1200 x 1600 (tools/ab_vit_xcd.py).
+// item = (blockIdx >> 3) * 4 + wave counts the XCD's (tile, column tile) pairs; returns false past the end.
+// (Also measured in round 3 and removed again -- both cut launches by concentrating a token tile's work in one workgroup: LayerNorm
+// computed inside the QKV / fc1 GEMMs by every wave that needs it, 63 launches, 1.64 ms; the MLP of a block as one launch per
+// 32-token tile with the hidden activations in the LDS, 75 launches, 1.09 ms -- 66 workgroups stream 2.4 MB of weights each
+// through one compute unit's L2 port with a register ring's worth of loads in flight, where the wide GEMMs spread the same bytes
+// over 256 compute units.)
+__device__ __forceinline__ bool xcd_item(int mtiles, int ntiles, int wave, int& mt, int& nt) {
+    const int xcd = blockIdx.x & 7;
+    const int it = (blockIdx.x >> 3) * 4 + wave;
+    const int lt = it / ntiles;
+    nt = it - lt * ntiles;
+    mt = xcd + 8 * lt;
+    return mt < mtiles;
+}
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -183,8 +202,10 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
     const int wave = threadIdx.x >> 6;
     const int ntiles = g.N / (32 * NT);
     const int wid = blockIdx.x * 4 + wave;
-    const int mt = wid / ntiles, nt = wid % ntiles;  // token tile, (32*NT)-channel tile
-    if (mt >= g.M / 32) return;
+    int mt = wid / ntiles, nt = wid % ntiles;  // token tile, (32*NT)-channel tile
+    if (g.xcd_map) {
+        if (!xcd_item(g.M / 32, ntiles, wave, mt, nt)) return;
+    } else if (mt >= g.M / 32) return;
     const uint4* Ap = g.A + (size_t)mt * g.KS * 64 + lane;
     const uint4* Wp = g.W + (size_t)(nt * NT) * g.KS * 64 + lane;
     floatx16 acc[NT];
@@ -312,8 +333,12 @@ __device__ __forceinline__ void wave_ln_stats(const float (&v)[4 * LN_CH], const
 
 __global__ __launch_bounds__(256) void vit_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bsh, int M, int D,
-                                                            _Float16* __restrict__ out) {
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                            _Float16* __restrict__ out, int xcd_map) {
+    int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (xcd_map) {   // token tile mt on XCD mt % 8: item = 32 lt + token of the tile
+        const int it = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+        m = ((blockIdx.x & 7) + 8 * (it >> 5)) * 32 + (it & 31);
+    }
     if (m >= M) return;
     const int lane = lane_id();
     float v[4 * LN_CH];
@@ -381,12 +406,17 @@ __device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
 template <int NKT>
 __global__ __launch_bounds__(256) void vit_attention_kernel(const uint4* __restrict__ Q, const uint4* __restrict__ K,
                                                             const uint4* __restrict__ VT, int T, int Tp, int heads, int D,
-                                                            int nwork, _Float16* __restrict__ out) {
+                                                            int nwork, _Float16* __restrict__ out, int xcd_map) {
     const int lane = lane_id();
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wid >= nwork) return;
     const int qtiles = Tp / 32;
-    const int bh = wid / qtiles, qt = wid % qtiles;
+    int bh = wid / qtiles, qt = wid % qtiles;
+    if (xcd_map) {   // the (token tile mt = b * qtiles + qt, head) pairs of XCD mt % 8
+        int mt, head_;
+        if (!xcd_item(nwork / heads, heads, threadIdx.x >> 6, mt, head_)) return;
+        bh = (mt / qtiles) * heads + head_;
+        qt = mt % qtiles;
+    } else if (wid >= nwork) return;
     const int b = bh / heads, head = bh % heads;
     const size_t base = (size_t)bh * Tp * 64 / 8;  // uint4 units per (b, head)
     // Q^T as B operand: query tile qt, 4 k-steps over d
@@ -515,12 +545,15 @@ inline VitWs carve_vit(void* p, const Dims& d) {
     return w;
 }
 
+int g_vit_xcd = 1;        // vfm_debug_set_vit_gemm(-3 / -4, .): XCD-consistent tile mapping on / off (A/B)
 int g_vit_cfg_narrow = 108, g_vit_cfg_wide = 108;  // (NT * 100 + PF) for N <= 512 / N > 512 (vfm_debug_set_vit_gemm)
 
 template <int EPI, int NT, int PF>
 int launch_gemm_cfg(const GemmArgs& g, hipStream_t st) {
     const int waves = (g.M / 32) * (g.N / (32 * NT));
-    hipLaunchKernelGGL((vit_gemm_kernel<EPI, NT, PF>), dim3(ceil_div(waves, 4)), dim3(256), 0, st, g);
+    // xcd_map: every XCD gets ceil(tiles / 8) token tiles' worth of workgroups
+    const int grid = g.xcd_map ? 8 * ceil_div(ceil_div(g.M / 32, 8) * (g.N / (32 * NT)), 4) : ceil_div(waves, 4);
+    hipLaunchKernelGGL((vit_gemm_kernel<EPI, NT, PF>), dim3(grid), dim3(256), 0, st, g);
     VFM_CHECK_LAUNCH("vit_gemm_kernel");
     return VFM_OK;
 }
@@ -543,6 +576,10 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
 }  // namespace
 
 VFM_EXPORT int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg) {
+    if (narrow_cfg == -3 || narrow_cfg == -4) {
+        g_vit_xcd = narrow_cfg == -3 ? 1 : 0;
+        return VFM_OK;
+    }
     g_vit_cfg_narrow = narrow_cfg ? narrow_cfg : 108;
     g_vit_cfg_wide = wide_cfg ? wide_cfg : 108;
     return VFM_OK;
@@ -591,24 +628,26 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
     GemmArgs g{};
     g.T = d.T; g.Tp = d.Tp; g.D = d.D; g.heads = d.heads; g.M = d.M;
     g.x = w.x; g.q = w.q; g.k = w.k; g.vt = w.vt;
+    g.xcd_map = g_vit_xcd;
+    const int ln_grid = g_vit_xcd ? 8 * ceil_div(ceil_div(d.M / 32, 8) * 32, 4) : ceil_div(d.M, 4);
+    const int att_grid = g_vit_xcd ? 8 * ceil_div(ceil_div(d.M / 32, 8) * d.heads, 4) : ceil_div(d.B * d.heads * (d.Tp / 32), 4);
     // patch embedding (+ cls token + position embedding)
     g.A = reinterpret_cast<const uint4*>(w.a); g.W = f16(SEG_PATCH_W); g.bias = f32(SEG_PATCH_B);
     g.N = d.D; g.KS = d.KP / 16; g.clspos = f32(SEG_CLS_POS);
     int rc = launch_gemm<EPI_PATCH>(g, st);
     if (rc) return rc;
-    const int ln_blocks = ceil_div(d.M, 4);
     const int att_work = d.B * d.heads * (d.Tp / 32);
     for (int l = 0; l < d.depth; ++l) {
         const int s0 = SEG_LAYER0 + l * SEGS_PER_LAYER;
-        hipLaunchKernelGGL(vit_layernorm_kernel, dim3(ln_blocks), dim3(256), 0, st, w.x, f32(s0 + L_LN1_W), f32(s0 + L_LN1_B),
-                           d.M, d.D, w.a);
+        hipLaunchKernelGGL(vit_layernorm_kernel, dim3(ln_grid), dim3(256), 0, st, w.x, f32(s0 + L_LN1_W), f32(s0 + L_LN1_B),
+                           d.M, d.D, w.a, g_vit_xcd);
         g.A = reinterpret_cast<const uint4*>(w.a); g.W = f16(s0 + L_QKV_W); g.bias = f32(s0 + L_QKV_B);
         g.N = 3 * d.D; g.KS = d.D / 16;
         if ((rc = launch_gemm<EPI_QKV>(g, st))) return rc;
 #define VIT_ATT(NKT)                                                                                                      \
-    hipLaunchKernelGGL(vit_attention_kernel<NKT>, dim3(ceil_div(att_work, 4)), dim3(256), 0, st,                          \
+    hipLaunchKernelGGL(vit_attention_kernel<NKT>, dim3(att_grid), dim3(256), 0, st,                                       \
                        reinterpret_cast<const uint4*>(w.q), reinterpret_cast<const uint4*>(w.k),                          \
-                       reinterpret_cast<const uint4*>(w.vt), d.T, d.Tp, d.heads, d.D, att_work, w.a)
+                       reinterpret_cast<const uint4*>(w.vt), d.T, d.Tp, d.heads, d.D, att_work, w.a, g_vit_xcd)
         switch (d.Tp / 32) {
             case 1: VIT_ATT(1); break;   case 2: VIT_ATT(2); break;   case 3: VIT_ATT(3); break;
             case 4: VIT_ATT(4); break;   case 5: VIT_ATT(5); break;   case 6: VIT_ATT(6); break;
@@ -622,8 +661,8 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
         g.A = reinterpret_cast<const uint4*>(w.a); g.W = f16(s0 + L_PROJ_W); g.bias = f32(s0 + L_PROJ_B);
         g.gamma = f32(s0 + L_LS1); g.N = d.D; g.KS = d.D / 16;
         if ((rc = launch_gemm<EPI_RESID>(g, st))) return rc;
-        hipLaunchKernelGGL(vit_layernorm_kernel, dim3(ln_blocks), dim3(256), 0, st, w.x, f32(s0 + L_LN2_W), f32(s0 + L_LN2_B),
-                           d.M, d.D, w.a);
+        hipLaunchKernelGGL(vit_layernorm_kernel, dim3(ln_grid), dim3(256), 0, st, w.x, f32(s0 + L_LN2_W), f32(s0 + L_LN2_B),
+                           d.M, d.D, w.a, g_vit_xcd);
         g.A = reinterpret_cast<const uint4*>(w.a); g.W = f16(s0 + L_FC1_W); g.bias = f32(s0 + L_FC1_B);
         g.N = d.mlp; g.KS = d.D / 16; g.out = w.h;
         if ((rc = launch_gemm<EPI_GELU>(g, st))) return rc;
