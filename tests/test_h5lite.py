@@ -103,6 +103,12 @@ def test_many_entries_need_a_two_level_group_index(tmp_path):
     if h5ls:
         out = subprocess.run([h5ls, "-r", str(f)], capture_output=True, text=True, check=True).stdout
         assert out.count("Dataset") == 704 and "/g/0699" in out
+    h5dump = _tool("h5dump")
+    if h5dump:   # look-ups BY NAME walk the B-tree's keys (a node's left key = its left sibling's largest name)
+        for name in ("0000", "0063", "0064", "0300", "0650", "0699"):
+            raw = tmp_path / f"{name}.bin"
+            subprocess.run([h5dump, "-d", f"/g/{name}", "-b", "LE", "-o", str(raw), str(f)], capture_output=True, text=True, check=True)
+            np.testing.assert_array_equal(np.fromfile(raw, dtype="<f4").reshape(2, 3), tree["g"][name])
 
 
 @pytest.mark.skipif(_tool("h5dump") is None, reason="HDF5 command-line tools not on this box")

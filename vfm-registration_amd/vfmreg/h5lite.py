@@ -141,6 +141,7 @@ class _Reader:
                 yield from self._symbols(int.from_bytes(pl[0:8], "little"), int.from_bytes(pl[8:16], "little"))
                 return
         links = [pl for mtype, _, pl in msgs if mtype == 0x06]
+        found = []
         for pl in links:  # compact new-style group: link messages
             flags = pl[1]
             p = 2
@@ -159,7 +160,10 @@ class _Reader:
             p += nlen
             if ltype != 0:
                 raise NotImplementedError("soft / external links")
-            yield name, int.from_bytes(pl[p:p + 8], "little")
+            found.append((name, int.from_bytes(pl[p:p + 8], "little")))
+        # link messages sit in CREATION order; h5py's keys() / values() iterate by name (the reference's read_h5.py:17-49
+        # walks them that way), as the symbol-table groups above do
+        yield from sorted(found, key=lambda kv: kv[0].encode())
         if not links:
             for mtype, _, pl in msgs:
                 if mtype == 0x02:  # link info: version, flags, [max creation index], fractal heap address, ...
@@ -378,7 +382,9 @@ class _Writer:
             nodes = []
             for i in range(0, len(level_nodes), fan):
                 part = level_nodes[i:i + fan]
-                body = struct.pack("<Q", 0)
+                # key[0] of a node: the largest key of its LEFT sibling's subtree (0 = the empty string for the leftmost node):
+                # libhdf5's H5B lookups compare against it (it was 0 in every node, wrong beyond 2 K entries)
+                body = struct.pack("<Q", level_nodes[i - 1][1] if i else 0)
                 for addr, key in part:
                     body += struct.pack("<QQ", addr, key)
                 body += b"\0" * (16 * (fan - len(part)))
