@@ -136,6 +136,7 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
             a.grest = B.grest;
             a.bin_cnt = w.bin_cnt;
             a.bins = w.bins;
+            a.bin_cap = w.bin_cap;
             a.cand_cnt = w.cand_cnt;
             a.cand = w.cand;
             a.cap = w.cap;

@@ -250,14 +250,15 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a)
                         const int64_t q = (int64_t)(qt0 + j) * 32 + lane;
                         // (the search's load figure is summed from the bin counts by match_rescan_chunk_kernel: ten thousand
                         // same-address atomics from inside this kernel cost it more than the selection kernel it replaces)
-                        // (a chunk that has collected FUSE_BIN_SATURATE survivors already -- descriptors that are all alike -- stops
+                        // (a chunk that has collected FUSE_BIN_SATURATE_X times its bin capacity already -- descriptors that are all alike -- stops
                         // recording: the entry is dropped and the search's guard flag raised, match_gatepass_kernel then decides
                         // every query; without the cut-off such data cost this kernel 31 million atomics)
                         const unsigned seen = __hip_atomic_load(&a.bin_cnt[chunk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned pos = seen >= (unsigned)FUSE_BIN_SATURATE ? seen : atomicAdd(&a.bin_cnt[chunk], 1u);
-                        if (pos < (unsigned)RESCAN_BIN_CAP) {
-                            a.bins[(size_t)chunk * RESCAN_BIN_CAP + pos] = (int)q;
-                        } else if (pos < (unsigned)FUSE_BIN_SATURATE) {   // a full bin leaves the entry in the query's own list (match_rescan_kernel)
+                        const unsigned saturate = (unsigned)(FUSE_BIN_SATURATE_X * a.bin_cap);
+                        const unsigned pos = seen >= saturate ? seen : atomicAdd(&a.bin_cnt[chunk], 1u);
+                        if (pos < (unsigned)a.bin_cap) {
+                            a.bins[(size_t)chunk * a.bin_cap + pos] = (int)q;
+                        } else if (pos < saturate) {   // a full bin leaves the entry in the query's own list (match_rescan_kernel)
                             const int slot = atomicAdd(&a.cand_cnt[q], 1);
                             if (slot < a.cap) a.cand[(size_t)q * a.cap + slot] = ((unsigned)chunk << 8) | 128u;
                         } else {

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64 * 8) void match_select_half_kernel(
     const unsigned* __restrict__ best, int nchunks, int64_t n, const float* __restrict__ invq, I8Bounds ib,
     const float* __restrict__ qrest, const float* __restrict__ grest, float gate, int chunk_lds, int* __restrict__ cand_cnt,
     unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count, int* __restrict__ fb_list, int stats,
-    unsigned* __restrict__ bin_cnt, int* __restrict__ bins) {
+    unsigned* __restrict__ bin_cnt, int* __restrict__ bins, int bin_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char select_smem[];  // the chunks' (step, max E) and max |rest|
     __shared__ int lcnt[32];
     __shared__ int lov[32];
@@ -381,9 +381,9 @@ __global__ __launch_bounds__(64 * 8) void match_select_half_kernel(
                         // (a full bin is not touched again: on descriptors that are all alike every query survives in every
                         // chunk, and 31 million atomics on 1563 addresses were most of this kernel's time there)
                         const unsigned seen = __hip_atomic_load(&bin_cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned pos = seen >= (unsigned)RESCAN_BIN_CAP ? seen : atomicAdd(&bin_cnt[c], 1u);
-                        if (pos < (unsigned)RESCAN_BIN_CAP) {
-                            bins[(size_t)c * RESCAN_BIN_CAP + pos] = (int)(q0 + j);
+                        const unsigned pos = seen >= (unsigned)bin_cap ? seen : atomicAdd(&bin_cnt[c], 1u);
+                        if (pos < (unsigned)bin_cap) {
+                            bins[(size_t)c * bin_cap + pos] = (int)(q0 + j);
                             slot = cap;
                         } else {
                             slot = atomicAdd(&lov[lq + j], 1);
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
     const unsigned* __restrict__ best, int nchunks, int64_t n, const unsigned* __restrict__ qmax, const float* __restrict__ invq,
     I8Bounds ib, float gate, int chunk_lds, int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
     int* __restrict__ fb_count, int* __restrict__ fb_list, int stats, unsigned* __restrict__ bin_cnt, int* __restrict__ bins,
-    int first_pad_chunk) {
+    int first_pad_chunk, int bin_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char select_smem[];  // the chunks' (step, max E)
     __shared__ int lcnt[32];      // candidate chunks of the query
     __shared__ int lov[32];       // bins != NULL: those of them that did not fit their chunk's bin (they go to the query's own list)
@@ -526,8 +526,8 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
                     int slot = atomicAdd(&lcnt[lq + j], 1);
                     if (bins) {  // chunk-major rescan: the query joins the chunk's bin; a full bin leaves the entry with the query
                         const unsigned pos = atomicAdd(&bin_cnt[c], 1u);
-                        if (pos < (unsigned)RESCAN_BIN_CAP) {
-                            bins[(size_t)c * RESCAN_BIN_CAP + pos] = (int)(q0 + j);
+                        if (pos < (unsigned)bin_cap) {
+                            bins[(size_t)c * bin_cap + pos] = (int)(q0 + j);
                             slot = cap;
                         } else {
                             slot = atomicAdd(&lov[lq + j], 1);
@@ -599,14 +599,17 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
                                                                  const uint4* __restrict__ b8, const unsigned* __restrict__ qmax,
                                                                  int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
                                                                  const unsigned* __restrict__ bin_cnt, const int* __restrict__ bins,
-                                                                 int use_gate, float gate, const int* __restrict__ guard, L2Terms l2) {
+                                                                 int use_gate, float gate, const int* __restrict__ guard, L2Terms l2,
+                                                                 int bin_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rescan_smem[];
     uint4* l_qf = reinterpret_cast<uint4*>(rescan_smem);   // [KS][64]: the 32 queries of a block as ONE MFMA operand image
     const int c = blockIdx.x;
     if (guard && *guard) return;   // half-width pass, too many survivors: match_gatepass_kernel has decided every query
     const unsigned filled = bin_cnt[c];
-    if (filled == 0u) return;
-    const int nq = filled < (unsigned)RESCAN_BIN_CAP ? (int)filled : RESCAN_BIN_CAP;
+    const int nall = filled < (unsigned)bin_cap ? (int)filled : bin_cap;
+    const int jbeg = blockIdx.y * RESCAN_SLICE;   // a long bin is shared by the workgroups (c, 0), (c, 1), ...
+    if (jbeg >= nall) return;
+    const int nq = nall - jbeg < RESCAN_SLICE ? nall - jbeg : RESCAN_SLICE;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     constexpr int TILE_U4 = KS * 64;
     intx4 af[KS];
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
             af[s] = *reinterpret_cast<const intx4*>(&v);
         }
     }
-    const int* bin = bins + (size_t)c * RESCAN_BIN_CAP;
+    const int* bin = bins + (size_t)c * bin_cap + jbeg;
     const float bstep = ib.bstep[c], berr = ib.berr[c];
     const long long base = (long long)c * CHUNK_ROWS;
     const int rr0 = wave * 32 + 4 * (lane >> 5);   // + (e & 3) + 8 (e >> 2): the chunk row of accumulator element e
@@ -1559,7 +1562,8 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
             hipLaunchKernelGGL(match_select_half_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * 8), half_lds ? (size_t)a.nchunks * 12 : 0,
                                st, reinterpret_cast<const unsigned*>(w.partials), a.nchunks, n, Q.inv, i8_bounds(Q, B, true, records),
                                (const float*)Q.rest, (const float*)B.grest, gate, half_lds, w.cand_cnt, w.cand, w.cap, w.fb_count,
-                               w.fb_list, g_match_stats, use_bins ? w.bin_cnt : (unsigned*)nullptr, use_bins ? w.bins : (int*)nullptr);
+                               w.fb_list, g_match_stats, use_bins ? w.bin_cnt : (unsigned*)nullptr, use_bins ? w.bins : (int*)nullptr,
+                               w.bin_cap);
         } else if (i8 && records == VFM_RECORDS_TOP2 && g_select_variant != 1) {
             hipLaunchKernelGGL(match_select_top2_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * SELECT_TOP2_WAVES),
                                chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, (const uint2*)w.partials, a.nchunks, n,
@@ -1570,7 +1574,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                                chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, reinterpret_cast<const unsigned*>(w.partials),
                                a.nchunks, n, (const unsigned*)w.qmax, Q.inv, i8_bounds(Q, B, true, records), gate, chunk_lds, w.cand_cnt,
                                w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats, use_bins ? w.bin_cnt : (unsigned*)nullptr,
-                               use_bins ? w.bins : (int*)nullptr, a.first_pad_chunk);
+                               use_bins ? w.bins : (int*)nullptr, a.first_pad_chunk, w.bin_cap);
         } else
         hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS),
                            chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, w.partials, a.nchunks, a.npad, n, a.first_pad_chunk, w.qmax,
@@ -1607,10 +1611,11 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
             if (use_bins) {
                 const size_t lds = (size_t)(d / 32) * 64 * sizeof(uint4);
 #define VFM_RESCAN_CHUNK(UH)                                                                                                  \
-    hipLaunchKernelGGL(match_rescan_chunk_kernel<UH>, dim3((unsigned)a.nchunks), dim3(256), lds, st, n, m,                      \
+    hipLaunchKernelGGL(match_rescan_chunk_kernel<UH>, dim3((unsigned)a.nchunks, (unsigned)((w.bin_cap + RESCAN_SLICE - 1) / RESCAN_SLICE)), \
+                       dim3(256), lds, st, n, m,                                                                                 \
                        i8_bounds(Q, B, true, records), (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, \
                        w.cand_cnt, w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, half ? 1 : 0, gate, guard, \
-                       L2Terms{nullptr, nullptr, 0.0f})
+                       L2Terms{nullptr, nullptr, 0.0f}, w.bin_cap)
                 switch (d / 32) {
                     case 8: VFM_RESCAN_CHUNK(8); break;
                     case 12: VFM_RESCAN_CHUNK(12); break;
@@ -1662,9 +1667,10 @@ int launch_i8_rescans(const SearchWs& w, const CoarseArgs& a, const Prepared& Q,
     if (use_bins) {
         const size_t lds = (size_t)(d / 32) * 64 * sizeof(uint4);
 #define VFM_RESCAN_CHUNK(UH)                                                                                                       \
-    hipLaunchKernelGGL(match_rescan_chunk_kernel<UH>, dim3((unsigned)a.nchunks), dim3(256), lds, st, n, m, ib, (const uint4*)Q.tiles8, \
+    hipLaunchKernelGGL(match_rescan_chunk_kernel<UH>, dim3((unsigned)a.nchunks, (unsigned)((w.bin_cap + RESCAN_SLICE - 1) / RESCAN_SLICE)), \
+                       dim3(256), lds, st, n, m, ib, (const uint4*)Q.tiles8,                                                        \
                        (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt, w.cand, w.cap, (const unsigned*)w.bin_cnt,     \
-                       (const int*)w.bins, 0, 0.0f, (const int*)nullptr, l2)
+                       (const int*)w.bins, 0, 0.0f, (const int*)nullptr, l2, w.bin_cap)
         switch (d / 32) {
             case 8: VFM_RESCAN_CHUNK(8); break;
             case 12: VFM_RESCAN_CHUNK(12); break;
@@ -1692,7 +1698,7 @@ int probe_half_select(const void* qprep, int64_t n, const void* bprep, int64_t m
     hipLaunchKernelGGL(match_select_half_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * 8), half_lds ? (size_t)a.nchunks * 12 : 0, st,
                        reinterpret_cast<const unsigned*>(w.partials), a.nchunks, n, Q.inv, i8_bounds(Q, B, true, VFM_RECORDS_HALF),
                        (const float*)Q.rest, (const float*)B.grest, gate, half_lds, w.cand_cnt, (unsigned*)nullptr, w.cap, w.fb_count,
-                       w.fb_list, 0, (unsigned*)nullptr, (int*)nullptr);
+                       w.fb_list, 0, (unsigned*)nullptr, (int*)nullptr, w.bin_cap);
     VFM_CHECK_LAUNCH("match_select_half_kernel(probe)");
     return VFM_OK;
 }

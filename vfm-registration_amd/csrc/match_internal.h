@@ -32,7 +32,14 @@ constexpr int CAND_CAP_MAX = 2048;  // candidate entries a query can hold = min(
 constexpr int REFINE_MIN = 3;     // queries with this many candidate entries (or a whole-chunk entry) go through the fp32 refinement
 constexpr int REFINE_MIN_I8 = 8;  // the same threshold for the row lists of the int8 pass (match_rescan_kernel)
 constexpr int REFINE_KEEP = 64;   // rows a query may keep after the refinement
-constexpr int RESCAN_BIN_CAP = 512;  // candidate queries a map chunk can collect for the chunk-major int8 rescan (the rest: query-major)
+// candidate queries a map chunk can collect for the chunk-major int8 rescan (the rest: query-major): sized per search from the
+// queries per chunk -- 128 per average query share, at least 1024 (C2: 1664; the reverse direction of a Euclidean search, 200 000
+// queries on 157 chunks: 65 536; round 2's fixed 512 sent such searches through the 48-KB-per-candidate query-major path)
+__host__ __device__ inline int rescan_bin_cap(int64_t npad, int64_t nchunks) {
+    int64_t c = (128 * npad / (nchunks > 0 ? nchunks : 1) + 63) / 64 * 64;
+    return (int)(c < 1024 ? 1024 : (c > 65536 ? 65536 : c));
+}
+constexpr int RESCAN_SLICE = 1024;   // bin entries one workgroup of match_rescan_chunk_kernel takes (grid.y slices a long bin)
 constexpr int RESCAN_BATCH = 64;     // ... of which match_rescan_chunk_kernel stages this many in LDS at a time
 // Half-width pass, device-side guard: a search whose bound leaves more than this many (query, chunk) pairs per query -- descriptors
 // that are all alike: every chunk survives -- does not rescan them (31 million 128-row rescans at C2: 171 ms) but falls through,
@@ -40,7 +47,7 @@ constexpr int RESCAN_BATCH = 64;     // ... of which match_rescan_chunk_kernel s
 // SearchWs::fb_count[7] is the flag (half_guard_kernel); the host policy (vfmreg/pipeline.py) leaves the mode on the same figure.
 constexpr int HALF_GUARD_PER_QUERY = 48;
 constexpr int HALF_GUARD_FLAG = 7;   // index into fb_count
-constexpr int FUSE_BIN_SATURATE = 8 * RESCAN_BIN_CAP;  // fused form: a chunk that collected this many survivors stops recording (and raises the flag)
+constexpr int FUSE_BIN_SATURATE_X = 8;  // fused form: a chunk that collected this many times its bin capacity stops recording (and raises the flag)
 constexpr int FILTER_LDS_ROWS = 1024;  // sparse fp16 records a query can hold (= SearchWs::rcap; match_filter_refine_kernel keeps them in LDS)
 constexpr int SPARSE_LREC_CAP = 1536;  // records a workgroup of the sparse coarse kernel buffers in LDS (12 KiB)
 constexpr float COARSE_OFFSET = 2.0f;   // accumulators start here: every coarse score is a
@@ -210,7 +217,8 @@ struct CoarseArgs {
     const float* qrest;     // [npad] |second half of the normalised query|, rounded up
     const float* grest;     // [nchunks] its maximum over the chunk's rows
     unsigned* bin_cnt;      // [nchunks], zeroed per search
-    int* bins;              // [nchunks][RESCAN_BIN_CAP]
+    int* bins;              // [nchunks][bin_cap]
+    int bin_cap;
     int* cand_cnt;          // [npad], zeroed per search (entries of the query's own list)
     unsigned* cand;         // [npad][cap]
     int cap;
@@ -385,7 +393,8 @@ struct SearchWs {
     int* fb_list;
     unsigned* qmax;
     unsigned* bin_cnt;  // int8 pass, best-score records: candidate queries per map chunk ...
-    int* bins;          // ... and the queries themselves, RESCAN_BIN_CAP per chunk (match_rescan_chunk_kernel)
+    int* bins;          // ... and the queries themselves, bin_cap per chunk (match_rescan_chunk_kernel)
+    int bin_cap;        // rescan_bin_cap(npad, chunks)
     size_t bytes;
 };
 
@@ -405,7 +414,8 @@ inline SearchWs carve_search(void* p, int64_t n, int64_t m) {
     w.qmax = c.take<unsigned>((size_t)npad);
     w.rec_cnt = c.take<unsigned>((size_t)npad);
     w.bin_cnt = c.take<unsigned>((size_t)((mpad / CHUNK_ROWS + 63) / 64 * 64));
-    w.bins = c.take<int>((size_t)(mpad / CHUNK_ROWS) * RESCAN_BIN_CAP);
+    w.bin_cap = rescan_bin_cap(npad, mpad / CHUNK_ROWS);
+    w.bins = c.take<int>((size_t)(mpad / CHUNK_ROWS) * (size_t)w.bin_cap);
     w.rcap = FILTER_LDS_ROWS;
     w.rec = c.take<uint2>((size_t)npad * (size_t)w.rcap);
     w.bytes = c.used();

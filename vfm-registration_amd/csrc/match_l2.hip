@@ -297,7 +297,8 @@ constexpr int SELECT_L2_LCAND = 4096;
 __global__ __launch_bounds__(64 * SELECT_L2_WAVES) void match_select_l2_kernel(
     const unsigned* __restrict__ best, int nchunks, int64_t n, I8Bounds ib, const float* __restrict__ qn, const float2* __restrict__ cn,
     float slack, int first_pad_chunk, int chunk_lds, unsigned* __restrict__ qmax, int* __restrict__ cand_cnt, unsigned* __restrict__ cand,
-    int cap, int* __restrict__ fb_count, int* __restrict__ fb_list, unsigned* __restrict__ bin_cnt, int* __restrict__ bins) {
+    int cap, int* __restrict__ fb_count, int* __restrict__ fb_list, unsigned* __restrict__ bin_cnt, int* __restrict__ bins,
+    int bin_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char select_smem[];  // per chunk: (step, max E, lo, hi)
     __shared__ int lcnt[32], lov[32];
     __shared__ unsigned llow[32];   // float_key of the query's lower bound of its best Euclidean score
@@ -414,8 +415,8 @@ __global__ __launch_bounds__(64 * SELECT_L2_WAVES) void match_select_l2_kernel(
             int slot = -1;
             if (bins) {  // chunk-major rescan: the query joins the chunk's bin; a full bin leaves the entry with the query
                 const unsigned seen = __hip_atomic_load(&bin_cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned pos = seen >= (unsigned)RESCAN_BIN_CAP ? seen : atomicAdd(&bin_cnt[c], 1u);
-                if (pos < (unsigned)RESCAN_BIN_CAP) bins[(size_t)c * RESCAN_BIN_CAP + pos] = (int)q;
+                const unsigned pos = seen >= (unsigned)bin_cap ? seen : atomicAdd(&bin_cnt[c], 1u);
+                if (pos < (unsigned)bin_cap) bins[(size_t)c * bin_cap + pos] = (int)q;
                 else slot = atomicAdd(&lov[qq], 1);
             } else {
                 slot = atomicAdd(&lov[qq], 1);
@@ -709,7 +710,8 @@ inline void carve_sorted(VfmCarver& c, L2SortedOperand& o, int64_t rows, int d) 
     o.lohi = c.take<float2>((size_t)(rp / CHUNK_ROWS));
     o.prep = c.take<unsigned char>(vfm_match_prepared_bytes(rows, d));
 }
-inline L2I8Ws carve_l2i8(void* p, int64_t n, int64_t m, int d, bool reverse) {
+// reverse: 0 = forward direction only, 1 = + the reverse direction restricted to the n matched rows (vfm_match_mutual_pairs)
+inline L2I8Ws carve_l2i8(void* p, int64_t n, int64_t m, int d, int reverse) {
     VfmCarver c(p);
     L2I8Ws w;
     w.max_bits = c.take<unsigned>(64);
@@ -723,12 +725,13 @@ inline L2I8Ws carve_l2i8(void* p, int64_t n, int64_t m, int d, bool reverse) {
     w.nn_ab = c.take<int64_t>((size_t)n);
     w.nn_rev = nullptr;
     if (reverse) {
+        const int64_t nq = n;   // queries of the reverse search: the matched map rows
         carve_sorted(c, w.A, n, d);
         w.qperm = c.take<int>((size_t)n);
         w.ss_bq = c.take<float>((size_t)n);
-        w.qn_bq = c.take<float>((size_t)rows_padded(n));
-        w.prep_bq = c.take<unsigned char>(vfm_match_prepared_bytes(n, d));
-        w.search_r = c.take<unsigned char>(carve_search(nullptr, n, n).bytes);
+        w.qn_bq = c.take<float>((size_t)rows_padded(nq));
+        w.prep_bq = c.take<unsigned char>(vfm_match_prepared_bytes(nq, d));
+        w.search_r = c.take<unsigned char>(carve_search(nullptr, nq, n).bytes);
         w.nn_rev = c.take<int64_t>((size_t)n);
     }
     w.bytes = c.used();
@@ -766,7 +769,7 @@ int l2i8_search(const float* qx, const int* qperm, int64_t n, const float* qn, v
     hipLaunchKernelGGL(match_select_l2_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * SELECT_L2_WAVES),
                        chunk_lds ? (size_t)a.nchunks * sizeof(float4) : 0, st, reinterpret_cast<const unsigned*>(w.partials), a.nchunks, n,
                        a.ib, qn, (const float2*)B.lohi, slack, a.first_pad_chunk, chunk_lds, w.qmax, w.cand_cnt, w.cand, w.cap, w.fb_count,
-                       w.fb_list, use_bins ? w.bin_cnt : (unsigned*)nullptr, use_bins ? w.bins : (int*)nullptr);
+                       w.fb_list, use_bins ? w.bin_cnt : (unsigned*)nullptr, use_bins ? w.bins : (int*)nullptr, w.bin_cap);
     VFM_CHECK_LAUNCH("match_select_l2_kernel");
     if (int rc = launch_i8_rescans(w, a, Q, P, n, m, d, use_bins, L2Terms{qn, (const float*)B.bn, slack}, st)) return rc;
     hipLaunchKernelGGL(l2i8_rescore_kernel, dim3((unsigned)((n + L2R_QUERIES - 1) / L2R_QUERIES)), dim3(256), 0, st, qx, bx, n, m, d,
@@ -802,12 +805,12 @@ VFM_EXPORT size_t vfm_match_mutual_l2_workspace_bytes(int64_t n, int64_t m, int 
     if (prec_mode == VFM_MATCH_EXACT || l2_padded_k(d) == 0 || n <= 0 || m <= 0) return 256;
     // int8-capable widths: the forward direction runs the int8 pass (its workspace sits behind the fp16 path's, which still
     // serves the full reverse direction nn_ba)
-    return carve_l2(nullptr, n, m, d, mutual != 0).bytes + (l2_i8(d) ? carve_l2i8(nullptr, n, m, d, false).bytes : 0);
+    return carve_l2(nullptr, n, m, d, mutual != 0).bytes + (l2_i8(d) ? carve_l2i8(nullptr, n, m, d, 0).bytes : 0);
 }
 
 VFM_EXPORT size_t vfm_match_mutual_pairs_workspace_bytes(int64_t n, int64_t m, int d) {
     if (n <= 0 || m <= 0 || d <= 0) return 256;
-    if (l2_i8(d)) return carve_l2i8(nullptr, n, m, d, true).bytes;
+    if (l2_i8(d)) return carve_l2i8(nullptr, n, m, d, 1).bytes;
     // other widths: nn_ab / nn_ba by vfm_match_mutual_l2 (FAST where it exists) + the filter
     return vfm_align_up((size_t)n * sizeof(int64_t), 256) * 2 + vfm_align_up((size_t)m * sizeof(int64_t), 256) + 512 +
            vfm_match_mutual_l2_workspace_bytes(n, m, d, l2_padded_k(d) ? VFM_MATCH_FAST : VFM_MATCH_EXACT, 1);
@@ -838,7 +841,7 @@ VFM_EXPORT int vfm_match_mutual_pairs(const float* a, int64_t n, const float* b,
         if (nn_ab_out) VFM_CHECK_HIP(hipMemcpyAsync(nn_ab_out, nn_ab, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
         return VFM_OK;
     }
-    L2I8Ws w = carve_l2i8(ws, n, m, d, true);
+    L2I8Ws w = carve_l2i8(ws, n, m, d, 1);
     int64_t* nn_ab = nn_ab_out ? nn_ab_out : w.nn_ab;
     if (int rc = l2i8_forward(a, n, b, m, d, w, nn_ab, d2_ab_out, st)) return rc;
     // reverse, restricted to what the filter reads: queries = the matched map rows b[nn_ab[i]], map = a sorted by norm
@@ -886,8 +889,13 @@ VFM_EXPORT int vfm_match_mutual_l2(const float* a, int64_t n, const float* b, in
     hipLaunchKernelGGL(l2_maxnorm_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, a, n, d, w.max_bits);
     hipLaunchKernelGGL(l2_maxnorm_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, b, m, d, w.max_bits);
     VFM_CHECK_LAUNCH("l2_maxnorm_kernel");
-    if (l2_i8(d)) {   // forward direction on the int8 pass (its own workspace behind the fp16 path's)
-        L2I8Ws w8 = carve_l2i8(static_cast<unsigned char*>(ws) + w.bytes, n, m, d, false);
+    if (l2_i8(d)) {
+        // the a -> b direction on the int8 pass (its workspace sits behind the fp16 path's).  The full b -> a direction stays on
+        // the fp16 pass: its queries are mostly map rows WITHOUT a near neighbour in the scan, and the int8 bounds -- 16x wider than
+        // the fp16 window -- leave each of them ~20 candidate chunks on a 157-chunk scan (measured at 20 000 x 200 000: 12.3 ms
+        // both ways on int8 against 11.8 with the fp16 reverse; 247 against 35 ms at d = 768).  find_correspondences' mutual
+        // filter needs the reverse direction only at the matched rows: vfm_match_mutual_pairs runs both directions on int8.
+        L2I8Ws w8 = carve_l2i8(static_cast<unsigned char*>(ws) + w.bytes, n, m, d, 0);
         if (int rc = l2i8_forward(a, n, b, m, d, w8, nn_ab, d2_ab, st)) return rc;
     } else {
         if (int rc = l2_prepare(a, n, d, kp, w.max_bits, 0, w.prep[0], st)) return rc;
