@@ -536,7 +536,8 @@ def main():
                         + ("packed top-2 records" if mode_top2 else "one best-score record per (query, chunk)") + ")") if i8
                   else "match_coarse_pipe_kernel<24, true> (fp16 32x32x16 MFMA, sparse row-level records)")
         traffic, traffic_src = None, None  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
-        for name in ((("r02_pmc_match_coarse_i8half.json",) if half else ("r02_pmc_match_coarse_i8.json",)) if i8
+        for name in ((("r03_pmc_match_coarse_i8half.json", "r02_pmc_match_coarse_i8half.json") if half
+                      else ("r03_pmc_match_coarse_i8.json", "r02_pmc_match_coarse_i8.json")) if i8
                      else ("r02_pmc_match_coarse_f16.json", "r01_pmc_match_coarse.json")):
             pmc = ROOT / "profiles" / name
             if pmc.exists() and (n, m, d) == (N_SCAN, N_MAP, DIM):

@@ -17,7 +17,7 @@ from oracle import oracle as orc  # noqa: E402
 from vfmreg import ops  # noqa: E402
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-rng = np.random.default_rng(12345)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 bad = 0
 for t in range(trials):
     d = int(rng.choice([128, 256, 384]))
