@@ -114,7 +114,7 @@ Pose delta vs the oracle on identical inputs (`extra.pose_delta_vs_oracle`): {ex
 The same pipeline away from the favourable case (VERDICT r2 item 2), same process, same box:
 
 - {variant('C2_full_width')} -- `coarse="int8"` pinned: every column in the coarse pass, nothing depends on how the descriptors prune
-- {variant('C2_sustained')} -- 300 steps instead of 20 (the first ~15 launches after a synchronise run slower)
+- {variant('C2_sustained')} -- {ex.get('C2_sustained', {}).get('steps', '?')} steps instead of 20 (the first ~15 launches after a synchronise run slower)
 - {variant('C2_lifted')} -- map descriptors lifted from overlapping patch grids (near-duplicates), policy by feedback
 - `extra.A6_mutual_l2`: {json.dumps(a6)[:600]}
 - `extra.C3`: {ex['C3']['ms_end_to_end']:.2f} ms end to end (ViT {ex['C3']['ms_vit']:.3f}, project + lift {ex['C3']['ms_project_lift']:.3f}, registration {ex['C3']['ms_registration']:.2f}; ViT at {ex['C3']['vit_roofline']['frac']:.3f} of the fp16 MFMA peak)
