@@ -46,6 +46,7 @@ for p in (ROOT, ROOT / "vfm-registration_amd"):
 N_SCAN, N_MAP, DIM, RANSAC_ITERS = 20000, 200000, 384, 50000
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/fp16 MFMA ~2.5 PFLOP/s
 MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 MFMA: 2 x the fp16 rate (same table: "I8 ~2x bf16 rate (2xK)", ubench >= 4404)
+MFMA_F6_PEAK_TFLOPS = 10000.0  # dense fp6 / fp4 scaled MFMA (same table: "~10 PF dense", FP6 ubench >= 7287; tools/probe/mx6_probe.hip: 6400)
 
 
 def cpu_baseline(p, iters=RANSAC_ITERS, T_gpu=None):
@@ -257,6 +258,8 @@ def timed_loop(lib, pipe, pairs, steps, warmup, settle=0):
 def pass_name(pipe):
     if not pipe.use_i8:
         return "fp16"
+    if getattr(pipe, "mx6", False):
+        return "fp6 (MX e2m3), full width, best-score records (VFM_RECORDS_MX6)"
     return "int8, half-width (VFM_RECORDS_HALF)" if pipe.half else ("int8, packed top-2 records" if pipe.top2 else "int8, best-score records")
 
 
@@ -264,7 +267,7 @@ def roofline_of(pipe, n, m, d, coarse_ms):
     """MFMA roofline entry of the coarse kernel a pipeline ran: operations AS LAUNCHED over the mean launch duration."""
     kcols = d // 2 if (pipe.use_i8 and pipe.half) else d
     flops = 2.0 * n * m * kcols
-    peak = MFMA_I8_PEAK_TOPS if pipe.use_i8 else MFMA_F16_PEAK_TFLOPS
+    peak = MFMA_F6_PEAK_TFLOPS if getattr(pipe, "mx6", False) else (MFMA_I8_PEAK_TOPS if pipe.use_i8 else MFMA_F16_PEAK_TFLOPS)
     return {"bound": "mfma", "flops_per_launch": flops, "avg_launch_ms": coarse_ms, "achieved": flops / (coarse_ms * 1e-3) / 1e12,
             "peak": peak, "unit": "TFLOP/s", "frac": flops / (coarse_ms * 1e-3) / 1e12 / peak,
             "columns_multiplied": kcols, "all_pairs_product_flops": 2.0 * n * m * d}
@@ -293,6 +296,13 @@ def c2_variants(dev, lib, pairs, steps, warmup, iters, streams):
     out["C2_full_width"] = {"workload": "C2, D.2 pairs, coarse pass pinned to the full-width int8 kernel (best-score records): 2 N M D per launch",
                             "value": v, "unit": "registrations/s", "steps": steps, "ms_per_step": msps, "coarse_pass": pass_name(pipe),
                             "roofline": roofline_of(pipe, n, m, d, cms)}
+    del pipe
+    pipe = build("mx6")
+    v, msps, cms, _ = timed_loop(lib, pipe, pairs, steps, warmup)
+    out["C2_full_width_mx6"] = {"workload": "C2, D.2 pairs, coarse pass pinned to the full-width fp6 kernel (MX e2m3 on the scaled MFMA, best-score "
+                                            "records; operands prepared with the fp6 image as well): 2 N M D per launch",
+                                "value": v, "unit": "registrations/s", "steps": steps, "ms_per_step": msps, "coarse_pass": pass_name(pipe),
+                                "roofline": roofline_of(pipe, n, m, d, cms)}
     del pipe
     pipe = build("auto")
     v, msps, cms, _ = timed_loop(lib, pipe, pairs, 200, warmup, settle=4)

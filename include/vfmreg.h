@@ -115,6 +115,9 @@ int vfm_match_prepare2_gated(const float *x1, int64_t rows1, void *prepared1, co
 #define VFM_PREPARE_DEFAULT 0
 #define VFM_PREPARE_PERSISTENT 1
 #define VFM_PREPARE_INTERLEAVED 2
+/*   VFM_PREPARE_MX6          flag, or-ed into `schedule`: write the fp6 image as well (d = 256 / 384; what VFM_RECORDS_MX6
+ *                            searches read; a quarter more bytes written, ~25 % more preparation time) */
+#define VFM_PREPARE_MX6 8
 int vfm_match_prepare2_gated_p(const float *x1, int64_t rows1, void *prepared1, const float *x2, int64_t rows2,
                                void *prepared2, int d, int schedule, vfm_stream_t stream);
 int vfm_match_search_coarse_gated(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
@@ -159,6 +162,15 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
  *                     d = 256 / 384 with more than 2048 queries and at least four queries per map chunk; elsewhere it behaves
  *                     as VFM_RECORDS_HALF. */
 #define VFM_RECORDS_HALF_FUSED 4
+/*   VFM_RECORDS_MX6   the coarse pass over ALL d columns in microscaled fp6 (OCP MX, e2m3 elements, one power-of-two scale per
+ *                     32 columns) on gfx950's scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4: twice the int8 instruction's
+ *                     operations per cycle), best-score records.  The bounds are the int8 pass's with the fp6 image's MEASURED
+ *                     residual norms in place of the int8 ones (about 3x wider: ~0.06 in cosine for unit Gaussian rows), so
+ *                     more candidate chunks reach the int8 rescan, which -- like the fp32 refinement and the fp64 decision
+ *                     behind it -- is unchanged: same answers.  Unlike VFM_RECORDS_HALF nothing here depends on how the
+ *                     descriptors' energy is spread over the columns.  Needs operands prepared with VFM_PREPARE_MX6;
+ *                     exists for d = 256 / 384 with more than 2048 queries, elsewhere it behaves as VFM_RECORDS_BEST. */
+#define VFM_RECORDS_MX6 5
 int vfm_match_search_coarse_gated_r(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
                                     int d, void *ws, size_t ws_bytes, int records, vfm_stream_t stream);
 /* _coarse_gated_r with the gate of the search (needed by VFM_RECORDS_HALF_FUSED; ignored by the other kinds) */

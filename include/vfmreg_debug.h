@@ -10,7 +10,7 @@
  *   - vfm_debug_set_* PROCESS-GLOBAL A/B switches: kernel variants and launch shapes; every setting returns the same
  *                     results (tests run the stress inputs through them), only the time changes.  Not thread-safe against
  *                     concurrent searches; a product integration never calls them.
- *   - vfm_debug_match_stats / vfm_debug_i8_rows  read-backs for tests; they synchronise the device.
+ *   - vfm_debug_match_stats / vfm_debug_i8_rows / vfm_debug_mx6_rows  read-backs for tests; they synchronise the device.
  */
 #ifndef VFMREG_DEBUG_H
 #define VFMREG_DEBUG_H
@@ -53,6 +53,10 @@ int vfm_debug_set_prep_grid(int workgroups);
  * quantisation step of its 128-row group, its residual norm E and the group's maximum E.  Synchronises the device. */
 int vfm_debug_i8_rows(const void *prepared, int64_t rows, int d, int8_t *q8_host, float *step_host,
                       float *err_host, float *gerr_host);
+/* tests: the fp6 image of an operand prepared with VFM_PREPARE_MX6 (d = 256, 384), dequantised on the host -- v6_host[rows][d]
+ * (code value x block scale), and per row the image's residual norm E (arithmetic slack included) and its group's maximum.
+ * Synchronises the device. */
+int vfm_debug_mx6_rows(const void *prepared, int64_t rows, int d, float *v6_host, float *err_host, float *gerr_host);
 /* A/B: the gated family takes the int8 pass for more than this many query rows (default 0: always) */
 int vfm_debug_set_i8_min_queries(int n);
 /* A/B: 1 = RANSAC scores every hypothesis in fp64 (skips the bounds) */

@@ -1,0 +1,174 @@
+"""The fp6 coarse pass (VFM_RECORDS_MX6; d = 256 / 384, more than 2048 queries): the microscaled e2m3 image of
+prep_chunk_kernel against its arithmetic definition, the measured residual norms, the bound they give pair by pair, and
+oracle-identical answers / the gate contract of the searches that run on it."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle as orc  # noqa: E402
+from vfmreg import _lib, synth  # noqa: E402
+from vfmreg.pipeline import RegistrationPipeline  # noqa: E402
+
+from .test_gpu_int8 import _gate_contract, _heavy_tailed  # noqa: E402
+
+PREPARE_MX6 = 8
+RECORDS_MX6 = 5
+E2M3 = np.array(sorted({(mm / 8 if e == 0 else (1 + mm / 8) * 2 ** (e - 1)) for e in range(4) for mm in range(8)}))
+
+
+def mx6_image(v):
+    """The definition of the fp6 image (csrc/match_prep.hip): the fp32-normalised rows rounded to fp16; per 32 columns the scale
+    2^e with max / 2^e <= 7.75 -- for max = (1 + f) 2^x: e = x - 2 if 1 + f <= 1.9375 else x - 1, never above 0; elements rounded
+    to the nearest e2m3 value (ties to even on the binade's grid, saturating at 7.5).  float64 on exactly representable values."""
+    n, d = v.shape
+    b = v.astype(np.float16).reshape(n, d // 32, 32).astype(np.float64)
+    amax = np.abs(b).max(-1, keepdims=True)
+    x = np.floor(np.log2(np.where(amax > 0, amax, 1.0)))
+    x = np.maximum(x, -14.0)                                   # fp16 denormals: exponent field 0 reads as 2^-15 below
+    frac = np.where(amax >= 2.0 ** -14, amax / 2.0 ** x, 0.0)
+    e = np.where(amax >= 2.0 ** -14, np.where(frac <= 1.9375, x - 2, x - 1), -17.0)
+    e = np.minimum(e, 0)
+    s = 2.0 ** e
+    a = np.abs(b) / s
+    sh = np.where(a < 2, 3, np.where(a < 4, 2, 1))
+    k = np.minimum(np.rint(a * 2.0 ** sh), np.where(sh == 1, 15, 16))
+    return (np.sign(b) * k / 2.0 ** sh * s).reshape(n, d)
+
+
+def _prepare(b, q, flags=PREPARE_MX6):
+    lib = _lib.load()
+    n, d = q.shape
+    m = b.shape[0]
+    qb = torch.empty(lib.vfm_match_prepared_bytes(n, d), dtype=torch.uint8, device="cuda")
+    bb = torch.empty(lib.vfm_match_prepared_bytes(m, d), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.vfm_match_prepare2_gated_p(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, flags,
+                                              torch.cuda.current_stream().cuda_stream))
+    return qb, bb
+
+
+def _mx6_rows(buf, rows, d):
+    lib = _lib.load()
+    v6 = np.empty((rows, d), np.float32)
+    err, gerr = np.empty(rows, np.float32), np.empty(rows, np.float32)
+    _lib.check(lib.vfm_debug_mx6_rows(buf.data_ptr(), rows, d, v6.ctypes.data, err.ctypes.data, gerr.ctypes.data))
+    return v6, err, gerr
+
+
+def _search(q, b, gate, records, flags=PREPARE_MX6):
+    lib = _lib.load()
+    n, d = q.shape
+    m = b.shape[0]
+    qb, bb = _prepare(b, q, flags)
+    ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=torch.uint8, device="cuda")
+    idx = torch.empty(n, dtype=torch.int64, device="cuda")
+    sim = torch.empty(n, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, gate, st))
+    _lib.check(lib.vfm_match_search_finish_gated_r(q.data_ptr(), qb.data_ptr(), n, b.data_ptr(), bb.data_ptr(), m, d, idx.data_ptr(),
+                                                   sim.data_ptr(), ws.data_ptr(), ws.numel(), gate, records, st))
+    torch.cuda.synchronize()
+    return idx, sim
+
+
+@pytest.mark.parametrize("d,n,m", [(384, 2500, 9000), (256, 3000, 777)])
+def test_mx6_image_is_the_e2m3_quantisation_of_the_fp16_rows_and_its_residuals_are_measured(d, n, m):
+    """Every element of the fp6 image equals the definition above on the oracle's normalised rows (bit-identical to the
+    library's); E of a row is at least the true |v - image|_2 (fp64) and at most that + the declared roundings; the group value is the
+    maximum over its 128 rows; heavy-tailed rows, one-hot rows, tiny norms, zero rows included."""
+    rng = np.random.default_rng(d + m)
+    b = _heavy_tailed(rng, m, d)
+    q = rng.standard_normal((n, d)).astype(np.float32)
+    qb, bb = _prepare(torch.from_numpy(b).cuda(), torch.from_numpy(q).cuda())
+    for x, buf, rows in ((b, bb, m), (q, qb, n)):
+        xn, _ = orc.l2norm_rows(x)
+        v6, err, gerr = _mx6_rows(buf, rows, d)
+        np.testing.assert_array_equal(v6.astype(np.float64), mx6_image(xn))
+        true = np.linalg.norm(xn.astype(np.float64) - v6.astype(np.float64), axis=1)
+        assert (err >= true).all()
+        assert (err <= true * 1.0003 + 1.1e-3).all()   # the fp16 rounding is bounded (4.9e-4), not measured, and sits inside `true` too
+        gmax = np.array([err[g:g + 128].max() for g in range(0, rows, 128)])
+        np.testing.assert_array_equal(gerr[::128], gmax)
+
+
+def test_mx6_bound_holds_pair_by_pair():
+    """| cos(a, b) - image_a . image_b | <= (1 + 2^-13 + E_b) E_a + (1 + 2^-13) E_b for sampled pairs (fp64), and for unit Gaussian
+    rows it is the ~0.06 the header states."""
+    d, n, m = 384, 2304, 4096
+    rng = np.random.default_rng(7)
+    b = rng.standard_normal((m, d)).astype(np.float32)
+    q = b[rng.integers(0, m, n)] + 0.3 * rng.standard_normal((n, d)).astype(np.float32)
+    qb, bb = _prepare(torch.from_numpy(b).cuda(), torch.from_numpy(q).cuda())
+    qn, _ = orc.l2norm_rows(q)
+    bn, _ = orc.l2norm_rows(b)
+    q6, eq, _ = _mx6_rows(qb, n, d)
+    b6, eb, _ = _mx6_rows(bb, m, d)
+    ii, jj = rng.integers(0, n, 20000), rng.integers(0, m, 20000)
+    exact = np.einsum("ij,ij->i", qn[ii].astype(np.float64), bn[jj].astype(np.float64))
+    coarse = np.einsum("ij,ij->i", q6[ii].astype(np.float64), b6[jj].astype(np.float64))
+    bound = (1.0 + 2.0 ** -13 + eb[jj]) * eq[ii] + (1.0 + 2.0 ** -13) * eb[jj]
+    assert (np.abs(exact - coarse) <= bound).all()
+    assert 0.04 < bound.mean() < 0.075
+
+
+@pytest.mark.parametrize("d,n,m", [(384, 2500, 9000), (256, 3000, 5003), (384, 2100, 130), (384, 300, 20011), (512, 2300, 4100)])
+def test_mx6_pass_gives_the_oracle_answers_and_keeps_the_gate_contract(d, n, m):
+    """VFM_RECORDS_MX6 on planted matches, heavy-tailed rows, rows that are all alike, exact duplicates, zero rows and
+    rows of tiny norm: every resolved query has the oracle's index and similarity, every unresolved one is below the gate in the
+    oracle, with the gate at 0.8 and switched off.  (384, 300, .) and d = 512 have no fp6 kernel: the call behaves as best-score
+    records there, with or without the fp6 image.)"""
+    rng = np.random.default_rng(d + n)
+    gate = float(np.nextafter(np.float32(0.8), np.float32(-np.inf)))
+    cases = {}
+    b = rng.standard_normal((m, d)).astype(np.float32)
+    q = b[rng.integers(0, m, n)] + 0.3 * rng.standard_normal((n, d)).astype(np.float32)
+    q[::3] = rng.standard_normal((len(q[::3]), d)).astype(np.float32)
+    cases["planted"] = (q, b)
+    cases["heavy-tailed"] = (_heavy_tailed(rng, n, d), _heavy_tailed(rng, m, d))
+    base = rng.standard_normal((1, d)).astype(np.float32)
+    cases["all alike"] = (base + 0.2 * rng.standard_normal((n, d)).astype(np.float32), base + 0.2 * rng.standard_normal((m, d)).astype(np.float32))
+    few = rng.standard_normal((16, d)).astype(np.float32)
+    cases["duplicates"] = (few[rng.integers(0, 16, n)] + 0.0, few[rng.integers(0, 16, m)] + 0.0)
+    b3, q3 = b.copy(), q.copy()
+    b3[100 % m] = 0.0
+    b3[(m // 2):(m // 2) + 3] = 0.0
+    q3[12] = 0.0
+    q3[13] = 1e-18 * q3[13]
+    cases["zero and tiny rows"] = (q3, b3)
+    for name, (qq, bb) in cases.items():
+        qn, _ = orc.l2norm_rows(qq)
+        bn, _ = orc.l2norm_rows(bb)
+        ridx, rsim = orc.match_ip_top1(qn, bn)
+        qd, bd = torch.from_numpy(qq).cuda(), torch.from_numpy(bb).cuda()
+        for g in (gate, float("-inf")):
+            idx, sim = _search(qd, bd, g, RECORDS_MX6)
+            solved = _gate_contract(idx, sim, ridx, rsim, g)
+            if g == float("-inf"):
+                assert solved.all(), name
+            assert solved[rsim >= 0.8].all(), name
+
+
+def test_mx6_pipeline_mode_equals_the_oracle_registration():
+    """RegistrationPipeline(coarse="mx6") -- prepare with the fp6 image, fp6 coarse pass, int8 rescans, fp64 decision, RANSAC --
+    against the oracle's registration of the same pair: correspondences, pose, inlier mask, winner; serial and overlapped."""
+    n, m, d = 3000, 20000, 384
+    p = synth.make_pair_device(n, m, d, seed=11)
+    qn, _ = orc.l2norm_rows(p["q_desc"].cpu().numpy())
+    bn, _ = orc.l2norm_rows(p["b_desc"].cpu().numpy())
+    ridx, rsim = orc.match_ip_top1(qn, bn)
+    keep = ~(rsim.astype(np.float64) < 0.8)
+    corres = np.stack([np.nonzero(keep)[0], ridx[keep]], 1).astype(np.int32)
+    ref = orc.ransac_corr(p["q_xyz"].cpu().numpy(), p["b_xyz"].cpu().numpy(), corres, 10000.0, 2000, seed=42)
+    for overlap in (False, True):
+        pipe = RegistrationPipeline(n, m, d, n_iter=2000, overlap_ransac=overlap, overlap_prepare=overlap, solve_streams=2, coarse="mx6")
+        for _ in range(3):
+            out = pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        c = int(out["count"].item())
+        assert c == len(corres)
+        np.testing.assert_array_equal(out["corres"].cpu().numpy()[:c], corres)
+        np.testing.assert_array_equal(out["T"].cpu().numpy(), ref.transformation)
+        assert int(out["best_hyp"].item()) == ref.best_hyp
+        np.testing.assert_array_equal(out["mask"].cpu().numpy()[:c], ref.inlier_mask[:c])

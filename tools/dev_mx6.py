@@ -1,0 +1,119 @@
+#!/usr/bin/env python
+"""Development check of the fp6 coarse pass (VFM_RECORDS_MX6): the image of prep_chunk_kernel<., ., true> against a numpy
+restatement of MX e2m3 quantisation, the measured residual norms, the searches' answers against best-score records, and the
+coarse kernel's time.   python tools/dev_mx6.py [n m d]"""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "vfm-registration_amd"))
+from vfmreg import _lib, synth  # noqa: E402
+
+lib = _lib.load()
+MX6 = 8
+GRID = np.array(sorted({(m / 8 if e == 0 else (1 + m / 8) * 2 ** (e - 1)) for e in range(4) for m in range(8)}), dtype=np.float64)
+
+
+def mx6_numpy(v):
+    """dequantised MX e2m3 image of the fp16 copy of fp32-normalised rows v (float64 arithmetic on exactly representable
+    quantities)"""
+    n, d = v.shape
+    b = v.astype(np.float16).reshape(n, d // 32, 32).astype(np.float64)
+    amax = np.abs(b).max(-1, keepdims=True)
+    with np.errstate(divide="ignore"):
+        x = np.floor(np.log2(np.where(amax > 0, amax, 1.0)))
+    frac = np.where(amax > 0, amax / 2.0 ** x, 1.0)
+    e = np.where(frac <= 1.9375, x - 2, x - 1)
+    e = np.clip(np.where(amax > 0, e, -17), -127, 0)   # (an all-zero block: fp16 exponent field 0 -> e = -15 - 2)
+    s = 2.0 ** e
+    a = np.abs(b) / s
+    sh = np.where(a < 2, 3, np.where(a < 4, 2, 1))
+    k = np.rint(a * 2.0 ** sh)
+    k = np.minimum(k, np.where(sh == 1, 15, 16))
+    return (np.sign(b) * k / 2.0 ** sh * s).reshape(n, d)
+
+
+def prepare(b, q, flags):
+    n, d = q.shape
+    m = b.shape[0]
+    qb = torch.empty(lib.vfm_match_prepared_bytes(n, d), dtype=torch.uint8, device="cuda")
+    bb = torch.empty(lib.vfm_match_prepared_bytes(m, d), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.vfm_match_prepare2_gated_p(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, flags, st))
+    return qb, bb
+
+
+def search(q, b, qb, bb, gate, records, time_coarse=False):
+    n, d = q.shape
+    m = b.shape[0]
+    ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=torch.uint8, device="cuda")
+    idx = torch.empty(n, dtype=torch.int64, device="cuda")
+    sim = torch.empty(n, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record()
+    _lib.check(lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, gate, st))
+    e1.record()
+    _lib.check(lib.vfm_match_search_finish_gated_r(q.data_ptr(), qb.data_ptr(), n, b.data_ptr(), bb.data_ptr(), m, d, idx.data_ptr(),
+                                                   sim.data_ptr(), ws.data_ptr(), ws.numel(), gate, records, st))
+    e2.record()
+    torch.cuda.synchronize()
+    st64 = (C.c_int32 * 64)()
+    _lib.check(lib.vfm_debug_match_stats(ws.data_ptr(), n, m, C.cast(st64, C.c_void_p)))
+    return idx, sim, e0.elapsed_time(e1), e1.elapsed_time(e2), list(st64)
+
+
+def main():
+    n, m, d = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (20000, 200000, 384)
+    gate = float(np.nextafter(np.float32(0.8), np.float32(-np.inf)))
+    # 1. the image
+    p = synth.make_pair_device(3000, 9000, d, seed=5)
+    qb, bb = prepare(p["b_desc"], p["q_desc"], MX6)
+    rows = 9000
+    v6 = np.empty((rows, d), np.float32)
+    err = np.empty(rows, np.float32)
+    gerr = np.empty(rows, np.float32)
+    _lib.check(lib.vfm_debug_mx6_rows(bb.data_ptr(), rows, d, v6.ctypes.data, err.ctypes.data, gerr.ctypes.data))
+    bn = torch.nn.functional.normalize(p["b_desc"], dim=1).cpu().numpy()   # (the library's own 1 / |row| differs in the last bit at most)
+    ref = mx6_numpy(bn)
+    bad = np.abs(v6.astype(np.float64) - ref) > 1e-7
+    print(f"image: {bad.sum()} of {bad.size} elements differ from the numpy restatement (rows with a differing element: {bad.any(1).sum()})")
+    e_true = np.linalg.norm(bn.astype(np.float64) - v6.astype(np.float64), axis=1)
+    print(f"E: measured {err.mean():.5f} mean (numpy {e_true.mean():.5f}); min(err - true) = {(err - e_true).min():.2e} (must be > 0); group max ok: "
+          f"{bool((gerr + 1e-9 >= err).all())}")
+    for flags in (0, MX6, 0, MX6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pp = synth.make_pair_device(n, m, d, seed=42)
+        prepare(pp["b_desc"], pp["q_desc"], flags)
+        e0.record()
+        for _ in range(10):
+            prepare(pp["b_desc"], pp["q_desc"], flags)
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"prepare2_gated_p flags {flags}: {e0.elapsed_time(e1) / 10:.3f} ms (incl. the workspace allocation of the wrapper)")
+    # 2. answers and time
+    for name, pair in (("D.2", synth.make_pair_device(n, m, d, seed=42)),
+                       ("lifted", synth.make_lifted_pair_device(n, m, d, seed=42, view_noise=0.1)),
+                       ("lifted + common", synth.make_lifted_pair_device(n, m, d, seed=42, view_noise=0.1, common=1.0))):
+        q, b = pair["q_desc"], pair["b_desc"]
+        qb, bb = prepare(b, q, MX6)
+        res = {}
+        for rec in (0, 5, 0, 5, 1, 3):
+            for _ in range(3):
+                out = search(q, b, qb, bb, gate, rec)
+            res[rec] = out
+        i0, s0 = res[0][0], res[0][1]
+        for rec in (5, 1, 3):
+            i, s = res[rec][0], res[rec][1]
+            same = bool((i == i0).all() and (s == s0).all())
+            print(f"{name:16s} records {rec}: coarse {res[rec][2]:.3f} ms finish {res[rec][3]:.3f} ms (records 0: {res[0][2]:.3f} + {res[0][3]:.3f}); "
+                  f"same answers as records 0: {same}; rescanned (query, chunk) pairs per query: {res[rec][4][5] / n:.2f} (records 0: {res[0][4][5] / n:.2f}); "
+                  f"all-pairs fallbacks {res[rec][4][0]}")
+
+
+if __name__ == "__main__":
+    main()

@@ -147,6 +147,12 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
         a.Qh = half ? Q.tiles8h : Q.tiles8;
         a.Bh = half ? B.tiles8h : B.tiles8;
         a.ib = I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr, records == VFM_RECORDS_TOP2 ? 1 : 0};
+        if (records == VFM_RECORDS_MX6) {   // the fp6 image and its bounds (operands prepared with VFM_PREPARE_MX6)
+            a.Qh = Q.tiles6;
+            a.Bh = B.tiles6;
+            a.ib = mx6_bounds(Q, B);
+            return launch_coarse_mx6(a, d, st);
+        }
         return launch_coarse_int8(a, d, n, records, st);
     }
     return launch_coarse_f16(a, d, st);
@@ -192,7 +198,8 @@ VFM_EXPORT int vfm_match_prepare2_gated_p(const float* x1, int64_t rows1, void* 
                                           void* prepared2, int d, int schedule, vfm_stream_t stream) {
     VFM_CHECK_ARG(rows1 > 0 && rows2 > 0 && d % 128 == 0 && d >= 128 && d <= 768, "prepare2: d must be in {128,256,384,512,640,768}");
     VFM_CHECK_ARG(x1 && x2 && prepared1 && prepared2, "prepare2: null pointer");
-    VFM_CHECK_ARG(schedule >= VFM_PREPARE_DEFAULT && schedule <= VFM_PREPARE_INTERLEAVED, "prepare2: unknown schedule %d", schedule);
+    VFM_CHECK_ARG((schedule & ~VFM_PREPARE_MX6) >= VFM_PREPARE_DEFAULT && (schedule & ~VFM_PREPARE_MX6) <= VFM_PREPARE_INTERLEAVED,
+                  "prepare2: unknown schedule %d", schedule);
     const bool want_f16 = !use_i8(d, rows2, rows1, true);
     return do_prepare2(x1, rows1, prepared1, x2, rows2, prepared2, d, (hipStream_t)stream, want_f16, schedule);
 }
@@ -244,7 +251,7 @@ VFM_EXPORT int vfm_match_search_coarse_gated_r(const void* q_prepared, int64_t n
                                                void* ws, size_t ws_bytes, int records, vfm_stream_t stream) {
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q_prepared && b_prepared && ws, "search_coarse: null pointer");
-    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_HALF, "search_coarse: unknown record kind %d", records);
+    VFM_CHECK_ARG((records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_HALF) || records == VFM_RECORDS_MX6, "search_coarse: unknown record kind %d", records);
     return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream, false, true, true, records);
 }
 
@@ -252,7 +259,7 @@ VFM_EXPORT int vfm_match_search_coarse_gated_g(const void* q_prepared, int64_t n
                                                void* ws, size_t ws_bytes, int records, float gate, vfm_stream_t stream) {
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q_prepared && b_prepared && ws, "search_coarse: null pointer");
-    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_HALF_FUSED, "search_coarse: unknown record kind %d", records);
+    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6, "search_coarse: unknown record kind %d", records);
     VFM_CHECK_ARG(gate == gate, "search_coarse: gate is NaN");
     return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream, false, true, true, records, gate);
 }
@@ -270,7 +277,7 @@ VFM_EXPORT int vfm_match_search_finish_gated_r(const float* q, const void* q_pre
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q && b && q_prepared && b_prepared && ws && idx_out && sim_out, "search_finish: null pointer");
     VFM_CHECK_ARG(gate == gate, "search_finish: gate is NaN");
-    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_HALF_FUSED, "search_finish: unknown record kind %d", records);
+    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6, "search_finish: unknown record kind %d", records);
     return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream, true, gate, records);
 }
 
@@ -379,6 +386,48 @@ VFM_EXPORT int vfm_debug_i8_rows(const void* prepared, int64_t rows, int d, int8
             for (int k = 0; k < 16; ++k) q8_host[r * (int64_t)d + 16 * u + k] = src[k];
         }
         step_host[r] = gstep[(size_t)(r / I8_GROUP)];
+        gerr_host[r] = gerr[(size_t)(r / I8_GROUP)];
+    }
+    return VFM_OK;
+}
+
+// The fp6 image of a prepared operand (VFM_PREPARE_MX6), dequantised on the host: v6_host[rows][d] (float: code value x block
+// scale), err_host[rows] (E of the fp6 image, slack included), gerr_host[rows] (its group's maximum).  Tests only.
+VFM_EXPORT int vfm_debug_mx6_rows(const void* prepared, int64_t rows, int d, float* v6_host, float* err_host, float* gerr_host) {
+    VFM_CHECK_ARG(prepared && rows > 0 && mx6_width(d) && v6_host && err_host && gerr_host, "mx6_rows: bad arguments");
+    Prepared p = carve_prepared(const_cast<void*>(prepared), rows, d);
+    const int64_t rp = rows_padded(rows);
+    const size_t units = (size_t)rp / TILE_ROWS * (size_t)(d / 64) * 128;
+    std::vector<uint4> tiles(units);
+    std::vector<float> gerr((size_t)rp / I8_GROUP);
+    VFM_CHECK_HIP(hipDeviceSynchronize());
+    VFM_CHECK_HIP(hipMemcpy(tiles.data(), p.tiles6, units * sizeof(uint4), hipMemcpyDeviceToHost));
+    VFM_CHECK_HIP(hipMemcpy(gerr.data(), p.gerr6, gerr.size() * sizeof(float), hipMemcpyDeviceToHost));
+    VFM_CHECK_HIP(hipMemcpy(err_host, p.err6, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost));
+    const int upt = (d / 64) * 128;  // units per tile
+    for (int64_t r = 0; r < rows; ++r) {
+        const int64_t tile = r / TILE_ROWS, pp = r % TILE_ROWS;
+        for (int blk = 0; blk < d / 32; ++blk) {   // block = (k-step s, half h): MFMA lane h * 32 + pp, columns 64 s + 32 h ...
+            const int s = blk >> 1, h = blk & 1;
+            unsigned char op[32];
+            const unsigned char* lo = reinterpret_cast<const unsigned char*>(&tiles[(size_t)tile * upt + (size_t)(2 * s) * 64 + h * 32 + pp]);
+            const unsigned char* hi = reinterpret_cast<const unsigned char*>(&tiles[(size_t)tile * upt + (size_t)(2 * s + 1) * 64 + h * 32 + pp]);
+            for (int i = 0; i < 16; ++i) {
+                op[i] = lo[i];
+                op[16 + i] = hi[i];
+            }
+            const unsigned char* sc = reinterpret_cast<const unsigned char*>(&tiles[(size_t)tile * upt + 64 + h * 32 + pp]) + 8;
+            const float scale = ldexpf(1.0f, (int)sc[s] - 127);
+            for (int f = 0; f < 32; ++f) {
+                const int bit = 6 * f;
+                const unsigned w = (unsigned)op[bit >> 3] | ((unsigned)op[(bit >> 3) + 1] << 8);
+                const unsigned code = (w >> (bit & 7)) & 63u;
+                const int e = (code >> 3) & 3, mnt = code & 7;
+                float v = e == 0 ? mnt / 8.0f : (1.0f + mnt / 8.0f) * (float)(1 << (e - 1));
+                if (code & 32u) v = -v;
+                v6_host[r * (int64_t)d + 32 * blk + f] = v * scale;
+            }
+        }
         gerr_host[r] = gerr[(size_t)(r / I8_GROUP)];
     }
     return VFM_OK;

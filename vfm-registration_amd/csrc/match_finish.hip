@@ -1553,7 +1553,8 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
         const int chunk_lds = i8 && (size_t)a.nchunks * sizeof(float2) <= 63 * 1024;  // (step, max E) of every chunk in LDS
         bool use_bins = false;
         // best-score records with many queries per map chunk: the rescan runs chunk-major (match_rescan_chunk_kernel)
-        const bool best = i8 && records == VFM_RECORDS_BEST && g_select_variant != 1;
+        const bool mx6 = i8 && records == VFM_RECORDS_MX6;   // best-score records of the fp6 pass: its own bounds in the selection
+        const bool best = i8 && (records == VFM_RECORDS_BEST || mx6) && g_select_variant != 1;
         use_bins = (best || half) && g_select_variant != 2 && n >= 4 * (int64_t)a.nchunks;
         if (fused) {
             // (nothing to select)
@@ -1572,14 +1573,15 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
         } else if (best) {
             hipLaunchKernelGGL(match_select_best_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * SELECT_BEST_WAVES),
                                chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, reinterpret_cast<const unsigned*>(w.partials),
-                               a.nchunks, n, (const unsigned*)w.qmax, Q.inv, i8_bounds(Q, B, true, records), gate, chunk_lds, w.cand_cnt,
+                               a.nchunks, n, (const unsigned*)w.qmax, Q.inv, mx6 ? mx6_bounds(Q, B) : i8_bounds(Q, B, true, records), gate,
+                               chunk_lds, w.cand_cnt,
                                w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats, use_bins ? w.bin_cnt : (unsigned*)nullptr,
                                use_bins ? w.bins : (int*)nullptr, a.first_pad_chunk, w.bin_cap);
         } else
         hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS),
                            chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, w.partials, a.nchunks, a.npad, n, a.first_pad_chunk, w.qmax,
-                           Q.inv, DEFAULT_WINDOW, i8_bounds(Q, B, i8, records), gate, chunk_lds, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list,
-                           g_match_stats);
+                           Q.inv, DEFAULT_WINDOW, mx6 ? mx6_bounds(Q, B) : i8_bounds(Q, B, i8, records), gate, chunk_lds, w.cand_cnt, w.cand, w.cap,
+                           w.fb_count, w.fb_list, g_match_stats);
         VFM_CHECK_LAUNCH("match_select_kernel");
         if (i8) {  // candidate chunks -> candidate rows (the record buffer of the fp16 pass is free: it holds the hit lists)
             const int* guard = half ? w.fb_count + HALF_GUARD_FLAG : (const int*)nullptr;

@@ -336,6 +336,11 @@ struct Prepared {
     uint4* tiles8h;   // int8 fragment tiles of the first d / 2 columns
     float* rest;      // per row: |second half of the normalised row|_2, rounded up
     float* grest;     // its maximum per group
+    // fp6 image (mx6_width(d); prep_chunk_kernel<., ., true>, written on request: VFM_PREPARE_MX6)
+    uint4* tiles6;    // MX fp6 (e2m3) fragment tiles of the 32x32x64 scaled MFMA
+    float* err6;      // per row: |v - dequantised row|_2 rounded up, plus the slack of the pass's fp32 / fixed-point arithmetic
+    float* gerr6;     // its maximum per group
+    float* gstep6;    // MX6_FIX_STEP for every group (the records are fixed-point: I8Bounds needs a step per group)
     size_t bytes;
 };
 
@@ -348,10 +353,14 @@ inline bool half_capable(int d, int64_t n) {
     (void)n;
     return i8_capable(d);
 }
+// widths the fp6 pass (VFM_RECORDS_MX6) has a kernel for: two resident query sets of d / 64 x 8 registers
+inline bool mx6_width(int d) { return d == 256 || d == 384; }
+constexpr float MX6_FIX_STEP = 0.0009765625f;   // 2^-10: an fp6 record is ceil(score * 2^20) -- "integer score" x step x step
 // the fused form exists where the 64-queries-per-wave kernel runs and a map chunk collects several queries (chunk-major rescan)
 inline int effective_records(int records, int d, int64_t n, int64_t m) {
     if (records == VFM_RECORDS_HALF_FUSED && !((d == 256 || d == 384) && n > 2048 && n >= 4 * ((m + CHUNK_ROWS - 1) / CHUNK_ROWS)))
         records = VFM_RECORDS_HALF;
+    if (records == VFM_RECORDS_MX6 && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_BEST;   // (the one-set kernels have no fp6 form)
     return (records == VFM_RECORDS_HALF && !half_capable(d, n)) ? VFM_RECORDS_BEST : records;
 }
 
@@ -366,6 +375,8 @@ inline Prepared carve_prepared(void* p, int64_t rows, int d) {
     r.tiles8 = nullptr;
     r.tiles8h = nullptr;
     r.rest = r.grest = nullptr;
+    r.tiles6 = nullptr;
+    r.err6 = r.gerr6 = r.gstep6 = nullptr;
     if (i8_capable(d)) {  // behind the fp16 image: the Euclidean path carves the same layout and ignores the rest
         r.err = c.take<float>((size_t)rp);
         r.gstep = c.take<float>((size_t)rp / I8_GROUP);
@@ -376,6 +387,12 @@ inline Prepared carve_prepared(void* p, int64_t rows, int d) {
         r.tiles8h = c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(d / 64) * 64);
         r.rest = c.take<float>((size_t)rp);
         r.grest = c.take<float>((size_t)rp / I8_GROUP);
+        if (mx6_width(d)) {   // the fp6 image: 32 bytes per (row, 64 columns) -- 24 of codes, the block scales, padding
+            r.tiles6 = c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(d / 64) * 128);
+            r.err6 = c.take<float>((size_t)rp);
+            r.gerr6 = c.take<float>((size_t)rp / I8_GROUP);
+            r.gstep6 = c.take<float>((size_t)rp / I8_GROUP);
+        }
     }
     r.bytes = c.used();
     return r;
@@ -451,6 +468,8 @@ int choose_slices(int nqb, int nchunks);
 inline I8Bounds i8_bounds(const Prepared& Q, const Prepared& B, bool on, int top2 = 0) {
     return on ? I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr, top2 == VFM_RECORDS_TOP2 ? 1 : 0} : I8Bounds{nullptr, nullptr, nullptr, nullptr, 0};
 }
+// bounds of the fp6 records (selection only: the rescans score the int8 image and use i8_bounds)
+inline I8Bounds mx6_bounds(const Prepared& Q, const Prepared& B) { return I8Bounds{Q.err6, Q.gstep6, B.gstep6, B.gerr6, 0}; }
 CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, int64_t n, int64_t m, int qblock = QBLOCK);
 
 // match_prep.hip
@@ -463,6 +482,7 @@ int do_prepare_perm(const float* x, int64_t rows, const int* perm, int d, void* 
 // match_coarse_f16.hip / match_coarse_i8.hip: launch the coarse kernel for arguments prepared by do_search_coarse
 int launch_coarse_f16(const CoarseArgs& a, int d, hipStream_t st);
 int launch_coarse_int8(CoarseArgs& a, int d, int64_t n, int records, hipStream_t st);
+int launch_coarse_mx6(CoarseArgs& a, int d, hipStream_t st);   // match_coarse_mx6.hip
 // match_api.hip
 int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, hipStream_t st,
                      bool bias_from_map_inv = false, bool inner_product = false, bool gated = false, int records = 0,

@@ -91,21 +91,50 @@ struct PrepOut {
     float* rest;      // |second half of the normalised row|_2, rounded up
     float* grest;     // its maximum over the group
     const int* perm;  // row r of the image is row perm[r] of x (NULL: identity)
+    uint4* tiles6;    // MX6: fp6 fragment tiles
+    float* err6;      // MX6: residual norm of the fp6 image per row (+ MX6_SLACK)
+    float* gerr6;     // MX6: its maximum over the group
+    float* gstep6;    // MX6: MX6_FIX_STEP
 };
-template <bool F16, int NC = 2>
+// MX6: additionally the microscaled fp6 image (OCP MX: e2m3 elements, one power-of-two scale per 32 columns) in fragment tiles
+// of v_mfma_scale_f32_32x32x64_f8f6f4.  Lane l of that MFMA holds, for row l & 31, the 32 columns 64 s + 32 (l >> 5) ... of
+// k-step s as 32 consecutive 6-bit codes (little-endian: code f at bits [6 f, 6 f + 6) -- tools/probe/mx6_probe.hip checks
+// the layout on the device), i.e. exactly ONE scale block.  A lane's operand is stored as two 16-byte units, 24 bytes of codes +
+// 8 spare, at uint4 index tile * (d/64 * 128) + (2 s + half) * 64 + l: the tile geometry of the int8 image (1 KiB per unit
+// row, d * 32 bytes per tile), so the coarse kernel stages both the same way.  The E8M0 scales of a lane's d / 64 blocks sit
+// together in the spare bytes of k-step 0 (byte 8 + s of the unit in unit row 1): one 8-byte read per tile, the MFMA's op_sel
+// picks the byte.
+// The image is made from the fp16 copy of the normalised rows that phase 2 leaves in the LDS (the staging of the fp16 image):
+// once the int8 tiles have left the LDS, a thread takes one (row, 32-column block) -- 1536 of them per group -- reads its 32
+// halves, picks the scale 2^e with max / 2^e <= 7.75 (the largest code is 7.5; up to 7.75 rounds there with the half-step
+// error of its binade) and converts with v_cvt_scalef32_pk32_fp6_f16 (round to nearest even, saturating:
+// tools/probe/mx6_cvt_probe.hip checks it against the arithmetic definition); the residual against the fp16 values is MEASURED
+// (codes converted back by v_cvt_scalef32_pk32_f16_fp6 at scale 1: exact), the rounding of the fp16 copy itself is bounded:
+// |v - fp16(v)|_2 <= 2^-11 |v|_2 + sqrt(d) 2^-25 (denormals), |v|_2 <= 1 + 2^-13.
+constexpr float MX6_SLACK = 2.0e-5f;   // on every E: the MFMA's fp32 accumulation (<= 6 steps x a few ulp of 4) + the records' 2^-20 grid
+constexpr float MX6_F16_ROUNDING = 4.8929e-4f;   // 2^-11 (1 + 2^-13) + sqrt(768) 2^-25, rounded up
+typedef _Float16 halfx32 __attribute__((ext_vector_type(32)));
+typedef int intx6 __attribute__((ext_vector_type(6)));
+typedef unsigned short ushortx2 __attribute__((ext_vector_type(2)));
+template <bool F16, int NC = 2, bool MX6 = false>
 __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restrict__ x1, int64_t rows1, int d, PrepOut o1, int groups1,
                                                           const float* __restrict__ x2, int64_t rows2, PrepOut o2, int groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ unsigned amax_bits, emax_bits, rmax_bits;
+    __shared__ unsigned amax_bits, emax_bits, rmax_bits, e6max_bits;
+    static_assert(!(F16 && MX6), "the fp6 image is made from the LDS copy of the fp16 one, which then is not stored");
     constexpr int RPW = I8_GROUP / 16;  // rows per wave: 16 waves x 8 rows, all of them in registers between the two phases
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int nchunks = d >> 2;  // float4 chunks per row (<= 64 NC): lane l owns chunks l, l + 64 (, l + 128)
     unsigned char* img8 = smem;                                                  // [4 tiles][d/32 * 64 units][16]
     _Float16* img16 = reinterpret_cast<_Float16*>(smem + (size_t)I8_GROUP * d);  // F16: [4 tiles][d/16 * 64 units][8]
+    unsigned char* img6 = smem;                                                  // MX6: [4 tiles][d/64 * 128 units][16], over img8 once that is stored
+    float* e6p = reinterpret_cast<float*>(smem + (size_t)I8_GROUP * d * 3);      // MX6: [d/32 blocks][128 rows] squared residuals
+    unsigned char* scb = reinterpret_cast<unsigned char*>(e6p + (d >> 5) * I8_GROUP);   // MX6: [128 rows][16] block scales (E8M0)
     if (threadIdx.x == 0) {
         amax_bits = 0u;
         emax_bits = 0u;
         rmax_bits = 0u;
+        e6max_bits = 0u;
     }
     // The kernel's registers allow one workgroup per compute unit, so a workgroup walks several groups (grid = compute
     // units) and reads row j of its NEXT group as soon as row j of the current one has been quantised: the read of the next
@@ -227,7 +256,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
                     const unsigned packed = __builtin_amdgcn_perm((unsigned)qi[1], (unsigned)qi[0], 0x0c0c0400u) |
                                             __builtin_amdgcn_perm((unsigned)qi[3], (unsigned)qi[2], 0x04000c0cu);
                     *reinterpret_cast<unsigned*>(img8 + (size_t)t * (d * 32) + (((c >> 3) * 2 + ((c >> 2) & 1)) * 32 + p) * 16 + (c & 3) * 4) = packed;
-                    if constexpr (F16) {
+                    if constexpr (F16 || MX6) {
                         half4 h;
                         h[0] = (_Float16)nv[0];
                         h[1] = (_Float16)nv[1];
@@ -240,7 +269,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
             }
             part[j] = e2;
             rpart[j] = r2;
-            if (gnext < groups) load_row(gnext, j);
+            if (!MX6 && gnext < groups) load_row(gnext, j);   // (MX6: the conversion below needs the registers; rows are read after it)
         }
         {
             // |e|_2 of row lane >> 3, rounded up: the fp32 sum of d non-negative terms is within (d + 8) 2^-24 of exact, sqrtf
@@ -293,6 +322,87 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
                 __builtin_nontemporal_store(tq.w, po + 3);
             }
         }
+        if constexpr (MX6) {
+            __syncthreads();   // the int8 tiles have left the LDS: the fp6 image takes their place
+            const int nblk = d >> 5;
+            for (int item = threadIdx.x; item < I8_GROUP * nblk; item += 1024) {
+                const int r = item & (I8_GROUP - 1), blk = item >> 7, t = r >> 5, p = r & 31;
+                // the block's 32 halves: fp16 units (k-step 2 blk + u, half hh) of row p, in column order
+                const uint4* up = reinterpret_cast<const uint4*>(img16 + (size_t)t * (d * 32)) + (4 * blk) * 32 + p;
+                union {
+                    uint4 u[4];
+                    halfx32 h;
+                    unsigned w[16];
+                } v;
+                v.u[0] = up[0];
+                v.u[1] = up[32];
+                v.u[2] = up[64];
+                v.u[3] = up[96];
+                ushortx2 m2 = {0, 0};   // packed maximum of the magnitudes (as 15-bit integers: the order of non-negative halves)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const unsigned a2 = v.w[i] & 0x7fff7fffu;
+                    m2 = __builtin_elementwise_max(m2, *reinterpret_cast<const ushortx2*>(&a2));
+                }
+                const unsigned am = max((unsigned)m2[0], (unsigned)m2[1]);
+                // am = (1 + f) 2^x: e = x - 2 when 1 + f <= 1.9375 (max / 2^e <= 7.75), else x - 1; Inf / NaN blocks: scale 1 (the
+                // residual turns E into Inf); normalised finite rows: e <= -2
+                int ex = (int)(am >> 10) - 15 - ((am & 0x3ffu) <= 0x3c0u ? 2 : 1);
+                ex = ex > 0 ? 0 : ex;
+                const float sc6 = __uint_as_float((unsigned)(ex + 127) << 23);
+                const intx6 codes = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v.h, sc6);
+                const halfx32 back = __builtin_amdgcn_cvt_scalef32_pk32_f16_fp6(codes, 1.0f);   // the code values: exact in fp16
+                float e6 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const float res = __builtin_fmaf(-(float)back[i], sc6, (float)v.h[i]);
+                    e6 = __builtin_fmaf(res, res, e6);
+                }
+                const int s6 = blk >> 1, l6 = (blk & 1) * 32 + p;
+                unsigned char* tile6 = img6 + (size_t)t * (d * 32);
+                *reinterpret_cast<uint4*>(tile6 + (size_t)((2 * s6) * 64 + l6) * 16) =
+                    make_uint4((unsigned)codes[0], (unsigned)codes[1], (unsigned)codes[2], (unsigned)codes[3]);
+                if (s6 > 0)   // (the spare bytes of unit row 1 take the lane's scales, below)
+                    *reinterpret_cast<uint4*>(tile6 + (size_t)((2 * s6 + 1) * 64 + l6) * 16) = make_uint4((unsigned)codes[4], (unsigned)codes[5], 0u, 0u);
+                else
+                    *reinterpret_cast<uint2*>(tile6 + (size_t)(64 + l6) * 16) = make_uint2((unsigned)codes[4], (unsigned)codes[5]);
+                scb[r * 16 + blk] = (unsigned char)(ex + 127);
+                e6p[blk * I8_GROUP + r] = e6;
+            }
+            __syncthreads();
+            if (threadIdx.x < 2 * I8_GROUP) {   // the d / 64 scales of MFMA lane (hh, p) of tile t: bytes 8 .. of its unit in unit row 1
+                const int r = threadIdx.x & (I8_GROUP - 1), hh = threadIdx.x >> 7;
+                unsigned lo = 0u, hi = 0u;
+                for (int s6 = 0; s6 < (d >> 6); ++s6) {
+                    const unsigned b = scb[r * 16 + 2 * s6 + hh];
+                    if (s6 < 4) lo |= b << (8 * s6);
+                    else hi |= b << (8 * (s6 - 4));
+                }
+                *reinterpret_cast<uint2*>(img6 + (size_t)(r >> 5) * (d * 32) + (size_t)(64 + hh * 32 + (r & 31)) * 16 + 8) = make_uint2(lo, hi);
+            } else if (threadIdx.x < 3 * I8_GROUP) {   // E of the fp6 image per row: blocks in order; rounded up like the int8 one
+                const int r = threadIdx.x - 2 * I8_GROUP;
+                float acc = 0.0f;
+                for (int blk = 0; blk < nblk; ++blk) acc = acc + e6p[blk * I8_GROUP + r];
+                float e6n = sqrtf(acc) * 1.000244140625f + (MX6_F16_ROUNDING + MX6_SLACK);
+                if (!(e6n == e6n)) e6n = __builtin_inff();
+                const int64_t row = (int64_t)grp * I8_GROUP + r;
+                if (row >= rows) e6n = 0.0f;
+                o.err6[row] = e6n;
+                if (e6n > 0.0f) atomicMax(&e6max_bits, __float_as_uint(e6n));
+            }
+            __syncthreads();
+            const int u6n = (d >> 5) * 64 * 4;   // same size as the int8 tiles
+            uint4* dst = o.tiles6 + (int64_t)grp * u6n;
+            const uint4* src = reinterpret_cast<const uint4*>(img6);
+            for (int u = threadIdx.x; u < u6n; u += 1024) {
+                const uint4 tq = src[u];
+                unsigned* po = reinterpret_cast<unsigned*>(dst + u);
+                __builtin_nontemporal_store(tq.x, po);
+                __builtin_nontemporal_store(tq.y, po + 1);
+                __builtin_nontemporal_store(tq.z, po + 2);
+                __builtin_nontemporal_store(tq.w, po + 3);
+            }
+        }
         if constexpr (F16) {
             const int u16n = (d >> 4) * 64 * 4;
             uint4* dst = o.tiles + (int64_t)grp * u16n;
@@ -306,10 +416,21 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
                 __builtin_nontemporal_store(tq.w, po + 3);
             }
         }
+        if constexpr (MX6) {
+            if (gnext < groups) {
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) load_row(gnext, j);
+            }
+        }
         if (threadIdx.x == 0) {
             o.gstep[grp] = qstep;
             o.gerr[grp] = __uint_as_float(emax_bits);
             o.grest[grp] = __uint_as_float(rmax_bits);
+            if constexpr (MX6) {
+                o.gerr6[grp] = __uint_as_float(e6max_bits);
+                o.gstep6[grp] = MX6_FIX_STEP;
+                e6max_bits = 0u;
+            }
             amax_bits = 0u;   // for the next group (read again only behind the next two barriers)
             emax_bits = 0u;
             rmax_bits = 0u;
@@ -343,7 +464,7 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x,
 }  // namespace
 
 inline PrepOut prep_out(const Prepared& p, const int* perm = nullptr) {
-    return PrepOut{p.inv, p.tiles, p.err, p.gstep, p.gerr, p.tiles8, p.tiles8h, p.rest, p.grest, perm};
+    return PrepOut{p.inv, p.tiles, p.err, p.gstep, p.gerr, p.tiles8, p.tiles8h, p.rest, p.grest, perm, p.tiles6, p.err6, p.gerr6, p.gstep6};
 }
 
 // Workgroups of prep_chunk_kernel (vfm_debug_set_prep_grid): -1 (default) = one per 128-row group; 0 = one per compute unit,
@@ -369,6 +490,8 @@ inline int prep_grid(int groups, int mode) {
 // will meet in an int8 search (use_i8): a third of the bytes written, a third of the LDS.
 int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2, int64_t rows2, void* prepared2, int d,
                 hipStream_t st, bool want_f16, int grid_mode) {
+    const bool want_mx6 = (grid_mode & VFM_PREPARE_MX6) != 0 && mx6_width(d);
+    grid_mode &= ~VFM_PREPARE_MX6;
     Prepared p1 = carve_prepared(prepared1, rows1, d);
     Prepared p2 = x2 ? carve_prepared(prepared2, rows2, d) : Prepared{};
     const int t1 = (int)(rows_padded(rows1) / TILE_ROWS), t2 = x2 ? (int)(rows_padded(rows2) / TILE_ROWS) : 0;
@@ -382,12 +505,20 @@ int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2
                                               hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * 512));
             VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_chunk_kernel<false, 3>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * 768));
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_chunk_kernel<false, 2, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * (384 * 3 + 384 / 8 + 16)));
             attr_mark(attr_set);
         }
         const int groups = g1 + g2;
         int pg = prep_grid(groups, grid_mode);
         const dim3 grid((unsigned)pg), block(1024);
-        if (want_f16 && d <= 384) {  // both images from one read of the rows (144 KB of LDS at d = 384)
+        if (want_mx6) {   // int8 + fp6 images from one read of the rows; the fp16 image, if wanted, by its own kernel
+            hipLaunchKernelGGL((prep_chunk_kernel<false, 2, true>), grid, block, (size_t)I8_GROUP * (d * 3 + d / 8 + 16), st, x1, rows1, d, prep_out(p1), g1,
+                               x2, rows2, prep_out(p2), groups);
+            if (want_f16)
+                hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)(t1 + t2)), dim3(256), (size_t)d * 64, st, x1, rows1, d, p1.inv,
+                                   p1.tiles, t1, x2, rows2, p2.inv, p2.tiles);
+        } else if (want_f16 && d <= 384) {  // both images from one read of the rows (144 KB of LDS at d = 384)
             hipLaunchKernelGGL((prep_chunk_kernel<true, 2>), grid, block, (size_t)I8_GROUP * d * 3, st, x1, rows1, d, prep_out(p1), g1, x2,
                                rows2, prep_out(p2), groups);
         } else {
