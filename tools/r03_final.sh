@@ -19,6 +19,11 @@ for i in 1 2 3 4 5 6 7; do cp $R/gpurun_out/pmc_coarse/p${i}_counter_collection.
 cd $R && VFM_RECORDS=0 bash tools/pmc_coarse.sh 2>&1 | tail -22
 cp $R/gpurun_out/pmc_coarse/pmc_match_coarse.json $O/ 2>/dev/null
 for i in 1 2 3 4 5 6 7; do cp $R/gpurun_out/pmc_coarse/p${i}_counter_collection.csv $O/pmc_pass${i}_counter_collection.csv 2>/dev/null; done
+cd $R && VFM_RECORDS=5 bash tools/pmc_coarse.sh 2>&1 | tail -22
+cp $R/gpurun_out/pmc_coarse/pmc_match_coarse.json $O/pmc_match_coarse_mx6.json 2>/dev/null
+for i in 1 2 3 4 5 6 7; do cp $R/gpurun_out/pmc_coarse/p${i}_counter_collection.csv $O/pmc_mx6_pass${i}_counter_collection.csv 2>/dev/null; done
+timeout 600 python tools/dev_mx6.py > $O/dev_mx6.txt 2>&1; tail -8 $O/dev_mx6.txt
+timeout 900 python tools/ab_mx6_bench.py > $O/ab_mx6_bench.txt 2>&1
 cd $R && timeout 900 python tools/time_neardup.py --steps 20 --out $O/neardup.json > $O/neardup.log 2>&1
 # row A6 (find_correspondences' mutual filter): timing, kernel sequence
 timeout 300 python tools/time_pairs.py 6 > $O/time_pairs.txt 2>&1; cat $O/time_pairs.txt
@@ -32,4 +37,5 @@ bash tools/prof_c3_one.sh > $O/prof_c3_one.txt 2>&1
 timeout 900 python tools/soak_half.py 40 303 2>&1 | tail -3 > $O/soak_half.txt; cat $O/soak_half.txt
 timeout 900 python tools/soak_match.py 16 303 2>&1 | tail -3 > $O/soak_match.txt; cat $O/soak_match.txt
 # fp6 (MX e2m3) MFMA: operand layout check + issue rate
-hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mx6_probe tools/probe/mx6_probe.hip && /tmp/mx6_probe > $O/mx6_probe.txt 2>&1; cat $O/mx6_probe.txt
+hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mx6_probe tools/probe/mx6_probe.hip && /tmp/mx6_probe > $O/mx6_probe.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mx6_cvt_probe tools/probe/mx6_cvt_probe.hip && /tmp/mx6_cvt_probe >> $O/mx6_probe.txt 2>&1; cat $O/mx6_probe.txt

@@ -50,10 +50,12 @@ def main():
               "neardup.json": "r03_neardup.json", "time_pairs.txt": "r03_time_pairs.txt", "prof_pairs.txt": "r03_prof_pairs.txt",
               "other_rows.txt": "r03_other_rows.txt", "time_c3_modes.txt": "r03_time_c3_modes.txt",
               "ab_vit_xcd.txt": "r03_ab_vit_xcd.txt", "prof_c3_one.txt": "r03_prof_c3_one.txt",
-              "soak_half.txt": "r03_soak_half.txt", "soak_match.txt": "r03_soak_match.txt", "mx6_probe.txt": "r03_mx6_probe.txt"}
+              "pmc_match_coarse_mx6.json": "r03_pmc_match_coarse_mx6.json", "dev_mx6.txt": "r03_dev_mx6.txt",
+              "ab_mx6_bench.txt": "r03_ab_mx6_bench.txt", "soak_half.txt": "r03_soak_half.txt", "soak_match.txt": "r03_soak_match.txt", "mx6_probe.txt": "r03_mx6_probe.txt"}
     for i in range(1, 8):
         copies[f"pmc_pass{i}_counter_collection.csv"] = f"r03_pmc_pass{i}_counter_collection.csv"
         copies[f"pmc_half_pass{i}_counter_collection.csv"] = f"r03_pmc_half_pass{i}_counter_collection.csv"
+        copies[f"pmc_mx6_pass{i}_counter_collection.csv"] = f"r03_pmc_mx6_pass{i}_counter_collection.csv"
     for a, b in copies.items():
         src = SRC / a
         if not src.exists() and "/" in a:   # rocprofv3 nests its output under the host name
@@ -66,6 +68,7 @@ def main():
     bi = last_json(DST / "r03_bench_int8_full_same_box.json")
     pmh = json.loads((DST / "r03_pmc_match_coarse_i8half.json").read_text())
     pmc = json.loads((DST / "r03_pmc_match_coarse_i8.json").read_text())
+    pm6 = json.loads((DST / "r03_pmc_match_coarse_mx6.json").read_text()) if (DST / "r03_pmc_match_coarse_mx6.json").exists() else None
     r = b["roofline"]
     ex = b["extra"]
     cfg = b["config"]
@@ -88,8 +91,9 @@ def main():
         if not v:
             return f"`extra.{k}`: (absent)"
         rl = v.get("roofline") or {}
+        which = "fp6" if rl.get("peak", 0) > 6000 else "int8"
         return (f"`extra.{k}`: **{v.get('value', float('nan')):.1f} registrations/s** ({v.get('ms_per_step', float('nan')):.3f} ms)"
-                + (f", coarse kernel {rl.get('avg_launch_ms', float('nan')):.3f} ms = {rl.get('frac', float('nan')):.3f} of the int8 peak" if rl else "")
+                + (f", coarse kernel {rl.get('avg_launch_ms', float('nan')):.3f} ms = {rl.get('frac', float('nan')):.3f} of the {which} peak" if rl else "")
                 + (f", pass in use: {v.get('coarse_pass')}" if v.get("coarse_pass") else ""))
 
     a6 = ex.get("A6_mutual_l2", {})
@@ -114,6 +118,7 @@ Pose delta vs the oracle on identical inputs (`extra.pose_delta_vs_oracle`): {ex
 The same pipeline away from the favourable case (VERDICT r2 item 2), same process, same box:
 
 - {variant('C2_full_width')} -- `coarse="int8"` pinned: every column in the coarse pass, nothing depends on how the descriptors prune
+- {variant('C2_full_width_mx6')} -- `coarse="mx6"` pinned: the same all-pairs product in microscaled fp6 on the scaled MFMA (DESIGN.md 0.8), as data independent as the line above
 - {variant('C2_sustained')} -- {ex.get('C2_sustained', {}).get('steps', '?')} steps instead of 20 (the first ~15 launches after a synchronise run slower)
 - {variant('C2_lifted')} -- map descriptors lifted from overlapping patch grids (near-duplicates), policy by feedback
 - `extra.A6_mutual_l2`: {json.dumps(a6)[:600]}
@@ -146,6 +151,9 @@ Half-width kernel (`VFM_RECORDS=3`; `profiles/r03_pmc_match_coarse_i8half.json` 
 
 Full-width kernel (`VFM_RECORDS=0`; `profiles/r03_pmc_match_coarse_i8.json` + `profiles/r03_pmc_pass*_counter_collection.csv`,
 {pmc['kernel']}): {pmc_line(pmc)}.
+
+fp6 kernel (`VFM_RECORDS=5`; `profiles/r03_pmc_match_coarse_mx6.json` + `profiles/r03_pmc_mx6_pass*_counter_collection.csv`,
+{pm6['kernel'] if pm6 else '?'}): {pmc_line(pm6) if pm6 else '(not collected)'}.
 
 Reading: the MFMA pipe is busy ~3/4 of the cycles at a clock of ~1.75 GHz (2.4 GHz is what the 5 POP/s peak assumes): the
 fraction of the peak is busy x clock / 2.4, i.e. the kernel sits against the power envelope, not against its own stalls.
@@ -188,6 +196,18 @@ ViT tile mapping A/B (`r03_ab_vit_xcd.txt`):
 
 ```
 {text('r03_ab_vit_xcd.txt')[-1200:]}
+```
+
+## fp6 coarse pass (`tools/dev_mx6.py`, `tools/ab_mx6_bench.py`)
+
+```
+{text('r03_dev_mx6.txt')[-2500:]}
+```
+
+Pipelined (the bench's pipeline construction), coarse pass pinned, three kinds of data, 20 / 200 timed steps (`r03_ab_mx6_bench.txt`):
+
+```
+{text('r03_ab_mx6_bench.txt')[-4500:]}
 ```
 
 ## Soaks beyond the suite's fixed seeds
