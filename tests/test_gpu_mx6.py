@@ -172,3 +172,69 @@ def test_mx6_pipeline_mode_equals_the_oracle_registration():
         np.testing.assert_array_equal(out["T"].cpu().numpy(), ref.transformation)
         assert int(out["best_hyp"].item()) == ref.best_hyp
         np.testing.assert_array_equal(out["mask"].cpu().numpy()[:c], ref.inlier_mask[:c])
+
+
+def soak_trial_mx6(lib, rng, st):
+    """one random trial of the fp6 pass (VFM_RECORDS_MX6 on operands prepared with VFM_PREPARE_MX6) against best-score int8
+    records: random shape (below and above the 2048 queries the fp6 kernel starts at), width, gate (or none) and data kind.
+    Gate contract, pairwise: the same answer where both resolve; whatever only one resolves lies below the gate; the matches
+    a caller keeps are identical; without a gate both resolve everything."""
+    d = int(rng.choice([256, 384, 384]))
+    n = int(rng.integers(1, 9000))
+    m = int(rng.integers(1, 60000))
+    gsel = rng.choice([0.5, 0.8, 0.8, 0.95, -1.0])
+    gate = float("-inf") if gsel < 0 else float(np.nextafter(np.float32(gsel), np.float32(-np.inf)))
+    kind = rng.choice(["planted", "alike", "duplicates", "scaled"])
+    g = torch.Generator(device="cuda")
+    g.manual_seed(int(rng.integers(1 << 30)))
+    b = torch.randn((m, d), generator=g, device="cuda")
+    pick = torch.randint(0, m, (n,), generator=g, device="cuda")
+    q = b[pick] + float(rng.choice([0.1, 0.3, 0.6])) * torch.randn((n, d), generator=g, device="cuda")
+    if kind == "alike":
+        base = torch.randn((1, d), generator=g, device="cuda")
+        b = base + 0.3 * b
+        q = base + 0.3 * q
+    elif kind == "duplicates":
+        b = b[torch.randint(0, max(1, m // 50), (m,), generator=g, device="cuda")].clone()
+        q = b[pick].clone()
+    elif kind == "scaled":   # blocks of very different magnitude inside a row: the block scales do the work
+        b[:, : d // 4] *= 1e-3
+        b[:, d // 2:] *= 30.0
+        q[:, : d // 4] *= 1e-3
+        q[:, d // 2:] *= 30.0
+    q[torch.rand(n, generator=g, device="cuda") < 0.3] = torch.randn((d,), generator=g, device="cuda")
+    q, b = q.contiguous(), b.contiguous()
+    qb = torch.empty(lib.vfm_match_prepared_bytes(n, d), dtype=torch.uint8, device="cuda")
+    bb = torch.empty(lib.vfm_match_prepared_bytes(m, d), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.vfm_match_prepare2_gated_p(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, PREPARE_MX6, st))
+    res = {}
+    for records in (0, RECORDS_MX6):
+        idx = torch.empty(n, dtype=torch.int64, device="cuda")
+        sim = torch.empty(n, dtype=torch.float32, device="cuda")
+        _lib.check(lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, gate, st))
+        _lib.check(lib.vfm_match_search_finish_gated_r(q.data_ptr(), qb.data_ptr(), n, b.data_ptr(), bb.data_ptr(), m, d, idx.data_ptr(),
+                                                       sim.data_ptr(), ws.data_ptr(), ws.numel(), gate, records, st))
+        torch.cuda.synchronize()
+        res[records] = (idx, sim)
+    (i0, s0), (i, s) = res[0], res[RECORDS_MX6]
+    both = (i >= 0) & (i0 >= 0)
+    ok = bool(torch.equal(i[both], i0[both]) and torch.equal(s[both], s0[both]))
+    ok &= bool((s0[(i0 >= 0) & (i < 0)] < gate).all()) and bool((s[(i >= 0) & (i0 < 0)] < gate).all())
+    keep, keep0 = s >= gate, s0 >= gate
+    ok &= bool(torch.equal(keep, keep0) and torch.equal(i[keep], i0[keep0]))
+    if gate == float("-inf"):
+        ok &= bool((i >= 0).all() and (i0 >= 0).all())
+    return ok, f"d {d} n {n} m {m} gate {gate:.3f} {kind}: kept {int(keep0.sum())}, resolved int8 / fp6 {int((i0 >= 0).sum())}/{int((i >= 0).sum())}"
+
+
+def test_mx6_pass_randomised_soak_fixed_seed():
+    lib = _lib.load()
+    rng = np.random.default_rng(20260930)
+    st = torch.cuda.current_stream().cuda_stream
+    bad = []
+    for t in range(12):
+        ok, desc = soak_trial_mx6(lib, rng, st)
+        if not ok:
+            bad.append(desc)
+    assert not bad, bad
