@@ -259,7 +259,8 @@ def pass_name(pipe):
     if not pipe.use_i8:
         return "fp16"
     if getattr(pipe, "mx6", False):
-        return "fp6 (MX e2m3), full width, best-score records (VFM_RECORDS_MX6)"
+        return ("fp6 (MX e2m3), full width, packed top-2 records (VFM_RECORDS_MX6_TOP2)" if getattr(pipe, "mx6_top2", False)
+                else "fp6 (MX e2m3), full width, best-score records (VFM_RECORDS_MX6)")
     return "int8, half-width (VFM_RECORDS_HALF)" if pipe.half else ("int8, packed top-2 records" if pipe.top2 else "int8, best-score records")
 
 

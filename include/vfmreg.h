@@ -174,6 +174,11 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
  *                     descriptors' energy is spread over the columns.  Needs operands prepared with VFM_PREPARE_MX6;
  *                     exists for d = 256 / 384 with more than 2048 queries, elsewhere it behaves as VFM_RECORDS_BEST. */
 #define VFM_RECORDS_MX6 5
+/*   VFM_RECORDS_MX6_TOP2  the fp6 pass with packed top-2 records (best and second-best score of the chunk plus the best row's
+ *                     index): as VFM_RECORDS_TOP2 is to VFM_RECORDS_BEST -- a candidate chunk whose second-best row cannot reach
+ *                     the bound costs one fp32 row instead of a rescan, which is what the fp6 pass's wider bounds need on
+ *                     duplicate-rich maps.  Same operands and limits as VFM_RECORDS_MX6; elsewhere it behaves as VFM_RECORDS_TOP2. */
+#define VFM_RECORDS_MX6_TOP2 6
 int vfm_match_search_coarse_gated_r(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
                                     int d, void *ws, size_t ws_bytes, int records, vfm_stream_t stream);
 /* _coarse_gated_r with the gate of the search (needed by VFM_RECORDS_HALF_FUSED; ignored by the other kinds) */

@@ -15,6 +15,7 @@ from .test_gpu_int8 import _gate_contract, _heavy_tailed  # noqa: E402
 
 PREPARE_MX6 = 8
 RECORDS_MX6 = 5
+RECORDS_MX6_TOP2 = 6
 E2M3 = np.array(sorted({(mm / 8 if e == 0 else (1 + mm / 8) * 2 ** (e - 1)) for e in range(4) for mm in range(8)}))
 
 
@@ -142,11 +143,12 @@ def test_mx6_pass_gives_the_oracle_answers_and_keeps_the_gate_contract(d, n, m):
         ridx, rsim = orc.match_ip_top1(qn, bn)
         qd, bd = torch.from_numpy(qq).cuda(), torch.from_numpy(bb).cuda()
         for g in (gate, float("-inf")):
-            idx, sim = _search(qd, bd, g, RECORDS_MX6)
-            solved = _gate_contract(idx, sim, ridx, rsim, g)
-            if g == float("-inf"):
-                assert solved.all(), name
-            assert solved[rsim >= 0.8].all(), name
+            for records in (RECORDS_MX6, RECORDS_MX6_TOP2):
+                idx, sim = _search(qd, bd, g, records)
+                solved = _gate_contract(idx, sim, ridx, rsim, g)
+                if g == float("-inf"):
+                    assert solved.all(), (name, records)
+                assert solved[rsim >= 0.8].all(), (name, records)
 
 
 def test_mx6_pipeline_mode_equals_the_oracle_registration():
@@ -160,8 +162,8 @@ def test_mx6_pipeline_mode_equals_the_oracle_registration():
     keep = ~(rsim.astype(np.float64) < 0.8)
     corres = np.stack([np.nonzero(keep)[0], ridx[keep]], 1).astype(np.int32)
     ref = orc.ransac_corr(p["q_xyz"].cpu().numpy(), p["b_xyz"].cpu().numpy(), corres, 10000.0, 2000, seed=42)
-    for overlap in (False, True):
-        pipe = RegistrationPipeline(n, m, d, n_iter=2000, overlap_ransac=overlap, overlap_prepare=overlap, solve_streams=2, coarse="mx6")
+    for overlap, mode in ((False, "mx6"), (True, "mx6"), (True, "mx6-top2")):
+        pipe = RegistrationPipeline(n, m, d, n_iter=2000, overlap_ransac=overlap, overlap_prepare=overlap, solve_streams=2, coarse=mode)
         for _ in range(3):
             out = pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
         pipe.synchronize()
@@ -209,7 +211,7 @@ def soak_trial_mx6(lib, rng, st):
     ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=torch.uint8, device="cuda")
     _lib.check(lib.vfm_match_prepare2_gated_p(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, PREPARE_MX6, st))
     res = {}
-    for records in (0, RECORDS_MX6):
+    for records in (0, RECORDS_MX6, RECORDS_MX6_TOP2):
         idx = torch.empty(n, dtype=torch.int64, device="cuda")
         sim = torch.empty(n, dtype=torch.float32, device="cuda")
         _lib.check(lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, gate, st))
@@ -217,15 +219,19 @@ def soak_trial_mx6(lib, rng, st):
                                                        sim.data_ptr(), ws.data_ptr(), ws.numel(), gate, records, st))
         torch.cuda.synchronize()
         res[records] = (idx, sim)
-    (i0, s0), (i, s) = res[0], res[RECORDS_MX6]
-    both = (i >= 0) & (i0 >= 0)
-    ok = bool(torch.equal(i[both], i0[both]) and torch.equal(s[both], s0[both]))
-    ok &= bool((s0[(i0 >= 0) & (i < 0)] < gate).all()) and bool((s[(i >= 0) & (i0 < 0)] < gate).all())
-    keep, keep0 = s >= gate, s0 >= gate
-    ok &= bool(torch.equal(keep, keep0) and torch.equal(i[keep], i0[keep0]))
-    if gate == float("-inf"):
-        ok &= bool((i >= 0).all() and (i0 >= 0).all())
-    return ok, f"d {d} n {n} m {m} gate {gate:.3f} {kind}: kept {int(keep0.sum())}, resolved int8 / fp6 {int((i0 >= 0).sum())}/{int((i >= 0).sum())}"
+    (i0, s0) = res[0]
+    ok = True
+    for records in (RECORDS_MX6, RECORDS_MX6_TOP2):
+        i, s = res[records]
+        both = (i >= 0) & (i0 >= 0)
+        ok &= bool(torch.equal(i[both], i0[both]) and torch.equal(s[both], s0[both]))
+        ok &= bool((s0[(i0 >= 0) & (i < 0)] < gate).all()) and bool((s[(i >= 0) & (i0 < 0)] < gate).all())
+        keep, keep0 = s >= gate, s0 >= gate
+        ok &= bool(torch.equal(keep, keep0) and torch.equal(i[keep], i0[keep0]))
+        if gate == float("-inf"):
+            ok &= bool((i >= 0).all() and (i0 >= 0).all())
+    return ok, (f"d {d} n {n} m {m} gate {gate:.3f} {kind}: kept {int((s0 >= gate).sum())}, resolved int8 / fp6 / fp6 top-2 "
+                f"{int((i0 >= 0).sum())}/{int((res[RECORDS_MX6][0] >= 0).sum())}/{int((res[RECORDS_MX6_TOP2][0] >= 0).sum())}")
 
 
 def test_mx6_pass_randomised_soak_fixed_seed():

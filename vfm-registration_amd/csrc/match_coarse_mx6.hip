@@ -49,7 +49,13 @@ __device__ __forceinline__ floatx16 mfma_mx6(const Mx6Frag& x, const uint2& xs, 
                                                            (int)(S < 4 ? ys.x : ys.y));
 }
 
-template <int KS6, bool LOW = true>
+// TOP2: packed top-2 records (VFM_RECORDS_MX6_TOP2).  The accumulators then start at 2.0 (an inline constant too): scores of unit
+// rows stay in [0.9, 3.1], positive floats whose bit patterns order like the values, and coarse_fold -- the fp16 pass's: low six
+// bits replaced by the row code, running best / second best by max / med3 -- works on them as it stands.  At the end of a
+// chunk the two packed values become fixed-point integers, each rounded UP from the top of its packing interval (64 ulp of 4 =
+// 1.5e-5): the selection reads record | 127 / | 63 as upper bounds, and the lower bound (record & ~127) can exceed the truth by
+// at most that interval, which MX6_SLACK covers.
+template <int KS6, bool TOP2 = false, bool LOW = true>
 __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVES = 8, T = 4;
@@ -108,6 +114,8 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
     const uint4* gnext = gsrc + (size_t)2 * T * TILE_U4;
 
     float s1[2] = {-__builtin_inff(), -__builtin_inff()};   // the scores are floats: v_max3_f32 folds them as they are
+    unsigned t1[2] = {0u, 0u}, t2[2] = {0u, 0u};            // TOP2: running best / second best, packed (coarse_fold)
+    constexpr float ACC0 = TOP2 ? 2.0f : 0.0f;
     auto emit_chunk = [&](int chunk) __attribute__((always_inline)) {  // chunk < 0: nothing folded yet
         float sb = 0.f, be = 0.f;
         const bool counted = LOW && chunk >= 0;  // wave-uniform
@@ -118,11 +126,32 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
         const bool padded = chunk >= a.first_pad_chunk;   // zero-padded rows score exactly 0
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            // the lane's best fp32 score of the chunk -> fixed point, rounded up
-            const int fix = (int)ceilf(fmaxf(s1[j], -4.0f) * 1048576.0f);
-            unsigned rec = (unsigned)(fix + I8_OFFSET);
-            const unsigned best = coarse_emit_chunk_best(a, rec, qt0 + j, chunk);
-            s1[j] = -__builtin_inff();
+            unsigned best;
+            if constexpr (TOP2) {
+                // merge the two half-waves (coarse_emit_chunk's rule: the larger packed value, ties to the lower half), then to
+                // fixed point
+                const int lane_ = lane_id(), hi = lane_ >> 5;
+                const unsigned o1 = __shfl_xor(t1[j], 32), o2 = __shfl_xor(t2[j], 32);
+                const bool own = (t1[j] > o1) || (t1[j] == o1 && hi == 0);
+                const unsigned w1 = own ? t1[j] : o1;
+                const int wh = own ? hi : (1 - hi);
+                const unsigned w2 = max(max(t2[j], o2), min(t1[j], o1));
+                const int code = 63 - (int)(w1 & 63u);
+                const int li = (code >> 4) * 32 + (code & 3) + 8 * ((code & 15) >> 2) + 4 * wh;  // row inside the chunk
+                const int f1 = (int)ceilf((fmaxf(__uint_as_float(w1 | 63u), 0.0f) - 2.0f) * 1048576.0f) + I8_OFFSET;
+                const int f2 = (int)ceilf((fmaxf(__uint_as_float(w2 | 63u), 0.0f) - 2.0f) * 1048576.0f) + I8_OFFSET;
+                if (lane_ < 32 && qt0 + j < a.nq_tiles && chunk >= 0)
+                    a.partials[((size_t)(qt0 + j) * a.nchunks + (size_t)chunk) * 32 + lane_] = make_uint2(((unsigned)f1 & ~127u) | (unsigned)li, (unsigned)f2);
+                t1[j] = 0u;
+                t2[j] = 0u;
+                best = (unsigned)f1 & ~127u;
+            } else {
+                // the lane's best fp32 score of the chunk -> fixed point, rounded up
+                const int fix = (int)ceilf(fmaxf(s1[j], -4.0f) * 1048576.0f);
+                unsigned rec = (unsigned)(fix + I8_OFFSET);
+                best = coarse_emit_chunk_best(a, rec, qt0 + j, chunk);
+                s1[j] = -__builtin_inff();
+            }
             if (counted) {
                 const int sbest = (int)best - I8_OFFSET;
                 const float low = __builtin_fmaf(fx_sq[j] * sb, (float)sbest, -(fx_A[j] + fx_mult[j] * be));
@@ -135,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accA[j][r] = accB[j][r] = -__builtin_inff();   // (folded into s1 by the first tile: no effect)
+        for (int r = 0; r < 16; ++r) accA[j][r] = accB[j][r] = TOP2 ? 0.0f : -__builtin_inff();   // (folded by the first tile: no effect)
 
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
@@ -165,10 +194,10 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
             sc_nxt = mx6_scales(tn);
             auto kstep = [&](auto Sc) __attribute__((always_inline)) {
                 constexpr int s = decltype(Sc)::value;
-                if constexpr (s == 0) {   // the tile's first MFMAs start from the inline constant 0: no accumulator to clear
+                if constexpr (s == 0) {   // the tile's first MFMAs start from an inline constant (0, or 2.0): no accumulator to clear
                     floatx16 zero;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
+                    for (int r = 0; r < 16; ++r) zero[r] = ACC0;
                     acc[0] = mfma_mx6<s>(fr[s % PF], sc_cur, qf[0][s], qs[0], zero);
                     acc[1] = mfma_mx6<s>(fr[s % PF], sc_cur, qf[1][s], qs[1], zero);
                 } else {
@@ -181,7 +210,10 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
                 asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
                 fr[s % PF] = (s + PF < KS6) ? mx6_frag(tb, s + PF) : mx6_frag(tn, s + PF - KS6);
 #pragma unroll
-                for (int e = s * 32 / KS6; e < (s + 1) * 32 / KS6; ++e) s1[e >> 4] = fmaxf(s1[e >> 4], done[e >> 4][e & 15]);
+                for (int e = s * 32 / KS6; e < (s + 1) * 32 / KS6; ++e) {   // `done` is tile (J + 3) & 3 of its chunk
+                    if constexpr (TOP2) coarse_fold(t1[e >> 4], t2[e >> 4], done[e >> 4][e & 15], ((J + 3) & 3) * 16 + (e & 15));
+                    else s1[e >> 4] = fmaxf(s1[e >> 4], done[e >> 4][e & 15]);
+                }
                 if ((J == 0 && s < EARLY) || (J == 3 && s < LATE)) {  // one 1 KiB piece per k-step
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) {
@@ -213,7 +245,10 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
         ring = ring1;
     }
 #pragma unroll
-    for (int e = 0; e < 32; ++e) s1[e >> 4] = fmaxf(s1[e >> 4], accB[e >> 4][e & 15]);
+    for (int e = 0; e < 32; ++e) {
+        if constexpr (TOP2) coarse_fold(t1[e >> 4], t2[e >> 4], accB[e >> 4][e & 15], 3 * 16 + (e & 15));
+        else s1[e >> 4] = fmaxf(s1[e >> 4], accB[e >> 4][e & 15]);
+    }
     emit_chunk(c0 + (ntiles >> 2) - 1);
     if constexpr (LOW) {
 #pragma unroll
@@ -222,16 +257,16 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
     }
 }
 
-template <int KS6>
+template <int KS6, bool TOP2>
 int launch_mx6q2(const CoarseArgs& a, hipStream_t st) {
     const int lds = 12 * (2 * KS6) * 1024;
     static unsigned long long attr_set = 0ull;  // one bit per device
     if (!attr_done(attr_set)) {
-        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_mx6q2_kernel<KS6, true>),
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_mx6q2_kernel<KS6, TOP2, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_mark(attr_set);
     }
-    hipLaunchKernelGGL((match_coarse_mx6q2_kernel<KS6, true>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((match_coarse_mx6q2_kernel<KS6, TOP2, true>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
     return VFM_OK;
 }
 
@@ -239,11 +274,12 @@ int launch_mx6q2(const CoarseArgs& a, hipStream_t st) {
 
 // the fp6 coarse kernel for the arguments do_search_coarse prepared (a.Qh / a.Bh = the fp6 tiles, a.ib = mx6_bounds);
 // d = 256 / 384 and more than 2048 queries (effective_records)
-int launch_coarse_mx6(CoarseArgs& a, int d, hipStream_t st) {
+int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, hipStream_t st) {
     a.nqb = (a.nq_tiles + 15) / 16;
     a.nslices = choose_slices(a.nqb, a.nchunks);
     if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
-    const int rc = d == 384 ? launch_mx6q2<6>(a, st) : launch_mx6q2<4>(a, st);
+    const int rc = d == 384 ? (top2 ? launch_mx6q2<6, true>(a, st) : launch_mx6q2<6, false>(a, st))
+                            : (top2 ? launch_mx6q2<4, true>(a, st) : launch_mx6q2<4, false>(a, st));
     if (rc) return rc;
     VFM_CHECK_LAUNCH("match_coarse_mx6q2_kernel");
     if (g_prof_stop) VFM_CHECK_HIP(hipEventRecord(g_prof_stop, st));

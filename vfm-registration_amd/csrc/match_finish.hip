@@ -1553,8 +1553,11 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
         const int chunk_lds = i8 && (size_t)a.nchunks * sizeof(float2) <= 63 * 1024;  // (step, max E) of every chunk in LDS
         bool use_bins = false;
         // best-score records with many queries per map chunk: the rescan runs chunk-major (match_rescan_chunk_kernel)
-        const bool mx6 = i8 && records == VFM_RECORDS_MX6;   // best-score records of the fp6 pass: its own bounds in the selection
-        const bool best = i8 && (records == VFM_RECORDS_BEST || mx6) && g_select_variant != 1;
+        // records of the fp6 pass: its own bounds in the selection; behind it the int8 image and bounds, as for the int8 kinds
+        const bool mx6 = i8 && (records == VFM_RECORDS_MX6 || records == VFM_RECORDS_MX6_TOP2);
+        const bool top2 = i8 && (records == VFM_RECORDS_TOP2 || records == VFM_RECORDS_MX6_TOP2);
+        if (mx6) records = top2 ? VFM_RECORDS_TOP2 : VFM_RECORDS_BEST;
+        const bool best = i8 && records == VFM_RECORDS_BEST && g_select_variant != 1;
         use_bins = (best || half) && g_select_variant != 2 && n >= 4 * (int64_t)a.nchunks;
         if (fused) {
             // (nothing to select)
@@ -1565,10 +1568,10 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                                (const float*)Q.rest, (const float*)B.grest, gate, half_lds, w.cand_cnt, w.cand, w.cap, w.fb_count,
                                w.fb_list, g_match_stats, use_bins ? w.bin_cnt : (unsigned*)nullptr, use_bins ? w.bins : (int*)nullptr,
                                w.bin_cap);
-        } else if (i8 && records == VFM_RECORDS_TOP2 && g_select_variant != 1) {
+        } else if (top2 && g_select_variant != 1) {
             hipLaunchKernelGGL(match_select_top2_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * SELECT_TOP2_WAVES),
                                chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, (const uint2*)w.partials, a.nchunks, n,
-                               a.first_pad_chunk, (const unsigned*)w.qmax, Q.inv, i8_bounds(Q, B, true, records), gate, chunk_lds,
+                               a.first_pad_chunk, (const unsigned*)w.qmax, Q.inv, mx6 ? mx6_bounds(Q, B, 1) : i8_bounds(Q, B, true, records), gate, chunk_lds,
                                w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
         } else if (best) {
             hipLaunchKernelGGL(match_select_best_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * SELECT_BEST_WAVES),
@@ -1580,7 +1583,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
         } else
         hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS),
                            chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, w.partials, a.nchunks, a.npad, n, a.first_pad_chunk, w.qmax,
-                           Q.inv, DEFAULT_WINDOW, mx6 ? mx6_bounds(Q, B) : i8_bounds(Q, B, i8, records), gate, chunk_lds, w.cand_cnt, w.cand, w.cap,
+                           Q.inv, DEFAULT_WINDOW, mx6 ? mx6_bounds(Q, B, top2 ? 1 : 0) : i8_bounds(Q, B, i8, records), gate, chunk_lds, w.cand_cnt, w.cand, w.cap,
                            w.fb_count, w.fb_list, g_match_stats);
         VFM_CHECK_LAUNCH("match_select_kernel");
         if (i8) {  // candidate chunks -> candidate rows (the record buffer of the fp16 pass is free: it holds the hit lists)

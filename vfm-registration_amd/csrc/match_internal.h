@@ -361,6 +361,7 @@ inline int effective_records(int records, int d, int64_t n, int64_t m) {
     if (records == VFM_RECORDS_HALF_FUSED && !((d == 256 || d == 384) && n > 2048 && n >= 4 * ((m + CHUNK_ROWS - 1) / CHUNK_ROWS)))
         records = VFM_RECORDS_HALF;
     if (records == VFM_RECORDS_MX6 && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_BEST;   // (the one-set kernels have no fp6 form)
+    if (records == VFM_RECORDS_MX6_TOP2 && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_TOP2;
     return (records == VFM_RECORDS_HALF && !half_capable(d, n)) ? VFM_RECORDS_BEST : records;
 }
 
@@ -469,7 +470,7 @@ inline I8Bounds i8_bounds(const Prepared& Q, const Prepared& B, bool on, int top
     return on ? I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr, top2 == VFM_RECORDS_TOP2 ? 1 : 0} : I8Bounds{nullptr, nullptr, nullptr, nullptr, 0};
 }
 // bounds of the fp6 records (selection only: the rescans score the int8 image and use i8_bounds)
-inline I8Bounds mx6_bounds(const Prepared& Q, const Prepared& B) { return I8Bounds{Q.err6, Q.gstep6, B.gstep6, B.gerr6, 0}; }
+inline I8Bounds mx6_bounds(const Prepared& Q, const Prepared& B, int top2 = 0) { return I8Bounds{Q.err6, Q.gstep6, B.gstep6, B.gerr6, top2}; }
 CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, int64_t n, int64_t m, int qblock = QBLOCK);
 
 // match_prep.hip
@@ -482,7 +483,7 @@ int do_prepare_perm(const float* x, int64_t rows, const int* perm, int d, void* 
 // match_coarse_f16.hip / match_coarse_i8.hip: launch the coarse kernel for arguments prepared by do_search_coarse
 int launch_coarse_f16(const CoarseArgs& a, int d, hipStream_t st);
 int launch_coarse_int8(CoarseArgs& a, int d, int64_t n, int records, hipStream_t st);
-int launch_coarse_mx6(CoarseArgs& a, int d, hipStream_t st);   // match_coarse_mx6.hip
+int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, hipStream_t st);   // match_coarse_mx6.hip
 // match_api.hip
 int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, hipStream_t st,
                      bool bias_from_map_inv = false, bool inner_product = false, bool gated = false, int records = 0,

@@ -78,8 +78,8 @@ class RegistrationPipeline:
         # candidate chunk of a resolved query is rescanned), "int8-top2" = the same with packed top-2 records (+ ~0.15 ms of
         # kernel at C2; a chunk with one row inside the bounds costs one fp32 row instead of a 48 KB rescan), "fp16" = the
         # ungated family, "auto" = chosen from the searches' own feedback (_poll_feedback)
-        if coarse not in ("auto", "int8-half", "int8", "int8-top2", "mx6", "fp16"):
-            raise ValueError("coarse must be 'auto', 'int8-half', 'int8', 'int8-top2', 'mx6' or 'fp16'")
+        if coarse not in ("auto", "int8-half", "int8", "int8-top2", "mx6", "mx6-top2", "fp16"):
+            raise ValueError("coarse must be 'auto', 'int8-half', 'int8', 'int8-top2', 'mx6', 'mx6-top2' or 'fp16'")
         if coarse == "int8-half" and not gate:
             raise ValueError("the half-width pass needs the gate")
         self.coarse = coarse
@@ -87,7 +87,8 @@ class RegistrationPipeline:
         self.top2 = coarse == "int8-top2"   # int8 pass with packed top-2 records (VFM_RECORDS_TOP2)
         # the full-width coarse pass in microscaled fp6 (VFM_RECORDS_MX6: twice the int8 instruction's rate, ~3x wider bounds;
         # the operands are prepared with VFM_PREPARE_MX6); where the library has no kernel for it, best-score records
-        self.mx6 = coarse == "mx6"
+        self.mx6 = coarse in ("mx6", "mx6-top2")   # "mx6-top2": the same pass with packed top-2 records (VFM_RECORDS_MX6_TOP2)
+        self.mx6_top2 = coarse == "mx6-top2"
         # half-width pass (VFM_RECORDS_HALF): where the library has no kernel for it the call behaves as best-score records
         # ... and where almost every chunk survives its bound (descriptors that are all alike) it is slower than the full-width
         # modes -- bounded by the library's device-side guard (csrc/match_finish.hip: above 48 survivors per query the search falls
@@ -181,7 +182,7 @@ class RegistrationPipeline:
 
     def _records(self) -> int:
         if self.mx6:
-            return 5   # VFM_RECORDS_MX6
+            return 6 if self.mx6_top2 else 5   # VFM_RECORDS_MX6_TOP2 / VFM_RECORDS_MX6
         return self._half_kind if self.half else (1 if self.top2 else 0)   # 4 = VFM_RECORDS_HALF_FUSED (falls back to 3 / 0 inside the library)
 
     def synchronize(self) -> None:
@@ -242,7 +243,7 @@ class RegistrationPipeline:
                 # the preparation kernel's launch shape: persistent when it runs alone or beside the half-width coarse kernel
                 # (which leaves registers free), short workgroups beside the full-width one (include/vfmreg.h)
                 schedule = 1 if (records in (3, 4) or not (self.overlap and self.overlap_prepare)) else 2
-                if records == 5:
+                if records in (5, 6):
                     schedule |= 8   # VFM_PREPARE_MX6: the fp6 image as well
                 _lib.check(lib.vfm_match_prepare2_gated_p(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
                                                           r.qprep.data_ptr(), self.d, schedule, pst), "prepare(map + scan)")
