@@ -261,6 +261,8 @@ def pass_name(pipe):
     if getattr(pipe, "mx6", False):
         return ("fp6 (MX e2m3), full width, packed top-2 records (VFM_RECORDS_MX6_TOP2)" if getattr(pipe, "mx6_top2", False)
                 else "fp6 (MX e2m3), full width, best-score records (VFM_RECORDS_MX6)")
+    if pipe.half and getattr(pipe, "mx6_half", False):
+        return "fp6 (MX e2m3), half-width (VFM_RECORDS_MX6_HALF)"
     return "int8, half-width (VFM_RECORDS_HALF)" if pipe.half else ("int8, packed top-2 records" if pipe.top2 else "int8, best-score records")
 
 
@@ -268,7 +270,7 @@ def roofline_of(pipe, n, m, d, coarse_ms):
     """MFMA roofline entry of the coarse kernel a pipeline ran: operations AS LAUNCHED over the mean launch duration."""
     kcols = d // 2 if (pipe.use_i8 and pipe.half) else d
     flops = 2.0 * n * m * kcols
-    peak = MFMA_F6_PEAK_TFLOPS if getattr(pipe, "mx6", False) else (MFMA_I8_PEAK_TOPS if pipe.use_i8 else MFMA_F16_PEAK_TFLOPS)
+    peak = MFMA_F6_PEAK_TFLOPS if (getattr(pipe, "mx6", False) or (pipe.half and getattr(pipe, "mx6_half", False))) else (MFMA_I8_PEAK_TOPS if pipe.use_i8 else MFMA_F16_PEAK_TFLOPS)
     return {"bound": "mfma", "flops_per_launch": flops, "avg_launch_ms": coarse_ms, "achieved": flops / (coarse_ms * 1e-3) / 1e12,
             "peak": peak, "unit": "TFLOP/s", "frac": flops / (coarse_ms * 1e-3) / 1e12 / peak,
             "columns_multiplied": kcols, "all_pairs_product_flops": 2.0 * n * m * d}

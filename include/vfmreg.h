@@ -116,8 +116,8 @@ int vfm_match_prepare2_gated(const float *x1, int64_t rows1, void *prepared1, co
 #define VFM_PREPARE_PERSISTENT 1
 #define VFM_PREPARE_INTERLEAVED 2
 /*   VFM_PREPARE_MX6          flag, or-ed into `schedule`: write the fp6 image (d = 256 / 384; what VFM_RECORDS_MX6 searches
- *                            read) INSTEAD of the half-width one: operands prepared this way serve VFM_RECORDS_BEST / _TOP2 /
- *                            _MX6 searches, not VFM_RECORDS_HALF / _HALF_FUSED ones nor the probe.  About twice the
+ *                            read) INSTEAD of the int8 half-width one: operands prepared this way serve VFM_RECORDS_BEST / _TOP2 /
+ *                            _MX6* searches, not VFM_RECORDS_HALF / _HALF_FUSED ones nor the probe.  About twice the
  *                            preparation time (0.2 against 0.1 ms at C2 size): the image is converted from an fp16 copy of
  *                            the rows behind the int8 one.  Ignored for other widths. */
 #define VFM_PREPARE_MX6 8
@@ -179,6 +179,12 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
  *                     the bound costs one fp32 row instead of a rescan, which is what the fp6 pass's wider bounds need on
  *                     duplicate-rich maps.  Same operands and limits as VFM_RECORDS_MX6; elsewhere it behaves as VFM_RECORDS_TOP2. */
 #define VFM_RECORDS_MX6_TOP2 6
+/*   VFM_RECORDS_MX6_HALF  the half-width pass in fp6: VFM_RECORDS_HALF's bound -- score over the first d / 2 columns + the
+ *                     image's quantisation bound + |rest of the query| * max |rest of a row of the chunk| against the gate -- on the
+ *                     scaled MFMA, over the first d / 64 / 2 k-steps of the fp6 image (no second image).  Needs a finite gate
+ *                     and operands prepared with VFM_PREPARE_MX6; behind the selection it is VFM_RECORDS_HALF (device-side guard
+ *                     included).  d = 256 / 384 with more than 2048 queries; elsewhere it behaves as VFM_RECORDS_BEST. */
+#define VFM_RECORDS_MX6_HALF 7
 int vfm_match_search_coarse_gated_r(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
                                     int d, void *ws, size_t ws_bytes, int records, vfm_stream_t stream);
 /* _coarse_gated_r with the gate of the search (needed by VFM_RECORDS_HALF_FUSED; ignored by the other kinds) */

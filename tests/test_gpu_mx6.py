@@ -16,6 +16,7 @@ from .test_gpu_int8 import _gate_contract, _heavy_tailed  # noqa: E402
 PREPARE_MX6 = 8
 RECORDS_MX6 = 5
 RECORDS_MX6_TOP2 = 6
+RECORDS_MX6_HALF = 7
 E2M3 = np.array(sorted({(mm / 8 if e == 0 else (1 + mm / 8) * 2 ** (e - 1)) for e in range(4) for mm in range(8)}))
 
 
@@ -143,7 +144,7 @@ def test_mx6_pass_gives_the_oracle_answers_and_keeps_the_gate_contract(d, n, m):
         ridx, rsim = orc.match_ip_top1(qn, bn)
         qd, bd = torch.from_numpy(qq).cuda(), torch.from_numpy(bb).cuda()
         for g in (gate, float("-inf")):
-            for records in (RECORDS_MX6, RECORDS_MX6_TOP2):
+            for records in (RECORDS_MX6, RECORDS_MX6_TOP2) + ((RECORDS_MX6_HALF,) if g > float("-inf") else ()):
                 idx, sim = _search(qd, bd, g, records)
                 solved = _gate_contract(idx, sim, ridx, rsim, g)
                 if g == float("-inf"):
@@ -162,7 +163,7 @@ def test_mx6_pipeline_mode_equals_the_oracle_registration():
     keep = ~(rsim.astype(np.float64) < 0.8)
     corres = np.stack([np.nonzero(keep)[0], ridx[keep]], 1).astype(np.int32)
     ref = orc.ransac_corr(p["q_xyz"].cpu().numpy(), p["b_xyz"].cpu().numpy(), corres, 10000.0, 2000, seed=42)
-    for overlap, mode in ((False, "mx6"), (True, "mx6"), (True, "mx6-top2")):
+    for overlap, mode in ((False, "mx6"), (True, "mx6"), (True, "mx6-top2"), (True, "mx6-half"), (False, "mx6-half")):
         pipe = RegistrationPipeline(n, m, d, n_iter=2000, overlap_ransac=overlap, overlap_prepare=overlap, solve_streams=2, coarse=mode)
         for _ in range(3):
             out = pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
@@ -211,7 +212,7 @@ def soak_trial_mx6(lib, rng, st):
     ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=torch.uint8, device="cuda")
     _lib.check(lib.vfm_match_prepare2_gated_p(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, PREPARE_MX6, st))
     res = {}
-    for records in (0, RECORDS_MX6, RECORDS_MX6_TOP2):
+    for records in (0, RECORDS_MX6, RECORDS_MX6_TOP2) + ((RECORDS_MX6_HALF,) if gate > float("-inf") else ()):
         idx = torch.empty(n, dtype=torch.int64, device="cuda")
         sim = torch.empty(n, dtype=torch.float32, device="cuda")
         _lib.check(lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, gate, st))
@@ -221,7 +222,9 @@ def soak_trial_mx6(lib, rng, st):
         res[records] = (idx, sim)
     (i0, s0) = res[0]
     ok = True
-    for records in (RECORDS_MX6, RECORDS_MX6_TOP2):
+    for records in (RECORDS_MX6, RECORDS_MX6_TOP2, RECORDS_MX6_HALF):
+        if records not in res:
+            continue
         i, s = res[records]
         both = (i >= 0) & (i0 >= 0)
         ok &= bool(torch.equal(i[both], i0[both]) and torch.equal(s[both], s0[both]))

@@ -102,12 +102,12 @@ def main():
         q, b = pair["q_desc"], pair["b_desc"]
         qb, bb = prepare(b, q, MX6)
         res = {}
-        for rec in (0, 5, 0, 5, 1, 6, 1, 6):
+        for rec in (0, 5, 0, 5, 1, 6, 7, 7):
             for _ in range(3):
                 out = search(q, b, qb, bb, gate, rec)
             res[rec] = out
         i0, s0 = res[0][0], res[0][1]
-        for rec in (5, 1, 6):
+        for rec in (5, 1, 6, 7):
             i, s = res[rec][0], res[rec][1]
             same = bool((i == i0).all() and (s == s0).all())
             print(f"{name:16s} records {rec}: coarse {res[rec][2]:.3f} ms finish {res[rec][3]:.3f} ms (records 0: {res[0][2]:.3f} + {res[0][3]:.3f}); "

@@ -55,7 +55,11 @@ __device__ __forceinline__ floatx16 mfma_mx6(const Mx6Frag& x, const uint2& xs, 
 // chunk the two packed values become fixed-point integers, each rounded UP from the top of its packing interval (64 ulp of 4 =
 // 1.5e-5): the selection reads record | 127 / | 63 as upper bounds, and the lower bound (record & ~127) can exceed the truth by
 // at most that interval, which MX6_SLACK covers.
-template <int KS6, bool TOP2 = false, bool LOW = true>
+// IMG_KS6 > KS6 (VFM_RECORDS_MX6_HALF): the pass runs over the first KS6 k-steps of an image whose tiles hold IMG_KS6 -- the
+// half-width pass in fp6.  A tile's first 2 KS6 unit rows are a prefix of the stored tile, so there is no second image: the
+// staging packs them into the ring unit row by unit row (wave w copies packed rows w, w + 8, ... of a step; packed row r is
+// unit row r % UNITS of tile r / UNITS), the queries' registers take the first KS6 k-steps, the scales sit in unit row 1 as ever.
+template <int KS6, bool TOP2 = false, bool LOW = true, int IMG_KS6 = KS6>
 __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVES = 8, T = 4;
@@ -64,8 +68,10 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
     constexpr int TILE_BYTES = TILE_U4 * 16;
     constexpr int PIECES = T * UNITS / NWAVES;  // 1 KiB pieces per wave per step: 6 (d = 384) or 4 (d = 256)
     constexpr int NBUF = 3 * T;
-    constexpr int PF = KS6 % 3 == 0 ? 3 : 2;    // fragment look-ahead in k-steps
-    static_assert(KS6 % PF == 0 && KS6 >= 2 * PF && PIECES <= 2 * T && (T * UNITS) % NWAVES == 0 && KS6 >= 3 && KS6 <= 8, "shape");
+    constexpr int IMG_TILE_U4 = 2 * IMG_KS6 * 64;   // stride of the stored tiles
+    constexpr int PF = KS6 % 3 == 0 ? 3 : 2;    // fragment look-ahead in k-steps (PF == KS6: every read is of the next tile)
+    static_assert(KS6 % PF == 0 && (KS6 >= 2 * PF || KS6 == PF) && PIECES <= 2 * T && (T * UNITS) % NWAVES == 0 && KS6 >= 2 && KS6 <= 6 &&
+                      IMG_KS6 >= KS6, "shape");
     static_assert(NBUF * TILE_BYTES <= 160 * 1024, "ring exceeds the LDS");
     // One barrier per step, between tiles 2 and 3.  A step of this kernel is half as long as the int8 kernel's for the same bytes
     // staged, so the staging loads need more of it: the pieces that lie inside tiles 0-2 of their step (EARLY of them) are
@@ -84,12 +90,18 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
     const int qt0 = (qb * NWAVES + wave) * 2;  // this wave's two 32-query tiles
 
     const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS unsigned char*)smem;
-    const uint4* gsrc = a.Bh + (size_t)c0 * 4 * TILE_U4 + wave * 64 + lane;
+    const uint4* gsrc = a.Bh + (size_t)c0 * 4 * IMG_TILE_U4 + lane;   // the step's first stored tile
     const unsigned ldst0 = lds_base + (unsigned)wave * 1024u;
+    // piece p of a step for this wave: packed unit row wave + 8 p = unit row r % UNITS of tile r / UNITS (contiguous when
+    // IMG_KS6 == KS6)
+    auto piece_src = [&](const uint4* step_base, int p) __attribute__((always_inline)) {
+        const int r = wave + NWAVES * p;
+        return step_base + (r / UNITS) * IMG_TILE_U4 + (r % UNITS) * 64;
+    };
     auto stage_step = [&](const uint4* src, unsigned ring_byte) {
 #pragma unroll
         for (int p = 0; p < PIECES; ++p)
-            glds16(src + p * NWAVES * 64, __builtin_amdgcn_readfirstlane(ldst0 + ring_byte + (unsigned)(p * NWAVES) * 1024u));
+            glds16(piece_src(src, p), __builtin_amdgcn_readfirstlane(ldst0 + ring_byte + (unsigned)(p * NWAVES) * 1024u));
     };
 
     Mx6Frag qf[2][KS6];
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int qt = qt0 + j < a.nq_tiles ? qt0 + j : 0;
-        const uint4* qsrc = a.Qh + (size_t)qt * TILE_U4 + lane;
+        const uint4* qsrc = a.Qh + (size_t)qt * IMG_TILE_U4 + lane;
 #pragma unroll
         for (int s = 0; s < KS6; ++s) qf[j][s] = mx6_frag(qsrc, s);
         qs[j] = mx6_scales(qsrc);
@@ -110,8 +122,8 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
         fx_low[j] = -__builtin_inff();
     }
     stage_step(gsrc, 0u);
-    if (ntiles > T) stage_step(gsrc + (size_t)T * TILE_U4, (unsigned)(T * TILE_BYTES));
-    const uint4* gnext = gsrc + (size_t)2 * T * TILE_U4;
+    if (ntiles > T) stage_step(gsrc + (size_t)T * IMG_TILE_U4, (unsigned)(T * TILE_BYTES));
+    const uint4* gnext = gsrc + (size_t)2 * T * IMG_TILE_U4;
 
     float s1[2] = {-__builtin_inff(), -__builtin_inff()};   // the scores are floats: v_max3_f32 folds them as they are
     unsigned t1[2] = {0u, 0u}, t2[2] = {0u, 0u};            // TOP2: running best / second best, packed (coarse_fold)
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) {
                         const int p = J == 0 ? s : EARLY + s;
-                        glds16(gnext + p * NWAVES * 64,
+                        glds16(piece_src(gnext, p),
                                __builtin_amdgcn_readfirstlane(ldst0 + ring2 * TILE_BYTES + (unsigned)(p * NWAVES) * 1024u));
                     }
                 }
@@ -226,8 +238,8 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
             };
             kstep(std::integral_constant<int, 0>{});
             kstep(std::integral_constant<int, 1>{});
-            kstep(std::integral_constant<int, 2>{});
-            kstep(std::integral_constant<int, 3>{});
+            if constexpr (KS6 > 2) kstep(std::integral_constant<int, 2>{});
+            if constexpr (KS6 > 3) kstep(std::integral_constant<int, 3>{});
             if constexpr (KS6 > 4) {
                 kstep(std::integral_constant<int, 4>{});
                 kstep(std::integral_constant<int, 5>{});
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         tile(std::integral_constant<int, 3>{}, accB, accA);
-        gnext += T * TILE_U4;
+        gnext += T * IMG_TILE_U4;
         ring = ring1;
     }
 #pragma unroll
@@ -270,16 +282,32 @@ int launch_mx6q2(const CoarseArgs& a, hipStream_t st) {
     return VFM_OK;
 }
 
+// the half-width pass in fp6: the first d / 2 columns of the same image, best-score records, no running lower bound
+template <int KS6, int IMG_KS6>
+int launch_mx6q2_half(const CoarseArgs& a, hipStream_t st) {
+    const int lds = 12 * (2 * KS6) * 1024;
+    static unsigned long long attr_set = 0ull;  // one bit per device
+    if (!attr_done(attr_set)) {
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_mx6q2_kernel<KS6, false, false, IMG_KS6>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_mark(attr_set);
+    }
+    hipLaunchKernelGGL((match_coarse_mx6q2_kernel<KS6, false, false, IMG_KS6>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
+    return VFM_OK;
+}
+
 }  // namespace
 
 // the fp6 coarse kernel for the arguments do_search_coarse prepared (a.Qh / a.Bh = the fp6 tiles, a.ib = mx6_bounds);
 // d = 256 / 384 and more than 2048 queries (effective_records)
-int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, hipStream_t st) {
+int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, bool half, hipStream_t st) {
     a.nqb = (a.nq_tiles + 15) / 16;
     a.nslices = choose_slices(a.nqb, a.nchunks);
     if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
-    const int rc = d == 384 ? (top2 ? launch_mx6q2<6, true>(a, st) : launch_mx6q2<6, false>(a, st))
-                            : (top2 ? launch_mx6q2<4, true>(a, st) : launch_mx6q2<4, false>(a, st));
+    int rc;
+    if (half) rc = d == 384 ? launch_mx6q2_half<3, 6>(a, st) : launch_mx6q2_half<2, 4>(a, st);
+    else rc = d == 384 ? (top2 ? launch_mx6q2<6, true>(a, st) : launch_mx6q2<6, false>(a, st))
+                       : (top2 ? launch_mx6q2<4, true>(a, st) : launch_mx6q2<4, false>(a, st));
     if (rc) return rc;
     VFM_CHECK_LAUNCH("match_coarse_mx6q2_kernel");
     if (g_prof_stop) VFM_CHECK_HIP(hipEventRecord(g_prof_stop, st));

@@ -1543,7 +1543,9 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     if (i8 && !gated) records = VFM_RECORDS_TOP2;  // as do_search_coarse chose
     records = effective_records(records, d, n, m);
     const bool fused = i8 && records == VFM_RECORDS_HALF_FUSED;   // the coarse kernel has filled the bins already
-    const bool half = i8 && (records == VFM_RECORDS_HALF || fused);
+    const bool mx6half = i8 && records == VFM_RECORDS_MX6_HALF;   // the half-width pass on the fp6 image: its bounds in the selection
+    const bool half = i8 && (records == VFM_RECORDS_HALF || fused || mx6half);
+    if (mx6half) records = VFM_RECORDS_HALF;
     if (half && !(gate > -__builtin_inff())) return vfm_fail(VFM_EINVAL, "search_finish: VFM_RECORDS_HALF needs a finite gate");
     if (!i8 && use_sparse(d, n, m)) {
         hipLaunchKernelGGL(match_filter_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d,
@@ -1564,8 +1566,8 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
         } else if (half) {
             const int half_lds = (size_t)a.nchunks * 12 <= 63 * 1024;  // (step, max E, max |rest|) of every chunk in LDS
             hipLaunchKernelGGL(match_select_half_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * 8), half_lds ? (size_t)a.nchunks * 12 : 0,
-                               st, reinterpret_cast<const unsigned*>(w.partials), a.nchunks, n, Q.inv, i8_bounds(Q, B, true, records),
-                               (const float*)Q.rest, (const float*)B.grest, gate, half_lds, w.cand_cnt, w.cand, w.cap, w.fb_count,
+                               st, reinterpret_cast<const unsigned*>(w.partials), a.nchunks, n, Q.inv,
+                               mx6half ? mx6_bounds(Q, B) : i8_bounds(Q, B, true, records), (const float*)Q.rest, (const float*)B.grest, gate, half_lds, w.cand_cnt, w.cand, w.cap, w.fb_count,
                                w.fb_list, g_match_stats, use_bins ? w.bin_cnt : (unsigned*)nullptr, use_bins ? w.bins : (int*)nullptr,
                                w.bin_cap);
         } else if (top2 && g_select_variant != 1) {

@@ -362,6 +362,7 @@ inline int effective_records(int records, int d, int64_t n, int64_t m) {
         records = VFM_RECORDS_HALF;
     if (records == VFM_RECORDS_MX6 && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_BEST;   // (the one-set kernels have no fp6 form)
     if (records == VFM_RECORDS_MX6_TOP2 && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_TOP2;
+    if (records == VFM_RECORDS_MX6_HALF && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_BEST;   // (such operands carry no int8 half image)
     return (records == VFM_RECORDS_HALF && !half_capable(d, n)) ? VFM_RECORDS_BEST : records;
 }
 
@@ -483,7 +484,7 @@ int do_prepare_perm(const float* x, int64_t rows, const int* perm, int d, void* 
 // match_coarse_f16.hip / match_coarse_i8.hip: launch the coarse kernel for arguments prepared by do_search_coarse
 int launch_coarse_f16(const CoarseArgs& a, int d, hipStream_t st);
 int launch_coarse_int8(CoarseArgs& a, int d, int64_t n, int records, hipStream_t st);
-int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, hipStream_t st);   // match_coarse_mx6.hip
+int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, bool half, hipStream_t st);   // match_coarse_mx6.hip
 // match_api.hip
 int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, hipStream_t st,
                      bool bias_from_map_inv = false, bool inner_product = false, bool gated = false, int records = 0,

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
                 const int c = lane + 64 * i;
                 if (c < nchunks) {
                     const float nv[4] = {v[j][i].x, v[j][i].y, v[j][i].z, v[j][i].w};
-                    if (!MX6 && 8 * c >= d) r2 = r2 + (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] + nv[3] * nv[3]);  // columns >= d / 2
+                    if (8 * c >= d) r2 = r2 + (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] + nv[3] * nv[3]);  // columns >= d / 2
                     int qi[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
                 o.err[r] = en;
                 if (en > 0.0f) atomicMax(&emax_bits, __float_as_uint(en));
             }
-            if constexpr (!MX6) {   // (the MX6 form writes the fp6 image INSTEAD of the half-width one)
+            {   // (the MX6 form keeps these: VFM_RECORDS_MX6_HALF bounds the second half of the columns with them)
                 // |second half of the row|_2, rounded up like E (d / 2 + 8 roundings of 2^-24 on non-negative terms, one sqrtf);
                 // NaN / Inf elements -> Inf: nothing is ever pruned against such a row
                 float rn = sqrtf(scatter8(rpart)) * 1.000244140625f + 1.0e-30f;
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
         if (threadIdx.x == 0) {
             o.gstep[grp] = qstep;
             o.gerr[grp] = __uint_as_float(emax_bits);
-            if constexpr (!MX6) o.grest[grp] = __uint_as_float(rmax_bits);
+            o.grest[grp] = __uint_as_float(rmax_bits);
             if constexpr (MX6) {
                 o.gerr6[grp] = __uint_as_float(e6max_bits);
                 o.gstep6[grp] = MX6_FIX_STEP;

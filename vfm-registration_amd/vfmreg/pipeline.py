@@ -78,9 +78,9 @@ class RegistrationPipeline:
         # candidate chunk of a resolved query is rescanned), "int8-top2" = the same with packed top-2 records (+ ~0.15 ms of
         # kernel at C2; a chunk with one row inside the bounds costs one fp32 row instead of a 48 KB rescan), "fp16" = the
         # ungated family, "auto" = chosen from the searches' own feedback (_poll_feedback)
-        if coarse not in ("auto", "int8-half", "int8", "int8-top2", "mx6", "mx6-top2", "fp16"):
-            raise ValueError("coarse must be 'auto', 'int8-half', 'int8', 'int8-top2', 'mx6', 'mx6-top2' or 'fp16'")
-        if coarse == "int8-half" and not gate:
+        if coarse not in ("auto", "int8-half", "int8", "int8-top2", "mx6", "mx6-top2", "mx6-half", "fp16"):
+            raise ValueError("coarse must be 'auto', 'int8-half', 'int8', 'int8-top2', 'mx6', 'mx6-top2', 'mx6-half' or 'fp16'")
+        if coarse in ("int8-half", "mx6-half") and not gate:
             raise ValueError("the half-width pass needs the gate")
         self.coarse = coarse
         self.use_i8 = coarse != "fp16"
@@ -95,7 +95,9 @@ class RegistrationPipeline:
         # through to one full-width pass with the gate as hit test: 6.8 ms per C2-size registration against 1.9; before the
         # guard: 171 ms): "auto" therefore PROBES it (vfm_match_search_probe_half: its coarse pass + a count of the survivors,
         # +0.7 ms once) on the first registration and at every re-probe interval, and switches to it only on a good count
-        self.half = coarse == "int8-half"
+        self.half = coarse in ("int8-half", "mx6-half")
+        # the half-width pass in fp6 (VFM_RECORDS_MX6_HALF): the same bound on the scaled MFMA; operands prepared with VFM_PREPARE_MX6
+        self.mx6_half = coarse == "mx6-half"
         self._probe_due = coarse == "auto" and self.gate
         # which form of the half-width pass: with the selection fused into the coarse kernel (VFM_RECORDS_HALF_FUSED = 4: no
         # records, no selection kernel) a serial registration is 1.5 % faster (1017 vs 1002 registrations/s), but in the
@@ -122,6 +124,11 @@ class RegistrationPipeline:
                          for _ in range(max(1, self.n_solve))]
         self.rws = self.rws_list[0]
         self.ransac_stream = self.solve_streams[0] if self.overlap else None
+        # (tools/trace_pipe.sh: the preparation kernel needs whole compute units -- 1024 threads x 127 registers -- and so does a
+        # coarse workgroup: neither starts while the solve stage's small kernels sit on every compute unit, so a cycle is coarse
+        # kernel + ~0.2 ms of small kernels + preparation, whatever the streams allow.  Measured and dropped in round 3: a
+        # high-priority preparation stream (1000 vs 1380/s), a high-priority coarse stream, enqueueing the solve stage of
+        # registration i behind the preparation of i + 1 (the coarse kernel then waits for the same small kernels))
         self.prep_stream = torch.cuda.Stream(device=dev) if self.overlap else None
         self._step = 0
 
@@ -183,6 +190,8 @@ class RegistrationPipeline:
     def _records(self) -> int:
         if self.mx6:
             return 6 if self.mx6_top2 else 5   # VFM_RECORDS_MX6_TOP2 / VFM_RECORDS_MX6
+        if self.half and self.mx6_half:
+            return 7                           # VFM_RECORDS_MX6_HALF
         return self._half_kind if self.half else (1 if self.top2 else 0)   # 4 = VFM_RECORDS_HALF_FUSED (falls back to 3 / 0 inside the library)
 
     def synchronize(self) -> None:
@@ -242,8 +251,8 @@ class RegistrationPipeline:
             if i8 and not reuse_map:
                 # the preparation kernel's launch shape: persistent when it runs alone or beside the half-width coarse kernel
                 # (which leaves registers free), short workgroups beside the full-width one (include/vfmreg.h)
-                schedule = 1 if (records in (3, 4) or not (self.overlap and self.overlap_prepare)) else 2
-                if records in (5, 6):
+                schedule = 1 if (records in (3, 4, 7) or not (self.overlap and self.overlap_prepare)) else 2
+                if records in (5, 6, 7):
                     schedule |= 8   # VFM_PREPARE_MX6: the fp6 image as well
                 _lib.check(lib.vfm_match_prepare2_gated_p(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
                                                           r.qprep.data_ptr(), self.d, schedule, pst), "prepare(map + scan)")
