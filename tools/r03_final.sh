@@ -24,6 +24,9 @@ cp $R/gpurun_out/pmc_coarse/pmc_match_coarse.json $O/pmc_match_coarse_mx6.json 2
 for i in 1 2 3 4 5 6 7; do cp $R/gpurun_out/pmc_coarse/p${i}_counter_collection.csv $O/pmc_mx6_pass${i}_counter_collection.csv 2>/dev/null; done
 timeout 600 python tools/dev_mx6.py > $O/dev_mx6.txt 2>&1; tail -8 $O/dev_mx6.txt
 timeout 900 python tools/ab_mx6_bench.py > $O/ab_mx6_bench.txt 2>&1
+timeout 600 python tools/soak_mx6.py 40 303 2>&1 | tail -3 > $O/soak_mx6.txt; cat $O/soak_mx6.txt
+# what a cycle of the pipeline consists of: per-stream kernel timeline (int8 half-width, fp6 half-width), thin kernels beside the coarse kernels
+{ bash tools/trace_pipe.sh int8-half 2>&1 | tail -40; echo; bash tools/trace_pipe.sh mx6-half 2>&1 | tail -40; echo; timeout 300 python tools/corun_probe.py 2>&1 | tail -4; } > $O/pipeline_cycle.txt
 cd $R && timeout 900 python tools/time_neardup.py --steps 20 --out $O/neardup.json > $O/neardup.log 2>&1
 # row A6 (find_correspondences' mutual filter): timing, kernel sequence
 timeout 300 python tools/time_pairs.py 6 > $O/time_pairs.txt 2>&1; cat $O/time_pairs.txt

@@ -51,7 +51,7 @@ def main():
               "other_rows.txt": "r03_other_rows.txt", "time_c3_modes.txt": "r03_time_c3_modes.txt",
               "ab_vit_xcd.txt": "r03_ab_vit_xcd.txt", "prof_c3_one.txt": "r03_prof_c3_one.txt",
               "pmc_match_coarse_mx6.json": "r03_pmc_match_coarse_mx6.json", "dev_mx6.txt": "r03_dev_mx6.txt",
-              "ab_mx6_bench.txt": "r03_ab_mx6_bench.txt", "soak_half.txt": "r03_soak_half.txt", "soak_match.txt": "r03_soak_match.txt", "mx6_probe.txt": "r03_mx6_probe.txt"}
+              "ab_mx6_bench.txt": "r03_ab_mx6_bench.txt", "soak_mx6.txt": "r03_soak_mx6.txt", "pipeline_cycle.txt": "r03_pipeline_cycle.txt", "soak_half.txt": "r03_soak_half.txt", "soak_match.txt": "r03_soak_match.txt", "mx6_probe.txt": "r03_mx6_probe.txt"}
     for i in range(1, 8):
         copies[f"pmc_pass{i}_counter_collection.csv"] = f"r03_pmc_pass{i}_counter_collection.csv"
         copies[f"pmc_half_pass{i}_counter_collection.csv"] = f"r03_pmc_half_pass{i}_counter_collection.csv"
@@ -210,9 +210,16 @@ Pipelined (the bench's pipeline construction), coarse pass pinned, three kinds o
 {text('r03_ab_mx6_bench.txt')[-4500:]}
 ```
 
+## What a cycle of the pipeline consists of (`tools/trace_pipe.sh`, `tools/corun_probe.py`; DESIGN.md 0.9)
+
+```
+{text('r03_pipeline_cycle.txt')[-6000:]}
+```
+
 ## Soaks beyond the suite's fixed seeds
 
 `python tools/soak_half.py 40 303`: `{text('r03_soak_half.txt').splitlines()[-1] if (DST / 'r03_soak_half.txt').exists() else '?'}`;
+`python tools/soak_mx6.py 40 303`: `{text('r03_soak_mx6.txt').splitlines()[-1] if (DST / 'r03_soak_mx6.txt').exists() else '?'}`;
 `python tools/soak_match.py 16 303`: `{text('r03_soak_match.txt').splitlines()[-1] if (DST / 'r03_soak_match.txt').exists() else '?'}`.
 
 ## fp6 (MX e2m3) MFMA probe (`tools/probe/mx6_probe.hip`, `r03_mx6_probe.txt`)

@@ -44,4 +44,14 @@ for q, rs in sorted(by.items(), key=lambda kv: -len(kv[1])):
     print(f"queue {q}: {len(rs)} kernels, busy {busy:.2f} ms = {busy / nreg:.3f} ms per registration")
     for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:9]:
         print(f"      {k:46s} {v / nreg:8.1f} us per registration ({names[k] / nreg:.1f} launches)")
+print("timeline of two registrations (kernels longer than 8 us; unnamed = RANSAC / torch kernels):")
+allrows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+co = [i for i, r in enumerate(allrows) if "match_coarse" in r["Kernel_Name"]]
+sub = allrows[co[30]:co[32]]
+t00 = int(sub[0]["Start_Timestamp"])
+for r in sub:
+    nm = r["Kernel_Name"].replace("vfmm::(anonymous namespace)::", "").replace("void ", "").split("(")[0][:44]
+    a0, a1 = (int(r["Start_Timestamp"]) - t00) / 1e3, (int(r["End_Timestamp"]) - t00) / 1e3
+    if a1 - a0 > 8 or "coarse" in nm or "prep" in nm:
+        print(f"  queue {r['Queue_Id']} {a0:8.1f} -> {a1:8.1f} us ({a1 - a0:6.1f})  {nm}")
 PY
