@@ -1,4 +1,4 @@
-// match_coarse_mx6.hip -- the coarse pass of the matcher in microscaled fp6 (VFM_RECORDS_MX6): gfx950's scaled MFMA
+// match_coarse_mx6.hip -- the coarse pass of the matcher in microscaled fp6 (VFM_RECORDS_MX6, _MX6_TOP2, _MX6_HALF): gfx950's scaled MFMA
 // v_mfma_scale_f32_32x32x64_f8f6f4 on e2m3 operands with one E8M0 scale per 32 columns does twice the int8 instruction's
 // multiply-adds per cycle (32 cycles for 32 x 32 x 64; tools/probe/mx6_probe.hip: 6.4 PFLOP/s sustained on the whole chip
 // against 4.4 for int8).  The fp6 image of prep_chunk_kernel<., ., true> has the int8 image's tile geometry -- two 1 KiB unit
@@ -49,7 +49,8 @@ __device__ __forceinline__ floatx16 mfma_mx6(const Mx6Frag& x, const uint2& xs, 
                                                            (int)(S < 4 ? ys.x : ys.y));
 }
 
-// TOP2: packed top-2 records (VFM_RECORDS_MX6_TOP2).  The accumulators then start at 2.0 (an inline constant too): scores of unit
+// TOP2: packed top-2 records (VFM_RECORDS_MX6_TOP2).  The accumulators then start at 2.0 (a splat the compiler keeps in sixteen registers: unlike 0 it is not folded into the
+// instruction): scores of unit
 // rows stay in [0.9, 3.1], positive floats whose bit patterns order like the values, and coarse_fold -- the fp16 pass's: low six
 // bits replaced by the row code, running best / second best by max / med3 -- works on them as it stands.  At the end of a
 // chunk the two packed values become fixed-point integers, each rounded UP from the top of its packing interval (64 ulp of 4 =
