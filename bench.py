@@ -307,6 +307,14 @@ def c2_variants(dev, lib, pairs, steps, warmup, iters, streams):
                                 "value": v, "unit": "registrations/s", "steps": steps, "ms_per_step": msps, "coarse_pass": pass_name(pipe),
                                 "roofline": roofline_of(pipe, n, m, d, cms)}
     del pipe
+    pipe = build("mx6-half")
+    v, msps, cms, _ = timed_loop(lib, pipe, pairs, steps, warmup)
+    out["C2_half_width_mx6"] = {"workload": "C2, D.2 pairs, coarse pass pinned to the half-width pass in fp6 (VFM_RECORDS_MX6_HALF: the headline's bound on "
+                                            "the scaled MFMA, N M D operations per launch; the preparation writes the fp6 image too)",
+                                "value": v, "unit": "registrations/s", "steps": steps, "ms_per_step": msps, "coarse_pass": pass_name(pipe),
+                                "roofline": roofline_of(pipe, n, m, d, cms),
+                                "note": "the coarse kernel is a third shorter than the int8 half-width kernel; the rate is not: DESIGN.md 0.9"}
+    del pipe
     pipe = build("auto")
     v, msps, cms, _ = timed_loop(lib, pipe, pairs, 200, warmup, settle=4)
     out["C2_sustained"] = {"workload": "C2, D.2 pairs, the headline's pipeline over 200 timed steps", "value": v, "unit": "registrations/s",

@@ -119,6 +119,7 @@ The same pipeline away from the favourable case (VERDICT r2 item 2), same proces
 
 - {variant('C2_full_width')} -- `coarse="int8"` pinned: every column in the coarse pass, nothing depends on how the descriptors prune
 - {variant('C2_full_width_mx6')} -- `coarse="mx6"` pinned: the same all-pairs product in microscaled fp6 on the scaled MFMA (DESIGN.md 0.8), as data independent as the line above
+- {variant('C2_half_width_mx6')} -- `coarse="mx6-half"` pinned: the headline's bound in fp6 (coarse kernel 0.40 ms alone)
 - {variant('C2_sustained')} -- {ex.get('C2_sustained', {}).get('steps', '?')} steps instead of 20 (the first ~15 launches after a synchronise run slower)
 - {variant('C2_lifted')} -- map descriptors lifted from overlapping patch grids (near-duplicates), policy by feedback
 - `extra.A6_mutual_l2`: {json.dumps(a6)[:600]}
