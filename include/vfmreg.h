@@ -115,11 +115,12 @@ int vfm_match_prepare2_gated(const float *x1, int64_t rows1, void *prepared1, co
 #define VFM_PREPARE_DEFAULT 0
 #define VFM_PREPARE_PERSISTENT 1
 #define VFM_PREPARE_INTERLEAVED 2
-/*   VFM_PREPARE_MX6          flag, or-ed into `schedule`: write the fp6 image (d = 256 / 384; what VFM_RECORDS_MX6 searches
- *                            read) INSTEAD of the int8 half-width one: operands prepared this way serve VFM_RECORDS_BEST / _TOP2 /
- *                            _MX6* searches, not VFM_RECORDS_HALF / _HALF_FUSED ones nor the probe.  About twice the
- *                            preparation time (0.2 against 0.1 ms at C2 size): the image is converted from an fp16 copy of
- *                            the rows behind the int8 one.  Ignored for other widths. */
+/*   VFM_PREPARE_MX6          flag, or-ed into `schedule`: write the fp6 image as well (d = 256 / 384; what the VFM_RECORDS_MX6*
+ *                            searches read).  About twice the preparation time (0.2 against 0.1 ms at C2 size): the image is
+ *                            converted from an fp16 copy of the rows behind the int8 one.  Ignored for other widths.  An
+ *                            operand prepared WITHOUT the flag says so in its fp6 bounds (infinite): a search that asks for an
+ *                            fp6 record kind on it prunes nothing and ends in the exact all-pairs decision -- the oracle's
+ *                            answers, orders of magnitude slower -- rather than reading an image that is not there. */
 #define VFM_PREPARE_MX6 8
 int vfm_match_prepare2_gated_p(const float *x1, int64_t rows1, void *prepared1, const float *x2, int64_t rows2,
                                void *prepared2, int d, int schedule, vfm_stream_t stream);

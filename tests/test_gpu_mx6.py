@@ -247,3 +247,27 @@ def test_mx6_pass_randomised_soak_fixed_seed():
         if not ok:
             bad.append(desc)
     assert not bad, bad
+
+
+def test_fp6_record_kinds_on_operands_without_the_fp6_image_stay_correct_and_half_width_kinds_work_with_it():
+    """Misuse is safe: an operand prepared WITHOUT VFM_PREPARE_MX6 carries infinite fp6 bounds, so an fp6 record kind prunes
+    nothing on it and the exact decision (all-pairs fallback, or the guard's full-width pass for the half-width kind) gives the
+    oracle's answers; and an operand prepared WITH the flag still carries the int8 half-width image for VFM_RECORDS_HALF / _FUSED."""
+    d, n, m = 384, 2100, 1300
+    rng = np.random.default_rng(5)
+    gate = float(np.nextafter(np.float32(0.8), np.float32(-np.inf)))
+    b = rng.standard_normal((m, d)).astype(np.float32)
+    q = b[rng.integers(0, m, n)] + 0.3 * rng.standard_normal((n, d)).astype(np.float32)
+    q[::3] = rng.standard_normal((len(q[::3]), d)).astype(np.float32)
+    qn, _ = orc.l2norm_rows(q)
+    bn, _ = orc.l2norm_rows(b)
+    ridx, rsim = orc.match_ip_top1(qn, bn)
+    qd, bd = torch.from_numpy(q).cuda(), torch.from_numpy(b).cuda()
+    for records in (RECORDS_MX6, RECORDS_MX6_TOP2, RECORDS_MX6_HALF):
+        idx, sim = _search(qd, bd, gate, records, flags=0)          # no fp6 image
+        solved = _gate_contract(idx, sim, ridx, rsim, gate)
+        assert solved[rsim >= 0.8].all(), records
+    for records in (3, 4):
+        idx, sim = _search(qd, bd, gate, records, flags=PREPARE_MX6)   # fp6 image AND the int8 half-width one
+        solved = _gate_contract(idx, sim, ridx, rsim, gate)
+        assert solved[rsim >= 0.8].all(), records

@@ -281,6 +281,11 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
             if ((lane & 7) == 0) {
                 o.err[r] = en;
                 if (en > 0.0f) atomicMax(&emax_bits, __float_as_uint(en));
+                // no fp6 image in this form: its E says so -- a search that asks for an fp6 record kind on such an operand bounds
+                // nothing and ends in the exact all-pairs decision (correct, slow) instead of trusting stale bytes
+                if constexpr (!MX6) {
+                    if (o.err6) o.err6[r] = __builtin_inff();
+                }
             }
             {   // (the MX6 form keeps these: VFM_RECORDS_MX6_HALF bounds the second half of the columns with them)
                 // |second half of the row|_2, rounded up like E (d / 2 + 8 roundings of 2^-24 on non-negative terms, one sqrtf);
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
                 __builtin_nontemporal_store(tq.w, po + 3);
             }
         }
-        if constexpr (!MX6) {  // the first d / 2 columns again, as tiles of their own (the first half of every tile's units)
+        {  // the first d / 2 columns again, as tiles of their own (the first half of every tile's units)
             const int uh = (d >> 6) * 64;  // uint4 units per half tile
             uint4* dst = o.tiles8h + (int64_t)grp * (uh * 4);
             const uint4* src = reinterpret_cast<const uint4*>(img8);
@@ -430,6 +435,9 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
                 o.gerr6[grp] = __uint_as_float(e6max_bits);
                 o.gstep6[grp] = MX6_FIX_STEP;
                 e6max_bits = 0u;
+            } else if (o.gerr6) {
+                o.gerr6[grp] = __builtin_inff();
+                o.gstep6[grp] = 0.0f;
             }
             amax_bits = 0u;   // for the next group (read again only behind the next two barriers)
             emax_bits = 0u;
