@@ -250,7 +250,10 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
         emit_chunk(it >= 4 ? c0 + (it >> 2) - 1 : -1);  // tile 0's slots folded the last tile of the previous chunk
         tile(std::integral_constant<int, 1>{}, accB, accA);
         tile(std::integral_constant<int, 2>{}, accA, accB);
-        wait_vmcnt<EARLY>();  // the next step's pieces (issued during the previous step) have landed; this step's early ones may fly on
+        // the next step's pieces (issued during the previous step) have landed; this step's early ones -- the newest EARLY loads,
+        // if it issued any -- may fly on
+        if (more) wait_vmcnt<EARLY>();
+        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         tile(std::integral_constant<int, 3>{}, accB, accA);
