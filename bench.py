@@ -238,6 +238,9 @@ def timed_loop(lib, pipe, pairs, steps, warmup, settle=0):
         reg(i)
     pipe.synchronize()
     torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     out = None
     for i in range(steps):
@@ -246,6 +249,7 @@ def timed_loop(lib, pipe, pairs, steps, warmup, settle=0):
     pipe.synchronize()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     ms = C.c_float()
     durs = []
     for a, b in events:
@@ -313,7 +317,13 @@ def c2_variants(dev, lib, pairs, steps, warmup, iters, streams):
                                             "the scaled MFMA, N M D operations per launch; the preparation writes the fp6 image too)",
                                 "value": v, "unit": "registrations/s", "steps": steps, "ms_per_step": msps, "coarse_pass": pass_name(pipe),
                                 "roofline": roofline_of(pipe, n, m, d, cms),
-                                "note": "the coarse kernel is a third shorter than the int8 half-width kernel; the rate is not: DESIGN.md 0.9"}
+                                "note": "what `auto` settles on for D.2 data since the end of round 3 (DESIGN.md 0.11)"}
+    del pipe
+    pipe = build("int8-half")
+    v, msps, cms, _ = timed_loop(lib, pipe, pairs, steps, warmup)
+    out["C2_half_width_int8"] = {"workload": "C2, D.2 pairs, coarse pass pinned to the half-width pass on the int8 image (VFM_RECORDS_HALF: round 2's headline mode)",
+                                 "value": v, "unit": "registrations/s", "steps": steps, "ms_per_step": msps, "coarse_pass": pass_name(pipe),
+                                 "roofline": roofline_of(pipe, n, m, d, cms)}
     del pipe
     pipe = build("auto")
     v, msps, cms, _ = timed_loop(lib, pipe, pairs, 200, warmup, settle=4)
@@ -469,6 +479,9 @@ def main():
     torch.cuda.current_stream().wait_stream(match_stream)
 
     grouped = dist.is_available() and dist.is_initialized()  # launched through torch.distributed.run
+    import gc
+    gc.collect()      # (the interpreter's cyclic collector stays out of the timed region: a pause there is tens of ms of a 15 ms run)
+    gc.disable()
     if grouped:
         dist.barrier()
     torch.cuda.synchronize()
@@ -489,6 +502,7 @@ def main():
     if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     per_rank = [steps / local_elapsed]
     if grouped:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -520,7 +534,8 @@ def main():
     iso = []
     if S == 2:
         pipe1 = RegistrationPipeline(n, m, d, n_iter=args.iters, device=dev, overlap_ransac=False,
-                                     coarse=("int8-half" if mode_half else "int8-top2" if mode_top2 else "int8" if mode_i8 else "fp16"))
+                                     coarse=(("mx6-half" if getattr(pipe, "mx6_half", False) else "int8-half") if mode_half
+                                             else "int8-top2" if mode_top2 else "int8" if mode_i8 else "fp16"))
         a, b = C.c_void_p(), C.c_void_p()
         _lib.check(lib.vfm_prof_events_create(C.byref(a), C.byref(b)))
         for i in range(6):
@@ -546,20 +561,28 @@ def main():
         # few chunks survive it -- D.2 descriptors -- else best-score / packed top-2 records over all d)
         i8 = d in (256, 384, 512, 640, 768) and os.environ.get("VFM_VARIANT", "0") in ("0", "10", "12") and mode_i8
         half = i8 and mode_half
+        half6 = half and bool(getattr(pipe, "mx6_half", False))   # the half-width pass on the fp6 image (VFM_RECORDS_MX6_HALF)
         kcols = d // 2 if half else d
         flops = 2.0 * n * m * kcols   # what the dominant kernel computes per launch
         achieved = flops / (coarse_ms * 1e-3) / 1e12
-        peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS
-        kernel = ((f"match_coarse_i8q2_kernel<{kcols // 32}> (int8 32x32x32 MFMA over the first {kcols} of {d} columns -- the half-width pass: the "
+        peak = MFMA_F6_PEAK_TFLOPS if half6 else (MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS)
+        kernel = ((f"match_coarse_mx6q2_kernel<{kcols // 64}, false, false, {d // 64}> (v_mfma_scale_f32_32x32x64_f8f6f4 on microscaled fp6 -- e2m3 "
+                   f"elements, one power-of-two scale per 32 columns -- over the first {kcols} of {d} columns: the half-width pass in fp6; the other "
+                   "half is bounded by Cauchy-Schwarz against the cosine gate, the image's quantisation by its measured residual norms, and only "
+                   "surviving chunks are scored over all columns (int8 MFMA rescan, fp32 refinement, fp64 decision); 64 resident queries per wave, "
+                   "one best-score record per (query, chunk))") if half6
+                  else (f"match_coarse_i8q2_kernel<{kcols // 32}> (int8 32x32x32 MFMA over the first {kcols} of {d} columns -- the half-width pass: the "
                    "other half is bounded by Cauchy-Schwarz against the cosine gate and only surviving chunks are scored over all columns -- "
                    "64 resident queries per wave, exact integer scores, one best-score record per (query, chunk))") if half
                   else ("match_coarse_i8q2_kernel<12> (int8 32x32x32 MFMA, 64 resident queries per wave, exact integer scores, "
                         + ("packed top-2 records" if mode_top2 else "one best-score record per (query, chunk)") + ")") if i8
                   else "match_coarse_pipe_kernel<24, true> (fp16 32x32x16 MFMA, sparse row-level records)")
         traffic, traffic_src = None, None  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
-        for name in ((("r03_pmc_match_coarse_i8half.json", "r02_pmc_match_coarse_i8half.json") if half
-                      else ("r03_pmc_match_coarse_i8.json", "r02_pmc_match_coarse_i8.json")) if i8
-                     else ("r02_pmc_match_coarse_f16.json", "r01_pmc_match_coarse.json")):
+        names = (("r03_pmc_match_coarse_mx6half.json",) if half6
+                 else ("r03_pmc_match_coarse_i8half.json", "r02_pmc_match_coarse_i8half.json") if half
+                 else ("r03_pmc_match_coarse_i8.json", "r02_pmc_match_coarse_i8.json") if i8
+                 else ("r02_pmc_match_coarse_f16.json", "r01_pmc_match_coarse.json"))
+        for name in names:
             pmc = ROOT / "profiles" / name
             if pmc.exists() and (n, m, d) == (N_SCAN, N_MAP, DIM):
                 traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
@@ -570,7 +593,8 @@ def main():
             "unit": "registrations/s", "n_gpus": world, "steps": vdist.pairs_per_rank(num_pairs, world), "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / vdist.pairs_per_rank(num_pairs, world), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("int8 coarse pass (MFMA, exact integer scores + proven quantisation bounds)" if i8 else "f16 coarse pass (MFMA)")
+            "dtype": ("fp6 (MX e2m3) coarse pass (scaled MFMA, fp32 scores + bounds from measured residuals) + int8 rescan (exact integer scores)" if half6
+                      else "int8 coarse pass (MFMA, exact integer scores + proven quantisation bounds)" if i8 else "f16 coarse pass (MFMA)")
                      + " + f32 refinement + f64 exact decision / f64 RANSAC",
             "data": "synthetic",
             "config": {"workload": f"C2: {n}-pt scan vs {m}-pt map, {d}-D descriptors precomputed and resident in "
@@ -582,7 +606,8 @@ def main():
                        "collective": (f"one all_gather_into_tensor of the poses ({dist.get_backend()} = RCCL)" if grouped
                                       else "none (single process, no launcher)"),
                        "correspondences_last_step": ncorr, "max_pose_err_vs_planted": max(errs),
-                       "coarse_pass": ("int8, half-width (VFM_RECORDS_HALF)" if half else "int8, packed top-2 records" if (i8 and mode_top2)
+                       "coarse_pass": ("fp6 (MX e2m3), half-width (VFM_RECORDS_MX6_HALF)" if half6 else "int8, half-width (VFM_RECORDS_HALF)" if half
+                                       else "int8, packed top-2 records" if (i8 and mode_top2)
                                        else "int8, best-score records" if i8 else "fp16"),
                        # (query, chunk) pairs that survive the half-width bound, per query, in the last search the policy has read back:
                        # the figure the pruning rests on (D.2: the planted matches and nothing else, ~0.5; descriptors that are alike: hundreds)
@@ -590,8 +615,9 @@ def main():
             "per_rank_registrations_per_s": per_rank,
             "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "peak_note": ("dense int8 MFMA, integer multiply-adds counted as 2 operations each" if i8
-                                       else "dense fp16 MFMA"),
+                         "peak_note": ("dense fp6 scaled MFMA, 10 PFLOP/s (the guide's spec at 2.4 GHz; bare MFMAs sustain 6.4-6.5 on this chip: "
+                                       "tools/probe/mx6_probe.hip)" if half6
+                                       else "dense int8 MFMA, integer multiply-adds counted as 2 operations each" if i8 else "dense fp16 MFMA"),
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "flops_per_launch": flops, "avg_launch_ms": coarse_ms,
                          "flops_note": ("operations this kernel performs: 2 N M D/2 -- the reference's all-pairs product is 2 N M D = "

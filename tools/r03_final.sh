@@ -22,7 +22,11 @@ for i in 1 2 3 4 5 6 7; do cp $R/gpurun_out/pmc_coarse/p${i}_counter_collection.
 cd $R && VFM_RECORDS=5 bash tools/pmc_coarse.sh 2>&1 | tail -22
 cp $R/gpurun_out/pmc_coarse/pmc_match_coarse.json $O/pmc_match_coarse_mx6.json 2>/dev/null
 for i in 1 2 3 4 5 6 7; do cp $R/gpurun_out/pmc_coarse/p${i}_counter_collection.csv $O/pmc_mx6_pass${i}_counter_collection.csv 2>/dev/null; done
+cd $R && VFM_RECORDS=7 bash tools/pmc_coarse.sh 2>&1 | tail -22
+cp $R/gpurun_out/pmc_coarse/pmc_match_coarse.json $O/pmc_match_coarse_mx6half.json 2>/dev/null
+for i in 1 2 3 4 5 6 7; do cp $R/gpurun_out/pmc_coarse/p${i}_counter_collection.csv $O/pmc_mx6half_pass${i}_counter_collection.csv 2>/dev/null; done
 timeout 600 python tools/dev_mx6.py > $O/dev_mx6.txt 2>&1; tail -8 $O/dev_mx6.txt
+timeout 600 python tools/queue_probe.py int8-half private > $O/queue_probe.txt 2>&1; timeout 600 python tools/queue_probe.py int8-half shared >> $O/queue_probe.txt 2>&1; timeout 600 python tools/queue_probe.py mx6-half shared >> $O/queue_probe.txt 2>&1
 timeout 900 python tools/ab_mx6_bench.py > $O/ab_mx6_bench.txt 2>&1
 timeout 600 python tools/soak_mx6.py 40 303 2>&1 | tail -3 > $O/soak_mx6.txt; cat $O/soak_mx6.txt
 # what a cycle of the pipeline consists of: per-stream kernel timeline (int8 half-width, fp6 half-width), thin kernels beside the coarse kernels

@@ -50,12 +50,14 @@ def main():
               "neardup.json": "r03_neardup.json", "time_pairs.txt": "r03_time_pairs.txt", "prof_pairs.txt": "r03_prof_pairs.txt",
               "other_rows.txt": "r03_other_rows.txt", "time_c3_modes.txt": "r03_time_c3_modes.txt",
               "ab_vit_xcd.txt": "r03_ab_vit_xcd.txt", "prof_c3_one.txt": "r03_prof_c3_one.txt",
-              "pmc_match_coarse_mx6.json": "r03_pmc_match_coarse_mx6.json", "dev_mx6.txt": "r03_dev_mx6.txt",
+              "pmc_match_coarse_mx6.json": "r03_pmc_match_coarse_mx6.json", "pmc_match_coarse_mx6half.json": "r03_pmc_match_coarse_mx6half.json",
+              "queue_probe.txt": "r03_queue_probe.txt", "dev_mx6.txt": "r03_dev_mx6.txt",
               "ab_mx6_bench.txt": "r03_ab_mx6_bench.txt", "soak_mx6.txt": "r03_soak_mx6.txt", "pipeline_cycle.txt": "r03_pipeline_cycle.txt", "soak_half.txt": "r03_soak_half.txt", "soak_match.txt": "r03_soak_match.txt", "mx6_probe.txt": "r03_mx6_probe.txt"}
     for i in range(1, 8):
         copies[f"pmc_pass{i}_counter_collection.csv"] = f"r03_pmc_pass{i}_counter_collection.csv"
         copies[f"pmc_half_pass{i}_counter_collection.csv"] = f"r03_pmc_half_pass{i}_counter_collection.csv"
         copies[f"pmc_mx6_pass{i}_counter_collection.csv"] = f"r03_pmc_mx6_pass{i}_counter_collection.csv"
+        copies[f"pmc_mx6half_pass{i}_counter_collection.csv"] = f"r03_pmc_mx6half_pass{i}_counter_collection.csv"
     for a, b in copies.items():
         src = SRC / a
         if not src.exists() and "/" in a:   # rocprofv3 nests its output under the host name
@@ -69,6 +71,7 @@ def main():
     pmh = json.loads((DST / "r03_pmc_match_coarse_i8half.json").read_text())
     pmc = json.loads((DST / "r03_pmc_match_coarse_i8.json").read_text())
     pm6 = json.loads((DST / "r03_pmc_match_coarse_mx6.json").read_text()) if (DST / "r03_pmc_match_coarse_mx6.json").exists() else None
+    pm6h = json.loads((DST / "r03_pmc_match_coarse_mx6half.json").read_text()) if (DST / "r03_pmc_match_coarse_mx6half.json").exists() else None
     r = b["roofline"]
     ex = b["extra"]
     cfg = b["config"]
@@ -120,6 +123,7 @@ The same pipeline away from the favourable case (VERDICT r2 item 2), same proces
 - {variant('C2_full_width')} -- `coarse="int8"` pinned: every column in the coarse pass, nothing depends on how the descriptors prune
 - {variant('C2_full_width_mx6')} -- `coarse="mx6"` pinned: the same all-pairs product in microscaled fp6 on the scaled MFMA (DESIGN.md 0.8), as data independent as the line above
 - {variant('C2_half_width_mx6')} -- `coarse="mx6-half"` pinned: the headline's bound in fp6 (coarse kernel 0.40 ms alone)
+- {variant('C2_half_width_int8')} -- `coarse="int8-half"` pinned: the half-width pass on the int8 image (round 2's headline mode)
 - {variant('C2_sustained')} -- {ex.get('C2_sustained', {}).get('steps', '?')} steps instead of 20 (the first ~15 launches after a synchronise run slower)
 - {variant('C2_lifted')} -- map descriptors lifted from overlapping patch grids (near-duplicates), policy by feedback
 - `extra.A6_mutual_l2`: {json.dumps(a6)[:600]}
@@ -155,6 +159,10 @@ Full-width kernel (`VFM_RECORDS=0`; `profiles/r03_pmc_match_coarse_i8.json` + `p
 
 fp6 kernel (`VFM_RECORDS=5`; `profiles/r03_pmc_match_coarse_mx6.json` + `profiles/r03_pmc_mx6_pass*_counter_collection.csv`,
 {pm6['kernel'] if pm6 else '?'}): {pmc_line(pm6) if pm6 else '(not collected)'}.
+
+fp6 half-width kernel (`VFM_RECORDS=7`: what the default bench runs on D.2 data since the end of round 3;
+`profiles/r03_pmc_match_coarse_mx6half.json` + `profiles/r03_pmc_mx6half_pass*_counter_collection.csv`,
+{pm6h['kernel'] if pm6h else '?'}): {pmc_line(pm6h) if pm6h else '(not collected)'}.
 
 Reading: the MFMA pipe is busy ~3/4 of the cycles at a clock of ~1.75 GHz (2.4 GHz is what the 5 POP/s peak assumes): the
 fraction of the peak is busy x clock / 2.4, i.e. the kernel sits against the power envelope, not against its own stalls.
@@ -209,6 +217,15 @@ Pipelined (the bench's pipeline construction), coarse pass pinned, three kinds o
 
 ```
 {text('r03_ab_mx6_bench.txt')[-4500:]}
+```
+
+## Hardware queues: the same pipeline at 1110, 1270 or 1375 registrations/s (`tools/queue_probe.py`; DESIGN.md 0.11)
+
+Pipelines built one after the other in one process, first with private side streams (`private`), then with the side streams
+shared per process (`shared`, the default since the end of round 3), int8 half-width and fp6 half-width:
+
+```
+{text('r03_queue_probe.txt')[-5000:]}
 ```
 
 ## What a cycle of the pipeline consists of (`tools/trace_pipe.sh`, `tools/corun_probe.py`; DESIGN.md 0.9)

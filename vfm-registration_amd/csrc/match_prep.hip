@@ -116,13 +116,17 @@ constexpr float MX6_F16_ROUNDING = 4.8929e-4f;   // 2^-11 (1 + 2^-13) + sqrt(768
 typedef _Float16 halfx32 __attribute__((ext_vector_type(32)));
 typedef int intx6 __attribute__((ext_vector_type(6)));
 typedef unsigned short ushortx2 __attribute__((ext_vector_type(2)));
-template <bool F16, int NC = 2, bool MX6 = false>
-__global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restrict__ x1, int64_t rows1, int d, PrepOut o1, int groups1,
+// WAVES = 8 (the MX6 form): 8 waves x 16 rows -- half the threads, twice the registers each: room for the conversion AND for the
+// next group's rows, which the 16-wave form had to read after it (128 registers: 49 spilled, the loads exposed; 0.21 ms)
+template <bool F16, int NC = 2, bool MX6 = false, int WAVES = 16>
+__global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __restrict__ x1, int64_t rows1, int d, PrepOut o1, int groups1,
                                                           const float* __restrict__ x2, int64_t rows2, PrepOut o2, int groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned amax_bits, emax_bits, rmax_bits, e6max_bits;
     static_assert(!(F16 && MX6), "the fp6 image is made from the LDS copy of the fp16 one, which then is not stored");
-    constexpr int RPW = I8_GROUP / 16;  // rows per wave: 16 waves x 8 rows, all of them in registers between the two phases
+    constexpr int RPW = I8_GROUP / WAVES;  // rows per wave (8 or 16), all of them in registers between the two phases
+    constexpr int NT = WAVES * 64;
+    static_assert(RPW % 8 == 0, "rows are reduced eight at a time");
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int nchunks = d >> 2;  // float4 chunks per row (<= 64 NC): lane l owns chunks l, l + 64 (, l + 128)
     unsigned char* img8 = smem;                                                  // [4 tiles][d/32 * 64 units][16]
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
     // its rows at every level and adds the partner's partial of those rows), then the xor-4 / 2 / 1 levels on the single
     // value.  Every addition pairs the same two partials as row_sumsq_wave's butterfly (which computes each of them in both
     // lanes), so the sum is bit-identical to the oracle's; 10 shuffles instead of 48.  Afterwards lane l holds row l >> 3.
-    auto scatter8 = [&](float (&p)[RPW]) __attribute__((always_inline)) {
+    auto scatter8 = [&](const float* p) __attribute__((always_inline)) {
         const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
         float q4[4], q2[2];
 #pragma unroll
@@ -206,12 +210,16 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
             }
             part[j] = p;
         }
-        const float my_inv = inv_norm_from_sumsq(scatter8(part));  // of row lane >> 3: eight rows in one evaluation
-        if ((lane & 7) == 0) o.inv[(int64_t)grp * I8_GROUP + wave * RPW + (lane >> 3)] = my_inv;
+        float my_inv[RPW / 8];   // of row 8 hb + (lane >> 3): eight rows in one evaluation
+#pragma unroll
+        for (int hb = 0; hb < RPW / 8; ++hb) {
+            my_inv[hb] = inv_norm_from_sumsq(scatter8(part + 8 * hb));
+            if ((lane & 7) == 0) o.inv[(int64_t)grp * I8_GROUP + wave * RPW + 8 * hb + (lane >> 3)] = my_inv[hb];
+        }
         float lmax = 0.0f;
 #pragma unroll
         for (int j = 0; j < RPW; ++j) {
-            const float iv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_inv), 8 * j));
+            const float iv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_inv[j >> 3]), 8 * (j & 7)));
 #pragma unroll
             for (int i = 0; i < NC; ++i) {  // normalised values exactly as faiss leaves them in fp32 (zero in the unused slots)
                 v[j][i].x = v[j][i].x * iv;
@@ -269,14 +277,15 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
             }
             part[j] = e2;
             rpart[j] = r2;
-            if (!MX6 && gnext < groups) load_row(gnext, j);   // (MX6: the conversion below needs the registers; rows are read after it)
+            if ((!MX6 || WAVES == 8) && gnext < groups) load_row(gnext, j);   // (MX6 with 16 waves: no registers left, rows are read below)
         }
-        {
+#pragma unroll
+        for (int hb = 0; hb < RPW / 8; ++hb) {
             // |e|_2 of row lane >> 3, rounded up: the fp32 sum of d non-negative terms is within (d + 8) 2^-24 of exact, sqrtf
             // within 2^-24
-            float en = sqrtf(scatter8(part)) * 1.000244140625f + 1.0e-30f;
+            float en = sqrtf(scatter8(part + 8 * hb)) * 1.000244140625f + 1.0e-30f;
             if (!(en == en)) en = __builtin_inff();
-            const int64_t r = (int64_t)grp * I8_GROUP + wave * RPW + (lane >> 3);
+            const int64_t r = (int64_t)grp * I8_GROUP + wave * RPW + 8 * hb + (lane >> 3);
             if (r >= rows) en = 0.0f;
             if ((lane & 7) == 0) {
                 o.err[r] = en;
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
             {   // (the MX6 form keeps these: VFM_RECORDS_MX6_HALF bounds the second half of the columns with them)
                 // |second half of the row|_2, rounded up like E (d / 2 + 8 roundings of 2^-24 on non-negative terms, one sqrtf);
                 // NaN / Inf elements -> Inf: nothing is ever pruned against such a row
-                float rn = sqrtf(scatter8(rpart)) * 1.000244140625f + 1.0e-30f;
+                float rn = sqrtf(scatter8(rpart + 8 * hb)) * 1.000244140625f + 1.0e-30f;
                 if (!(rn == rn)) rn = __builtin_inff();
                 if (r >= rows) rn = 0.0f;
                 if ((lane & 7) == 0) {
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
             const int u8n = (d >> 5) * 64 * 4;  // uint4 units of the group's four int8 tiles
             uint4* dst = o.tiles8 + (int64_t)grp * u8n;
             const uint4* src = reinterpret_cast<const uint4*>(img8);
-            for (int u = threadIdx.x; u < u8n; u += 1024) {
+            for (int u = threadIdx.x; u < u8n; u += NT) {
                 const uint4 tq = src[u];
                 unsigned* po = reinterpret_cast<unsigned*>(dst + u);
                 __builtin_nontemporal_store(tq.x, po);
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
             const int uh = (d >> 6) * 64;  // uint4 units per half tile
             uint4* dst = o.tiles8h + (int64_t)grp * (uh * 4);
             const uint4* src = reinterpret_cast<const uint4*>(img8);
-            for (int u = threadIdx.x; u < uh * 4; u += 1024) {
+            for (int u = threadIdx.x; u < uh * 4; u += NT) {
                 const int t = u / uh, w = u % uh;
                 const uint4 tq = src[t * (2 * uh) + w];
                 unsigned* po = reinterpret_cast<unsigned*>(dst + u);
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
         if constexpr (MX6) {
             __syncthreads();   // the int8 tiles have left the LDS: the fp6 image takes their place
             const int nblk = d >> 5;
-            for (int item = threadIdx.x; item < I8_GROUP * nblk; item += 1024) {
+            for (int item = threadIdx.x; item < I8_GROUP * nblk; item += NT) {
                 const int r = item & (I8_GROUP - 1), blk = item >> 7, t = r >> 5, p = r & 31;
                 // the block's 32 halves: fp16 units (k-step 2 blk + u, half hh) of row p, in column order
                 const uint4* up = reinterpret_cast<const uint4*>(img16 + (size_t)t * (d * 32)) + (4 * blk) * 32 + p;
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
             const int u6n = (d >> 5) * 64 * 4;   // same size as the int8 tiles
             uint4* dst = o.tiles6 + (int64_t)grp * u6n;
             const uint4* src = reinterpret_cast<const uint4*>(img6);
-            for (int u = threadIdx.x; u < u6n; u += 1024) {
+            for (int u = threadIdx.x; u < u6n; u += NT) {
                 const uint4 tq = src[u];
                 unsigned* po = reinterpret_cast<unsigned*>(dst + u);
                 __builtin_nontemporal_store(tq.x, po);
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
             const int u16n = (d >> 4) * 64 * 4;
             uint4* dst = o.tiles + (int64_t)grp * u16n;
             const uint4* src = reinterpret_cast<const uint4*>(img16);
-            for (int u = threadIdx.x; u < u16n; u += 1024) {
+            for (int u = threadIdx.x; u < u16n; u += NT) {
                 const uint4 tq = src[u];
                 unsigned* po = reinterpret_cast<unsigned*>(dst + u);
                 __builtin_nontemporal_store(tq.x, po);
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(1024) void prep_chunk_kernel(const float* __restric
                 __builtin_nontemporal_store(tq.w, po + 3);
             }
         }
-        if constexpr (MX6) {
+        if constexpr (MX6 && WAVES != 8) {
             if (gnext < groups) {
 #pragma unroll
                 for (int j = 0; j < RPW; ++j) load_row(gnext, j);
@@ -513,7 +522,7 @@ int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2
                                               hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * 512));
             VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_chunk_kernel<false, 3>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * 768));
-            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_chunk_kernel<false, 2, true>),
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_chunk_kernel<false, 2, true, 8>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, I8_GROUP * (384 * 3 + 384 / 8 + 16)));
             attr_mark(attr_set);
         }
@@ -521,7 +530,7 @@ int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2
         int pg = prep_grid(groups, grid_mode);
         const dim3 grid((unsigned)pg), block(1024);
         if (want_mx6) {   // int8 + fp6 images from one read of the rows; the fp16 image, if wanted, by its own kernel
-            hipLaunchKernelGGL((prep_chunk_kernel<false, 2, true>), grid, block, (size_t)I8_GROUP * (d * 3 + d / 8 + 16), st, x1, rows1, d, prep_out(p1), g1,
+            hipLaunchKernelGGL((prep_chunk_kernel<false, 2, true, 8>), grid, dim3(512), (size_t)I8_GROUP * (d * 3 + d / 8 + 16), st, x1, rows1, d, prep_out(p1), g1,
                                x2, rows2, prep_out(p2), groups);
             if (want_f16)
                 hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)(t1 + t2)), dim3(256), (size_t)d * 64, st, x1, rows1, d, p1.inv,

@@ -60,11 +60,30 @@ class _ResultSet:
         self.done: Optional[torch.cuda.Event] = None  # RANSAC of the pair that used this set finished
 
 
+# Side streams are shared by every pipeline of a process (per device): HIP spreads the streams a process creates over a few
+# hardware queues (4 by default), and streams on one queue run one after the other.  Which queues a NEW stream lands on depends
+# on how many were created before it: the same pipeline, built again later in the process, ran at 1110, 1270 or 1375
+# registrations/s depending on whether a solve stream had come to share the coarse stream's queue (tools/queue_probe.py,
+# tools/queue_probe_trace.sh).  The first streams a process creates get queues of their own; they are kept and reused.
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev: torch.device, n_solve: int):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    prep, solve = _SIDE_STREAMS.get(key, (None, []))
+    if prep is None:
+        prep = torch.cuda.Stream(device=dev)
+    while len(solve) < n_solve:
+        solve.append(torch.cuda.Stream(device=dev))
+    _SIDE_STREAMS[key] = (prep, solve)
+    return prep, solve[:n_solve]
+
+
 class RegistrationPipeline:
     def __init__(self, n: int, m: int, d: int = 384, n_iter: int = 50000, min_cosine: float = 0.8,
                  max_corr_dist: float = 10000.0, seed: int = 42, device="cuda", overlap_ransac: bool = False,
                  overlap_prepare: bool = False, solve_streams: int = 1, gate: bool = True, coarse: str = "auto",
-                 half_fused: Optional[bool] = None):
+                 half_fused: Optional[bool] = None, prep_schedule: Optional[int] = None, private_streams: bool = False):
         lib = _lib.load()
         self.n, self.m, self.d = n, m, d
         self.n_iter, self.min_cosine, self.max_corr_dist, self.seed = n_iter, min_cosine, max_corr_dist, seed
@@ -98,6 +117,10 @@ class RegistrationPipeline:
         self.half = coarse in ("int8-half", "mx6-half")
         # the half-width pass in fp6 (VFM_RECORDS_MX6_HALF): the same bound on the scaled MFMA; operands prepared with VFM_PREPARE_MX6
         self.mx6_half = coarse == "mx6-half"
+        # "auto": where the fp6 kernel exists the half-width pass it settles on is the fp6 one (0.40 against 0.60 ms of coarse
+        # kernel at C2 size, 1500-1600 against 1300-1360 registrations/s; the probe itself runs on the int8 half-width image, which
+        # every preparation writes)
+        self._mx6_half_ok = coarse == "auto" and d in (256, 384) and n > 2048
         self._probe_due = coarse == "auto" and self.gate
         # which form of the half-width pass: with the selection fused into the coarse kernel (VFM_RECORDS_HALF_FUSED = 4: no
         # records, no selection kernel) a serial registration is 1.5 % faster (1017 vs 1002 registrations/s), but in the
@@ -119,7 +142,8 @@ class RegistrationPipeline:
         # (stream priorities were measured with the half-width pass: the coarse stream on high priority 1040 vs 1220
         # registrations/s -- the side stages starve and the pipeline stalls on its own dependencies; the side streams on high
         # priority 1260 vs 1267: no difference)
-        self.solve_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_solve)]
+        shared_prep, shared_solve = (None, []) if (private_streams or not self.overlap) else _side_streams(dev, self.n_solve)
+        self.solve_streams = shared_solve if shared_solve else [torch.cuda.Stream(device=dev) for _ in range(self.n_solve)]
         self.rws_list = [torch.empty(lib.vfm_ransac_workspace_bytes(n, n_iter), dtype=u8, device=dev)
                          for _ in range(max(1, self.n_solve))]
         self.rws = self.rws_list[0]
@@ -129,8 +153,9 @@ class RegistrationPipeline:
         # kernel + ~0.2 ms of small kernels + preparation, whatever the streams allow.  Measured and dropped in round 3: a
         # high-priority preparation stream (1000 vs 1380/s), a high-priority coarse stream, enqueueing the solve stage of
         # registration i behind the preparation of i + 1 (the coarse kernel then waits for the same small kernels))
-        self.prep_stream = torch.cuda.Stream(device=dev) if self.overlap else None
+        self.prep_stream = (shared_prep if shared_prep is not None else torch.cuda.Stream(device=dev)) if self.overlap else None
         self._step = 0
+        self._prep_schedule = prep_schedule   # None: the rule in register(); 1 / 2 = VFM_PREPARE_PERSISTENT / _INTERLEAVED (A/B runs)
 
     def prepare_map(self, b_desc: torch.Tensor) -> None:
         """IndexFlatIP.add: normalise + convert the map once (it is immutable per scene); every buffer
@@ -170,6 +195,7 @@ class RegistrationPipeline:
                 self._slots.append(slot)
                 if self.coarse == "auto" and self.use_i8 and not self.half and self.last_probe <= self.HALF_LIMIT * self.n:
                     self.half, self.top2 = True, False
+                    self.mx6_half = self._mx6_half_ok
                     self._since_switch = 0
                 continue
             self.last_rescans = int(slot.item())
@@ -252,6 +278,8 @@ class RegistrationPipeline:
                 # the preparation kernel's launch shape: persistent when it runs alone or beside the half-width coarse kernel
                 # (which leaves registers free), short workgroups beside the full-width one (include/vfmreg.h)
                 schedule = 1 if (records in (3, 4, 7) or not (self.overlap and self.overlap_prepare)) else 2
+                if self._prep_schedule is not None:
+                    schedule = int(self._prep_schedule)
                 if records in (5, 6, 7):
                     schedule |= 8   # VFM_PREPARE_MX6: the fp6 image as well
                 _lib.check(lib.vfm_match_prepare2_gated_p(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
