@@ -141,14 +141,14 @@ def test_gate_leaves_only_provably_rejected_queries_unresolved():
 
 def test_pipeline_changes_records_on_a_duplicate_rich_map_and_results_do_not_change():
     """auto mode: the first gated search reports how many candidate chunks it had to rescan; on a map where every point has
-    about twenty near-copies the pipeline moves to the packed top-2 records (a chunk with one row inside the bounds then costs
+    about eighty near-copies the pipeline moves to the packed top-2 records (a chunk with one row inside the bounds then costs
     one fp32 row instead of a 48 KB rescan).  Poses and correspondences are those of every fixed mode."""
     n, m, d = 2000, 40000, 384
     g = torch.Generator(device="cuda")
     g.manual_seed(3)
     p = synth.make_pair_device(n, m, d, seed=9)
-    phys = torch.randn((2000, d), generator=g, device="cuda")      # every physical point ~20 times in the map
-    owner = torch.randint(0, 2000, (m,), generator=g, device="cuda")
+    phys = torch.randn((500, d), generator=g, device="cuda")       # every physical point ~80 times in the map
+    owner = torch.randint(0, 500, (m,), generator=g, device="cuda")
     b = phys[owner] + 0.01 * torch.randn((m, d), generator=g, device="cuda") / d ** 0.5
     q = b[p["match"].clamp(min=0)] + 0.02 * torch.randn((n, d), generator=g, device="cuda") / d ** 0.5
     q = torch.where((p["match"] < 0)[:, None], torch.randn((n, d), generator=g, device="cuda"), q)
@@ -168,7 +168,7 @@ def test_pipeline_changes_records_on_a_duplicate_rich_map_and_results_do_not_cha
         outs[coarse] = (out["T"].clone(), out["corres"][:k].clone(), pipe.use_i8, pipe.top2, first_rescans, pipe.half)
         del pipe
     # the int8 pass stays; best-score records do not: the feedback moves on to top-2 records, or -- where the probe of the
-    # half-width pass finds few enough survivors (the ~20 copies of a matched point) -- to the half-width pass
+    # half-width pass finds few enough survivors (the ~80 copies of a matched point) -- to the half-width pass
     assert outs["auto"][2] is True and (outs["auto"][3] is True or outs["auto"][5] is True)
     assert outs["auto"][4] > RegistrationPipeline.RESCAN_LIMIT * n         # what the first (best-score) search reported
     assert outs["int8"][2:4] == (True, False) and outs["int8-top2"][2:4] == (True, True) and outs["fp16"][2] is False

@@ -14,7 +14,7 @@ lifted0 = [synth.make_lifted_pair_device(n, m, d, seed=42 + p, device=dev, cloud
 def build(coarse):
     return RegistrationPipeline(n, m, d, n_iter=50000, device=dev, overlap_ransac=True, overlap_prepare=True, solve_streams=2, coarse=coarse)
 for name, data in (("D.2", pairs), ("lifted+common", lifted), ("lifted", lifted0)):
-    for mode in ("int8", "mx6", "int8-top2", "mx6-top2", "auto", "int8-half", "mx6-half", "int8-half", "mx6-half"):
+    for mode in ("int8", "mx6", "int8-top2", "mx6-top2", "auto", "int8-half", "mx6-half"):
         for steps in (20, 200):
             pipe = build(mode)
             v, msps, cms, res = bench.timed_loop(lib, pipe, data, steps, 3, settle=6 if mode == "auto" else 0)

@@ -121,6 +121,12 @@ class RegistrationPipeline:
         # kernel at C2 size, 1500-1600 against 1300-1360 registrations/s; the probe itself runs on the int8 half-width image, which
         # every preparation writes)
         self._mx6_half_ok = coarse == "auto" and d in (256, 384) and n > 2048
+        # ... and where the half-width bound does not prune but best-score int8 records rescan only a few chunks per query (maps of
+        # distinct places), the full-width pass moves to fp6 too: its bounds are ~3x wider, so it is tried below MX6_UP rescanned
+        # chunks per query and left again above MX6_DOWN (tools/ab_mx6_bench.py: lifted descriptors of independent scenes, 6.2 int8 /
+        # 21 fp6 rescans per query: 732 / 793 against 651 / 721 registrations/s; with a common component, 12.5 / 45: 590 against 630)
+        self._mx6_ok = self._mx6_half_ok
+        self._mx6_tried = False
         self._probe_due = coarse == "auto" and self.gate
         # which form of the half-width pass: with the selection fused into the coarse kernel (VFM_RECORDS_HALF_FUSED = 4: no
         # records, no selection kernel) a serial registration is 1.5 % faster (1017 vs 1002 registrations/s), but in the
@@ -181,8 +187,14 @@ class RegistrationPipeline:
     # registration, half-width vs best-score records: D.2 descriptors, 0.5 survivors per query -- the planted matches and nothing
     # else: 0.87 vs 1.48; lifted, independent views, 20 per query: 1.23 vs 1.60; lifted, shared scene, 96: 8.3 vs 1.8; descriptors
     # that are all alike (C3): every chunk, 195 vs 2.4)
+    # (round 3, with the chunk-major rescan on the matrix cores and the side streams on queues of their own -- the earlier
+    # figures carried a +-15 % scatter from the hardware queues -- tools/ab_mx6_bench.py, 20 / 200 steps: 6.2 rescanned chunks per
+    # query: best-score 651 / 721 vs top-2 593 / 655 registrations/s; 12.5: 630 / 683 vs 599 / 649; the crossover of round 2 is at
+    # ~30 (profiles/r03_neardup.json: 9.4 per query 3.16 vs 3.23 ms))
     HALF_LIMIT = 24.0
-    RESCAN_LIMIT = 10.0
+    RESCAN_LIMIT = 20.0
+    MX6_UP = 8.0
+    MX6_DOWN = 32.0
     TOP2_LIMIT = 40
     REPROBE = 256       # registrations before one step back towards the cheaper kernel is probed
 
@@ -194,7 +206,7 @@ class RegistrationPipeline:
                 self.last_probe = int(slot.item())
                 self._slots.append(slot)
                 if self.coarse == "auto" and self.use_i8 and not self.half and self.last_probe <= self.HALF_LIMIT * self.n:
-                    self.half, self.top2 = True, False
+                    self.half, self.top2, self.mx6 = True, False, False
                     self.mx6_half = self._mx6_half_ok
                     self._since_switch = 0
                 continue
@@ -206,8 +218,15 @@ class RegistrationPipeline:
                 if self.last_rescans > self.HALF_LIMIT * self.n:
                     self.half = False
                     self._since_switch = 0
+            elif self.mx6:   # (only "auto" gets here: a pinned mode returned above)
+                if self.last_rescans > self.MX6_DOWN * self.n:
+                    self.mx6, self._mx6_tried = False, True
+                    self._since_switch = 0
             elif not self.top2 and self.last_rescans > self.RESCAN_LIMIT * self.n:
                 self.top2 = True
+                self._since_switch = 0
+            elif not self.top2 and self._mx6_ok and not self._mx6_tried and self.last_rescans <= self.MX6_UP * self.n:
+                self.mx6 = True
                 self._since_switch = 0
             elif self.top2 and self.last_rescans > self.TOP2_LIMIT * self.n:
                 self.use_i8 = False
@@ -248,6 +267,7 @@ class RegistrationPipeline:
                     self.use_i8, self.top2 = True, True
                 elif self.top2:
                     self.top2 = False
+                self._mx6_tried = False
                 self._probe_due = self.gate
                 self._since_switch = 0
         i8, records = self.use_i8, self._records()
