@@ -106,11 +106,11 @@ Produced by `bash tools/r03_final.sh` through `gpurun` (a fresh box per call; bo
 collected by `python tools/refresh_profiles_r03.py`.  Raw files are next to this one (`r03_*`).  GPU suite on the same box:
 `{text('r03_pytest_gpu.txt').splitlines()[-1] if (DST / 'r03_pytest_gpu.txt').exists() else '?'}`.
 
-## bench.py (default: int8 coarse pass -- on D.2 descriptors the half-width pass; operand preparation | coarse pass | two solve streams)
+## bench.py (default: `auto` -- on D.2 descriptors the half-width pass, in fp6 since the end of round 3; operand preparation | coarse pass | two solve streams)
 
 `python bench.py` -> `profiles/r03_bench.json`: **{b['value']:.1f} registrations/s** ({b['ms_per_step']:.3f} ms per
 registration), dominant kernel `{r['kernel'].split(' (')[0]}` {r['avg_launch_ms']:.3f} ms per launch inside the timed region =
-{r['achieved']:.0f} TOP/s = {r['frac']:.3f} of the {r['peak'] / 1000:.1f} POP/s dense int8 MFMA peak (operations of the kernel as launched:
+{r['achieved']:.0f} TOP/s = {r['frac']:.3f} of {r['peak'] / 1000:.1f} POP/s ({r.get('peak_note', 'dense MFMA peak')}; operations of the kernel as launched:
 {r['flops_per_launch'] / 1e12:.3f} TOP -- coarse pass in use: {cfg.get('coarse_pass', '?')}; surviving chunks per query of the half-width
 selection: {cfg.get('half_width_survivors_per_query')}); alone on the GPU {r['single_stream']['avg_launch_ms']:.3f} ms =
 {r['single_stream']['achieved']:.0f} TOP/s = {r['single_stream']['frac']:.3f}.  `roofline.traffic` = {r.get('traffic')} bytes per launch
