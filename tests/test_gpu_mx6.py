@@ -271,3 +271,31 @@ def test_fp6_record_kinds_on_operands_without_the_fp6_image_stay_correct_and_hal
         idx, sim = _search(qd, bd, gate, records, flags=PREPARE_MX6)   # fp6 image AND the int8 half-width one
         solved = _gate_contract(idx, sim, ridx, rsim, gate)
         assert solved[rsim >= 0.8].all(), records
+
+
+def test_a_map_prepared_once_keeps_the_pipeline_off_the_fp6_kinds():
+    """prepare_map() + register(reuse_map=True) -- the IndexFlatIP.add-once form: the map operand then carries no fp6 image, so
+    `auto` must settle on the int8 half-width pass, not the fp6 one, and give the oracle's registration; the pinned fp6 modes
+    refuse prepare_map()."""
+    n, m, d = 3000, 20000, 384
+    p = synth.make_pair_device(n, m, d, seed=13)
+    qn, _ = orc.l2norm_rows(p["q_desc"].cpu().numpy())
+    bn, _ = orc.l2norm_rows(p["b_desc"].cpu().numpy())
+    ridx, rsim = orc.match_ip_top1(qn, bn)
+    keep = ~(rsim.astype(np.float64) < 0.8)
+    corres = np.stack([np.nonzero(keep)[0], ridx[keep]], 1).astype(np.int32)
+    ref = orc.ransac_corr(p["q_xyz"].cpu().numpy(), p["b_xyz"].cpu().numpy(), corres, 10000.0, 2000, seed=42)
+    pipe = RegistrationPipeline(n, m, d, n_iter=2000, overlap_ransac=True, overlap_prepare=True, solve_streams=2, coarse="auto")
+    pipe.prepare_map(p["b_desc"])
+    for _ in range(5):
+        out = pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"], reuse_map=True)
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        pipe._poll_feedback()
+    assert pipe.half and not pipe.mx6_half and not pipe.mx6
+    c = int(out["count"].item())
+    assert c == len(corres)
+    np.testing.assert_array_equal(out["corres"].cpu().numpy()[:c], corres)
+    np.testing.assert_array_equal(out["T"].cpu().numpy(), ref.transformation)
+    with pytest.raises(ValueError):
+        RegistrationPipeline(n, m, d, n_iter=2000, coarse="mx6-half").prepare_map(p["b_desc"])

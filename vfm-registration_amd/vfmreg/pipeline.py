@@ -170,6 +170,11 @@ class RegistrationPipeline:
         ops._chk(b_desc, torch.float32, "b_desc")
         if b_desc.shape != (self.m, self.d):
             raise ValueError("Invalid shape")
+        # a map prepared once carries the fp16 and int8 images, not the fp6 one (vfm_match_prepare): the fp6 kinds are out
+        if self.coarse in ("mx6", "mx6-top2", "mx6-half"):
+            raise ValueError("the fp6 modes prepare map and scan together in every registration: no prepare_map()")
+        self._mx6_ok = self._mx6_half_ok = False
+        self.mx6 = self.mx6_half = False
         main = torch.cuda.current_stream()
         for r in self.sets:
             if r.done is not None:
