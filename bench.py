@@ -198,15 +198,33 @@ def extra_configs(dev):
     r5 = pipe5.register(p5["q_desc"], p5["q_xyz"], p5["b_desc"], p5["b_xyz"])
     torch.cuda.synchronize()
     half5 = bool(pipe5.use_i8 and pipe5.half)   # the half-width pass: the kernel runs over the first 384 of the 768 columns
+    half5_fp6 = half5 and bool(getattr(pipe5, "mx6_half", False))
     f5 = 2.0 * n5 * m5 * (d5 // 2 if half5 else d5)
+    peak5 = MFMA_F6_PEAK_TFLOPS if half5_fp6 else MFMA_I8_PEAK_TOPS
     out["C5"] = {"workload": "50000-pt scan vs 1000000-pt map, 768-D, 50000 RANSAC iterations (one registration, serial)",
                  "ms_registration": t5_reg, "ms_coarse_kernel": t5, "correspondences": int(r5["count"].item()),
                  "pose_err_vs_planted": float(np.linalg.norm(r5["T"].cpu().numpy() - p5["T_gt"])),
-                 "coarse_pass": "int8, half-width (VFM_RECORDS_HALF)" if half5 else ("int8, packed top-2 records" if pipe5.top2 else "int8, best-score records"),
-                 "roofline": {"bound": "mfma", "kernel": ("match_coarse_i8q2_kernel<12> (int8 32x32x32 MFMA over the first 384 of 768 columns, 64 resident queries per wave)" if half5
+                 "coarse_pass": pass_name(pipe5),
+                 "roofline": {"bound": "mfma", "kernel": ("match_coarse_mx6q2_kernel<6, false, false, 12> (fp6 e2m3 32x32x64 scaled MFMA over the first 384 of 768 columns, 64 resident "
+                                                          "queries per wave)" if half5_fp6
+                                                          else "match_coarse_i8q2_kernel<12> (int8 32x32x32 MFMA over the first 384 of 768 columns, 64 resident queries per wave)" if half5
                                                           else "match_coarse_i8_kernel<24, 2> (int8 32x32x32 MFMA)"), "flops": f5,
-                              "achieved": f5 / (t5 * 1e-3) / 1e12, "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s",
-                              "frac": f5 / (t5 * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS}}
+                              "achieved": f5 / (t5 * 1e-3) / 1e12, "peak": peak5, "unit": "TFLOP/s",
+                              "frac": f5 / (t5 * 1e-3) / 1e12 / peak5}}
+    if half5_fp6:   # the same registration with the half-width pass on the int8 image (round 2's mode), for comparison
+        del pipe5
+        pipe5 = RegistrationPipeline(n5, m5, d5, n_iter=RANSAC_ITERS, device=dev, coarse="int8-half")
+        lib.vfm_prof_events_create(C.byref(a), C.byref(b))
+        ts = []
+        for k in range(3):
+            lib.vfm_prof_arm(a, b)
+            pipe5.register(p5["q_desc"], p5["q_xyz"], p5["b_desc"], p5["b_xyz"])
+            lib.vfm_prof_elapsed_ms(a, b, C.byref(ms))
+            if k:
+                ts.append(ms.value)
+        lib.vfm_prof_events_destroy(a, b)
+        out["C5"]["int8_half_width"] = {"ms_coarse_kernel": sorted(ts)[len(ts) // 2],
+                                        "ms_registration": timed(lambda: pipe5.register(p5["q_desc"], p5["q_xyz"], p5["b_desc"], p5["b_xyz"]), reps=3)}
     return out
 
 

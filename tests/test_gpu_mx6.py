@@ -74,7 +74,7 @@ def _search(q, b, gate, records, flags=PREPARE_MX6):
     return idx, sim
 
 
-@pytest.mark.parametrize("d,n,m", [(384, 2500, 9000), (256, 3000, 777)])
+@pytest.mark.parametrize("d,n,m", [(384, 2500, 9000), (256, 3000, 777), (768, 2300, 1500), (512, 700, 2600)])
 def test_mx6_image_is_the_e2m3_quantisation_of_the_fp16_rows_and_its_residuals_are_measured(d, n, m):
     """Every element of the fp6 image equals the definition above on the oracle's normalised rows (bit-identical to the
     library's); E of a row is at least the true |v - image|_2 (fp64) and at most that + the declared roundings; the group value is the
@@ -114,12 +114,14 @@ def test_mx6_bound_holds_pair_by_pair():
     assert 0.04 < bound.mean() < 0.075
 
 
-@pytest.mark.parametrize("d,n,m", [(384, 2500, 9000), (256, 3000, 5003), (384, 2100, 130), (384, 300, 20011), (512, 2300, 4100)])
+@pytest.mark.parametrize("d,n,m", [(384, 2500, 9000), (256, 3000, 5003), (384, 2100, 130), (384, 300, 20011), (512, 2300, 4100),
+                                   (768, 2200, 3000)])
 def test_mx6_pass_gives_the_oracle_answers_and_keeps_the_gate_contract(d, n, m):
     """VFM_RECORDS_MX6 on planted matches, heavy-tailed rows, rows that are all alike, exact duplicates, zero rows and
     rows of tiny norm: every resolved query has the oracle's index and similarity, every unresolved one is below the gate in the
-    oracle, with the gate at 0.8 and switched off.  (384, 300, .) and d = 512 have no fp6 kernel: the call behaves as best-score
-    records there, with or without the fp6 image.)"""
+    oracle, with the gate at 0.8 and switched off.  (384, 300, .) has no fp6 kernel: the call behaves as the int8 kinds there; d = 512
+    and 768 have the half-width fp6 kernel only -- the image comes from kernels of its own -- and the full-width kinds behave as their
+    int8 forms.)"""
     rng = np.random.default_rng(d + n)
     gate = float(np.nextafter(np.float32(0.8), np.float32(-np.inf)))
     cases = {}
@@ -182,7 +184,7 @@ def soak_trial_mx6(lib, rng, st):
     records: random shape (below and above the 2048 queries the fp6 kernel starts at), width, gate (or none) and data kind.
     Gate contract, pairwise: the same answer where both resolve; whatever only one resolves lies below the gate; the matches
     a caller keeps are identical; without a gate both resolve everything."""
-    d = int(rng.choice([256, 384, 384]))
+    d = int(rng.choice([256, 384, 384, 512, 768]))
     n = int(rng.integers(1, 9000))
     m = int(rng.integers(1, 60000))
     gsel = rng.choice([0.5, 0.8, 0.8, 0.95, -1.0])

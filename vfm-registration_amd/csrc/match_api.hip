@@ -395,7 +395,7 @@ VFM_EXPORT int vfm_debug_i8_rows(const void* prepared, int64_t rows, int d, int8
 // The fp6 image of a prepared operand (VFM_PREPARE_MX6), dequantised on the host: v6_host[rows][d] (float: code value x block
 // scale), err_host[rows] (E of the fp6 image, slack included), gerr_host[rows] (its group's maximum).  Tests only.
 VFM_EXPORT int vfm_debug_mx6_rows(const void* prepared, int64_t rows, int d, float* v6_host, float* err_host, float* gerr_host) {
-    VFM_CHECK_ARG(prepared && rows > 0 && mx6_width(d) && v6_host && err_host && gerr_host, "mx6_rows: bad arguments");
+    VFM_CHECK_ARG(prepared && rows > 0 && mx6_half_width(d) && v6_host && err_host && gerr_host, "mx6_rows: bad arguments");
     Prepared p = carve_prepared(const_cast<void*>(prepared), rows, d);
     const int64_t rp = rows_padded(rows);
     const size_t units = (size_t)rp / TILE_ROWS * (size_t)(d / 64) * 128;
@@ -417,8 +417,9 @@ VFM_EXPORT int vfm_debug_mx6_rows(const void* prepared, int64_t rows, int d, flo
                 op[i] = lo[i];
                 op[16 + i] = hi[i];
             }
-            const unsigned char* sc = reinterpret_cast<const unsigned char*>(&tiles[(size_t)tile * upt + 64 + h * 32 + pp]) + 8;
-            const float scale = ldexpf(1.0f, (int)sc[s] - 127);
+            // the scales of k-steps 0 .. 7 sit in the spare bytes of unit row 1, those of 8 .. 11 in unit row 3
+            const unsigned char* sc = reinterpret_cast<const unsigned char*>(&tiles[(size_t)tile * upt + (size_t)(s < 8 ? 1 : 3) * 64 + h * 32 + pp]) + 8;
+            const float scale = ldexpf(1.0f, (int)sc[s & 7] - 127);
             for (int f = 0; f < 32; ++f) {
                 const int bit = 6 * f;
                 const unsigned w = (unsigned)op[bit >> 3] | ((unsigned)op[(bit >> 3) + 1] << 8);

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
     constexpr int IMG_TILE_U4 = 2 * IMG_KS6 * 64;   // stride of the stored tiles
     constexpr int PF = KS6 % 3 == 0 ? 3 : 2;    // fragment look-ahead in k-steps (PF == KS6: every read is of the next tile)
     static_assert(KS6 % PF == 0 && (KS6 >= 2 * PF || KS6 == PF) && PIECES <= 2 * T && (T * UNITS) % NWAVES == 0 && KS6 >= 2 && KS6 <= 6 &&
-                      IMG_KS6 >= KS6, "shape");
+                      IMG_KS6 >= KS6 && IMG_KS6 <= 12, "shape (the scales of k-steps 0 .. 7 sit in unit row 1: KS6 <= 8)");
     static_assert(NBUF * TILE_BYTES <= 160 * 1024, "ring exceeds the LDS");
     // One barrier per step, between tiles 2 and 3.  A step of this kernel is half as long as the int8 kernel's for the same bytes
     // staged, so the staging loads need more of it: the pieces that lie inside tiles 0-2 of their step (EARLY of them) are
@@ -309,7 +309,8 @@ int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, bool half, hipStream_t st
     a.nslices = choose_slices(a.nqb, a.nchunks);
     if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
     int rc;
-    if (half) rc = d == 384 ? launch_mx6q2_half<3, 6>(a, st) : launch_mx6q2_half<2, 4>(a, st);
+    if (half) rc = d == 768 ? launch_mx6q2_half<6, 12>(a, st) : d == 512 ? launch_mx6q2_half<4, 8>(a, st)
+                            : d == 384 ? launch_mx6q2_half<3, 6>(a, st) : launch_mx6q2_half<2, 4>(a, st);
     else rc = d == 384 ? (top2 ? launch_mx6q2<6, true>(a, st) : launch_mx6q2<6, false>(a, st))
                        : (top2 ? launch_mx6q2<4, true>(a, st) : launch_mx6q2<4, false>(a, st));
     if (rc) return rc;

@@ -355,6 +355,8 @@ inline bool half_capable(int d, int64_t n) {
 }
 // widths the fp6 pass (VFM_RECORDS_MX6) has a kernel for: two resident query sets of d / 64 x 8 registers
 inline bool mx6_width(int d) { return d == 256 || d == 384; }
+// widths whose HALF-width pass has an fp6 kernel (d / 128 k-steps of queries in registers): the fp6 image exists for these
+inline bool mx6_half_width(int d) { return d == 256 || d == 384 || d == 512 || d == 768; }
 constexpr float MX6_FIX_STEP = 0.0009765625f;   // 2^-10: an fp6 record is ceil(score * 2^20) -- "integer score" x step x step
 // the fused form exists where the 64-queries-per-wave kernel runs and a map chunk collects several queries (chunk-major rescan)
 inline int effective_records(int records, int d, int64_t n, int64_t m) {
@@ -362,7 +364,7 @@ inline int effective_records(int records, int d, int64_t n, int64_t m) {
         records = VFM_RECORDS_HALF;
     if (records == VFM_RECORDS_MX6 && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_BEST;   // (the one-set kernels have no fp6 form)
     if (records == VFM_RECORDS_MX6_TOP2 && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_TOP2;
-    if (records == VFM_RECORDS_MX6_HALF && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_BEST;   // (such operands carry no int8 half image)
+    if (records == VFM_RECORDS_MX6_HALF && !(mx6_half_width(d) && n > 2048)) records = VFM_RECORDS_BEST;   // (such operands carry no int8 half image)
     return (records == VFM_RECORDS_HALF && !half_capable(d, n)) ? VFM_RECORDS_BEST : records;
 }
 
@@ -389,7 +391,7 @@ inline Prepared carve_prepared(void* p, int64_t rows, int d) {
         r.tiles8h = c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(d / 64) * 64);
         r.rest = c.take<float>((size_t)rp);
         r.grest = c.take<float>((size_t)rp / I8_GROUP);
-        if (mx6_width(d)) {   // the fp6 image: 32 bytes per (row, 64 columns) -- 24 of codes, the block scales, padding
+        if (mx6_half_width(d)) {   // the fp6 image: 32 bytes per (row, 64 columns) -- 24 of codes, the block scales, padding
             r.tiles6 = c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(d / 64) * 128);
             r.err6 = c.take<float>((size_t)rp);
             r.gerr6 = c.take<float>((size_t)rp / I8_GROUP);

@@ -455,6 +455,123 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The fp6 image for the wider rows (d = 512, 768: the half-width pass in fp6 reads its first d / 128 k-steps), by kernels of their
+// own behind prep_chunk_kernel (whose LDS cannot hold an fp16 copy of such a group): a thread takes one (row, 32-column block),
+// reads its 32 floats, normalises them with the 1 / |row| prep_chunk_kernel left, rounds to fp16 and converts exactly as that
+// kernel's second half does (same scale rule, v_cvt_scalef32_pk32_fp6_f16, residual measured against the fp16 values); the blocks
+// of a row are NBLK consecutive lanes, so the row's sum is a fixed xor tree.  The block scales of k-steps 0 .. 7 go to the spare
+// bytes of unit row 1, those of k-steps 8 .. 11 to unit row 3.  prep_mx6_group_kernel then takes the maximum E of every group.
+// ---------------------------------------------------------------------------------------------
+template <int NBLK>   // lanes per row: 16 (d = 512) or 32 (d = 768: 24 in use)
+__global__ __launch_bounds__(256) void prep_mx6_rows_kernel(const float* __restrict__ x1, int64_t rows1, int64_t pad1, int d, PrepOut o1,
+                                                            const float* __restrict__ x2, int64_t rows2, PrepOut o2, int64_t total) {
+    constexpr int RPB = 256 / NBLK;   // rows per workgroup
+    const int blk = threadIdx.x % NBLK;
+    int64_t g = (int64_t)blockIdx.x * RPB + threadIdx.x / NBLK;   // row of the padded concatenation
+    const bool beyond = g >= total;   // (total is a multiple of 256 rows: never with RPB = 8 / 16; kept for safety -- no early return before the barrier)
+    if (beyond) g = total - 1;
+    const bool second = g >= pad1;
+    const int64_t r = second ? g - pad1 : g;
+    const int64_t rows = second ? rows2 : rows1;
+    const float* x = second ? x2 : x1;
+    const PrepOut& o = second ? o2 : o1;
+    const bool active = blk < (d >> 5) && !beyond;
+    // the workgroup's RPB rows come in coalesced (consecutive threads, consecutive float4) and go through the LDS to the thread
+    // that owns their block: float4 j of block b at slot 8 b + (j ^ (b & 7)) of its row (the xor keeps the 128-byte-strided
+    // reads of a half-wave off one bank group)
+    extern __shared__ __attribute__((aligned(16))) unsigned char mx6_smem[];
+    float4* stage = reinterpret_cast<float4*>(mx6_smem);   // [RPB][d / 4]
+    const int nf4 = d >> 2;
+    const int64_t g0 = (int64_t)blockIdx.x * RPB;
+    for (int idx = threadIdx.x; idx < RPB * nf4; idx += 256) {
+        const int rr = idx / nf4, c4 = idx % nf4;
+        const int64_t gg = g0 + rr;
+        const bool sec = gg >= pad1;
+        const int64_t r2 = sec ? gg - pad1 : gg;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gg < total && r2 < (sec ? rows2 : rows1)) {
+            const float* pc = (sec ? x2 : x1) + r2 * (int64_t)d + 4 * c4;
+            t.x = __builtin_nontemporal_load(pc);
+            t.y = __builtin_nontemporal_load(pc + 1);
+            t.z = __builtin_nontemporal_load(pc + 2);
+            t.w = __builtin_nontemporal_load(pc + 3);
+        }
+        const int bb = c4 >> 3, jj = c4 & 7;
+        stage[rr * nf4 + bb * 8 + (jj ^ (bb & 7))] = t;
+    }
+    __syncthreads();
+    union {
+        halfx32 h;
+        unsigned w[16];
+    } v;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v.w[i] = 0u;
+    if (active && r < rows) {
+        const float iv = o.inv[r];
+        const float4* mine = stage + (threadIdx.x / NBLK) * nf4 + blk * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 t = mine[i ^ (blk & 7)];
+            v.h[4 * i + 0] = (_Float16)(t.x * iv);
+            v.h[4 * i + 1] = (_Float16)(t.y * iv);
+            v.h[4 * i + 2] = (_Float16)(t.z * iv);
+            v.h[4 * i + 3] = (_Float16)(t.w * iv);
+        }
+    }
+    ushortx2 m2 = {0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const unsigned a2 = v.w[i] & 0x7fff7fffu;
+        m2 = __builtin_elementwise_max(m2, *reinterpret_cast<const ushortx2*>(&a2));
+    }
+    const unsigned am = max((unsigned)m2[0], (unsigned)m2[1]);
+    int ex = (int)(am >> 10) - 15 - ((am & 0x3ffu) <= 0x3c0u ? 2 : 1);   // as in prep_chunk_kernel's conversion
+    ex = ex > 0 ? 0 : ex;
+    const float sc6 = __uint_as_float((unsigned)(ex + 127) << 23);
+    const intx6 codes = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v.h, sc6);
+    const halfx32 back = __builtin_amdgcn_cvt_scalef32_pk32_f16_fp6(codes, 1.0f);
+    float e6 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const float res = __builtin_fmaf(-(float)back[i], sc6, (float)v.h[i]);
+        e6 = __builtin_fmaf(res, res, e6);
+    }
+    if (!active) e6 = 0.0f;
+#pragma unroll
+    for (int off = NBLK / 2; off >= 1; off >>= 1) e6 = e6 + __shfl_xor(e6, off);
+    if (blk == 0 && !beyond) {
+        float e6n = sqrtf(e6) * 1.000244140625f + (MX6_F16_ROUNDING + MX6_SLACK);
+        if (!(e6n == e6n)) e6n = __builtin_inff();
+        if (r >= rows) e6n = 0.0f;
+        o.err6[r] = e6n;
+    }
+    if (active) {
+        const int t = (int)(r >> 5), p = (int)(r & 31), s6 = blk >> 1, l6 = (blk & 1) * 32 + p;
+        uint4* tile = o.tiles6 + (size_t)(r >> 5) * (size_t)((d >> 6) * 128);
+        (void)t;
+        tile[(2 * s6) * 64 + l6] = make_uint4((unsigned)codes[0], (unsigned)codes[1], (unsigned)codes[2], (unsigned)codes[3]);
+        *reinterpret_cast<uint2*>(tile + (2 * s6 + 1) * 64 + l6) = make_uint2((unsigned)codes[4], (unsigned)codes[5]);
+        reinterpret_cast<unsigned char*>(tile + (s6 < 8 ? 1 : 3) * 64 + l6)[8 + (s6 & 7)] = (unsigned char)(ex + 127);
+    }
+}
+
+__global__ __launch_bounds__(256) void prep_mx6_group_kernel(PrepOut o1, int groups1, PrepOut o2, int groups) {
+    const int gidx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gidx >= groups) return;
+    const bool second = gidx >= groups1;
+    const PrepOut& o = second ? o2 : o1;
+    const int grp = second ? gidx - groups1 : gidx;
+    const int lane = lane_id();
+    float m = fmaxf(o.err6[(int64_t)grp * I8_GROUP + lane], o.err6[(int64_t)grp * I8_GROUP + 64 + lane]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) {
+        o.gerr6[grp] = m;
+        o.gstep6[grp] = MX6_FIX_STEP;
+    }
+}
+
 // in-place renorm (vfm_l2norm_rows_f32): one wave per row
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x, int64_t rows, int d,
                                                           float* __restrict__ inv_out) {
@@ -507,7 +624,8 @@ inline int prep_grid(int groups, int mode) {
 // will meet in an int8 search (use_i8): a third of the bytes written, a third of the LDS.
 int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2, int64_t rows2, void* prepared2, int d,
                 hipStream_t st, bool want_f16, int grid_mode) {
-    const bool want_mx6 = (grid_mode & VFM_PREPARE_MX6) != 0 && mx6_width(d);
+    const bool want_mx6 = (grid_mode & VFM_PREPARE_MX6) != 0 && mx6_width(d);              // int8 + fp6 image from one kernel
+    const bool want_mx6_wide = (grid_mode & VFM_PREPARE_MX6) != 0 && !want_mx6 && mx6_half_width(d);   // d = 512, 768: kernels of their own
     grid_mode &= ~VFM_PREPARE_MX6;
     Prepared p1 = carve_prepared(prepared1, rows1, d);
     Prepared p2 = x2 ? carve_prepared(prepared2, rows2, d) : Prepared{};
@@ -551,6 +669,17 @@ int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2
             }
         }
         VFM_CHECK_LAUNCH("prep_chunk_kernel");
+        if (want_mx6_wide) {
+            const int64_t pad1 = rows_padded(rows1), total = pad1 + (x2 ? rows_padded(rows2) : 0);
+            if (d == 512)
+                hipLaunchKernelGGL((prep_mx6_rows_kernel<16>), dim3((unsigned)((total + 15) / 16)), dim3(256), (size_t)16 * d * 4, st, x1, rows1, pad1, d,
+                                   prep_out(p1), x2, rows2, prep_out(p2), total);
+            else
+                hipLaunchKernelGGL((prep_mx6_rows_kernel<32>), dim3((unsigned)((total + 7) / 8)), dim3(256), (size_t)8 * d * 4, st, x1, rows1, pad1, d,
+                                   prep_out(p1), x2, rows2, prep_out(p2), total);
+            hipLaunchKernelGGL(prep_mx6_group_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, st, prep_out(p1), g1, prep_out(p2), groups);
+            VFM_CHECK_LAUNCH("prep_mx6_rows_kernel");
+        }
         return VFM_OK;
     }
     hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)(t1 + t2)), dim3(256), (size_t)d * 64, st, x1, rows1, d, p1.inv, p1.tiles,

@@ -120,12 +120,12 @@ class RegistrationPipeline:
         # "auto": where the fp6 kernel exists the half-width pass it settles on is the fp6 one (0.40 against 0.60 ms of coarse
         # kernel at C2 size, 1500-1600 against 1300-1360 registrations/s; the probe itself runs on the int8 half-width image, which
         # every preparation writes)
-        self._mx6_half_ok = coarse == "auto" and d in (256, 384) and n > 2048
+        self._mx6_half_ok = coarse == "auto" and d in (256, 384, 512, 768) and n > 2048
         # ... and where the half-width bound does not prune but best-score int8 records rescan only a few chunks per query (maps of
         # distinct places), the full-width pass moves to fp6 too: its bounds are ~3x wider, so it is tried below MX6_UP rescanned
         # chunks per query and left again above MX6_DOWN (tools/ab_mx6_bench.py: lifted descriptors of independent scenes, 6.2 int8 /
         # 21 fp6 rescans per query: 732 / 793 against 651 / 721 registrations/s; with a common component, 12.5 / 45: 590 against 630)
-        self._mx6_ok = self._mx6_half_ok
+        self._mx6_ok = self._mx6_half_ok and d in (256, 384)   # (the full-width fp6 kernel: two query sets of d / 64 k-steps in registers)
         self._mx6_tried = False
         self._probe_due = coarse == "auto" and self.gate
         # which form of the half-width pass: with the selection fused into the coarse kernel (VFM_RECORDS_HALF_FUSED = 4: no
