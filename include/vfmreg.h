@@ -115,9 +115,10 @@ int vfm_match_prepare2_gated(const float *x1, int64_t rows1, void *prepared1, co
 #define VFM_PREPARE_DEFAULT 0
 #define VFM_PREPARE_PERSISTENT 1
 #define VFM_PREPARE_INTERLEAVED 2
-/*   VFM_PREPARE_MX6          flag, or-ed into `schedule`: write the fp6 image as well (d = 256 / 384; what the VFM_RECORDS_MX6*
- *                            searches read).  About twice the preparation time (0.2 against 0.1 ms at C2 size): the image is
- *                            converted from an fp16 copy of the rows behind the int8 one.  Ignored for other widths.  An
+/*   VFM_PREPARE_MX6          flag, or-ed into `schedule`: write the fp6 image as well (d = 256 / 384 / 512 / 768; what the
+ *                            VFM_RECORDS_MX6* searches read).  0.14 against 0.09 ms at C2 size: for d <= 384 the image is converted
+ *                            from an fp16 copy of the rows inside the int8 kernel; the wider rows are read a second time by a
+ *                            kernel of its own (C5 size: + 1 ms).  Ignored for other widths.  An
  *                            operand prepared WITHOUT the flag says so in its fp6 bounds (infinite): a search that asks for an
  *                            fp6 record kind on it prunes nothing and ends in the exact all-pairs decision -- the oracle's
  *                            answers, orders of magnitude slower -- rather than reading an image that is not there. */
@@ -184,7 +185,7 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
  *                     image's quantisation bound + |rest of the query| * max |rest of a row of the chunk| against the gate -- on the
  *                     scaled MFMA, over the first d / 64 / 2 k-steps of the fp6 image (no second image).  Needs a finite gate
  *                     and operands prepared with VFM_PREPARE_MX6; behind the selection it is VFM_RECORDS_HALF (device-side guard
- *                     included).  d = 256 / 384 with more than 2048 queries; elsewhere it behaves as VFM_RECORDS_BEST. */
+ *                     included).  d = 256 / 384 / 512 / 768 with more than 2048 queries; elsewhere it behaves as VFM_RECORDS_BEST. */
 #define VFM_RECORDS_MX6_HALF 7
 int vfm_match_search_coarse_gated_r(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
                                     int d, void *ws, size_t ws_bytes, int records, vfm_stream_t stream);

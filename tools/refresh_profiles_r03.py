@@ -128,7 +128,7 @@ The same pipeline away from the favourable case (VERDICT r2 item 2), same proces
 - {variant('C2_lifted')} -- map descriptors lifted from overlapping patch grids (near-duplicates), policy by feedback
 - `extra.A6_mutual_l2`: {json.dumps(a6)[:600]}
 - `extra.C3`: {ex['C3']['ms_end_to_end']:.2f} ms end to end (ViT {ex['C3']['ms_vit']:.3f}, project + lift {ex['C3']['ms_project_lift']:.3f}, registration {ex['C3']['ms_registration']:.2f}; ViT at {ex['C3']['vit_roofline']['frac']:.3f} of the fp16 MFMA peak)
-- `extra.C5` (50k x 1M x 768, int8 pass): coarse kernel {ex['C5']['ms_coarse_kernel']:.1f} ms = {ex['C5']['roofline']['frac']:.3f} of the int8 peak, registration {ex['C5']['ms_registration']:.1f} ms
+- `extra.C5` (50k x 1M x 768; pass in use: {ex['C5'].get('coarse_pass', '?')}): coarse kernel {ex['C5']['ms_coarse_kernel']:.1f} ms = {ex['C5']['roofline']['frac']:.3f} of {ex['C5']['roofline']['peak'] / 1000:.0f} P(FL)OP/s, registration {ex['C5']['ms_registration']:.1f} ms; half-width pass on the int8 image, same box: {json.dumps(ex['C5'].get('int8_half_width'))}
 
 Same box, `VFM_COARSE=int8 python bench.py` (full-width int8 pass as the whole run) -> `profiles/r03_bench_int8_full_same_box.json`:
 {bi['value']:.1f} registrations/s, kernel {bi['roofline']['avg_launch_ms']:.3f} ms ({bi['roofline']['frac']:.3f} of the int8 peak).
