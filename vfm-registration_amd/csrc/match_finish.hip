@@ -356,6 +356,14 @@ __global__ __launch_bounds__(64 * 8) void match_select_half_kernel(
     const uint4* src = reinterpret_cast<const uint4*>(best + (size_t)qt * nchunks * 32) + lane;
     const int nblocks = (nchunks + 7) >> 3;
     for (int cb0 = wave; cb0 < nblocks; cb0 += 8 * 8) {
+        if (cand) {
+            // The guard, early: once four queries of a lane average 4 x HALF_GUARD_PER_QUERY surviving chunks the search is going to
+            // take the gate pass anyway (half_guard_kernel) -- raise its flag now, leave a load figure that says so, and stop: on
+            // descriptors that are all alike the full sweep (31 million survivors, each a few atomics) took 21 ms.  Every workgroup
+            // stops at the flag; the gate pass ignores what the lists hold.
+            if (__hip_atomic_load(fb_count + HALF_GUARD_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        }
+        bool stop = false;
         uint4 rec[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -365,7 +373,12 @@ __global__ __launch_bounds__(64 * 8) void match_select_half_kernel(
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int c = (cb0 + 8 * u) * 8 + lc;
-            if (c >= nchunks) continue;
+            if (c >= nchunks || stop) continue;
+            if (cand && lcnt[lq] + lcnt[lq + 1] + lcnt[lq + 2] + lcnt[lq + 3] > 16 * HALF_GUARD_PER_QUERY) {
+                if (atomicExch(fb_count + HALF_GUARD_FLAG, 1) == 0) atomicExch(fb_count + 5, 0x3FFFFFFF);
+                stop = true;
+                continue;
+            }
             const float2 cb2 = chunk_lds ? lchunk[c] : make_float2(ib.bstep[c], ib.berr[c]);
             const float rb = chunk_lds ? lrest[c] : grest[c];
             const float sc = sq * cb2.x;
@@ -393,6 +406,7 @@ __global__ __launch_bounds__(64 * 8) void match_select_half_kernel(
                 }
             }
         }
+        if (stop) break;
     }
     __syncthreads();
     if (threadIdx.x < 64) {   // one wave: the tile's 32 queries
@@ -717,7 +731,14 @@ template <int KS>  // k-steps of 32 columns (d / 32)
 __global__ __launch_bounds__(256, 2) void match_gatepass_kernel(int64_t n, int64_t m, int nq_tiles, I8Bounds ib,
                                                                 const float* __restrict__ invq, const uint4* __restrict__ q8,
                                                                 const uint4* __restrict__ b8, float gate, int* __restrict__ cand_cnt,
-                                                                unsigned* __restrict__ cand, int cap, const int* __restrict__ guard) {
+                                                                unsigned* __restrict__ cand, int cap, const int* __restrict__ guard,
+                                                                unsigned* __restrict__ qlow) {
+    // qlow (the search's qmax array: unused by the half-width selection, zero = -Inf): float_key of a lower bound of the query's
+    // exact maximum, published by whichever workgroup finds a better one.  Where hundreds of rows per query reach the gate -- lifted
+    // descriptors with a common component -- a row whose upper bound lies below it cannot be the arg-max and is not appended (the
+    // arg-max itself, and every row tied with it, has an upper bound at or above every lower bound ever published): the lists the
+    // refinement gets shrink from "every row above the gate" to "rows near the best" (forced half-width pass on such a map: 22 ms
+    // per C2-size registration before)
     if (*guard == 0) return;
     constexpr int TILE_U4 = KS * 64;
     const int c = blockIdx.x, lane = lane_id(), wave = threadIdx.x >> 6;
@@ -770,12 +791,20 @@ __global__ __launch_bounds__(256, 2) void match_gatepass_kernel(int64_t n, int64
         for (int r = 1; r < 16; ++r) mx = max(mx, acc[r]);
         // the expressions of match_rescan_chunk_kernel / match_rescan_kernel: the same rows pass
         const float sc = sq * sb, bound = (eq * 1.0001220703125f + 1.0e-6f) + (1.0001220703125f + eq) * be;
-        const bool any = live && (sc * (float)mx + bound >= gate);
+        float thr = gate;
+        if (live) {
+            const float ql = key_float(__hip_atomic_load(qlow + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            // this lane's best row lies at or above sc * mx - bound (padding rows of the last chunk score 0: only a positive score counts)
+            const float mine = (row0 + 27 < m || mx > 0) ? __builtin_fmaf(sc, (float)mx, -bound) : -__builtin_inff();
+            if (mine > ql && mine >= gate) atomicMax(qlow + q, float_key(mine));
+            thr = fmaxf(gate, fmaxf(ql, mine));
+        }
+        const bool any = live && (sc * (float)mx + bound >= thr);
         if (__ballot(any) != 0ull && any) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const long long row = row0 + (e & 3) + 8 * (e >> 2);
-                if (row < m && sc * (float)acc[e] + bound >= gate) {
+                if (row < m && sc * (float)acc[e] + bound >= thr) {
                     const int pos = atomicAdd(&cand_cnt[q], 1);
                     if (pos < cap) cand[(size_t)q * cap + pos] = ((unsigned)c << 8) | (unsigned)(row - (long long)c * CHUNK_ROWS);
                 }
@@ -1604,7 +1633,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
 #define VFM_GATEPASS(KS)                                                                                                        \
     hipLaunchKernelGGL(match_gatepass_kernel<KS>, dim3((unsigned)a.nchunks), dim3(256), 0, st, n, m, a.nq_tiles,                  \
                        i8_bounds(Q, B, true, records), (const float*)Q.inv, (const uint4*)Q.tiles8, (const uint4*)B.tiles8, gate, \
-                       w.cand_cnt, w.cand, w.cap, guard)
+                       w.cand_cnt, w.cand, w.cap, guard, w.qmax)
                 switch (d / 32) {
                     case 8: VFM_GATEPASS(8); break;
                     case 12: VFM_GATEPASS(12); break;
