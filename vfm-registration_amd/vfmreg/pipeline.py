@@ -302,7 +302,9 @@ class RegistrationPipeline:
             if i8 and not reuse_map:
                 # the preparation kernel's launch shape: persistent when it runs alone or beside the half-width coarse kernel
                 # (which leaves registers free), short workgroups beside the full-width one (include/vfmreg.h)
-                schedule = 1 if (records in (3, 4, 7) or not (self.overlap and self.overlap_prepare)) else 2
+                # (re-measured on the stable pipeline, 20 / 200 steps: fp6 half-width 1345-1371 / 1568 persistent against 1364-1387 / 1578
+                # interleaved; int8 full width 701-704 / 779 against 705-707 / 788)
+                schedule = 1 if (records in (3, 4) or not (self.overlap and self.overlap_prepare)) else 2
                 if self._prep_schedule is not None:
                     schedule = int(self._prep_schedule)
                 if records in (5, 6, 7):
