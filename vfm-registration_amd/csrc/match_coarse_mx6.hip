@@ -307,6 +307,15 @@ int launch_mx6q2_half(const CoarseArgs& a, hipStream_t st) {
 int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, bool half, hipStream_t st) {
     a.nqb = (a.nq_tiles + 15) / 16;
     a.nslices = choose_slices(a.nqb, a.nchunks);
+    if (half && g_force_slices == 0) {
+        // the half-width kernel's workgroups are short, and shorter ones let the other stages of a pipeline in: ~7.5 rounds of 256
+        // workgroups instead of choose_slices' 5 (tools/sweep_slices.py, C2, 200 steps: 48 slices 1548 against 32 slices 1475
+        // registrations/s; the full-width fp6 kernel and the int8 kernels are flat from 32 on)
+        int s = (int)((1920 + a.nqb - 1) / a.nqb);
+        const int smax = a.nchunks / 8 < 64 ? a.nchunks / 8 : 64;
+        s = s > smax ? smax : s;
+        a.nslices = s < 1 ? 1 : s;
+    }
     if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
     int rc;
     if (half) rc = d == 768 ? launch_mx6q2_half<6, 12>(a, st) : d == 512 ? launch_mx6q2_half<4, 8>(a, st)
