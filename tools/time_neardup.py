@@ -94,7 +94,9 @@ def main():
             key = name + " | " + coarse
             hist = {f"<= {1 << bnum}": st[8 + bnum] for bnum in range(16) if st[8 + bnum]}
             res[key] = dict(ms_per_registration=1e3 * dt, registrations_per_s=1.0 / dt, correspondences=k, pose_err_vs_planted=err,
-                            pass_in_use=("int8" if pipe.use_i8 else "fp16"), records_in_use=("half-width" if (pipe.use_i8 and pipe.half) else "top-2" if pipe.top2 else "best score"),
+                            pass_in_use=(("fp6" if ((pipe.half and getattr(pipe, "mx6_half", False)) or (not pipe.half and getattr(pipe, "mx6", False))) else "int8")
+                                         if pipe.use_i8 else "fp16"),
+                            records_in_use=("half-width" if (pipe.use_i8 and pipe.half) else "top-2" if (pipe.top2 or getattr(pipe, "mx6_top2", False)) else "best score"),
                             same_result_as_auto=same,
                             rescanned_chunks_per_query=(pipe.last_rescans / n) if pipe.last_rescans is not None else None,
                             fallback_queries=st[0], refined_queries=st[1], coarse_records_per_query=st[4] / n, candidate_entries_per_query=st[2] / n,
