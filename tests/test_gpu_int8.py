@@ -141,7 +141,8 @@ def test_gate_leaves_only_provably_rejected_queries_unresolved():
 
 def test_pipeline_changes_records_on_a_duplicate_rich_map_and_results_do_not_change():
     """auto mode: the first gated search reports how many candidate chunks it had to rescan; on a map where every point has
-    about eighty near-copies the pipeline moves to the packed top-2 records (a chunk with one row inside the bounds then costs
+    about eighty near-copies the pipeline -- with the switch point set to 20 rescanned chunks per query here; the fitted value sits
+    beyond what this small map can produce -- moves to the packed top-2 records (a chunk with one row inside the bounds then costs
     one fp32 row instead of a 48 KB rescan).  Poses and correspondences are those of every fixed mode."""
     n, m, d = 2000, 40000, 384
     g = torch.Generator(device="cuda")
@@ -156,6 +157,7 @@ def test_pipeline_changes_records_on_a_duplicate_rich_map_and_results_do_not_cha
     outs = {}
     for coarse in ("auto", "int8", "int8-top2", "fp16"):
         pipe = RegistrationPipeline(n, m, d, n_iter=5000, overlap_ransac=True, coarse=coarse)
+        pipe.RESCAN_LIMIT = 20.0
         first_rescans = None
         for _ in range(5):
             out = pipe.register(q, p["q_xyz"], b, p["b_xyz"])
@@ -170,7 +172,7 @@ def test_pipeline_changes_records_on_a_duplicate_rich_map_and_results_do_not_cha
     # the int8 pass stays; best-score records do not: the feedback moves on to top-2 records, or -- where the probe of the
     # half-width pass finds few enough survivors (the ~80 copies of a matched point) -- to the half-width pass
     assert outs["auto"][2] is True and (outs["auto"][3] is True or outs["auto"][5] is True)
-    assert outs["auto"][4] > RegistrationPipeline.RESCAN_LIMIT * n         # what the first (best-score) search reported
+    assert outs["auto"][4] > 20.0 * n                                      # what the first (best-score) search reported
     assert outs["int8"][2:4] == (True, False) and outs["int8-top2"][2:4] == (True, True) and outs["fp16"][2] is False
     for coarse in ("int8", "int8-top2", "fp16"):
         assert torch.equal(outs["auto"][0], outs[coarse][0]) and torch.equal(outs["auto"][1], outs[coarse][1]), coarse

@@ -81,7 +81,7 @@ def main():
             q = torch.where(is_out[:, None], torch.randn((n, d), generator=g, device=dev), q)
             p["b_desc"], p["q_desc"] = b.contiguous(), q.contiguous()
         ref = None
-        for coarse in ("auto", "int8-half", "int8", "int8-top2", "fp16"):  # the bench's pipeline: prepare on its own stream, two solve streams
+        for coarse in ("auto", "int8-half", "int8", "mx6", "int8-top2", "fp16"):  # the bench's pipeline: prepare on its own stream, two solve streams
             pipe = RegistrationPipeline(n, m, d, n_iter=50000, overlap_ransac=True, overlap_prepare=True, solve_streams=2, coarse=coarse)
             dt, st, out = run(pipe, p, a.steps, lib, n, m)
             k = int(out["count"].item())

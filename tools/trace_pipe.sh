@@ -1,7 +1,7 @@
-# kernel timeline of the pipelined registration (mode $1, default mx6-half): per HIP stream (queue) the busy time and the
+# kernel timeline of the pipelined registration (mode $1, default mx6-half; data $2: d2 (default) or lifted; $3 = False: no overlap, every kernel alone): per HIP stream (queue) the busy time and the
 # kernels, per registration -> gpurun_out/trace_pipe
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/trace_pipe
+O=$R/gpurun_out/trace_pipe_${1:-mx6-half}_${2:-d2}_${3:-True}
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cat > /tmp/pipe_only.py <<PY
@@ -11,12 +11,13 @@ import torch
 from vfmreg import synth
 from vfmreg.pipeline import RegistrationPipeline
 n, m, d = 20000, 200000, 384
-pairs = [synth.make_pair_device(n, m, d, seed=42 + p) for p in range(2)]
+pairs = [synth.make_lifted_pair_device(n, m, d, seed=42 + p, device="cuda", clouds=10, view_noise=0.1, common=1.0) if "${2:-d2}" == "lifted" else synth.make_pair_device(n, m, d, seed=42 + p) for p in range(2)]
 ev = torch.cuda.Event(); ev.record()
-pipe = RegistrationPipeline(n, m, d, n_iter=50000, overlap_ransac=True, overlap_prepare=True, solve_streams=2, coarse="${1:-mx6-half}")
+pipe = RegistrationPipeline(n, m, d, n_iter=50000, overlap_ransac=${3:-True}, overlap_prepare=${3:-True}, solve_streams=2, coarse="${1:-mx6-half}")
 for i in range(60):
     p = pairs[i % 2]; pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"], inputs_ready=ev)
 pipe.synchronize(); torch.cuda.synchronize()
+print("records", pipe._records(), "rescanned chunks per query", (pipe.last_rescans or 0) / n)
 PY
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O -o t -- python /tmp/pipe_only.py > $O/out.txt 2>&1
 python - <<PY

@@ -253,9 +253,9 @@ __global__ __launch_bounds__(512, 2) void match_coarse_i8q2_kernel(CoarseArgs a)
                         // (a chunk that has collected FUSE_BIN_SATURATE_X times its bin capacity already -- descriptors that are all alike -- stops
                         // recording: the entry is dropped and the search's guard flag raised, match_gatepass_kernel then decides
                         // every query; without the cut-off such data cost this kernel 31 million atomics)
-                        const unsigned seen = __hip_atomic_load(&a.bin_cnt[chunk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned seen = __hip_atomic_load(&a.bin_cnt[(size_t)chunk * BIN_CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const unsigned saturate = (unsigned)(FUSE_BIN_SATURATE_X * a.bin_cap);
-                        const unsigned pos = seen >= saturate ? seen : atomicAdd(&a.bin_cnt[chunk], 1u);
+                        const unsigned pos = seen >= saturate ? seen : atomicAdd(&a.bin_cnt[(size_t)chunk * BIN_CNT_STRIDE], 1u);
                         if (pos < (unsigned)a.bin_cap) {
                             a.bins[(size_t)chunk * a.bin_cap + pos] = (int)q;
                         } else if (pos < saturate) {   // a full bin leaves the entry in the query's own list (match_rescan_kernel)

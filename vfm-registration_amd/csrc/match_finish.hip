@@ -393,8 +393,8 @@ __global__ __launch_bounds__(64 * 8) void match_select_half_kernel(
                     if (bins) {
                         // (a full bin is not touched again: on descriptors that are all alike every query survives in every
                         // chunk, and 31 million atomics on 1563 addresses were most of this kernel's time there)
-                        const unsigned seen = __hip_atomic_load(&bin_cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned pos = seen >= (unsigned)bin_cap ? seen : atomicAdd(&bin_cnt[c], 1u);
+                        const unsigned seen = __hip_atomic_load(&bin_cnt[(size_t)c * BIN_CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned pos = seen >= (unsigned)bin_cap ? seen : atomicAdd(&bin_cnt[(size_t)c * BIN_CNT_STRIDE], 1u);
                         if (pos < (unsigned)bin_cap) {
                             bins[(size_t)c * bin_cap + pos] = (int)(q0 + j);
                             slot = cap;
@@ -446,6 +446,7 @@ __global__ __launch_bounds__(64 * 8) void match_select_half_kernel(
 // record bytes (the general kernel reads two 128-byte pieces per instruction: 103 us for the 125 MB of C2's records; this
 // one is bound by the sweep itself).
 constexpr int SELECT_BEST_WAVES = 8;
+constexpr int SELECT_BEST_LCAND = 6144;   // candidates of a query tile staged in the LDS (192 per query; beyond: the direct path)
 __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kernel(
     const unsigned* __restrict__ best, int nchunks, int64_t n, const unsigned* __restrict__ qmax, const float* __restrict__ invq,
     I8Bounds ib, float gate, int chunk_lds, int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
@@ -457,6 +458,12 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
     __shared__ unsigned lub[32];  // float_key of the largest upper bound over the query's chunks
     __shared__ unsigned lmaxe;    // float_key of the largest max E over the chunks
     __shared__ int ldead[32];     // the query records nothing (see below)
+    // The tile's candidates, (query of the tile << 27) | chunk: a candidate costs two LDS atomics inside the sweep; the global
+    // side -- the chunk's bin (a returning atomic on one of ~1500 addresses) or the query's own list -- is done behind the
+    // sweep for all of them at once.  Inside the sweep every candidate had stalled its wave for a round trip: 151 us against
+    // 70 at 12 candidate chunks per query (lifted descriptors) and 317 at 46 (the fp6 pass's bounds).
+    __shared__ unsigned lcand[SELECT_BEST_LCAND];
+    __shared__ int lcand_n;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int qt = blockIdx.x;
     if (threadIdx.x < 32) {
@@ -464,7 +471,10 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
         lov[threadIdx.x] = 0;
         lub[threadIdx.x] = 0u;
     }
-    if (threadIdx.x == 0) lmaxe = 0u;
+    if (threadIdx.x == 0) {
+        lmaxe = 0u;
+        lcand_n = 0;
+    }
     __syncthreads();
     float2* lchunk = reinterpret_cast<float2*>(select_smem);
     if (chunk_lds) {
@@ -516,6 +526,21 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
     }
     const uint4* src = reinterpret_cast<const uint4*>(best + (size_t)qt * nchunks * 32) + lane;
     const int nblocks = (nchunks + 7) >> 3;
+    // candidate (query qq of the tile, chunk c): chunk-major rescan -> the query joins the chunk's bin, a full bin leaves the entry
+    // with the query; otherwise the entry goes to the query's own list (lov counts the list's entries either way)
+    auto place = [&](int qq, int c) {
+        const int64_t q = (int64_t)qt * 32 + qq;
+        if (bins) {
+            const unsigned seen = __hip_atomic_load(&bin_cnt[(size_t)c * BIN_CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned pos = seen >= (unsigned)bin_cap ? seen : atomicAdd(&bin_cnt[(size_t)c * BIN_CNT_STRIDE], 1u);
+            if (pos < (unsigned)bin_cap) {
+                bins[(size_t)c * bin_cap + pos] = (int)q;
+                return;
+            }
+        }
+        const int slot = atomicAdd(&lov[qq], 1);
+        if (slot < cap) cand[(size_t)q * cap + slot] = ((unsigned)c << 8) | 128u;  // whole-chunk entry
+    };
     for (int cb0 = wave; cb0 < nblocks; cb0 += 8 * SELECT_BEST_WAVES) {
         uint4 rec[8];
 #pragma unroll
@@ -537,19 +562,20 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
                 maxup[j] = fmaxf(maxup[j], up1);
                 // (zero-padded rows score exactly 0: a padded chunk is a candidate only if 0 is inside the bounds)
                 if (up1 >= qlow[j] && !((deadmask >> j) & 1u)) {
-                    int slot = atomicAdd(&lcnt[lq + j], 1);
-                    if (bins) {  // chunk-major rescan: the query joins the chunk's bin; a full bin leaves the entry with the query
-                        const unsigned pos = atomicAdd(&bin_cnt[c], 1u);
-                        if (pos < (unsigned)bin_cap) {
-                            bins[(size_t)c * bin_cap + pos] = (int)(q0 + j);
-                            slot = cap;
-                        } else {
-                            slot = atomicAdd(&lov[lq + j], 1);
-                        }
-                    }
-                    if (slot < cap) cand[(size_t)(q0 + j) * cap + slot] = ((unsigned)c << 8) | 128u;  // whole-chunk entry
+                    atomicAdd(&lcnt[lq + j], 1);
+                    const int at = atomicAdd(&lcand_n, 1);
+                    if (at < SELECT_BEST_LCAND) lcand[at] = ((unsigned)(lq + j) << 27) | (unsigned)c;
+                    else place(lq + j, c);   // the staging buffer is full: placed on the spot
                 }
             }
+        }
+    }
+    __syncthreads();
+    {
+        const int ncand = lcand_n < SELECT_BEST_LCAND ? lcand_n : SELECT_BEST_LCAND;
+        for (int i = threadIdx.x; i < ncand; i += 64 * SELECT_BEST_WAVES) {
+            const unsigned e = lcand[i];
+            place((int)(e >> 27), (int)(e & 0x7FFFFFFu));
         }
     }
 #pragma unroll
@@ -593,7 +619,7 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
             } else {
                 // chunk-major rescan: the list holds only the entries that missed their bins; match_rescan_chunk_kernel
                 // appends the rows it finds behind what match_rescan_kernel makes of these
-                cand_cnt[q] = bins ? lov[qq] : cnt;
+                cand_cnt[q] = lov[qq];
             }
         }
     }
@@ -608,6 +634,11 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
 // scores of 32 rows x 32 queries; a row inside the query's bounds is appended to the query's list (one atomic per lane and
 // block for all of its hits).  Same integers, same hit test, hence the same rows as the v_dot4 loop it replaces (24 LDS reads +
 // 96 dot4 per query and wave: 26 us at C2's 9891 candidates but 0.7 ms at the 220 000 of an ungated Euclidean search).
+constexpr int RESCAN_LHITS = 2048;   // rows a workgroup of match_rescan_chunk_kernel stages in the LDS before it touches the lists
+template <int KS>
+constexpr int rescan_ring_depth() { return KS <= 16 ? 3 : 2; }
+template <int KS>
+constexpr size_t rescan_slot_bytes() { return (size_t)KS * 1024 + 768; }   // operand image + three rows of 64 per-query terms
 template <int KS>  // k-steps of 32 columns (d / 32)
 __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int64_t m, I8Bounds ib, const uint4* __restrict__ q8,
                                                                  const uint4* __restrict__ b8, const unsigned* __restrict__ qmax,
@@ -615,17 +646,37 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
                                                                  const unsigned* __restrict__ bin_cnt, const int* __restrict__ bins,
                                                                  int use_gate, float gate, const int* __restrict__ guard, L2Terms l2,
                                                                  int bin_cap) {
+    // A ring of D slots, one per block of 32 queries: [KS][64] uint4 = the block's queries as ONE MFMA operand image (unit u =
+    // (k-step s, half h, column p) comes from query bin[j0 + p]), then [3][64] dwords of per-query terms.  Everything a block needs
+    // from global memory arrives by LDS-DMA issued D - 1 blocks ahead (wave w gathers k-steps w, w + 4, ...: its 64 lanes' units
+    // are 1 KiB of consecutive LDS), so that the loop holds no compiler-tracked global load -- one would drain the DMA queue at its
+    // s_waitcnt -- and a block costs its MFMAs, not its round trips (gather -> barrier -> MFMA -> returning atomic in sequence had
+    // cost ~5 us per block: 148 us at 12 candidate chunks per query, 616 at 46).
     extern __shared__ __attribute__((aligned(16))) unsigned char rescan_smem[];
-    uint4* l_qf = reinterpret_cast<uint4*>(rescan_smem);   // [KS][64]: the 32 queries of a block as ONE MFMA operand image
+    constexpr int D = rescan_ring_depth<KS>();
+    constexpr unsigned SLOT = (unsigned)rescan_slot_bytes<KS>();
+    constexpr int TILE_U4 = KS * 64;
+    constexpr int NG = KS / 4;      // gathered 1 KiB pieces per wave and block (KS % 4 == 0)
+    __shared__ int lbin[RESCAN_SLICE];
+    // The workgroup's hits, staged: the global side (a returning atomic on the query's list length, then the entry) is done
+    // for all of them at once behind the loop.
+    __shared__ int lhq[RESCAN_LHITS];
+    __shared__ unsigned char lhr[RESCAN_LHITS];
+    __shared__ int lhit_n;
     const int c = blockIdx.x;
     if (guard && *guard) return;   // half-width pass, too many survivors: match_gatepass_kernel has decided every query
-    const unsigned filled = bin_cnt[c];
+    const unsigned filled = bin_cnt[(size_t)c * BIN_CNT_STRIDE];
     const int nall = filled < (unsigned)bin_cap ? (int)filled : bin_cap;
     const int jbeg = blockIdx.y * RESCAN_SLICE;   // a long bin is shared by the workgroups (c, 0), (c, 1), ...
     if (jbeg >= nall) return;
     const int nq = nall - jbeg < RESCAN_SLICE ? nall - jbeg : RESCAN_SLICE;
+    const int nblocks = (nq + 31) >> 5;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    constexpr int TILE_U4 = KS * 64;
+    if (threadIdx.x == 0) lhit_n = 0;
+    {
+        const int* bin = bins + (size_t)c * bin_cap + jbeg;
+        for (int t = threadIdx.x; t < nblocks * 32; t += 256) lbin[t] = t < nq ? bin[t] : 0;
+    }
     intx4 af[KS];
     {
         const uint4* asrc = b8 + ((size_t)c * 4 + wave) * TILE_U4 + lane;
@@ -635,34 +686,48 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
             af[s] = *reinterpret_cast<const intx4*>(&v);
         }
     }
-    const int* bin = bins + (size_t)c * bin_cap + jbeg;
     const float bstep = ib.bstep[c], berr = ib.berr[c];
     const long long base = (long long)c * CHUNK_ROWS;
     const int rr0 = wave * 32 + 4 * (lane >> 5);   // + (e & 3) + 8 (e >> 2): the chunk row of accumulator element e
     float bn16[16];                                // Euclidean mode: |b~| of the lane's sixteen rows
 #pragma unroll
     for (int e = 0; e < 16; ++e) bn16[e] = l2.qn ? l2.bn[base + rr0 + (e & 3) + 8 * (e >> 2)] : 0.0f;
-    int qnext = (lane & 31) < nq ? bin[lane & 31] : 0;
-    for (int j0 = 0; j0 < nq; j0 += 32) {          // the bin, one MFMA column block at a time
-        const int j = j0 + (lane & 31);
-        const int qi = qnext;
-        if (j + 32 < nq) qnext = bin[j + 32];
-        // The block's fragment units are gathered ONCE per workgroup into the LDS (a unit shares its 512-byte line of the scan's
-        // tiles with 31 other queries: four waves gathering for themselves moved 100 KB through the L2 per block and wave).
-        // Unit u = (k-step s, half h, column p) comes from query bin[j0 + p]; thread t takes units t, t + 256, ...
-        if (j0) __syncthreads();                   // the previous block's image has been read
+    __syncthreads();   // (drains the loads above: from here on the vector-memory queue holds DMA only)
+    const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS unsigned char*)rescan_smem;
+    // terms of a slot, rows of 64 dwords: [0] cand_cnt | qerr, [1] qstep | qmax, [2] qn | -   (lanes 0-31 | 32-63)
+    auto issue = [&](int blk) {
+        const int qi = lbin[blk * 32 + (lane & 31)];
+        const unsigned slot = lds_base + (unsigned)(blk % D) * SLOT;
+        const uint4* src = q8 + (size_t)(qi >> 5) * TILE_U4 + (size_t)(2 * wave + (lane >> 5)) * 32 + (qi & 31);
 #pragma unroll
-        for (int u = threadIdx.x; u < TILE_U4; u += 256) {
-            // (u & 31 == lane & 31 for every u of this thread: the unit belongs to its own column's query)
-            l_qf[u] = q8[(size_t)(qi >> 5) * TILE_U4 + (size_t)(u >> 5) * 32 + (qi & 31)];
-        }
-        const bool live = j < nq && cand_cnt[qi] >= 0;   // (-2: below the gate, -1: already with the all-pairs kernel)
-        const float eq = ib.qerr[qi];
-        const float sc = ib.qstep[qi >> 7] * bstep;                    // the same expressions as match_rescan_kernel: the same rows pass
+        for (int t = 0; t < NG; ++t)
+            glds16(src + (size_t)t * 256, __builtin_amdgcn_readfirstlane(slot + (unsigned)(wave + 4 * t) * 1024u));
+        const unsigned terms = slot + (unsigned)KS * 1024u;
+        if (wave == 0) glds4(lane < 32 ? (const void*)(cand_cnt + qi) : (const void*)(ib.qerr + qi), __builtin_amdgcn_readfirstlane(terms));
+        if (wave == 1)
+            glds4(lane < 32 ? (const void*)(ib.qstep + (qi >> 7)) : (const void*)(qmax + qi), __builtin_amdgcn_readfirstlane(terms + 256u));
+        if (wave == 2 && l2.qn) glds4((const void*)(l2.qn + qi), __builtin_amdgcn_readfirstlane(terms + 512u));
+    };
+#pragma unroll
+    for (int blk = 0; blk < D - 1; ++blk)
+        if (blk < nblocks) issue(blk);
+    for (int blk = 0; blk < nblocks; ++blk) {          // the bin, one MFMA column block at a time
+        // this wave's pieces of block blk have landed: at most the D - 2 blocks issued behind it may still be in flight
+        if (D > 2 && blk + D - 2 < nblocks) wait_vmcnt<(D > 2 ? (D - 2) * NG : 0)>();
+        else wait_vmcnt<0>();
+        __syncthreads();                               // ... and every wave's; block blk - 1 has been read by every wave
+        if (blk + D - 1 < nblocks) issue(blk + D - 1);
+        const unsigned char* slot = rescan_smem + (size_t)(blk % D) * SLOT;
+        const uint4* l_qf = reinterpret_cast<const uint4*>(slot);
+        const int* lt = reinterpret_cast<const int*>(slot + (size_t)KS * 1024);
+        const int j = blk * 32 + (lane & 31);
+        const int qi = lbin[j];
+        const bool live = j < nq && lt[lane & 31] >= 0;   // (-2: below the gate, -1: already with the all-pairs kernel)
+        const float eq = __int_as_float(lt[32 + (lane & 31)]);
+        const float sc = __int_as_float(lt[64 + (lane & 31)]) * bstep;   // the same expressions as match_rescan_kernel: the same rows pass
         const float bound = (eq * 1.0001220703125f + 1.0e-6f) + (1.0001220703125f + eq) * berr;
-        const float qlow = use_gate ? gate : key_float(qmax[qi]);     // half-width pass: the hit test is the gate itself
-        const float qn = l2.qn ? l2.qn[qi] : 0.0f;
-        __syncthreads();
+        const float qlow = use_gate ? gate : key_float((unsigned)lt[96 + (lane & 31)]);   // half-width pass: the hit test is the gate itself
+        const float qn = l2.qn ? __int_as_float(lt[128 + (lane & 31)]) : 0.0f;
         intx16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0;
@@ -671,8 +736,6 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
             const uint4 v = l_qf[s * 64 + lane];
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s], *reinterpret_cast<const intx4*>(&v), acc, 0, 0, 0);
         }
-        // the lane's hits first (a bit per accumulator element), then ONE atomic for all of them: a returning atomic per hit
-        // stalled the wave once per element slot
         unsigned hits = 0u;
         if (live) {
 #pragma unroll
@@ -684,14 +747,62 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
             }
         }
         if (hits) {
-            int pos = atomicAdd(&cand_cnt[qi], __popc(hits));
+            int at = atomicAdd(&lhit_n, __popc(hits));
             while (hits) {
                 const int e = __ffs(hits) - 1;
                 hits &= hits - 1u;
-                if (pos < cap) cand[(size_t)qi * cap + pos] = ((unsigned)c << 8) | (unsigned)(rr0 + (e & 3) + 8 * (e >> 2));
-                ++pos;
+                const int rr = rr0 + (e & 3) + 8 * (e >> 2);
+                if (at < RESCAN_LHITS) {
+                    lhq[at] = qi;
+                    lhr[at] = (unsigned char)rr;
+                } else {   // more hits than the staging buffer holds (duplicate-rich chunk): on the spot
+                    const int pos = atomicAdd(&cand_cnt[qi], 1);
+                    if (pos < cap) cand[(size_t)qi * cap + pos] = ((unsigned)c << 8) | (unsigned)rr;
+                }
+                ++at;
             }
         }
+        // (a full staging buffer is emptied before the next block adds to it; lhit_n is read by every thread between two barriers
+        // that no atomic of another block can cross, so the branch is uniform)
+        __syncthreads();
+        if (lhit_n > RESCAN_LHITS - 32 * CHUNK_ROWS / 4 || blk + 1 == nblocks) {
+            wait_vmcnt<0>();   // (the atomics below are compiler-tracked: nothing of the ring may be pending behind them)
+            const int nh = lhit_n < RESCAN_LHITS ? lhit_n : RESCAN_LHITS;
+            for (int i = threadIdx.x; i < nh; i += 256) {
+                const int hq = lhq[i];
+                const int pos = atomicAdd(&cand_cnt[hq], 1);
+                if (pos < cap) cand[(size_t)hq * cap + pos] = ((unsigned)c << 8) | (unsigned)lhr[i];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) lhit_n = 0;
+        }
+    }
+}
+
+template <int KS>
+int launch_rescan_chunk_ks(const SearchWs& w, int nchunks, int64_t n, int64_t m, I8Bounds ib, const Prepared& Q, const Prepared& B,
+                           int use_gate, float gate, const int* guard, L2Terms l2, hipStream_t st) {
+    const size_t lds = (size_t)rescan_ring_depth<KS>() * rescan_slot_bytes<KS>();   // + ~14 KB of static LDS: past 64 KB in all from KS = 16
+    static unsigned long long attr_set = 0ull;  // one bit per device
+    if (!attr_done(attr_set)) {
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_rescan_chunk_kernel<KS>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_mark(attr_set);
+    }
+    hipLaunchKernelGGL(match_rescan_chunk_kernel<KS>, dim3((unsigned)nchunks, (unsigned)((w.bin_cap + RESCAN_SLICE - 1) / RESCAN_SLICE)),
+                       dim3(256), lds, st, n, m, ib, (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt,
+                       w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, use_gate, gate, guard, l2, w.bin_cap);
+    VFM_CHECK_LAUNCH("match_rescan_chunk_kernel");
+    return VFM_OK;
+}
+int launch_rescan_chunk(const SearchWs& w, int nchunks, int64_t n, int64_t m, int d, I8Bounds ib, const Prepared& Q, const Prepared& B,
+                        int use_gate, float gate, const int* guard, L2Terms l2, hipStream_t st) {
+    switch (d / 32) {
+        case 8: return launch_rescan_chunk_ks<8>(w, nchunks, n, m, ib, Q, B, use_gate, gate, guard, l2, st);
+        case 12: return launch_rescan_chunk_ks<12>(w, nchunks, n, m, ib, Q, B, use_gate, gate, guard, l2, st);
+        case 16: return launch_rescan_chunk_ks<16>(w, nchunks, n, m, ib, Q, B, use_gate, gate, guard, l2, st);
+        case 20: return launch_rescan_chunk_ks<20>(w, nchunks, n, m, ib, Q, B, use_gate, gate, guard, l2, st);
+        default: return launch_rescan_chunk_ks<24>(w, nchunks, n, m, ib, Q, B, use_gate, gate, guard, l2, st);
     }
 }
 
@@ -712,7 +823,7 @@ __global__ __launch_bounds__(256) void half_guard_kernel(int* __restrict__ fb_co
     __shared__ long long part[4];
     long long s = 0;
     if (fused)
-        for (int c = threadIdx.x; c < nchunks; c += 256) s += (long long)bin_cnt[c];
+        for (int c = threadIdx.x; c < nchunks; c += 256) s += (long long)bin_cnt[(size_t)c * BIN_CNT_STRIDE];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     if (lane_id() == 0) part[threadIdx.x >> 6] = s;
@@ -901,6 +1012,38 @@ struct RefineWave {
                     acc = __builtin_fmaf(qv[t].y, bv.y * ib, acc);
                     acc = __builtin_fmaf(qv[t].z, bv.z * ib, acc);
                     acc = __builtin_fmaf(qv[t].w, bv.w * ib, acc);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
+        return acc;
+    }
+    // score4 in two halves, so that the next pass's row can be on its way while this pass's is summed (the same operations in
+    // the same order: the same float)
+    struct Row {
+        float4 v[12];
+        float ib;
+    };
+    __device__ __forceinline__ void load4(Row& r, long long row) const {
+        if (row >= 0) {
+            r.ib = invb[row];
+            const float* br = b + row * (int64_t)d + 4 * l;
+#pragma unroll
+            for (int t = 0; t < 12; ++t)
+                if (t < nt) r.v[t] = *reinterpret_cast<const float4*>(br + 64 * t);
+        }
+    }
+    __device__ __forceinline__ float dot4(const Row& r, long long row) const {
+        float acc = 0.0f;
+        if (row >= 0) {
+#pragma unroll
+            for (int t = 0; t < 12; ++t) {
+                if (t < nt) {
+                    acc = __builtin_fmaf(qv[t].x, r.v[t].x * r.ib, acc);
+                    acc = __builtin_fmaf(qv[t].y, r.v[t].y * r.ib, acc);
+                    acc = __builtin_fmaf(qv[t].z, r.v[t].z * r.ib, acc);
+                    acc = __builtin_fmaf(qv[t].w, r.v[t].w * r.ib, acc);
                 }
             }
         }
@@ -1113,17 +1256,31 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
     if (cnt < REFINE_MIN && !__any(flagged)) continue;
     RefineWave R;
     R.init(q, invq[qi], qi, b, invb, d, w2, l_row[wave], l_sc[wave]);
-    // single-row entries: 4 per pass
-    for (int e0 = 0; e0 < cnt; e0 += 4) {
-        long long row = -1;
-        if (e0 + R.g < cnt) {
-            const unsigned ce = mycand[e0 + R.g];
+    // single-row entries: 4 per pass, 64 list entries per load, the next pass's rows in flight under the current pass's sums (a
+    // pass had been two dependent round trips -- the entry, then the row --: 164 us at the 25 rows per query of lifted descriptors)
+    for (int e0 = 0; e0 < cnt; e0 += 64) {
+        const int nblk = cnt - e0 < 64 ? cnt - e0 : 64;
+        long long myrow = -1;
+        if (lane < nblk) {
+            const unsigned ce = mycand[e0 + lane];
             if (!(ce & 128u)) {
-                row = (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u);
-                if (row >= m) row = -1;
+                myrow = (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u);
+                if (myrow >= m) myrow = -1;
             }
         }
-        if (__any(row >= 0)) R.consider(row, R.score4(row));
+        if (!__any(myrow >= 0)) continue;
+        auto row_at = [&](int p) { return p < nblk ? __shfl(myrow, (p + R.g) & 63) : -1ll; };   // (lanes >= nblk hold -1)
+        RefineWave::Row ra, rb;
+        long long rowa = row_at(0), rowb;
+        R.load4(ra, rowa);
+        for (int p = 0; p < nblk; p += 8) {
+            rowb = row_at(p + 4);
+            R.load4(rb, rowb);
+            if (__any(rowa >= 0)) R.consider(rowa, R.dot4(ra, rowa));
+            rowa = row_at(p + 8);
+            R.load4(ra, rowa);
+            if (__any(rowb >= 0)) R.consider(rowb, R.dot4(rb, rowb));
+        }
     }
     // whole-chunk entries: all 128 rows of the chunk
     for (int e = 0; e < cnt; ++e) {
@@ -1645,22 +1802,9 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                 VFM_CHECK_LAUNCH("match_gatepass_kernel");
             }
             if (use_bins) {
-                const size_t lds = (size_t)(d / 32) * 64 * sizeof(uint4);
-#define VFM_RESCAN_CHUNK(UH)                                                                                                  \
-    hipLaunchKernelGGL(match_rescan_chunk_kernel<UH>, dim3((unsigned)a.nchunks, (unsigned)((w.bin_cap + RESCAN_SLICE - 1) / RESCAN_SLICE)), \
-                       dim3(256), lds, st, n, m,                                                                                 \
-                       i8_bounds(Q, B, true, records), (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, \
-                       w.cand_cnt, w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, half ? 1 : 0, gate, guard, \
-                       L2Terms{nullptr, nullptr, 0.0f}, w.bin_cap)
-                switch (d / 32) {
-                    case 8: VFM_RESCAN_CHUNK(8); break;
-                    case 12: VFM_RESCAN_CHUNK(12); break;
-                    case 16: VFM_RESCAN_CHUNK(16); break;
-                    case 20: VFM_RESCAN_CHUNK(20); break;
-                    default: VFM_RESCAN_CHUNK(24); break;
-                }
-#undef VFM_RESCAN_CHUNK
-                VFM_CHECK_LAUNCH("match_rescan_chunk_kernel");
+                const int rc = launch_rescan_chunk(w, a.nchunks, n, m, d, i8_bounds(Q, B, true, records), Q, B, half ? 1 : 0, gate, guard,
+                                                   L2Terms{nullptr, nullptr, 0.0f}, st);
+                if (rc != VFM_OK) return rc;
             }
             hipLaunchKernelGGL(match_rescan_close_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, w.cand_cnt, w.cap,
                                w.fb_count, w.fb_list, reinterpret_cast<int*>(w.rec_cnt), half ? (const float*)Q.inv : (const float*)nullptr);
@@ -1701,21 +1845,8 @@ int launch_i8_rescans(const SearchWs& w, const CoarseArgs& a, const Prepared& Q,
                        2 * w.rcap, w.fb_count, w.fb_list, 0, 0.0f, (const int*)nullptr, l2);
     VFM_CHECK_LAUNCH("match_rescan_kernel");
     if (use_bins) {
-        const size_t lds = (size_t)(d / 32) * 64 * sizeof(uint4);
-#define VFM_RESCAN_CHUNK(UH)                                                                                                       \
-    hipLaunchKernelGGL(match_rescan_chunk_kernel<UH>, dim3((unsigned)a.nchunks, (unsigned)((w.bin_cap + RESCAN_SLICE - 1) / RESCAN_SLICE)), \
-                       dim3(256), lds, st, n, m, ib, (const uint4*)Q.tiles8,                                                        \
-                       (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt, w.cand, w.cap, (const unsigned*)w.bin_cnt,     \
-                       (const int*)w.bins, 0, 0.0f, (const int*)nullptr, l2, w.bin_cap)
-        switch (d / 32) {
-            case 8: VFM_RESCAN_CHUNK(8); break;
-            case 12: VFM_RESCAN_CHUNK(12); break;
-            case 16: VFM_RESCAN_CHUNK(16); break;
-            case 20: VFM_RESCAN_CHUNK(20); break;
-            default: VFM_RESCAN_CHUNK(24); break;
-        }
-#undef VFM_RESCAN_CHUNK
-        VFM_CHECK_LAUNCH("match_rescan_chunk_kernel");
+        const int rc = launch_rescan_chunk(w, a.nchunks, n, m, d, ib, Q, B, 0, 0.0f, (const int*)nullptr, l2, st);
+        if (rc != VFM_OK) return rc;
     }
     hipLaunchKernelGGL(match_rescan_close_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, w.cand_cnt, w.cap, w.fb_count,
                        w.fb_list, reinterpret_cast<int*>(w.rec_cnt), (const float*)nullptr);

@@ -414,8 +414,8 @@ __global__ __launch_bounds__(64 * SELECT_L2_WAVES) void match_select_l2_kernel(
             const int64_t q = (int64_t)qt * 32 + qq;
             int slot = -1;
             if (bins) {  // chunk-major rescan: the query joins the chunk's bin; a full bin leaves the entry with the query
-                const unsigned seen = __hip_atomic_load(&bin_cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned pos = seen >= (unsigned)bin_cap ? seen : atomicAdd(&bin_cnt[c], 1u);
+                const unsigned seen = __hip_atomic_load(&bin_cnt[(size_t)c * BIN_CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned pos = seen >= (unsigned)bin_cap ? seen : atomicAdd(&bin_cnt[(size_t)c * BIN_CNT_STRIDE], 1u);
                 if (pos < (unsigned)bin_cap) bins[(size_t)c * bin_cap + pos] = (int)q;
                 else slot = atomicAdd(&lov[qq], 1);
             } else {

@@ -196,10 +196,15 @@ class RegistrationPipeline:
     # figures carried a +-15 % scatter from the hardware queues -- tools/ab_mx6_bench.py, 20 / 200 steps: 6.2 rescanned chunks per
     # query: best-score 651 / 721 vs top-2 593 / 655 registrations/s; 12.5: 630 / 683 vs 599 / 649; the crossover of round 2 is at
     # ~30 (profiles/r03_neardup.json: 9.4 per query 3.16 vs 3.23 ms))
+    # (end of round 3, after the finish stage's rework -- candidates and hits staged in the LDS, the bin counters one per
+    # 128-byte line, the chunk-major rescan fed by an LDS-DMA ring: a candidate chunk costs a third of what it did -- best-score
+    # records win on every map of profiles/r03_neardup.json, in fp6 where the kernel exists: every point seen by 200 clouds,
+    # 99 rescanned chunks per query: fp6 2.48 / int8 2.67 / top-2 3.17 ms; by 50 clouds: 1.55 / 1.70 / 1.89; lifted + common
+    # component, 12.5 int8 / 46 fp6 rescans: 654 / 633 / 585 registrations/s.  The limits now sit beyond the measured range.)
     HALF_LIMIT = 24.0
-    RESCAN_LIMIT = 20.0
-    MX6_UP = 8.0
-    MX6_DOWN = 32.0
+    RESCAN_LIMIT = 128.0
+    MX6_UP = 128.0
+    MX6_DOWN = 400.0
     TOP2_LIMIT = 40
     REPROBE = 256       # registrations before one step back towards the cheaper kernel is probed
 
