@@ -32,6 +32,10 @@ timeout 600 python tools/soak_mx6.py 40 303 2>&1 | tail -3 > $O/soak_mx6.txt; ca
 # what a cycle of the pipeline consists of: per-stream kernel timeline (int8 half-width, fp6 half-width), thin kernels beside the coarse kernels
 { bash tools/trace_pipe.sh int8-half 2>&1 | tail -40; echo; bash tools/trace_pipe.sh mx6-half 2>&1 | tail -40; echo; timeout 300 python tools/corun_probe.py 2>&1 | tail -4; } > $O/pipeline_cycle.txt
 cd $R && timeout 900 python tools/time_neardup.py --steps 20 --out $O/neardup.json > $O/neardup.log 2>&1
+# the finish stage on descriptors that look like lifted ones: candidate / hit counts, kernel by kernel (alone), and the pipeline's timeline
+{ timeout 300 python tools/lifted_stats.py 1.0 2>&1 | grep -v amdgpu.ids; timeout 300 python tools/lifted_stats.py 0.0 2>&1 | grep -v amdgpu.ids; } > $O/lifted_stats.txt
+{ bash tools/prof_finish.sh 0,5 0 lifted 2>&1 | grep records; bash tools/prof_finish.sh 0,5 0 d2 2>&1 | grep records; } > $O/prof_finish.txt
+{ echo "== auto, overlapped"; bash tools/trace_pipe.sh auto lifted 2>&1 | tail -45; echo "== int8, every kernel alone"; bash tools/trace_pipe.sh int8 lifted False 2>&1 | tail -32; echo "== mx6, every kernel alone"; bash tools/trace_pipe.sh mx6 lifted False 2>&1 | tail -32; } > $O/lifted_cycle.txt
 # row A6 (find_correspondences' mutual filter): timing, kernel sequence
 timeout 300 python tools/time_pairs.py 6 > $O/time_pairs.txt 2>&1; cat $O/time_pairs.txt
 bash tools/prof_pairs.sh > $O/prof_pairs.txt 2>&1

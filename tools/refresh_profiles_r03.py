@@ -52,7 +52,8 @@ def main():
               "ab_vit_xcd.txt": "r03_ab_vit_xcd.txt", "prof_c3_one.txt": "r03_prof_c3_one.txt",
               "pmc_match_coarse_mx6.json": "r03_pmc_match_coarse_mx6.json", "pmc_match_coarse_mx6half.json": "r03_pmc_match_coarse_mx6half.json",
               "queue_probe.txt": "r03_queue_probe.txt", "dev_mx6.txt": "r03_dev_mx6.txt",
-              "ab_mx6_bench.txt": "r03_ab_mx6_bench.txt", "soak_mx6.txt": "r03_soak_mx6.txt", "pipeline_cycle.txt": "r03_pipeline_cycle.txt", "soak_half.txt": "r03_soak_half.txt", "soak_match.txt": "r03_soak_match.txt", "mx6_probe.txt": "r03_mx6_probe.txt"}
+              "ab_mx6_bench.txt": "r03_ab_mx6_bench.txt", "soak_mx6.txt": "r03_soak_mx6.txt", "pipeline_cycle.txt": "r03_pipeline_cycle.txt", "soak_half.txt": "r03_soak_half.txt", "soak_match.txt": "r03_soak_match.txt", "mx6_probe.txt": "r03_mx6_probe.txt",
+              "lifted_stats.txt": "r03_lifted_stats.txt", "prof_finish.txt": "r03_prof_finish.txt", "lifted_cycle.txt": "r03_lifted_cycle.txt"}
     for i in range(1, 8):
         copies[f"pmc_pass{i}_counter_collection.csv"] = f"r03_pmc_pass{i}_counter_collection.csv"
         copies[f"pmc_half_pass{i}_counter_collection.csv"] = f"r03_pmc_half_pass{i}_counter_collection.csv"
@@ -81,7 +82,7 @@ def main():
         name = k.split(" | ")[0]
         if name not in maps:
             maps.append(name)
-    modes = [c for c in ("int8-half", "int8", "int8-top2", "fp16") if all(f"{m} | {c}" in nd for m in maps)]
+    modes = [c for c in ("int8-half", "int8", "mx6", "int8-top2", "fp16") if all(f"{m} | {c}" in nd for m in maps)]
     nd_rows = "\n".join(
         f"| {name} | {nd[name + ' | auto']['ms_per_registration']:.2f} ({nd[name + ' | auto']['pass_in_use']}"
         f"{'' if nd[name + ' | auto']['pass_in_use'] == 'fp16' else ', ' + str(nd[name + ' | auto'].get('records_in_use', '?'))}) | "

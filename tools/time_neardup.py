@@ -55,6 +55,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--out", default="")
+    ap.add_argument("--rows", type=int, default=0, help="only the first so many maps")
+    ap.add_argument("--modes", default="auto,int8-half,int8,mx6,int8-top2,fp16")
     a = ap.parse_args()
     lib = _lib.load()
     n, m, d = 20000, 200000, 384
@@ -68,7 +70,7 @@ def main():
              "revisited: 20k physical points seen by 10 clouds each (view noise 0.02)": dict(clouds=10, view_noise=0.02, revisit=3334),
              "revisited: 4k physical points seen by 50 clouds each (view noise 0.01)": dict(clouds=50, view_noise=0.01, revisit=667),
              "revisited: 1k physical points seen by 200 clouds each (view noise 0.01)": dict(clouds=200, view_noise=0.01, revisit=167)}
-    for name, cfg in cases.items():
+    for name, cfg in list(cases.items())[:a.rows or None]:
         p = dict(base)
         if cfg is not None:
             b = lifted_map(m, d, cfg["clouds"], 6, 16, 21, 7, cfg["view_noise"], dev, cfg.get("revisit", 0))
@@ -81,7 +83,7 @@ def main():
             q = torch.where(is_out[:, None], torch.randn((n, d), generator=g, device=dev), q)
             p["b_desc"], p["q_desc"] = b.contiguous(), q.contiguous()
         ref = None
-        for coarse in ("auto", "int8-half", "int8", "mx6", "int8-top2", "fp16"):  # the bench's pipeline: prepare on its own stream, two solve streams
+        for coarse in a.modes.split(","):  # the bench's pipeline: prepare on its own stream, two solve streams
             pipe = RegistrationPipeline(n, m, d, n_iter=50000, overlap_ransac=True, overlap_prepare=True, solve_streams=2, coarse=coarse)
             dt, st, out = run(pipe, p, a.steps, lib, n, m)
             k = int(out["count"].item())
@@ -99,6 +101,7 @@ def main():
                             records_in_use=("half-width" if (pipe.use_i8 and pipe.half) else "top-2" if (pipe.top2 or getattr(pipe, "mx6_top2", False)) else "best score"),
                             same_result_as_auto=same,
                             rescanned_chunks_per_query=(pipe.last_rescans / n) if pipe.last_rescans is not None else None,
+                            half_width_probe_survivors_per_query=(pipe.last_probe / n) if getattr(pipe, "last_probe", None) is not None else None,
                             fallback_queries=st[0], refined_queries=st[1], coarse_records_per_query=st[4] / n, candidate_entries_per_query=st[2] / n,
                             rows_kept_per_refined_query=(st[3] / st[1]) if st[1] else 0.0, candidate_entry_histogram=hist)
             print(key, json.dumps(res[key]), flush=True)

@@ -528,10 +528,13 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
     const int nblocks = (nchunks + 7) >> 3;
     // candidate (query qq of the tile, chunk c): chunk-major rescan -> the query joins the chunk's bin, a full bin leaves the entry
     // with the query; otherwise the entry goes to the query's own list (lov counts the list's entries either way)
-    auto place = [&](int qq, int c) {
+    // (crowded: a tile with more than 64 candidate chunks per query looks at the counter first -- on descriptors that are all alike
+    // every bin is full after the first tiles, and 31 million atomics on 1563 addresses were most of the kernel's time then; below
+    // that the look is a second trip to the memory side per candidate for nothing)
+    auto place = [&](int qq, int c, bool crowded) {
         const int64_t q = (int64_t)qt * 32 + qq;
         if (bins) {
-            const unsigned seen = __hip_atomic_load(&bin_cnt[(size_t)c * BIN_CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned seen = crowded ? __hip_atomic_load(&bin_cnt[(size_t)c * BIN_CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             const unsigned pos = seen >= (unsigned)bin_cap ? seen : atomicAdd(&bin_cnt[(size_t)c * BIN_CNT_STRIDE], 1u);
             if (pos < (unsigned)bin_cap) {
                 bins[(size_t)c * bin_cap + pos] = (int)q;
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
                     atomicAdd(&lcnt[lq + j], 1);
                     const int at = atomicAdd(&lcand_n, 1);
                     if (at < SELECT_BEST_LCAND) lcand[at] = ((unsigned)(lq + j) << 27) | (unsigned)c;
-                    else place(lq + j, c);   // the staging buffer is full: placed on the spot
+                    else place(lq + j, c, true);   // the staging buffer is full: placed on the spot
                 }
             }
         }
@@ -573,9 +576,10 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
     __syncthreads();
     {
         const int ncand = lcand_n < SELECT_BEST_LCAND ? lcand_n : SELECT_BEST_LCAND;
+        const bool crowded = lcand_n > 32 * 64;
         for (int i = threadIdx.x; i < ncand; i += 64 * SELECT_BEST_WAVES) {
             const unsigned e = lcand[i];
-            place((int)(e >> 27), (int)(e & 0x7FFFFFFu));
+            place((int)(e >> 27), (int)(e & 0x7FFFFFFu), crowded);
         }
     }
 #pragma unroll
@@ -645,7 +649,7 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
                                                                  int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
                                                                  const unsigned* __restrict__ bin_cnt, const int* __restrict__ bins,
                                                                  int use_gate, float gate, const int* __restrict__ guard, L2Terms l2,
-                                                                 int bin_cap) {
+                                                                 int bin_cap, unsigned* __restrict__ hit_cnt) {
     // A ring of D slots, one per block of 32 queries: [KS][64] uint4 = the block's queries as ONE MFMA operand image (unit u =
     // (k-step s, half h, column p) comes from query bin[j0 + p]), then [3][64] dwords of per-query terms.  Everything a block needs
     // from global memory arrives by LDS-DMA issued D - 1 blocks ahead (wave w gathers k-steps w, w + 4, ...: its 64 lanes' units
@@ -756,7 +760,7 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
                     lhq[at] = qi;
                     lhr[at] = (unsigned char)rr;
                 } else {   // more hits than the staging buffer holds (duplicate-rich chunk): on the spot
-                    const int pos = atomicAdd(&cand_cnt[qi], 1);
+                    const int pos = cand_cnt[qi] + (int)atomicAdd(&hit_cnt[(size_t)qi * BIN_CNT_STRIDE], 1u);
                     if (pos < cap) cand[(size_t)qi * cap + pos] = ((unsigned)c << 8) | (unsigned)rr;
                 }
                 ++at;
@@ -769,8 +773,10 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
             wait_vmcnt<0>();   // (the atomics below are compiler-tracked: nothing of the ring may be pending behind them)
             const int nh = lhit_n < RESCAN_LHITS ? lhit_n : RESCAN_LHITS;
             for (int i = threadIdx.x; i < nh; i += 256) {
+                // (the list's length stays as the selection / match_rescan_kernel left it during this kernel; the appended rows are
+                // counted in hit_cnt, a line of their own per query, and added by match_rescan_close_kernel)
                 const int hq = lhq[i];
-                const int pos = atomicAdd(&cand_cnt[hq], 1);
+                const int pos = cand_cnt[hq] + (int)atomicAdd(&hit_cnt[(size_t)hq * BIN_CNT_STRIDE], 1u);
                 if (pos < cap) cand[(size_t)hq * cap + pos] = ((unsigned)c << 8) | (unsigned)lhr[i];
             }
             __syncthreads();
@@ -791,7 +797,7 @@ int launch_rescan_chunk_ks(const SearchWs& w, int nchunks, int64_t n, int64_t m,
     }
     hipLaunchKernelGGL(match_rescan_chunk_kernel<KS>, dim3((unsigned)nchunks, (unsigned)((w.bin_cap + RESCAN_SLICE - 1) / RESCAN_SLICE)),
                        dim3(256), lds, st, n, m, ib, (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt,
-                       w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, use_gate, gate, guard, l2, w.bin_cap);
+                       w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, use_gate, gate, guard, l2, w.bin_cap, w.hit_cnt);
     VFM_CHECK_LAUNCH("match_rescan_chunk_kernel");
     return VFM_OK;
 }
@@ -929,10 +935,15 @@ __global__ __launch_bounds__(256, 2) void match_gatepass_kernel(int64_t n, int64
 // took 190 us)
 __global__ __launch_bounds__(256) void match_rescan_close_kernel(int64_t n, int* __restrict__ cand_cnt, int cap,
                                                                  int* __restrict__ fb_count, int* __restrict__ fb_list,
-                                                                 int* __restrict__ todo, const float* __restrict__ invq_half) {
+                                                                 int* __restrict__ todo, const float* __restrict__ invq_half,
+                                                                 const unsigned* __restrict__ hit_cnt) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = lane_id();
-    const int cnt = q < n ? cand_cnt[q] : 0;
+    int cnt = q < n ? cand_cnt[q] : 0;
+    if (q < n && cnt >= 0) {   // + the rows of the chunk-major rescan
+        const int hits = (int)hit_cnt[(size_t)q * BIN_CNT_STRIDE];
+        if (hits) cand_cnt[q] = cnt = cnt + hits;
+    }
     // half-width pass (invq_half != NULL): a live query whose surviving chunks held no row at the gate has no match
     if (invq_half && q < n && cnt == 0 && invq_half[q] != 0.0f) cand_cnt[q] = -2;
     if (cnt > cap) {
@@ -1807,7 +1818,8 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                 if (rc != VFM_OK) return rc;
             }
             hipLaunchKernelGGL(match_rescan_close_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, w.cand_cnt, w.cap,
-                               w.fb_count, w.fb_list, reinterpret_cast<int*>(w.rec_cnt), half ? (const float*)Q.inv : (const float*)nullptr);
+                               w.fb_count, w.fb_list, reinterpret_cast<int*>(w.rec_cnt), half ? (const float*)Q.inv : (const float*)nullptr,
+                               (const unsigned*)w.hit_cnt);
             VFM_CHECK_LAUNCH("match_rescan_close_kernel");
             // (rec_cnt, unused by the int8 pass, holds the list of crowded queries; fb_count[6] its length)
             const unsigned grid = (unsigned)((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024);
@@ -1849,7 +1861,7 @@ int launch_i8_rescans(const SearchWs& w, const CoarseArgs& a, const Prepared& Q,
         if (rc != VFM_OK) return rc;
     }
     hipLaunchKernelGGL(match_rescan_close_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, w.cand_cnt, w.cap, w.fb_count,
-                       w.fb_list, reinterpret_cast<int*>(w.rec_cnt), (const float*)nullptr);
+                       w.fb_list, reinterpret_cast<int*>(w.rec_cnt), (const float*)nullptr, (const unsigned*)w.hit_cnt);
     VFM_CHECK_LAUNCH("match_rescan_close_kernel");
     return VFM_OK;
 }

@@ -432,6 +432,8 @@ struct SearchWs {
     int* fb_list;
     unsigned* qmax;
     unsigned* bin_cnt;  // int8 pass, best-score records: candidate queries per map chunk ...
+    unsigned* hit_cnt;  // rows match_rescan_chunk_kernel appended to a query's list, one counter per 128-byte line (added to cand_cnt by
+                        // match_rescan_close_kernel): the lists' own lengths sit 32 to a line, and a line is what the memory side serialises
     int* bins;          // ... and the queries themselves, bin_cap per chunk (match_rescan_chunk_kernel)
     int bin_cap;        // rescan_bin_cap(npad, chunks)
     size_t bytes;
@@ -447,12 +449,13 @@ inline SearchWs carve_search(void* p, int64_t n, int64_t m) {
     w.cand = c.take<unsigned>((size_t)npad * (size_t)w.cap);
     w.fb_list = c.take<int>((size_t)npad);
     // zeroed before every search by ONE memset (search_zero_bytes): [fb_count (64, padded to 256 B) | qmax (npad) |
-    // rec_cnt (npad) | bin_cnt (chunks padded to 64, x BIN_CNT_STRIDE)]; npad is a multiple of 256, so the arrays are contiguous under the
+    // rec_cnt (npad) | bin_cnt (chunks padded to 64, x BIN_CNT_STRIDE) | hit_cnt (npad x BIN_CNT_STRIDE)]; npad is a multiple of 256, so the arrays are contiguous under the
     // carver's 256-byte alignment
     w.fb_count = c.take<int>(64);
     w.qmax = c.take<unsigned>((size_t)npad);
     w.rec_cnt = c.take<unsigned>((size_t)npad);
     w.bin_cnt = c.take<unsigned>((size_t)((mpad / CHUNK_ROWS + 63) / 64 * 64) * BIN_CNT_STRIDE);
+    w.hit_cnt = c.take<unsigned>((size_t)npad * BIN_CNT_STRIDE);
     w.bin_cap = rescan_bin_cap(npad, mpad / CHUNK_ROWS);
     w.bins = c.take<int>((size_t)(mpad / CHUNK_ROWS) * (size_t)w.bin_cap);
     w.rcap = FILTER_LDS_ROWS;
@@ -463,7 +466,8 @@ inline SearchWs carve_search(void* p, int64_t n, int64_t m) {
 
 inline size_t search_zero_bytes(int64_t n, int64_t m) {
     const int64_t npad = rows_padded(n), mpad = rows_padded(m);
-    return 256 + 2 * (size_t)npad * sizeof(unsigned) + (size_t)((mpad / CHUNK_ROWS + 63) / 64 * 64) * BIN_CNT_STRIDE * sizeof(unsigned);
+    return 256 + 2 * (size_t)npad * sizeof(unsigned) + (size_t)((mpad / CHUNK_ROWS + 63) / 64 * 64) * BIN_CNT_STRIDE * sizeof(unsigned) +
+           (size_t)npad * BIN_CNT_STRIDE * sizeof(unsigned);
 }
 
 // hipFuncSetAttribute is per device: remember which devices have been configured (one bit each)
