@@ -172,11 +172,33 @@ fraction of the peak is busy x clock / 2.4, i.e. the kernel sits against the pow
 
 ms per registration with the coarse pass chosen by the pipeline's feedback (`auto`: the pass and record kind in use after the
 warm-up in brackets), and with each mode forced (int8-half = the half-width pass -- behind the device-side guard since this round,
-int8 = best-score records, int8-top2 = packed top-2 records):
+int8 = best-score records, mx6 = the same in fp6, int8-top2 = packed top-2 records):
 
 | map | auto | {' | '.join(modes)} | same correspondences + pose | all-pairs fallbacks |
 |---|---|{'---|' * len(modes)}---|---|
 {nd_rows}
+
+## The finish stage where a query has many candidate chunks (`tools/lifted_stats.py`, `tools/prof_finish.sh`, `tools/trace_pipe.sh`)
+
+bench.py's lifted descriptors (C2 size): rows / chunks within w of a query's best cosine (what bounds of total width w hand on),
+and the library's own counts and stage times for the four full-width record kinds (`r03_lifted_stats.txt`):
+
+```
+{text('r03_lifted_stats.txt')}
+```
+
+Kernel by kernel, every kernel alone on the GPU (us; records 0 = int8 best-score, 5 = fp6 best-score; first two lines: lifted
+descriptors + common component, last two: D.2; `r03_prof_finish.txt`):
+
+```
+{text('r03_prof_finish.txt')}
+```
+
+The pipeline's timeline on the same data (`auto`, overlapped), and the same kernels one after the other (`r03_lifted_cycle.txt`):
+
+```
+{text('r03_lifted_cycle.txt')}
+```
 
 ## Row A6: find_correspondences' mutual L2 filter (`tools/time_pairs.py`, `tools/prof_pairs.sh`)
 
