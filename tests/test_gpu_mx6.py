@@ -301,3 +301,31 @@ def test_a_map_prepared_once_keeps_the_pipeline_off_the_fp6_kinds():
     np.testing.assert_array_equal(out["T"].cpu().numpy(), ref.transformation)
     with pytest.raises(ValueError):
         RegistrationPipeline(n, m, d, n_iter=2000, coarse="mx6-half").prepare_map(p["b_desc"])
+
+
+@pytest.mark.parametrize("records", [0, RECORDS_MX6])
+def test_finish_stage_staging_buffers_overflow_into_the_direct_paths(records):
+    """More candidates than the selection stages per query tile (> 192 candidate chunks per query on a 313-chunk map: rows that are
+    all alike) and more hit rows than a rescan workgroup stages (> 2048 per chunk slice: a few distinct rows repeated through the
+    whole map): match_select_best_kernel places the rest on the spot (looking at the bin counters first), match_rescan_chunk_kernel
+    appends the rest directly, lists that outgrow their capacity go to the all-pairs kernel -- oracle answers and gate contract,
+    int8 and fp6 best-score records, gate on and off."""
+    d, n, m = 384, 2304, 40000
+    rng = np.random.default_rng(records + 17)
+    gate = float(np.nextafter(np.float32(0.8), np.float32(-np.inf)))
+    base = rng.standard_normal((1, d)).astype(np.float32)
+    alike = (base + 0.2 * rng.standard_normal((n, d)).astype(np.float32), base + 0.2 * rng.standard_normal((m, d)).astype(np.float32))
+    few = rng.standard_normal((24, d)).astype(np.float32)
+    dup_b = few[rng.integers(0, 24, m)] + 0.0
+    dup_q = few[rng.integers(0, 24, n)] + 0.001 * rng.standard_normal((n, d)).astype(np.float32)
+    for name, (qq, bb) in {"all alike": alike, "repeated rows": (dup_q, dup_b)}.items():
+        qn, _ = orc.l2norm_rows(qq)
+        bn, _ = orc.l2norm_rows(bb)
+        ridx, rsim = orc.match_ip_top1(qn, bn)
+        qd, bd = torch.from_numpy(qq).cuda(), torch.from_numpy(bb).cuda()
+        for g in (gate, float("-inf")):
+            idx, sim = _search(qd, bd, g, records)
+            solved = _gate_contract(idx, sim, ridx, rsim, g)
+            if g == float("-inf"):
+                assert solved.all(), name
+            assert solved[rsim >= 0.8].all(), name

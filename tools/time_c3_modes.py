@@ -40,7 +40,7 @@ q_xyz = torch.from_numpy(np.ascontiguousarray(xyz)).to(dev)
 b_xyz[pick] = q_xyz + 0.02 * torch.randn(n, 3, device=dev, generator=g, dtype=torch.float64)
 ref = None
 import os
-for coarse in os.environ.get("C3_MODES", "auto,int8-half,int8,int8-top2,fp16").split(","):
+for coarse in os.environ.get("C3_MODES", "auto,int8-half,int8,mx6,int8-top2,fp16").split(","):
     pipe = RegistrationPipeline(n, m, 384, n_iter=50000, device=dev, coarse=coarse)
     ts = []
     for r in range(8):
@@ -57,6 +57,6 @@ for coarse in os.environ.get("C3_MODES", "auto,int8-half,int8,int8-top2,fp16").s
         ref = (out["T"].clone(), out["corres"][:k].clone())
     else:
         same = bool(torch.equal(ref[0], out["T"]) and torch.equal(ref[1], out["corres"][:k]))
-    print(f"{coarse}: {sorted(ts)[len(ts) // 2]:.2f} ms per registration, pass in use {'int8' if pipe.use_i8 else 'fp16'}, "
+    print(f"{coarse}: {sorted(ts)[len(ts) // 2]:.2f} ms per registration, pass in use {('fp6' if (getattr(pipe, 'mx6', False) or (pipe.half and getattr(pipe, 'mx6_half', False))) else 'int8') if pipe.use_i8 else 'fp16'}, "
           f"rescanned chunks per query {'-' if pipe.last_rescans is None else round(pipe.last_rescans / n, 1)}, {k} correspondences, "
           f"same result {same}", flush=True)
