@@ -474,7 +474,6 @@ __global__ __launch_bounds__(256) void prep_mx6_rows_kernel(const float* __restr
     const bool second = g >= pad1;
     const int64_t r = second ? g - pad1 : g;
     const int64_t rows = second ? rows2 : rows1;
-    const float* x = second ? x2 : x1;
     const PrepOut& o = second ? o2 : o1;
     const bool active = blk < (d >> 5) && !beyond;
     // the workgroup's RPB rows come in coalesced (consecutive threads, consecutive float4) and go through the LDS to the thread
