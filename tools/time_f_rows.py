@@ -80,5 +80,5 @@ line("vfm_icp_step_nearest 20k pts (transform + 27-voxel nearest neighbour)",
      dev_ms(lambda: lib.vfm_icp_step_nearest(sx.data_ptr(), n, eye.ctypes.data, src2.data_ptr(), g.keys.data_ptr(), g.start.data_ptr(),
                                              g.pts.data_ptr(), g.n_voxels, 1.0, 3.0, tgt.data_ptr(), valid.data_ptr(), st)),
      n * (24 + 24 + 24 + 1) + n * 27 * (8 + 1.6 * 24))
-line("vfm_icp_build_system 20k pairs (6x6 normal equations, fixed reduction tree, one workgroup)",
+line("vfm_icp_build_system 20k pairs (6x6 normal equations, fixed reduction tree, one workgroup per entry)",
      dev_ms(lambda: lib.vfm_icp_build_system(src2.data_ptr(), tgt.data_ptr(), valid.data_ptr(), n, 1.0, out.data_ptr(), st)), n * 49)

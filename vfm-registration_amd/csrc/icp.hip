@@ -29,6 +29,11 @@ struct IcpStep {
     double T[12];
     int apply;
 };
+// 32 lanes per source point, lane l < 27 takes neighbour voxel l = 9 (a - kx + 1) + 3 (b - ky + 1) + (c - kz + 1) -- the
+// reference's loop order -- : one binary search and at most a voxel's points per lane instead of 27 searches in a row (a
+// point's chain of ~460 dependent loads was the whole 0.135 ms of an iteration at 20 000 points).  The lanes' candidates are
+// merged by (distance, scan position): the first minimum of the reference's scan, the same squared distances.
+constexpr int ICP_LANES = 32;
 __global__ __launch_bounds__(256) void icp_nearest_kernel(const double* __restrict__ src, int64_t n,
                                                           const long long* __restrict__ keys,
                                                           const int* __restrict__ start,
@@ -36,8 +41,10 @@ __global__ __launch_bounds__(256) void icp_nearest_kernel(const double* __restri
                                                           double max_dist, double* __restrict__ tgt,
                                                           uint8_t* __restrict__ valid, IcpStep step,
                                                           double* __restrict__ src_out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    const int l = threadIdx.x & (ICP_LANES - 1);
+    int64_t i = (int64_t)blockIdx.x * (256 / ICP_LANES) + (threadIdx.x / ICP_LANES);
+    const bool live = i < n;
+    if (!live) i = n - 1;   // (the shuffles below want every lane of the wave)
     double px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
     if (step.apply) {
         const double* T = step.T;
@@ -45,82 +52,120 @@ __global__ __launch_bounds__(256) void icp_nearest_kernel(const double* __restri
         const double qy = ((T[4] * px + T[5] * py) + T[6] * pz) + T[7] * 1.0;
         const double qz = ((T[8] * px + T[9] * py) + T[10] * pz) + T[11] * 1.0;
         px = qx; py = qy; pz = qz;
-        src_out[3 * i] = px;
-        src_out[3 * i + 1] = py;
-        src_out[3 * i + 2] = pz;
+        if (l == 0 && live) {
+            src_out[3 * i] = px;
+            src_out[3 * i + 1] = py;
+            src_out[3 * i + 2] = pz;
+        }
     }
     const int kx = (int)(px / voxel_size), ky = (int)(py / voxel_size), kz = (int)(pz / voxel_size);
     double bx = 0.0, by = 0.0, bz = 0.0, best = 1.7976931348623157e308;
-    bool found = false;
-    for (int a = kx - 1; a <= kx + 1; ++a)
-        for (int b = ky - 1; b <= ky + 1; ++b)
-            for (int c = kz - 1; c <= kz + 1; ++c) {
-                const long long key = voxel_key(a, b, c);
-                int lo = 0, hi = nv;  // lower_bound
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (keys[mid] < key) lo = mid + 1; else hi = mid;
-                }
-                if (lo < nv && keys[lo] == key) {
-                    for (int j = start[lo]; j < start[lo + 1]; ++j) {
-                        const double dx = pts[3 * j] - px, dy = pts[3 * j + 1] - py, dz = pts[3 * j + 2] - pz;
-                        const double d2 = (dx * dx + dy * dy) + dz * dz;
-                        if (d2 < best) {
-                            best = d2;
-                            bx = pts[3 * j];
-                            by = pts[3 * j + 1];
-                            bz = pts[3 * j + 2];
-                            found = true;
-                        }
-                    }
+    unsigned order = 0xFFFFFFFFu;   // scan position of the lane's best point: (neighbour << 20) | index inside the voxel; none yet
+    if (l < 27) {
+        const long long key = voxel_key(kx - 1 + l / 9, ky - 1 + (l / 3) % 3, kz - 1 + l % 3);
+        int lo = 0, hi = nv;  // lower_bound
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        if (lo < nv && keys[lo] == key) {
+            const int j0 = start[lo], j1 = start[lo + 1];
+            for (int j = j0; j < j1; ++j) {
+                const double dx = pts[3 * j] - px, dy = pts[3 * j + 1] - py, dz = pts[3 * j + 2] - pz;
+                const double d2 = (dx * dx + dy * dy) + dz * dz;
+                if (d2 < best) {
+                    best = d2;
+                    bx = pts[3 * j];
+                    by = pts[3 * j + 1];
+                    bz = pts[3 * j + 2];
+                    order = ((unsigned)l << 20) | (unsigned)min(j - j0, (1 << 20) - 1);
                 }
             }
+        }
+    }
+#pragma unroll
+    for (int off = ICP_LANES / 2; off >= 1; off >>= 1) {
+        const double ob = __shfl_xor(best, off), ox = __shfl_xor(bx, off), oy = __shfl_xor(by, off), oz = __shfl_xor(bz, off);
+        const unsigned oo = __shfl_xor(order, off);
+        // strict '<' in scan order: the smaller distance, and of equal distances the earlier position (a lane without a point
+        // holds the largest position and never wins against one that has a point: its `best` is the initial value, which no
+        // accepted point carries)
+        const bool take = oo != 0xFFFFFFFFu && (order == 0xFFFFFFFFu || ob < best || (ob == best && oo < order));
+        if (take) {
+            best = ob; bx = ox; by = oy; bz = oz; order = oo;
+        }
+    }
+    if (l != 0 || !live) return;
     // (closest - point).norm() < max_correspondence_distance (VoxelHashMap.cpp:147)
-    const bool ok = found && (sqrt(best) < max_dist);
+    const bool ok = order != 0xFFFFFFFFu && (sqrt(best) < max_dist);
     tgt[3 * i] = bx;
     tgt[3 * i + 1] = by;
     tgt[3 * i + 2] = bz;
     valid[i] = ok ? 1 : 0;
 }
 
-// out[0..35] = J^T W J (row-major 6x6), out[36..41] = J^T W r, out[42] = number of pairs
+// out[0..35] = J^T W J (row-major 6x6), out[36..41] = J^T W r, out[42] = number of pairs.
+// One workgroup per output value: the 43 sums are independent chains, so workgroup k recomputes w and the two Jacobian columns it
+// needs and adds ITS term of every pair in the order the oracle replays (thread t owns pairs i = t mod 256 ascending, then the
+// stride-halving tree) -- the same operations on the same operands as one workgroup holding all 43 accumulators per thread
+// (0.059 ms per iteration at 20 000 pairs: 79 pairs x 43 chains per thread on one compute unit), 43 times as wide.
+__device__ __forceinline__ double icp_jacobian(int row, int col, const double* s) {   // J = [ I | -hat(s) ]
+    if (col < 3) return row == col ? 1.0 : 0.0;
+    const int c = col - 3;
+    if (row == c) return 0.0;
+    // -hat(s) = [[0, s2, -s1], [-s2, 0, s0], [s1, -s0, 0]]
+    if (row == 0) return c == 1 ? s[2] : -s[1];
+    if (row == 1) return c == 0 ? -s[2] : s[0];
+    return c == 0 ? s[1] : -s[0];
+}
 __global__ __launch_bounds__(256) void icp_system_kernel(const double* __restrict__ src, const double* __restrict__ tgt,
                                                          const uint8_t* __restrict__ valid, int64_t n, double kernel,
                                                          double* __restrict__ out) {
-    __shared__ double red[43][256];
-    const int t = threadIdx.x;
-    double acc[43];
+    __shared__ double red[256];
+    const int t = threadIdx.x, k = blockIdx.x;   // k: a * 6 + b (J^T W J), 36 + a (J^T W r), 42 (count)
+    const int a = k < 36 ? k / 6 : k - 36, b = k % 6;
+    double acc = 0.0;
+    // eight pairs' loads in flight, their terms added in ascending order (a pair at a time had been a chain of 79 round trips)
+    constexpr int U = 8;
+    for (int64_t i0 = t; i0 < n; i0 += 256 * U) {
+        double sv[U][3], tv[U][3];
+        bool ok[U];
 #pragma unroll
-    for (int k = 0; k < 43; ++k) acc[k] = 0.0;
-    for (int64_t i = t; i < n; i += 256) {
-        if (!valid[i]) continue;
-        const double s[3] = {src[3 * i], src[3 * i + 1], src[3 * i + 2]};
-        const double r[3] = {s[0] - tgt[3 * i], s[1] - tgt[3 * i + 1], s[2] - tgt[3 * i + 2]};
-        const double r2 = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
-        const double w = (kernel * kernel) / ((kernel + r2) * (kernel + r2));
-        // J = [ I | -hat(s) ]
-        const double J[3][6] = {{1.0, 0.0, 0.0, 0.0, s[2], -s[1]},
-                                {0.0, 1.0, 0.0, -s[2], 0.0, s[0]},
-                                {0.0, 0.0, 1.0, s[1], -s[0], 0.0}};
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + 256 * (int64_t)u;
+            ok[u] = i < n && valid[i] != 0;
+            const int64_t j = i < n ? i : i0;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            const double jw[3] = {J[0][a] * w, J[1][a] * w, J[2][a] * w};
-#pragma unroll
-            for (int b = 0; b < 6; ++b)
-                acc[a * 6 + b] = acc[a * 6 + b] + ((jw[0] * J[0][b] + jw[1] * J[1][b]) + jw[2] * J[2][b]);
-            acc[36 + a] = acc[36 + a] + ((jw[0] * r[0] + jw[1] * r[1]) + jw[2] * r[2]);
+            for (int c = 0; c < 3; ++c) {
+                sv[u][c] = src[3 * j + c];
+                tv[u][c] = tgt[3 * j + c];
+            }
         }
-        acc[42] = acc[42] + 1.0;
-    }
 #pragma unroll
-    for (int k = 0; k < 43; ++k) red[k][t] = acc[k];
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            if (k == 42) {
+                acc = acc + 1.0;
+                continue;
+            }
+            const double* s = sv[u];
+            const double r[3] = {s[0] - tv[u][0], s[1] - tv[u][1], s[2] - tv[u][2]};
+            const double r2 = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
+            const double w = (kernel * kernel) / ((kernel + r2) * (kernel + r2));
+            const double jw[3] = {icp_jacobian(0, a, s) * w, icp_jacobian(1, a, s) * w, icp_jacobian(2, a, s) * w};
+            if (k < 36)
+                acc = acc + ((jw[0] * icp_jacobian(0, b, s) + jw[1] * icp_jacobian(1, b, s)) + jw[2] * icp_jacobian(2, b, s));
+            else
+                acc = acc + ((jw[0] * r[0] + jw[1] * r[1]) + jw[2] * r[2]);
+        }
+    }
+    red[t] = acc;
     __syncthreads();
     for (int stride = 128; stride >= 1; stride >>= 1) {
-        if (t < stride)
-            for (int k = 0; k < 43; ++k) red[k][t] = red[k][t] + red[k][t + stride];
+        if (t < stride) red[t] = red[t] + red[t + stride];
         __syncthreads();
     }
-    if (t < 43) out[t] = red[t][0];
+    if (t == 0) out[k] = red[0];
 }
 
 }  // namespace
@@ -133,7 +178,7 @@ VFM_EXPORT int vfm_icp_nearest(const double* src, int64_t n, const int64_t* keys
     if (n == 0) return VFM_OK;
     IcpStep step;
     step.apply = 0;
-    hipLaunchKernelGGL(icp_nearest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, n,
+    hipLaunchKernelGGL(icp_nearest_kernel, dim3((unsigned)((n + 256 / ICP_LANES - 1) / (256 / ICP_LANES))), dim3(256), 0, (hipStream_t)stream, src, n,
                        reinterpret_cast<const long long*>(keys), start, pts, n_voxels, voxel_size, max_dist, tgt_out,
                        valid_out, step, (double*)nullptr);
     VFM_CHECK_LAUNCH("icp_nearest_kernel");
@@ -149,7 +194,7 @@ VFM_EXPORT int vfm_icp_step_nearest(const double* src, int64_t n, const double* 
     IcpStep step;
     for (int k = 0; k < 12; ++k) step.T[k] = T_host[k];
     step.apply = 1;
-    hipLaunchKernelGGL(icp_nearest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, n,
+    hipLaunchKernelGGL(icp_nearest_kernel, dim3((unsigned)((n + 256 / ICP_LANES - 1) / (256 / ICP_LANES))), dim3(256), 0, (hipStream_t)stream, src, n,
                        reinterpret_cast<const long long*>(keys), start, pts, n_voxels, voxel_size, max_dist, tgt_out,
                        valid_out, step, src_out);
     VFM_CHECK_LAUNCH("icp_nearest_kernel(step)");
@@ -159,7 +204,7 @@ VFM_EXPORT int vfm_icp_step_nearest(const double* src, int64_t n, const double* 
 VFM_EXPORT int vfm_icp_build_system(const double* src, const double* tgt, const uint8_t* valid, int64_t n, double kernel,
                                     double* out43, vfm_stream_t stream) {
     VFM_CHECK_ARG(src && tgt && valid && out43 && n >= 0, "icp_build_system: bad arguments");
-    hipLaunchKernelGGL(icp_system_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, src, tgt, valid, n, kernel, out43);
+    hipLaunchKernelGGL(icp_system_kernel, dim3(43), dim3(256), 0, (hipStream_t)stream, src, tgt, valid, n, kernel, out43);
     VFM_CHECK_LAUNCH("icp_system_kernel");
     return VFM_OK;
 }
