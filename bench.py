@@ -46,6 +46,7 @@ for p in (ROOT, ROOT / "vfm-registration_amd"):
 N_SCAN, N_MAP, DIM, RANSAC_ITERS = 20000, 200000, 384, 50000
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/fp16 MFMA ~2.5 PFLOP/s
 MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 MFMA: 2 x the fp16 rate (same table: "I8 ~2x bf16 rate (2xK)", ubench >= 4404)
+SETTLE = 6   # registrations the auto policy gets, one at a time, before the warm-up (see main)
 MFMA_F6_PEAK_TFLOPS = 10000.0  # dense fp6 / fp4 scaled MFMA (same table: "~10 PF dense", FP6 ubench >= 7287; tools/probe/mx6_probe.hip: 6400)
 
 
@@ -252,13 +253,13 @@ def timed_loop(lib, pipe, pairs, steps, warmup, settle=0):
         a, b = C.c_void_p(), C.c_void_p()
         lib.vfm_prof_events_create(C.byref(a), C.byref(b))
         events.append((a, b))
+    import gc
+    gc.collect()   # (before the warm-up: behind it the GPU sat idle for the collection's length and the timed steps paid the clock ramp)
+    gc.disable()
     for i in range(max(warmup, 1)):
         reg(i)
     pipe.synchronize()
     torch.cuda.synchronize()
-    import gc
-    gc.collect()
-    gc.disable()
     t0 = time.perf_counter()
     out = None
     for i in range(steps):
@@ -490,6 +491,22 @@ def main():
     # untimed warm-up: the sharding / gather path first, then the complete step
     vdist.gather_poses(torch.zeros((1, 4, 4), dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev),
                        world, rank, world)
+    import gc
+    gc.collect()      # (the interpreter's cyclic collector stays out of the timed region: a pause there is tens of ms of a 15 ms run;
+    gc.disable()      # collected BEFORE the warm-up: between warm-up and timed region it left the GPU idle for its whole length)
+    # The `auto` policy picks the coarse pass from measurements of the data it is fed (a probe of the half-width pass on the first
+    # registration, then every search's own feedback): it is given SETTLE registrations, one at a time, to do so -- set-up, like
+    # the extras' timed_loop(settle=6); with W <= 2 pipelined warm-up steps the switch used to fall into the timed region (1020
+    # instead of 1330 registrations/s at --warmup 1).  Reported as config.policy_settle_registrations.
+    settle = SETTLE if pipe.coarse == "auto" else 0
+    for i in range(settle):
+        step(i)
+        with torch.cuda.stream(match_stream):
+            pipe.synchronize()
+        torch.cuda.synchronize()
+        pipe._poll_feedback()
+    for i in range(int(os.environ.get("VFM_BENCH_PRECOND", "0"))):   # A/B only (tools/): extra untimed registrations in front of the warm-up
+        step(i)
     for i in range(max(args.warmup, 1)):
         step(i)
     with torch.cuda.stream(match_stream):
@@ -497,9 +514,6 @@ def main():
     torch.cuda.current_stream().wait_stream(match_stream)
 
     grouped = dist.is_available() and dist.is_initialized()  # launched through torch.distributed.run
-    import gc
-    gc.collect()      # (the interpreter's cyclic collector stays out of the timed region: a pause there is tens of ms of a 15 ms run)
-    gc.disable()
     if grouped:
         dist.barrier()
     torch.cuda.synchronize()
@@ -624,6 +638,8 @@ def main():
                        "collective": (f"one all_gather_into_tensor of the poses ({dist.get_backend()} = RCCL)" if grouped
                                       else "none (single process, no launcher)"),
                        "correspondences_last_step": ncorr, "max_pose_err_vs_planted": max(errs),
+                       # untimed, in front of the W warm-up steps: registrations the auto policy reads its feedback between (set-up)
+                       "policy_settle_registrations": settle,
                        "coarse_pass": ("fp6 (MX e2m3), half-width (VFM_RECORDS_MX6_HALF)" if half6 else "int8, half-width (VFM_RECORDS_HALF)" if half
                                        else "int8, packed top-2 records" if (i8 and mode_top2)
                                        else "int8, best-score records" if i8 else "fp16"),

@@ -36,6 +36,8 @@ cd $R && timeout 900 python tools/time_neardup.py --steps 20 --out $O/neardup.js
 { timeout 300 python tools/lifted_stats.py 1.0 2>&1 | grep -v amdgpu.ids; timeout 300 python tools/lifted_stats.py 0.0 2>&1 | grep -v amdgpu.ids; } > $O/lifted_stats.txt
 { bash tools/prof_finish.sh 0,5 0 lifted 2>&1 | grep records; bash tools/prof_finish.sh 0,5 0 d2 2>&1 | grep records; } > $O/prof_finish.txt
 { echo "== auto, overlapped"; bash tools/trace_pipe.sh auto lifted 2>&1 | tail -45; echo "== int8, every kernel alone"; bash tools/trace_pipe.sh int8 lifted False 2>&1 | tail -32; echo "== mx6, every kernel alone"; bash tools/trace_pipe.sh mx6 lifted False 2>&1 | tail -32; } > $O/lifted_cycle.txt
+# the 20-step timed region against the length of what precedes it
+bash tools/ab_precond.sh > $O/warmup_ab.txt 2>&1
 # row A6 (find_correspondences' mutual filter): timing, kernel sequence
 timeout 300 python tools/time_pairs.py 6 > $O/time_pairs.txt 2>&1; cat $O/time_pairs.txt
 bash tools/prof_pairs.sh > $O/prof_pairs.txt 2>&1

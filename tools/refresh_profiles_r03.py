@@ -53,7 +53,7 @@ def main():
               "pmc_match_coarse_mx6.json": "r03_pmc_match_coarse_mx6.json", "pmc_match_coarse_mx6half.json": "r03_pmc_match_coarse_mx6half.json",
               "queue_probe.txt": "r03_queue_probe.txt", "dev_mx6.txt": "r03_dev_mx6.txt",
               "ab_mx6_bench.txt": "r03_ab_mx6_bench.txt", "soak_mx6.txt": "r03_soak_mx6.txt", "pipeline_cycle.txt": "r03_pipeline_cycle.txt", "soak_half.txt": "r03_soak_half.txt", "soak_match.txt": "r03_soak_match.txt", "mx6_probe.txt": "r03_mx6_probe.txt",
-              "lifted_stats.txt": "r03_lifted_stats.txt", "prof_finish.txt": "r03_prof_finish.txt", "lifted_cycle.txt": "r03_lifted_cycle.txt"}
+              "lifted_stats.txt": "r03_lifted_stats.txt", "prof_finish.txt": "r03_prof_finish.txt", "lifted_cycle.txt": "r03_lifted_cycle.txt", "warmup_ab.txt": "r03_warmup_ab.txt"}
     for i in range(1, 8):
         copies[f"pmc_pass{i}_counter_collection.csv"] = f"r03_pmc_pass{i}_counter_collection.csv"
         copies[f"pmc_half_pass{i}_counter_collection.csv"] = f"r03_pmc_half_pass{i}_counter_collection.csv"
@@ -136,6 +136,12 @@ Same box, `VFM_COARSE=int8 python bench.py` (full-width int8 pass as the whole r
 
 `python bench.py --streams 1` (every kernel serialised on one stream) -> `profiles/r03_bench_streams1.json`:
 {b1['value']:.1f} registrations/s, dominant kernel {b1['roofline']['avg_launch_ms']:.3f} ms.
+
+## The timed region against what precedes it (`tools/ab_precond.sh`, `r03_warmup_ab.txt`; DESIGN.md 0.13)
+
+```
+{text('r03_warmup_ab.txt')}
+```
 
 ## rocprofv3 --kernel-trace --stats of the default bench command
 
