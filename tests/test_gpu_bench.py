@@ -35,6 +35,8 @@ def test_bench_plain_small_run():
     assert r.returncode == 0, r.stderr[-3000:]
     d = _check(r.stdout, 4)
     assert d["config"]["collective"].startswith("none")
+    # one pipelined warm-up step is enough: the auto policy has settled (on the half-width pass, D.2 data) before the timed region
+    assert d["config"]["policy_settle_registrations"] == 6 and "half-width" in d["config"]["coarse_pass"]
 
 
 def test_bench_under_torch_distributed_run_world1():
