@@ -1662,53 +1662,78 @@ __global__ __launch_bounds__(256) void match_exact_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 // threshold + stable compaction (VoxelHashMap.cpp:501-511, 587-600), single workgroup
 // ---------------------------------------------------------------------------------------------
+// (one workgroup: the order of the survivors is the order of the queries.  A pass takes TC_ITERS x 1024 queries: all of a thread's
+// similarities are loaded at once, the per-wave counts of every 1024-query slab go to the LDS behind ONE barrier, and the gathers
+// of the survivors -- matched row, then its coordinates -- are in flight together; a slab at a time, three dependent round trips and
+// three barriers each, it was 25 us for 20 000 queries on the path every registration's RANSAC waits for.)
+constexpr int TC_ITERS = 4;   // (8: the arrays spilled at 1024 threads)
 __global__ __launch_bounds__(1024) void threshold_compact_kernel(const float* __restrict__ sim, const int64_t* __restrict__ idx,
                                                                  int64_t n, double thr, int64_t* __restrict__ keep,
                                                                  int64_t* __restrict__ count, int32_t* __restrict__ corres,
                                                                  const double* __restrict__ qxyz, const double* __restrict__ bxyz,
                                                                  double* __restrict__ src_out, double* __restrict__ tgt_out) {
-    __shared__ int wsum[16];
-    __shared__ int64_t base_s;
+    __shared__ int wsum[TC_ITERS][16];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) base_s = 0;
-    __syncthreads();
-    for (int64_t s = 0; s < n; s += 1024) {
-        const int64_t i = s + threadIdx.x;
-        const bool valid = (i < n) && !((double)sim[i] < thr);
-        const unsigned long long bal = __ballot(valid);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wave] = __popcll(bal);
-        __syncthreads();
-        int woff = 0, tot = 0;
-        for (int w = 0; w < 16; ++w) {
-            if (w < wave) woff += wsum[w];
-            tot += wsum[w];
+    int64_t base = 0;   // survivors in front of this pass (the same value in every thread)
+    for (int64_t s0 = 0; s0 < n; s0 += (int64_t)TC_ITERS * 1024) {
+        bool valid[TC_ITERS];
+        int before[TC_ITERS];
+        float sv[TC_ITERS];
+#pragma unroll
+        for (int t = 0; t < TC_ITERS; ++t) {
+            const int64_t i = s0 + (int64_t)t * 1024 + threadIdx.x;
+            sv[t] = i < n ? sim[i] : 0.0f;
         }
-        const int64_t base = base_s;
-        if (valid) {
-            const int64_t k = base + woff + before;
-            keep[k] = i;
-            const int64_t j = idx ? idx[i] : 0;
+#pragma unroll
+        for (int t = 0; t < TC_ITERS; ++t) {
+            const int64_t i = s0 + (int64_t)t * 1024 + threadIdx.x;
+            valid[t] = (i < n) && !((double)sv[t] < thr);
+            const unsigned long long bal = __ballot(valid[t]);
+            before[t] = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wsum[t][wave] = __popcll(bal);
+        }
+        __syncthreads();
+        int64_t k[TC_ITERS];
+        int j[TC_ITERS];   // (map rows fit 31 bits: the candidate entries hold chunk << 8)
+        int64_t run = base;
+#pragma unroll
+        for (int t = 0; t < TC_ITERS; ++t) {
+            int woff = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                const int c = wsum[t][w];
+                if (w < wave) woff += c;
+                tot += c;
+            }
+            k[t] = run + woff + before[t];
+            run += tot;
+            const int64_t i = s0 + (int64_t)t * 1024 + threadIdx.x;
+            j[t] = (valid[t] && idx) ? (int)idx[i] : 0;
+        }
+        base = run;
+#pragma unroll
+        for (int t = 0; t < TC_ITERS; ++t) {
+            if (!valid[t]) continue;
+            const int64_t i = s0 + (int64_t)t * 1024 + threadIdx.x;
+            keep[k[t]] = i;
             if (corres) {
-                corres[2 * k + 0] = (int32_t)i;
-                corres[2 * k + 1] = (int32_t)j;
+                corres[2 * k[t] + 0] = (int32_t)i;
+                corres[2 * k[t] + 1] = (int32_t)j[t];
             }
             if (src_out) {
-                src_out[3 * k + 0] = qxyz[3 * i + 0];
-                src_out[3 * k + 1] = qxyz[3 * i + 1];
-                src_out[3 * k + 2] = qxyz[3 * i + 2];
+                src_out[3 * k[t] + 0] = qxyz[3 * i + 0];
+                src_out[3 * k[t] + 1] = qxyz[3 * i + 1];
+                src_out[3 * k[t] + 2] = qxyz[3 * i + 2];
             }
             if (tgt_out) {
-                tgt_out[3 * k + 0] = bxyz[3 * j + 0];
-                tgt_out[3 * k + 1] = bxyz[3 * j + 1];
-                tgt_out[3 * k + 2] = bxyz[3 * j + 2];
+                tgt_out[3 * k[t] + 0] = bxyz[3 * (int64_t)j[t] + 0];
+                tgt_out[3 * k[t] + 1] = bxyz[3 * (int64_t)j[t] + 1];
+                tgt_out[3 * k[t] + 2] = bxyz[3 * (int64_t)j[t] + 2];
             }
         }
-        __syncthreads();
-        if (threadIdx.x == 0) base_s = base + tot;
-        __syncthreads();
+        __syncthreads();   // wsum is rewritten by the next pass
     }
-    if (threadIdx.x == 0) *count = base_s;
+    if (threadIdx.x == 0) *count = base;
 }
 
 
