@@ -108,3 +108,45 @@ def test_ransac_registration_with_icp_refinement():
     e_ransac, e_icp = compute_errors(ransac_pose, p["T_gt"]), compute_errors(pose, p["T_gt"])
     assert abs(np.linalg.det(ransac_pose[:3, :3]) - 1) <= 1e-12          # orthogonalised (RN:331-336)
     assert e_icp[0] < 0.05 and e_icp[1] < 0.05 and e_icp[0] <= e_ransac[0] + 1e-3
+
+
+def test_icp_nearest_keeps_the_first_minimum_of_the_reference_scan_on_exact_ties():
+    """vfm_icp_nearest spreads a point's 27 neighbour voxels over 32 lanes and merges their candidates by (squared distance, scan
+    position).  On a lattice map a source point at a cell centre / face centre / lattice point is EXACTLY equidistant from points
+    in several voxels, and doubled map points tie inside one voxel: the answer must be the first minimum of the reference's scan
+    (voxel loops i, j, k ascending, then insertion order; VoxelHashMap.cpp:96-130) -- the oracle's, bit for bit, negative
+    coordinates (truncation towards zero in the voxel index) included."""
+    import ctypes as C
+    from oracle import oracle as orc
+    from vfmreg import _lib, ops
+    from vfmreg.icp import VoxelGridDevice
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    ax = np.arange(-6, 7) * 0.5                       # lattice of pitch 0.5 in voxels of 1.0: up to eight points per voxel
+    mp = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    mp = np.concatenate([mp, mp[rng.integers(0, len(mp), 300)]])   # doubled points: ties inside a voxel, different insertion positions
+    mp = mp[rng.permutation(len(mp))].copy()
+    cells = rng.integers(-5, 5, (1500, 3)) * 0.5
+    src = np.concatenate([cells + 0.25,                            # cell centres: eight equidistant lattice points
+                          cells + np.array([0.25, 0.25, 0.0]),     # face centres: four
+                          cells + np.array([0.25, 0.0, 0.0]),      # edge midpoints: two
+                          cells])                                  # on a lattice point (possibly a doubled one)
+    keys, start, pts = orc.voxel_grid_csr(mp, 1.0)
+    g = VoxelGridDevice(mp, 1.0)
+    n = len(src)
+    tgt_r = np.empty_like(src)
+    val_r = np.empty(n, dtype=np.uint8)
+    orc.lib().orc_icp_nearest(orc._p(src, orc._f64p), C.c_int64(n), orc._p(keys, orc._i64p), orc._p(start, orc._i32p),
+                              orc._p(pts, orc._f64p), C.c_int32(len(keys)), C.c_double(1.0), C.c_double(2.0),
+                              orc._p(tgt_r, orc._f64p), orc._p(val_r, orc._u8p))
+    s_d = dev(src)
+    tgt = torch.empty_like(s_d)
+    val = torch.empty(n, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.vfm_icp_nearest(s_d.data_ptr(), n, g.keys.data_ptr(), g.start.data_ptr(), g.pts.data_ptr(),
+                                   g.n_voxels, 1.0, 2.0, tgt.data_ptr(), val.data_ptr(), ops._stream()))
+    np.testing.assert_array_equal(val.cpu().numpy(), val_r)
+    assert val_r.all()
+    np.testing.assert_array_equal(tgt.cpu().numpy(), tgt_r)
+    # the ties are real: at the cell centres several distinct map points are at the minimum distance
+    d = np.linalg.norm(mp[None] - src[:50, None], axis=2)
+    assert ((d == d.min(1, keepdims=True)).sum(1) >= 8).all()
