@@ -560,6 +560,7 @@ def main():
 
     hbm_peak = torch.cuda.max_memory_allocated(dev)   # resident pairs + buffer sets of this rank (config C4: 32 pairs -> ~11 GB of 288)
     mode_i8, mode_half, mode_top2 = bool(pipe.use_i8), bool(pipe.use_i8 and pipe.half), bool(pipe.use_i8 and pipe.top2 and not pipe.half)
+    records_kind = int(pipe._records()) if pipe.use_i8 else 2   # include/vfmreg.h VFM_RECORDS_*: the kind the timed region ended in
     pipe._poll_feedback()
     surv = pipe.last_rescans
     # the same kernel without the concurrent RANSAC stream (information only; not part of `value`)
@@ -640,6 +641,9 @@ def main():
                        "correspondences_last_step": ncorr, "max_pose_err_vs_planted": max(errs),
                        # untimed, in front of the W warm-up steps: registrations the auto policy reads its feedback between (set-up)
                        "policy_settle_registrations": settle,
+                       # the record kind (include/vfmreg.h VFM_RECORDS_*) of the timed registrations: tests/test_gpu_bench_config.py
+                       # compares exactly this kind with the oracle at this size (BENCH_RECORDS_KIND), tests/test_gpu_bench.py ties the two
+                       "records_kind": records_kind,
                        "coarse_pass": ("fp6 (MX e2m3), half-width (VFM_RECORDS_MX6_HALF)" if half6 else "int8, half-width (VFM_RECORDS_HALF)" if half
                                        else "int8, packed top-2 records" if (i8 and mode_top2)
                                        else "int8, best-score records" if i8 else "fp16"),

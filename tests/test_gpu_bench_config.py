@@ -2,10 +2,12 @@
 the half-width pass (was tools/soak_half.py) with a fixed seed.
 
 bench.py builds RegistrationPipeline(20000, 200000, 384, n_iter=50000, overlap_ransac=True, overlap_prepare=True,
-solve_streams=2) with coarse="auto"; on SURVEY D.2 data the policy settles on the half-width int8 pass.  Here that very
-construction registers three D.2 pairs (seeds 42 + p) in the overlapped form and every output a caller reads --
-correspondence list, inlier mask, pose, winning hypothesis, and the per-query index / similarity of every resolved query --
-is compared with the CPU oracle's registration of the same inputs (registration_node.py:273-328; VoxelHashMap.cpp:469-511).
+solve_streams=2) with coarse="auto"; on SURVEY D.2 data the policy settles on the half-width pass in microscaled fp6
+(record kind BENCH_RECORDS_KIND: bench.py prints the kind it timed as config.records_kind and tests/test_gpu_bench.py asserts
+that it is the one compared here).  Here that very construction registers three D.2 pairs (seeds 42 + p) in the overlapped
+form and every output a caller reads -- correspondence list, inlier mask, pose, winning hypothesis, and the per-query index /
+similarity of every resolved query -- is compared with the CPU oracle's registration of the same inputs
+(registration_node.py:273-328; VoxelHashMap.cpp:469-511).  A second case pins coarse="mx6-half" (no policy in between).
 """
 import numpy as np
 import pytest
@@ -14,6 +16,9 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 N, M, D, ITERS = 20000, 200000, 384, 50000
+# the record kind the bench's headline runs on D.2 data (include/vfmreg.h: VFM_RECORDS_MX6_HALF); a policy edit that moves the
+# pipeline to another coarse kernel turns the tests below -- and tests/test_gpu_bench.py -- red
+BENCH_RECORDS_KIND = 7
 
 
 def _oracle_registration(orc, p, iters):
@@ -75,6 +80,7 @@ def test_the_pipeline_bench_times_equals_the_oracle_at_c2_size():
         if pipe.half:
             break
     assert pipe.use_i8 and pipe.half, "the auto policy did not settle on the half-width pass on D.2 data"
+    assert pipe.mx6_half and pipe._records() == BENCH_RECORDS_KIND, ("the auto policy left the fp6 half-width kernel", pipe._records())
     # the timed form: registrations back to back, no host synchronisation, results snapshotted on their streams
     snaps, modes = [], []
     for i in range(6):
@@ -83,7 +89,7 @@ def test_the_pipeline_bench_times_equals_the_oracle_at_c2_size():
         snaps.append(_snapshot(out))
     pipe.synchronize()
     torch.cuda.synchronize()
-    assert all(m[0] and m[1] for m in modes), modes       # every compared registration ran the half-width pass
+    assert all(m[0] and m[1] and m[2] == BENCH_RECORDS_KIND for m in modes), modes   # every compared registration ran the kernel bench.py names
     assert pipe.last_rescans is not None and pipe.last_rescans <= pipe.HALF_LIMIT * N
     hosts = [{k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in p.items()} for p in pairs]
     for i in range(3, 6):                                 # one registration of each pair, from the steady state
@@ -94,6 +100,28 @@ def test_the_pipeline_bench_times_equals_the_oracle_at_c2_size():
         assert torch.equal(snaps[0][k], snaps[3][k]), k
     for k in ("corres", "mask"):
         assert torch.equal(snaps[0][k][:c], snaps[3][k][:c]), k
+
+
+def test_pinned_fp6_half_width_pass_equals_the_oracle_at_c2_size():
+    """coarse="mx6-half" pinned: no policy between the construction and the kernel.  All 20 000 rows, mask, pose, winner."""
+    from oracle import oracle as orc
+    from vfmreg import synth
+    from vfmreg.pipeline import RegistrationPipeline
+
+    p = synth.make_pair_device(N, M, D, seed=46)
+    host = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in p.items()}
+    for overlap in (True, False):
+        pipe = RegistrationPipeline(N, M, D, n_iter=ITERS, overlap_ransac=overlap, overlap_prepare=overlap, solve_streams=2, coarse="mx6-half")
+        assert pipe._records() == BENCH_RECORDS_KIND
+        out = None
+        for _ in range(2):
+            out = pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
+            assert pipe._records() == BENCH_RECORDS_KIND     # a pinned mode never moves
+        snap = _snapshot(out) if overlap else {k: out[k].clone() for k in ("T", "fitness", "rmse", "best_hyp", "mask", "idx", "sim", "count", "corres")}
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        _compare(orc, snap, host, ITERS, f"mx6-half pinned, overlap {overlap}")
+        del pipe
 
 
 def test_full_width_modes_equal_the_oracle_at_c2_size_too():

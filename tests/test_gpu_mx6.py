@@ -303,6 +303,40 @@ def test_a_map_prepared_once_keeps_the_pipeline_off_the_fp6_kinds():
         RegistrationPipeline(n, m, d, n_iter=2000, coarse="mx6-half").prepare_map(p["b_desc"])
 
 
+def test_reuse_map_without_prepare_map_keeps_auto_off_the_fp6_kinds():
+    """register(reuse_map=True) with no prepare_map() before it: the first registration prepares the map through
+    vfm_match_prepare2, which writes no fp6 image -- `auto` must never pick record kinds 5 / 6 / 7 on such operands (their err6 is
+    unset: nothing would be pruned), on D.2 data (where it would otherwise settle on kind 7) and on lifted-like data (kind 5);
+    pinned fp6 modes refuse reuse_map; the registrations equal the oracle's."""
+    n, m, d = 3000, 20000, 384
+    for name, p in (("D.2", synth.make_pair_device(n, m, d, seed=14)),
+                    ("lifted", synth.make_lifted_pair_device(n, m, d, seed=15, clouds=4, view_noise=0.1, common=0.0))):
+        qn, _ = orc.l2norm_rows(p["q_desc"].cpu().numpy())
+        bn, _ = orc.l2norm_rows(p["b_desc"].cpu().numpy())
+        ridx, rsim = orc.match_ip_top1(qn, bn)
+        keep = ~(rsim.astype(np.float64) < 0.8)
+        corres = np.stack([np.nonzero(keep)[0], ridx[keep]], 1).astype(np.int32)
+        ref = orc.ransac_corr(p["q_xyz"].cpu().numpy(), p["b_xyz"].cpu().numpy(), corres, 10000.0, 2000, seed=42)
+        pipe = RegistrationPipeline(n, m, d, n_iter=2000, overlap_ransac=True, overlap_prepare=True, solve_streams=2, coarse="auto")
+        kinds = []
+        for _ in range(8):
+            out = pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"], reuse_map=True)
+            kinds.append(pipe._records())
+            pipe.synchronize()
+            torch.cuda.synchronize()
+            pipe._poll_feedback()
+        assert not any(k in (5, 6, 7) for k in kinds + [pipe._records()]), (name, kinds)
+        assert not pipe.mx6 and not pipe.mx6_half, name
+        c = int(out["count"].item())
+        assert c == len(corres), name
+        np.testing.assert_array_equal(out["corres"].cpu().numpy()[:c], corres, err_msg=name)
+        np.testing.assert_array_equal(out["T"].cpu().numpy(), ref.transformation, err_msg=name)
+        del pipe
+    for coarse in ("mx6", "mx6-top2", "mx6-half"):
+        with pytest.raises(ValueError):
+            RegistrationPipeline(n, m, d, n_iter=2000, coarse=coarse).register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"], reuse_map=True)
+
+
 @pytest.mark.parametrize("records", [0, RECORDS_MX6])
 def test_finish_stage_staging_buffers_overflow_into_the_direct_paths(records):
     """More candidates than the selection stages per query tile (> 192 candidate chunks per query on a 313-chunk map: rows that are

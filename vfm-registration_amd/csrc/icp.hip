@@ -34,18 +34,25 @@ struct IcpStep {
 // point's chain of ~460 dependent loads was the whole 0.135 ms of an iteration at 20 000 points).  The lanes' candidates are
 // merged by (distance, scan position): the first minimum of the reference's scan, the same squared distances.
 constexpr int ICP_LANES = 32;
-__global__ __launch_bounds__(256) void icp_nearest_kernel(const double* __restrict__ src, int64_t n,
+// (src and src_out may be the same array -- include/vfmreg.h; icp.py transforms in place from the second iteration on -- so
+// neither is __restrict__; a group reads its point before lane 0 writes it, and no other group touches that point)
+__global__ __launch_bounds__(256) void icp_nearest_kernel(const double* src, int64_t n,
                                                           const long long* __restrict__ keys,
                                                           const int* __restrict__ start,
                                                           const double* __restrict__ pts, int nv, double voxel_size,
                                                           double max_dist, double* __restrict__ tgt,
                                                           uint8_t* __restrict__ valid, IcpStep step,
-                                                          double* __restrict__ src_out) {
+                                                          double* src_out) {
     const int l = threadIdx.x & (ICP_LANES - 1);
     int64_t i = (int64_t)blockIdx.x * (256 / ICP_LANES) + (threadIdx.x / ICP_LANES);
     const bool live = i < n;
-    if (!live) i = n - 1;   // (the shuffles below want every lane of the wave)
-    double px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
+    // (the shuffles below want every lane of the wave: a group past the end runs on the origin and stores nothing)
+    double px = 0.0, py = 0.0, pz = 0.0;
+    if (live) {
+        px = src[3 * i];
+        py = src[3 * i + 1];
+        pz = src[3 * i + 2];
+    }
     if (step.apply) {
         const double* T = step.T;
         const double qx = ((T[0] * px + T[1] * py) + T[2] * pz) + T[3] * 1.0;

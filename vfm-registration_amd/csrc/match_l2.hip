@@ -287,9 +287,12 @@ __global__ void l2i8_norms_kernel(const unsigned* __restrict__ ss_bits, int64_t 
     }
 }
 
+// (a query whose rows are not finite ends with no candidate at all -- every bound comparison is false -- and nn = -1: as a gather
+// index it is clamped to row 0 here; l2_mutual_pairs_kernel never reports such a query as mutual, whatever the reverse search
+// of row 0 returns)
 __global__ void l2i8_to_int_kernel(const int64_t* __restrict__ src, int* __restrict__ dst, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = (int)src[i];
+    if (i < n) dst[i] = src[i] < 0 ? 0 : (int)src[i];
 }
 
 constexpr int SELECT_L2_WAVES = 8;
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(1024) void l2_mutual_pairs_kernel(const int64_t* __
     __syncthreads();
     for (int64_t i0 = 0; i0 < n; i0 += 1024) {
         const int64_t i = i0 + threadIdx.x;
-        const bool keep = i < n && nn_rev[i] == i;
+        const bool keep = i < n && nn_ab[i] >= 0 && nn_rev[i] == i;   // nn_ab < 0: a query without any candidate (non-finite row)
         const unsigned long long bal = __ballot(keep);
         if (lane == 0) wsum[wave] = __popcll(bal);
         __syncthreads();

@@ -65,6 +65,10 @@ class _ResultSet:
 # on how many were created before it: the same pipeline, built again later in the process, ran at 1110, 1270 or 1375
 # registrations/s depending on whether a solve stream had come to share the coarse stream's queue (tools/queue_probe.py,
 # tools/queue_probe_trace.sh).  The first streams a process creates get queues of their own; they are kept and reused.
+# Consequences a caller should know: the streams are never released; two pipelines of one process -- or pipelines driven from
+# different threads -- serialise their side stages on these streams (results stay correct: every hand-off is ordered by events).
+# ``RegistrationPipeline(private_streams=True)`` gives a pipeline streams of its own and is the choice for concurrent pipelines;
+# the queue placement it then gets is the HIP runtime's (an observed heuristic, not a contract).
 _SIDE_STREAMS = {}
 
 
@@ -273,6 +277,13 @@ class RegistrationPipeline:
         ops._chk(b_xyz, torch.float64, "b_xyz")
         if q_desc.shape != (self.n, self.d) or b_desc.shape != (self.m, self.d):
             raise ValueError("Invalid shape")
+        if reuse_map:
+            # a reused map is prepared once (vfm_match_prepare2 / vfm_match_prepare below): it carries the fp16 and int8 images, not
+            # the fp6 one -- its err6 would be read as infinite and an fp6 search would prune nothing.  Same rule as prepare_map().
+            if self.coarse in ("mx6", "mx6-top2", "mx6-half"):
+                raise ValueError("the fp6 modes prepare map and scan together in every registration: no reuse_map")
+            self._mx6_ok = self._mx6_half_ok = False
+            self.mx6 = self.mx6_half = False
         self._poll_feedback()
         if self.coarse == "auto":
             self._since_switch += 1

@@ -42,24 +42,24 @@ def compute_errors(pose: np.ndarray, gt_pose: np.ndarray) -> Tuple[float, float]
 
 
 def find_correspondences(feats0: np.ndarray, feats1: np.ndarray, n_points: int = 5000, mutual_filter: bool = True):
-    """RN:482-538 (adapted from TEASER++): exact Euclidean 1-NN on the GPU instead of cKDTree."""
+    """RN:482-538 (adapted from TEASER++): exact Euclidean 1-NN on the GPU instead of cKDTree.
+
+    The rows are searched as float32 (the descriptors of this path are float32 -- image_features.py:101 --; the reference's
+    cKDTree works in the caller's dtype, so float64 inputs that differ only beyond float32 precision may resolve exact ties and
+    near-ties differently); the decision among float32 rows is the oracle's fp64 distance, ties to the lowest index."""
     f0 = torch.from_numpy(np.ascontiguousarray(feats0, dtype=np.float32)).cuda()
     f1 = torch.from_numpy(np.ascontiguousarray(feats1, dtype=np.float32)).cuda()
     if mutual_filter:   # RN:520-532 in one call: the reverse direction is searched only at the matched rows of feats1
         i0, i1, count = ops.match_mutual_pairs(f0, f1)
         k = int(count.item())
         return i0[:k].cpu().numpy(), i1[:k].cpu().numpy()
-    nn01, d2, nn10 = ops.match_mutual_l2(f0, f1, mutual=False)
+    # RN:505-518: the n_points pairs with the smallest distance
+    nn01, d2, _ = ops.match_mutual_l2(f0, f1, mutual=False)
     nns01 = nn01.cpu().numpy()
-    idx0 = np.arange(len(nns01))
-    if not mutual_filter:
-        dists = np.sqrt(d2.cpu().numpy())
-        n = min(n_points, len(dists) - 1)
-        top = np.argpartition(dists, n)[:n]
-        return idx0[top], nns01[top]
-    nns10 = nn10.cpu().numpy()
-    mutual = nns10[nns01] == idx0
-    return idx0[mutual], nns01[mutual]
+    dists = np.sqrt(d2.cpu().numpy())
+    n = min(n_points, len(dists) - 1)
+    top = np.argpartition(dists, n)[:n]
+    return np.arange(len(nns01))[top], nns01[top]
 
 
 class RegistrationNode:
