@@ -206,7 +206,7 @@ def extra_configs(dev):
                  "ms_registration": t5_reg, "ms_coarse_kernel": t5, "correspondences": int(r5["count"].item()),
                  "pose_err_vs_planted": float(np.linalg.norm(r5["T"].cpu().numpy() - p5["T_gt"])),
                  "coarse_pass": pass_name(pipe5),
-                 "roofline": {"bound": "mfma", "kernel": ("match_coarse_mx6q2_kernel<6, false, false, 12> (fp6 e2m3 32x32x64 scaled MFMA over the first 384 of 768 columns, 64 resident "
+                 "roofline": {"bound": "mfma", "kernel": ("match_coarse_mx6q2_kernel<6, MX6_FUSE, false, 12, 4> (fp6 e2m3 32x32x64 scaled MFMA over the first 384 of 768 columns, 64 resident "
                                                           "queries per wave)" if half5_fp6
                                                           else "match_coarse_i8q2_kernel<12> (int8 32x32x32 MFMA over the first 384 of 768 columns, 64 resident queries per wave)" if half5
                                                           else "match_coarse_i8_kernel<24, 2> (int8 32x32x32 MFMA)"), "flops": f5,
@@ -285,7 +285,8 @@ def pass_name(pipe):
         return ("fp6 (MX e2m3), full width, packed top-2 records (VFM_RECORDS_MX6_TOP2)" if getattr(pipe, "mx6_top2", False)
                 else "fp6 (MX e2m3), full width, best-score records (VFM_RECORDS_MX6)")
     if pipe.half and getattr(pipe, "mx6_half", False):
-        return "fp6 (MX e2m3), half-width (VFM_RECORDS_MX6_HALF)"
+        return ("fp6 (MX e2m3), half-width, survivor-only epilogue (VFM_RECORDS_MX6_HALF_FUSED)" if pipe._records() == 8
+                else "fp6 (MX e2m3), half-width (VFM_RECORDS_MX6_HALF)")
     return "int8, half-width (VFM_RECORDS_HALF)" if pipe.half else ("int8, packed top-2 records" if pipe.top2 else "int8, best-score records")
 
 
@@ -599,11 +600,12 @@ def main():
         flops = 2.0 * n * m * kcols   # what the dominant kernel computes per launch
         achieved = flops / (coarse_ms * 1e-3) / 1e12
         peak = MFMA_F6_PEAK_TFLOPS if half6 else (MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS)
-        kernel = ((f"match_coarse_mx6q2_kernel<{kcols // 64}, false, false, {d // 64}> (v_mfma_scale_f32_32x32x64_f8f6f4 on microscaled fp6 -- e2m3 "
-                   f"elements, one power-of-two scale per 32 columns -- over the first {kcols} of {d} columns: the half-width pass in fp6; the other "
-                   "half is bounded by Cauchy-Schwarz against the cosine gate, the image's quantisation by its measured residual norms, and only "
-                   "surviving chunks are scored over all columns (int8 MFMA rescan, fp32 refinement, fp64 decision); 64 resident queries per wave, "
-                   "one best-score record per (query, chunk))") if half6
+        fused6 = half6 and records_kind == 8
+        kernel = ((f"match_coarse_mx6q2_kernel<{kcols // 64}, {'MX6_FUSE' if fused6 else 'MX6_BEST'}, false, {d // 64}, 4> (v_mfma_scale_f32_32x32x64_f8f6f4 on "
+                   f"microscaled fp6 -- e2m3 elements, one power-of-two scale per 32 columns -- over the first {kcols} of {d} columns: the half-width pass "
+                   "in fp6; the other half is bounded by Cauchy-Schwarz against the cosine gate, the image's quantisation by its measured residual "
+                   "norms, and only surviving chunks are scored over all columns (int8 MFMA rescan, fp32 refinement, fp64 decision); 64 resident "
+                   "queries per wave, " + ("survivors of the bound listed by the kernel itself (no records)" if fused6 else "one best-score record per (query, chunk)") + ")") if half6
                   else (f"match_coarse_i8q2_kernel<{kcols // 32}> (int8 32x32x32 MFMA over the first {kcols} of {d} columns -- the half-width pass: the "
                    "other half is bounded by Cauchy-Schwarz against the cosine gate and only surviving chunks are scored over all columns -- "
                    "64 resident queries per wave, exact integer scores, one best-score record per (query, chunk))") if half
@@ -611,7 +613,7 @@ def main():
                         + ("packed top-2 records" if mode_top2 else "one best-score record per (query, chunk)") + ")") if i8
                   else "match_coarse_pipe_kernel<24, true> (fp16 32x32x16 MFMA, sparse row-level records)")
         traffic, traffic_src = None, None  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
-        names = (("r03_pmc_match_coarse_mx6half.json",) if half6
+        names = (("r04_pmc_match_coarse_mx6half.json", "r03_pmc_match_coarse_mx6half.json") if half6
                  else ("r03_pmc_match_coarse_i8half.json", "r02_pmc_match_coarse_i8half.json") if half
                  else ("r03_pmc_match_coarse_i8.json", "r02_pmc_match_coarse_i8.json") if i8
                  else ("r02_pmc_match_coarse_f16.json", "r01_pmc_match_coarse.json"))
@@ -644,7 +646,8 @@ def main():
                        # the record kind (include/vfmreg.h VFM_RECORDS_*) of the timed registrations: tests/test_gpu_bench_config.py
                        # compares exactly this kind with the oracle at this size (BENCH_RECORDS_KIND), tests/test_gpu_bench.py ties the two
                        "records_kind": records_kind,
-                       "coarse_pass": ("fp6 (MX e2m3), half-width (VFM_RECORDS_MX6_HALF)" if half6 else "int8, half-width (VFM_RECORDS_HALF)" if half
+                       "coarse_pass": (("fp6 (MX e2m3), half-width, survivor-only epilogue (VFM_RECORDS_MX6_HALF_FUSED)" if records_kind == 8
+                                        else "fp6 (MX e2m3), half-width (VFM_RECORDS_MX6_HALF)") if half6 else "int8, half-width (VFM_RECORDS_HALF)" if half
                                        else "int8, packed top-2 records" if (i8 and mode_top2)
                                        else "int8, best-score records" if i8 else "fp16"),
                        # (query, chunk) pairs that survive the half-width bound, per query, in the last search the policy has read back:

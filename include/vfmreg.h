@@ -187,6 +187,13 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
  *                     and operands prepared with VFM_PREPARE_MX6; behind the selection it is VFM_RECORDS_HALF (device-side guard
  *                     included).  d = 256 / 384 / 512 / 768 with more than 2048 queries; elsewhere it behaves as VFM_RECORDS_BEST. */
 #define VFM_RECORDS_MX6_HALF 7
+/*   VFM_RECORDS_MX6_HALF_FUSED  VFM_RECORDS_MX6_HALF with its selection inside the coarse kernel (needs the gate at the coarse call:
+ *                     vfm_match_search_coarse_gated_g): a (query, chunk) pair whose bound reaches the gate is listed by the
+ *                     kernel itself -- in the LDS, flushed once per workgroup by plain stores -- and no record is written: the
+ *                     122 MB record array of a 20 000 x 200 000 search and its 70 us selection sweep do not exist.  Same
+ *                     answers, same guard; where a map chunk does not collect several queries (n < 4 x chunks) it behaves as
+ *                     VFM_RECORDS_MX6_HALF. */
+#define VFM_RECORDS_MX6_HALF_FUSED 8
 int vfm_match_search_coarse_gated_r(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
                                     int d, void *ws, size_t ws_bytes, int records, vfm_stream_t stream);
 /* _coarse_gated_r with the gate of the search (needed by VFM_RECORDS_HALF_FUSED; ignored by the other kinds) */
@@ -404,9 +411,12 @@ typedef struct {
 } vfm_vit_config;
 size_t vfm_vit_weights_bytes(const vfm_vit_config *cfg);
 /* segment table of the weights blob for the host-side packer: byte offsets / sizes of
- * [patch_w, patch_b, cls_pos, {ln1_w, ln1_b, qkv_w, qkv_b, proj_w, proj_b, ls1, ln2_w, ln2_b, fc1_w,
- *  fc1_b, fc2_w, fc2_b, ls2} x depth, norm_w, norm_b, channel_norm_w, channel_norm_b];
- * *_w of the linear layers are fp16 fragment tiles, everything else fp32.  Returns the count. */
+ * [patch_w, patch_b, cls_pos, {qkv_w, qkv_b, qkv_c, proj_w, proj_b, ls1, fc1_w, fc1_b, fc1_c, fc2_w, fc2_b, ls2} x depth,
+ *  norm_w, norm_b, channel_norm_w, channel_norm_b];
+ * *_w of the linear layers are fp16 fragment tiles, everything else fp32.  The block's two LayerNorms are folded into the
+ * linear layers behind them (round 4): qkv_w = W_qkv diag(ln1 gamma), qkv_b = b_qkv + W_qkv ln1_beta, qkv_c[n] = the sum of
+ * row n of qkv_w AS ROUNDED to fp16; fc1_* likewise with ln2 -- the GEMM multiplies the raw residual stream and applies the
+ * token's mean / 1 / std in its epilogue (csrc/vit.hip; vfmreg/vit.py does the folding).  Returns the count. */
 int vfm_vit_weights_layout(const vfm_vit_config *cfg, int64_t *offsets_host, int64_t *bytes_host,
                            int max_n);
 size_t vfm_vit_workspace_bytes(const vfm_vit_config *cfg, int B);

@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 N, M, D, ITERS = 20000, 200000, 384, 50000
-# the record kind the bench's headline runs on D.2 data (include/vfmreg.h: VFM_RECORDS_MX6_HALF); a policy edit that moves the
+# the record kind the bench's headline runs on D.2 data (include/vfmreg.h: VFM_RECORDS_MX6_HALF_FUSED -- the half-width pass in
+# fp6 with the survivor-only epilogue, match_coarse_mx6q2_kernel<3, MX6_FUSE, false, 6, 4>); a policy edit that moves the
 # pipeline to another coarse kernel turns the tests below -- and tests/test_gpu_bench.py -- red
-BENCH_RECORDS_KIND = 7
+BENCH_RECORDS_KIND = 8
 
 
 def _oracle_registration(orc, p, iters):

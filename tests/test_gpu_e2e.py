@@ -134,12 +134,12 @@ def test_c5_solve_at_full_size():
     p = synth.make_pair_device(n, m, d, seed=77)
     outs = []
     # the serial and the overlapped pipeline with `auto` (first registration: best-score int8 records + the half-width probe),
-    # then the kernel bench.py's C5 line names, pinned: the half-width pass in fp6 (VFM_RECORDS_MX6_HALF = 7,
-    # match_coarse_mx6q2_kernel<6, false, false, 12>) -- every form must return the same bits
+    # then the kernel bench.py's C5 line names, pinned: the half-width pass in fp6 (VFM_RECORDS_MX6_HALF_FUSED = 8,
+    # match_coarse_mx6q2_kernel<6, MX6_FUSE, false, 12, 4>) -- every form must return the same bits
     for overlap, coarse in ((False, "auto"), (True, "auto"), (True, "mx6-half")):
         pipe = RegistrationPipeline(n, m, d, n_iter=iters, overlap_ransac=overlap, coarse=coarse)
         if coarse == "mx6-half":
-            assert pipe._records() == 7 and pipe.half and pipe.mx6_half
+            assert pipe._records() == 8 and pipe.half and pipe.mx6_half
         else:
             assert pipe._records() == 0
         out = pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
@@ -170,7 +170,7 @@ def test_c5_solve_at_full_size():
     qn, _ = orc.l2norm_rows(p["q_desc"][rows].cpu().numpy())
     bn, _ = orc.l2norm_rows(p["b_desc"].cpu().numpy())
     idx_ref, sim_ref = orc.match_ip_top1(qn, bn)
-    for which, o in (("auto (best-score int8 records)", out), ("mx6-half (record kind 7)", h)):
+    for which, o in (("auto (best-score int8 records)", out), ("mx6-half (record kind 8)", h)):
         got_i, got_s = o["idx"][rows].cpu().numpy(), o["sim"][rows].cpu().numpy()
         solved = got_i >= 0   # unresolved rows (-1, -2.0): provably below the cosine gate
         assert solved.sum() >= 50, which

@@ -17,6 +17,8 @@ PREPARE_MX6 = 8
 RECORDS_MX6 = 5
 RECORDS_MX6_TOP2 = 6
 RECORDS_MX6_HALF = 7
+RECORDS_MX6_HALF_FUSED = 8
+HALF_KINDS = (RECORDS_MX6_HALF, RECORDS_MX6_HALF_FUSED)
 E2M3 = np.array(sorted({(mm / 8 if e == 0 else (1 + mm / 8) * 2 ** (e - 1)) for e in range(4) for mm in range(8)}))
 
 
@@ -146,7 +148,7 @@ def test_mx6_pass_gives_the_oracle_answers_and_keeps_the_gate_contract(d, n, m):
         ridx, rsim = orc.match_ip_top1(qn, bn)
         qd, bd = torch.from_numpy(qq).cuda(), torch.from_numpy(bb).cuda()
         for g in (gate, float("-inf")):
-            for records in (RECORDS_MX6, RECORDS_MX6_TOP2) + ((RECORDS_MX6_HALF,) if g > float("-inf") else ()):
+            for records in (RECORDS_MX6, RECORDS_MX6_TOP2) + (HALF_KINDS if g > float("-inf") else ()):
                 idx, sim = _search(qd, bd, g, records)
                 solved = _gate_contract(idx, sim, ridx, rsim, g)
                 if g == float("-inf"):
@@ -214,7 +216,7 @@ def soak_trial_mx6(lib, rng, st):
     ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=torch.uint8, device="cuda")
     _lib.check(lib.vfm_match_prepare2_gated_p(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, PREPARE_MX6, st))
     res = {}
-    for records in (0, RECORDS_MX6, RECORDS_MX6_TOP2) + ((RECORDS_MX6_HALF,) if gate > float("-inf") else ()):
+    for records in (0, RECORDS_MX6, RECORDS_MX6_TOP2) + (HALF_KINDS if gate > float("-inf") else ()):
         idx = torch.empty(n, dtype=torch.int64, device="cuda")
         sim = torch.empty(n, dtype=torch.float32, device="cuda")
         _lib.check(lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, gate, st))
@@ -224,7 +226,7 @@ def soak_trial_mx6(lib, rng, st):
         res[records] = (idx, sim)
     (i0, s0) = res[0]
     ok = True
-    for records in (RECORDS_MX6, RECORDS_MX6_TOP2, RECORDS_MX6_HALF):
+    for records in (RECORDS_MX6, RECORDS_MX6_TOP2) + HALF_KINDS:
         if records not in res:
             continue
         i, s = res[records]
@@ -265,7 +267,7 @@ def test_fp6_record_kinds_on_operands_without_the_fp6_image_stay_correct_and_hal
     bn, _ = orc.l2norm_rows(b)
     ridx, rsim = orc.match_ip_top1(qn, bn)
     qd, bd = torch.from_numpy(q).cuda(), torch.from_numpy(b).cuda()
-    for records in (RECORDS_MX6, RECORDS_MX6_TOP2, RECORDS_MX6_HALF):
+    for records in (RECORDS_MX6, RECORDS_MX6_TOP2) + HALF_KINDS:
         idx, sim = _search(qd, bd, gate, records, flags=0)          # no fp6 image
         solved = _gate_contract(idx, sim, ridx, rsim, gate)
         assert solved[rsim >= 0.8].all(), records
@@ -325,7 +327,7 @@ def test_reuse_map_without_prepare_map_keeps_auto_off_the_fp6_kinds():
             pipe.synchronize()
             torch.cuda.synchronize()
             pipe._poll_feedback()
-        assert not any(k in (5, 6, 7) for k in kinds + [pipe._records()]), (name, kinds)
+        assert not any(k in (5, 6, 7, 8) for k in kinds + [pipe._records()]), (name, kinds)
         assert not pipe.mx6 and not pipe.mx6_half, name
         c = int(out["count"].item())
         assert c == len(corres), name

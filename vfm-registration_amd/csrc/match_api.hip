@@ -47,6 +47,7 @@ thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 int g_coarse_qsets = 0;
 int g_seed_units = 1;   // vfm_debug_set_coarse_variant(7): no seed units (A/B)
 int g_select_variant = 0;  // vfm_debug_set_coarse_variant(20 / 21): general select kernel / no chunk-major rescan (A/B)
+int g_mx6_t4 = 1;
 int g_match_stats = 0;  // vfm_debug_set_match_stats: per-query counters cost ~0.5 ms of same-address atomics per search
 // 4 = pipelined kernel with the DENSE per-chunk records + match_select_kernel (round-1 path; A/B reference)
 
@@ -128,7 +129,7 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
     if (i8) {
         if (!gated) records = VFM_RECORDS_TOP2;  // no feedback loop behind an ungated call: the robust record kind
         records = effective_records(records, d, n, m);
-        if (records == VFM_RECORDS_HALF_FUSED) {
+        if (records == VFM_RECORDS_HALF_FUSED || records == VFM_RECORDS_MX6_HALF_FUSED) {
             if (!(gate > -__builtin_inff())) return vfm_fail(VFM_EINVAL, "search_coarse: VFM_RECORDS_HALF_FUSED needs a finite gate");
             a.gate = gate;
             a.n_valid = n;
@@ -141,18 +142,20 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
             a.cand = w.cand;
             a.cap = w.cap;
             a.survivors = w.fb_count + 5;
+            a.surv = reinterpret_cast<unsigned*>(w.partials);   // the fp6 form: one slot per workgroup in the record buffer it does not write
             VFM_CHECK_HIP(hipMemsetAsync(w.cand_cnt, 0, (size_t)a.npad * sizeof(int), st));  // lengths of the queries' own lists
         }
         const bool half = records == VFM_RECORDS_HALF || records == VFM_RECORDS_HALF_FUSED;   // the image of the first d / 2 columns
         a.Qh = half ? Q.tiles8h : Q.tiles8;
         a.Bh = half ? B.tiles8h : B.tiles8;
         a.ib = I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr, records == VFM_RECORDS_TOP2 ? 1 : 0};
-        if (records == VFM_RECORDS_MX6 || records == VFM_RECORDS_MX6_TOP2 || records == VFM_RECORDS_MX6_HALF) {
+        if (records == VFM_RECORDS_MX6 || records == VFM_RECORDS_MX6_TOP2 || records == VFM_RECORDS_MX6_HALF || records == VFM_RECORDS_MX6_HALF_FUSED) {
             // the fp6 image and its bounds (operands prepared with VFM_PREPARE_MX6)
             a.Qh = Q.tiles6;
             a.Bh = B.tiles6;
             a.ib = mx6_bounds(Q, B, records == VFM_RECORDS_MX6_TOP2 ? 1 : 0);
-            return launch_coarse_mx6(a, d, records == VFM_RECORDS_MX6_TOP2, records == VFM_RECORDS_MX6_HALF, st);
+            const bool fuse6 = records == VFM_RECORDS_MX6_HALF_FUSED;
+            return launch_coarse_mx6(a, d, records == VFM_RECORDS_MX6_TOP2, records == VFM_RECORDS_MX6_HALF || fuse6, fuse6, st);
         }
         return launch_coarse_int8(a, d, n, records, st);
     }
@@ -260,7 +263,7 @@ VFM_EXPORT int vfm_match_search_coarse_gated_g(const void* q_prepared, int64_t n
                                                void* ws, size_t ws_bytes, int records, float gate, vfm_stream_t stream) {
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q_prepared && b_prepared && ws, "search_coarse: null pointer");
-    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6_HALF, "search_coarse: unknown record kind %d", records);
+    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6_HALF_FUSED, "search_coarse: unknown record kind %d", records);
     VFM_CHECK_ARG(gate == gate, "search_coarse: gate is NaN");
     return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream, false, true, true, records, gate);
 }
@@ -278,7 +281,7 @@ VFM_EXPORT int vfm_match_search_finish_gated_r(const float* q, const void* q_pre
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q && b && q_prepared && b_prepared && ws && idx_out && sim_out, "search_finish: null pointer");
     VFM_CHECK_ARG(gate == gate, "search_finish: gate is NaN");
-    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6_HALF, "search_finish: unknown record kind %d", records);
+    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6_HALF_FUSED, "search_finish: unknown record kind %d", records);
     return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream, true, gate, records);
 }
 
@@ -398,28 +401,26 @@ VFM_EXPORT int vfm_debug_mx6_rows(const void* prepared, int64_t rows, int d, flo
     VFM_CHECK_ARG(prepared && rows > 0 && mx6_half_width(d) && v6_host && err_host && gerr_host, "mx6_rows: bad arguments");
     Prepared p = carve_prepared(const_cast<void*>(prepared), rows, d);
     const int64_t rp = rows_padded(rows);
-    const size_t units = (size_t)rp / TILE_ROWS * (size_t)(d / 64) * 128;
+    const int ks = d / 64;
+    const size_t tb = (size_t)mx6_tile_bytes(ks);
+    const size_t units = (size_t)rp / TILE_ROWS * (tb / 16);
     std::vector<uint4> tiles(units);
     std::vector<float> gerr((size_t)rp / I8_GROUP);
     VFM_CHECK_HIP(hipDeviceSynchronize());
     VFM_CHECK_HIP(hipMemcpy(tiles.data(), p.tiles6, units * sizeof(uint4), hipMemcpyDeviceToHost));
     VFM_CHECK_HIP(hipMemcpy(gerr.data(), p.gerr6, gerr.size() * sizeof(float), hipMemcpyDeviceToHost));
     VFM_CHECK_HIP(hipMemcpy(err_host, p.err6, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost));
-    const int upt = (d / 64) * 128;  // units per tile
+    const unsigned char* img = reinterpret_cast<const unsigned char*>(tiles.data());
     for (int64_t r = 0; r < rows; ++r) {
         const int64_t tile = r / TILE_ROWS, pp = r % TILE_ROWS;
         for (int blk = 0; blk < d / 32; ++blk) {   // block = (k-step s, half h): MFMA lane h * 32 + pp, columns 64 s + 32 h ...
-            const int s = blk >> 1, h = blk & 1;
-            unsigned char op[32];
-            const unsigned char* lo = reinterpret_cast<const unsigned char*>(&tiles[(size_t)tile * upt + (size_t)(2 * s) * 64 + h * 32 + pp]);
-            const unsigned char* hi = reinterpret_cast<const unsigned char*>(&tiles[(size_t)tile * upt + (size_t)(2 * s + 1) * 64 + h * 32 + pp]);
-            for (int i = 0; i < 16; ++i) {
-                op[i] = lo[i];
-                op[16 + i] = hi[i];
-            }
-            // the scales of k-steps 0 .. 7 sit in the spare bytes of unit row 1, those of 8 .. 11 in unit row 3
-            const unsigned char* sc = reinterpret_cast<const unsigned char*>(&tiles[(size_t)tile * upt + (size_t)(s < 8 ? 1 : 3) * 64 + h * 32 + pp]) + 8;
-            const float scale = ldexpf(1.0f, (int)sc[s & 7] - 127);
+            const int s = blk >> 1, h = blk & 1, l6 = h * 32 + (int)pp;
+            unsigned char op[32] = {0};
+            const unsigned char* lo = img + (size_t)tile * tb + mx6_code_a(s, l6);   // code bytes 0 .. 15
+            const unsigned char* hi = img + (size_t)tile * tb + mx6_code_b(s, l6);   // code bytes 16 .. 23
+            for (int i = 0; i < 16; ++i) op[i] = lo[i];
+            for (int i = 0; i < 8; ++i) op[16 + i] = hi[i];
+            const float scale = ldexpf(1.0f, (int)img[(size_t)tile * tb + mx6_scale_at(ks, s, l6)] - 127);
             for (int f = 0; f < 32; ++f) {
                 const int bit = 6 * f;
                 const unsigned w = (unsigned)op[bit >> 3] | ((unsigned)op[(bit >> 3) + 1] << 8);
@@ -451,6 +452,10 @@ VFM_EXPORT int vfm_debug_set_coarse_slices(int slices) {
     return VFM_OK;
 }
 VFM_EXPORT int vfm_debug_set_coarse_variant(int qsets) {
+    if (qsets == 30 || qsets == 31) {   // the fused fp6 half-width kernel: 30 = one chunk per barrier (the default), 31 = two (A/B)
+        g_mx6_t4 = qsets == 30 ? 1 : 0;
+        return VFM_OK;
+    }
     g_seed_units = qsets == 7 ? 0 : 1;
     if (qsets == 7) qsets = 0;
     // 20: the general select kernel on best-score records too, 21: best-score select kernel, query-major rescan only (A/B)

@@ -440,6 +440,36 @@ __global__ __launch_bounds__(64 * 8) void match_select_half_kernel(
     }
 }
 
+// VFM_RECORDS_MX6_HALF_FUSED: the fused fp6 half-width kernel (match_coarse_mx6.hip) has tested every (query, chunk) pair against
+// the gate itself and left each workgroup's survivors in a slot of the record buffer -- [count, query block, first chunk, overflow]
+// + entries (chunk of the slice << 9 | query of the block).  This kernel does the placement match_select_half_kernel does for its
+// survivors: into the chunk's rescan bin, past a full bin into the query's own list.  One wave per slot; ~11 000 entries at C2 on
+// SURVEY D.2 data (0.56 per query) against the 122 MB sweep of the records this replaces.  With the guard up (a slot overflowed:
+// descriptors that are all alike) nothing is placed: match_gatepass_kernel decides every query.
+__global__ __launch_bounds__(256) void match_bin_survivors_kernel(const unsigned* __restrict__ surv, int slot_words, const int* __restrict__ fb_count,
+                                                                  unsigned* __restrict__ bin_cnt, int* __restrict__ bins, int bin_cap,
+                                                                  int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap) {
+    if (fb_count[HALF_GUARD_FLAG] != 0) return;
+    const int nslots = fb_count[MX6_GRID_SLOT];
+    const int lane = lane_id(), nwaves = (int)gridDim.x * 4;
+    for (int sidx = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); sidx < nslots; sidx += nwaves) {
+        const unsigned* slot = surv + (size_t)sidx * slot_words;
+        const unsigned cnt = slot[0], qb = slot[1], c0 = slot[2];
+        for (unsigned i = (unsigned)lane; i < cnt; i += 64u) {
+            const unsigned e = slot[4 + i];
+            const int chunk = (int)(c0 + (e >> 9));
+            const int64_t q = (int64_t)qb * 512 + (int64_t)(e & 511u);
+            const unsigned pos = atomicAdd(&bin_cnt[(size_t)chunk * BIN_CNT_STRIDE], 1u);
+            if (pos < (unsigned)bin_cap) {
+                bins[(size_t)chunk * bin_cap + pos] = (int)q;
+            } else {   // a full bin leaves the entry in the query's own list (match_rescan_kernel)
+                const int own = atomicAdd(&cand_cnt[q], 1);
+                if (own < cap) cand[(size_t)q * cap + own] = ((unsigned)chunk << 8) | 128u;
+            }
+        }
+    }
+}
+
 // Best-score records of the int8 pass ([query tile][chunk][32], 4 bytes each): the same decision as the int8 branch of
 // match_select_kernel, laid out for the sweep.  One workgroup per query tile; a lane owns four consecutive queries of the
 // tile and one chunk of a block of eight, so a wave's load instruction covers 8 chunks x 32 queries = 1 KiB of consecutive
@@ -836,6 +866,9 @@ __global__ __launch_bounds__(256) void half_guard_kernel(int* __restrict__ fb_co
     __syncthreads();
     if (threadIdx.x == 0) {
         long long total = fused ? part[0] + part[1] + part[2] + part[3] : (long long)fb_count[5];
+        // (the fused fp6 kernel raises the flag itself when a workgroup's list overflows, and its survivors are then not binned: the
+        // load figure must still say "far too many")
+        if (fused && fb_count[HALF_GUARD_FLAG] != 0 && total < 0x3FFFFFFFll) total = 0x3FFFFFFFll;
         if (fused) fb_count[5] = (int)(total > 0x7FFFFFFFll ? 0x7FFFFFFFll : total);   // the search's load figure
         if (total > limit || fb_count[HALF_GUARD_FLAG] != 0) {
             fb_count[HALF_GUARD_FLAG] = 1;
@@ -1764,10 +1797,11 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     const bool i8 = records != VFM_RECORDS_F16 && use_i8(d, n, m, gated);
     if (i8 && !gated) records = VFM_RECORDS_TOP2;  // as do_search_coarse chose
     records = effective_records(records, d, n, m);
-    const bool fused = i8 && records == VFM_RECORDS_HALF_FUSED;   // the coarse kernel has filled the bins already
+    const bool fused6 = i8 && records == VFM_RECORDS_MX6_HALF_FUSED;   // the fp6 coarse kernel has left the survivors in its workgroups' slots
+    const bool fused = i8 && (records == VFM_RECORDS_HALF_FUSED || fused6);   // the coarse kernel has done the selection already
     const bool mx6half = i8 && records == VFM_RECORDS_MX6_HALF;   // the half-width pass on the fp6 image: its bounds in the selection
     const bool half = i8 && (records == VFM_RECORDS_HALF || fused || mx6half);
-    if (mx6half) records = VFM_RECORDS_HALF;
+    if (mx6half || fused6) records = VFM_RECORDS_HALF;
     if (half && !(gate > -__builtin_inff())) return vfm_fail(VFM_EINVAL, "search_finish: VFM_RECORDS_HALF needs a finite gate");
     if (!i8 && use_sparse(d, n, m)) {
         hipLaunchKernelGGL(match_filter_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d,
@@ -1783,7 +1817,10 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
         if (mx6) records = top2 ? VFM_RECORDS_TOP2 : VFM_RECORDS_BEST;
         const bool best = i8 && records == VFM_RECORDS_BEST && g_select_variant != 1;
         use_bins = (best || half) && g_select_variant != 2 && n >= 4 * (int64_t)a.nchunks;
-        if (fused) {
+        if (fused6) {
+            hipLaunchKernelGGL(match_bin_survivors_kernel, dim3(256), dim3(256), 0, st, reinterpret_cast<const unsigned*>(w.partials),
+                               mx6_survivor_slot_words(), (const int*)w.fb_count, w.bin_cnt, w.bins, w.bin_cap, w.cand_cnt, w.cand, w.cap);
+        } else if (fused) {
             // (nothing to select)
         } else if (half) {
             const int half_lds = (size_t)a.nchunks * 12 <= 63 * 1024;  // (step, max E, max |rest|) of every chunk in LDS

@@ -51,6 +51,8 @@ constexpr int RESCAN_BATCH = 64;     // ... of which match_rescan_chunk_kernel s
 // SearchWs::fb_count[7] is the flag (half_guard_kernel); the host policy (vfmreg/pipeline.py) leaves the mode on the same figure.
 constexpr int HALF_GUARD_PER_QUERY = 48;
 constexpr int HALF_GUARD_FLAG = 7;   // index into fb_count
+constexpr int MX6_SURV_SLOT_WORDS = 2047 + 4;   // fused fp6 half-width pass: a workgroup's survivor slot = header (4 words) + up to 2047 entries
+constexpr int MX6_GRID_SLOT = 32;    // fb_count[.]: workgroups of the fused fp6 half-width kernel = survivor slots match_bin_survivors_kernel walks
 constexpr int FUSE_BIN_SATURATE_X = 8;  // fused form: a chunk that collected this many times its bin capacity stops recording (and raises the flag)
 constexpr int FILTER_LDS_ROWS = 1024;  // sparse fp16 records a query can hold (= SearchWs::rcap; match_filter_refine_kernel keeps them in LDS)
 constexpr int SPARSE_LREC_CAP = 1536;  // records a workgroup of the sparse coarse kernel buffers in LDS (12 KiB)
@@ -241,6 +243,7 @@ struct CoarseArgs {
     unsigned* cand;         // [npad][cap]
     int cap;
     int* survivors;         // fb_count + 5: the search's load figure
+    unsigned* surv;         // VFM_RECORDS_MX6_HALF_FUSED: a slot of mx6_survivor_slot_words() words per workgroup (in the record buffer)
 };
 
 // XCD-aware unit mapping shared by the coarse kernels: workgroup b runs on XCD b % 8 (observed, speed
@@ -376,6 +379,25 @@ inline bool mx6_width(int d) { return d == 256 || d == 384; }
 // widths whose HALF-width pass has an fp6 kernel (d / 128 k-steps of queries in registers): the fp6 image exists for these
 inline bool mx6_half_width(int d) { return d == 256 || d == 384 || d == 512 || d == 768; }
 constexpr float MX6_FIX_STEP = 0.0009765625f;   // 2^-10: an fp6 record is ceil(score * 2^20) -- "integer score" x step x step
+// ---------------------------------------------------------------------------------------------
+// fp6 image (VFM_PREPARE_MX6), dense since round 4.  Lane l of v_mfma_scale_f32_32x32x64_f8f6f4 holds, for row l & 31 of a 32-row
+// tile, the 32 columns 64 s + 32 (l >> 5) ... of k-step s as 32 consecutive 6-bit codes = 24 bytes, and one E8M0 scale per
+// k-step.  A stored tile (KS = d / 64 k-steps):
+//     [scale plane 0: 64 lanes x 8 B -- byte s of lane l = scale of k-step s < 8]
+//     [k-step 0: plane A = 64 lanes x 16 B (code bytes 0 .. 15) | plane B = 64 lanes x 8 B (code bytes 16 .. 23)] [k-step 1] ...
+//     [scale plane 1 (KS > 8 only): k-steps 8 ..]
+// so a wave's fragment of a k-step is one ds_read_b128 at 16-byte stride + one ds_read_b64 at 8-byte stride -- both free of bank
+// conflicts (MI355X_MICROARCH.md, LDS; round 3's 16-byte units with 8 spare bytes cost 35 % of the LDS cycles in conflicts and a
+// third more bytes to stage) -- and the scales + the first KS / 2 k-steps, what the half-width pass reads, are a PREFIX of the tile.
+// ---------------------------------------------------------------------------------------------
+constexpr int MX6_SCALE_PLANE = 512;
+constexpr int MX6_KSTEP_BYTES = 1536;
+__host__ __device__ constexpr int mx6_tile_bytes(int ks) { return MX6_SCALE_PLANE + ks * MX6_KSTEP_BYTES + (ks > 8 ? MX6_SCALE_PLANE : 0); }
+__host__ __device__ inline size_t mx6_code_a(int s, int lane) { return (size_t)MX6_SCALE_PLANE + (size_t)s * MX6_KSTEP_BYTES + (size_t)lane * 16; }
+__host__ __device__ inline size_t mx6_code_b(int s, int lane) { return (size_t)MX6_SCALE_PLANE + (size_t)s * MX6_KSTEP_BYTES + 1024 + (size_t)lane * 8; }
+__host__ __device__ inline size_t mx6_scale_at(int ks, int s, int lane) {
+    return (s < 8 ? 0 : (size_t)MX6_SCALE_PLANE + (size_t)ks * MX6_KSTEP_BYTES) + (size_t)lane * 8 + (size_t)(s & 7);
+}
 // the fused form exists where the 64-queries-per-wave kernel runs and a map chunk collects several queries (chunk-major rescan)
 inline int effective_records(int records, int d, int64_t n, int64_t m) {
     if (records == VFM_RECORDS_HALF_FUSED && !((d == 256 || d == 384) && n > 2048 && n >= 4 * ((m + CHUNK_ROWS - 1) / CHUNK_ROWS)))
@@ -383,6 +405,10 @@ inline int effective_records(int records, int d, int64_t n, int64_t m) {
     if (records == VFM_RECORDS_MX6 && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_BEST;   // (the one-set kernels have no fp6 form)
     if (records == VFM_RECORDS_MX6_TOP2 && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_TOP2;
     if (records == VFM_RECORDS_MX6_HALF && !(mx6_half_width(d) && n > 2048)) records = VFM_RECORDS_BEST;   // (such operands carry no int8 half image)
+    // the fused form needs the chunk-major rescan behind it (several queries per map chunk), like VFM_RECORDS_HALF_FUSED
+    if (records == VFM_RECORDS_MX6_HALF_FUSED)
+        records = !(mx6_half_width(d) && n > 2048) ? VFM_RECORDS_BEST
+                  : (n >= 4 * ((m + CHUNK_ROWS - 1) / CHUNK_ROWS) ? VFM_RECORDS_MX6_HALF_FUSED : VFM_RECORDS_MX6_HALF);
     return (records == VFM_RECORDS_HALF && !half_capable(d, n)) ? VFM_RECORDS_BEST : records;
 }
 
@@ -409,8 +435,8 @@ inline Prepared carve_prepared(void* p, int64_t rows, int d) {
         r.tiles8h = c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(d / 64) * 64);
         r.rest = c.take<float>((size_t)rp);
         r.grest = c.take<float>((size_t)rp / I8_GROUP);
-        if (mx6_half_width(d)) {   // the fp6 image: 32 bytes per (row, 64 columns) -- 24 of codes, the block scales, padding
-            r.tiles6 = c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(d / 64) * 128);
+        if (mx6_half_width(d)) {   // the fp6 image: 24 bytes of codes per (row, 64 columns) + the block scales (mx6_tile_bytes)
+            r.tiles6 = c.take<uint4>((size_t)rp / TILE_ROWS * (size_t)(mx6_tile_bytes(d / 64) / 16));
             r.err6 = c.take<float>((size_t)rp);
             r.gerr6 = c.take<float>((size_t)rp / I8_GROUP);
             r.gstep6 = c.take<float>((size_t)rp / I8_GROUP);
@@ -443,7 +469,16 @@ inline SearchWs carve_search(void* p, int64_t n, int64_t m) {
     VfmCarver c(p);
     SearchWs w;
     const int64_t npad = rows_padded(n), mpad = rows_padded(m);
-    w.partials = c.take<uint2>((size_t)(mpad / CHUNK_ROWS) * (size_t)npad);
+    // the records of a coarse pass: per (chunk, query) 8 bytes -- or, for the fused fp6 half-width pass (which writes none), one slot
+    // of MX6_SURV_SLOT_WORDS words per workgroup: (npad / 512 query blocks) x (at most min(64, chunks / 8) slices, at least one)
+    {
+        const size_t nch = (size_t)(mpad / CHUNK_ROWS);
+        size_t slices = nch / 8 < 1 ? 1 : (nch / 8 > 64 ? 64 : nch / 8);
+        if (slices < (nch + 254) / 255) slices = (nch + 254) / 255;   // (a slice's per-chunk constants fit the kernel's LDS table: <= 255 chunks)
+        const size_t slots = ((size_t)npad / 512 + 1) * slices * (size_t)MX6_SURV_SLOT_WORDS;   // 4-byte words
+        const size_t recs = nch * (size_t)npad;                                                  // 8-byte records
+        w.partials = c.take<uint2>(recs > (slots + 1) / 2 ? recs : (slots + 1) / 2);
+    }
     w.cand_cnt = c.take<int>((size_t)npad);
     w.cap = cand_cap(mpad);
     w.cand = c.take<unsigned>((size_t)npad * (size_t)w.cap);
@@ -484,6 +519,7 @@ inline void attr_mark(unsigned long long& mask) {
 
 // experiment knobs and profiling hook (match_api.hip)
 extern int g_force_slices, g_coarse_qsets, g_seed_units, g_match_stats, g_i8_min_queries, g_select_variant;
+extern int g_mx6_t4;   // vfm_debug_set_coarse_variant(30 / 31): the fused fp6 half-width kernel with one chunk per barrier (default) / two (A/B)
 extern thread_local hipEvent_t g_prof_start, g_prof_stop;  // vfm_prof_arm: events around the next coarse launch of this thread
 
 // which coarse pass / record kind a search takes (match_api.hip)
@@ -508,7 +544,8 @@ int do_prepare_perm(const float* x, int64_t rows, const int* perm, int d, void* 
 // match_coarse_f16.hip / match_coarse_i8.hip: launch the coarse kernel for arguments prepared by do_search_coarse
 int launch_coarse_f16(const CoarseArgs& a, int d, hipStream_t st);
 int launch_coarse_int8(CoarseArgs& a, int d, int64_t n, int records, hipStream_t st);
-int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, bool half, hipStream_t st);   // match_coarse_mx6.hip
+int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, bool half, bool fuse, hipStream_t st);   // match_coarse_mx6.hip
+int mx6_survivor_slot_words();   // words per workgroup slot of the fused half-width pass (header + entries)
 // match_api.hip
 int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, hipStream_t st,
                      bool bias_from_map_inv = false, bool inner_product = false, bool gated = false, int records = 0,

@@ -99,11 +99,10 @@ struct PrepOut {
 // MX6: additionally the microscaled fp6 image (OCP MX: e2m3 elements, one power-of-two scale per 32 columns) in fragment tiles
 // of v_mfma_scale_f32_32x32x64_f8f6f4.  Lane l of that MFMA holds, for row l & 31, the 32 columns 64 s + 32 (l >> 5) ... of
 // k-step s as 32 consecutive 6-bit codes (little-endian: code f at bits [6 f, 6 f + 6) -- tools/probe/mx6_probe.hip checks
-// the layout on the device), i.e. exactly ONE scale block.  A lane's operand is stored as two 16-byte units, 24 bytes of codes +
-// 8 spare, at uint4 index tile * (d/64 * 128) + (2 s + half) * 64 + l: the tile geometry of the int8 image (1 KiB per unit
-// row, d * 32 bytes per tile), so the coarse kernel stages both the same way.  The E8M0 scales of a lane's d / 64 blocks sit
-// together in the spare bytes of k-step 0 (byte 8 + s of the unit in unit row 1): one 8-byte read per tile, the MFMA's op_sel
-// picks the byte.
+// the layout on the device), i.e. exactly ONE scale block.  The stored tile is dense (match_internal.h, mx6_tile_bytes / mx6_code_a /
+// mx6_code_b / mx6_scale_at): a plane of the lanes' scales -- 8 bytes per lane, byte s = the E8M0 scale of k-step s: one 8-byte
+// read per tile, the MFMA's op_sel picks the byte --, then per k-step a plane of the lanes' first 16 code bytes and a plane of
+// their last 8.
 // The image is made from the fp16 copy of the normalised rows that phase 2 leaves in the LDS (the staging of the fp16 image):
 // once the int8 tiles have left the LDS, a thread takes one (row, 32-column block) -- 1536 of them per group -- reads its 32
 // halves, picks the scale 2^e with max / 2^e <= 7.75 (the largest code is 7.5; up to 7.75 rounds there with the half-step
@@ -339,6 +338,7 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
         if constexpr (MX6) {
             __syncthreads();   // the int8 tiles have left the LDS: the fp6 image takes their place
             const int nblk = d >> 5;
+            const int tb6 = mx6_tile_bytes(d >> 6);   // (d <= 384 here: one scale plane)
             for (int item = threadIdx.x; item < I8_GROUP * nblk; item += NT) {
                 const int r = item & (I8_GROUP - 1), blk = item >> 7, t = r >> 5, p = r & 31;
                 // the block's 32 halves: fp16 units (k-step 2 blk + u, half hh) of row p, in column order
@@ -373,18 +373,15 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
                     e6 = __builtin_fmaf(res, res, e6);
                 }
                 const int s6 = blk >> 1, l6 = (blk & 1) * 32 + p;
-                unsigned char* tile6 = img6 + (size_t)t * (d * 32);
-                *reinterpret_cast<uint4*>(tile6 + (size_t)((2 * s6) * 64 + l6) * 16) =
+                unsigned char* tile6 = img6 + (size_t)t * tb6;
+                *reinterpret_cast<uint4*>(tile6 + mx6_code_a(s6, l6)) =
                     make_uint4((unsigned)codes[0], (unsigned)codes[1], (unsigned)codes[2], (unsigned)codes[3]);
-                if (s6 > 0)   // (the spare bytes of unit row 1 take the lane's scales, below)
-                    *reinterpret_cast<uint4*>(tile6 + (size_t)((2 * s6 + 1) * 64 + l6) * 16) = make_uint4((unsigned)codes[4], (unsigned)codes[5], 0u, 0u);
-                else
-                    *reinterpret_cast<uint2*>(tile6 + (size_t)(64 + l6) * 16) = make_uint2((unsigned)codes[4], (unsigned)codes[5]);
+                *reinterpret_cast<uint2*>(tile6 + mx6_code_b(s6, l6)) = make_uint2((unsigned)codes[4], (unsigned)codes[5]);
                 scb[r * 16 + blk] = (unsigned char)(ex + 127);
                 e6p[blk * I8_GROUP + r] = e6;
             }
             __syncthreads();
-            if (threadIdx.x < 2 * I8_GROUP) {   // the d / 64 scales of MFMA lane (hh, p) of tile t: bytes 8 .. of its unit in unit row 1
+            if (threadIdx.x < 2 * I8_GROUP) {   // the d / 64 scales of MFMA lane (hh, p) of tile t: its 8 bytes of the scale plane
                 const int r = threadIdx.x & (I8_GROUP - 1), hh = threadIdx.x >> 7;
                 unsigned lo = 0u, hi = 0u;
                 for (int s6 = 0; s6 < (d >> 6); ++s6) {
@@ -392,7 +389,7 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
                     if (s6 < 4) lo |= b << (8 * s6);
                     else hi |= b << (8 * (s6 - 4));
                 }
-                *reinterpret_cast<uint2*>(img6 + (size_t)(r >> 5) * (d * 32) + (size_t)(64 + hh * 32 + (r & 31)) * 16 + 8) = make_uint2(lo, hi);
+                *reinterpret_cast<uint2*>(img6 + (size_t)(r >> 5) * tb6 + mx6_scale_at(d >> 6, 0, hh * 32 + (r & 31))) = make_uint2(lo, hi);
             } else if (threadIdx.x < 3 * I8_GROUP) {   // E of the fp6 image per row: blocks in order; rounded up like the int8 one
                 const int r = threadIdx.x - 2 * I8_GROUP;
                 float acc = 0.0f;
@@ -405,7 +402,7 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
                 if (e6n > 0.0f) atomicMax(&e6max_bits, __float_as_uint(e6n));
             }
             __syncthreads();
-            const int u6n = (d >> 5) * 64 * 4;   // same size as the int8 tiles
+            const int u6n = 4 * tb6 / 16;   // four tiles of the group, in 16-byte units
             uint4* dst = o.tiles6 + (int64_t)grp * u6n;
             const uint4* src = reinterpret_cast<const uint4*>(img6);
             for (int u = threadIdx.x; u < u6n; u += NT) {
@@ -460,8 +457,9 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
 // own behind prep_chunk_kernel (whose LDS cannot hold an fp16 copy of such a group): a thread takes one (row, 32-column block),
 // reads its 32 floats, normalises them with the 1 / |row| prep_chunk_kernel left, rounds to fp16 and converts exactly as that
 // kernel's second half does (same scale rule, v_cvt_scalef32_pk32_fp6_f16, residual measured against the fp16 values); the blocks
-// of a row are NBLK consecutive lanes, so the row's sum is a fixed xor tree.  The block scales of k-steps 0 .. 7 go to the spare
-// bytes of unit row 1, those of k-steps 8 .. 11 to unit row 3.  prep_mx6_group_kernel then takes the maximum E of every group.
+// of a row are NBLK consecutive lanes, so the row's sum is a fixed xor tree.  The block scales of k-steps 0 .. 7 go to the tile's
+// first scale plane, those of k-steps 8 .. 11 to the second one behind the codes (mx6_scale_at; spare scale bytes are never
+// read).  prep_mx6_group_kernel then takes the maximum E of every group.
 // ---------------------------------------------------------------------------------------------
 template <int NBLK>   // lanes per row: 16 (d = 512) or 32 (d = 768: 24 in use)
 __global__ __launch_bounds__(256) void prep_mx6_rows_kernel(const float* __restrict__ x1, int64_t rows1, int64_t pad1, int d, PrepOut o1,
@@ -546,12 +544,11 @@ __global__ __launch_bounds__(256) void prep_mx6_rows_kernel(const float* __restr
         o.err6[r] = e6n;
     }
     if (active) {
-        const int t = (int)(r >> 5), p = (int)(r & 31), s6 = blk >> 1, l6 = (blk & 1) * 32 + p;
-        uint4* tile = o.tiles6 + (size_t)(r >> 5) * (size_t)((d >> 6) * 128);
-        (void)t;
-        tile[(2 * s6) * 64 + l6] = make_uint4((unsigned)codes[0], (unsigned)codes[1], (unsigned)codes[2], (unsigned)codes[3]);
-        *reinterpret_cast<uint2*>(tile + (2 * s6 + 1) * 64 + l6) = make_uint2((unsigned)codes[4], (unsigned)codes[5]);
-        reinterpret_cast<unsigned char*>(tile + (s6 < 8 ? 1 : 3) * 64 + l6)[8 + (s6 & 7)] = (unsigned char)(ex + 127);
+        const int p = (int)(r & 31), s6 = blk >> 1, l6 = (blk & 1) * 32 + p, ks = d >> 6;
+        unsigned char* tile = reinterpret_cast<unsigned char*>(o.tiles6) + (size_t)(r >> 5) * (size_t)mx6_tile_bytes(ks);
+        *reinterpret_cast<uint4*>(tile + mx6_code_a(s6, l6)) = make_uint4((unsigned)codes[0], (unsigned)codes[1], (unsigned)codes[2], (unsigned)codes[3]);
+        *reinterpret_cast<uint2*>(tile + mx6_code_b(s6, l6)) = make_uint2((unsigned)codes[4], (unsigned)codes[5]);
+        tile[mx6_scale_at(ks, s6, l6)] = (unsigned char)(ex + 127);
     }
 }
 

@@ -55,13 +55,21 @@ struct Dims {
 // ---------------------------------------------------------------------------------------------
 // weights blob
 // ---------------------------------------------------------------------------------------------
+// Round 4: the two LayerNorms of a block are folded into the GEMMs that consume them.  With gamma, beta the
+// LayerNorm's affine, W the linear layer behind it, mu / r the token's mean / reciprocal standard deviation:
+//     y_n = sum_k ((x_k - mu) r gamma_k + beta_k) W_nk + b_n  =  r (sum_k x_k W'_nk  -  mu c_n) + b'_n
+//     W' = W diag(gamma)  (stored as fp16 fragments),  c_n = sum_k W'_nk  (of the ROUNDED fp16 values),  b' = b + W beta
+// so the QKV / fc1 GEMMs multiply the RAW residual stream (an fp16 copy the producing epilogue writes beside the fp32 one) and
+// apply mu, r in their epilogue; the producers -- patch embedding, proj and fc2 epilogues, which hold the new residual values
+// in registers -- leave per-token partial sums (sum x, sum x^2) per 32-channel slice in fixed slots, added in fixed order by the
+// consumer: deterministic, no atomics.  87 -> 63 launches with the same number of waves per GEMM.
+// The packer (vfmreg/vit.py) does the folding on the host.
 enum Seg {
     SEG_PATCH_W = 0, SEG_PATCH_B, SEG_CLS_POS,
-    SEG_LAYER0,  // per layer: LN1_W LN1_B QKV_W QKV_B PROJ_W PROJ_B LS1 LN2_W LN2_B FC1_W FC1_B FC2_W FC2_B LS2
+    SEG_LAYER0,  // per layer: QKV_W' QKV_B' QKV_C PROJ_W PROJ_B LS1 FC1_W' FC1_B' FC1_C FC2_W FC2_B LS2
 };
-constexpr int SEGS_PER_LAYER = 14;
-enum LayerSeg { L_LN1_W = 0, L_LN1_B, L_QKV_W, L_QKV_B, L_PROJ_W, L_PROJ_B, L_LS1, L_LN2_W, L_LN2_B, L_FC1_W, L_FC1_B,
-                L_FC2_W, L_FC2_B, L_LS2 };
+constexpr int SEGS_PER_LAYER = 12;
+enum LayerSeg { L_QKV_W = 0, L_QKV_B, L_QKV_C, L_PROJ_W, L_PROJ_B, L_LS1, L_FC1_W, L_FC1_B, L_FC1_C, L_FC2_W, L_FC2_B, L_LS2 };
 // tail: NORM_W NORM_B CN_W CN_B
 
 struct Layout {
@@ -89,12 +97,10 @@ inline Layout make_layout(const vfm_vit_config* c) {
     add((size_t)D * 4);                // patch_b  fp32
     add((size_t)T * D * 4);            // cls_pos  fp32 [T][D]: row 0 = cls + pos[0], row t = pos[t]
     for (int l = 0; l < c->depth; ++l) {
-        add((size_t)D * 4); add((size_t)D * 4);                         // ln1
-        add(frag_bytes(3 * D, D)); add((size_t)3 * D * 4);              // qkv
-        add(frag_bytes(D, D)); add((size_t)D * 4); add((size_t)D * 4);  // proj, ls1
-        add((size_t)D * 4); add((size_t)D * 4);                         // ln2
-        add(frag_bytes(c->mlp_dim, D)); add((size_t)c->mlp_dim * 4);    // fc1
-        add(frag_bytes(D, c->mlp_dim)); add((size_t)D * 4); add((size_t)D * 4);  // fc2, ls2
+        add(frag_bytes(3 * D, D)); add((size_t)3 * D * 4); add((size_t)3 * D * 4);             // qkv: W diag(ln1 gamma), b + W ln1 beta, row sums
+        add(frag_bytes(D, D)); add((size_t)D * 4); add((size_t)D * 4);                         // proj, ls1
+        add(frag_bytes(c->mlp_dim, D)); add((size_t)c->mlp_dim * 4); add((size_t)c->mlp_dim * 4);   // fc1: W diag(ln2 gamma), b + W ln2 beta, row sums
+        add(frag_bytes(D, c->mlp_dim)); add((size_t)D * 4); add((size_t)D * 4);                // fc2, ls2
     }
     add((size_t)D * 4); add((size_t)D * 4); add((size_t)D * 4); add((size_t)D * 4);  // norm, channel norm
     L.count = n;
@@ -172,6 +178,10 @@ struct GemmArgs {
     _Float16* k;
     _Float16* vt;
     int xcd_map;  // 1: token tile mt is worked on by workgroups with blockIdx % 8 == mt % 8 (see xcd_item)
+    // LayerNorm folded into the GEMMs (see Seg): producers (PATCH, RESID) write xh + stats, consumers (QKV, GELU) read stats + csum
+    _Float16* xh;        // fp16 fragment-tiled copy of the residual stream [M][D]
+    float* stats;        // [M][D / 32][2]: (sum x, sum x^2) of the token over each 32-channel slice
+    const float* csum;   // [N]: row sums of the (gamma-folded, fp16-rounded) weight
 };
 
 // XCD-consistent work mapping (round 3): workgroup b runs on XCD b % 8 (observed placement, speed only).  Every kernel of a block
@@ -244,32 +254,56 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
     const int m = mt * 32 + (lane & 31);
     const int b = m / g.Tp, t = m % g.Tp;
     const int hi = lane >> 5;
+    constexpr bool CONSUMES_LN = EPI == EPI_QKV || EPI == EPI_GELU, PRODUCES_LN = EPI == EPI_PATCH || EPI == EPI_RESID;
+    const int nsl = g.D / 32;   // 32-channel slices of the residual stream
+    float ln_mean = 0.f, ln_rstd = 1.f;
+    if constexpr (CONSUMES_LN) {   // the token's LayerNorm statistics from the producers' partial sums, slices in ascending order
+        const float2* sp = reinterpret_cast<const float2*>(g.stats) + (size_t)m * nsl;
+        float sx = 0.f, sq = 0.f;
+        for (int i = 0; i < nsl; ++i) {
+            const float2 p = sp[i];
+            sx += p.x;
+            sq += p.y;
+        }
+        ln_mean = sx / (float)g.D;
+        const float var = fmaxf(sq / (float)g.D - ln_mean * ln_mean, 0.0f);
+        ln_rstd = rsqrtf(var + 1e-6f);
+    }
 #pragma unroll
     for (int half = 0; half < NT; ++half) {
+        float psum = 0.f, psq = 0.f;   // PRODUCES_LN: this lane's share of the slice's (sum x, sum x^2)
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
             const int n0 = (nt * NT + half) * 32 + 8 * grp + 4 * hi;  // 4 consecutive channels n0..n0+3
             float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[half][grp * 4 + j] + g.bias[n0 + j];
-            if constexpr (EPI == EPI_PATCH) {
-                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t == 0) {
-                    o = *reinterpret_cast<const float4*>(g.clspos + n0);
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (CONSUMES_LN) v[j] = ln_rstd * (acc[half][grp * 4 + j] - ln_mean * g.csum[n0 + j]) + g.bias[n0 + j];
+                else v[j] = acc[half][grp * 4 + j] + g.bias[n0 + j];
+            }
+            if constexpr (PRODUCES_LN) {
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);   // the token's new residual values (padding rows stay exactly zero)
+                float4* xp = reinterpret_cast<float4*>(g.x + (size_t)m * g.D + n0);
+                if constexpr (EPI == EPI_PATCH) {
+                    if (t == 0) {
+                        o = *reinterpret_cast<const float4*>(g.clspos + n0);
+                    } else if (t < g.T) {
+                        const float4 pe = *reinterpret_cast<const float4*>(g.clspos + (size_t)t * g.D + n0);
+                        o = make_float4(v[0] + pe.x, v[1] + pe.y, v[2] + pe.z, v[3] + pe.w);
+                    }
+                    *xp = o;
                 } else if (t < g.T) {
-                    const float4 pe = *reinterpret_cast<const float4*>(g.clspos + (size_t)t * g.D + n0);
-                    o = make_float4(v[0] + pe.x, v[1] + pe.y, v[2] + pe.z, v[3] + pe.w);
-                }
-                *reinterpret_cast<float4*>(g.x + (size_t)m * g.D + n0) = o;
-            } else if constexpr (EPI == EPI_RESID) {
-                if (t < g.T) {
-                    float4* xp = reinterpret_cast<float4*>(g.x + (size_t)m * g.D + n0);
                     const float4 ga = *reinterpret_cast<const float4*>(g.gamma + n0);
-                    float4 xv = *xp;
-                    xv.x = xv.x + ga.x * v[0]; xv.y = xv.y + ga.y * v[1];
-                    xv.z = xv.z + ga.z * v[2]; xv.w = xv.w + ga.w * v[3];
-                    *xp = xv;
+                    o = *xp;
+                    o.x = o.x + ga.x * v[0]; o.y = o.y + ga.y * v[1];
+                    o.z = o.z + ga.z * v[2]; o.w = o.w + ga.w * v[3];
+                    *xp = o;
                 }
+                half4 oh;
+                oh[0] = (_Float16)o.x; oh[1] = (_Float16)o.y; oh[2] = (_Float16)o.z; oh[3] = (_Float16)o.w;
+                *reinterpret_cast<half4*>(g.xh + frag_index(m, n0, g.D / 16)) = oh;
+                psum += (o.x + o.y) + (o.z + o.w);
+                psq += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
             } else if constexpr (EPI == EPI_GELU) {
                 half4 o;
 #pragma unroll
@@ -291,6 +325,11 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
                     for (int j = 0; j < 4; ++j) dst[frag_index(dd + j, t, g.Tp / 16)] = (_Float16)v[j];
                 }
             }
+        }
+        if constexpr (PRODUCES_LN) {   // the two half-waves hold the slice's other 16 channels of the same token: lower + upper, in that order
+            const float osum = __shfl_xor(psum, 32), osq = __shfl_xor(psq, 32);
+            if (hi == 0)
+                reinterpret_cast<float2*>(g.stats)[(size_t)m * nsl + (nt * NT + half)] = make_float2(psum + osum, psq + osq);
         }
     }
 }
@@ -511,7 +550,9 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const uint4* __restr
 
 struct VitWs {
     float* x;          // [M][D] fp32 residual
-    _Float16* a;       // [M][max(D, KP)] fragment tiles (LN out / im2col / attention out)
+    _Float16* a;       // [M][max(D, KP)] fragment tiles (im2col / attention out)
+    _Float16* xh;      // [M][D] fragment tiles: fp16 copy of the residual stream (what the QKV / fc1 GEMMs multiply)
+    float* stats;      // [M][D / 32][2] LayerNorm partial sums of the residual stream
     _Float16* h;       // [M][mlp] fragment tiles
     _Float16* q;
     _Float16* k;
@@ -537,6 +578,8 @@ inline VitWs carve_vit(void* p, const Dims& d) {
     const int kmax = d.D > d.KP ? d.D : d.KP;
     w.x = c.take<float>((size_t)d.M * d.D);
     w.a = c.take<_Float16>((size_t)d.M * kmax);
+    w.xh = c.take<_Float16>((size_t)d.M * d.D);
+    w.stats = c.take<float>((size_t)d.M * (d.D / 32) * 2);
     w.h = c.take<_Float16>((size_t)d.M * d.mlp);
     w.q = c.take<_Float16>((size_t)d.M * d.D);
     w.k = c.take<_Float16>((size_t)d.M * d.D);
@@ -628,8 +671,8 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
     GemmArgs g{};
     g.T = d.T; g.Tp = d.Tp; g.D = d.D; g.heads = d.heads; g.M = d.M;
     g.x = w.x; g.q = w.q; g.k = w.k; g.vt = w.vt;
+    g.xh = w.xh; g.stats = w.stats;
     g.xcd_map = g_vit_xcd;
-    const int ln_grid = g_vit_xcd ? 8 * ceil_div(ceil_div(d.M / 32, 8) * 32, 4) : ceil_div(d.M, 4);
     const int att_grid = g_vit_xcd ? 8 * ceil_div(ceil_div(d.M / 32, 8) * d.heads, 4) : ceil_div(d.B * d.heads * (d.Tp / 32), 4);
     // patch embedding (+ cls token + position embedding)
     g.A = reinterpret_cast<const uint4*>(w.a); g.W = f16(SEG_PATCH_W); g.bias = f32(SEG_PATCH_B);
@@ -639,9 +682,8 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
     const int att_work = d.B * d.heads * (d.Tp / 32);
     for (int l = 0; l < d.depth; ++l) {
         const int s0 = SEG_LAYER0 + l * SEGS_PER_LAYER;
-        hipLaunchKernelGGL(vit_layernorm_kernel, dim3(ln_grid), dim3(256), 0, st, w.x, f32(s0 + L_LN1_W), f32(s0 + L_LN1_B),
-                           d.M, d.D, w.a, g_vit_xcd);
-        g.A = reinterpret_cast<const uint4*>(w.a); g.W = f16(s0 + L_QKV_W); g.bias = f32(s0 + L_QKV_B);
+        // LayerNorm 1 is inside this GEMM: raw residual stream x folded weight, statistics applied in the epilogue
+        g.A = reinterpret_cast<const uint4*>(w.xh); g.W = f16(s0 + L_QKV_W); g.bias = f32(s0 + L_QKV_B); g.csum = f32(s0 + L_QKV_C);
         g.N = 3 * d.D; g.KS = d.D / 16;
         if ((rc = launch_gemm<EPI_QKV>(g, st))) return rc;
 #define VIT_ATT(NKT)                                                                                                      \
@@ -661,9 +703,8 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
         g.A = reinterpret_cast<const uint4*>(w.a); g.W = f16(s0 + L_PROJ_W); g.bias = f32(s0 + L_PROJ_B);
         g.gamma = f32(s0 + L_LS1); g.N = d.D; g.KS = d.D / 16;
         if ((rc = launch_gemm<EPI_RESID>(g, st))) return rc;
-        hipLaunchKernelGGL(vit_layernorm_kernel, dim3(ln_grid), dim3(256), 0, st, w.x, f32(s0 + L_LN2_W), f32(s0 + L_LN2_B),
-                           d.M, d.D, w.a, g_vit_xcd);
-        g.A = reinterpret_cast<const uint4*>(w.a); g.W = f16(s0 + L_FC1_W); g.bias = f32(s0 + L_FC1_B);
+        // LayerNorm 2 likewise
+        g.A = reinterpret_cast<const uint4*>(w.xh); g.W = f16(s0 + L_FC1_W); g.bias = f32(s0 + L_FC1_B); g.csum = f32(s0 + L_FC1_C);
         g.N = d.mlp; g.KS = d.D / 16; g.out = w.h;
         if ((rc = launch_gemm<EPI_GELU>(g, st))) return rc;
         g.A = reinterpret_cast<const uint4*>(w.h); g.W = f16(s0 + L_FC2_W); g.bias = f32(s0 + L_FC2_B);

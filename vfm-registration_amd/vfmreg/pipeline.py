@@ -138,6 +138,10 @@ class RegistrationPipeline:
         # stream for free, the fused form adds a memset and the bin atomics to the stream everything waits for
         # (``half_fused``: None = that rule; True / False force VFM_RECORDS_HALF_FUSED / VFM_RECORDS_HALF -- A/B runs)
         self._half_kind = (3 if self.overlap else 4) if half_fused is None else (4 if half_fused else 3)
+        # the fp6 half-width pass: VFM_RECORDS_MX6_HALF_FUSED = 8 (round 4: the coarse kernel lists its survivors itself -- in the LDS,
+        # flushed once per workgroup by plain stores -- and writes no records: no 122 MB record array, no selection sweep) unless
+        # ``half_fused=False`` asks for VFM_RECORDS_MX6_HALF = 7 (records + match_select_half_kernel; A/B runs)
+        self._mx6_half_kind = 7 if half_fused is False else 8
         self.last_rescans: Optional[int] = None
         self.last_probe: Optional[int] = None
         self._since_switch = 0
@@ -256,7 +260,7 @@ class RegistrationPipeline:
         if self.mx6:
             return 6 if self.mx6_top2 else 5   # VFM_RECORDS_MX6_TOP2 / VFM_RECORDS_MX6
         if self.half and self.mx6_half:
-            return 7                           # VFM_RECORDS_MX6_HALF
+            return self._mx6_half_kind         # VFM_RECORDS_MX6_HALF_FUSED (VFM_RECORDS_MX6_HALF on request)
         return self._half_kind if self.half else (1 if self.top2 else 0)   # 4 = VFM_RECORDS_HALF_FUSED (falls back to 3 / 0 inside the library)
 
     def synchronize(self) -> None:
@@ -329,7 +333,7 @@ class RegistrationPipeline:
                 schedule = 1 if (records in (3, 4) or not (self.overlap and self.overlap_prepare)) else 2
                 if self._prep_schedule is not None:
                     schedule = int(self._prep_schedule)
-                if records in (5, 6, 7):
+                if records in (5, 6, 7, 8):
                     schedule |= 8   # VFM_PREPARE_MX6: the fp6 image as well
                 _lib.check(lib.vfm_match_prepare2_gated_p(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
                                                           r.qprep.data_ptr(), self.d, schedule, pst), "prepare(map + scan)")

@@ -178,7 +178,7 @@ class ViTS14:
         mlp = weights["blocks.0.mlp.fc1.weight"].shape[0]
         self.cfg = _lib.VitConfig(dim, depth, dim // 64, mlp, PATCH, PATCH_H, self.patch_w)
         self.dim = dim
-        nseg = 3 + 14 * depth + 4
+        nseg = 3 + 12 * depth + 4
         offs = (C.c_int64 * nseg)()
         sizes = (C.c_int64 * nseg)()
         cnt = lib.vfm_vit_weights_layout(C.byref(self.cfg), offs, sizes, nseg)
@@ -199,13 +199,20 @@ class ViTS14:
         put(1, g("patch_embed.proj.bias"))
         put(2, cls_pos.astype(np.float32))
         i = 3
+        def folded(W, b, gamma, beta):
+            """LayerNorm (gamma, beta) folded into the linear layer (W, b) behind it (csrc/vit.hip, Seg): the fp16 fragment
+            tiles of W diag(gamma), b + W beta, and the row sums of the weight AS ROUNDED (what the GEMM multiplies)."""
+            Wf = (W.astype(np.float64) * gamma.astype(np.float64)[None, :]).astype(np.float32)
+            Wh = Wf.astype(np.float16)
+            return (to_frag_f16(Wf), (b.astype(np.float64) + W.astype(np.float64) @ beta.astype(np.float64)).astype(np.float32),
+                    Wh.astype(np.float64).sum(1).astype(np.float32))
         for l in range(depth):
             p = f"blocks.{l}."
-            for name, frag in (("norm1.weight", 0), ("norm1.bias", 0), ("attn.qkv.weight", 1), ("attn.qkv.bias", 0),
-                               ("attn.proj.weight", 1), ("attn.proj.bias", 0), ("ls1.gamma", 0), ("norm2.weight", 0),
-                               ("norm2.bias", 0), ("mlp.fc1.weight", 1), ("mlp.fc1.bias", 0), ("mlp.fc2.weight", 1),
-                               ("mlp.fc2.bias", 0), ("ls2.gamma", 0)):
-                put(i, to_frag_f16(g(p + name)) if frag else g(p + name))
+            qw, qb, qc = folded(g(p + "attn.qkv.weight"), g(p + "attn.qkv.bias"), g(p + "norm1.weight"), g(p + "norm1.bias"))
+            fw, fb, fc = folded(g(p + "mlp.fc1.weight"), g(p + "mlp.fc1.bias"), g(p + "norm2.weight"), g(p + "norm2.bias"))
+            for arr in (qw, qb, qc, to_frag_f16(g(p + "attn.proj.weight")), g(p + "attn.proj.bias"), g(p + "ls1.gamma"),
+                        fw, fb, fc, to_frag_f16(g(p + "mlp.fc2.weight")), g(p + "mlp.fc2.bias"), g(p + "ls2.gamma")):
+                put(i, arr)
                 i += 1
         for name in ("norm.weight", "norm.bias", "channel_norm.weight", "channel_norm.bias"):
             put(i, g(name))
