@@ -123,6 +123,13 @@ int vfm_match_prepare2_gated(const float *x1, int64_t rows1, void *prepared1, co
  *                            fp6 record kind on it prunes nothing and ends in the exact all-pairs decision -- the oracle's
  *                            answers, orders of magnitude slower -- rather than reading an image that is not there. */
 #define VFM_PREPARE_MX6 8
+/*   VFM_PREPARE_MX6_HALF     flag (implies VFM_PREPARE_MX6): the fp6 image of the FIRST d / 2 COLUMNS only -- the tile prefix the
+ *                            half-width fp6 kinds (VFM_RECORDS_MX6_HALF / _HALF_FUSED) read -- and no int8 half-width image: half the
+ *                            conversions, 73 MB less written at 220 000 rows x 384.  The operand's full-width fp6 bounds are then
+ *                            infinite (a VFM_RECORDS_MX6 / _MX6_TOP2 search on it prunes nothing and ends in the exact decision:
+ *                            correct, slow), and VFM_RECORDS_HALF / _HALF_FUSED / the half-width probe must not be run on it.
+ *                            The half-width kinds bound with the image's residual over the columns they multiply either way. */
+#define VFM_PREPARE_MX6_HALF 16
 int vfm_match_prepare2_gated_p(const float *x1, int64_t rows1, void *prepared1, const float *x2, int64_t rows2,
                                void *prepared2, int d, int schedule, vfm_stream_t stream);
 int vfm_match_search_coarse_gated(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,

@@ -57,6 +57,8 @@ int vfm_debug_i8_rows(const void *prepared, int64_t rows, int d, int8_t *q8_host
  * (code value x block scale), and per row the image's residual norm E (arithmetic slack included) and its group's maximum.
  * Synchronises the device. */
 int vfm_debug_mx6_rows(const void *prepared, int64_t rows, int d, float *v6_host, float *err_host, float *gerr_host);
+/* tests: the same image's residual norm over the first d / 2 columns (the bound of the half-width fp6 kinds) and its group maximum */
+int vfm_debug_mx6_half_err(const void *prepared, int64_t rows, int d, float *errh_host, float *gerrh_host);
 /* A/B: the gated family takes the int8 pass for more than this many query rows (default 0: always) */
 int vfm_debug_set_i8_min_queries(int n);
 /* A/B: 1 = RANSAC scores every hypothesis in fp64 (skips the bounds) */

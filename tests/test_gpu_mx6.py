@@ -18,6 +18,7 @@ RECORDS_MX6 = 5
 RECORDS_MX6_TOP2 = 6
 RECORDS_MX6_HALF = 7
 RECORDS_MX6_HALF_FUSED = 8
+PREPARE_MX6_HALF = 16
 HALF_KINDS = (RECORDS_MX6_HALF, RECORDS_MX6_HALF_FUSED)
 E2M3 = np.array(sorted({(mm / 8 if e == 0 else (1 + mm / 8) * 2 ** (e - 1)) for e in range(4) for mm in range(8)}))
 
@@ -96,6 +97,51 @@ def test_mx6_image_is_the_e2m3_quantisation_of_the_fp16_rows_and_its_residuals_a
         np.testing.assert_array_equal(gerr[::128], gmax)
 
 
+def _mx6_half_err(buf, rows, d):
+    lib = _lib.load()
+    errh, gerrh = np.empty(rows, np.float32), np.empty(rows, np.float32)
+    _lib.check(lib.vfm_debug_mx6_half_err(buf.data_ptr(), rows, d, errh.ctypes.data, gerrh.ctypes.data))
+    return errh, gerrh
+
+
+@pytest.mark.parametrize("d,n,m", [(384, 2500, 9000), (256, 3000, 777), (768, 2300, 1500), (512, 700, 2600)])
+def test_half_width_fp6_image_and_its_bounds(d, n, m):
+    """VFM_PREPARE_MX6_HALF (round 4): only the first d / 2 columns are converted -- those columns of the image equal the definition,
+    the full-width E is infinite (a full-width fp6 search on such an operand prunes nothing), and E over the first d / 2 columns
+    -- what the half-width kinds bound with, also written by a full VFM_PREPARE_MX6 -- is at least the true residual of those
+    columns, the same bits in both forms; the bound holds pair by pair on the half dot products."""
+    rng = np.random.default_rng(d + m + 1)
+    b = _heavy_tailed(rng, m, d)
+    q = b[rng.integers(0, m, n)] + 0.3 * rng.standard_normal((n, d)).astype(np.float32)
+    bd, qd = torch.from_numpy(b).cuda(), torch.from_numpy(q).cuda()
+    qb_full, bb_full = _prepare(bd, qd, PREPARE_MX6)
+    qb, bb = _prepare(bd, qd, PREPARE_MX6 | PREPARE_MX6_HALF)
+    h = d // 2
+    got = {}
+    for name, x, buf, buf_full, rows in (("b", b, bb, bb_full, m), ("q", q, qb, qb_full, n)):
+        xn, _ = orc.l2norm_rows(x)
+        v6, err, gerr = _mx6_rows(buf, rows, d)
+        np.testing.assert_array_equal(v6[:, :h].astype(np.float64), mx6_image(xn)[:, :h])
+        assert np.isinf(err).all() and np.isinf(gerr).all()
+        errh, gerrh = _mx6_half_err(buf, rows, d)
+        errh_full, gerrh_full = _mx6_half_err(buf_full, rows, d)
+        np.testing.assert_array_equal(errh, errh_full)
+        np.testing.assert_array_equal(gerrh, gerrh_full)
+        true = np.linalg.norm(xn[:, :h].astype(np.float64) - v6[:, :h].astype(np.float64), axis=1)
+        assert (errh >= true).all() and (errh <= true * 1.0003 + 1.1e-3).all()
+        gmax = np.array([errh[g:g + 128].max() for g in range(0, rows, 128)])
+        np.testing.assert_array_equal(gerrh[::128], gmax)
+        _, err_full, _ = _mx6_rows(buf_full, rows, d)
+        assert (errh <= err_full).all()            # never looser than the full-width E the pass used before
+        got[name] = (xn, v6, errh)
+    (qn, q6, eq), (bn, b6, eb) = got["q"], got["b"]
+    ii, jj = rng.integers(0, n, 20000), rng.integers(0, m, 20000)
+    exact = np.einsum("ij,ij->i", qn[ii, :h].astype(np.float64), bn[jj, :h].astype(np.float64))
+    coarse = np.einsum("ij,ij->i", q6[ii, :h].astype(np.float64), b6[jj, :h].astype(np.float64))
+    bound = (1.0 + 2.0 ** -13 + eb[jj]) * eq[ii] + (1.0 + 2.0 ** -13) * eb[jj]
+    assert (np.abs(exact - coarse) <= bound).all()
+
+
 def test_mx6_bound_holds_pair_by_pair():
     """| cos(a, b) - image_a . image_b | <= (1 + 2^-13 + E_b) E_a + (1 + 2^-13) E_b for sampled pairs (fp64), and for unit Gaussian
     rows it is the ~0.06 the header states."""
@@ -148,8 +194,9 @@ def test_mx6_pass_gives_the_oracle_answers_and_keeps_the_gate_contract(d, n, m):
         ridx, rsim = orc.match_ip_top1(qn, bn)
         qd, bd = torch.from_numpy(qq).cuda(), torch.from_numpy(bb).cuda()
         for g in (gate, float("-inf")):
-            for records in (RECORDS_MX6, RECORDS_MX6_TOP2) + (HALF_KINDS if g > float("-inf") else ()):
-                idx, sim = _search(qd, bd, g, records)
+            for records, flags in ([(RECORDS_MX6, PREPARE_MX6), (RECORDS_MX6_TOP2, PREPARE_MX6)] +
+                                   ([(k, f) for k in HALF_KINDS for f in (PREPARE_MX6, PREPARE_MX6 | PREPARE_MX6_HALF)] if g > float("-inf") else [])):
+                idx, sim = _search(qd, bd, g, records, flags=flags)
                 solved = _gate_contract(idx, sim, ridx, rsim, g)
                 if g == float("-inf"):
                     assert solved.all(), (name, records)

@@ -85,7 +85,7 @@ def main():
     e_true = np.linalg.norm(bn.astype(np.float64) - v6.astype(np.float64), axis=1)
     print(f"E: measured {err.mean():.5f} mean (numpy {e_true.mean():.5f}); min(err - true) = {(err - e_true).min():.2e} (must be > 0); group max ok: "
           f"{bool((gerr + 1e-9 >= err).all())}")
-    for flags in (0, MX6, 0, MX6):
+    for flags in (0, MX6, MX6 | 16, 0, MX6, MX6 | 16):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         pp = synth.make_pair_device(n, m, d, seed=42)
         prepare(pp["b_desc"], pp["q_desc"], flags)

@@ -153,8 +153,8 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
             // the fp6 image and its bounds (operands prepared with VFM_PREPARE_MX6)
             a.Qh = Q.tiles6;
             a.Bh = B.tiles6;
-            a.ib = mx6_bounds(Q, B, records == VFM_RECORDS_MX6_TOP2 ? 1 : 0);
             const bool fuse6 = records == VFM_RECORDS_MX6_HALF_FUSED;
+            a.ib = (fuse6 || records == VFM_RECORDS_MX6_HALF) ? mx6_bounds_half(Q, B) : mx6_bounds(Q, B, records == VFM_RECORDS_MX6_TOP2 ? 1 : 0);
             return launch_coarse_mx6(a, d, records == VFM_RECORDS_MX6_TOP2, records == VFM_RECORDS_MX6_HALF || fuse6, fuse6, st);
         }
         return launch_coarse_int8(a, d, n, records, st);
@@ -202,7 +202,8 @@ VFM_EXPORT int vfm_match_prepare2_gated_p(const float* x1, int64_t rows1, void* 
                                           void* prepared2, int d, int schedule, vfm_stream_t stream) {
     VFM_CHECK_ARG(rows1 > 0 && rows2 > 0 && d % 128 == 0 && d >= 128 && d <= 768, "prepare2: d must be in {128,256,384,512,640,768}");
     VFM_CHECK_ARG(x1 && x2 && prepared1 && prepared2, "prepare2: null pointer");
-    VFM_CHECK_ARG((schedule & ~VFM_PREPARE_MX6) >= VFM_PREPARE_DEFAULT && (schedule & ~VFM_PREPARE_MX6) <= VFM_PREPARE_INTERLEAVED,
+    VFM_CHECK_ARG((schedule & ~(VFM_PREPARE_MX6 | VFM_PREPARE_MX6_HALF)) >= VFM_PREPARE_DEFAULT &&
+                      (schedule & ~(VFM_PREPARE_MX6 | VFM_PREPARE_MX6_HALF)) <= VFM_PREPARE_INTERLEAVED,
                   "prepare2: unknown schedule %d", schedule);
     const bool want_f16 = !use_i8(d, rows2, rows1, true);
     return do_prepare2(x1, rows1, prepared1, x2, rows2, prepared2, d, (hipStream_t)stream, want_f16, schedule);
@@ -433,6 +434,18 @@ VFM_EXPORT int vfm_debug_mx6_rows(const void* prepared, int64_t rows, int d, flo
         }
         gerr_host[r] = gerr[(size_t)(r / I8_GROUP)];
     }
+    return VFM_OK;
+}
+
+// E of the fp6 image over the first d / 2 columns (what the half-width fp6 kinds bound with) and its group maximum.  Tests only.
+VFM_EXPORT int vfm_debug_mx6_half_err(const void* prepared, int64_t rows, int d, float* errh_host, float* gerrh_host) {
+    VFM_CHECK_ARG(prepared && rows > 0 && mx6_half_width(d) && errh_host && gerrh_host, "mx6_half_err: bad arguments");
+    Prepared p = carve_prepared(const_cast<void*>(prepared), rows, d);
+    std::vector<float> g((size_t)rows_padded(rows) / I8_GROUP);
+    VFM_CHECK_HIP(hipDeviceSynchronize());
+    VFM_CHECK_HIP(hipMemcpy(errh_host, p.err6h, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost));
+    VFM_CHECK_HIP(hipMemcpy(g.data(), p.gerr6h, g.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < rows; ++r) gerrh_host[r] = g[(size_t)(r / I8_GROUP)];
     return VFM_OK;
 }
 

@@ -1826,7 +1826,7 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
             const int half_lds = (size_t)a.nchunks * 12 <= 63 * 1024;  // (step, max E, max |rest|) of every chunk in LDS
             hipLaunchKernelGGL(match_select_half_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * 8), half_lds ? (size_t)a.nchunks * 12 : 0,
                                st, reinterpret_cast<const unsigned*>(w.partials), a.nchunks, n, Q.inv,
-                               mx6half ? mx6_bounds(Q, B) : i8_bounds(Q, B, true, records), (const float*)Q.rest, (const float*)B.grest, gate, half_lds, w.cand_cnt, w.cand, w.cap, w.fb_count,
+                               mx6half ? mx6_bounds_half(Q, B) : i8_bounds(Q, B, true, records), (const float*)Q.rest, (const float*)B.grest, gate, half_lds, w.cand_cnt, w.cand, w.cap, w.fb_count,
                                w.fb_list, g_match_stats, use_bins ? w.bin_cnt : (unsigned*)nullptr, use_bins ? w.bins : (int*)nullptr,
                                w.bin_cap);
         } else if (top2 && g_select_variant != 1) {

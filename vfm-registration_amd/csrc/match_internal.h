@@ -362,6 +362,8 @@ struct Prepared {
     float* err6;      // per row: |v - dequantised row|_2 rounded up, plus the slack of the pass's fp32 / fixed-point arithmetic
     float* gerr6;     // its maximum per group
     float* gstep6;    // MX6_FIX_STEP for every group (the records are fixed-point: I8Bounds needs a step per group)
+    float* err6h;     // per row: the same residual norm over the FIRST d / 2 columns only -- what the half-width pass multiplies
+    float* gerr6h;    // its maximum per group
     size_t bytes;
 };
 
@@ -425,6 +427,7 @@ inline Prepared carve_prepared(void* p, int64_t rows, int d) {
     r.rest = r.grest = nullptr;
     r.tiles6 = nullptr;
     r.err6 = r.gerr6 = r.gstep6 = nullptr;
+    r.err6h = r.gerr6h = nullptr;
     if (i8_capable(d)) {  // behind the fp16 image: the Euclidean path carves the same layout and ignores the rest
         r.err = c.take<float>((size_t)rp);
         r.gstep = c.take<float>((size_t)rp / I8_GROUP);
@@ -440,6 +443,8 @@ inline Prepared carve_prepared(void* p, int64_t rows, int d) {
             r.err6 = c.take<float>((size_t)rp);
             r.gerr6 = c.take<float>((size_t)rp / I8_GROUP);
             r.gstep6 = c.take<float>((size_t)rp / I8_GROUP);
+            r.err6h = c.take<float>((size_t)rp);
+            r.gerr6h = c.take<float>((size_t)rp / I8_GROUP);
         }
     }
     r.bytes = c.used();
@@ -532,6 +537,9 @@ inline I8Bounds i8_bounds(const Prepared& Q, const Prepared& B, bool on, int top
 }
 // bounds of the fp6 records (selection only: the rescans score the int8 image and use i8_bounds)
 inline I8Bounds mx6_bounds(const Prepared& Q, const Prepared& B, int top2 = 0) { return I8Bounds{Q.err6, Q.gstep6, B.gstep6, B.gerr6, top2}; }
+// ... of the half-width fp6 kinds: the residual norms over the columns the pass multiplies (tighter, and all a VFM_PREPARE_MX6_HALF
+// operand carries: its full-width E is infinite)
+inline I8Bounds mx6_bounds_half(const Prepared& Q, const Prepared& B) { return I8Bounds{Q.err6h, Q.gstep6, B.gstep6, B.gerr6h, 0}; }
 CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, int64_t n, int64_t m, int qblock = QBLOCK);
 
 // match_prep.hip

@@ -95,6 +95,10 @@ struct PrepOut {
     float* err6;      // MX6: residual norm of the fp6 image per row (+ MX6_SLACK)
     float* gerr6;     // MX6: its maximum over the group
     float* gstep6;    // MX6: MX6_FIX_STEP
+    float* err6h;     // MX6: residual norm of the fp6 image over the first d / 2 columns (+ MX6_SLACK)
+    float* gerr6h;    // MX6: its maximum over the group
+    int mx6_half;     // MX6: VFM_PREPARE_MX6_HALF -- only the first d / 2 columns are converted (the tile prefix the half-width pass reads), err6 /
+                      // gerr6 are infinite, no int8 half-width image is written
 };
 // MX6: additionally the microscaled fp6 image (OCP MX: e2m3 elements, one power-of-two scale per 32 columns) in fragment tiles
 // of v_mfma_scale_f32_32x32x64_f8f6f4.  Lane l of that MFMA holds, for row l & 31, the 32 columns 64 s + 32 (l >> 5) ... of
@@ -121,7 +125,7 @@ template <bool F16, int NC = 2, bool MX6 = false, int WAVES = 16>
 __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __restrict__ x1, int64_t rows1, int d, PrepOut o1, int groups1,
                                                           const float* __restrict__ x2, int64_t rows2, PrepOut o2, int groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ unsigned amax_bits, emax_bits, rmax_bits, e6max_bits;
+    __shared__ unsigned amax_bits, emax_bits, rmax_bits, e6max_bits, e6hmax_bits;
     static_assert(!(F16 && MX6), "the fp6 image is made from the LDS copy of the fp16 one, which then is not stored");
     constexpr int RPW = I8_GROUP / WAVES;  // rows per wave (8 or 16), all of them in registers between the two phases
     constexpr int NT = WAVES * 64;
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
         emax_bits = 0u;
         rmax_bits = 0u;
         e6max_bits = 0u;
+        e6hmax_bits = 0u;
     }
     // The kernel's registers allow one workgroup per compute unit, so a workgroup walks several groups (grid = compute
     // units) and reads row j of its NEXT group as soon as row j of the current one has been quantised: the read of the next
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
                 // no fp6 image in this form: its E says so -- a search that asks for an fp6 record kind on such an operand bounds
                 // nothing and ends in the exact all-pairs decision (correct, slow) instead of trusting stale bytes
                 if constexpr (!MX6) {
-                    if (o.err6) o.err6[r] = __builtin_inff();
+                    if (o.err6) o.err6[r] = o.err6h[r] = __builtin_inff();
                 }
             }
             {   // (the MX6 form keeps these: VFM_RECORDS_MX6_HALF bounds the second half of the columns with them)
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
                 __builtin_nontemporal_store(tq.w, po + 3);
             }
         }
-        {  // the first d / 2 columns again, as tiles of their own (the first half of every tile's units)
+        if (!(MX6 && o.mx6_half)) {  // the first d / 2 columns again, as tiles of their own (the first half of every tile's units)
             const int uh = (d >> 6) * 64;  // uint4 units per half tile
             uint4* dst = o.tiles8h + (int64_t)grp * (uh * 4);
             const uint4* src = reinterpret_cast<const uint4*>(img8);
@@ -338,8 +343,9 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
         if constexpr (MX6) {
             __syncthreads();   // the int8 tiles have left the LDS: the fp6 image takes their place
             const int nblk = d >> 5;
+            const int nconv = o.mx6_half ? nblk >> 1 : nblk;   // blocks converted: VFM_PREPARE_MX6_HALF stops at column d / 2
             const int tb6 = mx6_tile_bytes(d >> 6);   // (d <= 384 here: one scale plane)
-            for (int item = threadIdx.x; item < I8_GROUP * nblk; item += NT) {
+            for (int item = threadIdx.x; item < I8_GROUP * nconv; item += NT) {
                 const int r = item & (I8_GROUP - 1), blk = item >> 7, t = r >> 5, p = r & 31;
                 // the block's 32 halves: fp16 units (k-step 2 blk + u, half hh) of row p, in column order
                 const uint4* up = reinterpret_cast<const uint4*>(img16 + (size_t)t * (d * 32)) + (4 * blk) * 32 + p;
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
             if (threadIdx.x < 2 * I8_GROUP) {   // the d / 64 scales of MFMA lane (hh, p) of tile t: its 8 bytes of the scale plane
                 const int r = threadIdx.x & (I8_GROUP - 1), hh = threadIdx.x >> 7;
                 unsigned lo = 0u, hi = 0u;
-                for (int s6 = 0; s6 < (d >> 6); ++s6) {
+                for (int s6 = 0; s6 < (nconv >> 1); ++s6) {
                     const unsigned b = scb[r * 16 + 2 * s6 + hh];
                     if (s6 < 4) lo |= b << (8 * s6);
                     else hi |= b << (8 * (s6 - 4));
@@ -392,20 +398,29 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
                 *reinterpret_cast<uint2*>(img6 + (size_t)(r >> 5) * tb6 + mx6_scale_at(d >> 6, 0, hh * 32 + (r & 31))) = make_uint2(lo, hi);
             } else if (threadIdx.x < 3 * I8_GROUP) {   // E of the fp6 image per row: blocks in order; rounded up like the int8 one
                 const int r = threadIdx.x - 2 * I8_GROUP;
-                float acc = 0.0f;
-                for (int blk = 0; blk < nblk; ++blk) acc = acc + e6p[blk * I8_GROUP + r];
+                float acc = 0.0f, acch = 0.0f;
+                for (int blk = 0; blk < nconv; ++blk) {
+                    acc = acc + e6p[blk * I8_GROUP + r];
+                    if (blk + 1 == (nblk >> 1)) acch = acc;   // the first d / 2 columns: the same additions in the same order
+                }
                 float e6n = sqrtf(acc) * 1.000244140625f + (MX6_F16_ROUNDING + MX6_SLACK);
-                if (!(e6n == e6n)) e6n = __builtin_inff();
+                float e6h = sqrtf(acch) * 1.000244140625f + (MX6_F16_ROUNDING + MX6_SLACK);
+                if (!(e6n == e6n) || o.mx6_half) e6n = __builtin_inff();   // (no full-width image in that form: its E says so)
+                if (!(e6h == e6h)) e6h = __builtin_inff();
                 const int64_t row = (int64_t)grp * I8_GROUP + r;
-                if (row >= rows) e6n = 0.0f;
+                if (row >= rows) e6n = e6h = 0.0f;
                 o.err6[row] = e6n;
+                o.err6h[row] = e6h;
                 if (e6n > 0.0f) atomicMax(&e6max_bits, __float_as_uint(e6n));
+                if (e6h > 0.0f) atomicMax(&e6hmax_bits, __float_as_uint(e6h));
             }
             __syncthreads();
-            const int u6n = 4 * tb6 / 16;   // four tiles of the group, in 16-byte units
-            uint4* dst = o.tiles6 + (int64_t)grp * u6n;
+            const int u6t = tb6 / 16;   // a tile in 16-byte units; VFM_PREPARE_MX6_HALF stores the prefix the half-width pass stages
+            const int u6p = o.mx6_half ? (MX6_SCALE_PLANE + (d >> 7) * MX6_KSTEP_BYTES) / 16 : u6t;
+            uint4* dst = o.tiles6 + (int64_t)grp * (4 * u6t);
             const uint4* src = reinterpret_cast<const uint4*>(img6);
-            for (int u = threadIdx.x; u < u6n; u += NT) {
+            for (int uu = threadIdx.x; uu < 4 * u6p; uu += NT) {
+                const int u = (uu / u6p) * u6t + uu % u6p;
                 const uint4 tq = src[u];
                 unsigned* po = reinterpret_cast<unsigned*>(dst + u);
                 __builtin_nontemporal_store(tq.x, po);
@@ -439,10 +454,12 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
             o.grest[grp] = __uint_as_float(rmax_bits);
             if constexpr (MX6) {
                 o.gerr6[grp] = __uint_as_float(e6max_bits);
+                o.gerr6h[grp] = __uint_as_float(e6hmax_bits);
                 o.gstep6[grp] = MX6_FIX_STEP;
                 e6max_bits = 0u;
+                e6hmax_bits = 0u;
             } else if (o.gerr6) {
-                o.gerr6[grp] = __builtin_inff();
+                o.gerr6[grp] = o.gerr6h[grp] = __builtin_inff();
                 o.gstep6[grp] = 0.0f;
             }
             amax_bits = 0u;   // for the next group (read again only behind the next two barriers)
@@ -473,7 +490,8 @@ __global__ __launch_bounds__(256) void prep_mx6_rows_kernel(const float* __restr
     const int64_t r = second ? g - pad1 : g;
     const int64_t rows = second ? rows2 : rows1;
     const PrepOut& o = second ? o2 : o1;
-    const bool active = blk < (d >> 5) && !beyond;
+    const int nblk = d >> 5, nconv = o.mx6_half ? nblk >> 1 : nblk;   // VFM_PREPARE_MX6_HALF: the first d / 2 columns only
+    const bool active = blk < nconv && !beyond;
     // the workgroup's RPB rows come in coalesced (consecutive threads, consecutive float4) and go through the LDS to the thread
     // that owns their block: float4 j of block b at slot 8 b + (j ^ (b & 7)) of its row (the xor keeps the 128-byte-strided
     // reads of a half-wave off one bank group)
@@ -535,13 +553,20 @@ __global__ __launch_bounds__(256) void prep_mx6_rows_kernel(const float* __restr
         e6 = __builtin_fmaf(res, res, e6);
     }
     if (!active) e6 = 0.0f;
+    float e6f = e6, e6hs = blk < (nblk >> 1) ? e6 : 0.0f;   // all converted columns / the first d / 2
 #pragma unroll
-    for (int off = NBLK / 2; off >= 1; off >>= 1) e6 = e6 + __shfl_xor(e6, off);
+    for (int off = NBLK / 2; off >= 1; off >>= 1) {
+        e6f = e6f + __shfl_xor(e6f, off);
+        e6hs = e6hs + __shfl_xor(e6hs, off);
+    }
     if (blk == 0 && !beyond) {
-        float e6n = sqrtf(e6) * 1.000244140625f + (MX6_F16_ROUNDING + MX6_SLACK);
-        if (!(e6n == e6n)) e6n = __builtin_inff();
-        if (r >= rows) e6n = 0.0f;
+        float e6n = sqrtf(e6f) * 1.000244140625f + (MX6_F16_ROUNDING + MX6_SLACK);
+        float e6h = sqrtf(e6hs) * 1.000244140625f + (MX6_F16_ROUNDING + MX6_SLACK);
+        if (!(e6n == e6n) || o.mx6_half) e6n = __builtin_inff();
+        if (!(e6h == e6h)) e6h = __builtin_inff();
+        if (r >= rows) e6n = e6h = 0.0f;
         o.err6[r] = e6n;
+        o.err6h[r] = e6h;
     }
     if (active) {
         const int p = (int)(r & 31), s6 = blk >> 1, l6 = (blk & 1) * 32 + p, ks = d >> 6;
@@ -560,10 +585,15 @@ __global__ __launch_bounds__(256) void prep_mx6_group_kernel(PrepOut o1, int gro
     const int grp = second ? gidx - groups1 : gidx;
     const int lane = lane_id();
     float m = fmaxf(o.err6[(int64_t)grp * I8_GROUP + lane], o.err6[(int64_t)grp * I8_GROUP + 64 + lane]);
+    float mh = fmaxf(o.err6h[(int64_t)grp * I8_GROUP + lane], o.err6h[(int64_t)grp * I8_GROUP + 64 + lane]);
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    for (int off = 32; off >= 1; off >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, off));
+        mh = fmaxf(mh, __shfl_xor(mh, off));
+    }
     if (lane == 0) {
-        o.gerr6[grp] = m;
+        o.gerr6[grp] = o.mx6_half ? __builtin_inff() : m;   // (a group of padding rows only: still "no full-width image")
+        o.gerr6h[grp] = mh;
         o.gstep6[grp] = MX6_FIX_STEP;
     }
 }
@@ -593,8 +623,9 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x,
 
 }  // namespace
 
-inline PrepOut prep_out(const Prepared& p, const int* perm = nullptr) {
-    return PrepOut{p.inv, p.tiles, p.err, p.gstep, p.gerr, p.tiles8, p.tiles8h, p.rest, p.grest, perm, p.tiles6, p.err6, p.gerr6, p.gstep6};
+inline PrepOut prep_out(const Prepared& p, const int* perm = nullptr, int mx6_half = 0) {
+    return PrepOut{p.inv, p.tiles, p.err, p.gstep, p.gerr, p.tiles8, p.tiles8h, p.rest, p.grest, perm, p.tiles6, p.err6, p.gerr6, p.gstep6,
+                   p.err6h, p.gerr6h, mx6_half};
 }
 
 // Workgroups of prep_chunk_kernel (vfm_debug_set_prep_grid): -1 (default) = one per 128-row group; 0 = one per compute unit,
@@ -620,9 +651,11 @@ inline int prep_grid(int groups, int mode) {
 // will meet in an int8 search (use_i8): a third of the bytes written, a third of the LDS.
 int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2, int64_t rows2, void* prepared2, int d,
                 hipStream_t st, bool want_f16, int grid_mode) {
+    const int h6 = (grid_mode & VFM_PREPARE_MX6_HALF) != 0 ? 1 : 0;   // the fp6 image of the first d / 2 columns only (implies VFM_PREPARE_MX6)
+    if (h6) grid_mode |= VFM_PREPARE_MX6;
     const bool want_mx6 = (grid_mode & VFM_PREPARE_MX6) != 0 && mx6_width(d);              // int8 + fp6 image from one kernel
     const bool want_mx6_wide = (grid_mode & VFM_PREPARE_MX6) != 0 && !want_mx6 && mx6_half_width(d);   // d = 512, 768: kernels of their own
-    grid_mode &= ~VFM_PREPARE_MX6;
+    grid_mode &= ~(VFM_PREPARE_MX6 | VFM_PREPARE_MX6_HALF);
     Prepared p1 = carve_prepared(prepared1, rows1, d);
     Prepared p2 = x2 ? carve_prepared(prepared2, rows2, d) : Prepared{};
     const int t1 = (int)(rows_padded(rows1) / TILE_ROWS), t2 = x2 ? (int)(rows_padded(rows2) / TILE_ROWS) : 0;
@@ -644,8 +677,8 @@ int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2
         int pg = prep_grid(groups, grid_mode);
         const dim3 grid((unsigned)pg), block(1024);
         if (want_mx6) {   // int8 + fp6 images from one read of the rows; the fp16 image, if wanted, by its own kernel
-            hipLaunchKernelGGL((prep_chunk_kernel<false, 2, true, 8>), grid, dim3(512), (size_t)I8_GROUP * (d * 3 + d / 8 + 16), st, x1, rows1, d, prep_out(p1), g1,
-                               x2, rows2, prep_out(p2), groups);
+            hipLaunchKernelGGL((prep_chunk_kernel<false, 2, true, 8>), grid, dim3(512), (size_t)I8_GROUP * (d * 3 + d / 8 + 16), st, x1, rows1, d,
+                               prep_out(p1, nullptr, h6), g1, x2, rows2, prep_out(p2, nullptr, h6), groups);
             if (want_f16)
                 hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)(t1 + t2)), dim3(256), (size_t)d * 64, st, x1, rows1, d, p1.inv,
                                    p1.tiles, t1, x2, rows2, p2.inv, p2.tiles);
@@ -669,11 +702,12 @@ int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2
             const int64_t pad1 = rows_padded(rows1), total = pad1 + (x2 ? rows_padded(rows2) : 0);
             if (d == 512)
                 hipLaunchKernelGGL((prep_mx6_rows_kernel<16>), dim3((unsigned)((total + 15) / 16)), dim3(256), (size_t)16 * d * 4, st, x1, rows1, pad1, d,
-                                   prep_out(p1), x2, rows2, prep_out(p2), total);
+                                   prep_out(p1, nullptr, h6), x2, rows2, prep_out(p2, nullptr, h6), total);
             else
                 hipLaunchKernelGGL((prep_mx6_rows_kernel<32>), dim3((unsigned)((total + 7) / 8)), dim3(256), (size_t)8 * d * 4, st, x1, rows1, pad1, d,
-                                   prep_out(p1), x2, rows2, prep_out(p2), total);
-            hipLaunchKernelGGL(prep_mx6_group_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, st, prep_out(p1), g1, prep_out(p2), groups);
+                                   prep_out(p1, nullptr, h6), x2, rows2, prep_out(p2, nullptr, h6), total);
+            hipLaunchKernelGGL(prep_mx6_group_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, st, prep_out(p1, nullptr, h6), g1,
+                               prep_out(p2, nullptr, h6), groups);
             VFM_CHECK_LAUNCH("prep_mx6_rows_kernel");
         }
         return VFM_OK;

@@ -100,6 +100,7 @@ DEBUG_SIGNATURES = {
     "vfm_debug_set_match_stats": (C.c_int, [C.c_int]),
     "vfm_debug_i8_rows": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp, c_vp]),
     "vfm_debug_mx6_rows": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp]),
+    "vfm_debug_mx6_half_err": (C.c_int, [c_vp, c_i64, C.c_int, c_vp, c_vp]),
     "vfm_debug_set_i8_min_queries": (C.c_int, [C.c_int]),
     "vfm_debug_set_vit_gemm": (C.c_int, [C.c_int, C.c_int]),
     "vfm_debug_set_prep_grid": (C.c_int, [C.c_int]),

@@ -333,8 +333,12 @@ class RegistrationPipeline:
                 schedule = 1 if (records in (3, 4) or not (self.overlap and self.overlap_prepare)) else 2
                 if self._prep_schedule is not None:
                     schedule = int(self._prep_schedule)
-                if records in (5, 6, 7, 8):
+                if records in (5, 6):
                     schedule |= 8   # VFM_PREPARE_MX6: the fp6 image as well
+                elif records in (7, 8):
+                    # VFM_PREPARE_MX6_HALF: the half-width pass reads the first d / 2 columns of the fp6 image -- only those are
+                    # converted, and no int8 half-width image is written (the probe that needs it runs outside this mode)
+                    schedule |= 8 | 16
                 _lib.check(lib.vfm_match_prepare2_gated_p(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
                                                           r.qprep.data_ptr(), self.d, schedule, pst), "prepare(map + scan)")
             else:
