@@ -66,3 +66,29 @@ def test_vit_b14_config_c5():
     w = V.random_weights(seed=3, dim=768, depth=4, mlp=3072)
     imgs = _smooth_images(np.random.default_rng(3), 2, 600, 800)
     _check(w, imgs, atol=1e-2, cos_min=0.99999)
+
+
+def test_vit_lds_tiled_gemms_equal_the_direct_kernels_bit_for_bit():
+    """The LDS-staged 128 x 128 workgroup-tile GEMM (round 4: chosen for batches of many images) accumulates every output over the same
+    k order with the same instruction as the direct kernel, so the two forwards are identical bits -- also where the token tiles do
+    not fill the last group of four (5 images x 288 padded tokens = 45 tiles), with the patch embedding's 37 k-steps (not a multiple of
+    the stage), at ViT-S and at a ViT-B-like width; and the forced LDS path passes the oracle tolerance."""
+    from vfmreg import _lib
+    from vfmreg import vit as V
+    lib = _lib.load()
+    try:
+        for (dim, depth, mlp, B, H, W) in ((384, 2, 1536, 5, 560, 700), (768, 1, 3072, 3, 560, 700), (384, 12, 1536, 6, 1200, 1600)):
+            w = V.random_weights(seed=11, dim=dim, depth=depth, mlp=mlp)
+            imgs = torch.from_numpy(_smooth_images(np.random.default_rng(3), B, H, W)).cuda()
+            model = V.ViTS14(w, H, W, device="cuda")
+            lib.vfm_debug_set_vit_gemm(-5, 0)        # never the LDS kernel
+            direct = model.forward(imgs).clone()
+            lib.vfm_debug_set_vit_gemm(-5, 1)        # always (every GEMM whose N is a multiple of 128)
+            tiled = model.forward(imgs).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(direct, tiled), (dim, B, float((direct - tiled).abs().max()))
+        lib.vfm_debug_set_vit_gemm(-5, 1)
+        w = V.random_weights(seed=5, dim=128, depth=2, mlp=256)
+        _check(w, _smooth_images(np.random.default_rng(0), 9, 300, 400), atol=1e-2, cos_min=0.99999)
+    finally:
+        lib.vfm_debug_set_vit_gemm(-5, 256)

@@ -1,4 +1,4 @@
-"""ViT forward only, for rocprofv3: python tools/prof_vit.py [default_tiles=1|0 (0 = round-1 tiles)] [reps]"""
+"""ViT forward only, for rocprofv3: python tools/prof_vit.py [default_tiles=1|0 (0 = round-1 tiles)] [reps] [images] [lds threshold]"""
 import sys
 from pathlib import Path
 
@@ -12,11 +12,15 @@ from vfmreg import vit as V  # noqa: E402
 
 fused = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+nimg = int(sys.argv[3]) if len(sys.argv) > 3 else 6        # images per call
+lds_thr = int(sys.argv[4]) if len(sys.argv) > 4 else -1    # workgroups from which the LDS-tiled GEMM is used (-1: the library's default)
 lib = _lib.load()
 if not fused:
     lib.vfm_debug_set_vit_gemm(108, 208)
+if lds_thr >= 0:
+    lib.vfm_debug_set_vit_gemm(-5, lds_thr)
 rng = np.random.default_rng(0)
-imgs = torch.from_numpy(rng.integers(1, 255, (6, 1200, 1600, 3), dtype=np.uint8)).cuda()
+imgs = torch.from_numpy(rng.integers(1, 255, (nimg, 1200, 1600, 3), dtype=np.uint8)).cuda()
 model = V.ViTS14(V.random_weights(0), 1200, 1600)
 for _ in range(reps):
     out = model.forward(imgs)

@@ -202,7 +202,123 @@ __device__ __forceinline__ bool xcd_item(int mtiles, int ntiles, int wave, int& 
     return mt < mtiles;
 }
 
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact (erf) GELU.  libm's erff is ~40 instructions per element, and the fc1 epilogue evaluates it 52 million times per 96-image
+// forward -- 60 of the kernel's 136 us (round 4 profile).  Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 on erf, i.e. below the
+// fp16 rounding of the value that is stored: 2^-11 relative) takes one reciprocal, one exp2 and seven FMAs.
+__device__ __forceinline__ float gelu_exact(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);   // exp(-z^2); underflows to 0 for large |x|
+    const float erf_abs = __builtin_fmaf(-(p * t), e, 1.0f);                     // erf(|x| / sqrt 2)
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+// NT = 32-channel tiles per wave (2 for the wide GEMMs, 1 for N = dim so that 66 x 12 = 792 waves
+// cover the chip instead of 396).
+// ---- the epilogue of one 32 x 32 output tile (tokens m = mt * 32 + lane % 32, channels n32 * 32 ...), shared by the two GEMM kernels.
+// D layout: column = lane & 31 = token, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) = channel in the tile.
+struct EpiRegs {
+    float4 bias[4], aux[4], x[4];   // aux: row sums of the folded weight (QKV, fc1) / LayerScale (proj, fc2); x: residual values / cls + pos
+};
+template <int EPI>
+__device__ __forceinline__ void epi_load(const GemmArgs& g, int m, int t, int hi, int n32, EpiRegs& e) {
+    constexpr bool CONSUMES_LN = EPI == EPI_QKV || EPI == EPI_GELU;
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+        const int n0 = n32 * 32 + 8 * grp + 4 * hi;
+        e.bias[grp] = *reinterpret_cast<const float4*>(g.bias + n0);
+        e.aux[grp] = make_float4(0.f, 0.f, 0.f, 0.f);
+        e.x[grp] = make_float4(0.f, 0.f, 0.f, 0.f);   // (padding rows t >= T stay exactly zero)
+        if constexpr (CONSUMES_LN) e.aux[grp] = *reinterpret_cast<const float4*>(g.csum + n0);
+        if constexpr (EPI == EPI_RESID) {
+            e.aux[grp] = *reinterpret_cast<const float4*>(g.gamma + n0);
+            if (t < g.T) e.x[grp] = *reinterpret_cast<const float4*>(g.x + (size_t)m * g.D + n0);
+        }
+        if constexpr (EPI == EPI_PATCH) {
+            if (t < g.T) e.x[grp] = *reinterpret_cast<const float4*>(g.clspos + (size_t)t * g.D + n0);   // row 0 = cls + pos[0]
+        }
+    }
+}
+// the token's LayerNorm statistics from the producers' partial sums, slices in ascending order
+__device__ __forceinline__ void ln_stats_load(const GemmArgs& g, int m, float& ln_mean, float& ln_rstd) {
+    const int nsl = g.D / 32;
+    const float4* sp = reinterpret_cast<const float4*>(g.stats + (size_t)m * nsl * 2);   // two slices per float4
+    float4 st[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = (2 * i < nsl) ? sp[i] : make_float4(0.f, 0.f, 0.f, 0.f);   // (D <= 1024: 32 slices)
+    float sx = 0.f, sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        sx += st[i].x; sq += st[i].y;
+        sx += st[i].z; sq += st[i].w;
+    }
+    ln_mean = sx / (float)g.D;
+    const float var = fmaxf(sq / (float)g.D - ln_mean * ln_mean, 0.0f);
+    ln_rstd = rsqrtf(var + 1e-6f);
+}
+template <int EPI>
+__device__ __forceinline__ void epi_tile(const GemmArgs& g, const floatx16& acc, int m, int b, int t, int hi, int n32, const EpiRegs& e,
+                                         float ln_mean, float ln_rstd) {
+    constexpr bool CONSUMES_LN = EPI == EPI_QKV || EPI == EPI_GELU, PRODUCES_LN = EPI == EPI_PATCH || EPI == EPI_RESID;
+    float psum = 0.f, psq = 0.f;   // PRODUCES_LN: this lane's share of the slice's (sum x, sum x^2)
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+        const int n0 = n32 * 32 + 8 * grp + 4 * hi;  // 4 consecutive channels n0..n0+3
+        const float bi[4] = {e.bias[grp].x, e.bias[grp].y, e.bias[grp].z, e.bias[grp].w};
+        const float au[4] = {e.aux[grp].x, e.aux[grp].y, e.aux[grp].z, e.aux[grp].w};
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (CONSUMES_LN) v[j] = ln_rstd * (acc[grp * 4 + j] - ln_mean * au[j]) + bi[j];
+            else v[j] = acc[grp * 4 + j] + bi[j];
+        }
+        if constexpr (PRODUCES_LN) {
+            float4 o = e.x[grp];   // the token's new residual values (padding rows stay exactly zero)
+            float4* xp = reinterpret_cast<float4*>(g.x + (size_t)m * g.D + n0);
+            if constexpr (EPI == EPI_PATCH) {
+                if (t != 0 && t < g.T) o = make_float4(v[0] + o.x, v[1] + o.y, v[2] + o.z, v[3] + o.w);   // (t == 0: cls + pos[0] as loaded)
+                *xp = o;
+            } else if (t < g.T) {
+                o.x = o.x + au[0] * v[0]; o.y = o.y + au[1] * v[1];
+                o.z = o.z + au[2] * v[2]; o.w = o.w + au[3] * v[3];
+                *xp = o;
+            }
+            half4 oh;
+            oh[0] = (_Float16)o.x; oh[1] = (_Float16)o.y; oh[2] = (_Float16)o.z; oh[3] = (_Float16)o.w;
+            *reinterpret_cast<half4*>(g.xh + frag_index(m, n0, g.D / 16)) = oh;
+            psum += (o.x + o.y) + (o.z + o.w);
+            psq += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+        } else if constexpr (EPI == EPI_GELU) {
+            half4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (_Float16)gelu_exact(v[j]);
+            *reinterpret_cast<half4*>(g.out + frag_index(m, n0, g.N / 16)) = o;
+        } else {  // EPI_QKV: channel n0 -> (which, head, d)
+            const int which = n0 / g.D, rem = n0 % g.D, head = rem / 64, dd = rem % 64;
+            const size_t bh = (size_t)b * g.heads + head;
+            if (which < 2) {
+                half4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[j];
+                _Float16* dst = (which == 0 ? g.q : g.k) + bh * (size_t)g.Tp * 64;
+                *reinterpret_cast<half4*>(dst + frag_index(t, dd, 4)) = o;
+            } else {
+                // V^T fragment tiles: rows = d (64), k = key index (Tp); element (d, key = t)
+                _Float16* dst = g.vt + bh * (size_t)g.Tp * 64;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[frag_index(dd + j, t, g.Tp / 16)] = (_Float16)v[j];
+            }
+        }
+    }
+    if constexpr (PRODUCES_LN) {   // the two half-waves hold the slice's other 16 channels of the same token: lower + upper, in that order
+        const float osum = __shfl_xor(psum, 32), osq = __shfl_xor(psq, 32);
+        if (hi == 0) reinterpret_cast<float2*>(g.stats)[(size_t)m * (g.D / 32) + n32] = make_float2(psum + osum, psq + osq);
+    }
+}
 
 // NT = 32-channel tiles per wave (2 for the wide GEMMs, 1 for N = dim so that 66 x 12 = 792 waves
 // cover the chip instead of 396).
@@ -233,6 +349,17 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) rw[j][i] = Wp[((size_t)j * g.KS + i) * 64];
         }
+    const int m = mt * 32 + (lane & 31);
+    const int b = m / g.Tp, t = m % g.Tp;
+    const int hi = lane >> 5;
+    // Everything the epilogue reads is requested HERE, behind the first operand fragments and in front of the k-loop (round 4): as
+    // the epilogue's own loads -- bias, row sums, LayerScale, the residual values, twelve partial sums in a loop the compiler could
+    // not unroll -- they were one more chain of L2 round trips at the end of every kernel of a forward that is nothing but such chains.
+    EpiRegs e[NT];
+#pragma unroll
+    for (int half = 0; half < NT; ++half) epi_load<EPI>(g, m, t, hi, nt * NT + half, e[half]);
+    float ln_mean = 0.f, ln_rstd = 1.f;
+    if constexpr (EPI == EPI_QKV || EPI == EPI_GELU) ln_stats_load(g, m, ln_mean, ln_rstd);
     for (int s0 = 0; s0 < g.KS; s0 += PF) {
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
@@ -250,86 +377,117 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
             }
         }
     }
-    // D layout: column = lane & 31 = token, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel in tile
-    const int m = mt * 32 + (lane & 31);
-    const int b = m / g.Tp, t = m % g.Tp;
-    const int hi = lane >> 5;
-    constexpr bool CONSUMES_LN = EPI == EPI_QKV || EPI == EPI_GELU, PRODUCES_LN = EPI == EPI_PATCH || EPI == EPI_RESID;
-    const int nsl = g.D / 32;   // 32-channel slices of the residual stream
-    float ln_mean = 0.f, ln_rstd = 1.f;
-    if constexpr (CONSUMES_LN) {   // the token's LayerNorm statistics from the producers' partial sums, slices in ascending order
-        const float2* sp = reinterpret_cast<const float2*>(g.stats) + (size_t)m * nsl;
-        float sx = 0.f, sq = 0.f;
-        for (int i = 0; i < nsl; ++i) {
-            const float2 p = sp[i];
-            sx += p.x;
-            sq += p.y;
+#pragma unroll
+    for (int half = 0; half < NT; ++half) epi_tile<EPI>(g, acc[half], m, b, t, hi, nt * NT + half, e[half], ln_mean, ln_rstd);
+}
+
+// ---- the same product with workgroup tiles of 128 tokens x 128 channels staged through the LDS (round 4): for
+// batches of many images.  The direct kernel above moves one A and one W fragment (2 KiB) from the L2 per MFMA -- at 96 images the
+// forward sits at 290 TFLOP/s on ~9 TB/s of L2 traffic --; here a k-step's eight fragments (4 token tiles + 4 channel tiles, 8 KiB)
+// feed the 16 MFMAs of four waves: 0.5 KiB per MFMA.  Four waves, each 64 tokens x 64 channels (2 x 2 MFMA tiles); stages of KB = 4
+// k-steps (32 KiB: 32 LDS-DMA pieces of one (tile, k-step) fragment row each), two stages in the LDS, one barrier per stage: the
+// pieces of stage i + 1 are issued behind the barrier that ends stage i - 1's reads and land under stage i's 16 MFMAs per wave.
+// At one scan (6 images: 17 x 3 workgroups for N = 384) the direct kernel's spread wins; launch_gemm picks by workgroup count.
+template <int N>
+__device__ __forceinline__ void vit_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void vit_glds16(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst_uniform)
+        : "memory");
+}
+// KB k-steps per stage, NS stages in the LDS ring (NS - 1 in flight or in use beside the one being filled): a stage is issued NS - 2
+// stages of MFMAs before it is needed -- an L2 round trip is ~1500 cycles, a stage's MFMAs 128 KB cycles per wave -- and 4 KB x NS KiB
+// of LDS lets several workgroups share a compute unit (KB = 2, NS = 4: 64 KiB, 2 per CU; KB = 2, NS = 3: 48 KiB, 3 per CU).
+template <int EPI, int KB, int NS>
+__global__ __launch_bounds__(256) void vit_gemm_lds_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [stage][A | W][tile][k-step][1 KiB]
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mtiles = g.M / 32, ngroups = g.N / 128, mgroups = (mtiles + 3) / 4;
+    // group of four token tiles mg on XCD mg % 8 (workgroup b runs on XCD b % 8: observed, speed only): the workgroups that share
+    // its A tiles -- one per channel group -- read them through one L2
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int mg = xcd + 8 * (idx / ngroups), ng = idx % ngroups;
+    if (mg >= mgroups) return;
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    constexpr int STAGE = 2 * 4 * KB * 1024;
+    constexpr int PW = 2 * KB;   // pieces per wave and stage: 8 KB fragment rows over 4 waves
+    const int nstages = (g.KS + KB - 1) / KB;
+    // piece p of a stage: operand p / (4 KB) (0 = A, 1 = W), tile (p / KB) % 4, k-step p % KB; wave w issues pieces w, w + 4, ...
+    // (a stage past the end, or a k-step past KS, re-reads the last valid fragment row: the piece count per stage is a constant,
+    // which is what the counted waits below rest on; nothing reads such bytes)
+    auto issue_stage = [&](int stage, int slot) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int p = wave + 4 * i;
+            const int op = p / (4 * KB), tile = (p / KB) & 3;
+            int ks = stage * KB + (p % KB);
+            ks = ks < g.KS ? ks : g.KS - 1;
+            int rowtile = op == 0 ? mg * 4 + tile : ng * 4 + tile;
+            if (op == 0 && rowtile >= mtiles) rowtile = mtiles - 1;   // (a partial last group of token tiles: its epilogue is skipped)
+            const uint4* src = (op == 0 ? g.A : g.W) + ((size_t)rowtile * g.KS + ks) * 64 + lane;
+            vit_glds16(src, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * STAGE + p * 1024)));
         }
-        ln_mean = sx / (float)g.D;
-        const float var = fmaxf(sq / (float)g.D - ln_mean * ln_mean, 0.0f);
-        ln_rstd = rsqrtf(var + 1e-6f);
+    };
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) issue_stage(st, st);   // stages 0 .. NS - 2 (dummies past the end)
+    int slot = 0;
+    for (int stage = 0; stage < nstages; ++stage) {
+        vit_wait_vmcnt<(NS - 2) * PW>();      // this wave's pieces of `stage`: the NS - 2 stages issued since may fly on
+        __builtin_amdgcn_s_barrier();         // everybody's; and everybody has left the slot of stage - 1
+        asm volatile("" ::: "memory");
+        issue_stage(stage + NS - 1, slot == 0 ? NS - 1 : slot - 1);
+        const unsigned char* st = lds + slot * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < KB; ++ks) {
+            if (stage * KB + ks < g.KS) {
+                half8 af[2], wf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = *reinterpret_cast<const half8*>(st + ((2 * wm + i) * KB + ks) * 1024 + lane * 16);
+                    wf[i] = *reinterpret_cast<const half8*>(st + 4 * KB * 1024 + ((2 * wn + i) * KB + ks) * 1024 + lane * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        slot = slot + 1 == NS ? 0 : slot + 1;
     }
+    vit_wait_vmcnt<0>();   // (the dummy stages: no LDS-DMA may be in flight when the workgroup's LDS is handed on)
+    const int hi = lane >> 5;
 #pragma unroll
-    for (int half = 0; half < NT; ++half) {
-        float psum = 0.f, psq = 0.f;   // PRODUCES_LN: this lane's share of the slice's (sum x, sum x^2)
+    for (int i = 0; i < 2; ++i) {
+        const int mt = mg * 4 + 2 * wm + i;
+        if (mt >= mtiles) continue;   // wave-uniform
+        const int m = mt * 32 + (lane & 31);
+        const int b = m / g.Tp, t = m % g.Tp;
+        float ln_mean = 0.f, ln_rstd = 1.f;
+        if constexpr (EPI == EPI_QKV || EPI == EPI_GELU) ln_stats_load(g, m, ln_mean, ln_rstd);
 #pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-            const int n0 = (nt * NT + half) * 32 + 8 * grp + 4 * hi;  // 4 consecutive channels n0..n0+3
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (CONSUMES_LN) v[j] = ln_rstd * (acc[half][grp * 4 + j] - ln_mean * g.csum[n0 + j]) + g.bias[n0 + j];
-                else v[j] = acc[half][grp * 4 + j] + g.bias[n0 + j];
-            }
-            if constexpr (PRODUCES_LN) {
-                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);   // the token's new residual values (padding rows stay exactly zero)
-                float4* xp = reinterpret_cast<float4*>(g.x + (size_t)m * g.D + n0);
-                if constexpr (EPI == EPI_PATCH) {
-                    if (t == 0) {
-                        o = *reinterpret_cast<const float4*>(g.clspos + n0);
-                    } else if (t < g.T) {
-                        const float4 pe = *reinterpret_cast<const float4*>(g.clspos + (size_t)t * g.D + n0);
-                        o = make_float4(v[0] + pe.x, v[1] + pe.y, v[2] + pe.z, v[3] + pe.w);
-                    }
-                    *xp = o;
-                } else if (t < g.T) {
-                    const float4 ga = *reinterpret_cast<const float4*>(g.gamma + n0);
-                    o = *xp;
-                    o.x = o.x + ga.x * v[0]; o.y = o.y + ga.y * v[1];
-                    o.z = o.z + ga.z * v[2]; o.w = o.w + ga.w * v[3];
-                    *xp = o;
-                }
-                half4 oh;
-                oh[0] = (_Float16)o.x; oh[1] = (_Float16)o.y; oh[2] = (_Float16)o.z; oh[3] = (_Float16)o.w;
-                *reinterpret_cast<half4*>(g.xh + frag_index(m, n0, g.D / 16)) = oh;
-                psum += (o.x + o.y) + (o.z + o.w);
-                psq += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
-            } else if constexpr (EPI == EPI_GELU) {
-                half4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (_Float16)gelu_exact(v[j]);
-                *reinterpret_cast<half4*>(g.out + frag_index(m, n0, g.N / 16)) = o;
-            } else {  // EPI_QKV: channel n0 -> (which, head, d)
-                const int which = n0 / g.D, rem = n0 % g.D, head = rem / 64, dd = rem % 64;
-                const size_t bh = (size_t)b * g.heads + head;
-                if (which < 2) {
-                    half4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[j];
-                    _Float16* dst = (which == 0 ? g.q : g.k) + bh * (size_t)g.Tp * 64;
-                    *reinterpret_cast<half4*>(dst + frag_index(t, dd, 4)) = o;
-                } else {
-                    // V^T fragment tiles: rows = d (64), k = key index (Tp); element (d, key = t)
-                    _Float16* dst = g.vt + bh * (size_t)g.Tp * 64;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) dst[frag_index(dd + j, t, g.Tp / 16)] = (_Float16)v[j];
-                }
-            }
-        }
-        if constexpr (PRODUCES_LN) {   // the two half-waves hold the slice's other 16 channels of the same token: lower + upper, in that order
-            const float osum = __shfl_xor(psum, 32), osq = __shfl_xor(psq, 32);
-            if (hi == 0)
-                reinterpret_cast<float2*>(g.stats)[(size_t)m * nsl + (nt * NT + half)] = make_float2(psum + osum, psq + osq);
+        for (int j = 0; j < 2; ++j) {
+            const int n32 = ng * 4 + 2 * wn + j;
+            EpiRegs e;
+            epi_load<EPI>(g, m, t, hi, n32, e);
+            epi_tile<EPI>(g, acc[i][j], m, b, t, hi, n32, e, ln_mean, ln_rstd);
         }
     }
 }
@@ -606,8 +764,38 @@ int launch_gemm_cfg(const GemmArgs& g, hipStream_t st) {
 // ~5 us floor of each of its 87 launches, not by L2 latency or bandwidth: PF = 8 / 16 / 24 make no difference, 32-channel
 // tiles everywhere (twice the waves) give 0.76 instead of 0.82 ms, 64 x 64 wave tiles and row-complete workgroups with the
 // LayerNorm fused into the epilogue (63 launches, but 66 workgroups per GEMM) gave 1.04 ms and were removed again.
+int g_vit_lds_shape = 24;     // vfm_debug_set_vit_gemm(-6, KB * 10 + NS): k-steps per stage / stages in the ring of the LDS-tiled kernel
+int g_vit_lds_min_wg = 256;   // vfm_debug_set_vit_gemm(-5, n): the LDS-tiled kernel from n workgroups of 128 x 128 on (0 = never)
 template <int EPI>
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
+    if (g.N % 128 == 0 && g_vit_lds_min_wg > 0) {
+        const int wgs = ceil_div(g.M / 32, 4) * (g.N / 128);
+        if (wgs >= g_vit_lds_min_wg) {
+            const int grid = 8 * ceil_div(ceil_div(g.M / 32, 4), 8) * (g.N / 128);   // every XCD: ceil(groups / 8) token groups x channel groups
+#define VIT_LDS(KB, NS)                                                                                                              \
+    do {                                                                                                                             \
+        static unsigned long long attr_set = 0ull;                                                                                   \
+        int dev = 0;                                                                                                                 \
+        (void)hipGetDevice(&dev);                                                                                                    \
+        if (!((attr_set >> (dev & 63)) & 1ull)) {                                                                                    \
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_gemm_lds_kernel<EPI, KB, NS>),                      \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, NS * 8 * KB * 1024));                      \
+            attr_set |= 1ull << (dev & 63);                                                                                          \
+        }                                                                                                                            \
+        hipLaunchKernelGGL((vit_gemm_lds_kernel<EPI, KB, NS>), dim3(grid), dim3(256), NS * 8 * KB * 1024, st, g);                    \
+    } while (0)
+            switch (g_vit_lds_shape) {
+                case 42: VIT_LDS(4, 2); break;
+                case 43: VIT_LDS(4, 3); break;
+                case 23: VIT_LDS(2, 3); break;
+                case 26: VIT_LDS(2, 6); break;
+                default: VIT_LDS(2, 4); break;
+            }
+#undef VIT_LDS
+            VFM_CHECK_LAUNCH("vit_gemm_lds_kernel");
+            return VFM_OK;
+        }
+    }
     const int cfg = g.N <= 512 ? g_vit_cfg_narrow : g_vit_cfg_wide;
     switch (cfg) {
         case 116: return launch_gemm_cfg<EPI, 1, 16>(g, st);
@@ -621,6 +809,14 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
 VFM_EXPORT int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg) {
     if (narrow_cfg == -3 || narrow_cfg == -4) {
         g_vit_xcd = narrow_cfg == -3 ? 1 : 0;
+        return VFM_OK;
+    }
+    if (narrow_cfg == -6) {
+        g_vit_lds_shape = wide_cfg;
+        return VFM_OK;
+    }
+    if (narrow_cfg == -5) {   // the LDS-tiled GEMM kernel from wide_cfg workgroups on (0: never; default 256)
+        g_vit_lds_min_wg = wide_cfg;
         return VFM_OK;
     }
     g_vit_cfg_narrow = narrow_cfg ? narrow_cfg : 108;
