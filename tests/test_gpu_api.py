@@ -334,3 +334,102 @@ def test_evaluation_harness_on_a_synthetic_scene(tmp_path):
     for k in ("vfm_ransac", "vfm_ransac_icp"):
         assert ev.rot_errors[k] == ref["rot_errors"][k] and ev.trans_errors[k] == ref["trans_errors"][k], k
     assert ev.error_string().startswith("vfm_ransac\t")
+
+
+def test_ransac_registration_keeps_the_scene_map_between_scans(orc):
+    """RegistrationNode keeps the VoxelHashMap it built for a map array while the caller passes the same array (RN:556-589: one
+    local_map per scene, many scans): the warm call returns the bits of a cold one; another array, or an edit of the array, rebuilds."""
+    from vfmreg import o3d
+    from vfmreg.mapping import VoxelHashMap
+    from vfmreg.registration import RegistrationNode
+    VoxelHashMap.quiet = True
+    voxel_map, raw_scan, p = _scene(n_scan=5000, n_map=24000, seed=21)
+    _, raw_scan2, _ = _scene(n_scan=5000, n_map=24000, seed=21)
+    node, cold = RegistrationNode(ransac_iterations=3000), RegistrationNode(ransac_iterations=3000, cache_map=False)
+    poses = []
+    for nd in (node, node, cold):
+        o3d.utility.random.seed(42)
+        poses.append(nd.ransac_registration(voxel_map, raw_scan, "vfm", run_icp=True))
+    built = node._map_cache[2]
+    assert cold._map_cache is None
+    for a, b in zip(poses[0], poses[1]):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(poses[0], poses[2]):
+        np.testing.assert_array_equal(a, b)
+    ref_pose, ref_icp, _ = orc.ransac_registration_vfm(voxel_map, raw_scan, n_iter=3000, run_icp=True)
+    np.testing.assert_array_equal(poses[1][0], ref_pose)
+    np.testing.assert_array_equal(poses[1][1], ref_icp)
+    node.ransac_registration(voxel_map, raw_scan2, "vfm")
+    assert node._map_cache[2] is built                       # another scan of the scene: the same map object
+    other = voxel_map.copy()
+    node.ransac_registration(other, raw_scan, "vfm")
+    assert node._map_cache[2] is not built                   # another array: rebuilt
+    built2 = node._map_cache[2]
+    other[0, 5] += 1.0                                       # an in-place edit the fingerprint sees (first row)
+    node.ransac_registration(other, raw_scan, "vfm")
+    assert node._map_cache[2] is not built2
+
+
+def test_scene_level_descriptor_builder_equals_the_per_cloud_calls(tmp_path):
+    """prepare_scenes.main's loop over the clouds of a scene (PS:110-171), with the ViT batched over clouds x cameras: every
+    cloud's descriptors are the bits of create_descriptors on that cloud alone, and the scene file read back holds them."""
+    from tests.test_gpu_e2e import _cameras
+    from tests.test_gpu_vit import _smooth_images
+    from vfmreg import vit as V
+    from vfmreg.dataloader import KittiOdometry
+    from vfmreg.evaluation import read_scenes
+    from vfmreg.image_features import ImageFeatureGenerator
+    from vfmreg.prepare_scenes import create_descriptors, create_descriptors_batch, prepare_scene
+
+    rng = np.random.default_rng(23)
+    H, W, ncam, nclouds = 560, 700, 3, 5
+    cams = [f"cam{i}" for i in range(ncam)]
+    Ps = _cameras()[:ncam]
+    for P in Ps:   # the 1600 x 1200 intrinsics of the C3 rig, scaled to the small test images
+        P[0] *= W / 1600.0
+        P[1] *= H / 1200.0
+    all_imgs = _smooth_images(rng, nclouds * ncam + ncam, H, W)
+    clouds = [np.c_[rng.uniform(-40, 40, 3000 + 100 * i), rng.uniform(-40, 40, 3000 + 100 * i), rng.uniform(-2.5, 6, 3000 + 100 * i)]
+              .astype(np.float32) for i in range(nclouds + 1)]
+
+    class Seq:
+        cameras = cams
+        image_subsample = 1
+
+        def __init__(self, name="s", root=None, high_level_api=True):
+            self._k = {c: KittiOdometry({"P2": Ps[i], "Tr_velo_to_cam": np.eye(4)}) for i, c in enumerate(cams)}
+
+        def read_pcl(self, filename=None):
+            return clouds[int(str(filename).rsplit("_", 1)[1])]
+
+        def read_images(self, filenames=None):
+            j = int(str(filenames[0]).rsplit("_", 1)[1])
+            return {c: all_imgs[j * ncam + k] for k, c in enumerate(cams)}
+
+        def project_pcl_to_image(self, pcl, image, camera, _device_inputs=None):
+            return self._k[camera].project_pcl_to_image(pcl, image, "camera", _device_inputs=_device_inputs)
+
+        def projection_params(self, camera, image_shape):
+            return self._k[camera].projection_params("camera", image_shape)
+
+    gen = ImageFeatureGenerator("dinov2", use_featup=False, weights=V.random_weights(seed=3, dim=384, depth=2, mlp=1536))
+    seq = Seq()
+    files = [[f"img_{i}"] for i in range(nclouds)]
+    single = [create_descriptors(files[i], seq, gen, clouds[i]) for i in range(nclouds)]
+    for per_forward in (2, 8):
+        batched = create_descriptors_batch(files, seq, gen, clouds[:nclouds], clouds_per_forward=per_forward)
+        for a, b in zip(single, batched):
+            np.testing.assert_array_equal(a, b)
+    assert all((np.abs(d).sum(1) > 0).sum() > 500 for d in single)
+    scene = {"mapping": {"point_clouds": [f"x/mapseq/cloud_{i}" for i in range(nclouds)], "images": [[f"img_{i}"] for i in range(nclouds)],
+                         "poses": [np.eye(4).tolist()] * nclouds},
+             "registration": [{"point_cloud": f"x/scanseq/cloud_{nclouds}", "images": [f"img_{nclouds}"], "pose": np.eye(4).tolist()}]}
+    out = tmp_path / "scene.h5"
+    sequences, map_poses, map_clouds, seq_poses, seq_clouds = prepare_scene(tmp_path, scene, Seq, gen, date_idx=1, output_filename=out,
+                                                                             voxel_down_sample=lambda p, v: p)
+    assert sequences == ["mapseq", "scanseq"] and len(map_clouds) == nclouds and len(seq_clouds) == 1
+    for i in range(nclouds):
+        np.testing.assert_array_equal(map_clouds[i][:, 3:], single[i])
+    back = read_scenes(out)
+    for a, b in zip(back["map_point_clouds"], map_clouds):
+        np.testing.assert_array_equal(a, b)

@@ -183,3 +183,74 @@ def test_c5_solve_at_full_size():
     assert out["best_hyp"].item() == r.best_hyp
     np.testing.assert_array_equal(T, r.transformation)
     np.testing.assert_array_equal(out["mask"][:k].cpu().numpy(), r.inlier_mask)
+
+
+def test_c3_pipelined_equals_the_stage_by_stage_path_and_the_oracle():
+    """EndToEndPipeline (round 4): the feature stage of pair i + 1 (ViT + projection / lifting on a stream of its own) beside the
+    registration of pair i.  For a sequence of different pairs every output -- lifted descriptors, correspondences, inlier mask,
+    pose, winner -- is bit-equal to model.forward -> LiftPlan -> RegistrationPipeline.register run one after the other, and the
+    solve of a registration equals the oracle's on the same descriptors (as test_c3_end_to_end)."""
+    from oracle import oracle as orc
+    from tests.test_gpu_vit import _smooth_images
+    from vfmreg import ops
+    from vfmreg import vit as V
+    from vfmreg.pipeline import EndToEndPipeline, RegistrationPipeline
+
+    rng = np.random.default_rng(31)
+    n, m, H, W, npairs = 6000, 40000, 560, 700, 7
+    Ps = _cameras()
+    for P in Ps:
+        P[0] *= W / 1600.0
+        P[1] *= H / 1200.0
+    cams = [dict(mode=ops.PROJ_KITTI, mats=[Ps[c]], fc=None, subsample=1.0, win=None, H=H, W=W, rot_mode=0) for c in range(6)]
+    model = V.ViTS14(V.random_weights(seed=4, dim=384, depth=3, mlp=1536), H, W)
+    dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()   # noqa: E731
+    pairs = []
+    for p in range(npairs):
+        imgs = dev(_smooth_images(np.random.default_rng(100 + p), 6, H, W), np.uint8)
+        xyz = np.c_[rng.uniform(-40, 40, n), rng.uniform(-40, 40, n), rng.uniform(-2.5, 6, n)]
+        pairs.append(dict(imgs=imgs, pcl=dev(np.insert(xyz, 3, 1, axis=1).T, np.float64), q_xyz=dev(xyz, np.float64)))
+    # maps: the scan's own lifted descriptors (stage by stage) + noise, planted pose
+    ref = []
+    reg = RegistrationPipeline(n, m, 384, n_iter=5000)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for p in pairs:
+        grids = model.forward(p["imgs"]).clone()
+        desc = torch.empty((n, 384), dtype=torch.float32, device="cuda")
+        filled = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        ops.LiftPlan([dict(c, proj_image=None, grid=grids[k], Hup=H, Wup=W, raw_image=p["imgs"][k]) for k, c in enumerate(cams)], 384)(p["pcl"], desc, filled)
+        b_desc = torch.randn(m, 384, device="cuda", generator=g)
+        pick = torch.randperm(m, device="cuda", generator=g)[:n]
+        b_desc[pick] = desc + 0.05 * desc.abs().mean() * torch.randn(n, 384, device="cuda", generator=g)
+        b_xyz = torch.rand(m, 3, device="cuda", generator=g, dtype=torch.float64) * 100.0
+        b_xyz[pick] = p["q_xyz"] + 0.02 * torch.randn(n, 3, device="cuda", generator=g, dtype=torch.float64)
+        p.update(b_desc=b_desc.contiguous(), b_xyz=b_xyz.contiguous())
+        out = reg.register(desc, p["q_xyz"], p["b_desc"], p["b_xyz"])
+        torch.cuda.synchronize()
+        ref.append({k: out[k].clone() for k in ("T", "count", "corres", "mask", "best_hyp", "idx", "sim")} | {"desc": desc.clone()})
+    e2e = EndToEndPipeline(model, cams, n, m, n_iter=5000, depth=4)
+    snaps = []
+    for p in pairs:                       # back to back: no host synchronisation between the pairs
+        out = e2e.submit(p["imgs"], p["pcl"], p["q_xyz"], p["b_desc"], p["b_xyz"])
+        with torch.cuda.stream(out["result_stream"]):
+            snaps.append({k: out[k].clone() for k in ("T", "count", "corres", "mask", "best_hyp", "desc")})
+    e2e.synchronize()
+    torch.cuda.synchronize()
+    for i, (s, r) in enumerate(zip(snaps, ref)):
+        assert torch.equal(s["desc"], r["desc"]), i
+        c = int(r["count"].item())
+        assert c > 1000 and int(s["count"].item()) == c, i
+        assert torch.equal(s["T"], r["T"]) and torch.equal(s["best_hyp"], r["best_hyp"]), i
+        assert torch.equal(s["corres"][:c], r["corres"][:c]) and torch.equal(s["mask"][:c], r["mask"][:c]), i
+    # the oracle's solve on the GPU-lifted descriptors of one pair (the chain's precision is the subject of test_c3_fp16_vit_...)
+    p, r = pairs[3], ref[3]
+    qn, _ = orc.l2norm_rows(r["desc"].cpu().numpy())
+    bn, _ = orc.l2norm_rows(p["b_desc"].cpu().numpy())
+    idx, sim = orc.match_ip_top1(qn, bn)
+    keep = orc.threshold_compact(sim, 0.8)
+    corres = np.stack([keep, idx[keep]], 1).astype(np.int32)
+    o = orc.ransac_corr(p["q_xyz"].cpu().numpy(), p["b_xyz"].cpu().numpy(), corres, 10000.0, 5000, seed=42)
+    c = int(snaps[3]["count"].item())
+    np.testing.assert_array_equal(snaps[3]["corres"][:c].cpu().numpy(), corres)
+    np.testing.assert_array_equal(snaps[3]["T"].cpu().numpy(), o.transformation)
+    np.testing.assert_array_equal(snaps[3]["mask"][:c].cpu().numpy(), o.inlier_mask)

@@ -45,6 +45,7 @@ class VoxelHashMap:
         self._chunks = {}
         self._ordered = {}      # kind -> (rows, xyz64) in container iteration order (cache)
         self._dev = None        # cached (descriptors fp32, xyz fp64) of the N-D map (IndexFlatIP.add)
+        self._xyz = None        # cached xyz_map() (it carries the ICP grid register_frame builds from it)
 
     @staticmethod
     def _kind(width: int) -> str:
@@ -87,6 +88,8 @@ class VoxelHashMap:
         self._chunks.setdefault(kind, []).append((rows[keep_new], xyz64[keep_new]))
         self._ordered.pop(kind, None)
         self._dev = None
+        self._xyz = None
+        self.__dict__.pop("_icp_grid", None)
 
     def _cloud(self, kind: str):
         """(rows, xyz64) of one of the maps as the reference walks it (VoxelHashMap.cpp:628-676), on the device."""
@@ -106,10 +109,13 @@ class VoxelHashMap:
     def xyz_map(self) -> "VoxelHashMap":
         """The 3-D map ``add_points(points[:, :3])`` would build from the same rows (registration_node.py:290-293 builds
         it next to the N-D one): same voxels, same kept points, same container order -- shared, not recomputed."""
+        if self._xyz is not None:   # (kept: a scene's map serves many scans, and the ICP grid built from it stays with it)
+            return self._xyz
         m = VoxelHashMap(self.voxel_size, self.max_distance, self.max_points_per_voxel)
         m._chunks["3"] = [(x, x) for _, x in self._chunks.get("n", [])]
         if "n" in self._ordered:
             m._ordered["3"] = (self._ordered["n"][1], self._ordered["n"][1])
+        self._xyz = m
         return m
 
     def point_cloud_device(self) -> Optional[torch.Tensor]:

@@ -400,3 +400,71 @@ class RegistrationPipeline:
         return dict(T=r.T, fitness=r.fitness, rmse=r.rmse, best_hyp=r.best_hyp, mask=r.mask, idx=r.idx, sim=r.sim,
                     keep=r.keep, count=r.count, corres=r.corres, done=r.done,
                     result_stream=solve if self.overlap else main)
+
+
+class EndToEndPipeline:
+    """Config C3 as a pipeline (round 4): surround images + scan points in, pose out, over a sequence of
+    independent pairs -- create_descriptors (prepare_scenes.py:50-107) feeding ransac_registration('vfm') (registration_node.py:273-328).
+
+    The feature stage of pair i + 1 -- ViT-S/14 on its cameras (63 dependent launches of 5 - 15 us: latency-bound, a few percent of
+    the chip) and the fused projection + lifting -- runs on a stream of its own beside the registration of pair i, whose coarse pass
+    is one fat MFMA kernel; ``RegistrationPipeline`` overlaps the solve stage of pair i - 1 as before.  ``depth`` buffer sets
+    (images, patch grids, lifted descriptors) rotate; a set is reused only when the registration that read it has finished (its
+    ``done`` event).  Results are those of ``model.forward`` + ``LiftPlan`` + ``RegistrationPipeline.register`` run one after the
+    other (tests/test_gpu_e2e.py)."""
+
+    def __init__(self, model, cams: list, n: int, m: int, n_iter: int = 50000, min_cosine: float = 0.8, max_corr_dist: float = 10000.0,
+                 seed: int = 42, depth: int = 4, coarse: str = "auto", device="cuda"):
+        """``model``: vit.ViTS14 for the rig's image size; ``cams``: the rig, one dict per camera in priority order with the
+        projection parameters of ``ops.LiftPlan`` (mode, mats, fc, subsample, win, H, W, rot_mode) -- image and grid pointers are
+        the pipeline's own."""
+        self.model, self.n = model, n
+        self.device = torch.device(device)
+        d = model.dim
+        B, H, W = len(cams), model.img_h, model.img_w
+        self.reg = RegistrationPipeline(n, m, d, n_iter=n_iter, min_cosine=min_cosine, max_corr_dist=max_corr_dist, seed=seed,
+                                        device=device, overlap_ransac=True, overlap_prepare=True, solve_streams=2, coarse=coarse)
+        self.depth = max(int(depth), len(self.reg.sets) + 1)
+        self.feat_stream = torch.cuda.Stream(device=self.device)
+        self.sets = []
+        for _ in range(self.depth):
+            imgs = torch.empty((B, H, W, 3), dtype=torch.uint8, device=self.device)
+            grids = torch.empty((B, 16, model.patch_w, d), dtype=torch.float32, device=self.device)
+            desc = torch.empty((n, d), dtype=torch.float32, device=self.device)
+            filled = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            pcl = torch.empty((4, n), dtype=torch.float64, device=self.device)
+            plan = ops.LiftPlan([dict(c, proj_image=(imgs[k] if c.get("needs_image") else None), grid=grids[k], Hup=H, Wup=W,
+                                      raw_image=imgs[k]) for k, c in enumerate(cams)], d)
+            self.sets.append(dict(imgs=imgs, grids=grids, desc=desc, filled=filled, pcl=pcl, plan=plan, done=None, ready=None))
+        self._step = 0
+
+    def submit(self, images: torch.Tensor, pcl4xn: torch.Tensor, q_xyz: torch.Tensor, b_desc: torch.Tensor, b_xyz: torch.Tensor,
+               inputs_ready: Optional[torch.cuda.Event] = None, want_mask: bool = True):
+        """Enqueue one pair: ``images`` [cameras, H, W, 3] uint8, ``pcl4xn`` [4, n] fp64 homogeneous scan points (PS:69), ``q_xyz``
+        [n, 3] fp64 the same points for the solve, the map's descriptors and points.  Returns ``RegistrationPipeline.register``'s
+        dict + ``desc`` (the lifted descriptors of this pair's buffer set, valid until ``depth`` further pairs were submitted)."""
+        s = self.sets[self._step % self.depth]
+        self._step += 1
+        fs = self.feat_stream
+        main = torch.cuda.current_stream()
+        if inputs_ready is not None:
+            fs.wait_event(inputs_ready)
+        else:
+            fs.wait_stream(main)
+        if s["done"] is not None:
+            fs.wait_event(s["done"])          # the registration that read this set's descriptors has finished
+        with torch.cuda.stream(fs):
+            s["imgs"].copy_(images, non_blocking=True)
+            s["pcl"].copy_(pcl4xn, non_blocking=True)
+            self.model.forward(s["imgs"], out=s["grids"])
+            s["plan"](s["pcl"], s["desc"], s["filled"])
+            s["ready"] = torch.cuda.Event()
+            s["ready"].record(fs)
+        out = self.reg.register(s["desc"], q_xyz, b_desc, b_xyz, want_mask=want_mask, inputs_ready=s["ready"])
+        s["done"] = out["done"]
+        out = dict(out)
+        out["desc"] = s["desc"]
+        return out
+
+    def synchronize(self) -> None:
+        self.reg.synchronize()

@@ -25,7 +25,9 @@ from .dataloader import NCLT
 _FORCE_PER_CAMERA = False  # tests: run the per-camera path (project -> compact -> gather per camera)
 
 
-def create_descriptors(image_files, sequence, feature_generator, pcl, images=None) -> np.ndarray:
+def create_descriptors(image_files, sequence, feature_generator, pcl, images=None, _grids=None) -> np.ndarray:
+    """``_grids`` (create_descriptors_batch): the cameras' patch features, already computed in a larger batch -- {camera: device
+    tensor [16, pw, C]}."""
     images = images if images is not None else sequence.read_images(filenames=image_files)
     cams = list(images.keys())  # the reference iterates images.items() (PS:70): dict order = camera priority
     dev = "cuda"
@@ -35,7 +37,9 @@ def create_descriptors(image_files, sequence, feature_generator, pcl, images=Non
     pcl_d = torch.from_numpy(np.ascontiguousarray(pcl_h, dtype=np.float64)).to(dev)
     img_d = {c: torch.from_numpy(np.ascontiguousarray(images[c], dtype=np.uint8)).to(dev) for c in cams}
     fused = hasattr(feature_generator, "patch_features_device")
-    if fused:
+    if _grids is not None:
+        grid = _grids
+    elif fused:
         shapes = {tuple(images[c].shape) for c in cams}
         if len(shapes) == 1:
             grids = feature_generator.patch_features_device(torch.stack([img_d[c] for c in cams]))
@@ -81,3 +85,69 @@ def create_descriptors(image_files, sequence, feature_generator, pcl, images=Non
                 continue
         ops.gather_bilinear(grid[c].contiguous(), H, W, 1 if is_nclt else 0, raw, u, v, idx, cnt, desc, filled)
     return desc.cpu().numpy()
+
+
+def create_descriptors_batch(image_files_list, sequence, feature_generator, pcls, images_list=None, clouds_per_forward: int = 8):
+    """``create_descriptors`` for a LIST of clouds of one sequence -- what prepare_scenes.main's loops over ~170 map clouds and the
+    scans of a scene call one cloud at a time (PS:129-163).  The ViT forward is batched over ``clouds_per_forward`` clouds x their
+    cameras (6 x 8 = 48 images per call: 0.33 ms per cloud against 0.70 for one cloud per call, and the wide GEMMs move to the
+    LDS-tiled kernel, csrc/vit.hip); projection and lifting stay per cloud.  A larger batch does not change a single bit of any
+    cloud's features (tests/test_gpu_vit.py, tools/time_vit_batch.py), so every returned array equals ``create_descriptors`` of
+    that cloud.  Falls back to the per-cloud call for generators without ``patch_features_device`` or cameras of mixed sizes."""
+    n_clouds = len(pcls)
+    if images_list is None:
+        images_list = [sequence.read_images(filenames=f) for f in image_files_list]
+    out = [None] * n_clouds
+    shapes = {tuple(np.asarray(im).shape) for images in images_list for im in images.values()}
+    if not hasattr(feature_generator, "patch_features_device") or len(shapes) != 1 or clouds_per_forward <= 1:
+        for i in range(n_clouds):
+            out[i] = create_descriptors(None, sequence, feature_generator, pcls[i], images=images_list[i])
+        return out
+    for i0 in range(0, n_clouds, clouds_per_forward):
+        group = range(i0, min(n_clouds, i0 + clouds_per_forward))
+        keys = [(i, c) for i in group for c in images_list[i].keys()]
+        batch = torch.stack([torch.from_numpy(np.ascontiguousarray(images_list[i][c], dtype=np.uint8)) for i, c in keys]).to("cuda")
+        grids = feature_generator.patch_features_device(batch)
+        per_cloud = {i: {} for i in group}
+        for k, (i, c) in enumerate(keys):
+            per_cloud[i][c] = grids[k]
+        for i in group:
+            out[i] = create_descriptors(None, sequence, feature_generator, pcls[i], images=images_list[i], _grids=per_cloud[i])
+    return out
+
+
+def prepare_scene(dataset_dir, scene_data: dict, Dataset, feature_generator, date_idx: int, output_filename=None,
+                  clouds_per_forward: int = 8, voxel_down_sample=None):
+    """prepare_scenes.main without its argument parsing and progress bars (PS:110-171): the map clouds of a scene (voxelised at
+    0.2 m, PS:134) and its scans (0.1 m, PS:152) with their lifted descriptors, through ``create_descriptors_batch``; written as the
+    reference's HDF5 scene file when ``output_filename`` is given (PS:165-166 -> evaluation.save_scene).  ``Dataset`` is one of
+    the vfmreg.dataloader classes (or anything with ``read_pcl`` / ``read_images`` / projection): reading the dataset's files is
+    the sequence object's business, as in the reference.  Returns (sequences, map_poses, map_clouds, seq_poses, seq_clouds)."""
+    from pathlib import Path
+    from .voxelization import voxel_down_sample as _vds
+    vds = voxel_down_sample or _vds
+    dataset_dir = Path(dataset_dir)
+    sequences = [scene_data["mapping"]["point_clouds"][date_idx].split("/")[1]]                      # PS:122-125
+    for seq in scene_data["registration"]:
+        sequences.append(seq["point_cloud"].split("/")[date_idx])
+    map_sequence = Dataset(sequences[0], dataset_dir, high_level_api=True)                           # PS:128
+    pcls = []
+    for pcl_file in scene_data["mapping"]["point_clouds"]:                                           # PS:131-134
+        pcl = map_sequence.read_pcl(filename=dataset_dir / pcl_file)
+        pcls.append(vds(pcl, 0.2).astype(pcl.dtype))
+    files = [[dataset_dir / f for f in fs] for fs in scene_data["mapping"]["images"]]                # PS:136
+    descs = create_descriptors_batch(files, map_sequence, feature_generator, pcls, clouds_per_forward=clouds_per_forward)
+    map_point_clouds = [np.c_[p, d] for p, d in zip(pcls, descs)]                                    # PS:138
+    map_poses = [np.array(pose) for pose in scene_data["mapping"]["poses"]]                          # PS:143
+    seq_point_clouds, seq_poses = [], []
+    for i, registration in enumerate(scene_data["registration"]):                                    # PS:148-163 (a sequence per scan)
+        registration_sequence = Dataset(sequences[i + 1], dataset_dir, high_level_api=True)
+        pcl = registration_sequence.read_pcl(filename=dataset_dir / registration["point_cloud"])
+        pcl = vds(pcl, 0.1).astype(pcl.dtype)
+        image_files = [dataset_dir / f for f in registration["images"]]
+        seq_point_clouds.append(np.c_[pcl, create_descriptors(image_files, registration_sequence, feature_generator, pcl)])
+        seq_poses.append(np.array(registration["pose"]))
+    if output_filename is not None:
+        from .evaluation import save_scene
+        save_scene(output_filename, sequences, map_poses, map_point_clouds, seq_poses, seq_point_clouds)
+    return sequences, map_poses, map_point_clouds, seq_poses, seq_point_clouds
