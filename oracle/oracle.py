@@ -598,6 +598,99 @@ def register_frame(points: np.ndarray, map_points: np.ndarray, voxel_size: float
     return (T, hist) if return_history else T
 
 
+def _transform_rows(xyz: np.ndarray, T: np.ndarray) -> np.ndarray:
+    out = np.empty_like(xyz)
+    lib().orc_transform_xyz(_p(np.ascontiguousarray(xyz), _f64p), C.c_int64(len(xyz)), _p(np.ascontiguousarray(T, dtype=np.float64), _f64p),
+                            _p(out, _f64p))
+    return out
+
+
+def median_like_the_reference(v: np.ndarray) -> float:
+    """Registration.cpp:297-309: nth_element at n = size / 2; for an even size the mean of that element and the largest of the
+    elements before it -- the two middle order statistics."""
+    s = np.sort(np.asarray(v, dtype=np.float64))
+    n = len(s) // 2
+    return float(s[n]) if len(s) & 1 else float((s[n] + s[n - 1]) / 2)
+
+
+def register_frame_nd(points: np.ndarray, map_points_n: np.ndarray, voxel_size: float, initial_guess: np.ndarray,
+                      max_correspondance_distance: float, kernel: float, min_cosine: float = 0.8, max_iter: int = 1000,
+                      return_history: bool = False):
+    """kiss_icp RegisterFrame(std::vector<VectorNd> ...) (Registration.cpp:197-382), the descriptor-seeded ICP, on an explicit map
+    (``map_points_n``: the rows of VoxelHashMap::PointcloudN(), container order): scan moved by the initial guess (:207-208), 5 m
+    voxel subset (first point per voxel, container order; the whole scan if fewer than 100 survive, :216-220), descriptor
+    correspondences at cosine >= 0.8 (:229-230), Gauss-Newton on those pairs with median + 1.5 MAD pruning until the mean pair
+    distance moves by less than 0.01 (:253-336), then the vanilla point-to-point loop on all points (:347-372, with the iteration
+    counter carried over).  Returns (pose, src_, tgt_) -- the surviving descriptor pairs, the source side moved by every later
+    update (:366) -- and the per-iteration history on request.  Choices where the reference leaves arithmetic open are the 3-D
+    path's (register_frame): 4x4 matrix product for T * point, the fixed-tree normal equations, numpy's solve for LDLT; the
+    vanilla loop stops when no pair is found (the reference prints and solves an empty system: dx = 0, the same exit)."""
+    pts = np.asarray(points, dtype=np.float64)
+    T0 = np.ascontiguousarray(initial_guess, dtype=np.float64)
+    src_xyz = _transform_rows(np.ascontiguousarray(pts[:, :3]), T0)                       # :207-208
+    source = np.c_[src_xyz, pts[:, 3:]]
+    vox = voxel_down_sample(source, 5.0)                                                   # :216
+    if len(vox) < 100:
+        vox = source                                                                       # :217-220
+    src_3d, tgt_3d, _, _, _ = get_vfm_correspondences(vox, np.asarray(map_points_n, dtype=np.float64), min_cosine)   # :229-230
+    src_3d, tgt_3d = np.ascontiguousarray(src_3d[:, :3]), np.ascontiguousarray(tgt_3d[:, :3])
+
+    def dists(a, b):
+        d = a - b
+        return np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+    prev = float(np.sum(dists(src_3d, tgt_3d)) / len(src_3d)) if len(src_3d) else float("nan")   # :233-240 (in-order sum)
+    source_3d = src_xyz
+    T_icp = np.eye(4)
+    hist = []
+    out = np.empty(43, dtype=np.float64)
+    j = 0
+    while j < max_iter:                                                                    # :253
+        if len(src_3d) == 0:
+            break
+        ones = np.ones(len(src_3d), dtype=np.uint8)
+        lib().orc_icp_system(_p(src_3d, _f64p), _p(tgt_3d, _f64p), _p(ones, _u8p), C.c_int64(len(src_3d)), C.c_double(kernel), _p(out, _f64p))
+        dx = np.linalg.solve(out[:36].reshape(6, 6), -out[36:42])
+        est = se3_exp(dx)
+        source_3d = _transform_rows(source_3d, est)                                        # :265-266
+        src_3d = _transform_rows(src_3d, est)
+        T_icp = est @ T_icp
+        d = dists(src_3d, tgt_3d)
+        mean = float(np.add.accumulate(d)[-1] / len(d))                                    # std::accumulate: in order
+        median = median_like_the_reference(d)
+        mad = median_like_the_reference(np.abs(d - median)) * 1.4826                       # :311-322
+        keep = np.abs(d - median) < 1.5 * mad                                              # :326-331
+        hist.append(("vfm", out.copy(), dx.copy(), int(keep.sum())))
+        src_3d, tgt_3d = np.ascontiguousarray(src_3d[keep]), np.ascontiguousarray(tgt_3d[keep])
+        if abs(prev - mean) < 0.01:                                                        # :332-334 (j is not incremented on break)
+            break
+        prev = mean
+        j += 1
+    src_, tgt_ = src_3d, tgt_3d
+    keys, start, mpts = voxel_grid_csr(np.asarray(map_points_n)[:, :3], voxel_size)
+    n = len(source_3d)
+    tgt = np.empty_like(source_3d)
+    valid = np.empty(n, dtype=np.uint8)
+    while j < max_iter:                                                                    # :347
+        lib().orc_icp_nearest(_p(source_3d, _f64p), C.c_int64(n), _p(keys, _i64p), _p(start, _i32p), _p(mpts, _f64p),
+                              C.c_int32(len(keys)), C.c_double(voxel_size), C.c_double(max_correspondance_distance),
+                              _p(tgt, _f64p), _p(valid, _u8p))
+        lib().orc_icp_system(_p(source_3d, _f64p), _p(tgt, _f64p), _p(valid, _u8p), C.c_int64(n), C.c_double(kernel), _p(out, _f64p))
+        if out[42] == 0:
+            break
+        dx = np.linalg.solve(out[:36].reshape(6, 6), -out[36:42])
+        est = se3_exp(dx)
+        source_3d = _transform_rows(source_3d, est)
+        T_icp = est @ T_icp
+        if len(src_):
+            src_ = _transform_rows(src_, est)                                              # :366
+        hist.append(("icp", out.copy(), dx.copy(), int(out[42])))
+        if np.linalg.norm(dx) < 1e-4:
+            break
+        j += 1
+    T = T_icp @ T0
+    return (T, src_, tgt_, hist) if return_history else (T, src_, tgt_)
+
+
 # ----------------------------------------------------------------------------- F4 evaluation harness
 def build_local_map(map_poses, map_point_clouds, voxel_size: float = .25, n_descriptors: int = 384) -> np.ndarray:
     """RN:556-580: rows with descriptor sum <= 0 dropped, every cloud voxelised (container order), moved into the map

@@ -150,3 +150,44 @@ def test_icp_nearest_keeps_the_first_minimum_of_the_reference_scan_on_exact_ties
     # the ties are real: at the cell centres several distinct map points are at the minimum distance
     d = np.linalg.norm(mp[None] - src[:50, None], axis=2)
     assert ((d == d.min(1, keepdims=True)).sum(1) >= 8).all()
+
+
+def test_register_frame_387_columns():
+    """The descriptor-seeded RegisterFrame (Registration.cpp:197-382; register_frame on rows of 3 + 384 columns): 5 m subset ->
+    GetVFMCorrespondences(0.8) -> Gauss-Newton on the descriptor pairs with median + 1.5 MAD pruning -> vanilla ICP, against the
+    oracle's restatement: pose, the surviving pairs (src_ moved by every later update) bit for bit; the pose improves on the guess;
+    the bare call returns the pose only (registration.py:47-66); an empty descriptor map hands the guess back."""
+    from oracle import oracle as orc
+    from vfmreg import synth
+    from vfmreg.config import load_config
+    from vfmreg.icp import register_frame
+    from vfmreg.mapping import VoxelHashMap, get_voxel_hash_map
+    VoxelHashMap.quiet = True
+    cfg = load_config(None, None)
+    sigma = cfg.adaptive_threshold.initial_threshold
+    for seed, n_scan, n_map, shift in ((9, 6000, 30000, 0.4), (10, 900, 12000, 0.15)):   # the second: fewer than 100 voxels of 5 m -> whole scan
+        p = synth.make_pair(n_scan, n_map, 384, seed=seed)
+        voxel_map = np.c_[p["b_xyz"], p["b_desc"]]
+        scan = np.c_[p["q_xyz"], p["q_desc"]]
+        if seed == 10:
+            keep = np.linalg.norm(scan[:, :3] - scan[:, :3].mean(0), axis=1) < 18.0       # a compact scan: few 5 m voxels
+            scan = scan[keep]
+        vhm = get_voxel_hash_map(cfg)
+        vhm.add_points(voxel_map)
+        rng = np.random.default_rng(seed)
+        guess = p["T_gt"].copy()
+        guess[:3, 3] += rng.normal(0, shift, 3)
+        pose, src_, tgt_ = register_frame(scan, vhm, guess, 3 * sigma, sigma / 3, src_=np.zeros((1, 3)), tgt_=np.zeros((1, 3)))
+        ref, rs, rt, hist = orc.register_frame_nd(scan, vhm.point_cloud_n(), cfg.mapping.voxel_size, guess, 3 * sigma, sigma / 3,
+                                                  return_history=True)
+        assert any(h[0] == "vfm" for h in hist) and any(h[0] == "icp" for h in hist)
+        np.testing.assert_array_equal(pose, ref)
+        np.testing.assert_array_equal(src_, rs)
+        np.testing.assert_array_equal(tgt_, rt)
+        assert len(src_) > 10 and np.linalg.norm(pose - p["T_gt"]) < 0.03 < np.linalg.norm(guess - p["T_gt"])
+        only = register_frame(scan, vhm, guess, 3 * sigma, sigma / 3)
+        np.testing.assert_array_equal(only, ref)
+    empty = get_voxel_hash_map(cfg)
+    np.testing.assert_array_equal(register_frame(scan, empty, guess, 6.0, 0.6), guess)
+    with pytest.raises(NotImplementedError):
+        register_frame(scan[:, :200], vhm, guess, 6.0, 0.6)

@@ -158,3 +158,26 @@ def test_icp_oracle_recovers_planted_pose():
     est = orc.register_frame(scan, m, 1.0, np.eye(4), 3.0, 1.0)
     est = est[0] if isinstance(est, tuple) else est
     assert np.linalg.norm(est - T) < 1e-6
+
+
+def test_descriptor_seeded_icp_restatement_recovers_the_planted_pose_and_its_median_is_numpys():
+    """oracle.register_frame_nd (Registration.cpp:197-382): both stages run, the pose ends within millimetres of the planted one from a
+    0.5 m error, the surviving descriptor pairs are a subset of the initial ones moved onto their targets; the reference's
+    nth_element median (the mean of the two middle order statistics for even sizes) is numpy's median."""
+    from oracle import oracle as orc
+    from vfmreg import synth
+    rng = np.random.default_rng(2)
+    for n in (1, 2, 7, 8, 101, 256):
+        v = rng.standard_normal(n)
+        assert orc.median_like_the_reference(v) == float(np.median(v))
+    p = synth.make_pair(3000, 15000, 384, seed=9)
+    vm = np.c_[p["b_xyz"], p["b_desc"]]
+    mp = vm[orc.voxel_hash_map_points(vm, 1.0, 20)]
+    scan = np.c_[p["q_xyz"], p["q_desc"]]
+    guess = p["T_gt"].copy()
+    guess[:3, 3] += 0.3
+    T, s, t, hist = orc.register_frame_nd(scan, mp, 1.0, guess, 6.0, 2 / 3, return_history=True)
+    kinds = [h[0] for h in hist]
+    assert "vfm" in kinds and "icp" in kinds and kinds == sorted(kinds, key=lambda k: k != "vfm")   # the VFM stage first
+    assert np.linalg.norm(T - p["T_gt"]) < 5e-3 < np.linalg.norm(guess - p["T_gt"])
+    assert len(s) == len(t) > 100 and np.linalg.norm(s - t, axis=1).max() < 0.2
