@@ -192,7 +192,7 @@ def extra_configs(dev):
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         res = None
-        for steps_e2e in (8, 40):                                     # settle the policy / warm up, then the timed run
+        for steps_e2e in (8, 60):                                     # settle the policy / warm up, then the timed run
             gc.collect()
             gc.disable()
             torch.cuda.synchronize()

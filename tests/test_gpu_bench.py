@@ -38,7 +38,7 @@ def test_bench_plain_small_run():
     # one pipelined warm-up step is enough: the auto policy has settled (on the half-width pass, D.2 data) before the timed region
     assert d["config"]["policy_settle_registrations"] == 6 and "half-width" in d["config"]["coarse_pass"]
     # the kernel the line reports is the kernel the C2 parity test compares with the oracle
-    from test_gpu_bench_config import BENCH_RECORDS_KIND
+    from tests.test_gpu_bench_config import BENCH_RECORDS_KIND
     assert d["config"]["records_kind"] == BENCH_RECORDS_KIND, d["config"]["records_kind"]
 
 

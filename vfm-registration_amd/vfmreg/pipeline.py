@@ -402,6 +402,21 @@ class RegistrationPipeline:
                     result_stream=solve if self.overlap else main)
 
 
+def masked_stream(ncu: int, offset: int = 0, total: int = 256) -> "torch.cuda.Stream":
+    """A HIP stream whose kernels may use ``ncu`` of the ``total`` compute units (hipExtStreamCreateWithCUMask, mask bits
+    offset .. offset + ncu - 1), as a torch stream."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")   # (the runtime torch has loaded)
+    words = (C.c_uint32 * (total // 32))()
+    for i in range(offset, offset + ncu):
+        words[(i % total) // 32] |= 1 << (i % 32)
+    st = C.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), total // 32, words)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(st.value)
+
+
 class EndToEndPipeline:
     """Config C3 as a pipeline (round 4): surround images + scan points in, pose out, over a sequence of
     independent pairs -- create_descriptors (prepare_scenes.py:50-107) feeding ransac_registration('vfm') (registration_node.py:273-328).
@@ -414,7 +429,7 @@ class EndToEndPipeline:
     other (tests/test_gpu_e2e.py)."""
 
     def __init__(self, model, cams: list, n: int, m: int, n_iter: int = 50000, min_cosine: float = 0.8, max_corr_dist: float = 10000.0,
-                 seed: int = 42, depth: int = 4, coarse: str = "auto", device="cuda"):
+                 seed: int = 42, depth: int = 4, coarse: str = "auto", device="cuda", feature_cus: int = 0):
         """``model``: vit.ViTS14 for the rig's image size; ``cams``: the rig, one dict per camera in priority order with the
         projection parameters of ``ops.LiftPlan`` (mode, mats, fc, subsample, win, H, W, rot_mode) -- image and grid pointers are
         the pipeline's own."""
@@ -425,7 +440,18 @@ class EndToEndPipeline:
         self.reg = RegistrationPipeline(n, m, d, n_iter=n_iter, min_cosine=min_cosine, max_corr_dist=max_corr_dist, seed=seed,
                                         device=device, overlap_ransac=True, overlap_prepare=True, solve_streams=2, coarse=coarse)
         self.depth = max(int(depth), len(self.reg.sets) + 1)
-        self.feat_stream = torch.cuda.Stream(device=self.device)
+        # ``feature_cus`` > 0: the feature stage on a stream restricted to that many compute units and the registration's main stream
+        # (operand preparation hand-off + coarse pass) on the others.  A coarse workgroup owns its compute unit (8 waves x ~200
+        # registers), so beside an unrestricted coarse kernel each of the ViT's 63 dependent launches waits for coarse workgroups to
+        # end before it gets a compute unit at all; with a few units of its own the latency-bound forward runs at its own pace.
+        self.feature_cus = int(feature_cus)
+        if self.feature_cus > 0:
+            ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+            self.feat_stream = masked_stream(self.feature_cus, 0, ncu)
+            self.reg_stream = masked_stream(ncu - self.feature_cus, self.feature_cus, ncu)
+        else:
+            self.feat_stream = torch.cuda.Stream(device=self.device)
+            self.reg_stream = None
         self.sets = []
         for _ in range(self.depth):
             imgs = torch.empty((B, H, W, 3), dtype=torch.uint8, device=self.device)
@@ -460,11 +486,22 @@ class EndToEndPipeline:
             s["plan"](s["pcl"], s["desc"], s["filled"])
             s["ready"] = torch.cuda.Event()
             s["ready"].record(fs)
-        out = self.reg.register(s["desc"], q_xyz, b_desc, b_xyz, want_mask=want_mask, inputs_ready=s["ready"])
+        if self.reg_stream is not None:
+            self.reg_stream.wait_stream(main)
+            with torch.cuda.stream(self.reg_stream):
+                out = self.reg.register(s["desc"], q_xyz, b_desc, b_xyz, want_mask=want_mask, inputs_ready=s["ready"])
+        else:
+            out = self.reg.register(s["desc"], q_xyz, b_desc, b_xyz, want_mask=want_mask, inputs_ready=s["ready"])
         s["done"] = out["done"]
         out = dict(out)
         out["desc"] = s["desc"]
         return out
 
     def synchronize(self) -> None:
-        self.reg.synchronize()
+        """Make the caller's current stream wait for everything submitted."""
+        if self.reg_stream is not None:
+            with torch.cuda.stream(self.reg_stream):
+                self.reg.synchronize()
+            torch.cuda.current_stream().wait_stream(self.reg_stream)
+        else:
+            self.reg.synchronize()
