@@ -499,7 +499,7 @@ int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, bool half, bool fuse, hip
         // the half-width kernel's workgroups are short, and shorter ones let the other stages of a pipeline in: ~7.5 rounds of 256
         // workgroups instead of choose_slices' 5 (tools/sweep_slices.py, C2, 200 steps: 48 slices 1548 against 32 slices 1475
         // registrations/s; the full-width fp6 kernel and the int8 kernels are flat from 32 on)
-        int s = (int)((1920 + a.nqb - 1) / a.nqb);
+        int s = (int)((1600 + a.nqb - 1) / a.nqb);   // (round 4, tools/sweep_slices_r4.py, fused kernel: 40 / 44 slices 1764 / 1762, 48: 1740, 57: 1690 registrations/s over 200 steps)
         const int smax = a.nchunks / 8 < 64 ? a.nchunks / 8 : 64;
         s = s > smax ? smax : s;
         a.nslices = s < 1 ? 1 : s;
