@@ -23,6 +23,7 @@ cd $R
 timeout 600 python tools/dev_mx6.py > $O/dev_mx6.txt 2>&1; tail -8 $O/dev_mx6.txt
 timeout 900 python tools/ab_r4.py > $O/ab_r4.txt 2>&1; tail -12 $O/ab_r4.txt
 timeout 600 python tools/soak_mx6.py 40 303 2>&1 | tail -3 > $O/soak_mx6.txt; cat $O/soak_mx6.txt
+timeout 600 python tools/sweep_slices_r4.py > $O/sweep_slices.txt 2>&1
 { bash tools/trace_pipe.sh mx6-half 2>&1 | tail -40; } > $O/pipeline_cycle.txt
 # ViT: one scan and batches, kernel by kernel
 timeout 600 python tools/time_vit_batch.py > $O/time_vit_batch.txt 2>&1; tail -12 $O/time_vit_batch.txt
@@ -35,5 +36,5 @@ timeout 600 python tools/time_c3_pipe.py 0 > $O/time_c3_pipe.txt 2>&1; tail -6 $
 timeout 300 python tools/time_pairs.py 6 > $O/time_pairs.txt 2>&1
 timeout 300 python tools/time_c3_modes.py 2>/dev/null | tail -6 > $O/time_c3_modes.txt
 # duplicate-rich maps through the bench's pipeline (policy by feedback and every mode forced)
-timeout 900 python tools/time_neardup.py --steps 20 --out $O/neardup.json > $O/neardup.log 2>&1
+timeout 1200 python tools/time_neardup.py --steps 20 --modes auto,mx6-half,int8-half,int8,mx6 --out $O/neardup.json > $O/neardup.log 2>&1
 timeout 900 python tools/soak_half.py 40 303 2>&1 | tail -3 > $O/soak_half.txt; cat $O/soak_half.txt
