@@ -223,6 +223,16 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
     int vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     float2 tab = make_float2(0.f, 0.f);                     // ltab entry of the chunk emit_chunk sees next (read a chunk ahead)
+    float thr[2] = {__builtin_inff(), __builtin_inff()};    // FUSE: the score from which that chunk survives for the lane's query
+    // (from `tab`, in the last tile of the step in front of the emit: the emit itself -- both waves of a SIMD reach it together, a
+    // barrier earlier they were released together -- then holds no chain of dependent VALU results in front of its branch)
+    auto next_thr = [&]() __attribute__((always_inline)) {
+        if constexpr (FUSE) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) thr[j] = ((a.gate - 1.0e-6f) - (fx_A[j] + fx_mult[j] * tab.x)) - (fx_rq[j] * tab.y + 1.0e-6f);
+            asm volatile("" ::"v"(thr[0]), "v"(thr[1]));
+        }
+    };
     auto emit_chunk = [&](int ci) __attribute__((always_inline)) {  // ci = chunk of the unit, < 0: nothing folded yet
         const bool valid = ci >= 0;                         // wave-uniform
         const int chunk = c0 + ci;
@@ -233,11 +243,12 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
             // 2^-20 grid, which MX6_SLACK pays for either way).  Each half-wave tests the maximum of ITS 64 rows and the two halves
             // meet as scalar masks: no cross-lane exchange, no per-lane branch (the ablations put the first form of this emit -- swap,
             // compare, exec-masked branch per query set -- at 10 % of the kernel).  m = queries of the set with a surviving chunk.
+            // The thresholds are there already (next_thr, a tile earlier): what is left behind the fold is two compares, the scalar masks
+            // and one branch, issued behind the first MFMAs of the tile this runs in.
             unsigned m[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const float thr = ((a.gate - 1.0e-6f) - (fx_A[j] + fx_mult[j] * tab.x)) - (fx_rq[j] * tab.y + 1.0e-6f);
-                const unsigned long long hit = __ballot(!(s1[j] < thr));
+                const unsigned long long hit = __ballot(!(s1[j] < thr[j]));
                 m[j] = ((unsigned)hit | (unsigned)(hit >> 32)) & livemask[j];
                 s1[j] = -__builtin_inff();
             }
@@ -343,6 +354,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
         const bool more = it + (RING - 1) * T < ntiles;                 // step k + RING - 1 exists: this step's window issues it
         const bool more_prev = it >= T && it + (RING - 2) * T < ntiles; // the window that opened in step k - 1 (it closes at this barrier) issues
         const bool lax = it + (RING - 2) * T < ntiles;                  // step k + RING - 2 was issued (by that window; the pre-loop, for k = 0)
+        const int ck = it >> 2;   // first chunk of the step (of the unit)
         // tile J of the step into `acc`, folding `done` (the tile before it)
         auto tile = [&](auto Jc, floatx16 (&acc)[2], const floatx16 (&done)[2]) __attribute__((always_inline)) {
             constexpr int J = decltype(Jc)::value;
@@ -372,6 +384,18 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
 #else
                 asm volatile("" : "+v"(fr[s % PF].c[0]));   // (the fragment "changes": the MFMAs are not loop-invariant to the compiler)
 #endif
+#ifndef VFM_ABL_NOEMIT
+                // The chunk that ended with the previous tile's slots is emitted HERE -- behind the first two MFMAs of the second tile of
+                // the next chunk, in front of this slot's folds (which start that chunk's maxima) --, not between two tiles: the matrix
+                // pipe has 64 cycles of work while the compares, the scalar masks and the branch resolve.  (Between the tiles it was a
+                // hole in every wave of the workgroup at the same time: 10 % of the kernel in tools/ablate6.py's timings.)
+                if constexpr (s == 0 && (J & 3) == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    emit_chunk(ck + (J >> 2) - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
+                if constexpr (s == 0 && (J & 3) == 3) next_thr();
 #ifndef VFM_ABL_NOFOLD
 #pragma unroll
                 for (int e = s * 32 / KS6; e < (s + 1) * 32 / KS6; ++e) {   // `done` is tile (J + 3) & 3 of its chunk
@@ -409,19 +433,12 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
             // register allocator handed it out again right behind the ds_read_b64, and the wave waited on lgkmcnt(0) to overwrite it)
             asm volatile("" ::"v"(sc_nxt.x), "v"(sc_nxt.y));
         };
-        const int ck = it >> 2;   // first chunk of the step (of the unit)
-        tile(std::integral_constant<int, 0>{}, accA, accB);
-#ifndef VFM_ABL_NOEMIT
-        emit_chunk(ck - 1);  // tile 0's slots folded the last tile of the previous chunk
-#endif
+        tile(std::integral_constant<int, 0>{}, accA, accB);   // (its slots fold the last tile of the previous chunk; tile 1 emits that chunk)
         tile(std::integral_constant<int, 1>{}, accB, accA);
         tile(std::integral_constant<int, 2>{}, accA, accB);
         if constexpr (T == 8) {
             tile(std::integral_constant<int, 3>{}, accB, accA);
             tile(std::integral_constant<int, 4>{}, accA, accB);
-#ifndef VFM_ABL_NOEMIT
-            emit_chunk(ck);
-#endif
             tile(std::integral_constant<int, 5>{}, accB, accA);
             tile(std::integral_constant<int, 6>{}, accA, accB);
         }
@@ -446,6 +463,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
         if constexpr (TOP2) coarse_fold(t1[e >> 4], t2[e >> 4], accB[e >> 4][e & 15], 3 * 16 + (e & 15));
         else s1[e >> 4] = fmaxf(s1[e >> 4], accB[e >> 4][e & 15]);
     }
+    next_thr();
     emit_chunk(nch - 1);
     if constexpr (LOW) {
 #pragma unroll

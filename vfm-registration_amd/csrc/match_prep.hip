@@ -160,7 +160,12 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef VFM_PABL_NOLOAD   // (timing experiments, tools/ablate_prep.py: results are garbage)
+            if (r < rows && c < nchunks) t = make_float4(0.01f * (float)(c & 15), 0.5f, -0.25f, 1.0f);
+            if (false) {
+#else
             if (r < rows && c < nchunks) {
+#endif
                 const float* pc = x + rsrc * (int64_t)d + 4 * c;
                 t.x = __builtin_nontemporal_load(pc);
                 t.y = __builtin_nontemporal_load(pc + 1);
@@ -252,7 +257,11 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
                 const int c = lane + 64 * i;
+#ifdef VFM_PABL_NOP2
+                if (c < nchunks && v[j][i].x == 12345.0f) {
+#else
                 if (c < nchunks) {
+#endif
                     const float nv[4] = {v[j][i].x, v[j][i].y, v[j][i].z, v[j][i].w};
                     if (8 * c >= d) r2 = r2 + (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] + nv[3] * nv[3]);  // columns >= d / 2
                     int qi[4];
@@ -317,7 +326,11 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
             const int u8n = (d >> 5) * 64 * 4;  // uint4 units of the group's four int8 tiles
             uint4* dst = o.tiles8 + (int64_t)grp * u8n;
             const uint4* src = reinterpret_cast<const uint4*>(img8);
+#ifdef VFM_PABL_NOST8
+            for (int u = threadIdx.x; u < u8n && d < 0; u += NT) {
+#else
             for (int u = threadIdx.x; u < u8n; u += NT) {
+#endif
                 const uint4 tq = src[u];
                 unsigned* po = reinterpret_cast<unsigned*>(dst + u);
                 __builtin_nontemporal_store(tq.x, po);
@@ -340,10 +353,18 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
                 __builtin_nontemporal_store(tq.w, po + 3);
             }
         }
+#ifdef VFM_PABL_NOMX6
+        if constexpr (false) {
+#else
         if constexpr (MX6) {
+#endif
             __syncthreads();   // the int8 tiles have left the LDS: the fp6 image takes their place
             const int nblk = d >> 5;
+#ifdef VFM_PABL_NOCONV
+            const int nconv = 0;
+#else
             const int nconv = o.mx6_half ? nblk >> 1 : nblk;   // blocks converted: VFM_PREPARE_MX6_HALF stops at column d / 2
+#endif
             const int tb6 = mx6_tile_bytes(d >> 6);   // (d <= 384 here: one scale plane)
             for (int item = threadIdx.x; item < I8_GROUP * nconv; item += NT) {
                 const int r = item & (I8_GROUP - 1), blk = item >> 7, t = r >> 5, p = r & 31;
@@ -419,7 +440,11 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
             const int u6p = o.mx6_half ? (MX6_SCALE_PLANE + (d >> 7) * MX6_KSTEP_BYTES) / 16 : u6t;
             uint4* dst = o.tiles6 + (int64_t)grp * (4 * u6t);
             const uint4* src = reinterpret_cast<const uint4*>(img6);
+#ifdef VFM_PABL_NOST6
+            for (int uu = threadIdx.x; uu < 4 * u6p && d < 0; uu += NT) {
+#else
             for (int uu = threadIdx.x; uu < 4 * u6p; uu += NT) {
+#endif
                 const int u = (uu / u6p) * u6t + uu % u6p;
                 const uint4 tq = src[u];
                 unsigned* po = reinterpret_cast<unsigned*>(dst + u);
