@@ -412,3 +412,37 @@ def test_finish_stage_staging_buffers_overflow_into_the_direct_paths(records):
             if g == float("-inf"):
                 assert solved.all(), name
             assert solved[rsim >= 0.8].all(), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,n,m,flags", [(384, 3000, 9001, PREPARE_MX6), (384, 3000, 9001, PREPARE_MX6 | PREPARE_MX6_HALF),
+                                         (256, 1234, 5000, PREPARE_MX6), (256, 129, 5000, PREPARE_MX6 | PREPARE_MX6_HALF),
+                                         (384, 1, 127, PREPARE_MX6 | PREPARE_MX6_HALF)])
+def test_the_two_forms_of_the_fp6_preparation_write_the_same_bytes(d, n, m, flags):
+    """prep_stream_kernel (two passes over the rows, 4 waves: the default, fits beside a coarse workgroup) against prep_chunk_kernel
+    (rows in registers): every image, every E, every group figure byte for byte -- ragged sizes, a zero row, a row with a NaN, a row
+    of huge magnitude."""
+    lib = _lib.load()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(d + n + m + flags)
+    q = torch.randn((n, d), generator=g, device="cuda")
+    b = torch.randn((m, d), generator=g, device="cuda")
+    b[m // 2] = 0.0
+    b[m // 3, 5] = float("nan")
+    b[m // 4] *= 1e30
+    q[0, : d // 2] *= 1e-3
+    st = torch.cuda.current_stream().cuda_stream
+    out = []
+    try:
+        for variant in (40, 41):
+            lib.vfm_debug_set_coarse_variant(variant)
+            qb = torch.zeros(lib.vfm_match_prepared_bytes(n, d), dtype=torch.uint8, device="cuda")
+            bb = torch.zeros(lib.vfm_match_prepared_bytes(m, d), dtype=torch.uint8, device="cuda")
+            _lib.check(lib.vfm_match_prepare2_gated_p(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, flags, st))
+            torch.cuda.synchronize()
+            out.append((qb, bb))
+    finally:
+        lib.vfm_debug_set_coarse_variant(41)
+    for k, name in ((0, "scan"), (1, "map")):
+        diff = torch.nonzero(out[0][k] != out[1][k]).flatten()
+        assert diff.numel() == 0, f"{name}: {diff.numel()} bytes differ, first at {diff[:8].tolist()}, last at {int(diff[-1])} of {out[0][k].numel()}"
