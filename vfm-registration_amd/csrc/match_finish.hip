@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
                                                                  int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
                                                                  const unsigned* __restrict__ bin_cnt, const int* __restrict__ bins,
                                                                  int use_gate, float gate, const int* __restrict__ guard, L2Terms l2,
-                                                                 int bin_cap, unsigned* __restrict__ hit_cnt) {
+                                                                 int bin_cap, unsigned* __restrict__ hit_cnt, float* __restrict__ cand_up) {
     // A ring of D slots, one per block of 32 queries: [KS][64] uint4 = the block's queries as ONE MFMA operand image (unit u =
     // (k-step s, half h, column p) comes from query bin[j0 + p]), then [3][64] dwords of per-query terms.  Everything a block needs
     // from global memory arrives by LDS-DMA issued D - 1 blocks ahead (wave w gathers k-steps w, w + 4, ...: its 64 lanes' units
@@ -696,6 +696,7 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
     // for all of them at once behind the loop.
     __shared__ int lhq[RESCAN_LHITS];
     __shared__ unsigned char lhr[RESCAN_LHITS];
+    __shared__ float lhu[RESCAN_LHITS];   // the row's upper bound (cand_up)
     __shared__ int lhit_n;
     const int c = blockIdx.x;
     if (guard && *guard) return;   // half-width pass, too many survivors: match_gatepass_kernel has decided every query
@@ -786,12 +787,18 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
                 const int e = __ffs(hits) - 1;
                 hits &= hits - 1u;
                 const int rr = rr0 + (e & 3) + 8 * (e >> 2);
+                // (a Euclidean search's bound is not symmetric about the score: its rows are never filtered -- +Inf)
+                const float upe = l2.qn ? __builtin_inff() : sc * (float)acc[e] + bound;
                 if (at < RESCAN_LHITS) {
                     lhq[at] = qi;
                     lhr[at] = (unsigned char)rr;
+                    lhu[at] = upe;
                 } else {   // more hits than the staging buffer holds (duplicate-rich chunk): on the spot
                     const int pos = cand_cnt[qi] + (int)atomicAdd(&hit_cnt[(size_t)qi * BIN_CNT_STRIDE], 1u);
-                    if (pos < cap) cand[(size_t)qi * cap + pos] = ((unsigned)c << 8) | (unsigned)rr;
+                    if (pos < cap) {
+                        cand[(size_t)qi * cap + pos] = ((unsigned)c << 8) | (unsigned)rr;
+                        cand_up[(size_t)qi * cap + pos] = upe;
+                    }
                 }
                 ++at;
             }
@@ -807,7 +814,10 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
                 // counted in hit_cnt, a line of their own per query, and added by match_rescan_close_kernel)
                 const int hq = lhq[i];
                 const int pos = cand_cnt[hq] + (int)atomicAdd(&hit_cnt[(size_t)hq * BIN_CNT_STRIDE], 1u);
-                if (pos < cap) cand[(size_t)hq * cap + pos] = ((unsigned)c << 8) | (unsigned)lhr[i];
+                if (pos < cap) {
+                    cand[(size_t)hq * cap + pos] = ((unsigned)c << 8) | (unsigned)lhr[i];
+                    cand_up[(size_t)hq * cap + pos] = lhu[i];
+                }
             }
             __syncthreads();
             if (threadIdx.x == 0) lhit_n = 0;
@@ -827,7 +837,7 @@ int launch_rescan_chunk_ks(const SearchWs& w, int nchunks, int64_t n, int64_t m,
     }
     hipLaunchKernelGGL(match_rescan_chunk_kernel<KS>, dim3((unsigned)nchunks, (unsigned)((w.bin_cap + RESCAN_SLICE - 1) / RESCAN_SLICE)),
                        dim3(256), lds, st, n, m, ib, (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt,
-                       w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, use_gate, gate, guard, l2, w.bin_cap, w.hit_cnt);
+                       w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, use_gate, gate, guard, l2, w.bin_cap, w.hit_cnt, w.cand_up);
     VFM_CHECK_LAUNCH("match_rescan_chunk_kernel");
     return VFM_OK;
 }
@@ -1280,7 +1290,8 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
                                                            int64_t n, int64_t m, int d, float w2, int* __restrict__ cand_cnt,
                                                            unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count,
                                                            int* __restrict__ fb_list, int stats, const int* __restrict__ todo,
-                                                           const int* __restrict__ todo_count) {
+                                                           const int* __restrict__ todo_count, const float* __restrict__ cand_up,
+                                                           const unsigned* __restrict__ hit_cnt, I8Bounds ib) {
     __shared__ unsigned l_row[4][REFINE_KEEP];
     __shared__ float l_sc[4][REFINE_KEEP];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -1298,6 +1309,28 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
     bool flagged = false;
     for (int e = lane; e < cnt; e += 64) flagged |= (mycand[e] & 128u) != 0u;
     if (cnt < REFINE_MIN && !__any(flagged)) continue;
+    // The rows the chunk-major rescan appended (the last hit_cnt entries of the list) carry the upper bound U = s_q s_c S + A + B_c of
+    // their exact score (cand_up), S their exact integer score; U - 2 (A + B_c) is a LOWER bound of the same score.  The rescans tested
+    // a row against the coarse pass's lower bound of the query's maximum -- the fp6 image's, 0.06 below the maximum on unit rows, so
+    // that 45 rows per query came through on lifted descriptors where 13 lie inside the int8 bounds --; here every
+    // row is tested against the best lower bound among the list's own rows, and the rest never has its 1.5 KB fp32 row read.  A row
+    // dropped has U < L <= the exact score of another row of the list: it is not the arg-max and does not tie with it.
+    int split = cnt;        // first appended entry
+    float lowest = -__builtin_inff();
+    const float* myup = cand_up ? cand_up + (size_t)qi * cap : nullptr;
+    if (cand_up) {
+        const int hits = (int)hit_cnt[(size_t)qi * BIN_CNT_STRIDE];
+        split = cnt - hits < 0 ? 0 : cnt - hits;
+        const float eq = ib.qerr[qi];
+        const float A = eq * 1.0001220703125f + 1.0e-6f, mult = 1.0001220703125f + eq;
+        for (int e = split + lane; e < cnt; e += 64) {
+            const float u = myup[e];
+            const float bnd = A + mult * ib.berr[mycand[e] >> 8];
+            if (u < 3.0e38f) lowest = fmaxf(lowest, (u - 2.0f * bnd) - 4.0e-6f);   // (fp32 evaluation of U and of this line: a few 1e-7)
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) lowest = fmaxf(lowest, __shfl_xor(lowest, off));
+    }
     RefineWave R;
     R.init(q, invq[qi], qi, b, invb, d, w2, l_row[wave], l_sc[wave]);
     // single-row entries: 4 per pass, 64 list entries per load, the next pass's rows in flight under the current pass's sums (a
@@ -1310,14 +1343,39 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
             if (!(ce & 128u)) {
                 myrow = (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u);
                 if (myrow >= m) myrow = -1;
+                if (e0 + lane >= split && myup[e0 + lane] < lowest) myrow = -1;
             }
         }
         if (!__any(myrow >= 0)) continue;
-        auto row_at = [&](int p) { return p < nblk ? __shfl(myrow, (p + R.g) & 63) : -1ll; };   // (lanes >= nblk hold -1)
+        // the rows that are left, packed to the front (the dropped ones are scattered through the list: a pass of four costs its
+        // round trip as long as one of its rows is live)
+        const unsigned long long keep = __ballot(myrow >= 0);
+        const int nkeep = __popcll(keep);
+        {
+            // lane l takes the row of the l-th live lane: the position of the l-th set bit of `keep`, by halving
+            int need = lane, src = 0;
+            unsigned long long rest = keep;
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) {
+                const unsigned long long lowmask = (1ull << sh) - 1ull;
+                const int below = __popcll(rest & lowmask);
+                if (need >= below) {
+                    need -= below;
+                    rest >>= sh;
+                    src += sh;
+                } else {
+                    rest &= lowmask;
+                }
+            }
+            const long long packed = __shfl(myrow, src & 63);
+            myrow = lane < nkeep ? packed : -1;
+        }
+        const int nblk_keep = nkeep;
+        auto row_at = [&](int p) { return p < nblk_keep ? __shfl(myrow, (p + R.g) & 63) : -1ll; };   // (lanes >= nkeep hold -1)
         RefineWave::Row ra, rb;
         long long rowa = row_at(0), rowb;
         R.load4(ra, rowa);
-        for (int p = 0; p < nblk; p += 8) {
+        for (int p = 0; p < nblk_keep; p += 8) {
             rowb = row_at(p + 4);
             R.load4(rb, rowb);
             if (__any(rowa >= 0)) R.consider(rowa, R.dot4(ra, rowa));
@@ -1886,10 +1944,13 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
             // (rec_cnt, unused by the int8 pass, holds the list of crowded queries; fb_count[6] its length)
             const unsigned grid = (unsigned)((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024);
             hipLaunchKernelGGL(match_refine_kernel, dim3(grid), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2, w.cand_cnt, w.cand,
-                               w.cap, w.fb_count, w.fb_list, g_match_stats, (const int*)w.rec_cnt, (const int*)(w.fb_count + 6));
+                               w.cap, w.fb_count, w.fb_list, g_match_stats, (const int*)w.rec_cnt, (const int*)(w.fb_count + 6),
+                               use_bins ? (const float*)w.cand_up : (const float*)nullptr, (const unsigned*)w.hit_cnt,
+                               i8_bounds(Q, B, true, records));
         } else {
             hipLaunchKernelGGL(match_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2,
-                               w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats, (const int*)nullptr, (const int*)nullptr);
+                               w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats, (const int*)nullptr, (const int*)nullptr,
+                               (const float*)nullptr, (const unsigned*)nullptr, I8Bounds{});
         }
         VFM_CHECK_LAUNCH("match_refine_kernel");
     }

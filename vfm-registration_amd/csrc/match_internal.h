@@ -467,6 +467,8 @@ struct SearchWs {
                         // match_rescan_close_kernel): the lists' own lengths sit 32 to a line, and a line is what the memory side serialises
     int* bins;          // ... and the queries themselves, bin_cap per chunk (match_rescan_chunk_kernel)
     int bin_cap;        // rescan_bin_cap(npad, chunks)
+    float* cand_up;     // [npad][cap] upper bound of the exact score of the rows match_rescan_chunk_kernel appended (same positions as
+                        // `cand`; other entries' slots are never read): match_refine_kernel drops rows below the list's best lower bound
     size_t bytes;
 };
 
@@ -500,6 +502,7 @@ inline SearchWs carve_search(void* p, int64_t n, int64_t m) {
     w.bins = c.take<int>((size_t)(mpad / CHUNK_ROWS) * (size_t)w.bin_cap);
     w.rcap = FILTER_LDS_ROWS;
     w.rec = c.take<uint2>((size_t)npad * (size_t)w.rcap);
+    w.cand_up = c.take<float>((size_t)npad * (size_t)w.cap);
     w.bytes = c.used();
     return w;
 }
