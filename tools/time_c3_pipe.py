@@ -36,8 +36,13 @@ b_xyz = torch.rand(m, 3, device=dev, generator=g, dtype=torch.float64) * 100.0
 q_xyz = torch.from_numpy(np.ascontiguousarray(xyz)).to(dev)
 b_xyz[pick] = q_xyz + 0.02 * torch.randn(n, 3, device=dev, generator=g, dtype=torch.float64)
 img_sets = [imgs, torch.flip(imgs, dims=[0]).contiguous()]
+import os
+from vfmreg import _lib
+if os.environ.get("VFM_VARIANT"):
+    _lib.load().vfm_debug_set_coarse_variant(int(os.environ["VFM_VARIANT"]))
+PRIO = int(os.environ.get("VFM_FEATURE_PRIORITY", "0"))
 for cus in [int(x) for x in (sys.argv[1:] or ["0", "16", "32", "48", "64", "0"])]:
-    e2e = EndToEndPipeline(model, rig, n, m, n_iter=50000, depth=4, feature_cus=cus)
+    e2e = EndToEndPipeline(model, rig, n, m, n_iter=50000, depth=4, feature_cus=cus, feature_priority=PRIO)
     torch.cuda.synchronize()
     ready = torch.cuda.Event()
     ready.record(torch.cuda.current_stream())

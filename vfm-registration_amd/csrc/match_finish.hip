@@ -679,7 +679,8 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
                                                                  int* __restrict__ cand_cnt, unsigned* __restrict__ cand, int cap,
                                                                  const unsigned* __restrict__ bin_cnt, const int* __restrict__ bins,
                                                                  int use_gate, float gate, const int* __restrict__ guard, L2Terms l2,
-                                                                 int bin_cap, unsigned* __restrict__ hit_cnt, float* __restrict__ cand_up) {
+                                                                 int bin_cap, unsigned* __restrict__ hit_cnt, float* __restrict__ cand_up,
+                                                                 int slice) {
     // A ring of D slots, one per block of 32 queries: [KS][64] uint4 = the block's queries as ONE MFMA operand image (unit u =
     // (k-step s, half h, column p) comes from query bin[j0 + p]), then [3][64] dwords of per-query terms.  Everything a block needs
     // from global memory arrives by LDS-DMA issued D - 1 blocks ahead (wave w gathers k-steps w, w + 4, ...: its 64 lanes' units
@@ -702,9 +703,9 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
     if (guard && *guard) return;   // half-width pass, too many survivors: match_gatepass_kernel has decided every query
     const unsigned filled = bin_cnt[(size_t)c * BIN_CNT_STRIDE];
     const int nall = filled < (unsigned)bin_cap ? (int)filled : bin_cap;
-    const int jbeg = blockIdx.y * RESCAN_SLICE;   // a long bin is shared by the workgroups (c, 0), (c, 1), ...
+    const int jbeg = blockIdx.y * slice;   // a long bin is shared by the workgroups (c, 0), (c, 1), ... (slice <= RESCAN_SLICE entries each)
     if (jbeg >= nall) return;
-    const int nq = nall - jbeg < RESCAN_SLICE ? nall - jbeg : RESCAN_SLICE;
+    const int nq = nall - jbeg < slice ? nall - jbeg : slice;
     const int nblocks = (nq + 31) >> 5;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) lhit_n = 0;
@@ -835,9 +836,14 @@ int launch_rescan_chunk_ks(const SearchWs& w, int nchunks, int64_t n, int64_t m,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_mark(attr_set);
     }
-    hipLaunchKernelGGL(match_rescan_chunk_kernel<KS>, dim3((unsigned)nchunks, (unsigned)((w.bin_cap + RESCAN_SLICE - 1) / RESCAN_SLICE)),
+    // Short workgroups: a workgroup that walks a whole bin (~600 queries on lifted descriptors) lives ~80 us on 160 registers x 4 waves
+    // and 61 KB, and while a grid of those is resident nothing as register-heavy as a ViT GEMM wave (156 - 416 registers) is placed
+    // beside it -- in C3 as a pipeline the feature stage of the next pair stood still behind this kernel (tools/trace_c3_pipe.sh).
+    const int slice = g_finish_short ? 128 : RESCAN_SLICE;
+    hipLaunchKernelGGL(match_rescan_chunk_kernel<KS>, dim3((unsigned)nchunks, (unsigned)((w.bin_cap + slice - 1) / slice)),
                        dim3(256), lds, st, n, m, ib, (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt,
-                       w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, use_gate, gate, guard, l2, w.bin_cap, w.hit_cnt, w.cand_up);
+                       w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, use_gate, gate, guard, l2, w.bin_cap, w.hit_cnt, w.cand_up,
+                       slice);
     VFM_CHECK_LAUNCH("match_rescan_chunk_kernel");
     return VFM_OK;
 }
@@ -1942,7 +1948,9 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                                (const unsigned*)w.hit_cnt);
             VFM_CHECK_LAUNCH("match_rescan_close_kernel");
             // (rec_cnt, unused by the int8 pass, holds the list of crowded queries; fb_count[6] its length)
-            const unsigned grid = (unsigned)((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024);
+            // (one query per wave, a workgroup per four: the work list's length is on the device, workgroups past its end return at once.
+            // A grid of 1024 workgroups walking the list kept 196 registers x 8 waves per compute unit for the kernel's whole length)
+            const unsigned grid = g_finish_short ? (unsigned)((n + 3) / 4) : (unsigned)((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024);
             hipLaunchKernelGGL(match_refine_kernel, dim3(grid), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2, w.cand_cnt, w.cand,
                                w.cap, w.fb_count, w.fb_list, g_match_stats, (const int*)w.rec_cnt, (const int*)(w.fb_count + 6),
                                use_bins ? (const float*)w.cand_up : (const float*)nullptr, (const unsigned*)w.hit_cnt,

@@ -429,7 +429,7 @@ class EndToEndPipeline:
     other (tests/test_gpu_e2e.py)."""
 
     def __init__(self, model, cams: list, n: int, m: int, n_iter: int = 50000, min_cosine: float = 0.8, max_corr_dist: float = 10000.0,
-                 seed: int = 42, depth: int = 4, coarse: str = "auto", device="cuda", feature_cus: int = 0):
+                 seed: int = 42, depth: int = 4, coarse: str = "auto", device="cuda", feature_cus: int = 0, feature_priority: int = 0):
         """``model``: vit.ViTS14 for the rig's image size; ``cams``: the rig, one dict per camera in priority order with the
         projection parameters of ``ops.LiftPlan`` (mode, mats, fc, subsample, win, H, W, rot_mode) -- image and grid pointers are
         the pipeline's own."""
@@ -450,7 +450,8 @@ class EndToEndPipeline:
             self.feat_stream = masked_stream(self.feature_cus, 0, ncu)
             self.reg_stream = masked_stream(ncu - self.feature_cus, self.feature_cus, ncu)
         else:
-            self.feat_stream = torch.cuda.Stream(device=self.device)
+            # (``feature_priority`` < 0: a high-priority stream -- its workgroups are placed first whenever a compute unit has room)
+            self.feat_stream = torch.cuda.Stream(device=self.device, priority=int(feature_priority))
             self.reg_stream = None
         self.sets = []
         for _ in range(self.depth):
