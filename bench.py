@@ -577,12 +577,15 @@ def main():
     # the extras' timed_loop(settle=6); with W <= 2 pipelined warm-up steps the switch used to fall into the timed region (1020
     # instead of 1330 registrations/s at --warmup 1).  Reported as config.policy_settle_registrations.
     settle = SETTLE if pipe.coarse == "auto" else 0
+    settle_ms = []   # what each of them took, host clock, synchronised: the probe of the first one and the policy's switches are in here
     for i in range(settle):
+        ts = time.perf_counter()
         step(i)
         with torch.cuda.stream(match_stream):
             pipe.synchronize()
         torch.cuda.synchronize()
         pipe._poll_feedback()
+        settle_ms.append(round((time.perf_counter() - ts) * 1e3, 3))
     for i in range(int(os.environ.get("VFM_BENCH_PRECOND", "0"))):   # A/B only (tools/): extra untimed registrations in front of the warm-up
         step(i)
     for i in range(max(args.warmup, 1)):
@@ -720,6 +723,9 @@ def main():
                        "correspondences_last_step": ncorr, "max_pose_err_vs_planted": max(errs),
                        # untimed, in front of the W warm-up steps: registrations the auto policy reads its feedback between (set-up)
                        "policy_settle_registrations": settle,
+                       # ... and how long each took, one at a time, synchronised (ms): the first carries the half-width probe, the lazy
+                       # set-up of the kernels' attributes and the first launches; none of it is in the timed region
+                       "policy_settle_ms": settle_ms,
                        # the record kind (include/vfmreg.h VFM_RECORDS_*) of the timed registrations: tests/test_gpu_bench_config.py
                        # compares exactly this kind with the oracle at this size (BENCH_RECORDS_KIND), tests/test_gpu_bench.py ties the two
                        "records_kind": records_kind,

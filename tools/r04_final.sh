@@ -31,6 +31,10 @@ bash tools/prof_vit_batch.sh > $O/prof_vit_batch.txt 2>&1
 # the reference-shaped API (map kept between scans; with and without ICP), C3 as a pipeline
 timeout 600 python tools/time_api.py > $O/time_api.txt 2>&1; tail -12 $O/time_api.txt
 timeout 600 python tools/time_c3_pipe.py 0 > $O/time_c3_pipe.txt 2>&1; tail -6 $O/time_c3_pipe.txt
+bash tools/trace_c3_pipe.sh > $O/trace_c3_pipe.txt 2>&1
+timeout 600 python tools/ab_prep_r4.py 2>&1 | grep -v amdgpu > $O/ab_prep_forms.txt
+timeout 300 python tools/ab_vit_split.py 2>&1 | grep -v amdgpu > $O/vit_split.txt
+hipcc --offload-arch=gfx950 -O3 -w -o /tmp/hbm_probe tools/probe/hbm_probe.hip && /tmp/hbm_probe > $O/hbm_probe.txt 2>&1
 # F rows, C3 stages, RANSAC alone, row A6
 { timeout 300 python tools/time_f_rows.py 2>&1; echo; timeout 300 python tools/time_c3.py 2>&1; echo; timeout 200 python tools/time_ransac.py 2>&1; } > $O/other_rows.txt; tail -30 $O/other_rows.txt
 timeout 300 python tools/time_pairs.py 6 > $O/time_pairs.txt 2>&1
