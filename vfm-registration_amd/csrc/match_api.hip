@@ -50,6 +50,7 @@ int g_select_variant = 0;  // vfm_debug_set_coarse_variant(20 / 21): general sel
 int g_mx6_t4 = 1;
 int g_prep_stream = 1;
 int g_finish_short = 0;
+int g_rescan_rows = 1;
 int g_match_stats = 0;  // vfm_debug_set_match_stats: per-query counters cost ~0.5 ms of same-address atomics per search
 // 4 = pipelined kernel with the DENSE per-chunk records + match_select_kernel (round-1 path; A/B reference)
 
@@ -467,6 +468,10 @@ VFM_EXPORT int vfm_debug_set_coarse_slices(int slices) {
     return VFM_OK;
 }
 VFM_EXPORT int vfm_debug_set_coarse_variant(int qsets) {
+    if (qsets == 60 || qsets == 61) {   // chunk-major rescan: queries gathered from the int8 fragment tiles (60) / the row-major int8 scan (61, default)
+        g_rescan_rows = qsets == 61 ? 1 : 0;
+        return VFM_OK;
+    }
     if (qsets == 50 || qsets == 51) {   // finish stage: 50 = long-lived workgroups (rescan: a bin per workgroup; refinement: 1024 workgroups walk the list; the default), 51 = short ones
         g_finish_short = qsets == 51 ? 1 : 0;
         return VFM_OK;

@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
                                                                  const unsigned* __restrict__ bin_cnt, const int* __restrict__ bins,
                                                                  int use_gate, float gate, const int* __restrict__ guard, L2Terms l2,
                                                                  int bin_cap, unsigned* __restrict__ hit_cnt, float* __restrict__ cand_up,
-                                                                 int slice) {
+                                                                 int slice, const unsigned char* __restrict__ qrows) {
     // A ring of D slots, one per block of 32 queries: [KS][64] uint4 = the block's queries as ONE MFMA operand image (unit u =
     // (k-step s, half h, column p) comes from query bin[j0 + p]), then [3][64] dwords of per-query terms.  Everything a block needs
     // from global memory arrives by LDS-DMA issued D - 1 blocks ahead (wave w gathers k-steps w, w + 4, ...: its 64 lanes' units
@@ -734,10 +734,17 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
     auto issue = [&](int blk) {
         const int qi = lbin[blk * 32 + (lane & 31)];
         const unsigned slot = lds_base + (unsigned)(blk % D) * SLOT;
+        if (qrows) {   // row-major int8 scan (Prepared::rows8): unit (k-step s, half h) of query qi = bytes 32 s + 16 h .. of its row
+            const unsigned char* rsrc = qrows + (size_t)qi * (KS * 32) + (size_t)(2 * wave + (lane >> 5)) * 16;
+#pragma unroll
+            for (int t = 0; t < NG; ++t)
+                glds16(rsrc + (size_t)t * 128, __builtin_amdgcn_readfirstlane(slot + (unsigned)(wave + 4 * t) * 1024u));
+        } else {
         const uint4* src = q8 + (size_t)(qi >> 5) * TILE_U4 + (size_t)(2 * wave + (lane >> 5)) * 32 + (qi & 31);
 #pragma unroll
         for (int t = 0; t < NG; ++t)
             glds16(src + (size_t)t * 256, __builtin_amdgcn_readfirstlane(slot + (unsigned)(wave + 4 * t) * 1024u));
+        }
         const unsigned terms = slot + (unsigned)KS * 1024u;
         if (wave == 0) glds4(lane < 32 ? (const void*)(cand_cnt + qi) : (const void*)(ib.qerr + qi), __builtin_amdgcn_readfirstlane(terms));
         if (wave == 1)
@@ -843,7 +850,7 @@ int launch_rescan_chunk_ks(const SearchWs& w, int nchunks, int64_t n, int64_t m,
     hipLaunchKernelGGL(match_rescan_chunk_kernel<KS>, dim3((unsigned)nchunks, (unsigned)((w.bin_cap + slice - 1) / slice)),
                        dim3(256), lds, st, n, m, ib, (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt,
                        w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, use_gate, gate, guard, l2, w.bin_cap, w.hit_cnt, w.cand_up,
-                       slice);
+                       slice, g_rescan_rows ? (const unsigned char*)Q.rows8 : (const unsigned char*)nullptr);
     VFM_CHECK_LAUNCH("match_rescan_chunk_kernel");
     return VFM_OK;
 }

@@ -364,8 +364,13 @@ struct Prepared {
     float* gstep6;    // MX6_FIX_STEP for every group (the records are fixed-point: I8Bounds needs a step per group)
     float* err6h;     // per row: the same residual norm over the FIRST d / 2 columns only -- what the half-width pass multiplies
     float* gerr6h;    // its maximum per group
+    // the int8 image once more, ROW-major (d bytes per row), for operands of at most ROWS8_MAX_ROWS rows -- scans: the chunk-major
+    // rescan gathers 32 queries' k-steps per LDS-DMA instruction, and from the fragment tiles that is 64 different 128-byte lines per
+    // instruction (a query's 16-byte units lie 512 bytes apart), from rows 32 lines that the block's other k-steps touch again
+    unsigned char* rows8;
     size_t bytes;
 };
+constexpr int64_t ROWS8_MAX_ROWS = 131072;
 
 // widths the int8 coarse pass exists for (match_coarse_pipe_kernel<d/32, false, true>; d = 128 has too few k-steps for the
 // fragment ring)
@@ -428,6 +433,7 @@ inline Prepared carve_prepared(void* p, int64_t rows, int d) {
     r.tiles6 = nullptr;
     r.err6 = r.gerr6 = r.gstep6 = nullptr;
     r.err6h = r.gerr6h = nullptr;
+    r.rows8 = nullptr;
     if (i8_capable(d)) {  // behind the fp16 image: the Euclidean path carves the same layout and ignores the rest
         r.err = c.take<float>((size_t)rp);
         r.gstep = c.take<float>((size_t)rp / I8_GROUP);
@@ -446,6 +452,7 @@ inline Prepared carve_prepared(void* p, int64_t rows, int d) {
             r.err6h = c.take<float>((size_t)rp);
             r.gerr6h = c.take<float>((size_t)rp / I8_GROUP);
         }
+        if (rp <= ROWS8_MAX_ROWS) r.rows8 = c.take<unsigned char>((size_t)rp * (size_t)d);
     }
     r.bytes = c.used();
     return r;
@@ -527,6 +534,7 @@ inline void attr_mark(unsigned long long& mask) {
 
 // experiment knobs and profiling hook (match_api.hip)
 extern int g_force_slices, g_coarse_qsets, g_seed_units, g_match_stats, g_i8_min_queries, g_select_variant;
+extern int g_rescan_rows;    // vfm_debug_set_coarse_variant(60 / 61): chunk-major rescan gathers its queries from the fragment tiles / from the row-major int8 scan (default)
 extern int g_finish_short;   // vfm_debug_set_coarse_variant(50 / 51): chunk-major rescan and fp32 refinement as long-lived workgroups (default) / short ones (A/B: no gain in C3 as a pipeline, +10 us of empty workgroups on D.2)
 extern int g_prep_stream;   // vfm_debug_set_coarse_variant(40 / 41): fp6 operand preparation by prep_chunk_kernel (rows in registers) / prep_stream_kernel (default)
 extern int g_mx6_t4;   // vfm_debug_set_coarse_variant(30 / 31): the fused fp6 half-width kernel with one chunk per barrier (default) / two (A/B)

@@ -97,6 +97,7 @@ struct PrepOut {
     float* gstep6;    // MX6: MX6_FIX_STEP
     float* err6h;     // MX6: residual norm of the fp6 image over the first d / 2 columns (+ MX6_SLACK)
     float* gerr6h;    // MX6: its maximum over the group
+    unsigned char* rows8;   // the int8 image row-major (NULL: operand too large to be a scan, Prepared::rows8)
     int mx6_half;     // MX6: VFM_PREPARE_MX6_HALF -- only the first d / 2 columns are converted (the tile prefix the half-width pass reads), err6 /
                       // gerr6 are infinite, no int8 half-width image is written
 };
@@ -337,6 +338,15 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
                 __builtin_nontemporal_store(tq.y, po + 1);
                 __builtin_nontemporal_store(tq.z, po + 2);
                 __builtin_nontemporal_store(tq.w, po + 3);
+            }
+        }
+        if (o.rows8) {   // ... and row-major (scan-sized operands): unit un of row `row` sits at tile row >> 5, column un, row & 31
+            const int nu = d >> 4;
+            const uint4* src = reinterpret_cast<const uint4*>(img8);
+            for (int u = threadIdx.x; u < I8_GROUP * nu; u += NT) {
+                const int row = u / nu, un = u - row * nu;
+                const uint4 tq = src[(row >> 5) * (nu * 32) + un * 32 + (row & 31)];
+                *reinterpret_cast<uint4*>(o.rows8 + ((size_t)grp * I8_GROUP + row) * (size_t)d + 16 * un) = tq;
             }
         }
         if (!(MX6 && o.mx6_half)) {  // the first d / 2 columns again, as tiles of their own (the first half of every tile's units)
@@ -721,6 +731,14 @@ __global__ __launch_bounds__(256, 3) void prep_stream_kernel(const float* __rest
                 }
             }
         }
+        if (o.rows8) {   // row-major copy (scan-sized operands): the batch's rows as they lie in the slice
+#pragma unroll
+            for (int rd = 0; rd < (NU * 8 + 63) / 64; ++rd) {
+                const int e = rd * 64 + lane, j = e / NU, u = e - j * NU;
+                if (e < NU * 8)
+                    *reinterpret_cast<uint4*>(o.rows8 + (size_t)(row0 + 8 * b + j) * D + 16 * u) = *reinterpret_cast<const uint4*>(my8 + j * RS8 + 16 * u);
+            }
+        }
         // fp6: lane = (row j, block) of the batch -- prep_chunk_kernel's conversion
 #pragma unroll
         for (int item0 = 0; item0 < nitems; item0 += 64) {
@@ -964,7 +982,7 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x,
 
 inline PrepOut prep_out(const Prepared& p, const int* perm = nullptr, int mx6_half = 0) {
     return PrepOut{p.inv, p.tiles, p.err, p.gstep, p.gerr, p.tiles8, p.tiles8h, p.rest, p.grest, perm, p.tiles6, p.err6, p.gerr6, p.gstep6,
-                   p.err6h, p.gerr6h, mx6_half};
+                   p.err6h, p.gerr6h, p.rows8, mx6_half};
 }
 
 // Workgroups of prep_chunk_kernel (vfm_debug_set_prep_grid): -1 (default) = one per 128-row group; 0 = one per compute unit,
