@@ -668,7 +668,7 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
 // scores of 32 rows x 32 queries; a row inside the query's bounds is appended to the query's list (one atomic per lane and
 // block for all of its hits).  Same integers, same hit test, hence the same rows as the v_dot4 loop it replaces (24 LDS reads +
 // 96 dot4 per query and wave: 26 us at C2's 9891 candidates but 0.7 ms at the 220 000 of an ungated Euclidean search).
-constexpr int RESCAN_LHITS = 2048;   // rows a workgroup of match_rescan_chunk_kernel stages in the LDS before it touches the lists
+constexpr int RESCAN_LHITS = 1024;   // rows a workgroup of match_rescan_chunk_kernel stages in the LDS before it touches the lists (1024: 13 KB of static LDS beside the 39 KB ring at d = 384 -- three workgroups per compute unit instead of two)
 template <int KS>
 constexpr int rescan_ring_depth() { return KS <= 16 ? 3 : 2; }
 template <int KS>
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
         // (a full staging buffer is emptied before the next block adds to it; lhit_n is read by every thread between two barriers
         // that no atomic of another block can cross, so the branch is uniform)
         __syncthreads();
-        if (lhit_n > RESCAN_LHITS - 32 * CHUNK_ROWS / 4 || blk + 1 == nblocks) {
+        if (lhit_n > RESCAN_LHITS / 2 || blk + 1 == nblocks) {
             wait_vmcnt<0>();   // (the atomics below are compiler-tracked: nothing of the ring may be pending behind them)
             const int nh = lhit_n < RESCAN_LHITS ? lhit_n : RESCAN_LHITS;
             for (int i = threadIdx.x; i < nh; i += 256) {
@@ -1034,12 +1034,15 @@ __global__ __launch_bounds__(256) void match_rescan_close_kernel(int64_t n, int*
 // replace the query's list as single-row entries: match_rescore_kernel is unchanged.
 // ---------------------------------------------------------------------------------------------
 // state of one wavefront refining one query: the fp32-normalised query in registers, the kept rows in LDS
+// (NT = float4 per lane the arrays hold, >= d / 64: 6 at d = 384 -- 24 + 2 x 25 registers instead of 48 + 2 x 49, which is what lets the
+// refinement run four waves per SIMD instead of two)
+template <int NT>
 struct RefineWave {
     const float* b;
     const float* invb;
     int d, nt, g, l, lane;
     float w2;
-    float4 qv[12];
+    float4 qv[NT];
     unsigned* lrow;
     float* lsc;
     int kept;        // wave-uniform
@@ -1057,7 +1060,7 @@ struct RefineWave {
         runmax = -3.0e38f;
         overflow = false;
 #pragma unroll
-        for (int t = 0; t < 12; ++t) {
+        for (int t = 0; t < NT; ++t) {
             if (t < nt) {
                 float4 v = *reinterpret_cast<const float4*>(q + qi * (int64_t)d + 4 * (l + 16 * t));
                 v.x = v.x * iq; v.y = v.y * iq; v.z = v.z * iq; v.w = v.w * iq;  // the fp32-normalised query (faiss' xq)
@@ -1072,7 +1075,7 @@ struct RefineWave {
             const float ib = invb[row];
             const float* br = b + row * (int64_t)d + 4 * l;
 #pragma unroll
-            for (int t = 0; t < 12; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 if (t < nt) {
                     const float4 bv = *reinterpret_cast<const float4*>(br + 64 * t);
                     acc = __builtin_fmaf(qv[t].x, bv.x * ib, acc);
@@ -1089,7 +1092,7 @@ struct RefineWave {
     // score4 in two halves, so that the next pass's row can be on its way while this pass's is summed (the same operations in
     // the same order: the same float)
     struct Row {
-        float4 v[12];
+        float4 v[NT];
         float ib;
     };
     __device__ __forceinline__ void load4(Row& r, long long row) const {
@@ -1097,7 +1100,7 @@ struct RefineWave {
             r.ib = invb[row];
             const float* br = b + row * (int64_t)d + 4 * l;
 #pragma unroll
-            for (int t = 0; t < 12; ++t)
+            for (int t = 0; t < NT; ++t)
                 if (t < nt) r.v[t] = *reinterpret_cast<const float4*>(br + 64 * t);
         }
     }
@@ -1105,7 +1108,7 @@ struct RefineWave {
         float acc = 0.0f;
         if (row >= 0) {
 #pragma unroll
-            for (int t = 0; t < 12; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 if (t < nt) {
                     acc = __builtin_fmaf(qv[t].x, r.v[t].x * r.ib, acc);
                     acc = __builtin_fmaf(qv[t].y, r.v[t].y * r.ib, acc);
@@ -1298,6 +1301,7 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
 }
 
 // dense records: the candidate entries of match_select_kernel (int8 pass: as rewritten by match_rescan_kernel)
+template <int NT>
 __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restrict__ q, const float* __restrict__ invq,
                                                            const float* __restrict__ b, const float* __restrict__ invb,
                                                            int64_t n, int64_t m, int d, float w2, int* __restrict__ cand_cnt,
@@ -1344,7 +1348,7 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) lowest = fmaxf(lowest, __shfl_xor(lowest, off));
     }
-    RefineWave R;
+    RefineWave<NT> R;
     R.init(q, invq[qi], qi, b, invb, d, w2, l_row[wave], l_sc[wave]);
     // single-row entries: 4 per pass, 64 list entries per load, the next pass's rows in flight under the current pass's sums (a
     // pass had been two dependent round trips -- the entry, then the row --: 164 us at the 25 rows per query of lifted descriptors)
@@ -1385,7 +1389,7 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
         }
         const int nblk_keep = nkeep;
         auto row_at = [&](int p) { return p < nblk_keep ? __shfl(myrow, (p + R.g) & 63) : -1ll; };   // (lanes >= nkeep hold -1)
-        RefineWave::Row ra, rb;
+        typename RefineWave<NT>::Row ra, rb;
         long long rowa = row_at(0), rowb;
         R.load4(ra, rowa);
         for (int p = 0; p < nblk_keep; p += 8) {
@@ -1476,7 +1480,7 @@ __global__ __launch_bounds__(256) void match_filter_refine_kernel(const float* _
         if (lane == 0) cand_cnt[qi] = ncand;
         return;
     }
-    RefineWave R;
+    RefineWave<12> R;
     R.init(q, iq, qi, b, invb, d, w2, l_row[wave], l_sc[wave]);
     for (int e0 = 0; e0 < ncand; e0 += 4) {
         const long long row = (e0 + R.g < ncand) ? (long long)lc[e0 + R.g] : -1;
@@ -1958,12 +1962,18 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
             // (one query per wave, a workgroup per four: the work list's length is on the device, workgroups past its end return at once.
             // A grid of 1024 workgroups walking the list kept 196 registers x 8 waves per compute unit for the kernel's whole length)
             const unsigned grid = g_finish_short ? (unsigned)((n + 3) / 4) : (unsigned)((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024);
-            hipLaunchKernelGGL(match_refine_kernel, dim3(grid), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2, w.cand_cnt, w.cand,
-                               w.cap, w.fb_count, w.fb_list, g_match_stats, (const int*)w.rec_cnt, (const int*)(w.fb_count + 6),
-                               use_bins ? (const float*)w.cand_up : (const float*)nullptr, (const unsigned*)w.hit_cnt,
-                               i8_bounds(Q, B, true, records));
+#define VFM_REFINE(NT)                                                                                                          \
+    hipLaunchKernelGGL(match_refine_kernel<NT>, dim3(grid), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2, w.cand_cnt, w.cand, \
+                       w.cap, w.fb_count, w.fb_list, g_match_stats, (const int*)w.rec_cnt, (const int*)(w.fb_count + 6),            \
+                       use_bins ? (const float*)w.cand_up : (const float*)nullptr, (const unsigned*)w.hit_cnt,                     \
+                       i8_bounds(Q, B, true, records))
+            if (d <= 256) VFM_REFINE(4);
+            else if (d <= 384) VFM_REFINE(6);
+            else if (d <= 512) VFM_REFINE(8);
+            else VFM_REFINE(12);
+#undef VFM_REFINE
         } else {
-            hipLaunchKernelGGL(match_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2,
+            hipLaunchKernelGGL(match_refine_kernel<12>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2,
                                w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats, (const int*)nullptr, (const int*)nullptr,
                                (const float*)nullptr, (const unsigned*)nullptr, I8Bounds{});
         }
