@@ -201,6 +201,14 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
  *                     answers, same guard; where a map chunk does not collect several queries (n < 4 x chunks) it behaves as
  *                     VFM_RECORDS_MX6_HALF. */
 #define VFM_RECORDS_MX6_HALF_FUSED 8
+/*   VFM_RECORDS_MX6_PILOT  VFM_RECORDS_MX6 with a pilot rescan in front of the selection: the coarse kernel also notes, per query,
+ *                     the chunk with the best fp6 score; the finish stage scores that ONE chunk per query exactly on the int8
+ *                     image first (chunk-major, on the matrix cores) and raises the query's lower bound to what it finds --
+ *                     the fp6 bound enters the selection's window once instead of twice (candidate chunks within ~0.07 of the
+ *                     best cosine instead of ~0.12: about half as many on descriptors with many near neighbours, e.g. lifted
+ *                     ViT features).  Costs three short launches; pays from ~8 rescanned chunks per query.  Same operands,
+ *                     limits and answers as VFM_RECORDS_MX6; needs at least four queries per map chunk, else it is VFM_RECORDS_MX6. */
+#define VFM_RECORDS_MX6_PILOT 9
 int vfm_match_search_coarse_gated_r(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
                                     int d, void *ws, size_t ws_bytes, int records, vfm_stream_t stream);
 /* _coarse_gated_r with the gate of the search (needed by VFM_RECORDS_HALF_FUSED; ignored by the other kinds) */

@@ -16,6 +16,7 @@ from .test_gpu_int8 import _gate_contract, _heavy_tailed  # noqa: E402
 PREPARE_MX6 = 8
 RECORDS_MX6 = 5
 RECORDS_MX6_TOP2 = 6
+RECORDS_MX6_PILOT = 9
 RECORDS_MX6_HALF = 7
 RECORDS_MX6_HALF_FUSED = 8
 PREPARE_MX6_HALF = 16
@@ -194,7 +195,7 @@ def test_mx6_pass_gives_the_oracle_answers_and_keeps_the_gate_contract(d, n, m):
         ridx, rsim = orc.match_ip_top1(qn, bn)
         qd, bd = torch.from_numpy(qq).cuda(), torch.from_numpy(bb).cuda()
         for g in (gate, float("-inf")):
-            for records, flags in ([(RECORDS_MX6, PREPARE_MX6), (RECORDS_MX6_TOP2, PREPARE_MX6)] +
+            for records, flags in ([(RECORDS_MX6, PREPARE_MX6), (RECORDS_MX6_TOP2, PREPARE_MX6), (RECORDS_MX6_PILOT, PREPARE_MX6)] +
                                    ([(k, f) for k in HALF_KINDS for f in (PREPARE_MX6, PREPARE_MX6 | PREPARE_MX6_HALF)] if g > float("-inf") else [])):
                 idx, sim = _search(qd, bd, g, records, flags=flags)
                 solved = _gate_contract(idx, sim, ridx, rsim, g)
@@ -263,7 +264,7 @@ def soak_trial_mx6(lib, rng, st):
     ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=torch.uint8, device="cuda")
     _lib.check(lib.vfm_match_prepare2_gated_p(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, PREPARE_MX6, st))
     res = {}
-    for records in (0, RECORDS_MX6, RECORDS_MX6_TOP2) + (HALF_KINDS if gate > float("-inf") else ()):
+    for records in (0, RECORDS_MX6, RECORDS_MX6_TOP2, RECORDS_MX6_PILOT) + (HALF_KINDS if gate > float("-inf") else ()):
         idx = torch.empty(n, dtype=torch.int64, device="cuda")
         sim = torch.empty(n, dtype=torch.float32, device="cuda")
         _lib.check(lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, gate, st))
@@ -273,7 +274,7 @@ def soak_trial_mx6(lib, rng, st):
         res[records] = (idx, sim)
     (i0, s0) = res[0]
     ok = True
-    for records in (RECORDS_MX6, RECORDS_MX6_TOP2) + HALF_KINDS:
+    for records in (RECORDS_MX6, RECORDS_MX6_TOP2, RECORDS_MX6_PILOT) + HALF_KINDS:
         if records not in res:
             continue
         i, s = res[records]
@@ -374,7 +375,7 @@ def test_reuse_map_without_prepare_map_keeps_auto_off_the_fp6_kinds():
             pipe.synchronize()
             torch.cuda.synchronize()
             pipe._poll_feedback()
-        assert not any(k in (5, 6, 7, 8) for k in kinds + [pipe._records()]), (name, kinds)
+        assert not any(k in (5, 6, 7, 8, 9) for k in kinds + [pipe._records()]), (name, kinds)
         assert not pipe.mx6 and not pipe.mx6_half, name
         c = int(out["count"].item())
         assert c == len(corres), name

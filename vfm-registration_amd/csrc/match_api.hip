@@ -101,6 +101,7 @@ CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, 
     a.rcap = 0;
     a.window = DEFAULT_WINDOW;
     a.ib = I8Bounds{nullptr, nullptr, nullptr, nullptr, 0};
+    a.qbest = nullptr;
     return a;
 }
 
@@ -152,6 +153,10 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
         a.Qh = half ? Q.tiles8h : Q.tiles8;
         a.Bh = half ? B.tiles8h : B.tiles8;
         a.ib = I8Bounds{Q.err, Q.gstep, B.gstep, B.gerr, records == VFM_RECORDS_TOP2 ? 1 : 0};
+        if (records == VFM_RECORDS_MX6_PILOT) {   // the full-width fp6 pass, which also notes every query's best chunk
+            a.qbest = w.qbest;
+            records = VFM_RECORDS_MX6;
+        }
         if (records == VFM_RECORDS_MX6 || records == VFM_RECORDS_MX6_TOP2 || records == VFM_RECORDS_MX6_HALF || records == VFM_RECORDS_MX6_HALF_FUSED) {
             // the fp6 image and its bounds (operands prepared with VFM_PREPARE_MX6)
             a.Qh = Q.tiles6;
@@ -259,7 +264,7 @@ VFM_EXPORT int vfm_match_search_coarse_gated_r(const void* q_prepared, int64_t n
                                                void* ws, size_t ws_bytes, int records, vfm_stream_t stream) {
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q_prepared && b_prepared && ws, "search_coarse: null pointer");
-    VFM_CHECK_ARG((records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_HALF) || (records >= VFM_RECORDS_MX6 && records <= VFM_RECORDS_MX6_HALF), "search_coarse: unknown record kind %d", records);
+    VFM_CHECK_ARG((records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_HALF) || (records >= VFM_RECORDS_MX6 && records <= VFM_RECORDS_MX6_HALF) || records == VFM_RECORDS_MX6_PILOT, "search_coarse: unknown record kind %d", records);
     return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream, false, true, true, records);
 }
 
@@ -267,7 +272,7 @@ VFM_EXPORT int vfm_match_search_coarse_gated_g(const void* q_prepared, int64_t n
                                                void* ws, size_t ws_bytes, int records, float gate, vfm_stream_t stream) {
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q_prepared && b_prepared && ws, "search_coarse: null pointer");
-    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6_HALF_FUSED, "search_coarse: unknown record kind %d", records);
+    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6_PILOT, "search_coarse: unknown record kind %d", records);
     VFM_CHECK_ARG(gate == gate, "search_coarse: gate is NaN");
     return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream, false, true, true, records, gate);
 }
@@ -285,7 +290,7 @@ VFM_EXPORT int vfm_match_search_finish_gated_r(const float* q, const void* q_pre
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q && b && q_prepared && b_prepared && ws && idx_out && sim_out, "search_finish: null pointer");
     VFM_CHECK_ARG(gate == gate, "search_finish: gate is NaN");
-    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6_HALF_FUSED, "search_finish: unknown record kind %d", records);
+    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6_PILOT, "search_finish: unknown record kind %d", records);
     return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream, true, gate, records);
 }
 

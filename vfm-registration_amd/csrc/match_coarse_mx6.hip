@@ -180,6 +180,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
     Mx6Frag qf[2][KS6];
     uint2 qs[2];
     float fx_A[2], fx_mult[2], fx_low[2], fx_rq[2];
+    int fx_arg[2] = {0, 0};
     bool live[2] = {false, false};
     unsigned livemask[2] = {0u, 0u};   // FUSE: the set's queries that exist and are not zero rows, one bit per query of the tile
     const unsigned char* qimg = reinterpret_cast<const unsigned char*>(a.Qh);
@@ -296,7 +297,9 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
             if (LOW && valid) {
                 const int sbest = (int)best - I8_OFFSET;
                 const float low = __builtin_fmaf(MX6_FIX_STEP * tab.x, (float)sbest, -(fx_A[j] + fx_mult[j] * tab.y));
-                fx_low[j] = fmaxf(fx_low[j], (!padded || sbest > 0) ? low : -__builtin_inff());
+                const float cand = (!padded || sbest > 0) ? low : -__builtin_inff();
+                fx_arg[j] = cand > fx_low[j] ? chunk : fx_arg[j];   // (VFM_RECORDS_MX6_PILOT: the chunk the running lower bound comes from)
+                fx_low[j] = fmaxf(fx_low[j], cand);
             }
         }
         const int cn = ci + 1 < nch ? ci + 1 : nch - 1;
@@ -468,7 +471,11 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
     if constexpr (LOW) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            if (lane < 32 && qt0 + j < a.nq_tiles) atomicMax(a.qmax + (size_t)(qt0 + j) * 32 + lane, float_key(fx_low[j]));
+            if (lane < 32 && qt0 + j < a.nq_tiles) {
+                atomicMax(a.qmax + (size_t)(qt0 + j) * 32 + lane, float_key(fx_low[j]));
+                if (a.qbest && fx_low[j] > -__builtin_inff())
+                    atomicMax(a.qbest + (size_t)(qt0 + j) * 32 + lane, ((unsigned long long)float_key(fx_low[j]) << 32) | (unsigned)fx_arg[j]);
+            }
     }
     if constexpr (FUSE) {
         // the workgroup's list -> its slot of the survivor buffer: [count, query block, first chunk, -][entries]; plain stores

@@ -680,7 +680,8 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
                                                                  const unsigned* __restrict__ bin_cnt, const int* __restrict__ bins,
                                                                  int use_gate, float gate, const int* __restrict__ guard, L2Terms l2,
                                                                  int bin_cap, unsigned* __restrict__ hit_cnt, float* __restrict__ cand_up,
-                                                                 int slice, const unsigned char* __restrict__ qrows) {
+                                                                 int slice, const unsigned char* __restrict__ qrows,
+                                                                 unsigned* __restrict__ pilot_qmax) {
     // A ring of D slots, one per block of 32 queries: [KS][64] uint4 = the block's queries as ONE MFMA operand image (unit u =
     // (k-step s, half h, column p) comes from query bin[j0 + p]), then [3][64] dwords of per-query terms.  Everything a block needs
     // from global memory arrives by LDS-DMA issued D - 1 blocks ahead (wave w gathers k-steps w, w + 4, ...: its 64 lanes' units
@@ -779,6 +780,21 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
             const uint4 v = l_qf[s * 64 + lane];
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s], *reinterpret_cast<const intx4*>(&v), acc, 0, 0, 0);
         }
+        if (pilot_qmax) {
+            // VFM_RECORDS_MX6_PILOT, in front of the selection: the bin holds the queries whose best fp6 chunk this is; the chunk's best
+            // EXACT integer score gives a lower bound of the query's exact maximum that carries the int8 image's bound (~0.01) instead of
+            // the fp6 image's (~0.06): it raises qmax, which the selection and the rescans behind it test against.  No hits are listed.
+            int smax = -0x7fffffff;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = rr0 + (e & 3) + 8 * (e >> 2);
+                if (base + rr < m) smax = max(smax, acc[e]);
+            }
+            smax = max(smax, __shfl_xor(smax, 32));   // the two half-waves hold the same query's other rows
+            if (j < nq && lane < 32 && smax > -0x7fffffff) atomicMax(&pilot_qmax[qi], float_key((sc * (float)smax - bound) - 2.0e-6f));
+            __syncthreads();
+            continue;
+        }
         unsigned hits = 0u;
         if (live) {
 #pragma unroll
@@ -835,7 +851,7 @@ __global__ __launch_bounds__(256) void match_rescan_chunk_kernel(int64_t n, int6
 
 template <int KS>
 int launch_rescan_chunk_ks(const SearchWs& w, int nchunks, int64_t n, int64_t m, I8Bounds ib, const Prepared& Q, const Prepared& B,
-                           int use_gate, float gate, const int* guard, L2Terms l2, hipStream_t st) {
+                           int use_gate, float gate, const int* guard, L2Terms l2, hipStream_t st, bool pilot) {
     const size_t lds = (size_t)rescan_ring_depth<KS>() * rescan_slot_bytes<KS>();   // + ~14 KB of static LDS: past 64 KB in all from KS = 16
     static unsigned long long attr_set = 0ull;  // one bit per device
     if (!attr_done(attr_set)) {
@@ -850,19 +866,33 @@ int launch_rescan_chunk_ks(const SearchWs& w, int nchunks, int64_t n, int64_t m,
     hipLaunchKernelGGL(match_rescan_chunk_kernel<KS>, dim3((unsigned)nchunks, (unsigned)((w.bin_cap + slice - 1) / slice)),
                        dim3(256), lds, st, n, m, ib, (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt,
                        w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, use_gate, gate, guard, l2, w.bin_cap, w.hit_cnt, w.cand_up,
-                       slice, g_rescan_rows ? (const unsigned char*)Q.rows8 : (const unsigned char*)nullptr);
+                       slice, g_rescan_rows ? (const unsigned char*)Q.rows8 : (const unsigned char*)nullptr, pilot ? w.qmax : (unsigned*)nullptr);
     VFM_CHECK_LAUNCH("match_rescan_chunk_kernel");
     return VFM_OK;
 }
 int launch_rescan_chunk(const SearchWs& w, int nchunks, int64_t n, int64_t m, int d, I8Bounds ib, const Prepared& Q, const Prepared& B,
-                        int use_gate, float gate, const int* guard, L2Terms l2, hipStream_t st) {
+                        int use_gate, float gate, const int* guard, L2Terms l2, hipStream_t st, bool pilot = false) {
     switch (d / 32) {
-        case 8: return launch_rescan_chunk_ks<8>(w, nchunks, n, m, ib, Q, B, use_gate, gate, guard, l2, st);
-        case 12: return launch_rescan_chunk_ks<12>(w, nchunks, n, m, ib, Q, B, use_gate, gate, guard, l2, st);
-        case 16: return launch_rescan_chunk_ks<16>(w, nchunks, n, m, ib, Q, B, use_gate, gate, guard, l2, st);
-        case 20: return launch_rescan_chunk_ks<20>(w, nchunks, n, m, ib, Q, B, use_gate, gate, guard, l2, st);
-        default: return launch_rescan_chunk_ks<24>(w, nchunks, n, m, ib, Q, B, use_gate, gate, guard, l2, st);
+        case 8: return launch_rescan_chunk_ks<8>(w, nchunks, n, m, ib, Q, B, use_gate, gate, guard, l2, st, pilot);
+        case 12: return launch_rescan_chunk_ks<12>(w, nchunks, n, m, ib, Q, B, use_gate, gate, guard, l2, st, pilot);
+        case 16: return launch_rescan_chunk_ks<16>(w, nchunks, n, m, ib, Q, B, use_gate, gate, guard, l2, st, pilot);
+        case 20: return launch_rescan_chunk_ks<20>(w, nchunks, n, m, ib, Q, B, use_gate, gate, guard, l2, st, pilot);
+        default: return launch_rescan_chunk_ks<24>(w, nchunks, n, m, ib, Q, B, use_gate, gate, guard, l2, st, pilot);
     }
+}
+
+// VFM_RECORDS_MX6_PILOT: every query (zero rows aside) into the bin of the chunk its best fp6 score came from
+__global__ __launch_bounds__(256) void match_pilot_bin_kernel(int64_t n, const unsigned long long* __restrict__ qbest,
+                                                              const float* __restrict__ invq, unsigned* __restrict__ bin_cnt,
+                                                              int* __restrict__ bins, int bin_cap, int nchunks) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n || invq[q] == 0.0f) return;
+    const unsigned long long v = qbest[q];
+    if ((v >> 32) == 0ull) return;   // no un-padded chunk gave a lower bound
+    const unsigned c = (unsigned)v;
+    if (c >= (unsigned)nchunks) return;
+    const unsigned pos = atomicAdd(&bin_cnt[(size_t)c * BIN_CNT_STRIDE], 1u);
+    if (pos < (unsigned)bin_cap) bins[(size_t)c * bin_cap + pos] = (int)q;   // (a bin that is full: those queries keep the fp6 lower bound)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1887,11 +1917,24 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
         bool use_bins = false;
         // best-score records with many queries per map chunk: the rescan runs chunk-major (match_rescan_chunk_kernel)
         // records of the fp6 pass: its own bounds in the selection; behind it the int8 image and bounds, as for the int8 kinds
+        const bool pilot = i8 && records == VFM_RECORDS_MX6_PILOT;
+        if (pilot) records = VFM_RECORDS_MX6;
         const bool mx6 = i8 && (records == VFM_RECORDS_MX6 || records == VFM_RECORDS_MX6_TOP2);
         const bool top2 = i8 && (records == VFM_RECORDS_TOP2 || records == VFM_RECORDS_MX6_TOP2);
         if (mx6) records = top2 ? VFM_RECORDS_TOP2 : VFM_RECORDS_BEST;
         const bool best = i8 && records == VFM_RECORDS_BEST && g_select_variant != 1;
         use_bins = (best || half) && g_select_variant != 2 && n >= 4 * (int64_t)a.nchunks;
+        if (pilot && use_bins) {
+            // the pilot rescan: one chunk per query, scored exactly on the int8 image, raises qmax (match_rescan_chunk_kernel, pilot
+            // branch); the bins it used are emptied again for the selection
+            hipLaunchKernelGGL(match_pilot_bin_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (const unsigned long long*)w.qbest,
+                               (const float*)Q.inv, w.bin_cnt, w.bins, w.bin_cap, a.nchunks);
+            VFM_CHECK_LAUNCH("match_pilot_bin_kernel");
+            const int rc = launch_rescan_chunk(w, a.nchunks, n, m, d, i8_bounds(Q, B, true, VFM_RECORDS_BEST), Q, B, 0, gate, (const int*)nullptr,
+                                               L2Terms{nullptr, nullptr, 0.0f}, st, true);
+            if (rc != VFM_OK) return rc;
+            VFM_CHECK_HIP(hipMemsetAsync(w.bin_cnt, 0, (size_t)((a.nchunks + 63) / 64 * 64) * BIN_CNT_STRIDE * sizeof(unsigned), st));
+        }
         if (fused6) {
             hipLaunchKernelGGL(match_bin_survivors_kernel, dim3(256), dim3(256), 0, st, reinterpret_cast<const unsigned*>(w.partials),
                                mx6_survivor_slot_words(), (const int*)w.fb_count, w.bin_cnt, w.bins, w.bin_cap, w.cand_cnt, w.cand, w.cap);

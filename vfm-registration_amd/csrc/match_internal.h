@@ -243,6 +243,7 @@ struct CoarseArgs {
     unsigned* cand;         // [npad][cap]
     int cap;
     int* survivors;         // fb_count + 5: the search's load figure
+    unsigned long long* qbest;   // VFM_RECORDS_MX6_PILOT: [npad] (float_key(lower bound) << 32 | chunk) of the query's best chunk, by 64-bit atomicMax (NULL: not kept)
     unsigned* surv;         // VFM_RECORDS_MX6_HALF_FUSED: a slot of mx6_survivor_slot_words() words per workgroup (in the record buffer)
 };
 
@@ -409,7 +410,9 @@ __host__ __device__ inline size_t mx6_scale_at(int ks, int s, int lane) {
 inline int effective_records(int records, int d, int64_t n, int64_t m) {
     if (records == VFM_RECORDS_HALF_FUSED && !((d == 256 || d == 384) && n > 2048 && n >= 4 * ((m + CHUNK_ROWS - 1) / CHUNK_ROWS)))
         records = VFM_RECORDS_HALF;
-    if (records == VFM_RECORDS_MX6 && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_BEST;   // (the one-set kernels have no fp6 form)
+    // (the pilot rescan is chunk-major: several queries per map chunk)
+    if (records == VFM_RECORDS_MX6_PILOT && !(n >= 4 * ((m + CHUNK_ROWS - 1) / CHUNK_ROWS))) records = VFM_RECORDS_MX6;
+    if ((records == VFM_RECORDS_MX6 || records == VFM_RECORDS_MX6_PILOT) && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_BEST;   // (the one-set kernels have no fp6 form)
     if (records == VFM_RECORDS_MX6_TOP2 && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_TOP2;
     if (records == VFM_RECORDS_MX6_HALF && !(mx6_half_width(d) && n > 2048)) records = VFM_RECORDS_BEST;   // (such operands carry no int8 half image)
     // the fused form needs the chunk-major rescan behind it (several queries per map chunk), like VFM_RECORDS_HALF_FUSED
@@ -474,6 +477,7 @@ struct SearchWs {
                         // match_rescan_close_kernel): the lists' own lengths sit 32 to a line, and a line is what the memory side serialises
     int* bins;          // ... and the queries themselves, bin_cap per chunk (match_rescan_chunk_kernel)
     int bin_cap;        // rescan_bin_cap(npad, chunks)
+    unsigned long long* qbest;   // [npad] VFM_RECORDS_MX6_PILOT: the query's best chunk (CoarseArgs::qbest); inside the zeroed region
     float* cand_up;     // [npad][cap] upper bound of the exact score of the rows match_rescan_chunk_kernel appended (same positions as
                         // `cand`; other entries' slots are never read): match_refine_kernel drops rows below the list's best lower bound
     size_t bytes;
@@ -505,6 +509,7 @@ inline SearchWs carve_search(void* p, int64_t n, int64_t m) {
     w.rec_cnt = c.take<unsigned>((size_t)npad);
     w.bin_cnt = c.take<unsigned>((size_t)((mpad / CHUNK_ROWS + 63) / 64 * 64) * BIN_CNT_STRIDE);
     w.hit_cnt = c.take<unsigned>((size_t)npad * BIN_CNT_STRIDE);
+    w.qbest = c.take<unsigned long long>((size_t)npad);   // (the last array of the region search_zero_bytes covers)
     w.bin_cap = rescan_bin_cap(npad, mpad / CHUNK_ROWS);
     w.bins = c.take<int>((size_t)(mpad / CHUNK_ROWS) * (size_t)w.bin_cap);
     w.rcap = FILTER_LDS_ROWS;
@@ -517,7 +522,7 @@ inline SearchWs carve_search(void* p, int64_t n, int64_t m) {
 inline size_t search_zero_bytes(int64_t n, int64_t m) {
     const int64_t npad = rows_padded(n), mpad = rows_padded(m);
     return 256 + 2 * (size_t)npad * sizeof(unsigned) + (size_t)((mpad / CHUNK_ROWS + 63) / 64 * 64) * BIN_CNT_STRIDE * sizeof(unsigned) +
-           (size_t)npad * BIN_CNT_STRIDE * sizeof(unsigned);
+           (size_t)npad * BIN_CNT_STRIDE * sizeof(unsigned) + (size_t)npad * sizeof(unsigned long long);
 }
 
 // hipFuncSetAttribute is per device: remember which devices have been configured (one bit each)

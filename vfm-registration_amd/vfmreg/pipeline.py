@@ -70,15 +70,19 @@ class _ResultSet:
 # ``RegistrationPipeline(private_streams=True)`` gives a pipeline streams of its own and is the choice for concurrent pipelines;
 # the queue placement it then gets is the HIP runtime's (an observed heuristic, not a contract).
 _SIDE_STREAMS = {}
+# priority of the preparation stream / the solve streams when they are first created (0 = default, -1 = high); A/B runs set these
+# before the first pipeline of the process is built (tools/ab_priority.py)
+PREP_STREAM_PRIORITY = 0
+SOLVE_STREAM_PRIORITY = 0
 
 
 def _side_streams(dev: torch.device, n_solve: int):
     key = (dev.index if dev.index is not None else torch.cuda.current_device())
     prep, solve = _SIDE_STREAMS.get(key, (None, []))
     if prep is None:
-        prep = torch.cuda.Stream(device=dev)
+        prep = torch.cuda.Stream(device=dev, priority=PREP_STREAM_PRIORITY)
     while len(solve) < n_solve:
-        solve.append(torch.cuda.Stream(device=dev))
+        solve.append(torch.cuda.Stream(device=dev, priority=SOLVE_STREAM_PRIORITY))
     _SIDE_STREAMS[key] = (prep, solve)
     return prep, solve[:n_solve]
 
@@ -101,7 +105,7 @@ class RegistrationPipeline:
         # candidate chunk of a resolved query is rescanned), "int8-top2" = the same with packed top-2 records (+ ~0.15 ms of
         # kernel at C2; a chunk with one row inside the bounds costs one fp32 row instead of a 48 KB rescan), "fp16" = the
         # ungated family, "auto" = chosen from the searches' own feedback (_poll_feedback)
-        if coarse not in ("auto", "int8-half", "int8", "int8-top2", "mx6", "mx6-top2", "mx6-half", "fp16"):
+        if coarse not in ("auto", "int8-half", "int8", "int8-top2", "mx6", "mx6-top2", "mx6-pilot", "mx6-half", "fp16"):
             raise ValueError("coarse must be 'auto', 'int8-half', 'int8', 'int8-top2', 'mx6', 'mx6-top2', 'mx6-half' or 'fp16'")
         if coarse in ("int8-half", "mx6-half") and not gate:
             raise ValueError("the half-width pass needs the gate")
@@ -110,8 +114,11 @@ class RegistrationPipeline:
         self.top2 = coarse == "int8-top2"   # int8 pass with packed top-2 records (VFM_RECORDS_TOP2)
         # the full-width coarse pass in microscaled fp6 (VFM_RECORDS_MX6: twice the int8 instruction's rate, ~3x wider bounds;
         # the operands are prepared with VFM_PREPARE_MX6); where the library has no kernel for it, best-score records
-        self.mx6 = coarse in ("mx6", "mx6-top2")   # "mx6-top2": the same pass with packed top-2 records (VFM_RECORDS_MX6_TOP2)
+        self.mx6 = coarse in ("mx6", "mx6-top2", "mx6-pilot")   # "mx6-top2": the same pass with packed top-2 records (VFM_RECORDS_MX6_TOP2)
         self.mx6_top2 = coarse == "mx6-top2"
+        # "mx6-pilot": VFM_RECORDS_MX6_PILOT -- one chunk per query rescanned exactly in front of the selection (about half the candidate
+        # chunks where a query has many near neighbours); `auto` turns it on above PILOT_UP rescanned chunks per query
+        self.mx6_pilot = coarse == "mx6-pilot"
         # half-width pass (VFM_RECORDS_HALF): where the library has no kernel for it the call behaves as best-score records
         # ... and where almost every chunk survives its bound (descriptors that are all alike) it is slower than the full-width
         # modes -- bounded by the library's device-side guard (csrc/match_finish.hip: above 48 survivors per query the search falls
@@ -179,7 +186,7 @@ class RegistrationPipeline:
         if b_desc.shape != (self.m, self.d):
             raise ValueError("Invalid shape")
         # a map prepared once carries the fp16 and int8 images, not the fp6 one (vfm_match_prepare): the fp6 kinds are out
-        if self.coarse in ("mx6", "mx6-top2", "mx6-half"):
+        if self.coarse in ("mx6", "mx6-top2", "mx6-pilot", "mx6-half"):
             raise ValueError("the fp6 modes prepare map and scan together in every registration: no prepare_map()")
         self._mx6_ok = self._mx6_half_ok = False
         self.mx6 = self.mx6_half = False
@@ -213,6 +220,7 @@ class RegistrationPipeline:
     RESCAN_LIMIT = 128.0
     MX6_UP = 128.0
     MX6_DOWN = 400.0
+    PILOT_UP = 1.0e9   # rescanned chunks per query above which `auto` adds the pilot rescan to the full-width fp6 pass (A/B: tools/ab_pilot.py)
     TOP2_LIMIT = 40
     REPROBE = 256       # registrations before one step back towards the cheaper kernel is probed
 
@@ -246,6 +254,9 @@ class RegistrationPipeline:
                 if self.last_rescans > self.MX6_DOWN * self.n:
                     self.mx6, self._mx6_tried = False, True
                     self._since_switch = 0
+                elif not self.mx6_pilot and self.last_rescans > self.PILOT_UP * self.n:
+                    self.mx6_pilot = True
+                    self._since_switch = 0
             elif not self.top2 and self.last_rescans > self.RESCAN_LIMIT * self.n:
                 self.top2 = True
                 self._since_switch = 0
@@ -258,7 +269,7 @@ class RegistrationPipeline:
 
     def _records(self) -> int:
         if self.mx6:
-            return 6 if self.mx6_top2 else 5   # VFM_RECORDS_MX6_TOP2 / VFM_RECORDS_MX6
+            return 6 if self.mx6_top2 else (9 if self.mx6_pilot else 5)   # VFM_RECORDS_MX6_TOP2 / VFM_RECORDS_MX6_PILOT / VFM_RECORDS_MX6
         if self.half and self.mx6_half:
             return self._mx6_half_kind         # VFM_RECORDS_MX6_HALF_FUSED (VFM_RECORDS_MX6_HALF on request)
         return self._half_kind if self.half else (1 if self.top2 else 0)   # 4 = VFM_RECORDS_HALF_FUSED (falls back to 3 / 0 inside the library)
@@ -284,7 +295,7 @@ class RegistrationPipeline:
         if reuse_map:
             # a reused map is prepared once (vfm_match_prepare2 / vfm_match_prepare below): it carries the fp16 and int8 images, not
             # the fp6 one -- its err6 would be read as infinite and an fp6 search would prune nothing.  Same rule as prepare_map().
-            if self.coarse in ("mx6", "mx6-top2", "mx6-half"):
+            if self.coarse in ("mx6", "mx6-top2", "mx6-pilot", "mx6-half"):
                 raise ValueError("the fp6 modes prepare map and scan together in every registration: no reuse_map")
             self._mx6_ok = self._mx6_half_ok = False
             self.mx6 = self.mx6_half = False
@@ -333,7 +344,7 @@ class RegistrationPipeline:
                 schedule = 1 if (records in (3, 4) or not (self.overlap and self.overlap_prepare)) else 2
                 if self._prep_schedule is not None:
                     schedule = int(self._prep_schedule)
-                if records in (5, 6):
+                if records in (5, 6, 9):
                     schedule |= 8   # VFM_PREPARE_MX6: the fp6 image as well
                 elif records in (7, 8):
                     # VFM_PREPARE_MX6_HALF: the half-width pass reads the first d / 2 columns of the fp6 image -- only those are
