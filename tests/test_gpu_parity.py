@@ -179,6 +179,36 @@ def test_match_fast_full_size_property(ops, orc):
     np.testing.assert_array_equal(sim[rows].cpu().numpy(), sim_ref)
 
 
+@pytest.mark.parametrize("n,m,d,world,gate", [(5000, 60000, 384, 2, 0.8), (3000, 70001, 768, 3, 0.8), (2500, 40000, 384, 4, None)])
+def test_map_rows_sharded_over_ranks_equal_the_unsharded_search(ops, n, m, d, world, gate):
+    """SURVEY.md 8 E, second mode (vfmreg.dist.shard_map_rows / pack_top1 / reduce_top1): the map's rows split over `world` ranks --
+    here the shards are searched one after the other on one GPU and the keys merged by the MAX an all_reduce would take (the
+    collective itself: tests/test_dist_gloo.py) --, every shard's own top-1 per query, one MAX over packed (similarity, row) keys.
+    Gated: identical kept matches and similarities; ungated: identical everywhere (ties: lower row)."""
+    from vfmreg import dist as vd, synth
+    p = synth.make_pair_device(n, m, d, seed=11)
+    q, b = p["q_desc"], p["b_desc"].clone()
+    b[m - 5] = b[7]                      # a duplicate row in another shard: the lower row has to win
+    q[3] = b[7] * 2.0
+    idx0, sim0 = ops.match_ip_top1(q, b, ops.FAST, gate=gate)
+    packed = None
+    for r in range(world):
+        lo, hi = vd.shard_map_rows(m, r, world)
+        assert hi > lo and (lo % 128 == 0)
+        il, sl = ops.match_ip_top1(q, b[lo:hi].contiguous(), ops.FAST, gate=gate)
+        k = vd.pack_top1(il, sl, lo)
+        packed = k if packed is None else torch.maximum(packed, k)
+    gi, gs = vd.unpack_top1(packed)
+    torch.cuda.synchronize()
+    assert int(gi[3]) == 7
+    if gate is None:
+        assert torch.equal(gi, idx0) and torch.equal(gs, sim0)
+    else:
+        keep0, keep = sim0 >= gate, gs >= gate
+        assert torch.equal(keep0, keep) and torch.equal(gi[keep], idx0[keep0]) and torch.equal(gs[keep], sim0[keep0])
+        assert bool((gs[(gi >= 0) & ~keep] < gate).all())
+
+
 def test_match_fast_c5_size_property(ops, orc):
     """BASELINE config C5 (stretch): 50k x 1M x 768.  Planted-match recovery on all rows, exactness against
     the accelerated oracle on a row sample, and the edge cases of the wide-descriptor kernel at small size."""

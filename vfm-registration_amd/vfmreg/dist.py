@@ -6,6 +6,10 @@ PAIRS: one process per GPU (torchrun), pair p runs on rank p mod G, no data-path
 only exchange is the final gather of the 4x4 poses (+ inlier counts): one
 ``all_gather_into_tensor`` of fp64[pairs_per_rank, 4, 4] -- backend "nccl" (= RCCL over xGMI) on
 GPUs, "gloo" in the CPU tests.  256 pairs x 128 B = 32 KB: latency-bound, topology irrelevant.
+
+Second mode (optional: one pair that must beat one GPU, e.g. config C5): the MAP's rows are split over the ranks,
+every rank searches its shard for all queries, and one ``all_reduce(MAX)`` over packed (similarity, row) keys -- N x 8 bytes --
+leaves the global top-1 of every query on every rank (``shard_map_rows`` / ``reduce_top1``).
 """
 from __future__ import annotations
 
@@ -98,3 +102,45 @@ def register_sharded(num_pairs: int, register_pair: Callable[[int], Tuple[torch.
         poses[j].copy_(T)
         aux[j:j + 1].copy_(cnt.reshape(1))
     return gather_poses(poses, aux, num_pairs, rank, world)
+
+
+def shard_map_rows(m: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous row range [lo, hi) of a map of m rows for this rank (whole 128-row chunks of the matcher except at the end)."""
+    per = ((m + world - 1) // world + 127) // 128 * 128
+    lo = min(m, rank * per)
+    return lo, min(m, lo + per)
+
+
+def pack_top1(idx_local: torch.Tensor, sim: torch.Tensor, row_offset: int) -> torch.Tensor:
+    """(index into this rank's shard, similarity) of every query -> one non-negative int64 key per query whose order is
+    "higher similarity first, then LOWER global row" (the oracle's tie rule): 32 bits of the similarity's order-preserving
+    integer image above 31 bits of (2^31 - 1 - global row).  Unresolved queries (index < 0: the gated search proved them below
+    the caller's threshold) pack as 0, below every resolved one."""
+    bits = sim.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    neg = bits >= 0x80000000
+    key32 = torch.where(neg, 0xFFFFFFFF - bits, bits + 0x80000000)          # float order -> unsigned order
+    row = idx_local.to(torch.int64) + int(row_offset)
+    packed = (key32 << 31) | (0x7FFFFFFF - row)
+    return torch.where(idx_local >= 0, packed, torch.zeros_like(packed))
+
+
+def unpack_top1(packed: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Inverse of ``pack_top1``: (global row int64, similarity fp32); key 0 -> (-1, -2.0), the gated search's "no match"."""
+    key32 = packed >> 31
+    bits = torch.where(key32 >= 0x80000000, key32 - 0x80000000, 0xFFFFFFFF - key32)
+    sim = (bits & 0xFFFFFFFF).to(torch.int64)
+    sim = torch.where(sim >= 0x80000000, sim - (1 << 32), sim).to(torch.int32).view(torch.float32)
+    row = 0x7FFFFFFF - (packed & 0x7FFFFFFF)
+    none = packed == 0
+    return torch.where(none, torch.full_like(row, -1), row), torch.where(none, torch.full_like(sim, -2.0), sim)
+
+
+def reduce_top1(idx_local: torch.Tensor, sim: torch.Tensor, row_offset: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Global top-1 per query from every rank's top-1 over its own map rows: one ``all_reduce(MAX)`` of N int64 keys (RCCL over
+    xGMI on GPUs: 160 KB at N = 20 000, 400 KB at C5's 50 000 -- microseconds).  Every rank returns the same (row, similarity);
+    identical to the unsharded search wherever that resolves the query (the similarity is the fp32 image of the exact fp64
+    score of the winning row on whichever rank holds it; ties go to the lower global row)."""
+    packed = pack_top1(idx_local, sim, row_offset)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(packed, op=dist.ReduceOp.MAX)
+    return unpack_top1(packed)
