@@ -474,6 +474,113 @@ def c2_variants(dev, lib, pairs, steps, warmup, iters, streams):
 RESIDENT_MAX = 32  # distinct scene pairs kept in HBM per rank (338 MB each); longer runs cycle through them
 
 
+def run_c3_form(args, dev, rank, world):
+    """`--form c3`: the job's scene pairs end to end from uint8 images, sharded pair p -> rank p mod N like the c2 form:
+    every rank drives one EndToEndPipeline over its resident pairs, no data-path collective, one gather of the poses at the end."""
+    import gc
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from vfmreg import dist as vdist, ops
+    from vfmreg import vit as V
+    from vfmreg.pipeline import EndToEndPipeline
+    n, m = args.n, args.m
+    B, H, W = 6, 1200, 1600
+    num_pairs = args.pairs if args.pairs > 0 else world * args.steps
+    if 0 < args.pairs < world:
+        raise SystemExit(f"--pairs {args.pairs} is smaller than the number of GPUs ({world})")
+    mine = vdist.shard_pairs(num_pairs, rank, world)
+    steps = len(mine) if args.pairs > 0 else args.steps
+    n_res = max(1, min(len(mine), 8))   # resident pairs per GPU (6 images + a 200 000 x 384 map each: 0.35 GB)
+    model = V.ViTS14(V.random_weights(0), H, W, device=dev)
+    K = np.array([[800.0, 0, 800], [0, 800, 600], [0, 0, 1]])
+    Ps = []
+    for i in range(6):
+        y = np.deg2rad(60 * i)
+        R = np.stack([[np.sin(y), -np.cos(y), 0], [0, 0, -1], [np.cos(y), np.sin(y), 0]])
+        Ps.append(K @ np.c_[R, np.zeros(3)])
+    rig = [dict(mode=ops.PROJ_KITTI, mats=[Ps[c]], fc=None, subsample=1.0, win=None, H=H, W=W, rot_mode=0) for c in range(6)]
+    pairs = []
+    for j in range(n_res):   # generated ON the owning rank from seed 42 + global pair id, resident before the timed region
+        rng = np.random.default_rng(42 + mine[j])
+        imgs = torch.from_numpy(rng.integers(1, 255, (B, H, W, 3), dtype=np.uint8)).to(dev)
+        xyz = np.c_[rng.uniform(-40, 40, n), rng.uniform(-40, 40, n), rng.uniform(-2, 6, n)]
+        pcl = torch.from_numpy(np.ascontiguousarray(np.insert(xyz, 3, 1, axis=1).T)).to(dev)
+        grids = model.forward(imgs)
+        desc = torch.empty((n, 384), dtype=torch.float32, device=dev)
+        filled = torch.zeros(n, dtype=torch.uint8, device=dev)
+        ops.LiftPlan([dict(c, proj_image=None, grid=grids[k], Hup=H, Wup=W, raw_image=imgs[k]) for k, c in enumerate(rig)], 384)(pcl, desc, filled)
+        g = torch.Generator(device=dev).manual_seed(3 + mine[j])
+        b_desc = torch.randn(m, 384, device=dev, generator=g)
+        pick = torch.randperm(m, device=dev, generator=g)[:n]
+        b_desc[pick] = desc + 0.02 * desc.abs().mean() * torch.randn(n, 384, device=dev, generator=g)
+        b_xyz = torch.rand(m, 3, device=dev, generator=g, dtype=torch.float64) * 100.0
+        q_xyz = torch.from_numpy(np.ascontiguousarray(xyz)).to(dev)
+        b_xyz[pick] = q_xyz + 0.02 * torch.randn(n, 3, device=dev, generator=g, dtype=torch.float64)
+        pairs.append(dict(imgs=imgs, pcl=pcl, q_xyz=q_xyz, b_desc=b_desc, b_xyz=b_xyz))
+    e2e = EndToEndPipeline(model, rig, n, m, n_iter=args.iters, depth=4, device=dev)
+    torch.cuda.synchronize()
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream())
+    res_T = torch.empty((steps, 4, 4), dtype=torch.float64, device=dev)
+    res_c = torch.empty((steps, 1), dtype=torch.int64, device=dev)
+
+    def step(i, keep=None):
+        p = pairs[i % n_res]
+        out = e2e.submit(p["imgs"], p["pcl"], p["q_xyz"], p["b_desc"], p["b_xyz"], inputs_ready=ready)
+        if keep is not None:
+            with torch.cuda.stream(out["result_stream"]):
+                res_T[keep].copy_(out["T"])
+                res_c[keep].copy_(out["count"])
+    vdist.gather_poses(torch.zeros((1, 4, 4), dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev), world, rank, world)
+    gc.collect()
+    gc.disable()
+    for i in range(8 + max(args.warmup, 1)):   # the policy settles (one registration at a time), then the pipelined warm-up
+        step(i)
+        e2e.reg._poll_feedback()
+        if i < 8:
+            e2e.synchronize()
+            torch.cuda.synchronize()
+    e2e.synchronize()
+    grouped = dist.is_available() and dist.is_initialized()
+    if grouped:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i, keep=i)
+    e2e.synchronize()
+    torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0
+    all_poses, all_counts = vdist.gather_poses(res_T[:steps], res_c[:steps].reshape(-1), num_pairs, rank, world)
+    torch.cuda.synchronize()
+    if grouped:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    if grouped:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    local_ids = mine[:steps] if args.pairs > 0 else [rank + world * i for i in range(steps)]
+    errs = [float(np.linalg.norm(all_poses[g].cpu().numpy() - np.eye(4))) for g in local_ids]   # the planted transform is the identity
+    if rank == 0:
+        print(json.dumps({
+            "metric": "registrations/sec from uint8 images (C3: ViT-S/14 on 6 x 1200x1600 + lifting + 20k<->200k registration)",
+            "value": num_pairs / elapsed, "unit": "registrations/s", "n_gpus": world, "steps": vdist.pairs_per_rank(num_pairs, world),
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / vdist.pairs_per_rank(num_pairs, world), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "fp16 ViT (fp32 accumulation) + the c2 form's matcher and f64 RANSAC", "data": "synthetic",
+            "config": {"workload": f"C3 form: {num_pairs} scene pair(s) end to end from uint8 images, pair p -> rank p mod N, {n_res} resident per GPU; "
+                                   f"{n}-pt scan vs {m}-pt map, {args.iters} RANSAC iterations", "scene_pairs_total": num_pairs,
+                       "records_kind": int(e2e.reg._records()), "max_pose_err_vs_planted": max(errs),
+                       "correspondences_last_step": int(all_counts[local_ids[-1]].item()),
+                       "per_rank_registrations_per_s": steps / local_elapsed,
+                       "collective": "one all_gather_into_tensor of the poses" if grouped else "none (single process, no launcher)"},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -487,6 +594,10 @@ def main():
     ap.add_argument("--n", type=int, default=N_SCAN)
     ap.add_argument("--m", type=int, default=N_MAP)
     ap.add_argument("--iters", type=int, default=RANSAC_ITERS)
+    ap.add_argument("--form", choices=("c2", "c3"), default="c2",
+                    help="c2 (default, BASELINE.json's metric): descriptors resident in HBM; c3: every pair end to end from uint8 images "
+                         "(ViT-S/14 on 6 x 1200x1600 + projection / lifting + registration, vfmreg.pipeline.EndToEndPipeline) -- with --pairs an "
+                         "N-GPU job shards end-to-end pairs the same way (information only: the headline stays the c2 form)")
     ap.add_argument("--streams", type=int, default=2,
                     help="2: RANSAC of pair i overlaps the matching of pair i+1 on a second HIP stream; 1: serial")
     args = ap.parse_args()
@@ -515,6 +626,11 @@ def main():
     if os.environ.get("VFM_SLICES"):   # A/B runs: number of map slices of the coarse pass (0 = heuristic)
         lib.vfm_debug_set_coarse_slices(int(os.environ["VFM_SLICES"]))
     n, m, d = args.n, args.m, DIM
+    if args.form == "c3":
+        run_c3_form(args, dev, rank, world)
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
+        return
     # Global scene pairs: pair p runs on rank p mod world and is generated ON ITS OWNER from
     # seed 42 + p (D.2).  They are resident in HBM before the timed region starts.
     if 0 < args.pairs < world:
