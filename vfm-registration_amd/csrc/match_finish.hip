@@ -1349,13 +1349,25 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
   for (int64_t slot = slot0; slot < nslots; slot += (int64_t)gridDim.x * 4) {
     const int64_t qi = todo ? (int64_t)todo[slot] : slot;
     if (qi >= n) return;
-    const int cnt = cand_cnt[qi];
-    if (cnt <= 0) continue;  // zero query / nothing / overflow (-1: the all-pairs kernel decides)
+    // Everything that depends on the query's index alone is requested at once -- the list's length, how much of it the chunk-major
+    // rescan appended, the query's E and 1 / |q|, the first 64 entries with their upper bounds -- and the query's row (R.init) right
+    // behind: a query had been a chain of seven dependent round trips (length -> entries -> flags -> appended count -> bounds ->
+    // entries again -> rows), 60 us per query at 9891 queries on 4096 waves.
     unsigned* mycand = cand + (size_t)qi * cap;
+    const float* myup = cand_up ? cand_up + (size_t)qi * cap : nullptr;
+    const int cnt = cand_cnt[qi];
+    const int hits = cand_up ? (int)hit_cnt[(size_t)qi * BIN_CNT_STRIDE] : 0;
+    const float eq = cand_up ? ib.qerr[qi] : 0.0f;
+    const float iq = invq[qi];
+    const unsigned ce0 = mycand[lane];                  // (cap >= 64: the first 64 slots exist whatever the length)
+    const float up0 = cand_up ? myup[lane] : 0.0f;
+    if (cnt <= 0) continue;  // zero query / nothing / overflow (-1: the all-pairs kernel decides)
     // wave-uniform: is this list crowded?
-    bool flagged = false;
-    for (int e = lane; e < cnt; e += 64) flagged |= (mycand[e] & 128u) != 0u;
+    bool flagged = lane < cnt && (ce0 & 128u) != 0u;
+    for (int e = 64 + lane; e < cnt; e += 64) flagged |= (mycand[e] & 128u) != 0u;
     if (cnt < REFINE_MIN && !__any(flagged)) continue;
+    RefineWave<NT> R;
+    R.init(q, iq, qi, b, invb, d, w2, l_row[wave], l_sc[wave]);
     // The rows the chunk-major rescan appended (the last hit_cnt entries of the list) carry the upper bound U = s_q s_c S + A + B_c of
     // their exact score (cand_up), S their exact integer score; U - 2 (A + B_c) is a LOWER bound of the same score.  The rescans tested
     // a row against the coarse pass's lower bound of the query's maximum -- the fp6 image's, 0.06 below the maximum on unit rows, so
@@ -1364,33 +1376,32 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
     // dropped has U < L <= the exact score of another row of the list: it is not the arg-max and does not tie with it.
     int split = cnt;        // first appended entry
     float lowest = -__builtin_inff();
-    const float* myup = cand_up ? cand_up + (size_t)qi * cap : nullptr;
     if (cand_up) {
-        const int hits = (int)hit_cnt[(size_t)qi * BIN_CNT_STRIDE];
         split = cnt - hits < 0 ? 0 : cnt - hits;
-        const float eq = ib.qerr[qi];
         const float A = eq * 1.0001220703125f + 1.0e-6f, mult = 1.0001220703125f + eq;
-        for (int e = split + lane; e < cnt; e += 64) {
+        if (lane >= split && lane < cnt) {
+            const float bnd = A + mult * ib.berr[ce0 >> 8];
+            if (up0 < 3.0e38f) lowest = (up0 - 2.0f * bnd) - 4.0e-6f;   // (fp32 evaluation of U and of this line: a few 1e-7)
+        }
+        for (int e = (split > 64 ? split : 64) + lane; e < cnt; e += 64) {
             const float u = myup[e];
             const float bnd = A + mult * ib.berr[mycand[e] >> 8];
-            if (u < 3.0e38f) lowest = fmaxf(lowest, (u - 2.0f * bnd) - 4.0e-6f);   // (fp32 evaluation of U and of this line: a few 1e-7)
+            if (u < 3.0e38f) lowest = fmaxf(lowest, (u - 2.0f * bnd) - 4.0e-6f);
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) lowest = fmaxf(lowest, __shfl_xor(lowest, off));
     }
-    RefineWave<NT> R;
-    R.init(q, invq[qi], qi, b, invb, d, w2, l_row[wave], l_sc[wave]);
     // single-row entries: 4 per pass, 64 list entries per load, the next pass's rows in flight under the current pass's sums (a
     // pass had been two dependent round trips -- the entry, then the row --: 164 us at the 25 rows per query of lifted descriptors)
     for (int e0 = 0; e0 < cnt; e0 += 64) {
         const int nblk = cnt - e0 < 64 ? cnt - e0 : 64;
         long long myrow = -1;
         if (lane < nblk) {
-            const unsigned ce = mycand[e0 + lane];
+            const unsigned ce = e0 == 0 ? ce0 : mycand[e0 + lane];
             if (!(ce & 128u)) {
                 myrow = (long long)(ce >> 8) * CHUNK_ROWS + (ce & 127u);
                 if (myrow >= m) myrow = -1;
-                if (e0 + lane >= split && myup[e0 + lane] < lowest) myrow = -1;
+                if (e0 + lane >= split && (e0 == 0 ? up0 : myup[e0 + lane]) < lowest) myrow = -1;
             }
         }
         if (!__any(myrow >= 0)) continue;
