@@ -92,3 +92,26 @@ def test_vit_lds_tiled_gemms_equal_the_direct_kernels_bit_for_bit():
         _check(w, _smooth_images(np.random.default_rng(0), 9, 300, 400), atol=1e-2, cos_min=0.99999)
     finally:
         lib.vfm_debug_set_vit_gemm(-5, 256)
+
+
+def test_vit_attention_with_keys_and_values_in_the_lds_equals_the_per_tile_kernel_bit_for_bit():
+    """vit_attention_lds_kernel (K / V^T of an (image, head) staged once per workgroup, four query tiles per workgroup) against the
+    one-wave-per-tile kernel: the same MFMAs over the same fragments in the same order -- identical bits; token counts whose last group
+    has one, two or three query tiles (9, 10, 11 tiles), one image and several."""
+    from vfmreg import _lib
+    from vfmreg import vit as V
+    lib = _lib.load()
+    try:
+        for (dim, depth, mlp, B, H, W) in ((384, 2, 1536, 5, 560, 700), (384, 1, 1536, 1, 1200, 1600), (768, 1, 3072, 2, 560, 600),
+                                           (384, 12, 1536, 6, 1200, 1600)):
+            w = V.random_weights(seed=13, dim=dim, depth=depth, mlp=mlp)
+            imgs = torch.from_numpy(_smooth_images(np.random.default_rng(4), B, H, W)).cuda()
+            model = V.ViTS14(w, H, W, device="cuda")
+            lib.vfm_debug_set_vit_gemm(-7, 0)        # never
+            per_tile = model.forward(imgs).clone()
+            lib.vfm_debug_set_vit_gemm(-7, 1)        # always
+            shared = model.forward(imgs).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(per_tile, shared), (dim, B, H, W, float((per_tile - shared).abs().max()))
+    finally:
+        lib.vfm_debug_set_vit_gemm(-7, 1)

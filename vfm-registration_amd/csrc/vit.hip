@@ -706,6 +706,139 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const uint4* __restr
     }
 }
 
+// ---- the same attention with K and V^T of an (image, head) shared by four query tiles through the LDS
+template <int NKT>
+__global__ __launch_bounds__(256) void vit_attention_lds_kernel(const uint4* __restrict__ Q, const uint4* __restrict__ K,
+                                                                const uint4* __restrict__ VT, int T, int Tp, int heads, int D,
+                                                                _Float16* __restrict__ out) {
+    // The four waves of a workgroup take four query tiles of ONE (image, head) and share its K and V^T through the LDS: both are
+    // NKT x 4 KiB of consecutive fragment rows in global memory (8 KiB per key tile together: 88 KiB at 352 tokens), copied once per
+    // workgroup by LDS-DMA.  The one-wave-per-tile kernel above fetches every fragment from the L2 in every wave: 11 waves per
+    // (image, head) read the same 88 KiB -- 545 MB per layer at 96 images, what that kernel's 93 us consist of.
+    extern __shared__ __attribute__((aligned(16))) unsigned char att_lds[];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qtiles = Tp / 32, ngroups = (qtiles + 3) / 4;
+    const int bh = blockIdx.x / ngroups, qt = (blockIdx.x % ngroups) * 4 + wave;
+    const int b = bh / heads, head = bh % heads;
+    const size_t base = (size_t)bh * Tp * 64 / 8;  // uint4 units per (b, head)
+    {
+        const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)att_lds;
+        // 1 KiB pieces: NKT x 4 of K, then as many of V^T; wave w issues pieces w, w + 4, ... of each -- NKT per wave and operand, K first,
+        // so that "at most NKT of my loads in flight" means this wave's share of K has landed while V^T is still on its way
+        // (the wave's own query tile goes the same way, first: a compiler-tracked load would be waited for with vmcnt(0) at its first
+        // use -- the compiler does not see the DMA behind it -- and V^T would be waited for with it)
+        const int qt_ = qt < qtiles ? qt : qtiles - 1;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+            vit_glds16(Q + base + ((size_t)qt_ * 4 + s4) * 64 + lane,
+                       __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(NKT * 8 + wave * 4 + s4) * 1024u));
+#pragma unroll
+        for (int i = 0; i < NKT; ++i)
+            vit_glds16(K + base + (size_t)(wave + 4 * i) * 64 + lane, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave + 4 * i) * 1024u));
+#pragma unroll
+        for (int i = 0; i < NKT; ++i)
+            vit_glds16(VT + base + (size_t)(wave + 4 * i) * 64 + lane,
+                       __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(NKT * 4 + wave + 4 * i) * 1024u));
+    }
+    const uint4* K_l = reinterpret_cast<const uint4*>(att_lds);
+    const uint4* VT_l = reinterpret_cast<const uint4*>(att_lds + (size_t)NKT * 4096);
+    const bool active = qt < qtiles;   // (the last group of an image may have fewer than four tiles: those waves only stage)
+    // Q^T as B operand: query tile qt, 4 k-steps over d
+    vit_wait_vmcnt<NKT>();   // the query tile and K are here (V^T lands under the scores and the softmax)
+    __syncthreads();
+    half8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        uint4 v = reinterpret_cast<const uint4*>(att_lds + (size_t)(NKT * 8 + wave * 4 + s) * 1024)[lane];
+        qf[s] = *reinterpret_cast<half8*>(&v);
+    }
+    // S^T tiles: rows = keys, column = query (lane & 31)
+    floatx16 S[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint4 v = K_l[((size_t)kt * 4 + s) * 64 + lane];
+            S[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&v), qf[s], S[kt], 0, 0, 0);
+        }
+    }
+    const int hi = lane >> 5;
+    // softmax over keys (scale 1/8), keys >= T masked
+    const float scale = 0.125f * 1.44269504088896340736f;  // fold log2(e): exp(x) = exp2(x*log2e)
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float s = (key < T) ? S[kt][r] * scale : -3.0e38f;
+            S[kt][r] = s;
+            mx = fmaxf(mx, s);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = exp2f(S[kt][r] - mx);
+            S[kt][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    vit_wait_vmcnt<0>();   // V^T
+    __syncthreads();
+    if (!active) return;
+    // O^T[d][query] = sum_keys V^T[d][key] P^T[key][query]: A = V^T fragment, B = P^T in registers.
+    floatx16 O0, O1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { O0[r] = 0.f; O1[r] = 0.f; }
+    const int vks = Tp / 16;  // k-steps over keys
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            // keys 16*(2kt+s2) .. +15: register groups g = 2*s2, 2*s2+1 of tile kt.
+            // lanes 0-31 hold keys 8g..8g+3, lanes 32-63 keys 8g+4..8g+7 of each group (packed 2x fp16x2)
+            unsigned x0 = pack_f16x2(S[kt][8 * s2 + 0], S[kt][8 * s2 + 1]);
+            unsigned x1 = pack_f16x2(S[kt][8 * s2 + 2], S[kt][8 * s2 + 3]);
+            unsigned y0 = pack_f16x2(S[kt][8 * s2 + 4], S[kt][8 * s2 + 5]);
+            unsigned y1 = pack_f16x2(S[kt][8 * s2 + 6], S[kt][8 * s2 + 7]);
+            // swap upper half of x with lower half of y: lower lanes end with keys 16s..16s+7,
+            // upper lanes with keys 16s+8..16s+15 -- the B-operand layout (k = 8*(lane>>5) + e)
+            auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+            uint4 pb;
+            pb.x = r0[0]; pb.y = r1[0]; pb.z = r0[1]; pb.w = r1[1];
+            const half8 pf = *reinterpret_cast<half8*>(&pb);
+            const int ks = kt * 2 + s2;
+            uint4 v0 = VT_l[((size_t)0 * vks + ks) * 64 + lane];
+            uint4 v1 = VT_l[((size_t)1 * vks + ks) * 64 + lane];
+            O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&v0), pf, O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&v1), pf, O1, 0, 0, 0);
+        }
+    }
+    // write O[query][head*64 + d] as fragment tiles of the [M][D] activation for the proj GEMM
+    const int t = qt * 32 + (lane & 31);
+    const int m = b * Tp + t;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const floatx16& O = half ? O1 : O0;
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const int dd = half * 32 + 8 * grp + 4 * hi;
+            half4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (_Float16)(O[grp * 4 + j] * inv);
+            *reinterpret_cast<half4*>(out + frag_index(m, head * 64 + dd, D / 16)) = o;
+        }
+    }
+}
+
 struct VitWs {
     float* x;          // [M][D] fp32 residual
     _Float16* a;       // [M][max(D, KP)] fragment tiles (im2col / attention out)
@@ -765,6 +898,7 @@ int launch_gemm_cfg(const GemmArgs& g, hipStream_t st) {
 // tiles everywhere (twice the waves) give 0.76 instead of 0.82 ms, 64 x 64 wave tiles and row-complete workgroups with the
 // LayerNorm fused into the epilogue (63 launches, but 66 workgroups per GEMM) gave 1.04 ms and were removed again.
 int g_vit_lds_shape = 24;     // vfm_debug_set_vit_gemm(-6, KB * 10 + NS): k-steps per stage / stages in the ring of the LDS-tiled kernel
+int g_vit_att_lds_min = 1;   // vfm_debug_set_vit_gemm(-7, n): attention with K / V^T in the LDS from n images per call on (0 = never)
 int g_vit_lds_min_wg = 256;   // vfm_debug_set_vit_gemm(-5, n): the LDS-tiled kernel from n workgroups of 128 x 128 on (0 = never)
 template <int EPI>
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
@@ -813,6 +947,10 @@ VFM_EXPORT int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg) {
     }
     if (narrow_cfg == -6) {
         g_vit_lds_shape = wide_cfg;
+        return VFM_OK;
+    }
+    if (narrow_cfg == -7) {   // attention with K / V^T of an (image, head) in the LDS from wide_cfg images per call on (0: never)
+        g_vit_att_lds_min = wide_cfg;
         return VFM_OK;
     }
     if (narrow_cfg == -5) {   // the LDS-tiled GEMM kernel from wide_cfg workgroups on (0: never; default 256)
@@ -876,6 +1014,9 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
     int rc = launch_gemm<EPI_PATCH>(g, st);
     if (rc) return rc;
     const int att_work = d.B * d.heads * (d.Tp / 32);
+    // K / V^T of an (image, head) shared by four query tiles through the LDS from g_vit_att_lds_min images on (0: never): at one scan the
+    // one-wave-per-tile kernel's 396 waves spread over the chip win, at batches the shared form reads a quarter of the L2 bytes
+    const bool att_lds = g_vit_att_lds_min > 0 && d.B >= g_vit_att_lds_min && d.Tp / 32 <= 16;
     for (int l = 0; l < d.depth; ++l) {
         const int s0 = SEG_LAYER0 + l * SEGS_PER_LAYER;
         // LayerNorm 1 is inside this GEMM: raw residual stream x folded weight, statistics applied in the epilogue
@@ -883,6 +1024,19 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
         g.N = 3 * d.D; g.KS = d.D / 16;
         if ((rc = launch_gemm<EPI_QKV>(g, st))) return rc;
 #define VIT_ATT(NKT)                                                                                                      \
+    if (att_lds) {                                                                                                        \
+        static unsigned long long attr_set = 0ull;                                                                        \
+        int dev_ = 0;                                                                                                     \
+        (void)hipGetDevice(&dev_);                                                                                        \
+        if (!((attr_set >> (dev_ & 63)) & 1ull)) {                                                                        \
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_attention_lds_kernel<NKT>),             \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, NKT * 8192 + 16384));           \
+            attr_set |= 1ull << (dev_ & 63);                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(vit_attention_lds_kernel<NKT>, dim3(d.B * d.heads * ((d.Tp / 32 + 3) / 4)), dim3(256), NKT * 8192 + 16384, st, \
+                           reinterpret_cast<const uint4*>(w.q), reinterpret_cast<const uint4*>(w.k),                      \
+                           reinterpret_cast<const uint4*>(w.vt), d.T, d.Tp, d.heads, d.D, w.a);                           \
+    } else                                                                                                                \
     hipLaunchKernelGGL(vit_attention_kernel<NKT>, dim3(att_grid), dim3(256), 0, st,                                       \
                        reinterpret_cast<const uint4*>(w.q), reinterpret_cast<const uint4*>(w.k),                          \
                        reinterpret_cast<const uint4*>(w.vt), d.T, d.Tp, d.heads, d.D, att_work, w.a, g_vit_xcd)
