@@ -1,4 +1,4 @@
-# PMC passes for the ViT kernels (6 x 1200 x 1600, ViT-S/14) -> gpurun_out/pmc_vit/summary.json
+# PMC passes for the ViT kernels (\$VIT_IMAGES x 1200 x 1600, default 6, ViT-S/14) -> gpurun_out/pmc_vit/summary.json
 # Separate --pmc passes with --kernel-trace only (MI355X_MICROARCH.md, rocprofv3 section).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -10,15 +10,18 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
            "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O -o p$i -- python $R/tools/prof_vit.py ${DEFAULT_TILES:-1} 3 > $O/log$i.txt 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O -o p$i -- python $R/tools/prof_vit.py ${DEFAULT_TILES:-1} 3 ${VIT_IMAGES:-6} > $O/log$i.txt 2>&1
   echo "pass $i ($set): rc=$?"
 done
 python - <<PY
 import csv, glob, collections, json
 agg = collections.defaultdict(lambda: collections.defaultdict(list)); dur = collections.defaultdict(list)
 def short(n):
-    for k in ("vit_gemm_kernel<1", "vit_gemm_kernel<2", "vit_gemm_kernel<3", "vit_gemm_kernel<0", "vit_attention", "vit_layernorm", "vit_final", "vit_preprocess", "vit_gemm64", "vit_gemm_row"):
-        if k in n: return {"vit_gemm_kernel<1": "gemm QKV", "vit_gemm_kernel<2": "gemm proj/fc2 (+residual)", "vit_gemm_kernel<3": "gemm fc1 (+GELU)", "vit_gemm_kernel<0": "gemm patch embed"}.get(k, k)
+    names = {"vit_gemm_kernel<1": "gemm QKV", "vit_gemm_kernel<2": "gemm proj/fc2 (+residual)", "vit_gemm_kernel<3": "gemm fc1 (+GELU)", "vit_gemm_kernel<0": "gemm patch embed",
+             "vit_gemm_lds_kernel<1": "gemm QKV (LDS-tiled)", "vit_gemm_lds_kernel<2": "gemm proj/fc2 (+residual) (LDS-tiled)", "vit_gemm_lds_kernel<3": "gemm fc1 (+GELU) (LDS-tiled)",
+             "vit_gemm_lds_kernel<0": "gemm patch embed (LDS-tiled)", "vit_attention_lds": "attention (K / V^T in the LDS)"}
+    for k in ("vit_gemm_lds_kernel<1", "vit_gemm_lds_kernel<2", "vit_gemm_lds_kernel<3", "vit_gemm_lds_kernel<0", "vit_gemm_kernel<1", "vit_gemm_kernel<2", "vit_gemm_kernel<3", "vit_gemm_kernel<0", "vit_attention_lds", "vit_attention", "vit_layernorm", "vit_final", "vit_preprocess", "vit_gemm64", "vit_gemm_row"):
+        if k in n: return names.get(k, k)
     return None
 for f in sorted(glob.glob("$O/p*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):

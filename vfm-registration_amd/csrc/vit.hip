@@ -260,14 +260,40 @@ __device__ __forceinline__ void ln_stats_load(const GemmArgs& g, int m, float& l
     const float var = fmaxf(sq / (float)g.D - ln_mean * ln_mean, 0.0f);
     ln_rstd = rsqrtf(var + 1e-6f);
 }
+// Index arithmetic (round 4, from the counters: profiles/r04_pmc_vit_96images.json): a wave of the QKV GEMM issued 1635 VALU and 1010 SALU
+// instructions for its 96 MFMAs -- the epilogue computed every group's destination with runtime integer divisions (n0 / D, n0 % D, m / Tp)
+// and 64-bit frag_index() chains, ~100 instructions per group of four channels.  A 32 x 32 output tile lies inside one (q | k | v, head)
+// and one token tile of one image, so everything but the lane's own offset inside a fragment row is uniform: mt (token tile), tq (token
+// tile inside its image), b, n32 come in as scalars and the destinations are   base(tile) + grp * 256 + lane_off.
 template <int EPI>
-__device__ __forceinline__ void epi_tile(const GemmArgs& g, const floatx16& acc, int m, int b, int t, int hi, int n32, const EpiRegs& e,
-                                         float ln_mean, float ln_rstd) {
+__device__ __forceinline__ void epi_tile(const GemmArgs& g, const floatx16& acc, int m, int mt, int b, int tq, int t, int hi, int n32,
+                                         const EpiRegs& e, float ln_mean, float ln_rstd) {
     constexpr bool CONSUMES_LN = EPI == EPI_QKV || EPI == EPI_GELU, PRODUCES_LN = EPI == EPI_PATCH || EPI == EPI_RESID;
     float psum = 0.f, psq = 0.f;   // PRODUCES_LN: this lane's share of the slice's (sum x, sum x^2)
+    const int lane31 = lane_id() & 31;
+    const unsigned lane_off = (unsigned)lane31 * 8u + 4u * (unsigned)hi;   // halves: row lane31 of a 32 x 8 fragment row, elements 4 hi ..
+    // fragment-tiled [M][K] matrix with ks = K / 16 k-steps: element (m, n0 .. n0 + 3) of this lane and group sits at
+    //   ((mt * ks * 2 + n32 * 4 + grp) * 256 + lane_off   (= frag_index(m, n0, ks))
+    _Float16* frag_base = nullptr;
+    if constexpr (PRODUCES_LN) frag_base = g.xh + ((size_t)mt * (unsigned)(g.D / 16) * 2u + (unsigned)n32 * 4u) * 256u + lane_off;
+    if constexpr (EPI == EPI_GELU) frag_base = g.out + ((size_t)mt * (unsigned)(g.N / 16) * 2u + (unsigned)n32 * 4u) * 256u + lane_off;
+    _Float16* qk_base = nullptr;     // EPI_QKV, q or k: [b * heads + head][Tp][64] fragment-tiled, 4 k-steps
+    _Float16* vt_base = nullptr;     // EPI_QKV, v: V^T [b * heads + head][64][Tp] fragment-tiled, Tp / 16 k-steps
+    if constexpr (EPI == EPI_QKV) {
+        const int hg = n32 >> 1;                                  // 64-channel unit = (which, head)
+        const int which = hg >= 2 * g.heads ? 2 : (hg >= g.heads ? 1 : 0);
+        const int head = hg - which * g.heads;
+        const size_t bh_off = ((size_t)b * g.heads + head) * (size_t)g.Tp * 64;
+        if (which < 2)   // (tq * 4 + s) * 2 + h with s = (n32 & 1) * 2 + (grp >> 1), h = grp & 1
+            qk_base = (which == 0 ? g.q : g.k) + bh_off + ((unsigned)tq * 8u + (unsigned)(n32 & 1) * 4u) * 256u + lane_off;
+        else             // row d = (n32 & 1) * 32 + 8 grp + 4 hi + j, key t: tile n32 & 1, k-step 2 tq + (lane31 >> 4), half (lane31 >> 3) & 1
+            vt_base = g.vt + bh_off + ((unsigned)(n32 & 1) * (unsigned)(g.Tp / 16) * 2u + (unsigned)tq * 4u + (unsigned)(lane31 >> 3)) * 256u +
+                      (unsigned)(4 * hi) * 8u + (unsigned)(lane31 & 7);
+    }
+    float* xrow = nullptr;
+    if constexpr (PRODUCES_LN) xrow = g.x + (size_t)m * g.D + n32 * 32 + 4 * hi;
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
-        const int n0 = n32 * 32 + 8 * grp + 4 * hi;  // 4 consecutive channels n0..n0+3
         const float bi[4] = {e.bias[grp].x, e.bias[grp].y, e.bias[grp].z, e.bias[grp].w};
         const float au[4] = {e.aux[grp].x, e.aux[grp].y, e.aux[grp].z, e.aux[grp].w};
         float v[4];
@@ -278,7 +304,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const floatx16& acc,
         }
         if constexpr (PRODUCES_LN) {
             float4 o = e.x[grp];   // the token's new residual values (padding rows stay exactly zero)
-            float4* xp = reinterpret_cast<float4*>(g.x + (size_t)m * g.D + n0);
+            float4* xp = reinterpret_cast<float4*>(xrow + 8 * grp);
             if constexpr (EPI == EPI_PATCH) {
                 if (t != 0 && t < g.T) o = make_float4(v[0] + o.x, v[1] + o.y, v[2] + o.z, v[3] + o.w);   // (t == 0: cls + pos[0] as loaded)
                 *xp = o;
@@ -289,28 +315,23 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const floatx16& acc,
             }
             half4 oh;
             oh[0] = (_Float16)o.x; oh[1] = (_Float16)o.y; oh[2] = (_Float16)o.z; oh[3] = (_Float16)o.w;
-            *reinterpret_cast<half4*>(g.xh + frag_index(m, n0, g.D / 16)) = oh;
+            *reinterpret_cast<half4*>(frag_base + grp * 256) = oh;
             psum += (o.x + o.y) + (o.z + o.w);
             psq += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
         } else if constexpr (EPI == EPI_GELU) {
             half4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (_Float16)gelu_exact(v[j]);
-            *reinterpret_cast<half4*>(g.out + frag_index(m, n0, g.N / 16)) = o;
-        } else {  // EPI_QKV: channel n0 -> (which, head, d)
-            const int which = n0 / g.D, rem = n0 % g.D, head = rem / 64, dd = rem % 64;
-            const size_t bh = (size_t)b * g.heads + head;
-            if (which < 2) {
+            *reinterpret_cast<half4*>(frag_base + grp * 256) = o;
+        } else {  // EPI_QKV
+            if (qk_base) {
                 half4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[j];
-                _Float16* dst = (which == 0 ? g.q : g.k) + bh * (size_t)g.Tp * 64;
-                *reinterpret_cast<half4*>(dst + frag_index(t, dd, 4)) = o;
+                *reinterpret_cast<half4*>(qk_base + grp * 256) = o;
             } else {
-                // V^T fragment tiles: rows = d (64), k = key index (Tp); element (d, key = t)
-                _Float16* dst = g.vt + bh * (size_t)g.Tp * 64;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dst[frag_index(dd + j, t, g.Tp / 16)] = (_Float16)v[j];
+                for (int j = 0; j < 4; ++j) vt_base[(8 * grp + j) * 8] = (_Float16)v[j];
             }
         }
     }
@@ -350,7 +371,8 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
             for (int j = 0; j < NT; ++j) rw[j][i] = Wp[((size_t)j * g.KS + i) * 64];
         }
     const int m = mt * 32 + (lane & 31);
-    const int b = m / g.Tp, t = m % g.Tp;
+    const int mtu = __builtin_amdgcn_readfirstlane(mt), qtiles = g.Tp >> 5;   // (a token tile lies inside one image: Tp % 32 == 0)
+    const int b = mtu / qtiles, tq = mtu - b * qtiles, t = tq * 32 + (lane & 31);
     const int hi = lane >> 5;
     // Everything the epilogue reads is requested HERE, behind the first operand fragments and in front of the k-loop (round 4): as
     // the epilogue's own loads -- bias, row sums, LayerScale, the residual values, twelve partial sums in a loop the compiler could
@@ -378,7 +400,8 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
         }
     }
 #pragma unroll
-    for (int half = 0; half < NT; ++half) epi_tile<EPI>(g, acc[half], m, b, t, hi, nt * NT + half, e[half], ln_mean, ln_rstd);
+    for (int half = 0; half < NT; ++half)
+        epi_tile<EPI>(g, acc[half], m, mtu, b, tq, t, hi, __builtin_amdgcn_readfirstlane(nt * NT + half), e[half], ln_mean, ln_rstd);
 }
 
 // ---- the same product with workgroup tiles of 128 tokens x 128 channels staged through the LDS (round 4): for
@@ -479,15 +502,16 @@ __global__ __launch_bounds__(256) void vit_gemm_lds_kernel(GemmArgs g) {
         const int mt = mg * 4 + 2 * wm + i;
         if (mt >= mtiles) continue;   // wave-uniform
         const int m = mt * 32 + (lane & 31);
-        const int b = m / g.Tp, t = m % g.Tp;
+        const int mtu = __builtin_amdgcn_readfirstlane(mt), qtiles = g.Tp >> 5;
+        const int b = mtu / qtiles, tq = mtu - b * qtiles, t = tq * 32 + (lane & 31);
         float ln_mean = 0.f, ln_rstd = 1.f;
         if constexpr (EPI == EPI_QKV || EPI == EPI_GELU) ln_stats_load(g, m, ln_mean, ln_rstd);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int n32 = ng * 4 + 2 * wn + j;
+            const int n32 = __builtin_amdgcn_readfirstlane(ng * 4 + 2 * wn + j);
             EpiRegs e;
             epi_load<EPI>(g, m, t, hi, n32, e);
-            epi_tile<EPI>(g, acc[i][j], m, b, t, hi, n32, e, ln_mean, ln_rstd);
+            epi_tile<EPI>(g, acc[i][j], m, mtu, b, tq, t, hi, n32, e, ln_mean, ln_rstd);
         }
     }
 }
@@ -643,8 +667,13 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const uint4* __restr
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float s = (key < T) ? S[kt][r] * scale : -3.0e38f;
+            // (only the last key tile holds padding -- Tp - T < 32 --: the others are scaled without the test; per wave the softmax is
+            // 176 values per lane, and at one wave per SIMD every instruction of it is kernel time)
+            float s = S[kt][r] * scale;
+            if (kt == NKT - 1) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                s = (key < T) ? s : -3.0e38f;
+            }
             S[kt][r] = s;
             mx = fmaxf(mx, s);
         }
@@ -654,7 +683,7 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const uint4* __restr
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = exp2f(S[kt][r] - mx);
+            const float p = __builtin_amdgcn_exp2f(S[kt][r] - mx);   // (v_exp_f32: arguments <= 0, a result below 2^-126 is 0 either way)
             S[kt][r] = p;
             sum += p;
         }
@@ -773,8 +802,13 @@ __global__ __launch_bounds__(256) void vit_attention_lds_kernel(const uint4* __r
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float s = (key < T) ? S[kt][r] * scale : -3.0e38f;
+            // (only the last key tile holds padding -- Tp - T < 32 --: the others are scaled without the test; per wave the softmax is
+            // 176 values per lane, and at one wave per SIMD every instruction of it is kernel time)
+            float s = S[kt][r] * scale;
+            if (kt == NKT - 1) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                s = (key < T) ? s : -3.0e38f;
+            }
             S[kt][r] = s;
             mx = fmaxf(mx, s);
         }
@@ -784,7 +818,7 @@ __global__ __launch_bounds__(256) void vit_attention_lds_kernel(const uint4* __r
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = exp2f(S[kt][r] - mx);
+            const float p = __builtin_amdgcn_exp2f(S[kt][r] - mx);   // (v_exp_f32: arguments <= 0, a result below 2^-126 is 0 either way)
             S[kt][r] = p;
             sum += p;
         }
