@@ -33,7 +33,11 @@ int vfm_prof_events_destroy(void *start, void *stop);
  * sparse fp16 records for d <= 384, dense fp16 records elsewhere; 1 = 8 waves x 32 queries, 2 = 4 waves x 64, 4 = pipelined
  * kernel with dense fp16 records, 5 = the fp16 pass in the gated family too, 7 = 5 without seed units, 12 = int8 kernel with
  * 32 resident queries per wave at every size, 10 = 12 with two tiles per step at every width, 20 = default kernels with the
- * general selection kernel on best-score records too, 21 = default kernels without the chunk-major rescan) */
+ * general selection kernel on best-score records too, 21 = default kernels without the chunk-major rescan).
+ * Values that switch one thing and leave the rest as it is (round 4): 30 / 31 = fused fp6 half-width kernel with one (default) / two
+ * chunks per barrier; 40 / 41 = fp6 operand preparation by prep_chunk_kernel (rows in registers) / prep_stream_kernel (default);
+ * 50 / 51 = chunk-major rescan and fp32 refinement as long-lived (default) / short-lived workgroups; 60 / 61 = the chunk-major rescan
+ * gathers its queries from the int8 fragment tiles / from the row-major int8 scan (default) */
 int vfm_debug_set_coarse_variant(int qsets);
 /* A/B: force the number of map slices of the coarse pass (0 = heuristic) */
 int vfm_debug_set_coarse_slices(int slices);
@@ -43,7 +47,9 @@ int vfm_debug_match_stats(void *ws, int64_t n, int64_t m, int32_t *out64_host);
 /* the counters are collected only while this switch is on (they cost same-address atomics) */
 int vfm_debug_set_match_stats(int on);
 /* A/B: ViT GEMM wave tile / prefetch depth: NT * 100 + PF for N <= 512 and N > 512 (see csrc/vit.hip); narrow_cfg = -3 / -4:
- * XCD-consistent tile mapping of the ViT kernels on (default) / off */
+ * XCD-consistent tile mapping of the ViT kernels on (default) / off; -5: the LDS-tiled GEMM from wide_cfg workgroups of 128 x 128 on
+ * (0 = never, default 256); -6: its stage shape, k-steps per stage * 10 + stages (default 24); -7: attention with K / V^T shared through
+ * the LDS from wide_cfg images per call on (0 = never, default 1) */
 int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
 /* A/B: workgroups of the int8 operand-preparation kernel (-1, default = one per 128-row group; 0 = one per compute unit, each
  * walking several groups with the next group's rows read under the current group's quantisation and store: faster alone,
