@@ -507,11 +507,14 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
     }
     __syncthreads();
     float2* lchunk = reinterpret_cast<float2*>(select_smem);
+    unsigned* lhist = reinterpret_cast<unsigned*>(lchunk + nchunks);   // chunk_lds == 2: the tile's candidates per chunk, then the bins' positions
+    const bool hist = chunk_lds == 2 && bins != nullptr;
     if (chunk_lds) {
         float me = 0.0f;
         for (int c = threadIdx.x; c < nchunks; c += 64 * SELECT_BEST_WAVES) {
             const float2 v = make_float2(ib.bstep[c], ib.berr[c]);
             lchunk[c] = v;
+            if (hist) lhist[c] = 0u;
             me = fmaxf(me, v.y);
         }
 #pragma unroll
@@ -607,6 +610,53 @@ __global__ __launch_bounds__(64 * SELECT_BEST_WAVES) void match_select_best_kern
     {
         const int ncand = lcand_n < SELECT_BEST_LCAND ? lcand_n : SELECT_BEST_LCAND;
         const bool crowded = lcand_n > 32 * 64;
+        if (hist) {
+            // One atomic per chunk and tile instead of one per candidate: the tile's candidates are counted per chunk in the LDS (a
+            // candidate keeps its rank there: at most 32 queries of a tile share a chunk), the chunk's bin is asked once for that many
+            // places, and every candidate takes base + rank.  (920 000 returning atomics on 1564 counters were 40 of the kernel's
+            // 105 us on lifted descriptors with a common component; what this form leaves depends on how many of a tile's candidates share their chunks.)
+            for (int i = threadIdx.x; i < ncand; i += 64 * SELECT_BEST_WAVES) {
+                const unsigned e = lcand[i];
+                const unsigned rank = atomicAdd(&lhist[e & 0xFFFFu], 1u);
+                lcand[i] = e | (rank << 16);
+            }
+            __syncthreads();
+            constexpr int PU = 4;
+            for (int c0 = threadIdx.x; c0 < nchunks; c0 += 64 * SELECT_BEST_WAVES * PU) {
+                unsigned want[PU], pos[PU];
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    const int c = c0 + 64 * SELECT_BEST_WAVES * u;
+                    want[u] = c < nchunks ? lhist[c] : 0u;
+                    pos[u] = 0u;
+                }
+                if (crowded) {
+#pragma unroll
+                    for (int u = 0; u < PU; ++u)
+                        if (want[u]) pos[u] = __hip_atomic_load(&bin_cnt[(size_t)(c0 + 64 * SELECT_BEST_WAVES * u) * BIN_CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int u = 0; u < PU; ++u)
+                    if (want[u] && pos[u] < (unsigned)bin_cap)
+                        pos[u] = __hip_atomic_fetch_add(&bin_cnt[(size_t)(c0 + 64 * SELECT_BEST_WAVES * u) * BIN_CNT_STRIDE], want[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int u = 0; u < PU; ++u)
+                    if (want[u]) lhist[c0 + 64 * SELECT_BEST_WAVES * u] = pos[u];
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < ncand; i += 64 * SELECT_BEST_WAVES) {
+                const unsigned e = lcand[i];
+                const int qq = (int)(e >> 27), c = (int)(e & 0xFFFFu);
+                const unsigned pos = lhist[c] + ((e >> 16) & 31u);
+                const int64_t q = (int64_t)qt * 32 + qq;
+                if (pos < (unsigned)bin_cap) {
+                    bins[(size_t)c * bin_cap + pos] = (int)q;
+                } else {
+                    const int slot = atomicAdd(&lov[qq], 1);
+                    if (slot < cap) cand[(size_t)q * cap + slot] = ((unsigned)c << 8) | 128u;  // whole-chunk entry
+                }
+            }
+        } else
         for (int i = threadIdx.x; i < ncand; i += 64 * SELECT_BEST_WAVES) {
             const unsigned e = lcand[i];
             place((int)(e >> 27), (int)(e & 0x7FFFFFFu), crowded);
@@ -1964,10 +2014,12 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                                a.first_pad_chunk, (const unsigned*)w.qmax, Q.inv, mx6 ? mx6_bounds(Q, B, 1) : i8_bounds(Q, B, true, records), gate, chunk_lds,
                                w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
         } else if (best) {
+            // (chunk_lds 2: room for the per-chunk histogram of the tile's candidates as well -- chunks must fit 16 bits of a staged entry)
+            const int best_lds = chunk_lds && use_bins && (size_t)a.nchunks * 12 <= 63 * 1024 && a.nchunks < 65536 ? 2 : chunk_lds;
             hipLaunchKernelGGL(match_select_best_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * SELECT_BEST_WAVES),
-                               chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, reinterpret_cast<const unsigned*>(w.partials),
+                               best_lds == 2 ? (size_t)a.nchunks * 12 : chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, reinterpret_cast<const unsigned*>(w.partials),
                                a.nchunks, n, (const unsigned*)w.qmax, Q.inv, mx6 ? mx6_bounds(Q, B) : i8_bounds(Q, B, true, records), gate,
-                               chunk_lds, w.cand_cnt,
+                               best_lds, w.cand_cnt,
                                w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats, use_bins ? w.bin_cnt : (unsigned*)nullptr,
                                use_bins ? w.bins : (int*)nullptr, a.first_pad_chunk, w.bin_cap);
         } else
