@@ -2067,7 +2067,12 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
             // (rec_cnt, unused by the int8 pass, holds the list of crowded queries; fb_count[6] its length)
             // (one query per wave, a workgroup per four: the work list's length is on the device, workgroups past its end return at once.
             // A grid of 1024 workgroups walking the list kept 196 registers x 8 waves per compute unit for the kernel's whole length)
-            const unsigned grid = g_finish_short ? (unsigned)((n + 3) / 4) : (unsigned)((n + 3) / 4 < 1024 ? (n + 3) / 4 : 1024);
+            // (round 4: one wave per possible entry after all.  With 1024 workgroups striding over the list a wave had two or three
+            // queries of 30 - 40 us each and the kernel lasted as long as the unluckiest wave -- 137 us at 9891 crowded queries; a wave per
+            // entry is placed as slots come free: 125 us.  Handing the entries out through an atomic cursor was tried: 186 us -- 4096
+            // waves ask the same address at once and every later load of a wave waits behind its atomic.  The refinement is 124 registers
+            // since R4.5, and workgroups past the list's end return at once: ~2 us for 5000 of them.)
+            const unsigned grid = (unsigned)((n + 3) / 4);
 #define VFM_REFINE(NT)                                                                                                          \
     hipLaunchKernelGGL(match_refine_kernel<NT>, dim3(grid), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2, w.cand_cnt, w.cand, \
                        w.cap, w.fb_count, w.fb_list, g_match_stats, (const int*)w.rec_cnt, (const int*)(w.fb_count + 6),            \
