@@ -415,6 +415,31 @@ def test_finish_stage_staging_buffers_overflow_into_the_direct_paths(records):
             assert solved[rsim >= 0.8].all(), name
 
 
+def test_crowded_lists_at_c2_size_every_record_kind_gives_the_oracle_answers():
+    """C2 size on descriptors that look like lifted ViT features with a common component (bench.py's `C2_lifted`: 12 candidate chunks per
+    query behind the int8 pass, 46 behind the fp6 pass, ~10 000 queries above the gate): the best-score selection (a tile's candidates
+    counted per chunk in the LDS, one bin atomic per (tile, chunk)), the chunk-major rescan and the refinement as one wave per list entry
+    against the oracle on all 20 000 rows; the packed top-2 kinds -- another selection kernel, query-major rescans -- must agree too."""
+    n, m, d = 20000, 200000, 384
+    p = synth.make_lifted_pair_device(n, m, d, seed=42, device="cuda", clouds=10, view_noise=0.1, common=1.0)
+    q, b = p["q_desc"], p["b_desc"]
+    gate = float(np.nextafter(np.float32(0.8), np.float32(-np.inf)))
+    qn, _ = orc.l2norm_rows(q.cpu().numpy())
+    bn, _ = orc.l2norm_rows(b.cpu().numpy())
+    ridx, rsim = orc.match_ip_top1(qn, bn)
+    assert int((rsim >= 0.8).sum()) > 5000
+    first = None
+    for records in (0, RECORDS_MX6, 1, RECORDS_MX6_TOP2, RECORDS_MX6_PILOT):
+        idx, sim = _search(q, b, gate, records)
+        solved = _gate_contract(idx, sim, ridx, rsim, gate)
+        assert solved[rsim >= 0.8].all(), records
+        keep = (sim >= 0.8)
+        if first is None:
+            first = (idx[keep].clone(), keep.clone())
+        else:
+            assert torch.equal(keep, first[1]) and torch.equal(idx[keep], first[0]), records
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("d,n,m,flags", [(384, 3000, 9001, PREPARE_MX6), (384, 3000, 9001, PREPARE_MX6 | PREPARE_MX6_HALF),
                                          (256, 1234, 5000, PREPARE_MX6), (256, 129, 5000, PREPARE_MX6 | PREPARE_MX6_HALF),
