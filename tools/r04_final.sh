@@ -42,3 +42,6 @@ timeout 300 python tools/time_c3_modes.py 2>/dev/null | tail -6 > $O/time_c3_mod
 # duplicate-rich maps through the bench's pipeline (policy by feedback and every mode forced)
 timeout 1200 python tools/time_neardup.py --steps 20 --modes auto,mx6-half,int8-half,int8,mx6 --out $O/neardup.json > $O/neardup.log 2>&1
 timeout 900 python tools/soak_half.py 40 303 2>&1 | tail -3 > $O/soak_half.txt; cat $O/soak_half.txt
+# the finish stage kernel by kernel on lifted descriptors with a common component (fp6 and int8 best-score records), and on D.2 (fused half-width)
+{ bash tools/prof_finish.sh 5,0 50 lifted 2>&1 | tail -3; bash tools/prof_finish.sh 8 50 d2 2>&1 | tail -1; } > $O/prof_finish.txt
+hipcc --offload-arch=gfx950 -O3 -w -o /tmp/launch_probe tools/probe/launch_probe.hip && /tmp/launch_probe > $O/launch_probe.txt 2>&1
