@@ -1392,8 +1392,8 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
     __shared__ unsigned l_row[4][REFINE_KEEP];
     __shared__ float l_sc[4][REFINE_KEEP];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    // todo != NULL (int8 pass): the queries match_rescan_kernel found crowded, a short list walked by a small grid;
-    // otherwise one wave per query
+    // todo != NULL (int8 pass): the queries match_rescan_close_kernel found crowded, a list whose length is on the device -- one wave
+    // per possible entry, waves past its end leave at once (the loop serves a caller that launches fewer); otherwise one wave per query
     const int64_t slot0 = (int64_t)blockIdx.x * 4 + wave;
     const int64_t nslots = todo ? (int64_t)*todo_count : n;
   for (int64_t slot = slot0; slot < nslots; slot += (int64_t)gridDim.x * 4) {
@@ -2065,8 +2065,6 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
                                (const unsigned*)w.hit_cnt);
             VFM_CHECK_LAUNCH("match_rescan_close_kernel");
             // (rec_cnt, unused by the int8 pass, holds the list of crowded queries; fb_count[6] its length)
-            // (one query per wave, a workgroup per four: the work list's length is on the device, workgroups past its end return at once.
-            // A grid of 1024 workgroups walking the list kept 196 registers x 8 waves per compute unit for the kernel's whole length)
             // (round 4: one wave per possible entry after all.  With 1024 workgroups striding over the list a wave had two or three
             // queries of 30 - 40 us each and the kernel lasted as long as the unluckiest wave -- 137 us at 9891 crowded queries; a wave per
             // entry is placed as slots come free: 125 us.  Handing the entries out through an atomic cursor was tried: 186 us -- 4096
