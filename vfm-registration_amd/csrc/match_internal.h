@@ -43,7 +43,7 @@ __host__ __device__ inline int rescan_bin_cap(int64_t npad, int64_t nchunks) {
 // consecutive lines took ~0.3 ns per atomic whatever the number of threads (select_best: 64 us of 122 at 250 000 candidates, 283 of
 // 345 at 920 000).
 constexpr int BIN_CNT_STRIDE = 32;
-constexpr int RESCAN_SLICE = 1024;   // bin entries one workgroup of match_rescan_chunk_kernel takes (grid.y slices a long bin)
+constexpr int RESCAN_SLICE = 256;    // bin entries one workgroup of match_rescan_chunk_kernel takes (grid.y slices a long bin; 1024 until the end of round 4: the longest workgroups -- 32 blocks of 2.6 us -- were the kernel, 155 -> 140 us at 590 queries per chunk; 128 pays more prologues than it balances)
 constexpr int RESCAN_BATCH = 64;     // ... of which match_rescan_chunk_kernel stages this many in LDS at a time
 // Half-width pass, device-side guard: a search whose bound leaves more than this many (query, chunk) pairs per query -- descriptors
 // that are all alike: every chunk survives -- does not rescan them (31 million 128-row rescans at C2: 171 ms) but falls through,
