@@ -48,7 +48,7 @@ int vfm_debug_match_stats(void *ws, int64_t n, int64_t m, int32_t *out64_host);
 int vfm_debug_set_match_stats(int on);
 /* A/B: ViT GEMM wave tile / prefetch depth: NT * 100 + PF for N <= 512 and N > 512 (see csrc/vit.hip); narrow_cfg = -3 / -4:
  * XCD-consistent tile mapping of the ViT kernels on (default) / off; -5: the LDS-tiled GEMM from wide_cfg workgroups of 128 x 128 on
- * (0 = never, default 256); -6: its stage shape, k-steps per stage * 10 + stages (default 24); -7: attention with K / V^T shared through
+ * (0 = never, default 256); -6: its stage shape, k-steps per stage * 10 + stages (default 23); -7: attention with K / V^T shared through
  * the LDS from wide_cfg images per call on (0 = never, default 1) */
 int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
 /* A/B: workgroups of the int8 operand-preparation kernel (-1, default = one per 128-row group; 0 = one per compute unit, each

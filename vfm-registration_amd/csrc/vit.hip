@@ -441,8 +441,11 @@ __device__ __forceinline__ void vit_glds16(const void* gsrc, unsigned lds_dst_un
 // KB k-steps per stage, NS stages in the LDS ring (NS - 1 in flight or in use beside the one being filled): a stage is issued NS - 2
 // stages of MFMAs before it is needed -- an L2 round trip is ~1500 cycles, a stage's MFMAs 128 KB cycles per wave -- and 4 KB x NS KiB
 // of LDS lets several workgroups share a compute unit (KB = 2, NS = 4: 64 KiB, 2 per CU; KB = 2, NS = 3: 48 KiB, 3 per CU).
+// (__launch_bounds__(256, 3): without the bound the compiler kept the 64 accumulators in AGPRs beside 116 - 140 VGPRs and moved them back and
+// forth -- 180 - 204 registers, two waves per SIMD; with it 112 - 137 and no AGPR, no spill: three waves per SIMD with a ring of three stages
+// (48 KiB): 96 images 4.20 -> 4.09 ms, 48 images 2.39 -> 2.29)
 template <int EPI, int KB, int NS>
-__global__ __launch_bounds__(256) void vit_gemm_lds_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 3) void vit_gemm_lds_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [stage][A | W][tile][k-step][1 KiB]
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -942,7 +945,7 @@ int launch_gemm_cfg(const GemmArgs& g, hipStream_t st) {
 // ~5 us floor of each of its 87 launches, not by L2 latency or bandwidth: PF = 8 / 16 / 24 make no difference, 32-channel
 // tiles everywhere (twice the waves) give 0.76 instead of 0.82 ms, 64 x 64 wave tiles and row-complete workgroups with the
 // LayerNorm fused into the epilogue (63 launches, but 66 workgroups per GEMM) gave 1.04 ms and were removed again.
-int g_vit_lds_shape = 24;     // vfm_debug_set_vit_gemm(-6, KB * 10 + NS): k-steps per stage / stages in the ring of the LDS-tiled kernel
+int g_vit_lds_shape = 23;     // vfm_debug_set_vit_gemm(-6, KB * 10 + NS): k-steps per stage / stages in the ring of the LDS-tiled kernel (23: 48 KiB, three workgroups per compute unit)
 int g_vit_att_lds_min = 1;   // vfm_debug_set_vit_gemm(-7, n): attention with K / V^T in the LDS from n images per call on (0 = never)
 int g_vit_lds_min_wg = 256;   // vfm_debug_set_vit_gemm(-5, n): the LDS-tiled kernel from n workgroups of 128 x 128 on (0 = never)
 template <int EPI>
@@ -966,9 +969,9 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
             switch (g_vit_lds_shape) {
                 case 42: VIT_LDS(4, 2); break;
                 case 43: VIT_LDS(4, 3); break;
-                case 23: VIT_LDS(2, 3); break;
+                case 24: VIT_LDS(2, 4); break;
                 case 26: VIT_LDS(2, 6); break;
-                default: VIT_LDS(2, 4); break;
+                default: VIT_LDS(2, 3); break;
             }
 #undef VIT_LDS
             VFM_CHECK_LAUNCH("vit_gemm_lds_kernel");
