@@ -195,7 +195,7 @@ struct GemmArgs {
 // over 256 compute units.)
 __device__ __forceinline__ bool xcd_item(int mtiles, int ntiles, int wave, int& mt, int& nt) {
     const int xcd = blockIdx.x & 7;
-    const int it = (blockIdx.x >> 3) * 4 + wave;
+    const int it = (blockIdx.x >> 3) * (int)(blockDim.x >> 6) + wave;
     const int lt = it / ntiles;
     nt = it - lt * ntiles;
     mt = xcd + 8 * lt;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int ntiles = g.N / (32 * NT);
-    const int wid = blockIdx.x * 4 + wave;
+    const int wid = blockIdx.x * (int)(blockDim.x >> 6) + wave;   // (1, 2 or 4 waves per workgroup: launch_gemm_cfg)
     int mt = wid / ntiles, nt = wid % ntiles;  // token tile, (32*NT)-channel tile
     if (g.xcd_map) {
         if (!xcd_item(g.M / 32, ntiles, wave, mt, nt)) return;
@@ -930,12 +930,16 @@ inline VitWs carve_vit(void* p, const Dims& d) {
 int g_vit_xcd = 1;        // vfm_debug_set_vit_gemm(-3 / -4, .): XCD-consistent tile mapping on / off (A/B)
 int g_vit_cfg_narrow = 108, g_vit_cfg_wide = 108;  // (NT * 100 + PF) for N <= 512 / N > 512 (vfm_debug_set_vit_gemm)
 
+int g_vit_wpw = 0;   // vfm_debug_set_vit_gemm(-8, n): waves per workgroup of the direct GEMM kernel (0 = the default, one)
 template <int EPI, int NT, int PF>
 int launch_gemm_cfg(const GemmArgs& g, hipStream_t st) {
     const int waves = (g.M / 32) * (g.N / (32 * NT));
+    // waves per workgroup: one -- the waves share nothing, and single waves are spread over more compute units (one scan, N = 384: 648 waves
+    // were 168 workgroups); tools/ab_vit_wpw.py: 6 / 12 / 24 images 0.62 / 0.865 / 1.444 ms with four waves per workgroup, 0.62 / 0.845 / 1.425 with one
+    const int wpw = g_vit_wpw > 0 ? g_vit_wpw : 1;
     // xcd_map: every XCD gets ceil(tiles / 8) token tiles' worth of workgroups
-    const int grid = g.xcd_map ? 8 * ceil_div(ceil_div(g.M / 32, 8) * (g.N / (32 * NT)), 4) : ceil_div(waves, 4);
-    hipLaunchKernelGGL((vit_gemm_kernel<EPI, NT, PF>), dim3(grid), dim3(256), 0, st, g);
+    const int grid = g.xcd_map ? 8 * ceil_div(ceil_div(g.M / 32, 8) * (g.N / (32 * NT)), wpw) : ceil_div(waves, wpw);
+    hipLaunchKernelGGL((vit_gemm_kernel<EPI, NT, PF>), dim3(grid), dim3(64 * wpw), 0, st, g);
     VFM_CHECK_LAUNCH("vit_gemm_kernel");
     return VFM_OK;
 }
@@ -995,6 +999,10 @@ VFM_EXPORT int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg) {
     }
     if (narrow_cfg == -6) {
         g_vit_lds_shape = wide_cfg;
+        return VFM_OK;
+    }
+    if (narrow_cfg == -8) {   // waves per workgroup of the direct GEMM kernel (0: the default, one)
+        g_vit_wpw = wide_cfg;
         return VFM_OK;
     }
     if (narrow_cfg == -7) {   // attention with K / V^T of an (image, head) in the LDS from wide_cfg images per call on (0: never)
