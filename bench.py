@@ -50,6 +50,9 @@ SETTLE = 6   # registrations the auto policy gets, one at a time, before the war
 MFMA_F6_PEAK_TFLOPS = 10000.0  # dense fp6 / fp4 scaled MFMA (same table: "~10 PF dense", FP6 ubench >= 7287; tools/probe/mx6_probe.hip: 6400)
 
 
+C3_GROUP = 4   # pairs whose cameras share one ViT call in the grouped C3 pipeline (tools/time_c3_group.py)
+
+
 def cpu_baseline(p, iters=RANSAC_ITERS, T_gpu=None):
     """Reference-CPU-path stand-in (kind 'port'): the oracle's restatement -- fp32 BLAS Q.B^T + exact
     fp64 decision, threshold, OpenMP RANSAC -- on the SAME scene pair the GPU registered (host copies `p`),
@@ -210,6 +213,27 @@ def extra_configs(dev):
                                "value": steps_e2e / dt, "unit": "registrations/s", "steps": steps_e2e, "ms_per_step": 1e3 * dt / steps_e2e,
                                "coarse_pass": pass_name(e2e.reg), "correspondences": int(res["count"].item()),
                                "serial_equivalent_ms": t_all}
+        del e2e
+        # the same job with the feature stages of C3_GROUP pairs sharing one ViT call (EndToEndPipeline.submit_group; parity: the same test)
+        e2e = EndToEndPipeline(model, rig, n, m, n_iter=RANSAC_ITERS, depth=4, device=dev, group=C3_GROUP, group_depth=3)
+        for steps_e2e in (8, 64):
+            gc.collect()
+            gc.disable()
+            torch.cuda.synchronize()
+            t0 = _time.perf_counter()
+            for lo in range(0, steps_e2e, C3_GROUP):
+                res = e2e.submit_group([(img_sets[i % 2], pcl, q_xyz, b_desc, b_xyz) for i in range(lo, min(lo + C3_GROUP, steps_e2e))],
+                                       inputs_ready=ready)[-1]
+                e2e.reg._poll_feedback()
+            e2e.synchronize()
+            torch.cuda.synchronize()
+            dt = _time.perf_counter() - t0
+            gc.enable()
+        out["C3_pipelined"]["grouped"] = {"workload": f"the same pairs, the cameras of {C3_GROUP} pairs per ViT call ({6 * C3_GROUP} images: the batch "
+                                                      "kernels), each pair lifted and registered on its own as before",
+                                          "pairs_per_vit_call": C3_GROUP, "value": steps_e2e / dt, "unit": "registrations/s", "steps": steps_e2e,
+                                          "ms_per_step": 1e3 * dt / steps_e2e, "coarse_pass": pass_name(e2e.reg),
+                                          "correspondences": int(res["count"].item())}
         del e2e
     except Exception as e:  # never lose the line to an auxiliary measurement
         out["C3_pipelined"] = {"error": f"{type(e).__name__}: {e}"}
@@ -518,12 +542,22 @@ def run_c3_form(args, dev, rank, world):
         q_xyz = torch.from_numpy(np.ascontiguousarray(xyz)).to(dev)
         b_xyz[pick] = q_xyz + 0.02 * torch.randn(n, 3, device=dev, generator=g, dtype=torch.float64)
         pairs.append(dict(imgs=imgs, pcl=pcl, q_xyz=q_xyz, b_desc=b_desc, b_xyz=b_xyz))
-    e2e = EndToEndPipeline(model, rig, n, m, n_iter=args.iters, depth=4, device=dev)
+    G = max(int(args.feature_group), 1)
+    e2e = EndToEndPipeline(model, rig, n, m, n_iter=args.iters, depth=4, device=dev, group=G, group_depth=3)
     torch.cuda.synchronize()
     ready = torch.cuda.Event()
     ready.record(torch.cuda.current_stream())
     res_T = torch.empty((steps, 4, 4), dtype=torch.float64, device=dev)
     res_c = torch.empty((steps, 1), dtype=torch.int64, device=dev)
+
+    def group_step(lo, hi, keep):
+        def snap(k, out):
+            if keep:
+                with torch.cuda.stream(out["result_stream"]):
+                    res_T[lo + k].copy_(out["T"])
+                    res_c[lo + k].copy_(out["count"])
+        ps = [pairs[i % n_res] for i in range(lo, hi)]
+        e2e.submit_group([(p["imgs"], p["pcl"], p["q_xyz"], p["b_desc"], p["b_xyz"]) for p in ps], inputs_ready=ready, on_result=snap)
 
     def step(i, keep=None):
         p = pairs[i % n_res]
@@ -541,14 +575,22 @@ def run_c3_form(args, dev, rank, world):
         if i < 8:
             e2e.synchronize()
             torch.cuda.synchronize()
+    if G > 1:
+        for lo in range(0, 2 * G, G):           # ... and two groups through the batch path
+            group_step(lo, lo + G, keep=False)
+            e2e.reg._poll_feedback()
     e2e.synchronize()
     grouped = dist.is_available() and dist.is_initialized()
     if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(steps):
-        step(i, keep=i)
+    if G > 1:
+        for lo in range(0, steps, G):
+            group_step(lo, min(lo + G, steps), keep=True)
+    else:
+        for i in range(steps):
+            step(i, keep=i)
     e2e.synchronize()
     torch.cuda.synchronize()
     local_elapsed = time.perf_counter() - t0
@@ -572,7 +614,7 @@ def run_c3_form(args, dev, rank, world):
             "scaling": "weak", "vs_baseline": None, "dtype": "fp16 ViT (fp32 accumulation) + the c2 form's matcher and f64 RANSAC", "data": "synthetic",
             "config": {"workload": f"C3 form: {num_pairs} scene pair(s) end to end from uint8 images, pair p -> rank p mod N, {n_res} resident per GPU; "
                                    f"{n}-pt scan vs {m}-pt map, {args.iters} RANSAC iterations", "scene_pairs_total": num_pairs,
-                       "records_kind": int(e2e.reg._records()), "max_pose_err_vs_planted": max(errs),
+                       "records_kind": int(e2e.reg._records()), "max_pose_err_vs_planted": max(errs), "pairs_per_vit_call": G,
                        "correspondences_last_step": int(all_counts[local_ids[-1]].item()),
                        "per_rank_registrations_per_s": steps / local_elapsed,
                        "collective": "one all_gather_into_tensor of the poses" if grouped else "none (single process, no launcher)"},
@@ -598,6 +640,9 @@ def main():
                     help="c2 (default, BASELINE.json's metric): descriptors resident in HBM; c3: every pair end to end from uint8 images "
                          "(ViT-S/14 on 6 x 1200x1600 + projection / lifting + registration, vfmreg.pipeline.EndToEndPipeline) -- with --pairs an "
                          "N-GPU job shards end-to-end pairs the same way (information only: the headline stays the c2 form)")
+    ap.add_argument("--feature-group", type=int, default=1,
+                    help="--form c3 only: the cameras of this many consecutive pairs of a rank go through the ViT in one call "
+                         "(EndToEndPipeline.submit_group); 1 = one ViT call per pair")
     ap.add_argument("--streams", type=int, default=2,
                     help="2: RANSAC of pair i overlaps the matching of pair i+1 on a second HIP stream; 1: serial")
     args = ap.parse_args()

@@ -92,16 +92,19 @@ def test_bench_pairs_form_for_config_c4():
     assert 5.0 < d["config"]["hbm_peak_allocated_gb"] < 40.0
 
 
-def test_bench_c3_form_shards_end_to_end_pairs():
+@pytest.mark.parametrize("group", [1, 4])
+def test_bench_c3_form_shards_end_to_end_pairs(group):
     """`--form c3 --pairs P`: the job's pairs end to end from uint8 images, sharded like the c2 form; the planted
-    transform (the identity) is recovered for every pair."""
+    transform (the identity) is recovered for every pair -- one ViT call per pair, and the cameras of four pairs per call
+    (`--feature-group 4`: 10 pairs = groups of 4 + 4 + 2)."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29523", str(ROOT / "bench.py"), "--gpus", "1", "--form", "c3", "--pairs", "10", "--warmup", "1"]
+           "--master-port", str(29523 + group), str(ROOT / "bench.py"), "--gpus", "1", "--form", "c3", "--pairs", "10", "--warmup", "1",
+           "--feature-group", str(group)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["config"]["scene_pairs_total"] == 10 and d["unit"] == "registrations/s"
     assert d["value"] > 50 and d["config"]["max_pose_err_vs_planted"] < 0.05 and d["config"]["correspondences_last_step"] > 15000
-    assert "C3" in d["metric"] and d["roofline"] is None
+    assert "C3" in d["metric"] and d["roofline"] is None and d["config"]["pairs_per_vit_call"] == group

@@ -242,6 +242,28 @@ def test_c3_pipelined_equals_the_stage_by_stage_path_and_the_oracle():
         assert c > 1000 and int(s["count"].item()) == c, i
         assert torch.equal(s["T"], r["T"]) and torch.equal(s["best_hyp"], r["best_hyp"]), i
         assert torch.equal(s["corres"][:c], r["corres"][:c]) and torch.equal(s["mask"][:c], r["mask"][:c]), i
+    # the same pairs in groups of three (3 + 3 + 1): one ViT call per group (EndToEndPipeline.submit_group), everything else as above
+    del e2e
+    e2g = EndToEndPipeline(model, cams, n, m, n_iter=5000, depth=4, group=3, group_depth=2)
+    gsnaps = []
+
+    def keep(k, out):
+        with torch.cuda.stream(out["result_stream"]):
+            gsnaps.append({k2: out[k2].clone() for k2 in ("T", "count", "corres", "mask", "best_hyp", "desc")})
+    for lo in range(0, npairs, 3):
+        outs = e2g.submit_group([(p["imgs"], p["pcl"], p["q_xyz"], p["b_desc"], p["b_xyz"]) for p in pairs[lo:lo + 3]], on_result=keep)
+        assert len(outs) == min(3, npairs - lo)
+    e2g.synchronize()
+    torch.cuda.synchronize()
+    assert len(gsnaps) == npairs
+    for i, (s, r) in enumerate(zip(gsnaps, ref)):
+        c = int(r["count"].item())
+        assert torch.equal(s["desc"], r["desc"]) and int(s["count"].item()) == c, i
+        assert torch.equal(s["T"], r["T"]) and torch.equal(s["best_hyp"], r["best_hyp"]), i
+        assert torch.equal(s["corres"][:c], r["corres"][:c]) and torch.equal(s["mask"][:c], r["mask"][:c]), i
+    with pytest.raises(ValueError):
+        e2g.submit_group([])
+    del e2g
     # the oracle's solve on the GPU-lifted descriptors of one pair (the chain's precision is the subject of test_c3_fp16_vit_...)
     p, r = pairs[3], ref[3]
     qn, _ = orc.l2norm_rows(r["desc"].cpu().numpy())

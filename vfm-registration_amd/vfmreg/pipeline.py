@@ -87,6 +87,19 @@ def _side_streams(dev: torch.device, n_solve: int):
     return prep, solve[:n_solve]
 
 
+_FEATURE_STREAMS = {}
+
+
+def _feature_stream(dev: torch.device, priority: int):
+    """The feature stage's stream, one per (device, priority) and process for the same reason as ``_side_streams``: which hardware
+    queue a new stream lands on depends on how many the process created before, and the same EndToEndPipeline ran at 400, 470 or
+    520 registrations/s depending on it (tools/time_c3_group.py, profiles/r04_time_c3_group.txt)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(priority))
+    if key not in _FEATURE_STREAMS:
+        _FEATURE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=int(priority))
+    return _FEATURE_STREAMS[key]
+
+
 class RegistrationPipeline:
     def __init__(self, n: int, m: int, d: int = 384, n_iter: int = 50000, min_cosine: float = 0.8,
                  max_corr_dist: float = 10000.0, seed: int = 42, device="cuda", overlap_ransac: bool = False,
@@ -440,10 +453,13 @@ class EndToEndPipeline:
     other (tests/test_gpu_e2e.py)."""
 
     def __init__(self, model, cams: list, n: int, m: int, n_iter: int = 50000, min_cosine: float = 0.8, max_corr_dist: float = 10000.0,
-                 seed: int = 42, depth: int = 4, coarse: str = "auto", device="cuda", feature_cus: int = 0, feature_priority: int = 0):
+                 seed: int = 42, depth: int = 4, coarse: str = "auto", device="cuda", feature_cus: int = 0, feature_priority: int = 0,
+                 group: int = 1, group_depth: int = 3):
         """``model``: vit.ViTS14 for the rig's image size; ``cams``: the rig, one dict per camera in priority order with the
         projection parameters of ``ops.LiftPlan`` (mode, mats, fc, subsample, win, H, W, rot_mode) -- image and grid pointers are
-        the pipeline's own."""
+        the pipeline's own.  ``group`` > 1 allocates ``group_depth`` buffer sets for ``submit_group``: the cameras of up to ``group``
+        pairs go through the ViT in ONE call (6 images are 63 launches of 5 - 15 us each, bounded by their boundaries; 24 images cost
+        2.3x of that, not 4x -- the batch path prepare_scenes.create_descriptors_batch uses offline, here inside the pipeline)."""
         self.model, self.n = model, n
         self.device = torch.device(device)
         d = model.dim
@@ -462,7 +478,7 @@ class EndToEndPipeline:
             self.reg_stream = masked_stream(ncu - self.feature_cus, self.feature_cus, ncu)
         else:
             # (``feature_priority`` < 0: a high-priority stream -- its workgroups are placed first whenever a compute unit has room)
-            self.feat_stream = torch.cuda.Stream(device=self.device, priority=int(feature_priority))
+            self.feat_stream = _feature_stream(self.device, feature_priority)
             self.reg_stream = None
         self.sets = []
         for _ in range(self.depth):
@@ -475,6 +491,21 @@ class EndToEndPipeline:
                                       raw_image=imgs[k]) for k, c in enumerate(cams)], d)
             self.sets.append(dict(imgs=imgs, grids=grids, desc=desc, filled=filled, pcl=pcl, plan=plan, done=None, ready=None))
         self._step = 0
+        self.group = max(int(group), 1)
+        self.gsets = []
+        if self.group > 1:
+            G = self.group
+            for _ in range(max(int(group_depth), 2)):
+                imgs = torch.empty((G * B, H, W, 3), dtype=torch.uint8, device=self.device)
+                grids = torch.empty((G * B, 16, model.patch_w, d), dtype=torch.float32, device=self.device)
+                desc = torch.empty((G, n, d), dtype=torch.float32, device=self.device)
+                filled = torch.zeros((G, n), dtype=torch.uint8, device=self.device)
+                pcl = torch.empty((G, 4, n), dtype=torch.float64, device=self.device)
+                plans = [ops.LiftPlan([dict(c, proj_image=(imgs[g * B + k] if c.get("needs_image") else None), grid=grids[g * B + k],
+                                            Hup=H, Wup=W, raw_image=imgs[g * B + k]) for k, c in enumerate(cams)], d) for g in range(G)]
+                self.gsets.append(dict(imgs=imgs, grids=grids, desc=desc, filled=filled, pcl=pcl, plans=plans, done=[]))
+        self._gstep = 0
+        self._cams = B
 
     def submit(self, images: torch.Tensor, pcl4xn: torch.Tensor, q_xyz: torch.Tensor, b_desc: torch.Tensor, b_xyz: torch.Tensor,
                inputs_ready: Optional[torch.cuda.Event] = None, want_mask: bool = True):
@@ -508,6 +539,58 @@ class EndToEndPipeline:
         out = dict(out)
         out["desc"] = s["desc"]
         return out
+
+    def submit_group(self, pairs: list, inputs_ready: Optional[torch.cuda.Event] = None, want_mask: bool = True, on_result=None) -> list:
+        """Enqueue 1 ... ``group`` pairs whose feature stages share one ViT call.  ``pairs``: a list of ``(images, pcl4xn, q_xyz,
+        b_desc, b_xyz)`` as ``submit`` takes them.  The cameras of all pairs are copied into one [pairs x cameras, H, W, 3] buffer
+        and go through ``model.forward`` once (the batch kernels are bit-identical to the one-scan kernels: tests/test_gpu_vit.py),
+        then every pair is lifted from its own slice of the patch grids and registered as ``submit`` would, in order.  A
+        registration's outputs live in ``RegistrationPipeline``'s rotating buffer sets, of which there are fewer than pairs in a
+        group: ``on_result(k, out)`` is called right after pair k's registration was enqueued -- snapshot what you need there, on
+        ``out["result_stream"]``.  Returns the list of the ``out`` dicts (the last ``len(reg.sets)`` are still valid).  The feature
+        stage of the next group runs beside the registrations of this one; a group's buffers are reused ``group_depth`` groups
+        later, when all of its registrations are done."""
+        G = len(pairs)
+        if not 1 <= G <= self.group or not self.gsets:
+            raise ValueError(f"submit_group takes 1 ... group = {self.group} pairs (EndToEndPipeline(group=...)); got {G}")
+        B = self._cams
+        gs = self.gsets[self._gstep % len(self.gsets)]
+        self._gstep += 1
+        fs = self.feat_stream
+        main = torch.cuda.current_stream()
+        if inputs_ready is not None:
+            fs.wait_event(inputs_ready)
+        else:
+            fs.wait_stream(main)
+        for ev in gs["done"]:
+            fs.wait_event(ev)                 # the registrations that read this set's descriptors have finished
+        ready = []
+        with torch.cuda.stream(fs):
+            for k, p in enumerate(pairs):
+                gs["imgs"][k * B:(k + 1) * B].copy_(p[0], non_blocking=True)
+                gs["pcl"][k].copy_(p[1], non_blocking=True)
+            self.model.forward(gs["imgs"][:G * B], out=gs["grids"][:G * B])
+            for k in range(G):
+                gs["plans"][k](gs["pcl"][k], gs["desc"][k], gs["filled"][k])
+                ev = torch.cuda.Event()
+                ev.record(fs)
+                ready.append(ev)
+        outs, done = [], []
+        for k, p in enumerate(pairs):
+            if self.reg_stream is not None:
+                self.reg_stream.wait_stream(main)
+                with torch.cuda.stream(self.reg_stream):
+                    out = self.reg.register(gs["desc"][k], p[2], p[3], p[4], want_mask=want_mask, inputs_ready=ready[k])
+            else:
+                out = self.reg.register(gs["desc"][k], p[2], p[3], p[4], want_mask=want_mask, inputs_ready=ready[k])
+            done.append(out["done"])
+            out = dict(out)
+            out["desc"] = gs["desc"][k]
+            if on_result is not None:
+                on_result(k, out)
+            outs.append(out)
+        gs["done"] = done
+        return outs
 
     def synchronize(self) -> None:
         """Make the caller's current stream wait for everything submitted."""
