@@ -106,6 +106,46 @@ def cpu_baseline(p, iters=RANSAC_ITERS, T_gpu=None):
     return out, delta
 
 
+def live_traffic(records_kind: int, timeout_s: int = 120):
+    """HBM bytes per launch of the coarse kernel, measured while bench.py runs: FETCH_SIZE and WRITE_SIZE from two SEPARATE
+    `rocprofv3 --kernel-trace --pmc <counter>` passes (MI355X_MICROARCH.md, HBM / rocprofv3 section: no other trace domain beside
+    --pmc) of tools/prof_match.py -- the matching stage of config C2 at the record kind the timed region ran, three launches --
+    each in a subprocess of its own.  Units and the gfx950 correction as tools/pmc_coarse.sh applies them (both counters in KB;
+    FETCH_SIZE doubled).  Returns None when rocprofv3 is missing, fails or reports no such kernel: the line then carries the
+    round's committed passes and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    t0 = time.perf_counter()
+    got, kernel = {}, ""
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                env = dict(os.environ, VFM_RECORDS=str(records_kind), TMPDIR="/tmp")
+                subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", td, "-o", ctr, "--",
+                                sys.executable, str(ROOT / "tools" / "prof_match.py"), "3"],
+                               cwd="/tmp", env=env, capture_output=True, timeout=timeout_s, check=True)
+                vals = []
+                for f in glob.glob(f"{td}/**/{ctr}_counter_collection.csv", recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if "match_coarse" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                            kernel = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip()
+                            vals.append(float(r["Counter_Value"]))
+                if not vals:
+                    return None
+                got[ctr] = vals
+    except Exception as e:  # never lose the line to the profiler
+        print(f"[bench] live traffic measurement failed ({type(e).__name__}: {e}); using the committed passes", file=sys.stderr, flush=True)
+        return None
+    fetch, write = (sum(got[c]) / len(got[c]) for c in ("FETCH_SIZE", "WRITE_SIZE"))
+    return {"hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
+            "launches": len(got["FETCH_SIZE"]), "kernel": kernel, "seconds": time.perf_counter() - t0}
+
+
 def extra_configs(dev):
     """Other BASELINE configs, measured OUTSIDE the timed region (information only; the headline stays C2):
     C3 = C2 + DINOv2 ViT-S/14 on 6 x 1200 x 1600 + 6-camera projection/lifting, one pair end to end (latency);
@@ -633,6 +673,9 @@ def main():
                          "(overrides --steps: every rank registers its ceil(pairs / N) pairs once)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C5 measurements reported under `extra`")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed PMC passes under profiles/ instead of two rocprofv3 --pmc subprocesses of this run "
+                         "(--no-extra implies it; so does running bench.py itself under rocprofv3)")
     ap.add_argument("--n", type=int, default=N_SCAN)
     ap.add_argument("--m", type=int, default=N_MAP)
     ap.add_argument("--iters", type=int, default=RANSAC_ITERS)
@@ -864,6 +907,17 @@ def main():
                 traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
                 traffic_src = f"profiles/{name} (FETCH_SIZE / WRITE_SIZE from separate --pmc passes, corrected per MI355X_MICROARCH.md)"
                 break
+        traffic_committed = traffic
+        profiled = any(k.startswith(("ROCP_", "ROCPROF", "ROCTRACER_")) for k in os.environ)   # bench.py itself under rocprofv3: no nested profiler
+        if (world == 1 and not args.no_live_traffic and not args.no_extra and not profiled and (n, m, d) == (N_SCAN, N_MAP, DIM) and mode_i8):
+            # ... and measured in THIS run: the same two passes on the same kernel, in subprocesses (this process holds no counters)
+            live = live_traffic(records_kind)
+            if live is not None:
+                traffic = live["hbm_bytes_per_launch"]
+                traffic_src = (f"this run: two separate `rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE` passes of tools/prof_match.py at record "
+                               f"kind {records_kind} ({live['launches']} launches of {live['kernel']}; FETCH_SIZE {live['FETCH_SIZE_KB']:.0f} KB doubled per "
+                               f"MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE {live['WRITE_SIZE_KB']:.0f} KB; {live['seconds']:.0f} s); committed "
+                               f"passes of the round: {traffic_committed} bytes")
         line = {
             "metric": "registrations/sec (20k<->200k pts, 384-D)", "value": num_pairs / elapsed,
             "unit": "registrations/s", "n_gpus": world, "steps": vdist.pairs_per_rank(num_pairs, world), "warmup": args.warmup,

@@ -52,6 +52,10 @@ def test_bench_under_torch_distributed_run_world1():
     d = _check(r.stdout, 4)
     assert "nccl" in d["config"]["collective"]  # the RCCL process group was created and used
     assert d["cpu_baseline"] is not None and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    # roofline.traffic is measured in the run itself (two rocprofv3 --pmc subprocesses on the kernel the timed region ran) and is
+    # what the survivor-only epilogue left of the 0.38 GB the record-writing kernel moved
+    assert d["roofline"]["traffic_source"].startswith("this run"), d["roofline"]["traffic_source"]
+    assert 0.05e9 < d["roofline"]["traffic"] < 0.25e9, d["roofline"]["traffic"]
     # the metric's "pose delta vs ref" and the other configs ride on the same line, outside the timed region
     ex = d["extra"]
     assert "error" not in ex, ex
@@ -71,6 +75,7 @@ def test_bench_under_torch_distributed_run_world1():
     assert lf["value"] > 100 and lf["pose_err_vs_planted"] < 0.05 and lf["correspondences"] > 5000
     assert 0 < ex["A6_mutual_l2"]["ms_mutual_pairs"] < 6.0 and ex["A6_mutual_l2"]["mutual_pairs"] > 9000
     assert ex["C3"]["ms_end_to_end"] > ex["C3"]["ms_vit"] > 0 and 0 < ex["C3"]["vit_roofline"]["frac"] < 1
+    assert ex["C3_pipelined"]["value"] > 100 and ex["C3_pipelined"]["grouped"]["value"] > 100 and ex["C3_pipelined"]["grouped"]["pairs_per_vit_call"] == 4
     assert ex["C5"]["pose_err_vs_planted"] < 0.05 and 0.05 < ex["C5"]["roofline"]["frac"] < 1
 
 
