@@ -441,6 +441,101 @@ def roofline_of(pipe, n, m, d, coarse_ms):
             "columns_multiplied": kcols, "all_pairs_product_flops": 2.0 * n * m * d}
 
 
+HBM_PEAK_TBS = 8.0       # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64 (~79)
+
+
+def stage_table(dev, lib, pair, iters, records_kind):
+    """every stage of a C2 registration ALONE on the GPU (HIP events on the stream it is launched on, median of 9),
+    with the algorithmic work of D.3 and the fraction of the peak that bounds it.  The stages are the C-ABI calls the pipeline makes,
+    at the record kind the timed region ran; in the pipeline they overlap (the headline is not their sum)."""
+    import torch
+    from vfmreg import _lib, ops
+    q, b, q_xyz, b_xyz = pair["q_desc"], pair["b_desc"], pair["q_xyz"], pair["b_xyz"]
+    n, d = q.shape
+    m = b.shape[0]
+    u8 = torch.uint8
+    qb = torch.empty(lib.vfm_match_prepared_bytes(n, d), dtype=u8, device=dev)
+    bb = torch.empty(lib.vfm_match_prepared_bytes(m, d), dtype=u8, device=dev)
+    ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=u8, device=dev)
+    idx = torch.empty(n, dtype=torch.int64, device=dev)
+    sim = torch.empty(n, dtype=torch.float32, device=dev)
+    gate = 0.8
+    flags = (8 | 16) if records_kind in (7, 8) else 8 if records_kind in (5, 6, 9) else 0   # VFM_PREPARE_MX6 (| _MX6_HALF)
+
+    def st():
+        return torch.cuda.current_stream().cuda_stream
+
+    def prep():
+        _lib.check(lib.vfm_match_prepare2_gated_p(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, flags, st()))
+
+    def coarse():
+        _lib.check(lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records_kind, gate, st()))
+
+    def finish():
+        _lib.check(lib.vfm_match_search_finish_gated_r(q.data_ptr(), qb.data_ptr(), n, b.data_ptr(), bb.data_ptr(), m, d, idx.data_ptr(),
+                                                       sim.data_ptr(), ws.data_ptr(), ws.numel(), gate, records_kind, st()))
+    tc = {}
+
+    def compact():
+        tc["r"] = ops.threshold_compact(sim, idx, gate, q_xyz, b_xyz)
+    ro = {}
+
+    def ransac():
+        r = tc["r"]
+        ro["o"] = ops.ransac_corr(q_xyz, b_xyz, r["corres"], 10000.0, iters, seed=42, count=r["count"], out=ro.get("o"))
+
+    def med(fn, before=(), reps=9):
+        ts = []
+        for i in range(reps + 2):
+            for f in before:      # (coarse and finish consume the workspace: re-run what feeds them, untimed)
+                f()
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            e.record()
+            e.synchronize()
+            if i >= 2:
+                ts.append(a.elapsed_time(e))
+        return sorted(ts)[len(ts) // 2]
+    t_prep = med(prep)
+    t_coarse = med(coarse)
+    t_finish = med(finish, before=(coarse,))
+    t_compact = med(compact)
+    t_ransac = med(ransac)
+    C = int(tc["r"]["count"].item())
+    half = records_kind in (3, 7, 8)
+    kcols = d // 2 if half else d
+    peak_mm = MFMA_F6_PEAK_TFLOPS if records_kind in (5, 6, 7, 8, 9) else MFMA_I8_PEAK_TOPS
+    moved_prep = 4.0 * (n + m) * d + (n + m) * d * (1.0 + (0.375 if flags & 16 else 0.75 if flags else 0.0)) + n * d   # fp32 rows in; int8 image, fp6 image (half), scan's row-major int8 copy out
+    rows = {
+        "prepare (normalise rows, int8 + fp6 images)": {
+            "ms": t_prep, "bound": "hbm", "algorithmic_bytes": 8.0 * (n + m) * d, "bytes_this_kernel_moves_once": moved_prep,
+            "achieved_TBs": moved_prep / (t_prep * 1e-3) / 1e12, "peak_TBs": HBM_PEAK_TBS, "frac": moved_prep / (t_prep * 1e-3) / 1e12 / HBM_PEAK_TBS,
+            "note": "SURVEY 8 D.3's figure (fp32 in, fp32 out) is 8 (N + M) D; the kernel writes one-byte and 6-bit images instead, and reads "
+                    "the rows a second time from L2 / the memory-side cache (DESIGN.md R4.4) -- the fraction counts what must move once"},
+        "coarse pass": {
+            "ms": t_coarse, "bound": "mfma", "flops": 2.0 * n * m * kcols, "achieved_TFLOPs": 2.0 * n * m * kcols / (t_coarse * 1e-3) / 1e12,
+            "peak_TFLOPs": peak_mm, "frac": 2.0 * n * m * kcols / (t_coarse * 1e-3) / 1e12 / peak_mm},
+        "finish (bin survivors, int8 rescan on the matrix cores, fp32 refinement, fp64 decision)": {
+            "ms": t_finish, "bound": "latency (dependent round trips per surviving query; DESIGN.md R4.5)", "frac": None},
+        "threshold + compact (VHM.cpp:501-511, 587-600)": {
+            "ms": t_compact, "bound": "hbm", "algorithmic_bytes": 12.0 * n + 72.0 * C,
+            "achieved_TBs": (12.0 * n + 72.0 * C) / (t_compact * 1e-3) / 1e12, "peak_TBs": HBM_PEAK_TBS,
+            "frac": (12.0 * n + 72.0 * C) / (t_compact * 1e-3) / 1e12 / HBM_PEAK_TBS, "note": "a launch-latency object (1 MB); timed through ops.threshold_compact, which allocates its outputs on the host side -- the "
+                                                      "kernel itself is 11-18 us in profiles/r04_bench_kernel_stats.csv"},
+        "RANSAC + Kabsch (50 000 hypotheses, fp64)": {
+            "ms": t_ransac, "bound": "fp64 valu", "correspondences": C, "algorithmic_flops": iters * (27.0 * C + 400.0),
+            "achieved_TFLOPs": iters * (27.0 * C + 400.0) / (t_ransac * 1e-3) / 1e12, "peak_TFLOPs": FP64_VALU_PEAK_TFLOPS,
+            "frac": iters * (27.0 * C + 400.0) / (t_ransac * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+            "note": "SURVEY 8 D.3's count of the reference's work (every hypothesis scored over every correspondence); the kernels bound every "
+                    "hypothesis in fp32 first and run the oracle's fp64 arithmetic for the survivors only (DESIGN.md 4.3), so a fraction above "
+                    "what fp64 VALUs could do for the full count is work avoided, not a faster ALU"},
+    }
+    rows["sum_of_stages_ms"] = t_prep + t_coarse + t_finish + t_compact + t_ransac
+    return rows
+
+
 def c2_variants(dev, lib, pairs, steps, warmup, iters, streams):
     """Driver-timed C2 figures that do not rest on D.2's prunable noise, same pipeline construction and the
     same timed-loop form as the headline, OUTSIDE the headline's timed region:
@@ -981,12 +1076,30 @@ def main():
                 extra.update(c2_variants(dev, lib, pairs[:4], vdist.pairs_per_rank(num_pairs, world), args.warmup, args.iters, S))
             except Exception as e:
                 extra["error_c2_variants"] = f"{type(e).__name__}: {e}"
+            try:
+                extra["stages"] = stage_table(dev, lib, pairs[0], args.iters, records_kind)
+            except Exception as e:
+                extra["stages"] = {"error": f"{type(e).__name__}: {e}"}
             pairs.clear()
             torch.cuda.empty_cache()
             try:
                 extra.update(extra_configs(dev))
             except Exception as e:  # never lose the headline line to an auxiliary measurement
                 extra["error"] = f"{type(e).__name__}: {e}"
+            try:   # the two stages of C3 in front of the registration, in the same table
+                c3 = extra.get("C3", {})
+                if "ms_vit" in c3 and isinstance(extra.get("stages"), dict) and "error" not in extra["stages"]:
+                    extra["stages"]["ViT-S/14 on 6 x 1200x1600 (C3)"] = {
+                        "ms": c3["ms_vit"], "bound": "mfma", "flops": c3["vit_roofline"]["flops"], "achieved_TFLOPs": c3["vit_roofline"]["achieved"],
+                        "peak_TFLOPs": MFMA_F16_PEAK_TFLOPS, "frac": c3["vit_roofline"]["frac"],
+                        "note": "63 dependent launches; per scan 0.30-0.36 ms when the cameras of 4-8 pairs share a call (extra.ViT_batched, C3_pipelined.grouped)"}
+                    lift_bytes = 6 * N_SCAN * 24.0 + 4.0 * N_SCAN * DIM + 6 * 16 * 21 * DIM * 4.0
+                    extra["stages"]["projection + lifting, 6 cameras (C3)"] = {
+                        "ms": c3["ms_project_lift"], "bound": "hbm", "algorithmic_bytes": lift_bytes,
+                        "achieved_TBs": lift_bytes / (c3["ms_project_lift"] * 1e-3) / 1e12, "peak_TBs": HBM_PEAK_TBS,
+                        "frac": lift_bytes / (c3["ms_project_lift"] * 1e-3) / 1e12 / HBM_PEAK_TBS}
+            except Exception as e:
+                extra["stages"]["error_c3_rows"] = f"{type(e).__name__}: {e}"
         line["extra"] = extra
         print(json.dumps(line), flush=True)
     if grouped:

@@ -77,6 +77,15 @@ def test_bench_under_torch_distributed_run_world1():
     assert ex["C3"]["ms_end_to_end"] > ex["C3"]["ms_vit"] > 0 and 0 < ex["C3"]["vit_roofline"]["frac"] < 1
     assert ex["C3_pipelined"]["value"] > 100 and ex["C3_pipelined"]["grouped"]["value"] > 100 and ex["C3_pipelined"]["grouped"]["pairs_per_vit_call"] == 4
     assert ex["C5"]["pose_err_vs_planted"] < 0.05 and 0.05 < ex["C5"]["roofline"]["frac"] < 1
+    # every stage alone on the GPU with its algorithmic work and the fraction of the peak that bounds it
+    stg = ex["stages"]
+    assert "error" not in stg and "error_c3_rows" not in stg, stg
+    assert 0.05 < stg["coarse pass"]["frac"] < 1.0 and stg["coarse pass"]["bound"] == "mfma"
+    prep = stg["prepare (normalise rows, int8 + fp6 images)"]
+    assert prep["bound"] == "hbm" and 0.1 < prep["frac"] < 1.0 and 0.05 < prep["ms"] < 0.5
+    assert stg["RANSAC + Kabsch (50 000 hypotheses, fp64)"]["correspondences"] > 5000
+    assert 0 < stg["ViT-S/14 on 6 x 1200x1600 (C3)"]["frac"] < 1 and 0 < stg["projection + lifting, 6 cameras (C3)"]["frac"] < 1
+    assert abs(stg["sum_of_stages_ms"] - sum(v["ms"] for k, v in stg.items() if isinstance(v, dict) and "(C3)" not in k)) < 1e-6
 
 
 def test_bench_pairs_form_for_config_c4():
