@@ -37,6 +37,20 @@ def text(name, tail=None):
     return t[-tail:] if tail else t
 
 
+def stage_rows(st):
+    if not st or "error" in st:
+        return "(not collected)"
+    out = ["| stage | ms alone | bound | achieved | fraction of the peak |", "|---|---|---|---|---|"]
+    for k, v in st.items():
+        if not isinstance(v, dict):
+            continue
+        ach = (f"{v['achieved_TBs']:.2f} TB/s" if "achieved_TBs" in v else f"{v['achieved_TFLOPs']:.0f} T(FL)OP/s" if "achieved_TFLOPs" in v else "-")
+        fr = "-" if v.get("frac") is None else f"{v['frac']:.3f}"
+        out.append(f"| {k} | {v['ms']:.3f} | {v['bound'].split(' (')[0]} | {ach} | {fr} |")
+    out.append(f"| sum of the C2 stages | {st.get('sum_of_stages_ms', float('nan')):.3f} | | | |")
+    return "\n".join(out)
+
+
 def pmc_line(p):
     if not p:
         return "(not collected)"
@@ -57,7 +71,7 @@ def main():
               "pipeline_cycle.txt": "r04_pipeline_cycle.txt", "time_vit_batch.txt": "r04_time_vit_batch.txt", "prof_vit_batch.txt": "r04_prof_vit_batch.txt",
               "time_api.txt": "r04_time_api.txt", "time_c3_pipe.txt": "r04_time_c3_pipe.txt", "other_rows.txt": "r04_other_rows.txt",
               "time_pairs.txt": "r04_time_pairs.txt", "time_c3_modes.txt": "r04_time_c3_modes.txt", "neardup.json": "r04_neardup.json", "sweep_slices.txt": "r04_sweep_slices.txt", "trace_c3_pipe.txt": "r04_trace_c3_pipe.txt",
-              "ab_prep_forms.txt": "r04_ab_prep_forms.txt", "vit_split.txt": "r04_vit_split.txt", "hbm_probe.txt": "r04_hbm_probe.txt", "prof_finish.txt": "r04_prof_finish.txt"}
+              "time_c3_group.txt": "r04_time_c3_group.txt", "ab_prep_forms.txt": "r04_ab_prep_forms.txt", "vit_split.txt": "r04_vit_split.txt", "hbm_probe.txt": "r04_hbm_probe.txt", "prof_finish.txt": "r04_prof_finish.txt"}
     for i in range(1, 8):
         copies[f"pmc_mx6_pass{i}_counter_collection.csv"] = f"r04_pmc_mx6_pass{i}_counter_collection.csv"
         copies[f"pmc_mx6half_pass{i}_counter_collection.csv"] = f"r04_pmc_mx6half_pass{i}_counter_collection.csv"
@@ -136,9 +150,19 @@ The same pipeline with the coarse pass pinned, other data, other rows (same proc
 - `extra.A6_mutual_l2`: {a6.get('ms_mutual_pairs', float('nan')):.2f} ms per `find_correspondences(mutual_filter=True)` at C2 size ({a6.get('mutual_pairs')} mutual pairs)
 - `extra.C3`: {c3.get('ms_end_to_end', float('nan')):.2f} ms end to end, one pair at a time (ViT {c3.get('ms_vit', float('nan')):.3f}, project + lift {c3.get('ms_project_lift', float('nan')):.3f}, registration {c3.get('ms_registration', float('nan')):.2f}; ViT at {c3.get('vit_roofline', {}).get('frac', float('nan')):.3f} of the fp16 MFMA peak)
 - `extra.C3_pipelined`: **{c3p.get('value', float('nan')):.1f} registrations/s** from uint8 images ({c3p.get('ms_per_step', float('nan')):.3f} ms per pair; feature stage of pair i + 1 beside the registration of pair i)
+- `extra.C3_pipelined.grouped`: **{c3p.get('grouped', {}).get('value', float('nan')):.1f} registrations/s** with the cameras of {c3p.get('grouped', {}).get('pairs_per_vit_call')} pairs per ViT call (`EndToEndPipeline.submit_group`; {c3p.get('grouped', {}).get('ms_per_step', float('nan')):.3f} ms per pair); `tools/time_c3_group.py` (`r04_time_c3_group.txt`, pairs per call against registrations/s, a process of its own):
+
+```
+{text('r04_time_c3_group.txt')}
+```
+
 - `extra.ViT_batched`: {vb.get('images')} images per call {vb.get('ms', float('nan')):.2f} ms = {vb.get('ms_per_scan_of_6', float('nan')):.3f} ms per scan of 6 ({vb.get('roofline', {}).get('achieved', float('nan')):.0f} TFLOP/s)
 - `extra.API_ransac_registration`: {api.get('ms_without_icp', float('nan')):.2f} ms numpy in / numpy out, {api.get('ms_with_icp', float('nan')):.2f} ms with the ICP refinement (scene's map kept between scans)
 - `extra.C5` (50k x 1M x 768; pass in use: {c5.get('coarse_pass', '?')}): coarse kernel {c5.get('ms_coarse_kernel', float('nan')):.2f} ms = {c5.get('roofline', {}).get('frac', float('nan')):.3f} of {c5.get('roofline', {}).get('peak', 0) / 1000:.0f} P(FL)OP/s, registration {c5.get('ms_registration', float('nan')):.2f} ms
+
+Every stage alone on the GPU with SURVEY 8 D.3's algorithmic work and the peak that bounds it (`extra.stages`; in the pipeline the stages overlap):
+
+{stage_rows(ex.get('stages', {}))}
 
 `python bench.py --streams 1` (every kernel serialised on one stream) -> `profiles/r04_bench_streams1.json`:
 {(f"{b1['value']:.1f} registrations/s, dominant kernel {b1['roofline']['avg_launch_ms']:.3f} ms") if b1 else '(not collected)'}.
