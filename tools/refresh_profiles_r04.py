@@ -123,7 +123,7 @@ def main():
                       f"{sum(nd[name + ' | ' + c]['fallback_queries'] for c in ['auto'] + modes)} |" for name in maps))
     md = f"""# Round 4 -- measurements on one MI355X (config C2: 20 000 x 200 000 x 384, 50 000 RANSAC iterations)
 
-Produced by `bash tools/r04_final.sh` through `gpurun` (a fresh box per call; boxes of the pool differ by up to ~15 %),
+Produced by `bash tools/r04_final.sh` (and, for what changed after it -- tests, bench, kernel stats, C3 in groups --, `bash tools/r04_slim.sh`) through `gpurun` (a fresh box per call; boxes of the pool differ by up to ~15 %),
 collected by `python tools/refresh_profiles_r04.py`.  Raw files are next to this one (`r04_*`).  GPU suite on the same box:
 `{text('r04_pytest_gpu.txt').splitlines()[-1]}`; `__graft_entry__.smoke()`: `{text('r04_smoke.txt').splitlines()[-1]}`.
 
