@@ -144,16 +144,22 @@ class VoxelHashMap:
             self._dev = (rows[:, 3:].float().contiguous(), xyz)   # VoxelHashMap.cpp:472-473: static_cast<float>
         return self._dev
 
-    def search_device(self, q_rows: torch.Tensor, min_cosine_similarity: float, resolve_all: bool = False):
+    def search_device(self, q_rows: Optional[torch.Tensor], min_cosine_similarity: float, resolve_all: bool = False,
+                      q_desc: Optional[torch.Tensor] = None):
         """Device form of the search: (query_idx int64[K], map_idx int64[K], sim fp32[N]) as device tensors.  ``sim`` is the
         best cosine of every query that can reach ``min_cosine_similarity`` and the sentinel -2.0 for queries that provably
         cannot (the gated search does not resolve them; the correspondences are unaffected).  ``resolve_all=True`` runs the
         ungated search instead: ``sim`` is then the reference's D array (VoxelHashMap.cpp:486-495) for every query."""
         b_desc, _ = self._device_map()
-        if q_rows.dim() != 2 or q_rows.shape[1] != b_desc.shape[1] + 3:
-            raise RuntimeError("Unable to cast Python instance to C++ type: expected %d columns"
-                               % (b_desc.shape[1] + 3))  # py::cast_error, stl_vector_eigen.h:76-78
-        q_desc = q_rows[:, 3:].float().contiguous()            # VoxelHashMap.cpp:478-481
+        if q_desc is not None:     # the descriptor columns alone, already float32 (a caller that keeps the coordinates elsewhere)
+            if q_desc.dim() != 2 or q_desc.shape[1] != b_desc.shape[1] or q_desc.dtype != torch.float32:
+                raise RuntimeError("Unable to cast Python instance to C++ type: expected %d float32 descriptor columns" % b_desc.shape[1])
+            q_desc = q_desc.contiguous()
+        else:
+            if q_rows.dim() != 2 or q_rows.shape[1] != b_desc.shape[1] + 3:
+                raise RuntimeError("Unable to cast Python instance to C++ type: expected %d columns"
+                                   % (b_desc.shape[1] + 3))  # py::cast_error, stl_vector_eigen.h:76-78
+            q_desc = q_rows[:, 3:].float().contiguous()            # VoxelHashMap.cpp:478-481
         d = q_desc.shape[1]
         prec = ops.FAST if (d % 128 == 0 and 128 <= d <= 768) else ops.EXACT
         # only matches with cosine >= min_cosine_similarity leave this function (VoxelHashMap.cpp:501-511): the gated search

@@ -32,7 +32,34 @@ class PointCloud:
         self.points = np.zeros((0, 3)) if points is None else points
 
 
+class DeviceArray:
+    """An array that already lives on the GPU (N x 3 fp64 points / C x 2 int32 correspondences), accepted wherever the stand-ins
+    take a numpy array.  ``np.asarray()`` downloads it once, on demand; ``registration_ransac_based_on_correspondence`` reads the
+    device tensor directly -- the reference-shaped call (vfmreg/registration.py) hands the map's 200 000 points over this way instead
+    of downloading 4.8 MB and uploading them again in every call."""
+
+    def __init__(self, t: torch.Tensor):
+        self.device_tensor = t
+        self._host = None
+
+    def __array__(self, dtype=None, copy=None):
+        if self._host is None:
+            self._host = self.device_tensor.cpu().numpy()
+        return self._host if dtype is None else self._host.astype(dtype, copy=False)
+
+    def __len__(self):
+        return int(self.device_tensor.shape[0])
+
+    @property
+    def shape(self):
+        return tuple(self.device_tensor.shape)
+
+
 def Vector3dVector(a):
+    if isinstance(a, DeviceArray):
+        if a.device_tensor.dim() != 2 or a.device_tensor.shape[1] != 3 or a.device_tensor.dtype != torch.float64:
+            raise RuntimeError("Vector3dVector: expected an N x 3 float64 array")
+        return a
     a = np.ascontiguousarray(a, dtype=np.float64)
     if a.ndim != 2 or a.shape[1] != 3:
         raise RuntimeError("Vector3dVector: expected an N x 3 array")
@@ -40,6 +67,10 @@ def Vector3dVector(a):
 
 
 def Vector2iVector(a):
+    if isinstance(a, DeviceArray):
+        if a.device_tensor.dim() != 2 or a.device_tensor.shape[1] != 2 or a.device_tensor.dtype != torch.int32:
+            raise RuntimeError("Vector2iVector: expected a C x 2 int32 array")
+        return a
     a = np.ascontiguousarray(np.asarray(a).reshape(-1, 2), dtype=np.int32)
     return a
 
@@ -60,7 +91,21 @@ class RegistrationResult:
         self.transformation = np.eye(4)
         self.fitness = 0.0
         self.inlier_rmse = 0.0
-        self.correspondence_set = np.zeros((0, 2), dtype=np.int32)
+        self._cs = np.zeros((0, 2), dtype=np.int32)
+        self._cs_lazy = None   # (correspondences, device mask): the inlier set is gathered when somebody reads it (RN:328 reads the pose only)
+
+    @property
+    def correspondence_set(self):
+        if self._cs_lazy is not None:
+            cs, mask = self._cs_lazy
+            cs = np.asarray(cs)
+            self._cs = cs[mask[:len(cs)].cpu().numpy().astype(bool)]
+            self._cs_lazy = None
+        return self._cs
+
+    @correspondence_set.setter
+    def correspondence_set(self, v):
+        self._cs, self._cs_lazy = v, None
 
     def __repr__(self):
         return (f"RegistrationResult with fitness={self.fitness:e}, inlier_rmse={self.inlier_rmse:e}, "
@@ -80,26 +125,42 @@ def registration_ransac_based_on_correspondence(source, target, corres, max_corr
         raise NotImplementedError("correspondence checkers are not used by the reference call")
     if criteria.confidence != 1.0:
         raise NotImplementedError("confidence must be 1 (no early exit), as at registration_node.py:326")
-    src = torch.from_numpy(Vector3dVector(np.asarray(source.points))).cuda()
-    tgt = torch.from_numpy(Vector3dVector(np.asarray(target.points))).cuda()
+    def points_of(pc):
+        pts = pc.points
+        if isinstance(pts, DeviceArray):
+            return Vector3dVector(pts).device_tensor.contiguous()
+        return torch.from_numpy(Vector3dVector(np.asarray(pts))).cuda()
+    src, tgt = points_of(source), points_of(target)
     cs = Vector2iVector(corres)
     res = RegistrationResult()
     if len(cs) < ransac_n or max_correspondence_distance <= 0.0:
         return res  # Open3D returns the default result
-    if cs.min() < 0 or cs[:, 0].max() >= len(src) or cs[:, 1].max() >= len(tgt):
+    if isinstance(cs, DeviceArray):
+        cs_dev = cs.device_tensor.contiguous()
+        lo = cs_dev.min(dim=0).values
+        hi = cs_dev.max(dim=0).values
+        bounds = torch.stack((lo[0], lo[1], hi[0], hi[1])).cpu().numpy()      # one read-back
+        bad = bounds[0] < 0 or bounds[1] < 0 or bounds[2] >= len(src) or bounds[3] >= len(tgt)
+    else:
+        cs_dev = torch.from_numpy(cs).cuda()
+        bad = cs.min() < 0 or cs[:, 0].max() >= len(src) or cs[:, 1].max() >= len(tgt)
+    if bad:
         raise IndexError("correspondence index out of range")
-    out = ops.ransac_corr(src, tgt, torch.from_numpy(cs).cuda(), float(max_correspondence_distance),
+    out = ops.ransac_corr(src, tgt, cs_dev, float(max_correspondence_distance),
                           criteria.max_iteration, seed=_seed[0] if seed is None else seed)
-    res.transformation = out["T"].cpu().numpy()
-    res.fitness = float(out["fitness"].item())
-    res.inlier_rmse = float(out["rmse"].item())
-    res.correspondence_set = cs[out["mask"][:len(cs)].cpu().numpy().astype(bool)]
-    res.best_hypothesis = int(out["best_hyp"].item())
+    # one read-back for pose, fitness, rmse and winner (four .item() / .cpu() calls were four synchronisations)
+    packed = torch.cat((out["T"].reshape(-1), out["fitness"].reshape(-1), out["rmse"].reshape(-1),
+                        out["best_hyp"].reshape(-1).double())).cpu().numpy()
+    res.transformation = packed[:16].reshape(4, 4).copy()
+    res.fitness = float(packed[16])
+    res.inlier_rmse = float(packed[17])
+    res.best_hypothesis = int(packed[18])
+    res._cs_lazy = (cs, out["mask"])
     return res
 
 
 geometry = SimpleNamespace(PointCloud=PointCloud)
-utility = SimpleNamespace(Vector3dVector=Vector3dVector, Vector2iVector=Vector2iVector,
+utility = SimpleNamespace(Vector3dVector=Vector3dVector, Vector2iVector=Vector2iVector, DeviceArray=DeviceArray,
                           random=SimpleNamespace(seed=_seed_fn))
 pipelines = SimpleNamespace(registration=SimpleNamespace(
     registration_ransac_based_on_correspondence=registration_ransac_based_on_correspondence,

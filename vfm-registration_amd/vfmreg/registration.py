@@ -122,16 +122,28 @@ class RegistrationNode:
     # step (85 ms for a 6 000-point scan against a 30 000-point map, against 6 ms this way).
     def _correspond(self, voxel_map, raw_scan, initial_pose):
         vs = self.config.mapping.voxel_size
-        rows, xyz = to_device_rows(np.asarray(raw_scan))
-        rows, xyz, _ = down_sample_device(rows, xyz, vs * 0.5)          # RN:399
-        rows, xyz, _ = down_sample_device(rows, xyz, vs * 1.0)          # RN:400  -> voxel_scan
+        # Only the scan's COORDINATES go to the device up front (N x 3): the three chained voxelisations key on them alone, and of
+        # the N x 387 rows only the few hundred to ~2000 that survive the 5 m grid (RN:414) are ever searched -- their descriptor
+        # columns are gathered on the host by the composed index chain and uploaded then (1 - 3 MB instead of 31 MB at C2 size).
+        scan = np.asarray(raw_scan)
+        if scan.ndim != 2 or scan.shape[1] < 3:
+            raise ValueError("Invalid shape")
+        xyz = torch.from_numpy(np.ascontiguousarray(scan[:, :3], dtype=np.float64)).cuda()
+        o1 = ops.voxel_robin(xyz, vs * 0.5)                             # RN:399
+        xyz = xyz[o1]
+        o2 = ops.voxel_robin(xyz, vs * 1.0)                             # RN:400  -> voxel_scan
+        xyz = xyz[o2]
+        raw_of_voxel_scan = o1[o2]                                      # rows of raw_scan behind voxel_scan, in its order
         voxel_hash_map = self._hash_map_for(voxel_map)                  # RN:402-403 (kept across the scans of a scene)
         T = torch.from_numpy(np.ascontiguousarray(initial_pose, dtype=np.float64)).cuda()
         pcl_xyz = ops.transform_xyz(xyz, T)                             # RN:408 (descriptors carried through)
         out = None
         for voxel in (5.0, 1.0):                                        # RN:414, retry RN:420-423
-            _, sub_xyz, order = down_sample_device(rows, pcl_xyz, voxel)
-            qi, mi, _ = voxel_hash_map.search_device(rows[order], self.min_cosine_similarity)   # RN:418
+            order = ops.voxel_robin(pcl_xyz, voxel)
+            sub_xyz = pcl_xyz[order]
+            raw_idx = raw_of_voxel_scan[order].cpu().numpy()
+            q_desc = torch.from_numpy(np.ascontiguousarray(scan[raw_idx, 3:], dtype=np.float32)).cuda()     # VoxelHashMap.cpp:478-481
+            qi, mi, _ = voxel_hash_map.search_device(None, self.min_cosine_similarity, q_desc=q_desc)       # RN:418
             out = dict(src_rows=order[qi], tgt_rows=mi, src_xyz=sub_xyz[qi])
             if len(qi) >= 75:
                 break
@@ -151,13 +163,13 @@ class RegistrationNode:
         # correspondence indices (RN:288-317).  The reference re-voxelises the scan and the map in 3-D and recovers the
         # rows with two KD-trees (distance < 1e-3); the containers are the same ones (same hash, same order), so the rows
         # are the ones the search already produced.
-        voxel_scan = c["voxel_scan_xyz"].cpu().numpy()
-        voxel_map_3d = c["map_xyz"].cpu().numpy()
+        # (the clouds and the index pairs stay on the device: o3d.utility.DeviceArray -- np.asarray() of one downloads it on demand;
+        # the map's 200 000 points used to go down and up again, 4.8 MB each way, in every call)
         pcd_src = o3d.geometry.PointCloud()
-        pcd_src.points = o3d.utility.Vector3dVector(voxel_scan)
+        pcd_src.points = o3d.utility.Vector3dVector(o3d.utility.DeviceArray(c["voxel_scan_xyz"]))
         pcd_tgt = o3d.geometry.PointCloud()
-        pcd_tgt.points = o3d.utility.Vector3dVector(voxel_map_3d)
-        coors = o3d.utility.Vector2iVector(torch.stack((c["src_rows"], c["tgt_rows"]), dim=1).cpu().numpy())
+        pcd_tgt.points = o3d.utility.Vector3dVector(o3d.utility.DeviceArray(c["map_xyz"]))
+        coors = o3d.utility.Vector2iVector(o3d.utility.DeviceArray(torch.stack((c["src_rows"], c["tgt_rows"]), dim=1).to(torch.int32)))
         result = o3d.pipelines.registration.registration_ransac_based_on_correspondence(
             pcd_src, pcd_tgt, coors, self.max_correspondence_distance,
             o3d.pipelines.registration.TransformationEstimationPointToPoint(False), ransac_n=3,
@@ -168,6 +180,7 @@ class RegistrationNode:
             sigma = self.config.adaptive_threshold.initial_threshold          # RN:339
             # RN:290-293 builds the 3-D hash map from voxel_map[:, :3]: the same kept points in the same container
             vhm = c["voxel_hash_map"]
+            voxel_scan = np.asarray(pcd_src.points)
             pose = register_frame(points=voxel_scan, voxel_map=vhm if not vhm.empty() else vhm.xyz_map(), initial_guess=ransac_pose,
                                   max_correspondance_distance=3 * sigma, kernel=sigma / 3)   # RN:340-344
             return ransac_pose, pose
