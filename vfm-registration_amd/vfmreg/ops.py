@@ -383,5 +383,6 @@ def voxel_robin(xyz: torch.Tensor, voxel_size: float, max_per_voxel: int = 1, re
     _lib.check(lib.vfm_voxel_robin(xyz.data_ptr(), n, stride, float(voxel_size), int(max_per_voxel), int(hash_mul),
                                    n if reserve else -1, keep.data_ptr(), count.data_ptr(), C.cast(info, C.c_void_p),
                                    ws.data_ptr(), ws.numel(), _stream()), "voxel_robin")
-    out = keep[:int(count.item())]
+    # (the entry point synchronises and reports the number of voxels: with one point per voxel that IS the count -- no second read-back)
+    out = keep[:int(info[1]) if max_per_voxel == 1 else int(count.item())]
     return (out, list(info)) if return_info else out
