@@ -49,7 +49,10 @@ int vfm_debug_set_match_stats(int on);
 /* A/B: ViT GEMM wave tile / prefetch depth: NT * 100 + PF for N <= 512 and N > 512 (see csrc/vit.hip); narrow_cfg = -3 / -4:
  * XCD-consistent tile mapping of the ViT kernels on (default) / off; -5: the LDS-tiled GEMM from wide_cfg workgroups of 128 x 128 on
  * (0 = never, default 256); -6: its stage shape, k-steps per stage * 10 + stages (default 23); -7: attention with K / V^T shared through
- * the LDS from wide_cfg images per call on (0 = never, default 1); -8: waves per workgroup of the direct GEMM kernel (1, 2 or 4; 0 = default, 1) */
+ * the LDS from wide_cfg images per call on (0 = never, default 1); -8: waves per workgroup of the direct GEMM kernel (1, 2 or 4; 0 = default, 1);
+ * -9: the token-stationary QKV / fc1 kernel from wide_cfg groups of 128 token rows on (0 = default: where its rounds of one workgroup per
+ * compute unit are at least three quarters full; -1 = never); -10: its waves per workgroup (6, 8, 12 = default; 112 = 12 with non-temporal
+ * output stores); -11 / -12: low / high 32 bits of a device pointer to its per-workgroup placement trace (tools/ab_vit_astat_trace.py; 0 = off) */
 int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
 /* A/B: workgroups of the int8 operand-preparation kernel (-1, default = one per 128-row group; 0 = one per compute unit, each
  * walking several groups with the next group's rows read under the current group's quantisation and store: faster alone,

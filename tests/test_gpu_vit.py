@@ -94,6 +94,30 @@ def test_vit_lds_tiled_gemms_equal_the_direct_kernels_bit_for_bit():
         lib.vfm_debug_set_vit_gemm(-5, 256)
 
 
+def test_vit_token_stationary_gemms_equal_the_other_kernels_bit_for_bit():
+    """vit_gemm_astat_kernel (end of round 4: the QKV / fc1 products of large batches with 128 token rows resident in the LDS, the weight
+    fragments streamed through registers by waves that share nothing else) accumulates every output over the same k order with the same
+    instruction as the direct and the LDS-tiled kernels: identical bits -- also where the token tiles do not fill the last group of four,
+    and at a ViT-B-like width, whose rows (192 KiB) do not fit the LDS: the launcher then keeps the other kernels."""
+    from vfmreg import _lib
+    from vfmreg import vit as V
+    lib = _lib.load()
+    try:
+        for (dim, depth, mlp, B, H, W) in ((384, 2, 1536, 5, 560, 700), (384, 1, 1536, 7, 1200, 1600), (768, 1, 3072, 3, 560, 700),
+                                           (384, 12, 1536, 6, 1200, 1600)):
+            w = V.random_weights(seed=17, dim=dim, depth=depth, mlp=mlp)
+            imgs = torch.from_numpy(_smooth_images(np.random.default_rng(5), B, H, W)).cuda()
+            model = V.ViTS14(w, H, W, device="cuda")
+            lib.vfm_debug_set_vit_gemm(-9, -1)       # never
+            ref = model.forward(imgs).clone()
+            lib.vfm_debug_set_vit_gemm(-9, 1)        # always (QKV and fc1, wherever 128 rows of A fit the LDS)
+            got = model.forward(imgs).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(ref, got), (dim, B, float((ref - got).abs().max()))
+    finally:
+        lib.vfm_debug_set_vit_gemm(-9, 0)            # the default policy: where its rounds of one workgroup per compute unit are full
+
+
 def test_vit_attention_with_keys_and_values_in_the_lds_equals_the_per_tile_kernel_bit_for_bit():
     """vit_attention_lds_kernel (K / V^T of an (image, head) staged once per workgroup, four query tiles per workgroup) against the
     one-wave-per-tile kernel: the same MFMAs over the same fragments in the same order -- identical bits; token counts whose last group

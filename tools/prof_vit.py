@@ -19,6 +19,8 @@ if not fused:
     lib.vfm_debug_set_vit_gemm(108, 208)
 if lds_thr >= 0:
     lib.vfm_debug_set_vit_gemm(-5, lds_thr)
+if len(sys.argv) > 5:                                      # token-stationary QKV / fc1 kernel from this many groups of 128 rows on (0: the default policy, -1: never)
+    lib.vfm_debug_set_vit_gemm(-9, int(sys.argv[5]))
 rng = np.random.default_rng(0)
 imgs = torch.from_numpy(rng.integers(1, 255, (nimg, 1200, 1600, 3), dtype=np.uint8)).cuda()
 model = V.ViTS14(V.random_weights(0), 1200, 1600)

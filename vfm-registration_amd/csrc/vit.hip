@@ -182,6 +182,7 @@ struct GemmArgs {
     _Float16* xh;        // fp16 fragment-tiled copy of the residual stream [M][D]
     float* stats;        // [M][D / 32][2]: (sum x, sum x^2) of the token over each 32-channel slice
     const float* csum;   // [N]: row sums of the (gamma-folded, fp16-rounded) weight
+    unsigned long long* dbg;   // (tools only) per-workgroup start / end / placement of vit_gemm_astat_kernel, or null
 };
 
 // XCD-consistent work mapping (round 3): workgroup b runs on XCD b % 8 (observed placement, speed only).  Every kernel of a block
@@ -276,7 +277,17 @@ __device__ __forceinline__ void ln_stats_load(const GemmArgs& g, int m, float& l
 // and 64-bit frag_index() chains, ~100 instructions per group of four channels.  A 32 x 32 output tile lies inside one (q | k | v, head)
 // and one token tile of one image, so everything but the lane's own offset inside a fragment row is uniform: mt (token tile), tq (token
 // tile inside its image), b, n32 come in as scalars and the destinations are   base(tile) + grp * 256 + lane_off.
-template <int EPI>
+// NT: the fp16 outputs leave with non-temporal stores (vfm_debug_set_vit_gemm(-13, 1), token-stationary kernel only: A/B)
+__device__ __forceinline__ void store_half4(_Float16* p, half4 v, bool nt) {
+    if (nt) {
+        const uint2 u = *reinterpret_cast<const uint2*>(&v);
+        __builtin_nontemporal_store(u.x, reinterpret_cast<unsigned*>(p));
+        __builtin_nontemporal_store(u.y, reinterpret_cast<unsigned*>(p) + 1);
+    } else {
+        *reinterpret_cast<half4*>(p) = v;
+    }
+}
+template <int EPI, bool NT = false>
 __device__ __forceinline__ void epi_tile(const GemmArgs& g, const floatx16& acc, int m, int mt, int b, int tq, int t, int hi, int n32,
                                          const EpiRegs& e, float ln_mean, float ln_rstd) {
     constexpr bool CONSUMES_LN = EPI == EPI_QKV || EPI == EPI_GELU, PRODUCES_LN = EPI == EPI_PATCH || EPI == EPI_RESID;
@@ -333,13 +344,13 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const floatx16& acc,
             half4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (_Float16)gelu_exact(v[j]);
-            *reinterpret_cast<half4*>(frag_base + grp * 256) = o;
+            store_half4(frag_base + grp * 256, o, NT);
         } else {  // EPI_QKV
             if (qk_base) {
                 half4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[j];
-                *reinterpret_cast<half4*>(qk_base + grp * 256) = o;
+                store_half4(qk_base + grp * 256, o, NT);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) vt_base[(8 * grp + j) * 8] = (_Float16)v[j];
@@ -527,6 +538,91 @@ __global__ __launch_bounds__(256, 3) void vit_gemm_lds_kernel(GemmArgs g) {
             epi_load<EPI>(g, m, t, hi, n32, e);
             epi_tile<EPI>(g, acc[i][j], m, mtu, b, tq, t, hi, n32, e, ln_mean, ln_rstd);
         }
+    }
+}
+
+// ---- the wide K = dim products (QKV, fc1) of LARGE batches with the token rows stationary (end of round 4).  The 128 x 128 kernel above
+// fetches every A tile N / 128 times and every W tile M / 128 times from the L2: 0.5 KiB per MFMA, 370 - 500 MB per GEMM at 96 images, and
+// it runs at the ~5.5 TB/s the L2 -> LDS path delivers to it (fc2, with four times the k-loop per tile, reaches 7.8).  Here a workgroup keeps
+// its 128 token rows -- 4 tiles x KS fragment rows = 96 KiB at K = 384 -- in the LDS for the whole kernel and its NW waves share nothing
+// else: wave w takes channel tiles w, w + NW, ... , streams THEIR weight fragments through a register ring (plain loads: the compiler
+// counts them) and multiplies each with the four A fragments of the k-step from the LDS.  0.25 KiB per MFMA from the L2, no barrier after
+// the first, a wave's epilogue stalls nobody else.  One workgroup per compute unit: it pays when its rounds of 256 workgroups are full
+// (launch_gemm's policy; measured per batch size in tools/ab_vit_astat.py).
+// Same MFMAs over the same fragments in the same k order: bit-identical to the other two kernels.
+template <int EPI, int NW, int PF, bool NTS = false>
+__global__ __launch_bounds__(64 * NW, 1) void vit_gemm_astat_kernel(GemmArgs g) {
+    static_assert(EPI == EPI_QKV || EPI == EPI_GELU, "the residual epilogues read a row-sized operand per tile: not this kernel");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [4 token tiles][KS][1 KiB]
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mtiles = g.M / 32, KS = g.KS, mg = blockIdx.x;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    unsigned long long dbg_t0 = 0;
+    if (g.dbg) dbg_t0 = wall_clock64();
+    for (int p = wave; p < 4 * KS; p += NW) {
+        const int tile = p / KS, ks = p - tile * KS;
+        int rowtile = mg * 4 + tile;
+        if (rowtile >= mtiles) rowtile = mtiles - 1;   // (a partial last group: its epilogue is skipped)
+        vit_glds16(g.A + ((size_t)rowtile * KS + ks) * 64 + lane, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)p * 1024u));
+    }
+    const int hi = lane >> 5, lane31 = lane & 31;
+    float ln_mean[4], ln_rstd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int mt = mg * 4 + i;
+        if (mt >= mtiles) mt = mtiles - 1;
+        ln_stats_load(g, mt * 32 + lane31, ln_mean[i], ln_rstd[i]);
+    }
+    vit_wait_vmcnt<0>();
+    __syncthreads();
+    const int ntiles = g.N / 32, qtiles = g.Tp >> 5;
+    for (int nt = wave; nt < ntiles; nt += NW) {
+        const uint4* Wp = g.W + (size_t)nt * KS * 64 + lane;
+        uint4 rw[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+            if (i < KS) rw[i] = Wp[(size_t)i * 64];
+        const int n32 = __builtin_amdgcn_readfirstlane(nt);
+        EpiRegs e;
+        epi_load<EPI>(g, 0, 0, hi, n32, e);   // bias + row sums of the folded weight: per channel, the same for the four token tiles
+        floatx16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int s0 = 0; s0 < KS; s0 += PF) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int s = s0 + i;
+                if (s < KS) {
+                    const half8 wv = *reinterpret_cast<half8*>(&rw[i]);
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) {
+                        const half8 af = *reinterpret_cast<const half8*>(lds + ((size_t)(t4 * KS + s)) * 1024 + lane * 16);
+                        acc[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, af, acc[t4], 0, 0, 0);
+                    }
+                    if (s + PF < KS) rw[i] = Wp[(size_t)(s + PF) * 64];
+                }
+            }
+        }
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const int mt = mg * 4 + t4;
+            if (mt >= mtiles) continue;   // workgroup-uniform
+            const int mtu = __builtin_amdgcn_readfirstlane(mt);
+            const int b = mtu / qtiles, tq = mtu - b * qtiles;
+            epi_tile<EPI, NTS>(g, acc[t4], mt * 32 + lane31, mtu, b, tq, tq * 32 + lane31, hi, n32, e, ln_mean[t4], ln_rstd[t4]);
+        }
+    }
+    if (g.dbg && wave == NW - 1 && lane == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g.dbg[blockIdx.x * 4 + 0] = dbg_t0;
+        g.dbg[blockIdx.x * 4 + 1] = wall_clock64();
+        g.dbg[blockIdx.x * 4 + 2] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+        g.dbg[blockIdx.x * 4 + 3] = 0;
     }
 }
 
@@ -954,8 +1050,67 @@ int launch_gemm_cfg(const GemmArgs& g, hipStream_t st) {
 int g_vit_lds_shape = 23;     // vfm_debug_set_vit_gemm(-6, KB * 10 + NS): k-steps per stage / stages in the ring of the LDS-tiled kernel (23: 48 KiB, three workgroups per compute unit)
 int g_vit_att_lds_min = 1;   // vfm_debug_set_vit_gemm(-7, n): attention with K / V^T in the LDS from n images per call on (0 = never)
 int g_vit_lds_min_wg = 256;   // vfm_debug_set_vit_gemm(-5, n): the LDS-tiled kernel from n workgroups of 128 x 128 on (0 = never)
+unsigned long long* g_vit_astat_dbg = nullptr;   // vfm_debug_set_vit_gemm(-11, lo) / (-12, hi): device buffer [workgroup][4] = start, end (100 MHz ticks), (xcc << 32 | HW_ID), 0
+int g_vit_astat_min = 0;      // vfm_debug_set_vit_gemm(-9, n): the token-stationary kernel for QKV / fc1 from n groups of 128 token rows on (0 = where its rounds are full: launch_gemm; -1 = never)
+int g_vit_astat_nw = 0;       // vfm_debug_set_vit_gemm(-10, n): its waves per workgroup where n divides N / 32 (6, 8, 16; otherwise 12)
 template <int EPI>
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
+    if constexpr (EPI == EPI_QKV || EPI == EPI_GELU) {
+        const int groups = ceil_div(g.M / 32, 4);
+        const int nw = g_vit_astat_nw == 112 ? 112 : (g_vit_astat_nw > 0 && (g.N / 32) % g_vit_astat_nw == 0 ? g_vit_astat_nw : 12);
+        // One workgroup per compute unit: the kernel pays when its rounds are full.  g_vit_astat_min > 0: from that many groups on whatever
+        // the fill (tools); 0 (default): when the last round of `ncu` workgroups is at least three quarters full and there is at least one
+        // such round -- 69 ... 93 images of 1200 x 1600 at a time on 256 compute units (tools/ab_vit_astat.py: 48 images 2.19 -> 2.30 ms,
+        // 84: 3.35 -> 3.22, 93: 3.60 -> 3.49, 96 = 264 groups, eight of them alone in a second round: 3.95 -> 4.58)
+        static int ncu = 0;
+        if (ncu == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            (void)hipGetDevice(&dev);
+            ncu = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        const int last_round = groups % ncu;
+        const bool full_rounds = groups >= (3 * ncu) / 4 && (last_round == 0 || 4 * last_round >= 3 * ncu);
+        const bool want = g_vit_astat_min > 0 ? groups >= g_vit_astat_min : (g_vit_astat_min == 0 && full_rounds);
+        if (want && 4 * g.KS * 1024 <= 128 * 1024 && (nw == 112 || (g.N / 32) % nw == 0)) {
+#define VIT_ASTAT(NW)                                                                                                                \
+    do {                                                                                                                             \
+        static unsigned long long attr_set = 0ull;                                                                                   \
+        int dev = 0;                                                                                                                 \
+        (void)hipGetDevice(&dev);                                                                                                    \
+        if (!((attr_set >> (dev & 63)) & 1ull)) {                                                                                    \
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_gemm_astat_kernel<EPI, NW, 6>),                     \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));                              \
+            attr_set |= 1ull << (dev & 63);                                                                                          \
+        }                                                                                                                            \
+        GemmArgs ga = g;                                                                                                             \
+        ga.dbg = g_vit_astat_dbg;                                                                                                    \
+        hipLaunchKernelGGL((vit_gemm_astat_kernel<EPI, NW, 6>), dim3(groups), dim3(64 * NW), 4 * g.KS * 1024, st, ga);               \
+    } while (0)
+            switch (nw) {
+                case 6: VIT_ASTAT(6); break;
+                case 112: {   // (A/B) twelve waves, non-temporal output stores
+                    static unsigned long long attr_set2 = 0ull;
+                    int dev = 0;
+                    (void)hipGetDevice(&dev);
+                    if (!((attr_set2 >> (dev & 63)) & 1ull)) {
+                        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_gemm_astat_kernel<EPI, 12, 6, true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                        attr_set2 |= 1ull << (dev & 63);
+                    }
+                    GemmArgs ga = g;
+                    ga.dbg = g_vit_astat_dbg;
+                    hipLaunchKernelGGL((vit_gemm_astat_kernel<EPI, 12, 6, true>), dim3(groups), dim3(768), 4 * g.KS * 1024, st, ga);
+                } break;
+                case 8: VIT_ASTAT(8); break;
+                case 16: VIT_ASTAT(16); break;
+                default: VIT_ASTAT(12); break;
+            }
+#undef VIT_ASTAT
+            VFM_CHECK_LAUNCH("vit_gemm_astat_kernel");
+            return VFM_OK;
+        }
+    }
     if (g.N % 128 == 0 && g_vit_lds_min_wg > 0) {
         const int wgs = ceil_div(g.M / 32, 4) * (g.N / 128);
         if (wgs >= g_vit_lds_min_wg) {
@@ -1009,6 +1164,20 @@ VFM_EXPORT int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg) {
     }
     if (narrow_cfg == -7) {   // attention with K / V^T of an (image, head) in the LDS from wide_cfg images per call on (0: never)
         g_vit_att_lds_min = wide_cfg;
+        return VFM_OK;
+    }
+    if (narrow_cfg == -11 || narrow_cfg == -12) {   // (tools/ab_vit_astat_trace.py) device pointer of the placement trace, low / high 32 bits
+        unsigned long long v = (unsigned long long)(uintptr_t)g_vit_astat_dbg;
+        v = narrow_cfg == -11 ? ((v & 0xffffffff00000000ull) | (unsigned)wide_cfg) : ((v & 0xffffffffull) | ((unsigned long long)(unsigned)wide_cfg << 32));
+        g_vit_astat_dbg = reinterpret_cast<unsigned long long*>((uintptr_t)v);
+        return VFM_OK;
+    }
+    if (narrow_cfg == -10) {
+        g_vit_astat_nw = wide_cfg;
+        return VFM_OK;
+    }
+    if (narrow_cfg == -9) {   // the token-stationary kernel (QKV, fc1) from wide_cfg groups of 128 token rows on (0: the default policy, -1: never)
+        g_vit_astat_min = wide_cfg;
         return VFM_OK;
     }
     if (narrow_cfg == -5) {   // the LDS-tiled GEMM kernel from wide_cfg workgroups on (0: never; default 256)
