@@ -71,7 +71,7 @@ def main():
               "pipeline_cycle.txt": "r04_pipeline_cycle.txt", "time_vit_batch.txt": "r04_time_vit_batch.txt", "prof_vit_batch.txt": "r04_prof_vit_batch.txt",
               "time_api.txt": "r04_time_api.txt", "time_c3_pipe.txt": "r04_time_c3_pipe.txt", "other_rows.txt": "r04_other_rows.txt",
               "time_pairs.txt": "r04_time_pairs.txt", "time_c3_modes.txt": "r04_time_c3_modes.txt", "neardup.json": "r04_neardup.json", "sweep_slices.txt": "r04_sweep_slices.txt", "trace_c3_pipe.txt": "r04_trace_c3_pipe.txt",
-              "time_c3_group.txt": "r04_time_c3_group.txt", "ab_prep_forms.txt": "r04_ab_prep_forms.txt", "vit_split.txt": "r04_vit_split.txt", "hbm_probe.txt": "r04_hbm_probe.txt", "prof_finish.txt": "r04_prof_finish.txt"}
+              "time_c3_group.txt": "r04_time_c3_group.txt", "ab_vit_astat.txt": "r04_ab_vit_astat.txt", "ab_prep_forms.txt": "r04_ab_prep_forms.txt", "vit_split.txt": "r04_vit_split.txt", "hbm_probe.txt": "r04_hbm_probe.txt", "prof_finish.txt": "r04_prof_finish.txt"}
     for i in range(1, 8):
         copies[f"pmc_mx6_pass{i}_counter_collection.csv"] = f"r04_pmc_mx6_pass{i}_counter_collection.csv"
         copies[f"pmc_mx6half_pass{i}_counter_collection.csv"] = f"r04_pmc_mx6half_pass{i}_counter_collection.csv"

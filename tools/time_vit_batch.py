@@ -22,7 +22,7 @@ import os
 if os.environ.get("VFM_VIT_LDS_SHAPE"):
     lib.vfm_debug_set_vit_gemm(-6, int(os.environ["VFM_VIT_LDS_SHAPE"]))
 THRS = [int(x) for x in os.environ.get("VFM_VIT_LDS_THR", "0,512,256,128").split(",")]   # workgroups from which the LDS-tiled GEMM is used (0: never)
-for thr, nimg in [(t, n) for t in THRS for n in (6, 12, 24, 48, 96)]:
+for thr, nimg in [(t, n) for t in THRS for n in (6, 12, 24, 48, 90, 96)]:
     lib.vfm_debug_set_vit_gemm(-5, thr)
     imgs = all_imgs[:nimg]
     model = V.ViTS14(V.random_weights(0), 1200, 1600)
