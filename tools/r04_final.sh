@@ -32,6 +32,8 @@ bash tools/prof_vit_batch.sh > $O/prof_vit_batch.txt 2>&1
 timeout 600 python tools/time_api.py > $O/time_api.txt 2>&1; tail -12 $O/time_api.txt
 timeout 600 python tools/time_c3_pipe.py 0 > $O/time_c3_pipe.txt 2>&1; tail -6 $O/time_c3_pipe.txt
 bash tools/trace_c3_pipe.sh > $O/trace_c3_pipe.txt 2>&1
+timeout 400 python tools/time_c3_group.py 1 2 4 8 1 4 2>&1 | grep -v amdgpu > $O/time_c3_group.txt; cat $O/time_c3_group.txt
+VFM_AB_IMAGES=48,72,84,90,93,96,144 timeout 400 python tools/ab_vit_astat.py 144 2>&1 | grep -v amdgpu > $O/ab_vit_astat.txt; cat $O/ab_vit_astat.txt
 timeout 600 python tools/ab_prep_r4.py 2>&1 | grep -v amdgpu > $O/ab_prep_forms.txt
 timeout 300 python tools/ab_vit_split.py 2>&1 | grep -v amdgpu > $O/vit_split.txt
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/hbm_probe tools/probe/hbm_probe.hip && /tmp/hbm_probe > $O/hbm_probe.txt 2>&1
