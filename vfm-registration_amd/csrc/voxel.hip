@@ -284,6 +284,7 @@ __global__ __launch_bounds__(64) void robin_replay_kernel(const int* __restrict_
     const int64_t ncl = cidx[m - 1];
     if (c >= ncl) return;
     const int i0 = cl_start[c], L = cl_start[c + 1] - i0, base = cl_base[c];
+    if (L > RH_MAX_CLUSTER) return;   // (one thread replays a cluster: the host rejects such a table from geninfo[4], in the same read-back)
     int* D = tab_dist + i0;
     int* I = tab_id + i0;
     int maxd = 0;
@@ -567,15 +568,6 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
                                w.cl_of_pos, w.cl_start, w.cl_base, w.tab_dist);
             hipLaunchKernelGGL(robin_wrap_kernel, dim3(1), dim3(1), 0, st, w.cm, m, B, (int64_t)z, w.geninfo);
             hipLaunchKernelGGL(robin_maxlen_kernel, dim3(gm), dim3(256), 0, st, w.cl_start, w.cidx, m, w.geninfo);
-            {
-                int64_t gl[5];
-                VFM_CHECK_HIP(hipMemcpyAsync(gl, w.geninfo, sizeof(gl), hipMemcpyDeviceToHost, st));
-                VFM_CHECK_HIP(hipStreamSynchronize(st));
-                if (gl[4] > RH_MAX_CLUSTER)
-                    return vfm_fail(VFM_EINVAL, "voxel_robin: a run of %lld occupied buckets -- the reference container's 20-bit "
-                                    "VoxelHash is saturated (%lld voxels in %lld buckets); not reproduced", (long long)gl[4],
-                                    (long long)m, (long long)B);
-            }
             int cbits = 1;
             while ((1ll << cbits) < m) ++cbits;
             tb = w.cub_bytes;
@@ -583,9 +575,13 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
                                                             cbits, st));
             hipLaunchKernelGGL(robin_replay_kernel, dim3(blocks_of(m, 64)), dim3(64), 0, st, w.cl_start, w.cl_base, w.cidx, m,
                                w.arrivals, w.vhash, mask, z, w.tab_dist, w.tab_id, w.geninfo);
-            int64_t gi[4];
+            int64_t gi[5];   // one read-back per pass: wrap analysis, probe distance and the longest run (the replay skips runs beyond the limit)
             VFM_CHECK_HIP(hipMemcpyAsync(gi, w.geninfo, sizeof(gi), hipMemcpyDeviceToHost, st));
             VFM_CHECK_HIP(hipStreamSynchronize(st));
+            if (gi[4] > RH_MAX_CLUSTER)
+                return vfm_fail(VFM_EINVAL, "voxel_robin: a run of %lld occupied buckets -- the reference container's 20-bit "
+                                "VoxelHash is saturated (%lld voxels in %lld buckets); not reproduced", (long long)gi[4],
+                                (long long)m, (long long)B);
             if (gi[0] > 0) {  // entries wrapped past the last bucket: redo in rotated coordinates
                 if (pass == 1 || gi[1] < 0) return vfm_fail(VFM_EINVAL, "voxel_robin: wrap analysis failed (table saturated)");
                 z = (unsigned)gi[1];
