@@ -45,6 +45,7 @@ class VoxelHashMap:
         self._chunks = {}
         self._ordered = {}      # kind -> (rows, xyz64) in container iteration order (cache)
         self._dev = None        # cached (descriptors fp32, xyz fp64) of the N-D map (IndexFlatIP.add)
+        self._prep = None       # ... and its prepared search operand (1 / |row| + the coarse pass's images), made at the first gated search
         self._xyz = None        # cached xyz_map() (it carries the ICP grid register_frame builds from it)
 
     @staticmethod
@@ -88,6 +89,7 @@ class VoxelHashMap:
         self._chunks.setdefault(kind, []).append((rows[keep_new], xyz64[keep_new]))
         self._ordered.pop(kind, None)
         self._dev = None
+        self._prep = None
         self._xyz = None
         self.__dict__.pop("_icp_grid", None)
 
@@ -165,7 +167,14 @@ class VoxelHashMap:
         # only matches with cosine >= min_cosine_similarity leave this function (VoxelHashMap.cpp:501-511): the gated search
         # leaves queries that provably cannot reach it unresolved (sim = -2.0 in the returned array)
         gate = float(np.nextafter(np.float32(min_cosine_similarity), np.float32(-np.inf)))
-        idx, sim = ops.match_ip_top1(q_desc, b_desc, prec, gate=gate if (prec == ops.FAST and not resolve_all) else None)
+        if prec == ops.FAST and not resolve_all and ops.gated_split_ok(d) and q_desc.shape[0] > 0:
+            # the map is searched by every scan of a scene (RN:587-589): its operand is prepared once (IndexFlatIP.add happens once in the
+            # reference too, VoxelHashMap.cpp:486-487), a call prepares its few hundred query rows and runs the gated search on both
+            if self._prep is None or self._prep.x is not b_desc:
+                self._prep = ops.PreparedRows(b_desc)
+            idx, sim = ops.match_search_gated(ops.PreparedRows(q_desc), self._prep, gate)
+        else:
+            idx, sim = ops.match_ip_top1(q_desc, b_desc, prec, gate=gate if (prec == ops.FAST and not resolve_all) else None)
         r = ops.threshold_compact(sim, idx, float(min_cosine_similarity), want_corres=True)
         k = int(r["count"].item())
         corres = r["corres"][:k]

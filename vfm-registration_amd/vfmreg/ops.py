@@ -110,6 +110,35 @@ def match_search(q: PreparedRows, b: PreparedRows, idx: Optional[torch.Tensor] =
     return idx, sim
 
 
+def gated_split_ok(d: int) -> bool:
+    """Widths for which the gated family's split calls exist (the int8 coarse pass: d = 256 ... 768 in steps of 128)."""
+    return d % 128 == 0 and 256 <= d <= 768
+
+
+def match_search_gated(q: PreparedRows, b: PreparedRows, gate: float, idx: Optional[torch.Tensor] = None,
+                       sim: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None):
+    """vfm_match_search_coarse_gated + vfm_match_search_finish_gated on prepared operands: what vfm_match_ip_top1_gated does after
+    preparing both -- for a map that is prepared once and searched by many scans.  Same answers (idx -1 / sim -2.0 for queries that
+    provably cannot reach ``gate``)."""
+    lib = _lib.load()
+    if q.d != b.d or not gated_split_ok(q.d):
+        raise ValueError("Invalid shape")
+    dev = q.x.device
+    need = lib.vfm_match_search_workspace_bytes(q.rows, b.rows, q.d)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, dev)
+    if idx is None:
+        idx = torch.empty(q.rows, dtype=torch.int64, device=dev)
+    if sim is None:
+        sim = torch.empty(q.rows, dtype=torch.float32, device=dev)
+    st = _stream()
+    _lib.check(lib.vfm_match_search_coarse_gated(q.buf.data_ptr(), q.rows, b.buf.data_ptr(), b.rows, q.d, ws.data_ptr(), ws.numel(), st),
+               "search(coarse)")
+    _lib.check(lib.vfm_match_search_finish_gated(q.x.data_ptr(), q.buf.data_ptr(), q.rows, b.x.data_ptr(), b.buf.data_ptr(), b.rows, q.d,
+                                                 idx.data_ptr(), sim.data_ptr(), ws.data_ptr(), ws.numel(), float(gate), st), "search(finish)")
+    return idx, sim
+
+
 def threshold_compact(sim: torch.Tensor, idx: Optional[torch.Tensor], thr: float,
                       q_xyz: Optional[torch.Tensor] = None, b_xyz: Optional[torch.Tensor] = None,
                       want_corres: bool = True):
