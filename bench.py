@@ -107,7 +107,7 @@ def cpu_baseline(p, iters=RANSAC_ITERS, T_gpu=None):
     return out, delta
 
 
-def live_traffic(records_kind: int, timeout_s: int = 120):
+def live_traffic(records_kind: int, timeout_s: int = 60):
     """HBM bytes per launch of the coarse kernel, measured while bench.py runs: FETCH_SIZE and WRITE_SIZE from two SEPARATE
     `rocprofv3 --kernel-trace --pmc <counter>` passes (MI355X_MICROARCH.md, HBM / rocprofv3 section: no other trace domain beside
     --pmc) of tools/prof_match.py -- the matching stage of config C2 at the record kind the timed region ran, three launches --
