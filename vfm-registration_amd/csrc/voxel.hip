@@ -501,16 +501,18 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
     select_first_k(pts, n, stride, voxel_size, K, w, st);
     hipcub::CountingInputIterator<int64_t> it(0);
     size_t tb = w.cub_bytes;
-    VFM_CHECK_HIP(hipcub::DeviceSelect::Flagged(w.cub, tb, it, w.keepflag, w.kept, w.counts + 0, (int)n, st));
+    // (one point per voxel: the kept points ARE the voxels' first points -- one compaction instead of two, and nk = nv)
+    if (K > 1) VFM_CHECK_HIP(hipcub::DeviceSelect::Flagged(w.cub, tb, it, w.keepflag, w.kept, w.counts + 0, (int)n, st));
     tb = w.cub_bytes;
     VFM_CHECK_HIP(hipcub::DeviceSelect::Flagged(w.cub, tb, it, w.first, w.vfirst, w.counts + 1, (int)n, st));
+
     hipLaunchKernelGGL(robin_voxel_info_kernel, dim3(blocks_of(n)), dim3(256), 0, st, pts, stride, voxel_size, hash_mul_y,
                        w.vfirst, w.counts + 1, w.slot_of, w.vhash, w.slot_vid);
     // the generation sizes depend on the number of voxels: one 16-byte read-back (this entry point synchronises)
     int64_t counts_h[2];
     VFM_CHECK_HIP(hipMemcpyAsync(counts_h, w.counts, sizeof(counts_h), hipMemcpyDeviceToHost, st));
     VFM_CHECK_HIP(hipStreamSynchronize(st));
-    const int64_t nk = counts_h[0], nv = counts_h[1];
+    const int64_t nv = counts_h[1], nk = K == 1 ? nv : counts_h[0];
 
     // tsl::robin_map state: bucket count B, s entries inserted, current iteration order in `cur`
     int64_t B = 0, s = 0, max_dist = 0, n_wrapped_gens = 0;
@@ -615,7 +617,7 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
             VFM_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(w.cub, tb, pkey, w.cl_of_pos, w.kept, keep_out, (int)nk, 0, vbits, st));
         }
     }
-    VFM_CHECK_HIP(hipMemcpyAsync(count_out, w.counts + 0, sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    VFM_CHECK_HIP(hipMemcpyAsync(count_out, w.counts + (K == 1 ? 1 : 0), sizeof(int64_t), hipMemcpyDeviceToDevice, st));
     VFM_CHECK_LAUNCH("voxel_robin kernels");
     if (info_host) {
         info_host[0] = B;
