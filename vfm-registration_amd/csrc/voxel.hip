@@ -441,7 +441,8 @@ inline VoxelWs carve_voxel(void* p, int64_t n, bool robin) {
 inline unsigned blocks_of(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per > 0 ? (n + per - 1) / per : 1); }
 
 // step (1): state[i] == 1 for the survivors, first[i] for the first point of every voxel
-int select_first_k(const double* pts, int64_t n, int64_t stride, double voxel_size, int32_t K, const VoxelWs& w, hipStream_t st) {
+int select_first_k(const double* pts, int64_t n, int64_t stride, double voxel_size, int32_t K, const VoxelWs& w, hipStream_t st,
+                   bool want_keepflag = true) {
     const unsigned gb = blocks_of(n);
     hipLaunchKernelGGL(voxel_init_kernel, dim3(blocks_of(w.hsize)), dim3(256), 0, st, w.owner, w.tcount, w.tmin, w.hsize);
     if (n > 0) {
@@ -454,7 +455,7 @@ int select_first_k(const double* pts, int64_t n, int64_t stride, double voxel_si
             hipLaunchKernelGGL(voxel_round_min_kernel, dim3(gb), dim3(256), 0, st, n, w.slot_of, w.state, w.tmin);
             hipLaunchKernelGGL(voxel_round_take_kernel, dim3(gb), dim3(256), 0, st, n, w.slot_of, w.state, w.tmin);
         }
-        hipLaunchKernelGGL(voxel_keepflag_kernel, dim3(gb), dim3(256), 0, st, n, w.state, w.keepflag);
+        if (want_keepflag) hipLaunchKernelGGL(voxel_keepflag_kernel, dim3(gb), dim3(256), 0, st, n, w.state, w.keepflag);
     }
     return VFM_OK;
 }
@@ -498,7 +499,7 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
         return VFM_OK;
     }
     const int K = max_per_voxel;
-    select_first_k(pts, n, stride, voxel_size, K, w, st);
+    select_first_k(pts, n, stride, voxel_size, K, w, st, K > 1);
     hipcub::CountingInputIterator<int64_t> it(0);
     size_t tb = w.cub_bytes;
     // (one point per voxel: the kept points ARE the voxels' first points -- one compaction instead of two, and nk = nv)
