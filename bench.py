@@ -243,6 +243,9 @@ def extra_configs(dev):
             t0 = _time.perf_counter()
             for i in range(steps_e2e):
                 res = e2e.submit(img_sets[i % 2], pcl, q_xyz, b_desc, b_xyz, inputs_ready=ready)
+                if steps_e2e == 8:        # the settle pass: one pair at a time, so that the policy reads every search's feedback (as --form c3 does)
+                    e2e.synchronize()
+                    torch.cuda.synchronize()
                 e2e.reg._poll_feedback()
             e2e.synchronize()
             torch.cuda.synchronize()
@@ -266,6 +269,9 @@ def extra_configs(dev):
                 for lo in range(0, steps_e2e, G):
                     res = e2e.submit_group([(img_sets[i % 2], pcl, q_xyz, b_desc, b_xyz) for i in range(lo, min(lo + G, steps_e2e))],
                                            inputs_ready=ready)[-1]
+                    if steps_e2e == 8:    # the settle pass, one group at a time
+                        e2e.synchronize()
+                        torch.cuda.synchronize()
                     e2e.reg._poll_feedback()
                 e2e.synchronize()
                 torch.cuda.synchronize()
@@ -808,6 +814,9 @@ def main():
     from vfmreg import _lib, synth
     from vfmreg import dist as vdist
     from vfmreg.pipeline import RegistrationPipeline
+    if os.environ.get("VFM_LAZY_STREAMS") == "1":   # A/B only (tools/ab_queue_touch.sh): side streams bound to hardware queues at first use
+        from vfmreg import pipeline as _pl
+        _pl.TOUCH_STREAMS_AT_CREATION = False
 
     rank, world = vdist.init_from_env(backend="nccl", device=dev)  # "nccl" == RCCL on ROCm
 

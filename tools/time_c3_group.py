@@ -37,6 +37,24 @@ q_xyz = torch.from_numpy(np.ascontiguousarray(xyz)).to(dev)
 b_xyz[pick] = q_xyz + 0.02 * torch.randn(n, 3, device=dev, generator=g, dtype=torch.float64)
 img_sets = [imgs, torch.flip(imgs, dims=[0]).contiguous()]
 STEPS = 192
+import os
+from vfmreg import pipeline as _pl
+_pl.FEATURE_QUEUE_SKIP = int(os.environ.get("VFM_FEATURE_SKIP", _pl.FEATURE_QUEUE_SKIP))
+if os.environ.get("VFM_PREAMBLE"):   # what bench.py has done by the time it measures extra.C3_pipelined: C2 pipelines on D.2 data, then freed
+    from vfmreg import synth
+    from vfmreg.pipeline import RegistrationPipeline
+    prs = [synth.make_pair_device(20000, 200000, 384, seed=42 + j, device=dev) for j in range(4)]
+    for mode in os.environ["VFM_PREAMBLE"].split(","):
+        pp = RegistrationPipeline(20000, 200000, 384, n_iter=50000, device=dev, overlap_ransac=True, overlap_prepare=True, solve_streams=2, coarse=mode)
+        for i in range(200):
+            q = prs[i % 4]
+            pp.register(q["q_desc"], q["q_xyz"], q["b_desc"], q["b_xyz"])
+            pp._poll_feedback()
+        pp.synchronize()
+        torch.cuda.synchronize()
+        del pp
+    del prs
+    torch.cuda.empty_cache()
 for G in [int(x) for x in (sys.argv[1:] or ["1", "2", "4", "8", "1"])]:
     e2e = EndToEndPipeline(model, rig, n, m, n_iter=50000, depth=4, group=G, group_depth=3)
     torch.cuda.synchronize()

@@ -76,18 +76,36 @@ PREP_STREAM_PRIORITY = 0
 SOLVE_STREAM_PRIORITY = 0
 
 
+# A HIP stream is bound to one of the process's hardware queues (four by default, round robin) when it is first USED, not when it is created.
+# The side streams are therefore used once, in a fixed order, the moment they are created: preparation, solve 0, solve 1 take the three queues
+# behind the default stream's whatever the program does between building a pipeline and its first registration -- under torch.distributed.run
+# the warm-up collective's stream used to slip in between and push the second solve stream onto the coarse kernels' queue
+# (tools/ab_queue_touch.sh).  TOUCH_STREAMS_AT_CREATION = False restores the lazy binding (A/B).
+TOUCH_STREAMS_AT_CREATION = True
+
+
+def _touch(stream: torch.cuda.Stream, dev: torch.device) -> None:
+    if TOUCH_STREAMS_AT_CREATION:
+        with torch.cuda.stream(stream):
+            torch.zeros(1, device=dev)
+
+
 def _side_streams(dev: torch.device, n_solve: int):
     key = (dev.index if dev.index is not None else torch.cuda.current_device())
     prep, solve = _SIDE_STREAMS.get(key, (None, []))
     if prep is None:
         prep = torch.cuda.Stream(device=dev, priority=PREP_STREAM_PRIORITY)
+        _touch(prep, dev)
     while len(solve) < n_solve:
         solve.append(torch.cuda.Stream(device=dev, priority=SOLVE_STREAM_PRIORITY))
+        _touch(solve[-1], dev)
     _SIDE_STREAMS[key] = (prep, solve)
     return prep, solve[:n_solve]
 
 
 _FEATURE_STREAMS = {}
+_PLACEHOLDER_STREAMS = []
+FEATURE_QUEUE_SKIP = 2   # placeholder streams used in front of the feature stream (tools/time_c3_group.py VFM_FEATURE_SKIP: A/B)
 
 
 def _feature_stream(dev: torch.device, priority: int):
@@ -96,7 +114,20 @@ def _feature_stream(dev: torch.device, priority: int):
     520 registrations/s depending on it (tools/time_c3_group.py, profiles/r04_time_c3_group.txt)."""
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(priority))
     if key not in _FEATURE_STREAMS:
-        _FEATURE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=int(priority))
+        # The feature stream is the fifth stream of a process whose pipeline has the default stream, the preparation stream and two solve
+        # streams on the four hardware queues: bound next in the round robin it would land on the DEFAULT stream's queue, and the ViT's 63
+        # launches would queue behind the 0.7 ms coarse kernels they are meant to run beside (453 instead of 517 - 524 registrations/s from
+        # uint8 images, 565 instead of 627 in groups of four: tools/time_c3_group.py with VFM_PREAMBLE / VFM_FEATURE_SKIP).  Two placeholder
+        # streams are used first, so that it shares the first solve stream's queue instead (three: the second's, 500 / 617).
+        for _ in range(FEATURE_QUEUE_SKIP if TOUCH_STREAMS_AT_CREATION else 0):
+            ph = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(ph):
+                torch.zeros(1, device=dev)
+            _PLACEHOLDER_STREAMS.append(ph)
+        fs = torch.cuda.Stream(device=dev, priority=int(priority))
+        with torch.cuda.stream(fs):
+            torch.zeros(1, device=dev)
+        _FEATURE_STREAMS[key] = fs
     return _FEATURE_STREAMS[key]
 
 
