@@ -78,9 +78,9 @@ SOLVE_STREAM_PRIORITY = 0
 
 # A HIP stream is bound to one of the process's hardware queues (four by default, round robin) when it is first USED, not when it is created.
 # The side streams are therefore used once, in a fixed order, the moment they are created: preparation, solve 0, solve 1 take the three queues
-# behind the default stream's whatever the program does between building a pipeline and its first registration -- under torch.distributed.run
-# the warm-up collective's stream used to slip in between and push the second solve stream onto the coarse kernels' queue
-# (tools/ab_queue_touch.sh).  TOUCH_STREAMS_AT_CREATION = False restores the lazy binding (A/B).
+# behind the default stream's whatever the program does between building a pipeline and its first registration, and the feature stream of
+# the C3 pipelines can be placed relative to them (_feature_stream).  Measured neutral for the C2 pipeline, plain and under
+# torch.distributed.run (tools/ab_queue_touch.sh).  TOUCH_STREAMS_AT_CREATION = False restores the lazy binding (A/B).
 TOUCH_STREAMS_AT_CREATION = True
 
 
