@@ -40,6 +40,7 @@ STEPS = 192
 import os
 from vfmreg import pipeline as _pl
 _pl.FEATURE_QUEUE_SKIP = int(os.environ.get("VFM_FEATURE_SKIP", _pl.FEATURE_QUEUE_SKIP))
+_pl.E2E_SOLVE_STREAMS = int(os.environ.get("VFM_E2E_SOLVE", _pl.E2E_SOLVE_STREAMS))
 if os.environ.get("VFM_PREAMBLE"):   # what bench.py has done by the time it measures extra.C3_pipelined: C2 pipelines on D.2 data, then freed
     from vfmreg import synth
     from vfmreg.pipeline import RegistrationPipeline

@@ -105,6 +105,7 @@ def _side_streams(dev: torch.device, n_solve: int):
 
 _FEATURE_STREAMS = {}
 _PLACEHOLDER_STREAMS = []
+E2E_SOLVE_STREAMS = 2    # solve streams of EndToEndPipeline's registration pipeline (tools/time_c3_group.py VFM_E2E_SOLVE: A/B)
 FEATURE_QUEUE_SKIP = 2   # placeholder streams used in front of the feature stream (tools/time_c3_group.py VFM_FEATURE_SKIP: A/B)
 
 
@@ -496,7 +497,7 @@ class EndToEndPipeline:
         d = model.dim
         B, H, W = len(cams), model.img_h, model.img_w
         self.reg = RegistrationPipeline(n, m, d, n_iter=n_iter, min_cosine=min_cosine, max_corr_dist=max_corr_dist, seed=seed,
-                                        device=device, overlap_ransac=True, overlap_prepare=True, solve_streams=2, coarse=coarse)
+                                        device=device, overlap_ransac=True, overlap_prepare=True, solve_streams=E2E_SOLVE_STREAMS, coarse=coarse)
         self.depth = max(int(depth), len(self.reg.sets) + 1)
         # ``feature_cus`` > 0: the feature stage on a stream restricted to that many compute units and the registration's main stream
         # (operand preparation hand-off + coarse pass) on the others.  A coarse workgroup owns its compute unit (8 waves x ~200
