@@ -319,7 +319,7 @@ def extra_configs(dev):
         raw_scan = np.c_[pp["q_xyz"], pp["q_desc"]].astype(np.float32)
         api = {}
         for name, icp in (("ms_without_icp", False), ("ms_with_icp", True)):
-            node = RegistrationNode()
+            node = RegistrationNode(cache_map=True)
             node.ransac_registration(voxel_map, raw_scan, "vfm", run_icp=icp)
             ts = []
             for _ in range(5):
@@ -751,12 +751,18 @@ def run_c3_form(args, dev, rank, world):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    per_rank = [steps / local_elapsed]
     if grouped:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        vdist.all_reduce_max(tmax)
         elapsed = float(tmax.item())
+        rates = torch.zeros(world, dtype=torch.float64, device=dev)
+        vdist.all_gather_rows(rates, torch.tensor([steps / local_elapsed], dtype=torch.float64, device=dev))
+        per_rank = [float(x) for x in rates.cpu()]
     local_ids = mine[:steps] if args.pairs > 0 else [rank + world * i for i in range(steps)]
     errs = [float(np.linalg.norm(all_poses[g].cpu().numpy() - np.eye(4))) for g in local_ids]   # the planted transform is the identity
+    if rank == 0 and args.dump_poses:
+        np.savez(args.dump_poses, poses=all_poses.cpu().numpy(), counts=all_counts.cpu().numpy())
     if rank == 0:
         print(json.dumps({
             "metric": "registrations/sec from uint8 images (C3: ViT-S/14 on 6 x 1200x1600 + lifting + 20k<->200k registration)",
@@ -767,9 +773,9 @@ def run_c3_form(args, dev, rank, world):
                                    f"{n}-pt scan vs {m}-pt map, {args.iters} RANSAC iterations", "scene_pairs_total": num_pairs,
                        "records_kind": int(e2e.reg._records()), "max_pose_err_vs_planted": max(errs), "pairs_per_vit_call": G,
                        "correspondences_last_step": int(all_counts[local_ids[-1]].item()),
-                       "per_rank_registrations_per_s": steps / local_elapsed,
-                       "collective": "one all_gather_into_tensor of the poses" if grouped else "none (single process, no launcher)"},
-            "roofline": None, "cpu_baseline": None}), flush=True)
+                       "per_rank_registrations_per_s": per_rank,
+                       "collective": f"one all_gather_into_tensor of the poses ({dist.get_backend()})" if grouped else "none (single process, no launcher)"},
+            "per_rank_registrations_per_s": per_rank, "roofline": None, "cpu_baseline": None}), flush=True)
 
 
 
@@ -799,13 +805,21 @@ def main():
                          "(EndToEndPipeline.submit_group); 1 = one ViT call per pair")
     ap.add_argument("--streams", type=int, default=2,
                     help="2: RANSAC of pair i overlaps the matching of pair i+1 on a second HIP stream; 1: serial")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend under a launcher: nccl (= RCCL over xGMI, the default and what an N-GPU job runs) or gloo "
+                         "(collectives staged through host memory: lets several ranks share ONE device, which RCCL refuses -- the form "
+                         "tests/test_gpu_multirank.py drives the real path in on a one-GPU box)")
+    ap.add_argument("--device-index", type=int, default=None,
+                    help="HIP device of this rank (default: LOCAL_RANK); with --backend gloo every rank may name device 0")
+    ap.add_argument("--dump-poses", default=None,
+                    help="rank 0 writes the gathered poses / correspondence counts of the job (global pair order) to this .npz")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if args.device_index is None else args.device_index
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (there is no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -818,7 +832,7 @@ def main():
         from vfmreg import pipeline as _pl
         _pl.TOUCH_STREAMS_AT_CREATION = False
 
-    rank, world = vdist.init_from_env(backend="nccl", device=dev)  # "nccl" == RCCL on ROCm
+    rank, world = vdist.init_from_env(backend=args.backend, device=dev)  # "nccl" == RCCL on ROCm
 
     lib = _lib.load()
     if os.environ.get("VFM_VARIANT"):  # A/B runs (tools/r02_prof.sh): 4 = dense per-chunk records + select kernel
@@ -937,10 +951,10 @@ def main():
     per_rank = [steps / local_elapsed]
     if grouped:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        vdist.all_reduce_max(tmax)
         elapsed = float(tmax.item())
         rates = torch.zeros(world, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(rates, torch.tensor([steps / local_elapsed], dtype=torch.float64, device=dev))
+        vdist.all_gather_rows(rates, torch.tensor([steps / local_elapsed], dtype=torch.float64, device=dev))
         per_rank = [float(x) for x in rates.cpu()]
     print(f"[rank {rank}] {steps} registrations in {local_elapsed * 1e3:.1f} ms = {steps / local_elapsed:.1f} registrations/s "
           f"(before the gather)", file=sys.stderr, flush=True)
@@ -986,6 +1000,8 @@ def main():
     errs = [float(np.linalg.norm(all_poses[g].cpu().numpy() - pairs[i % n_res]["T_gt"])) for i, g in enumerate(local_ids)]
     ncorr = int(all_counts[local_ids[-1]].item())
     T0 = all_poses[0].cpu().numpy()  # global pair 0 lives on rank 0
+    if rank == 0 and args.dump_poses:
+        np.savez(args.dump_poses, poses=all_poses.cpu().numpy(), counts=all_counts.cpu().numpy())
 
     if rank == 0:
         # which coarse pass ran: the int8 one for d = 256 ... 768 unless an A/B variant forces the fp16 pass; of the int8 pass the
@@ -1047,7 +1063,7 @@ def main():
                        "resident_scene_pairs_per_gpu": n_res, "pair_seed": "42 + global pair id, generated on the owning rank",
                        "hbm_peak_allocated_gb": hbm_peak / 1e9,
                        "parallelism": f"{world} GPU shard(s) x {S} stream(s), independent scene pairs (pair p -> rank p mod N)",
-                       "collective": (f"one all_gather_into_tensor of the poses ({dist.get_backend()} = RCCL)" if grouped
+                       "collective": (f"one all_gather_into_tensor of the poses ({dist.get_backend()}{' = RCCL' if dist.get_backend() == 'nccl' else ', staged through host memory'})" if grouped
                                       else "none (single process, no launcher)"),
                        "correspondences_last_step": ncorr, "max_pose_err_vs_planted": max(errs),
                        # untimed, in front of the W warm-up steps: registrations the auto policy reads its feedback between (set-up)

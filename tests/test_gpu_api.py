@@ -345,7 +345,7 @@ def test_ransac_registration_keeps_the_scene_map_between_scans(orc):
     VoxelHashMap.quiet = True
     voxel_map, raw_scan, p = _scene(n_scan=5000, n_map=24000, seed=21)
     _, raw_scan2, _ = _scene(n_scan=5000, n_map=24000, seed=21)
-    node, cold = RegistrationNode(ransac_iterations=3000), RegistrationNode(ransac_iterations=3000, cache_map=False)
+    node, cold = RegistrationNode(ransac_iterations=3000, cache_map=True), RegistrationNode(ransac_iterations=3000)   # off by default
     poses = []
     for nd in (node, node, cold):
         o3d.utility.random.seed(42)
@@ -368,6 +368,18 @@ def test_ransac_registration_keeps_the_scene_map_between_scans(orc):
     other[0, 5] += 1.0                                       # an in-place edit the fingerprint sees (first row)
     node.ransac_registration(other, raw_scan, "vfm")
     assert node._map_cache[2] is not built2
+    # ... and one it does NOT see: a single element off the fingerprint's ~4096 strided samples and off the first / last
+    # rows -- the stale map is searched.  That is why the cache is opt-in; invalidate_map() is the caller's remedy
+    built3 = node._map_cache[2]
+    step = max(1, other.size // 4096)
+    flat = 1 * other.shape[1] + 1                            # row 1, column 1
+    assert flat % step != 0 and flat // other.shape[1] not in (0, other.shape[0] - 1)
+    other[1, 1] += 1.0
+    node.ransac_registration(other, raw_scan, "vfm")
+    assert node._map_cache[2] is built3                      # undetected, by construction of the fingerprint
+    node.invalidate_map()
+    node.ransac_registration(other, raw_scan, "vfm")
+    assert node._map_cache[2] is not built3
 
 
 def test_scene_level_descriptor_builder_equals_the_per_cloud_calls(tmp_path):

@@ -381,6 +381,21 @@ def test_reuse_map_without_prepare_map_keeps_auto_off_the_fp6_kinds():
         assert c == len(corres), name
         np.testing.assert_array_equal(out["corres"].cpu().numpy()[:c], corres, err_msg=name)
         np.testing.assert_array_equal(out["T"].cpu().numpy(), ref.transformation, err_msg=name)
+        # ... and back: the fp6 passes are off only while a reused map is searched -- registrations that prepare map
+        # and scan together again get them back (D.2: the half-width pass on the fp6 image, record kind 8), same answers
+        kinds2 = []
+        for _ in range(8):
+            out = pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])
+            kinds2.append(pipe._records())
+            pipe.synchronize()
+            torch.cuda.synchronize()
+            pipe._poll_feedback()
+        assert pipe._mx6_half_ok, name
+        if name == "D.2":
+            assert kinds2[-1] == 8 and pipe.mx6_half, (name, kinds2)
+        assert int(out["count"].item()) == c, name
+        np.testing.assert_array_equal(out["corres"].cpu().numpy()[:c], corres, err_msg=name)
+        np.testing.assert_array_equal(out["T"].cpu().numpy(), ref.transformation, err_msg=name)
         del pipe
     for coarse in ("mx6", "mx6-top2", "mx6-half"):
         with pytest.raises(ValueError):

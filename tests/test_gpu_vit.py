@@ -35,6 +35,42 @@ def _check(w, imgs, atol, cos_min):
     return err.max(), cos.min()
 
 
+def test_vit_with_dinov2_like_statistics():
+    """VERDICT r4 item 7b / ADVICE r4: a trained DINOv2 carries a few residual channels 50-200x the rest and LayerScale gammas over
+    four decades; seeded random weights have neither.  `dinov2_like_weights` plants both (6 channels at 50-200x on the residual path
+    of every token, gamma log-uniform in [1e-4, 1]); the fp16-operand forward with the LayerNorm folded into the GEMMs must hold the
+    same tolerances against the fp32 oracle -- on the full output AND on the channels that are NOT outliers (the planted channels
+    alone would carry a cosine to 1), at C3's resolution with all 12 blocks."""
+    from oracle import oracle as orc
+    from vfmreg import vit as V
+    w, ch = V.dinov2_like_weights(seed=21)
+    imgs = _smooth_images(np.random.default_rng(8), 6, 1200, 1600)
+    model = V.ViTS14(w, 1200, 1600, device="cuda")
+    out = model.forward(torch.from_numpy(imgs).cuda()).cpu().numpy()
+    ref = orc.vit_reference(w, imgs)
+    assert np.isfinite(out).all()
+    rest = np.setdiff1d(np.arange(384), ch)
+    cos = lambda a, b: (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))   # noqa: E731
+    c_all, c_rest = cos(out, ref).min(), cos(out[..., rest], ref[..., rest]).min()
+    err = np.abs(out - ref).max()
+    rel_rest = np.abs(out[..., rest] - ref[..., rest]).max() / np.abs(ref[..., rest]).max()
+    print("dinov2-like: max abs err", err, "min cosine", c_all, "min cosine off the outlier channels", c_rest, "rel err there", rel_rest,
+          "| ref abs max", np.abs(ref).max(), "off-outlier abs max", np.abs(ref[..., rest]).max())
+    assert c_all >= 0.99999 and c_rest >= 0.99999, (c_all, c_rest)
+    assert err <= 1e-2 and rel_rest <= 1e-2, (err, rel_rest)
+
+
+def test_vit_rows_with_a_large_common_offset():
+    """tokens whose |mean| is several times their spread -- the case where a LayerNorm computed from an fp16 copy of the
+    un-normalised row loses bits to the subtraction.  A common offset of 4x the spread on every channel of the residual path."""
+    from vfmreg import vit as V
+    w = V.random_weights(seed=23, dim=384, depth=4, mlp=1536)
+    w["patch_embed.proj.bias"] += 4.0
+    w["cls_token"] += 4.0
+    imgs = _smooth_images(np.random.default_rng(9), 2, 560, 700)
+    _check(w, imgs, atol=1e-2, cos_min=0.99999)
+
+
 def test_vit_small_config():
     from vfmreg import vit as V
     w = V.random_weights(seed=5, dim=128, depth=2, mlp=256)

@@ -12,7 +12,7 @@ p = synth.make_pair(int(sys.argv[1]) if len(sys.argv) > 1 else 6000, int(sys.arg
 ICP = (sys.argv[3] == "1") if len(sys.argv) > 3 else True
 voxel_map = np.c_[p["b_xyz"], p["b_desc"]].astype(np.float32)
 raw_scan = np.c_[p["q_xyz"], p["q_desc"]].astype(np.float32)
-node = RegistrationNode()
+node = RegistrationNode(cache_map=True)
 node.ransac_registration(voxel_map, raw_scan, "vfm", run_icp=ICP)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(10): node.ransac_registration(voxel_map, raw_scan, "vfm", run_icp=ICP)

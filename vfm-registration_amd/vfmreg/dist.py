@@ -36,6 +36,32 @@ def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] 
     return rank, world
 
 
+def _host_staged(t: torch.Tensor) -> bool:
+    """True where the collective has to go through host memory: the "gloo" backend with device tensors (the form the single-GPU
+    two-rank test of the real path uses -- RCCL refuses two ranks on one device, gloo does not care where the ranks compute)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_gather_rows(out: torch.Tensor, buf: torch.Tensor) -> None:
+    """``all_gather_into_tensor(out, buf)`` on whatever backend the group has (RCCL over xGMI: directly on the device tensors)."""
+    if _host_staged(buf):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h, buf.cpu())
+        out.copy_(h)
+    else:
+        dist.all_gather_into_tensor(out, buf)
+
+
+def all_reduce_max(t: torch.Tensor) -> None:
+    """In-place ``all_reduce(MAX)``, host-staged under gloo like ``all_gather_rows``."""
+    if _host_staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+
+
 def shard_pairs(num_pairs: int, rank: int, world: int) -> List[int]:
     """Pair p -> rank p mod world (round robin)."""
     return list(range(rank, num_pairs, world))
@@ -64,7 +90,7 @@ def gather_poses(local_poses: torch.Tensor, local_aux: torch.Tensor, num_pairs: 
         buf[:n_local, 16] = local_aux.to(torch.float64)
     if dist.is_available() and dist.is_initialized():
         out = torch.empty((world, cap, 17), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(out.view(world * cap, 17), buf)  # RCCL over xGMI on GPUs, gloo on CPU
+        all_gather_rows(out.view(world * cap, 17), buf)  # RCCL over xGMI on GPUs, gloo on CPU
     else:
         assert world == 1, "world > 1 needs an initialised process group"
         out = buf.unsqueeze(0)
@@ -142,5 +168,5 @@ def reduce_top1(idx_local: torch.Tensor, sim: torch.Tensor, row_offset: int) -> 
     score of the winning row on whichever rank holds it; ties go to the lower global row)."""
     packed = pack_top1(idx_local, sim, row_offset)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(packed, op=dist.ReduceOp.MAX)
+        all_reduce_max(packed)
     return unpack_top1(packed)

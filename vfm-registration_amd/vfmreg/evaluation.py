@@ -170,7 +170,7 @@ def evaluate_scene(scene: Dict[str, list], node: Optional[RegistrationNode] = No
     """The VFM + RANSAC (+ ICP) branch of make_step for one scene (RN:587-589, 593, 860-882, 943-951):
     every scan is registered against the accumulated map with the identity as initial guess and
     compared with its ground-truth pose."""
-    node = node or RegistrationNode()
+    node = node or RegistrationNode(cache_map=True)   # local_map below is built here and never edited: one map per scene (RN:556-589)
     ev = evaluation or Evaluation()
     n_desc = scene["map_point_clouds"][0].shape[1] - 3
     local_map = build_local_map(scene["map_poses"], scene["map_point_clouds"], n_descriptors=n_desc)

@@ -110,7 +110,10 @@ def _icp_loop(cur: torch.Tensor, g: "VoxelGridDevice", first_step, max_correspon
         if o[42] == 0:
             print("[3D] No correspondences found")  # Registration.cpp:166
             break
-        dx = np.linalg.solve(o[:36].reshape(6, 6), -o[36:42])  # JTJ.ldlt().solve(-JTr)
+        dx = _solve6(o[:36].reshape(6, 6), -o[36:42])  # JTJ.ldlt().solve(-JTr)
+        if dx is None:
+            print("[3D] singular system")                       # (fewer than three non-collinear pairs: no update can be estimated)
+            break
         estimation = se3_exp(dx)
         step = estimation                                       # applied by the next iteration's launch (in place from then on)
         T_icp = estimation @ T_icp
@@ -130,6 +133,16 @@ def _median_like_the_reference(v: np.ndarray) -> float:
 
 
 EUCL_DIST_THRESHOLD = 0.01  # Registration.cpp:94
+
+
+def _solve6(JTJ: np.ndarray, rhs: np.ndarray):
+    """JTJ.ldlt().solve(rhs) (Registration.cpp:261) where the system is regular -- numpy's LU, the oracle's arithmetic --, None where it is
+    singular or the solution is not finite."""
+    try:
+        dx = np.linalg.solve(JTJ, rhs)
+    except np.linalg.LinAlgError:
+        return None
+    return dx if np.isfinite(dx).all() else None
 
 
 def _register_frame_nd(points: np.ndarray, voxel_map, initial_guess: np.ndarray, max_correspondance_distance: float, kernel: float):
@@ -169,7 +182,13 @@ def _register_frame_nd(points: np.ndarray, voxel_map, initial_guess: np.ndarray,
         out_h.copy_(out, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         o = out_h.numpy()
-        dx = np.linalg.solve(o[:36].reshape(6, 6), -o[36:42])
+        dx = _solve6(o[:36].reshape(6, 6), -o[36:42])
+        if dx is None:
+            # one or two surviving pairs, or collinear ones: the 6 x 6 system is singular.  The reference's JTJ.ldlt().solve() does not
+            # throw there (its update is then arbitrary); here the descriptor-seeded loop stops and the vanilla loop below takes over
+            # from the pose reached so far (numpy's LinAlgError used to escape)
+            print("[ND] singular system in the VFM loop")
+            break
         est = se3_exp(dx)
         est_d = torch.from_numpy(np.ascontiguousarray(est)).cuda()
         source_3d = ops.transform_xyz(source_3d, est_d)                        # :265-266

@@ -184,6 +184,11 @@ class RegistrationPipeline:
         self._mx6_ok = self._mx6_half_ok and d in (256, 384)   # (the full-width fp6 kernel: two query sets of d / 64 k-steps in registers)
         self._mx6_tried = False
         self._probe_due = coarse == "auto" and self.gate
+        # what `auto` may use, as decided above: register(reuse_map=True) turns the fp6 passes off for as long as a reused map is
+        # searched and restores these afterwards (it used to clear them for the rest of the pipeline's life)
+        self._mx6_allowed = (self._mx6_ok, self._mx6_half_ok)
+        self._fp6_off_by_reuse = False
+        self._map_prepared = False    # prepare_map() was called: the buffer sets hold a map without the fp6 image
         # which form of the half-width pass: with the selection fused into the coarse kernel (VFM_RECORDS_HALF_FUSED = 4: no
         # records, no selection kernel) a serial registration is 1.5 % faster (1017 vs 1002 registrations/s), but in the
         # overlapped pipeline it is 1-2 % slower (1363 vs 1378; 1190 vs 1211 in 20-step runs): the selection kernel ran on a side
@@ -235,6 +240,7 @@ class RegistrationPipeline:
             raise ValueError("the fp6 modes prepare map and scan together in every registration: no prepare_map()")
         self._mx6_ok = self._mx6_half_ok = False
         self.mx6 = self.mx6_half = False
+        self._map_prepared = True
         main = torch.cuda.current_stream()
         for r in self.sets:
             if r.done is not None:
@@ -344,6 +350,16 @@ class RegistrationPipeline:
                 raise ValueError("the fp6 modes prepare map and scan together in every registration: no reuse_map")
             self._mx6_ok = self._mx6_half_ok = False
             self.mx6 = self.mx6_half = False
+            self._fp6_off_by_reuse = True
+        elif self._fp6_off_by_reuse and not self._map_prepared:
+            # back to registrations that prepare map and scan together: the fp6 passes are available again, and the policy decides
+            # anew from the next searches' feedback (half-width probe first)
+            self._mx6_ok, self._mx6_half_ok = self._mx6_allowed
+            self._fp6_off_by_reuse = False
+            self._mx6_tried = False
+            self._probe_due = self.coarse == "auto" and self.gate and not self.half
+            if self.coarse == "auto" and self.half:
+                self.mx6_half = self._mx6_half_ok      # the half-width pass the probe had chosen, on the fp6 image again
         self._poll_feedback()
         if self.coarse == "auto":
             self._since_switch += 1
@@ -458,16 +474,29 @@ class RegistrationPipeline:
                     result_stream=solve if self.overlap else main)
 
 
+def cu_mask_words(ncu: int, offset: int = 0, total: int = 256) -> list:
+    """The 32-bit words of a compute-unit mask with bits offset .. offset + ncu - 1 set, wrapping around ``total`` units --
+    ceil(total / 32) words (parts whose unit count is not a multiple of 32: 304, 228, 110 ...)."""
+    if not (0 < ncu <= total) or offset < 0:
+        raise ValueError("Invalid compute-unit range")
+    words = [0] * ((total + 31) // 32)
+    for i in range(offset, offset + ncu):
+        j = i % total                   # wrap around the chip, THEN split into word / bit
+        words[j // 32] |= 1 << (j % 32)
+    return words
+
+
 def masked_stream(ncu: int, offset: int = 0, total: int = 256) -> "torch.cuda.Stream":
     """A HIP stream whose kernels may use ``ncu`` of the ``total`` compute units (hipExtStreamCreateWithCUMask, mask bits
     offset .. offset + ncu - 1), as a torch stream."""
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")   # (the runtime torch has loaded)
-    words = (C.c_uint32 * (total // 32))()
-    for i in range(offset, offset + ncu):
-        words[(i % total) // 32] |= 1 << (i % 32)
+    w = cu_mask_words(ncu, offset, total)
+    words = (C.c_uint32 * len(w))(*w)
+    hip.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+    hip.hipExtStreamCreateWithCUMask.restype = C.c_int
     st = C.c_void_p()
-    rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), total // 32, words)
+    rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), len(w), words)
     if rc != 0:
         raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
     return torch.cuda.ExternalStream(st.value)

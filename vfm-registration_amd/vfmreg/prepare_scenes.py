@@ -25,9 +25,9 @@ from .dataloader import NCLT
 _FORCE_PER_CAMERA = False  # tests: run the per-camera path (project -> compact -> gather per camera)
 
 
-def create_descriptors(image_files, sequence, feature_generator, pcl, images=None, _grids=None) -> np.ndarray:
+def create_descriptors(image_files, sequence, feature_generator, pcl, images=None, _grids=None, _img_d=None) -> np.ndarray:
     """``_grids`` (create_descriptors_batch): the cameras' patch features, already computed in a larger batch -- {camera: device
-    tensor [16, pw, C]}."""
+    tensor [16, pw, C]}; ``_img_d``: the cameras' images where that batch already put them on the device ({camera: uint8 tensor})."""
     images = images if images is not None else sequence.read_images(filenames=image_files)
     cams = list(images.keys())  # the reference iterates images.items() (PS:70): dict order = camera priority
     dev = "cuda"
@@ -35,7 +35,7 @@ def create_descriptors(image_files, sequence, feature_generator, pcl, images=Non
     # PS:69: np.insert(pcl, 3, 1, axis=1).T (float32 xyz promoted to fp64 inside the projection)
     pcl_h = np.insert(np.asarray(pcl)[:, :3], 3, values=1, axis=1).T
     pcl_d = torch.from_numpy(np.ascontiguousarray(pcl_h, dtype=np.float64)).to(dev)
-    img_d = {c: torch.from_numpy(np.ascontiguousarray(images[c], dtype=np.uint8)).to(dev) for c in cams}
+    img_d = _img_d if _img_d is not None else {c: torch.from_numpy(np.ascontiguousarray(images[c], dtype=np.uint8)).to(dev) for c in cams}
     fused = hasattr(feature_generator, "patch_features_device")
     if _grids is not None:
         grid = _grids
@@ -97,24 +97,30 @@ def create_descriptors_batch(image_files_list, sequence, feature_generator, pcls
     cloud's features (tests/test_gpu_vit.py, tools/time_vit_batch.py), so every returned array equals ``create_descriptors`` of
     that cloud.  Falls back to the per-cloud call for generators without ``patch_features_device`` or cameras of mixed sizes."""
     n_clouds = len(pcls)
-    if images_list is None:
-        images_list = [sequence.read_images(filenames=f) for f in image_files_list]
+    # images are read -- and uploaded -- one group of clouds at a time (ADVICE r4: ~170 clouds x 6 cameras x 5.8 MB read up front were
+    # ~6 GB of host memory for one scene, and every image went to the device twice: once for the ViT batch, once for the lifting)
+    def images_of(i):
+        return images_list[i] if images_list is not None else sequence.read_images(filenames=image_files_list[i])
     out = [None] * n_clouds
-    shapes = {tuple(np.asarray(im).shape) for images in images_list for im in images.values()}
-    if not hasattr(feature_generator, "patch_features_device") or len(shapes) != 1 or clouds_per_forward <= 1:
-        for i in range(n_clouds):
-            out[i] = create_descriptors(None, sequence, feature_generator, pcls[i], images=images_list[i])
-        return out
-    for i0 in range(0, n_clouds, clouds_per_forward):
-        group = range(i0, min(n_clouds, i0 + clouds_per_forward))
-        keys = [(i, c) for i in group for c in images_list[i].keys()]
-        batch = torch.stack([torch.from_numpy(np.ascontiguousarray(images_list[i][c], dtype=np.uint8)) for i, c in keys]).to("cuda")
+    batched = hasattr(feature_generator, "patch_features_device") and clouds_per_forward > 1
+    for i0 in range(0, n_clouds, max(clouds_per_forward, 1)):
+        group = range(i0, min(n_clouds, i0 + max(clouds_per_forward, 1)))
+        imgs = {i: images_of(i) for i in group}
+        shapes = {tuple(np.asarray(im).shape) for i in group for im in imgs[i].values()}
+        if not batched or len(shapes) != 1:
+            for i in group:
+                out[i] = create_descriptors(None, sequence, feature_generator, pcls[i], images=imgs[i])
+            continue
+        keys = [(i, c) for i in group for c in imgs[i].keys()]
+        batch = torch.stack([torch.from_numpy(np.ascontiguousarray(imgs[i][c], dtype=np.uint8)) for i, c in keys]).to("cuda")
         grids = feature_generator.patch_features_device(batch)
-        per_cloud = {i: {} for i in group}
+        per_cloud = {i: ({}, {}) for i in group}
         for k, (i, c) in enumerate(keys):
-            per_cloud[i][c] = grids[k]
+            per_cloud[i][0][c] = grids[k]
+            per_cloud[i][1][c] = batch[k]
         for i in group:
-            out[i] = create_descriptors(None, sequence, feature_generator, pcls[i], images=images_list[i], _grids=per_cloud[i])
+            out[i] = create_descriptors(None, sequence, feature_generator, pcls[i], images=imgs[i], _grids=per_cloud[i][0],
+                                        _img_d=per_cloud[i][1])
     return out
 
 

@@ -77,22 +77,27 @@ def _fingerprint(a: np.ndarray) -> Optional[int]:
 class RegistrationNode:
     """The registration methods of the reference's node, without ROS (RN:44-89).
 
-    ``cache_map`` (default on): the reference registers every scan of a scene against the same ``local_map`` (built once,
+    ``cache_map`` (default OFF = the reference's behaviour, a fresh map per call): the reference registers every scan of a scene against the same ``local_map`` (built once,
     RN:556-580, used at RN:587-589), and re-builds its ``VoxelHashMap`` from that array in every call (RN:402-403).  Here the built
     map -- the kept rows in the container's order, uploaded and cast for the search -- is kept for as long as the caller passes the
     SAME array object (identity, shape, dtype) with the same fingerprint (``_fingerprint``: a CRC of ~4096 sampled elements and the
     first / last rows); a 200 000 x 387 fp64 map is 619 MB of PCIe upload and ~4 ms of container replay per call otherwise.  An
-    in-place edit that misses every sampled element goes unnoticed: pass ``cache_map=False`` (or a new array) when the map is
-    edited in place."""
+    in-place edit that misses every sampled element goes unnoticed (tests/test_gpu_api.py documents one): a caller that opts in
+    promises not to edit the array in place between calls, or calls ``invalidate_map()`` after doing so.  ``evaluate_scene`` -- which
+    builds the scene's map itself and never edits it -- opts in."""
 
     def __init__(self, config=None, ransac_iterations: int = 50000, max_correspondence_distance: float = 10000.0,
-                 min_cosine_similarity: float = 0.8, cache_map: bool = True):
+                 min_cosine_similarity: float = 0.8, cache_map: bool = False):
         self.config = config or load_config(None, None)  # RN:85
         self.ransac_iterations = ransac_iterations       # RN:326
         self.max_correspondence_distance = max_correspondence_distance  # RN:323
         self.min_cosine_similarity = min_cosine_similarity              # RN:418
         self.cache_map = bool(cache_map)
         self._map_cache = None   # (weakref to the array, (shape, dtype, fingerprint), VoxelHashMap)
+
+    def invalidate_map(self) -> None:
+        """Forget the kept map (``cache_map=True``): the next call rebuilds it from the array it is handed."""
+        self._map_cache = None
 
     def _hash_map_for(self, voxel_map):
         """The VoxelHashMap of RN:402-403 for this map array -- built, or the one built for the same array before."""

@@ -59,6 +59,28 @@ def random_weights(seed: int = 0, dim: int = 384, depth: int = 12, mlp: int = 15
     return w
 
 
+def dinov2_like_weights(seed: int = 0, dim: int = 384, depth: int = 12, mlp: int = 1536, outlier_channels: int = 6,
+                        outlier_scale=(50.0, 200.0), layerscale_range=(1e-4, 1.0)) -> Dict[str, np.ndarray]:
+    """``random_weights`` with the two statistics of a TRAINED DINOv2 that a seeded initialisation lacks (no checkpoint can be
+    fetched here): a handful of residual-stream channels that carry activations 50-200x the others in every token and through
+    every block (planted in the patch embedding's bias and the position embedding, i.e. on the residual path itself), and
+    LayerScale gammas spread log-uniformly over four decades.  The LayerNorms in front of QKV / fc1 / the output then normalise rows
+    whose variance is dominated by those channels: the regime in which an fp16 operand of the un-normalised stream
+    (csrc/vit.hip folds the LayerNorm into the consuming GEMM) has to hold up.  Returns (weights, outlier channel indices)."""
+    rng = np.random.default_rng(seed + 7919)
+    w = random_weights(seed, dim, depth, mlp)
+    ch = np.sort(rng.choice(dim, size=outlier_channels, replace=False))
+    amp = rng.uniform(outlier_scale[0], outlier_scale[1], outlier_channels) * rng.choice([-1.0, 1.0], outlier_channels)
+    w["patch_embed.proj.bias"][ch] += amp.astype(np.float32)
+    w["cls_token"][0, 0, ch] += amp.astype(np.float32)                 # the cls token has no patch embedding: same channels, same size
+    w["pos_embed"][0, :, ch] += (0.05 * amp[:, None] * rng.standard_normal((outlier_channels, w["pos_embed"].shape[1]))).astype(np.float32)
+    lo, hi = math.log(layerscale_range[0]), math.log(layerscale_range[1])
+    for k in w:
+        if k.endswith(".gamma"):
+            w[k] = np.exp(rng.uniform(lo, hi, w[k].shape)).astype(np.float32)
+    return w, ch
+
+
 def load_state_dict(state_dict, channel_norm: str = "identity") -> Dict[str, np.ndarray]:
     """Weights dict for ``ViTS14`` / ``ImageFeatureGenerator(weights=...)`` from a checkpoint's state dict
     (torch tensors or numpy arrays).  Accepted key layouts:
