@@ -440,6 +440,7 @@ def pass_name(pipe):
         return "fp16"
     if getattr(pipe, "mx6", False):
         return ("fp6 (MX e2m3), full width, packed top-2 records (VFM_RECORDS_MX6_TOP2)" if getattr(pipe, "mx6_top2", False)
+                else "fp6 (MX e2m3), full width, gate test in the epilogue, no records (VFM_RECORDS_MX6_FUSED)" if getattr(pipe, "mx6_fused", False)
                 else "fp6 (MX e2m3), full width, best-score records (VFM_RECORDS_MX6)")
     if pipe.half and getattr(pipe, "mx6_half", False):
         return ("fp6 (MX e2m3), half-width, survivor-only epilogue (VFM_RECORDS_MX6_HALF_FUSED)" if pipe._records() == 8
@@ -582,6 +583,15 @@ def c2_variants(dev, lib, pairs, steps, warmup, iters, streams):
                                             "records; operands prepared with the fp6 image as well): 2 N M D per launch",
                                 "value": v, "unit": "registrations/s", "steps": steps, "ms_per_step": msps, "coarse_pass": pass_name(pipe),
                                 "roofline": roofline_of(pipe, n, m, d, cms)}
+    del pipe
+    pipe = build("mx6-fused")
+    v, msps, cms, _ = timed_loop(lib, pipe, pairs, steps, warmup)
+    out["C2_full_width_mx6_fused"] = {"workload": "C2, D.2 pairs, the full-width fp6 kernel with the gate test in its epilogue (VFM_RECORDS_MX6_FUSED, round 5): 2 N M D "
+                                                  "per launch, no record array and no selection sweep -- every column is multiplied, but what the kernel lists "
+                                                  "depends on how many rows reach the gate (D.2: the planted match; maps with many rows above the gate overflow "
+                                                  "the lists and take the guard's full-width int8 pass)",
+                                      "value": v, "unit": "registrations/s", "steps": steps, "ms_per_step": msps, "coarse_pass": pass_name(pipe),
+                                      "roofline": roofline_of(pipe, n, m, d, cms)}
     del pipe
     pipe = build("mx6-half")
     v, msps, cms, _ = timed_loop(lib, pipe, pairs, steps, warmup)
@@ -793,8 +803,10 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from the committed PMC passes under profiles/ instead of two rocprofv3 --pmc subprocesses of this run "
                          "(--no-extra implies it; so does running bench.py itself under rocprofv3)")
-    ap.add_argument("--n", type=int, default=N_SCAN)
-    ap.add_argument("--m", type=int, default=N_MAP)
+    # (--scan-rows / --map-rows: the spellings to use behind `python -m torch.distributed.run`, whose own parser takes "--n" / "--m" for
+    # abbreviations of its options even behind the script's name)
+    ap.add_argument("--n", "--scan-rows", dest="n", type=int, default=N_SCAN)
+    ap.add_argument("--m", "--map-rows", dest="m", type=int, default=N_MAP)
     ap.add_argument("--iters", type=int, default=RANSAC_ITERS)
     ap.add_argument("--form", choices=("c2", "c3"), default="c2",
                     help="c2 (default, BASELINE.json's metric): descriptors resident in HBM; c3: every pair end to end from uint8 images "

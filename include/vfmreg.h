@@ -209,6 +209,17 @@ int vfm_match_search_finish_gated(const float *q, const void *q_prepared, int64_
  *                     ViT features).  Costs three short launches; pays from ~8 rescanned chunks per query.  Same operands,
  *                     limits and answers as VFM_RECORDS_MX6; needs at least four queries per map chunk, else it is VFM_RECORDS_MX6. */
 #define VFM_RECORDS_MX6_PILOT 9
+/*   VFM_RECORDS_MX6_FUSED  VFM_RECORDS_MX6_HALF_FUSED's idea at FULL width (round 5): the fp6 pass over all d columns lists, in its
+ *                     own epilogue, the (query, chunk) pairs whose best score + the image's measured bound reaches the gate, and
+ *                     writes no records -- no 122 MB record array, no selection sweep.  The test is the gate alone (there is no
+ *                     unmultiplied half to bound), so it prunes exactly where few rows of the map reach the gate for a query
+ *                     (the planted match and nothing else); on maps where a query has many rows above the gate the
+ *                     workgroups' lists overflow, the device-side guard of VFM_RECORDS_HALF goes up and one full-width int8 pass
+ *                     decides every query (correct, slow) -- a caller measures (vfm_match_search_rescans_async) and uses
+ *                     VFM_RECORDS_MX6 there.  Needs the gate at the coarse call (_coarse_gated_g), operands prepared with
+ *                     VFM_PREPARE_MX6, d = 256 / 384, more than 2048 queries and at least four queries per map chunk; elsewhere it
+ *                     behaves as VFM_RECORDS_MX6. */
+#define VFM_RECORDS_MX6_FUSED 10
 int vfm_match_search_coarse_gated_r(const void *q_prepared, int64_t n, const void *b_prepared, int64_t m,
                                     int d, void *ws, size_t ws_bytes, int records, vfm_stream_t stream);
 /* _coarse_gated_r with the gate of the search (needed by VFM_RECORDS_HALF_FUSED; ignored by the other kinds) */

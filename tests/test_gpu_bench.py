@@ -67,7 +67,7 @@ def test_bench_under_torch_distributed_run_world1():
     assert fw["coarse_pass"] == "int8, best-score records" and fw["roofline"]["columns_multiplied"] == 384
     assert fw["value"] > 100 and 0.05 < fw["roofline"]["frac"] < 1.0
     assert abs(fw["roofline"]["flops_per_launch"] / (fw["roofline"]["avg_launch_ms"] * 1e-3) / 1e12 / fw["roofline"]["peak"] - fw["roofline"]["frac"]) < 1e-9
-    for k in ("C2_full_width_mx6", "C2_half_width_mx6"):   # the fp6 forms of the two lines above: same construction, fp6 roofline
+    for k in ("C2_full_width_mx6", "C2_full_width_mx6_fused", "C2_half_width_mx6"):   # the fp6 forms of the two lines above: same construction, fp6 roofline
         assert ex[k]["value"] > 100 and ex[k]["roofline"]["peak"] == 10000.0 and 0.05 < ex[k]["roofline"]["frac"] < 1.0, k
         assert "fp6" in ex[k]["coarse_pass"], k
     assert ex["C2_sustained"]["steps"] == 200 and ex["C2_sustained"]["value"] > 100

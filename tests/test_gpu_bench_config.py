@@ -134,8 +134,9 @@ def test_full_width_modes_equal_the_oracle_at_c2_size_too():
     p = synth.make_pair_device(N, M, D, seed=45)
     host = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in p.items()}
     ref = None
-    for coarse in ("int8", "int8-top2"):
+    for coarse in ("int8", "int8-top2", "mx6-fused"):    # "mx6-fused": bench.py's extra.C2_full_width_mx6_fused (record kind 10)
         pipe = RegistrationPipeline(N, M, D, n_iter=ITERS, overlap_ransac=True, overlap_prepare=True, solve_streams=2, coarse=coarse)
+        assert coarse != "mx6-fused" or pipe._records() == 10
         out = None
         for _ in range(2):
             out = pipe.register(p["q_desc"], p["q_xyz"], p["b_desc"], p["b_xyz"])

@@ -39,7 +39,7 @@ def _run(tmp_path, tag, world, extra, port):
 @pytest.mark.parametrize("form", ["c2", "c3"])
 def test_two_ranks_on_one_device_equal_the_single_process_job(tmp_path, form):
     pairs = 7                                       # ragged: rank 0 owns pairs 0 2 4 6, rank 1 owns 1 3 5 (padded to 4 rows in the gather)
-    extra = ["--pairs", str(pairs)] + (["--form", "c3", "--n", "6000", "--m", "40000", "--iters", "5000"] if form == "c3" else [])
+    extra = ["--pairs", str(pairs)] + (["--form", "c3", "--scan-rows", "6000", "--map-rows", "40000", "--iters", "5000"] if form == "c3" else [])
     d2, poses2, counts2, err2 = _run(tmp_path, form + "_w2", 2, extra, 29541 if form == "c2" else 29543)
     d1, poses1, counts1, _ = _run(tmp_path, form + "_w1", 1, extra, 0)
     assert d2["n_gpus"] == 2 and d2["steps"] == 4 and d2["config"]["scene_pairs_total"] == pairs and d1["steps"] == pairs

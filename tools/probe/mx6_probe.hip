@@ -49,6 +49,24 @@ __global__ void rate(float* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
 }
 
+// round 5: the K = 128 shape of the same instruction family, v_mfma_scale_f32_16x16x128_f8f6f4 -- 16 x 16 x 128
+// multiply-adds per instruction (half of 32 x 32 x 64's), four result registers per lane
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+__global__ void rate16(float* out, int iters) {
+    intx8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = threadIdx.x * 7 + i; b[i] = threadIdx.x * 13 + i; }
+    floatx4 c[8];
+    for (int j = 0; j < 8; ++j)
+        for (int i = 0; i < 4; ++i) c[j][i] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c[j], 2, 2, 0, 127, 0, 127);
+    }
+    float s = 0.f;
+    for (int j = 0; j < 8; ++j) s += c[j][j & 3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 int main() {
     std::vector<unsigned char> A(32 * 64), B(32 * 64), sa(64), sb(64);
     srand(1);
@@ -89,5 +107,26 @@ int main() {
     hipEventElapsedTime(&ms, e0, e1);
     const double flops = 1024.0 * 4 * iters * 4 * 2.0 * 32 * 32 * 64;
     printf("rate: %.1f TFLOP/s (fp6 x fp6, 4 accumulators per wave, 4 waves per workgroup, 1024 workgroups)\n", flops / (ms * 1e-3) / 1e12);
+    // the same instruction at other occupancies (waves per SIMD: 1 / 2 / 4), then the 16 x 16 x 128 shape
+    for (int threads : {256, 512, 1024}) {
+        for (int wgs : {256, 1024}) {
+            rate<<<wgs, threads>>>(dout, 100);
+            hipEventRecord(e0);
+            rate<<<wgs, threads>>>(dout, iters);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("32x32x64  %4d threads x %4d workgroups: %.1f TFLOP/s\n", threads, wgs,
+                   (double)wgs * (threads / 64) * iters * 4 * 2.0 * 32 * 32 * 64 / (ms * 1e-3) / 1e12);
+            rate16<<<wgs, threads>>>(dout, 100);
+            hipEventRecord(e0);
+            rate16<<<wgs, threads>>>(dout, iters);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("16x16x128 %4d threads x %4d workgroups: %.1f TFLOP/s\n", threads, wgs,
+                   (double)wgs * (threads / 64) * iters * 8 * 2.0 * 16 * 16 * 128 / (ms * 1e-3) / 1e12);
+        }
+    }
     return 0;
 }

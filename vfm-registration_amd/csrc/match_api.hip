@@ -133,7 +133,7 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
     if (i8) {
         if (!gated) records = VFM_RECORDS_TOP2;  // no feedback loop behind an ungated call: the robust record kind
         records = effective_records(records, d, n, m);
-        if (records == VFM_RECORDS_HALF_FUSED || records == VFM_RECORDS_MX6_HALF_FUSED) {
+        if (records == VFM_RECORDS_HALF_FUSED || records == VFM_RECORDS_MX6_HALF_FUSED || records == VFM_RECORDS_MX6_FUSED) {
             if (!(gate > -__builtin_inff())) return vfm_fail(VFM_EINVAL, "search_coarse: VFM_RECORDS_HALF_FUSED needs a finite gate");
             a.gate = gate;
             a.n_valid = n;
@@ -157,13 +157,14 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
             a.qbest = w.qbest;
             records = VFM_RECORDS_MX6;
         }
-        if (records == VFM_RECORDS_MX6 || records == VFM_RECORDS_MX6_TOP2 || records == VFM_RECORDS_MX6_HALF || records == VFM_RECORDS_MX6_HALF_FUSED) {
+        if (records == VFM_RECORDS_MX6 || records == VFM_RECORDS_MX6_TOP2 || records == VFM_RECORDS_MX6_HALF || records == VFM_RECORDS_MX6_HALF_FUSED ||
+            records == VFM_RECORDS_MX6_FUSED) {
             // the fp6 image and its bounds (operands prepared with VFM_PREPARE_MX6)
             a.Qh = Q.tiles6;
             a.Bh = B.tiles6;
-            const bool fuse6 = records == VFM_RECORDS_MX6_HALF_FUSED;
+            const bool fuse6 = records == VFM_RECORDS_MX6_HALF_FUSED, fusefull = records == VFM_RECORDS_MX6_FUSED;
             a.ib = (fuse6 || records == VFM_RECORDS_MX6_HALF) ? mx6_bounds_half(Q, B) : mx6_bounds(Q, B, records == VFM_RECORDS_MX6_TOP2 ? 1 : 0);
-            return launch_coarse_mx6(a, d, records == VFM_RECORDS_MX6_TOP2, records == VFM_RECORDS_MX6_HALF || fuse6, fuse6, st);
+            return launch_coarse_mx6(a, d, records == VFM_RECORDS_MX6_TOP2, records == VFM_RECORDS_MX6_HALF || fuse6, fuse6 || fusefull, st);
         }
         return launch_coarse_int8(a, d, n, records, st);
     }
@@ -272,7 +273,7 @@ VFM_EXPORT int vfm_match_search_coarse_gated_g(const void* q_prepared, int64_t n
                                                void* ws, size_t ws_bytes, int records, float gate, vfm_stream_t stream) {
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q_prepared && b_prepared && ws, "search_coarse: null pointer");
-    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6_PILOT, "search_coarse: unknown record kind %d", records);
+    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6_FUSED, "search_coarse: unknown record kind %d", records);
     VFM_CHECK_ARG(gate == gate, "search_coarse: gate is NaN");
     return do_search_coarse(q_prepared, n, b_prepared, m, d, ws, (hipStream_t)stream, false, true, true, records, gate);
 }
@@ -290,7 +291,7 @@ VFM_EXPORT int vfm_match_search_finish_gated_r(const float* q, const void* q_pre
     if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
     VFM_CHECK_ARG(q && b && q_prepared && b_prepared && ws && idx_out && sim_out, "search_finish: null pointer");
     VFM_CHECK_ARG(gate == gate, "search_finish: gate is NaN");
-    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6_PILOT, "search_finish: unknown record kind %d", records);
+    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6_FUSED, "search_finish: unknown record kind %d", records);
     return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream, true, gate, records);
 }
 

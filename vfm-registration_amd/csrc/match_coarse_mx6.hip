@@ -132,7 +132,8 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
     // FUSE: entries the workgroup's list holds (the slot in global memory is MX6_LCAP + 4 words for every shape; d = 768's ring leaves 4 KiB)
     constexpr int LCAP = RING * STEP_BYTES + MX6_LTAB * 8 + (MX6_LCAP + 1) * 4 <= 160 * 1024 ? MX6_LCAP : 1023;   // (= launch_mx6q2's)
     static_assert(RING * STEP_BYTES + MX6_LTAB * 8 + (FUSE ? (LCAP + 1) * 4 : 0) <= 160 * 1024, "ring exceeds the LDS");
-    static_assert(!FUSE || (!LOW && IMG_KS6 > KS6), "the fused form is the half-width pass");
+    static_assert(!FUSE || !LOW, "the fused forms keep no running lower bound");
+    constexpr bool FUSE_HALF = FUSE && IMG_KS6 > KS6;   // FUSE at full width (VFM_RECORDS_MX6_FUSED, round 5): the same test without the rest term
 
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
         fx_low[j] = -__builtin_inff();
         fx_rq[j] = 0.0f;
         if constexpr (FUSE) {
-            fx_rq[j] = a.qrest[qi];
+            if constexpr (FUSE_HALF) fx_rq[j] = a.qrest[qi];
             live[j] = lane < 32 && qt0 + j < a.nq_tiles && (int64_t)qi < a.n_valid && a.qinv[qi] != 0.0f;
             livemask[j] = (unsigned)__ballot(live[j]);
         }
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
     // per-chunk constants of the slice: (step, max E) for the running lower bound, (max E, max |rest|) for the fused test
     const int nch = ntiles >> 2;
     for (int c = threadIdx.x; c < nch; c += 512)
-        ltab[c] = FUSE ? make_float2(a.ib.berr[c0 + c], a.grest[c0 + c]) : make_float2(a.ib.bstep[c0 + c], a.ib.berr[c0 + c]);
+        ltab[c] = FUSE ? make_float2(a.ib.berr[c0 + c], FUSE_HALF ? a.grest[c0 + c] : 0.0f) : make_float2(a.ib.bstep[c0 + c], a.ib.berr[c0 + c]);
     if (FUSE && threadIdx.x == 0) llist[0] = 0u;
 
     // steps 0 .. RING - 2 of the unit (as many as it has) go out before the loop
@@ -540,7 +541,9 @@ int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, bool half, bool fuse, hip
     // show (tools/ablate6.py: -10 % without barrier and staging) does not come back by halving the barriers, and the larger ring
     // leaves the side kernels less LDS.  One chunk per barrier stays the default; vfm_debug_set_coarse_variant(31) selects T = 8.
     const bool t8 = half && fuse && (d == 384 || d == 256) && !g_mx6_t4 && a.nslices <= a.nchunks / 2;
-    if (half && fuse && t8)
+    if (fuse && !half)   // VFM_RECORDS_MX6_FUSED: the full-width pass with the gate test in its epilogue
+        rc = d == 384 ? launch_mx6q2<6, MX6_FUSE, false, 6, 4>(a, st) : launch_mx6q2<4, MX6_FUSE, false, 4, 4>(a, st);
+    else if (half && fuse && t8)
         rc = d == 384 ? launch_mx6q2<3, MX6_FUSE, false, 6, 3, 8>(a, st) : launch_mx6q2<2, MX6_FUSE, false, 4, 3, 8>(a, st);
     else if (half && fuse)
         rc = d == 768 ? launch_mx6q2<6, MX6_FUSE, false, 12, 4>(a, st) : d == 512 ? launch_mx6q2<4, MX6_FUSE, false, 8, 4>(a, st)

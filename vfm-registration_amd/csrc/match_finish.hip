@@ -1963,7 +1963,9 @@ int do_search_finish(const float* q, const void* qprep, int64_t n, const float* 
     const bool i8 = records != VFM_RECORDS_F16 && use_i8(d, n, m, gated);
     if (i8 && !gated) records = VFM_RECORDS_TOP2;  // as do_search_coarse chose
     records = effective_records(records, d, n, m);
-    const bool fused6 = i8 && records == VFM_RECORDS_MX6_HALF_FUSED;   // the fp6 coarse kernel has left the survivors in its workgroups' slots
+    // the fp6 coarse kernel has left the survivors in its workgroups' slots (half width, or -- VFM_RECORDS_MX6_FUSED -- full width: behind
+    // the kernel the two are the same search: survivors of a gate test, binned, rescanned on the int8 image with the gate as hit test)
+    const bool fused6 = i8 && (records == VFM_RECORDS_MX6_HALF_FUSED || records == VFM_RECORDS_MX6_FUSED);
     const bool fused = i8 && (records == VFM_RECORDS_HALF_FUSED || fused6);   // the coarse kernel has done the selection already
     const bool mx6half = i8 && records == VFM_RECORDS_MX6_HALF;   // the half-width pass on the fp6 image: its bounds in the selection
     const bool half = i8 && (records == VFM_RECORDS_HALF || fused || mx6half);

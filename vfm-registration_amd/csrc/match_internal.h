@@ -244,7 +244,7 @@ struct CoarseArgs {
     int cap;
     int* survivors;         // fb_count + 5: the search's load figure
     unsigned long long* qbest;   // VFM_RECORDS_MX6_PILOT: [npad] (float_key(lower bound) << 32 | chunk) of the query's best chunk, by 64-bit atomicMax (NULL: not kept)
-    unsigned* surv;         // VFM_RECORDS_MX6_HALF_FUSED: a slot of mx6_survivor_slot_words() words per workgroup (in the record buffer)
+    unsigned* surv;         // VFM_RECORDS_MX6_HALF_FUSED / _MX6_FUSED: a slot of mx6_survivor_slot_words() words per workgroup (in the record buffer)
 };
 
 // XCD-aware unit mapping shared by the coarse kernels: workgroup b runs on XCD b % 8 (observed, speed
@@ -412,7 +412,9 @@ inline int effective_records(int records, int d, int64_t n, int64_t m) {
         records = VFM_RECORDS_HALF;
     // (the pilot rescan is chunk-major: several queries per map chunk)
     if (records == VFM_RECORDS_MX6_PILOT && !(n >= 4 * ((m + CHUNK_ROWS - 1) / CHUNK_ROWS))) records = VFM_RECORDS_MX6;
-    if ((records == VFM_RECORDS_MX6 || records == VFM_RECORDS_MX6_PILOT) && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_BEST;   // (the one-set kernels have no fp6 form)
+    // (the fused full-width form: the chunk-major rescan behind it, like the other fused kinds)
+    if (records == VFM_RECORDS_MX6_FUSED && !(n >= 4 * ((m + CHUNK_ROWS - 1) / CHUNK_ROWS))) records = VFM_RECORDS_MX6;
+    if ((records == VFM_RECORDS_MX6 || records == VFM_RECORDS_MX6_PILOT || records == VFM_RECORDS_MX6_FUSED) && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_BEST;   // (the one-set kernels have no fp6 form)
     if (records == VFM_RECORDS_MX6_TOP2 && !(mx6_width(d) && n > 2048)) records = VFM_RECORDS_TOP2;
     if (records == VFM_RECORDS_MX6_HALF && !(mx6_half_width(d) && n > 2048)) records = VFM_RECORDS_BEST;   // (such operands carry no int8 half image)
     // the fused form needs the chunk-major rescan behind it (several queries per map chunk), like VFM_RECORDS_HALF_FUSED
@@ -570,7 +572,7 @@ int do_prepare_perm(const float* x, int64_t rows, const int* perm, int d, void* 
 // match_coarse_f16.hip / match_coarse_i8.hip: launch the coarse kernel for arguments prepared by do_search_coarse
 int launch_coarse_f16(const CoarseArgs& a, int d, hipStream_t st);
 int launch_coarse_int8(CoarseArgs& a, int d, int64_t n, int records, hipStream_t st);
-int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, bool half, bool fuse, hipStream_t st);   // match_coarse_mx6.hip
+int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, bool half, bool fuse, hipStream_t st);   // match_coarse_mx6.hip (fuse && !half: VFM_RECORDS_MX6_FUSED)
 int mx6_survivor_slot_words();   // words per workgroup slot of the fused half-width pass (header + entries)
 // match_api.hip
 int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m, int d, void* ws, hipStream_t st,

@@ -150,16 +150,20 @@ class RegistrationPipeline:
         # candidate chunk of a resolved query is rescanned), "int8-top2" = the same with packed top-2 records (+ ~0.15 ms of
         # kernel at C2; a chunk with one row inside the bounds costs one fp32 row instead of a 48 KB rescan), "fp16" = the
         # ungated family, "auto" = chosen from the searches' own feedback (_poll_feedback)
-        if coarse not in ("auto", "int8-half", "int8", "int8-top2", "mx6", "mx6-top2", "mx6-pilot", "mx6-half", "fp16"):
+        if coarse not in ("auto", "int8-half", "int8", "int8-top2", "mx6", "mx6-top2", "mx6-pilot", "mx6-fused", "mx6-half", "fp16"):
             raise ValueError("coarse must be 'auto', 'int8-half', 'int8', 'int8-top2', 'mx6', 'mx6-top2', 'mx6-half' or 'fp16'")
-        if coarse in ("int8-half", "mx6-half") and not gate:
-            raise ValueError("the half-width pass needs the gate")
+        if coarse in ("int8-half", "mx6-half", "mx6-fused") and not gate:
+            raise ValueError("the half-width pass (and the fused full-width one) need the gate")
         self.coarse = coarse
         self.use_i8 = coarse != "fp16"
         self.top2 = coarse == "int8-top2"   # int8 pass with packed top-2 records (VFM_RECORDS_TOP2)
         # the full-width coarse pass in microscaled fp6 (VFM_RECORDS_MX6: twice the int8 instruction's rate, ~3x wider bounds;
         # the operands are prepared with VFM_PREPARE_MX6); where the library has no kernel for it, best-score records
-        self.mx6 = coarse in ("mx6", "mx6-top2", "mx6-pilot")   # "mx6-top2": the same pass with packed top-2 records (VFM_RECORDS_MX6_TOP2)
+        self.mx6 = coarse in ("mx6", "mx6-top2", "mx6-pilot", "mx6-fused")   # "mx6-top2": the same pass with packed top-2 records (VFM_RECORDS_MX6_TOP2)
+        # "mx6-fused": VFM_RECORDS_MX6_FUSED (round 5) -- the full-width fp6 pass lists the (query, chunk) pairs that reach the gate in its
+        # own epilogue and writes no records (no record array, no selection sweep); prunes where few rows reach the gate (D.2), falls
+        # through to the guard's full-width int8 pass where many do -- a pinned mode for such data, not one `auto` picks
+        self.mx6_fused = coarse == "mx6-fused"
         self.mx6_top2 = coarse == "mx6-top2"
         # "mx6-pilot": VFM_RECORDS_MX6_PILOT -- one chunk per query rescanned exactly in front of the selection (about half the candidate
         # chunks where a query has many near neighbours); `auto` turns it on above PILOT_UP rescanned chunks per query
@@ -236,7 +240,7 @@ class RegistrationPipeline:
         if b_desc.shape != (self.m, self.d):
             raise ValueError("Invalid shape")
         # a map prepared once carries the fp16 and int8 images, not the fp6 one (vfm_match_prepare): the fp6 kinds are out
-        if self.coarse in ("mx6", "mx6-top2", "mx6-pilot", "mx6-half"):
+        if self.coarse in ("mx6", "mx6-top2", "mx6-pilot", "mx6-fused", "mx6-half"):
             raise ValueError("the fp6 modes prepare map and scan together in every registration: no prepare_map()")
         self._mx6_ok = self._mx6_half_ok = False
         self.mx6 = self.mx6_half = False
@@ -320,6 +324,8 @@ class RegistrationPipeline:
 
     def _records(self) -> int:
         if self.mx6:
+            if self.mx6_fused:
+                return 10                      # VFM_RECORDS_MX6_FUSED
             return 6 if self.mx6_top2 else (9 if self.mx6_pilot else 5)   # VFM_RECORDS_MX6_TOP2 / VFM_RECORDS_MX6_PILOT / VFM_RECORDS_MX6
         if self.half and self.mx6_half:
             return self._mx6_half_kind         # VFM_RECORDS_MX6_HALF_FUSED (VFM_RECORDS_MX6_HALF on request)
@@ -346,7 +352,7 @@ class RegistrationPipeline:
         if reuse_map:
             # a reused map is prepared once (vfm_match_prepare2 / vfm_match_prepare below): it carries the fp16 and int8 images, not
             # the fp6 one -- its err6 would be read as infinite and an fp6 search would prune nothing.  Same rule as prepare_map().
-            if self.coarse in ("mx6", "mx6-top2", "mx6-pilot", "mx6-half"):
+            if self.coarse in ("mx6", "mx6-top2", "mx6-pilot", "mx6-fused", "mx6-half"):
                 raise ValueError("the fp6 modes prepare map and scan together in every registration: no reuse_map")
             self._mx6_ok = self._mx6_half_ok = False
             self.mx6 = self.mx6_half = False
@@ -405,7 +411,7 @@ class RegistrationPipeline:
                 schedule = 1 if (records in (3, 4) or not (self.overlap and self.overlap_prepare)) else 2
                 if self._prep_schedule is not None:
                     schedule = int(self._prep_schedule)
-                if records in (5, 6, 9):
+                if records in (5, 6, 9, 10):
                     schedule |= 8   # VFM_PREPARE_MX6: the fp6 image as well
                 elif records in (7, 8):
                     # VFM_PREPARE_MX6_HALF: the half-width pass reads the first d / 2 columns of the fp6 image -- only those are
