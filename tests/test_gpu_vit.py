@@ -175,3 +175,25 @@ def test_vit_attention_with_keys_and_values_in_the_lds_equals_the_per_tile_kerne
             assert torch.equal(per_tile, shared), (dim, B, H, W, float((per_tile - shared).abs().max()))
     finally:
         lib.vfm_debug_set_vit_gemm(-7, 1)
+
+
+def test_vit_preprocessing_one_workgroup_per_patch_equals_the_per_unit_kernel_bit_for_bit():
+    """vit_preprocess_patch_kernel (round 5: a workgroup per 14 x 14 patch, each thread's two source rows read once for the three channels,
+    the token's fragment units assembled in the LDS) evaluates the expressions of round 1's kernel in the same order: identical features --
+    C3's resolution, NCLT's (padding tokens), an up-sampling resize (source smaller than 224 rows: taps at the right / bottom border)."""
+    from vfmreg import _lib
+    from vfmreg import vit as V
+    lib = _lib.load()
+    try:
+        for (B, H, W) in ((6, 1200, 1600), (2, 700, 820), (3, 150, 210)):
+            w = V.random_weights(seed=19, dim=384, depth=1, mlp=1536)
+            imgs = torch.from_numpy(_smooth_images(np.random.default_rng(6), B, max(H, 80), max(W, 80))[:, :H, :W].copy()).cuda()
+            model = V.ViTS14(w, H, W, device="cuda")
+            lib.vfm_debug_set_vit_gemm(-14, 0)
+            old = model.forward(imgs).clone()
+            lib.vfm_debug_set_vit_gemm(-14, 1)
+            new = model.forward(imgs).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(old, new), (B, H, W, float((old - new).abs().max()))
+    finally:
+        lib.vfm_debug_set_vit_gemm(-14, 1)

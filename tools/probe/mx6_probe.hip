@@ -94,7 +94,7 @@ int main() {
         }
     printf("layout hypothesis: max |D - ref| = %g (D[0][0] = %g, D[3][5] = %g)\n", worst, D[0], D[3 * 32 + 5]);
     float* dout;
-    hipMalloc(&dout, 256 * 4 * 256 * 4);
+    hipMalloc(&dout, (size_t)1024 * 1024 * 4);   // (the largest launch below: 1024 threads x 1024 workgroups)
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20000;

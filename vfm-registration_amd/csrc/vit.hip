@@ -156,6 +156,71 @@ __global__ __launch_bounds__(256) void vit_preprocess_kernel(const uint8_t* __re
     *reinterpret_cast<half8*>(out + idx) = v;
 }
 
+// Round 5 (the kernel above issues 32 single-byte loads per thread -- a thread owns 8 consecutive k = 8 samples of one
+// channel, four taps each -- and stalls on their issue: 0.8 of its wave time, 189 us at 96 images).  Here a workgroup takes one token =
+// one 14 x 14 patch: thread (py, px) reads its two source rows ONCE for all three channels -- the taps x0, x0 + 1 are six consecutive
+// bytes: a dword and a short per row, four loads instead of twelve byte loads --, evaluates the three channels with the arithmetic of
+// the kernel above (same expressions, same order: the same bits), leaves them in the LDS in k order (k = c 196 + py 14 + px) and the
+// first KP / 8 threads write the token's fragment units, 16 bytes each.  Tokens without a patch (cls, padding) are zero rows.
+__global__ __launch_bounds__(256) void vit_preprocess_patch_kernel(const uint8_t* __restrict__ img, Dims d, _Float16* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) _Float16 vals[640];   // KP <= 640 halves (3 x 196 = 588 -> 592)
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int b = m / d.Tp, t = m - b * d.Tp;
+    const int ksteps = d.KP / 16, units = ksteps * 2;
+    const bool patch_row = t >= 1 && t <= d.Np;   // workgroup-uniform
+    if (patch_row) {
+        if (tid >= 196 && tid < 196 + 52) vals[588 + (tid - 196)] = (_Float16)0.0f;   // the k >= 588 tail of the last unit(s): 588 .. 639
+        if (tid < 196) {
+            const int patch = t - 1, pr = patch / d.gw, pc = patch - pr * d.gw;
+            const int py = tid / 14, px = tid - py * 14;
+            const float sh = (float)d.H / (float)d.Hr, sw = (float)d.W / (float)d.Wr;
+            const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+            const int oy = pr * 14 + py, ox = pc * 14 + px;
+            // torch upsample_bilinear2d, align_corners=False, antialias=False
+            float sy = sh * ((float)oy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+            float sx = sw * ((float)ox + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+            int y0 = (int)sy; if (y0 > d.H - 1) y0 = d.H - 1;
+            int x0 = (int)sx; if (x0 > d.W - 1) x0 = d.W - 1;
+            const int y1 = y0 + (y0 < d.H - 1 ? 1 : 0), x1 = x0 + (x0 < d.W - 1 ? 1 : 0);
+            const float ly = sy - (float)y0, lx = sx - (float)x0;
+            const uint8_t* base = img + (size_t)b * d.H * d.W * 3;
+            // six bytes from pixel xs = min(x0, W - 2): pixels xs, xs + 1 (W >= 2); tap0 = pixel x0, tap1 = pixel x1
+            const int xs = x0 < d.W - 1 ? x0 : d.W - 2;
+            const int o0 = (x0 - xs) * 3, o1 = (x1 - xs) * 3;
+            unsigned long long r0, r1;   // bytes 0 .. 5: the two pixels of each source row
+            {
+                const uint8_t* p0 = base + ((size_t)y0 * d.W + xs) * 3;
+                const uint8_t* p1 = base + ((size_t)y1 * d.W + xs) * 3;
+                unsigned a0, a1;
+                unsigned short c0, c1;
+                __builtin_memcpy(&a0, p0, 4); __builtin_memcpy(&c0, p0 + 4, 2);
+                __builtin_memcpy(&a1, p1, 4); __builtin_memcpy(&c1, p1 + 4, 2);
+                r0 = (unsigned long long)a0 | ((unsigned long long)c0 << 32);
+                r1 = (unsigned long long)a1 | ((unsigned long long)c1 << 32);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float p00 = (float)(unsigned)((r0 >> (8 * (o0 + c))) & 0xffull) * (1.0f / 255.0f);
+                const float p01 = (float)(unsigned)((r0 >> (8 * (o1 + c))) & 0xffull) * (1.0f / 255.0f);
+                const float p10 = (float)(unsigned)((r1 >> (8 * (o0 + c))) & 0xffull) * (1.0f / 255.0f);
+                const float p11 = (float)(unsigned)((r1 >> (8 * (o1 + c))) & 0xffull) * (1.0f / 255.0f);
+                const float r = (1.f - ly) * ((1.f - lx) * p00 + lx * p01) + ly * ((1.f - lx) * p10 + lx * p11);
+                vals[c * 196 + tid] = (_Float16)((r - mean[c]) / stdv[c]);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < units) {
+        half8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.0f;
+        if (patch_row) v = *reinterpret_cast<const half8*>(vals + tid * 8);
+        const int s = tid >> 1, h = tid & 1;
+        const size_t idx = ((((size_t)(m >> 5) * ksteps + s) * 2 + h) * 32 + (m & 31)) * 8;
+        *reinterpret_cast<half8*>(out + idx) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 2. GEMM on fragment tiles.  out[m][n] = sum_k A[m][k] W[n][k]  (+ fused epilogue)
 //    One wavefront per (32 tokens) x (64 output channels); swapped product D = W . A^T:
@@ -182,6 +247,8 @@ struct GemmArgs {
     _Float16* xh;        // fp16 fragment-tiled copy of the residual stream [M][D]
     float* stats;        // [M][D / 32][2]: (sum x, sum x^2) of the token over each 32-channel slice
     const float* csum;   // [N]: row sums of the (gamma-folded, fp16-rounded) weight
+    float invD;          // 1 / D (the consumers' mean and variance)
+    unsigned qt_magic;   // 2^20 / (Tp / 32) + 1: image of a token tile = (mt qt_magic) >> 20 (exact for mt < 2^16: vfm_vit_forward checks)
     unsigned long long* dbg;   // (tools only) per-workgroup start / end / placement of vit_gemm_astat_kernel, or null
 };
 
@@ -218,41 +285,96 @@ __device__ __forceinline__ float gelu_exact(float x) {
     return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
-// NT = 32-channel tiles per wave (2 for the wide GEMMs, 1 for N = dim so that 66 x 12 = 792 waves
-// cover the chip instead of 396).
-// ---- the epilogue of one 32 x 32 output tile (tokens m = mt * 32 + lane % 32, channels n32 * 32 ...), shared by the two GEMM kernels.
+// ---- the epilogue of one 32 x 32 output tile (tokens m = mt * 32 + lane % 32, channels n32 * 32 ...), shared by the GEMM kernels.
 // D layout: column = lane & 31 = token, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) = channel in the tile.
+//
+// Round 5 (17 VALU + 10 SALU per MFMA, matrix pipe 13 - 19 % busy -- the GEMMs were bound by the issue of their own
+// prologues and epilogues).  What the assembly of round 4's epilogue showed (124 VALU per 32 x 32 tile for 16 values per lane):
+// an IEEE division (12 instructions) for the token's mean and another for its variance, rsqrtf's denormal guard, one multiply +
+// subtract + multiply + add per value (the library is built with -ffp-contract=off), 64-bit VALU address chains for every load and
+// store of a group, a per-LANE branch between the q | k and the V^T destinations (the test was on a pointer that held the lane's
+// offset) and ~300 register moves to pair values up for the packed instructions the compiler did find.  Now:
+//   * the token's statistics arrive as (a, nb) = (rstd, -rstd mean): one reciprocal of D from the host, v_rsq_f32;
+//   * two packed fp32 FMAs per pair of values (y = acc a + (nb c + b'); residual: x + gamma (acc + b)), v_cvt_pk_f16_f32, one
+//     8-byte store per group: ~1.5 instructions per value;
+//   * the exact GELU on pairs (packed FMAs; 0.5 x + 0.5 |x| erf(|x| / sqrt 2) needs no copysign);
+//   * every address = a wave-uniform base (scalar registers) + one 32-bit lane offset + an immediate;
+//   * which of q | k | V^T a tile belongs to is a scalar branch.
+// Floating point: the values differ from round 4's in the last bits (fused multiply-adds, multiplication by 1 / D); every GEMM kernel
+// shares this code, so the bit-equality of the kernel variants stands (tests/test_gpu_vit.py), and the tolerance against the fp32
+// oracle is unchanged.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat2(float v) { return f2{v, v}; }
+__device__ __forceinline__ half4 to_half4(f2 lo, f2 hi) {
+    half4 o;
+    o[0] = (_Float16)lo[0]; o[1] = (_Float16)lo[1]; o[2] = (_Float16)hi[0]; o[3] = (_Float16)hi[1];
+    return o;
+}
+// exact GELU of a pair (gelu_exact's formula: Abramowitz & Stegun 7.1.26), x Phi(x) = 0.5 x + 0.5 |x| erf(|x| / sqrt 2)
+__device__ __forceinline__ f2 gelu2(f2 x) {
+    const f2 ax = f2{fabsf(x[0]), fabsf(x[1])};
+    const f2 z = ax * splat2(0.70710678118654752440f);
+    const f2 den = fma2(splat2(0.3275911f), z, splat2(1.0f));
+    const f2 t = f2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    f2 p = fma2(splat2(1.061405429f), t, splat2(-1.453152027f));
+    p = fma2(p, t, splat2(1.421413741f));
+    p = fma2(p, t, splat2(-0.284496736f));
+    p = fma2(p, t, splat2(0.254829592f));
+    const f2 ea = (z * z) * splat2(-1.44269504088896340736f);
+    const f2 e = f2{__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};   // exp(-z^2); underflows to 0 for large |x|
+    const f2 erf_abs = fma2(-(p * t), e, splat2(1.0f));                                // erf(|x| / sqrt 2)
+    return fma2(ax * splat2(0.5f), erf_abs, x * splat2(0.5f));
+}
 struct EpiRegs {
     float4 bias[4], aux[4], x[4];   // aux: row sums of the folded weight (QKV, fc1) / LayerScale (proj, fc2); x: residual values / cls + pos
 };
+// (n32u: the 32-channel tile, wave-uniform; the lane's part of every address is 16 hi bytes -- or its row of the residual stream)
 template <int EPI>
-__device__ __forceinline__ void epi_load(const GemmArgs& g, int m, int t, int hi, int n32, EpiRegs& e) {
+__device__ __forceinline__ void epi_load(const GemmArgs& g, int m, int t, int hi, int n32u, EpiRegs& e) {
     constexpr bool CONSUMES_LN = EPI == EPI_QKV || EPI == EPI_GELU;
+    const unsigned hoff = 16u * (unsigned)hi;
+    const char* bias_b = reinterpret_cast<const char*>(g.bias + n32u * 32);
+    const char* aux_b = reinterpret_cast<const char*>((CONSUMES_LN ? g.csum : g.gamma) + n32u * 32);
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
-        const int n0 = n32 * 32 + 8 * grp + 4 * hi;
-        e.bias[grp] = *reinterpret_cast<const float4*>(g.bias + n0);
+        e.bias[grp] = *reinterpret_cast<const float4*>(bias_b + (hoff + 32u * grp));
         e.aux[grp] = make_float4(0.f, 0.f, 0.f, 0.f);
         e.x[grp] = make_float4(0.f, 0.f, 0.f, 0.f);   // (padding rows t >= T stay exactly zero)
-        if constexpr (CONSUMES_LN) e.aux[grp] = *reinterpret_cast<const float4*>(g.csum + n0);
-        if constexpr (EPI == EPI_RESID) {
-            e.aux[grp] = *reinterpret_cast<const float4*>(g.gamma + n0);
-            if (t < g.T) e.x[grp] = *reinterpret_cast<const float4*>(g.x + (size_t)m * g.D + n0);
+        if constexpr (CONSUMES_LN || EPI == EPI_RESID) e.aux[grp] = *reinterpret_cast<const float4*>(aux_b + (hoff + 32u * grp));
+    }
+    if constexpr (EPI == EPI_RESID) {
+        if (t < g.T) {
+            const char* xb = reinterpret_cast<const char*>(g.x + n32u * 32);
+            const unsigned xoff = (unsigned)m * (unsigned)g.D * 4u + hoff;   // (M D 4 < 2^32: vfm_vit_forward checks)
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) e.x[grp] = *reinterpret_cast<const float4*>(xb + (xoff + 32u * grp));
         }
-        if constexpr (EPI == EPI_PATCH) {
-            if (t < g.T) e.x[grp] = *reinterpret_cast<const float4*>(g.clspos + (size_t)t * g.D + n0);   // row 0 = cls + pos[0]
+    }
+    if constexpr (EPI == EPI_PATCH) {
+        if (t < g.T) {
+            const char* cb = reinterpret_cast<const char*>(g.clspos + n32u * 32);
+            const unsigned coff = (unsigned)t * (unsigned)g.D * 4u + hoff;
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) e.x[grp] = *reinterpret_cast<const float4*>(cb + (coff + 32u * grp));   // row 0 = cls + pos[0]
         }
     }
 }
-// the token's LayerNorm statistics from the producers' partial sums, slices in ascending order
-__device__ __forceinline__ void ln_stats_load(const GemmArgs& g, int m, float& ln_mean, float& ln_rstd) {
+// the token's LayerNorm statistics from the producers' partial sums, slices in ascending order: (a, nb) = (rstd, -rstd mean), so that
+// LN(x) W^T = a (x W'^T) + nb c + b'
+__device__ __forceinline__ void ln_stats_load(const GemmArgs& g, int m, float& ln_a, float& ln_nb) {
     const int nsl = g.D / 32;
-    const float4* sp = reinterpret_cast<const float4*>(g.stats + (size_t)m * nsl * 2);   // two slices per float4
+    const float4* sp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(g.stats) + (unsigned)m * (unsigned)nsl * 8u);   // two slices per float4
     float sx = 0.f, sq = 0.f;
     if (nsl <= 12) {   // ViT-S: six float4 instead of sixteen predicated ones and their 64 additions (the same sums: the rest were + 0)
         float4 st[6];
+        if (nsl == 12) {   // (the usual case without a branch per load)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) st[i] = (2 * i < nsl) ? sp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < 6; ++i) st[i] = sp[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) st[i] = (2 * i < nsl) ? sp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             sx += st[i].x; sq += st[i].y;
@@ -268,17 +390,13 @@ __device__ __forceinline__ void ln_stats_load(const GemmArgs& g, int m, float& l
             sx += st[i].z; sq += st[i].w;
         }
     }
-    ln_mean = sx / (float)g.D;
-    const float var = fmaxf(sq / (float)g.D - ln_mean * ln_mean, 0.0f);
-    ln_rstd = rsqrtf(var + 1e-6f);
+    const float mean = sx * g.invD;
+    const float var = fmaxf(__builtin_fmaf(sq, g.invD, -(mean * mean)), 0.0f);
+    ln_a = __builtin_amdgcn_rsqf(var + 1e-6f);   // (the argument is >= 1e-6: no denormal guard)
+    ln_nb = -(ln_a * mean);
 }
-// Index arithmetic (round 4, from the counters: profiles/r04_pmc_vit_96images.json): a wave of the QKV GEMM issued 1635 VALU and 1010 SALU
-// instructions for its 96 MFMAs -- the epilogue computed every group's destination with runtime integer divisions (n0 / D, n0 % D, m / Tp)
-// and 64-bit frag_index() chains, ~100 instructions per group of four channels.  A 32 x 32 output tile lies inside one (q | k | v, head)
-// and one token tile of one image, so everything but the lane's own offset inside a fragment row is uniform: mt (token tile), tq (token
-// tile inside its image), b, n32 come in as scalars and the destinations are   base(tile) + grp * 256 + lane_off.
 // NT: the fp16 outputs leave with non-temporal stores (vfm_debug_set_vit_gemm(-13, 1), token-stationary kernel only: A/B)
-__device__ __forceinline__ void store_half4(_Float16* p, half4 v, bool nt) {
+__device__ __forceinline__ void store_half4(void* p, half4 v, bool nt) {
     if (nt) {
         const uint2 u = *reinterpret_cast<const uint2*>(&v);
         __builtin_nontemporal_store(u.x, reinterpret_cast<unsigned*>(p));
@@ -287,79 +405,80 @@ __device__ __forceinline__ void store_half4(_Float16* p, half4 v, bool nt) {
         *reinterpret_cast<half4*>(p) = v;
     }
 }
+// mt, b, tq, n32: wave-uniform (the callers pass them through readfirstlane); (ln_a, ln_nb) of the lane's token
 template <int EPI, bool NT = false>
 __device__ __forceinline__ void epi_tile(const GemmArgs& g, const floatx16& acc, int m, int mt, int b, int tq, int t, int hi, int n32,
-                                         const EpiRegs& e, float ln_mean, float ln_rstd) {
-    constexpr bool CONSUMES_LN = EPI == EPI_QKV || EPI == EPI_GELU, PRODUCES_LN = EPI == EPI_PATCH || EPI == EPI_RESID;
-    float psum = 0.f, psq = 0.f;   // PRODUCES_LN: this lane's share of the slice's (sum x, sum x^2)
+                                         const EpiRegs& e, float ln_a, float ln_nb) {
     const int lane31 = lane_id() & 31;
-    const unsigned lane_off = (unsigned)lane31 * 8u + 4u * (unsigned)hi;   // halves: row lane31 of a 32 x 8 fragment row, elements 4 hi ..
-    // fragment-tiled [M][K] matrix with ks = K / 16 k-steps: element (m, n0 .. n0 + 3) of this lane and group sits at
-    //   ((mt * ks * 2 + n32 * 4 + grp) * 256 + lane_off   (= frag_index(m, n0, ks))
-    _Float16* frag_base = nullptr;
-    if constexpr (PRODUCES_LN) frag_base = g.xh + ((size_t)mt * (unsigned)(g.D / 16) * 2u + (unsigned)n32 * 4u) * 256u + lane_off;
-    if constexpr (EPI == EPI_GELU) frag_base = g.out + ((size_t)mt * (unsigned)(g.N / 16) * 2u + (unsigned)n32 * 4u) * 256u + lane_off;
-    _Float16* qk_base = nullptr;     // EPI_QKV, q or k: [b * heads + head][Tp][64] fragment-tiled, 4 k-steps
-    _Float16* vt_base = nullptr;     // EPI_QKV, v: V^T [b * heads + head][64][Tp] fragment-tiled, Tp / 16 k-steps
+    // bytes: row lane31 of a 32 x 8 fragment row (16 B), halves 4 hi ..; a fragment-tiled [M][K] matrix with ks = K / 16 k-steps keeps
+    // element (m, n0 .. n0 + 3) of this lane and group at ((mt ks 2 + n32 4 + grp) 256 halves + lane part   (= frag_index(m, n0, ks))
+    const unsigned lane_off = (unsigned)lane31 * 16u + 8u * (unsigned)hi;
+    const f2 A2 = splat2(ln_a), NB2 = splat2(ln_nb);
     if constexpr (EPI == EPI_QKV) {
         const int hg = n32 >> 1;                                  // 64-channel unit = (which, head)
         const int which = hg >= 2 * g.heads ? 2 : (hg >= g.heads ? 1 : 0);
         const int head = hg - which * g.heads;
-        const size_t bh_off = ((size_t)b * g.heads + head) * (size_t)g.Tp * 64;
-        if (which < 2)   // (tq * 4 + s) * 2 + h with s = (n32 & 1) * 2 + (grp >> 1), h = grp & 1
-            qk_base = (which == 0 ? g.q : g.k) + bh_off + ((unsigned)tq * 8u + (unsigned)(n32 & 1) * 4u) * 256u + lane_off;
-        else             // row d = (n32 & 1) * 32 + 8 grp + 4 hi + j, key t: tile n32 & 1, k-step 2 tq + (lane31 >> 4), half (lane31 >> 3) & 1
-            vt_base = g.vt + bh_off + ((unsigned)(n32 & 1) * (unsigned)(g.Tp / 16) * 2u + (unsigned)tq * 4u + (unsigned)(lane31 >> 3)) * 256u +
-                      (unsigned)(4 * hi) * 8u + (unsigned)(lane31 & 7);
-    }
-    float* xrow = nullptr;
-    if constexpr (PRODUCES_LN) xrow = g.x + (size_t)m * g.D + n32 * 32 + 4 * hi;
+        // (offsets in 32 bits -- vfm_vit_forward checks that every activation buffer is below 4 GiB --, one 64-bit add per tile)
+        const unsigned bh_off = ((unsigned)b * (unsigned)g.heads + (unsigned)head) * (unsigned)g.Tp * 64u;   // halves; q, k: [b heads + head][Tp][64], 4 k-steps
+        if (which < 2) {   // (tq 4 + s) 2 + h with s = (n32 & 1) 2 + (grp >> 1), h = grp & 1
+            char* base = reinterpret_cast<char*>(which == 0 ? g.q : g.k) + (size_t)((bh_off + ((unsigned)tq * 8u + (unsigned)(n32 & 1) * 4u) * 256u) * 2u);
 #pragma unroll
-    for (int grp = 0; grp < 4; ++grp) {
-        const float bi[4] = {e.bias[grp].x, e.bias[grp].y, e.bias[grp].z, e.bias[grp].w};
-        const float au[4] = {e.aux[grp].x, e.aux[grp].y, e.aux[grp].z, e.aux[grp].w};
-        float v[4];
+            for (int grp = 0; grp < 4; ++grp) {
+                const f2 v01 = fma2(f2{acc[grp * 4 + 0], acc[grp * 4 + 1]}, A2, fma2(NB2, f2{e.aux[grp].x, e.aux[grp].y}, f2{e.bias[grp].x, e.bias[grp].y}));
+                const f2 v23 = fma2(f2{acc[grp * 4 + 2], acc[grp * 4 + 3]}, A2, fma2(NB2, f2{e.aux[grp].z, e.aux[grp].w}, f2{e.bias[grp].z, e.bias[grp].w}));
+                store_half4(base + (lane_off + 512u * grp), to_half4(v01, v23), NT);
+            }
+        } else {
+            // V^T [b heads + head][64][Tp], Tp / 16 k-steps: row d = (n32 & 1) 32 + 8 grp + 4 hi + j, key t: tile n32 & 1, k-step
+            // 2 tq + (lane31 >> 4), half (lane31 >> 3) & 1, element lane31 & 7
+            char* base = reinterpret_cast<char*>(g.vt) + (size_t)((bh_off + ((unsigned)(n32 & 1) * (unsigned)(g.Tp / 16) * 2u + (unsigned)tq * 4u) * 256u) * 2u);
+            const unsigned voff = ((unsigned)(lane31 >> 3) * 256u + (unsigned)(4 * hi) * 8u + (unsigned)(lane31 & 7)) * 2u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if constexpr (CONSUMES_LN) v[j] = ln_rstd * (acc[grp * 4 + j] - ln_mean * au[j]) + bi[j];
-            else v[j] = acc[grp * 4 + j] + bi[j];
+            for (int grp = 0; grp < 4; ++grp) {
+                const f2 v01 = fma2(f2{acc[grp * 4 + 0], acc[grp * 4 + 1]}, A2, fma2(NB2, f2{e.aux[grp].x, e.aux[grp].y}, f2{e.bias[grp].x, e.bias[grp].y}));
+                const f2 v23 = fma2(f2{acc[grp * 4 + 2], acc[grp * 4 + 3]}, A2, fma2(NB2, f2{e.aux[grp].z, e.aux[grp].w}, f2{e.bias[grp].z, e.bias[grp].w}));
+                const half4 o = to_half4(v01, v23);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<_Float16*>(base + (voff + (unsigned)(8 * grp + j) * 16u)) = o[j];
+            }
         }
-        if constexpr (PRODUCES_LN) {
-            float4 o = e.x[grp];   // the token's new residual values (padding rows stay exactly zero)
-            float4* xp = reinterpret_cast<float4*>(xrow + 8 * grp);
+    } else if constexpr (EPI == EPI_GELU) {
+        char* base = reinterpret_cast<char*>(g.out) + (size_t)((((unsigned)mt * (unsigned)(g.N / 16) * 2u + (unsigned)n32 * 4u) * 256u) * 2u);
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const f2 v01 = fma2(f2{acc[grp * 4 + 0], acc[grp * 4 + 1]}, A2, fma2(NB2, f2{e.aux[grp].x, e.aux[grp].y}, f2{e.bias[grp].x, e.bias[grp].y}));
+            const f2 v23 = fma2(f2{acc[grp * 4 + 2], acc[grp * 4 + 3]}, A2, fma2(NB2, f2{e.aux[grp].z, e.aux[grp].w}, f2{e.bias[grp].z, e.bias[grp].w}));
+            store_half4(base + (lane_off + 512u * grp), to_half4(gelu2(v01), gelu2(v23)), NT);
+        }
+    } else {   // PRODUCES_LN: the residual stream's new values, their fp16 copy, the slice's (sum x, sum x^2)
+        char* fbase = reinterpret_cast<char*>(g.xh) + (size_t)((((unsigned)mt * (unsigned)(g.D / 16) * 2u + (unsigned)n32 * 4u) * 256u) * 2u);
+        char* xb = reinterpret_cast<char*>(g.x + n32 * 32);
+        const unsigned xoff = (unsigned)m * (unsigned)g.D * 4u + 16u * (unsigned)hi;
+        f2 ps = splat2(0.f), pq = splat2(0.f);   // this lane's share of the slice's (sum x, sum x^2), pairwise
+        const bool row = t < g.T;
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            f2 o01 = f2{e.x[grp].x, e.x[grp].y}, o23 = f2{e.x[grp].z, e.x[grp].w};   // (padding rows stay exactly zero)
+            const f2 v01 = f2{acc[grp * 4 + 0], acc[grp * 4 + 1]} + f2{e.bias[grp].x, e.bias[grp].y};
+            const f2 v23 = f2{acc[grp * 4 + 2], acc[grp * 4 + 3]} + f2{e.bias[grp].z, e.bias[grp].w};
             if constexpr (EPI == EPI_PATCH) {
-                if (t != 0 && t < g.T) o = make_float4(v[0] + o.x, v[1] + o.y, v[2] + o.z, v[3] + o.w);   // (t == 0: cls + pos[0] as loaded)
-                *xp = o;
-            } else if (t < g.T) {
-                o.x = o.x + au[0] * v[0]; o.y = o.y + au[1] * v[1];
-                o.z = o.z + au[2] * v[2]; o.w = o.w + au[3] * v[3];
-                *xp = o;
+                if (t != 0 && row) {   // (t == 0: cls + pos[0] as loaded)
+                    o01 = v01 + o01;
+                    o23 = v23 + o23;
+                }
+            } else if (row) {
+                o01 = fma2(f2{e.aux[grp].x, e.aux[grp].y}, v01, o01);
+                o23 = fma2(f2{e.aux[grp].z, e.aux[grp].w}, v23, o23);
             }
-            half4 oh;
-            oh[0] = (_Float16)o.x; oh[1] = (_Float16)o.y; oh[2] = (_Float16)o.z; oh[3] = (_Float16)o.w;
-            *reinterpret_cast<half4*>(frag_base + grp * 256) = oh;
-            psum += (o.x + o.y) + (o.z + o.w);
-            psq += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
-        } else if constexpr (EPI == EPI_GELU) {
-            half4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (_Float16)gelu_exact(v[j]);
-            store_half4(frag_base + grp * 256, o, NT);
-        } else {  // EPI_QKV
-            if (qk_base) {
-                half4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[j];
-                store_half4(qk_base + grp * 256, o, NT);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) vt_base[(8 * grp + j) * 8] = (_Float16)v[j];
-            }
+            if (EPI == EPI_PATCH || row) *reinterpret_cast<float4*>(xb + (xoff + 32u * grp)) = make_float4(o01[0], o01[1], o23[0], o23[1]);
+            *reinterpret_cast<half4*>(fbase + (lane_off + 512u * grp)) = to_half4(o01, o23);
+            ps += o01 + o23;
+            pq = fma2(o01, o01, fma2(o23, o23, pq));
         }
-    }
-    if constexpr (PRODUCES_LN) {   // the two half-waves hold the slice's other 16 channels of the same token: lower + upper, in that order
+        // the two half-waves hold the slice's other 16 channels of the same token: lower + upper, in that order
+        float psum = ps[0] + ps[1], psq = pq[0] + pq[1];
         const float osum = __shfl_xor(psum, 32), osq = __shfl_xor(psq, 32);
-        if (hi == 0) reinterpret_cast<float2*>(g.stats)[(size_t)m * (g.D / 32) + n32] = make_float2(psum + osum, psq + osq);
+        if (hi == 0) *reinterpret_cast<float2*>(reinterpret_cast<char*>(g.stats) + ((unsigned)m * (unsigned)(g.D / 32) + (unsigned)n32) * 8u) = make_float2(psum + osum, psq + osq);
     }
 }
 
@@ -394,15 +513,15 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
         }
     const int m = mt * 32 + (lane & 31);
     const int mtu = __builtin_amdgcn_readfirstlane(mt), qtiles = g.Tp >> 5;   // (a token tile lies inside one image: Tp % 32 == 0)
-    const int b = mtu / qtiles, tq = mtu - b * qtiles, t = tq * 32 + (lane & 31);
+    const int b = (int)(((unsigned)mtu * g.qt_magic) >> 20), tq = mtu - b * qtiles, t = tq * 32 + (lane & 31);
     const int hi = lane >> 5;
     // Everything the epilogue reads is requested HERE, behind the first operand fragments and in front of the k-loop (round 4): as
     // the epilogue's own loads -- bias, row sums, LayerScale, the residual values, twelve partial sums in a loop the compiler could
     // not unroll -- they were one more chain of L2 round trips at the end of every kernel of a forward that is nothing but such chains.
     EpiRegs e[NT];
 #pragma unroll
-    for (int half = 0; half < NT; ++half) epi_load<EPI>(g, m, t, hi, nt * NT + half, e[half]);
-    float ln_mean = 0.f, ln_rstd = 1.f;
+    for (int half = 0; half < NT; ++half) epi_load<EPI>(g, m, t, hi, __builtin_amdgcn_readfirstlane(nt * NT + half), e[half]);
+    float ln_mean = 0.f, ln_rstd = 0.f;   // (a, nb) of the lane's token: see ln_stats_load
     if constexpr (EPI == EPI_QKV || EPI == EPI_GELU) ln_stats_load(g, m, ln_mean, ln_rstd);
     for (int s0 = 0; s0 < g.KS; s0 += PF) {
 #pragma unroll
@@ -472,20 +591,36 @@ __global__ __launch_bounds__(256, 3) void vit_gemm_lds_kernel(GemmArgs g) {
     constexpr int PW = 2 * KB;   // pieces per wave and stage: 8 KB fragment rows over 4 waves
     const int nstages = (g.KS + KB - 1) / KB;
     // piece p of a stage: operand p / (4 KB) (0 = A, 1 = W), tile (p / KB) % 4, k-step p % KB; wave w issues pieces w, w + 4, ...
-    // (a stage past the end, or a k-step past KS, re-reads the last valid fragment row: the piece count per stage is a constant,
-    // which is what the counted waits below rest on; nothing reads such bytes)
-    auto issue_stage = [&](int stage, int slot) {
+    // Round 5 (the loop spent 45 scalar instructions per stage of 8 MFMAs on these addresses): a piece's source is a wave-uniform
+    // 64-bit pointer kept in scalar registers -- set up once -- plus a 32-bit offset (the saddr form of global_load_lds): the lane's 16
+    // bytes + KB KiB per stage issued so far; the pieces of a stage go out in one block that saves and restores m0 once.
+    // A k-step past the end keeps its pointer (re-reads a valid fragment row; the piece count per stage is a constant, which is what
+    // the counted waits below rest on; nothing reads such bytes).
+    const char* src[PW];
 #pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            const int p = wave + 4 * i;
-            const int op = p / (4 * KB), tile = (p / KB) & 3;
-            int ks = stage * KB + (p % KB);
-            ks = ks < g.KS ? ks : g.KS - 1;
-            int rowtile = op == 0 ? mg * 4 + tile : ng * 4 + tile;
-            if (op == 0 && rowtile >= mtiles) rowtile = mtiles - 1;   // (a partial last group of token tiles: its epilogue is skipped)
-            const uint4* src = (op == 0 ? g.A : g.W) + ((size_t)rowtile * g.KS + ks) * 64 + lane;
-            vit_glds16(src, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * STAGE + p * 1024)));
-        }
+    for (int i = 0; i < PW; ++i) {
+        const int p = wave + 4 * i;
+        const int op = p / (4 * KB), tile = (p / KB) & 3;
+        int ks = p % KB;
+        ks = ks < g.KS ? ks : g.KS - 1;
+        int rowtile = op == 0 ? mg * 4 + tile : ng * 4 + tile;
+        if (op == 0 && rowtile >= mtiles) rowtile = mtiles - 1;   // (a partial last group of token tiles: its epilogue is skipped)
+        src[i] = reinterpret_cast<const char*>((op == 0 ? g.A : g.W) + ((size_t)rowtile * g.KS + ks) * 64);
+    }
+    unsigned lane16 = (unsigned)lane * 16u;   // + the bytes the wave's pieces have moved on by (one VALU add per stage instead of PW 64-bit scalar ones)
+    const int kk_wave = wave % KB;
+    int ks_next = 0;   // first k-step of the stage issue_stage sends next
+    auto issue_stage = [&](int slot) {
+        const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * STAGE) + (unsigned)wave * 1024u);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0" : "=s"(keep)::"memory");
+#pragma unroll
+        for (int i = 0; i < PW; ++i)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(src[i]), "s"(dst0 + 4096u * (unsigned)i) : "memory");
+        asm volatile("s_mov_b32 m0, %0" ::"s"(keep) : "memory");
+        ks_next += KB;
+        // (wave + 4 i) % KB = wave % KB: every piece of this wave is the same k-step of its stage; it moves on while its next k-step exists
+        lane16 += (ks_next + kk_wave < g.KS) ? (unsigned)(KB * 1024) : 0u;
     };
     floatx16 acc[2][2];
 #pragma unroll
@@ -495,13 +630,13 @@ __global__ __launch_bounds__(256, 3) void vit_gemm_lds_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 #pragma unroll
-    for (int st = 0; st < NS - 1; ++st) issue_stage(st, st);   // stages 0 .. NS - 2 (dummies past the end)
+    for (int st = 0; st < NS - 1; ++st) issue_stage(st);   // stages 0 .. NS - 2 (dummies past the end)
     int slot = 0;
     for (int stage = 0; stage < nstages; ++stage) {
         vit_wait_vmcnt<(NS - 2) * PW>();      // this wave's pieces of `stage`: the NS - 2 stages issued since may fly on
         __builtin_amdgcn_s_barrier();         // everybody's; and everybody has left the slot of stage - 1
         asm volatile("" ::: "memory");
-        issue_stage(stage + NS - 1, slot == 0 ? NS - 1 : slot - 1);
+        issue_stage(slot == 0 ? NS - 1 : slot - 1);   // stage + NS - 1
         const unsigned char* st = lds + slot * STAGE;
 #pragma unroll
         for (int ks = 0; ks < KB; ++ks) {
@@ -528,8 +663,8 @@ __global__ __launch_bounds__(256, 3) void vit_gemm_lds_kernel(GemmArgs g) {
         if (mt >= mtiles) continue;   // wave-uniform
         const int m = mt * 32 + (lane & 31);
         const int mtu = __builtin_amdgcn_readfirstlane(mt), qtiles = g.Tp >> 5;
-        const int b = mtu / qtiles, tq = mtu - b * qtiles, t = tq * 32 + (lane & 31);
-        float ln_mean = 0.f, ln_rstd = 1.f;
+        const int b = (int)(((unsigned)mtu * g.qt_magic) >> 20), tq = mtu - b * qtiles, t = tq * 32 + (lane & 31);
+        float ln_mean = 0.f, ln_rstd = 0.f;   // (a, nb) of the lane's token: see ln_stats_load
         if constexpr (EPI == EPI_QKV || EPI == EPI_GELU) ln_stats_load(g, m, ln_mean, ln_rstd);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -611,7 +746,7 @@ __global__ __launch_bounds__(64 * NW, 1) void vit_gemm_astat_kernel(GemmArgs g) 
             const int mt = mg * 4 + t4;
             if (mt >= mtiles) continue;   // workgroup-uniform
             const int mtu = __builtin_amdgcn_readfirstlane(mt);
-            const int b = mtu / qtiles, tq = mtu - b * qtiles;
+            const int b = (int)(((unsigned)mtu * g.qt_magic) >> 20), tq = mtu - b * qtiles;
             epi_tile<EPI, NTS>(g, acc[t4], mt * 32 + lane31, mtu, b, tq, tq * 32 + lane31, hi, n32, e, ln_mean[t4], ln_rstd[t4]);
         }
     }
@@ -734,6 +869,42 @@ __device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
     return *reinterpret_cast<unsigned*>(&h);
 }
 
+// softmax over the keys of NKT score tiles S^T (rows = keys, column = query = lane & 31; the two half-waves hold a query's other keys):
+// p = exp2((s - max s) scale) with scale = log2(e) / 8 -- the maximum on the raw scores (v_max3), scale and subtraction as ONE packed FMA per
+// pair of scores, the sum by packed adds (round 5: 6 instructions per score were 4 of the kernel's 5 600 VALU cycles per wave; the exponential
+// itself -- a quarter-rate instruction -- is the floor).  Keys >= T (padding: only in the last key tile, Tp - T < 32) get -3e38: exp2 gives 0.
+// Shared by the two attention kernels (bit-equal to each other).  Returns 1 / sum.
+template <int NKT>
+__device__ __forceinline__ float att_softmax(floatx16 (&S)[NKT], int T, int hi) {
+    const float scale = 0.125f * 1.44269504088896340736f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = (NKT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        S[NKT - 1][r] = (key < T) ? S[NKT - 1][r] : -3.0e38f;
+    }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, S[kt][r]), S[kt][r + 1]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const f2 sc2 = splat2(scale), off2 = splat2(-(mx * scale));
+    f2 sum2 = splat2(0.f);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const f2 a = fma2(f2{S[kt][r], S[kt][r + 1]}, sc2, off2);
+            const f2 pr = f2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};   // (v_exp_f32: arguments <= 0, a result below 2^-126 is 0 either way)
+            S[kt][r] = pr[0];
+            S[kt][r + 1] = pr[1];
+            sum2 += pr;
+        }
+    float sum = sum2[0] + sum2[1];
+    sum += __shfl_xor(sum, 32);
+    return 1.0f / sum;
+}
+
 template <int NKT>
 __global__ __launch_bounds__(256) void vit_attention_kernel(const uint4* __restrict__ Q, const uint4* __restrict__ K,
                                                             const uint4* __restrict__ VT, int T, int Tp, int heads, int D,
@@ -770,35 +941,8 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const uint4* __restr
         }
     }
     const int hi = lane >> 5;
-    // softmax over keys (scale 1/8), keys >= T masked
-    const float scale = 0.125f * 1.44269504088896340736f;  // fold log2(e): exp(x) = exp2(x*log2e)
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // (only the last key tile holds padding -- Tp - T < 32 --: the others are scaled without the test; per wave the softmax is
-            // 176 values per lane, and at one wave per SIMD every instruction of it is kernel time)
-            float s = S[kt][r] * scale;
-            if (kt == NKT - 1) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                s = (key < T) ? s : -3.0e38f;
-            }
-            S[kt][r] = s;
-            mx = fmaxf(mx, s);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(S[kt][r] - mx);   // (v_exp_f32: arguments <= 0, a result below 2^-126 is 0 either way)
-            S[kt][r] = p;
-            sum += p;
-        }
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
+    // softmax over keys (scale 1/8), keys >= T masked: S becomes the unnormalised probabilities, inv = 1 / their sum
+    const float inv = att_softmax<NKT>(S, T, hi);
     // O^T[d][query] = sum_keys V^T[d][key] P^T[key][query]: A = V^T fragment, B = P^T in registers.
     floatx16 O0, O1;
 #pragma unroll
@@ -907,35 +1051,8 @@ __global__ __launch_bounds__(256, 2) void vit_attention_lds_kernel(const uint4* 
         }
     }
     const int hi = lane >> 5;
-    // softmax over keys (scale 1/8), keys >= T masked
-    const float scale = 0.125f * 1.44269504088896340736f;  // fold log2(e): exp(x) = exp2(x*log2e)
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // (only the last key tile holds padding -- Tp - T < 32 --: the others are scaled without the test; per wave the softmax is
-            // 176 values per lane, and at one wave per SIMD every instruction of it is kernel time)
-            float s = S[kt][r] * scale;
-            if (kt == NKT - 1) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                s = (key < T) ? s : -3.0e38f;
-            }
-            S[kt][r] = s;
-            mx = fmaxf(mx, s);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(S[kt][r] - mx);   // (v_exp_f32: arguments <= 0, a result below 2^-126 is 0 either way)
-            S[kt][r] = p;
-            sum += p;
-        }
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
+    // softmax over keys (scale 1/8), keys >= T masked: S becomes the unnormalised probabilities, inv = 1 / their sum
+    const float inv = att_softmax<NKT>(S, T, hi);
     vit_wait_vmcnt<0>();   // V^T
     __syncthreads();
     if (!active) return;
@@ -1025,6 +1142,7 @@ inline VitWs carve_vit(void* p, const Dims& d) {
     return w;
 }
 
+int g_vit_preprocess_patch = 1;   // vfm_debug_set_vit_gemm(-14, 0 / 1): the per-thread-unit preprocessing kernel / one workgroup per patch (default; A/B + bit-equality test)
 int g_vit_xcd = 1;        // vfm_debug_set_vit_gemm(-3 / -4, .): XCD-consistent tile mapping on / off (A/B)
 int g_vit_cfg_narrow = 108, g_vit_cfg_wide = 108;  // (NT * 100 + PF) for N <= 512 / N > 512 (vfm_debug_set_vit_gemm)
 
@@ -1158,6 +1276,10 @@ VFM_EXPORT int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg) {
         g_vit_lds_shape = wide_cfg;
         return VFM_OK;
     }
+    if (narrow_cfg == -14) {   // preprocessing: 1 = one workgroup per patch (default), 0 = round 1's kernel
+        g_vit_preprocess_patch = wide_cfg;
+        return VFM_OK;
+    }
     if (narrow_cfg == -8) {   // waves per workgroup of the direct GEMM kernel (0: the default, one)
         g_vit_wpw = wide_cfg;
         return VFM_OK;
@@ -1215,6 +1337,8 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
     VFM_CHECK_ARG(cfg->patch == 14 && cfg->patch_h >= 1 && cfg->patch_w >= 1 && B >= 1, "vit: bad patch grid");
     const Dims d = make_dims(cfg, B, H, W);
     VFM_CHECK_ARG(d.Tp / 32 <= 16, "vit: at most 512 tokens per image supported (got %d)", d.T);
+    // (the GEMM epilogues address every activation buffer with 32-bit byte offsets and find a token tile's image by a 20-bit reciprocal)
+    VFM_CHECK_ARG((uint64_t)d.M * (uint64_t)(d.mlp > 3 * d.D ? d.mlp : 3 * d.D) * 4u < (1ull << 32) && d.M / 32 < 65536, "vit: batch of %d images too large for one call", B);
     if (ws_bytes < carve_vit(nullptr, d).bytes) return vfm_fail(VFM_EWORKSPACE, "vit: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const Layout L = make_layout(cfg);
@@ -1226,13 +1350,16 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
     // padded token rows stay exactly zero in the residual stream
     {
         const int64_t total = (int64_t)d.M * (d.KP / 16) * 2;
-        hipLaunchKernelGGL(vit_preprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, d, w.a);
+        if (g_vit_preprocess_patch && d.KP <= 640 && d.W >= 2)
+            hipLaunchKernelGGL(vit_preprocess_patch_kernel, dim3((unsigned)d.M), dim3(256), 0, st, img, d, w.a);
+        else
+            hipLaunchKernelGGL(vit_preprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, d, w.a);
         VFM_CHECK_LAUNCH("vit_preprocess_kernel");
     }
     GemmArgs g{};
     g.T = d.T; g.Tp = d.Tp; g.D = d.D; g.heads = d.heads; g.M = d.M;
     g.x = w.x; g.q = w.q; g.k = w.k; g.vt = w.vt;
-    g.xh = w.xh; g.stats = w.stats;
+    g.xh = w.xh; g.stats = w.stats; g.invD = 1.0f / (float)d.D; g.qt_magic = (1u << 20) / (unsigned)(d.Tp / 32) + 1u;
     g.xcd_map = g_vit_xcd;
     const int att_grid = g_vit_xcd ? 8 * ceil_div(ceil_div(d.M / 32, 8) * d.heads, 4) : ceil_div(d.B * d.heads * (d.Tp / 32), 4);
     // patch embedding (+ cls token + position embedding)
