@@ -52,8 +52,12 @@ int vfm_debug_set_match_stats(int on);
  * the LDS from wide_cfg images per call on (0 = never, default 1); -8: waves per workgroup of the direct GEMM kernel (1, 2 or 4; 0 = default, 1);
  * -9: the token-stationary QKV / fc1 kernel from wide_cfg groups of 128 token rows on (0 = default: where its rounds of one workgroup per
  * compute unit are at least three quarters full; -1 = never); -10: its waves per workgroup (6, 8, 12 = default; 112 = 12 with non-temporal
- * output stores); -11 / -12: low / high 32 bits of a device pointer to its per-workgroup placement trace (tools/ab_vit_astat_trace.py; 0 = off) */
+ * output stores); -11 / -12: low / high 32 bits of a device pointer to its per-workgroup placement trace (tools/ab_vit_astat_trace.py; 0 = off);
+ * -14: image preprocessing by one workgroup per 14 x 14 patch (1, default since round 5) / by round 1's one-thread-per-fragment-unit kernel (0) */
 int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
+/* A/B + tests: vfm_voxel_robin on a VoxelDownsample-shaped call (one point per voxel, reserve(n), n <= 2^18) by the one-launch kernel
+ * (1, default since round 5) / always by the general multi-launch path (0); both give the container's order */
+int vfm_debug_set_voxel_small(int on);
 /* A/B: workgroups of the int8 operand-preparation kernel (-1, default = one per 128-row group; 0 = one per compute unit, each
  * walking several groups with the next group's rows read under the current group's quantisation and store: faster alone,
  * slower beside the coarse kernel; n > 0 = n workgroups) */

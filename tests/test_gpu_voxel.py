@@ -155,3 +155,63 @@ def test_voxel_hash_map_caps_points_per_voxel():
     np.testing.assert_array_equal(m.point_cloud_n(), wide[order])
     np.testing.assert_array_equal(m.point_cloud(), wide[order][:, :3])
     assert m.empty() and not m.empty_n()
+
+
+def test_one_launch_downsample_equals_the_general_path_and_the_oracle():
+    """voxel_robin_small_kernel (round 5: VoxelDownsample of up to 2^18 points in one launch -- the last workgroup to finish the first-point
+    table goes on alone: counting sort by home bucket, clusters, per-cluster replay) against the general multi-launch path and the
+    oracle's robin-map replay: sizes on both sides of a workgroup's worth of points, dense and sparse tables, duplicates, the chained
+    voxelisations of registration_node.py:399-414, tables whose last cluster wraps."""
+    from oracle import oracle as orc
+    from vfmreg import _lib, ops
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    cases = [(1, 1.0, 1.0), (2, 1.0, 1.0), (63, 2.0, 0.5), (1024, 6.0, 0.5), (1025, 6.0, 1.0), (4097, 3.0, 1.0), (20000, 60.0, 0.5),
+             (20000, 60.0, 5.0), (60000, 50.0, 0.5), (60000, 50.0, 0.05), (131072, 60.0, 0.25), (262144, 80.0, 0.5)]
+    try:
+        for n, extent, vs in cases:
+            pts = rng.uniform(-extent, extent, (n, 3)) * [1, 1, 0.15]
+            if n > 10:
+                pts[n // 2] = pts[0]
+                pts[n - 1] = pts[1]
+            ref, rinfo = orc.voxel_robin(pts, vs, return_info=True)
+            d = torch.from_numpy(pts).cuda()
+            lib.vfm_debug_set_voxel_small(0)
+            gen, ginfo = ops.voxel_robin(d, vs, return_info=True)
+            lib.vfm_debug_set_voxel_small(1)
+            one, oinfo = ops.voxel_robin(d, vs, return_info=True)
+            np.testing.assert_array_equal(one.cpu().numpy(), ref, err_msg=str((n, extent, vs)))
+            np.testing.assert_array_equal(gen.cpu().numpy(), ref, err_msg=str((n, extent, vs)))
+            assert oinfo[:2] == ginfo[:2] == list(rinfo[:2]), (n, oinfo, ginfo, rinfo)
+        # chained: .5 -> 1.0 -> 5.0 on the survivors, as the node does
+        pts = rng.uniform(-50, 50, (60000, 3)) * [1, 1, 0.1]
+        cur_h, cur_d = pts, torch.from_numpy(pts).cuda()
+        for vs in (0.5, 1.0, 5.0):
+            o = ops.voxel_robin(cur_d, vs)
+            r = orc.voxel_robin(cur_h, vs)
+            np.testing.assert_array_equal(o.cpu().numpy(), r)
+            cur_h, cur_d = cur_h[r], cur_d[o]
+        # wrapping clusters (homes in the last buckets): the construction of test_downsample_order_with_wrapping_clusters
+        wrapped = 0
+        for trial in range(12):
+            n = int(rng.integers(50, 3000))
+            c = int(np.ceil(np.float32(n) / np.float32(0.5)))
+            B = 1
+            while B < c:
+                B <<= 1
+            xs = []
+            x = 0
+            while len(xs) < n:       # voxels (x, 0, 0) whose VoxelHash & (B - 1) falls into the last 8 buckets or anywhere
+                h = ((x * 73856093) & 0xFFFFFFFF) & ((1 << 20) - 1) & (B - 1)
+                if h >= B - 8 or rng.random() < 0.3:
+                    xs.append(x)
+                x += 1
+            pts = np.c_[np.array(xs, dtype=np.float64) + 0.5, np.full(n, 0.5), np.full(n, 0.5)]
+            pts = pts[rng.permutation(n)]
+            ref, rinfo = orc.voxel_robin(pts, 1.0, return_info=True)
+            one, oinfo = ops.voxel_robin(torch.from_numpy(pts).cuda(), 1.0, return_info=True)
+            np.testing.assert_array_equal(one.cpu().numpy(), ref, err_msg=f"trial {trial}")
+            wrapped += int(oinfo[3] > 0)
+        assert wrapped >= 3, wrapped
+    finally:
+        lib.vfm_debug_set_voxel_small(1)

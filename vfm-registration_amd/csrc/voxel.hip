@@ -332,6 +332,292 @@ __global__ __launch_bounds__(256) void robin_pointkey_kernel(const int64_t* __re
     if (k < nk) pkey[k] = vrank[slot_vid[slot_of[kept[k]]]];
 }
 
+// ---------------------------------------------------------------------------------- one launch for VoxelDownsample-sized clouds
+// Round 5.  The reference-shaped call chains three VoxelDownsample()s of 10^3 .. 10^5 points
+// (registration_node.py:399-414); through the general path above each is ~28 dependent launches and two read-backs (0.23 ms: launch
+// latency, not work).  For ONE generation of a reserved table (reserve(n): B = 2^ceil(log2 2n) buckets, no rehash), one point per
+// voxel, this kernel does the whole of it:
+//   phase A, every workgroup: the first-point table (atomicCAS / atomicMin, as voxel_insert_kernel);
+//   the LAST workgroup to finish A (agent-scope release / acquire around a counter: nobody waits for anybody) goes on alone:
+//   B  first points in ascending order (block scan) = the voxels in arrival order, their 20-bit VoxelHash;
+//   C  the voxels counting-sorted by home bucket (histogram over the B buckets, block scan, scatter) -- ties in any order: the
+//      replay below orders a cluster's members by arrival itself;
+//   D  bucket of sorted entry i = i + running max (home_i - i): clusters, their windows, the entries that would wrap past the last
+//      bucket (then once more in coordinates rotated to a bucket that stays empty -- robin_wrap_kernel's rule);
+//   E  one thread per cluster: members sorted by arrival (insertion sort: clusters of a half-empty table are a few entries), then
+//      the container's insertions (tsl's swap rule) inside the cluster's window;
+//   F  iteration order -> kept point indices.
+// A cluster longer than SMALLW_MAX_CLUSTER raises `fail`: the caller takes the general path.  Same container order, bit for bit
+// (tests/test_gpu_voxel.py runs both paths against the oracle's robin-map replay).
+int g_voxel_small = 1;   // vfm_debug_set_voxel_small(0 / 1): the general path always / the one-launch kernel where it applies (default)
+constexpr int SMALLW_THREADS = 1024;
+constexpr int SMALLW_MAX_CLUSTER = 192;
+constexpr int64_t SMALLW_MAX_N = 1 << 18;   // points (B <= 2^19 buckets)
+
+__device__ __forceinline__ int block_scan_excl_sum(int v, int* lds, int* total) {   // 1024 threads; lds[1024]
+    const int t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (int off = 1; off < SMALLW_THREADS; off <<= 1) {
+        const int add = t >= off ? lds[t - off] : 0;
+        __syncthreads();
+        lds[t] += add;
+        __syncthreads();
+    }
+    const int incl = lds[t];
+    if (total) *total = lds[SMALLW_THREADS - 1];
+    __syncthreads();
+    return incl - v;
+}
+__device__ __forceinline__ int block_scan_excl_max(int v, int* lds, int identity) {   // max of the values of threads < t
+    const int t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (int off = 1; off < SMALLW_THREADS; off <<= 1) {
+        const int o = t >= off ? lds[t - off] : identity;
+        __syncthreads();
+        lds[t] = max(lds[t], o);
+        __syncthreads();
+    }
+    const int r = t > 0 ? lds[t - 1] : identity;
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ int block_reduce_min(int v, int* lds) {
+    const int t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (int off = SMALLW_THREADS / 2; off > 0; off >>= 1) {
+        if (t < off) lds[t] = min(lds[t], lds[t + off]);
+        __syncthreads();
+    }
+    const int r = lds[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void voxel_small_init_kernel(int* __restrict__ owner, int* __restrict__ tmin, int64_t hsize,
+                                                               unsigned* __restrict__ done) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s == 0) *done = 0u;
+    if (s >= hsize) return;
+    owner[s] = EMPTY_OWNER;
+    tmin[s] = 0x7fffffff;
+}
+
+struct SmallRobinArgs {
+    const double* pts;
+    int64_t n, stride;
+    double vs;
+    unsigned mul_y;
+    int B;                 // buckets of the reserved table (power of two)
+    int* owner; int* tmin; int hmask; int* slot_of;   // first-point table (owner = -1, tmin = INT_MAX before the launch)
+    unsigned* done;        // [1] workgroups that have finished phase A (0 before the launch)
+    int* vfirst32;         // [n] first point of voxel v
+    unsigned* vhash;       // [n]
+    int* hist;             // [B]
+    int* sorted_v;         // [n] voxels by home bucket
+    int* key_s;            // [n] their (rotated) home buckets
+    int* cm;               // [n] running maximum of home - index
+    int* cl_start;         // [n + 1]
+    int* tab_dist; int* tab_id;   // [n] the table, cluster windows back to back
+    int64_t* keep_out;     // [n]
+    int64_t* count_out;    // [1]
+    int64_t* info;         // [4] device copy of {B, nv, max distance, wrapped} + [4] = fail
+};
+
+__global__ __launch_bounds__(SMALLW_THREADS) void voxel_robin_small_kernel(SmallRobinArgs a) {
+    __shared__ int lds[SMALLW_THREADS];
+    __shared__ int sh_last, sh_w;
+    const int tid = threadIdx.x;
+    const int n = (int)a.n;
+    // ---- A: first-point table, all workgroups
+    for (int64_t i = (int64_t)blockIdx.x * SMALLW_THREADS + tid; i < a.n; i += (int64_t)gridDim.x * SMALLW_THREADS) {
+        const Vox v = voxel_of(a.pts + i * a.stride, a.vs);
+        int s = (int)(slot_hash(v) & (unsigned)a.hmask);
+        while (true) {
+            const int prev = atomicCAS(a.owner + s, EMPTY_OWNER, (int)i);
+            if (prev == EMPTY_OWNER) break;
+            const Vox o = voxel_of(a.pts + (int64_t)prev * a.stride, a.vs);
+            if (o.x == v.x && o.y == v.y && o.z == v.z) break;
+            s = (s + 1) & a.hmask;
+        }
+        a.slot_of[i] = s;
+        atomicMin(a.tmin + s, (int)i);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        sh_last = prev + 1u == gridDim.x;
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // ---- B: voxels in arrival order
+    const int chunk = (n + SMALLW_THREADS - 1) / SMALLW_THREADS;
+    const int lo = min(n, tid * chunk), hi = min(n, lo + chunk);
+    int cnt = 0;
+    for (int i = lo; i < hi; ++i) cnt += a.tmin[a.slot_of[i]] == i ? 1 : 0;
+    int nv;
+    int pos = block_scan_excl_sum(cnt, lds, &nv);
+    for (int i = lo; i < hi; ++i)
+        if (a.tmin[a.slot_of[i]] == i) {
+            a.vfirst32[pos] = i;
+            a.vhash[pos] = reference_hash(voxel_of(a.pts + (int64_t)i * a.stride, a.vs), a.mul_y);
+            ++pos;
+        }
+    __syncthreads();
+    const int B = a.B;
+    const unsigned mask = (unsigned)(B - 1);
+    const int bchunk = (B + SMALLW_THREADS - 1) / SMALLW_THREADS;
+    const int vchunk = (nv + SMALLW_THREADS - 1) / SMALLW_THREADS;
+    const int vlo = min(nv, tid * vchunk), vhi = min(nv, vlo + vchunk);
+    unsigned z = 0;
+    int wrapped = 0, rot = 0, fail = 0, ncl = 0;
+    for (int pass = 0; pass < 2 && nv > 0; ++pass) {
+        // ---- C: counting sort by home bucket
+        for (int b = tid; b < B; b += SMALLW_THREADS) a.hist[b] = 0;
+        __syncthreads();
+        for (int v = tid; v < nv; v += SMALLW_THREADS) atomicAdd(a.hist + (int)((a.vhash[v] - z) & mask), 1);
+        __syncthreads();
+        {
+            const int blo = min(B, tid * bchunk), bhi = min(B, blo + bchunk);
+            // (the counts were made by atomics, at the L2: read them there -- a plain load may hit a line this compute unit cached in pass 0)
+            int sum = 0;
+            for (int b = blo; b < bhi; ++b) sum += __hip_atomic_load(a.hist + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int off = block_scan_excl_sum(sum, lds, nullptr);
+            for (int b = blo; b < bhi; ++b) {
+                const int c = __hip_atomic_load(a.hist + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.hist[b] = off;
+                off += c;
+            }
+        }
+        __syncthreads();
+        for (int v = tid; v < nv; v += SMALLW_THREADS) {
+            const int h = (int)((a.vhash[v] - z) & mask);
+            const int p = atomicAdd(a.hist + h, 1);
+            a.sorted_v[p] = v;
+            a.key_s[p] = h;
+        }
+        __syncthreads();
+        // ---- D: running maximum of d_i = home_i - i, clusters
+        int lmax = -0x7fffffff;
+        for (int i = vlo; i < vhi; ++i) lmax = max(lmax, a.key_s[i] - i);
+        int run = block_scan_excl_max(lmax, lds, -0x7fffffff);   // maximum over the entries in front of this thread's
+        int nflag = 0, nwrap = 0;
+        for (int i = vlo; i < vhi; ++i) {
+            const int d = a.key_s[i] - i;
+            if (i == 0 || d > run) ++nflag;
+            run = max(run, d);
+            a.cm[i] = run;
+            a.tab_dist[i] = -1;
+            if (i + run >= B) ++nwrap;
+        }
+        int cbase = block_scan_excl_sum(nflag, lds, &ncl);
+        {
+            int total_w;
+            (void)block_scan_excl_sum(nwrap, lds, &total_w);
+            if (tid == 0) sh_w = total_w;
+        }
+        int prev = vlo > 0 ? a.cm[vlo - 1] : -0x7fffffff;   // (written by the neighbour above: visible after the scans' barriers)
+        for (int i = vlo; i < vhi; ++i) {
+            const int d = a.key_s[i] - i;
+            if (i == 0 || d > prev) a.cl_start[cbase++] = i;
+            prev = a.cm[i];
+        }
+        if (tid == 0) a.cl_start[ncl] = nv;
+        __syncthreads();
+        const int w = sh_w;
+        if (w > 0) {
+            if (pass == 1) { fail = 1; break; }
+            // smallest i with cm[i] >= w + 1: the bucket just below its cluster stays empty once the w wrapped entries have landed
+            int cand = 0x7fffffff;
+            for (int i = vlo; i < vhi; ++i)
+                if (a.cm[i] >= w + 1) { cand = i; break; }
+            const int ibest = block_reduce_min(cand, lds);
+            if (ibest == 0x7fffffff) { fail = 1; break; }
+            z = (unsigned)(ibest + a.cm[ibest] - 1);
+            wrapped = 1;
+            __syncthreads();
+            continue;
+        }
+        if (z != 0) {   // actual bucket = (rotated bucket + z) mod B: iteration starts at rotated bucket B - z
+            int cand = nv;
+            for (int i = vlo; i < vhi; ++i)
+                if (i + a.cm[i] >= B - (int)z) { cand = i; break; }
+            rot = block_reduce_min(cand, lds);
+        }
+        break;
+    }
+    // ---- E: one thread per cluster replays the container
+    int maxd = 0;
+    if (!fail)
+        for (int c = tid; c < ncl; c += SMALLW_THREADS) {
+            const int i0 = a.cl_start[c], L = a.cl_start[c + 1] - i0;
+            if (L > SMALLW_MAX_CLUSTER) { fail = 1; continue; }
+            int* mem = a.sorted_v + i0;
+            const int base = a.key_s[i0];
+            for (int x = 1; x < L; ++x) {   // members by arrival (= voxel rank)
+                const int v = mem[x];
+                int y = x - 1;
+                while (y >= 0 && mem[y] > v) { mem[y + 1] = mem[y]; --y; }
+                mem[y + 1] = v;
+            }
+            int* D = a.tab_dist + i0;
+            int* I = a.tab_id + i0;
+            for (int t = 0; t < L; ++t) {
+                int v = mem[t];
+                int ib = (int)((a.vhash[v] - z) & mask) - base;
+                int d = 0;
+                for (;;) {   // tsl insert_value_on_rehash (== insert_impl + insert_value_impl for an absent key)
+                    const int rd = D[ib];
+                    if (d > rd) {
+                        if (rd < 0) { D[ib] = d; I[ib] = v; if (d > maxd) maxd = d; break; }
+                        const int tv = I[ib];
+                        D[ib] = d; I[ib] = v;
+                        if (d > maxd) maxd = d;
+                        d = rd; v = tv;
+                    }
+                    d++;
+                    ib++;   // never leaves [0, L): the window is the cluster's final extent
+                }
+            }
+        }
+    // (fail / maxd: any thread's)
+    lds[tid] = fail;
+    __syncthreads();
+    for (int off = SMALLW_THREADS / 2; off > 0; off >>= 1) {
+        if (tid < off) lds[tid] = max(lds[tid], lds[tid + off]);
+        __syncthreads();
+    }
+    fail = lds[0];
+    __syncthreads();
+    lds[tid] = maxd;
+    __syncthreads();
+    for (int off = SMALLW_THREADS / 2; off > 0; off >>= 1) {
+        if (tid < off) lds[tid] = max(lds[tid], lds[tid + off]);
+        __syncthreads();
+    }
+    maxd = lds[0];
+    __syncthreads();
+    // ---- F: iteration order -> kept point indices
+    if (!fail)
+        for (int i = tid; i < nv; i += SMALLW_THREADS) {
+            int j = i + rot;
+            if (j >= nv) j -= nv;
+            a.keep_out[i] = (int64_t)a.vfirst32[a.tab_id[j]];
+        }
+    if (tid == 0) {
+        *a.count_out = nv;
+        a.info[0] = B;
+        a.info[1] = nv;
+        a.info[2] = maxd;
+        a.info[3] = wrapped;
+        a.info[4] = fail;
+    }
+}
+
 struct VoxelWs {
     int* owner;
     int* tcount;
@@ -366,6 +652,7 @@ struct VoxelWs {
     int* cl_base;      // [n]
     int* tab_dist;     // [n]
     int* tab_id;       // [n]
+    int* hist_small;   // [2^ceil(log2 2n)] bucket histogram of voxel_robin_small_kernel
     void* cub;         // hipCUB temporary storage
     size_t cub_bytes;
     size_t bytes;
@@ -431,6 +718,11 @@ inline VoxelWs carve_voxel(void* p, int64_t n, bool robin) {
         w.cl_base = c.take<int>(nn);
         w.tab_dist = c.take<int>(nn);
         w.tab_id = c.take<int>(nn);
+        {
+            size_t hb = 2;
+            while (hb < 2 * nn) hb <<= 1;
+            w.hist_small = c.take<int>(n <= SMALLW_MAX_N ? 2 * hb : 1);   // (B = the power of two >= 2 reserve_n, reserve_n = n)
+        }
     }
     w.cub_bytes = (p != nullptr || true) ? cub_temp_bytes(n) : 0;
     w.cub = c.take<unsigned char>(w.cub_bytes);
@@ -461,6 +753,11 @@ int select_first_k(const double* pts, int64_t n, int64_t stride, double voxel_si
 }
 
 }  // namespace
+
+VFM_EXPORT int vfm_debug_set_voxel_small(int on) {
+    g_voxel_small = on;
+    return VFM_OK;
+}
 
 VFM_EXPORT size_t vfm_voxel_first_workspace_bytes(int64_t n) { return carve_voxel(nullptr, n, false).bytes; }
 
@@ -499,6 +796,44 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
         return VFM_OK;
     }
     const int K = max_per_voxel;
+    if (K == 1 && reserve_n >= 0 && n <= SMALLW_MAX_N && g_voxel_small) {
+        // VoxelDownsample of a cloud of this size: one generation of a reserved table in ONE launch (voxel_robin_small_kernel)
+        int64_t B = 0;
+        {
+            const float c = ceilf((float)reserve_n / 0.5f);
+            const int64_t want = (int64_t)c;
+            if (want > 0) {
+                B = 1;
+                while (B < want) B <<= 1;
+            }
+        }
+        if (B >= 2 * n && B <= (1ll << 20) && reserve_n == n) {   // (no rehash: nv <= n <= the load threshold B / 2; the histogram is sized for reserve(n))
+            SmallRobinArgs a{};
+            a.pts = pts; a.n = n; a.stride = stride; a.vs = voxel_size; a.mul_y = hash_mul_y; a.B = (int)B;
+            a.owner = w.owner; a.tmin = w.tmin; a.hmask = (int)(w.hsize - 1); a.slot_of = w.slot_of;
+            a.done = reinterpret_cast<unsigned*>(w.smallinfo);
+            a.vfirst32 = w.seq_a; a.vhash = w.vhash; a.hist = w.hist_small;
+            a.sorted_v = w.seq_b; a.key_s = reinterpret_cast<int*>(w.key_s); a.cm = w.cm; a.cl_start = w.cl_start;
+            a.tab_dist = w.tab_dist; a.tab_id = w.tab_id; a.keep_out = keep_out; a.count_out = count_out; a.info = w.geninfo;
+            hipLaunchKernelGGL(voxel_small_init_kernel, dim3(blocks_of(w.hsize)), dim3(256), 0, st, w.owner, w.tmin, w.hsize, a.done);
+            const unsigned grid = (unsigned)((n + SMALLW_THREADS - 1) / SMALLW_THREADS < 64 ? (n + SMALLW_THREADS - 1) / SMALLW_THREADS : 64);
+            hipLaunchKernelGGL(voxel_robin_small_kernel, dim3(grid), dim3(SMALLW_THREADS), 0, st, a);
+            VFM_CHECK_LAUNCH("voxel_robin_small_kernel");
+            int64_t gi[5];
+            VFM_CHECK_HIP(hipMemcpyAsync(gi, w.geninfo, sizeof(gi), hipMemcpyDeviceToHost, st));
+            VFM_CHECK_HIP(hipStreamSynchronize(st));
+            if (gi[4] == 0) {
+                if (info_host) {
+                    info_host[0] = gi[0];
+                    info_host[1] = gi[1];
+                    info_host[2] = gi[2];
+                    info_host[3] = gi[3];
+                }
+                return VFM_OK;
+            }
+            // (a cluster beyond the kernel's limit, or a wrap it could not place: the general path decides)
+        }
+    }
     select_first_k(pts, n, stride, voxel_size, K, w, st, K > 1);
     hipcub::CountingInputIterator<int64_t> it(0);
     size_t tb = w.cub_bytes;

@@ -104,6 +104,7 @@ DEBUG_SIGNATURES = {
     "vfm_debug_set_i8_min_queries": (C.c_int, [C.c_int]),
     "vfm_debug_set_vit_gemm": (C.c_int, [C.c_int, C.c_int]),
     "vfm_debug_set_prep_grid": (C.c_int, [C.c_int]),
+    "vfm_debug_set_voxel_small": (C.c_int, [C.c_int]),
     "vfm_debug_set_coarse_variant": (C.c_int, [C.c_int]),
     "vfm_debug_set_coarse_slices": (C.c_int, [C.c_int]),
     "vfm_debug_set_ransac_exact_only": (C.c_int, [C.c_int]),
