@@ -229,6 +229,21 @@ int vfm_match_search_finish_gated_r(const float *q, const void *q_prepared, int6
                                     const void *b_prepared, int64_t m, int d, int64_t *idx_out,
                                     float *sim_out, void *ws, size_t ws_bytes, float gate, int records,
                                     vfm_stream_t stream);
+/* Round 5 -- descriptor rows stored in fp16 (BASELINE.json configs[4]: "fp16 descriptor storage"; a 1 000 000 x 768 map is 1.54 GB
+ * instead of 3.07).  The reference converts its fp64 rows to fp32 one by one (VoxelHashMap.cpp:469-482) and everything behind that
+ * is fp32 / fp64; here an fp16 row is widened to fp32 element by element as it is loaded -- by the preparation (norms, int8 and fp6
+ * images) and by the finish stage (fp32 refinement, fp64 decision) -- and from there on the arithmetic is the fp32 path's, operation for
+ * operation: the result equals the search of the widened rows, bit for bit (oracle: the same function on rows.astype(float32)).
+ * _prepare2_gated_t = _prepare2_gated_p, _search_finish_gated_t = _search_finish_gated_r, each operand with its row type; the coarse
+ * calls read prepared operands only and are unchanged.  fp16 rows are taken where the gated family runs its int8 / fp6 passes
+ * (d = 256 ... 768); the fp16-tile pass of small searches reads fp32 rows (VFM_EINVAL otherwise). */
+#define VFM_ROWS_F32 0
+#define VFM_ROWS_F16 1
+int vfm_match_prepare2_gated_t(const void *x1, int dtype1, int64_t rows1, void *prepared1, const void *x2, int dtype2,
+                               int64_t rows2, void *prepared2, int d, int schedule, vfm_stream_t stream);
+int vfm_match_search_finish_gated_t(const void *q, int dtype_q, const void *q_prepared, int64_t n, const void *b, int dtype_b,
+                                    const void *b_prepared, int64_t m, int d, int64_t *idx_out, float *sim_out, void *ws,
+                                    size_t ws_bytes, float gate, int records, vfm_stream_t stream);
 /* Feedback for a caller that registers many scans: the number of candidate chunks the last gated search in `ws` had to
  * rescan (0 where the int8 pass did not run), copied to out_host (pinned memory) asynchronously on `stream`, after the
  * _finish_gated call on that stream.  Duplicate-rich maps put hundreds of rows inside the int8 bounds of every query;

@@ -56,7 +56,8 @@ int vfm_debug_set_match_stats(int on);
  * -14: image preprocessing by one workgroup per 14 x 14 patch (1, default since round 5) / by round 1's one-thread-per-fragment-unit kernel (0) */
 int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
 /* A/B + tests: vfm_voxel_robin on a VoxelDownsample-shaped call (one point per voxel, reserve(n), n <= 2^18) by the one-launch kernel
- * (1, default since round 5) / always by the general multi-launch path (0); both give the container's order */
+ * (1) / always by the general multi-launch path (0, default: the one-launch form measured slower -- csrc/voxel.hip); both give the
+ * container's order */
 int vfm_debug_set_voxel_small(int on);
 /* A/B: workgroups of the int8 operand-preparation kernel (-1, default = one per 128-row group; 0 = one per compute unit, each
  * walking several groups with the next group's rows read under the current group's quantisation and store: faster alone,

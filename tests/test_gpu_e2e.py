@@ -189,6 +189,35 @@ def test_c5_solve_at_full_size():
     assert out["best_hyp"].item() == r.best_hyp
     np.testing.assert_array_equal(T, r.transformation)
     np.testing.assert_array_equal(out["mask"][:k].cpu().numpy(), r.inlier_mask)
+    # ... and with the map stored in fp16 (configs[4]: "fp16 descriptor storage"; 1.54 GB instead of 3.07): the registration of the
+    # widened rows, bit for bit -- against the same pipeline fed map.half().float(), and against the oracle on every 100th row of it
+    del outs, h
+    b16 = p["b_desc"].half().contiguous()
+    res = []
+    for bdesc in (b16, b16.float().contiguous()):
+        pipe = RegistrationPipeline(n, m, d, n_iter=iters, overlap_ransac=True, coarse="mx6-half")
+        o = pipe.register(p["q_desc"], p["q_xyz"], bdesc, p["b_xyz"])
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        res.append({kk: o[kk].clone() for kk in ("T", "idx", "sim", "count", "mask", "corres", "best_hyp")})
+        del pipe, o
+    k16 = int(res[1]["count"].item())
+    assert k16 > 20000 and int(res[0]["count"].item()) == k16
+    for key in ("T", "best_hyp", "idx", "sim"):
+        assert torch.equal(res[0][key], res[1][key]), key
+    for key in ("corres", "mask"):
+        assert torch.equal(res[0][key][:k16], res[1][key][:k16]), key
+    assert np.linalg.norm(res[0]["T"].cpu().numpy() - T_gt) < 0.05
+    rows = torch.arange(0, n, 100, device="cuda")
+    qn16, _ = orc.l2norm_rows(p["q_desc"][rows].cpu().numpy())
+    bn16, _ = orc.l2norm_rows(b16.float().cpu().numpy())
+    idx16, sim16 = orc.match_ip_top1(qn16, bn16)
+    gi, gs = res[0]["idx"][rows].cpu().numpy(), res[0]["sim"][rows].cpu().numpy()
+    solved = gi >= 0
+    assert solved.sum() >= 50
+    np.testing.assert_array_equal(gi[solved], idx16[solved])
+    np.testing.assert_array_equal(gs[solved], sim16[solved])
+    assert (sim16[~solved] < 0.8).all()
 
 
 def test_c3_pipelined_equals_the_stage_by_stage_path_and_the_oracle():

@@ -186,6 +186,7 @@ def test_one_launch_downsample_equals_the_general_path_and_the_oracle():
         # chained: .5 -> 1.0 -> 5.0 on the survivors, as the node does
         pts = rng.uniform(-50, 50, (60000, 3)) * [1, 1, 0.1]
         cur_h, cur_d = pts, torch.from_numpy(pts).cuda()
+        lib.vfm_debug_set_voxel_small(1)
         for vs in (0.5, 1.0, 5.0):
             o = ops.voxel_robin(cur_d, vs)
             r = orc.voxel_robin(cur_h, vs)
@@ -209,9 +210,10 @@ def test_one_launch_downsample_equals_the_general_path_and_the_oracle():
             pts = np.c_[np.array(xs, dtype=np.float64) + 0.5, np.full(n, 0.5), np.full(n, 0.5)]
             pts = pts[rng.permutation(n)]
             ref, rinfo = orc.voxel_robin(pts, 1.0, return_info=True)
+            lib.vfm_debug_set_voxel_small(1)
             one, oinfo = ops.voxel_robin(torch.from_numpy(pts).cuda(), 1.0, return_info=True)
             np.testing.assert_array_equal(one.cpu().numpy(), ref, err_msg=f"trial {trial}")
             wrapped += int(oinfo[3] > 0)
         assert wrapped >= 3, wrapped
     finally:
-        lib.vfm_debug_set_voxel_small(1)
+        lib.vfm_debug_set_voxel_small(0)

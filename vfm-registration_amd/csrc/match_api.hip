@@ -218,6 +218,21 @@ VFM_EXPORT int vfm_match_prepare2_gated_p(const float* x1, int64_t rows1, void* 
     return do_prepare2(x1, rows1, prepared1, x2, rows2, prepared2, d, (hipStream_t)stream, want_f16, schedule);
 }
 
+// the gated pair with the rows' storage type stated (VFM_ROWS_F32 / VFM_ROWS_F16): fp16 rows are widened to fp32 element by element as
+// they are loaded, everything else is the fp32 path
+VFM_EXPORT int vfm_match_prepare2_gated_t(const void* x1, int dtype1, int64_t rows1, void* prepared1, const void* x2, int dtype2,
+                                          int64_t rows2, void* prepared2, int d, int schedule, vfm_stream_t stream) {
+    VFM_CHECK_ARG(rows1 > 0 && rows2 > 0 && d % 128 == 0 && d >= 128 && d <= 768, "prepare2: d must be in {128,256,384,512,640,768}");
+    VFM_CHECK_ARG(x1 && x2 && prepared1 && prepared2, "prepare2: null pointer");
+    VFM_CHECK_ARG((dtype1 == VFM_ROWS_F32 || dtype1 == VFM_ROWS_F16) && (dtype2 == VFM_ROWS_F32 || dtype2 == VFM_ROWS_F16), "prepare2: unknown row type");
+    VFM_CHECK_ARG((schedule & ~(VFM_PREPARE_MX6 | VFM_PREPARE_MX6_HALF)) >= VFM_PREPARE_DEFAULT &&
+                      (schedule & ~(VFM_PREPARE_MX6 | VFM_PREPARE_MX6_HALF)) <= VFM_PREPARE_INTERLEAVED,
+                  "prepare2: unknown schedule %d", schedule);
+    const bool want_f16 = !use_i8(d, rows2, rows1, true);
+    return do_prepare2(Rows(x1, dtype1 == VFM_ROWS_F16), rows1, prepared1, Rows(x2, dtype2 == VFM_ROWS_F16), rows2, prepared2, d,
+                       (hipStream_t)stream, want_f16, schedule);
+}
+
 VFM_EXPORT size_t vfm_match_search_workspace_bytes(int64_t n, int64_t m, int d) {
     (void)d;
     return carve_search(nullptr, n, m).bytes;
@@ -293,6 +308,20 @@ VFM_EXPORT int vfm_match_search_finish_gated_r(const float* q, const void* q_pre
     VFM_CHECK_ARG(gate == gate, "search_finish: gate is NaN");
     VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6_FUSED, "search_finish: unknown record kind %d", records);
     return do_search_finish(q, q_prepared, n, b, b_prepared, m, d, idx_out, sim_out, ws, (hipStream_t)stream, true, gate, records);
+}
+
+VFM_EXPORT int vfm_match_search_finish_gated_t(const void* q, int dtype_q, const void* q_prepared, int64_t n, const void* b, int dtype_b,
+                                               const void* b_prepared, int64_t m, int d, int64_t* idx_out, float* sim_out, void* ws,
+                                               size_t ws_bytes, float gate, int records, vfm_stream_t stream) {
+    if (int rc = check_search_args(n, m, d, ws_bytes)) return rc;
+    VFM_CHECK_ARG(q && b && q_prepared && b_prepared && ws && idx_out && sim_out, "search_finish: null pointer");
+    VFM_CHECK_ARG(gate == gate, "search_finish: gate is NaN");
+    VFM_CHECK_ARG(records >= VFM_RECORDS_BEST && records <= VFM_RECORDS_MX6_FUSED, "search_finish: unknown record kind %d", records);
+    VFM_CHECK_ARG((dtype_q == VFM_ROWS_F32 || dtype_q == VFM_ROWS_F16) && (dtype_b == VFM_ROWS_F32 || dtype_b == VFM_ROWS_F16), "search_finish: unknown row type");
+    VFM_CHECK_ARG((dtype_q == VFM_ROWS_F32 && dtype_b == VFM_ROWS_F32) || (records != VFM_RECORDS_F16 && use_i8(d, n, m, true)),
+                  "search_finish: fp16 rows are taken by the int8 / fp6 searches only");
+    return do_search_finish(Rows(q, dtype_q == VFM_ROWS_F16), q_prepared, n, Rows(b, dtype_b == VFM_ROWS_F16), b_prepared, m, d, idx_out, sim_out,
+                            ws, (hipStream_t)stream, true, gate, records);
 }
 
 VFM_EXPORT int vfm_match_search_rescans_async(const void* ws, int64_t n, int64_t m, int32_t* out_host, vfm_stream_t stream) {

@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(256) void match_rescan_close_kernel(int64_t n, int*
 // refinement run four waves per SIMD instead of two)
 template <int NT>
 struct RefineWave {
-    const float* b;
+    Rows b;
     const float* invb;
     int d, nt, g, l, lane;
     float w2;
@@ -1129,7 +1129,7 @@ struct RefineWave {
     float runmax;    // wave-uniform
     bool overflow;
 
-    __device__ __forceinline__ void init(const float* q, float iq, int64_t qi, const float* b_, const float* invb_, int d_, float w2_,
+    __device__ __forceinline__ void init(Rows q, float iq, int64_t qi, Rows b_, const float* invb_, int d_, float w2_,
                                          unsigned* lrow_, float* lsc_) {
         b = b_; invb = invb_; d = d_; w2 = w2_; lrow = lrow_; lsc = lsc_;
         lane = lane_id();
@@ -1142,7 +1142,7 @@ struct RefineWave {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             if (t < nt) {
-                float4 v = *reinterpret_cast<const float4*>(q + qi * (int64_t)d + 4 * (l + 16 * t));
+                float4 v = q.ld4(qi * (int64_t)d + 4 * (l + 16 * t));
                 v.x = v.x * iq; v.y = v.y * iq; v.z = v.z * iq; v.w = v.w * iq;  // the fp32-normalised query (faiss' xq)
                 qv[t] = v;
             }
@@ -1153,11 +1153,11 @@ struct RefineWave {
         float acc = 0.0f;
         if (row >= 0) {
             const float ib = invb[row];
-            const float* br = b + row * (int64_t)d + 4 * l;
+            const int64_t br = row * (int64_t)d + 4 * l;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (t < nt) {
-                    const float4 bv = *reinterpret_cast<const float4*>(br + 64 * t);
+                    const float4 bv = b.ld4(br + 64 * t);
                     acc = __builtin_fmaf(qv[t].x, bv.x * ib, acc);
                     acc = __builtin_fmaf(qv[t].y, bv.y * ib, acc);
                     acc = __builtin_fmaf(qv[t].z, bv.z * ib, acc);
@@ -1178,10 +1178,10 @@ struct RefineWave {
     __device__ __forceinline__ void load4(Row& r, long long row) const {
         if (row >= 0) {
             r.ib = invb[row];
-            const float* br = b + row * (int64_t)d + 4 * l;
+            const int64_t br = row * (int64_t)d + 4 * l;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                if (t < nt) r.v[t] = *reinterpret_cast<const float4*>(br + 64 * t);
+                if (t < nt) r.v[t] = b.ld4(br + 64 * t);
         }
     }
     __device__ __forceinline__ float dot4(const Row& r, long long row) const {
@@ -1382,8 +1382,8 @@ __global__ __launch_bounds__(256) void match_rescan_kernel(int64_t n, int64_t m,
 
 // dense records: the candidate entries of match_select_kernel (int8 pass: as rewritten by match_rescan_kernel)
 template <int NT>
-__global__ __launch_bounds__(256) void match_refine_kernel(const float* __restrict__ q, const float* __restrict__ invq,
-                                                           const float* __restrict__ b, const float* __restrict__ invb,
+__global__ __launch_bounds__(256) void match_refine_kernel(Rows q, const float* __restrict__ invq,
+                                                           Rows b, const float* __restrict__ invb,
                                                            int64_t n, int64_t m, int d, float w2, int* __restrict__ cand_cnt,
                                                            unsigned* __restrict__ cand, int cap, int* __restrict__ fb_count,
                                                            int* __restrict__ fb_list, int stats, const int* __restrict__ todo,
@@ -1512,8 +1512,8 @@ __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restri
 
 // sparse records (match_coarse_pipe_kernel<., true>): filter the query's records against its FINAL coarse maximum, then
 // refine in fp32 if more than two rows remain.  Replaces match_select_kernel + match_refine_kernel; one wave per query.
-__global__ __launch_bounds__(256) void match_filter_refine_kernel(const float* __restrict__ q, const float* __restrict__ invq,
-                                                                  const float* __restrict__ b, const float* __restrict__ invb,
+__global__ __launch_bounds__(256) void match_filter_refine_kernel(Rows q, const float* __restrict__ invq,
+                                                                  Rows b, const float* __restrict__ invb,
                                                                   int64_t n, int64_t m, int d, float window, float w2,
                                                                   const unsigned* __restrict__ qmax,
                                                                   const unsigned* __restrict__ rec_cnt, const uint2* __restrict__ rec,
@@ -1589,10 +1589,10 @@ __global__ __launch_bounds__(256) void match_filter_refine_kernel(const float* _
 }
 
 // exact score of normalised rows, sequential k, fp64 (products of two fp32 are exact in fp64)
-__device__ __forceinline__ double dot_norm_f64(const float* __restrict__ qrow_n, const float* __restrict__ brow, float invb, int d) {
+__device__ __forceinline__ double dot_norm_f64(const float* __restrict__ qrow_n, Rows b, int64_t brow, float invb, int d) {
     double acc = 0.0;
     for (int k = 0; k < d; k += 4) {
-        const float4 bv = *reinterpret_cast<const float4*>(brow + k);
+        const float4 bv = b.ld4(brow + k);
         const float b0 = bv.x * invb, b1 = bv.y * invb, b2 = bv.z * invb, b3 = bv.w * invb;
         acc = acc + (double)qrow_n[k + 0] * (double)b0;
         acc = acc + (double)qrow_n[k + 1] * (double)b1;
@@ -1614,8 +1614,8 @@ __device__ __forceinline__ double dot_norm_f64(const float* __restrict__ qrow_n,
 constexpr int RS_KC = 96;             // k values per chunk (24 float4 per row)
 constexpr int RS_STRIDE = RS_KC + 1;  // doubles per LDS row: 194 words == 2 (mod 64) -> conflict-free ds_read_b64
 constexpr int RS_PAIRS = 1024;        // pair slots per epoch (a block has ~80 pairs; more run in further epochs)
-__global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restrict__ q, const float* __restrict__ invq,
-                                                            const float* __restrict__ b, const float* __restrict__ invb,
+__global__ __launch_bounds__(256) void match_rescore_kernel(Rows q, const float* __restrict__ invq,
+                                                            Rows b, const float* __restrict__ invb,
                                                             int64_t n, int64_t m, int d, const int* __restrict__ cand_cnt,
                                                             const unsigned* __restrict__ cand, int cap,
                                                             int64_t* __restrict__ idx_out, float* __restrict__ sim_out, float min_sim) {
@@ -1707,8 +1707,8 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restr
                     const int sl = 16 * wave + 2 * it + sub;
                     const long long jj = s_j[sl];
                     if (jj >= 0 && 4 * l4 < kn) {
-                        qv[it] = *reinterpret_cast<const float4*>(q + (q0 + s_ql[sl]) * (int64_t)d + k0 + 4 * l4);
-                        bv[it] = *reinterpret_cast<const float4*>(b + jj * (int64_t)d + k0 + 4 * l4);
+                        qv[it] = q.ld4((q0 + s_ql[sl]) * (int64_t)d + k0 + 4 * l4);
+                        bv[it] = b.ld4(jj * (int64_t)d + k0 + 4 * l4);
                     }
                 }
             };
@@ -1769,7 +1769,7 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restr
             const int cq = __shfl(cnt, ql);
             __builtin_amdgcn_wave_barrier();
             for (int k = lane * 4; k < d; k += 256) {
-                float4 v = *reinterpret_cast<const float4*>(q + qq * (int64_t)d + k);
+                float4 v = q.ld4(qq * (int64_t)d + k);
                 v.x = v.x * iqq; v.y = v.y * iqq; v.z = v.z * iqq; v.w = v.w * iqq;
                 *reinterpret_cast<float4*>(qn + k) = v;
             }
@@ -1783,7 +1783,7 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restr
                 for (int li = lane; li < CHUNK_ROWS; li += 64) {
                     const long long j = base + li;
                     if (j < m) {
-                        const double sc = dot_norm_f64(qn, b + j * (int64_t)d, invb[j], d);
+                        const double sc = dot_norm_f64(qn, b, j * (int64_t)d, invb[j], d);
                         if (rj < 0 || sc > rbest || (sc == rbest && j < rj)) {
                             rbest = sc;
                             rj = j;
@@ -1815,8 +1815,8 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float* __restr
 }
 
 // all-pairs exact decision for the queries in `list` (or all queries if list == NULL)
-__global__ __launch_bounds__(256) void match_exact_kernel(const float* __restrict__ q, const float* __restrict__ invq,
-                                                          const float* __restrict__ b, const float* __restrict__ invb,
+__global__ __launch_bounds__(256) void match_exact_kernel(Rows q, const float* __restrict__ invq,
+                                                          Rows b, const float* __restrict__ invb,
                                                           int64_t n, int64_t m, int d, const int* __restrict__ list,
                                                           const int* __restrict__ list_count,
                                                           int64_t* __restrict__ idx_out, float* __restrict__ sim_out) {
@@ -1829,12 +1829,12 @@ __global__ __launch_bounds__(256) void match_exact_kernel(const float* __restric
         const int64_t qi = list ? (int64_t)list[e] : e;
         const float iq = invq ? invq[qi] : 1.0f;
         __syncthreads();
-        for (int k = threadIdx.x; k < d; k += 256) qn[k] = q[qi * (int64_t)d + k] * iq;
+        for (int k = threadIdx.x; k < d; k += 256) qn[k] = q.ld1(qi * (int64_t)d + k) * iq;
         __syncthreads();
         double best = 0.0;
         long long bj = -1;
         for (long long j = threadIdx.x; j < m; j += 256) {
-            const double s = dot_norm_f64(qn, b + j * (int64_t)d, invb ? invb[j] : 1.0f, d);
+            const double s = dot_norm_f64(qn, b, j * (int64_t)d, invb ? invb[j] : 1.0f, d);
             if (bj < 0 || s > best) {
                 best = s;
                 bj = j;
@@ -1953,7 +1953,7 @@ __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__
 // stage 2 of a search: candidate selection + exact fp64 decision (reads ws of stage 1)
 // gated: the search was started by the gated family (do_search_coarse(..., gated)); gate: queries whose best similarity is
 // provably below it are reported as (-1, -2.0) instead of being resolved (int8 pass only; -Inf = resolve every query)
-int do_search_finish(const float* q, const void* qprep, int64_t n, const float* b, const void* bprep, int64_t m, int d,
+int do_search_finish(Rows q, const void* qprep, int64_t n, Rows b, const void* bprep, int64_t m, int d,
                      int64_t* idx_out, float* sim_out, void* ws, hipStream_t st, bool gated, float gate, int records) {
     Prepared Q = carve_prepared(const_cast<void*>(qprep), n, d);
     Prepared B = carve_prepared(const_cast<void*>(bprep), m, d);

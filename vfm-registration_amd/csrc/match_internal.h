@@ -539,6 +539,45 @@ inline void attr_mark(unsigned long long& mask) {
     mask |= 1ull << (dev & 63);
 }
 
+// Descriptor rows as the caller stores them (round 5, BASELINE.json configs[4] "fp16 descriptor storage"): fp32 -- the reference's layout
+// behind VoxelHashMap.cpp:469-482 -- or fp16 (VFM_ROWS_F16: half the bytes of a resident map and of the preparation's read), every
+// element widened to fp32 as it is loaded; from there on the arithmetic is the fp32 path's, operation for operation -- the oracle of an
+// fp16 operand is the oracle of its widened rows.  A `const float*` converts implicitly (f16 = 0).
+struct Rows {
+    const void* p;
+    int f16;
+    __host__ __device__ Rows() : p(nullptr), f16(0) {}
+    __host__ __device__ Rows(const float* x) : p(x), f16(0) {}
+    __host__ __device__ Rows(const void* x, int is_f16) : p(x), f16(is_f16) {}
+#if defined(__HIPCC__)
+    typedef _Float16 rows_half4 __attribute__((ext_vector_type(4)));
+    // four consecutive elements from element index e (a multiple of 4)
+    __device__ __forceinline__ float4 ld4(int64_t e) const {
+        if (f16) {
+            const rows_half4 h = *reinterpret_cast<const rows_half4*>(static_cast<const _Float16*>(p) + e);
+            return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        }
+        return *reinterpret_cast<const float4*>(static_cast<const float*>(p) + e);
+    }
+    // the same, streamed (read-once rows of the preparation: do not displace the coarse pass' map slice from the L2)
+    __device__ __forceinline__ float4 ld4_nt(int64_t e) const {
+        if (f16) {
+            const unsigned* pc = reinterpret_cast<const unsigned*>(static_cast<const _Float16*>(p) + e);
+            unsigned w[2] = {__builtin_nontemporal_load(pc), __builtin_nontemporal_load(pc + 1)};
+            rows_half4 h;
+            __builtin_memcpy(&h, w, 8);
+            return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        }
+        const float* pc = static_cast<const float*>(p) + e;
+        return make_float4(__builtin_nontemporal_load(pc), __builtin_nontemporal_load(pc + 1), __builtin_nontemporal_load(pc + 2),
+                           __builtin_nontemporal_load(pc + 3));
+    }
+    __device__ __forceinline__ float ld1(int64_t e) const {
+        return f16 ? (float)static_cast<const _Float16*>(p)[e] : static_cast<const float*>(p)[e];
+    }
+#endif
+};
+
 // experiment knobs and profiling hook (match_api.hip)
 extern int g_force_slices, g_coarse_qsets, g_seed_units, g_match_stats, g_i8_min_queries, g_select_variant;
 extern int g_rescan_rows;    // vfm_debug_set_coarse_variant(60 / 61): chunk-major rescan gathers its queries from the fragment tiles / from the row-major int8 scan (default)
@@ -563,7 +602,7 @@ inline I8Bounds mx6_bounds_half(const Prepared& Q, const Prepared& B) { return I
 CoarseArgs coarse_args(const Prepared& Q, const Prepared& B, const SearchWs& w, int64_t n, int64_t m, int qblock = QBLOCK);
 
 // match_prep.hip
-int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2, int64_t rows2, void* prepared2, int d,
+int do_prepare2(Rows x1, int64_t rows1, void* prepared1, Rows x2, int64_t rows2, void* prepared2, int d,
                 hipStream_t st, bool want_f16 = true, int grid_mode = 0 /* VFM_PREPARE_DEFAULT */);
 int do_prepare(const float* x, int64_t rows, int d, void* prepared, hipStream_t st);
 // int8 image alone of ONE operand whose row r is x[perm[r]] (perm == NULL: identity) -- the Euclidean search prepares its map
@@ -579,7 +618,7 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
                      bool bias_from_map_inv = false, bool inner_product = false, bool gated = false, int records = 0,
                      float gate = -__builtin_inff());
 // match_finish.hip
-int do_search_finish(const float* q, const void* qprep, int64_t n, const float* b, const void* bprep, int64_t m, int d,
+int do_search_finish(Rows q, const void* qprep, int64_t n, Rows b, const void* bprep, int64_t m, int d,
                      int64_t* idx_out, float* sim_out, void* ws, hipStream_t st, bool gated = false,
                      float gate = -__builtin_inff(), int records = 0);
 int launch_select_dense(const SearchWs& w, const CoarseArgs& a, const float* qinv, int64_t n, hipStream_t st);

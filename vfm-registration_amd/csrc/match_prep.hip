@@ -123,8 +123,8 @@ typedef unsigned short ushortx2 __attribute__((ext_vector_type(2)));
 // WAVES = 8 (the MX6 form): 8 waves x 16 rows -- half the threads, twice the registers each: room for the conversion AND for the
 // next group's rows, which the 16-wave form had to read after it (128 registers: 49 spilled, the loads exposed; 0.21 ms)
 template <bool F16, int NC = 2, bool MX6 = false, int WAVES = 16>
-__global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __restrict__ x1, int64_t rows1, int d, PrepOut o1, int groups1,
-                                                          const float* __restrict__ x2, int64_t rows2, PrepOut o2, int groups) {
+__global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(Rows x1, int64_t rows1, int d, PrepOut o1, int groups1,
+                                                          Rows x2, int64_t rows2, PrepOut o2, int groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned amax_bits, emax_bits, rmax_bits, e6max_bits, e6hmax_bits;
     static_assert(!(F16 && MX6), "the fp6 image is made from the LDS copy of the fp16 one, which then is not stored");
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
     float4 v[RPW][NC];
     auto load_row = [&](int grp, int j) __attribute__((always_inline)) {
         const bool second = grp >= groups1;
-        const float* x = second ? x2 : x1;
+        const Rows x = second ? x2 : x1;
         const int64_t rows = second ? rows2 : rows1;
         const int64_t r = (int64_t)(second ? grp - groups1 : grp) * I8_GROUP + wave * RPW + j;
         const int* perm = second ? o2.perm : o1.perm;
@@ -167,11 +167,7 @@ __global__ __launch_bounds__(WAVES * 64) void prep_chunk_kernel(const float* __r
 #else
             if (r < rows && c < nchunks) {
 #endif
-                const float* pc = x + rsrc * (int64_t)d + 4 * c;
-                t.x = __builtin_nontemporal_load(pc);
-                t.y = __builtin_nontemporal_load(pc + 1);
-                t.z = __builtin_nontemporal_load(pc + 2);
-                t.w = __builtin_nontemporal_load(pc + 3);
+                t = x.ld4_nt(rsrc * (int64_t)d + 4 * c);   // (fp16 rows: widened here, VFM_ROWS_F16)
             }
             v[j][i] = t;
         }
@@ -836,8 +832,8 @@ __global__ __launch_bounds__(256, 3) void prep_stream_kernel(const float* __rest
 // read).  prep_mx6_group_kernel then takes the maximum E of every group.
 // ---------------------------------------------------------------------------------------------
 template <int NBLK>   // lanes per row: 16 (d = 512) or 32 (d = 768: 24 in use)
-__global__ __launch_bounds__(256) void prep_mx6_rows_kernel(const float* __restrict__ x1, int64_t rows1, int64_t pad1, int d, PrepOut o1,
-                                                            const float* __restrict__ x2, int64_t rows2, PrepOut o2, int64_t total) {
+__global__ __launch_bounds__(256) void prep_mx6_rows_kernel(Rows x1, int64_t rows1, int64_t pad1, int d, PrepOut o1,
+                                                            Rows x2, int64_t rows2, PrepOut o2, int64_t total) {
     constexpr int RPB = 256 / NBLK;   // rows per workgroup
     const int blk = threadIdx.x % NBLK;
     int64_t g = (int64_t)blockIdx.x * RPB + threadIdx.x / NBLK;   // row of the padded concatenation
@@ -863,11 +859,7 @@ __global__ __launch_bounds__(256) void prep_mx6_rows_kernel(const float* __restr
         const int64_t r2 = sec ? gg - pad1 : gg;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gg < total && r2 < (sec ? rows2 : rows1)) {
-            const float* pc = (sec ? x2 : x1) + r2 * (int64_t)d + 4 * c4;
-            t.x = __builtin_nontemporal_load(pc);
-            t.y = __builtin_nontemporal_load(pc + 1);
-            t.z = __builtin_nontemporal_load(pc + 2);
-            t.w = __builtin_nontemporal_load(pc + 3);
+            t = (sec ? x2 : x1).ld4_nt(r2 * (int64_t)d + 4 * c4);
         }
         const int bb = c4 >> 3, jj = c4 & 7;
         stage[rr * nf4 + bb * 8 + (jj ^ (bb & 7))] = t;
@@ -1006,8 +998,15 @@ inline int prep_grid(int groups, int mode) {
 
 // one or two operands (x2 may be NULL) in one launch.  want_f16 = false: only the int8 image (d = 256, 384), for operands that
 // will meet in an int8 search (use_i8): a third of the bytes written, a third of the LDS.
-int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2, int64_t rows2, void* prepared2, int d,
+int do_prepare2(Rows x1r, int64_t rows1, void* prepared1, Rows x2r, int64_t rows2, void* prepared2, int d,
                 hipStream_t st, bool want_f16, int grid_mode) {
+    // fp16 rows (VFM_ROWS_F16): the kernels that widen on load are prep_chunk_kernel and prep_mx6_rows_kernel -- the int8 and fp6
+    // images of the gated family; the fp16-tile image (ungated fp16 pass) and the streamed fp6 form read fp32 rows only
+    const bool any_f16 = x1r.f16 || (x2r.p && x2r.f16);
+    if (any_f16 && (want_f16 || !i8_capable(d)))
+        return vfm_fail(VFM_EINVAL, "prepare: fp16 rows are taken by the gated int8 / fp6 searches (d in {256 .. 768}, more queries than the fp16 pass' limit)");
+    const float* x1 = static_cast<const float*>(x1r.p);   // (read as fp32 only where !any_f16)
+    const float* x2 = static_cast<const float*>(x2r.p);
     const int h6 = (grid_mode & VFM_PREPARE_MX6_HALF) != 0 ? 1 : 0;   // the fp6 image of the first d / 2 columns only (implies VFM_PREPARE_MX6)
     if (h6) grid_mode |= VFM_PREPARE_MX6;
     const bool want_mx6 = (grid_mode & VFM_PREPARE_MX6) != 0 && mx6_width(d);              // int8 + fp6 image from one kernel
@@ -1034,27 +1033,27 @@ int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2
         int pg = prep_grid(groups, grid_mode);
         const dim3 grid((unsigned)pg), block(1024);
         if (want_mx6) {   // int8 + fp6 images from one read of the rows; the fp16 image, if wanted, by its own kernel
-            if (g_prep_stream && (d == 384 || d == 256)) {   // the form that fits beside a coarse workgroup (prep_stream_kernel)
+            if (g_prep_stream && (d == 384 || d == 256) && !any_f16) {   // the form that fits beside a coarse workgroup (prep_stream_kernel)
                 const dim3 sg((unsigned)groups), sb(256);
                 if (d == 384 && h6) hipLaunchKernelGGL((prep_stream_kernel<384, true>), sg, sb, 0, st, x1, rows1, prep_out(p1, nullptr, h6), g1, x2, rows2, prep_out(p2, nullptr, h6), groups);
                 else if (d == 384) hipLaunchKernelGGL((prep_stream_kernel<384, false>), sg, sb, 0, st, x1, rows1, prep_out(p1, nullptr, h6), g1, x2, rows2, prep_out(p2, nullptr, h6), groups);
                 else if (h6) hipLaunchKernelGGL((prep_stream_kernel<256, true>), sg, sb, 0, st, x1, rows1, prep_out(p1, nullptr, h6), g1, x2, rows2, prep_out(p2, nullptr, h6), groups);
                 else hipLaunchKernelGGL((prep_stream_kernel<256, false>), sg, sb, 0, st, x1, rows1, prep_out(p1, nullptr, h6), g1, x2, rows2, prep_out(p2, nullptr, h6), groups);
             } else
-            hipLaunchKernelGGL((prep_chunk_kernel<false, 2, true, 8>), grid, dim3(512), (size_t)I8_GROUP * (d * 3 + d / 8 + 16), st, x1, rows1, d,
-                               prep_out(p1, nullptr, h6), g1, x2, rows2, prep_out(p2, nullptr, h6), groups);
+            hipLaunchKernelGGL((prep_chunk_kernel<false, 2, true, 8>), grid, dim3(512), (size_t)I8_GROUP * (d * 3 + d / 8 + 16), st, x1r, rows1, d,
+                               prep_out(p1, nullptr, h6), g1, x2r, rows2, prep_out(p2, nullptr, h6), groups);
             if (want_f16)
                 hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)(t1 + t2)), dim3(256), (size_t)d * 64, st, x1, rows1, d, p1.inv,
                                    p1.tiles, t1, x2, rows2, p2.inv, p2.tiles);
         } else if (want_f16 && d <= 384) {  // both images from one read of the rows (144 KB of LDS at d = 384)
-            hipLaunchKernelGGL((prep_chunk_kernel<true, 2>), grid, block, (size_t)I8_GROUP * d * 3, st, x1, rows1, d, prep_out(p1), g1, x2,
+            hipLaunchKernelGGL((prep_chunk_kernel<true, 2>), grid, block, (size_t)I8_GROUP * d * 3, st, x1r, rows1, d, prep_out(p1), g1, x2r,
                                rows2, prep_out(p2), groups);
         } else {
             if (d <= 512)
-                hipLaunchKernelGGL((prep_chunk_kernel<false, 2>), grid, block, (size_t)I8_GROUP * d, st, x1, rows1, d, prep_out(p1), g1, x2,
+                hipLaunchKernelGGL((prep_chunk_kernel<false, 2>), grid, block, (size_t)I8_GROUP * d, st, x1r, rows1, d, prep_out(p1), g1, x2r,
                                    rows2, prep_out(p2), groups);
             else
-                hipLaunchKernelGGL((prep_chunk_kernel<false, 3>), grid, block, (size_t)I8_GROUP * d, st, x1, rows1, d, prep_out(p1), g1, x2,
+                hipLaunchKernelGGL((prep_chunk_kernel<false, 3>), grid, block, (size_t)I8_GROUP * d, st, x1r, rows1, d, prep_out(p1), g1, x2r,
                                    rows2, prep_out(p2), groups);
             if (want_f16) {  // wider rows: the fp16 image by its own kernel (both images would not fit the LDS)
                 hipLaunchKernelGGL(prep_rows_kernel, dim3((unsigned)(t1 + t2)), dim3(256), (size_t)d * 64, st, x1, rows1, d, p1.inv,
@@ -1065,11 +1064,11 @@ int do_prepare2(const float* x1, int64_t rows1, void* prepared1, const float* x2
         if (want_mx6_wide) {
             const int64_t pad1 = rows_padded(rows1), total = pad1 + (x2 ? rows_padded(rows2) : 0);
             if (d == 512)
-                hipLaunchKernelGGL((prep_mx6_rows_kernel<16>), dim3((unsigned)((total + 15) / 16)), dim3(256), (size_t)16 * d * 4, st, x1, rows1, pad1, d,
-                                   prep_out(p1, nullptr, h6), x2, rows2, prep_out(p2, nullptr, h6), total);
+                hipLaunchKernelGGL((prep_mx6_rows_kernel<16>), dim3((unsigned)((total + 15) / 16)), dim3(256), (size_t)16 * d * 4, st, x1r, rows1, pad1, d,
+                                   prep_out(p1, nullptr, h6), x2r, rows2, prep_out(p2, nullptr, h6), total);
             else
-                hipLaunchKernelGGL((prep_mx6_rows_kernel<32>), dim3((unsigned)((total + 7) / 8)), dim3(256), (size_t)8 * d * 4, st, x1, rows1, pad1, d,
-                                   prep_out(p1, nullptr, h6), x2, rows2, prep_out(p2, nullptr, h6), total);
+                hipLaunchKernelGGL((prep_mx6_rows_kernel<32>), dim3((unsigned)((total + 7) / 8)), dim3(256), (size_t)8 * d * 4, st, x1r, rows1, pad1, d,
+                                   prep_out(p1, nullptr, h6), x2r, rows2, prep_out(p2, nullptr, h6), total);
             hipLaunchKernelGGL(prep_mx6_group_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, st, prep_out(p1, nullptr, h6), g1,
                                prep_out(p2, nullptr, h6), groups);
             VFM_CHECK_LAUNCH("prep_mx6_rows_kernel");

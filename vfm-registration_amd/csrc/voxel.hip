@@ -349,7 +349,12 @@ __global__ __launch_bounds__(256) void robin_pointkey_kernel(const int64_t* __re
 //   F  iteration order -> kept point indices.
 // A cluster longer than SMALLW_MAX_CLUSTER raises `fail`: the caller takes the general path.  Same container order, bit for bit
 // (tests/test_gpu_voxel.py runs both paths against the oracle's robin-map replay).
-int g_voxel_small = 1;   // vfm_debug_set_voxel_small(0 / 1): the general path always / the one-launch kernel where it applies (default)
+// MEASURED AND NOT ADOPTED (profiles/r05_time_api_onelaunch.txt): the part one workgroup runs alone is a chain of ~10 phases, each a
+// loop of n / 1024 .. B / 1024 dependent-latency iterations plus block scans of 20 barriers -- 0.5 ms at 20 000 points, 1.2 ms at
+// 60 000, against 0.23 / 0.25 ms for the ~28 short full-width launches of the general path (the reference-shaped call went from 1.7 to
+// 2.5 ms, from 2.2 to 5.6 ms at a 60 000-point scan).  Launch latency is cheaper than one compute unit's memory latency; the kernel
+// stays behind vfm_debug_set_voxel_small(1) with its test.
+int g_voxel_small = 0;   // vfm_debug_set_voxel_small(0 / 1): the general path always (default: measured faster, see below) / the one-launch kernel where it applies
 constexpr int SMALLW_THREADS = 1024;
 constexpr int SMALLW_MAX_CLUSTER = 192;
 constexpr int64_t SMALLW_MAX_N = 1 << 18;   // points (B <= 2^19 buckets)

@@ -42,6 +42,9 @@ SIGNATURES = {
     "vfm_match_prepare2": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, C.c_int, c_vp]),
     "vfm_match_prepare2_gated": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, C.c_int, c_vp]),
     "vfm_match_prepare2_gated_p": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, C.c_int, C.c_int, c_vp]),
+    "vfm_match_prepare2_gated_t": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, C.c_int, c_i64, c_vp, C.c_int, C.c_int, c_vp]),
+    "vfm_match_search_finish_gated_t": (C.c_int, [c_vp, C.c_int, c_vp, c_i64, c_vp, C.c_int, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp,
+                                                  C.c_size_t, C.c_float, C.c_int, c_vp]),
     "vfm_match_search_workspace_bytes": (C.c_size_t, [c_i64, c_i64, C.c_int]),
     "vfm_match_search_prepared": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, c_vp, c_vp, c_vp,
                                             C.c_size_t, c_vp]),

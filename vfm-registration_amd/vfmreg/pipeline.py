@@ -343,12 +343,18 @@ class RegistrationPipeline:
         reads an input; with ``overlap_prepare`` it also spares the prepare stage from queueing behind the coarse pass of the
         previous pair on the caller's stream (without the event, it conservatively does)."""
         lib = _lib.load()
-        ops._chk(q_desc, torch.float32, "q_desc")
-        ops._chk(b_desc, torch.float32, "b_desc")
+        # descriptor rows: float32 (the reference's layout behind VoxelHashMap.cpp:469-482) or float16 storage (round 5, BASELINE.json
+        # configs[4]: half the bytes of a resident map; every element is widened to fp32 as the kernels load it -- the result is that
+        # of the widened rows, include/vfmreg.h VFM_ROWS_F16).  fp16 rows go through the gated int8 / fp6 passes only.
+        f16q, f16b = q_desc.dtype == torch.float16, b_desc.dtype == torch.float16
+        ops._chk(q_desc, torch.float16 if f16q else torch.float32, "q_desc")
+        ops._chk(b_desc, torch.float16 if f16b else torch.float32, "b_desc")
         ops._chk(q_xyz, torch.float64, "q_xyz")
         ops._chk(b_xyz, torch.float64, "b_xyz")
         if q_desc.shape != (self.n, self.d) or b_desc.shape != (self.m, self.d):
             raise ValueError("Invalid shape")
+        if (f16q or f16b) and (reuse_map or not self.use_i8 or self._map_prepared):
+            raise ValueError("float16 descriptor rows: the int8 / fp6 passes with map and scan prepared together (no reuse_map, no fp16 pass)")
         if reuse_map:
             # a reused map is prepared once (vfm_match_prepare2 / vfm_match_prepare below): it carries the fp16 and int8 images, not
             # the fp6 one -- its err6 would be read as infinite and an fp6 search would prune nothing.  Same rule as prepare_map().
@@ -417,8 +423,12 @@ class RegistrationPipeline:
                     # VFM_PREPARE_MX6_HALF: the half-width pass reads the first d / 2 columns of the fp6 image -- only those are
                     # converted, and no int8 half-width image is written (the probe that needs it runs outside this mode)
                     schedule |= 8 | 16
-                _lib.check(lib.vfm_match_prepare2_gated_p(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
-                                                          r.qprep.data_ptr(), self.d, schedule, pst), "prepare(map + scan)")
+                if f16q or f16b:
+                    _lib.check(lib.vfm_match_prepare2_gated_t(b_desc.data_ptr(), int(f16b), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), int(f16q),
+                                                              self.n, r.qprep.data_ptr(), self.d, schedule, pst), "prepare(map + scan)")
+                else:
+                    _lib.check(lib.vfm_match_prepare2_gated_p(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
+                                                              r.qprep.data_ptr(), self.d, schedule, pst), "prepare(map + scan)")
             else:
                 _lib.check(lib.vfm_match_prepare2(b_desc.data_ptr(), self.m, r.bprep.data_ptr(), q_desc.data_ptr(), self.n,
                                                   r.qprep.data_ptr(), self.d, pst), "prepare(map + scan)")
@@ -450,10 +460,15 @@ class RegistrationPipeline:
             solve.wait_event(ev)
             rst = solve.cuda_stream
         # only matches with cosine >= min_cosine are kept below: queries that provably cannot reach it stay unresolved (gate)
-        if i8:
+        if i8 and (f16q or f16b):
+            _lib.check(lib.vfm_match_search_finish_gated_t(q_desc.data_ptr(), int(f16q), r.qprep.data_ptr(), self.n, b_desc.data_ptr(), int(f16b),
+                                                           r.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(), r.sim.data_ptr(),
+                                                           r.sws.data_ptr(), r.sws.numel(), gate, records, rst), "search(finish)")
+        if i8 and not (f16q or f16b):
             _lib.check(lib.vfm_match_search_finish_gated_r(q_desc.data_ptr(), r.qprep.data_ptr(), self.n, b_desc.data_ptr(),
                                                            r.bprep.data_ptr(), self.m, self.d, r.idx.data_ptr(), r.sim.data_ptr(),
                                                            r.sws.data_ptr(), r.sws.numel(), gate, records, rst), "search(finish)")
+        if i8:
             if self.coarse == "auto" and len(self._pending) < 8:  # feedback: candidate chunks this search rescans
                 slot = self._slots.pop() if self._slots else torch.zeros(1, dtype=torch.int32).pin_memory()
                 _lib.check(lib.vfm_match_search_rescans_async(r.sws.data_ptr(), self.n, self.m, slot.data_ptr(), rst), "rescans")
