@@ -22,8 +22,8 @@ def _search(q, b, gate, records, flags):
     n, d = q.shape
     m = b.shape[0]
     fq, fb = int(q.dtype == torch.float16), int(b.dtype == torch.float16)
-    qb = torch.empty(lib.vfm_match_prepared_bytes(n, d), dtype=torch.uint8, device="cuda")
-    bb = torch.empty(lib.vfm_match_prepared_bytes(m, d), dtype=torch.uint8, device="cuda")
+    qb = torch.zeros(lib.vfm_match_prepared_bytes(n, d), dtype=torch.uint8, device="cuda")   # (zeroed: the buffers are compared byte for byte)
+    bb = torch.zeros(lib.vfm_match_prepared_bytes(m, d), dtype=torch.uint8, device="cuda")
     ws = torch.empty(lib.vfm_match_search_workspace_bytes(n, m, d), dtype=torch.uint8, device="cuda")
     idx = torch.empty(n, dtype=torch.int64, device="cuda")
     sim = torch.empty(n, dtype=torch.float32, device="cuda")
