@@ -383,6 +383,34 @@ def extra_configs(dev):
         lib.vfm_prof_events_destroy(a, b)
         out["C5"]["int8_half_width"] = {"ms_coarse_kernel": sorted(ts)[len(ts) // 2],
                                         "ms_registration": timed(lambda: pipe5.register(p5["q_desc"], p5["q_xyz"], p5["b_desc"], p5["b_xyz"]), reps=3)}
+    # BASELINE.json configs[4] "fp16 descriptor storage": the same registration with the map held in fp16 (include/vfmreg.h VFM_ROWS_F16: rows
+    # widened to fp32 as the kernels load them; tests/test_gpu_f16rows.py, test_c5_solve_at_full_size: the result of the widened rows, bit
+    # for bit); the pair with fp32 storage is the line above
+    try:
+        del pipe5
+        b16 = p5["b_desc"].half().contiguous()
+        bw = b16.float().contiguous()
+        pipe5 = RegistrationPipeline(n5, m5, d5, n_iter=RANSAC_ITERS, device=dev)
+        for _ in range(3):
+            pipe5.register(p5["q_desc"], p5["q_xyz"], b16, p5["b_xyz"])
+            pipe5.synchronize()
+            torch.cuda.synchronize()
+            pipe5._poll_feedback()
+        t16 = timed(lambda: pipe5.register(p5["q_desc"], p5["q_xyz"], b16, p5["b_xyz"]), reps=3)
+        r16 = pipe5.register(p5["q_desc"], p5["q_xyz"], b16, p5["b_xyz"])
+        torch.cuda.synchronize()
+        T16 = r16["T"].clone()
+        tw = timed(lambda: pipe5.register(p5["q_desc"], p5["q_xyz"], bw, p5["b_xyz"]), reps=3)
+        rw = pipe5.register(p5["q_desc"], p5["q_xyz"], bw, p5["b_xyz"])
+        torch.cuda.synchronize()
+        out["C5"]["fp16_descriptor_storage"] = {
+            "ms_registration": t16, "ms_registration_same_rows_stored_as_fp32": tw, "map_bytes": int(b16.numel() * 2), "map_bytes_fp32": int(bw.numel() * 4),
+            "coarse_pass": pass_name(pipe5), "correspondences": int(r16["count"].item()),
+            "pose_err_vs_planted": float(np.linalg.norm(T16.cpu().numpy() - p5["T_gt"])),
+            "pose_equals_the_widened_rows_registration": bool(torch.equal(T16, rw["T"]))}
+        del b16, bw
+    except Exception as e:
+        out["C5"]["fp16_descriptor_storage"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

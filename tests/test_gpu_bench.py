@@ -77,6 +77,9 @@ def test_bench_under_torch_distributed_run_world1():
     assert ex["C3"]["ms_end_to_end"] > ex["C3"]["ms_vit"] > 0 and 0 < ex["C3"]["vit_roofline"]["frac"] < 1
     assert ex["C3_pipelined"]["value"] > 100 and ex["C3_pipelined"]["grouped"]["value"] > 100 and ex["C3_pipelined"]["grouped"]["pairs_per_vit_call"] == 4
     assert ex["C5"]["pose_err_vs_planted"] < 0.05 and 0.05 < ex["C5"]["roofline"]["frac"] < 1
+    f16 = ex["C5"]["fp16_descriptor_storage"]   # configs[4]: the map stored in fp16 -- half the bytes, the registration of the widened rows
+    assert "error" not in f16 and f16["pose_equals_the_widened_rows_registration"] and f16["map_bytes"] * 2 == f16["map_bytes_fp32"]
+    assert f16["pose_err_vs_planted"] < 0.05 and 0 < f16["ms_registration"] < 40
     # every stage alone on the GPU with its algorithmic work and the fraction of the peak that bounds it
     stg = ex["stages"]
     assert "error" not in stg and "error_c3_rows" not in stg, stg
