@@ -75,6 +75,9 @@ int vfm_debug_mx6_rows(const void *prepared, int64_t rows, int d, float *v6_host
 int vfm_debug_mx6_half_err(const void *prepared, int64_t rows, int d, float *errh_host, float *gerrh_host);
 /* A/B: the gated family takes the int8 pass for more than this many query rows (default 0: always) */
 int vfm_debug_set_i8_min_queries(int n);
+/* tests / bench: what the last vfm_ransac_corr in `ws` (same c_max, n_iter) did: out_host[0] = hypotheses scored in fp64 from the candidate
+ * list, [1] = the list overflowed (every hypothesis scored in fp64), [2] = the point-wise fp32 pass was needed.  Synchronises. */
+int vfm_debug_ransac_counts(const void *ws, int64_t c_max, int32_t n_iter, int32_t *out_host);
 /* A/B: 1 = RANSAC scores every hypothesis in fp64 (skips the bounds) */
 int vfm_debug_set_ransac_exact_only(int on);
 

@@ -420,7 +420,7 @@ def test_half_width_probe_counts_the_survivors_and_prepare_schedules_write_the_s
     matched = int((p["match"] >= 0).sum())
     assert int(probe.item()) == counts[3] == counts[4] and matched <= counts[3] <= matched + n // 20
     assert int((sim >= 0.8).sum()) == matched
-    assert lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), 10, gate, st) != 0
+    assert lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), 11, gate, st) != 0   # (10 = VFM_RECORDS_MX6_FUSED since round 5)
     with pytest.raises(RuntimeError, match="finite gate"):
         _lib.check(lib.vfm_match_search_probe_half(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), float("-inf"),
                                                    probe.data_ptr(), st))

@@ -990,6 +990,20 @@ VFM_EXPORT int vfm_debug_set_ransac_exact_only(int on) {
     return VFM_OK;
 }
 
+// tests / bench: what the last vfm_ransac_corr in `ws` did -- out_host[0] = hypotheses scored in the oracle's fp64 arithmetic from the
+// candidate list, [1] = 1 if the list overflowed (then every hypothesis was scored in fp64), [2] = 1 if the point-wise fp32 pass was
+// needed (some hypothesis not provably all-inlier).  Synchronises the device.
+VFM_EXPORT int vfm_debug_ransac_counts(const void* ws, int64_t c_max, int32_t n_iter, int32_t* out_host) {
+    VFM_CHECK_ARG(ws && out_host && c_max >= 0 && n_iter > 0, "ransac_counts: bad arguments");
+    RansacWs w = carve_ransac(const_cast<void*>(ws), c_max, n_iter);
+    SelectState h;
+    VFM_CHECK_HIP(hipMemcpy(&h, w.sel, sizeof(h), hipMemcpyDeviceToHost));
+    out_host[0] = h.count < CAND_MAX ? h.count : CAND_MAX;
+    out_host[1] = h.overflow;
+    out_host[2] = h.unsure;
+    return VFM_OK;
+}
+
 VFM_EXPORT size_t vfm_ransac_workspace_bytes(int64_t c_max, int32_t n_iter) { return carve_ransac(nullptr, c_max, n_iter).bytes; }
 
 VFM_EXPORT int vfm_ransac_corr(const double* src, const double* tgt, const int32_t* corres, const int64_t* count_dev,

@@ -111,6 +111,7 @@ DEBUG_SIGNATURES = {
     "vfm_debug_set_coarse_variant": (C.c_int, [C.c_int]),
     "vfm_debug_set_coarse_slices": (C.c_int, [C.c_int]),
     "vfm_debug_set_ransac_exact_only": (C.c_int, [C.c_int]),
+    "vfm_debug_ransac_counts": (C.c_int, [c_vp, c_i64, C.c_int, c_vp]),
 }
 
 
