@@ -53,7 +53,8 @@ int vfm_debug_set_match_stats(int on);
  * -9: the token-stationary QKV / fc1 kernel from wide_cfg groups of 128 token rows on (0 = default: where its rounds of one workgroup per
  * compute unit are at least three quarters full; -1 = never); -10: its waves per workgroup (6, 8, 12 = default; 112 = 12 with non-temporal
  * output stores); -11 / -12: low / high 32 bits of a device pointer to its per-workgroup placement trace (tools/ab_vit_astat_trace.py; 0 = off);
- * -14: image preprocessing by one workgroup per 14 x 14 patch (1, default since round 5) / by round 1's one-thread-per-fragment-unit kernel (0) */
+ * -14: image preprocessing by one workgroup per 14 x 14 patch (1, default since round 5) / by round 1's one-thread-per-fragment-unit kernel (0);
+ * -15: the token-stationary kernel with two channel tiles per wave (1, default since round 5) / one (0) */
 int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
 /* A/B + tests: vfm_voxel_robin on a VoxelDownsample-shaped call (one point per voxel, reserve(n), n <= 2^18) by the one-launch kernel
  * (1) / always by the general multi-launch path (0, default: the one-launch form measured slower -- csrc/voxel.hip); both give the

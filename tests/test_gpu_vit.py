@@ -147,10 +147,13 @@ def test_vit_token_stationary_gemms_equal_the_other_kernels_bit_for_bit():
             lib.vfm_debug_set_vit_gemm(-9, -1)       # never
             ref = model.forward(imgs).clone()
             lib.vfm_debug_set_vit_gemm(-9, 1)        # always (QKV and fc1, wherever 128 rows of A fit the LDS)
-            got = model.forward(imgs).clone()
-            torch.cuda.synchronize()
-            assert torch.equal(ref, got), (dim, B, float((ref - got).abs().max()))
+            for two in (0, 1):                       # round 4's form (one channel tile per wave) and round 5's (two: half the LDS reads per MFMA)
+                lib.vfm_debug_set_vit_gemm(-15, two)
+                got = model.forward(imgs).clone()
+                torch.cuda.synchronize()
+                assert torch.equal(ref, got), (dim, B, two, float((ref - got).abs().max()))
     finally:
+        lib.vfm_debug_set_vit_gemm(-15, 1)
         lib.vfm_debug_set_vit_gemm(-9, 0)            # the default policy: where its rounds of one workgroup per compute unit are full
 
 

@@ -761,6 +761,92 @@ __global__ __launch_bounds__(64 * NW, 1) void vit_gemm_astat_kernel(GemmArgs g) 
     }
 }
 
+// ---- the token-stationary product with TWO channel tiles per wave (round 5).  What the counters said once the epilogues were on a diet
+// (profiles/r05_pmc_vit_96images.json): the GEMMs issue few instructions and still keep the matrix pipe 22 - 24 % busy -- every MFMA of the
+// kernel above is fed by one 1 KiB ds_read_b128 of an A fragment, i.e. 32 cycles of the LDS port (128 B / clk per compute unit) per 32-cycle
+// MFMA on each of four SIMDs: the LDS runs at its peak exactly when the matrix pipes do, and neither gets there.  Here a wave holds the weight
+// fragments of two channel tiles and multiplies each A fragment with both: half the LDS bytes per MFMA (8 MFMAs per four ds_reads), 128
+// accumulator registers, two waves per SIMD (eight per workgroup).  A wave takes the channel-tile pairs w, w + 8, ... (36 tiles of QKV = 18
+// pairs: waves 0 and 1 run a third round).  The epilogue's per-channel operands are fetched behind the k-loop, when the weight ring's
+// registers are free.  Same MFMAs over the same fragments in the same k order: bit-identical to the other GEMM kernels.
+template <int EPI, int NW, int PF>
+__global__ __launch_bounds__(64 * NW, 1) void vit_gemm_astat2_kernel(GemmArgs g) {
+    static_assert(EPI == EPI_QKV || EPI == EPI_GELU, "the residual epilogues read a row-sized operand per tile: not this kernel");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [4 token tiles][KS][1 KiB]
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mtiles = g.M / 32, KS = g.KS, mg = blockIdx.x;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    for (int p = wave; p < 4 * KS; p += NW) {
+        const int tile = p / KS, ks = p - tile * KS;
+        int rowtile = mg * 4 + tile;
+        if (rowtile >= mtiles) rowtile = mtiles - 1;   // (a partial last group: its epilogue is skipped)
+        vit_glds16(g.A + ((size_t)rowtile * KS + ks) * 64 + lane, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)p * 1024u));
+    }
+    const int hi = lane >> 5, lane31 = lane & 31;
+    float ln_a[4], ln_nb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int mt = mg * 4 + i;
+        if (mt >= mtiles) mt = mtiles - 1;
+        ln_stats_load(g, mt * 32 + lane31, ln_a[i], ln_nb[i]);
+    }
+    vit_wait_vmcnt<0>();
+    __syncthreads();
+    const int npairs = g.N / 64, qtiles = g.Tp >> 5;
+    const unsigned char* la = lds + lane * 16;
+    for (int pr = wave; pr < npairs; pr += NW) {
+        const uint4* W0 = g.W + (size_t)(2 * pr) * KS * 64 + lane;
+        const uint4* W1 = W0 + (size_t)KS * 64;
+        uint4 rw0[PF], rw1[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+            if (i < KS) {
+                rw0[i] = W0[(size_t)i * 64];
+                rw1[i] = W1[(size_t)i * 64];
+            }
+        floatx16 acc0[4], acc1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[i][r] = acc1[i][r] = 0.f;
+        for (int s0 = 0; s0 < KS; s0 += PF) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int s = s0 + i;
+                if (s < KS) {
+                    const half8 w0 = *reinterpret_cast<half8*>(&rw0[i]);
+                    const half8 w1 = *reinterpret_cast<half8*>(&rw1[i]);
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) {
+                        const half8 af = *reinterpret_cast<const half8*>(la + ((size_t)(t4 * KS + s)) * 1024);
+                        acc0[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, af, acc0[t4], 0, 0, 0);
+                        acc1[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, af, acc1[t4], 0, 0, 0);
+                    }
+                    if (s + PF < KS) {
+                        rw0[i] = W0[(size_t)(s + PF) * 64];
+                        rw1[i] = W1[(size_t)(s + PF) * 64];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n32 = __builtin_amdgcn_readfirstlane(2 * pr + j);
+            EpiRegs e;
+            epi_load<EPI>(g, 0, 0, hi, n32, e);   // bias + row sums of the folded weight: per channel, the same for the four token tiles
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const int mt = mg * 4 + t4;
+                if (mt >= mtiles) continue;   // workgroup-uniform
+                const int mtu = __builtin_amdgcn_readfirstlane(mt);
+                const int b = (int)(((unsigned)mtu * g.qt_magic) >> 20), tq = mtu - b * qtiles;
+                epi_tile<EPI, false>(g, j ? acc1[t4] : acc0[t4], mt * 32 + lane31, mtu, b, tq, tq * 32 + lane31, hi, n32, e, ln_a[t4], ln_nb[t4]);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3. LayerNorm over channels, fp32 in -> fp16 fragment tiles out.  One wavefront per token.
 // ---------------------------------------------------------------------------------------------
@@ -1170,6 +1256,7 @@ int g_vit_att_lds_min = 1;   // vfm_debug_set_vit_gemm(-7, n): attention with K 
 int g_vit_lds_min_wg = 256;   // vfm_debug_set_vit_gemm(-5, n): the LDS-tiled kernel from n workgroups of 128 x 128 on (0 = never)
 unsigned long long* g_vit_astat_dbg = nullptr;   // vfm_debug_set_vit_gemm(-11, lo) / (-12, hi): device buffer [workgroup][4] = start, end (100 MHz ticks), (xcc << 32 | HW_ID), 0
 int g_vit_astat_min = 0;      // vfm_debug_set_vit_gemm(-9, n): the token-stationary kernel for QKV / fc1 from n groups of 128 token rows on (0 = where its rounds are full: launch_gemm; -1 = never)
+int g_vit_astat_two = 1;      // vfm_debug_set_vit_gemm(-15, 0 / 1): the token-stationary kernel with one / two (default) channel tiles per wave
 int g_vit_astat_nw = 0;       // vfm_debug_set_vit_gemm(-10, n): its waves per workgroup where n divides N / 32 (6, 8, 16; otherwise 12)
 template <int EPI>
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
@@ -1205,6 +1292,19 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         ga.dbg = g_vit_astat_dbg;                                                                                                    \
         hipLaunchKernelGGL((vit_gemm_astat_kernel<EPI, NW, 6>), dim3(groups), dim3(64 * NW), 4 * g.KS * 1024, st, ga);               \
     } while (0)
+            if (g_vit_astat_two && (g.N / 64) >= 8 && g.N % 64 == 0) {   // two channel tiles per wave, eight waves (round 5)
+                static unsigned long long attr2 = 0ull;
+                int dev2 = 0;
+                (void)hipGetDevice(&dev2);
+                if (!((attr2 >> (dev2 & 63)) & 1ull)) {
+                    VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_gemm_astat2_kernel<EPI, 8, 4>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                    attr2 |= 1ull << (dev2 & 63);
+                }
+                hipLaunchKernelGGL((vit_gemm_astat2_kernel<EPI, 8, 4>), dim3(groups), dim3(512), 4 * g.KS * 1024, st, g);
+                VFM_CHECK_LAUNCH("vit_gemm_astat2_kernel");
+                return VFM_OK;
+            }
             switch (nw) {
                 case 6: VIT_ASTAT(6); break;
                 case 112: {   // (A/B) twelve waves, non-temporal output stores
@@ -1274,6 +1374,10 @@ VFM_EXPORT int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg) {
     }
     if (narrow_cfg == -6) {
         g_vit_lds_shape = wide_cfg;
+        return VFM_OK;
+    }
+    if (narrow_cfg == -15) {   // token-stationary GEMM: 1 = two channel tiles per wave (default), 0 = round 4's one
+        g_vit_astat_two = wide_cfg;
         return VFM_OK;
     }
     if (narrow_cfg == -14) {   // preprocessing: 1 = one workgroup per patch (default), 0 = round 1's kernel
