@@ -503,14 +503,20 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     // The grid is ~1 wave per SIMD, so nothing hides a load's L2 round trip except the wave itself:
     // keep PF k-steps of operand fragments in flight in a register ring.
+    // Round 5: every load of the ring is UNCONDITIONAL (k-steps past the end re-read the last one) and stays where it is issued
+    // (sched_barrier), so that the compiler can count the loads in flight.  With the ring's loads under `if (s + PF < KS)` it waited for
+    // vmcnt(0) at the head of every block of PF k-steps: each block began by exposing the L2 round trip of the fragments it had just
+    // asked for (and the token-stationary kernels did so in front of every k-step).
     uint4 ra[PF], rw[NT][PF];
+    const int klast = g.KS - 1;
 #pragma unroll
-    for (int i = 0; i < PF; ++i)
-        if (i < g.KS) {
-            ra[i] = Ap[(size_t)i * 64];
+    for (int i = 0; i < PF; ++i) {
+        const int si = i < klast ? i : klast;
+        ra[i] = Ap[(size_t)si * 64];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) rw[j][i] = Wp[((size_t)j * g.KS + i) * 64];
-        }
+        for (int j = 0; j < NT; ++j) rw[j][i] = Wp[((size_t)j * g.KS + si) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     const int m = mt * 32 + (lane & 31);
     const int mtu = __builtin_amdgcn_readfirstlane(mt), qtiles = g.Tp >> 5;   // (a token tile lies inside one image: Tp % 32 == 0)
     const int b = (int)(((unsigned)mtu * g.qt_magic) >> 20), tq = mtu - b * qtiles, t = tq * 32 + (lane & 31);
@@ -523,21 +529,30 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
     for (int half = 0; half < NT; ++half) epi_load<EPI>(g, m, t, hi, __builtin_amdgcn_readfirstlane(nt * NT + half), e[half]);
     float ln_mean = 0.f, ln_rstd = 0.f;   // (a, nb) of the lane's token: see ln_stats_load
     if constexpr (EPI == EPI_QKV || EPI == EPI_GELU) ln_stats_load(g, m, ln_mean, ln_rstd);
-    for (int s0 = 0; s0 < g.KS; s0 += PF) {
+    const int nblk = (g.KS + PF - 1) / PF;
+    for (int blk = 0; blk + 1 < nblk; ++blk) {   // every block but the last: multiply, reload the slot for the next block
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
-            const int s = s0 + i;
-            if (s < g.KS) {
-                const half8 av = *reinterpret_cast<half8*>(&ra[i]);
+            const int s = blk * PF + i;
+            const half8 av = *reinterpret_cast<half8*>(&ra[i]);
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&rw[j][i]), av, acc[j], 0, 0, 0);
-                if (s + PF < g.KS) {
-                    ra[i] = Ap[(size_t)(s + PF) * 64];
+            for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&rw[j][i]), av, acc[j], 0, 0, 0);
+            const int sn = s + PF < klast ? s + PF : klast;
+            ra[i] = Ap[(size_t)sn * 64];
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) rw[j][i] = Wp[((size_t)j * g.KS + s + PF) * 64];
-                }
-            }
+            for (int j = 0; j < NT; ++j) rw[j][i] = Wp[((size_t)j * g.KS + sn) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // the last block: no reloads (nothing is in flight when the epilogue starts); a partial one where KS % PF != 0 (the patch embedding's 37)
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        if ((nblk - 1) * PF + i < g.KS) {
+            const half8 av = *reinterpret_cast<half8*>(&ra[i]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&rw[j][i]), av, acc[j], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -716,8 +731,8 @@ __global__ __launch_bounds__(64 * NW, 1) void vit_gemm_astat_kernel(GemmArgs g) 
         const uint4* Wp = g.W + (size_t)nt * KS * 64 + lane;
         uint4 rw[PF];
 #pragma unroll
-        for (int i = 0; i < PF; ++i)
-            if (i < KS) rw[i] = Wp[(size_t)i * 64];
+        for (int i = 0; i < PF; ++i) rw[i] = Wp[(size_t)(i < KS - 1 ? i : KS - 1) * 64];   // (unconditional: see vit_gemm_kernel)
+        __builtin_amdgcn_sched_barrier(0);
         const int n32 = __builtin_amdgcn_readfirstlane(nt);
         EpiRegs e;
         epi_load<EPI>(g, 0, 0, hi, n32, e);   // bias + row sums of the folded weight: per channel, the same for the four token tiles
@@ -726,18 +741,30 @@ __global__ __launch_bounds__(64 * NW, 1) void vit_gemm_astat_kernel(GemmArgs g) 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        for (int s0 = 0; s0 < KS; s0 += PF) {
+        const int nblk = (KS + PF - 1) / PF;
+        for (int blk = 0; blk + 1 < nblk; ++blk) {
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
-                const int s = s0 + i;
-                if (s < KS) {
-                    const half8 wv = *reinterpret_cast<half8*>(&rw[i]);
+                const int s = blk * PF + i;
+                const half8 wv = *reinterpret_cast<half8*>(&rw[i]);
 #pragma unroll
-                    for (int t4 = 0; t4 < 4; ++t4) {
-                        const half8 af = *reinterpret_cast<const half8*>(lds + ((size_t)(t4 * KS + s)) * 1024 + lane * 16);
-                        acc[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, af, acc[t4], 0, 0, 0);
-                    }
-                    if (s + PF < KS) rw[i] = Wp[(size_t)(s + PF) * 64];
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const half8 af = *reinterpret_cast<const half8*>(lds + ((size_t)(t4 * KS + s)) * 1024 + lane * 16);
+                    acc[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, af, acc[t4], 0, 0, 0);
+                }
+                rw[i] = Wp[(size_t)(s + PF < KS - 1 ? s + PF : KS - 1) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {   // the last block (partial where KS % PF != 0): no reloads
+            const int s = (nblk - 1) * PF + i;
+            if (s < KS) {
+                const half8 wv = *reinterpret_cast<half8*>(&rw[i]);
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const half8 af = *reinterpret_cast<const half8*>(lds + ((size_t)(t4 * KS + s)) * 1024 + lane * 16);
+                    acc[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, af, acc[t4], 0, 0, 0);
                 }
             }
         }
@@ -800,34 +827,47 @@ __global__ __launch_bounds__(64 * NW, 1) void vit_gemm_astat2_kernel(GemmArgs g)
         const uint4* W1 = W0 + (size_t)KS * 64;
         uint4 rw0[PF], rw1[PF];
 #pragma unroll
-        for (int i = 0; i < PF; ++i)
-            if (i < KS) {
-                rw0[i] = W0[(size_t)i * 64];
-                rw1[i] = W1[(size_t)i * 64];
-            }
+        for (int i = 0; i < PF; ++i) {   // (KS >= PF: unconditional, in k-step order -- the order the loop's counted waits assume)
+            rw0[i] = W0[(size_t)i * 64];
+            rw1[i] = W1[(size_t)i * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         floatx16 acc0[4], acc1[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc0[i][r] = acc1[i][r] = 0.f;
-        for (int s0 = 0; s0 < KS; s0 += PF) {
+        // (KS % PF == 0 -- launch_gemm checks -- and the ring's reloads are unconditional, the last PF of them re-reading the final k-step:
+        // a straight-line loop body, so that the compiler can COUNT the loads in flight.  With the reload under `if (s + PF < KS)` it waited
+        // for vmcnt(0) in front of every k-step -- every weight fragment's L2 round trip was exposed, 24 times per tile pair: that, not
+        // the LDS and not the issue rate, was what the token-stationary kernels' 50 - 66 us consisted of.)
+        for (int s0 = 0; s0 + PF < KS; s0 += PF) {   // every block of PF k-steps but the last
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int s = s0 + i;
-                if (s < KS) {
-                    const half8 w0 = *reinterpret_cast<half8*>(&rw0[i]);
-                    const half8 w1 = *reinterpret_cast<half8*>(&rw1[i]);
+                const half8 w0 = *reinterpret_cast<half8*>(&rw0[i]);
+                const half8 w1 = *reinterpret_cast<half8*>(&rw1[i]);
 #pragma unroll
-                    for (int t4 = 0; t4 < 4; ++t4) {
-                        const half8 af = *reinterpret_cast<const half8*>(la + ((size_t)(t4 * KS + s)) * 1024);
-                        acc0[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, af, acc0[t4], 0, 0, 0);
-                        acc1[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, af, acc1[t4], 0, 0, 0);
-                    }
-                    if (s + PF < KS) {
-                        rw0[i] = W0[(size_t)(s + PF) * 64];
-                        rw1[i] = W1[(size_t)(s + PF) * 64];
-                    }
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const half8 af = *reinterpret_cast<const half8*>(la + ((size_t)(t4 * KS + s)) * 1024);
+                    acc0[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, af, acc0[t4], 0, 0, 0);
+                    acc1[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, af, acc1[t4], 0, 0, 0);
                 }
+                rw0[i] = W0[(size_t)(s + PF) * 64];
+                rw1[i] = W1[(size_t)(s + PF) * 64];
+                __builtin_amdgcn_sched_barrier(0);   // (the reload stays HERE, behind its k-step: the scheduler had gathered all PF pairs at the loop's end)
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {   // the last block: nothing left to fetch
+            const int s = KS - PF + i;
+            const half8 w0 = *reinterpret_cast<half8*>(&rw0[i]);
+            const half8 w1 = *reinterpret_cast<half8*>(&rw1[i]);
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const half8 af = *reinterpret_cast<const half8*>(la + ((size_t)(t4 * KS + s)) * 1024);
+                acc0[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, af, acc0[t4], 0, 0, 0);
+                acc1[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, af, acc1[t4], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -1292,7 +1332,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         ga.dbg = g_vit_astat_dbg;                                                                                                    \
         hipLaunchKernelGGL((vit_gemm_astat_kernel<EPI, NW, 6>), dim3(groups), dim3(64 * NW), 4 * g.KS * 1024, st, ga);               \
     } while (0)
-            if (g_vit_astat_two && (g.N / 64) >= 8 && g.N % 64 == 0) {   // two channel tiles per wave, eight waves (round 5)
+            if (g_vit_astat_two && (g.N / 64) >= 8 && g.N % 64 == 0 && g.KS % 4 == 0) {   // two channel tiles per wave, eight waves (round 5)
                 static unsigned long long attr2 = 0ull;
                 int dev2 = 0;
                 (void)hipGetDevice(&dev2);
