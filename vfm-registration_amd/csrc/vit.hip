@@ -1143,25 +1143,25 @@ __global__ __launch_bounds__(256, 2) void vit_attention_lds_kernel(const uint4* 
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
             vit_glds16(Q + base + ((size_t)qt_ * 4 + s4) * 64 + lane,
-                       __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(NKT * 8 + wave * 4 + s4) * 1024u));
+                       __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(NKT * 4 + wave * 4 + s4) * 1024u));
 #pragma unroll
         for (int i = 0; i < NKT; ++i)
             vit_glds16(K + base + (size_t)(wave + 4 * i) * 64 + lane, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave + 4 * i) * 1024u));
-#pragma unroll
-        for (int i = 0; i < NKT; ++i)
-            vit_glds16(VT + base + (size_t)(wave + 4 * i) * 64 + lane,
-                       __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(NKT * 4 + wave + 4 * i) * 1024u));
     }
+    // Round 5: V^T takes K's place.  With both resident a workgroup held 104 KiB of LDS -- one workgroup of four waves per compute unit,
+    // and the kernel ran at the pace of its staging (173 MB fetched per launch at 96 images, L2 hit rate 0.12, 3.5 TB/s: memory-bound with
+    // nothing to overlap the fetch with).  K is dead once the scores are in registers: V^T is copied over it behind a barrier and lands
+    // under the softmax, as before; 60 KiB per workgroup, two workgroups per compute unit, one's staging under the other's MFMAs.
     const uint4* K_l = reinterpret_cast<const uint4*>(att_lds);
-    const uint4* VT_l = reinterpret_cast<const uint4*>(att_lds + (size_t)NKT * 4096);
+    const uint4* VT_l = reinterpret_cast<const uint4*>(att_lds);
     const bool active = qt < qtiles;   // (the last group of an image may have fewer than four tiles: those waves only stage)
     // Q^T as B operand: query tile qt, 4 k-steps over d
-    vit_wait_vmcnt<NKT>();   // the query tile and K are here (V^T lands under the scores and the softmax)
+    vit_wait_vmcnt<0>();   // the query tile and K are here
     __syncthreads();
     half8 qf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        uint4 v = reinterpret_cast<const uint4*>(att_lds + (size_t)(NKT * 8 + wave * 4 + s) * 1024)[lane];
+        uint4 v = reinterpret_cast<const uint4*>(att_lds + (size_t)(NKT * 4 + wave * 4 + s) * 1024)[lane];
         qf[s] = *reinterpret_cast<half8*>(&v);
     }
     // S^T tiles: rows = keys, column = query (lane & 31)
@@ -1175,6 +1175,14 @@ __global__ __launch_bounds__(256, 2) void vit_attention_lds_kernel(const uint4* 
             uint4 v = K_l[((size_t)kt * 4 + s) * 64 + lane];
             S[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&v), qf[s], S[kt], 0, 0, 0);
         }
+    }
+    asm volatile("" ::: "memory");
+    __syncthreads();   // every wave has read its last K fragment
+    {
+        const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)att_lds;
+#pragma unroll
+        for (int i = 0; i < NKT; ++i)
+            vit_glds16(VT + base + (size_t)(wave + 4 * i) * 64 + lane, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave + 4 * i) * 1024u));
     }
     const int hi = lane >> 5;
     // softmax over keys (scale 1/8), keys >= T masked: S becomes the unnormalised probabilities, inv = 1 / their sum
@@ -1528,10 +1536,10 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
         (void)hipGetDevice(&dev_);                                                                                        \
         if (!((attr_set >> (dev_ & 63)) & 1ull)) {                                                                        \
             VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_attention_lds_kernel<NKT>),             \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, NKT * 8192 + 16384));           \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, NKT * 4096 + 16384));           \
             attr_set |= 1ull << (dev_ & 63);                                                                              \
         }                                                                                                                 \
-        hipLaunchKernelGGL(vit_attention_lds_kernel<NKT>, dim3(d.B * d.heads * ((d.Tp / 32 + 3) / 4)), dim3(256), NKT * 8192 + 16384, st, \
+        hipLaunchKernelGGL(vit_attention_lds_kernel<NKT>, dim3(d.B * d.heads * ((d.Tp / 32 + 3) / 4)), dim3(256), NKT * 4096 + 16384, st, \
                            reinterpret_cast<const uint4*>(w.q), reinterpret_cast<const uint4*>(w.k),                      \
                            reinterpret_cast<const uint4*>(w.vt), d.T, d.Tp, d.heads, d.D, w.a);                           \
     } else                                                                                                                \
