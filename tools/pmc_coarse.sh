@@ -32,6 +32,7 @@ d = sorted(dur)[len(dur) // 2]
 out = {
     "kernel": kname.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip()
               + (" (fp6 e2m3 32x32x64 scaled MFMA over the first half of the columns, the bound test fused: survivors listed per workgroup, no per-chunk records)" if ("mx6" in kname and "${VFM_RECORDS:-0}" == "8")
+                 else " (fp6 e2m3 32x32x64 scaled MFMA over all columns, the gate test fused: survivors listed per workgroup, no per-chunk records)" if ("mx6" in kname and "${VFM_RECORDS:-0}" == "10")
                  else " (fp6 e2m3 32x32x64 scaled MFMA over the first half of the columns, one best-score record per (query, chunk))" if ("mx6" in kname and "<3," in kname)
                  else " (fp6 e2m3 32x32x64 scaled MFMA, one best-score record per (query, chunk))" if "mx6" in kname
                  else " (fp16 32x32x16 MFMA)" if "i8" not in kname

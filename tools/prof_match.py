@@ -38,7 +38,7 @@ else:             # the gated family, split form, as vfmreg/pipeline.py calls it
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(reps):
         _lib.check(lib.vfm_match_prepare2_gated_p(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d,
-                                                  (8 | 16) if records in (7, 8) else 8 if records in (5, 6, 9) else 0, st))   # VFM_PREPARE_MX6 (| _MX6_HALF) for the VFM_RECORDS_MX6* kinds
+                                                  (8 | 16) if records in (7, 8) else 8 if records in (5, 6, 9, 10) else 0, st))   # VFM_PREPARE_MX6 (| _MX6_HALF) for the VFM_RECORDS_MX6* kinds
         _lib.check(lib.vfm_match_search_coarse_gated_g(qb.data_ptr(), n, bb.data_ptr(), m, d, ws.data_ptr(), ws.numel(), records, float(g), st))
         _lib.check(lib.vfm_match_search_finish_gated_r(q.data_ptr(), qb.data_ptr(), n, b.data_ptr(), bb.data_ptr(), m, d, idx.data_ptr(),
                                                        sim.data_ptr(), ws.data_ptr(), ws.numel(), float(g), records, st))
