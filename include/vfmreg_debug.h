@@ -58,7 +58,8 @@ int vfm_debug_set_match_stats(int on);
 int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
 /* A/B + tests: vfm_voxel_robin on a VoxelDownsample-shaped call (one point per voxel, reserve(n), n <= 2^18) by the one-launch kernel
  * (1) / always by the general multi-launch path (0, default: the one-launch form measured slower -- csrc/voxel.hip); both give the
- * container's order */
+ * container's order.  2 / 3: the per-cluster replay of a generation as in round 4 (a radix sort by (cluster, arrival) in front of a
+ * global-memory replay) / as in round 5 (3, default: the replay sorts its cluster and runs in the LDS) */
 int vfm_debug_set_voxel_small(int on);
 /* A/B: workgroups of the int8 operand-preparation kernel (-1, default = one per 128-row group; 0 = one per compute unit, each
  * walking several groups with the next group's rows read under the current group's quantisation and store: faster alone,

@@ -217,3 +217,29 @@ def test_one_launch_downsample_equals_the_general_path_and_the_oracle():
         assert wrapped >= 3, wrapped
     finally:
         lib.vfm_debug_set_voxel_small(0)
+
+
+def test_replay_in_the_lds_equals_the_replay_behind_a_radix_sort():
+    """robin_replay2_kernel (round 5: a cluster's members ordered by the replaying thread itself, the replay in a per-thread slice of the
+    LDS; clusters beyond 24 entries in place in global memory) against round 4's form (radix sort by (cluster, arrival), replay through
+    global memory) and the oracle: down-sampling and growing maps, a dense table with long clusters (more voxels than 20-bit hashes spread),
+    wrapping clusters."""
+    from oracle import oracle as orc
+    from vfmreg import _lib, ops
+    lib = _lib.load()
+    rng = np.random.default_rng(91)
+    try:
+        for n, extent, vs, K, reserve in [(700, 10.0, 0.5, 1, True), (20000, 60.0, 0.5, 1, True), (120000, 60.0, 0.25, 1, True),
+                                          (8000, 3.0, 1.0, 20, False), (200000, 60.0, 1.0, 20, False), (400000, 80.0, 0.5, 1, True)]:
+            pts = rng.uniform(-extent, extent, (n, 3)) * [1, 1, 0.15]
+            d = torch.from_numpy(pts).cuda()
+            hm = ops.HASH_DOWNSAMPLE if reserve else ops.HASH_MAP
+            ref = orc.voxel_robin(pts, vs, K, reserve, orc.HASH_MUL_DOWNSAMPLE if reserve else orc.HASH_MUL_MAP)
+            outs = []
+            for mode in (2, 3):
+                lib.vfm_debug_set_voxel_small(mode)
+                outs.append(ops.voxel_robin(d, vs, K, reserve=reserve, hash_mul=hm).cpu().numpy())
+            np.testing.assert_array_equal(outs[0], ref, err_msg=str((n, K, "radix sort + global replay")))
+            np.testing.assert_array_equal(outs[1], ref, err_msg=str((n, K, "replay in the LDS")))
+    finally:
+        lib.vfm_debug_set_voxel_small(3)

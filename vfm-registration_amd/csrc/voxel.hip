@@ -307,6 +307,87 @@ __global__ __launch_bounds__(64) void robin_replay_kernel(const int* __restrict_
     }
     if (maxd > 0) atomicMax((unsigned long long*)(geninfo + 3), (unsigned long long)maxd);
 }
+// Round 5: the same replay without the second radix sort in front of it and without a global-memory round trip per probe.  A cluster's
+// members are a contiguous range of the HOME-sorted entries (pos_s = their positions in the generation's input sequence `cur`); their
+// arrival order is ascending position, so the thread sorts its own range (insertion sort: clusters of a half-empty table hold one to a
+// few entries) instead of the whole generation going through a radix sort by (cluster, arrival) -- ~8 launches per generation.  Clusters
+// of up to REPLAY_L entries are replayed in a per-thread slice of the LDS (positions, voxels, homes fetched with independent loads first;
+// the old kernel's chain of dependent global loads per probe was 30 us per generation at 20 000 voxels); longer ones in place, in global
+// memory, as before.  Same insertions in the same order: the same table.
+constexpr int REPLAY_L = 24;
+__global__ __launch_bounds__(64) void robin_replay2_kernel(const int* __restrict__ cl_start, const int* __restrict__ cl_base,
+                                                           const int* __restrict__ cidx, int64_t m, int* __restrict__ pos_s,
+                                                           const int* __restrict__ cur, const unsigned* __restrict__ vhash,
+                                                           unsigned mask, unsigned z, int* __restrict__ tab_dist,
+                                                           int* __restrict__ tab_id, int64_t* __restrict__ geninfo) {
+    __shared__ int sP[REPLAY_L][64], sH[REPLAY_L][64], sD[REPLAY_L][64], sI[REPLAY_L][64];   // [slot][thread]: conflict-free
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t ncl = cidx[m - 1];
+    if (c >= ncl) return;
+    const int tx = threadIdx.x;
+    const int i0 = cl_start[c], L = cl_start[c + 1] - i0, base = cl_base[c];
+    if (L > RH_MAX_CLUSTER) return;   // (the host rejects such a table from geninfo[4], in the same read-back)
+    int maxd = 0;
+    if (L <= REPLAY_L) {
+        for (int t = 0; t < L; ++t) sP[t][tx] = pos_s[i0 + t];
+        for (int x = 1; x < L; ++x) {   // arrival order = ascending position in `cur`
+            const int p = sP[x][tx];
+            int y = x - 1;
+            while (y >= 0 && sP[y][tx] > p) { sP[y + 1][tx] = sP[y][tx]; --y; }
+            sP[y + 1][tx] = p;
+        }
+        for (int t = 0; t < L; ++t) sP[t][tx] = cur[sP[t][tx]];                                   // positions -> voxels
+        for (int t = 0; t < L; ++t) sH[t][tx] = (int)((vhash[sP[t][tx]] - z) & mask) - base;     // their homes inside the window
+        for (int t = 0; t < L; ++t) sD[t][tx] = -1;
+        for (int t = 0; t < L; ++t) {
+            int v = sP[t][tx], ib = sH[t][tx], d = 0;
+            for (;;) {  // tsl insert_value_on_rehash (== insert_impl + insert_value_impl for an absent key)
+                const int rd = sD[ib][tx];
+                if (d > rd) {
+                    if (rd < 0) { sD[ib][tx] = d; sI[ib][tx] = v; if (d > maxd) maxd = d; break; }
+                    const int tv = sI[ib][tx];
+                    sD[ib][tx] = d; sI[ib][tx] = v;
+                    if (d > maxd) maxd = d;
+                    d = rd; v = tv;
+                }
+                d++;
+                ib++;  // never leaves [0, L): the window is the cluster's final extent
+            }
+        }
+        for (int t = 0; t < L; ++t) {
+            tab_dist[i0 + t] = sD[t][tx];
+            tab_id[i0 + t] = sI[t][tx];
+        }
+    } else {
+        int* P = pos_s + i0;
+        for (int x = 1; x < L; ++x) {
+            const int p = P[x];
+            int y = x - 1;
+            while (y >= 0 && P[y] > p) { P[y + 1] = P[y]; --y; }
+            P[y + 1] = p;
+        }
+        int* D = tab_dist + i0;
+        int* I = tab_id + i0;
+        for (int t = 0; t < L; ++t) {
+            int v = cur[P[t]];
+            int ib = (int)((vhash[v] - z) & mask) - base;
+            int d = 0;
+            for (;;) {
+                const int rd = D[ib];
+                if (d > rd) {
+                    if (rd < 0) { D[ib] = d; I[ib] = v; if (d > maxd) maxd = d; break; }
+                    const int tv = I[ib];
+                    D[ib] = d; I[ib] = v;
+                    if (d > maxd) maxd = d;
+                    d = rd; v = tv;
+                }
+                d++;
+                ib++;
+            }
+        }
+    }
+    if (maxd > 0) atomicMax((unsigned long long*)(geninfo + 3), (unsigned long long)maxd);
+}
 __global__ __launch_bounds__(256) void robin_emit_kernel(const int* __restrict__ tab_id, int64_t m, const int64_t* __restrict__ geninfo,
                                                          int* __restrict__ order) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -354,6 +435,7 @@ __global__ __launch_bounds__(256) void robin_pointkey_kernel(const int64_t* __re
 // 60 000, against 0.23 / 0.25 ms for the ~28 short full-width launches of the general path (the reference-shaped call went from 1.7 to
 // 2.5 ms, from 2.2 to 5.6 ms at a 60 000-point scan).  Launch latency is cheaper than one compute unit's memory latency; the kernel
 // stays behind vfm_debug_set_voxel_small(1) with its test.
+int g_voxel_replay2 = 1;   // vfm_debug_set_voxel_small(2 / 3): round 4's replay (radix sort by cluster + global-memory replay) / round 5's (default)
 int g_voxel_small = 0;   // vfm_debug_set_voxel_small(0 / 1): the general path always (default: measured faster, see below) / the one-launch kernel where it applies
 constexpr int SMALLW_THREADS = 1024;
 constexpr int SMALLW_MAX_CLUSTER = 192;
@@ -760,7 +842,8 @@ int select_first_k(const double* pts, int64_t n, int64_t stride, double voxel_si
 }  // namespace
 
 VFM_EXPORT int vfm_debug_set_voxel_small(int on) {
-    g_voxel_small = on;
+    if (on == 2 || on == 3) g_voxel_replay2 = on == 3;
+    else g_voxel_small = on;
     return VFM_OK;
 }
 
@@ -911,13 +994,18 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
                                w.cl_of_pos, w.cl_start, w.cl_base, w.tab_dist);
             hipLaunchKernelGGL(robin_wrap_kernel, dim3(1), dim3(1), 0, st, w.cm, m, B, (int64_t)z, w.geninfo);
             hipLaunchKernelGGL(robin_maxlen_kernel, dim3(gm), dim3(256), 0, st, w.cl_start, w.cidx, m, w.geninfo);
-            int cbits = 1;
-            while ((1ll << cbits) < m) ++cbits;
-            tb = w.cub_bytes;
-            VFM_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(w.cub, tb, w.cl_of_pos, w.cl_sorted, cur, w.arrivals, (int)m, 0,
-                                                            cbits, st));
-            hipLaunchKernelGGL(robin_replay_kernel, dim3(blocks_of(m, 64)), dim3(64), 0, st, w.cl_start, w.cl_base, w.cidx, m,
-                               w.arrivals, w.vhash, mask, z, w.tab_dist, w.tab_id, w.geninfo);
+            if (g_voxel_replay2) {   // round 5: the replay orders a cluster's members itself and runs in the LDS (robin_replay2_kernel)
+                hipLaunchKernelGGL(robin_replay2_kernel, dim3(blocks_of(m, 64)), dim3(64), 0, st, w.cl_start, w.cl_base, w.cidx, m, w.pos_s,
+                                   cur, w.vhash, mask, z, w.tab_dist, w.tab_id, w.geninfo);
+            } else {
+                int cbits = 1;
+                while ((1ll << cbits) < m) ++cbits;
+                tb = w.cub_bytes;
+                VFM_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(w.cub, tb, w.cl_of_pos, w.cl_sorted, cur, w.arrivals, (int)m, 0,
+                                                                cbits, st));
+                hipLaunchKernelGGL(robin_replay_kernel, dim3(blocks_of(m, 64)), dim3(64), 0, st, w.cl_start, w.cl_base, w.cidx, m,
+                                   w.arrivals, w.vhash, mask, z, w.tab_dist, w.tab_id, w.geninfo);
+            }
             int64_t gi[5];   // one read-back per pass: wrap analysis, probe distance and the longest run (the replay skips runs beyond the limit)
             VFM_CHECK_HIP(hipMemcpyAsync(gi, w.geninfo, sizeof(gi), hipMemcpyDeviceToHost, st));
             VFM_CHECK_HIP(hipStreamSynchronize(st));
