@@ -48,6 +48,7 @@ int g_coarse_qsets = 0;
 int g_seed_units = 1;   // vfm_debug_set_coarse_variant(7): no seed units (A/B)
 int g_select_variant = 0;  // vfm_debug_set_coarse_variant(20 / 21): general select kernel / no chunk-major rescan (A/B)
 int g_mx6_t4 = 1;
+int g_mx6_ns3 = 1;   // vfm_debug_set_coarse_variant(32 / 33): the fused fp6 half-width kernel at d = 384 with two / three (default since round 5) query tiles per wave
 int g_prep_stream = 1;
 int g_finish_short = 0;
 int g_rescan_rows = 1;
@@ -513,6 +514,10 @@ VFM_EXPORT int vfm_debug_set_coarse_variant(int qsets) {
     }
     if (qsets == 40 || qsets == 41) {   // fp6 operand preparation: 40 = prep_chunk_kernel (rows in registers), 41 = prep_stream_kernel (the default)
         g_prep_stream = qsets == 41 ? 1 : 0;
+        return VFM_OK;
+    }
+    if (qsets == 32 || qsets == 33) {   // the fused fp6 half-width kernel at d = 384: 32 = two 32-query tiles per wave, 33 = three (round 5)
+        g_mx6_ns3 = qsets == 33 ? 1 : 0;
         return VFM_OK;
     }
     if (qsets == 30 || qsets == 31) {   // the fused fp6 half-width kernel: 30 = one chunk per barrier (the default), 31 = two (A/B)

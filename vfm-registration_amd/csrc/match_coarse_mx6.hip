@@ -114,8 +114,15 @@ constexpr int MX6_LCAP = 2047;      // FUSE: survivors a workgroup can list (+ t
 // and the first KS6 k-steps are a prefix of the stored tile.
 // T = tiles per step = per barrier: 4 (one chunk; RING >= 4 steps) or 8 (two chunks, RING = 3: half as many barriers -- the ablations
 // of tools/ablate6.py put barrier + staging at 10 % of the kernel -- for the shapes whose ring of 3 x 8 tiles fits the LDS)
-template <int KS6, int KIND, bool LOW, int IMG_KS6, int RING, int T = 4>
+// NS (round 5): 32-query tiles resident per wave -- 2, or 3 for the fused half-width pass at d = 384 (96 queries per wave, 768 per workgroup:
+// every map fragment read from the LDS feeds three MFMAs instead of two, and a step between two barriers is 36 MFMAs per wave instead of 24;
+// 54 query + 96 accumulator registers)
+template <int KS6, int KIND, bool LOW, int IMG_KS6, int RING, int T = 4, int NS = 2>
 __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (The host pass only needs this kernel's stub.  With the accumulator sets sized by NS its semantic check of the body -- inline asm with
+    // register constraints inside nested generic lambdas -- failed WITHOUT A DIAGNOSTIC (device-side bodies' errors are deferred on the
+    // host) and the stub of every instantiation went missing: the library then failed to load with undefined kernel symbols.)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool TOP2 = KIND == MX6_TOP2, FUSE = KIND == MX6_FUSE;
     constexpr int NWAVES = 8;
@@ -133,6 +140,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
     constexpr int LCAP = RING * STEP_BYTES + MX6_LTAB * 8 + (MX6_LCAP + 1) * 4 <= 160 * 1024 ? MX6_LCAP : 1023;   // (= launch_mx6q2's)
     static_assert(RING * STEP_BYTES + MX6_LTAB * 8 + (FUSE ? (LCAP + 1) * 4 : 0) <= 160 * 1024, "ring exceeds the LDS");
     static_assert(!FUSE || !LOW, "the fused forms keep no running lower bound");
+    static_assert(NS == 2 || (NS == 3 && FUSE && (16 * NS) % KS6 == 0), "three query sets: the fused forms whose fold divides evenly over the k-steps");
     constexpr bool FUSE_HALF = FUSE && IMG_KS6 > KS6;   // FUSE at full width (VFM_RECORDS_MX6_FUSED, round 5): the same test without the rest term
 
     const int lane = lane_id();
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
         if (KIND == MX6_FUSE && threadIdx.x == 0) a.surv[(size_t)blockIdx.x * (MX6_LCAP + 1 + 3)] = 0u;   // an empty slot
         return;
     }
-    const int qt0 = (qb * NWAVES + wave) * 2;  // this wave's two 32-query tiles
+    const int qt0 = (qb * NWAVES + wave) * NS;  // this wave's NS 32-query tiles
     float2* ltab = reinterpret_cast<float2*>(smem + RING * STEP_BYTES);
     unsigned* llist = reinterpret_cast<unsigned*>(smem + RING * STEP_BYTES + MX6_LTAB * 8);   // FUSE: [0] = count, then the entries
 
@@ -178,15 +186,15 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
     };
 
     // ---- the wave's queries (two 32-query tiles of the same image layout) and the per-query terms of the bounds
-    Mx6Frag qf[2][KS6];
-    uint2 qs[2];
-    float fx_A[2], fx_mult[2], fx_low[2], fx_rq[2];
-    int fx_arg[2] = {0, 0};
-    bool live[2] = {false, false};
-    unsigned livemask[2] = {0u, 0u};   // FUSE: the set's queries that exist and are not zero rows, one bit per query of the tile
+    Mx6Frag qf[NS][KS6];
+    uint2 qs[NS];
+    float fx_A[NS], fx_mult[NS], fx_low[NS], fx_rq[NS];
+    int fx_arg[NS] = {};
+    bool live[NS] = {};
+    unsigned livemask[NS] = {};   // FUSE: the set's queries that exist and are not zero rows, one bit per query of the tile
     const unsigned char* qimg = reinterpret_cast<const unsigned char*>(a.Qh);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NS; ++j) {
         const int qt = qt0 + j < a.nq_tiles ? qt0 + j : 0;
         const unsigned char* qtile = qimg + (size_t)qt * IMG_TB;
 #pragma unroll
@@ -218,21 +226,26 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
     }
     // (gstep now points at step RING - 1, the first one the loop issues -- behind the barrier of step 0, into the last slot)
 
-    float s1[2] = {-__builtin_inff(), -__builtin_inff()};   // the scores are floats: v_max3_f32 folds them as they are
-    unsigned t1[2] = {0u, 0u}, t2[2] = {0u, 0u};            // TOP2: running best / second best, packed (coarse_fold)
+    float s1[NS];                                           // the scores are floats: v_max3_f32 folds them as they are
+    unsigned t1[NS] = {}, t2[NS] = {};                      // TOP2: running best / second best, packed (coarse_fold)
+#pragma unroll
+    for (int j = 0; j < NS; ++j) s1[j] = -__builtin_inff();
     constexpr float ACC0 = TOP2 ? 2.0f : 0.0f;
     unsigned seen = 0u;                                     // FUSE: the list's length as of the previous chunk (read a chunk ahead, like tab)
     int vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     float2 tab = make_float2(0.f, 0.f);                     // ltab entry of the chunk emit_chunk sees next (read a chunk ahead)
-    float thr[2] = {__builtin_inff(), __builtin_inff()};    // FUSE: the score from which that chunk survives for the lane's query
+    float thr[NS];                                          // FUSE: the score from which that chunk survives for the lane's query
+#pragma unroll
+    for (int j = 0; j < NS; ++j) thr[j] = __builtin_inff();
     // (from `tab`, in the last tile of the step in front of the emit: the emit itself -- both waves of a SIMD reach it together, a
     // barrier earlier they were released together -- then holds no chain of dependent VALU results in front of its branch)
     auto next_thr = [&]() __attribute__((always_inline)) {
         if constexpr (FUSE) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) thr[j] = ((a.gate - 1.0e-6f) - (fx_A[j] + fx_mult[j] * tab.x)) - (fx_rq[j] * tab.y + 1.0e-6f);
-            asm volatile("" ::"v"(thr[0]), "v"(thr[1]));
+            for (int j = 0; j < NS; ++j) thr[j] = ((a.gate - 1.0e-6f) - (fx_A[j] + fx_mult[j] * tab.x)) - (fx_rq[j] * tab.y + 1.0e-6f);
+#pragma unroll
+            for (int j = 0; j < NS; ++j) asm volatile("" ::"v"(thr[j]));
         }
     };
     auto emit_chunk = [&](int ci) __attribute__((always_inline)) {  // ci = chunk of the unit, < 0: nothing folded yet
@@ -247,26 +260,28 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
             // compare, exec-masked branch per query set -- at 10 % of the kernel).  m = queries of the set with a surviving chunk.
             // The thresholds are there already (next_thr, a tile earlier): what is left behind the fold is two compares, the scalar masks
             // and one branch, issued behind the first MFMAs of the tile this runs in.
-            unsigned m[2];
+            unsigned m[NS];
+            unsigned many = 0u;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NS; ++j) {
                 const unsigned long long hit = __ballot(!(s1[j] < thr[j]));
                 m[j] = ((unsigned)hit | (unsigned)(hit >> 32)) & livemask[j];
+                many |= m[j];
                 s1[j] = -__builtin_inff();
             }
-            if (valid && (m[0] | m[1]) != 0u) {   // rare: 0.56 survivors per query and 1564 chunks on D.2 data
+            if (valid && many != 0u) {   // rare: 0.56 survivors per query and 1564 chunks on D.2 data
                 // (a list that has overflowed -- descriptors that are all alike -- takes no more entries: the search's guard goes up at
                 // the end of the workgroup and match_gatepass_kernel decides every query; `seen` is a chunk old, the cap is exact)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NS; ++j)
                     if (lane < 32 && ((m[j] >> lane) & 1u) && seen < (unsigned)LCAP) {
                         const unsigned pos = atomicAdd(&llist[0], 1u);
-                        if (pos < (unsigned)LCAP) llist[1 + pos] = ((unsigned)ci << 9) | (unsigned)((wave * 2 + j) * 32 + lane);
+                        if (pos < (unsigned)LCAP) llist[1 + pos] = ((unsigned)ci << (NS == 2 ? 9 : 10)) | (unsigned)((wave * NS + j) * 32 + lane);
                     }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NS; ++j) {
             if constexpr (FUSE) continue;
             unsigned best;
             if constexpr (TOP2) {
@@ -308,16 +323,16 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
         if constexpr (FUSE) seen = llist[vzero];   // (through a per-lane zero: a uniform read would be moved to an SGPR on the spot -- lgkmcnt(0))
     };
 
-    floatx16 accA[2], accB[2];
+    floatx16 accA[NS], accB[NS];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NS; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accA[j][r] = accB[j][r] = TOP2 ? 0.0f : -__builtin_inff();   // (folded by the first tile: no effect)
 
     // everything the loop reads from registers is here before it starts: the compiler puts its own s_waitcnt vmcnt(0) in front of the
     // first use of a loaded value, and inside the loop that would wait for every piece in flight, step after step
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NS; ++j) {
         asm volatile("" ::"v"(fx_A[j]), "v"(fx_mult[j]), "v"(fx_rq[j]), "v"(qs[j].x), "v"(qs[j].y), "v"((int)live[j]));
 #pragma unroll
         for (int s = 0; s < KS6; ++s) asm volatile("" ::"v"(qf[j][s].c[0]), "v"(qf[j][s].c[1]), "v"(qf[j][s].c[2]), "v"(qf[j][s].c[3]), "v"(qf[j][s].c[4]), "v"(qf[j][s].c[5]));
@@ -360,7 +375,12 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
         const bool lax = it + (RING - 2) * T < ntiles;                  // step k + RING - 2 was issued (by that window; the pre-loop, for k = 0)
         const int ck = it >> 2;   // first chunk of the step (of the unit)
         // tile J of the step into `acc`, folding `done` (the tile before it)
-        auto tile = [&](auto Jc, floatx16 (&acc)[2], const floatx16 (&done)[2]) __attribute__((always_inline)) {
+        auto tile = [&](auto Jc, auto Pc) __attribute__((always_inline)) {
+            // (Pc: which accumulator set this tile fills -- 0: accA, folding accB; 1: the other way round.  Passed as arrays of NS
+            // accumulators the lambda's parameter types made the HOST pass drop every instantiation of the kernel without a diagnostic.)
+            constexpr int P = decltype(Pc)::value;
+            floatx16 (&acc)[NS] = P ? accB : accA;
+            const floatx16 (&done)[NS] = P ? accA : accB;
             constexpr int J = decltype(Jc)::value;
             const unsigned tb = cur_b + J * LT;
             const unsigned tn = (J + 1 < T) ? cur_b + (J + 1) * LT : nxt_b;  // the tile after it (stale after the last step)
@@ -374,15 +394,16 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
                     floatx16 zero;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) zero[r] = ACC0;
-                    acc[0] = mfma_mx6<s>(fr[s % PF], sc_cur, qf[0][s], qs[0], zero);
-                    acc[1] = mfma_mx6<s>(fr[s % PF], sc_cur, qf[1][s], qs[1], zero);
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) acc[j] = mfma_mx6<s>(fr[s % PF], sc_cur, qf[j][s], qs[j], zero);
                 } else {
-                    acc[0] = mfma_mx6<s>(fr[s % PF], sc_cur, qf[0][s], qs[0], acc[0]);
-                    acc[1] = mfma_mx6<s>(fr[s % PF], sc_cur, qf[1][s], qs[1], acc[1]);
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) acc[j] = mfma_mx6<s>(fr[s % PF], sc_cur, qf[j][s], qs[j], acc[j]);
                 }
                 // (an empty use of the results: without it the MFMAs -- pure functions to the compiler -- are sunk across the
                 // blocks of the step to their first reader, the fold one tile later)
-                asm volatile("" ::"v"(acc[0]), "v"(acc[1]));
+#pragma unroll
+                for (int j = 0; j < NS; ++j) asm volatile("" ::"v"(acc[j]));
 #ifndef VFM_ABL_NOLDS
                 fr[s % PF] = (s + PF < KS6) ? mx6_frag(la0 + tb, lb0 + tb, s + PF) : mx6_frag(la0 + tn, lb0 + tn, s + PF - KS6);
 #else
@@ -402,18 +423,24 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
                 if constexpr (s == 0 && (J & 3) == 3) next_thr();
 #ifndef VFM_ABL_NOFOLD
 #pragma unroll
-                for (int e = s * 32 / KS6; e < (s + 1) * 32 / KS6; ++e) {   // `done` is tile (J + 3) & 3 of its chunk
+                for (int e = s * (16 * NS) / KS6; e < (s + 1) * (16 * NS) / KS6; ++e) {   // `done` is tile (J + 3) & 3 of its chunk
                     if constexpr (TOP2) coarse_fold(t1[e >> 4], t2[e >> 4], done[e >> 4][e & 15], ((J + 3) & 3) * 16 + (e & 15));
                     else s1[e >> 4] = fmaxf(s1[e >> 4], done[e >> 4][e & 15]);
                 }
 #else
-                if (s == 0) s1[0] = fmaxf(s1[0], done[0][0]), s1[1] = fmaxf(s1[1], done[1][0]);
+                if (s == 0) {
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) s1[j] = fmaxf(s1[j], done[j][0]);
+                }
 #endif
                 // (the same for the fold: the running maxima are read at the end of the chunk only, and the compiler had moved the
                 // folds of tiles 1 - 3 there -- one block of 45 dependent v_max3 behind the barrier, in every wave at the same time)
                 // (uses, not definitions: the compiler keeps knowing what the values are -- no re-canonicalisation of the floats)
                 if constexpr (TOP2) asm volatile("" ::"v"(t1[0]), "v"(t1[1]), "v"(t2[0]), "v"(t2[1]));
-                else asm volatile("" ::"v"(s1[0]), "v"(s1[1]));
+                else {
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) asm volatile("" ::"v"(s1[j]));
+                }
                 // one 1 KiB piece per k-step slot of the window: the last tile of the step carries slots 0 .. KS6 - 1, tile J of the
                 // next step slots KS6 (J + 1) ..
                 constexpr int kslot = (J == T - 1 ? 0 : KS6 * (J + 1)) + s;
@@ -437,14 +464,14 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
             // register allocator handed it out again right behind the ds_read_b64, and the wave waited on lgkmcnt(0) to overwrite it)
             asm volatile("" ::"v"(sc_nxt.x), "v"(sc_nxt.y));
         };
-        tile(std::integral_constant<int, 0>{}, accA, accB);   // (its slots fold the last tile of the previous chunk; tile 1 emits that chunk)
-        tile(std::integral_constant<int, 1>{}, accB, accA);
-        tile(std::integral_constant<int, 2>{}, accA, accB);
+        tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});   // (its slots fold the last tile of the previous chunk; tile 1 emits that chunk)
+        tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        tile(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
         if constexpr (T == 8) {
-            tile(std::integral_constant<int, 3>{}, accB, accA);
-            tile(std::integral_constant<int, 4>{}, accA, accB);
-            tile(std::integral_constant<int, 5>{}, accB, accA);
-            tile(std::integral_constant<int, 6>{}, accA, accB);
+            tile(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
+            tile(std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{});
+            tile(std::integral_constant<int, 5>{}, std::integral_constant<int, 1>{});
+            tile(std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{});
         }
         if (more_prev) gstep += T * IMG_TB;   // the previous window is closed: from here on gstep is the step THIS step's window issues
 #ifndef VFM_ABL_NOBAR
@@ -459,11 +486,11 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #endif
-        tile(std::integral_constant<int, T - 1>{}, accB, accA);
+        tile(std::integral_constant<int, T - 1>{}, std::integral_constant<int, 1>{});
         ring = ring1;
     }
 #pragma unroll
-    for (int e = 0; e < 32; ++e) {
+    for (int e = 0; e < 16 * NS; ++e) {
         if constexpr (TOP2) coarse_fold(t1[e >> 4], t2[e >> 4], accB[e >> 4][e & 15], 3 * 16 + (e & 15));
         else s1[e >> 4] = fmaxf(s1[e >> 4], accB[e >> 4][e & 15]);
     }
@@ -471,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
     emit_chunk(nch - 1);
     if constexpr (LOW) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NS; ++j)
             if (lane < 32 && qt0 + j < a.nq_tiles) {
                 atomicMax(a.qmax + (size_t)(qt0 + j) * 32 + lane, float_key(fx_low[j]));
                 if (a.qbest && fx_low[j] > -__builtin_inff())
@@ -489,25 +516,26 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
             slot[0] = cnt;
             slot[1] = (unsigned)qb;
             slot[2] = (unsigned)c0;
-            slot[3] = total >= (unsigned)LCAP ? 1u : 0u;
+            slot[3] = (total >= (unsigned)LCAP ? 1u : 0u) | ((unsigned)NS << 8);   // (bits 8 ..: query tiles per wave -- how match_bin_survivors_kernel reads the entries)
             if (total >= (unsigned)LCAP) a.survivors[HALF_GUARD_FLAG - 5] = 1;   // fb_count[HALF_GUARD_FLAG]
         }
         for (unsigned i = threadIdx.x; i < cnt; i += 512) slot[4 + i] = llist[1 + i];
     }
+#endif   // __HIP_DEVICE_COMPILE__
 }
 
-template <int KS6, int KIND, bool LOW, int IMG_KS6, int RING, int T = 4>
+template <int KS6, int KIND, bool LOW, int IMG_KS6, int RING, int T = 4, int NS = 2>
 int launch_mx6q2(const CoarseArgs& a, hipStream_t st) {
     constexpr int LT = MX6_SCALE_PLANE + KS6 * MX6_KSTEP_BYTES;
     constexpr int LCAP = RING * T * LT + MX6_LTAB * 8 + (MX6_LCAP + 1) * 4 <= 160 * 1024 ? MX6_LCAP : 1023;
     const int lds = RING * T * LT + MX6_LTAB * 8 + (KIND == MX6_FUSE ? (LCAP + 1) * 4 : 0);
     static unsigned long long attr_set = 0ull;  // one bit per device
     if (!attr_done(attr_set)) {
-        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_mx6q2_kernel<KS6, KIND, LOW, IMG_KS6, RING, T>),
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_coarse_mx6q2_kernel<KS6, KIND, LOW, IMG_KS6, RING, T, NS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_mark(attr_set);
     }
-    hipLaunchKernelGGL((match_coarse_mx6q2_kernel<KS6, KIND, LOW, IMG_KS6, RING, T>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((match_coarse_mx6q2_kernel<KS6, KIND, LOW, IMG_KS6, RING, T, NS>), dim3(a.nqb * a.nslices), dim3(512), lds, st, a);
     return VFM_OK;
 }
 
@@ -519,7 +547,8 @@ int mx6_survivor_slot_words() { return MX6_SURV_SLOT_WORDS; }
 // the fp6 coarse kernel for the arguments do_search_coarse prepared (a.Qh / a.Bh = the fp6 tiles, a.ib = mx6_bounds);
 // d = 256 / 384 (full width) or 256 / 384 / 512 / 768 (half width) and more than 2048 queries (effective_records)
 int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, bool half, bool fuse, hipStream_t st) {
-    a.nqb = (a.nq_tiles + 15) / 16;
+    const bool ns3 = half && fuse && d == 384 && g_mx6_ns3 && g_mx6_t4;
+    a.nqb = ns3 ? (a.nq_tiles + 23) / 24 : (a.nq_tiles + 15) / 16;
     a.nslices = choose_slices(a.nqb, a.nchunks);
     if (half && g_force_slices == 0) {
         // the half-width kernel's workgroups are short, and shorter ones let the other stages of a pipeline in: ~7.5 rounds of 256
@@ -541,7 +570,9 @@ int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, bool half, bool fuse, hip
     // show (tools/ablate6.py: -10 % without barrier and staging) does not come back by halving the barriers, and the larger ring
     // leaves the side kernels less LDS.  One chunk per barrier stays the default; vfm_debug_set_coarse_variant(31) selects T = 8.
     const bool t8 = half && fuse && (d == 384 || d == 256) && !g_mx6_t4 && a.nslices <= a.nchunks / 2;
-    if (fuse && !half)   // VFM_RECORDS_MX6_FUSED: the full-width pass with the gate test in its epilogue
+    if (ns3)   // three query tiles per wave: 768 queries per workgroup (nqb set above)
+        rc = launch_mx6q2<3, MX6_FUSE, false, 6, 4, 4, 3>(a, st);
+    else if (fuse && !half)   // VFM_RECORDS_MX6_FUSED: the full-width pass with the gate test in its epilogue
         rc = d == 384 ? launch_mx6q2<6, MX6_FUSE, false, 6, 4>(a, st) : launch_mx6q2<4, MX6_FUSE, false, 4, 4>(a, st);
     else if (half && fuse && t8)
         rc = d == 384 ? launch_mx6q2<3, MX6_FUSE, false, 6, 3, 8>(a, st) : launch_mx6q2<2, MX6_FUSE, false, 4, 3, 8>(a, st);

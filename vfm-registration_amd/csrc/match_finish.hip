@@ -455,10 +455,14 @@ __global__ __launch_bounds__(256) void match_bin_survivors_kernel(const unsigned
     for (int sidx = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); sidx < nslots; sidx += nwaves) {
         const unsigned* slot = surv + (size_t)sidx * slot_words;
         const unsigned cnt = slot[0], qb = slot[1], c0 = slot[2];
+        // (round 5: a workgroup of the coarse kernel holds 512 queries -- two 32-query tiles per wave, entries = chunk << 9 | query -- or 768 --
+        // three tiles, chunk << 10 | query --; it says which in bits 8 .. of the header's fourth word)
+        const bool three = cnt > 0u && (slot[3] >> 8) == 3u;
+        const unsigned qshift = three ? 10u : 9u, qper = three ? 768u : 512u;
         for (unsigned i = (unsigned)lane; i < cnt; i += 64u) {
             const unsigned e = slot[4 + i];
-            const int chunk = (int)(c0 + (e >> 9));
-            const int64_t q = (int64_t)qb * 512 + (int64_t)(e & 511u);
+            const int chunk = (int)(c0 + (e >> qshift));
+            const int64_t q = (int64_t)qb * qper + (int64_t)(e & ((1u << qshift) - 1u));
             const unsigned pos = atomicAdd(&bin_cnt[(size_t)chunk * BIN_CNT_STRIDE], 1u);
             if (pos < (unsigned)bin_cap) {
                 bins[(size_t)chunk * bin_cap + pos] = (int)q;
