@@ -1074,10 +1074,11 @@ def main():
         achieved = flops / (coarse_ms * 1e-3) / 1e12
         peak = MFMA_F6_PEAK_TFLOPS if half6 else (MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS)
         fused6 = half6 and records_kind == 8
-        kernel = ((f"match_coarse_mx6q2_kernel<{kcols // 64}, {'MX6_FUSE' if fused6 else 'MX6_BEST'}, false, {d // 64}, 4> (v_mfma_scale_f32_32x32x64_f8f6f4 on "
+        ns3 = fused6 and d == 384   # (round 5: three 32-query tiles per wave in the fused half-width kernel at d = 384)
+        kernel = ((f"match_coarse_mx6q2_kernel<{kcols // 64}, {'MX6_FUSE' if fused6 else 'MX6_BEST'}, false, {d // 64}, 4, 4, {3 if ns3 else 2}> (v_mfma_scale_f32_32x32x64_f8f6f4 on "
                    f"microscaled fp6 -- e2m3 elements, one power-of-two scale per 32 columns -- over the first {kcols} of {d} columns: the half-width pass "
                    "in fp6; the other half is bounded by Cauchy-Schwarz against the cosine gate, the image's quantisation by its measured residual "
-                   "norms, and only surviving chunks are scored over all columns (int8 MFMA rescan, fp32 refinement, fp64 decision); 64 resident "
+                   "norms, and only surviving chunks are scored over all columns (int8 MFMA rescan, fp32 refinement, fp64 decision); " + ("96" if ns3 else "64") + " resident "
                    "queries per wave, " + ("survivors of the bound listed by the kernel itself (no records)" if fused6 else "one best-score record per (query, chunk)") + ")") if half6
                   else (f"match_coarse_i8q2_kernel<{kcols // 32}> (int8 32x32x32 MFMA over the first {kcols} of {d} columns -- the half-width pass: the "
                    "other half is bounded by Cauchy-Schwarz against the cosine gate and only surviving chunks are scored over all columns -- "
