@@ -310,6 +310,15 @@ int vfm_ransac_corr(const double *src, const double *tgt, const int32_t *corres,
                     uint64_t seed, double *T_out, double *fitness_out, double *rmse_out,
                     uint8_t *inlier_mask, int32_t *best_hyp_out, void *ws, size_t ws_bytes,
                     vfm_stream_t stream);
+/* The same with the index check Open3D makes on the host (an out-of-range correspondence index raises there) done by the kernel that
+ * gathers the point pairs: src has ns rows, tgt nt; *bad_out (device int32, ZERO before the call) becomes 1 if an index of the
+ * first count rows of corres is negative or beyond its cloud -- that entry is read as row 0 and the caller discards the result (one
+ * read-back with the pose instead of a min / max pass and a read-back in front of the search for the pose). */
+int vfm_ransac_corr_bounded(const double *src, int64_t ns, const double *tgt, int64_t nt, const int32_t *corres,
+                            const int64_t *count_dev, int64_t c_max, double max_dist, int32_t n_iter,
+                            uint64_t seed, double *T_out, double *fitness_out, double *rmse_out,
+                            uint8_t *inlier_mask, int32_t *best_hyp_out, int32_t *bad_out, void *ws,
+                            size_t ws_bytes, vfm_stream_t stream);
 
 /* Eigen::umeyama(with_scaling=false) / pointdsc.common.rigid_transform_3d
  * (src/vfm-reg/src/pointdsc/common.py:7-47), batched: A, B b x n x 3, w b x n or NULL,

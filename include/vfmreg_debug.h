@@ -61,6 +61,10 @@ int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
  * container's order.  2 / 3: the per-cluster replay of a generation as in round 4 (a radix sort by (cluster, arrival) in front of a
  * global-memory replay) / as in round 5 (3, default: the replay sorts its cluster and runs in the LDS) */
 int vfm_debug_set_voxel_small(int on);
+/* tools: wall-clock stamps (100 MHz) workgroup 0 of the one-launch VoxelDownsample kernel took behind each of its grid-wide barriers
+ * during the last vfm_voxel_robin in `ws` (n as at that call; recorded while vfm_debug_set_voxel_small(101) is in force, 100 = off);
+ * out_host: HOST int64[32], [31] = number of stamps.  Synchronises the device. */
+int vfm_debug_voxel_trace(void *ws, int64_t n, int64_t *out_host);
 /* A/B: workgroups of the int8 operand-preparation kernel (-1, default = one per 128-row group; 0 = one per compute unit, each
  * walking several groups with the next group's rows read under the current group's quantisation and store: faster alone,
  * slower beside the coarse kernel; n > 0 = n workgroups) */

@@ -92,6 +92,31 @@ def test_open3d_standin_ransac(orc):
     with pytest.raises(NotImplementedError):
         o3d.pipelines.registration.registration_ransac_based_on_correspondence(
             pcd_src, pcd_tgt, corr, 0.5, criteria=o3d.pipelines.registration.RANSACConvergenceCriteria(10, 0.999))
+    # device-resident clouds and indices (what RegistrationNode hands over): the same result, and the index check Open3D makes on the
+    # host is made by the kernel that gathers the point pairs (vfm_ransac_corr_bounded) -- an index outside its cloud raises here too
+    import torch
+    dsrc, dtgt = o3d.geometry.PointCloud(), o3d.geometry.PointCloud()
+    dsrc.points = o3d.utility.Vector3dVector(o3d.utility.DeviceArray(torch.from_numpy(src).cuda()))
+    dtgt.points = o3d.utility.Vector3dVector(o3d.utility.DeviceArray(torch.from_numpy(tgt).cuda()))
+    dcorr = torch.from_numpy(corr.astype(np.int32)).cuda()
+    o3d.utility.random.seed(42)
+    rd = o3d.pipelines.registration.registration_ransac_based_on_correspondence(
+        dsrc, dtgt, o3d.utility.Vector2iVector(o3d.utility.DeviceArray(dcorr)), 0.5,
+        criteria=o3d.pipelines.registration.RANSACConvergenceCriteria(4000, 1))
+    np.testing.assert_array_equal(np.array(rd.transformation), ref.transformation)
+    assert rd.fitness == ref.fitness and rd.inlier_rmse == ref.inlier_rmse
+    for row, col, val in ((5, 0, 900), (899, 1, -1), (17, 1, 900)):
+        bad = dcorr.clone()
+        bad[row, col] = val
+        with pytest.raises(IndexError):
+            o3d.pipelines.registration.registration_ransac_based_on_correspondence(
+                dsrc, dtgt, o3d.utility.Vector2iVector(o3d.utility.DeviceArray(bad)), 0.5,
+                criteria=o3d.pipelines.registration.RANSACConvergenceCriteria(100, 1))
+        hb = corr.copy()
+        hb[row, col] = val
+        with pytest.raises(IndexError):
+            o3d.pipelines.registration.registration_ransac_based_on_correspondence(
+                pcd_src, pcd_tgt, o3d.utility.Vector2iVector(hb), 0.5, criteria=o3d.pipelines.registration.RANSACConvergenceCriteria(100, 1))
 
 
 def test_ransac_registration_end_to_end(orc):
@@ -334,6 +359,54 @@ def test_evaluation_harness_on_a_synthetic_scene(tmp_path):
     for k in ("vfm_ransac", "vfm_ransac_icp"):
         assert ev.rot_errors[k] == ref["rot_errors"][k] and ev.trans_errors[k] == ref["trans_errors"][k], k
     assert ev.error_string().startswith("vfm_ransac\t")
+
+
+def test_kept_map_searches_take_the_half_width_pass_only_where_it_prunes(orc):
+    """VoxelHashMap.search_device on a map that is searched repeatedly: the first search probes the half-width coarse pass
+    (vfm_match_search_probe_half); descriptors whose matches stand clear of the background take it from then on, descriptors that are
+    all alike (every chunk survives the half-width bound) stay on the full-width pass -- and a map that was probed with the one kind and
+    is then searched with the other switches on the search's own load figure.  Every search equals the oracle's."""
+    import torch
+    from vfmreg import synth
+    from vfmreg.mapping import VoxelHashMap
+    VoxelHashMap.quiet = True
+    rng = np.random.default_rng(3)
+    d = 384
+    # (a) planted matches on random descriptors
+    p = synth.make_pair(1500, 40000, d, seed=5)
+    vm = VoxelHashMap(0.01, 1.0e9, 20)
+    vm.add_points(np.c_[p["b_xyz"], p["b_desc"]].astype(np.float32))
+    mp = vm.point_cloud_n()
+    q = p["q_desc"].astype(np.float32)
+    qd = torch.from_numpy(q).cuda()
+    for _ in range(2):
+        qi, mi, _ = vm.search_device(None, 0.8, q_desc=qd)
+        _, _, qr, mr, _ = orc.get_vfm_correspondences(np.c_[p["q_xyz"], q], mp, 0.8)
+        np.testing.assert_array_equal(qi.cpu().numpy(), qr)
+        np.testing.assert_array_equal(mi.cpu().numpy(), mr)
+    assert vm._half is True
+    # (b) the same map searched by descriptors that are all alike (a large common component): the load figure of the half-width search
+    #     is over the limit -- the guard decides that search, the next ones run at full width
+    common = rng.standard_normal(d).astype(np.float32)
+    alike = (0.25 * rng.standard_normal((1500, d)) + common).astype(np.float32)
+    vm2 = VoxelHashMap(0.01, 1.0e9, 20)
+    bd = (0.25 * rng.standard_normal((40000, d)) + common).astype(np.float32)
+    bx = rng.uniform(-500, 500, (40000, 3)).astype(np.float32)
+    vm2.add_points(np.c_[bx, bd])
+    mp2 = vm2.point_cloud_n()
+    ad = torch.from_numpy(alike).cuda()
+    _, _, qr, mr, _ = orc.get_vfm_correspondences(np.c_[np.zeros((1500, 3), np.float32), alike], mp2, 0.8)
+    assert len(qr) > 1000
+    qi, mi, _ = vm2.search_device(None, 0.8, q_desc=ad)
+    assert vm2._half is False                       # probed: no half-width pass on this map
+    np.testing.assert_array_equal(qi.cpu().numpy(), qr)
+    np.testing.assert_array_equal(mi.cpu().numpy(), mr)
+    vm2._half = True                                # (as if the probe had seen a scan that prunes)
+    for expect in (False, False):
+        qi, mi, _ = vm2.search_device(None, 0.8, q_desc=ad)
+        np.testing.assert_array_equal(qi.cpu().numpy(), qr)
+        np.testing.assert_array_equal(mi.cpu().numpy(), mr)
+        assert vm2._half is expect
 
 
 def test_ransac_registration_keeps_the_scene_map_between_scans(orc):

@@ -158,10 +158,11 @@ def test_voxel_hash_map_caps_points_per_voxel():
 
 
 def test_one_launch_downsample_equals_the_general_path_and_the_oracle():
-    """voxel_robin_small_kernel (round 5: VoxelDownsample of up to 2^18 points in one launch -- the last workgroup to finish the first-point
-    table goes on alone: counting sort by home bucket, clusters, per-cluster replay) against the general multi-launch path and the
-    oracle's robin-map replay: sizes on both sides of a workgroup's worth of points, dense and sparse tables, duplicates, the chained
-    voxelisations of registration_node.py:399-414, tables whose last cluster wraps."""
+    """voxel_robin_grid_kernel (round 5: VoxelDownsample of up to 2^18 points in one launch -- up to 256 resident workgroups walk through
+    first-point table, counting sort by home bucket, clusters and the per-cluster replay together, grid-wide barriers between the
+    phases) against the general multi-launch path and the oracle's robin-map replay: sizes on both sides of a workgroup's worth of
+    points, dense and sparse tables, duplicates, the chained voxelisations of registration_node.py:399-414, tables whose last cluster
+    wraps (clusters beyond the kernel's limit fall back to the general path)."""
     from oracle import oracle as orc
     from vfmreg import _lib, ops
     lib = _lib.load()
@@ -216,7 +217,48 @@ def test_one_launch_downsample_equals_the_general_path_and_the_oracle():
             wrapped += int(oinfo[3] > 0)
         assert wrapped >= 3, wrapped
     finally:
-        lib.vfm_debug_set_voxel_small(0)
+        lib.vfm_debug_set_voxel_small(1)
+
+
+def test_one_launch_downsample_from_several_threads_beside_other_work():
+    """The one-launch kernel's grid-wide barriers need all of its workgroups resident: four host threads, each on a stream of its own,
+    down-sample clouds of different sizes at once while a fifth stream keeps the device busy with large products; every result equals
+    the oracle's (a grid that could not become resident would raise the kernel's abort flag and take the general path -- still the
+    same order)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    from vfmreg import ops
+    rng = np.random.default_rng(5)
+    clouds = [rng.uniform(-60, 60, (n, 3)) * [1, 1, 0.15] for n in (20000, 60000, 1700, 131072)]
+    refs = [orc.voxel_robin(c, 0.5) for c in clouds]
+    dev = [torch.from_numpy(c).cuda() for c in clouds]
+    busy = torch.randn(8192, 8192, device="cuda")
+    stop = []
+
+    def load():
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            while not stop:
+                (busy @ busy).sum().item()
+
+    def work(k):
+        st = torch.cuda.Stream()
+        outs = []
+        with torch.cuda.stream(st):
+            for _ in range(15):
+                outs.append(ops.voxel_robin(dev[k], 0.5).cpu().numpy())
+        return outs
+
+    torch.cuda.synchronize()
+    with ThreadPoolExecutor(5) as ex:
+        bg = ex.submit(load)
+        futs = [ex.submit(work, k) for k in range(4)]
+        res = [f.result() for f in futs]
+        stop.append(1)
+        bg.result()
+    for k in range(4):
+        for o in res[k]:
+            np.testing.assert_array_equal(o, refs[k])
 
 
 def test_replay_in_the_lds_equals_the_replay_behind_a_radix_sort():
@@ -229,6 +271,7 @@ def test_replay_in_the_lds_equals_the_replay_behind_a_radix_sort():
     lib = _lib.load()
     rng = np.random.default_rng(91)
     try:
+        lib.vfm_debug_set_voxel_small(0)   # (the general path: the one-launch kernel would take the down-sampling cases)
         for n, extent, vs, K, reserve in [(700, 10.0, 0.5, 1, True), (20000, 60.0, 0.5, 1, True), (120000, 60.0, 0.25, 1, True),
                                           (8000, 3.0, 1.0, 20, False), (200000, 60.0, 1.0, 20, False), (400000, 80.0, 0.5, 1, True)]:
             pts = rng.uniform(-extent, extent, (n, 3)) * [1, 1, 0.15]
@@ -243,3 +286,4 @@ def test_replay_in_the_lds_equals_the_replay_behind_a_radix_sort():
             np.testing.assert_array_equal(outs[1], ref, err_msg=str((n, K, "replay in the LDS")))
     finally:
         lib.vfm_debug_set_voxel_small(3)
+        lib.vfm_debug_set_voxel_small(1)

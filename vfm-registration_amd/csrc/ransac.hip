@@ -186,11 +186,16 @@ __device__ __forceinline__ double err2(const double T[12], double sx, double sy,
 __global__ __launch_bounds__(256) void ransac_gather_kernel(const double* __restrict__ src, const double* __restrict__ tgt,
                                                             const int32_t* __restrict__ corres,
                                                             const int64_t* __restrict__ count_dev, int64_t c_max,
-                                                            double* __restrict__ pts) {
+                                                            double* __restrict__ pts, int64_t ns, int64_t nt,
+                                                            int32_t* __restrict__ bad_out) {
     const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= C) return;
-    const int64_t a = corres[2 * i], b = corres[2 * i + 1];
+    int64_t a = corres[2 * i], b = corres[2 * i + 1];
+    if (bad_out && (a < 0 || a >= ns || b < 0 || b >= nt)) {   // vfm_ransac_corr_bounded: flagged, read as row 0
+        *bad_out = 1;
+        a = b = 0;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         pts[6 * i + c] = src[3 * a + c];
@@ -1006,10 +1011,32 @@ VFM_EXPORT int vfm_debug_ransac_counts(const void* ws, int64_t c_max, int32_t n_
 
 VFM_EXPORT size_t vfm_ransac_workspace_bytes(int64_t c_max, int32_t n_iter) { return carve_ransac(nullptr, c_max, n_iter).bytes; }
 
+namespace {
+int ransac_corr_impl(const double* src, int64_t ns, const double* tgt, int64_t nt, const int32_t* corres, const int64_t* count_dev,
+                     int64_t c_max, double max_dist, int32_t n_iter, uint64_t seed, double* T_out, double* fitness_out,
+                     double* rmse_out, uint8_t* inlier_mask, int32_t* best_hyp_out, int32_t* bad_out, void* ws, size_t ws_bytes,
+                     vfm_stream_t stream);
+}
 VFM_EXPORT int vfm_ransac_corr(const double* src, const double* tgt, const int32_t* corres, const int64_t* count_dev,
                                int64_t c_max, double max_dist, int32_t n_iter, uint64_t seed, double* T_out,
                                double* fitness_out, double* rmse_out, uint8_t* inlier_mask, int32_t* best_hyp_out,
                                void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    return ransac_corr_impl(src, 0, tgt, 0, corres, count_dev, c_max, max_dist, n_iter, seed, T_out, fitness_out, rmse_out, inlier_mask,
+                            best_hyp_out, nullptr, ws, ws_bytes, stream);
+}
+VFM_EXPORT int vfm_ransac_corr_bounded(const double* src, int64_t ns, const double* tgt, int64_t nt, const int32_t* corres,
+                                       const int64_t* count_dev, int64_t c_max, double max_dist, int32_t n_iter, uint64_t seed,
+                                       double* T_out, double* fitness_out, double* rmse_out, uint8_t* inlier_mask,
+                                       int32_t* best_hyp_out, int32_t* bad_out, void* ws, size_t ws_bytes, vfm_stream_t stream) {
+    VFM_CHECK_ARG(bad_out && ns > 0 && nt > 0, "ransac: bad_out / cloud sizes");
+    return ransac_corr_impl(src, ns, tgt, nt, corres, count_dev, c_max, max_dist, n_iter, seed, T_out, fitness_out, rmse_out, inlier_mask,
+                            best_hyp_out, bad_out, ws, ws_bytes, stream);
+}
+namespace {
+int ransac_corr_impl(const double* src, int64_t ns, const double* tgt, int64_t nt, const int32_t* corres, const int64_t* count_dev,
+                     int64_t c_max, double max_dist, int32_t n_iter, uint64_t seed, double* T_out, double* fitness_out,
+                     double* rmse_out, uint8_t* inlier_mask, int32_t* best_hyp_out, int32_t* bad_out, void* ws, size_t ws_bytes,
+                     vfm_stream_t stream) {
     VFM_CHECK_ARG(src && tgt && corres && T_out && fitness_out && rmse_out && best_hyp_out && ws, "ransac: null pointer");
     VFM_CHECK_ARG(c_max >= 0 && n_iter > 0, "ransac: bad sizes (c_max=%lld n_iter=%d)", (long long)c_max, n_iter);
     if (ws_bytes < vfm_ransac_workspace_bytes(c_max, n_iter)) return vfm_fail(VFM_EWORKSPACE, "ransac: workspace too small");
@@ -1021,7 +1048,7 @@ VFM_EXPORT int vfm_ransac_corr(const double* src, const double* tgt, const int32
     const int nblocks = (n_iter + 63) / 64;
     if (c_max > 0) {
         hipLaunchKernelGGL(ransac_gather_kernel, dim3((unsigned)((c_max + 255) / 256)), dim3(256), 0, st, src, tgt, corres,
-                           count_dev, c_max, w.pts);
+                           count_dev, c_max, w.pts, ns, nt, bad_out);
         VFM_CHECK_LAUNCH("ransac_gather_kernel");
     }
     if (g_ransac_exact_only) {
@@ -1061,6 +1088,7 @@ VFM_EXPORT int vfm_ransac_corr(const double* src, const double* tgt, const int32
     }
     return VFM_OK;
 }
+}  // namespace
 
 VFM_EXPORT int vfm_kabsch_batched(const double* A, const double* B, const double* w, int64_t b, int64_t n,
                                   double denom_eps, double* T_out, int32_t* valid, vfm_stream_t stream) {

@@ -415,91 +415,49 @@ __global__ __launch_bounds__(256) void robin_pointkey_kernel(const int64_t* __re
 
 // ---------------------------------------------------------------------------------- one launch for VoxelDownsample-sized clouds
 // Round 5.  The reference-shaped call chains three VoxelDownsample()s of 10^3 .. 10^5 points
-// (registration_node.py:399-414); through the general path above each is ~28 dependent launches and two read-backs (0.23 ms: launch
+// (registration_node.py:399-414); through the general path above each is ~40 dependent launches and two read-backs (0.3 ms: launch
 // latency, not work).  For ONE generation of a reserved table (reserve(n): B = 2^ceil(log2 2n) buckets, no rehash), one point per
-// voxel, this kernel does the whole of it:
-//   phase A, every workgroup: the first-point table (atomicCAS / atomicMin, as voxel_insert_kernel);
-//   the LAST workgroup to finish A (agent-scope release / acquire around a counter: nobody waits for anybody) goes on alone:
-//   B  first points in ascending order (block scan) = the voxels in arrival order, their 20-bit VoxelHash;
-//   C  the voxels counting-sorted by home bucket (histogram over the B buckets, block scan, scatter) -- ties in any order: the
-//      replay below orders a cluster's members by arrival itself;
-//   D  bucket of sorted entry i = i + running max (home_i - i): clusters, their windows, the entries that would wrap past the last
-//      bucket (then once more in coordinates rotated to a bucket that stays empty -- robin_wrap_kernel's rule);
-//   E  one thread per cluster: members sorted by arrival (insertion sort: clusters of a half-empty table are a few entries), then
-//      the container's insertions (tsl's swap rule) inside the cluster's window;
+// voxel, voxel_robin_grid_kernel does the whole of it in one launch: up to 256 workgroups of 256 threads, all resident at once, walk
+// through the phases together, a grid-wide barrier (agent-scope release -> one atomic on an arrival counter -> spin -> acquire: ~3 us)
+// where the general path has a launch boundary (~8 us) and a device-wide scan as "every workgroup's total, barrier, 256-entry prefix":
+//   0  tables and histogram cleared;  A  the first-point table (atomicCAS / atomicMin, as voxel_insert_kernel);
+//   B  first points in ascending order (grid scan) = the voxels in arrival order, their 20-bit VoxelHash, home-bucket histogram;
+//   C  the voxels counting-sorted by home bucket (grid scan of the histogram, scatter) -- ties in any order: the replay below
+//      orders a cluster's members by arrival itself;
+//   D  bucket of sorted entry i = i + running max (home_i - i) (grid max-scan): clusters, their windows, the entries that would wrap
+//      past the last bucket (then C and D once more in coordinates rotated to a bucket that stays empty -- robin_wrap_kernel's rule);
+//   E  one thread per cluster: members sorted by arrival (insertion sort: clusters of a half-empty table are a few entries), then the
+//      container's insertions (tsl's swap rule) inside the cluster's window -- in a per-thread slice of the LDS up to GRID_REPLAY_L
+//      entries, in global memory beyond;
 //   F  iteration order -> kept point indices.
-// A cluster longer than SMALLW_MAX_CLUSTER raises `fail`: the caller takes the general path.  Same container order, bit for bit
+// A cluster longer than GRID_MAX_CLUSTER raises `fail`: the caller takes the general path.  Same container order, bit for bit
 // (tests/test_gpu_voxel.py runs both paths against the oracle's robin-map replay).
-// MEASURED AND NOT ADOPTED (profiles/r05_time_api_onelaunch.txt): the part one workgroup runs alone is a chain of ~10 phases, each a
-// loop of n / 1024 .. B / 1024 dependent-latency iterations plus block scans of 20 barriers -- 0.5 ms at 20 000 points, 1.2 ms at
-// 60 000, against 0.23 / 0.25 ms for the ~28 short full-width launches of the general path (the reference-shaped call went from 1.7 to
-// 2.5 ms, from 2.2 to 5.6 ms at a 60 000-point scan).  Launch latency is cheaper than one compute unit's memory latency; the kernel
-// stays behind vfm_debug_set_voxel_small(1) with its test.
+// All workgroups must be resident for the barriers to pass: 256 x 256 threads and 48 KB of LDS each are a fraction of the chip, and a
+// workgroup that finds the chip busy is placed when the kernels in front of it retire (they do not wait for this one).  A barrier that
+// is not passed within GRID_SPIN_LIMIT polls (seconds) raises `abort`: every workgroup leaves, the host sees info[5] == 0 and takes
+// the general path.  (Round 5's first attempt let the LAST workgroup to finish phase A run B .. F alone: one compute unit's
+// dependent-latency loops, 0.5 ms at 20 000 points against 0.23 for the launches -- profiles/r05_time_api_onelaunch.txt.)
 int g_voxel_replay2 = 1;   // vfm_debug_set_voxel_small(2 / 3): round 4's replay (radix sort by cluster + global-memory replay) / round 5's (default)
-int g_voxel_small = 0;   // vfm_debug_set_voxel_small(0 / 1): the general path always (default: measured faster, see below) / the one-launch kernel where it applies
-constexpr int SMALLW_THREADS = 1024;
-constexpr int SMALLW_MAX_CLUSTER = 192;
-constexpr int64_t SMALLW_MAX_N = 1 << 18;   // points (B <= 2^19 buckets)
+int g_voxel_small = 1;     // vfm_debug_set_voxel_small(0 / 1): the general path always / the one-launch kernel where it applies (default)
+int g_voxel_trace = 0;     // vfm_debug_set_voxel_small(100 / 101): phase stamps of the one-launch kernel off / on
+int g_voxel_grid_ppt = 1;  // vfm_debug_set_voxel_small(10 + k): k points per thread of the one-launch kernel (fewer workgroups at the barriers)
+constexpr int GRID_T = 256;
+constexpr int GRID_MAX_WG = 256;
+constexpr int GRID_REPLAY_L = 16;
+constexpr int GRID_MAX_CLUSTER = 192;
+constexpr int64_t GRID_MAX_N = 1 << 18;   // points (B <= 2^19 buckets)
+constexpr unsigned GRID_SPIN_LIMIT = 1u << 22;
+constexpr int GRID_NONE = 0x7fffffff;
 
-__device__ __forceinline__ int block_scan_excl_sum(int v, int* lds, int* total) {   // 1024 threads; lds[1024]
-    const int t = threadIdx.x;
-    lds[t] = v;
-    __syncthreads();
-    for (int off = 1; off < SMALLW_THREADS; off <<= 1) {
-        const int add = t >= off ? lds[t - off] : 0;
-        __syncthreads();
-        lds[t] += add;
-        __syncthreads();
-    }
-    const int incl = lds[t];
-    if (total) *total = lds[SMALLW_THREADS - 1];
-    __syncthreads();
-    return incl - v;
-}
-__device__ __forceinline__ int block_scan_excl_max(int v, int* lds, int identity) {   // max of the values of threads < t
-    const int t = threadIdx.x;
-    lds[t] = v;
-    __syncthreads();
-    for (int off = 1; off < SMALLW_THREADS; off <<= 1) {
-        const int o = t >= off ? lds[t - off] : identity;
-        __syncthreads();
-        lds[t] = max(lds[t], o);
-        __syncthreads();
-    }
-    const int r = t > 0 ? lds[t - 1] : identity;
-    __syncthreads();
-    return r;
-}
-__device__ __forceinline__ int block_reduce_min(int v, int* lds) {
-    const int t = threadIdx.x;
-    lds[t] = v;
-    __syncthreads();
-    for (int off = SMALLW_THREADS / 2; off > 0; off >>= 1) {
-        if (t < off) lds[t] = min(lds[t], lds[t + off]);
-        __syncthreads();
-    }
-    const int r = lds[0];
-    __syncthreads();
-    return r;
-}
-
-__global__ __launch_bounds__(256) void voxel_small_init_kernel(int* __restrict__ owner, int* __restrict__ tmin, int64_t hsize,
-                                                               unsigned* __restrict__ done) {
-    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s == 0) *done = 0u;
-    if (s >= hsize) return;
-    owner[s] = EMPTY_OWNER;
-    tmin[s] = 0x7fffffff;
-}
-
-struct SmallRobinArgs {
+struct GridRobinArgs {
     const double* pts;
     int64_t n, stride;
     double vs;
     unsigned mul_y;
     int B;                 // buckets of the reserved table (power of two)
-    int* owner; int* tmin; int hmask; int* slot_of;   // first-point table (owner = -1, tmin = INT_MAX before the launch)
-    unsigned* done;        // [1] workgroups that have finished phase A (0 before the launch)
+    int* owner; int* tmin; int hsize; int* slot_of;   // first-point table
+    unsigned* ctl;         // [0] barrier arrivals, [1] abort, [2] wrap: entry below which a bucket stays empty, [3] rotation, [4] max distance, [5] fail, [6] barrier rounds completed (all 0 before the launch)
+    int* part;             // [5][GRID_MAX_WG] per-workgroup totals of the grid scans
     int* vfirst32;         // [n] first point of voxel v
     unsigned* vhash;       // [n]
     int* hist;             // [B]
@@ -510,199 +468,390 @@ struct SmallRobinArgs {
     int* tab_dist; int* tab_id;   // [n] the table, cluster windows back to back
     int64_t* keep_out;     // [n]
     int64_t* count_out;    // [1]
-    int64_t* info;         // [4] device copy of {B, nv, max distance, wrapped} + [4] = fail
+    int64_t* info;         // {B, nv (-1: a cluster beyond the limit / a wrap that could not be placed), max distance, wrapped} (0 before the launch)
+    long long* trace;      // [32] wall-clock stamps (100 MHz) of workgroup 0 behind every barrier (vfm_debug_voxel_trace), or NULL
 };
 
-__global__ __launch_bounds__(SMALLW_THREADS) void voxel_robin_small_kernel(SmallRobinArgs a) {
-    __shared__ int lds[SMALLW_THREADS];
-    __shared__ int sh_last, sh_w;
-    const int tid = threadIdx.x;
-    const int n = (int)a.n;
-    // ---- A: first-point table, all workgroups
-    for (int64_t i = (int64_t)blockIdx.x * SMALLW_THREADS + tid; i < a.n; i += (int64_t)gridDim.x * SMALLW_THREADS) {
-        const Vox v = voxel_of(a.pts + i * a.stride, a.vs);
-        int s = (int)(slot_hash(v) & (unsigned)a.hmask);
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// every workgroup of the grid arrives, then all leave; false: the grid gave up (abort flag), the caller returns at once.
+// ctl[0] counts arrivals (one atomic per workgroup and barrier); the workgroup that completes a round publishes the round in ctl[6],
+// which is what the others poll (plain agent-scope loads of a word nobody adds to).  The agent-scope release (L2 write-back) and
+// acquire (L1 / L2 invalidate) are per compute unit / per L2, not per thread: thread 0 issues them for its workgroup, on either side
+// of the workgroup's own barrier -- issued by all 65 536 threads they were most of the kernel's time.
+__device__ __forceinline__ bool grid_sync(unsigned* ctl, unsigned target, int* sh_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's stores and atomics have reached the L2 (a workgroup-scope barrier alone need not wait for them)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned prev = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ordered by the fences around it)
+        int ok = 1;
+        if (prev + 1u == target) {
+            __hip_atomic_store(ctl + 6, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            unsigned spins = 0;
+            while (ld_agent(ctl + 6) < target) {   // (relaxed: an acquire here would invalidate the caches at every poll; the fence below does it once)
+                if (ld_agent(ctl + 1) != 0u) { ok = 0; break; }
+                if (++spins > GRID_SPIN_LIMIT) {
+                    __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *sh_flag = ok;
+    }
+    __syncthreads();
+    return *sh_flag != 0;
+}
+// 256 threads: sum / maximum over the threads in front of this one, and over the workgroup
+__device__ __forceinline__ int block_excl_sum(int v, int* sh4, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) sh4[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < GRID_T / 64; ++w) {
+        const int s = sh4[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    total = tot;
+    return base + incl - v;
+}
+__device__ __forceinline__ int block_excl_max(int v, int* sh4, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl = max(incl, t);
+    }
+    int excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = -GRID_NONE;
+    __syncthreads();
+    if (lane == 63) sh4[wave] = incl;
+    __syncthreads();
+    int tot = -GRID_NONE;
+#pragma unroll
+    for (int w = 0; w < GRID_T / 64; ++w) {
+        const int s = sh4[w];
+        if (w < wave) excl = max(excl, s);
+        tot = max(tot, s);
+    }
+    total = tot;
+    return excl;
+}
+// the totals of the workgroups in front of this one (sum / maximum), and of the grid
+__device__ __forceinline__ int grid_prefix_sum(const int* part, int G, int* sh4, int* sh_b, int& total) {
+    const int v = (int)threadIdx.x < G ? ld_agent(part + threadIdx.x) : 0;
+    const int ex = block_excl_sum(v, sh4, total);
+    if (threadIdx.x == blockIdx.x) *sh_b = ex;
+    __syncthreads();
+    return *sh_b;
+}
+__device__ __forceinline__ int grid_prefix_max(const int* part, int G, int* sh4, int* sh_b) {
+    const int v = (int)threadIdx.x < G ? ld_agent(part + threadIdx.x) : -GRID_NONE;
+    int total;
+    const int ex = block_excl_max(v, sh4, total);
+    if (threadIdx.x == blockIdx.x) *sh_b = ex;
+    __syncthreads();
+    return *sh_b;
+}
+
+__global__ __launch_bounds__(GRID_T) void voxel_robin_grid_kernel(GridRobinArgs a) {
+    __shared__ int sh4[GRID_T / 64];
+    __shared__ int sh_b, sh_c, sh_flag;
+    __shared__ int sV[GRID_REPLAY_L][GRID_T], sI[GRID_REPLAY_L][GRID_T];        // [slot][thread]: conflict-free
+    __shared__ short sH[GRID_REPLAY_L][GRID_T], sD[GRID_REPLAY_L][GRID_T];
+    __shared__ int wv_mem[GRID_T / 64][GRID_MAX_CLUSTER], ws_mem[GRID_T / 64][GRID_MAX_CLUSTER], wi_mem[GRID_T / 64][GRID_MAX_CLUSTER];   // a wave's long cluster
+    __shared__ short wh_mem[GRID_T / 64][GRID_MAX_CLUSTER], wd_mem[GRID_T / 64][GRID_MAX_CLUSTER];
+    const int tid = threadIdx.x, G = (int)gridDim.x, T = G * GRID_T, gt = (int)blockIdx.x * GRID_T + tid;
+    const int n = (int)a.n, B = a.B;
+    const unsigned mask = (unsigned)(B - 1);
+    unsigned arrivals = 0;
+    int stamp = 0;
+    if (a.trace && gt == 0) a.trace[stamp++] = wall_clock64();
+#define GRID_SYNC()                                             \
+    do {                                                        \
+        arrivals += (unsigned)G;                                \
+        if (!grid_sync(a.ctl, arrivals, &sh_flag)) return;      \
+        if (a.trace && gt == 0 && stamp < 31) a.trace[stamp++] = wall_clock64();   \
+    } while (0)
+    // ---- 0: tables
+    for (int s = gt; s < a.hsize; s += T) {
+        a.owner[s] = EMPTY_OWNER;
+        a.tmin[s] = 0x7fffffff;
+    }
+    for (int b = gt; b < B; b += T) a.hist[b] = 0;
+    if (gt == 0) {
+        __hip_atomic_store(a.ctl + 2, (unsigned)GRID_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.ctl + 3, (unsigned)GRID_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    GRID_SYNC();
+    // ---- A: first-point table; a thread owns a run of consecutive points (one point up to 65 536)
+    const int pc = (n + T - 1) / T;
+    const int plo = min(n, gt * pc), phi = min(n, plo + pc);
+    for (int i = plo; i < phi; ++i) {
+        const Vox v = voxel_of(a.pts + (int64_t)i * a.stride, a.vs);
+        int s = (int)(slot_hash(v) & (unsigned)(a.hsize - 1));
         while (true) {
-            const int prev = atomicCAS(a.owner + s, EMPTY_OWNER, (int)i);
+            const int prev = atomicCAS(a.owner + s, EMPTY_OWNER, i);
             if (prev == EMPTY_OWNER) break;
             const Vox o = voxel_of(a.pts + (int64_t)prev * a.stride, a.vs);
             if (o.x == v.x && o.y == v.y && o.z == v.z) break;
-            s = (s + 1) & a.hmask;
+            s = (s + 1) & (a.hsize - 1);
         }
         a.slot_of[i] = s;
-        atomicMin(a.tmin + s, (int)i);
+        atomicMin(a.tmin + s, i);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned prev = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        sh_last = prev + 1u == gridDim.x;
-    }
-    __syncthreads();
-    if (!sh_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    GRID_SYNC();
     // ---- B: voxels in arrival order
-    const int chunk = (n + SMALLW_THREADS - 1) / SMALLW_THREADS;
-    const int lo = min(n, tid * chunk), hi = min(n, lo + chunk);
-    int cnt = 0;
-    for (int i = lo; i < hi; ++i) cnt += a.tmin[a.slot_of[i]] == i ? 1 : 0;
     int nv;
-    int pos = block_scan_excl_sum(cnt, lds, &nv);
-    for (int i = lo; i < hi; ++i)
-        if (a.tmin[a.slot_of[i]] == i) {
-            a.vfirst32[pos] = i;
-            a.vhash[pos] = reference_hash(voxel_of(a.pts + (int64_t)i * a.stride, a.vs), a.mul_y);
-            ++pos;
-        }
-    __syncthreads();
-    const int B = a.B;
-    const unsigned mask = (unsigned)(B - 1);
-    const int bchunk = (B + SMALLW_THREADS - 1) / SMALLW_THREADS;
-    const int vchunk = (nv + SMALLW_THREADS - 1) / SMALLW_THREADS;
-    const int vlo = min(nv, tid * vchunk), vhi = min(nv, vlo + vchunk);
+    {
+        int cnt = 0;
+        for (int i = plo; i < phi; ++i) cnt += a.tmin[a.slot_of[i]] == i ? 1 : 0;
+        int wg_total;
+        const int ex = block_excl_sum(cnt, sh4, wg_total);
+        if (tid == 0) st_agent(a.part + blockIdx.x, wg_total);
+        GRID_SYNC();
+        int pos = grid_prefix_sum(a.part, G, sh4, &sh_b, nv) + ex;
+        for (int i = plo; i < phi; ++i)
+            if (a.tmin[a.slot_of[i]] == i) {
+                const unsigned h = reference_hash(voxel_of(a.pts + (int64_t)i * a.stride, a.vs), a.mul_y);
+                a.vfirst32[pos] = i;
+                a.vhash[pos] = h;
+                atomicAdd(a.hist + (int)(h & mask), 1);
+                ++pos;
+            }
+    }
+    GRID_SYNC();
+    const int vc = (nv + T - 1) / T, bc = (B + T - 1) / T;
+    const int vlo = min(nv, gt * vc), vhi = min(nv, vlo + vc);
+    const int blo = min(B, gt * bc), bhi = min(B, blo + bc);
     unsigned z = 0;
-    int wrapped = 0, rot = 0, fail = 0, ncl = 0;
-    for (int pass = 0; pass < 2 && nv > 0; ++pass) {
+    int wrapped = 0, fail = 0, ncl = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {   // once more with the homes rotated by z
+            for (int b = blo; b < bhi; ++b) a.hist[b] = 0;
+            GRID_SYNC();
+            for (int v = vlo; v < vhi; ++v) atomicAdd(a.hist + (int)((a.vhash[v] - z) & mask), 1);
+            GRID_SYNC();
+        }
         // ---- C: counting sort by home bucket
-        for (int b = tid; b < B; b += SMALLW_THREADS) a.hist[b] = 0;
-        __syncthreads();
-        for (int v = tid; v < nv; v += SMALLW_THREADS) atomicAdd(a.hist + (int)((a.vhash[v] - z) & mask), 1);
-        __syncthreads();
         {
-            const int blo = min(B, tid * bchunk), bhi = min(B, blo + bchunk);
-            // (the counts were made by atomics, at the L2: read them there -- a plain load may hit a line this compute unit cached in pass 0)
             int sum = 0;
-            for (int b = blo; b < bhi; ++b) sum += __hip_atomic_load(a.hist + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int off = block_scan_excl_sum(sum, lds, nullptr);
+            for (int b = blo; b < bhi; ++b) sum += a.hist[b];
+            int wg_total;
+            const int ex = block_excl_sum(sum, sh4, wg_total);
+            if (tid == 0) st_agent(a.part + GRID_MAX_WG + blockIdx.x, wg_total);
+            GRID_SYNC();
+            int all;
+            int off = grid_prefix_sum(a.part + GRID_MAX_WG, G, sh4, &sh_b, all) + ex;
             for (int b = blo; b < bhi; ++b) {
-                const int c = __hip_atomic_load(a.hist + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int c = a.hist[b];
                 a.hist[b] = off;
                 off += c;
             }
         }
-        __syncthreads();
-        for (int v = tid; v < nv; v += SMALLW_THREADS) {
+        GRID_SYNC();
+        for (int v = vlo; v < vhi; ++v) {
             const int h = (int)((a.vhash[v] - z) & mask);
             const int p = atomicAdd(a.hist + h, 1);
             a.sorted_v[p] = v;
             a.key_s[p] = h;
         }
-        __syncthreads();
+        GRID_SYNC();
         // ---- D: running maximum of d_i = home_i - i, clusters
-        int lmax = -0x7fffffff;
-        for (int i = vlo; i < vhi; ++i) lmax = max(lmax, a.key_s[i] - i);
-        int run = block_scan_excl_max(lmax, lds, -0x7fffffff);   // maximum over the entries in front of this thread's
-        int nflag = 0, nwrap = 0;
-        for (int i = vlo; i < vhi; ++i) {
-            const int d = a.key_s[i] - i;
-            if (i == 0 || d > run) ++nflag;
-            run = max(run, d);
-            a.cm[i] = run;
-            a.tab_dist[i] = -1;
-            if (i + run >= B) ++nwrap;
-        }
-        int cbase = block_scan_excl_sum(nflag, lds, &ncl);
+        int run0, w;
         {
-            int total_w;
-            (void)block_scan_excl_sum(nwrap, lds, &total_w);
-            if (tid == 0) sh_w = total_w;
+            int lmax = -GRID_NONE;
+            for (int i = vlo; i < vhi; ++i) lmax = max(lmax, a.key_s[i] - i);
+            int wg_max;
+            const int ex = block_excl_max(lmax, sh4, wg_max);
+            if (tid == 0) st_agent(a.part + 2 * GRID_MAX_WG + blockIdx.x, wg_max);
+            GRID_SYNC();
+            run0 = max(ex, grid_prefix_max(a.part + 2 * GRID_MAX_WG, G, sh4, &sh_b));   // over the entries in front of this thread's
+            int run = run0, nflag = 0, nwrap = 0;
+            for (int i = vlo; i < vhi; ++i) {
+                const int d = a.key_s[i] - i;
+                if (i == 0 || d > run) ++nflag;
+                run = max(run, d);
+                a.cm[i] = run;
+                if (i + run >= B) ++nwrap;
+            }
+            int ftot, wtot;
+            const int fex = block_excl_sum(nflag, sh4, ftot);
+            (void)block_excl_sum(nwrap, sh4, wtot);
+            if (tid == 0) {
+                st_agent(a.part + 3 * GRID_MAX_WG + blockIdx.x, ftot);
+                st_agent(a.part + 4 * GRID_MAX_WG + blockIdx.x, wtot);
+            }
+            GRID_SYNC();
+            int cbase = grid_prefix_sum(a.part + 3 * GRID_MAX_WG, G, sh4, &sh_b, ncl) + fex;
+            (void)grid_prefix_sum(a.part + 4 * GRID_MAX_WG, G, sh4, &sh_c, w);
+            run = run0;
+            for (int i = vlo; i < vhi; ++i) {
+                const int d = a.key_s[i] - i;
+                if (i == 0 || d > run) a.cl_start[cbase++] = i;
+                run = max(run, d);
+            }
+            if (gt == 0) a.cl_start[ncl] = nv;
         }
-        int prev = vlo > 0 ? a.cm[vlo - 1] : -0x7fffffff;   // (written by the neighbour above: visible after the scans' barriers)
-        for (int i = vlo; i < vhi; ++i) {
-            const int d = a.key_s[i] - i;
-            if (i == 0 || d > prev) a.cl_start[cbase++] = i;
-            prev = a.cm[i];
-        }
-        if (tid == 0) a.cl_start[ncl] = nv;
-        __syncthreads();
-        const int w = sh_w;
         if (w > 0) {
             if (pass == 1) { fail = 1; break; }
             // smallest i with cm[i] >= w + 1: the bucket just below its cluster stays empty once the w wrapped entries have landed
-            int cand = 0x7fffffff;
+            int cand = GRID_NONE;
             for (int i = vlo; i < vhi; ++i)
                 if (a.cm[i] >= w + 1) { cand = i; break; }
-            const int ibest = block_reduce_min(cand, lds);
-            if (ibest == 0x7fffffff) { fail = 1; break; }
+            if (cand != GRID_NONE) atomicMin(a.ctl + 2, (unsigned)cand);
+            GRID_SYNC();
+            const int ibest = (int)ld_agent(a.ctl + 2);
+            if (ibest == GRID_NONE) { fail = 1; break; }
             z = (unsigned)(ibest + a.cm[ibest] - 1);
             wrapped = 1;
-            __syncthreads();
             continue;
         }
         if (z != 0) {   // actual bucket = (rotated bucket + z) mod B: iteration starts at rotated bucket B - z
-            int cand = nv;
+            int cand = GRID_NONE;
             for (int i = vlo; i < vhi; ++i)
                 if (i + a.cm[i] >= B - (int)z) { cand = i; break; }
-            rot = block_reduce_min(cand, lds);
+            if (cand != GRID_NONE) atomicMin(a.ctl + 3, (unsigned)cand);
         }
         break;
     }
-    // ---- E: one thread per cluster replays the container
-    int maxd = 0;
-    if (!fail)
-        for (int c = tid; c < ncl; c += SMALLW_THREADS) {
-            const int i0 = a.cl_start[c], L = a.cl_start[c + 1] - i0;
-            if (L > SMALLW_MAX_CLUSTER) { fail = 1; continue; }
-            int* mem = a.sorted_v + i0;
-            const int base = a.key_s[i0];
-            for (int x = 1; x < L; ++x) {   // members by arrival (= voxel rank)
-                const int v = mem[x];
-                int y = x - 1;
-                while (y >= 0 && mem[y] > v) { mem[y + 1] = mem[y]; --y; }
-                mem[y + 1] = v;
-            }
-            int* D = a.tab_dist + i0;
-            int* I = a.tab_id + i0;
-            for (int t = 0; t < L; ++t) {
-                int v = mem[t];
-                int ib = (int)((a.vhash[v] - z) & mask) - base;
-                int d = 0;
-                for (;;) {   // tsl insert_value_on_rehash (== insert_impl + insert_value_impl for an absent key)
-                    const int rd = D[ib];
-                    if (d > rd) {
-                        if (rd < 0) { D[ib] = d; I[ib] = v; if (d > maxd) maxd = d; break; }
-                        const int tv = I[ib];
-                        D[ib] = d; I[ib] = v;
-                        if (d > maxd) maxd = d;
-                        d = rd; v = tv;
+    GRID_SYNC();
+    // ---- E: one thread per cluster replays the container; a cluster beyond GRID_REPLAY_L entries is taken by the thread's whole wave
+    //      (members ranked and their homes fetched by all lanes, the insertions by lane 0, everything in the LDS): replayed by its one
+    //      thread in global memory such a cluster was a chain of ~L^2 / 4 dependent round trips -- 20 of the kernel's 59 us at 1 700
+    //      points, 100 of 245 at 60 000, where the longest cluster of the half-empty table has 30 - 60 entries
+    {
+        int maxd = 0, myfail = 0;
+        const int lane = tid & 63, wave = tid >> 6;
+        int* wV = wv_mem[wave];
+        int* wS = ws_mem[wave];
+        int* wI = wi_mem[wave];
+        short* wH = wh_mem[wave];
+        short* wD = wd_mem[wave];
+        if (!fail)
+            for (int c0 = gt - lane; c0 < ncl; c0 += T) {   // (wave-uniform bounds: the lanes of a wave hold consecutive clusters)
+                const int c = c0 + lane;
+                const bool valid = c < ncl;
+                const int i0 = valid ? a.cl_start[c] : 0, L = valid ? a.cl_start[c + 1] - i0 : 0;
+                if (L > GRID_MAX_CLUSTER) myfail = 1;
+                const int base = valid ? a.key_s[i0] : 0;
+                if (valid && L <= GRID_REPLAY_L) {
+                    for (int t = 0; t < L; ++t) sV[t][tid] = a.sorted_v[i0 + t];
+                    for (int x = 1; x < L; ++x) {   // members by arrival (= voxel rank)
+                        const int v = sV[x][tid];
+                        int y = x - 1;
+                        while (y >= 0 && sV[y][tid] > v) { sV[y + 1][tid] = sV[y][tid]; --y; }
+                        sV[y + 1][tid] = v;
                     }
-                    d++;
-                    ib++;   // never leaves [0, L): the window is the cluster's final extent
+                    for (int t = 0; t < L; ++t) sH[t][tid] = (short)((int)((a.vhash[sV[t][tid]] - z) & mask) - base);
+                    for (int t = 0; t < L; ++t) sD[t][tid] = -1;
+                    for (int t = 0; t < L; ++t) {
+                        int v = sV[t][tid], ib = sH[t][tid], d = 0;
+                        for (;;) {   // tsl insert_value_on_rehash (== insert_impl + insert_value_impl for an absent key)
+                            const int rd = sD[ib][tid];
+                            if (d > rd) {
+                                if (rd < 0) { sD[ib][tid] = (short)d; sI[ib][tid] = v; if (d > maxd) maxd = d; break; }
+                                const int tv = sI[ib][tid];
+                                sD[ib][tid] = (short)d; sI[ib][tid] = v;
+                                if (d > maxd) maxd = d;
+                                d = rd; v = tv;
+                            }
+                            d++;
+                            ib++;   // never leaves [0, L): the window is the cluster's final extent
+                        }
+                    }
+                    for (int t = 0; t < L; ++t) a.tab_id[i0 + t] = sI[t][tid];
+                }
+                unsigned long long todo = __ballot(valid && L > GRID_REPLAY_L && L <= GRID_MAX_CLUSTER);
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    const int ci0 = __shfl(i0, src), cL = __shfl(L, src), cbase = __shfl(base, src);
+                    for (int t = lane; t < cL; t += 64) wV[t] = a.sorted_v[ci0 + t];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (int t = lane; t < cL; t += 64) {   // rank = members that arrived earlier (voxel ranks are distinct)
+                        const int v = wV[t];
+                        int r = 0;
+                        for (int u = 0; u < cL; ++u) r += wV[u] < v ? 1 : 0;
+                        wS[r] = v;
+                        wH[r] = (short)((int)((a.vhash[v] - z) & mask) - cbase);
+                        wD[t] = -1;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (lane == 0)
+                        for (int t = 0; t < cL; ++t) {
+                            int v = wS[t], ib = wH[t], d = 0;
+                            for (;;) {
+                                const int rd = wD[ib];
+                                if (d > rd) {
+                                    if (rd < 0) { wD[ib] = (short)d; wI[ib] = v; if (d > maxd) maxd = d; break; }
+                                    const int tv = wI[ib];
+                                    wD[ib] = (short)d; wI[ib] = v;
+                                    if (d > maxd) maxd = d;
+                                    d = rd; v = tv;
+                                }
+                                d++;
+                                ib++;
+                            }
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (int t = lane; t < cL; t += 64) a.tab_id[ci0 + t] = wI[t];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
-        }
-    // (fail / maxd: any thread's)
-    lds[tid] = fail;
-    __syncthreads();
-    for (int off = SMALLW_THREADS / 2; off > 0; off >>= 1) {
-        if (tid < off) lds[tid] = max(lds[tid], lds[tid + off]);
-        __syncthreads();
+        if (maxd > 0) atomicMax(a.ctl + 4, (unsigned)maxd);
+        if (myfail) atomicMax(a.ctl + 5, 1u);
     }
-    fail = lds[0];
-    __syncthreads();
-    lds[tid] = maxd;
-    __syncthreads();
-    for (int off = SMALLW_THREADS / 2; off > 0; off >>= 1) {
-        if (tid < off) lds[tid] = max(lds[tid], lds[tid + off]);
-        __syncthreads();
-    }
-    maxd = lds[0];
-    __syncthreads();
+    GRID_SYNC();
     // ---- F: iteration order -> kept point indices
-    if (!fail)
-        for (int i = tid; i < nv; i += SMALLW_THREADS) {
+    if (!fail) fail = ld_agent(a.ctl + 5) != 0u;
+    if (!fail) {
+        int rot = 0;
+        if (z != 0) {
+            const unsigned r = ld_agent(a.ctl + 3);
+            rot = r < (unsigned)nv ? (int)r : nv;
+        }
+        for (int i = gt; i < nv; i += T) {
             int j = i + rot;
             if (j >= nv) j -= nv;
             a.keep_out[i] = (int64_t)a.vfirst32[a.tab_id[j]];
         }
-    if (tid == 0) {
+    }
+    if (gt == 0) {
         *a.count_out = nv;
         a.info[0] = B;
-        a.info[1] = nv;
-        a.info[2] = maxd;
+        a.info[1] = fail ? -1 : nv;      // (0, as the host left it: the grid gave up at a barrier)
+        a.info[2] = (int64_t)ld_agent(a.ctl + 4);
         a.info[3] = wrapped;
-        a.info[4] = fail;
+        if (a.trace) {
+            a.trace[stamp++] = wall_clock64();
+            a.trace[31] = stamp;
+        }
     }
+#undef GRID_SYNC
 }
 
 struct VoxelWs {
@@ -739,7 +888,10 @@ struct VoxelWs {
     int* cl_base;      // [n]
     int* tab_dist;     // [n]
     int* tab_id;       // [n]
-    int* hist_small;   // [2^ceil(log2 2n)] bucket histogram of voxel_robin_small_kernel
+    int* hist_small;   // [2^ceil(log2 2n)] bucket histogram of voxel_robin_grid_kernel
+    int64_t* gridctl;  // [8] info + [8] control words of voxel_robin_grid_kernel
+    int* gridpart;     // [5][256] its per-workgroup totals
+    long long* gridtrace;  // [32] vfm_debug_voxel_trace
     void* cub;         // hipCUB temporary storage
     size_t cub_bytes;
     size_t bytes;
@@ -808,7 +960,10 @@ inline VoxelWs carve_voxel(void* p, int64_t n, bool robin) {
         {
             size_t hb = 2;
             while (hb < 2 * nn) hb <<= 1;
-            w.hist_small = c.take<int>(n <= SMALLW_MAX_N ? 2 * hb : 1);   // (B = the power of two >= 2 reserve_n, reserve_n = n)
+            w.hist_small = c.take<int>(n <= GRID_MAX_N ? 2 * hb : 1);   // (B = the power of two >= 2 reserve_n, reserve_n = n)
+            w.gridctl = c.take<int64_t>(16);
+            w.gridpart = c.take<int>(5 * GRID_MAX_WG);
+            w.gridtrace = c.take<long long>(32);
         }
     }
     w.cub_bytes = (p != nullptr || true) ? cub_temp_bytes(n) : 0;
@@ -843,7 +998,18 @@ int select_first_k(const double* pts, int64_t n, int64_t stride, double voxel_si
 
 VFM_EXPORT int vfm_debug_set_voxel_small(int on) {
     if (on == 2 || on == 3) g_voxel_replay2 = on == 3;
+    else if (on > 10 && on <= 10 + 64) g_voxel_grid_ppt = on - 10;
+    else if (on == 100 || on == 101) g_voxel_trace = on - 100;
     else g_voxel_small = on;
+    return VFM_OK;
+}
+
+// tools: the phase stamps of the last one-launch VoxelDownsample in `ws` (n as at that call), 100 MHz ticks; out_host[31] = their number
+VFM_EXPORT int vfm_debug_voxel_trace(void* ws, int64_t n, int64_t* out_host) {
+    VFM_CHECK_ARG(ws && out_host && n > 0, "voxel_trace: bad arguments");
+    VoxelWs w = carve_voxel(ws, n, true);
+    VFM_CHECK_HIP(hipDeviceSynchronize());
+    VFM_CHECK_HIP(hipMemcpy(out_host, w.gridtrace, 32 * sizeof(long long), hipMemcpyDeviceToHost));
     return VFM_OK;
 }
 
@@ -884,8 +1050,8 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
         return VFM_OK;
     }
     const int K = max_per_voxel;
-    if (K == 1 && reserve_n >= 0 && n <= SMALLW_MAX_N && g_voxel_small) {
-        // VoxelDownsample of a cloud of this size: one generation of a reserved table in ONE launch (voxel_robin_small_kernel)
+    if (K == 1 && reserve_n >= 0 && n <= GRID_MAX_N && g_voxel_small) {
+        // VoxelDownsample of a cloud of this size: one generation of a reserved table in ONE launch (voxel_robin_grid_kernel)
         int64_t B = 0;
         {
             const float c = ceilf((float)reserve_n / 0.5f);
@@ -896,30 +1062,28 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
             }
         }
         if (B >= 2 * n && B <= (1ll << 20) && reserve_n == n) {   // (no rehash: nv <= n <= the load threshold B / 2; the histogram is sized for reserve(n))
-            SmallRobinArgs a{};
+            GridRobinArgs a{};
             a.pts = pts; a.n = n; a.stride = stride; a.vs = voxel_size; a.mul_y = hash_mul_y; a.B = (int)B;
-            a.owner = w.owner; a.tmin = w.tmin; a.hmask = (int)(w.hsize - 1); a.slot_of = w.slot_of;
-            a.done = reinterpret_cast<unsigned*>(w.smallinfo);
+            a.owner = w.owner; a.tmin = w.tmin; a.hsize = (int)w.hsize; a.slot_of = w.slot_of;
+            a.info = w.gridctl;
+            a.ctl = reinterpret_cast<unsigned*>(w.gridctl + 8);
+            a.part = w.gridpart;
+            a.trace = g_voxel_trace ? w.gridtrace : nullptr;
             a.vfirst32 = w.seq_a; a.vhash = w.vhash; a.hist = w.hist_small;
             a.sorted_v = w.seq_b; a.key_s = reinterpret_cast<int*>(w.key_s); a.cm = w.cm; a.cl_start = w.cl_start;
-            a.tab_dist = w.tab_dist; a.tab_id = w.tab_id; a.keep_out = keep_out; a.count_out = count_out; a.info = w.geninfo;
-            hipLaunchKernelGGL(voxel_small_init_kernel, dim3(blocks_of(w.hsize)), dim3(256), 0, st, w.owner, w.tmin, w.hsize, a.done);
-            const unsigned grid = (unsigned)((n + SMALLW_THREADS - 1) / SMALLW_THREADS < 64 ? (n + SMALLW_THREADS - 1) / SMALLW_THREADS : 64);
-            hipLaunchKernelGGL(voxel_robin_small_kernel, dim3(grid), dim3(SMALLW_THREADS), 0, st, a);
-            VFM_CHECK_LAUNCH("voxel_robin_small_kernel");
-            int64_t gi[5];
-            VFM_CHECK_HIP(hipMemcpyAsync(gi, w.geninfo, sizeof(gi), hipMemcpyDeviceToHost, st));
+            a.tab_dist = w.tab_dist; a.tab_id = w.tab_id; a.keep_out = keep_out; a.count_out = count_out;
+            VFM_CHECK_HIP(hipMemsetAsync(w.gridctl, 0, 16 * sizeof(int64_t), st));
+            const int64_t per_wg = (int64_t)GRID_T * g_voxel_grid_ppt;
+            const unsigned grid = (unsigned)((n + per_wg - 1) / per_wg < GRID_MAX_WG ? (n + per_wg - 1) / per_wg : GRID_MAX_WG);
+            hipLaunchKernelGGL(voxel_robin_grid_kernel, dim3(grid), dim3(GRID_T), 0, st, a);
+            VFM_CHECK_LAUNCH("voxel_robin_grid_kernel");
+            int64_t local[4];
+            int64_t* gi = info_host ? info_host : local;   // (straight into the caller's array: a DMA without a staging copy if it is page-locked)
+            VFM_CHECK_HIP(hipMemcpyAsync(gi, w.gridctl, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
             VFM_CHECK_HIP(hipStreamSynchronize(st));
-            if (gi[4] == 0) {
-                if (info_host) {
-                    info_host[0] = gi[0];
-                    info_host[1] = gi[1];
-                    info_host[2] = gi[2];
-                    info_host[3] = gi[3];
-                }
-                return VFM_OK;
-            }
-            // (a cluster beyond the kernel's limit, or a wrap it could not place: the general path decides)
+            if (gi[1] > 0) return VFM_OK;
+            if (info_host) info_host[0] = info_host[1] = info_host[2] = info_host[3] = 0;
+            // (a cluster beyond the kernel's limit, a wrap it could not place, or a grid that did not become resident: the general path decides)
         }
     }
     select_first_k(pts, n, stride, voxel_size, K, w, st, K > 1);

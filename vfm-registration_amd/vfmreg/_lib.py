@@ -69,6 +69,8 @@ SIGNATURES = {
     "vfm_ransac_workspace_bytes": (C.c_size_t, [c_i64, C.c_int32]),
     "vfm_ransac_corr": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, C.c_double, C.c_int32, C.c_uint64, c_vp, c_vp, c_vp,
                                   c_vp, c_vp, c_vp, C.c_size_t, c_vp]),
+    "vfm_ransac_corr_bounded": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_double, C.c_int32, C.c_uint64, c_vp, c_vp, c_vp,
+                                          c_vp, c_vp, c_vp, c_vp, C.c_size_t, c_vp]),
     "vfm_kabsch_batched": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, C.c_double, c_vp, c_vp, c_vp]),
     "vfm_project_workspace_bytes": (C.c_size_t, [c_i64]),
     "vfm_project_pinhole_f64": (C.c_int, [C.c_int, c_vp, c_i64, c_vp, c_vp, C.c_double, c_vp, c_vp, c_i64, c_i64,
@@ -108,6 +110,7 @@ DEBUG_SIGNATURES = {
     "vfm_debug_set_vit_gemm": (C.c_int, [C.c_int, C.c_int]),
     "vfm_debug_set_prep_grid": (C.c_int, [C.c_int]),
     "vfm_debug_set_voxel_small": (C.c_int, [C.c_int]),
+    "vfm_debug_voxel_trace": (C.c_int, [c_vp, c_i64, c_vp]),
     "vfm_debug_set_coarse_variant": (C.c_int, [C.c_int]),
     "vfm_debug_set_coarse_slices": (C.c_int, [C.c_int]),
     "vfm_debug_set_ransac_exact_only": (C.c_int, [C.c_int]),

@@ -31,6 +31,7 @@ def get_voxel_hash_map(config):
 
 class VoxelHashMap:
     quiet = False  # the reference prints a stats line per search (VoxelHashMap.cpp:613-616)
+    HALF_LIMIT = 24.0  # surviving chunks per query up to which a map's searches take the half-width coarse pass (pipeline.py's rule)
 
     def __init__(self, voxel_size: float, max_distance: float, max_points_per_voxel: int):
         self.voxel_size = float(voxel_size)
@@ -46,6 +47,9 @@ class VoxelHashMap:
         self._ordered = {}      # kind -> (rows, xyz64) in container iteration order (cache)
         self._dev = None        # cached (descriptors fp32, xyz fp64) of the N-D map (IndexFlatIP.add)
         self._prep = None       # ... and its prepared search operand (1 / |row| + the coarse pass's images), made at the first gated search
+        self._half = None       # whether searches of this map take the half-width coarse pass (probed at the first search)
+        self._load = None       # pinned int32[1]: load figure of the last gated search
+        self._load_pending = None
         self._xyz = None        # cached xyz_map() (it carries the ICP grid register_frame builds from it)
 
     @staticmethod
@@ -172,11 +176,32 @@ class VoxelHashMap:
             # reference too, VoxelHashMap.cpp:486-487), a call prepares its few hundred query rows and runs the gated search on both
             if self._prep is None or self._prep.x is not b_desc:
                 self._prep = ops.PreparedRows(b_desc)
-            idx, sim = ops.match_search_gated(ops.PreparedRows(q_desc), self._prep, gate)
+                self._half = None   # not yet probed for this map
+            qp = ops.PreparedRows(q_desc)
+            if self._load is None:
+                self._load = torch.zeros(1, dtype=torch.int32).pin_memory()
+            n = q_desc.shape[0]
+            if self._half is None:
+                # Half-width coarse pass (VFM_RECORDS_HALF: the int8 image of the first d / 2 columns, the other half bounded by
+                # Cauchy-Schwarz against the gate) where it prunes: half the coarse kernel, which is most of a search of ~10^3 queries.
+                # On descriptors that are alike every chunk survives its bound and the pass is far slower than the full-width one,
+                # so the first search of a map PROBES it (its coarse pass + a count of the survivors, one read-back) -- the rule
+                # of vfmreg/pipeline.py's `auto`: at most HALF_LIMIT surviving chunks per query.
+                ops.match_probe_half(qp, self._prep, gate, self._load)
+                torch.cuda.current_stream().synchronize()
+                self._half = int(self._load.item()) <= self.HALF_LIMIT * n
+            records = 3 if self._half else 0    # VFM_RECORDS_HALF / VFM_RECORDS_BEST
+            idx, sim = ops.match_search_gated(qp, self._prep, gate, records=records, rescans_out=self._load)
+            self._load_pending = (records, n)
         else:
             idx, sim = ops.match_ip_top1(q_desc, b_desc, prec, gate=gate if (prec == ops.FAST and not resolve_all) else None)
         r = ops.threshold_compact(sim, idx, float(min_cosine_similarity), want_corres=True)
         k = int(r["count"].item())
+        if self._load_pending is not None:      # (the read-back above has passed the search: its load figure is in)
+            records, n = self._load_pending
+            self._load_pending = None
+            if records == 3 and int(self._load.item()) > self.HALF_LIMIT * n:
+                self._half = False              # this scan's descriptors do not prune at half width: full width from the next search on
         corres = r["corres"][:k]
         return corres[:, 0].long(), corres[:, 1].long(), sim
 

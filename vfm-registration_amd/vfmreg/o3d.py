@@ -135,22 +135,24 @@ def registration_ransac_based_on_correspondence(source, target, corres, max_corr
     res = RegistrationResult()
     if len(cs) < ransac_n or max_correspondence_distance <= 0.0:
         return res  # Open3D returns the default result
-    if isinstance(cs, DeviceArray):
+    on_device = isinstance(cs, DeviceArray)
+    if on_device:
+        # device-resident indices: the range check Open3D makes on the host is made by the kernel that gathers the point pairs
+        # (vfm_ransac_corr_bounded) and comes back with the pose -- a min / max pass and a read-back of its own were 50 us per call
         cs_dev = cs.device_tensor.contiguous()
-        lo = cs_dev.min(dim=0).values
-        hi = cs_dev.max(dim=0).values
-        bounds = torch.stack((lo[0], lo[1], hi[0], hi[1])).cpu().numpy()      # one read-back
-        bad = bounds[0] < 0 or bounds[1] < 0 or bounds[2] >= len(src) or bounds[3] >= len(tgt)
     else:
         cs_dev = torch.from_numpy(cs).cuda()
-        bad = cs.min() < 0 or cs[:, 0].max() >= len(src) or cs[:, 1].max() >= len(tgt)
-    if bad:
-        raise IndexError("correspondence index out of range")
+        if cs.min() < 0 or cs[:, 0].max() >= len(src) or cs[:, 1].max() >= len(tgt):
+            raise IndexError("correspondence index out of range")
     out = ops.ransac_corr(src, tgt, cs_dev, float(max_correspondence_distance),
-                          criteria.max_iteration, seed=_seed[0] if seed is None else seed)
-    # one read-back for pose, fitness, rmse and winner (four .item() / .cpu() calls were four synchronisations)
-    packed = torch.cat((out["T"].reshape(-1), out["fitness"].reshape(-1), out["rmse"].reshape(-1),
-                        out["best_hyp"].reshape(-1).double())).cpu().numpy()
+                          criteria.max_iteration, seed=_seed[0] if seed is None else seed, check_bounds=on_device)
+    # one read-back for pose, fitness, rmse, winner (and the range flag): four .item() / .cpu() calls were four synchronisations
+    parts = [out["T"].reshape(-1), out["fitness"].reshape(-1), out["rmse"].reshape(-1), out["best_hyp"].reshape(-1).double()]
+    if on_device:
+        parts.append(out["bad"].double())
+    packed = torch.cat(parts).cpu().numpy()
+    if on_device and packed[19] != 0.0:
+        raise IndexError("correspondence index out of range")
     res.transformation = packed[:16].reshape(4, 4).copy()
     res.fitness = float(packed[16])
     res.inlier_rmse = float(packed[17])

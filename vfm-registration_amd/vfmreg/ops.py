@@ -6,6 +6,7 @@ implementation: every function raises if the tensors are not on a GPU.
 """
 from __future__ import annotations
 
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -16,6 +17,9 @@ FAST = 0
 EXACT = 1
 
 PROJ_NCLT, PROJ_ROBOTCAR, PROJ_KITTI = 0, 1, 2
+
+
+_tls = threading.local()
 
 
 def _stream() -> int:
@@ -116,10 +120,13 @@ def gated_split_ok(d: int) -> bool:
 
 
 def match_search_gated(q: PreparedRows, b: PreparedRows, gate: float, idx: Optional[torch.Tensor] = None,
-                       sim: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None):
+                       sim: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None, records: Optional[int] = None,
+                       rescans_out: Optional[torch.Tensor] = None):
     """vfm_match_search_coarse_gated + vfm_match_search_finish_gated on prepared operands: what vfm_match_ip_top1_gated does after
     preparing both -- for a map that is prepared once and searched by many scans.  Same answers (idx -1 / sim -2.0 for queries that
-    provably cannot reach ``gate``)."""
+    provably cannot reach ``gate``).  ``records``: the record kind of the coarse pass (include/vfmreg.h VFM_RECORDS_*; None = the
+    default, best-score records); ``rescans_out``: a pinned 1-element int32 tensor that receives the search's load figure
+    (vfm_match_search_rescans_async: candidate chunks rescanned) once the stream has passed this call."""
     lib = _lib.load()
     if q.d != b.d or not gated_split_ok(q.d):
         raise ValueError("Invalid shape")
@@ -132,11 +139,31 @@ def match_search_gated(q: PreparedRows, b: PreparedRows, gate: float, idx: Optio
     if sim is None:
         sim = torch.empty(q.rows, dtype=torch.float32, device=dev)
     st = _stream()
-    _lib.check(lib.vfm_match_search_coarse_gated(q.buf.data_ptr(), q.rows, b.buf.data_ptr(), b.rows, q.d, ws.data_ptr(), ws.numel(), st),
-               "search(coarse)")
-    _lib.check(lib.vfm_match_search_finish_gated(q.x.data_ptr(), q.buf.data_ptr(), q.rows, b.x.data_ptr(), b.buf.data_ptr(), b.rows, q.d,
-                                                 idx.data_ptr(), sim.data_ptr(), ws.data_ptr(), ws.numel(), float(gate), st), "search(finish)")
+    if records is None:
+        _lib.check(lib.vfm_match_search_coarse_gated(q.buf.data_ptr(), q.rows, b.buf.data_ptr(), b.rows, q.d, ws.data_ptr(), ws.numel(), st),
+                   "search(coarse)")
+        _lib.check(lib.vfm_match_search_finish_gated(q.x.data_ptr(), q.buf.data_ptr(), q.rows, b.x.data_ptr(), b.buf.data_ptr(), b.rows, q.d,
+                                                     idx.data_ptr(), sim.data_ptr(), ws.data_ptr(), ws.numel(), float(gate), st), "search(finish)")
+    else:
+        _lib.check(lib.vfm_match_search_coarse_gated_g(q.buf.data_ptr(), q.rows, b.buf.data_ptr(), b.rows, q.d, ws.data_ptr(), ws.numel(),
+                                                       int(records), float(gate), st), "search(coarse)")
+        _lib.check(lib.vfm_match_search_finish_gated_r(q.x.data_ptr(), q.buf.data_ptr(), q.rows, b.x.data_ptr(), b.buf.data_ptr(), b.rows, q.d,
+                                                       idx.data_ptr(), sim.data_ptr(), ws.data_ptr(), ws.numel(), float(gate), int(records), st),
+                   "search(finish)")
+    if rescans_out is not None:
+        _lib.check(lib.vfm_match_search_rescans_async(ws.data_ptr(), q.rows, b.rows, rescans_out.data_ptr(), st), "rescans")
     return idx, sim
+
+
+def match_probe_half(q: PreparedRows, b: PreparedRows, gate: float, out: torch.Tensor, ws: Optional[torch.Tensor] = None) -> None:
+    """vfm_match_search_probe_half: the (query, chunk) pairs the half-width coarse pass would leave for this pair, to the pinned
+    1-element int32 tensor ``out`` (asynchronously on the current stream)."""
+    lib = _lib.load()
+    need = lib.vfm_match_search_workspace_bytes(q.rows, b.rows, q.d)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, q.x.device)
+    _lib.check(lib.vfm_match_search_probe_half(q.buf.data_ptr(), q.rows, b.buf.data_ptr(), b.rows, q.d, ws.data_ptr(), ws.numel(),
+                                               float(gate), out.data_ptr(), _stream()), "probe_half")
 
 
 def threshold_compact(sim: torch.Tensor, idx: Optional[torch.Tensor], thr: float,
@@ -207,9 +234,11 @@ def match_mutual_pairs(a: torch.Tensor, b: torch.Tensor, want_nn: bool = False):
 # --------------------------------------------------------------------------------------- RANSAC
 def ransac_corr(src: torch.Tensor, tgt: torch.Tensor, corres: torch.Tensor, max_dist: float, n_iter: int,
                 seed: int = 42, count: Optional[torch.Tensor] = None, want_mask: bool = True,
-                ws: Optional[torch.Tensor] = None, out: Optional[dict] = None):
+                ws: Optional[torch.Tensor] = None, out: Optional[dict] = None, check_bounds: bool = False):
     """registration_ransac_based_on_correspondence (registration_node.py:319-327).  `count`
-    (1-element int64 device tensor) gives the number of valid rows of `corres` without a host sync."""
+    (1-element int64 device tensor) gives the number of valid rows of `corres` without a host sync.  ``check_bounds``: the kernel that
+    gathers the point pairs tests every index against the clouds' lengths (vfm_ransac_corr_bounded); ``out["bad"]`` (int32[1]) is 1
+    if one was out of range -- such an entry is read as row 0 and the caller discards the result."""
     _chk(src, torch.float64, "src")
     _chk(tgt, torch.float64, "tgt")
     _chk(corres, torch.int32, "corres")
@@ -227,6 +256,14 @@ def ransac_corr(src: torch.Tensor, tgt: torch.Tensor, corres: torch.Tensor, max_
                    mask=torch.empty(max(c_max, 1), dtype=torch.uint8, device=dev) if want_mask else None)
     if count is not None:
         _chk(count, torch.int64, "count")
+    if check_bounds:
+        out["bad"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.vfm_ransac_corr_bounded(src.data_ptr(), src.shape[0], tgt.data_ptr(), tgt.shape[0], corres.data_ptr(), _ptr(count), c_max,
+                                               float(max_dist), int(n_iter), int(seed) & 0xFFFFFFFFFFFFFFFF, out["T"].data_ptr(),
+                                               out["fitness"].data_ptr(), out["rmse"].data_ptr(), _ptr(out.get("mask")),
+                                               out["best_hyp"].data_ptr(), out["bad"].data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+                   "ransac_corr")
+        return out
     _lib.check(lib.vfm_ransac_corr(src.data_ptr(), tgt.data_ptr(), corres.data_ptr(), _ptr(count), c_max,
                                    float(max_dist), int(n_iter), int(seed) & 0xFFFFFFFFFFFFFFFF, out["T"].data_ptr(),
                                    out["fitness"].data_ptr(), out["rmse"].data_ptr(), _ptr(out.get("mask")),
@@ -401,17 +438,19 @@ def voxel_robin(xyz: torch.Tensor, voxel_size: float, max_per_voxel: int = 1, re
     """The survivors of ``voxel_first`` in the order the reference emits them (tsl::robin_map iteration
     order): ``reserve=True, HASH_DOWNSAMPLE`` = VoxelDownsample (Preprocessing.cpp:50-69);
     ``reserve=False, HASH_MAP`` = a fresh VoxelHashMap after AddPoints, as Pointcloud*() walk it."""
-    import ctypes as C
     _chk(xyz, torch.float64, "xyz")
     lib = _lib.load()
     n, stride = xyz.shape
     keep = torch.empty(max(n, 1), dtype=torch.int64, device=xyz.device)
     count = torch.empty(1, dtype=torch.int64, device=xyz.device)
-    info = (C.c_int64 * 4)()
+    info = getattr(_tls, "voxel_info", None)     # page-locked: the entry point's one read-back lands in it by DMA
+    if info is None:
+        info = _tls.voxel_info = torch.zeros(4, dtype=torch.int64).pin_memory()
     ws = _ws(lib.vfm_voxel_robin_workspace_bytes(n), xyz.device)
     _lib.check(lib.vfm_voxel_robin(xyz.data_ptr(), n, stride, float(voxel_size), int(max_per_voxel), int(hash_mul),
-                                   n if reserve else -1, keep.data_ptr(), count.data_ptr(), C.cast(info, C.c_void_p),
+                                   n if reserve else -1, keep.data_ptr(), count.data_ptr(), info.data_ptr(),
                                    ws.data_ptr(), ws.numel(), _stream()), "voxel_robin")
     # (the entry point synchronises and reports the number of voxels: with one point per voxel that IS the count -- no second read-back)
-    out = keep[:int(info[1]) if max_per_voxel == 1 else int(count.item())]
-    return (out, list(info)) if return_info else out
+    vals = info.tolist()
+    out = keep[:vals[1] if max_per_voxel == 1 else int(count.item())]
+    return (out, vals) if return_info else out
