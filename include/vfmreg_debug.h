@@ -57,9 +57,10 @@ int vfm_debug_set_match_stats(int on);
  * -15: the token-stationary kernel with two channel tiles per wave (1, default since round 5) / one (0) */
 int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
 /* A/B + tests: vfm_voxel_robin on a VoxelDownsample-shaped call (one point per voxel, reserve(n), n <= 2^18) by the one-launch kernel
- * (1) / always by the general multi-launch path (0, default: the one-launch form measured slower -- csrc/voxel.hip); both give the
+ * (1, default: up to 256 resident workgroups with grid-wide barriers -- csrc/voxel.hip) / always by the general multi-launch path (0); both give the
  * container's order.  2 / 3: the per-cluster replay of a generation as in round 4 (a radix sort by (cluster, arrival) in front of a
- * global-memory replay) / as in round 5 (3, default: the replay sorts its cluster and runs in the LDS) */
+ * global-memory replay) / as in round 5 (3, default: the replay sorts its cluster and runs in the LDS); 10 + k: k points per thread of
+ * the one-launch kernel (10 = by size, default); 100 / 101: its phase stamps off / on (vfm_debug_voxel_trace) */
 int vfm_debug_set_voxel_small(int on);
 /* tools: wall-clock stamps (100 MHz) workgroup 0 of the one-launch VoxelDownsample kernel took behind each of its grid-wide barriers
  * during the last vfm_voxel_robin in `ws` (n as at that call; recorded while vfm_debug_set_voxel_small(101) is in force, 100 = off);

@@ -23,7 +23,7 @@ for n in (1700, 6000, 20000, 60000, 200000):
     row = []
     for mode in (0, 1, 12, 14, 18):
         lib.vfm_debug_set_voxel_small(1 if mode else 0)
-        lib.vfm_debug_set_voxel_small(mode if mode > 10 else 11)
+        lib.vfm_debug_set_voxel_small(mode if mode > 10 else 10)
         outs = ops.voxel_robin(d, 0.5)
         ts = []
         for _ in range(30):
@@ -33,9 +33,9 @@ for n in (1700, 6000, 20000, 60000, 200000):
             ts.append(time.perf_counter() - t0)
         row.append((sorted(ts)[len(ts) // 2] * 1e3, int(o.numel())))
         assert torch.equal(o, outs)
-    print(f"voxel_robin n = {n}: general path {row[0][0]:.3f} ms, one launch {row[1][0]:.3f} ms; 2 / 4 / 8 points per thread "
+    print(f"voxel_robin n = {n}: general path {row[0][0]:.3f} ms, one launch {row[1][0]:.3f} ms (points per thread by size); 2 / 4 / 8 points per thread "
           f"{row[2][0]:.3f} / {row[3][0]:.3f} / {row[4][0]:.3f} ({row[1][1]} voxels)", flush=True)
-lib.vfm_debug_set_voxel_small(11)
+lib.vfm_debug_set_voxel_small(10)
 
 for n_scan, n_map in ((20000, 200000), (60000, 200000)):
     p = synth.make_pair(n_scan, n_map, 384, seed=11)

@@ -21,6 +21,9 @@ if lds_thr >= 0:
     lib.vfm_debug_set_vit_gemm(-5, lds_thr)
 if len(sys.argv) > 5:                                      # token-stationary QKV / fc1 kernel from this many groups of 128 rows on (0: the default policy, -1: never)
     lib.vfm_debug_set_vit_gemm(-9, int(sys.argv[5]))
+import os
+if os.environ.get("VFM_HOT_A") == "1":                      # timing experiment (wrong results): tools/ab_vit_hot_a.sh
+    lib.vfm_debug_set_vit_gemm(-16, 1)
 rng = np.random.default_rng(0)
 imgs = torch.from_numpy(rng.integers(1, 255, (nimg, 1200, 1600, 3), dtype=np.uint8)).cuda()
 model = V.ViTS14(V.random_weights(0), 1200, 1600)

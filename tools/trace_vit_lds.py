@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Inside the LDS-tiled residual GEMMs (proj, fc2) of a ViT forward at N images: per workgroup the time in the k loop and in the epilogue
+(residual read-modify-write, fp16 copy, LayerNorm statistics), from the kernel's own trace (start / end of loop / end, 100 MHz)."""
+import ctypes as C
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "vfm-registration_amd"))
+from vfmreg import _lib  # noqa: E402
+from vfmreg import vit as V  # noqa: E402
+
+lib = _lib.load()
+rng = np.random.default_rng(0)
+nimg = int(sys.argv[1]) if len(sys.argv) > 1 else 90
+imgs = torch.from_numpy(rng.integers(1, 255, (nimg, 1200, 1600, 3), dtype=np.uint8)).cuda()
+buf = torch.zeros((2, 4096, 4), dtype=torch.int64, device="cuda")
+ptr = buf.data_ptr()
+lib.vfm_debug_set_vit_gemm(-11, C.c_int32(ptr & 0xffffffff).value)
+lib.vfm_debug_set_vit_gemm(-12, C.c_int32((ptr >> 32) & 0xffffffff).value)
+# depth 1: the LAST residual GEMM of the forward is the block's fc2; with VFM_ONLY_PROJ=1 the MLP is skipped by reading after a
+# forward whose weights make fc2 the traced launch anyway -- the two are told apart by the k-steps the kernel records
+model = V.ViTS14(V.random_weights(0, depth=1), 1200, 1600)
+for _ in range(3):
+    buf.zero_()
+    model.forward(imgs)
+torch.cuda.synchronize()
+both = buf.cpu().numpy()
+live = both[0][:, 0] > 0
+t = both[0][live]
+cyc = both[1][live].astype(np.float64)
+t0 = t[:, 0].min()
+start, loop_end, end, ks = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0, t[:, 3]
+print(f"{nimg} images: {len(t)} workgroups traced, k-steps {sorted(set(int(k) for k in ks))}")
+print(f"  start: median {np.median(start):.1f} us, max {start.max():.1f}; kernel end {end.max():.1f} us")
+print(f"  k loop: min / median / max {np.min(loop_end - start):.1f} / {np.median(loop_end - start):.1f} / {np.max(loop_end - start):.1f} us")
+print(f"  epilogue: min / median / max {np.min(end - loop_end):.1f} / {np.median(end - loop_end):.1f} / {np.max(end - loop_end):.1f} us")
+ns = ks / 2.0
+print("  cycles per stage of wave 3 (shader clock), median over the workgroups: DMA wait %.0f, barrier %.0f, DMA issue + LDS reads %.0f, MFMAs %.0f"
+      % tuple(np.median(cyc[:, i] / ns) for i in range(4)))
+slow = (loop_end - start) > np.quantile(loop_end - start, 0.9)
+print("  the slowest tenth of the workgroups: DMA wait %.0f, barrier %.0f, DMA issue + LDS reads %.0f, MFMAs %.0f"
+      % tuple(np.median(cyc[slow, i] / ns[slow]) for i in range(4)))
+q = np.quantile(end, [0.1, 0.5, 0.9, 1.0])
+print(f"  workgroup end times: 10 % {q[0]:.1f}, 50 % {q[1]:.1f}, 90 % {q[2]:.1f}, last {q[3]:.1f} us")

@@ -36,4 +36,4 @@ for n, ppt in ((1700, 1), (20000, 1), (60000, 1), (60000, 4), (200000, 1)):
     a = np.median(np.array(acc[1:]), axis=0)
     print(f"n = {n}, {ppt} point(s) per thread: total {a.sum():.1f} us: " + ", ".join(f"{nm} {v:.1f}" for nm, v in zip(names, a)), flush=True)
 lib.vfm_debug_set_voxel_small(100)
-lib.vfm_debug_set_voxel_small(11)
+lib.vfm_debug_set_voxel_small(10)

@@ -49,7 +49,7 @@ struct Dims {
     int Np, T, Tp;    // patches, tokens (Np+1), tokens padded to a multiple of 32
     int M;            // B * Tp rows
     int D, heads, mlp, depth;
-    int KP;           // patch-embed K padded to a multiple of 16 (3*14*14 = 588 -> 592)
+    int KP;           // patch-embed K padded to a multiple of 32 (3*14*14 = 588 -> 608: an even number of k-steps, whole stages of the LDS-tiled GEMM)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -84,7 +84,7 @@ inline size_t frag_bytes(int rows, int k) { return (size_t)ceil_div(rows, 32) * 
 inline Layout make_layout(const vfm_vit_config* c) {
     Layout L;
     const int D = c->dim, T = c->patch_h * c->patch_w + 1;
-    const int KP = ceil_div(3 * c->patch * c->patch, 16) * 16;
+    const int KP = ceil_div(3 * c->patch * c->patch, 32) * 32;
     int n = 0;
     size_t off = 0;
     auto add = [&](size_t b) {
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void vit_preprocess_kernel(const uint8_t* __re
 // the kernel above (same expressions, same order: the same bits), leaves them in the LDS in k order (k = c 196 + py 14 + px) and the
 // first KP / 8 threads write the token's fragment units, 16 bytes each.  Tokens without a patch (cls, padding) are zero rows.
 __global__ __launch_bounds__(256) void vit_preprocess_patch_kernel(const uint8_t* __restrict__ img, Dims d, _Float16* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) _Float16 vals[640];   // KP <= 640 halves (3 x 196 = 588 -> 592)
+    __shared__ __attribute__((aligned(16))) _Float16 vals[640];   // KP <= 640 halves (3 x 196 = 588 -> 608)
     const int m = blockIdx.x, tid = threadIdx.x;
     const int b = m / d.Tp, t = m - b * d.Tp;
     const int ksteps = d.KP / 16, units = ksteps * 2;
@@ -250,6 +250,7 @@ struct GemmArgs {
     float invD;          // 1 / D (the consumers' mean and variance)
     unsigned qt_magic;   // 2^20 / (Tp / 32) + 1: image of a token tile = (mt qt_magic) >> 20 (exact for mt < 2^16: vfm_vit_forward checks)
     unsigned long long* dbg;   // (tools only) per-workgroup start / end / placement of vit_gemm_astat_kernel, or null
+    int hot_a;                 // (tools only, WRONG RESULTS) 1: every workgroup of the LDS-tiled kernel reads token group 0 -- its A operand then hits the L2
 };
 
 // XCD-consistent work mapping (round 3): workgroup b runs on XCD b % 8 (observed placement, speed only).  Every kernel of a block
@@ -600,6 +601,8 @@ __global__ __launch_bounds__(256, 3) void vit_gemm_lds_kernel(GemmArgs g) {
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int mg = xcd + 8 * (idx / ngroups), ng = idx % ngroups;
     if (mg >= mgroups) return;
+    unsigned long long dbg_t0 = 0, dbg_t1 = 0;
+    if (g.dbg) dbg_t0 = wall_clock64();
     const int wm = wave >> 1, wn = wave & 1;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     constexpr int STAGE = 2 * 4 * KB * 1024;
@@ -620,6 +623,7 @@ __global__ __launch_bounds__(256, 3) void vit_gemm_lds_kernel(GemmArgs g) {
         ks = ks < g.KS ? ks : g.KS - 1;
         int rowtile = op == 0 ? mg * 4 + tile : ng * 4 + tile;
         if (op == 0 && rowtile >= mtiles) rowtile = mtiles - 1;   // (a partial last group of token tiles: its epilogue is skipped)
+        if (op == 0 && g.hot_a) rowtile = tile;                   // (timing experiment: tools/ab_vit_hot_a.sh)
         src[i] = reinterpret_cast<const char*>((op == 0 ? g.A : g.W) + ((size_t)rowtile * g.KS + ks) * 64);
     }
     unsigned lane16 = (unsigned)lane * 16u;   // + the bytes the wave's pieces have moved on by (one VALU add per stage instead of PW 64-bit scalar ones)
@@ -647,30 +651,50 @@ __global__ __launch_bounds__(256, 3) void vit_gemm_lds_kernel(GemmArgs g) {
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st) issue_stage(st);   // stages 0 .. NS - 2 (dummies past the end)
     int slot = 0;
+    unsigned long long c_wait = 0, c_bar = 0, c_lds = 0, c_mfma = 0;   // (g.dbg: cycles of wave 3 at the DMA wait, the barrier, issue + LDS reads, the MFMAs)
     for (int stage = 0; stage < nstages; ++stage) {
+        unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
+        if (g.dbg) tc0 = __builtin_readcyclecounter();
         vit_wait_vmcnt<(NS - 2) * PW>();      // this wave's pieces of `stage`: the NS - 2 stages issued since may fly on
+        if (g.dbg) tc1 = __builtin_readcyclecounter();
         __builtin_amdgcn_s_barrier();         // everybody's; and everybody has left the slot of stage - 1
         asm volatile("" ::: "memory");
+        if (g.dbg) tc2 = __builtin_readcyclecounter();
         issue_stage(slot == 0 ? NS - 1 : slot - 1);   // stage + NS - 1
         const unsigned char* st = lds + slot * STAGE;
+        // (the launcher sends only whole stages here: KS % KB == 0.  All of a stage's fragments are requested up front -- straight-line
+        // code, the k-steps' registers distinct --, so that the LDS reads of k-step ks + 1 are under the MFMAs of k-step ks; with a
+        // bounds test per k-step the compiler had each k-step wait for its own four reads.  Measured: no difference -- the other two
+        // waves of the SIMD covered that wait already)
+        half8 af[KB][2], wf[KB][2];
 #pragma unroll
-        for (int ks = 0; ks < KB; ++ks) {
-            if (stage * KB + ks < g.KS) {
-                half8 af[2], wf[2];
+        for (int ks = 0; ks < KB; ++ks)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[i] = *reinterpret_cast<const half8*>(st + ((2 * wm + i) * KB + ks) * 1024 + lane * 16);
-                    wf[i] = *reinterpret_cast<const half8*>(st + 4 * KB * 1024 + ((2 * wn + i) * KB + ks) * 1024 + lane * 16);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) {
+                af[ks][i] = *reinterpret_cast<const half8*>(st + ((2 * wm + i) * KB + ks) * 1024 + lane * 16);
+                wf[ks][i] = *reinterpret_cast<const half8*>(st + 4 * KB * 1024 + ((2 * wn + i) * KB + ks) * 1024 + lane * 16);
             }
+        if (g.dbg) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            tc3 = __builtin_readcyclecounter();
+        }
+#pragma unroll
+        for (int ks = 0; ks < KB; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+        if (g.dbg) {
+            const unsigned long long tc4 = __builtin_readcyclecounter();
+            c_wait += tc1 - tc0;
+            c_bar += tc2 - tc1;
+            c_lds += tc3 - tc2;
+            c_mfma += tc4 - tc3;
         }
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
     vit_wait_vmcnt<0>();   // (the dummy stages: no LDS-DMA may be in flight when the workgroup's LDS is handed on)
+    if (g.dbg) dbg_t1 = wall_clock64();
     const int hi = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -688,6 +712,18 @@ __global__ __launch_bounds__(256, 3) void vit_gemm_lds_kernel(GemmArgs g) {
             epi_load<EPI>(g, m, t, hi, n32, e);
             epi_tile<EPI>(g, acc[i][j], m, mtu, b, tq, t, hi, n32, e, ln_mean, ln_rstd);
         }
+    }
+    if (g.dbg && wave == 3 && lane == 0) {   // (tools/trace_vit_lds.py) start, end of the k loop, end: 100 MHz ticks
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g.dbg[blockIdx.x * 4 + 0] = dbg_t0;
+        g.dbg[blockIdx.x * 4 + 1] = dbg_t1;
+        g.dbg[blockIdx.x * 4 + 2] = wall_clock64();
+        g.dbg[blockIdx.x * 4 + 3] = (unsigned long long)g.KS;
+        unsigned long long* more = g.dbg + 4 * 4096 + blockIdx.x * 4;   // (the tools' buffer holds [2][4096][4])
+        more[0] = c_wait;
+        more[1] = c_bar;
+        more[2] = c_lds;
+        more[3] = c_mfma;
     }
 }
 
@@ -1256,7 +1292,7 @@ inline Dims make_dims(const vfm_vit_config* c, int B, int H, int W) {
     d.Np = d.gh * d.gw; d.T = d.Np + 1; d.Tp = ceil_div(d.T, 32) * 32;
     d.M = B * d.Tp;
     d.D = c->dim; d.heads = c->heads; d.mlp = c->mlp_dim; d.depth = c->depth;
-    d.KP = ceil_div(3 * c->patch * c->patch, 16) * 16;
+    d.KP = ceil_div(3 * c->patch * c->patch, 32) * 32;
     return d;
 }
 
@@ -1299,6 +1335,7 @@ int launch_gemm_cfg(const GemmArgs& g, hipStream_t st) {
 // ~5 us floor of each of its 87 launches, not by L2 latency or bandwidth: PF = 8 / 16 / 24 make no difference, 32-channel
 // tiles everywhere (twice the waves) give 0.76 instead of 0.82 ms, 64 x 64 wave tiles and row-complete workgroups with the
 // LayerNorm fused into the epilogue (63 launches, but 66 workgroups per GEMM) gave 1.04 ms and were removed again.
+int g_vit_hot_a = 0;
 int g_vit_lds_shape = 23;     // vfm_debug_set_vit_gemm(-6, KB * 10 + NS): k-steps per stage / stages in the ring of the LDS-tiled kernel (23: 48 KiB, three workgroups per compute unit)
 int g_vit_att_lds_min = 1;   // vfm_debug_set_vit_gemm(-7, n): attention with K / V^T in the LDS from n images per call on (0 = never)
 int g_vit_lds_min_wg = 256;   // vfm_debug_set_vit_gemm(-5, n): the LDS-tiled kernel from n workgroups of 128 x 128 on (0 = never)
@@ -1377,9 +1414,12 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
             return VFM_OK;
         }
     }
-    if (g.N % 128 == 0 && g_vit_lds_min_wg > 0) {
+    if (g.N % 128 == 0 && g_vit_lds_min_wg > 0 && g.KS % (g_vit_lds_shape / 10 == 4 ? 4 : 2) == 0) {   // (whole stages of 2 or 4 k-steps)
         const int wgs = ceil_div(g.M / 32, 4) * (g.N / 128);
         if (wgs >= g_vit_lds_min_wg) {
+            GemmArgs gl = g;
+            gl.hot_a = g_vit_hot_a;
+            gl.dbg = EPI == EPI_RESID ? g_vit_astat_dbg : nullptr;   // (the trace buffer serves whichever kernel a tool looks at)
             const int grid = 8 * ceil_div(ceil_div(g.M / 32, 4), 8) * (g.N / 128);   // every XCD: ceil(groups / 8) token groups x channel groups
 #define VIT_LDS(KB, NS)                                                                                                              \
     do {                                                                                                                             \
@@ -1391,7 +1431,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
                                               hipFuncAttributeMaxDynamicSharedMemorySize, NS * 8 * KB * 1024));                      \
             attr_set |= 1ull << (dev & 63);                                                                                          \
         }                                                                                                                            \
-        hipLaunchKernelGGL((vit_gemm_lds_kernel<EPI, KB, NS>), dim3(grid), dim3(256), NS * 8 * KB * 1024, st, g);                    \
+        hipLaunchKernelGGL((vit_gemm_lds_kernel<EPI, KB, NS>), dim3(grid), dim3(256), NS * 8 * KB * 1024, st, gl);                    \
     } while (0)
             switch (g_vit_lds_shape) {
                 case 42: VIT_LDS(4, 2); break;
@@ -1422,6 +1462,10 @@ VFM_EXPORT int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg) {
     }
     if (narrow_cfg == -6) {
         g_vit_lds_shape = wide_cfg;
+        return VFM_OK;
+    }
+    if (narrow_cfg == -16) {   // timing experiment (wrong results): the LDS-tiled kernel's A operand from token group 0 in every workgroup
+        g_vit_hot_a = wide_cfg;
         return VFM_OK;
     }
     if (narrow_cfg == -15) {   // token-stationary GEMM: 1 = two channel tiles per wave (default), 0 = round 4's one

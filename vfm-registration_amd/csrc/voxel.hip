@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void robin_pointkey_kernel(const int64_t* __re
 int g_voxel_replay2 = 1;   // vfm_debug_set_voxel_small(2 / 3): round 4's replay (radix sort by cluster + global-memory replay) / round 5's (default)
 int g_voxel_small = 1;     // vfm_debug_set_voxel_small(0 / 1): the general path always / the one-launch kernel where it applies (default)
 int g_voxel_trace = 0;     // vfm_debug_set_voxel_small(100 / 101): phase stamps of the one-launch kernel off / on
-int g_voxel_grid_ppt = 1;  // vfm_debug_set_voxel_small(10 + k): k points per thread of the one-launch kernel (fewer workgroups at the barriers)
+int g_voxel_grid_ppt = 0;  // vfm_debug_set_voxel_small(10 + k): k points per thread of the one-launch kernel (fewer workgroups at the barriers); 10 = by size (default)
 constexpr int GRID_T = 256;
 constexpr int GRID_MAX_WG = 256;
 constexpr int GRID_REPLAY_L = 16;
@@ -998,7 +998,7 @@ int select_first_k(const double* pts, int64_t n, int64_t stride, double voxel_si
 
 VFM_EXPORT int vfm_debug_set_voxel_small(int on) {
     if (on == 2 || on == 3) g_voxel_replay2 = on == 3;
-    else if (on > 10 && on <= 10 + 64) g_voxel_grid_ppt = on - 10;
+    else if (on >= 10 && on <= 10 + 64) g_voxel_grid_ppt = on - 10;
     else if (on == 100 || on == 101) g_voxel_trace = on - 100;
     else g_voxel_small = on;
     return VFM_OK;
@@ -1073,7 +1073,10 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
             a.sorted_v = w.seq_b; a.key_s = reinterpret_cast<int*>(w.key_s); a.cm = w.cm; a.cl_start = w.cl_start;
             a.tab_dist = w.tab_dist; a.tab_id = w.tab_id; a.keep_out = keep_out; a.count_out = count_out;
             VFM_CHECK_HIP(hipMemsetAsync(w.gridctl, 0, 16 * sizeof(int64_t), st));
-            const int64_t per_wg = (int64_t)GRID_T * g_voxel_grid_ppt;
+            // (a barrier costs ~2.5 us + 0.04 us per workgroup, a second point per thread a dependent round trip in every phase:
+            //  tools/ab_voxel_grid.py -- 60 000 points: 0.24 / 0.19 / 0.20 ms at 1 / 2 / 4 points per thread, 20 000: 0.130 / 0.125 / 0.140)
+            const int ppt = g_voxel_grid_ppt > 0 ? g_voxel_grid_ppt : (n <= 32768 ? 1 : n <= 131072 ? 2 : 4);
+            const int64_t per_wg = (int64_t)GRID_T * ppt;
             const unsigned grid = (unsigned)((n + per_wg - 1) / per_wg < GRID_MAX_WG ? (n + per_wg - 1) / per_wg : GRID_MAX_WG);
             hipLaunchKernelGGL(voxel_robin_grid_kernel, dim3(grid), dim3(GRID_T), 0, st, a);
             VFM_CHECK_LAUNCH("voxel_robin_grid_kernel");

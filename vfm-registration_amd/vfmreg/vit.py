@@ -175,10 +175,10 @@ def interpolate_pos_embed(pos_embed: np.ndarray, h: int, w: int) -> np.ndarray:
     return torch.cat([pe[0, :1], patch], 0).numpy()
 
 
-def to_frag_f16(W: np.ndarray) -> np.ndarray:
-    """[N, K] fp32 -> fp16 fragment tiles [N/32][K/16][2][32][8] (N, K zero-padded to 32 / 16)."""
+def to_frag_f16(W: np.ndarray, k_multiple: int = 16) -> np.ndarray:
+    """[N, K] fp32 -> fp16 fragment tiles [N/32][K/16][2][32][8] (N, K zero-padded to 32 / ``k_multiple``)."""
     n, k = W.shape
-    npad, kpad = -(-n // 32) * 32, -(-k // 16) * 16
+    npad, kpad = -(-n // 32) * 32, -(-k // k_multiple) * k_multiple
     Wp = np.zeros((npad, kpad), dtype=np.float16)
     Wp[:n, :k] = W.astype(np.float16)
     return np.ascontiguousarray(Wp.reshape(npad // 32, 32, kpad // 16, 2, 8).transpose(0, 2, 3, 1, 4))
@@ -217,7 +217,7 @@ class ViTS14:
         pos = interpolate_pos_embed(g("pos_embed"), PATCH_H, self.patch_w)
         cls_pos = pos.copy()
         cls_pos[0] += g("cls_token").reshape(-1)
-        put(0, to_frag_f16(g("patch_embed.proj.weight").reshape(dim, -1)))
+        put(0, to_frag_f16(g("patch_embed.proj.weight").reshape(dim, -1), 32))   # (588 -> 608 columns: whole stages of two k-steps, csrc/vit.hip)
         put(1, g("patch_embed.proj.bias"))
         put(2, cls_pos.astype(np.float32))
         i = 3
