@@ -54,7 +54,9 @@ int vfm_debug_set_match_stats(int on);
  * compute unit are at least three quarters full; -1 = never); -10: its waves per workgroup (6, 8, 12 = default; 112 = 12 with non-temporal
  * output stores); -11 / -12: low / high 32 bits of a device pointer to its per-workgroup placement trace (tools/ab_vit_astat_trace.py; 0 = off);
  * -14: image preprocessing by one workgroup per 14 x 14 patch (1, default since round 5) / by round 1's one-thread-per-fragment-unit kernel (0);
- * -15: the token-stationary kernel with two channel tiles per wave (1, default since round 5) / one (0) */
+ * -15: the token-stationary kernel with two channel tiles per wave (1, default since round 5) / one (0);
+ * -16: timing experiment, WRONG RESULTS: every workgroup of the LDS-tiled kernel reads token group 0 (its A operand then hits the L2);
+ * -17: the residual GEMMs (N = 384) of the LDS-tiled path as 128 x 128 tiles (0, default) / one 128 x 384 tile per workgroup (1) */
 int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg);
 /* A/B + tests: vfm_voxel_robin on a VoxelDownsample-shaped call (one point per voxel, reserve(n), n <= 2^18) by the one-launch kernel
  * (1, default: up to 256 resident workgroups with grid-wide barriers -- csrc/voxel.hip) / always by the general multi-launch path (0); both give the

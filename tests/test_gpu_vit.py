@@ -107,8 +107,8 @@ def test_vit_b14_config_c5():
 def test_vit_lds_tiled_gemms_equal_the_direct_kernels_bit_for_bit():
     """The LDS-staged 128 x 128 workgroup-tile GEMM (round 4: chosen for batches of many images) accumulates every output over the same
     k order with the same instruction as the direct kernel, so the two forwards are identical bits -- also where the token tiles do
-    not fill the last group of four (5 images x 288 padded tokens = 45 tiles), with the patch embedding's 37 k-steps (not a multiple of
-    the stage), at ViT-S and at a ViT-B-like width; and the forced LDS path passes the oracle tolerance."""
+    not fill the last group of four (5 images x 288 padded tokens = 45 tiles), at ViT-S and at a ViT-B-like width, with the residual
+    GEMMs as 128 x 128 tiles and as one 128 x 384 tile per workgroup; and the forced LDS path passes the oracle tolerance."""
     from vfmreg import _lib
     from vfmreg import vit as V
     lib = _lib.load()
@@ -120,14 +120,17 @@ def test_vit_lds_tiled_gemms_equal_the_direct_kernels_bit_for_bit():
             lib.vfm_debug_set_vit_gemm(-5, 0)        # never the LDS kernel
             direct = model.forward(imgs).clone()
             lib.vfm_debug_set_vit_gemm(-5, 1)        # always (every GEMM whose N is a multiple of 128)
-            tiled = model.forward(imgs).clone()
-            torch.cuda.synchronize()
-            assert torch.equal(direct, tiled), (dim, B, float((direct - tiled).abs().max()))
+            for wide in (0, 1):                      # the residual GEMMs (N = 384) as 128 x 128 tiles / as one 128 x 384 tile per workgroup (round 5)
+                lib.vfm_debug_set_vit_gemm(-17, wide)
+                tiled = model.forward(imgs).clone()
+                torch.cuda.synchronize()
+                assert torch.equal(direct, tiled), (dim, B, wide, float((direct - tiled).abs().max()))
         lib.vfm_debug_set_vit_gemm(-5, 1)
         w = V.random_weights(seed=5, dim=128, depth=2, mlp=256)
         _check(w, _smooth_images(np.random.default_rng(0), 9, 300, 400), atol=1e-2, cos_min=0.99999)
     finally:
         lib.vfm_debug_set_vit_gemm(-5, 256)
+        lib.vfm_debug_set_vit_gemm(-17, 0)
 
 
 def test_vit_token_stationary_gemms_equal_the_other_kernels_bit_for_bit():

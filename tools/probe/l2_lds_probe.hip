@@ -68,7 +68,7 @@ static void run(const char* src, bool shared, int wg_per_cu, float* out) {
     size_t lds = (size_t)(160 * 1024 / wg_per_cu) & ~(size_t)1023;
     if (lds > 64 * 1024) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<D, TOREG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (lds < (size_t)4 * D * 1024) { printf("  (D = %d does not fit %d workgroups per unit)\n", D, wg_per_cu); return; }
-    const unsigned span_mask = shared ? (1u << 20) - 1u : (1u << 18) - 1u;
+    const unsigned span_mask = shared ? (1u << 20) - 1u : (1u << 17) - 1u;   // (own region: half of the workgroup's 256 KiB, so that a wave's KiB never leaves it)
     const unsigned own = shared ? 0u : (1u << 18);
     const int iters = 2048 / D;
     hipEvent_t e0, e1;
@@ -85,6 +85,7 @@ static void run(const char* src, bool shared, int wg_per_cu, float* out) {
     const double bytes = (double)grid * 4.0 * (double)(iters * D + D) * 1024.0;
     printf("  %s, %2d waves per unit x %2d KiB in flight each = %4d KiB per unit: %7.2f TB/s (%6.1f GB/s per unit), %.3f ms\n",
            TOREG ? "registers" : "LDS-DMA  ", 4 * wg_per_cu, D, 4 * wg_per_cu * D, bytes / ms * 1e-9, bytes / ms * 1e-6 / cus, ms);
+    fflush(stdout);
 }
 
 int main() {

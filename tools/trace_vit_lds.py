@@ -40,10 +40,10 @@ print(f"  start: median {np.median(start):.1f} us, max {start.max():.1f}; kernel
 print(f"  k loop: min / median / max {np.min(loop_end - start):.1f} / {np.median(loop_end - start):.1f} / {np.max(loop_end - start):.1f} us")
 print(f"  epilogue: min / median / max {np.min(end - loop_end):.1f} / {np.median(end - loop_end):.1f} / {np.max(end - loop_end):.1f} us")
 ns = ks / 2.0
-print("  cycles per stage of wave 3 (shader clock), median over the workgroups: DMA wait %.0f, barrier %.0f, DMA issue + LDS reads %.0f, MFMAs %.0f"
+print("  counter ticks per stage of the last wave, median over the workgroups: DMA wait %.0f, LDS wait + barrier %.0f, - %.0f, fragment reads + MFMAs + DMA issue %.0f"
       % tuple(np.median(cyc[:, i] / ns) for i in range(4)))
 slow = (loop_end - start) > np.quantile(loop_end - start, 0.9)
-print("  the slowest tenth of the workgroups: DMA wait %.0f, barrier %.0f, DMA issue + LDS reads %.0f, MFMAs %.0f"
+print("  the slowest tenth of the workgroups: DMA wait %.0f, LDS wait + barrier %.0f, - %.0f, fragment reads + MFMAs + DMA issue %.0f"
       % tuple(np.median(cyc[slow, i] / ns[slow]) for i in range(4)))
 q = np.quantile(end, [0.1, 0.5, 0.9, 1.0])
 print(f"  workgroup end times: 10 % {q[0]:.1f}, 50 % {q[1]:.1f}, 90 % {q[2]:.1f}, last {q[3]:.1f} us")

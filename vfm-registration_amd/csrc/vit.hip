@@ -590,23 +590,35 @@ __device__ __forceinline__ void vit_glds16(const void* gsrc, unsigned lds_dst_un
 // (__launch_bounds__(256, 3): without the bound the compiler kept the 64 accumulators in AGPRs beside 116 - 140 VGPRs and moved them back and
 // forth -- 180 - 204 registers, two waves per SIMD; with it 112 - 137 and no AGPR, no spill: three waves per SIMD with a ring of three stages
 // (48 KiB): 96 images 4.20 -> 4.09 ms, 48 images 2.39 -> 2.29)
-template <int EPI, int KB, int NS>
-__global__ __launch_bounds__(256, 3) void vit_gemm_lds_kernel(GemmArgs g) {
+// NG (round 5): channel groups of 128 a workgroup takes -- 1: a 128 x 128 tile (three workgroups per compute unit); 3: all 384 channels of
+// the residual GEMMs (proj, fc2) for its 128 tokens: one workgroup per compute unit, 64 x 192 per wave.  Why: LDS-DMA moves at most
+// ~64 bytes per clock and compute unit (tools/probe/l2_lds_probe.hip: 125 - 145 GB/s per unit from the L2 whatever is in flight), and a
+// 128 x 128 tile asks for exactly that at the matrix pipes' peak -- (128 + 128) x 32 B per k-step of 4 x 4 MFMAs = 64 B per clock:
+// the loop can be at best half address path, half MFMA (measured: a stage's waves spend half their time between the barrier and
+// their fragments' arrival, tools/trace_vit_lds.py).  128 x 384 asks for 43 B per clock, reads the token operand once instead of
+// three times, and 237 equal workgroups on 256 units have no tail (with three 128 x 128 workgroups per unit the last one ended 17 us
+// behind the median of fc2's 62).
+// NW waves per workgroup (4, or 8 for the wide tile: 64 x 96 per wave, two waves per SIMD -- with four waves of 64 x 192 a SIMD's one
+// wave did its stage's LDS-DMA issue + fragment reads and its 24 MFMAs one after the other: 661 + 820 cycles per stage, slower than
+// the 128 x 128 form)
+// DBG: the tools' trace (s_memtime in the loop makes the compiler drain the LDS queue at every wait: an instantiation of its own)
+template <int EPI, int KB, int NS, int NG = 1, int NW = 4, bool DBG = false>
+__global__ __launch_bounds__(64 * NW, NG == 1 ? 3 : 1) void vit_gemm_lds_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [stage][A | W][tile][k-step][1 KiB]
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mtiles = g.M / 32, ngroups = g.N / 128, mgroups = (mtiles + 3) / 4;
+    const int mtiles = g.M / 32, ngroups = g.N / (128 * NG), mgroups = (mtiles + 3) / 4;
     // group of four token tiles mg on XCD mg % 8 (workgroup b runs on XCD b % 8: observed, speed only): the workgroups that share
     // its A tiles -- one per channel group -- read them through one L2
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int mg = xcd + 8 * (idx / ngroups), ng = idx % ngroups;
     if (mg >= mgroups) return;
     unsigned long long dbg_t0 = 0, dbg_t1 = 0;
-    if (g.dbg) dbg_t0 = wall_clock64();
-    const int wm = wave >> 1, wn = wave & 1;
+    if (DBG && g.dbg) dbg_t0 = wall_clock64();
+    const int wm = wave / (NW / 2), wn = wave % (NW / 2);
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    constexpr int STAGE = 2 * 4 * KB * 1024;
-    constexpr int PW = 2 * KB;   // pieces per wave and stage: 8 KB fragment rows over 4 waves
+    constexpr int STAGE = (1 + NG) * 4 * KB * 1024;
+    constexpr int PW = (4 + 4 * NG) * KB / NW;   // pieces per wave and stage: (4 + 4 NG) KB fragment rows over NW waves
     const int nstages = (g.KS + KB - 1) / KB;
     // piece p of a stage: operand p / (4 KB) (0 = A, 1 = W), tile (p / KB) % 4, k-step p % KB; wave w issues pieces w, w + 4, ...
     // Round 5 (the loop spent 45 scalar instructions per stage of 8 MFMAs on these addresses): a piece's source is a wave-uniform
@@ -617,11 +629,11 @@ __global__ __launch_bounds__(256, 3) void vit_gemm_lds_kernel(GemmArgs g) {
     const char* src[PW];
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
-        const int p = wave + 4 * i;
-        const int op = p / (4 * KB), tile = (p / KB) & 3;
+        const int p = wave + NW * i;
+        const int op = p < 4 * KB ? 0 : 1, tile = op == 0 ? p / KB : (p - 4 * KB) / KB;   // (A: four tiles; W: 4 NG tiles)
         int ks = p % KB;
         ks = ks < g.KS ? ks : g.KS - 1;
-        int rowtile = op == 0 ? mg * 4 + tile : ng * 4 + tile;
+        int rowtile = op == 0 ? mg * 4 + tile : ng * 4 * NG + tile;
         if (op == 0 && rowtile >= mtiles) rowtile = mtiles - 1;   // (a partial last group of token tiles: its epilogue is skipped)
         if (op == 0 && g.hot_a) rowtile = tile;                   // (timing experiment: tools/ab_vit_hot_a.sh)
         src[i] = reinterpret_cast<const char*>((op == 0 ? g.A : g.W) + ((size_t)rowtile * g.KS + ks) * 64);
@@ -629,72 +641,119 @@ __global__ __launch_bounds__(256, 3) void vit_gemm_lds_kernel(GemmArgs g) {
     unsigned lane16 = (unsigned)lane * 16u;   // + the bytes the wave's pieces have moved on by (one VALU add per stage instead of PW 64-bit scalar ones)
     const int kk_wave = wave % KB;
     int ks_next = 0;   // first k-step of the stage issue_stage sends next
-    auto issue_stage = [&](int slot) {
-        const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * STAGE) + (unsigned)wave * 1024u);
+    // a stage goes out piece by piece, BETWEEN the MFMAs of the stage in use (issue_piece): issued in one block right behind the
+    // barrier the PW LDS-DMA instructions of every wave filled the vector-memory queue at once -- the address path moves ~64 bytes per
+    // clock and compute unit, a stage is 16 - 32 KiB: 250 - 500 cycles -- and the fragment reads queued up behind them: a stage's waves
+    // spent as long between the barrier and their fragments' arrival as in their MFMAs (tools/trace_vit_lds.py)
+    unsigned dst_cur = 0;
+    auto begin_stage = [&](int slot) { dst_cur = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * STAGE) + (unsigned)wave * 1024u); };
+    auto issue_piece = [&](int i) {
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0" : "=s"(keep)::"memory");
-#pragma unroll
-        for (int i = 0; i < PW; ++i)
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(src[i]), "s"(dst0 + 4096u * (unsigned)i) : "memory");
-        asm volatile("s_mov_b32 m0, %0" ::"s"(keep) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane16), "s"(src[i]), "s"(dst_cur + (unsigned)(NW * 1024) * (unsigned)i) : "memory");
+    };
+    auto end_stage = [&]() {
         ks_next += KB;
-        // (wave + 4 i) % KB = wave % KB: every piece of this wave is the same k-step of its stage; it moves on while its next k-step exists
+        // (wave + NW i) % KB = wave % KB: every piece of this wave is the same k-step of its stage; it moves on while its next k-step exists
         lane16 += (ks_next + kk_wave < g.KS) ? (unsigned)(KB * 1024) : 0u;
     };
-    floatx16 acc[2][2];
+    auto issue_stage = [&](int slot) {
+        begin_stage(slot);
+#pragma unroll
+        for (int i = 0; i < PW; ++i) issue_piece(i);
+        end_stage();
+    };
+    constexpr int NJ = 8 * NG / NW;   // channel tiles per wave
+    floatx16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 #pragma unroll
-    for (int st = 0; st < NS - 1; ++st) issue_stage(st);   // stages 0 .. NS - 2 (dummies past the end)
-    int slot = 0;
-    unsigned long long c_wait = 0, c_bar = 0, c_lds = 0, c_mfma = 0;   // (g.dbg: cycles of wave 3 at the DMA wait, the barrier, issue + LDS reads, the MFMAs)
-    for (int stage = 0; stage < nstages; ++stage) {
-        unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
-        if (g.dbg) tc0 = __builtin_readcyclecounter();
-        vit_wait_vmcnt<(NS - 2) * PW>();      // this wave's pieces of `stage`: the NS - 2 stages issued since may fly on
-        if (g.dbg) tc1 = __builtin_readcyclecounter();
-        __builtin_amdgcn_s_barrier();         // everybody's; and everybody has left the slot of stage - 1
-        asm volatile("" ::: "memory");
-        if (g.dbg) tc2 = __builtin_readcyclecounter();
-        issue_stage(slot == 0 ? NS - 1 : slot - 1);   // stage + NS - 1
-        const unsigned char* st = lds + slot * STAGE;
-        // (the launcher sends only whole stages here: KS % KB == 0.  All of a stage's fragments are requested up front -- straight-line
-        // code, the k-steps' registers distinct --, so that the LDS reads of k-step ks + 1 are under the MFMAs of k-step ks; with a
-        // bounds test per k-step the compiler had each k-step wait for its own four reads.  Measured: no difference -- the other two
-        // waves of the SIMD covered that wait already)
-        half8 af[KB][2], wf[KB][2];
+    for (int st = 0; st < NS; ++st) issue_stage(st);   // stages 0 .. NS - 1: every slot of the ring (dummies past the end)
+    // Fragments double-buffered in registers across the stage barrier (round 5).  A stage's fragments are all read into registers
+    // before its MFMAs; so behind the barrier that says "stage s + 1 has landed" everybody has READ stage s, its slot takes stage
+    // s + NS at once, and the reads of stage s + 1 go out in front of the MFMAs of stage s: LDS reads (80 KiB per stage and compute
+    // unit for the wide tile: 310 cycles at the LDS's 256 B per clock), LDS-DMA (16 - 32 KiB at ~64 B per clock) and MFMAs (768 cycles)
+    // run under one another instead of one after the other -- the barrier kept the waves of a workgroup in the same phase, and the
+    // phases added up (tools/trace_vit_lds.py: 26 + 114 + 554 + 543 cycles per stage).
+    struct Frags {
+        half8 a[KB][2], w[KB][NJ];
+    };
+    auto read_frags = [&](Frags& f, int sl) {
+        const unsigned char* st = lds + sl * STAGE;
 #pragma unroll
-        for (int ks = 0; ks < KB; ++ks)
+        for (int ks = 0; ks < KB; ++ks) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[ks][i] = *reinterpret_cast<const half8*>(st + ((2 * wm + i) * KB + ks) * 1024 + lane * 16);
-                wf[ks][i] = *reinterpret_cast<const half8*>(st + 4 * KB * 1024 + ((2 * wn + i) * KB + ks) * 1024 + lane * 16);
-            }
-        if (g.dbg) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            tc3 = __builtin_readcyclecounter();
+            for (int i = 0; i < 2; ++i) f.a[ks][i] = *reinterpret_cast<const half8*>(st + ((2 * wm + i) * KB + ks) * 1024 + lane * 16);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) f.w[ks][j] = *reinterpret_cast<const half8*>(st + 4 * KB * 1024 + ((NJ * wn + j) * KB + ks) * 1024 + lane * 16);
         }
+    };
+    int slot = 0;   // slot of the stage whose fragments are in registers
+    unsigned long long c_wait = 0, c_bar = 0, c_lds = 0, c_mfma = 0;   // (g.dbg: cycles of the last wave at the DMA wait, the barrier, -, everything else)
+    auto body = [&](const Frags& cur, Frags& nxt, int stage) {
+        unsigned long long tc0 = 0, tc1 = 0, tc2 = 0;
+        const bool more = stage + 1 < nstages;   // wave-uniform, the same in every wave
+        if (DBG && g.dbg) tc0 = __builtin_readcyclecounter();
+        if (more) {
+            vit_wait_vmcnt<(NS - 2) * PW>();      // this wave's pieces of stage + 1: the NS - 2 stages issued since may fly on
+            if (DBG && g.dbg) tc1 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of stage `stage` (issued a stage of MFMAs ago) have returned
+            __builtin_amdgcn_s_barrier();         // everybody's; and everybody holds stage `stage` in registers: its slot is free
+            asm volatile("" ::: "memory");
+            if (DBG && g.dbg) tc2 = __builtin_readcyclecounter();
+            begin_stage(slot);                    // stage + NS
+            read_frags(nxt, slot + 1 == NS ? 0 : slot + 1);
+        }
+        constexpr int NMFMA = KB * 2 * NJ, EVERY = NMFMA / PW > 0 ? NMFMA / PW : 1;
+        int piece = 0;
 #pragma unroll
         for (int ks = 0; ks < KB; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
-        if (g.dbg) {
-            const unsigned long long tc4 = __builtin_readcyclecounter();
+                for (int j = 0; j < NJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.w[ks][j], cur.a[ks][i], acc[i][j], 0, 0, 0);
+                    const int q = (ks * 2 + i) * NJ + j;
+                    if (q % EVERY == 0 && piece < PW) {   // (compile-time: the loops are unrolled)
+                        if (more) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue_piece(piece);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        ++piece;
+                    }
+                }
+        if (more) {
+#pragma unroll
+            for (int i2 = 0; i2 < PW; ++i2)
+                if (i2 >= piece) issue_piece(i2);
+            end_stage();
+        }
+        if (DBG && g.dbg && more) {
+            const unsigned long long tc3 = __builtin_readcyclecounter();
             c_wait += tc1 - tc0;
             c_bar += tc2 - tc1;
-            c_lds += tc3 - tc2;
-            c_mfma += tc4 - tc3;
+            c_mfma += tc3 - tc2;
         }
         slot = slot + 1 == NS ? 0 : slot + 1;
+    };
+    Frags f0, f1;
+    vit_wait_vmcnt<(NS - 1) * PW>();   // stage 0
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(f0, 0);
+    int stage = 0;
+    for (; stage + 1 < nstages; stage += 2) {
+        body(f0, f1, stage);
+        body(f1, f0, stage + 1);
     }
+    if (stage < nstages) body(f0, f1, stage);
     vit_wait_vmcnt<0>();   // (the dummy stages: no LDS-DMA may be in flight when the workgroup's LDS is handed on)
-    if (g.dbg) dbg_t1 = wall_clock64();
+    if (DBG && g.dbg) dbg_t1 = wall_clock64();
     const int hi = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -706,14 +765,14 @@ __global__ __launch_bounds__(256, 3) void vit_gemm_lds_kernel(GemmArgs g) {
         float ln_mean = 0.f, ln_rstd = 0.f;   // (a, nb) of the lane's token: see ln_stats_load
         if constexpr (EPI == EPI_QKV || EPI == EPI_GELU) ln_stats_load(g, m, ln_mean, ln_rstd);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n32 = __builtin_amdgcn_readfirstlane(ng * 4 + 2 * wn + j);
+        for (int j = 0; j < NJ; ++j) {
+            const int n32 = __builtin_amdgcn_readfirstlane(ng * 4 * NG + NJ * wn + j);
             EpiRegs e;
             epi_load<EPI>(g, m, t, hi, n32, e);
             epi_tile<EPI>(g, acc[i][j], m, mtu, b, tq, t, hi, n32, e, ln_mean, ln_rstd);
         }
     }
-    if (g.dbg && wave == 3 && lane == 0) {   // (tools/trace_vit_lds.py) start, end of the k loop, end: 100 MHz ticks
+    if (DBG && g.dbg && wave == NW - 1 && lane == 0) {   // (tools/trace_vit_lds.py) start, end of the k loop, end: 100 MHz ticks
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         g.dbg[blockIdx.x * 4 + 0] = dbg_t0;
         g.dbg[blockIdx.x * 4 + 1] = dbg_t1;
@@ -1336,6 +1395,7 @@ int launch_gemm_cfg(const GemmArgs& g, hipStream_t st) {
 // tiles everywhere (twice the waves) give 0.76 instead of 0.82 ms, 64 x 64 wave tiles and row-complete workgroups with the
 // LayerNorm fused into the epilogue (63 launches, but 66 workgroups per GEMM) gave 1.04 ms and were removed again.
 int g_vit_hot_a = 0;
+int g_vit_wide_tile = 0;      // vfm_debug_set_vit_gemm(-17, 0 / 1): the residual GEMMs (N = 384) of the LDS-tiled path as 128 x 128 tiles (default) / as one 128 x 384 tile per workgroup (measured slower: DESIGN.md R5.9)
 int g_vit_lds_shape = 23;     // vfm_debug_set_vit_gemm(-6, KB * 10 + NS): k-steps per stage / stages in the ring of the LDS-tiled kernel (23: 48 KiB, three workgroups per compute unit)
 int g_vit_att_lds_min = 1;   // vfm_debug_set_vit_gemm(-7, n): attention with K / V^T in the LDS from n images per call on (0 = never)
 int g_vit_lds_min_wg = 256;   // vfm_debug_set_vit_gemm(-5, n): the LDS-tiled kernel from n workgroups of 128 x 128 on (0 = never)
@@ -1420,6 +1480,26 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
             GemmArgs gl = g;
             gl.hot_a = g_vit_hot_a;
             gl.dbg = EPI == EPI_RESID ? g_vit_astat_dbg : nullptr;   // (the trace buffer serves whichever kernel a tool looks at)
+            if (EPI == EPI_RESID && g.N == 384 && g_vit_wide_tile && g.KS % 2 == 0) {   // one workgroup per 128 tokens x all 384 channels (NG = 3)
+                const int gridw = 8 * ceil_div(ceil_div(g.M / 32, 4), 8);
+                constexpr int ldsw = 4 * 16 * 2 * 1024;   // NS = 4 stages of (4 + 12) x KB = 2 KiB: 128 KiB
+                static unsigned long long attr_w = 0ull;
+                int devw = 0;
+                (void)hipGetDevice(&devw);
+                if (!((attr_w >> (devw & 63)) & 1ull)) {
+                    VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_gemm_lds_kernel<EPI, 2, 4, 3, 8>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, ldsw));
+                    attr_w |= 1ull << (devw & 63);
+                }
+                if (gl.dbg) {
+                    VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_gemm_lds_kernel<EPI, 2, 4, 3, 8, true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, ldsw));
+                    hipLaunchKernelGGL((vit_gemm_lds_kernel<EPI, 2, 4, 3, 8, true>), dim3(gridw), dim3(512), ldsw, st, gl);
+                } else
+                hipLaunchKernelGGL((vit_gemm_lds_kernel<EPI, 2, 4, 3, 8>), dim3(gridw), dim3(512), ldsw, st, gl);
+                VFM_CHECK_LAUNCH("vit_gemm_lds_kernel (128 x 384)");
+                return VFM_OK;
+            }
             const int grid = 8 * ceil_div(ceil_div(g.M / 32, 4), 8) * (g.N / 128);   // every XCD: ceil(groups / 8) token groups x channel groups
 #define VIT_LDS(KB, NS)                                                                                                              \
     do {                                                                                                                             \
@@ -1431,6 +1511,11 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
                                               hipFuncAttributeMaxDynamicSharedMemorySize, NS * 8 * KB * 1024));                      \
             attr_set |= 1ull << (dev & 63);                                                                                          \
         }                                                                                                                            \
+        if (gl.dbg) {                                                                                                                \
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_gemm_lds_kernel<EPI, KB, NS, 1, 4, true>),          \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, NS * 8 * KB * 1024));                      \
+            hipLaunchKernelGGL((vit_gemm_lds_kernel<EPI, KB, NS, 1, 4, true>), dim3(grid), dim3(256), NS * 8 * KB * 1024, st, gl);   \
+        } else                                                                                                                       \
         hipLaunchKernelGGL((vit_gemm_lds_kernel<EPI, KB, NS>), dim3(grid), dim3(256), NS * 8 * KB * 1024, st, gl);                    \
     } while (0)
             switch (g_vit_lds_shape) {
@@ -1462,6 +1547,10 @@ VFM_EXPORT int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg) {
     }
     if (narrow_cfg == -6) {
         g_vit_lds_shape = wide_cfg;
+        return VFM_OK;
+    }
+    if (narrow_cfg == -17) {   // residual GEMMs of the LDS-tiled path: 128 x 384 tiles (1) / 128 x 128 (0, default)
+        g_vit_wide_tile = wide_cfg;
         return VFM_OK;
     }
     if (narrow_cfg == -16) {   // timing experiment (wrong results): the LDS-tiled kernel's A operand from token group 0 in every workgroup
