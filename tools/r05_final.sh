@@ -23,12 +23,19 @@ cd $R
 # ViT
 VFM_VIT_LDS_THR=256 timeout 400 python tools/time_vit_batch.py 2>&1 | grep -v amdgpu > $O/time_vit_batch.txt; tail -7 $O/time_vit_batch.txt
 bash tools/prof_vit_r05.sh > $O/prof_vit.txt 2>&1
+timeout 300 python tools/ab_vit_wide.py 2>&1 | grep -v amdgpu > $O/ab_vit_wide.txt; cat $O/ab_vit_wide.txt
+timeout 100 python tools/trace_vit_lds.py 90 2>&1 | grep -v amdgpu > $O/trace_vit_lds.txt
+timeout 300 bash tools/ab_vit_hot_a.sh 90 > $O/ab_vit_hot_a.txt 2>&1
 VIT_IMAGES=96 bash tools/pmc_vit.sh > $O/pmc_vit96.txt 2>&1; cp gpurun_out/pmc_vit/summary.json $O/pmc_vit_96images.json
 VIT_IMAGES=90 bash tools/pmc_vit.sh > $O/pmc_vit90.txt 2>&1; cp gpurun_out/pmc_vit/summary.json $O/pmc_vit_90images.json
 VIT_IMAGES=6 bash tools/pmc_vit.sh > $O/pmc_vit6.txt 2>&1; cp gpurun_out/pmc_vit/summary.json $O/pmc_vit_6images.json
 for i in 1 2 3 4 5 6; do cp gpurun_out/pmc_vit/p${i}_counter_collection.csv $O/pmc_vit6_pass${i}_counter_collection.csv 2>/dev/null; done
 # the reference-shaped API, C3 in groups, other rows
 timeout 600 python tools/time_api.py > $O/time_api.txt 2>&1; tail -8 $O/time_api.txt
+{ timeout 200 python tools/time_api_steps.py 2>&1; timeout 200 python tools/time_api_steps.py 60000 200000 2>&1; } | grep -v amdgpu > $O/time_api_steps.txt
+timeout 200 python tools/ab_voxel_grid.py 2>&1 | grep -v amdgpu > $O/ab_voxel_grid.txt; cat $O/ab_voxel_grid.txt
+timeout 100 python tools/trace_voxel_grid.py 2>&1 | grep -v amdgpu > $O/trace_voxel_grid.txt
+timeout 200 python tools/ab_api_search.py 2>&1 | grep -v amdgpu > $O/ab_api_search.txt
 timeout 400 python tools/time_c3_group.py 1 2 4 8 1 4 2>&1 | grep -v amdgpu > $O/time_c3_group.txt; cat $O/time_c3_group.txt
 { timeout 300 python tools/time_f_rows.py 2>&1; echo; timeout 300 python tools/time_c3.py 2>&1; echo; timeout 200 python tools/time_ransac.py 2>&1; } > $O/other_rows.txt; tail -20 $O/other_rows.txt
 { bash tools/prof_finish.sh 5,0 50 lifted 2>&1 | tail -3; bash tools/prof_finish.sh 8 50 d2 2>&1 | tail -1; } > $O/prof_finish.txt
@@ -36,3 +43,5 @@ timeout 400 python tools/time_c3_group.py 1 2 4 8 1 4 2>&1 | grep -v amdgpu > $O
 timeout 600 python tools/soak_mx6.py 40 505 2>&1 | tail -3 > $O/soak_mx6.txt; cat $O/soak_mx6.txt
 timeout 600 python tools/soak_half.py 40 505 2>&1 | tail -3 > $O/soak_half.txt; cat $O/soak_half.txt
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mx6_probe tools/probe/mx6_probe.hip && timeout 120 /tmp/mx6_probe > $O/mx6_probe.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -w -o /tmp/f16_mfma_probe tools/probe/f16_mfma_probe.hip && timeout 120 /tmp/f16_mfma_probe > $O/f16_mfma_probe.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -w -o /tmp/l2_lds_probe tools/probe/l2_lds_probe.hip && timeout 120 /tmp/l2_lds_probe > $O/l2_lds_probe.txt 2>&1; tail -3 $O/l2_lds_probe.txt

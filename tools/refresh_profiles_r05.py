@@ -75,6 +75,9 @@ def main():
     copies.update({"pmc_match_coarse_mx6fused.json": "r05_pmc_match_coarse_mx6fused.json", "prof_vit.txt": "r05_prof_vit.txt",
                    "pmc_vit_96images.json": "r05_pmc_vit_96images.json", "pmc_vit_90images.json": "r05_pmc_vit_90images.json",
                    "pmc_vit_6images.json": "r05_pmc_vit_6images.json", "mx6_probe.txt": "r05_mx6_probe.txt"})
+    copies.update({"time_api_steps.txt": "r05_time_api_steps.txt", "ab_voxel_grid.txt": "r05_ab_voxel_grid.txt", "trace_voxel_grid.txt": "r05_trace_voxel_grid.txt",
+                   "ab_api_search.txt": "r05_ab_api_search.txt", "ab_vit_wide.txt": "r05_ab_vit_wide.txt", "trace_vit_lds.txt": "r05_trace_vit_lds.txt",
+                   "ab_vit_hot_a.txt": "r05_ab_vit_hot_a.txt", "f16_mfma_probe.txt": "r05_f16_mfma_probe.txt", "l2_lds_probe.txt": "r05_l2_lds_probe.txt"})
     for i in range(1, 7):
         copies[f"pmc_vit6_pass{i}_counter_collection.csv"] = f"r05_pmc_vit6_pass{i}_counter_collection.csv"
     for i in range(1, 8):
@@ -248,10 +251,26 @@ Counters per kernel (separate `--pmc` passes, `--kernel-trace` only), 96 images 
 {text('r05_time_api.txt', 2500)}
 ```
 
-The one-launch VoxelDownsample kernel, measured and not adopted (`r05_time_api_onelaunch.txt`, same script with the kernel on):
+Step by step (`tools/time_api_steps.py`), and VoxelDownsample alone: the general multi-launch path against the one-launch kernel (`tools/ab_voxel_grid.py`),
+the kernel phase by phase (`tools/trace_voxel_grid.py`), the search of ~10^3 queries at half / full width (`tools/ab_api_search.py`):
 
 ```
-{text('r05_time_api_onelaunch.txt', 2500)}
+{text('r05_time_api_steps.txt', 2500)}
+{text('r05_ab_voxel_grid.txt', 2500)}
+{text('r05_trace_voxel_grid.txt', 2500)}
+{text('r05_ab_api_search.txt', 2500)}
+```
+
+(The first one-launch attempt of the round -- one workgroup going on alone -- measured slower and is gone: `r05_time_api_onelaunch.txt`.)
+
+## What bounds the ViT GEMMs (`tools/probe/f16_mfma_probe.hip`, `tools/probe/l2_lds_probe.hip`, `tools/trace_vit_lds.py`, `tools/ab_vit_hot_a.sh`, `tools/ab_vit_wide.py`)
+
+```
+{text('r05_f16_mfma_probe.txt', 2500)}
+{text('r05_l2_lds_probe.txt', 4000)}
+{text('r05_trace_vit_lds.txt', 2500)}
+{text('r05_ab_vit_hot_a.txt', 2500)}
+{text('r05_ab_vit_wide.txt', 2500)}
 ```
 
 The finish stage kernel by kernel (`tools/prof_finish.sh`; lifted + common descriptors behind the fp6 / int8 full-width pass, D.2 behind the fused half-width pass):

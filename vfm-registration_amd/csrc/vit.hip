@@ -936,6 +936,13 @@ __global__ __launch_bounds__(64 * NW, 1) void vit_gemm_astat2_kernel(GemmArgs g)
         // a straight-line loop body, so that the compiler can COUNT the loads in flight.  With the reload under `if (s + PF < KS)` it waited
         // for vmcnt(0) in front of every k-step -- every weight fragment's L2 round trip was exposed, 24 times per tile pair: that, not
         // the LDS and not the issue rate, was what the token-stationary kernels' 50 - 66 us consisted of.)
+        // The token fragments of k-step s + 1 are requested in front of the MFMAs of k-step s (two register sets, alternating: PF is even
+        // and every block starts at a multiple of PF): re-used registers had every k-step begin with its own four LDS reads and a wait
+        // for the first of them -- ~150 cycles in front of 256 cycles of MFMAs, with one other wave per SIMD to fill them.
+        static_assert(PF % 2 == 0, "two alternating fragment sets");
+        half8 af[2][4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) af[0][t4] = *reinterpret_cast<const half8*>(la + ((size_t)(t4 * KS)) * 1024);
         for (int s0 = 0; s0 + PF < KS; s0 += PF) {   // every block of PF k-steps but the last
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
@@ -943,10 +950,11 @@ __global__ __launch_bounds__(64 * NW, 1) void vit_gemm_astat2_kernel(GemmArgs g)
                 const half8 w0 = *reinterpret_cast<half8*>(&rw0[i]);
                 const half8 w1 = *reinterpret_cast<half8*>(&rw1[i]);
 #pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) af[(i + 1) & 1][t4] = *reinterpret_cast<const half8*>(la + ((size_t)(t4 * KS + s + 1)) * 1024);
+#pragma unroll
                 for (int t4 = 0; t4 < 4; ++t4) {
-                    const half8 af = *reinterpret_cast<const half8*>(la + ((size_t)(t4 * KS + s)) * 1024);
-                    acc0[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, af, acc0[t4], 0, 0, 0);
-                    acc1[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, af, acc1[t4], 0, 0, 0);
+                    acc0[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, af[i & 1][t4], acc0[t4], 0, 0, 0);
+                    acc1[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, af[i & 1][t4], acc1[t4], 0, 0, 0);
                 }
                 rw0[i] = W0[(size_t)(s + PF) * 64];
                 rw1[i] = W1[(size_t)(s + PF) * 64];
@@ -958,11 +966,14 @@ __global__ __launch_bounds__(64 * NW, 1) void vit_gemm_astat2_kernel(GemmArgs g)
             const int s = KS - PF + i;
             const half8 w0 = *reinterpret_cast<half8*>(&rw0[i]);
             const half8 w1 = *reinterpret_cast<half8*>(&rw1[i]);
+            if (i + 1 < PF) {
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) af[(i + 1) & 1][t4] = *reinterpret_cast<const half8*>(la + ((size_t)(t4 * KS + s + 1)) * 1024);
+            }
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) {
-                const half8 af = *reinterpret_cast<const half8*>(la + ((size_t)(t4 * KS + s)) * 1024);
-                acc0[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, af, acc0[t4], 0, 0, 0);
-                acc1[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, af, acc1[t4], 0, 0, 0);
+                acc0[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, af[i & 1][t4], acc0[t4], 0, 0, 0);
+                acc1[t4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, af[i & 1][t4], acc1[t4], 0, 0, 0);
             }
         }
 #pragma unroll
