@@ -104,6 +104,7 @@ int main() {
             run<8, false>(src, shared, w, out);
             run<16, false>(src, shared, w, out);
         }
+        if (shared)
         for (int w : {1, 3, 8}) {
             run<2, true>(src, shared, w, out);
             run<8, true>(src, shared, w, out);
