@@ -44,4 +44,5 @@ timeout 600 python tools/soak_mx6.py 40 505 2>&1 | tail -3 > $O/soak_mx6.txt; ca
 timeout 600 python tools/soak_half.py 40 505 2>&1 | tail -3 > $O/soak_half.txt; cat $O/soak_half.txt
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mx6_probe tools/probe/mx6_probe.hip && timeout 120 /tmp/mx6_probe > $O/mx6_probe.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/f16_mfma_probe tools/probe/f16_mfma_probe.hip && timeout 120 /tmp/f16_mfma_probe > $O/f16_mfma_probe.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_lds_probe tools/probe/mfma_lds_probe.hip && timeout 120 /tmp/mfma_lds_probe > $O/mfma_lds_probe.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/l2_lds_probe tools/probe/l2_lds_probe.hip && timeout 120 /tmp/l2_lds_probe > $O/l2_lds_probe.txt 2>&1; tail -3 $O/l2_lds_probe.txt

@@ -77,7 +77,7 @@ def main():
                    "pmc_vit_6images.json": "r05_pmc_vit_6images.json", "mx6_probe.txt": "r05_mx6_probe.txt"})
     copies.update({"time_api_steps.txt": "r05_time_api_steps.txt", "ab_voxel_grid.txt": "r05_ab_voxel_grid.txt", "trace_voxel_grid.txt": "r05_trace_voxel_grid.txt",
                    "ab_api_search.txt": "r05_ab_api_search.txt", "ab_vit_wide.txt": "r05_ab_vit_wide.txt", "trace_vit_lds.txt": "r05_trace_vit_lds.txt",
-                   "ab_vit_hot_a.txt": "r05_ab_vit_hot_a.txt", "f16_mfma_probe.txt": "r05_f16_mfma_probe.txt", "l2_lds_probe.txt": "r05_l2_lds_probe.txt"})
+                   "ab_vit_hot_a.txt": "r05_ab_vit_hot_a.txt", "f16_mfma_probe.txt": "r05_f16_mfma_probe.txt", "mfma_lds_probe.txt": "r05_mfma_lds_probe.txt", "l2_lds_probe.txt": "r05_l2_lds_probe.txt"})
     for i in range(1, 7):
         copies[f"pmc_vit6_pass{i}_counter_collection.csv"] = f"r05_pmc_vit6_pass{i}_counter_collection.csv"
     for i in range(1, 8):
@@ -267,6 +267,7 @@ the kernel phase by phase (`tools/trace_voxel_grid.py`), the search of ~10^3 que
 
 ```
 {text('r05_f16_mfma_probe.txt', 2500)}
+{text('r05_mfma_lds_probe.txt', 4000)}
 {text('r05_l2_lds_probe.txt', 4000)}
 {text('r05_trace_vit_lds.txt', 2500)}
 {text('r05_ab_vit_hot_a.txt', 2500)}

@@ -39,6 +39,29 @@ print(f"{nimg} images: {len(t)} workgroups traced, k-steps {sorted(set(int(k) fo
 print(f"  start: median {np.median(start):.1f} us, max {start.max():.1f}; kernel end {end.max():.1f} us")
 print(f"  k loop: min / median / max {np.min(loop_end - start):.1f} / {np.median(loop_end - start):.1f} / {np.max(loop_end - start):.1f} us")
 print(f"  epilogue: min / median / max {np.min(end - loop_end):.1f} / {np.median(end - loop_end):.1f} / {np.max(end - loop_end):.1f} us")
+from collections import Counter, defaultdict
+place = both[1][live][:, 2]
+xcc = (place >> 32) & 0xf
+hw = place & 0xffffffff
+cu = (xcc << 8) | (((hw >> 13) & 0x7) << 4) | ((hw >> 8) & 0xf)      # (XCC, shader engine, compute unit)
+per_cu = Counter(int(c) for c in cu)
+print(f"  compute units used: {len(per_cu)}; workgroups per unit: {sorted(Counter(per_cu.values()).items())}")
+by_n = defaultdict(list)
+for c, lo, en in zip(cu, loop_end - start, end):
+    by_n[per_cu[int(c)]].append((lo, en))
+for k in sorted(by_n):
+    v = np.array(by_n[k])
+    print(f"    units with {k} workgroup(s): k loop median {np.median(v[:, 0]):.1f} us (max {v[:, 0].max():.1f}), end median {np.median(v[:, 1]):.1f} us (max {v[:, 1].max():.1f})")
+lp = loop_end - start
+print("    k loop median per XCC: " + ", ".join(f"{int(x)}: {np.median(lp[xcc == x]):.1f}" for x in sorted(set(int(v) for v in xcc))))
+three = np.array([per_cu[int(c)] == 3 for c in cu])
+slow_cu = sorted(((np.median(lp[cu == c]), int(c)) for c in set(int(v) for v in cu[three])), reverse=True)[:8]
+print("    slowest units (k loop median us, XCC / SE / CU): " + ", ".join(f"{t:.1f} @ {c >> 8}/{(c >> 4) & 7}/{c & 15}" for t, c in slow_cu))
+se = (cu >> 4) & 7
+print("    k loop median per shader engine (all XCCs): " + ", ".join(f"{int(x)}: {np.median(lp[se == x]):.1f}" for x in sorted(set(int(v) for v in se))))
+cuix = cu & 15
+print("    k loop median per CU index within its engine: " + ", ".join(f"{int(x)}: {np.median(lp[cuix == x]):.1f}" for x in sorted(set(int(v) for v in cuix))))
+cyc[:, 2] = 0
 ns = ks / 2.0
 print("  counter ticks per stage of the last wave, median over the workgroups: DMA wait %.0f, LDS wait + barrier %.0f, - %.0f, fragment reads + MFMAs + DMA issue %.0f"
       % tuple(np.median(cyc[:, i] / ns) for i in range(4)))

@@ -693,7 +693,7 @@ __global__ __launch_bounds__(64 * NW, NG == 1 ? 3 : 1) void vit_gemm_lds_kernel(
         }
     };
     int slot = 0;   // slot of the stage whose fragments are in registers
-    unsigned long long c_wait = 0, c_bar = 0, c_lds = 0, c_mfma = 0;   // (g.dbg: cycles of the last wave at the DMA wait, the barrier, -, everything else)
+    unsigned long long c_wait = 0, c_bar = 0, c_mfma = 0;   // (DBG: counter ticks of the last wave at the DMA wait, the LDS wait + barrier, everything else)
     auto body = [&](const Frags& cur, Frags& nxt, int stage) {
         unsigned long long tc0 = 0, tc1 = 0, tc2 = 0;
         const bool more = stage + 1 < nstages;   // wave-uniform, the same in every wave
@@ -779,9 +779,12 @@ __global__ __launch_bounds__(64 * NW, NG == 1 ? 3 : 1) void vit_gemm_lds_kernel(
         g.dbg[blockIdx.x * 4 + 2] = wall_clock64();
         g.dbg[blockIdx.x * 4 + 3] = (unsigned long long)g.KS;
         unsigned long long* more = g.dbg + 4 * 4096 + blockIdx.x * 4;   // (the tools' buffer holds [2][4096][4])
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         more[0] = c_wait;
         more[1] = c_bar;
-        more[2] = c_lds;
+        more[2] = ((unsigned long long)(xcc & 0xf) << 32) | hw;   // where the workgroup ran
         more[3] = c_mfma;
     }
 }
