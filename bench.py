@@ -317,22 +317,35 @@ def extra_configs(dev):
         pp = synth.make_pair(N_SCAN, N_MAP, DIM, seed=11)
         voxel_map = np.c_[pp["b_xyz"], pp["b_desc"]].astype(np.float32)
         raw_scan = np.c_[pp["q_xyz"], pp["q_desc"]].astype(np.float32)
-        api = {}
-        for name, icp in (("ms_without_icp", False), ("ms_with_icp", True)):
-            node = RegistrationNode(cache_map=True)
-            node.ransac_registration(voxel_map, raw_scan, "vfm", run_icp=icp)
-            ts = []
-            for _ in range(5):
-                torch.cuda.synchronize()
-                t0 = _time.perf_counter()
-                poses = node.ransac_registration(voxel_map, raw_scan, "vfm", run_icp=icp)
-                torch.cuda.synchronize()
-                ts.append(1e3 * (_time.perf_counter() - t0))
-            api[name] = sorted(ts)[len(ts) // 2]
+        def time_api(vmap, scan):
+            api = {}
+            for name, icp in (("ms_without_icp", False), ("ms_with_icp", True)):
+                node = RegistrationNode(cache_map=True)
+                for _ in range(2):
+                    node.ransac_registration(vmap, scan, "vfm", run_icp=icp)
+                ts = []
+                for _ in range(15):
+                    torch.cuda.synchronize()
+                    t0 = _time.perf_counter()
+                    poses = node.ransac_registration(vmap, scan, "vfm", run_icp=icp)
+                    torch.cuda.synchronize()
+                    ts.append(1e3 * (_time.perf_counter() - t0))
+                api[name] = sorted(ts)[len(ts) // 2]
+            return api, poses
+
+        api, poses = time_api(voxel_map, raw_scan)
         api["pose_err_vs_planted"] = float(np.linalg.norm(poses[1] - pp["T_gt"]))
         out["API_ransac_registration"] = dict(api, workload="RegistrationNode.ransac_registration(voxel_map, raw_scan, 'vfm'): numpy in / numpy out, "
-                                              f"{N_SCAN}-row scan, {N_MAP}-row map x 387 columns fp32, three chained voxelisations, descriptor "
-                                              "search, 50000-iteration RANSAC; the scene's map kept between scans (warm)")
+                                              f"{N_SCAN}-row scan, {N_MAP}-row map x 387 columns fp32, three chained voxelisations (one kernel launch each), "
+                                              "descriptor search, 50000-iteration RANSAC; the scene's map kept between scans (warm)")
+        # the shape of a raw sensor scan: 60 000 points down to ~2 x 10^3 searched rows
+        pp6 = synth.make_pair(60000, N_MAP, DIM, seed=11)
+        raw6 = np.c_[pp6["q_xyz"], pp6["q_desc"]].astype(np.float32)
+        map6 = np.c_[pp6["b_xyz"], pp6["b_desc"]].astype(np.float32)
+        api6, poses6 = time_api(map6, raw6)
+        api6["pose_err_vs_planted"] = float(np.linalg.norm(poses6[1] - pp6["T_gt"]))
+        out["API_ransac_registration"]["raw_scan_60000"] = dict(api6, workload=f"the same call with a 60000-row raw scan against a {N_MAP}-row map")
+        del pp6, raw6, map6
         del voxel_map, raw_scan, pp
     except Exception as e:
         out["API_ransac_registration"] = {"error": f"{type(e).__name__}: {e}"}

@@ -419,6 +419,18 @@ int vfm_voxel_robin(const double *pts, int64_t n, int64_t stride, double voxel_s
                     int32_t max_per_voxel, uint32_t hash_mul_y, int64_t reserve_n, int64_t *keep_out,
                     int64_t *count_out, int64_t *info_host, void *ws, size_t ws_bytes,
                     vfm_stream_t stream);
+/* One level of a CHAIN of VoxelDownsample()s (RN:399-414: voxel sizes .5 x, 1 x, then 5.0 m on the survivors of the one before), enqueued
+ * without a read-back: the level's points are pts[idx[i]], i < *n_dev (idx NULL: pts[i]; n_dev NULL: n_max), moved by the 4 x 4 pose T_dev
+ * first when given (the arithmetic of vfm_transform_xyz_f64).  keep_out: the survivors in the container's iteration order as indices INTO pts
+ * -- the next level's idx; keep_local_out (nullable): their positions in this level's input; count_out: their number; info_dev (device
+ * int64[8]): {buckets, voxels or -1, largest probe distance, wrapped, -, 1 = ran to its end}.  Same order as vfm_voxel_robin(..., 1,
+ * hash_mul_y, n, ...) on the gathered (and moved) points, bit for bit.  The one-launch kernel only (1 <= n_max <= 2^18): a level it does
+ * not reproduce (info[1] = -1: a run of occupied buckets beyond its limit; info[5] = 0: its grid did not become resident) is redone by the
+ * caller through vfm_voxel_robin.  ws: vfm_voxel_robin_workspace_bytes(n_max), one per level in flight. */
+int vfm_voxel_robin_level(const double *pts, int64_t stride, const int64_t *idx, int64_t n_max, const int64_t *n_dev,
+                          const double *T_dev, double voxel_size, uint32_t hash_mul_y, int64_t *keep_out,
+                          int64_t *keep_local_out, int64_t *count_out, int64_t *info_dev, void *ws, size_t ws_bytes,
+                          vfm_stream_t stream);
 
 /* ------------------------------------------------------------------ ICP refinement (row F2) */
 

@@ -220,6 +220,46 @@ def test_one_launch_downsample_equals_the_general_path_and_the_oracle():
         lib.vfm_debug_set_voxel_small(1)
 
 
+def test_chained_levels_without_a_read_back_equal_the_level_by_level_path():
+    """vfm_voxel_robin_level (round 5): the three chained VoxelDownsample()s of registration_node.py:399-414 enqueued as three launches --
+    each level takes the survivors of the one before as rows of the raw cloud, its size read on the device, the third level on the points
+    moved by a pose -- against the level-by-level path (gather, transform, vfm_voxel_robin, read-back) and the oracle."""
+    from oracle import oracle as orc
+    from vfmreg import ops, synth
+    rng = np.random.default_rng(12)
+    for n, extent in ((5, 1.0), (3000, 20.0), (20000, 60.0), (60000, 50.0), (200000, 80.0)):
+        pts = rng.uniform(-extent, extent, (n, 3)) * [1, 1, 0.15]
+        pose = synth.random_pose(rng)
+        d = torch.from_numpy(pts).cuda()
+        T = torch.from_numpy(np.ascontiguousarray(pose)).cuda()
+        l1 = ops.voxel_robin_level(d, 0.5)
+        l2 = ops.voxel_robin_level(d, 1.0, idx=l1["keep"], n_dev=l1["count"], n_max=n)
+        l3 = ops.voxel_robin_level(d, 5.0, idx=l2["keep"], n_dev=l2["count"], n_max=n, T=T, want_local=True)
+        torch.cuda.synchronize()
+        infos = [l["info"].cpu().numpy() for l in (l1, l2, l3)]
+        assert all(i[5] == 1 and i[1] > 0 for i in infos), infos
+        n1, n2, n3 = (int(l["count"].item()) for l in (l1, l2, l3))
+        assert [n1, n2, n3] == [int(i[1]) for i in infos]
+        # level by level on the device
+        o1 = ops.voxel_robin(d, 0.5)
+        x1 = d[o1]
+        o2 = ops.voxel_robin(x1, 1.0)
+        x2 = x1[o2]
+        o3 = ops.voxel_robin(ops.transform_xyz(x2, T), 5.0)
+        np.testing.assert_array_equal(l1["keep"][:n1].cpu().numpy(), o1.cpu().numpy())
+        np.testing.assert_array_equal(l2["keep"][:n2].cpu().numpy(), o1[o2].cpu().numpy())
+        np.testing.assert_array_equal(l3["local"][:n3].cpu().numpy(), o3.cpu().numpy())
+        np.testing.assert_array_equal(l3["keep"][:n3].cpu().numpy(), o1[o2][o3].cpu().numpy())
+        # and the oracle
+        r1 = orc.voxel_robin(pts, 0.5)
+        r2 = orc.voxel_robin(pts[r1], 1.0)
+        moved = ops.transform_xyz(x2, T).cpu().numpy()
+        r3 = orc.voxel_robin(moved, 5.0)
+        np.testing.assert_array_equal(o1.cpu().numpy(), r1)
+        np.testing.assert_array_equal(o2.cpu().numpy(), r2)
+        np.testing.assert_array_equal(o3.cpu().numpy(), r3)
+
+
 def test_one_launch_downsample_from_several_threads_beside_other_work():
     """The one-launch kernel's grid-wide barriers need all of its workgroups resident: four host threads, each on a stream of its own,
     down-sample clouds of different sizes at once while a fifth stream keeps the device busy with large products; every result equals

@@ -39,26 +39,18 @@ def run():
     mark("host: xyz columns as fp64")
     xyz = torch.from_numpy(xyz_h).cuda()
     mark("upload xyz")
-    o1 = ops.voxel_robin(xyz, vs * 0.5)
-    mark("voxel_robin 1")
-    xyz = xyz[o1]
-    o2 = ops.voxel_robin(xyz, vs * 1.0)
-    mark("index + voxel_robin 2")
-    xyz = xyz[o2]
-    raw_of = o1[o2]
-    vhm = node._hash_map_for(voxel_map)
-    mark("2 x index + map lookup (fingerprint)")
     pose = np.ascontiguousarray(np.eye(4), dtype=np.float64)
     key = pose.tobytes()
     if node._pose_cache is None or node._pose_cache[0] != key:
         node._pose_cache = (key, torch.from_numpy(pose).cuda())
-    pcl = ops.transform_xyz(xyz, node._pose_cache[1])
-    mark("pose (kept on the device) + transform")
-    order = ops.voxel_robin(pcl, 5.0)
-    mark("voxel_robin 3")
+    T = node._pose_cache[1]
+    chain = node._voxel_chain(xyz, T, vs)
+    mark("three chained voxelisations: three launches, one read-back (levels' sizes + the 5 m level's rows)")
+    xyz, raw_of, order, raw_idx = chain
+    vhm = node._hash_map_for(voxel_map)
+    pcl = ops.transform_xyz(xyz, T)
     sub = pcl[order]
-    raw_idx = raw_of[order].cpu().numpy()
-    mark("2 x index + rows to the host")
+    mark("gather of voxel_scan, map lookup (fingerprint), transform, index")
     q_desc = node._upload_rows(scan, raw_idx)
     torch.cuda.current_stream().synchronize()   # (measurement only: the copy is asynchronous)
     mark("host: gather descriptor rows + upload")

@@ -1536,6 +1536,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
                 case 42: VIT_LDS(4, 2); break;
                 case 43: VIT_LDS(4, 3); break;
                 case 24: VIT_LDS(2, 4); break;
+                case 25: VIT_LDS(2, 5); break;
                 case 26: VIT_LDS(2, 6); break;
                 default: VIT_LDS(2, 3); break;
             }

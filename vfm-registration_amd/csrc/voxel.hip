@@ -470,7 +470,24 @@ struct GridRobinArgs {
     int64_t* count_out;    // [1]
     int64_t* info;         // {B, nv (-1: a cluster beyond the limit / a wrap that could not be placed), max distance, wrapped} (0 before the launch)
     long long* trace;      // [32] wall-clock stamps (100 MHz) of workgroup 0 behind every barrier (vfm_debug_voxel_trace), or NULL
+    // chained form (vfm_voxel_robin_level): point i is pts[idx[i]] (idx == NULL: pts[i]), moved by the 4 x 4 pose T first (NULL: as it is),
+    // the number of points is read on the device (n_dev, <= n: the launch is sized for n), keep_out holds indices INTO pts (idx composed),
+    // keep_local the positions in the level's own input
+    const int64_t* idx;
+    const int64_t* n_dev;
+    const double* T;
+    int64_t* keep_local;
 };
+// a level's point: gathered, then moved as vfm_transform_xyz_f64 moves it (csrc/project.hip dot4: the same operations in the same order)
+__device__ __forceinline__ Vox grid_voxel_of(const GridRobinArgs& a, int i) {
+    const double* p = a.pts + (a.idx ? a.idx[i] : (int64_t)i) * a.stride;
+    if (!a.T) return voxel_of(p, a.vs);
+    const double x = p[0], y = p[1], z = p[2];
+    double q[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) q[r] = ((a.T[4 * r] * x + a.T[4 * r + 1] * y) + a.T[4 * r + 2] * z) + a.T[4 * r + 3] * 1.0;
+    return voxel_of(q, a.vs);
+}
 
 __device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -578,7 +595,15 @@ __global__ __launch_bounds__(GRID_T) void voxel_robin_grid_kernel(GridRobinArgs 
     __shared__ int wv_mem[GRID_T / 64][GRID_MAX_CLUSTER], ws_mem[GRID_T / 64][GRID_MAX_CLUSTER], wi_mem[GRID_T / 64][GRID_MAX_CLUSTER];   // a wave's long cluster
     __shared__ short wh_mem[GRID_T / 64][GRID_MAX_CLUSTER], wd_mem[GRID_T / 64][GRID_MAX_CLUSTER];
     const int tid = threadIdx.x, G = (int)gridDim.x, T = G * GRID_T, gt = (int)blockIdx.x * GRID_T + tid;
-    const int n = (int)a.n, B = a.B;
+    int n = (int)a.n, B = a.B;
+    if (a.n_dev) {   // chained level: the previous level's count; reserve(n) -> B = 2^ceil(log2(ceil(float(n) / 0.5f))) as the host computes it
+        const int64_t nd = *a.n_dev;
+        n = (int)(nd < a.n ? nd : a.n);
+        const float c = ceilf((float)n / 0.5f);
+        const long long want = (long long)c;
+        B = 1;
+        while (B < want) B <<= 1;
+    }
     const unsigned mask = (unsigned)(B - 1);
     unsigned arrivals = 0;
     int stamp = 0;
@@ -604,12 +629,12 @@ __global__ __launch_bounds__(GRID_T) void voxel_robin_grid_kernel(GridRobinArgs 
     const int pc = (n + T - 1) / T;
     const int plo = min(n, gt * pc), phi = min(n, plo + pc);
     for (int i = plo; i < phi; ++i) {
-        const Vox v = voxel_of(a.pts + (int64_t)i * a.stride, a.vs);
+        const Vox v = grid_voxel_of(a, i);
         int s = (int)(slot_hash(v) & (unsigned)(a.hsize - 1));
         while (true) {
             const int prev = atomicCAS(a.owner + s, EMPTY_OWNER, i);
             if (prev == EMPTY_OWNER) break;
-            const Vox o = voxel_of(a.pts + (int64_t)prev * a.stride, a.vs);
+            const Vox o = grid_voxel_of(a, prev);
             if (o.x == v.x && o.y == v.y && o.z == v.z) break;
             s = (s + 1) & (a.hsize - 1);
         }
@@ -629,7 +654,7 @@ __global__ __launch_bounds__(GRID_T) void voxel_robin_grid_kernel(GridRobinArgs 
         int pos = grid_prefix_sum(a.part, G, sh4, &sh_b, nv) + ex;
         for (int i = plo; i < phi; ++i)
             if (a.tmin[a.slot_of[i]] == i) {
-                const unsigned h = reference_hash(voxel_of(a.pts + (int64_t)i * a.stride, a.vs), a.mul_y);
+                const unsigned h = reference_hash(grid_voxel_of(a, i), a.mul_y);
                 a.vfirst32[pos] = i;
                 a.vhash[pos] = h;
                 atomicAdd(a.hist + (int)(h & mask), 1);
@@ -752,14 +777,20 @@ __global__ __launch_bounds__(GRID_T) void voxel_robin_grid_kernel(GridRobinArgs 
                 if (L > GRID_MAX_CLUSTER) myfail = 1;
                 const int base = valid ? a.key_s[i0] : 0;
                 if (valid && L <= GRID_REPLAY_L) {
-                    for (int t = 0; t < L; ++t) sV[t][tid] = a.sorted_v[i0 + t];
+                    // (an entry's home bucket lies beside it in key_s: fetched with the members, carried through their sort -- looked up
+                    // from the voxel's hash behind the sort it was one more dependent round trip per cluster)
+                    for (int t = 0; t < L; ++t) {
+                        sV[t][tid] = a.sorted_v[i0 + t];
+                        sH[t][tid] = (short)(a.key_s[i0 + t] - base);
+                    }
                     for (int x = 1; x < L; ++x) {   // members by arrival (= voxel rank)
                         const int v = sV[x][tid];
+                        const short hv = sH[x][tid];
                         int y = x - 1;
-                        while (y >= 0 && sV[y][tid] > v) { sV[y + 1][tid] = sV[y][tid]; --y; }
+                        while (y >= 0 && sV[y][tid] > v) { sV[y + 1][tid] = sV[y][tid]; sH[y + 1][tid] = sH[y][tid]; --y; }
                         sV[y + 1][tid] = v;
+                        sH[y + 1][tid] = hv;
                     }
-                    for (int t = 0; t < L; ++t) sH[t][tid] = (short)((int)((a.vhash[sV[t][tid]] - z) & mask) - base);
                     for (int t = 0; t < L; ++t) sD[t][tid] = -1;
                     for (int t = 0; t < L; ++t) {
                         int v = sV[t][tid], ib = sH[t][tid], d = 0;
@@ -837,13 +868,16 @@ __global__ __launch_bounds__(GRID_T) void voxel_robin_grid_kernel(GridRobinArgs 
         for (int i = gt; i < nv; i += T) {
             int j = i + rot;
             if (j >= nv) j -= nv;
-            a.keep_out[i] = (int64_t)a.vfirst32[a.tab_id[j]];
+            const int first = a.vfirst32[a.tab_id[j]];
+            a.keep_out[i] = a.idx ? a.idx[first] : (int64_t)first;
+            if (a.keep_local) a.keep_local[i] = (int64_t)first;
         }
     }
     if (gt == 0) {
         *a.count_out = nv;
         a.info[0] = B;
-        a.info[1] = fail ? -1 : nv;      // (0, as the host left it: the grid gave up at a barrier)
+        a.info[1] = fail ? -1 : nv;      // (0, as the host left it: the grid gave up at a barrier -- or an empty chained level: info[5] tells)
+        a.info[5] = 1;
         a.info[2] = (int64_t)ld_agent(a.ctl + 4);
         a.info[3] = wrapped;
         if (a.trace) {
@@ -1035,6 +1069,50 @@ VFM_EXPORT int vfm_voxel_first(const double* pts, int64_t n, int64_t stride, dou
 }
 
 VFM_EXPORT size_t vfm_voxel_robin_workspace_bytes(int64_t n) { return carve_voxel(nullptr, n, true).bytes; }
+
+// One level of a CHAIN of VoxelDownsample()s (registration_node.py:399-414: .5 -> 1.0 -> 5.0 on the survivors), without a read-back: the
+// level's points are pts[idx[i]] for i < *n_dev (idx == NULL: pts[i]; n_dev == NULL: n_max), moved by the pose T first if T != NULL
+// (as vfm_transform_xyz_f64 moves them); keep_out receives the survivors in the container's order as indices INTO pts (what the next level
+// takes as its idx), keep_local_out (nullable) their positions in this level's input, count_out their number, info_dev (device int64[8])
+// {buckets, voxels or -1 = not reproduced by this kernel, largest probe distance, wrapped, -, 1 = ran to its end}.  Nothing is
+// synchronised: a caller enqueues the levels of its chain and reads counts and infos once.  The one-launch kernel only (n_max <= 2^18);
+// a level it cannot reproduce (a cluster beyond its limit: info[1] = -1, or a grid that did not become resident: info[5] = 0) is the
+// caller's to redo through vfm_voxel_robin.  `ws`: vfm_voxel_robin_workspace_bytes(n_max), a workspace of its own per level in flight.
+VFM_EXPORT int vfm_voxel_robin_level(const double* pts, int64_t stride, const int64_t* idx, int64_t n_max, const int64_t* n_dev,
+                                     const double* T_dev, double voxel_size, uint32_t hash_mul_y, int64_t* keep_out,
+                                     int64_t* keep_local_out, int64_t* count_out, int64_t* info_dev, void* ws, size_t ws_bytes,
+                                     vfm_stream_t stream) {
+    VFM_CHECK_ARG(pts && keep_out && count_out && info_dev && ws && stride >= 3, "voxel_robin_level: bad arguments");
+    VFM_CHECK_ARG(voxel_size > 0.0 && n_max >= 1 && n_max <= GRID_MAX_N, "voxel_robin_level: bad voxel_size / n_max (1 .. 2^18)");
+    if (ws_bytes < vfm_voxel_robin_workspace_bytes(n_max)) return vfm_fail(VFM_EWORKSPACE, "voxel_robin_level: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    VoxelWs w = carve_voxel(ws, n_max, true);
+    int64_t B = 1;
+    {
+        const float c = ceilf((float)n_max / 0.5f);
+        const int64_t want = (int64_t)c;
+        while (B < want) B <<= 1;
+    }
+    GridRobinArgs a{};
+    a.pts = pts; a.n = n_max; a.stride = stride; a.vs = voxel_size; a.mul_y = hash_mul_y; a.B = (int)B;
+    a.owner = w.owner; a.tmin = w.tmin; a.hsize = (int)w.hsize; a.slot_of = w.slot_of;
+    a.info = info_dev;
+    a.ctl = reinterpret_cast<unsigned*>(w.gridctl + 8);
+    a.part = w.gridpart;
+    a.trace = nullptr;
+    a.vfirst32 = w.seq_a; a.vhash = w.vhash; a.hist = w.hist_small;
+    a.sorted_v = w.seq_b; a.key_s = reinterpret_cast<int*>(w.key_s); a.cm = w.cm; a.cl_start = w.cl_start;
+    a.tab_dist = w.tab_dist; a.tab_id = w.tab_id; a.keep_out = keep_out; a.count_out = count_out;
+    a.idx = idx; a.n_dev = n_dev; a.T = T_dev; a.keep_local = keep_local_out;
+    VFM_CHECK_HIP(hipMemsetAsync(w.gridctl, 0, 16 * sizeof(int64_t), st));
+    VFM_CHECK_HIP(hipMemsetAsync(info_dev, 0, 8 * sizeof(int64_t), st));
+    const int ppt = g_voxel_grid_ppt > 0 ? g_voxel_grid_ppt : (n_max <= 32768 ? 1 : n_max <= 131072 ? 2 : 4);
+    const int64_t per_wg = (int64_t)GRID_T * ppt;
+    const unsigned grid = (unsigned)((n_max + per_wg - 1) / per_wg < GRID_MAX_WG ? (n_max + per_wg - 1) / per_wg : GRID_MAX_WG);
+    hipLaunchKernelGGL(voxel_robin_grid_kernel, dim3(grid), dim3(GRID_T), 0, st, a);
+    VFM_CHECK_LAUNCH("voxel_robin_grid_kernel");
+    return VFM_OK;
+}
 
 VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, double voxel_size, int32_t max_per_voxel,
                                uint32_t hash_mul_y, int64_t reserve_n, int64_t* keep_out, int64_t* count_out,

@@ -84,6 +84,7 @@ SIGNATURES = {
     "vfm_voxel_robin_workspace_bytes": (C.c_size_t, [c_i64]),
     "vfm_voxel_robin": (C.c_int, [c_vp, c_i64, c_i64, C.c_double, C.c_int32, C.c_uint32, c_i64, c_vp, c_vp, c_vp, c_vp,
                                   C.c_size_t, c_vp]),
+    "vfm_voxel_robin_level": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, C.c_double, C.c_uint32, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_size_t, c_vp]),
     "vfm_icp_nearest": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, C.c_int32, C.c_double, C.c_double, c_vp, c_vp, c_vp]),
     "vfm_icp_step_nearest": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int32, C.c_double, C.c_double, c_vp, c_vp, c_vp]),
     "vfm_icp_build_system": (C.c_int, [c_vp, c_vp, c_vp, c_i64, C.c_double, c_vp, c_vp]),

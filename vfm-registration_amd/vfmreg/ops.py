@@ -415,6 +415,33 @@ def transform_xyz(xyz: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------ voxel maps
+def voxel_robin_level(pts: torch.Tensor, voxel_size: float, idx: Optional[torch.Tensor] = None, n_dev: Optional[torch.Tensor] = None,
+                      n_max: Optional[int] = None, T: Optional[torch.Tensor] = None, hash_mul: int = 19349663, want_local: bool = False):
+    """One level of a chain of VoxelDownsample()s, enqueued without a read-back (vfm_voxel_robin_level): the points ``pts[idx[:n_dev]]``
+    (``idx`` None: ``pts`` itself), moved by the pose ``T`` first when given.  Returns ``dict(keep, local, count, info)`` of device tensors:
+    ``keep`` the survivors in the container's order as rows of ``pts`` (the next level's ``idx``), ``local`` their positions in this
+    level's input (``want_local``), ``count`` int64[1], ``info`` int64[8] = {buckets, voxels or -1, probe distance, wrapped, -, done}."""
+    _chk(pts, torch.float64, "pts")
+    lib = _lib.load()
+    stride = pts.shape[1]
+    n_max = int(n_max if n_max is not None else (idx.shape[0] if idx is not None else pts.shape[0]))
+    dev = pts.device
+    keep = torch.empty(n_max, dtype=torch.int64, device=dev)
+    local = torch.empty(n_max, dtype=torch.int64, device=dev) if want_local else None
+    count = torch.empty(1, dtype=torch.int64, device=dev)
+    info = torch.empty(8, dtype=torch.int64, device=dev)
+    ws = _ws(lib.vfm_voxel_robin_workspace_bytes(n_max), dev)
+    if idx is not None:
+        _chk(idx, torch.int64, "idx")
+    if T is not None:
+        _chk(T, torch.float64, "T")
+    _lib.check(lib.vfm_voxel_robin_level(pts.data_ptr(), stride, _ptr(idx), n_max, _ptr(n_dev), _ptr(T), float(voxel_size), int(hash_mul),
+                                         keep.data_ptr(), _ptr(local), count.data_ptr(), info.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+               "voxel_robin_level")
+    return dict(keep=keep, local=local, count=count, info=info, ws=ws)
+
+
+
 def voxel_first(xyz: torch.Tensor, voxel_size: float, max_per_voxel: int = 1) -> torch.Tensor:
     """Indices (ascending) of the points that are among the first `max_per_voxel` of their voxel:
     VoxelDownsample (Preprocessing.cpp:50-137) for 1, VoxelHashMap::AddPoints' cap otherwise."""

@@ -95,6 +95,7 @@ class RegistrationNode:
         self.cache_map = bool(cache_map)
         self._map_cache = None   # (weakref to the array, (shape, dtype, fingerprint), VoxelHashMap)
         self._pose_cache = None  # (bytes of the last initial pose, its device copy): the node passes the identity in every call
+        self._chain_host = None  # page-locked landing area of the voxel chain's one read-back
 
     def invalidate_map(self) -> None:
         """Forget the kept map (``cache_map=True``): the next call rebuilds it from the array it is handed."""
@@ -134,23 +135,34 @@ class RegistrationNode:
         scan = np.asarray(raw_scan)
         if scan.ndim != 2 or scan.shape[1] < 3:
             raise ValueError("Invalid shape")
-        xyz = torch.from_numpy(np.ascontiguousarray(scan[:, :3], dtype=np.float64)).cuda()
-        o1 = ops.voxel_robin(xyz, vs * 0.5)                             # RN:399
-        xyz = xyz[o1]
-        o2 = ops.voxel_robin(xyz, vs * 1.0)                             # RN:400  -> voxel_scan
-        xyz = xyz[o2]
-        raw_of_voxel_scan = o1[o2]                                      # rows of raw_scan behind voxel_scan, in its order
-        voxel_hash_map = self._hash_map_for(voxel_map)                  # RN:402-403 (kept across the scans of a scene)
+        raw_xyz = torch.from_numpy(np.ascontiguousarray(scan[:, :3], dtype=np.float64)).cuda()
         pose = np.ascontiguousarray(initial_pose, dtype=np.float64)
         key = pose.tobytes()
         if self._pose_cache is None or self._pose_cache[0] != key:
             self._pose_cache = (key, torch.from_numpy(pose).cuda())
-        pcl_xyz = ops.transform_xyz(xyz, self._pose_cache[1])          # RN:408 (descriptors carried through)
+        T = self._pose_cache[1]
+        chain = self._voxel_chain(raw_xyz, T, vs) if 1 <= len(raw_xyz) <= (1 << 18) else None
+        if chain is not None:
+            # RN:399-400 + 414 in three launches and ONE read-back (round 5): every level takes the survivors of the one before as rows of
+            # the raw scan, on the device
+            xyz, raw_of_voxel_scan, order5, raw_idx5 = chain
+        else:
+            o1 = ops.voxel_robin(raw_xyz, vs * 0.5)                     # RN:399
+            xyz = raw_xyz[o1]
+            o2 = ops.voxel_robin(xyz, vs * 1.0)                         # RN:400  -> voxel_scan
+            xyz = xyz[o2]
+            raw_of_voxel_scan = o1[o2]                                  # rows of raw_scan behind voxel_scan, in its order
+            order5 = raw_idx5 = None
+        voxel_hash_map = self._hash_map_for(voxel_map)                  # RN:402-403 (kept across the scans of a scene)
+        pcl_xyz = ops.transform_xyz(xyz, T)                             # RN:408 (descriptors carried through)
         out = None
         for voxel in (5.0, 1.0):                                        # RN:414, retry RN:420-423
-            order = ops.voxel_robin(pcl_xyz, voxel)
+            if voxel == 5.0 and order5 is not None:
+                order, raw_idx = order5, raw_idx5
+            else:
+                order = ops.voxel_robin(pcl_xyz, voxel)
+                raw_idx = raw_of_voxel_scan[order].cpu().numpy()
             sub_xyz = pcl_xyz[order]
-            raw_idx = raw_of_voxel_scan[order].cpu().numpy()
             q_desc = self._upload_rows(scan, raw_idx)                   # VoxelHashMap.cpp:478-481
             qi, mi, _ = voxel_hash_map.search_device(None, self.min_cosine_similarity, q_desc=q_desc)       # RN:418
             out = dict(src_rows=order[qi], tgt_rows=mi, src_xyz=sub_xyz[qi])
@@ -160,6 +172,33 @@ class RegistrationNode:
                 print("[WARNING] Voxelized too sparse, retrying with a larger voxel size")
         out.update(voxel_scan_xyz=xyz, voxel_hash_map=voxel_hash_map, map_xyz=voxel_hash_map.point_cloud_device())
         return out
+
+    def _voxel_chain(self, raw_xyz: torch.Tensor, T: torch.Tensor, vs: float):
+        """The three chained VoxelDownsample()s of RN:399-400 and 414 (voxel sizes vs / 2, vs, 5 m; the third on the points moved by the
+        initial pose) as three kernel launches and one read-back: (voxel_scan xyz, its rows of the raw scan, the 5 m level's positions in
+        voxel_scan, their rows of the raw scan on the host) -- or None where a level is not the one-launch kernel's (the caller then takes
+        the level-by-level path: the same answers)."""
+        n = raw_xyz.shape[0]
+        l1 = ops.voxel_robin_level(raw_xyz, vs * 0.5)
+        l2 = ops.voxel_robin_level(raw_xyz, vs * 1.0, idx=l1["keep"], n_dev=l1["count"], n_max=n)
+        l3 = ops.voxel_robin_level(raw_xyz, 5.0, idx=l2["keep"], n_dev=l2["count"], n_max=n, T=T, want_local=True)
+        head = min(n, self._CHAIN_HEAD)
+        if self._chain_host is None:
+            self._chain_host = torch.empty(24 + self._CHAIN_HEAD, dtype=torch.int64).pin_memory()
+        packed = torch.cat((l1["info"], l2["info"], l3["info"], l3["keep"][:head]))
+        self._chain_host[:packed.numel()].copy_(packed, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        h = self._chain_host.numpy()
+        if any(h[8 * k + 5] != 1 or h[8 * k + 1] < 0 for k in range(3)):
+            return None
+        n2, n3 = int(h[9]), int(h[17])
+        if n2 == 0 or n3 == 0:
+            return None
+        raw_of_voxel_scan = l2["keep"][:n2]
+        raw_idx5 = h[24:24 + n3].copy() if n3 <= head else l3["keep"][:n3].cpu().numpy()
+        return raw_xyz[raw_of_voxel_scan], raw_of_voxel_scan, l3["local"][:n3], raw_idx5
+
+    _CHAIN_HEAD = 8192   # rows of the 5 m level read back together with the levels' infos (more: a second read-back)
 
     @staticmethod
     def _upload_rows(scan: np.ndarray, raw_idx: np.ndarray) -> torch.Tensor:
