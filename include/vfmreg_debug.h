@@ -35,7 +35,7 @@ int vfm_prof_events_destroy(void *start, void *stop);
  * 32 resident queries per wave at every size, 10 = 12 with two tiles per step at every width, 20 = default kernels with the
  * general selection kernel on best-score records too, 21 = default kernels without the chunk-major rescan).
  * Values that switch one thing and leave the rest as it is (round 4): 30 / 31 = fused fp6 half-width kernel with one (default) / two
- * chunks per barrier; 32 / 33 = the same kernel at d = 384 with two / three (default since round 5) 32-query tiles per wave; 40 / 41 / 42 = fp6 operand preparation by prep_chunk_kernel (rows in registers, one pass) / prep_stream_kernel / by width (default since round 5: d = 256 the stream form, d = 384 the one-pass form);
+ * chunks per barrier; 32 / 33 = the same kernel at d = 384 with two / three (default since round 5) 32-query tiles per wave; 40 / 41 / 42 = fp6 operand preparation by prep_chunk_kernel (rows in registers, one pass) / prep_stream_kernel (default) / by width (d = 256 the stream form, d = 384 the one-pass form: ahead in long pipelines, behind in the 20-step form);
  * 50 / 51 = chunk-major rescan as long-lived (default) / short-lived workgroups (the fp32 refinement is one wave per list entry either way); 60 / 61 = the chunk-major rescan
  * gathers its queries from the int8 fragment tiles / from the row-major int8 scan (default) */
 int vfm_debug_set_coarse_variant(int qsets);

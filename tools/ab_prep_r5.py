@@ -31,4 +31,4 @@ for rep in range(2):
                 v, msps, cms, res = bench.timed_loop(lib, pipe, data, 200, 5)
                 print(f"{mode:14s} {name:45s} preparation on its own stream {int(op)}: {v:7.1f}/s  coarse kernel {cms:.3f} ms", flush=True)
                 del pipe
-lib.vfm_debug_set_coarse_variant(42)
+lib.vfm_debug_set_coarse_variant(41)

@@ -1035,9 +1035,11 @@ int do_prepare2(Rows x1r, int64_t rows1, void* prepared1, Rows x2r, int64_t rows
         if (want_mx6) {   // int8 + fp6 images from one read of the rows; the fp16 image, if wanted, by its own kernel
             // Which form: prep_stream_kernel was built to run BESIDE a coarse workgroup of round 4 (332 of a SIMD's 512 registers, 90 KiB).
             // Since round 5 the d = 384 coarse kernel holds three query tiles per wave (444 registers) and the full-width ones fill the
-            // LDS: nothing runs beside them, and the one-pass form below -- rows in registers, fat and fast -- is the better neighbour
-            // in time (tools/ab_prep_r5.py, 200-step pipelines on one box: headline + 0.7 %, full width with the fused epilogue + 3.5 %,
-            // lifted descriptors + 2.2 %, full width with records - 0.5 %).  d = 256 keeps the two-tile coarse kernel and the stream form.
+            // LDS: nothing runs beside them, and in a LONG pipeline the one-pass form below (rows in registers: 0.185 ms alone against
+            // 0.139, but short fat workgroups that leave the coarse kernel alone) is the better neighbour -- tools/ab_prep_r5.py, 200-step
+            // pipelines on one box: headline + 1.7 %, full width with the fused epilogue + 3.5 %, lifted descriptors + 2.2 %, full width
+            // with records - 0.5 %.  In the driver's 20-step form it LOSES 2.9 % (tools/ab_prep_r5_20.py: 1624 against 1672
+            // registrations/s): the default stays the stream form; vfm_debug_set_coarse_variant(42) selects by width (d = 384: one pass).
             const bool stream_form = g_prep_stream == 1 || (g_prep_stream == 2 && d == 256);
             if (stream_form && (d == 384 || d == 256) && !any_f16) {   // the form that fits beside a coarse workgroup (prep_stream_kernel)
                 const dim3 sg((unsigned)groups), sb(256);
