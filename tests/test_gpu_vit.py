@@ -203,3 +203,31 @@ def test_vit_preprocessing_one_workgroup_per_patch_equals_the_per_unit_kernel_bi
             assert torch.equal(old, new), (B, H, W, float((old - new).abs().max()))
     finally:
         lib.vfm_debug_set_vit_gemm(-14, 1)
+
+
+def test_vit_batch_as_two_half_batches_on_two_streams_equals_one_forward_bit_for_bit():
+    """ViTS14.SPLIT_FROM (opt-in, round 5): batches from that many images on run as two half-batches on two side streams, the second
+    half enqueued by a helper thread (each kernel's tail under the other half's next kernel): the images are independent, so the outputs
+    are those of one forward, bit for bit -- odd batch sizes, a caller's own stream, two calls in a row (the halves' workspaces are reused),
+    and a batch right under the threshold."""
+    from vfmreg import vit as V
+    w = V.random_weights(seed=4, dim=384, depth=2, mlp=1536)
+    H, W = 280, 350
+    model = V.ViTS14(w, H, W, device="cuda")
+    rng = np.random.default_rng(2)
+    old = V.ViTS14.SPLIT_FROM
+    try:
+        for B in (63, 64, 71):
+            imgs = torch.from_numpy(rng.integers(1, 255, (B, H, W, 3), dtype=np.uint8)).cuda()
+            V.ViTS14.SPLIT_FROM = 64
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                a = model.forward(imgs).clone()
+                b = model.forward(imgs).clone()
+            st.synchronize()
+            V.ViTS14.SPLIT_FROM = 0
+            ref = model.forward(imgs).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(a, ref) and torch.equal(b, ref), B
+    finally:
+        V.ViTS14.SPLIT_FROM = old

@@ -241,8 +241,21 @@ class ViTS14:
             i += 1
         self.blob = torch.from_numpy(blob).to(self.device)
         self._ws = {}
+        self._side = None   # two side streams for batches from SPLIT_FROM images on
+        self._pool = None   # ... and the helper thread that enqueues the second half
 
-    def forward(self, images: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    # OPT-IN (round 5): batches from SPLIT_FROM images on run as two half-batches on two side streams, the second half enqueued by a helper
+    # thread.  Every kernel of a forward ends in a tail -- its workgroups start together, and as they finish the compute units run three,
+    # then two, then one of them, the last at a quarter of the matrix pipes -- and the next kernel cannot start under it;
+    # two independent half-batches fill each other's tails.  tools/ab_vit_two_streams.py and profiles/r05_ab_vit_two_streams.txt, one
+    # forward -> two halves, forwards back to back: 66 images 2.39 -> 2.25 ms, 72: 2.54 -> 2.36, 90: 2.96 -> 2.89, 96: 3.33 -> 3.09,
+    # 120: 4.0 -> 3.85; a single synchronised forward gains half of that; below 64 images the halves fall under the sizes the batch kernels
+    # are chosen for and lose.  Identical outputs (the images are independent).  Off by default (0): which hardware queue a side stream
+    # lands on depends on what the process created before (pipeline.py, _side_streams), and a figure that moves with that is not a default;
+    # a caller that walks a sequence in batches sets ViTS14.SPLIT_FROM = 64.
+    SPLIT_FROM = 0
+
+    def forward(self, images: torch.Tensor, out: Optional[torch.Tensor] = None, _slot: int = 0) -> torch.Tensor:
         """images: [B, H, W, 3] uint8 on the device -> [B, 16, pw, dim] fp32 patch features (written into ``out`` when given:
         a consumer that holds pointers into it -- ops.LiftPlan -- then needs no re-marshalling)."""
         ops._chk(images, torch.uint8, "images")
@@ -250,16 +263,42 @@ class ViTS14:
         if (H, W) != (self.img_h, self.img_w):
             raise ValueError("Invalid shape")
         lib = _lib.load()
-        if B not in self._ws:
-            self._ws[B] = torch.empty(lib.vfm_vit_workspace_bytes(C.byref(self.cfg), B), dtype=torch.uint8,
-                                      device=self.device)
         if out is None:
             out = torch.empty((B, PATCH_H, self.patch_w, self.dim), dtype=torch.float32, device=self.device)
         else:
             ops._chk(out, torch.float32, "out")
             if tuple(out.shape) != (B, PATCH_H, self.patch_w, self.dim):
                 raise ValueError("Invalid shape")
+        if self.SPLIT_FROM and B >= self.SPLIT_FROM and _slot == 0:
+            if self._side is None:
+                self._side = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(main)
+            h = (B + 1) // 2
+
+            def half(k, lo, hi):
+                self._side[k].wait_event(ready)
+                with torch.cuda.stream(self._side[k]):
+                    self.forward(images[lo:hi], out[lo:hi], _slot=k + 1)
+
+            # the second half is enqueued by a helper thread while this one enqueues the first (the C call releases the GIL): enqueued one
+            # after the other the second half started ~0.3 ms -- 65 launches -- behind the first, and a single forward lost what the
+            # overlap gained
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(1)
+            fut = self._pool.submit(half, 1, h, B)
+            half(0, 0, h)
+            fut.result()
+            for st in self._side:
+                main.wait_stream(st)
+            return out
+        key = (B, _slot)
+        if key not in self._ws:
+            self._ws[key] = torch.empty(lib.vfm_vit_workspace_bytes(C.byref(self.cfg), B), dtype=torch.uint8,
+                                        device=self.device)
         _lib.check(lib.vfm_vit_forward(C.byref(self.cfg), self.blob.data_ptr(), images.data_ptr(), B, H, W,
-                                       out.data_ptr(), self._ws[B].data_ptr(), self._ws[B].numel(), ops._stream()),
+                                       out.data_ptr(), self._ws[key].data_ptr(), self._ws[key].numel(), ops._stream()),
                    "vit_forward")
         return out
