@@ -247,7 +247,7 @@ class ViTS14:
     # OPT-IN (round 5): batches from SPLIT_FROM images on run as two half-batches on two side streams, the second half enqueued by a helper
     # thread.  Every kernel of a forward ends in a tail -- its workgroups start together, and as they finish the compute units run three,
     # then two, then one of them, the last at a quarter of the matrix pipes -- and the next kernel cannot start under it;
-    # two independent half-batches fill each other's tails.  tools/ab_vit_two_streams.py and profiles/r05_ab_vit_two_streams.txt, one
+    # two independent half-batches fill each other's tails.  tools/ab_vit_two_halves.py and profiles/r05_ab_vit_two_streams.txt, one
     # forward -> two halves, forwards back to back: 66 images 2.39 -> 2.25 ms, 72: 2.54 -> 2.36, 90: 2.96 -> 2.89, 96: 3.33 -> 3.09,
     # 120: 4.0 -> 3.85; a single synchronised forward gains half of that; below 64 images the halves fall under the sizes the batch kernels
     # are chosen for and lose.  Identical outputs (the images are independent).  Off by default (0): which hardware queue a side stream
