@@ -142,3 +142,44 @@ def test_pipeline_with_an_fp16_map_equals_the_pipeline_on_the_widened_rows_and_t
     np.testing.assert_array_equal(a["mask"][:c].cpu().numpy(), ref.inlier_mask)
     with pytest.raises(ValueError):
         RegistrationPipeline(n, m, d, n_iter=iters, coarse="fp16").register(p["q_desc"], p["q_xyz"], b16, p["b_xyz"])
+
+
+def test_auto_policy_never_hands_fp16_rows_to_the_fp32_kernels():
+    """`auto` may leave the int8 passes for the fp16 one from the searches' feedback (above TOP2_LIMIT rescans per
+    query: duplicate-rich maps).  That decision is taken inside register() -- after the dtype check of round 5 -- and the fp16 pass
+    reads float32 rows: float16 storage then went to kernels that read twice as far.  The policy is now read after it is updated and
+    fp16 rows stay on the int8 pass with top-2 records; the registration is that of the widened rows."""
+    n, m, d, iters = 3000, 20000, 384, 2000
+    p = synth.make_pair_device(n, m, d, seed=29)
+    # a duplicate-rich map: every row eight times (the rescan count per query goes up with it)
+    b = p["b_desc"][: m // 8].repeat(8, 1).contiguous()
+    bx = p["b_xyz"][: m // 8].repeat(8, 1).contiguous()
+    b16 = b.half().contiguous()
+    bw = b16.float().contiguous()
+    outs = {}
+    for name, bdesc in (("fp16 map", b16), ("widened", bw)):
+        pipe = RegistrationPipeline(n, m, d, n_iter=iters, overlap_ransac=True, overlap_prepare=True, solve_streams=2, coarse="auto")
+        pipe.HALF_LIMIT = pipe.RESCAN_LIMIT = pipe.MX6_UP = -1.0     # every feedback says "too many": auto walks the whole ladder
+        pipe.TOP2_LIMIT = -1.0
+        seen_fp16_pass = False
+        out = None
+        for _ in range(8):
+            out = pipe.register(p["q_desc"], p["q_xyz"], bdesc, bx)
+            pipe.synchronize()
+            torch.cuda.synchronize()
+            pipe._poll_feedback()
+            seen_fp16_pass |= not pipe.use_i8
+        assert seen_fp16_pass, "the policy never asked for the fp16 pass: the test does not exercise the hand-over"
+        outs[name] = {k: out[k].clone() for k in ("T", "count", "corres", "idx", "sim")}
+        del pipe
+    a, w = outs["fp16 map"], outs["widened"]
+    c = int(w["count"].item())
+    assert int(a["count"].item()) == c
+    assert torch.equal(a["T"], w["T"]) and torch.equal(a["corres"][:c], w["corres"][:c])
+    qn, _ = orc.l2norm_rows(p["q_desc"].cpu().numpy())
+    bn, _ = orc.l2norm_rows(bw.cpu().numpy())
+    ridx, rsim = orc.match_ip_top1(qn, bn)
+    gi = a["idx"].cpu().numpy()
+    solved = gi >= 0
+    np.testing.assert_array_equal(gi[solved], ridx[solved])
+    assert (rsim[~solved] < 0.8).all()

@@ -353,7 +353,7 @@ class RegistrationPipeline:
         ops._chk(b_xyz, torch.float64, "b_xyz")
         if q_desc.shape != (self.n, self.d) or b_desc.shape != (self.m, self.d):
             raise ValueError("Invalid shape")
-        if (f16q or f16b) and (reuse_map or not self.use_i8 or self._map_prepared):
+        if (f16q or f16b) and (reuse_map or self.coarse == "fp16" or self._map_prepared):
             raise ValueError("float16 descriptor rows: the int8 / fp6 passes with map and scan prepared together (no reuse_map, no fp16 pass)")
         if reuse_map:
             # a reused map is prepared once (vfm_match_prepare2 / vfm_match_prepare below): it carries the fp16 and int8 images, not
@@ -385,7 +385,15 @@ class RegistrationPipeline:
                 self._mx6_tried = False
                 self._probe_due = self.gate
                 self._since_switch = 0
+        if (f16q or f16b) and not self.use_i8:
+            # the policy is decided ABOVE (feedback polled, re-probe applied) and only then read.  `auto` may have
+            # left the int8 passes for the fp16 one (above TOP2_LIMIT rescans per query: duplicate-rich maps) -- the fp16 pass and its
+            # finish stage read float32 rows (vfm_match_prepare2, vfm_match_search_finish_gated_r with records 2): float16 storage must
+            # never reach them.  Such rows stay on the int8 pass with packed top-2 records, the widest gated mode that widens on load.
+            self.use_i8, self.top2 = True, True
+            self.half = self.mx6 = False
         i8, records = self.use_i8, self._records()
+        assert i8 or not (f16q or f16b)
         r = self.sets[self._step % len(self.sets)]
         solve = self.solve_streams[self._step % self.n_solve] if self.overlap else None
         rws = self.rws_list[self._step % self.n_solve] if self.overlap else self.rws
