@@ -327,3 +327,74 @@ def test_replay_in_the_lds_equals_the_replay_behind_a_radix_sort():
     finally:
         lib.vfm_debug_set_voxel_small(3)
         lib.vfm_debug_set_voxel_small(1)
+
+
+def _cloud_with_a_long_cluster(n, rng, members=400):
+    """voxels (x, 0, 0) of which `members` have their home bucket in one window of 100 buckets of the reserved table: one run of
+    occupied buckets longer than the one-launch kernel's limit (GRID_MAX_CLUSTER = 192)"""
+    c = int(np.ceil(np.float32(n) / np.float32(0.5)))
+    B = 1
+    while B < c:
+        B <<= 1
+    xs, dense, x = [], 0, 0
+    while len(xs) < n:
+        h = ((x * 73856093) & 0xFFFFFFFF) & ((1 << 20) - 1) & (B - 1)
+        if 1000 <= h < 1100 and dense < members:
+            xs.append(x)
+            dense += 1
+        elif not (900 <= h < 1700) and rng.random() < 0.2 and len(xs) < n - (members - dense):
+            xs.append(x)
+        x += 1
+    pts = np.c_[np.array(xs, dtype=np.float64) + 0.5, np.full(n, 0.5), np.full(n, 0.5)]
+    return pts[rng.permutation(n)]
+
+
+def test_a_level_the_kernel_cannot_reproduce_leaves_an_empty_level_to_the_chain():
+    """vfm_voxel_robin_level on a cloud with a cluster beyond the one-launch kernel's limit reports info[1] = -1 -- and used
+    to publish count = nv with keep_out unwritten, so the next levels of a chain (enqueued without a read-back) gathered points through
+    uninitialised indices.  Now such a level publishes count 0: the later levels are empty, the caller redoes the chain level by level
+    (RegistrationNode._voxel_chain returns None), and vfm_voxel_robin on the same cloud takes the general path: the oracle's order."""
+    from oracle import oracle as orc
+    from vfmreg import ops
+    rng = np.random.default_rng(31)
+    n = 3000
+    pts = _cloud_with_a_long_cluster(n, rng)
+    d = torch.from_numpy(pts).cuda()
+    for _ in range(3):
+        l1 = ops.voxel_robin_level(d, 1.0)
+        l1["keep"].fill_(1 << 40)           # what uninitialised memory may hold
+        l2 = ops.voxel_robin_level(d, 2.0, idx=l1["keep"], n_dev=l1["count"], n_max=n)
+        l3 = ops.voxel_robin_level(d, 5.0, idx=l2["keep"], n_dev=l2["count"], n_max=n, want_local=True)
+        torch.cuda.synchronize()
+        i1, i2, i3 = (l["info"].cpu().numpy() for l in (l1, l2, l3))
+        assert i1[5] == 1 and i1[1] == -1, i1
+        assert [int(l["count"].item()) for l in (l1, l2, l3)] == [0, 0, 0]
+        assert i2[5] == 1 and i3[5] == 1 and i2[1] == 0 and i3[1] == 0, (i2, i3)
+    ref = orc.voxel_robin(pts, 1.0)
+    np.testing.assert_array_equal(ops.voxel_robin(d, 1.0).cpu().numpy(), ref)
+
+
+def test_one_launch_downsample_on_a_stream_with_few_compute_units():
+    """the one-launch kernel's grid is clamped to what can be resident on the compute units the STREAM may use (occupancy x
+    the stream's compute-unit mask): on a stream restricted to 8 units the 256-workgroup grid of round 5 could never pass its first
+    barrier and every call span for seconds before it fell back.  Same order as the oracle's, and quickly."""
+    import time
+    from oracle import oracle as orc
+    from vfmreg import ops
+    from vfmreg.pipeline import masked_stream
+    rng = np.random.default_rng(8)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    st = masked_stream(8, 16, ncu)
+    for n in (1700, 20000, 60000, 200000):
+        pts = rng.uniform(-60, 60, (n, 3)) * [1, 1, 0.15]
+        ref = orc.voxel_robin(pts, 0.5)
+        d = torch.from_numpy(pts).cuda()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            ops.voxel_robin(d, 0.5)
+            t0 = time.perf_counter()
+            got = ops.voxel_robin(d, 0.5)
+            st.synchronize()
+            dt = time.perf_counter() - t0
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+        assert dt < 0.25, (n, dt)     # (a grid that is not resident spins for seconds)

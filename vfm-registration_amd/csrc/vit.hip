@@ -22,6 +22,7 @@
 //     straight from HBM/L2 (337 tokens x 64: 43 KB per head, L2 resident).
 //   * all 6 cameras are batched (6 x 352 padded tokens = 66 row tiles) to fill the chip.
 // Floating point => tolerance parity (tests state it); weights are seeded-random in tests/bench.
+#include <atomic>
 #include "common.h"
 
 #include <type_traits>
@@ -1426,7 +1427,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         // the fill (tools); 0 (default): when the last round of `ncu` workgroups is at least three quarters full and there is at least one
         // such round -- 69 ... 93 images of 1200 x 1600 at a time on 256 compute units (tools/ab_vit_astat.py: 48 images 2.19 -> 2.30 ms,
         // 84: 3.35 -> 3.22, 93: 3.60 -> 3.49, 96 = 264 groups, eight of them alone in a second round: 3.95 -> 4.58)
-        static int ncu = 0;
+        static std::atomic<int> ncu{0};   // (atomics: vfm_vit_forward may run on two host threads at once -- ViTS14.SPLIT_FROM)
         if (ncu == 0) {
             int dev = 0;
             hipDeviceProp_t prop;
@@ -1439,7 +1440,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         if (want && 4 * g.KS * 1024 <= 128 * 1024 && (nw == 112 || (g.N / 32) % nw == 0)) {
 #define VIT_ASTAT(NW)                                                                                                                \
     do {                                                                                                                             \
-        static unsigned long long attr_set = 0ull;                                                                                   \
+        static std::atomic<unsigned long long> attr_set{0ull};                                                                                   \
         int dev = 0;                                                                                                                 \
         (void)hipGetDevice(&dev);                                                                                                    \
         if (!((attr_set >> (dev & 63)) & 1ull)) {                                                                                    \
@@ -1452,7 +1453,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         hipLaunchKernelGGL((vit_gemm_astat_kernel<EPI, NW, 6>), dim3(groups), dim3(64 * NW), 4 * g.KS * 1024, st, ga);               \
     } while (0)
             if (g_vit_astat_two && (g.N / 64) >= 8 && g.N % 64 == 0 && g.KS % 4 == 0) {   // two channel tiles per wave, eight waves (round 5)
-                static unsigned long long attr2 = 0ull;
+                static std::atomic<unsigned long long> attr2{0ull};
                 int dev2 = 0;
                 (void)hipGetDevice(&dev2);
                 if (!((attr2 >> (dev2 & 63)) & 1ull)) {
@@ -1467,7 +1468,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
             switch (nw) {
                 case 6: VIT_ASTAT(6); break;
                 case 112: {   // (A/B) twelve waves, non-temporal output stores
-                    static unsigned long long attr_set2 = 0ull;
+                    static std::atomic<unsigned long long> attr_set2{0ull};
                     int dev = 0;
                     (void)hipGetDevice(&dev);
                     if (!((attr_set2 >> (dev & 63)) & 1ull)) {
@@ -1497,7 +1498,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
             if (EPI == EPI_RESID && g.N == 384 && g_vit_wide_tile && g.KS % 2 == 0) {   // one workgroup per 128 tokens x all 384 channels (NG = 3)
                 const int gridw = 8 * ceil_div(ceil_div(g.M / 32, 4), 8);
                 constexpr int ldsw = 4 * 16 * 2 * 1024;   // NS = 4 stages of (4 + 12) x KB = 2 KiB: 128 KiB
-                static unsigned long long attr_w = 0ull;
+                static std::atomic<unsigned long long> attr_w{0ull};
                 int devw = 0;
                 (void)hipGetDevice(&devw);
                 if (!((attr_w >> (devw & 63)) & 1ull)) {
@@ -1517,7 +1518,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
             const int grid = 8 * ceil_div(ceil_div(g.M / 32, 4), 8) * (g.N / 128);   // every XCD: ceil(groups / 8) token groups x channel groups
 #define VIT_LDS(KB, NS)                                                                                                              \
     do {                                                                                                                             \
-        static unsigned long long attr_set = 0ull;                                                                                   \
+        static std::atomic<unsigned long long> attr_set{0ull};                                                                                   \
         int dev = 0;                                                                                                                 \
         (void)hipGetDevice(&dev);                                                                                                    \
         if (!((attr_set >> (dev & 63)) & 1ull)) {                                                                                    \
@@ -1638,7 +1639,9 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
     const Dims d = make_dims(cfg, B, H, W);
     VFM_CHECK_ARG(d.Tp / 32 <= 16, "vit: at most 512 tokens per image supported (got %d)", d.T);
     // (the GEMM epilogues address every activation buffer with 32-bit byte offsets and find a token tile's image by a 20-bit reciprocal)
-    VFM_CHECK_ARG((uint64_t)d.M * (uint64_t)(d.mlp > 3 * d.D ? d.mlp : 3 * d.D) * 4u < (1ull << 32) && d.M / 32 < 65536, "vit: batch of %d images too large for one call", B);
+    VFM_CHECK_ARG((uint64_t)d.M * (uint64_t)(d.mlp > 3 * d.D ? d.mlp : 3 * d.D) * 4u < (1ull << 32) && d.M / 32 < 65536 &&
+                  (uint64_t)(d.M / 32) * ((1u << 20) / (unsigned)(d.Tp / 32) + 1u) < (1ull << 32),   // (the reciprocal's product is 32-bit in the kernels)
+                  "vit: batch of %d images too large for one call", B);
     if (ws_bytes < carve_vit(nullptr, d).bytes) return vfm_fail(VFM_EWORKSPACE, "vit: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const Layout L = make_layout(cfg);
@@ -1679,7 +1682,7 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
         if ((rc = launch_gemm<EPI_QKV>(g, st))) return rc;
 #define VIT_ATT(NKT)                                                                                                      \
     if (att_lds) {                                                                                                        \
-        static unsigned long long attr_set = 0ull;                                                                        \
+        static std::atomic<unsigned long long> attr_set{0ull};                                                                        \
         int dev_ = 0;                                                                                                     \
         (void)hipGetDevice(&dev_);                                                                                        \
         if (!((attr_set >> (dev_ & 63)) & 1ull)) {                                                                        \

@@ -22,6 +22,7 @@
 //     re-running the generation in coordinates rotated to start at a bucket that is provably empty.
 // HBM-bound integer work: coalesced SoA passes, atomics only on the (L2-resident) tables; hipCUB supplies the
 // device-wide radix sort / scan / select primitives.
+#include <atomic>
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
@@ -874,7 +875,10 @@ __global__ __launch_bounds__(GRID_T) void voxel_robin_grid_kernel(GridRobinArgs 
         }
     }
     if (gt == 0) {
-        *a.count_out = nv;
+        // (a level that was not reproduced publishes NO survivors -- keep_out was not written, and the next level of a chain
+        //  reads its points through it: count 0 makes that level an empty one instead of a gather through uninitialised indices.  The
+        //  launchers also clear count_out before the launch: a grid that gave up at a barrier never gets here.)
+        *a.count_out = fail ? 0 : nv;
         a.info[0] = B;
         a.info[1] = fail ? -1 : nv;      // (0, as the host left it: the grid gave up at a barrier -- or an empty chained level: info[5] tells)
         a.info[5] = 1;
@@ -887,6 +891,45 @@ __global__ __launch_bounds__(GRID_T) void voxel_robin_grid_kernel(GridRobinArgs 
     }
 #undef GRID_SYNC
 }
+
+// How many workgroups of voxel_robin_grid_kernel can be resident at once on the compute units `st` may use (the grid-wide
+// barriers need every workgroup of the launch resident; the grid was sized for 256 free compute units whatever the device or the
+// stream): occupancy per compute unit (LDS: ~60 KB per workgroup) x the compute units in the stream's mask (hipExtStreamGetCUMask:
+// a stream made by hipExtStreamCreateWithCUMask reports its own, any other the device's).  The kernel's loops are grid-stride, so a
+// smaller grid still covers n.  0: the occupancy query failed -- the caller takes the general path.
+static int grid_resident_limit(hipStream_t st) {
+    static std::atomic<int> per_cu{-1};
+    static std::atomic<int> dev_cus{0};
+    int pc = per_cu.load(std::memory_order_relaxed);
+    if (pc < 0) {
+        int nb = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, voxel_robin_grid_kernel, GRID_T, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+            hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        dev_cus.store(prop.multiProcessorCount, std::memory_order_relaxed);
+        per_cu.store(nb, std::memory_order_relaxed);
+        pc = nb;
+    }
+    int cus = dev_cus.load(std::memory_order_relaxed);
+    uint32_t mask[16] = {0};
+    if (hipExtStreamGetCUMask(st, 16, mask) == hipSuccess) {
+        int bits = 0;
+        for (int i = 0; i < 16; ++i) bits += __builtin_popcount(mask[i]);
+        if (bits > 0 && bits < cus) cus = bits;
+    } else {
+        (void)hipGetLastError();
+    }
+    // one workgroup per compute unit is what the barrier cost was measured with; more than that only where the units are few
+    long long lim = (long long)pc * cus;
+    return (int)(lim < GRID_MAX_WG ? lim : GRID_MAX_WG);
+}
+// A grid that did not become resident (other tenants on the device: a second rank, a masked stream beside a long kernel) costs
+// GRID_SPIN_LIMIT polls before it gives up.  After one such call the next GRID_BACKOFF calls go straight to the general path.
+constexpr int GRID_BACKOFF = 64;
+static std::atomic<int> g_grid_backoff{0};
 
 struct VoxelWs {
     int* owner;
@@ -1106,9 +1149,13 @@ VFM_EXPORT int vfm_voxel_robin_level(const double* pts, int64_t stride, const in
     a.idx = idx; a.n_dev = n_dev; a.T = T_dev; a.keep_local = keep_local_out;
     VFM_CHECK_HIP(hipMemsetAsync(w.gridctl, 0, 16 * sizeof(int64_t), st));
     VFM_CHECK_HIP(hipMemsetAsync(info_dev, 0, 8 * sizeof(int64_t), st));
+    VFM_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int64_t), st));   // a level that fails or gives up leaves an EMPTY level to the next one
+    const int resident = grid_resident_limit(st);
+    if (resident <= 0) return VFM_OK;   // (info stays 0: "not reproduced by this kernel", the caller's to redo through vfm_voxel_robin)
     const int ppt = g_voxel_grid_ppt > 0 ? g_voxel_grid_ppt : (n_max <= 32768 ? 1 : n_max <= 131072 ? 2 : 4);
     const int64_t per_wg = (int64_t)GRID_T * ppt;
-    const unsigned grid = (unsigned)((n_max + per_wg - 1) / per_wg < GRID_MAX_WG ? (n_max + per_wg - 1) / per_wg : GRID_MAX_WG);
+    const int64_t want_wg = (n_max + per_wg - 1) / per_wg;
+    const unsigned grid = (unsigned)(want_wg < resident ? want_wg : resident);
     hipLaunchKernelGGL(voxel_robin_grid_kernel, dim3(grid), dim3(GRID_T), 0, st, a);
     VFM_CHECK_LAUNCH("voxel_robin_grid_kernel");
     return VFM_OK;
@@ -1139,7 +1186,14 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
                 while (B < want) B <<= 1;
             }
         }
-        if (B >= 2 * n && B <= (1ll << 20) && reserve_n == n) {   // (no rehash: nv <= n <= the load threshold B / 2; the histogram is sized for reserve(n))
+        const int resident = grid_resident_limit(st);
+        bool backoff = false;
+        {
+            int b = g_grid_backoff.load(std::memory_order_relaxed);
+            while (b > 0 && !g_grid_backoff.compare_exchange_weak(b, b - 1, std::memory_order_relaxed)) {}
+            backoff = b > 0;
+        }
+        if (B >= 2 * n && B <= (1ll << 20) && reserve_n == n && resident > 0 && !backoff) {   // (no rehash: nv <= n <= the load threshold B / 2; the histogram is sized for reserve(n))
             GridRobinArgs a{};
             a.pts = pts; a.n = n; a.stride = stride; a.vs = voxel_size; a.mul_y = hash_mul_y; a.B = (int)B;
             a.owner = w.owner; a.tmin = w.tmin; a.hsize = (int)w.hsize; a.slot_of = w.slot_of;
@@ -1155,7 +1209,8 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
             //  tools/ab_voxel_grid.py -- 60 000 points: 0.24 / 0.19 / 0.20 ms at 1 / 2 / 4 points per thread, 20 000: 0.130 / 0.125 / 0.140)
             const int ppt = g_voxel_grid_ppt > 0 ? g_voxel_grid_ppt : (n <= 32768 ? 1 : n <= 131072 ? 2 : 4);
             const int64_t per_wg = (int64_t)GRID_T * ppt;
-            const unsigned grid = (unsigned)((n + per_wg - 1) / per_wg < GRID_MAX_WG ? (n + per_wg - 1) / per_wg : GRID_MAX_WG);
+            const int64_t want_wg = (n + per_wg - 1) / per_wg;
+            const unsigned grid = (unsigned)(want_wg < resident ? want_wg : resident);
             hipLaunchKernelGGL(voxel_robin_grid_kernel, dim3(grid), dim3(GRID_T), 0, st, a);
             VFM_CHECK_LAUNCH("voxel_robin_grid_kernel");
             int64_t local[4];
@@ -1163,6 +1218,7 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
             VFM_CHECK_HIP(hipMemcpyAsync(gi, w.gridctl, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
             VFM_CHECK_HIP(hipStreamSynchronize(st));
             if (gi[1] > 0) return VFM_OK;
+            if (gi[1] == 0) g_grid_backoff.store(GRID_BACKOFF, std::memory_order_relaxed);   // the grid gave up at a barrier: not resident
             if (info_host) info_host[0] = info_host[1] = info_host[2] = info_host[3] = 0;
             // (a cluster beyond the kernel's limit, a wrap it could not place, or a grid that did not become resident: the general path decides)
         }

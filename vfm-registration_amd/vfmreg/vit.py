@@ -289,10 +289,16 @@ class ViTS14:
                 from concurrent.futures import ThreadPoolExecutor
                 self._pool = ThreadPoolExecutor(1)
             fut = self._pool.submit(half, 1, h, B)
-            half(0, 0, h)
-            fut.result()
-            for st in self._side:
-                main.wait_stream(st)
+            try:
+                half(0, 0, h)
+            finally:
+                # (whatever the first half did, the helper is joined and the caller's stream waits for both side streams --
+                #  no half-enqueued forward is left running on buffers the caller believes free)
+                try:
+                    fut.result()
+                finally:
+                    for st in self._side:
+                        main.wait_stream(st)
             return out
         key = (B, _slot)
         if key not in self._ws:
