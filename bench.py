@@ -574,8 +574,8 @@ def stage_table(dev, lib, pair, iters, records_kind):
         "prepare (normalise rows, int8 + fp6 images)": {
             "ms": t_prep, "bound": "hbm", "algorithmic_bytes": 8.0 * (n + m) * d, "bytes_this_kernel_moves_once": moved_prep,
             "achieved_TBs": moved_prep / (t_prep * 1e-3) / 1e12, "peak_TBs": HBM_PEAK_TBS, "frac": moved_prep / (t_prep * 1e-3) / 1e12 / HBM_PEAK_TBS,
-            "note": "SURVEY 8 D.3's figure (fp32 in, fp32 out) is 8 (N + M) D; the kernel writes one-byte and 6-bit images instead, and reads "
-                    "the rows a second time from L2 / the memory-side cache (DESIGN.md R4.4) -- the fraction counts what must move once"},
+            "note": "SURVEY 8 D.3's figure (fp32 in, fp32 out) is 8 (N + M) D; the kernel writes one-byte and 6-bit images instead; since round 6 "
+                    "(prep_once_kernel, DESIGN.md R6) every row is read ONCE -- the fraction counts what must move once"},
         "coarse pass": {
             "ms": t_coarse, "bound": "mfma", "flops": 2.0 * n * m * kcols, "achieved_TFLOPs": 2.0 * n * m * kcols / (t_coarse * 1e-3) / 1e12,
             "peak_TFLOPs": peak_mm, "frac": 2.0 * n * m * kcols / (t_coarse * 1e-3) / 1e12 / peak_mm},
@@ -587,12 +587,11 @@ def stage_table(dev, lib, pair, iters, records_kind):
             "frac": (12.0 * n + 72.0 * C) / (t_compact * 1e-3) / 1e12 / HBM_PEAK_TBS, "note": "a launch-latency object (1 MB); timed through ops.threshold_compact, which allocates its outputs on the host side -- the "
                                                       "kernel itself is 11-18 us in profiles/r04_bench_kernel_stats.csv"},
         "RANSAC + Kabsch (50 000 hypotheses, fp64)": {
-            "ms": t_ransac, "bound": "fp64 valu", "correspondences": C, "algorithmic_flops": iters * (27.0 * C + 400.0),
-            "achieved_TFLOPs": iters * (27.0 * C + 400.0) / (t_ransac * 1e-3) / 1e12, "peak_TFLOPs": FP64_VALU_PEAK_TFLOPS,
-            "frac": iters * (27.0 * C + 400.0) / (t_ransac * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-            "note": "SURVEY 8 D.3's count of the reference's work (every hypothesis scored over every correspondence); the kernels bound every "
-                    "hypothesis in fp32 first and run the oracle's fp64 arithmetic for the survivors only (DESIGN.md 4.3), so a fraction above "
-                    "what fp64 VALUs could do for the full count is work avoided, not a faster ALU -- `executed` counts what ran"},
+            "ms": t_ransac, "bound": "latency (dependent launches; fp64 valu for what is executed)", "correspondences": C,
+            "reference_flops": iters * (27.0 * C + 400.0), "peak_TFLOPs": FP64_VALU_PEAK_TFLOPS, "frac": None,
+            "note": "reference_flops = SURVEY 8 D.3's count of the reference's work (every hypothesis scored over every correspondence); the kernels "
+                    "bound every hypothesis first and run the oracle's fp64 arithmetic for the survivors only (DESIGN.md 4.3): no roofline fraction is "
+                    "quoted against work that was avoided (VERDICT r5) -- `executed` counts what ran"},
     }
     try:   # the same stage on the operations it EXECUTED (the closed-form moment bound per hypothesis, the point-wise
         # fp32 pass where it was needed, the oracle-order fp64 scoring of the candidates)
@@ -858,6 +857,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=0,
                     help="config C4: total number of independent scene pairs of the job, sharded pair p -> rank p mod N "
                          "(overrides --steps: every rank registers its ceil(pairs / N) pairs once)")
+    ap.add_argument("--resident", type=int, default=RESIDENT_MAX,
+                    help="distinct scene pairs kept in HBM per rank (338 MB each at C2 size); a rank with more pairs than that cycles through "
+                         "its resident ones (pair j of the rank is registered on the data of its pair j mod resident)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C5 measurements reported under `extra`")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -926,7 +928,7 @@ def main():
     num_pairs = args.pairs if args.pairs > 0 else world * args.steps
     mine = vdist.shard_pairs(num_pairs, rank, world)
     steps = len(mine) if args.pairs > 0 else args.steps
-    n_res = max(1, min(len(mine), RESIDENT_MAX))
+    n_res = max(1, min(len(mine), max(1, args.resident)))
     pairs = [synth.make_pair_device(n, m, d, seed=42 + mine[j], device=dev) for j in range(n_res)]
     # --streams 2 (default): pipeline over independent scene pairs (BASELINE config C4: "one per stream"):
     # operand preparation + the MFMA coarse pass of pair i+1 run on the main stream while the filter / exact decision /

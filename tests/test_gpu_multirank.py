@@ -52,3 +52,27 @@ def test_two_ranks_on_one_device_equal_the_single_process_job(tmp_path, form):
     np.testing.assert_array_equal(counts2, counts1)
     np.testing.assert_array_equal(poses2, poses1)   # bit-equal, pair by pair, whichever rank registered it
     assert d2["config"]["max_pose_err_vs_planted"] < 0.05
+
+
+def test_c4_workload_256_pairs_over_two_ranks(tmp_path):
+    """BASELINE.json configs[3] -- 256 independent scene pairs at C2's own size (20 000 x 200 000 x 384, 50 000 RANSAC iterations),
+    sharded pair p -> rank p mod N, one gather of the poses -- over two ranks that share the device (the 8-GPU /
+    RCCL execution is the driver's).  Every rank keeps `resident_scene_pairs_per_gpu` = 32 of its 128 pairs in HBM and cycles through
+    them: its pair j is registered on the data of its pair j mod 32.  All 256 gathered poses and correspondence counts, in global pair
+    order, against a single-process job that holds 64 DISTINCT pairs (no wrap-around there): pose[p] must be bit-equal to the
+    single-process pose of the pair whose data the owning rank actually registered, (p mod 2) + 2 ((p div 2) mod 32)."""
+    pairs, world, resident = 256, 2, 32
+    d2, poses2, counts2, err2 = _run(tmp_path, "c4_w2", world, ["--pairs", str(pairs), "--resident", str(resident)], 29547)
+    d1, poses1, counts1, _ = _run(tmp_path, "c4_w1", 1, ["--pairs", str(world * resident), "--resident", str(world * resident)], 0)
+    assert d2["n_gpus"] == 2 and d2["steps"] == pairs // world and d2["config"]["scene_pairs_total"] == pairs
+    assert d2["config"]["resident_scene_pairs_per_gpu"] == resident and d1["config"]["resident_scene_pairs_per_gpu"] == world * resident
+    assert "[rank 0] 128 registrations" in err2 and "[rank 1] 128 registrations" in err2
+    assert poses2.shape == (pairs, 4, 4) and counts2.shape == (pairs,) and poses1.shape == (world * resident, 4, 4)
+    src = np.array([(p % world) + world * ((p // world) % resident) for p in range(pairs)])
+    assert len(set(src.tolist())) == world * resident          # every resident pair of both ranks is registered (four times)
+    np.testing.assert_array_equal(counts2, counts1[src])
+    np.testing.assert_array_equal(poses2, poses1[src])          # bit-equal, all 256, in global pair order
+    assert (counts2 > 1000).all()
+    # the 64 distinct pairs have 64 distinct poses: an ordering mistake in the gather could not hide behind equal rows
+    assert len({poses1[k].tobytes() for k in range(world * resident)}) == world * resident
+    assert d2["config"]["max_pose_err_vs_planted"] < 0.05

@@ -488,7 +488,91 @@ def test_the_two_forms_of_the_fp6_preparation_write_the_same_bytes(d, n, m, flag
             torch.cuda.synchronize()
             out.append((qb, bb))
     finally:
-        lib.vfm_debug_set_coarse_variant(41)
+        lib.vfm_debug_set_coarse_variant(43)     # the default (round 6): prep_once_kernel
     for k, name in ((0, "scan"), (1, "map")):
         diff = torch.nonzero(out[0][k] != out[1][k]).flatten()
         assert diff.numel() == 0, f"{name}: {diff.numel()} bytes differ, first at {diff[:8].tolist()}, last at {int(diff[-1])} of {out[0][k].numel()}"
+
+
+
+def _i8_rows(buf, rows, d):
+    lib = _lib.load()
+    q8 = np.empty((rows, d), np.int8)
+    step, err, gerr = (np.empty(rows, np.float32) for _ in range(3))
+    _lib.check(lib.vfm_debug_i8_rows(buf.data_ptr(), rows, d, q8.ctypes.data, step.ctypes.data, err.ctypes.data, gerr.ctypes.data))
+    return q8, step, err, gerr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,n,m,flags", [(384, 3000, 9001, PREPARE_MX6), (384, 3000, 9001, PREPARE_MX6 | PREPARE_MX6_HALF),
+                                         (256, 1234, 5000, PREPARE_MX6), (256, 129, 5000, PREPARE_MX6 | PREPARE_MX6_HALF),
+                                         (384, 1, 127, PREPARE_MX6 | PREPARE_MX6_HALF)])
+def test_the_one_read_form_of_the_fp6_preparation(d, n, m, flags):
+    """prep_once_kernel (round 6, the default: every row read ONCE, the wave's tile kept as packed halves in registers between the pass
+    that finds 1 / |row| and the group's step and the pass that quantises) against prep_stream_kernel.  Identical, byte for byte:
+    1 / |row| (the oracle's), the fp6 image with its block scales, err6 / err6h and their group maxima, the int8 steps.  Its own
+    definition: the int8 codes are rint(fp16(v) / s) -- at most one unit from rint(v / s) -- and E(int8) = |fp16(v) - s q| measured +
+    the fp16 rounding bounded; E must still bound the residual against the ORACLE's normalised rows (that is all the search's proofs
+    use: tests/test_gpu_int8.py::test_quantisation_bound_holds_for_every_pair), and stay within 6 % of the other form's."""
+    from oracle import oracle as orc
+    lib = _lib.load()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(d + n + m + flags)
+    q = torch.randn((n, d), generator=g, device="cuda")
+    b = torch.randn((m, d), generator=g, device="cuda")
+    b[m // 2] = 0.0
+    b[m // 4] *= 1e18
+    q[0, : d // 2] *= 1e-3
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    try:
+        for variant in (41, 43):
+            lib.vfm_debug_set_coarse_variant(variant)
+            qb = torch.zeros(lib.vfm_match_prepared_bytes(n, d), dtype=torch.uint8, device="cuda")
+            bb = torch.zeros(lib.vfm_match_prepared_bytes(m, d), dtype=torch.uint8, device="cuda")
+            _lib.check(lib.vfm_match_prepare2_gated_p(b.data_ptr(), m, bb.data_ptr(), q.data_ptr(), n, qb.data_ptr(), d, flags, st))
+            torch.cuda.synchronize()
+            out[variant] = (qb, bb)
+    finally:
+        lib.vfm_debug_set_coarse_variant(43)
+    for k, (x, rows) in enumerate(((q, n), (b, m))):
+        A, B = out[41][k], out[43][k]
+        assert torch.equal(A[: 4 * rows], B[: 4 * rows])                               # 1 / |row|
+        for u, v in zip(_mx6_rows(A, rows, d), _mx6_rows(B, rows, d)):                 # fp6 image (dequantised), err6, gerr6
+            np.testing.assert_array_equal(u, v)
+        eh = [np.empty(rows, np.float32) for _ in range(4)]
+        _lib.check(lib.vfm_debug_mx6_half_err(A.data_ptr(), rows, d, eh[0].ctypes.data, eh[1].ctypes.data))
+        _lib.check(lib.vfm_debug_mx6_half_err(B.data_ptr(), rows, d, eh[2].ctypes.data, eh[3].ctypes.data))
+        np.testing.assert_array_equal(eh[0], eh[2])
+        np.testing.assert_array_equal(eh[1], eh[3])
+        a8, b8 = _i8_rows(A, rows, d), _i8_rows(B, rows, d)
+        np.testing.assert_array_equal(a8[1], b8[1])                                    # the groups' steps
+        assert np.abs(a8[0].astype(np.int32) - b8[0].astype(np.int32)).max() <= 1
+        v, _ = orc.l2norm_rows(x.cpu().numpy())
+        res = np.linalg.norm(v.astype(np.float64) - b8[1][:, None].astype(np.float64) * b8[0].astype(np.float64), axis=1)
+        assert (b8[2].astype(np.float64) >= res).all()
+        assert (b8[3] >= b8[2]).all()
+        ok = a8[2] > 0
+        assert (b8[2][ok] <= 1.06 * a8[2][ok] + 5e-4).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("data", ["D.2", "lifted"])
+def test_searches_behind_either_form_of_the_preparation_give_the_same_answers(data):
+    """the exact decision does not depend on which int8 image the rescans read: fp6 half-width fused, fp6 full width, int8 records"""
+    from vfmreg import synth
+    lib = _lib.load()
+    n, m, d = 6000, 40000, 384
+    p = synth.make_pair_device(n, m, d, seed=3) if data == "D.2" else synth.make_lifted_pair_device(n, m, d, seed=3, common=1.0)
+    gate = float(np.nextafter(np.float32(0.8), np.float32(-np.inf)))
+    res = {}
+    try:
+        for variant in (41, 43):
+            lib.vfm_debug_set_coarse_variant(variant)
+            for records, flags in ((8, PREPARE_MX6 | PREPARE_MX6_HALF), (5, PREPARE_MX6), (0, PREPARE_MX6)):
+                res[(variant, records)] = _search(p["q_desc"], p["b_desc"], gate, records, flags)
+    finally:
+        lib.vfm_debug_set_coarse_variant(43)
+    for records in (8, 5, 0):
+        a, b_ = res[(41, records)], res[(43, records)]
+        assert torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1]), records

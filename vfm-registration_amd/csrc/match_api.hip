@@ -49,7 +49,7 @@ int g_seed_units = 1;   // vfm_debug_set_coarse_variant(7): no seed units (A/B)
 int g_select_variant = 0;  // vfm_debug_set_coarse_variant(20 / 21): general select kernel / no chunk-major rescan (A/B)
 int g_mx6_t4 = 1;
 int g_mx6_ns3 = 1;   // vfm_debug_set_coarse_variant(32 / 33): the fused fp6 half-width kernel at d = 384 with two / three (default since round 5) query tiles per wave
-int g_prep_stream = 1;   // 1: prep_stream_kernel (default), 0: prep_chunk_kernel, 2: by width (d = 384: the one-pass form) -- see match_prep.hip
+int g_prep_stream = 3;   // 3: prep_once_kernel (default since round 6), 1: prep_stream_kernel, 0: prep_chunk_kernel, 2: by width (d = 384: prep_chunk_kernel) -- see match_prep.hip
 int g_finish_short = 0;
 int g_rescan_rows = 1;
 int g_match_stats = 0;  // vfm_debug_set_match_stats: per-query counters cost ~0.5 ms of same-address atomics per search
@@ -512,8 +512,8 @@ VFM_EXPORT int vfm_debug_set_coarse_variant(int qsets) {
         g_finish_short = qsets == 51 ? 1 : 0;
         return VFM_OK;
     }
-    if (qsets >= 40 && qsets <= 42) {   // fp6 operand preparation: 40 = prep_chunk_kernel (rows in registers), 41 = prep_stream_kernel (the default), 42 = by width
-        g_prep_stream = qsets == 42 ? 2 : qsets == 41 ? 1 : 0;
+    if (qsets >= 40 && qsets <= 43) {   // fp6 operand preparation: 40 = prep_chunk_kernel (rows in registers), 41 = prep_stream_kernel, 42 = by width, 43 = prep_once_kernel (round 6: one read, a tile's fp16 copy in registers)
+        g_prep_stream = qsets == 43 ? 3 : qsets == 42 ? 2 : qsets == 41 ? 1 : 0;
         return VFM_OK;
     }
     if (qsets == 32 || qsets == 33) {   // the fused fp6 half-width kernel at d = 384: 32 = two 32-query tiles per wave, 33 = three (round 5)

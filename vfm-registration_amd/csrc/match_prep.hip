@@ -116,6 +116,7 @@ struct PrepOut {
 // (codes converted back by v_cvt_scalef32_pk32_f16_fp6 at scale 1: exact), the rounding of the fp16 copy itself is bounded:
 // |v - fp16(v)|_2 <= 2^-11 |v|_2 + sqrt(d) 2^-25 (denormals), |v|_2 <= 1 + 2^-13.
 constexpr float MX6_SLACK = 4.0e-5f;   // on every E: the MFMA's fp32 accumulation (<= 6 steps x a few ulp of 4), the records' 2^-20 grid, the top-2 packing (64 ulp of 4)
+constexpr float PREP_F16_ROUNDING = 4.8929e-4f;  // the same bound, for the int8 image prep_once_kernel quantises from the fp16 copy
 constexpr float MX6_F16_ROUNDING = 4.8929e-4f;   // 2^-11 (1 + 2^-13) + sqrt(768) 2^-25, rounded up
 typedef _Float16 halfx32 __attribute__((ext_vector_type(32)));
 typedef int intx6 __attribute__((ext_vector_type(6)));
@@ -823,6 +824,371 @@ __global__ __launch_bounds__(256, 3) void prep_stream_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same images from ONE read of the rows by a workgroup of prep_stream_kernel's size (round 6; VERDICT r5 item 3c: the stream form
+// moves 782 MB -- every row twice through the fabric, the second time from the L2 / the memory-side cache -- for 462 MB that must
+// move once, and in the pipeline a cycle is coarse kernel + preparation).  What has to survive from the pass that needs all 128 rows
+// of a group (1 / |row|, the group's largest magnitude = its quantisation step) to the pass that quantises is the NORMALISED row, and
+// the fp6 image is defined on its fp16 rounding anyway: pass 1 leaves the wave's 32 rows as packed halves in REGISTERS -- 3 registers
+// per row at d = 384 (a lane's first chunk: 2; the second chunks of a pair of rows share 2: lanes 0 - 31 the even row's, lanes 32 - 63
+// the odd row's, moved there by v_permlane32_swap), 96 in all -- beside a batch of 8 rows in flight; nothing is read twice and no
+// group lives in the LDS (prep_chunk_kernel: 8 waves x 200 registers + 150 KB, one workgroup per compute unit, 0.185 ms alone).
+// Definition of THIS form's int8 image (it is not byte-identical to the other two forms'): with h = fp16(v), v the fp32-normalised
+// element, q = clamp(rint(h * 127 / amax)), amax the group's largest |v| in fp32 as before; E = |h - s q|_2 + |v - h|_2, both terms
+// MEASURED (the second in pass 1, where v and h are both at hand; ~1.4e-4 beside ~1e-2), each rounded up.  The fp6 image, err6 / err6h,
+// 1 / |row|, rest / grest and every group datum are the other forms', bit for bit (same arithmetic on the same values).
+// ---------------------------------------------------------------------------------------------
+template <int D, bool HALF>
+__global__ __launch_bounds__(256, 2) void prep_once_kernel(const float* __restrict__ x1, int64_t rows1, PrepOut o1, int groups1,
+                                                           const float* __restrict__ x2, int64_t rows2, PrepOut o2, int groups) {
+    constexpr int NC = D > 256 ? 2 : 1;          // float4 chunks per lane and row
+    constexpr int NCH = D >> 2;                  // float4 chunks per row
+    constexpr int NU = D >> 4;                   // 16-byte int8 units per row
+    constexpr int NBLK = D >> 5;                 // 32-column blocks per row
+    constexpr int RS8 = D + 16;                  // LDS bytes per int8 row of a batch (padded: the 8 rows of a unit column in 8 bank groups)
+    constexpr int nconv = HALF ? NBLK >> 1 : NBLK;   // blocks the fp6 image covers (HALF: VFM_PREPARE_MX6_HALF, o.mx6_half)
+    constexpr int nitems = 8 * nconv;            // (row, block) items of a batch
+    static_assert(D == 256 || D == 384, "a lane owns one chunk (d = 256) or one and a half (d = 384) of a row");
+    __shared__ __attribute__((aligned(16))) unsigned char l_i8[4][8 * RS8];
+    __shared__ __attribute__((aligned(16))) unsigned char l_h16[4][4 * nitems * 16];
+    __shared__ float l_e6[NBLK][I8_GROUP];
+    __shared__ unsigned char l_sc[I8_GROUP][16];
+    __shared__ unsigned amax_bits, emax_bits, rmax_bits, e6max_bits, e6hmax_bits;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int gidx = blockIdx.x;
+    const bool second = gidx >= groups1;
+    const int grp = second ? gidx - groups1 : gidx;
+    const float* x = second ? x2 : x1;
+    const int64_t rows = second ? rows2 : rows1;
+    const PrepOut& o = second ? o2 : o1;
+    if (threadIdx.x == 0) {
+        amax_bits = 0u;
+        emax_bits = 0u;
+        rmax_bits = 0u;
+        e6max_bits = 0u;
+        e6hmax_bits = 0u;
+    }
+    float4 v[8][NC];
+    const int64_t row0 = (int64_t)grp * I8_GROUP + wave * 32;   // first row of the wave's tile
+    auto load_row = [&](int b, int j) __attribute__((always_inline)) {
+        const int64_t r = row0 + 8 * b + j;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + 64 * i;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows && c < NCH) {
+                const float* pc = x + r * (int64_t)D + 4 * c;
+                t.x = __builtin_nontemporal_load(pc);
+                t.y = __builtin_nontemporal_load(pc + 1);
+                t.z = __builtin_nontemporal_load(pc + 2);
+                t.w = __builtin_nontemporal_load(pc + 3);
+            }
+            v[j][i] = t;
+        }
+    };
+    auto scatter8 = [&](const float* p) __attribute__((always_inline)) {   // (prep_chunk_kernel's: lane l ends with row l >> 3)
+        const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+        float q4[4], q2[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q4[j] = (b5 ? p[j + 4] : p[j]) + __shfl_xor(b5 ? p[j] : p[j + 4], 32);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) q2[j] = (b4 ? q4[j + 2] : q4[j]) + __shfl_xor(b4 ? q4[j] : q4[j + 2], 16);
+        float q1 = (b3 ? q2[1] : q2[0]) + __shfl_xor(b3 ? q2[0] : q2[1], 8);
+        q1 = q1 + __shfl_xor(q1, 4);
+        q1 = q1 + __shfl_xor(q1, 2);
+        q1 = q1 + __shfl_xor(q1, 1);
+        return q1;
+    };
+    // the wave's 32 normalised rows as packed halves: hs0[row] = the lane's first chunk; hs1[pair] (d = 384) = the second chunk of rows
+    // 2 pair (lanes 0 - 31) and 2 pair + 1 (lanes 32 - 63: the value its lane l - 32 computed)
+    uint2 hs0[32];
+    uint2 hs1[NC > 1 ? 16 : 1];
+    auto pack4 = [&](const float (&nv)[4]) __attribute__((always_inline)) {
+        // (the fp32 product is rounded to fp16 as a value of its own -- see prep_stream_kernel: hidden from the compiler, which otherwise
+        // fuses product and conversion into one v_fma_mixlo_f16, a single rounding)
+        float nh[4] = {nv[0], nv[1], nv[2], nv[3]};
+        asm volatile("" : "+v"(nh[0]), "+v"(nh[1]), "+v"(nh[2]), "+v"(nh[3]));
+        half4 h;
+        h[0] = (_Float16)nh[0];
+        h[1] = (_Float16)nh[1];
+        h[2] = (_Float16)nh[2];
+        h[3] = (_Float16)nh[3];
+        uint2 u;
+        __builtin_memcpy(&u, &h, 8);
+        // (as two PACKED registers from here on: left to itself the compiler keeps the four halves in four registers until their last use
+        // -- the 96-register copy of the tile became 192 and 262 registers were spilled)
+        asm volatile("" : "+v"(u.x), "+v"(u.y));
+        return u;
+    };
+    auto unpack4 = [&](uint2 u, float (&nv)[4]) __attribute__((always_inline)) {
+        half4 h;
+        __builtin_memcpy(&h, &u, 8);
+        nv[0] = (float)h[0];
+        nv[1] = (float)h[1];
+        nv[2] = (float)h[2];
+        nv[3] = (float)h[3];
+    };
+    // ---- pass 1: 1 / |row| (oracle order), the group's largest normalised magnitude, |second half|, the fp16 copy and its residual
+#pragma unroll
+    for (int j = 0; j < 8; ++j) load_row(0, j);
+    __syncthreads();   // the maxima are initialised (pass 1 already adds to rmax_bits)
+    float lmax = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        __builtin_amdgcn_sched_barrier(0);   // (the four unrolled batches stay apart: interleaved by the scheduler they spilled 262 registers)
+        float part[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float p = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                if (lane + 64 * i < NCH) {
+                    float t;
+                    t = v[j][i].x * v[j][i].x; p = p + t;
+                    t = v[j][i].y * v[j][i].y; p = p + t;
+                    t = v[j][i].z * v[j][i].z; p = p + t;
+                    t = v[j][i].w * v[j][i].w; p = p + t;
+                }
+            }
+            part[j] = p;
+        }
+        const float my_inv = inv_norm_from_sumsq(scatter8(part));   // of row lane >> 3 of the batch
+        if ((lane & 7) == 0) o.inv[row0 + 8 * b + (lane >> 3)] = my_inv;
+        float rpart[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float iv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_inv), 8 * j));
+            float r2 = 0.0f;
+            uint2 hh[NC];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const int c = lane + 64 * i;
+                // normalised values exactly as faiss leaves them in fp32 (chunks beyond the row: zeros)
+                const float nv[4] = {v[j][i].x * iv, v[j][i].y * iv, v[j][i].z * iv, v[j][i].w * iv};
+                lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(nv[0]), fabsf(nv[1])), fmaxf(fabsf(nv[2]), fabsf(nv[3]))));
+                const float ss = nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] + nv[3] * nv[3];
+                r2 = r2 + ((8 * c >= D && c < NCH) ? ss : 0.0f);   // columns >= d / 2 (the other forms' sum: x + 0 = x)
+                hh[i] = pack4(nv);
+            }
+            // (the row's sums are wanted HERE: left to the compiler they were formed at the end of the batch and the 64 normalised
+            // values of its rows were spilled to wait for it)
+            asm volatile("" : "+v"(r2), "+v"(lmax));
+            hs0[8 * b + j] = hh[0];
+            if constexpr (NC > 1) {
+                if ((j & 1) == 0) {
+                    hs1[4 * b + (j >> 1)] = hh[1];          // lanes 0 - 31: the even row's second chunk (the upper lanes' zeros are replaced below)
+                } else {
+                    const uint2 t = hs1[4 * b + (j >> 1)];
+                    const auto sx = __builtin_amdgcn_permlane32_swap(t.x, hh[1].x, false, false);   // result 0 = {t lanes 0-31 | hh lanes 0-31}
+                    const auto sy = __builtin_amdgcn_permlane32_swap(t.y, hh[1].y, false, false);
+                    hs1[4 * b + (j >> 1)] = make_uint2((unsigned)sx[0], (unsigned)sy[0]);
+                }
+            }
+            rpart[j] = r2;
+            if (b < 3) load_row(b + 1, j);
+        }
+        {
+            float rn = sqrtf(scatter8(rpart)) * 1.000244140625f + 1.0e-30f;
+            if (!(rn == rn)) rn = __builtin_inff();
+            const int64_t r = row0 + 8 * b + (lane >> 3);
+            if (r >= rows) rn = 0.0f;
+            if ((lane & 7) == 0) {
+                o.rest[r] = rn;
+                if (rn > 0.0f) atomicMax(&rmax_bits, __float_as_uint(rn));
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    __syncthreads();
+    if (lane == 0 && lmax > 0.0f) atomicMax(&amax_bits, __float_as_uint(lmax));
+    __syncthreads();
+    const float amax = __uint_as_float(amax_bits);
+    const bool usable = amax > 0.0f && amax < 3.0e38f;
+    const float qstep = usable ? amax / 127.0f : 1.0f;
+    const float inv_qstep = usable ? 127.0f / amax : 0.0f;
+    // ---- pass 2: from the registers
+    unsigned char* my8 = l_i8[wave];
+    unsigned char* my16 = l_h16[wave];
+    const int tb6 = mx6_tile_bytes(D >> 6);
+    unsigned char* tile6 = reinterpret_cast<unsigned char*>(o.tiles6) + ((size_t)grp * 4 + wave) * (size_t)tb6;
+    uint4* tile8 = o.tiles8 + ((size_t)grp * 4 + wave) * (size_t)(NU * 32);
+    uint4* tile8h = o.tiles8h + ((size_t)grp * 4 + wave) * (size_t)((NU >> 1) * 32);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        __builtin_amdgcn_sched_barrier(0);
+        float part[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float e2 = 0.0f;
+            uint2 hh[NC];
+            hh[0] = hs0[8 * b + j];
+            if constexpr (NC > 1) {
+                const uint2 t = hs1[4 * b + (j >> 1)];
+                if ((j & 1) == 0) {
+                    hh[1] = t;
+                } else {   // the odd row's second chunk sits in lanes 32 - 63: back to lanes 0 - 31
+                    const auto sx = __builtin_amdgcn_permlane32_swap(t.x, t.x, false, false);   // result 1, lanes 0 - 31 = lanes 32 - 63 of t
+                    const auto sy = __builtin_amdgcn_permlane32_swap(t.y, t.y, false, false);
+                    hh[1].x = (unsigned)sx[1];
+                    hh[1].y = (unsigned)sy[1];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const int c = lane + 64 * i;
+                if (c < NCH) {
+                    float nv[4];
+                    unpack4(hh[i], nv);
+                    int qi[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float qf = rintf(nv[e] * inv_qstep);
+                        qf = fminf(fmaxf(qf, -127.0f), 127.0f);
+                        const float res = __builtin_fmaf(-qstep, qf, nv[e]);
+                        e2 = __builtin_fmaf(res, res, e2);
+                        qi[e] = (int)qf;
+                    }
+                    const unsigned packed = __builtin_amdgcn_perm((unsigned)qi[1], (unsigned)qi[0], 0x0c0c0400u) |
+                                            __builtin_amdgcn_perm((unsigned)qi[3], (unsigned)qi[2], 0x04000c0cu);
+                    *reinterpret_cast<unsigned*>(my8 + j * RS8 + 4 * c) = packed;
+                    if (c < 8 * nconv) {   // quarter k of (row, block): 8 halves = chunks 2 k, 2 k + 1 of the block
+                        const int blk = c >> 3, k = (c & 7) >> 1, sub = c & 1;
+                        *reinterpret_cast<uint2*>(my16 + ((size_t)(k * nitems + j * nconv + blk) * 16 + sub * 8)) = hh[i];
+                    }
+                }
+            }
+            part[j] = e2;
+        }
+        {
+            // E = |h - s q|_2 (measured, rounded up) + |v - h|_2 (bounded: PREP_F16_ROUNDING)
+            float en = (sqrtf(scatter8(part)) * 1.000244140625f + PREP_F16_ROUNDING) * 1.0000002384185791f + 1.0e-30f;
+            if (!(en == en)) en = __builtin_inff();
+            const int64_t r = row0 + 8 * b + (lane >> 3);
+            if (r >= rows) en = 0.0f;
+            if ((lane & 7) == 0) {
+                o.err[r] = en;
+                if (en > 0.0f) atomicMax(&emax_bits, __float_as_uint(en));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // int8: unit column u of the batch's 8 rows = 128 consecutive bytes of the tile
+#pragma unroll
+        for (int rd = 0; rd < (NU * 8 + 63) / 64; ++rd) {
+            const int e = rd * 64 + lane, u = e >> 3, j = e & 7;
+            if (e < NU * 8) {
+                const uint4 tq = *reinterpret_cast<const uint4*>(my8 + j * RS8 + 16 * u);
+                unsigned* po = reinterpret_cast<unsigned*>(tile8 + u * 32 + 8 * b + j);
+                __builtin_nontemporal_store(tq.x, po);
+                __builtin_nontemporal_store(tq.y, po + 1);
+                __builtin_nontemporal_store(tq.z, po + 2);
+                __builtin_nontemporal_store(tq.w, po + 3);
+                if (!HALF && u < (NU >> 1)) {   // the first d / 2 columns again, as tiles of their own
+                    unsigned* ph = reinterpret_cast<unsigned*>(tile8h + u * 32 + 8 * b + j);
+                    __builtin_nontemporal_store(tq.x, ph);
+                    __builtin_nontemporal_store(tq.y, ph + 1);
+                    __builtin_nontemporal_store(tq.z, ph + 2);
+                    __builtin_nontemporal_store(tq.w, ph + 3);
+                }
+            }
+        }
+        if (o.rows8) {   // row-major copy (scan-sized operands): the batch's rows as they lie in the slice
+#pragma unroll
+            for (int rd = 0; rd < (NU * 8 + 63) / 64; ++rd) {
+                const int e = rd * 64 + lane, j = e / NU, u = e - j * NU;
+                if (e < NU * 8)
+                    *reinterpret_cast<uint4*>(o.rows8 + (size_t)(row0 + 8 * b + j) * D + 16 * u) = *reinterpret_cast<const uint4*>(my8 + j * RS8 + 16 * u);
+            }
+        }
+        // fp6: lane = (row j, block) of the batch -- prep_chunk_kernel's conversion
+#pragma unroll
+        for (int item0 = 0; item0 < nitems; item0 += 64) {
+            const int item = item0 + lane;
+            if (item >= nitems) break;
+            const int j = item / nconv, blk = item - j * nconv, p = 8 * b + j;
+            union {
+                uint4 u[4];
+                halfx32 h;
+                unsigned w[16];
+            } vv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vv.u[k] = *reinterpret_cast<const uint4*>(my16 + (size_t)(k * nitems + item) * 16);
+            ushortx2 m2 = {0, 0};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const unsigned a2 = vv.w[i] & 0x7fff7fffu;
+                m2 = __builtin_elementwise_max(m2, *reinterpret_cast<const ushortx2*>(&a2));
+            }
+            const unsigned am = max((unsigned)m2[0], (unsigned)m2[1]);
+            int ex = (int)(am >> 10) - 15 - ((am & 0x3ffu) <= 0x3c0u ? 2 : 1);
+            ex = ex > 0 ? 0 : ex;
+            const float sc6 = __uint_as_float((unsigned)(ex + 127) << 23);
+            const intx6 codes = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(vv.h, sc6);
+            const halfx32 back = __builtin_amdgcn_cvt_scalef32_pk32_f16_fp6(codes, 1.0f);
+            float e6 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const float res = __builtin_fmaf(-(float)back[i], sc6, (float)vv.h[i]);
+                e6 = __builtin_fmaf(res, res, e6);
+            }
+            const int s6 = blk >> 1, l6 = (blk & 1) * 32 + p;
+            unsigned* pa = reinterpret_cast<unsigned*>(tile6 + mx6_code_a(s6, l6));
+            __builtin_nontemporal_store((unsigned)codes[0], pa);
+            __builtin_nontemporal_store((unsigned)codes[1], pa + 1);
+            __builtin_nontemporal_store((unsigned)codes[2], pa + 2);
+            __builtin_nontemporal_store((unsigned)codes[3], pa + 3);
+            unsigned* pb = reinterpret_cast<unsigned*>(tile6 + mx6_code_b(s6, l6));
+            __builtin_nontemporal_store((unsigned)codes[4], pb);
+            __builtin_nontemporal_store((unsigned)codes[5], pb + 1);
+            l_sc[wave * 32 + p][blk] = (unsigned char)(ex + 127);
+            l_e6[blk][wave * 32 + p] = e6;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // (the batch's slices of the LDS are read: the next batch may overwrite them)
+    }
+    __syncthreads();
+    {   // the d / 64 scales of MFMA lane (hh, p) of tile t: its 8 bytes of the scale plane
+        const int r = threadIdx.x & (I8_GROUP - 1), hh = threadIdx.x >> 7;
+        unsigned lo = 0u, hi = 0u;
+        for (int s6 = 0; s6 < (nconv >> 1); ++s6) {
+            const unsigned bsc = l_sc[r][2 * s6 + hh];
+            if (s6 < 4) lo |= bsc << (8 * s6);
+            else hi |= bsc << (8 * (s6 - 4));
+        }
+        unsigned char* t6 = reinterpret_cast<unsigned char*>(o.tiles6) + ((size_t)grp * 4 + (r >> 5)) * (size_t)tb6;
+        *reinterpret_cast<uint2*>(t6 + mx6_scale_at(D >> 6, 0, hh * 32 + (r & 31))) = make_uint2(lo, hi);
+    }
+    if (threadIdx.x < I8_GROUP) {   // E of the fp6 image per row: blocks in order; rounded up like the int8 one
+        const int r = threadIdx.x;
+        float acc = 0.0f, acch = 0.0f;
+        for (int blk = 0; blk < nconv; ++blk) {
+            acc = acc + l_e6[blk][r];
+            if (blk + 1 == (NBLK >> 1)) acch = acc;
+        }
+        float e6n = sqrtf(acc) * 1.000244140625f + (MX6_F16_ROUNDING + MX6_SLACK);
+        float e6h = sqrtf(acch) * 1.000244140625f + (MX6_F16_ROUNDING + MX6_SLACK);
+        if (!(e6n == e6n) || HALF) e6n = __builtin_inff();
+        if (!(e6h == e6h)) e6h = __builtin_inff();
+        const int64_t row = (int64_t)grp * I8_GROUP + r;
+        if (row >= rows) e6n = e6h = 0.0f;
+        o.err6[row] = e6n;
+        o.err6h[row] = e6h;
+        if (e6n > 0.0f) atomicMax(&e6max_bits, __float_as_uint(e6n));
+        if (e6h > 0.0f) atomicMax(&e6hmax_bits, __float_as_uint(e6h));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        o.gstep[grp] = qstep;
+        o.gerr[grp] = __uint_as_float(emax_bits);
+        o.grest[grp] = __uint_as_float(rmax_bits);
+        o.gerr6[grp] = __uint_as_float(e6max_bits);
+        o.gerr6h[grp] = __uint_as_float(e6hmax_bits);
+        o.gstep6[grp] = MX6_FIX_STEP;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The fp6 image for the wider rows (d = 512, 768: the half-width pass in fp6 reads its first d / 128 k-steps), by kernels of their
 // own behind prep_chunk_kernel (whose LDS cannot hold an fp16 copy of such a group): a thread takes one (row, 32-column block),
 // reads its 32 floats, normalises them with the 1 / |row| prep_chunk_kernel left, rounds to fp16 and converts exactly as that
@@ -1041,6 +1407,13 @@ int do_prepare2(Rows x1r, int64_t rows1, void* prepared1, Rows x2r, int64_t rows
             // with records - 0.5 %.  In the driver's 20-step form it LOSES 2.9 % (tools/ab_prep_r5_20.py: 1624 against 1672
             // registrations/s): the default stays the stream form; vfm_debug_set_coarse_variant(42) selects by width (d = 384: one pass).
             const bool stream_form = g_prep_stream == 1 || (g_prep_stream == 2 && d == 256);
+            if (g_prep_stream == 3 && (d == 384 || d == 256) && !any_f16) {   // one read of the rows, the fp16 copy of a tile in registers (prep_once_kernel, round 6)
+                const dim3 sg((unsigned)groups), sb(256);
+                if (d == 384 && h6) hipLaunchKernelGGL((prep_once_kernel<384, true>), sg, sb, 0, st, x1, rows1, prep_out(p1, nullptr, h6), g1, x2, rows2, prep_out(p2, nullptr, h6), groups);
+                else if (d == 384) hipLaunchKernelGGL((prep_once_kernel<384, false>), sg, sb, 0, st, x1, rows1, prep_out(p1, nullptr, h6), g1, x2, rows2, prep_out(p2, nullptr, h6), groups);
+                else if (h6) hipLaunchKernelGGL((prep_once_kernel<256, true>), sg, sb, 0, st, x1, rows1, prep_out(p1, nullptr, h6), g1, x2, rows2, prep_out(p2, nullptr, h6), groups);
+                else hipLaunchKernelGGL((prep_once_kernel<256, false>), sg, sb, 0, st, x1, rows1, prep_out(p1, nullptr, h6), g1, x2, rows2, prep_out(p2, nullptr, h6), groups);
+            } else
             if (stream_form && (d == 384 || d == 256) && !any_f16) {   // the form that fits beside a coarse workgroup (prep_stream_kernel)
                 const dim3 sg((unsigned)groups), sb(256);
                 if (d == 384 && h6) hipLaunchKernelGGL((prep_stream_kernel<384, true>), sg, sb, 0, st, x1, rows1, prep_out(p1, nullptr, h6), g1, x2, rows2, prep_out(p2, nullptr, h6), groups);
