@@ -36,6 +36,8 @@
 // pass's and reads the int8 image.
 #include "match_internal.h"
 
+#include <atomic>
+
 namespace vfmm {
 namespace {
 
@@ -557,6 +559,37 @@ int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, bool half, bool fuse, hip
         int s = (int)((1600 + a.nqb - 1) / a.nqb);   // (round 4, tools/sweep_slices_r4.py, fused kernel: 40 / 44 slices 1764 / 1762, 48: 1740, 57: 1690 registrations/s over 200 steps)
         const int smax = a.nchunks / 8 < 64 ? a.nchunks / 8 : 64;
         s = s > smax ? smax : s;
+        s = s < 1 ? 1 : s;
+        // Round 6: the workgroups are equal and a compute unit holds one, so the kernel lasts ceil(workgroups / units) rounds whatever the last
+        // round holds (tools/sweep_slices_r6.py, the kernel alone at C2, 27 query blocks: 60 slices = 6.33 rounds 0.388 ms; 56 = 5.9 rounds
+        // 0.370; 47 = 4.96 rounds 0.367; 19 slices = 2.004 rounds 0.445).  Near the count above, take the slice count whose last round is
+        // (almost) full -- at most 4 above, 12 below; in the pipeline 56 against 60 is +1 % over 200 steps, even in the 20-step form.
+        {
+            static std::atomic<int> ncu{0};
+            int cus = ncu.load(std::memory_order_relaxed);
+            if (cus == 0) {
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+                ncu.store(cus, std::memory_order_relaxed);
+            }
+            int best = s;
+            double best_fill = 0.0;
+            for (int t = (s + 4 < smax ? s + 4 : smax); t >= 1 && t >= s - 12; --t) {
+                const long long wg = (long long)a.nqb * t, rounds = (wg + cus - 1) / cus;
+                const double fill = (double)wg / (double)(rounds * cus);
+                if (fill >= 0.975) {   // the largest such count (short workgroups let the pipeline's other stages in)
+                    best = t;
+                    best_fill = 2.0;
+                    break;
+                }
+                if (fill > best_fill) {
+                    best_fill = fill;
+                    best = t;
+                }
+            }
+            s = best;
+        }
         a.nslices = s < 1 ? 1 : s;
     }
     while ((a.nchunks + a.nslices - 1) / a.nslices + 1 > MX6_LTAB && a.nslices < a.nchunks) ++a.nslices;   // a slice's constants fit the LDS table

@@ -840,8 +840,7 @@ __global__ __launch_bounds__(256, 3) void prep_stream_kernel(const float* __rest
 template <int D, bool HALF>
 __global__ __launch_bounds__(256, 2) void prep_once_kernel(const float* __restrict__ x1, int64_t rows1, PrepOut o1, int groups1,
                                                            const float* __restrict__ x2, int64_t rows2, PrepOut o2, int groups) {
-    constexpr int NC = D > 256 ? 2 : 1;          // float4 chunks per lane and row
-    constexpr int NCH = D >> 2;                  // float4 chunks per row
+    constexpr bool PAIR = D > 256;               // d = 384: a row is one chunk per lane + half a chunk -- the second chunks of TWO rows share a register
     constexpr int NU = D >> 4;                   // 16-byte int8 units per row
     constexpr int NBLK = D >> 5;                 // 32-column blocks per row
     constexpr int RS8 = D + 16;                  // LDS bytes per int8 row of a batch (padded: the 8 rows of a unit column in 8 bank groups)
@@ -854,6 +853,7 @@ __global__ __launch_bounds__(256, 2) void prep_once_kernel(const float* __restri
     __shared__ unsigned char l_sc[I8_GROUP][16];
     __shared__ unsigned amax_bits, emax_bits, rmax_bits, e6max_bits, e6hmax_bits;
     const int wave = threadIdx.x >> 6, lane = lane_id();
+    const bool lo = lane < 32;
     const int gidx = blockIdx.x;
     const bool second = gidx >= groups1;
     const int grp = second ? gidx - groups1 : gidx;
@@ -867,24 +867,30 @@ __global__ __launch_bounds__(256, 2) void prep_once_kernel(const float* __restri
         e6max_bits = 0u;
         e6hmax_bits = 0u;
     }
-    float4 v[8][NC];
+    // a batch of 8 rows in flight: v0[j] = the lane's first chunk (columns 4 lane ..) of row j; vp[jp] (d = 384) = the second chunk --
+    // columns 256 + 4 (lane & 31) .. -- of row 2 jp (lanes 0 - 31) and of row 2 jp + 1 (lanes 32 - 63): every lane of every load, every
+    // multiply and every conversion below works on a real element (with one register per row the upper half of the wave carried zeros
+    // through a quarter of the kernel's VALU work)
+    float4 v0[8];
+    float4 vp[PAIR ? 4 : 1];
     const int64_t row0 = (int64_t)grp * I8_GROUP + wave * 32;   // first row of the wave's tile
-    auto load_row = [&](int b, int j) __attribute__((always_inline)) {
-        const int64_t r = row0 + 8 * b + j;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int c = lane + 64 * i;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < rows && c < NCH) {
-                const float* pc = x + r * (int64_t)D + 4 * c;
-                t.x = __builtin_nontemporal_load(pc);
-                t.y = __builtin_nontemporal_load(pc + 1);
-                t.z = __builtin_nontemporal_load(pc + 2);
-                t.w = __builtin_nontemporal_load(pc + 3);
-            }
-            v[j][i] = t;
+    auto load4 = [&](int64_t r, int c) __attribute__((always_inline)) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef VFM_POABL_NOLOAD   // (timing experiments, tools/build_ablate_prep.sh: results are garbage)
+        if (r < rows) t = make_float4(1.0f + (float)c, 2.0f - (float)(r & 7), 0.5f * (float)lane, 3.0f);
+#else
+        if (r < rows) {
+            const float* pc = x + r * (int64_t)D + 4 * c;
+            t.x = __builtin_nontemporal_load(pc);
+            t.y = __builtin_nontemporal_load(pc + 1);
+            t.z = __builtin_nontemporal_load(pc + 2);
+            t.w = __builtin_nontemporal_load(pc + 3);
         }
+#endif
+        return t;
     };
+    auto load_row = [&](int b, int j) __attribute__((always_inline)) { v0[j] = load4(row0 + 8 * b + j, lane); };
+    auto load_pair = [&](int b, int jp) __attribute__((always_inline)) { vp[jp] = load4(row0 + 8 * b + 2 * jp + (lane >> 5), 64 + (lane & 31)); };
     auto scatter8 = [&](const float* p) __attribute__((always_inline)) {   // (prep_chunk_kernel's: lane l ends with row l >> 3)
         const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
         float q4[4], q2[2];
@@ -898,10 +904,18 @@ __global__ __launch_bounds__(256, 2) void prep_once_kernel(const float* __restri
         q1 = q1 + __shfl_xor(q1, 1);
         return q1;
     };
-    // the wave's 32 normalised rows as packed halves: hs0[row] = the lane's first chunk; hs1[pair] (d = 384) = the second chunk of rows
-    // 2 pair (lanes 0 - 31) and 2 pair + 1 (lanes 32 - 63: the value its lane l - 32 computed)
+    // v_permlane32_swap(a, b): result 0 = {a lanes 0-31 | b lanes 0-31}, result 1 = {a lanes 32-63 | b lanes 32-63} (rows of 32 lanes)
+    auto lo_lo = [&](float a, float b) __attribute__((always_inline)) {   // lanes 0-31: a's lower half; lanes 32-63: b's LOWER half
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        return __uint_as_float((unsigned)sw[0]);
+    };
+    auto hi_to_lo = [&](float a) __attribute__((always_inline)) {         // lanes 0-31: a's UPPER half (lanes 32-63: a's own)
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+        return __uint_as_float((unsigned)sw[1]);
+    };
+    // the wave's 32 normalised rows as packed halves: hs0[row] = the lane's first chunk; hs1[pair] (d = 384) = the pair's second chunks
     uint2 hs0[32];
-    uint2 hs1[NC > 1 ? 16 : 1];
+    uint2 hs1[PAIR ? 16 : 1];
     auto pack4 = [&](const float (&nv)[4]) __attribute__((always_inline)) {
         // (the fp32 product is rounded to fp16 as a value of its own -- see prep_stream_kernel: hidden from the compiler, which otherwise
         // fuses product and conversion into one v_fma_mixlo_f16, a single rounding)
@@ -927,64 +941,75 @@ __global__ __launch_bounds__(256, 2) void prep_once_kernel(const float* __restri
         nv[2] = (float)h[2];
         nv[3] = (float)h[3];
     };
-    // ---- pass 1: 1 / |row| (oracle order), the group's largest normalised magnitude, |second half|, the fp16 copy and its residual
+    // sum of a chunk's squares onto p in the oracle's order: ((((p + x^2) + y^2) + z^2) + w^2)
+    auto fold4 = [&](float p, const float4& t) __attribute__((always_inline)) {
+        float q;
+        q = t.x * t.x; p = p + q;
+        q = t.y * t.y; p = p + q;
+        q = t.z * t.z; p = p + q;
+        q = t.w * t.w; p = p + q;
+        return p;
+    };
+    // ---- pass 1: 1 / |row| (oracle order), the group's largest normalised magnitude, |second half|, the fp16 copy
 #pragma unroll
     for (int j = 0; j < 8; ++j) load_row(0, j);
+    if constexpr (PAIR) {
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) load_pair(0, jp);
+    }
     __syncthreads();   // the maxima are initialised (pass 1 already adds to rmax_bits)
     float lmax = 0.0f;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        __builtin_amdgcn_sched_barrier(0);   // (the four unrolled batches stay apart: interleaved by the scheduler they spilled 262 registers)
+        __builtin_amdgcn_sched_barrier(0);   // (the four unrolled batches stay apart)
         float part[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float p = 0.0f;
+        for (int j = 0; j < 8; ++j) part[j] = fold4(0.0f, v0[j]);
+        if constexpr (PAIR) {
+            // lane l < 32 of a row goes on with its chunk 64 + l: the even row's continues in place, the odd row's in lane l + 32, where its
+            // second chunk was loaded -- one fold for both rows -- and comes back to lane l for the butterfly (whose tree is the oracle's)
 #pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                if (lane + 64 * i < NCH) {
-                    float t;
-                    t = v[j][i].x * v[j][i].x; p = p + t;
-                    t = v[j][i].y * v[j][i].y; p = p + t;
-                    t = v[j][i].z * v[j][i].z; p = p + t;
-                    t = v[j][i].w * v[j][i].w; p = p + t;
-                }
+            for (int jp = 0; jp < 4; ++jp) {
+                const float s = fold4(lo_lo(part[2 * jp], part[2 * jp + 1]), vp[jp]);
+                const float sb = hi_to_lo(s);
+                part[2 * jp] = lo ? s : part[2 * jp];
+                part[2 * jp + 1] = lo ? sb : part[2 * jp + 1];
             }
-            part[j] = p;
         }
         const float my_inv = inv_norm_from_sumsq(scatter8(part));   // of row lane >> 3 of the batch
         if ((lane & 7) == 0) o.inv[row0 + 8 * b + (lane >> 3)] = my_inv;
-        float rpart[8];
+        float rpart[8], ivs[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float iv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_inv), 8 * j));
+            ivs[j] = iv;
+            // normalised values exactly as faiss leaves them in fp32
+            const float nv[4] = {v0[j].x * iv, v0[j].y * iv, v0[j].z * iv, v0[j].w * iv};
+            lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(nv[0]), fabsf(nv[1])), fmaxf(fabsf(nv[2]), fabsf(nv[3]))));
+            const float ss = nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] + nv[3] * nv[3];
             float r2 = 0.0f;
-            uint2 hh[NC];
-#pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                const int c = lane + 64 * i;
-                // normalised values exactly as faiss leaves them in fp32 (chunks beyond the row: zeros)
-                const float nv[4] = {v[j][i].x * iv, v[j][i].y * iv, v[j][i].z * iv, v[j][i].w * iv};
-                lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(nv[0]), fabsf(nv[1])), fmaxf(fabsf(nv[2]), fabsf(nv[3]))));
-                const float ss = nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] + nv[3] * nv[3];
-                r2 = r2 + ((8 * c >= D && c < NCH) ? ss : 0.0f);   // columns >= d / 2 (the other forms' sum: x + 0 = x)
-                hh[i] = pack4(nv);
-            }
-            // (the row's sums are wanted HERE: left to the compiler they were formed at the end of the batch and the 64 normalised
-            // values of its rows were spilled to wait for it)
+            r2 = r2 + ((8 * lane >= D) ? ss : 0.0f);   // columns >= d / 2 (the other forms' sum: x + 0 = x)
+            hs0[8 * b + j] = pack4(nv);
+            // (the row's sums are wanted HERE: left to the compiler they were formed at the end of the batch and the normalised values of
+            // its rows were spilled to wait for it)
             asm volatile("" : "+v"(r2), "+v"(lmax));
-            hs0[8 * b + j] = hh[0];
-            if constexpr (NC > 1) {
-                if ((j & 1) == 0) {
-                    hs1[4 * b + (j >> 1)] = hh[1];          // lanes 0 - 31: the even row's second chunk (the upper lanes' zeros are replaced below)
-                } else {
-                    const uint2 t = hs1[4 * b + (j >> 1)];
-                    const auto sx = __builtin_amdgcn_permlane32_swap(t.x, hh[1].x, false, false);   // result 0 = {t lanes 0-31 | hh lanes 0-31}
-                    const auto sy = __builtin_amdgcn_permlane32_swap(t.y, hh[1].y, false, false);
-                    hs1[4 * b + (j >> 1)] = make_uint2((unsigned)sx[0], (unsigned)sy[0]);
-                }
-            }
             rpart[j] = r2;
             if (b < 3) load_row(b + 1, j);
+        }
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                const float iv = lo ? ivs[2 * jp] : ivs[2 * jp + 1];
+                const float nv[4] = {vp[jp].x * iv, vp[jp].y * iv, vp[jp].z * iv, vp[jp].w * iv};
+                lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(nv[0]), fabsf(nv[1])), fmaxf(fabsf(nv[2]), fabsf(nv[3]))));
+                float ss = nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] + nv[3] * nv[3];   // all of these columns are >= d / 2
+                hs1[4 * b + jp] = pack4(nv);
+                asm volatile("" : "+v"(ss), "+v"(lmax));
+                const float ssb = hi_to_lo(ss);                       // the odd row's, back in the lanes the oracle's tree expects
+                rpart[2 * jp] = rpart[2 * jp] + (lo ? ss : 0.0f);
+                rpart[2 * jp + 1] = rpart[2 * jp + 1] + (lo ? ssb : 0.0f);
+                if (b < 3) load_pair(b + 1, jp);
+            }
         }
         {
             float rn = sqrtf(scatter8(rpart)) * 1.000244140625f + 1.0e-30f;
@@ -1013,51 +1038,43 @@ __global__ __launch_bounds__(256, 2) void prep_once_kernel(const float* __restri
     unsigned char* tile6 = reinterpret_cast<unsigned char*>(o.tiles6) + ((size_t)grp * 4 + wave) * (size_t)tb6;
     uint4* tile8 = o.tiles8 + ((size_t)grp * 4 + wave) * (size_t)(NU * 32);
     uint4* tile8h = o.tiles8h + ((size_t)grp * 4 + wave) * (size_t)((NU >> 1) * 32);
+    // one chunk of a row: quantise (codes to the batch's int8 slice), residual against the fp16 value, the halves to the fp6 staging
+    auto quant_chunk = [&](uint2 hh, int jr, int c) __attribute__((always_inline)) {
+        float nv[4];
+        unpack4(hh, nv);
+        int qi[4];
+        float e2 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float qf = rintf(nv[e] * inv_qstep);
+            qf = fminf(fmaxf(qf, -127.0f), 127.0f);
+            const float res = __builtin_fmaf(-qstep, qf, nv[e]);
+            e2 = __builtin_fmaf(res, res, e2);
+            qi[e] = (int)qf;
+        }
+        const unsigned packed = __builtin_amdgcn_perm((unsigned)qi[1], (unsigned)qi[0], 0x0c0c0400u) |
+                                __builtin_amdgcn_perm((unsigned)qi[3], (unsigned)qi[2], 0x04000c0cu);
+        *reinterpret_cast<unsigned*>(my8 + jr * RS8 + 4 * c) = packed;
+        if (c < 8 * nconv) {   // quarter k of (row, block): 8 halves = chunks 2 k, 2 k + 1 of the block
+            const int blk = c >> 3, k = (c & 7) >> 1, sub = c & 1;
+            *reinterpret_cast<uint2*>(my16 + ((size_t)(k * nitems + jr * nconv + blk) * 16 + sub * 8)) = hh;
+        }
+        return e2;
+    };
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         __builtin_amdgcn_sched_barrier(0);
         float part[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float e2 = 0.0f;
-            uint2 hh[NC];
-            hh[0] = hs0[8 * b + j];
-            if constexpr (NC > 1) {
-                const uint2 t = hs1[4 * b + (j >> 1)];
-                if ((j & 1) == 0) {
-                    hh[1] = t;
-                } else {   // the odd row's second chunk sits in lanes 32 - 63: back to lanes 0 - 31
-                    const auto sx = __builtin_amdgcn_permlane32_swap(t.x, t.x, false, false);   // result 1, lanes 0 - 31 = lanes 32 - 63 of t
-                    const auto sy = __builtin_amdgcn_permlane32_swap(t.y, t.y, false, false);
-                    hh[1].x = (unsigned)sx[1];
-                    hh[1].y = (unsigned)sy[1];
-                }
-            }
+        for (int j = 0; j < 8; ++j) part[j] = quant_chunk(hs0[8 * b + j], j, lane);
+        if constexpr (PAIR) {
 #pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                const int c = lane + 64 * i;
-                if (c < NCH) {
-                    float nv[4];
-                    unpack4(hh[i], nv);
-                    int qi[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float qf = rintf(nv[e] * inv_qstep);
-                        qf = fminf(fmaxf(qf, -127.0f), 127.0f);
-                        const float res = __builtin_fmaf(-qstep, qf, nv[e]);
-                        e2 = __builtin_fmaf(res, res, e2);
-                        qi[e] = (int)qf;
-                    }
-                    const unsigned packed = __builtin_amdgcn_perm((unsigned)qi[1], (unsigned)qi[0], 0x0c0c0400u) |
-                                            __builtin_amdgcn_perm((unsigned)qi[3], (unsigned)qi[2], 0x04000c0cu);
-                    *reinterpret_cast<unsigned*>(my8 + j * RS8 + 4 * c) = packed;
-                    if (c < 8 * nconv) {   // quarter k of (row, block): 8 halves = chunks 2 k, 2 k + 1 of the block
-                        const int blk = c >> 3, k = (c & 7) >> 1, sub = c & 1;
-                        *reinterpret_cast<uint2*>(my16 + ((size_t)(k * nitems + j * nconv + blk) * 16 + sub * 8)) = hh[i];
-                    }
-                }
+            for (int jp = 0; jp < 4; ++jp) {
+                const float e2 = quant_chunk(hs1[4 * b + jp], 2 * jp + (lane >> 5), 64 + (lane & 31));
+                // (the residual's sum has no prescribed order: the odd row's share stays in the upper lanes)
+                part[2 * jp] = part[2 * jp] + (lo ? e2 : 0.0f);
+                part[2 * jp + 1] = part[2 * jp + 1] + (lo ? 0.0f : e2);
             }
-            part[j] = e2;
         }
         {
             // E = |h - s q|_2 (measured, rounded up) + |v - h|_2 (bounded: PREP_F16_ROUNDING)
@@ -1074,6 +1091,7 @@ __global__ __launch_bounds__(256, 2) void prep_once_kernel(const float* __restri
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // int8: unit column u of the batch's 8 rows = 128 consecutive bytes of the tile
+#ifndef VFM_POABL_NOST8
 #pragma unroll
         for (int rd = 0; rd < (NU * 8 + 63) / 64; ++rd) {
             const int e = rd * 64 + lane, u = e >> 3, j = e & 7;
@@ -1093,6 +1111,7 @@ __global__ __launch_bounds__(256, 2) void prep_once_kernel(const float* __restri
                 }
             }
         }
+#endif
         if (o.rows8) {   // row-major copy (scan-sized operands): the batch's rows as they lie in the slice
 #pragma unroll
             for (int rd = 0; rd < (NU * 8 + 63) / 64; ++rd) {
@@ -1102,6 +1121,7 @@ __global__ __launch_bounds__(256, 2) void prep_once_kernel(const float* __restri
             }
         }
         // fp6: lane = (row j, block) of the batch -- prep_chunk_kernel's conversion
+#ifndef VFM_POABL_NOMX6
 #pragma unroll
         for (int item0 = 0; item0 < nitems; item0 += 64) {
             const int item = item0 + lane;
@@ -1144,20 +1164,21 @@ __global__ __launch_bounds__(256, 2) void prep_once_kernel(const float* __restri
             l_sc[wave * 32 + p][blk] = (unsigned char)(ex + 127);
             l_e6[blk][wave * 32 + p] = e6;
         }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();   // (the batch's slices of the LDS are read: the next batch may overwrite them)
     }
     __syncthreads();
     {   // the d / 64 scales of MFMA lane (hh, p) of tile t: its 8 bytes of the scale plane
         const int r = threadIdx.x & (I8_GROUP - 1), hh = threadIdx.x >> 7;
-        unsigned lo = 0u, hi = 0u;
+        unsigned lo4 = 0u, hi4 = 0u;
         for (int s6 = 0; s6 < (nconv >> 1); ++s6) {
             const unsigned bsc = l_sc[r][2 * s6 + hh];
-            if (s6 < 4) lo |= bsc << (8 * s6);
-            else hi |= bsc << (8 * (s6 - 4));
+            if (s6 < 4) lo4 |= bsc << (8 * s6);
+            else hi4 |= bsc << (8 * (s6 - 4));
         }
         unsigned char* t6 = reinterpret_cast<unsigned char*>(o.tiles6) + ((size_t)grp * 4 + (r >> 5)) * (size_t)tb6;
-        *reinterpret_cast<uint2*>(t6 + mx6_scale_at(D >> 6, 0, hh * 32 + (r & 31))) = make_uint2(lo, hi);
+        *reinterpret_cast<uint2*>(t6 + mx6_scale_at(D >> 6, 0, hh * 32 + (r & 31))) = make_uint2(lo4, hi4);
     }
     if (threadIdx.x < I8_GROUP) {   // E of the fp6 image per row: blocks in order; rounded up like the int8 one
         const int r = threadIdx.x;
