@@ -335,6 +335,36 @@ def extra_configs(dev):
 
         api, poses = time_api(voxel_map, raw_scan)
         api["pose_err_vs_planted"] = float(np.linalg.norm(poses[1] - pp["T_gt"]))
+        # the same call the two other ways -- (cold) the DEFAULT node, cache_map=False: the map rebuilt from the array in
+        # every call as registration_node.py:402-403 does (upload of the 200000 x 387 rows, voxel cap, container replay, cast, search
+        # operand), and (handle) RegistrationNode.set_map(): the scene's map built once, explicitly, no fingerprint
+        try:
+            def med(fn, reps):
+                ts = []
+                for _ in range(reps):
+                    torch.cuda.synchronize()
+                    t0 = _time.perf_counter()
+                    r = fn()
+                    torch.cuda.synchronize()
+                    ts.append(1e3 * (_time.perf_counter() - t0))
+                return sorted(ts)[len(ts) // 2], r
+            cold_node = RegistrationNode()
+            cold_node.ransac_registration(voxel_map, raw_scan, "vfm")
+            api["ms_cold"], pc = med(lambda: cold_node.ransac_registration(voxel_map, raw_scan, "vfm"), 5)
+            hnode = RegistrationNode()
+            t0 = _time.perf_counter()
+            handle = hnode.set_map(voxel_map)
+            torch.cuda.synchronize()
+            api["ms_set_map"] = 1e3 * (_time.perf_counter() - t0)
+            for _ in range(2):
+                hnode.ransac_registration(handle, raw_scan, "vfm")
+            api["ms_warm_handle"], ph = med(lambda: hnode.ransac_registration(handle, raw_scan, "vfm"), 15)
+            api["cold_and_handle_poses_equal_the_warm_pose"] = bool(np.array_equal(pc[0], poses[0]) and np.array_equal(ph[0], poses[0]))
+            api["note"] = ("ms_without_icp / ms_with_icp: cache_map=True (opt-in: the map kept while the caller passes the same array); ms_cold: the default "
+                           "node, the reference's behaviour (RN:402-403: map rebuilt per call); ms_warm_handle: set_map() once (ms_set_map), then the handle")
+            del cold_node, hnode, handle
+        except Exception as e:
+            api["cold_error"] = f"{type(e).__name__}: {e}"
         out["API_ransac_registration"] = dict(api, workload="RegistrationNode.ransac_registration(voxel_map, raw_scan, 'vfm'): numpy in / numpy out, "
                                               f"{N_SCAN}-row scan, {N_MAP}-row map x 387 columns fp32, three chained voxelisations (one kernel launch each), "
                                               "descriptor search, 50000-iteration RANSAC; the scene's map kept between scans (warm)")

@@ -455,6 +455,47 @@ def test_ransac_registration_keeps_the_scene_map_between_scans(orc):
     assert node._map_cache[2] is not built3
 
 
+def test_set_map_handle_is_the_explicit_form_of_the_kept_map(orc):
+    """RegistrationNode.set_map(voxel_map) -> MapHandle: the scene's map built once and passed in place of the array
+    (RN:556-589 builds local_map once per scene).  Every method that takes ``voxel_map`` takes the handle; the answers are the cold
+    call's and the oracle's bit for bit; the array may be edited or dropped afterwards (the handle owns device copies); a handle is
+    independent of cache_map and of other handles."""
+    from vfmreg import o3d
+    from vfmreg.mapping import VoxelHashMap
+    from vfmreg.registration import MapHandle, RegistrationNode
+    VoxelHashMap.quiet = True
+    voxel_map, raw_scan, p = _scene(n_scan=5000, n_map=24000, seed=33)
+    voxel_map_b, raw_scan_b, _ = _scene(n_scan=5000, n_map=24000, seed=34)
+    node = RegistrationNode(ransac_iterations=3000)
+    o3d.utility.random.seed(42)
+    cold = node.ransac_registration(voxel_map, raw_scan, "vfm", run_icp=True)
+    h = node.set_map(voxel_map)
+    hb = node.set_map(voxel_map_b)
+    assert isinstance(h, MapHandle) and (h.rows, h.cols) == voxel_map.shape and node._map_cache is None
+    keep = voxel_map.copy()
+    voxel_map[:] = 0.0                                      # the caller's array is no longer needed
+    for _ in range(2):
+        o3d.utility.random.seed(42)
+        warm = node.ransac_registration(h, raw_scan, "vfm", run_icp=True)
+        for a, b in zip(cold, warm):
+            np.testing.assert_array_equal(a, b)
+    ref_pose, ref_icp, _ = orc.ransac_registration_vfm(keep, raw_scan, n_iter=3000, run_icp=True)
+    np.testing.assert_array_equal(warm[0], ref_pose)
+    np.testing.assert_array_equal(warm[1], ref_icp)
+    # the other scene's handle, interleaved: each answers for its own map
+    o3d.utility.random.seed(42)
+    pb = node.ransac_registration(hb, raw_scan_b, "vfm")
+    ref_b, _, _ = orc.ransac_registration_vfm(voxel_map_b, raw_scan_b, n_iter=3000, run_icp=False)
+    np.testing.assert_array_equal(pb[0], ref_b)
+    # compute_vfm_correspondences takes it too
+    s1, t1 = node.compute_vfm_correspondences(h, raw_scan)
+    s2, t2 = RegistrationNode(ransac_iterations=3000).compute_vfm_correspondences(keep, raw_scan)
+    np.testing.assert_array_equal(s1, s2)
+    np.testing.assert_array_equal(t1, t2)
+    with pytest.raises(ValueError):
+        node.set_map(np.zeros((5, 2)))
+
+
 def test_scene_level_descriptor_builder_equals_the_per_cloud_calls(tmp_path):
     """prepare_scenes.main's loop over the clouds of a scene (PS:110-171), with the ViT batched over clouds x cameras: every
     cloud's descriptors are the bits of create_descriptors on that cloud alone, and the scene file read back holds them."""

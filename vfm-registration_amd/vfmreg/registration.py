@@ -74,6 +74,23 @@ def _fingerprint(a: np.ndarray) -> Optional[int]:
     return zlib.crc32(np.ascontiguousarray(flat[::step]).tobytes() + a[0].tobytes() + a[-1].tobytes())
 
 
+class MapHandle:
+    """A scene's map, built once (``RegistrationNode.set_map``): the VoxelHashMap of RN:402-403 with its kept rows in the container's
+    order on the device, cast and prepared for the search.  Pass it wherever a method takes ``voxel_map``: the scene loop of
+    RN:556-589 builds ``local_map`` once and registers every scan of the scene against it -- with a handle nothing is rebuilt and
+    nothing is guessed (no fingerprint of a 600 MB array: the caller says which map it means)."""
+
+    __slots__ = ("voxel_hash_map", "rows", "cols", "dtype")
+
+    def __init__(self, voxel_hash_map, shape, dtype):
+        self.voxel_hash_map = voxel_hash_map
+        self.rows, self.cols = int(shape[0]), int(shape[1])
+        self.dtype = dtype
+
+    def __repr__(self):
+        return f"MapHandle({self.rows} x {self.cols} {self.dtype})"
+
+
 class RegistrationNode:
     """The registration methods of the reference's node, without ROS (RN:44-89).
 
@@ -101,8 +118,23 @@ class RegistrationNode:
         """Forget the kept map (``cache_map=True``): the next call rebuilds it from the array it is handed."""
         self._map_cache = None
 
+    def set_map(self, voxel_map) -> MapHandle:
+        """Build the scene's map ONCE (RN:402-403 + the upload and the search operand) and return a handle to pass in place of the array
+        -- the explicit form of what ``cache_map=True`` infers from a sampled CRC.  The array may be edited or freed
+        afterwards: the handle owns device copies."""
+        vm = np.asarray(voxel_map)
+        if vm.ndim != 2 or vm.shape[1] < 3:
+            raise ValueError("Invalid shape")
+        voxel_hash_map = get_voxel_hash_map(self.config)
+        voxel_hash_map.add_points(vm)
+        if not voxel_hash_map.empty_n():
+            voxel_hash_map._device_map()
+        return MapHandle(voxel_hash_map, vm.shape, vm.dtype.str)
+
     def _hash_map_for(self, voxel_map):
         """The VoxelHashMap of RN:402-403 for this map array -- built, or the one built for the same array before."""
+        if isinstance(voxel_map, MapHandle):
+            return voxel_map.voxel_hash_map
         vm = np.asarray(voxel_map)
         key = None
         if self.cache_map and isinstance(vm, np.ndarray) and vm.ndim == 2:
