@@ -10,8 +10,9 @@
  *     last-error string.  All work is enqueued on `stream` (a hipStream_t passed as void*);
  *     nothing synchronises the device unless its comment says so (vfm_voxel_robin), so the
  *     registration path can be chained and captured in a hipGraph.
- *   - nothing declared here has a process-global effect.  The measurement hooks and tuning switches of the test and
- *     bench tooling (vfm_prof_*, vfm_debug_*) are NOT part of the drop-in contract: include/vfmreg_debug.h.
+ *   - nothing declared here has a process-global effect: the only state the library keeps outside the caller's buffers is THREAD-LOCAL
+ *     (the last-error string, the thread's bound vfm_config_t).  The measurement hooks of the test and bench tooling (vfm_prof_*,
+ *     vfm_debug_*: read-backs that synchronise the device) are NOT part of the drop-in contract: include/vfmreg_debug.h.
  *   - return 0 on success, a negative VFM_E* code otherwise; vfm_last_error() describes it.
  *
  * Reference interfaces replaced (paths relative to /root/reference):
@@ -41,6 +42,48 @@ typedef void *vfm_stream_t; /* hipStream_t */
 const char *vfm_last_error(void);
 /* "gfx950" build id + version, for the loader's sanity check */
 const char *vfm_build_info(void);
+
+/* ------------------------------------------------------------------ kernel policy (round 6)
+ * Which kernel variant / launch shape an entry point takes is a property of a CALLER-OWNED object, not of the process (SURVEY.md 8 B.5:
+ * no global state except the last-error string).  A vfm_config_t starts with the factory settings -- what every call uses when nothing
+ * is bound --; vfm_config_use() binds it to the CALLING THREAD (thread-local, like vfm_last_error's string; NULL unbinds) and every
+ * entry point called from that thread afterwards reads its policy from it at call time.  Two pipelines with different settings are two
+ * configs on two threads -- or one thread that binds the one it is about to call for.  The object must outlive its binding.
+ * Every setting gives the same RESULTS (tests run the stress inputs through them); only kernels, launch shapes and times change.
+ * A product integration never needs one.  Keys of vfm_config_set (value ranges as listed; unknown key: VFM_EINVAL):
+ *   "coarse_slices"      map slices of the coarse pass (0 = the launchers' rules)
+ *   "coarse_variant"     a code: 0 defaults; 1 / 2 = 8 waves x 32 / 4 waves x 64 resident queries; 4 = pipelined kernel with dense fp16
+ *                        records; 5 = the fp16 pass in the gated family too; 7 = 5 without seed units; 12 / 10 = int8 kernel with 32 resident
+ *                        queries per wave (10: two tiles per step); 20 = general selection kernel on best-score records; 21 = no chunk-major
+ *                        rescan; 30 / 31 = fused fp6 half-width kernel with one (default) / two chunks per barrier; 32 / 33 = ... with two /
+ *                        three (default) 32-query tiles per wave at d = 384; 40 / 41 / 42 / 43 = fp6 operand preparation by prep_chunk_kernel
+ *                        (a 128-row group in registers) / prep_stream_kernel (rows read twice) / by width / prep_once_kernel (default since
+ *                        round 6: one read, a tile's fp16 copy in registers); 50 / 51 = chunk-major rescan as long-lived (default) / short
+ *                        workgroups; 60 / 61 = the rescan gathers its queries from the int8 fragment tiles / the row-major int8 scan (default)
+ *   "match_stats"        1: the searches collect the counters vfm_debug_match_stats reads (they cost same-address atomics)
+ *   "i8_min_queries"     the gated family takes the int8 pass for more than this many query rows (default 0: always)
+ *   "prep_grid"          workgroups of prep_chunk_kernel: -1 (default) one per 128-row group, 0 one per compute unit, n > 0
+ *   "ransac_exact_only"  1: RANSAC scores every hypothesis in fp64 (no bounds)
+ *   "voxel_small"        a code: 0 / 1 = VoxelDownsample-shaped calls by the general multi-launch path / the one-launch kernel (default);
+ *                        2 / 3 = round 4's / round 5's (default) per-cluster replay; 10 + k = k points per thread of the one-launch kernel
+ *                        (10 = by size); 100 / 101 = its phase stamps off / on (vfm_debug_voxel_trace)
+ *   "vit_gemm"           value = (narrow << 32) | (uint32) wide: narrow > 0: ViT GEMM wave tile / prefetch depth NT * 100 + PF for N <= 512
+ *                        (narrow) and N > 512 (wide); narrow = -3 / -4 XCD-consistent tile mapping on (default) / off; -5 the LDS-tiled GEMM
+ *                        from `wide` workgroups on (default 256, 0 never); -6 its stage shape, k-steps x 10 + stages (23); -7 attention with
+ *                        K / V^T through the LDS from `wide` images on (1; 0 never); -8 waves per workgroup of the direct kernel; -9 the
+ *                        token-stationary QKV / fc1 kernel from `wide` groups of 128 rows on (0 default rule, -1 never); -10 its waves per
+ *                        workgroup; -11 / -12 low / high half of a device pointer to its placement trace (tools); -14 preprocessing by one
+ *                        workgroup per patch (1, default) / round 1's kernel (0); -15 two (default) / one channel tile per wave; -16 timing
+ *                        experiment, WRONG RESULTS; -17 residual GEMMs of the LDS-tiled path as 128 x 384 tiles (1) / 128 x 128 (0, default)
+ *   and the single fields behind the codes: "coarse_qsets", "seed_units", "select_variant", "mx6_t4", "mx6_ns3", "prep_form" (0 .. 3),
+ *   "finish_short", "rescan_rows", "vit_*", "voxel_replay2", "voxel_one_launch", "voxel_trace", "voxel_grid_ppt" (vfm_config_get reads these;
+ *   cfg == NULL there: what the calling thread's entry points would read now). */
+typedef struct vfm_config vfm_config_t;
+int vfm_config_create(vfm_config_t **out);
+int vfm_config_destroy(vfm_config_t *cfg);
+int vfm_config_set(vfm_config_t *cfg, const char *key, int64_t value);
+int vfm_config_get(const vfm_config_t *cfg, const char *key, int64_t *value);
+int vfm_config_use(const vfm_config_t *cfg);
 
 /* ------------------------------------------------------------------ matching (row A5) */
 

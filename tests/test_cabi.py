@@ -49,6 +49,10 @@ def test_contract_header_declares_nothing_with_process_global_effect(built):
                          capture_output=True, text=True, check=True).stdout
     exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("vfm_")}
     assert exported == set(contract) | set(debug), sorted(exported ^ (set(contract) | set(debug)))
+    # round 6: no exported function writes a process-global switch -- kernel policy is a caller-owned vfm_config_t
+    # bound per thread (vfm_config_* in the contract header); what is left under vfm_debug_* reads back and synchronises
+    assert not [n for n in exported if n.startswith("vfm_debug_set_")]
+    assert {"vfm_config_create", "vfm_config_destroy", "vfm_config_set", "vfm_config_get", "vfm_config_use"} <= set(contract)
     # the product's Python side reads no tuning switch from the environment (the launcher's RANK / WORLD_SIZE / MASTER_* in
     # vfmreg/dist.py are the torch.distributed contract, not switches)
     for py in (ROOT / "vfm-registration_amd" / "vfmreg").glob("*.py"):

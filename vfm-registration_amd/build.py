@@ -23,7 +23,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the fp64 / fp32 parity kernels must not fuse a*b+c
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
-SOURCES = ["error.cpp", "match_api.hip", "match_prep.hip", "match_coarse_f16.hip", "match_coarse_i8.hip", "match_coarse_mx6.hip", "match_finish.hip",
+SOURCES = ["error.cpp", "config.cpp", "match_api.hip", "match_prep.hip", "match_coarse_f16.hip", "match_coarse_i8.hip", "match_coarse_mx6.hip", "match_finish.hip",
            "match_l2.hip", "ransac.hip", "project.hip", "vit.hip", "icp.hip", "voxel.hip"]
 
 

@@ -6,6 +6,7 @@
 #include <stdio.h>
 
 #include "../../include/vfmreg.h"
+#include "config.h"
 
 #define VFM_EXPORT extern "C" __attribute__((visibility("default")))
 

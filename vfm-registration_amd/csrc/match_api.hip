@@ -5,10 +5,9 @@
 
 namespace vfmm {
 
-int g_force_slices = 0;  // experiment knob (vfm_debug_set_coarse_slices): 0 = heuristic below
 
 int choose_slices(int nqb, int nchunks) {
-    if (g_force_slices > 0) return g_force_slices < nchunks ? g_force_slices : nchunks;
+    if (vfm_cfg().force_slices > 0) return vfm_cfg().force_slices < nchunks ? vfm_cfg().force_slices : nchunks;
     // Fill 256 CUs with whole "rounds" of workgroups (tail efficiency).  Every (query block, slice) unit re-reads its 256
     // queries (196 KB), so HBM / Infinity-Cache traffic grows with the slice count (C2: 55 slices 1.45 GB per launch).
     // Round 2 sweep at C2 with the seeded sparse kernel (registrations/s in the pipeline): 14-16 slices 349, 21: 367,
@@ -44,15 +43,6 @@ thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 
 // 0 = default (pipelined kernel for d <= 384); 1 = match_coarse_kernel<.,1>; 2 = match_coarse_kernel<.,2>;
 // set through vfm_debug_set_coarse_variant for A/B runs
-int g_coarse_qsets = 0;
-int g_seed_units = 1;   // vfm_debug_set_coarse_variant(7): no seed units (A/B)
-int g_select_variant = 0;  // vfm_debug_set_coarse_variant(20 / 21): general select kernel / no chunk-major rescan (A/B)
-int g_mx6_t4 = 1;
-int g_mx6_ns3 = 1;   // vfm_debug_set_coarse_variant(32 / 33): the fused fp6 half-width kernel at d = 384 with two / three (default since round 5) query tiles per wave
-int g_prep_stream = 3;   // 3: prep_once_kernel (default since round 6), 1: prep_stream_kernel, 0: prep_chunk_kernel, 2: by width (d = 384: prep_chunk_kernel) -- see match_prep.hip
-int g_finish_short = 0;
-int g_rescan_rows = 1;
-int g_match_stats = 0;  // vfm_debug_set_match_stats: per-query counters cost ~0.5 ms of same-address atomics per search
 // 4 = pipelined kernel with the DENSE per-chunk records + match_select_kernel (round-1 path; A/B reference)
 
 // inner-product searches with d <= 384 use the sparse row-level records of match_coarse_pipe_kernel<., true>
@@ -60,21 +50,20 @@ int g_match_stats = 0;  // vfm_debug_set_match_stats: per-query counters cost ~0
 // measured faster -- 244 vs 282 us per registration at 300 x 50000)
 bool use_sparse(int d, int64_t n, int64_t m) {
     return d <= 384 && d % 128 == 0 && m < (1ll << 24) && n > 2 * QBLOCK &&
-           (g_coarse_qsets == 0 || g_coarse_qsets == 3 || g_coarse_qsets == 5);
+           (vfm_cfg().coarse_qsets == 0 || vfm_cfg().coarse_qsets == 3 || vfm_cfg().coarse_qsets == 5);
 }
 
 // ... and before those, in the GATED family of entry points (callers that keep only matches above a similarity gate), for
 // d = 256 / 384: the int8 coarse pass with one best-score record per (query, chunk).  Its exact re-decision costs an int8
 // rescan per candidate chunk, cheap when most unmatched queries stop at the gate and slower than the fp16 pass when every
 // query must be resolved -- so the ungated entry points keep the fp16 pass.  (variant 5 = fp16 pass everywhere, A/B)
-int g_i8_min_queries = 0;  // vfm_debug_set_i8_min_queries (A/B knob): the int8 pass wins at every size measured (300 x 50 000: 209 vs 244 us)
 // Ungated calls (every query resolved) take the int8 pass, with packed top-2 records, from 8192 queries x 1e9 pairs on
 // (tools/time_ungated.py, coarse + finish: 20 000 x 200 000 x 384 1.98 vs 2.69 ms, 20 000 x 50 000 x 256 0.55 vs 0.65,
 // 50 000 x 1 000 000 x 768 41.8 vs 74.2; below that the fp16 pass wins: 2000 x 200 000 0.39 vs 0.45, 300 x 50 000 0.15 vs 0.22).
 bool use_i8(int d, int64_t n, int64_t m, bool gated) {
     const bool large = n >= 8192 && n * m >= 1000000000ll;
-    return (gated || large) && i8_capable(d) && m < (1ll << 24) && n > g_i8_min_queries &&
-           (g_coarse_qsets == 0 || g_coarse_qsets == 10 || g_coarse_qsets == 12);
+    return (gated || large) && i8_capable(d) && m < (1ll << 24) && n > vfm_cfg().i8_min_queries &&
+           (vfm_cfg().coarse_qsets == 0 || vfm_cfg().coarse_qsets == 10 || vfm_cfg().coarse_qsets == 12);
 }
 
 // queries per workgroup of the coarse kernel that do_search_coarse will launch
@@ -123,7 +112,7 @@ int do_search_coarse(const void* qprep, int64_t n, const void* bprep, int64_t m,
         a.rec_cnt = w.rec_cnt;
         a.rec = w.rec;
         a.rcap = w.rcap;
-        if (g_seed_units && a.nchunks >= 256 && a.nqb <= 256) {  // seed units: one short round at the head of the grid
+        if (vfm_cfg().seed_units && a.nchunks >= 256 && a.nqb <= 256) {  // seed units: one short round at the head of the grid
             a.seed_parts = 256 / a.nqb < 4 ? 256 / a.nqb : 4;
             a.seed_chunks = 5;
             a.nseed_pad = (a.nqb * a.seed_parts + 7) / 8 * 8;
@@ -488,50 +477,9 @@ VFM_EXPORT int vfm_debug_mx6_half_err(const void* prepared, int64_t rows, int d,
     return VFM_OK;
 }
 
-VFM_EXPORT int vfm_debug_set_i8_min_queries(int n) {
-    g_i8_min_queries = n;
-    return VFM_OK;
-}
 
 
-VFM_EXPORT int vfm_debug_set_match_stats(int on) {
-    g_match_stats = on;
-    return VFM_OK;
-}
 
-VFM_EXPORT int vfm_debug_set_coarse_slices(int slices) {
-    g_force_slices = slices;
-    return VFM_OK;
-}
-VFM_EXPORT int vfm_debug_set_coarse_variant(int qsets) {
-    if (qsets == 60 || qsets == 61) {   // chunk-major rescan: queries gathered from the int8 fragment tiles (60) / the row-major int8 scan (61, default)
-        g_rescan_rows = qsets == 61 ? 1 : 0;
-        return VFM_OK;
-    }
-    if (qsets == 50 || qsets == 51) {   // finish stage: 50 = long-lived workgroups (rescan: a bin per workgroup; refinement: 1024 workgroups walk the list; the default), 51 = short ones
-        g_finish_short = qsets == 51 ? 1 : 0;
-        return VFM_OK;
-    }
-    if (qsets >= 40 && qsets <= 43) {   // fp6 operand preparation: 40 = prep_chunk_kernel (rows in registers), 41 = prep_stream_kernel, 42 = by width, 43 = prep_once_kernel (round 6: one read, a tile's fp16 copy in registers)
-        g_prep_stream = qsets == 43 ? 3 : qsets == 42 ? 2 : qsets == 41 ? 1 : 0;
-        return VFM_OK;
-    }
-    if (qsets == 32 || qsets == 33) {   // the fused fp6 half-width kernel at d = 384: 32 = two 32-query tiles per wave, 33 = three (round 5)
-        g_mx6_ns3 = qsets == 33 ? 1 : 0;
-        return VFM_OK;
-    }
-    if (qsets == 30 || qsets == 31) {   // the fused fp6 half-width kernel: 30 = one chunk per barrier (the default), 31 = two (A/B)
-        g_mx6_t4 = qsets == 30 ? 1 : 0;
-        return VFM_OK;
-    }
-    g_seed_units = qsets == 7 ? 0 : 1;
-    if (qsets == 7) qsets = 0;
-    // 20: the general select kernel on best-score records too, 21: best-score select kernel, query-major rescan only (A/B)
-    g_select_variant = qsets == 20 ? 1 : (qsets == 21 ? 2 : 0);
-    if (qsets == 20 || qsets == 21) qsets = 0;
-    g_coarse_qsets = qsets;
-    return VFM_OK;
-}
 
 VFM_EXPORT int vfm_prof_events_create(void** start, void** stop) {
     VFM_CHECK_ARG(start && stop, "prof: null pointer");

@@ -634,8 +634,8 @@ int launch_coarse(const CoarseArgs& a, hipStream_t st) {
     if (g_prof_start) VFM_CHECK_HIP(hipEventRecord(g_prof_start, st));
     int rc;
     if constexpr (KSTEPS <= 24) {
-        rc = (g_coarse_qsets == 2)   ? launch_coarse_v<KSTEPS, 2>(a, st)
-             : (g_coarse_qsets == 1) ? launch_coarse_v<KSTEPS, 1>(a, st)
+        rc = (vfm_cfg().coarse_qsets == 2)   ? launch_coarse_v<KSTEPS, 2>(a, st)
+             : (vfm_cfg().coarse_qsets == 1) ? launch_coarse_v<KSTEPS, 1>(a, st)
                                      : (a.rec ? launch_coarse_pipe<KSTEPS, true>(a, st) : launch_coarse_pipe<KSTEPS, false>(a, st));  // 0, 3
     } else {
         rc = launch_coarse_v<KSTEPS, 1>(a, st);  // d = 512: 2 x 128 query VGPRs would not fit

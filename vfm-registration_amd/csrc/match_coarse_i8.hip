@@ -399,7 +399,7 @@ int launch_coarse_int8(CoarseArgs& a, int d, int64_t n, int records, hipStream_t
         rc8 = d == 384 ? launch_coarse_i8q2<6, false, false, true>(a, st) : launch_coarse_i8q2<4, false, false, true>(a, st);
     } else if (records == VFM_RECORDS_HALF) {
         // the half-width pass: the same kernels on the image of the first d / 2 columns (a.Qh / a.Bh = tiles8h), best-score records
-        if (n > 2048 && g_coarse_qsets == 0) {   // 64 resident queries per wave at every width: d / 2 columns are at most 384
+        if (n > 2048 && vfm_cfg().coarse_qsets == 0) {   // 64 resident queries per wave at every width: d / 2 columns are at most 384
             a.nqb = (a.nq_tiles + 15) / 16;
             a.nslices = choose_slices(a.nqb, a.nchunks);
             switch (d / 64) {
@@ -418,7 +418,7 @@ int launch_coarse_int8(CoarseArgs& a, int d, int64_t n, int records, hipStream_t
                 default: rc8 = launch_coarse_i8<12, 4, false, false>(a, st); break;
             }
         }
-    } else if (d <= 384 && n > 2048 && g_coarse_qsets == 0) {
+    } else if (d <= 384 && n > 2048 && vfm_cfg().coarse_qsets == 0) {
         // 64 resident queries per wave: 11-15 % faster than the one-set kernel from ~3000 queries on (C2: 1.09 vs 1.23 ms;
         // 1500 x 100 000: 0.059 vs 0.056 ms -- half as many, twice as large workgroups); variants 10 / 12 = one set, A/B
         a.nqb = (a.nq_tiles + 15) / 16;
@@ -426,7 +426,7 @@ int launch_coarse_int8(CoarseArgs& a, int d, int64_t n, int records, hipStream_t
         rc8 = d == 384 ? (top2 ? launch_coarse_i8q2<12, true>(a, st) : launch_coarse_i8q2<12, false>(a, st))
                        : (top2 ? launch_coarse_i8q2<8, true>(a, st) : launch_coarse_i8q2<8, false>(a, st));
     } else {
-        const bool t2 = g_coarse_qsets == 10;  // variant 10 (A/B): 2 tiles per step at every width
+        const bool t2 = vfm_cfg().coarse_qsets == 10;  // variant 10 (A/B): 2 tiles per step at every width
         switch (d / 32) {
             case 8: rc8 = top2 ? launch_coarse_i8<8, 4, true>(a, st) : t2 ? launch_coarse_i8<8, 2>(a, st) : launch_coarse_i8<8, 4>(a, st); break;
             case 12: rc8 = top2 ? launch_coarse_i8<12, 4, true>(a, st) : t2 ? launch_coarse_i8<12, 2>(a, st) : launch_coarse_i8<12, 4>(a, st); break;

@@ -549,10 +549,10 @@ int mx6_survivor_slot_words() { return MX6_SURV_SLOT_WORDS; }
 // the fp6 coarse kernel for the arguments do_search_coarse prepared (a.Qh / a.Bh = the fp6 tiles, a.ib = mx6_bounds);
 // d = 256 / 384 (full width) or 256 / 384 / 512 / 768 (half width) and more than 2048 queries (effective_records)
 int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, bool half, bool fuse, hipStream_t st) {
-    const bool ns3 = half && fuse && d == 384 && g_mx6_ns3 && g_mx6_t4;
+    const bool ns3 = half && fuse && d == 384 && vfm_cfg().mx6_ns3 && vfm_cfg().mx6_t4;
     a.nqb = ns3 ? (a.nq_tiles + 23) / 24 : (a.nq_tiles + 15) / 16;
     a.nslices = choose_slices(a.nqb, a.nchunks);
-    if (half && g_force_slices == 0) {
+    if (half && vfm_cfg().force_slices == 0) {
         // the half-width kernel's workgroups are short, and shorter ones let the other stages of a pipeline in: ~7.5 rounds of 256
         // workgroups instead of choose_slices' 5 (tools/sweep_slices.py, C2, 200 steps: 48 slices 1548 against 32 slices 1475
         // registrations/s; the full-width fp6 kernel and the int8 kernels are flat from 32 on)
@@ -602,7 +602,7 @@ int launch_coarse_mx6(CoarseArgs& a, int d, bool top2, bool half, bool fuse, hip
     // against 0.419 alone, 1715 against 1725 registrations/s in the pipeline (tools/ab_r4.py) -- the barrier share the ablations
     // show (tools/ablate6.py: -10 % without barrier and staging) does not come back by halving the barriers, and the larger ring
     // leaves the side kernels less LDS.  One chunk per barrier stays the default; vfm_debug_set_coarse_variant(31) selects T = 8.
-    const bool t8 = half && fuse && (d == 384 || d == 256) && !g_mx6_t4 && a.nslices <= a.nchunks / 2;
+    const bool t8 = half && fuse && (d == 384 || d == 256) && !vfm_cfg().mx6_t4 && a.nslices <= a.nchunks / 2;
     if (ns3)   // three query tiles per wave: 768 queries per workgroup (nqb set above)
         rc = launch_mx6q2<3, MX6_FUSE, false, 6, 4, 4, 3>(a, st);
     else if (fuse && !half)   // VFM_RECORDS_MX6_FUSED: the full-width pass with the gate test in its epilogue

@@ -916,11 +916,11 @@ int launch_rescan_chunk_ks(const SearchWs& w, int nchunks, int64_t n, int64_t m,
     // Short workgroups: a workgroup that walks a whole bin (~600 queries on lifted descriptors) lives ~80 us on 160 registers x 4 waves
     // and 61 KB, and while a grid of those is resident nothing as register-heavy as a ViT GEMM wave (156 - 416 registers) is placed
     // beside it -- in C3 as a pipeline the feature stage of the next pair stood still behind this kernel (tools/trace_c3_pipe.sh).
-    const int slice = g_finish_short ? 128 : RESCAN_SLICE;
+    const int slice = vfm_cfg().finish_short ? 128 : RESCAN_SLICE;
     hipLaunchKernelGGL(match_rescan_chunk_kernel<KS>, dim3((unsigned)nchunks, (unsigned)((w.bin_cap + slice - 1) / slice)),
                        dim3(256), lds, st, n, m, ib, (const uint4*)Q.tiles8, (const uint4*)B.tiles8, (const unsigned*)w.qmax, w.cand_cnt,
                        w.cand, w.cap, (const unsigned*)w.bin_cnt, (const int*)w.bins, use_gate, gate, guard, l2, w.bin_cap, w.hit_cnt, w.cand_up,
-                       slice, g_rescan_rows ? (const unsigned char*)Q.rows8 : (const unsigned char*)nullptr, pilot ? w.qmax : (unsigned*)nullptr);
+                       slice, vfm_cfg().rescan_rows ? (const unsigned char*)Q.rows8 : (const unsigned char*)nullptr, pilot ? w.qmax : (unsigned*)nullptr);
     VFM_CHECK_LAUNCH("match_rescan_chunk_kernel");
     return VFM_OK;
 }
@@ -1977,7 +1977,7 @@ int do_search_finish(Rows q, const void* qprep, int64_t n, Rows b, const void* b
     if (half && !(gate > -__builtin_inff())) return vfm_fail(VFM_EINVAL, "search_finish: VFM_RECORDS_HALF needs a finite gate");
     if (!i8 && use_sparse(d, n, m)) {
         hipLaunchKernelGGL(match_filter_refine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d,
-                           DEFAULT_WINDOW, w2, w.qmax, w.rec_cnt, w.rec, w.rcap, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
+                           DEFAULT_WINDOW, w2, w.qmax, w.rec_cnt, w.rec, w.rcap, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, vfm_cfg().match_stats);
         VFM_CHECK_LAUNCH("match_filter_refine_kernel");
     } else {
         const int chunk_lds = i8 && (size_t)a.nchunks * sizeof(float2) <= 63 * 1024;  // (step, max E) of every chunk in LDS
@@ -1989,8 +1989,8 @@ int do_search_finish(Rows q, const void* qprep, int64_t n, Rows b, const void* b
         const bool mx6 = i8 && (records == VFM_RECORDS_MX6 || records == VFM_RECORDS_MX6_TOP2);
         const bool top2 = i8 && (records == VFM_RECORDS_TOP2 || records == VFM_RECORDS_MX6_TOP2);
         if (mx6) records = top2 ? VFM_RECORDS_TOP2 : VFM_RECORDS_BEST;
-        const bool best = i8 && records == VFM_RECORDS_BEST && g_select_variant != 1;
-        use_bins = (best || half) && g_select_variant != 2 && n >= 4 * (int64_t)a.nchunks;
+        const bool best = i8 && records == VFM_RECORDS_BEST && vfm_cfg().select_variant != 1;
+        use_bins = (best || half) && vfm_cfg().select_variant != 2 && n >= 4 * (int64_t)a.nchunks;
         if (pilot && use_bins) {
             // the pilot rescan: one chunk per query, scored exactly on the int8 image, raises qmax (match_rescan_chunk_kernel, pilot
             // branch); the bins it used are emptied again for the selection
@@ -2012,13 +2012,13 @@ int do_search_finish(Rows q, const void* qprep, int64_t n, Rows b, const void* b
             hipLaunchKernelGGL(match_select_half_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * 8), half_lds ? (size_t)a.nchunks * 12 : 0,
                                st, reinterpret_cast<const unsigned*>(w.partials), a.nchunks, n, Q.inv,
                                mx6half ? mx6_bounds_half(Q, B) : i8_bounds(Q, B, true, records), (const float*)Q.rest, (const float*)B.grest, gate, half_lds, w.cand_cnt, w.cand, w.cap, w.fb_count,
-                               w.fb_list, g_match_stats, use_bins ? w.bin_cnt : (unsigned*)nullptr, use_bins ? w.bins : (int*)nullptr,
+                               w.fb_list, vfm_cfg().match_stats, use_bins ? w.bin_cnt : (unsigned*)nullptr, use_bins ? w.bins : (int*)nullptr,
                                w.bin_cap);
-        } else if (top2 && g_select_variant != 1) {
+        } else if (top2 && vfm_cfg().select_variant != 1) {
             hipLaunchKernelGGL(match_select_top2_kernel, dim3((unsigned)a.nq_tiles), dim3(64 * SELECT_TOP2_WAVES),
                                chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, (const uint2*)w.partials, a.nchunks, n,
                                a.first_pad_chunk, (const unsigned*)w.qmax, Q.inv, mx6 ? mx6_bounds(Q, B, 1) : i8_bounds(Q, B, true, records), gate, chunk_lds,
-                               w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
+                               w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, vfm_cfg().match_stats);
         } else if (best) {
             // (chunk_lds 2: room for the per-chunk histogram of the tile's candidates as well -- chunks must fit 16 bits of a staged entry)
             const int best_lds = chunk_lds && use_bins && (size_t)a.nchunks * 12 <= 63 * 1024 && a.nchunks < 65536 ? 2 : chunk_lds;
@@ -2026,13 +2026,13 @@ int do_search_finish(Rows q, const void* qprep, int64_t n, Rows b, const void* b
                                best_lds == 2 ? (size_t)a.nchunks * 12 : chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, reinterpret_cast<const unsigned*>(w.partials),
                                a.nchunks, n, (const unsigned*)w.qmax, Q.inv, mx6 ? mx6_bounds(Q, B) : i8_bounds(Q, B, true, records), gate,
                                best_lds, w.cand_cnt,
-                               w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats, use_bins ? w.bin_cnt : (unsigned*)nullptr,
+                               w.cand, w.cap, w.fb_count, w.fb_list, vfm_cfg().match_stats, use_bins ? w.bin_cnt : (unsigned*)nullptr,
                                use_bins ? w.bins : (int*)nullptr, a.first_pad_chunk, w.bin_cap);
         } else
         hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS),
                            chunk_lds ? (size_t)a.nchunks * sizeof(float2) : 0, st, w.partials, a.nchunks, a.npad, n, a.first_pad_chunk, w.qmax,
                            Q.inv, DEFAULT_WINDOW, mx6 ? mx6_bounds(Q, B, top2 ? 1 : 0) : i8_bounds(Q, B, i8, records), gate, chunk_lds, w.cand_cnt, w.cand, w.cap,
-                           w.fb_count, w.fb_list, g_match_stats);
+                           w.fb_count, w.fb_list, vfm_cfg().match_stats);
         VFM_CHECK_LAUNCH("match_select_kernel");
         if (i8) {  // candidate chunks -> candidate rows (the record buffer of the fp16 pass is free: it holds the hit lists)
             const int* guard = half ? w.fb_count + HALF_GUARD_FLAG : (const int*)nullptr;
@@ -2079,7 +2079,7 @@ int do_search_finish(Rows q, const void* qprep, int64_t n, Rows b, const void* b
             const unsigned grid = (unsigned)((n + 3) / 4);
 #define VFM_REFINE(NT)                                                                                                          \
     hipLaunchKernelGGL(match_refine_kernel<NT>, dim3(grid), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2, w.cand_cnt, w.cand, \
-                       w.cap, w.fb_count, w.fb_list, g_match_stats, (const int*)w.rec_cnt, (const int*)(w.fb_count + 6),            \
+                       w.cap, w.fb_count, w.fb_list, vfm_cfg().match_stats, (const int*)w.rec_cnt, (const int*)(w.fb_count + 6),            \
                        use_bins ? (const float*)w.cand_up : (const float*)nullptr, (const unsigned*)w.hit_cnt,                     \
                        i8_bounds(Q, B, true, records))
             if (d <= 256) VFM_REFINE(4);
@@ -2089,7 +2089,7 @@ int do_search_finish(Rows q, const void* qprep, int64_t n, Rows b, const void* b
 #undef VFM_REFINE
         } else {
             hipLaunchKernelGGL(match_refine_kernel<12>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, q, Q.inv, b, B.inv, n, m, d, w2,
-                               w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats, (const int*)nullptr, (const int*)nullptr,
+                               w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, vfm_cfg().match_stats, (const int*)nullptr, (const int*)nullptr,
                                (const float*)nullptr, (const unsigned*)nullptr, I8Bounds{});
         }
         VFM_CHECK_LAUNCH("match_refine_kernel");
@@ -2149,7 +2149,7 @@ int probe_half_select(const void* qprep, int64_t n, const void* bprep, int64_t m
 int launch_select_dense(const SearchWs& w, const CoarseArgs& a, const float* qinv, int64_t n, hipStream_t st) {
     hipLaunchKernelGGL(match_select_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * SELECT_GROUPS), 0, st, w.partials, a.nchunks,
                        a.npad, n, a.first_pad_chunk, w.qmax, qinv, DEFAULT_WINDOW, i8_bounds(Prepared{}, Prepared{}, false),
-                       -__builtin_inff(), 0, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, g_match_stats);
+                       -__builtin_inff(), 0, w.cand_cnt, w.cand, w.cap, w.fb_count, w.fb_list, vfm_cfg().match_stats);
     VFM_CHECK_LAUNCH("match_select_kernel");
     return VFM_OK;
 }

@@ -579,12 +579,6 @@ struct Rows {
 };
 
 // experiment knobs and profiling hook (match_api.hip)
-extern int g_force_slices, g_coarse_qsets, g_seed_units, g_match_stats, g_i8_min_queries, g_select_variant;
-extern int g_rescan_rows;    // vfm_debug_set_coarse_variant(60 / 61): chunk-major rescan gathers its queries from the fragment tiles / from the row-major int8 scan (default)
-extern int g_finish_short;   // vfm_debug_set_coarse_variant(50 / 51): chunk-major rescan as long-lived workgroups (default) / short ones (A/B: no gain in C3 as a pipeline, +10 us of empty workgroups on D.2)
-extern int g_prep_stream;   // vfm_debug_set_coarse_variant(40 / 41 / 42): fp6 operand preparation by prep_chunk_kernel (rows in registers) / prep_stream_kernel / by width (d = 256 the stream form, d = 384 the one-pass form); default 41
-extern int g_mx6_ns3;   // vfm_debug_set_coarse_variant(32 / 33): the fused fp6 half-width kernel at d = 384 with two / three query tiles per wave
-extern int g_mx6_t4;   // vfm_debug_set_coarse_variant(30 / 31): the fused fp6 half-width kernel with one chunk per barrier (default) / two (A/B)
 extern thread_local hipEvent_t g_prof_start, g_prof_stop;  // vfm_prof_arm: events around the next coarse launch of this thread
 
 // which coarse pass / record kind a search takes (match_api.hip)

@@ -1370,7 +1370,6 @@ inline PrepOut prep_out(const Prepared& p, const int* perm = nullptr, int mx6_ha
 // Alone on the GPU the persistent form is the faster one (C2: 81 vs 109 us, 5.2 vs 3.9 TB/s); beside the coarse kernel of the
 // previous registration -- whose workgroups need a whole compute unit each -- the short workgroups interleave better
 // (791 vs 783 registrations/s over 300 steps, same box), and that is where the pipeline runs it.
-int g_prep_grid = -1;
 inline int prep_grid(int groups, int mode) {
     static thread_local int cus = 0;
     if (!cus) {
@@ -1378,7 +1377,7 @@ inline int prep_grid(int groups, int mode) {
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
-    const int knob = mode == VFM_PREPARE_DEFAULT ? g_prep_grid : (mode == VFM_PREPARE_PERSISTENT ? 0 : -1);
+    const int knob = mode == VFM_PREPARE_DEFAULT ? vfm_cfg().prep_grid : (mode == VFM_PREPARE_PERSISTENT ? 0 : -1);
     int g = knob > 0 ? knob : (knob < 0 ? groups : cus);
     return g < groups ? g : groups;
 }
@@ -1427,8 +1426,8 @@ int do_prepare2(Rows x1r, int64_t rows1, void* prepared1, Rows x2r, int64_t rows
             // pipelines on one box: headline + 1.7 %, full width with the fused epilogue + 3.5 %, lifted descriptors + 2.2 %, full width
             // with records - 0.5 %.  In the driver's 20-step form it LOSES 2.9 % (tools/ab_prep_r5_20.py: 1624 against 1672
             // registrations/s): the default stays the stream form; vfm_debug_set_coarse_variant(42) selects by width (d = 384: one pass).
-            const bool stream_form = g_prep_stream == 1 || (g_prep_stream == 2 && d == 256);
-            if (g_prep_stream == 3 && (d == 384 || d == 256) && !any_f16) {   // one read of the rows, the fp16 copy of a tile in registers (prep_once_kernel, round 6)
+            const bool stream_form = vfm_cfg().prep_stream == 1 || (vfm_cfg().prep_stream == 2 && d == 256);
+            if (vfm_cfg().prep_stream == 3 && (d == 384 || d == 256) && !any_f16) {   // one read of the rows, the fp16 copy of a tile in registers (prep_once_kernel, round 6)
                 const dim3 sg((unsigned)groups), sb(256);
                 if (d == 384 && h6) hipLaunchKernelGGL((prep_once_kernel<384, true>), sg, sb, 0, st, x1, rows1, prep_out(p1, nullptr, h6), g1, x2, rows2, prep_out(p2, nullptr, h6), groups);
                 else if (d == 384) hipLaunchKernelGGL((prep_once_kernel<384, false>), sg, sb, 0, st, x1, rows1, prep_out(p1, nullptr, h6), g1, x2, rows2, prep_out(p2, nullptr, h6), groups);
@@ -1523,7 +1522,3 @@ VFM_EXPORT int vfm_l2norm_rows_f32(float* x, int64_t n, int d, float* inv_out, v
     return VFM_OK;
 }
 
-VFM_EXPORT int vfm_debug_set_prep_grid(int workgroups) {
-    g_prep_grid = workgroups;
-    return VFM_OK;
-}

@@ -985,15 +985,9 @@ inline RansacWs carve_ransac(void* p, int64_t c_max, int32_t n_iter) {
     return w;
 }
 
-int g_ransac_exact_only = 0;
 
 }  // namespace
 
-// A/B switch: 1 = score every hypothesis in fp64 (no fp32 coarse pass)
-VFM_EXPORT int vfm_debug_set_ransac_exact_only(int on) {
-    g_ransac_exact_only = on;
-    return VFM_OK;
-}
 
 // tests / bench: what the last vfm_ransac_corr in `ws` did -- out_host[0] = hypotheses scored in the oracle's fp64 arithmetic from the
 // candidate list, [1] = 1 if the list overflowed (then every hypothesis was scored in fp64), [2] = 1 if the point-wise fp32 pass was
@@ -1051,7 +1045,7 @@ int ransac_corr_impl(const double* src, int64_t ns, const double* tgt, int64_t n
                            count_dev, c_max, w.pts, ns, nt, bad_out);
         VFM_CHECK_LAUNCH("ransac_gather_kernel");
     }
-    if (g_ransac_exact_only) {
+    if (vfm_cfg().ransac_exact_only) {
         // reference-order fp64 scoring of every hypothesis (A/B switch, and the semantics the
         // two-level path below must reproduce bit for bit)
         hipLaunchKernelGGL(ransac_score_kernel, dim3(nblocks), dim3(64), 0, st, w.pts, count_dev, c_max, max_d2, n_iter, seed,

@@ -1386,17 +1386,13 @@ inline VitWs carve_vit(void* p, const Dims& d) {
     return w;
 }
 
-int g_vit_preprocess_patch = 1;   // vfm_debug_set_vit_gemm(-14, 0 / 1): the per-thread-unit preprocessing kernel / one workgroup per patch (default; A/B + bit-equality test)
-int g_vit_xcd = 1;        // vfm_debug_set_vit_gemm(-3 / -4, .): XCD-consistent tile mapping on / off (A/B)
-int g_vit_cfg_narrow = 108, g_vit_cfg_wide = 108;  // (NT * 100 + PF) for N <= 512 / N > 512 (vfm_debug_set_vit_gemm)
 
-int g_vit_wpw = 0;   // vfm_debug_set_vit_gemm(-8, n): waves per workgroup of the direct GEMM kernel (0 = the default, one)
 template <int EPI, int NT, int PF>
 int launch_gemm_cfg(const GemmArgs& g, hipStream_t st) {
     const int waves = (g.M / 32) * (g.N / (32 * NT));
     // waves per workgroup: one -- the waves share nothing, and single waves are spread over more compute units (one scan, N = 384: 648 waves
     // were 168 workgroups); tools/ab_vit_wpw.py: 6 / 12 / 24 images 0.62 / 0.865 / 1.444 ms with four waves per workgroup, 0.62 / 0.845 / 1.425 with one
-    const int wpw = g_vit_wpw > 0 ? g_vit_wpw : 1;
+    const int wpw = vfm_cfg().vit_wpw > 0 ? vfm_cfg().vit_wpw : 1;
     // xcd_map: every XCD gets ceil(tiles / 8) token tiles' worth of workgroups
     const int grid = g.xcd_map ? 8 * ceil_div(ceil_div(g.M / 32, 8) * (g.N / (32 * NT)), wpw) : ceil_div(waves, wpw);
     hipLaunchKernelGGL((vit_gemm_kernel<EPI, NT, PF>), dim3(grid), dim3(64 * wpw), 0, st, g);
@@ -1409,21 +1405,12 @@ int launch_gemm_cfg(const GemmArgs& g, hipStream_t st) {
 // ~5 us floor of each of its 87 launches, not by L2 latency or bandwidth: PF = 8 / 16 / 24 make no difference, 32-channel
 // tiles everywhere (twice the waves) give 0.76 instead of 0.82 ms, 64 x 64 wave tiles and row-complete workgroups with the
 // LayerNorm fused into the epilogue (63 launches, but 66 workgroups per GEMM) gave 1.04 ms and were removed again.
-int g_vit_hot_a = 0;
-int g_vit_wide_tile = 0;      // vfm_debug_set_vit_gemm(-17, 0 / 1): the residual GEMMs (N = 384) of the LDS-tiled path as 128 x 128 tiles (default) / as one 128 x 384 tile per workgroup (measured slower: DESIGN.md R5.9)
-int g_vit_lds_shape = 23;     // vfm_debug_set_vit_gemm(-6, KB * 10 + NS): k-steps per stage / stages in the ring of the LDS-tiled kernel (23: 48 KiB, three workgroups per compute unit)
-int g_vit_att_lds_min = 1;   // vfm_debug_set_vit_gemm(-7, n): attention with K / V^T in the LDS from n images per call on (0 = never)
-int g_vit_lds_min_wg = 256;   // vfm_debug_set_vit_gemm(-5, n): the LDS-tiled kernel from n workgroups of 128 x 128 on (0 = never)
-unsigned long long* g_vit_astat_dbg = nullptr;   // vfm_debug_set_vit_gemm(-11, lo) / (-12, hi): device buffer [workgroup][4] = start, end (100 MHz ticks), (xcc << 32 | HW_ID), 0
-int g_vit_astat_min = 0;      // vfm_debug_set_vit_gemm(-9, n): the token-stationary kernel for QKV / fc1 from n groups of 128 token rows on (0 = where its rounds are full: launch_gemm; -1 = never)
-int g_vit_astat_two = 1;      // vfm_debug_set_vit_gemm(-15, 0 / 1): the token-stationary kernel with one / two (default) channel tiles per wave
-int g_vit_astat_nw = 0;       // vfm_debug_set_vit_gemm(-10, n): its waves per workgroup where n divides N / 32 (6, 8, 16; otherwise 12)
 template <int EPI>
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
     if constexpr (EPI == EPI_QKV || EPI == EPI_GELU) {
         const int groups = ceil_div(g.M / 32, 4);
-        const int nw = g_vit_astat_nw == 112 ? 112 : (g_vit_astat_nw > 0 && (g.N / 32) % g_vit_astat_nw == 0 ? g_vit_astat_nw : 12);
-        // One workgroup per compute unit: the kernel pays when its rounds are full.  g_vit_astat_min > 0: from that many groups on whatever
+        const int nw = vfm_cfg().vit_astat_nw == 112 ? 112 : (vfm_cfg().vit_astat_nw > 0 && (g.N / 32) % vfm_cfg().vit_astat_nw == 0 ? vfm_cfg().vit_astat_nw : 12);
+        // One workgroup per compute unit: the kernel pays when its rounds are full.  vfm_cfg().vit_astat_min > 0: from that many groups on whatever
         // the fill (tools); 0 (default): when the last round of `ncu` workgroups is at least three quarters full and there is at least one
         // such round -- 69 ... 93 images of 1200 x 1600 at a time on 256 compute units (tools/ab_vit_astat.py: 48 images 2.19 -> 2.30 ms,
         // 84: 3.35 -> 3.22, 93: 3.60 -> 3.49, 96 = 264 groups, eight of them alone in a second round: 3.95 -> 4.58)
@@ -1436,7 +1423,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         }
         const int last_round = groups % ncu;
         const bool full_rounds = groups >= (3 * ncu) / 4 && (last_round == 0 || 4 * last_round >= 3 * ncu);
-        const bool want = g_vit_astat_min > 0 ? groups >= g_vit_astat_min : (g_vit_astat_min == 0 && full_rounds);
+        const bool want = vfm_cfg().vit_astat_min > 0 ? groups >= vfm_cfg().vit_astat_min : (vfm_cfg().vit_astat_min == 0 && full_rounds);
         if (want && 4 * g.KS * 1024 <= 128 * 1024 && (nw == 112 || (g.N / 32) % nw == 0)) {
 #define VIT_ASTAT(NW)                                                                                                                \
     do {                                                                                                                             \
@@ -1449,10 +1436,10 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
             attr_set |= 1ull << (dev & 63);                                                                                          \
         }                                                                                                                            \
         GemmArgs ga = g;                                                                                                             \
-        ga.dbg = g_vit_astat_dbg;                                                                                                    \
+        ga.dbg = vfm_cfg().vit_astat_dbg;                                                                                                    \
         hipLaunchKernelGGL((vit_gemm_astat_kernel<EPI, NW, 6>), dim3(groups), dim3(64 * NW), 4 * g.KS * 1024, st, ga);               \
     } while (0)
-            if (g_vit_astat_two && (g.N / 64) >= 8 && g.N % 64 == 0 && g.KS % 4 == 0) {   // two channel tiles per wave, eight waves (round 5)
+            if (vfm_cfg().vit_astat_two && (g.N / 64) >= 8 && g.N % 64 == 0 && g.KS % 4 == 0) {   // two channel tiles per wave, eight waves (round 5)
                 static std::atomic<unsigned long long> attr2{0ull};
                 int dev2 = 0;
                 (void)hipGetDevice(&dev2);
@@ -1477,7 +1464,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
                         attr_set2 |= 1ull << (dev & 63);
                     }
                     GemmArgs ga = g;
-                    ga.dbg = g_vit_astat_dbg;
+                    ga.dbg = vfm_cfg().vit_astat_dbg;
                     hipLaunchKernelGGL((vit_gemm_astat_kernel<EPI, 12, 6, true>), dim3(groups), dim3(768), 4 * g.KS * 1024, st, ga);
                 } break;
                 case 8: VIT_ASTAT(8); break;
@@ -1489,13 +1476,13 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
             return VFM_OK;
         }
     }
-    if (g.N % 128 == 0 && g_vit_lds_min_wg > 0 && g.KS % (g_vit_lds_shape / 10 == 4 ? 4 : 2) == 0) {   // (whole stages of 2 or 4 k-steps)
+    if (g.N % 128 == 0 && vfm_cfg().vit_lds_min_wg > 0 && g.KS % (vfm_cfg().vit_lds_shape / 10 == 4 ? 4 : 2) == 0) {   // (whole stages of 2 or 4 k-steps)
         const int wgs = ceil_div(g.M / 32, 4) * (g.N / 128);
-        if (wgs >= g_vit_lds_min_wg) {
+        if (wgs >= vfm_cfg().vit_lds_min_wg) {
             GemmArgs gl = g;
-            gl.hot_a = g_vit_hot_a;
-            gl.dbg = EPI == EPI_RESID ? g_vit_astat_dbg : nullptr;   // (the trace buffer serves whichever kernel a tool looks at)
-            if (EPI == EPI_RESID && g.N == 384 && g_vit_wide_tile && g.KS % 2 == 0) {   // one workgroup per 128 tokens x all 384 channels (NG = 3)
+            gl.hot_a = vfm_cfg().vit_hot_a;
+            gl.dbg = EPI == EPI_RESID ? vfm_cfg().vit_astat_dbg : nullptr;   // (the trace buffer serves whichever kernel a tool looks at)
+            if (EPI == EPI_RESID && g.N == 384 && vfm_cfg().vit_wide_tile && g.KS % 2 == 0) {   // one workgroup per 128 tokens x all 384 channels (NG = 3)
                 const int gridw = 8 * ceil_div(ceil_div(g.M / 32, 4), 8);
                 constexpr int ldsw = 4 * 16 * 2 * 1024;   // NS = 4 stages of (4 + 12) x KB = 2 KiB: 128 KiB
                 static std::atomic<unsigned long long> attr_w{0ull};
@@ -1533,7 +1520,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         } else                                                                                                                       \
         hipLaunchKernelGGL((vit_gemm_lds_kernel<EPI, KB, NS>), dim3(grid), dim3(256), NS * 8 * KB * 1024, st, gl);                    \
     } while (0)
-            switch (g_vit_lds_shape) {
+            switch (vfm_cfg().vit_lds_shape) {
                 case 42: VIT_LDS(4, 2); break;
                 case 43: VIT_LDS(4, 3); break;
                 case 24: VIT_LDS(2, 4); break;
@@ -1546,7 +1533,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
             return VFM_OK;
         }
     }
-    const int cfg = g.N <= 512 ? g_vit_cfg_narrow : g_vit_cfg_wide;
+    const int cfg = g.N <= 512 ? vfm_cfg().vit_cfg_narrow : vfm_cfg().vit_cfg_wide;
     switch (cfg) {
         case 116: return launch_gemm_cfg<EPI, 1, 16>(g, st);
         case 208: return launch_gemm_cfg<EPI, 2, 8>(g, st);
@@ -1556,61 +1543,6 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
 
 }  // namespace
 
-VFM_EXPORT int vfm_debug_set_vit_gemm(int narrow_cfg, int wide_cfg) {
-    if (narrow_cfg == -3 || narrow_cfg == -4) {
-        g_vit_xcd = narrow_cfg == -3 ? 1 : 0;
-        return VFM_OK;
-    }
-    if (narrow_cfg == -6) {
-        g_vit_lds_shape = wide_cfg;
-        return VFM_OK;
-    }
-    if (narrow_cfg == -17) {   // residual GEMMs of the LDS-tiled path: 128 x 384 tiles (1) / 128 x 128 (0, default)
-        g_vit_wide_tile = wide_cfg;
-        return VFM_OK;
-    }
-    if (narrow_cfg == -16) {   // timing experiment (wrong results): the LDS-tiled kernel's A operand from token group 0 in every workgroup
-        g_vit_hot_a = wide_cfg;
-        return VFM_OK;
-    }
-    if (narrow_cfg == -15) {   // token-stationary GEMM: 1 = two channel tiles per wave (default), 0 = round 4's one
-        g_vit_astat_two = wide_cfg;
-        return VFM_OK;
-    }
-    if (narrow_cfg == -14) {   // preprocessing: 1 = one workgroup per patch (default), 0 = round 1's kernel
-        g_vit_preprocess_patch = wide_cfg;
-        return VFM_OK;
-    }
-    if (narrow_cfg == -8) {   // waves per workgroup of the direct GEMM kernel (0: the default, one)
-        g_vit_wpw = wide_cfg;
-        return VFM_OK;
-    }
-    if (narrow_cfg == -7) {   // attention with K / V^T of an (image, head) in the LDS from wide_cfg images per call on (0: never)
-        g_vit_att_lds_min = wide_cfg;
-        return VFM_OK;
-    }
-    if (narrow_cfg == -11 || narrow_cfg == -12) {   // (tools/ab_vit_astat_trace.py) device pointer of the placement trace, low / high 32 bits
-        unsigned long long v = (unsigned long long)(uintptr_t)g_vit_astat_dbg;
-        v = narrow_cfg == -11 ? ((v & 0xffffffff00000000ull) | (unsigned)wide_cfg) : ((v & 0xffffffffull) | ((unsigned long long)(unsigned)wide_cfg << 32));
-        g_vit_astat_dbg = reinterpret_cast<unsigned long long*>((uintptr_t)v);
-        return VFM_OK;
-    }
-    if (narrow_cfg == -10) {
-        g_vit_astat_nw = wide_cfg;
-        return VFM_OK;
-    }
-    if (narrow_cfg == -9) {   // the token-stationary kernel (QKV, fc1) from wide_cfg groups of 128 token rows on (0: the default policy, -1: never)
-        g_vit_astat_min = wide_cfg;
-        return VFM_OK;
-    }
-    if (narrow_cfg == -5) {   // the LDS-tiled GEMM kernel from wide_cfg workgroups on (0: never; default 256)
-        g_vit_lds_min_wg = wide_cfg;
-        return VFM_OK;
-    }
-    g_vit_cfg_narrow = narrow_cfg ? narrow_cfg : 108;
-    g_vit_cfg_wide = wide_cfg ? wide_cfg : 108;
-    return VFM_OK;
-}
 
 VFM_EXPORT size_t vfm_vit_weights_bytes(const vfm_vit_config* cfg) { return cfg ? make_layout(cfg).total : 0; }
 
@@ -1653,7 +1585,7 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
     // padded token rows stay exactly zero in the residual stream
     {
         const int64_t total = (int64_t)d.M * (d.KP / 16) * 2;
-        if (g_vit_preprocess_patch && d.KP <= 640 && d.W >= 2)
+        if (vfm_cfg().vit_preprocess_patch && d.KP <= 640 && d.W >= 2)
             hipLaunchKernelGGL(vit_preprocess_patch_kernel, dim3((unsigned)d.M), dim3(256), 0, st, img, d, w.a);
         else
             hipLaunchKernelGGL(vit_preprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, d, w.a);
@@ -1663,17 +1595,17 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
     g.T = d.T; g.Tp = d.Tp; g.D = d.D; g.heads = d.heads; g.M = d.M;
     g.x = w.x; g.q = w.q; g.k = w.k; g.vt = w.vt;
     g.xh = w.xh; g.stats = w.stats; g.invD = 1.0f / (float)d.D; g.qt_magic = (1u << 20) / (unsigned)(d.Tp / 32) + 1u;
-    g.xcd_map = g_vit_xcd;
-    const int att_grid = g_vit_xcd ? 8 * ceil_div(ceil_div(d.M / 32, 8) * d.heads, 4) : ceil_div(d.B * d.heads * (d.Tp / 32), 4);
+    g.xcd_map = vfm_cfg().vit_xcd;
+    const int att_grid = vfm_cfg().vit_xcd ? 8 * ceil_div(ceil_div(d.M / 32, 8) * d.heads, 4) : ceil_div(d.B * d.heads * (d.Tp / 32), 4);
     // patch embedding (+ cls token + position embedding)
     g.A = reinterpret_cast<const uint4*>(w.a); g.W = f16(SEG_PATCH_W); g.bias = f32(SEG_PATCH_B);
     g.N = d.D; g.KS = d.KP / 16; g.clspos = f32(SEG_CLS_POS);
     int rc = launch_gemm<EPI_PATCH>(g, st);
     if (rc) return rc;
     const int att_work = d.B * d.heads * (d.Tp / 32);
-    // K / V^T of an (image, head) shared by four query tiles through the LDS from g_vit_att_lds_min images on (0: never): at one scan the
+    // K / V^T of an (image, head) shared by four query tiles through the LDS from vfm_cfg().vit_att_lds_min images on (0: never): at one scan the
     // one-wave-per-tile kernel's 396 waves spread over the chip win, at batches the shared form reads a quarter of the L2 bytes
-    const bool att_lds = g_vit_att_lds_min > 0 && d.B >= g_vit_att_lds_min && d.Tp / 32 <= 16;
+    const bool att_lds = vfm_cfg().vit_att_lds_min > 0 && d.B >= vfm_cfg().vit_att_lds_min && d.Tp / 32 <= 16;
     for (int l = 0; l < d.depth; ++l) {
         const int s0 = SEG_LAYER0 + l * SEGS_PER_LAYER;
         // LayerNorm 1 is inside this GEMM: raw residual stream x folded weight, statistics applied in the epilogue
@@ -1696,7 +1628,7 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
     } else                                                                                                                \
     hipLaunchKernelGGL(vit_attention_kernel<NKT>, dim3(att_grid), dim3(256), 0, st,                                       \
                        reinterpret_cast<const uint4*>(w.q), reinterpret_cast<const uint4*>(w.k),                          \
-                       reinterpret_cast<const uint4*>(w.vt), d.T, d.Tp, d.heads, d.D, att_work, w.a, g_vit_xcd)
+                       reinterpret_cast<const uint4*>(w.vt), d.T, d.Tp, d.heads, d.D, att_work, w.a, vfm_cfg().vit_xcd)
         switch (d.Tp / 32) {
             case 1: VIT_ATT(1); break;   case 2: VIT_ATT(2); break;   case 3: VIT_ATT(3); break;
             case 4: VIT_ATT(4); break;   case 5: VIT_ATT(5); break;   case 6: VIT_ATT(6); break;

@@ -438,10 +438,6 @@ __global__ __launch_bounds__(256) void robin_pointkey_kernel(const int64_t* __re
 // is not passed within GRID_SPIN_LIMIT polls (seconds) raises `abort`: every workgroup leaves, the host sees info[5] == 0 and takes
 // the general path.  (Round 5's first attempt let the LAST workgroup to finish phase A run B .. F alone: one compute unit's
 // dependent-latency loops, 0.5 ms at 20 000 points against 0.23 for the launches -- profiles/r05_time_api_onelaunch.txt.)
-int g_voxel_replay2 = 1;   // vfm_debug_set_voxel_small(2 / 3): round 4's replay (radix sort by cluster + global-memory replay) / round 5's (default)
-int g_voxel_small = 1;     // vfm_debug_set_voxel_small(0 / 1): the general path always / the one-launch kernel where it applies (default)
-int g_voxel_trace = 0;     // vfm_debug_set_voxel_small(100 / 101): phase stamps of the one-launch kernel off / on
-int g_voxel_grid_ppt = 0;  // vfm_debug_set_voxel_small(10 + k): k points per thread of the one-launch kernel (fewer workgroups at the barriers); 10 = by size (default)
 constexpr int GRID_T = 256;
 constexpr int GRID_MAX_WG = 256;
 constexpr int GRID_REPLAY_L = 16;
@@ -927,9 +923,9 @@ static int grid_resident_limit(hipStream_t st) {
     return (int)(lim < GRID_MAX_WG ? lim : GRID_MAX_WG);
 }
 // A grid that did not become resident (other tenants on the device: a second rank, a masked stream beside a long kernel) costs
-// GRID_SPIN_LIMIT polls before it gives up.  After one such call the next GRID_BACKOFF calls go straight to the general path.
+// GRID_SPIN_LIMIT polls before it gives up.  After one such call the next GRID_BACKOFF calls of the same host thread go straight to the general path.
 constexpr int GRID_BACKOFF = 64;
-static std::atomic<int> g_grid_backoff{0};
+static thread_local int t_grid_backoff = 0;   // (thread-local, like the last-error string: the library keeps no process-global mutable state)
 
 struct VoxelWs {
     int* owner;
@@ -1073,13 +1069,6 @@ int select_first_k(const double* pts, int64_t n, int64_t stride, double voxel_si
 
 }  // namespace
 
-VFM_EXPORT int vfm_debug_set_voxel_small(int on) {
-    if (on == 2 || on == 3) g_voxel_replay2 = on == 3;
-    else if (on >= 10 && on <= 10 + 64) g_voxel_grid_ppt = on - 10;
-    else if (on == 100 || on == 101) g_voxel_trace = on - 100;
-    else g_voxel_small = on;
-    return VFM_OK;
-}
 
 // tools: the phase stamps of the last one-launch VoxelDownsample in `ws` (n as at that call), 100 MHz ticks; out_host[31] = their number
 VFM_EXPORT int vfm_debug_voxel_trace(void* ws, int64_t n, int64_t* out_host) {
@@ -1152,7 +1141,7 @@ VFM_EXPORT int vfm_voxel_robin_level(const double* pts, int64_t stride, const in
     VFM_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int64_t), st));   // a level that fails or gives up leaves an EMPTY level to the next one
     const int resident = grid_resident_limit(st);
     if (resident <= 0) return VFM_OK;   // (info stays 0: "not reproduced by this kernel", the caller's to redo through vfm_voxel_robin)
-    const int ppt = g_voxel_grid_ppt > 0 ? g_voxel_grid_ppt : (n_max <= 32768 ? 1 : n_max <= 131072 ? 2 : 4);
+    const int ppt = vfm_cfg().voxel_grid_ppt > 0 ? vfm_cfg().voxel_grid_ppt : (n_max <= 32768 ? 1 : n_max <= 131072 ? 2 : 4);
     const int64_t per_wg = (int64_t)GRID_T * ppt;
     const int64_t want_wg = (n_max + per_wg - 1) / per_wg;
     const unsigned grid = (unsigned)(want_wg < resident ? want_wg : resident);
@@ -1175,7 +1164,7 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
         return VFM_OK;
     }
     const int K = max_per_voxel;
-    if (K == 1 && reserve_n >= 0 && n <= GRID_MAX_N && g_voxel_small) {
+    if (K == 1 && reserve_n >= 0 && n <= GRID_MAX_N && vfm_cfg().voxel_small) {
         // VoxelDownsample of a cloud of this size: one generation of a reserved table in ONE launch (voxel_robin_grid_kernel)
         int64_t B = 0;
         {
@@ -1188,10 +1177,9 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
         }
         const int resident = grid_resident_limit(st);
         bool backoff = false;
-        {
-            int b = g_grid_backoff.load(std::memory_order_relaxed);
-            while (b > 0 && !g_grid_backoff.compare_exchange_weak(b, b - 1, std::memory_order_relaxed)) {}
-            backoff = b > 0;
+        if (t_grid_backoff > 0) {
+            --t_grid_backoff;
+            backoff = true;
         }
         if (B >= 2 * n && B <= (1ll << 20) && reserve_n == n && resident > 0 && !backoff) {   // (no rehash: nv <= n <= the load threshold B / 2; the histogram is sized for reserve(n))
             GridRobinArgs a{};
@@ -1200,14 +1188,14 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
             a.info = w.gridctl;
             a.ctl = reinterpret_cast<unsigned*>(w.gridctl + 8);
             a.part = w.gridpart;
-            a.trace = g_voxel_trace ? w.gridtrace : nullptr;
+            a.trace = vfm_cfg().voxel_trace ? w.gridtrace : nullptr;
             a.vfirst32 = w.seq_a; a.vhash = w.vhash; a.hist = w.hist_small;
             a.sorted_v = w.seq_b; a.key_s = reinterpret_cast<int*>(w.key_s); a.cm = w.cm; a.cl_start = w.cl_start;
             a.tab_dist = w.tab_dist; a.tab_id = w.tab_id; a.keep_out = keep_out; a.count_out = count_out;
             VFM_CHECK_HIP(hipMemsetAsync(w.gridctl, 0, 16 * sizeof(int64_t), st));
             // (a barrier costs ~2.5 us + 0.04 us per workgroup, a second point per thread a dependent round trip in every phase:
             //  tools/ab_voxel_grid.py -- 60 000 points: 0.24 / 0.19 / 0.20 ms at 1 / 2 / 4 points per thread, 20 000: 0.130 / 0.125 / 0.140)
-            const int ppt = g_voxel_grid_ppt > 0 ? g_voxel_grid_ppt : (n <= 32768 ? 1 : n <= 131072 ? 2 : 4);
+            const int ppt = vfm_cfg().voxel_grid_ppt > 0 ? vfm_cfg().voxel_grid_ppt : (n <= 32768 ? 1 : n <= 131072 ? 2 : 4);
             const int64_t per_wg = (int64_t)GRID_T * ppt;
             const int64_t want_wg = (n + per_wg - 1) / per_wg;
             const unsigned grid = (unsigned)(want_wg < resident ? want_wg : resident);
@@ -1218,7 +1206,7 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
             VFM_CHECK_HIP(hipMemcpyAsync(gi, w.gridctl, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
             VFM_CHECK_HIP(hipStreamSynchronize(st));
             if (gi[1] > 0) return VFM_OK;
-            if (gi[1] == 0) g_grid_backoff.store(GRID_BACKOFF, std::memory_order_relaxed);   // the grid gave up at a barrier: not resident
+            if (gi[1] == 0) t_grid_backoff = GRID_BACKOFF;   // the grid gave up at a barrier: not resident
             if (info_host) info_host[0] = info_host[1] = info_host[2] = info_host[3] = 0;
             // (a cluster beyond the kernel's limit, a wrap it could not place, or a grid that did not become resident: the general path decides)
         }
@@ -1295,7 +1283,7 @@ VFM_EXPORT int vfm_voxel_robin(const double* pts, int64_t n, int64_t stride, dou
                                w.cl_of_pos, w.cl_start, w.cl_base, w.tab_dist);
             hipLaunchKernelGGL(robin_wrap_kernel, dim3(1), dim3(1), 0, st, w.cm, m, B, (int64_t)z, w.geninfo);
             hipLaunchKernelGGL(robin_maxlen_kernel, dim3(gm), dim3(256), 0, st, w.cl_start, w.cidx, m, w.geninfo);
-            if (g_voxel_replay2) {   // round 5: the replay orders a cluster's members itself and runs in the LDS (robin_replay2_kernel)
+            if (vfm_cfg().voxel_replay2) {   // round 5: the replay orders a cluster's members itself and runs in the LDS (robin_replay2_kernel)
                 hipLaunchKernelGGL(robin_replay2_kernel, dim3(blocks_of(m, 64)), dim3(64), 0, st, w.cl_start, w.cl_base, w.cidx, m, w.pos_s,
                                    cur, w.vhash, mask, z, w.tab_dist, w.tab_id, w.geninfo);
             } else {

@@ -136,8 +136,13 @@ class RegistrationPipeline:
     def __init__(self, n: int, m: int, d: int = 384, n_iter: int = 50000, min_cosine: float = 0.8,
                  max_corr_dist: float = 10000.0, seed: int = 42, device="cuda", overlap_ransac: bool = False,
                  overlap_prepare: bool = False, solve_streams: int = 1, gate: bool = True, coarse: str = "auto",
-                 half_fused: Optional[bool] = None, prep_schedule: Optional[int] = None, private_streams: bool = False):
+                 half_fused: Optional[bool] = None, prep_schedule: Optional[int] = None, private_streams: bool = False,
+                 config: Optional["_lib.Config"] = None):
         lib = _lib.load()
+        # kernel policy of THIS pipeline's library calls (round 6: a caller-owned vfm_config_t, include/vfmreg.h): bound to the calling
+        # thread for the length of every register() / prepare_map(); None = whatever the calling thread has bound (factory settings
+        # if nothing).  Two pipelines with different configs may run from two threads at once.
+        self.config = config
         self.n, self.m, self.d = n, m, d
         self.n_iter, self.min_cosine, self.max_corr_dist, self.seed = n_iter, min_cosine, max_corr_dist, seed
         self.device = torch.device(device)
@@ -338,6 +343,13 @@ class RegistrationPipeline:
 
     def register(self, q_desc: torch.Tensor, q_xyz: torch.Tensor, b_desc: torch.Tensor, b_xyz: torch.Tensor,
                  reuse_map: bool = False, want_mask: bool = True, inputs_ready: Optional[torch.cuda.Event] = None):
+        if self.config is None:
+            return self._register(q_desc, q_xyz, b_desc, b_xyz, reuse_map, want_mask, inputs_ready)
+        with _lib.using(self.config):
+            return self._register(q_desc, q_xyz, b_desc, b_xyz, reuse_map, want_mask, inputs_ready)
+
+    def _register(self, q_desc: torch.Tensor, q_xyz: torch.Tensor, b_desc: torch.Tensor, b_xyz: torch.Tensor,
+                  reuse_map: bool = False, want_mask: bool = True, inputs_ready: Optional[torch.cuda.Event] = None):
         """Enqueue one registration.  ``inputs_ready``: an event after which the four input tensors are complete (inputs
         produced on a stream other than the caller's current one).  Every mode waits for it before the first kernel that
         reads an input; with ``overlap_prepare`` it also spares the prepare stage from queueing behind the coarse pass of the

@@ -277,9 +277,11 @@ class ViTS14:
             ready.record(main)
             h = (B + 1) // 2
 
+            cfg = _lib.current()   # the caller's kernel policy (vfm_config_t, bound per thread): the helper thread binds the same one
+
             def half(k, lo, hi):
                 self._side[k].wait_event(ready)
-                with torch.cuda.stream(self._side[k]):
+                with _lib.using(cfg), torch.cuda.stream(self._side[k]):
                     self.forward(images[lo:hi], out[lo:hi], _slot=k + 1)
 
             # the second half is enqueued by a helper thread while this one enqueues the first (the C call releases the GIL): enqueued one
