@@ -64,6 +64,9 @@ const char *vfm_build_info(void);
  *   "i8_min_queries"     the gated family takes the int8 pass for more than this many query rows (default 0: always)
  *   "prep_grid"          workgroups of prep_chunk_kernel: -1 (default) one per 128-row group, 0 one per compute unit, n > 0
  *   "ransac_exact_only"  1: RANSAC scores every hypothesis in fp64 (no bounds)
+ *   "ransac_fused"       2 (default): the stage as 8 launches (select state reset by the centring kernel, R* out of the moment pass, the
+ *                        point-wise pass from a small grid, final + mask in one workgroup); 1: 5 launches (gather + moments in one workgroup,
+ *                        select + exact score per wave -- measured slower); 0: round 5's chain of 11
  *   "voxel_small"        a code: 0 / 1 = VoxelDownsample-shaped calls by the general multi-launch path / the one-launch kernel (default);
  *                        2 / 3 = round 4's / round 5's (default) per-cluster replay; 10 + k = k points per thread of the one-launch kernel
  *                        (10 = by size); 100 / 101 = its phase stamps off / on (vfm_debug_voxel_trace)

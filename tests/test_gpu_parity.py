@@ -495,14 +495,11 @@ def test_ransac_two_level_equals_exact(ops, orc, n_corr, outlier, noise, max_dis
     lib = _lib.load()
     src, tgt, corres, _ = _ransac_case(n_corr, outlier, seed=n_corr + n_iter, noise=noise)
     ref = orc.ransac_corr(src, tgt, corres, max_dist, n_iter, seed=7)
-    for exact_only in (1, 0):
-        lib.vfm_debug_set_ransac_exact_only(exact_only)
-        try:
+    for exact_only, fused in ((1, 2), (0, 2), (0, 1), (0, 0)):   # fused: round 6's 5-launch chain (default) / round 5's 11 launches
+        with _lib.using(_lib.Config(ransac_exact_only=exact_only, ransac_fused=fused)):
             out = ops.ransac_corr(dev(src), dev(tgt), dev(corres), max_dist, n_iter, seed=7)
             torch.cuda.synchronize()
-        finally:
-            lib.vfm_debug_set_ransac_exact_only(0)
-        assert out["best_hyp"].item() == ref.best_hyp, exact_only
+        assert out["best_hyp"].item() == ref.best_hyp, (exact_only, fused)
         np.testing.assert_array_equal(out["T"].cpu().numpy(), ref.transformation)
         assert out["fitness"].item() == ref.fitness and out["rmse"].item() == ref.inlier_rmse
         np.testing.assert_array_equal(out["mask"][:n_corr].cpu().numpy(), ref.inlier_mask)
@@ -521,13 +518,16 @@ def test_ransac_moment_prefilter_equals_exact(ops, orc, n_corr, outlier, noise, 
     src, tgt, corres, _ = _ransac_case(n_corr, outlier, seed=n_corr + n_iter, noise=noise)
     src = src + offset
     tgt = tgt + np.array([offset, -2.0 * offset, 0.25 * offset])
+    from vfmreg import _lib
     ref = orc.ransac_corr(src, tgt, corres, max_dist, n_iter, seed=11)
-    out = ops.ransac_corr(dev(src), dev(tgt), dev(corres), max_dist, n_iter, seed=11)
-    torch.cuda.synchronize()
-    assert out["best_hyp"].item() == ref.best_hyp
-    np.testing.assert_array_equal(out["T"].cpu().numpy(), ref.transformation)
-    assert out["fitness"].item() == ref.fitness and out["rmse"].item() == ref.inlier_rmse
-    np.testing.assert_array_equal(out["mask"][:n_corr].cpu().numpy(), ref.inlier_mask)
+    for fused in (2, 1, 0):
+        with _lib.using(_lib.Config(ransac_fused=fused)):
+            out = ops.ransac_corr(dev(src), dev(tgt), dev(corres), max_dist, n_iter, seed=11)
+            torch.cuda.synchronize()
+        assert out["best_hyp"].item() == ref.best_hyp, fused
+        np.testing.assert_array_equal(out["T"].cpu().numpy(), ref.transformation)
+        assert out["fitness"].item() == ref.fitness and out["rmse"].item() == ref.inlier_rmse
+        np.testing.assert_array_equal(out["mask"][:n_corr].cpu().numpy(), ref.inlier_mask)
 
 
 def test_ransac_device_count_and_degenerate(ops, orc):

@@ -23,7 +23,7 @@ struct Field {
 const Field k_fields[] = {
     {"coarse_slices", &VfmConfig::force_slices},     {"match_stats", &VfmConfig::match_stats},
     {"i8_min_queries", &VfmConfig::i8_min_queries},  {"prep_grid", &VfmConfig::prep_grid},
-    {"ransac_exact_only", &VfmConfig::ransac_exact_only},
+    {"ransac_exact_only", &VfmConfig::ransac_exact_only}, {"ransac_fused", &VfmConfig::ransac_fused},
     // the fields behind the compound keys, readable (and writable) one by one
     {"coarse_qsets", &VfmConfig::coarse_qsets},      {"seed_units", &VfmConfig::seed_units},
     {"select_variant", &VfmConfig::select_variant},  {"mx6_t4", &VfmConfig::mx6_t4},

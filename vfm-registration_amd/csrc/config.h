@@ -21,6 +21,7 @@ struct VfmConfig {
     int prep_grid = -1;        // workgroups of prep_chunk_kernel (-1 = one per 128-row group, 0 = one per compute unit, n > 0)
     // ---- RANSAC (ransac.hip)
     int ransac_exact_only = 0;   // 1 = every hypothesis scored in fp64 (no bounds)
+    int ransac_fused = 2;        // 2 (default since round 6) = 8 launches, 1 = the 5-launch chain (slower: its one-workgroup gather), 0 = round 5's 11
     // ---- ViT (vit.hip): "vit_gemm" (narrow, wide) codes, see include/vfmreg.h
     int vit_preprocess_patch = 1, vit_xcd = 1, vit_cfg_narrow = 108, vit_cfg_wide = 108, vit_wpw = 0, vit_hot_a = 0, vit_wide_tile = 0,
         vit_lds_shape = 23, vit_att_lds_min = 1, vit_lds_min_wg = 256, vit_astat_min = 0, vit_astat_two = 1, vit_astat_nw = 0;

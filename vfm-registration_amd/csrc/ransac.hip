@@ -17,6 +17,8 @@
 // -> ransac_final_kernel: total order (fitness desc, rmse asc, id asc), pose of the winner; ransac_mask_kernel.
 // Exact arithmetic is fp64, compiled with -ffp-contract=off, written as the exact operation sequence of
 // oracle/vfm_oracle.c so that poses, masks and the winning hypothesis are bit-identical to the oracle's.
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -476,12 +478,8 @@ struct RansacStats {
 };
 
 // one workgroup: centroids, extent, and the centred fp32 copy of the correspondence stream
-__global__ __launch_bounds__(1024) void ransac_center_kernel(const double* __restrict__ pts,
-                                                             const int64_t* __restrict__ count_dev, int64_t c_max,
-                                                             RansacStats* __restrict__ stats, float* __restrict__ pts32) {
-    __shared__ double red[6][1024];
-    __shared__ double cen[6];
-    const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
+__device__ __forceinline__ void ransac_center_body(const double* __restrict__ pts, int64_t C, RansacStats* __restrict__ stats,
+                                                   float* __restrict__ pts32, double (&red)[6][1024], double (&cen)[6]) {
     const int t = threadIdx.x;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int64_t i = t; i < C; i += 1024)
@@ -502,6 +500,8 @@ __global__ __launch_bounds__(1024) void ransac_center_kernel(const double* __res
     double mom[22];  // Sss (6), K (9), Akk, sbar (3), kbar (3)
 #pragma unroll
     for (int k = 0; k < 22; ++k) mom[k] = 0.0;
+    // (measured and dropped in round 6: the loads of four strides issued together -- 48 more registers -- made the kernel slower,
+    // 0.193 against 0.185 ms for the stage: tools/time_ransac.py)
     for (int64_t i = t; i < C; i += 1024) {
         double v[6];
 #pragma unroll
@@ -567,6 +567,18 @@ __global__ __launch_bounds__(1024) void ransac_center_kernel(const double* __res
         stats->gm = (double)((C + 1023) / 1024) + 32.0;  // per-thread terms + butterfly (6) + partials (16) + products / centring
     }
 }
+struct SelectState;
+__device__ __forceinline__ void ransac_sel_reset(SelectState* sel);
+__global__ __launch_bounds__(1024) void ransac_center_kernel(const double* __restrict__ pts,
+                                                             const int64_t* __restrict__ count_dev, int64_t c_max,
+                                                             RansacStats* __restrict__ stats, float* __restrict__ pts32,
+                                                             SelectState* __restrict__ sel_to_reset) {
+    __shared__ double red[6][1024];
+    __shared__ double cen[6];
+    const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
+    if (sel_to_reset && threadIdx.x == 0) ransac_sel_reset(sel_to_reset);   // (chain 2: ransac_sel_init_kernel's launch)
+    ransac_center_body(pts, C, stats, pts32, red, cen);
+}
 
 struct SelectState {           // zeroed per call (Rbits = +inf)
     int F;                     // max certain inlier count
@@ -574,14 +586,52 @@ struct SelectState {           // zeroed per call (Rbits = +inf)
     unsigned long long Rbits;  // min r_hi among hypotheses whose count is certainly F (bits of a double >= 0)
     int overflow;              // candidate list overflowed -> score everything exactly
     int unsure;                // some hypothesis is not certainly all-inlier -> point-wise coarse pass needed
+    int done;                  // fused chain: workgroups of the point-wise pass that have finished (the last one recomputes Rbits)
 };
 
-__global__ void ransac_sel_init_kernel(SelectState* sel) {
+__device__ __forceinline__ void ransac_sel_reset(SelectState* sel) {
     sel->F = 0;
     sel->count = 0;
     sel->Rbits = 0x7FF0000000000000ull;  // +inf
     sel->overflow = 0;
     sel->unsure = 0;
+    sel->done = 0;
+}
+__global__ void ransac_sel_init_kernel(SelectState* sel) { ransac_sel_reset(sel); }
+
+// Fused chain (round 6; VERDICT r5 item 3a: the stage is a chain of dependent launches, 11 of them, 0.18 ms for 0.02 ms of arithmetic):
+// gather + select-state + centring / moments in ONE workgroup (the stream is 10^4 correspondences: 480 KB).
+__global__ __launch_bounds__(1024) void ransac_prepare_kernel(const double* __restrict__ src, const double* __restrict__ tgt,
+                                                              const int32_t* __restrict__ corres, const int64_t* __restrict__ count_dev,
+                                                              int64_t c_max, double* __restrict__ pts, int64_t ns, int64_t nt,
+                                                              int32_t* __restrict__ bad_out, RansacStats* __restrict__ stats,
+                                                              float* __restrict__ pts32, SelectState* __restrict__ sel) {
+    __shared__ double red[6][1024];
+    __shared__ double cen[6];
+    const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
+    if (threadIdx.x == 0) {
+        sel->F = 0;
+        sel->count = 0;
+        sel->Rbits = 0x7FF0000000000000ull;
+        sel->overflow = 0;
+        sel->unsure = 0;
+        sel->done = 0;
+    }
+    for (int64_t i = threadIdx.x; i < C; i += 1024) {
+        int64_t a = corres[2 * i], b = corres[2 * i + 1];
+        if (bad_out && (a < 0 || a >= ns || b < 0 || b >= nt)) {   // vfm_ransac_corr_bounded: flagged, read as row 0
+            *bad_out = 1;
+            a = b = 0;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            pts[6 * i + c] = src[3 * a + c];
+            pts[6 * i + 3 + c] = tgt[3 * b + c];
+        }
+    }
+    __threadfence();     // the stream is read back below by other threads of this workgroup (and by the kernels behind it)
+    __syncthreads();
+    ransac_center_body(pts, C, stats, pts32, red, cen);
 }
 
 struct CoarseHyp {
@@ -604,7 +654,7 @@ struct CoarseHyp {
 __global__ __launch_bounds__(64) void ransac_moment_kernel(const double* __restrict__ pts, const RansacStats* __restrict__ stats,
                                                            const int64_t* __restrict__ count_dev, int64_t c_max,
                                                            double max_d2, int32_t n_iter, uint64_t seed,
-                                                           CoarseHyp* __restrict__ out, SelectState* __restrict__ sel) {
+                                                           CoarseHyp* __restrict__ out, SelectState* __restrict__ sel, int rfuse) {
     const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
     const int lane = threadIdx.x;
     const int32_t h = (int32_t)(blockIdx.x * 64 + lane);
@@ -663,17 +713,26 @@ __global__ __launch_bounds__(64) void ransac_moment_kernel(const double* __restr
     if (h < n_iter) out[h] = o;
     if (__any(unsure) && lane == 0) atomicExch(&sel->unsure, 1);
     if (__any(sure_live) && lane == 0) atomicMax(&sel->F, (int)C);
+    if (rfuse) {
+        // fused chain: R* = min r_hi over the hypotheses whose count is certainly F -- here F = C is known in advance (a hypothesis bounded
+        // in closed form has every correspondence as an inlier, and no count exceeds C), so ransac_select_rmin_kernel's pass is this one.
+        // (Should some workgroup raise `unsure`, the point-wise pass recomputes every bound and its last workgroup recomputes R*.)
+        double r = sure_live ? o.r_hi : 1.7976931348623157e308;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) r = fmin(r, __shfl_xor(r, off));
+        if (lane == 0 && r < 1.7976931348623157e308) atomicMin(&sel->Rbits, (unsigned long long)__double_as_longlong(r));
+    }
 }
 
 // 512 threads = 8 waves per 64 hypotheses: wave w scores chunks w, w+8, ... of the stream (the coarse
 // sums have no prescribed order), so 6 waves share a SIMD and hide each other's issue latency (a lone
 // wave issues one instruction per ~4 cycles whatever its type).  Wave 0 derives the fp32 transform
 // and the thresholds of each hypothesis once; partial results are combined in LDS in wave order.
-__global__ __launch_bounds__(512) void ransac_coarse_kernel(const double* __restrict__ pts, const float* __restrict__ pts32,
-                                                            const RansacStats* __restrict__ stats,
-                                                            const int64_t* __restrict__ count_dev, int64_t c_max,
-                                                            double max_dist, int32_t n_iter, uint64_t seed,
-                                                            CoarseHyp* __restrict__ out, SelectState* __restrict__ sel) {
+__device__ __forceinline__ void ransac_coarse_block(const int hblock, const double* __restrict__ pts, const float* __restrict__ pts32,
+                                                    const RansacStats* __restrict__ stats,
+                                                    const int64_t* __restrict__ count_dev, int64_t c_max,
+                                                    double max_dist, int32_t n_iter, uint64_t seed,
+                                                    CoarseHyp* __restrict__ out, SelectState* __restrict__ sel) {
     __shared__ __attribute__((aligned(16))) float lbuf[COARSE_WAVES][2][COARSE_CHUNK * 6];
     __shared__ float hyp_f[14][64];  // R (9), t' (3), Lf, Hf per hypothesis
     __shared__ double hyp_eta[64];
@@ -684,7 +743,7 @@ __global__ __launch_bounds__(512) void ransac_coarse_kernel(const double* __rest
     if (sel->unsure == 0) return;  // ransac_moment_kernel bounded every hypothesis already (uniform)
     const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int32_t h = (int32_t)(blockIdx.x * 64 + lane);
+    const int32_t h = (int32_t)(hblock * 64 + lane);
     if (C < 3) {
         if (wave == 0 && h < n_iter) out[h] = CoarseHyp{0, -1, 0.0, 0.0};
         return;
@@ -849,6 +908,52 @@ __global__ __launch_bounds__(512) void ransac_coarse_kernel(const double* __rest
     for (int off = 32; off >= 1; off >>= 1) f = max(f, __shfl_xor(f, off));
     if (lane == 0 && f > 0) atomicMax(&sel->F, f);
 }
+__global__ __launch_bounds__(512) void ransac_coarse_kernel(const double* __restrict__ pts, const float* __restrict__ pts32,
+                                                            const RansacStats* __restrict__ stats,
+                                                            const int64_t* __restrict__ count_dev, int64_t c_max,
+                                                            double max_dist, int32_t n_iter, uint64_t seed,
+                                                            CoarseHyp* __restrict__ out, SelectState* __restrict__ sel) {
+    ransac_coarse_block((int)blockIdx.x, pts, pts32, stats, count_dev, c_max, max_dist, n_iter, seed, out, sel);
+}
+// Fused chain: the same pass from a SMALL grid that walks the blocks of 64 hypotheses.  In the regime the reference runs (max distance
+// 10 000 m: every hypothesis bounded in closed form) the pass has nothing to do, and 782 workgroups of 512 threads + 66 KB of LDS that
+// only look at a flag took 5 us alone and 60 us beside a coarse kernel of the matcher, whose workgroups own their compute units
+// (profiles/r06_trace_pipe_d2.txt); now it is as many workgroups as fit at once.  Where it does run, its LAST workgroup (a ticket)
+// recomputes R* from the bounds it wrote -- ransac_select_rmin_kernel's pass -- with the final F.
+__global__ __launch_bounds__(512) void ransac_coarse_loop_kernel(const double* __restrict__ pts, const float* __restrict__ pts32,
+                                                                 const RansacStats* __restrict__ stats,
+                                                                 const int64_t* __restrict__ count_dev, int64_t c_max,
+                                                                 double max_dist, int32_t n_iter, uint64_t seed,
+                                                                 CoarseHyp* __restrict__ out, SelectState* __restrict__ sel) {
+    __shared__ int last_s;
+    __shared__ double rmin_s[8];
+    if (sel->unsure == 0) return;
+    const int nblocks = (n_iter + 63) / 64;
+    for (int hb = (int)blockIdx.x; hb < nblocks; hb += (int)gridDim.x) {
+        __syncthreads();   // (the block's LDS tables are reused)
+        ransac_coarse_block(hb, pts, pts32, stats, count_dev, c_max, max_dist, n_iter, seed, out, sel);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last_s = (atomicAdd(&sel->done, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    const int F = __hip_atomic_load(&sel->F, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double r = 1.7976931348623157e308;
+    for (int h = threadIdx.x; h < n_iter; h += 512) {
+        const CoarseHyp c = out[h];
+        if (c.n_hi >= 0 && c.n_lo == F && c.n_hi == F) r = fmin(r, c.r_hi);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) r = fmin(r, __shfl_xor(r, off));
+    if ((threadIdx.x & 63) == 0) rmin_s[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 8; ++w) r = fmin(r, rmin_s[w]);
+        sel->Rbits = r < 1.7976931348623157e308 ? (unsigned long long)__double_as_longlong(r) : 0x7FF0000000000000ull;
+    }
+}
 
 // which hypotheses can still be the exact winner?
 //   F* = max n_lo (some hypothesis certainly has that many inliers); a winner needs n_hi >= F*.
@@ -889,6 +994,169 @@ __global__ __launch_bounds__(256) void ransac_select_list_kernel(const CoarseHyp
 // correspondence order by a sequential loop over LDS -- the oracle's accumulation order -- so a
 // candidate costs ~C * (1/64 * 31 + 1) fp64 ops of latency instead of C * 31.
 constexpr int EXACT_CHUNK = 1024;
+// the oracle's score of hypothesis h by one wavefront (see ransac_exact_list_kernel below): every lane returns the same HypScore
+__device__ __forceinline__ HypScore ransac_exact_one(const double* __restrict__ pts, int64_t C, double max_d2, int32_t h, uint64_t seed,
+                                                     double (&d2s)[EXACT_CHUNK]) {
+    const int lane = threadIdx.x & 63;
+    HypScore res;
+    res.fit = 0.0;
+    res.rmse = 0.0;
+    res.hyp = -1;
+    double T[12];
+    if (!sample_T(pts, C, (uint32_t)h, seed, T)) return res;   // wave-uniform
+    int64_t good = 0;
+    double e2 = 0.0;
+    for (int64_t base = 0; base < C; base += EXACT_CHUNK) {
+        const int cnt = (int)min((int64_t)EXACT_CHUNK, C - base);
+        __builtin_amdgcn_wave_barrier();
+        int mine = 0;
+        for (int i = lane; i < cnt; i += 64) {
+            const double* p = pts + 6 * (base + i);
+            const double d2 = err2(T, p[0], p[1], p[2], p[3], p[4], p[5]);
+            const bool in = d2 < max_d2;
+            mine += in ? 1 : 0;
+            d2s[i] = in ? d2 : 0.0;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
+        good += mine;
+        __builtin_amdgcn_wave_barrier();
+        int i = 0;
+        if (cnt >= 32) {
+            double va[16], vb[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) va[u] = d2s[u];
+            for (; i + 48 <= cnt; i += 32) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) vb[u] = d2s[i + 16 + u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) e2 = e2 + va[u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) va[u] = d2s[i + 32 + u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) e2 = e2 + vb[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) e2 = e2 + va[u];
+            i += 16;
+        }
+        for (; i < cnt; ++i) e2 = e2 + d2s[i];
+    }
+    if (good > 0) {
+        res.fit = (double)good / (double)C;
+        res.rmse = sqrt(e2 / (double)good);
+        res.hyp = h;
+    }
+    return res;
+}
+
+// Fused chain: ransac_select_list_kernel + ransac_exact_list_kernel in one launch and without the list -- the wave that owns 64
+// hypotheses tests them against (F*, R*) and scores the ones that can still win itself, one after the other (in the reference's
+// regime ONE hypothesis of 50 000 survives the closed-form bound).  No candidate cap, hence no overflow pass behind it.
+__global__ __launch_bounds__(64) void ransac_select_exact_kernel(const double* __restrict__ pts, const int64_t* __restrict__ count_dev,
+                                                                 int64_t c_max, double max_d2, int32_t n_iter, uint64_t seed,
+                                                                 const CoarseHyp* __restrict__ hyps, SelectState* __restrict__ sel,
+                                                                 HypScore* __restrict__ block_best) {
+    __shared__ __attribute__((aligned(16))) double d2s[EXACT_CHUNK];
+    const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
+    const int lane = threadIdx.x;
+    const int h = (int)blockIdx.x * 64 + lane;
+    const int F = sel->F;
+    const double Rs = __longlong_as_double((long long)sel->Rbits);
+    bool cand = false;
+    if (h < n_iter && C >= 3) {
+        const CoarseHyp c = hyps[h];
+        cand = c.n_hi > 0 && c.n_hi >= F && (c.n_hi > F || c.r_lo <= Rs);
+    }
+    unsigned long long todo = __ballot(cand);
+    HypScore best;
+    best.fit = 0.0;
+    best.rmse = 0.0;
+    best.hyp = -1;
+    if (todo != 0ull && lane == 0) atomicAdd(&sel->count, (int)__popcll(todo));   // (vfm_debug_ransac_counts)
+    while (todo != 0ull) {   // ascending hypothesis index: wave-uniform
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const HypScore r = ransac_exact_one(pts, C, max_d2, (int)blockIdx.x * 64 + l, seed, d2s);
+        if (better(r.fit, r.rmse, r.hyp, best.fit, best.rmse, best.hyp)) best = r;
+    }
+    if (lane == 0) block_best[blockIdx.x] = best;
+}
+
+// Fused chain: ransac_final_kernel + ransac_mask_kernel in one workgroup (the mask is 10^4 residuals).
+__global__ __launch_bounds__(1024) void ransac_final_mask_kernel(const double* __restrict__ pts, const int64_t* __restrict__ count_dev,
+                                                                 int64_t c_max, double max_d2, uint64_t seed,
+                                                                 const HypScore* __restrict__ block_best, int nblocks,
+                                                                 double* __restrict__ T_out, double* __restrict__ fitness_out,
+                                                                 double* __restrict__ rmse_out, int32_t* __restrict__ best_hyp_out,
+                                                                 uint8_t* __restrict__ mask) {
+    __shared__ double sf[16], sr[16];
+    __shared__ int sh[16];
+    __shared__ double Ts[12];
+    const int64_t C = count_dev ? min(*count_dev, c_max) : c_max;
+    double fit = 0.0, rmse = 0.0;
+    int hyp = -1;
+    for (int b = threadIdx.x; b < nblocks; b += 1024) {
+        const HypScore s = block_best[b];
+        if (better(s.fit, s.rmse, s.hyp, fit, rmse, hyp)) {
+            fit = s.fit;
+            rmse = s.rmse;
+            hyp = s.hyp;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double of = __shfl_xor(fit, off), orr = __shfl_xor(rmse, off);
+        const int oh = __shfl_xor(hyp, off);
+        if (better(of, orr, oh, fit, rmse, hyp)) {
+            fit = of;
+            rmse = orr;
+            hyp = oh;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sf[threadIdx.x >> 6] = fit;
+        sr[threadIdx.x >> 6] = rmse;
+        sh[threadIdx.x >> 6] = hyp;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (better(sf[w], sr[w], sh[w], sf[0], sr[0], sh[0])) {
+                sf[0] = sf[w];
+                sr[0] = sr[w];
+                sh[0] = sh[w];
+            }
+        double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        if (sh[0] >= 0) sample_T(pts, C, (uint32_t)sh[0], seed, T);
+        for (int k = 0; k < 12; ++k) {
+            T_out[k] = T[k];
+            Ts[k] = T[k];
+        }
+        T_out[12] = 0.0;
+        T_out[13] = 0.0;
+        T_out[14] = 0.0;
+        T_out[15] = 1.0;
+        *fitness_out = (sh[0] >= 0) ? sf[0] : 0.0;
+        *rmse_out = (sh[0] >= 0) ? sr[0] : 0.0;
+        *best_hyp_out = sh[0];
+    }
+    __syncthreads();
+    if (!mask) return;
+    const bool have = sh[0] >= 0;
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = Ts[k];
+    for (int64_t i = threadIdx.x; i < c_max; i += 1024) {
+        uint8_t m = 0;
+        if (i < C && have) {
+            const double* p = pts + 6 * i;
+            m = (err2(T, p[0], p[1], p[2], p[3], p[4], p[5]) < max_d2) ? 1 : 0;
+        }
+        mask[i] = m;
+    }
+}
+
 __global__ __launch_bounds__(64) void ransac_exact_list_kernel(const double* __restrict__ pts,
                                                                const int64_t* __restrict__ count_dev, int64_t c_max,
                                                                double max_d2, int32_t n_iter, uint64_t seed,
@@ -1040,6 +1308,31 @@ int ransac_corr_impl(const double* src, int64_t ns, const double* tgt, int64_t n
     // a non-positive squared threshold admits no inlier, which yields exactly that here.
     const double max_d2 = (max_dist > 0.0) ? max_dist * max_dist : -1.0;
     const int nblocks = (n_iter + 63) / 64;
+    if (vfm_cfg().ransac_fused == 1 && !vfm_cfg().ransac_exact_only && c_max > 0) {
+        // chain 1 (round 6, measured and NOT the default: 0.195 ms against 0.187 at 10^4 correspondences -- the stage is its kernels'
+        // own dependent chains, not its launch boundaries: tools/time_ransac.py): 5 launches for the 11 below, same winner
+        static std::atomic<int> ncu{0};
+        int cus = ncu.load(std::memory_order_relaxed);
+        if (cus == 0) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            ncu.store(cus, std::memory_order_relaxed);
+        }
+        hipLaunchKernelGGL(ransac_prepare_kernel, dim3(1), dim3(1024), 0, st, src, tgt, corres, count_dev, c_max, w.pts, ns, nt, bad_out,
+                           w.stats, w.pts32, w.sel);
+        hipLaunchKernelGGL(ransac_moment_kernel, dim3(nblocks), dim3(64), 0, st, w.pts, w.stats, count_dev, c_max, max_d2, n_iter, seed,
+                           w.hyps, w.sel, 1);
+        hipLaunchKernelGGL(ransac_coarse_loop_kernel, dim3(nblocks < cus ? nblocks : cus), dim3(64 * COARSE_WAVES), 0, st, w.pts, w.pts32,
+                           w.stats, count_dev, c_max, max_dist, n_iter, seed, w.hyps, w.sel);
+        hipLaunchKernelGGL(ransac_select_exact_kernel, dim3(nblocks), dim3(64), 0, st, w.pts, count_dev, c_max, max_d2, n_iter, seed,
+                           w.hyps, w.sel, w.block_best + CAND_MAX);
+        VFM_CHECK_LAUNCH("ransac fused chain");
+        hipLaunchKernelGGL(ransac_final_mask_kernel, dim3(1), dim3(1024), 0, st, w.pts, count_dev, c_max, max_d2, seed,
+                           w.block_best + CAND_MAX, nblocks, T_out, fitness_out, rmse_out, best_hyp_out, inlier_mask);
+        VFM_CHECK_LAUNCH("ransac_final_mask_kernel");
+        return VFM_OK;
+    }
     if (c_max > 0) {
         hipLaunchKernelGGL(ransac_gather_kernel, dim3((unsigned)((c_max + 255) / 256)), dim3(256), 0, st, src, tgt, corres,
                            count_dev, c_max, w.pts, ns, nt, bad_out);
@@ -1057,13 +1350,37 @@ int ransac_corr_impl(const double* src, int64_t ns, const double* tgt, int64_t n
         // coarse bounds (closed form from the stream's moments when every point is provably an inlier,
         // else the point-wise fp32 pass) -> candidates -> exact fp64 on the candidates (or on everything
         // if the candidate list overflowed)
+        const unsigned gsel = (unsigned)((n_iter + 255) / 256);
+        if (vfm_cfg().ransac_fused == 2) {
+            // chain 2 (round 6, default): round 5's kernels where one of them alone is the faster one (the parallel gather, the candidate
+            // list + one wave per candidate), minus the launches that only hand a flag on: the select state is reset by the centring
+            // kernel, R* comes out of the moment pass (F = C is known there), the point-wise pass is a small grid that looks at the flag,
+            // final + mask are one workgroup.  8 launches for 11.
+            int cus = 256, dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            hipLaunchKernelGGL(ransac_center_kernel, dim3(1), dim3(1024), 0, st, w.pts, count_dev, c_max, w.stats, w.pts32, w.sel);
+            hipLaunchKernelGGL(ransac_moment_kernel, dim3(nblocks), dim3(64), 0, st, w.pts, w.stats, count_dev, c_max, max_d2,
+                               n_iter, seed, w.hyps, w.sel, 1);
+            hipLaunchKernelGGL(ransac_coarse_loop_kernel, dim3(nblocks < cus ? nblocks : cus), dim3(64 * COARSE_WAVES), 0, st, w.pts, w.pts32,
+                               w.stats, count_dev, c_max, max_dist, n_iter, seed, w.hyps, w.sel);
+            hipLaunchKernelGGL(ransac_select_list_kernel, dim3(gsel), dim3(256), 0, st, w.hyps, n_iter, w.sel, w.list);
+            hipLaunchKernelGGL(ransac_exact_list_kernel, dim3(CAND_MAX), dim3(64), 0, st, w.pts, count_dev, c_max, max_d2, n_iter,
+                               seed, w.list, w.sel, w.block_best);
+            hipLaunchKernelGGL(ransac_score_kernel, dim3(nblocks), dim3(64), 0, st, w.pts, count_dev, c_max, max_d2, n_iter, seed,
+                               &w.sel->overflow, w.block_best + CAND_MAX);
+            VFM_CHECK_LAUNCH("ransac coarse/select/score kernels");
+            hipLaunchKernelGGL(ransac_final_mask_kernel, dim3(1), dim3(1024), 0, st, w.pts, count_dev, c_max, max_d2, seed, w.block_best,
+                               CAND_MAX + nblocks, T_out, fitness_out, rmse_out, best_hyp_out, c_max > 0 ? inlier_mask : (uint8_t*)nullptr);
+            VFM_CHECK_LAUNCH("ransac_final_mask_kernel");
+            return VFM_OK;
+        }
         hipLaunchKernelGGL(ransac_sel_init_kernel, dim3(1), dim3(1), 0, st, w.sel);
-        hipLaunchKernelGGL(ransac_center_kernel, dim3(1), dim3(1024), 0, st, w.pts, count_dev, c_max, w.stats, w.pts32);
+        hipLaunchKernelGGL(ransac_center_kernel, dim3(1), dim3(1024), 0, st, w.pts, count_dev, c_max, w.stats, w.pts32, (SelectState*)nullptr);
         hipLaunchKernelGGL(ransac_moment_kernel, dim3(nblocks), dim3(64), 0, st, w.pts, w.stats, count_dev, c_max, max_d2,
-                           n_iter, seed, w.hyps, w.sel);
+                           n_iter, seed, w.hyps, w.sel, 0);
         hipLaunchKernelGGL(ransac_coarse_kernel, dim3(nblocks), dim3(64 * COARSE_WAVES), 0, st, w.pts, w.pts32, w.stats, count_dev, c_max,
                            max_dist, n_iter, seed, w.hyps, w.sel);
-        const unsigned gsel = (unsigned)((n_iter + 255) / 256);
         hipLaunchKernelGGL(ransac_select_rmin_kernel, dim3(gsel), dim3(256), 0, st, w.hyps, n_iter, w.sel);
         hipLaunchKernelGGL(ransac_select_list_kernel, dim3(gsel), dim3(256), 0, st, w.hyps, n_iter, w.sel, w.list);
         hipLaunchKernelGGL(ransac_exact_list_kernel, dim3(CAND_MAX), dim3(64), 0, st, w.pts, count_dev, c_max, max_d2, n_iter,
