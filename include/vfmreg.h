@@ -496,6 +496,18 @@ int vfm_icp_step_nearest(const double *src, int64_t n, const double *T_host, dou
                          const int32_t *start, const double *pts, int32_t n_voxels, double voxel_size, double max_dist,
                          double *tgt_out, uint8_t *valid_out, vfm_stream_t stream);
 
+/* RegisterFrame(std::vector<Eigen::VectorXd>, ...) (src/kiss-icp/cpp/kiss_icp/core/Registration.cpp:384-423): the search of its loop,
+ * VoxelHashMap::GetCorrespondences(VectorXdVector) (VHM:321-448) -- among the points of the 27 voxels around a source point the first
+ * minimum of |dxyz|^2 x clamp(0.5 (1 - cos(desc, desc')), 0.01, 1) (1 where a descriptor's element sum is zero), accepted if the Euclidean
+ * distance is below max_dist.  vfm_icp_desc_stats: |row| and "element sum != 0" of n descriptor rows of f doubles (column order, no FMA).
+ * vfm_icp_step_nearest_desc: as vfm_icp_step_nearest (T_host NULL: the points are searched where they are, as vfm_icp_nearest) with the
+ * descriptor rows / statistics of the source points and of the map's points (map_*: in the order of `pts`). */
+int vfm_icp_desc_stats(const double *desc, int64_t n, int32_t f, double *norm_out, uint8_t *has_out, vfm_stream_t stream);
+int vfm_icp_step_nearest_desc(const double *src, int64_t n, const double *T_host, double *src_out, const double *src_desc,
+                              const double *src_norm, const uint8_t *src_has, int32_t f, const int64_t *keys, const int32_t *start,
+                              const double *pts, const double *map_desc, const double *map_norm, const uint8_t *map_has,
+                              int32_t n_voxels, double voxel_size, double max_dist, double *tgt_out, uint8_t *valid_out,
+                              vfm_stream_t stream);
 /* BuildLinearSystem (src/kiss-icp/cpp/kiss_icp/core/Registration.cpp:96-141): out43 =
  * [J^T W J row-major 6x6 | J^T W r (6) | pair count], J = [I | -hat(s)], w = k^2/(k+|r|^2)^2. */
 int vfm_icp_build_system(const double *src, const double *tgt, const uint8_t *valid, int64_t n,

@@ -598,6 +598,56 @@ def register_frame(points: np.ndarray, map_points: np.ndarray, voxel_size: float
     return (T, hist) if return_history else T
 
 
+def register_frame_xd(points: np.ndarray, map_rows: np.ndarray, voxel_size: float, initial_guess: np.ndarray,
+                      max_correspondance_distance: float, kernel: float, max_iter: int = 1000, return_history: bool = False):
+    """kiss_icp RegisterFrame(std::vector<Eigen::VectorXd> ...) (Registration.cpp:384-423) on an explicit map row set (xyz + descriptors of
+    any width, the rows of map_x_ in insertion order): the 3-D loop with VoxelHashMap::GetCorrespondences(VectorXdVector)
+    (VoxelHashMap.cpp:321-448, orc_icp_nearest_desc) as its search.  An iteration without correspondences ends the loop (the reference
+    solves an all-zero system there: dx = 0, below the threshold)."""
+    pts_all = np.asarray(points, dtype=np.float64)
+    rows = np.asarray(map_rows, dtype=np.float64)
+    f = pts_all.shape[1] - 3
+    assert rows.shape[1] == pts_all.shape[1] and f >= 1
+    v = np.trunc(rows[:, :3] / voxel_size).astype(np.int64) + (1 << 20)
+    k = (v[:, 0] << 42) | (v[:, 1] << 21) | v[:, 2]
+    order = np.argsort(k, kind="stable")
+    keys, first = np.unique(k[order], return_index=True)
+    keys = np.ascontiguousarray(keys)
+    start = np.r_[first, len(order)].astype(np.int32)
+    mpts = np.ascontiguousarray(rows[order, :3])
+    mdesc = np.ascontiguousarray(rows[order, 3:])
+    sdesc = np.ascontiguousarray(pts_all[:, 3:])
+    mnorm, snorm = np.empty(len(mdesc)), np.empty(len(sdesc))
+    mhas, shas = np.empty(len(mdesc), np.uint8), np.empty(len(sdesc), np.uint8)
+    lib().orc_icp_desc_stats(_p(mdesc, _f64p), C.c_int64(len(mdesc)), C.c_int32(f), _p(mnorm, _f64p), _p(mhas, _u8p))
+    lib().orc_icp_desc_stats(_p(sdesc, _f64p), C.c_int64(len(sdesc)), C.c_int32(f), _p(snorm, _f64p), _p(shas, _u8p))
+    T0 = np.ascontiguousarray(initial_guess, dtype=np.float64)
+    source = _transform_rows(np.ascontiguousarray(pts_all[:, :3]), T0)
+    n = len(source)
+    tgt = np.empty_like(source)
+    valid = np.empty(n, dtype=np.uint8)
+    out = np.empty(43, dtype=np.float64)
+    T_icp = np.eye(4)
+    hist = []
+    for _ in range(max_iter):
+        lib().orc_icp_nearest_desc(_p(source, _f64p), C.c_int64(n), _p(sdesc, _f64p), _p(snorm, _f64p), _p(shas, _u8p), C.c_int32(f),
+                                   _p(keys, _i64p), _p(start, _i32p), _p(mpts, _f64p), _p(mdesc, _f64p), _p(mnorm, _f64p), _p(mhas, _u8p),
+                                   C.c_int32(len(keys)), C.c_double(voxel_size), C.c_double(max_correspondance_distance),
+                                   _p(tgt, _f64p), _p(valid, _u8p))
+        lib().orc_icp_system(_p(source, _f64p), _p(tgt, _f64p), _p(valid, _u8p), C.c_int64(n), C.c_double(kernel), _p(out, _f64p))
+        if out[42] == 0:
+            break
+        dx = np.linalg.solve(out[:36].reshape(6, 6), -out[36:42])
+        est = se3_exp(dx)
+        source = _transform_rows(source, est)
+        T_icp = est @ T_icp
+        hist.append((out.copy(), dx.copy(), tgt.copy(), valid.copy()))
+        if np.linalg.norm(dx) < 1e-4:
+            break
+    T = T_icp @ T0
+    return (T, hist) if return_history else T
+
+
 def _transform_rows(xyz: np.ndarray, T: np.ndarray) -> np.ndarray:
     out = np.empty_like(xyz)
     lib().orc_transform_xyz(_p(np.ascontiguousarray(xyz), _f64p), C.c_int64(len(xyz)), _p(np.ascontiguousarray(T, dtype=np.float64), _f64p),

@@ -915,6 +915,73 @@ ORC_API void orc_icp_nearest(const double *src, int64_t n, const int64_t *keys, 
     }
 }
 
+/* VoxelHashMap::GetCorrespondences(VectorXdVector) (VoxelHashMap.cpp:321-448; the search of RegisterFrame(VectorXd ...),
+ * Registration.cpp:384-423): the neighbour scan of orc_icp_nearest with the VFM-ICP weight -- first minimum of
+ * |dxyz|^2 * clamp(0.5 (1 - cos), 0.01, 1) (VHM:367-383; 1 where either descriptor's element sum is zero, VHM:366, 373), cos =
+ * dot / (|n| |p| + 1e-5); accepted if the EUCLIDEAN distance to the chosen neighbour is below max_dist (VHM:425-432).  Sums in column
+ * order (Eigen's vectorised reduction order is not part of its interface: parity with the reference is exact up to that order). */
+ORC_API void orc_icp_desc_stats(const double *desc, int64_t n, int32_t f, double *norm_out, uint8_t *has_out) {
+    for (int64_t i = 0; i < n; ++i) {
+        const double *r = desc + i * f;
+        double ss = 0.0, sm = 0.0;
+        for (int k = 0; k < f; ++k) {
+            ss = ss + r[k] * r[k];
+            sm = sm + r[k];
+        }
+        norm_out[i] = sqrt(ss);
+        has_out[i] = sm != 0.0 ? 1 : 0;
+    }
+}
+ORC_API void orc_icp_nearest_desc(const double *src, int64_t n, const double *src_desc, const double *src_norm, const uint8_t *src_has,
+                                  int32_t f, const int64_t *keys, const int32_t *start, const double *pts, const double *map_desc,
+                                  const double *map_norm, const uint8_t *map_has, int32_t nv, double voxel_size, double max_dist,
+                                  double *tgt, uint8_t *valid) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const double px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
+        const int kx = (int)(px / voxel_size), ky = (int)(py / voxel_size), kz = (int)(pz / voxel_size);
+        double bx = 0, by = 0, bz = 0, best = 1.7976931348623157e308;
+        int found = 0;
+        const double *pd = src_desc + i * f;
+        for (int a = kx - 1; a <= kx + 1; ++a)
+            for (int b = ky - 1; b <= ky + 1; ++b)
+                for (int c = kz - 1; c <= kz + 1; ++c) {
+                    const int64_t key = orc_voxel_key(a, b, c);
+                    int lo = 0, hi = nv;
+                    while (lo < hi) {
+                        int mid = (lo + hi) >> 1;
+                        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+                    }
+                    if (lo < nv && keys[lo] == key) {
+                        for (int j = start[lo]; j < start[lo + 1]; ++j) {
+                            double dx = pts[3 * j] - px, dy = pts[3 * j + 1] - py, dz = pts[3 * j + 2] - pz;
+                            double d = (dx * dx + dy * dy) + dz * dz;
+                            if (f > 0) {
+                                double cd = 1.0;
+                                if (src_has[i] && map_has[j]) {
+                                    const double *nd = map_desc + (int64_t)j * f;
+                                    double dot = 0.0;
+                                    for (int k = 0; k < f; ++k) dot = dot + nd[k] * pd[k];
+                                    const double cs = dot / (map_norm[j] * src_norm[i] + 1e-5);
+                                    cd = 0.5 * (1.0 - cs);
+                                    cd = cd < 0.01 ? 0.01 : (1.0 < cd ? 1.0 : cd);
+                                }
+                                d = d * cd;
+                            }
+                            if (d < best) {
+                                best = d;
+                                bx = pts[3 * j]; by = pts[3 * j + 1]; bz = pts[3 * j + 2];
+                                found = 1;
+                            }
+                        }
+                    }
+                }
+        tgt[3 * i] = bx; tgt[3 * i + 1] = by; tgt[3 * i + 2] = bz;
+        const double ex = bx - px, ey = by - py, ez = bz - pz;
+        valid[i] = (found && sqrt((ex * ex + ey * ey) + ez * ez) < max_dist) ? 1 : 0;
+    }
+}
+
 /* BuildLinearSystem (Registration.cpp:96-141): J = [I | -hat(s)], w = k^2 / (k + |r|^2)^2,
  * JTJ += J^T w J, JTr += J^T w r.  TBB's reduction order is unspecified; fixed here to 256
  * interleaved partial sums (pair i -> partial i % 256, ascending i) + stride-halving tree. */

@@ -27,6 +27,7 @@ const Field k_fields[] = {
     // the fields behind the compound keys, readable (and writable) one by one
     {"coarse_qsets", &VfmConfig::coarse_qsets},      {"seed_units", &VfmConfig::seed_units},
     {"select_variant", &VfmConfig::select_variant},  {"mx6_t4", &VfmConfig::mx6_t4},
+    {"mx6_tune", &VfmConfig::mx6_tune},
     {"mx6_ns3", &VfmConfig::mx6_ns3},                {"prep_form", &VfmConfig::prep_stream},
     {"finish_short", &VfmConfig::finish_short},      {"rescan_rows", &VfmConfig::rescan_rows},
     {"vit_preprocess_patch", &VfmConfig::vit_preprocess_patch}, {"vit_xcd", &VfmConfig::vit_xcd},

@@ -16,6 +16,7 @@ struct VfmConfig {
     int prep_stream = 3;       // "coarse_variant" 40 .. 43: fp6 operand preparation by prep_chunk_kernel (0) / prep_stream_kernel (1) / by width (2) / prep_once_kernel (3, default)
     int finish_short = 0;      // "coarse_variant" 50 / 51: chunk-major rescan as long-lived (default) / short workgroups
     int rescan_rows = 1;       // "coarse_variant" 60 / 61: rescan gathers its queries from the fragment tiles / the row-major int8 scan (default)
+    int mx6_tune = 0;          // (A/B) bit 0: s_setprio 1 for waves 4 - 7 of the fp6 coarse kernel; bit 1: its ring five steps deep (headline shape)
     int match_stats = 0;       // per-query counters of a search (they cost same-address atomics)
     int i8_min_queries = 0;    // the gated family takes the int8 pass for more than this many query rows
     int prep_grid = -1;        // workgroups of prep_chunk_kernel (-1 = one per 128-row group, 0 = one per compute unit, n > 0)

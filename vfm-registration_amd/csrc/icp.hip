@@ -111,6 +111,119 @@ __global__ __launch_bounds__(256) void icp_nearest_kernel(const double* src, int
     valid[i] = ok ? 1 : 0;
 }
 
+// ---- RegisterFrame(std::vector<Eigen::VectorXd>, ...) (Registration.cpp:384-423; round 6): the same loop on rows that carry descriptors of
+// any width, with VoxelHashMap::GetCorrespondences(VectorXdVector) (VoxelHashMap.cpp:321-448) as its search: among the points of the 27
+// voxels the FIRST minimum of   d = |xyz_n - xyz_p|^2 x c,   c = clamp(0.5 (1 - cos(desc_n, desc_p)), 0.01, 1)  if both descriptors
+// have a non-zero element sum, else 1;  cos = dot / (|desc_n| |desc_p| + 1e-5);  accepted if the EUCLIDEAN distance is below
+// max_correspondence_distance.  Sums in column order, no fused multiply-add (oracle/vfm_oracle.c orc_icp_nearest_desc replays them; Eigen's
+// own reduction order is not specified -- the arg-min can differ from the reference's only between candidates whose d agree to the last bits).
+__global__ __launch_bounds__(256) void icp_desc_stats_kernel(const double* __restrict__ desc, int64_t n, int f, double* __restrict__ norm_out,
+                                                             uint8_t* __restrict__ has_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double* r = desc + i * f;
+    double ss = 0.0, sm = 0.0;
+    for (int k = 0; k < f; ++k) {
+        ss = ss + r[k] * r[k];
+        sm = sm + r[k];
+    }
+    norm_out[i] = sqrt(ss);
+    has_out[i] = sm != 0.0 ? 1 : 0;
+}
+struct IcpDesc {
+    const double* src_desc;   // [n][f]
+    const double* src_norm;   // [n]
+    const uint8_t* src_has;   // [n]
+    const double* map_desc;   // [m][f], rows in the grid's (CSR) order
+    const double* map_norm;
+    const uint8_t* map_has;
+    int f;
+};
+__global__ __launch_bounds__(256) void icp_nearest_desc_kernel(const double* src, int64_t n, const long long* __restrict__ keys,
+                                                               const int* __restrict__ start, const double* __restrict__ pts, int nv,
+                                                               double voxel_size, double max_dist, double* __restrict__ tgt,
+                                                               uint8_t* __restrict__ valid, IcpStep step, double* src_out, IcpDesc dd) {
+    const int l = threadIdx.x & (ICP_LANES - 1);
+    int64_t i = (int64_t)blockIdx.x * (256 / ICP_LANES) + (threadIdx.x / ICP_LANES);
+    const bool live = i < n;
+    double px = 0.0, py = 0.0, pz = 0.0;
+    if (live) {
+        px = src[3 * i];
+        py = src[3 * i + 1];
+        pz = src[3 * i + 2];
+    }
+    if (step.apply) {
+        const double* T = step.T;
+        const double qx = ((T[0] * px + T[1] * py) + T[2] * pz) + T[3] * 1.0;
+        const double qy = ((T[4] * px + T[5] * py) + T[6] * pz) + T[7] * 1.0;
+        const double qz = ((T[8] * px + T[9] * py) + T[10] * pz) + T[11] * 1.0;
+        px = qx; py = qy; pz = qz;
+        if (l == 0 && live) {
+            src_out[3 * i] = px;
+            src_out[3 * i + 1] = py;
+            src_out[3 * i + 2] = pz;
+        }
+    }
+    const int kx = (int)(px / voxel_size), ky = (int)(py / voxel_size), kz = (int)(pz / voxel_size);
+    double bx = 0.0, by = 0.0, bz = 0.0, best = 1.7976931348623157e308;
+    unsigned order = 0xFFFFFFFFu;
+    if (l < 27 && live) {
+        const long long key = voxel_key(kx - 1 + l / 9, ky - 1 + (l / 3) % 3, kz - 1 + l % 3);
+        int lo = 0, hi = nv;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        if (lo < nv && keys[lo] == key) {
+            const int j0 = start[lo], j1 = start[lo + 1];
+            const double* pd = dd.src_desc + i * dd.f;
+            const double pn = dd.src_norm[i];
+            const bool phas = dd.f > 0 && dd.src_has[i] != 0;
+            for (int j = j0; j < j1; ++j) {
+                const double dx = pts[3 * j] - px, dy = pts[3 * j + 1] - py, dz = pts[3 * j + 2] - pz;
+                double d = (dx * dx + dy * dy) + dz * dz;
+                if (dd.f > 0) {
+                    double c = 1.0;
+                    if (phas && dd.map_has[j] != 0) {
+                        const double* nd = dd.map_desc + (int64_t)j * dd.f;
+                        double dot = 0.0;
+                        for (int k = 0; k < dd.f; ++k) dot = dot + nd[k] * pd[k];
+                        const double cs = dot / (dd.map_norm[j] * pn + 1e-5);
+                        c = 0.5 * (1.0 - cs);
+                        c = c < 0.01 ? 0.01 : (1.0 < c ? 1.0 : c);   // std::clamp(c, 0.01, 1.0)
+                    }
+                    d = d * c;
+                }
+                if (d < best) {
+                    best = d;
+                    bx = pts[3 * j];
+                    by = pts[3 * j + 1];
+                    bz = pts[3 * j + 2];
+                    order = ((unsigned)l << 20) | (unsigned)min(j - j0, (1 << 20) - 1);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = ICP_LANES / 2; off >= 1; off >>= 1) {
+        const double ob = __shfl_xor(best, off), ox = __shfl_xor(bx, off), oy = __shfl_xor(by, off), oz = __shfl_xor(bz, off);
+        const unsigned oo = __shfl_xor(order, off);
+        const bool take = oo != 0xFFFFFFFFu && (order == 0xFFFFFFFFu || ob < best || (ob == best && oo < order));
+        if (take) {
+            best = ob; bx = ox; by = oy; bz = oz; order = oo;
+        }
+    }
+    if (l != 0 || !live) return;
+    // (closest_neighbor.head<3>() - point.head<3>()).norm() < max_correspondance_distance (VoxelHashMap.cpp:425-432): the Euclidean
+    // distance of the chosen neighbour, not its weighted one
+    const double ex = bx - px, ey = by - py, ez = bz - pz;
+    const bool ok = order != 0xFFFFFFFFu && (sqrt((ex * ex + ey * ey) + ez * ez) < max_dist);
+    tgt[3 * i] = bx;
+    tgt[3 * i + 1] = by;
+    tgt[3 * i + 2] = bz;
+    valid[i] = ok ? 1 : 0;
+}
+
 // out[0..35] = J^T W J (row-major 6x6), out[36..41] = J^T W r, out[42] = number of pairs.
 // One workgroup per output value: the 43 sums are independent chains, so workgroup k recomputes w and the two Jacobian columns it
 // needs and adds ITS term of every pair in the order the oracle replays (thread t owns pairs i = t mod 256 ascending, then the
@@ -205,6 +318,34 @@ VFM_EXPORT int vfm_icp_step_nearest(const double* src, int64_t n, const double* 
                        reinterpret_cast<const long long*>(keys), start, pts, n_voxels, voxel_size, max_dist, tgt_out,
                        valid_out, step, src_out);
     VFM_CHECK_LAUNCH("icp_nearest_kernel(step)");
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_icp_desc_stats(const double* desc, int64_t n, int32_t f, double* norm_out, uint8_t* has_out, vfm_stream_t stream) {
+    VFM_CHECK_ARG(desc && norm_out && has_out && n >= 0 && f >= 1, "icp_desc_stats: bad arguments");
+    if (n == 0) return VFM_OK;
+    hipLaunchKernelGGL(icp_desc_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, desc, n, (int)f, norm_out, has_out);
+    VFM_CHECK_LAUNCH("icp_desc_stats_kernel");
+    return VFM_OK;
+}
+
+VFM_EXPORT int vfm_icp_step_nearest_desc(const double* src, int64_t n, const double* T_host, double* src_out, const double* src_desc,
+                                         const double* src_norm, const uint8_t* src_has, int32_t f, const int64_t* keys, const int32_t* start,
+                                         const double* pts, const double* map_desc, const double* map_norm, const uint8_t* map_has,
+                                         int32_t n_voxels, double voxel_size, double max_dist, double* tgt_out, uint8_t* valid_out,
+                                         vfm_stream_t stream) {
+    VFM_CHECK_ARG(src && keys && start && pts && tgt_out && valid_out && n >= 0 && n_voxels >= 0 && voxel_size > 0.0 && f >= 1 && src_desc &&
+                      src_norm && src_has && map_desc && map_norm && map_has && (!T_host || src_out),
+                  "icp_step_nearest_desc: bad arguments");
+    if (n == 0) return VFM_OK;
+    IcpStep step;
+    step.apply = T_host ? 1 : 0;
+    for (int k = 0; k < 12; ++k) step.T[k] = T_host ? T_host[k] : 0.0;
+    IcpDesc dd{src_desc, src_norm, src_has, map_desc, map_norm, map_has, (int)f};
+    hipLaunchKernelGGL(icp_nearest_desc_kernel, dim3((unsigned)((n + 256 / ICP_LANES - 1) / (256 / ICP_LANES))), dim3(256), 0, (hipStream_t)stream,
+                       src, n, reinterpret_cast<const long long*>(keys), start, pts, n_voxels, voxel_size, max_dist, tgt_out, valid_out, step,
+                       src_out, dd);
+    VFM_CHECK_LAUNCH("icp_nearest_desc_kernel");
     return VFM_OK;
 }
 

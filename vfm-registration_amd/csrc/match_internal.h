@@ -244,6 +244,7 @@ struct CoarseArgs {
     int cap;
     int* survivors;         // fb_count + 5: the search's load figure
     unsigned long long* qbest;   // VFM_RECORDS_MX6_PILOT: [npad] (float_key(lower bound) << 32 | chunk) of the query's best chunk, by 64-bit atomicMax (NULL: not kept)
+    int tune;               // (A/B, vfm_config "mx6_tune") bit 0: waves 4 - 7 of a workgroup of the fp6 kernel at s_setprio 1
     unsigned* surv;         // VFM_RECORDS_MX6_HALF_FUSED / _MX6_FUSED: a slot of mx6_survivor_slot_words() words per workgroup (in the record buffer)
 };
 

@@ -93,6 +93,9 @@ SIGNATURES = {
     "vfm_icp_nearest": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, C.c_int32, C.c_double, C.c_double, c_vp, c_vp, c_vp]),
     "vfm_icp_step_nearest": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int32, C.c_double, C.c_double, c_vp, c_vp, c_vp]),
     "vfm_icp_build_system": (C.c_int, [c_vp, c_vp, c_vp, c_i64, C.c_double, c_vp, c_vp]),
+    "vfm_icp_desc_stats": (C.c_int, [c_vp, c_i64, C.c_int32, c_vp, c_vp, c_vp]),
+    "vfm_icp_step_nearest_desc": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int32,
+                                            C.c_double, C.c_double, c_vp, c_vp, c_vp]),
     "vfm_vit_weights_bytes": (C.c_size_t, [C.POINTER(VitConfig)]),
     "vfm_vit_weights_layout": (C.c_int, [C.POINTER(VitConfig), C.POINTER(c_i64), C.POINTER(c_i64), C.c_int]),
     "vfm_vit_workspace_bytes": (C.c_size_t, [C.POINTER(VitConfig), C.c_int]),

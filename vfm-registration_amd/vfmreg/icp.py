@@ -10,6 +10,8 @@ Termination: |dx| < 1e-4 or 1000 iterations (Registration.cpp:92-93, 183).
 The descriptor-seeded variant for rows that carry descriptors (Registration.cpp:197-382; not on the headline evaluation: every call
 site there passes [:, :3], registration_node.py:646, 929) is ``register_frame`` on 3 + D columns (round 4): 5 m subset ->
 GetVFMCorrespondences(0.8) on the GPU -> Gauss-Newton on those pairs with median + 1.5 MAD pruning -> the vanilla loop.
+Rows of any OTHER width > 3 take RegisterFrame(std::vector<Eigen::VectorXd> ...) (Registration.cpp:384-423; round 6): the 3-D loop whose
+search weighs the squared distance of a neighbour by the cosine distance of the descriptors (VoxelHashMap.cpp:321-448).
 """
 from __future__ import annotations
 
@@ -217,6 +219,92 @@ def _register_frame_nd(points: np.ndarray, voxel_map, initial_guess: np.ndarray,
     return pose, src_moved.cpu().numpy(), tgt_3d.cpu().numpy()
 
 
+POINT_SIZE = 3 + 384   # kiss_icp_pybind._point_size(): 3 + DESCRIPTOR_SIZE, a compile-time 384 (DescriptorSize.hpp:7) -- the width that
+                       # takes the descriptor-seeded RegisterFrame; every other width > 3 takes the VectorXd one (registration.py:37-42)
+
+
+class _DescGrid:
+    """The ICP grid of a map's rows WITH their descriptor columns (what VoxelHashMap::GetCorrespondences(VectorXdVector) reads from
+    map_x_): the CSR of ``VoxelGridDevice`` + the descriptor rows in its order as fp64 + their norms / "element sum != 0" flags."""
+
+    def __init__(self, rows: np.ndarray, voxel_size: float):
+        lib = _lib.load()
+        rows = np.asarray(rows, dtype=np.float64)
+        pts = np.ascontiguousarray(rows[:, :3])
+        v = np.trunc(pts / voxel_size).astype(np.int64)
+        if len(v) and (np.abs(v).max() >= (1 << 20) - 1):
+            raise ValueError("voxel coordinate outside +-2^20 voxels: shift the clouds towards the origin")
+        v = v + (1 << 20)
+        keys = (v[:, 0] << 42) | (v[:, 1] << 21) | v[:, 2]
+        order = np.argsort(keys, kind="stable")
+        uniq, first = np.unique(keys[order], return_index=True)
+        self.voxel_size = float(voxel_size)
+        self.n_voxels = len(uniq)
+        self.f = rows.shape[1] - 3
+        self.keys = torch.from_numpy(np.ascontiguousarray(uniq)).cuda()
+        self.start = torch.from_numpy(np.r_[first, len(order)].astype(np.int32)).cuda()
+        self.pts = torch.from_numpy(np.ascontiguousarray(pts[order])).cuda()
+        self.desc = torch.from_numpy(np.ascontiguousarray(rows[order, 3:])).cuda()
+        self.norm = torch.empty(len(order), dtype=torch.float64, device="cuda")
+        self.has = torch.empty(len(order), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.vfm_icp_desc_stats(self.desc.data_ptr(), len(order), self.f, self.norm.data_ptr(), self.has.data_ptr(), ops._stream()),
+                   "icp_desc_stats")
+
+
+def _register_frame_xd(points: np.ndarray, voxel_map, initial_guess: np.ndarray, max_correspondance_distance: float, kernel: float):
+    """RegisterFrame(std::vector<Eigen::VectorXd> ...) (Registration.cpp:384-423): the 3-D loop with the descriptor-weighted nearest
+    neighbour of VoxelHashMap.cpp:321-448 as its search (csrc/icp.hip icp_nearest_desc_kernel).  Every iterate equals the oracle's
+    (oracle.register_frame_xd) bit for bit."""
+    lib = _lib.load()
+    st = ops._stream()
+    g = getattr(voxel_map, "_icp_desc_grid", None)
+    rows_n = voxel_map._cloud("n")
+    if g is None or g[0] != len(rows_n[0]):
+        g = (len(rows_n[0]), _DescGrid(voxel_map.point_cloud_n(), voxel_map.voxel_size))
+        voxel_map._icp_desc_grid = g
+    g = g[1]
+    pts = np.asarray(points, dtype=np.float64)
+    n, f = pts.shape[0], pts.shape[1] - 3
+    cur = torch.from_numpy(np.ascontiguousarray(pts[:, :3])).cuda()
+    sdesc = torch.from_numpy(np.ascontiguousarray(pts[:, 3:])).cuda()
+    snorm = torch.empty(n, dtype=torch.float64, device="cuda")
+    shas = torch.empty(n, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.vfm_icp_desc_stats(sdesc.data_ptr(), n, f, snorm.data_ptr(), shas.data_ptr(), st), "icp_desc_stats")
+    source = torch.empty_like(cur)
+    tgt = torch.empty_like(cur)
+    valid = torch.empty(n, dtype=torch.uint8, device="cuda")
+    out = torch.empty(43, dtype=torch.float64, device="cuda")
+    out_h = torch.empty(43, dtype=torch.float64).pin_memory()
+    step = np.ascontiguousarray(initial_guess, dtype=np.float64)    # Equation (9), applied by the first launch
+    T_icp = np.eye(4)
+    for j in range(MAX_NUM_ITERATIONS):
+        Th = np.ascontiguousarray(step, dtype=np.float64)
+        _lib.check(lib.vfm_icp_step_nearest_desc(cur.data_ptr(), n, Th.ctypes.data, source.data_ptr(), sdesc.data_ptr(), snorm.data_ptr(),
+                                                 shas.data_ptr(), f, g.keys.data_ptr(), g.start.data_ptr(), g.pts.data_ptr(),
+                                                 g.desc.data_ptr(), g.norm.data_ptr(), g.has.data_ptr(), g.n_voxels, g.voxel_size,
+                                                 float(max_correspondance_distance), tgt.data_ptr(), valid.data_ptr(), st),
+                   "icp_step_nearest_desc")
+        cur = source
+        _lib.check(lib.vfm_icp_build_system(source.data_ptr(), tgt.data_ptr(), valid.data_ptr(), n, float(kernel), out.data_ptr(), st),
+                   "icp_build_system")
+        out_h.copy_(out, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        o = out_h.numpy()
+        if j == 0:
+            print(f"[XD] [{j}] correspondences {int(o[42])}")          # Registration.cpp:400
+        if o[42] == 0:
+            break
+        dx = _solve6(o[:36].reshape(6, 6), -o[36:42])
+        if dx is None:
+            break
+        estimation = se3_exp(dx)
+        step = estimation
+        T_icp = estimation @ T_icp
+        if np.linalg.norm(dx) < ESTIMATION_THRESHOLD:
+            break
+    return T_icp @ initial_guess
+
+
 def register_frame(points: np.ndarray, voxel_map, initial_guess: np.ndarray, max_correspondance_distance: float,
                    kernel: float, src_=None, tgt_=None):
     points = np.asarray(points)
@@ -224,11 +312,17 @@ def register_frame(points: np.ndarray, voxel_map, initial_guess: np.ndarray, max
         raise ValueError("Invalid shape")  # registration.py:43
     initial_guess = np.ascontiguousarray(initial_guess, dtype=np.float64)
     if points.shape[1] != 3:
-        # registration.py:37-66: rows of _point_size() columns take the descriptor-seeded RegisterFrame and return the surviving pairs
-        # when the caller passed src_ / tgt_; other widths (VectorXd: a nearest-neighbour search on all columns) are not built
+        # registration.py:37-66: rows of _point_size() = 387 columns take the descriptor-seeded RegisterFrame and return the surviving pairs
+        # when the caller passed src_ / tgt_; every other width > 3 takes RegisterFrame(VectorXd ...) (Registration.cpp:384-423, round 6):
+        # the 3-D loop with the descriptor-weighted nearest neighbour as its search, against the map's rows of the same width (the
+        # reference keeps those in map_x_; here the wide rows of a map live in one container whatever their width)
         ncols = None if voxel_map.empty_n() else voxel_map._cloud("n")[0].shape[1]
         if ncols is not None and points.shape[1] != ncols:
-            raise NotImplementedError("register_frame on rows that are neither 3-D nor of the map's descriptor width (Registration.cpp:384-423)")
+            raise ValueError("Invalid shape")   # (rows of a width the map does not hold: the reference's map_x_ would be empty or of another width)
+        if points.shape[1] != POINT_SIZE:
+            if voxel_map.empty_n():
+                return initial_guess                                # Registration.cpp:389
+            return _register_frame_xd(points, voxel_map, initial_guess, max_correspondance_distance, kernel)
         if voxel_map.empty_n():
             pose, s_out, t_out = initial_guess, np.asarray(src_ if src_ is not None else [[0, 0, 0]], dtype=np.float64), \
                 np.asarray(tgt_ if tgt_ is not None else [[0, 0, 0]], dtype=np.float64)   # Registration.cpp:204
