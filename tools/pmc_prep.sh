@@ -16,11 +16,11 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list)); dur = coll
 for f in sorted(glob.glob("$O/p*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         if "prep_" in r["Kernel_Name"]:
-            agg[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("vfmm::(anonymous namespace)::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[r["Kernel_Name"].replace("void ", "").replace("vfmm::(anonymous namespace)::", "").split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in sorted(glob.glob("$O/p*_kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
         if "prep_" in r["Kernel_Name"]:
-            dur[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("vfmm::(anonymous namespace)::", "")].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            dur[r["Kernel_Name"].replace("void ", "").replace("vfmm::(anonymous namespace)::", "").split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print("operand preparation at C2 (20 000 + 200 000 rows x 384 fp32 = 338 MB in; int8 image + fp6 half image + per-row data out), flags 24;")
 print("HBM bytes = 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE, per launch; duration under the counters")
 for k, v in agg.items():
