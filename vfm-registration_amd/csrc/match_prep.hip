@@ -1046,8 +1046,10 @@ __global__ __launch_bounds__(256, 2) void prep_once_kernel(const float* __restri
         float e2 = 0.0f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float qf = rintf(nv[e] * inv_qstep);
-            qf = fminf(fmaxf(qf, -127.0f), 127.0f);
+            // (no clamp: |h| <= fp16(amax) <= amax (1 + 2^-11) and inv_qstep <= (127 / amax)(1 + 2^-24), so |h inv_qstep| < 127.07 and the
+            // rounded value is within [-127, 127] by itself -- two of this loop's eight VALU operations per element, in a kernel the
+            // ablations put on the VALU (profiles/r06_ablations_prep_once.txt).  A NaN element converts to code 0; its row's E is infinite.)
+            const float qf = rintf(nv[e] * inv_qstep);
             const float res = __builtin_fmaf(-qstep, qf, nv[e]);
             e2 = __builtin_fmaf(res, res, e2);
             qi[e] = (int)qf;
