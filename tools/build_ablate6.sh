@@ -1,7 +1,7 @@
 #!/bin/bash
 # builds timing-experiment variants of the fp6 coarse kernel next to the real library (results of such builds are garbage):
 #   tools/build_ablate6.sh NAME:"-DVFM_ABL_NOFOLD -DVFM_ABL_NOLDS" ...   ->  vfmreg/lib/libvfmreg_hip_NAME.so
-# switches (csrc/match_coarse_mx6.hip): VFM_ABL_NOFOLD, _NOLDS, _NODMA, _NOBAR, _NOEMIT, _NOSCALE
+# switches (csrc/match_coarse_mx6.hip): VFM_ABL_NOFOLD, _NOLDS, _NODMA, _NOBAR, _NOEMIT, _NOSCALE, _NOCMP, _NOTAB, _EMITSB
 set -e
 cd "$(dirname "$0")/../vfm-registration_amd"
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden"

@@ -271,6 +271,9 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
                 many |= m[j];
                 s1[j] = -__builtin_inff();
             }
+#ifdef VFM_ABL_NOCMP   // (timing experiment: nothing ever survives)
+            many = 0u;
+#endif
             if (valid && many != 0u) {   // rare: 0.56 survivors per query and 1564 chunks on D.2 data
                 // (a list that has overflowed -- descriptors that are all alike -- takes no more entries: the search's guard goes up at
                 // the end of the workgroup and match_gatepass_kernel decides every query; `seen` is a chunk old, the cap is exact)
@@ -321,8 +324,12 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
             }
         }
         const int cn = ci + 1 < nch ? ci + 1 : nch - 1;
+#ifndef VFM_ABL_NOTAB
         tab = ltab[cn];   // for the next call (broadcast reads, consumed a chunk later: nothing waits for them here)
         if constexpr (FUSE) seen = llist[vzero];   // (through a per-lane zero: a uniform read would be moved to an SGPR on the spot -- lgkmcnt(0))
+#else
+        (void)cn;
+#endif
     };
 
     floatx16 accA[NS], accB[NS];
@@ -419,10 +426,16 @@ __global__ __launch_bounds__(512, 2) void match_coarse_mx6q2_kernel(CoarseArgs a
                 // the next chunk, in front of this slot's folds (which start that chunk's maxima) --, not between two tiles: the matrix
                 // pipe has 64 cycles of work while the compares, the scalar masks and the branch resolve.  (Between the tiles it was a
                 // hole in every wave of the workgroup at the same time: 10 % of the kernel in tools/ablate6.py's timings.)
+                // (No scheduling barriers around it: the compiler spreads the compares and the scalar masks through the slot's folds.  With the
+                // two barriers -- rounds 4 and 5 -- the kernel is 1.5 % slower, tools/ab_two_libs_coarse.py; VFM_ABL_EMITSB puts them back.)
                 if constexpr (s == 0 && (J & 3) == 1) {
+#ifdef VFM_ABL_EMITSB
                     __builtin_amdgcn_sched_barrier(0);
+#endif
                     emit_chunk(ck + (J >> 2) - 1);
+#ifdef VFM_ABL_EMITSB
                     __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
 #endif
                 if constexpr (s == 0 && (J & 3) == 3) next_thr();
