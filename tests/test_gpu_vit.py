@@ -183,6 +183,27 @@ def test_vit_attention_with_keys_and_values_in_the_lds_equals_the_per_tile_kerne
         lib.vfm_debug_set_vit_gemm(-7, 1)
 
 
+def test_vit_qkv_and_attention_in_one_workgroup_equal_the_two_kernels_bit_for_bit():
+    """vit_qkv_attention_kernel (round 6: q, K and V^T of an (image, head) never leave the compute unit) against the QKV GEMM + the attention
+    kernel: the same MFMAs over the same fragments in the same k order and the same epilogue arithmetic -- identical bits.  Token counts
+    with 9, 10, 11 and 12 tiles (the waves' last tiles missing or not), image counts that are no multiple of 8 (the XCD mapping's empty
+    slots), one layer and twelve; a width the kernel is not built for (768) takes the two kernels whatever the key says."""
+    from vfmreg import _lib
+    from vfmreg import vit as V
+    for (dim, depth, mlp, B, H, W) in ((384, 2, 1536, 5, 560, 700), (384, 1, 1536, 1, 1200, 1600), (384, 1, 1536, 9, 1200, 1800),
+                                       (384, 1, 1536, 3, 300, 200), (768, 1, 3072, 2, 560, 600), (384, 12, 1536, 13, 1200, 1600)):
+        w = V.random_weights(seed=13, dim=dim, depth=depth, mlp=mlp)
+        imgs = torch.from_numpy(_smooth_images(np.random.default_rng(4), B, H, W)).cuda()
+        model = V.ViTS14(w, H, W, device="cuda")
+        with _lib.using(_lib.Config().set("vit_fused_qkv", 0)):
+            two = model.forward(imgs).clone()
+        with _lib.using(_lib.Config().set("vit_fused_qkv", 1)):
+            one = model.forward(imgs).clone()
+        torch.cuda.synchronize()
+        assert torch.isfinite(one).all()
+        assert torch.equal(two, one), (dim, B, H, W, float((two - one).abs().max()))
+
+
 def test_vit_preprocessing_one_workgroup_per_patch_equals_the_per_unit_kernel_bit_for_bit():
     """vit_preprocess_patch_kernel (round 5: a workgroup per 14 x 14 patch, each thread's two source rows read once for the three channels,
     the token's fragment units assembled in the LDS) evaluates the expressions of round 1's kernel in the same order: identical features --

@@ -24,6 +24,8 @@ if len(sys.argv) > 5:                                      # token-stationary QK
 import os
 if os.environ.get("VFM_HOT_A") == "1":                      # timing experiment (wrong results): tools/ab_vit_hot_a.sh
     lib.vfm_debug_set_vit_gemm(-16, 1)
+if os.environ.get("VFM_FUSED_QKV"):                         # QKV + attention in one workgroup from this many images on (round 6)
+    _lib.thread_config().set("vit_fused_qkv", int(os.environ["VFM_FUSED_QKV"]))
 rng = np.random.default_rng(0)
 imgs = torch.from_numpy(rng.integers(1, 255, (nimg, 1200, 1600, 3), dtype=np.uint8)).cuda()
 model = V.ViTS14(V.random_weights(0), 1200, 1600)

@@ -1346,6 +1346,287 @@ __global__ __launch_bounds__(256, 2) void vit_attention_lds_kernel(const uint4* 
     }
 }
 
+// ---- QKV + attention of ONE (image, head) in one workgroup (round 6).  The two kernels it replaces hand q, k and V^T of
+// every token through HBM: 73 MB written and 73 MB read per layer at 90 images, of the 680 MB a layer moves.  Here they never leave the
+// compute unit.  Four waves, one per SIMD, up to 512 registers each:
+//   * wave w keeps the token tiles w, w + 4, w + 8 of the image STATIONARY in registers (24 k-steps x 4 registers each: 288) through three
+//     products -- with the head's 64 q, 64 k and 64 v rows of the folded weight, 48 KiB each, staged through two LDS slots by LDS-DMA (the
+//     next product's weights land under the current one's MFMAs).  One 1 KiB fragment read feeds three MFMAs (the token-stationary GEMM: one);
+//   * q goes from the accumulators to the B-operand layout in registers (v_permlane32_swap, as the probabilities do in the attention);
+//     K goes to the LDS in the fragment layout the score product reads (the stores of epi_tile, into the LDS);  V is computed as
+//     tokens x channels (operands swapped), so that a lane holds 4 consecutive KEYS of one channel: V^T leaves with the same 8-byte stores,
+//     no 2-byte scatter;  V^T takes the k weights' slot;
+//   * then the attention of vit_attention_lds_kernel for the wave's own query tiles, K and V^T from the LDS.
+// The six heads of an image read the same 264 KB of tokens: workgroups of one image are neighbours on ONE XCD (blockIdx % 8), so five of
+// the six reads hit that XCD's L2 (the item mapping at the top of the kernel).  D = 384 and at most 12 token tiles (vfm_vit_forward falls back to the two kernels otherwise).
+// Same MFMAs over the same fragments in the same k order, the same epilogue arithmetic: q, K, V^T and the output are bit-equal to the two
+// kernels' (tests/test_gpu_vit.py).
+template <int NKT>
+__global__ __launch_bounds__(256, 1) void vit_qkv_attention_kernel(GemmArgs g, int B, _Float16* __restrict__ out) {
+    constexpr int KS = 24;                 // k-steps of D = 384
+    constexpr int NTW = (NKT + 3) / 4;     // token tiles per wave
+    constexpr unsigned SLOT = 24u * 1024u, KR = 2u * SLOT, VR = KR + (unsigned)NKT * 4096u, STR = VR + (unsigned)NKT * 4096u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fl[];   // [2 weight slots x 24 KiB][K: NKT x 4 KiB][V^T: NKT x 4 KiB][(a, nb) per token]
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int lane = lane_id(), hi = lane >> 5, lane31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (image, head) items in image-major order, an eighth of them per XCD (workgroup i runs on XCD i % 8): the heads of an image are
+    // neighbours on one XCD -- at most one image per XCD boundary is split --, and every XCD gets the same number of workgroups (whole
+    // images per XCD: 84 images = 66 workgroups on the XCDs with 11 images, a third round on 32 compute units for 2 of them)
+    const int xcd = blockIdx.x & 7, per_xcd = (int)(gridDim.x >> 3);
+    const int item = xcd * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= B * g.heads) return;   // workgroup-uniform
+    const int b = item / g.heads, head = item - b * g.heads;
+    unsigned long long tr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (tools: phase times of the workgroup, 100 MHz ticks)
+    if (g.dbg) tr[0] = wall_clock64();
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)fl;
+    // The six 32-channel weight tiles of the head in the order k0 k1 v0 v1 q0 q1 (q last: its result stays in registers, and by then the
+    // tokens' registers are on their way out) through a ring of two 24 KiB slots: 24 consecutive 1 KiB fragment rows each, six per wave.
+    auto stage_w = [&](int n) __attribute__((always_inline)) {
+        const int which = n < 2 ? 1 : (n < 4 ? 2 : 0), c = n & 1;
+        const uint4* src = g.W + (size_t)((which * g.heads + head) * 2 + c) * KS * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int p = wave + 4 * i;
+            vit_glds16(src + (size_t)p * 64, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(n & 1) * SLOT + (unsigned)p * 1024u));
+        }
+    };
+    stage_w(0);
+    stage_w(1);
+    u32x4 tok[NTW][KS];
+    float ln_a[NTW], ln_nb[NTW];
+    float2* st_l = reinterpret_cast<float2*>(fl + STR);
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int tile = wave + 4 * i;
+        const int tl = tile < NKT ? tile : NKT - 1;   // (a tile past the image: this wave multiplies the last one again and drops the result)
+        const u32x4* Ap = reinterpret_cast<const u32x4*>(g.A) + (size_t)(b * NKT + tl) * KS * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) tok[i][s] = Ap[(size_t)s * 64];
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int tile = wave + 4 * i;
+        const int tl = tile < NKT ? tile : NKT - 1;
+        ln_stats_load(g, (b * NKT + tl) * 32 + lane31, ln_a[i], ln_nb[i]);
+        if (tile < NKT && hi == 0) st_l[tile * 32 + lane31] = make_float2(ln_a[i], ln_nb[i]);
+    }
+    vit_wait_vmcnt<0>();
+    // Where the stationary fragments live is not left to the register allocator (it split them between the two files in a way that
+    // needed 76 spills, reloaded from scratch inside the k-loop): tiles 0 and 1 in accumulation registers -- an MFMA reads its operands from
+    // either file --, tile 2 and everything the VALU touches in the architectural ones.
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (i < 2) asm volatile("" : "+a"(tok[i][s]));
+            else asm volatile("" : "+v"(tok[i][s]));
+        }
+    if (g.dbg) tr[1] = wall_clock64();
+    const unsigned lane_off = (unsigned)lane31 * 16u + 8u * (unsigned)hi;
+    floatx16 acc[NTW];
+    uint4 qf[NTW][4];   // q as the B operand of the score product: 4 k-steps over the head's 64 channels
+    // One wave per SIMD: nobody covers an LDS round trip (~130 cycles against the 96 of a k-step's three MFMAs), so the weight fragments
+    // come through a ring of PF registers, read PF k-steps ahead (left to the compiler the loop was read - wait - multiply).
+    auto run_tile = [&](auto Nc) __attribute__((always_inline)) {
+        constexpr int n = decltype(Nc)::value;
+        constexpr int which = n < 2 ? 1 : (n < 4 ? 2 : 0), c = n & 1;
+        constexpr bool SW = which == 2;   // V as tokens x channels
+        // tile n has landed (this wave's pieces: issued a tile ago; the others': the barrier); everybody has left tile n - 1: its slot takes tile n + 1
+        vit_wait_vmcnt<0>();
+        __syncthreads();
+        if constexpr (n >= 1 && n + 1 < 6) stage_w(n + 1);
+        constexpr int PF = 4;
+        const unsigned char* wp = fl + (unsigned)(n & 1) * SLOT + (unsigned)lane * 16u;
+        half8 wr[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) wr[i] = *reinterpret_cast<const half8*>(wp + (unsigned)i * 1024u);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const half8 wv = wr[s % PF];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                const half8 tv = *reinterpret_cast<const half8*>(&tok[i][s]);
+                if constexpr (SW) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tv, wv, acc[i], 0, 0, 0);
+                else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, tv, acc[i], 0, 0, 0);
+            }
+            if (s + PF < KS) wr[s % PF] = *reinterpret_cast<const half8*>(wp + (unsigned)(s + PF) * 1024u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int n32 = __builtin_amdgcn_readfirstlane((which * g.heads + head) * 2 + c);
+        if constexpr (SW) {
+            // V^T: rows = the head's 64 channels (2 tiles), k = keys (2 NKT k-steps); a lane holds channel lane31 and keys 8 grp + 4 hi .. + 3 of a tile
+            const float bv = g.bias[n32 * 32 + lane31], cv = g.csum[n32 * 32 + lane31];
+            const f2 B2 = splat2(bv), C2 = splat2(cv);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                const int tile = wave + 4 * i;
+                if (tile >= NKT) continue;
+                unsigned char* vb = fl + VR + (unsigned)(c * (2 * NKT) * 2 + tile * 4) * 512u + lane_off;
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp) {
+                    const float4 s01 = *reinterpret_cast<const float4*>(st_l + tile * 32 + 8 * grp + 4 * hi);       // (a, nb) of keys + 0, + 1
+                    const float4 s23 = *reinterpret_cast<const float4*>(st_l + tile * 32 + 8 * grp + 4 * hi + 2);   // + 2, + 3
+                    const f2 v01 = fma2(f2{acc[i][grp * 4 + 0], acc[i][grp * 4 + 1]}, f2{s01.x, s01.z}, fma2(f2{s01.y, s01.w}, C2, B2));
+                    const f2 v23 = fma2(f2{acc[i][grp * 4 + 2], acc[i][grp * 4 + 3]}, f2{s23.x, s23.z}, fma2(f2{s23.y, s23.w}, C2, B2));
+                    *reinterpret_cast<half4*>(vb + 512u * grp) = to_half4(v01, v23);
+                }
+            }
+        } else {
+            // per-channel operands of the tile in the accumulator's row order (epi_load's)
+            float4 bias[4], csum[4];
+            const char* bias_b = reinterpret_cast<const char*>(g.bias + n32 * 32);
+            const char* csum_b = reinterpret_cast<const char*>(g.csum + n32 * 32);
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                bias[grp] = *reinterpret_cast<const float4*>(bias_b + (16u * (unsigned)hi + 32u * grp));
+                csum[grp] = *reinterpret_cast<const float4*>(csum_b + (16u * (unsigned)hi + 32u * grp));
+            }
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                const int tile = wave + 4 * i;
+                const f2 A2 = splat2(ln_a[i]), NB2 = splat2(ln_nb[i]);
+                f2 v01[4], v23[4];
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp) {
+                    v01[grp] = fma2(f2{acc[i][grp * 4 + 0], acc[i][grp * 4 + 1]}, A2, fma2(NB2, f2{csum[grp].x, csum[grp].y}, f2{bias[grp].x, bias[grp].y}));
+                    v23[grp] = fma2(f2{acc[i][grp * 4 + 2], acc[i][grp * 4 + 3]}, A2, fma2(NB2, f2{csum[grp].z, csum[grp].w}, f2{bias[grp].z, bias[grp].w}));
+                }
+                if constexpr (which == 1) {
+                    // K: fragment rows [key tile][4 k-steps][2 halves][32 keys] x 8 channels, 4 KiB per key tile (epi_tile's stores, into the LDS)
+                    if (tile < NKT) {
+                        unsigned char* kb = fl + KR + (unsigned)(tile * 8 + c * 4) * 512u + lane_off;
+#pragma unroll
+                        for (int grp = 0; grp < 4; ++grp) *reinterpret_cast<half4*>(kb + 512u * grp) = to_half4(v01[grp], v23[grp]);
+                    }
+                } else {
+                    unsigned pk[8];
+#pragma unroll
+                    for (int grp = 0; grp < 4; ++grp) {
+                        pk[grp * 2 + 0] = pack_f16x2(v01[grp][0], v01[grp][1]);
+                        pk[grp * 2 + 1] = pack_f16x2(v23[grp][0], v23[grp][1]);
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {   // channels 16 s2 .. + 15 of the tile: groups 2 s2 (lower lanes' half) and 2 s2 + 1 (upper lanes')
+                        auto r0 = __builtin_amdgcn_permlane32_swap(pk[4 * s2 + 0], pk[4 * s2 + 2], false, false);
+                        auto r1 = __builtin_amdgcn_permlane32_swap(pk[4 * s2 + 1], pk[4 * s2 + 3], false, false);
+                        qf[i][c * 2 + s2] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                    }
+                }
+            }
+        }
+    };
+    run_tile(std::integral_constant<int, 0>{});
+    run_tile(std::integral_constant<int, 1>{});
+    if (g.dbg) tr[2] = wall_clock64();
+    run_tile(std::integral_constant<int, 2>{});
+    run_tile(std::integral_constant<int, 3>{});
+    if (g.dbg) tr[3] = wall_clock64();
+    run_tile(std::integral_constant<int, 4>{});
+    run_tile(std::integral_constant<int, 5>{});
+    __syncthreads();   // K and V^T are complete
+    if (g.dbg) tr[4] = wall_clock64();
+    // ---- attention of the wave's query tiles (vit_attention_lds_kernel's body)
+    const uint4* K_l = reinterpret_cast<const uint4*>(fl + KR);
+    const uint4* VT_l = reinterpret_cast<const uint4*>(fl + VR);
+    constexpr int vks = 2 * NKT;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {   // (unrolled: indexed by a loop counter, qf went to the stack)
+        const int qt = wave + 4 * i;
+        if (qt >= NKT) break;
+        uint4 q4[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) q4[s] = qf[i][s];
+        floatx16 S[NKT];
+        {   // (fragments through a ring, PFK reads ahead: see `product`)
+            constexpr int PFK = 6, NP = 4 * NKT;
+            uint4 kr[PFK];
+#pragma unroll
+            for (int p = 0; p < PFK; ++p) kr[p] = K_l[(size_t)(p < NP ? p : NP - 1) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int p = kt * 4 + s;
+                    S[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&kr[p % PFK]), *reinterpret_cast<half8*>(&q4[s]), S[kt], 0, 0, 0);
+                    if (p + PFK < NP) kr[p % PFK] = K_l[(size_t)(p + PFK) * 64 + lane];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (g.dbg && i == 0) tr[7] = wall_clock64();
+        const float inv = att_softmax<NKT>(S, g.T, hi);
+        if (g.dbg && i == 0) tr[8] = wall_clock64();
+        floatx16 O0, O1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { O0[r] = 0.f; O1[r] = 0.f; }
+        {
+            constexpr int PFV = 3;
+            uint4 vr0[PFV], vr1[PFV];
+#pragma unroll
+            for (int p = 0; p < PFV; ++p) {
+                vr0[p] = VT_l[((size_t)0 * vks + (p < vks ? p : vks - 1)) * 64 + lane];
+                vr1[p] = VT_l[((size_t)1 * vks + (p < vks ? p : vks - 1)) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    unsigned x0 = pack_f16x2(S[kt][8 * s2 + 0], S[kt][8 * s2 + 1]);
+                    unsigned x1 = pack_f16x2(S[kt][8 * s2 + 2], S[kt][8 * s2 + 3]);
+                    unsigned y0 = pack_f16x2(S[kt][8 * s2 + 4], S[kt][8 * s2 + 5]);
+                    unsigned y1 = pack_f16x2(S[kt][8 * s2 + 6], S[kt][8 * s2 + 7]);
+                    auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+                    uint4 pb;
+                    pb.x = r0[0]; pb.y = r1[0]; pb.z = r0[1]; pb.w = r1[1];
+                    const half8 pf = *reinterpret_cast<half8*>(&pb);
+                    const int ks = kt * 2 + s2;
+                    O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&vr0[ks % PFV]), pf, O0, 0, 0, 0);
+                    O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&vr1[ks % PFV]), pf, O1, 0, 0, 0);
+                    if (ks + PFV < vks) {
+                        vr0[ks % PFV] = VT_l[((size_t)0 * vks + ks + PFV) * 64 + lane];
+                        vr1[ks % PFV] = VT_l[((size_t)1 * vks + ks + PFV) * 64 + lane];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (g.dbg && i == 0) tr[9] = wall_clock64();
+        const int m = b * g.Tp + qt * 32 + lane31;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const floatx16& O = half ? O1 : O0;
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                const int dd = half * 32 + 8 * grp + 4 * hi;
+                half4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (_Float16)(O[grp * 4 + j] * inv);
+                *reinterpret_cast<half4*>(out + frag_index(m, head * 64 + dd, g.D / 16)) = o;
+            }
+        }
+        if (g.dbg && i == 0) tr[5] = wall_clock64();
+    }
+    if (g.dbg && wave == 0 && lane == 0) {
+        tr[6] = wall_clock64();
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+#pragma unroll
+        for (int k = 0; k < 10; ++k) g.dbg[(size_t)blockIdx.x * 16 + k] = tr[k];
+        g.dbg[(size_t)blockIdx.x * 16 + 10] = xcc & 0xf;
+    }
+}
+
 struct VitWs {
     float* x;          // [M][D] fp32 residual
     _Float16* a;       // [M][max(D, KP)] fragment tiles (im2col / attention out)
@@ -1436,7 +1717,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
             attr_set |= 1ull << (dev & 63);                                                                                          \
         }                                                                                                                            \
         GemmArgs ga = g;                                                                                                             \
-        ga.dbg = vfm_cfg().vit_astat_dbg;                                                                                                    \
+        ga.dbg = vfm_cfg().vit_trace_fused ? nullptr : vfm_cfg().vit_astat_dbg;                                                                                                    \
         hipLaunchKernelGGL((vit_gemm_astat_kernel<EPI, NW, 6>), dim3(groups), dim3(64 * NW), 4 * g.KS * 1024, st, ga);               \
     } while (0)
             if (vfm_cfg().vit_astat_two && (g.N / 64) >= 8 && g.N % 64 == 0 && g.KS % 4 == 0) {   // two channel tiles per wave, eight waves (round 5)
@@ -1464,7 +1745,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
                         attr_set2 |= 1ull << (dev & 63);
                     }
                     GemmArgs ga = g;
-                    ga.dbg = vfm_cfg().vit_astat_dbg;
+                    ga.dbg = vfm_cfg().vit_trace_fused ? nullptr : vfm_cfg().vit_astat_dbg;
                     hipLaunchKernelGGL((vit_gemm_astat_kernel<EPI, 12, 6, true>), dim3(groups), dim3(768), 4 * g.KS * 1024, st, ga);
                 } break;
                 case 8: VIT_ASTAT(8); break;
@@ -1481,7 +1762,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         if (wgs >= vfm_cfg().vit_lds_min_wg) {
             GemmArgs gl = g;
             gl.hot_a = vfm_cfg().vit_hot_a;
-            gl.dbg = EPI == EPI_RESID ? vfm_cfg().vit_astat_dbg : nullptr;   // (the trace buffer serves whichever kernel a tool looks at)
+            gl.dbg = EPI == EPI_RESID && !vfm_cfg().vit_trace_fused ? vfm_cfg().vit_astat_dbg : nullptr;   // (the trace buffer serves whichever kernel a tool looks at)
             if (EPI == EPI_RESID && g.N == 384 && vfm_cfg().vit_wide_tile && g.KS % 2 == 0) {   // one workgroup per 128 tokens x all 384 channels (NG = 3)
                 const int gridw = 8 * ceil_div(ceil_div(g.M / 32, 4), 8);
                 constexpr int ldsw = 4 * 16 * 2 * 1024;   // NS = 4 stages of (4 + 12) x KB = 2 KiB: 128 KiB
@@ -1606,11 +1887,39 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
     // K / V^T of an (image, head) shared by four query tiles through the LDS from vfm_cfg().vit_att_lds_min images on (0: never): at one scan the
     // one-wave-per-tile kernel's 396 waves spread over the chip win, at batches the shared form reads a quarter of the L2 bytes
     const bool att_lds = vfm_cfg().vit_att_lds_min > 0 && d.B >= vfm_cfg().vit_att_lds_min && d.Tp / 32 <= 16;
+    // QKV + attention per (image, head) in one workgroup (vit_qkv_attention_kernel) from vfm_cfg().vit_fused_qkv images on (0: never)
+    const bool fused_qkv = vfm_cfg().vit_fused_qkv > 0 && d.B >= vfm_cfg().vit_fused_qkv && d.D == 384 && d.Tp / 32 <= 12;
     for (int l = 0; l < d.depth; ++l) {
         const int s0 = SEG_LAYER0 + l * SEGS_PER_LAYER;
         // LayerNorm 1 is inside this GEMM: raw residual stream x folded weight, statistics applied in the epilogue
         g.A = reinterpret_cast<const uint4*>(w.xh); g.W = f16(s0 + L_QKV_W); g.bias = f32(s0 + L_QKV_B); g.csum = f32(s0 + L_QKV_C);
         g.N = 3 * d.D; g.KS = d.D / 16;
+        if (fused_qkv) {
+#define VIT_FQA(NKT)                                                                                                      \
+    do {                                                                                                                  \
+        constexpr int lds_ = 48 * 1024 + 2 * NKT * 4096 + NKT * 32 * 8;                                                       \
+        static std::atomic<unsigned long long> attr_set{0ull};                                                            \
+        int dev_ = 0;                                                                                                     \
+        (void)hipGetDevice(&dev_);                                                                                        \
+        if (!((attr_set >> (dev_ & 63)) & 1ull)) {                                                                        \
+            VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_qkv_attention_kernel<NKT>),             \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_));                         \
+            attr_set |= 1ull << (dev_ & 63);                                                                              \
+        }                                                                                                                 \
+        GemmArgs gf = g;                                                                                                  \
+        gf.dbg = vfm_cfg().vit_trace_fused ? vfm_cfg().vit_astat_dbg : nullptr;                                                                             \
+        hipLaunchKernelGGL(vit_qkv_attention_kernel<NKT>, dim3(8 * ceil_div(d.B * d.heads, 8)), dim3(256), lds_, st, gf, d.B, w.a);       \
+    } while (0)
+            switch (d.Tp / 32) {
+                case 1: VIT_FQA(1); break;   case 2: VIT_FQA(2); break;   case 3: VIT_FQA(3); break;
+                case 4: VIT_FQA(4); break;   case 5: VIT_FQA(5); break;   case 6: VIT_FQA(6); break;
+                case 7: VIT_FQA(7); break;   case 8: VIT_FQA(8); break;   case 9: VIT_FQA(9); break;
+                case 10: VIT_FQA(10); break; case 11: VIT_FQA(11); break;
+                default: VIT_FQA(12); break;
+            }
+#undef VIT_FQA
+            VFM_CHECK_LAUNCH("vit_qkv_attention_kernel");
+        } else {
         if ((rc = launch_gemm<EPI_QKV>(g, st))) return rc;
 #define VIT_ATT(NKT)                                                                                                      \
     if (att_lds) {                                                                                                        \
@@ -1639,6 +1948,7 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
         }
 #undef VIT_ATT
         VFM_CHECK_LAUNCH("vit_attention_kernel");
+        }
         g.A = reinterpret_cast<const uint4*>(w.a); g.W = f16(s0 + L_PROJ_W); g.bias = f32(s0 + L_PROJ_B);
         g.gamma = f32(s0 + L_LS1); g.N = d.D; g.KS = d.D / 16;
         if ((rc = launch_gemm<EPI_RESID>(g, st))) return rc;
