@@ -23,6 +23,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the fp64 / fp32 parity kernels must not fuse a*b+c
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
+# per-file additions.  vit.hip: MFMA results in architectural registers -- vit_qkv_attention_kernel runs one wave per SIMD with 512 registers, and
+# with the accumulators in the accumulation file every value the softmax and the epilogues touch was moved across first (936 v_accvgpr_read
+# in 5 900 instructions); the kernels that stay under 256 registers do not change
+FILE_FLAGS = {"vit.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 SOURCES = ["error.cpp", "config.cpp", "match_api.hip", "match_prep.hip", "match_coarse_f16.hip", "match_coarse_i8.hip", "match_coarse_mx6.hip", "match_finish.hip",
            "match_l2.hip", "ransac.hip", "project.hip", "vit.hip", "icp.hip", "voxel.hip"]
 
@@ -45,7 +49,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         src, obj = pair
         if not force and not _stale(obj, [src] + headers):
             return
-        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.suffix == ".cpp" else []) + ["-c", str(src), "-o", str(obj)]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src.name, []) + (["-x", "hip"] if src.suffix == ".cpp" else []) + ["-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -1396,36 +1396,53 @@ __global__ __launch_bounds__(256, 1) void vit_qkv_attention_kernel(GemmArgs g, i
     u32x4 tok[NTW][KS];
     float ln_a[NTW], ln_nb[NTW];
     float2* st_l = reinterpret_cast<float2*>(fl + STR);
+    // Issue order = completion order: weights of tiles 0 and 1, the tokens' LayerNorm sums, then the token fragments k-step by k-step -- the
+    // first product starts on the first k-steps while the rest of the wave's 72 KiB is on its way (the compiler's own vmcnt before each
+    // fragment's first use; waited for as a whole, the loads were 4.9 us of a workgroup's 32 with every compute unit asking at once).
+    float4 sraw[NTW][6];
+    const u32x4* Ap[NTW];
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         const int tile = wave + 4 * i;
         const int tl = tile < NKT ? tile : NKT - 1;   // (a tile past the image: this wave multiplies the last one again and drops the result)
-        const u32x4* Ap = reinterpret_cast<const u32x4*>(g.A) + (size_t)(b * NKT + tl) * KS * 64 + lane;
+        Ap[i] = reinterpret_cast<const u32x4*>(g.A) + (size_t)(b * NKT + tl) * KS * 64 + lane;
+        const float4* sp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(g.stats) + (unsigned)((b * NKT + tl) * 32 + lane31) * 12u * 8u);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) tok[i][s] = Ap[(size_t)s * 64];
+        for (int k = 0; k < 6; ++k) sraw[i][k] = sp[k];
     }
+    // (a compute unit's vector memory path takes 64 B per clock: the 288 KiB of its four waves' fragments are 4 600 cycles of ISSUE, in
+    // order, before a wave's first MFMA if they are all requested up front -- the first PRE k-steps here, the rest from inside the first
+    // product's k-loop, PRE k-steps ahead)
+    constexpr int PRE = 6;
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        const int tile = wave + 4 * i;
-        const int tl = tile < NKT ? tile : NKT - 1;
-        ln_stats_load(g, (b * NKT + tl) * 32 + lane31, ln_a[i], ln_nb[i]);
-        if (tile < NKT && hi == 0) st_l[tile * 32 + lane31] = make_float2(ln_a[i], ln_nb[i]);
-    }
-    vit_wait_vmcnt<0>();
+    for (int s = 0; s < PRE; ++s)
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) tok[i][s] = Ap[i][(size_t)s * 64];
     // Where the stationary fragments live is not left to the register allocator (it split them between the two files in a way that
     // needed 76 spills, reloaded from scratch inside the k-loop): tiles 0 and 1 in accumulation registers -- an MFMA reads its operands from
-    // either file --, tile 2 and everything the VALU touches in the architectural ones.
-#pragma unroll
-    for (int i = 0; i < NTW; ++i)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            if (i < 2) asm volatile("" : "+a"(tok[i][s]));
-            else asm volatile("" : "+v"(tok[i][s]));
-        }
+    // either file --, tile 2 and everything the VALU touches in the architectural ones.  (Pinned at their first use, in tile 0's k-loop.)
     if (g.dbg) tr[1] = wall_clock64();
     const unsigned lane_off = (unsigned)lane31 * 16u + 8u * (unsigned)hi;
     floatx16 acc[NTW];
     uint4 qf[NTW][4];   // q as the B operand of the score product: 4 k-steps over the head's 64 channels
+    // (the tokens' (a, nb) from the sums requested first: consumed behind the first product's k-loop, whose start they would hold up)
+    auto finish_stats = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {   // (ln_stats_load's arithmetic on the sums of D / 32 = 12 slices)
+            float sx = 0.f, sq = 0.f;
+    #pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                sx += sraw[i][k].x; sq += sraw[i][k].y;
+                sx += sraw[i][k].z; sq += sraw[i][k].w;
+            }
+            const float mean = sx * g.invD;
+            const float var = fmaxf(__builtin_fmaf(sq, g.invD, -(mean * mean)), 0.0f);
+            ln_a[i] = __builtin_amdgcn_rsqf(var + 1e-6f);
+            ln_nb[i] = -(ln_a[i] * mean);
+            const int tile = wave + 4 * i;
+            if (tile < NKT && hi == 0) st_l[tile * 32 + lane31] = make_float2(ln_a[i], ln_nb[i]);
+        }
+};
     // One wave per SIMD: nobody covers an LDS round trip (~130 cycles against the 96 of a k-step's three MFMAs), so the weight fragments
     // come through a ring of PF registers, read PF k-steps ahead (left to the compiler the loop was read - wait - multiply).
     auto run_tile = [&](auto Nc) __attribute__((always_inline)) {
@@ -1433,9 +1450,25 @@ __global__ __launch_bounds__(256, 1) void vit_qkv_attention_kernel(GemmArgs g, i
         constexpr int which = n < 2 ? 1 : (n < 4 ? 2 : 0), c = n & 1;
         constexpr bool SW = which == 2;   // V as tokens x channels
         // tile n has landed (this wave's pieces: issued a tile ago; the others': the barrier); everybody has left tile n - 1: its slot takes tile n + 1
-        vit_wait_vmcnt<0>();
+        if constexpr (n == 0) vit_wait_vmcnt<36>();   // (the weights of tiles 0 and 1: everything older than the 18 loads of sums and the PRE k-steps of fragments)
+        else vit_wait_vmcnt<0>();
         __syncthreads();
         if constexpr (n >= 1 && n + 1 < 6) stage_w(n + 1);
+        // the epilogue's per-channel operands, requested here: an L2 round trip behind the k-loop was 0.5 us per tile with nothing beside it
+        const int n32 = __builtin_amdgcn_readfirstlane((which * g.heads + head) * 2 + c);
+        float4 bias[4], csum[4];   // (q, K: the tile's 32 channels in the accumulator's row order, epi_load's; V: the lane's channel in [0].x)
+        if constexpr (SW) {
+            bias[0].x = g.bias[n32 * 32 + lane31];
+            csum[0].x = g.csum[n32 * 32 + lane31];
+        } else {
+            const char* bias_b = reinterpret_cast<const char*>(g.bias + n32 * 32);
+            const char* csum_b = reinterpret_cast<const char*>(g.csum + n32 * 32);
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                bias[grp] = *reinterpret_cast<const float4*>(bias_b + (16u * (unsigned)hi + 32u * grp));
+                csum[grp] = *reinterpret_cast<const float4*>(csum_b + (16u * (unsigned)hi + 32u * grp));
+            }
+        }
         constexpr int PF = 4;
         const unsigned char* wp = fl + (unsigned)(n & 1) * SLOT + (unsigned)lane * 16u;
         half8 wr[PF];
@@ -1449,6 +1482,13 @@ __global__ __launch_bounds__(256, 1) void vit_qkv_attention_kernel(GemmArgs g, i
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const half8 wv = wr[s % PF];
+            if constexpr (n == 0) {
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) {
+                    if (i < 2) asm volatile("" : "+a"(tok[i][s]));
+                    else asm volatile("" : "+v"(tok[i][s]));
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NTW; ++i) {
                 const half8 tv = *reinterpret_cast<const half8*>(&tok[i][s]);
@@ -1456,13 +1496,18 @@ __global__ __launch_bounds__(256, 1) void vit_qkv_attention_kernel(GemmArgs g, i
                 else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, tv, acc[i], 0, 0, 0);
             }
             if (s + PF < KS) wr[s % PF] = *reinterpret_cast<const half8*>(wp + (unsigned)(s + PF) * 1024u);
+            if constexpr (n == 0) {
+                if (s + PRE < KS) {
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i) tok[i][s + PRE] = Ap[i][(size_t)(s + PRE) * 64];
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        const int n32 = __builtin_amdgcn_readfirstlane((which * g.heads + head) * 2 + c);
+        if constexpr (n == 0) finish_stats();
         if constexpr (SW) {
             // V^T: rows = the head's 64 channels (2 tiles), k = keys (2 NKT k-steps); a lane holds channel lane31 and keys 8 grp + 4 hi .. + 3 of a tile
-            const float bv = g.bias[n32 * 32 + lane31], cv = g.csum[n32 * 32 + lane31];
-            const f2 B2 = splat2(bv), C2 = splat2(cv);
+            const f2 B2 = splat2(bias[0].x), C2 = splat2(csum[0].x);
 #pragma unroll
             for (int i = 0; i < NTW; ++i) {
                 const int tile = wave + 4 * i;
@@ -1478,15 +1523,6 @@ __global__ __launch_bounds__(256, 1) void vit_qkv_attention_kernel(GemmArgs g, i
                 }
             }
         } else {
-            // per-channel operands of the tile in the accumulator's row order (epi_load's)
-            float4 bias[4], csum[4];
-            const char* bias_b = reinterpret_cast<const char*>(g.bias + n32 * 32);
-            const char* csum_b = reinterpret_cast<const char*>(g.csum + n32 * 32);
-#pragma unroll
-            for (int grp = 0; grp < 4; ++grp) {
-                bias[grp] = *reinterpret_cast<const float4*>(bias_b + (16u * (unsigned)hi + 32u * grp));
-                csum[grp] = *reinterpret_cast<const float4*>(csum_b + (16u * (unsigned)hi + 32u * grp));
-            }
 #pragma unroll
             for (int i = 0; i < NTW; ++i) {
                 const int tile = wave + 4 * i;
@@ -1535,6 +1571,14 @@ __global__ __launch_bounds__(256, 1) void vit_qkv_attention_kernel(GemmArgs g, i
     const uint4* K_l = reinterpret_cast<const uint4*>(fl + KR);
     const uint4* VT_l = reinterpret_cast<const uint4*>(fl + VR);
     constexpr int vks = 2 * NKT;
+    // K is the same for the wave's three query tiles and the token fragments' registers are free: every wave keeps ALL of K (4 NKT fragments,
+    // 176 registers at 11 key tiles) in registers, read from the LDS once -- with a fragment read per MFMA in all four waves at once the
+    // score products ran at the LDS port's pace, twice their MFMAs' time.  V^T still streams (K + V^T + the scores are 528 registers).
+    u32x4 kreg[4 * NKT];
+#pragma unroll
+    for (int p = 0; p < 4 * NKT; ++p) kreg[p] = reinterpret_cast<const u32x4*>(K_l)[(size_t)p * 64 + lane];
+#pragma unroll
+    for (int p = 0; p < 4 * NKT; ++p) asm volatile("" : "+a"(kreg[p]));
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {   // (unrolled: indexed by a loop counter, qf went to the stack)
         const int qt = wave + 4 * i;
@@ -1543,24 +1587,13 @@ __global__ __launch_bounds__(256, 1) void vit_qkv_attention_kernel(GemmArgs g, i
 #pragma unroll
         for (int s = 0; s < 4; ++s) q4[s] = qf[i][s];
         floatx16 S[NKT];
-        {   // (fragments through a ring, PFK reads ahead: see `product`)
-            constexpr int PFK = 6, NP = 4 * NKT;
-            uint4 kr[PFK];
 #pragma unroll
-            for (int p = 0; p < PFK; ++p) kr[p] = K_l[(size_t)(p < NP ? p : NP - 1) * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);
+        for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
+            for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int p = kt * 4 + s;
-                    S[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&kr[p % PFK]), *reinterpret_cast<half8*>(&q4[s]), S[kt], 0, 0, 0);
-                    if (p + PFK < NP) kr[p % PFK] = K_l[(size_t)(p + PFK) * 64 + lane];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+            for (int s = 0; s < 4; ++s)
+                S[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&kreg[kt * 4 + s]), *reinterpret_cast<half8*>(&q4[s]), S[kt], 0, 0, 0);
         }
         if (g.dbg && i == 0) tr[7] = wall_clock64();
         const float inv = att_softmax<NKT>(S, g.T, hi);
