@@ -78,6 +78,9 @@ const char *vfm_build_info(void);
  *                        workgroup; -11 / -12 low / high half of a device pointer to its placement trace (tools); -14 preprocessing by one
  *                        workgroup per patch (1, default) / round 1's kernel (0); -15 two (default) / one channel tile per wave; -16 timing
  *                        experiment, WRONG RESULTS; -17 residual GEMMs of the LDS-tiled path as 128 x 384 tiles (1) / 128 x 128 (0, default)
+ *   "vit_fused_qkv"      QKV product + attention of an (image, head) in one workgroup (vit_qkv_attention_kernel: q, K, V^T never leave the
+ *                        compute unit; the same bits as the two kernels): 0 (default) vfm_vit_forward's policy -- ViT-S width, from 24 images per
+ *                        call on, unless a second round of workgroups would be less than a quarter full --, n > 0 from n images on, -1 never
  *   and the single fields behind the codes: "coarse_qsets", "seed_units", "select_variant", "mx6_t4", "mx6_ns3", "prep_form" (0 .. 3),
  *   "finish_short", "rescan_rows", "vit_*", "voxel_replay2", "voxel_one_launch", "voxel_trace", "voxel_grid_ppt" (vfm_config_get reads these;
  *   cfg == NULL there: what the calling thread's entry points would read now). */

@@ -195,7 +195,7 @@ def test_vit_qkv_and_attention_in_one_workgroup_equal_the_two_kernels_bit_for_bi
         w = V.random_weights(seed=13, dim=dim, depth=depth, mlp=mlp)
         imgs = torch.from_numpy(_smooth_images(np.random.default_rng(4), B, H, W)).cuda()
         model = V.ViTS14(w, H, W, device="cuda")
-        with _lib.using(_lib.Config().set("vit_fused_qkv", 0)):
+        with _lib.using(_lib.Config().set("vit_fused_qkv", -1)):
             two = model.forward(imgs).clone()
         with _lib.using(_lib.Config().set("vit_fused_qkv", 1)):
             one = model.forward(imgs).clone()

@@ -14,7 +14,7 @@ for nimg in sizes:
     acc = {0: [], 1: []}
     for rep in range(4):
         for fused in (0, 1):
-            with _lib.using(_lib.Config().set("vit_fused_qkv", fused)):
+            with _lib.using(_lib.Config().set("vit_fused_qkv", 1 if fused else -1)):
                 for _ in range(3): model.forward(imgs)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()

@@ -34,6 +34,10 @@ for nimg in [int(x) for x in (sys.argv[1:] or ["6", "42", "84", "90"])]:
     first = rel[:, 0] < 5.0
     print(f"{nimg} images, {len(t)} workgroups, kernel {rel[:, 6].max():.1f} us; workgroups started in the first 5 us: {int(first.sum())}; "
           f"duration median {np.median(rel[:, 6] - rel[:, 0]):.1f} us (first round {np.median((rel[:, 6] - rel[:, 0])[first]):.1f}, later {np.median((rel[:, 6] - rel[:, 0])[~first]) if (~first).any() else 0:.1f})")
+    v1 = (t[:, [10, 11, 3]] - t[:, [2, 10, 11]]) / 100.0   # tile v1: from the end of v0 (tr[2] is the end of k1: v0 + wait), k-loop, epilogue
+    q0 = (t[:, [13, 14, 15]] - t[:, [3, 13, 14]]) / 100.0
+    print(f"    tile v1: [v0 + barrier] {np.median(v1[:, 0]):.2f}, k-loop {np.median(v1[:, 1]):.2f}, epilogue {np.median(v1[:, 2]):.2f} us;   "
+          f"tile q0: barrier {np.median(q0[:, 0]):.2f}, k-loop {np.median(q0[:, 1]):.2f}, epilogue {np.median(q0[:, 2]):.2f} us")
     for k, nm in enumerate(names):
         if k == 5:
             for j, sn in enumerate(["scores", "softmax", "P V", "stores"]):

@@ -1377,7 +1377,7 @@ __global__ __launch_bounds__(256, 1) void vit_qkv_attention_kernel(GemmArgs g, i
     const int item = xcd * per_xcd + (int)(blockIdx.x >> 3);
     if (item >= B * g.heads) return;   // workgroup-uniform
     const int b = item / g.heads, head = item - b * g.heads;
-    unsigned long long tr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (tools: phase times of the workgroup, 100 MHz ticks)
+    unsigned long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (tools: phase times of the workgroup, 100 MHz ticks)
     if (g.dbg) tr[0] = wall_clock64();
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)fl;
     // The six 32-channel weight tiles of the head in the order k0 k1 v0 v1 q0 q1 (q last: its result stays in registers, and by then the
@@ -1453,6 +1453,8 @@ __global__ __launch_bounds__(256, 1) void vit_qkv_attention_kernel(GemmArgs g, i
         if constexpr (n == 0) vit_wait_vmcnt<36>();   // (the weights of tiles 0 and 1: everything older than the 18 loads of sums and the PRE k-steps of fragments)
         else vit_wait_vmcnt<0>();
         __syncthreads();
+        if constexpr (n == 3) { if (g.dbg) tr[10] = wall_clock64(); }
+        if constexpr (n == 4) { if (g.dbg) tr[13] = wall_clock64(); }
         if constexpr (n >= 1 && n + 1 < 6) stage_w(n + 1);
         // the epilogue's per-channel operands, requested here: an L2 round trip behind the k-loop was 0.5 us per tile with nothing beside it
         const int n32 = __builtin_amdgcn_readfirstlane((which * g.heads + head) * 2 + c);
@@ -1505,6 +1507,8 @@ __global__ __launch_bounds__(256, 1) void vit_qkv_attention_kernel(GemmArgs g, i
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (n == 0) finish_stats();
+        if constexpr (n == 3) { if (g.dbg) tr[11] = wall_clock64(); }
+        if constexpr (n == 4) { if (g.dbg) tr[14] = wall_clock64(); }
         if constexpr (SW) {
             // V^T: rows = the head's 64 channels (2 tiles), k = keys (2 NKT k-steps); a lane holds channel lane31 and keys 8 grp + 4 hi .. + 3 of a tile
             const f2 B2 = splat2(bias[0].x), C2 = splat2(csum[0].x);
@@ -1564,6 +1568,7 @@ __global__ __launch_bounds__(256, 1) void vit_qkv_attention_kernel(GemmArgs g, i
     run_tile(std::integral_constant<int, 3>{});
     if (g.dbg) tr[3] = wall_clock64();
     run_tile(std::integral_constant<int, 4>{});
+    if (g.dbg) tr[15] = wall_clock64();
     run_tile(std::integral_constant<int, 5>{});
     __syncthreads();   // K and V^T are complete
     if (g.dbg) tr[4] = wall_clock64();
@@ -1655,8 +1660,8 @@ __global__ __launch_bounds__(256, 1) void vit_qkv_attention_kernel(GemmArgs g, i
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
 #pragma unroll
-        for (int k = 0; k < 10; ++k) g.dbg[(size_t)blockIdx.x * 16 + k] = tr[k];
-        g.dbg[(size_t)blockIdx.x * 16 + 10] = xcc & 0xf;
+        for (int k = 0; k < 16; ++k) g.dbg[(size_t)blockIdx.x * 16 + k] = tr[k];
+        (void)xcc;
     }
 }
 
@@ -1920,8 +1925,17 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
     // K / V^T of an (image, head) shared by four query tiles through the LDS from vfm_cfg().vit_att_lds_min images on (0: never): at one scan the
     // one-wave-per-tile kernel's 396 waves spread over the chip win, at batches the shared form reads a quarter of the L2 bytes
     const bool att_lds = vfm_cfg().vit_att_lds_min > 0 && d.B >= vfm_cfg().vit_att_lds_min && d.Tp / 32 <= 16;
-    // QKV + attention per (image, head) in one workgroup (vit_qkv_attention_kernel) from vfm_cfg().vit_fused_qkv images on (0: never)
-    const bool fused_qkv = vfm_cfg().vit_fused_qkv > 0 && d.B >= vfm_cfg().vit_fused_qkv && d.D == 384 && d.Tp / 32 <= 12;
+    // QKV + attention per (image, head) in one workgroup (vit_qkv_attention_kernel).  vfm_cfg().vit_fused_qkv: n > 0 from n images on, -1 never,
+    // 0 (default) the policy: one workgroup per compute unit, B x heads of them, an eighth per XCD in rounds of 32 -- from 24 images on
+    // (below, the two kernels' many small workgroups fill the chip better) unless a second round would be less than a quarter full
+    // (profiles/r06_ab_vit_fused_qkv_sweep.txt: 42 images -12.6 %, 44: +1.7 %, 48: +0.2 %, 54: -2.1 %, 84: -11 %, 86: -3.7 %; three
+    // rounds and more: -4 ... -9 % wherever the last one ends)
+    bool fused_qkv = false;
+    if (d.D == 384 && d.Tp / 32 <= 12) {
+        const int per_xcd = ceil_div(d.B * d.heads, 8), rounds = ceil_div(per_xcd, 32), last = per_xcd - 32 * (rounds - 1);
+        const int k = vfm_cfg().vit_fused_qkv;
+        fused_qkv = k > 0 ? d.B >= k : (k == 0 && d.B >= 24 && (rounds >= 3 || rounds == 1 || 4 * last >= 32));
+    }
     for (int l = 0; l < d.depth; ++l) {
         const int s0 = SEG_LAYER0 + l * SEGS_PER_LAYER;
         // LayerNorm 1 is inside this GEMM: raw residual stream x folded weight, statistics applied in the epilogue
