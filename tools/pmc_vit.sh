@@ -19,8 +19,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list)); dur = coll
 def short(n):
     names = {"vit_gemm_kernel<1": "gemm QKV", "vit_gemm_kernel<2": "gemm proj/fc2 (+residual)", "vit_gemm_kernel<3": "gemm fc1 (+GELU)", "vit_gemm_kernel<0": "gemm patch embed",
              "vit_gemm_lds_kernel<1": "gemm QKV (LDS-tiled)", "vit_gemm_lds_kernel<2": "gemm proj/fc2 (+residual) (LDS-tiled)", "vit_gemm_lds_kernel<3": "gemm fc1 (+GELU) (LDS-tiled)",
-             "vit_gemm_lds_kernel<0": "gemm patch embed (LDS-tiled)", "vit_attention_lds": "attention (K / V^T in the LDS)"}
-    for k in ("vit_gemm_lds_kernel<1", "vit_gemm_lds_kernel<2", "vit_gemm_lds_kernel<3", "vit_gemm_lds_kernel<0", "vit_gemm_kernel<1", "vit_gemm_kernel<2", "vit_gemm_kernel<3", "vit_gemm_kernel<0", "vit_attention_lds", "vit_attention", "vit_layernorm", "vit_final", "vit_preprocess", "vit_gemm64", "vit_gemm_row"):
+             "vit_gemm_lds_kernel<0": "gemm patch embed (LDS-tiled)", "vit_attention_lds": "attention (K / V^T in the LDS)", "vit_qkv_attention": "QKV + attention, one workgroup per (image, head)",
+             "vit_gemm_astat2_kernel<3": "gemm fc1 (+GELU) (token-stationary, two tiles)", "vit_gemm_astat2_kernel<1": "gemm QKV (token-stationary, two tiles)"}
+    for k in ("vit_qkv_attention", "vit_gemm_astat2_kernel<3", "vit_gemm_astat2_kernel<1", "vit_gemm_lds_kernel<1", "vit_gemm_lds_kernel<2", "vit_gemm_lds_kernel<3", "vit_gemm_lds_kernel<0", "vit_gemm_kernel<1", "vit_gemm_kernel<2", "vit_gemm_kernel<3", "vit_gemm_kernel<0", "vit_attention_lds", "vit_attention", "vit_layernorm", "vit_final", "vit_preprocess", "vit_gemm64", "vit_gemm_row"):
         if k in n: return names.get(k, k)
     return None
 for f in sorted(glob.glob("$O/p*_counter_collection.csv")):

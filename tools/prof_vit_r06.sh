@@ -4,7 +4,7 @@ O=$R/gpurun_out/prof_vit_r06
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for n in ${1:-84 90}; do
- for fq in 0 1; do
+ for fq in -1 1; do
   VFM_FUSED_QKV=$fq timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/n${n}_$fq -o b -- python $R/tools/prof_vit.py 1 6 $n > $O/out_${n}_$fq.txt 2> $O/err_${n}_$fq.txt
   echo "== images $n, vit_fused_qkv $fq"
   python - <<PY
