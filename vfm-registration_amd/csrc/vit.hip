@@ -1614,43 +1614,49 @@ __global__ __launch_bounds__(256, 1) void vit_qkv_attention_kernel(GemmArgs g, i
                 vr0[p] = VT_l[((size_t)0 * vks + (p < vks ? p : vks - 1)) * 64 + lane];
                 vr1[p] = VT_l[((size_t)1 * vks + (p < vks ? p : vks - 1)) * 64 + lane];
             }
+            // probabilities of keys 16 ks .. + 15 as the B operand (see vit_attention_kernel), one k-step AHEAD of the MFMAs that take them: the
+            // conversions and lane swaps of step ks + 1 issue between the two MFMAs of step ks (one wave per SIMD: nobody else fills that time)
+            auto make_pf = [&](int ks) __attribute__((always_inline)) {
+                const int kt = ks >> 1, s2 = ks & 1;
+                unsigned x0 = pack_f16x2(S[kt][8 * s2 + 0], S[kt][8 * s2 + 1]);
+                unsigned x1 = pack_f16x2(S[kt][8 * s2 + 2], S[kt][8 * s2 + 3]);
+                unsigned y0 = pack_f16x2(S[kt][8 * s2 + 4], S[kt][8 * s2 + 5]);
+                unsigned y1 = pack_f16x2(S[kt][8 * s2 + 6], S[kt][8 * s2 + 7]);
+                auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+                uint4 pb;
+                pb.x = r0[0]; pb.y = r1[0]; pb.z = r0[1]; pb.w = r1[1];
+                return pb;
+            };
+            uint4 pnext = make_pf(0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    unsigned x0 = pack_f16x2(S[kt][8 * s2 + 0], S[kt][8 * s2 + 1]);
-                    unsigned x1 = pack_f16x2(S[kt][8 * s2 + 2], S[kt][8 * s2 + 3]);
-                    unsigned y0 = pack_f16x2(S[kt][8 * s2 + 4], S[kt][8 * s2 + 5]);
-                    unsigned y1 = pack_f16x2(S[kt][8 * s2 + 6], S[kt][8 * s2 + 7]);
-                    auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
-                    auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
-                    uint4 pb;
-                    pb.x = r0[0]; pb.y = r1[0]; pb.z = r0[1]; pb.w = r1[1];
-                    const half8 pf = *reinterpret_cast<half8*>(&pb);
-                    const int ks = kt * 2 + s2;
-                    O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&vr0[ks % PFV]), pf, O0, 0, 0, 0);
-                    O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&vr1[ks % PFV]), pf, O1, 0, 0, 0);
-                    if (ks + PFV < vks) {
-                        vr0[ks % PFV] = VT_l[((size_t)0 * vks + ks + PFV) * 64 + lane];
-                        vr1[ks % PFV] = VT_l[((size_t)1 * vks + ks + PFV) * 64 + lane];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int ks = 0; ks < vks; ++ks) {
+                uint4 pcur = pnext;
+                const half8 pf = *reinterpret_cast<half8*>(&pcur);
+                O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&vr0[ks % PFV]), pf, O0, 0, 0, 0);
+                if (ks + 1 < vks) pnext = make_pf(ks + 1);
+                O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8*>(&vr1[ks % PFV]), pf, O1, 0, 0, 0);
+                if (ks + PFV < vks) {
+                    vr0[ks % PFV] = VT_l[((size_t)0 * vks + ks + PFV) * 64 + lane];
+                    vr1[ks % PFV] = VT_l[((size_t)1 * vks + ks + PFV) * 64 + lane];
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (g.dbg && i == 0) tr[9] = wall_clock64();
-        const int m = b * g.Tp + qt * 32 + lane31;
+        // O[query][head 64 + d] into the fragment tiles of the [M][D] activation (frag_index(m, head 64 + half 32 + 8 grp + 4 hi, KS)): one
+        // wave-uniform base + the lane's 16 lane31 + 8 hi bytes + 512 (4 half + grp)
+        unsigned char* ob = reinterpret_cast<unsigned char*>(out) + ((size_t)(b * NKT + qt) * KS + (size_t)head * 4) * 1024u + lane_off;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const floatx16& O = half ? O1 : O0;
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
-                const int dd = half * 32 + 8 * grp + 4 * hi;
                 half4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (_Float16)(O[grp * 4 + j] * inv);
-                *reinterpret_cast<half4*>(out + frag_index(m, head * 64 + dd, g.D / 16)) = o;
+                *reinterpret_cast<half4*>(ob + 512u * (unsigned)(half * 4 + grp)) = o;
             }
         }
         if (g.dbg && i == 0) tr[5] = wall_clock64();
