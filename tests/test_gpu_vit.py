@@ -186,12 +186,15 @@ def test_vit_attention_with_keys_and_values_in_the_lds_equals_the_per_tile_kerne
 def test_vit_qkv_and_attention_in_one_workgroup_equal_the_two_kernels_bit_for_bit():
     """vit_qkv_attention_kernel (round 6: q, K and V^T of an (image, head) never leave the compute unit) against the QKV GEMM + the attention
     kernel: the same MFMAs over the same fragments in the same k order and the same epilogue arithmetic -- identical bits.  Token counts
-    with 9, 10, 11 and 12 tiles (the waves' last tiles missing or not), image counts that are no multiple of 8 (the XCD mapping's empty
+    with 1, 4, 6, 9, 10, 11 and 12 tiles (the waves' last tiles missing or not, one to three tiles per wave), image counts that are no multiple of 8 (the XCD mapping's empty
     slots), one layer and twelve; a width the kernel is not built for (768) takes the two kernels whatever the key says."""
     from vfmreg import _lib
     from vfmreg import vit as V
     for (dim, depth, mlp, B, H, W) in ((384, 2, 1536, 5, 560, 700), (384, 1, 1536, 1, 1200, 1600), (384, 1, 1536, 9, 1200, 1800),
-                                       (384, 1, 1536, 3, 300, 200), (768, 1, 3072, 2, 560, 600), (384, 12, 1536, 13, 1200, 1600)):
+                                       (384, 1, 1536, 3, 300, 200), (768, 1, 3072, 2, 560, 600), (384, 12, 1536, 13, 1200, 1600),
+                                       # 12, 9, 10, 4 and 1 token tiles (1200 x 1800 above has 13: the two kernels either way)
+                                       (384, 1, 1536, 7, 1200, 1700), (384, 1, 1536, 4, 1200, 1300), (384, 1, 1536, 2, 1200, 1400),
+                                       (384, 1, 1536, 10, 1200, 500), (384, 2, 1536, 17, 1200, 100)):
         w = V.random_weights(seed=13, dim=dim, depth=depth, mlp=mlp)
         imgs = torch.from_numpy(_smooth_images(np.random.default_rng(4), B, H, W)).cuda()
         model = V.ViTS14(w, H, W, device="cuda")
