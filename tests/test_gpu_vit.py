@@ -87,6 +87,17 @@ def test_vit_s14_six_cameras_1600x1200():
     print("vit-s/14 6 cams: max abs err", e, "min cosine", c)
 
 
+def test_vit_s14_through_the_one_workgroup_qkv_attention_kernel_against_the_fp32_reference():
+    """The same comparison with `vit_fused_qkv` = 1: QKV + attention of every (image, head) in vit_qkv_attention_kernel (what batches of
+    24 images and more take by policy), straight against the fp32 oracle -- 12 blocks at the 6-camera size, and a token count that is
+    no multiple of 32 (700 x 820: 289 tokens, keys masked in the last tile)."""
+    from vfmreg import _lib
+    from vfmreg import vit as V
+    with _lib.using(_lib.Config().set("vit_fused_qkv", 1)):
+        _check(V.random_weights(seed=0), _smooth_images(np.random.default_rng(1), 3, 1200, 1600), atol=1e-2, cos_min=0.99999)
+        _check(V.random_weights(seed=2, dim=384, depth=3, mlp=1536), _smooth_images(np.random.default_rng(2), 2, 700, 820), atol=1e-2, cos_min=0.99999)
+
+
 def test_vit_nclt_resolution_padding():
     """700 x 820 -> 16 x 18 patches = 289 tokens: not a multiple of 32 (key masking / padded rows)."""
     from vfmreg import vit as V
