@@ -50,8 +50,9 @@ SETTLE = 6   # registrations the auto policy gets, one at a time, before the war
 MFMA_F6_PEAK_TFLOPS = 10000.0  # dense fp6 / fp4 scaled MFMA (same table: "~10 PF dense", FP6 ubench >= 7287; tools/probe/mx6_probe.hip: 6400)
 
 
-C3_GROUP = 4   # pairs whose cameras share one ViT call in the grouped C3 pipeline (tools/time_c3_group.py)
-C3_GROUP_ALSO = (2,)   # ... and reported beside it
+C3_GROUP = 7   # pairs whose cameras share one ViT call in the grouped C3 pipeline (tools/time_c3_group.py; 42 images: one full round of the
+               # fused QKV + attention kernel's workgroups -- round 5: 4)
+C3_GROUP_ALSO = (4,)   # ... and reported beside it
 
 
 def cpu_baseline(p, iters=RANSAC_ITERS, T_gpu=None):
@@ -261,7 +262,7 @@ def extra_configs(dev):
         # the same job with the feature stages of G pairs sharing one ViT call (EndToEndPipeline.submit_group; parity: the same test)
         for G in (C3_GROUP,) + C3_GROUP_ALSO:
             e2e = EndToEndPipeline(model, rig, n, m, n_iter=RANSAC_ITERS, depth=4, device=dev, group=G, group_depth=3)
-            for steps_e2e in (8, 64):
+            for steps_e2e in (G if G > 8 else 8, 9 * G if 9 * G > 64 else 64):
                 gc.collect()
                 gc.disable()
                 torch.cuda.synchronize()
@@ -269,7 +270,7 @@ def extra_configs(dev):
                 for lo in range(0, steps_e2e, G):
                     res = e2e.submit_group([(img_sets[i % 2], pcl, q_xyz, b_desc, b_xyz) for i in range(lo, min(lo + G, steps_e2e))],
                                            inputs_ready=ready)[-1]
-                    if steps_e2e == 8:    # the settle pass, one group at a time
+                    if steps_e2e <= 8 or steps_e2e == G:    # the settle pass, one group at a time
                         e2e.synchronize()
                         torch.cuda.synchronize()
                     e2e.reg._poll_feedback()

@@ -22,6 +22,11 @@ done
 cd $R
 # ViT
 VFM_VIT_LDS_THR=256 timeout 400 python tools/time_vit_batch.py 2>&1 | grep -v amdgpu > $O/time_vit_batch.txt; tail -7 $O/time_vit_batch.txt
+timeout 500 python tools/ab_vit_fused_qkv.py 6 24 30 42 44 48 60 84 85 86 90 96 126 2>&1 | grep -v amdgpu > $O/ab_vit_fused_qkv_sweep.txt; tail -5 $O/ab_vit_fused_qkv_sweep.txt
+timeout 300 python tools/trace_vit_fused.py 42 84 2>&1 | grep -v amdgpu > $O/trace_vit_fused.txt
+bash tools/prof_vit_r06.sh 84 > $O/prof_vit_84images.txt 2>&1; tail -26 $O/prof_vit_84images.txt | head -8
+VIT_IMAGES=84 bash tools/pmc_vit.sh > $O/pmc_vit_84.log 2>&1; cp $R/gpurun_out/pmc_vit/summary.json $O/pmc_vit_84images.json
+cd $R
 # operand preparation: HBM traffic of the three forms, the one-read form's checks and times, the A/Bs of the round
 cd $R && bash tools/pmc_prep.sh 2>&1 | tail -8; cp gpurun_out/pmc_prep/summary.txt $O/pmc_prep.txt
 timeout 300 python tools/dev_prep_once.py 2>&1 | grep -v amdgpu > $O/dev_prep_once.txt; tail -7 $O/dev_prep_once.txt
