@@ -251,7 +251,8 @@ struct GemmArgs {
     float invD;          // 1 / D (the consumers' mean and variance)
     unsigned qt_magic;   // 2^20 / (Tp / 32) + 1: image of a token tile = (mt qt_magic) >> 20 (exact for mt < 2^16: vfm_vit_forward checks)
     unsigned long long* dbg;   // (tools only) per-workgroup start / end / placement of vit_gemm_astat_kernel, or null
-    int hot_a;                 // (tools only, WRONG RESULTS) 1: every workgroup of the LDS-tiled kernel reads token group 0 -- its A operand then hits the L2
+    int hot_a;                 // (tools only, WRONG RESULTS; LDS-tiled kernel) bit 0: every workgroup reads token group 0 -- its A operand then hits the L2;
+                               // bits 1 / 2 / 3: the residual epilogue without its loads of the stream / its stores to it / its fp16 copy
 };
 
 // XCD-consistent work mapping (round 3): workgroup b runs on XCD b % 8 (observed placement, speed only).  Every kernel of a block
@@ -346,7 +347,7 @@ __device__ __forceinline__ void epi_load(const GemmArgs& g, int m, int t, int hi
         if constexpr (CONSUMES_LN || EPI == EPI_RESID) e.aux[grp] = *reinterpret_cast<const float4*>(aux_b + (hoff + 32u * grp));
     }
     if constexpr (EPI == EPI_RESID) {
-        if (t < g.T) {
+        if (t < g.T && !(g.hot_a & 2)) {
             const char* xb = reinterpret_cast<const char*>(g.x + n32u * 32);
             const unsigned xoff = (unsigned)m * (unsigned)g.D * 4u + hoff;   // (M D 4 < 2^32: vfm_vit_forward checks)
 #pragma unroll
@@ -472,8 +473,8 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const floatx16& acc,
                 o01 = fma2(f2{e.aux[grp].x, e.aux[grp].y}, v01, o01);
                 o23 = fma2(f2{e.aux[grp].z, e.aux[grp].w}, v23, o23);
             }
-            if (EPI == EPI_PATCH || row) *reinterpret_cast<float4*>(xb + (xoff + 32u * grp)) = make_float4(o01[0], o01[1], o23[0], o23[1]);
-            *reinterpret_cast<half4*>(fbase + (lane_off + 512u * grp)) = to_half4(o01, o23);
+            if ((EPI == EPI_PATCH || row) && !(g.hot_a & 4)) *reinterpret_cast<float4*>(xb + (xoff + 32u * grp)) = make_float4(o01[0], o01[1], o23[0], o23[1]);
+            if (!(g.hot_a & 8)) *reinterpret_cast<half4*>(fbase + (lane_off + 512u * grp)) = to_half4(o01, o23);
             ps += o01 + o23;
             pq = fma2(o01, o01, fma2(o23, o23, pq));
         }
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(64 * NW, NG == 1 ? 3 : 1) void vit_gemm_lds_kernel(
         ks = ks < g.KS ? ks : g.KS - 1;
         int rowtile = op == 0 ? mg * 4 + tile : ng * 4 * NG + tile;
         if (op == 0 && rowtile >= mtiles) rowtile = mtiles - 1;   // (a partial last group of token tiles: its epilogue is skipped)
-        if (op == 0 && g.hot_a) rowtile = tile;                   // (timing experiment: tools/ab_vit_hot_a.sh)
+        if (op == 0 && (g.hot_a & 1)) rowtile = tile;                   // (timing experiment: tools/ab_vit_hot_a.sh)
         src[i] = reinterpret_cast<const char*>((op == 0 ? g.A : g.W) + ((size_t)rowtile * g.KS + ks) * 64);
     }
     unsigned lane16 = (unsigned)lane * 16u;   // + the bytes the wave's pieces have moved on by (one VALU add per stage instead of PW 64-bit scalar ones)
