@@ -218,6 +218,28 @@ def test_vit_qkv_and_attention_in_one_workgroup_equal_the_two_kernels_bit_for_bi
         assert torch.equal(two, one), (dim, B, H, W, float((two - one).abs().max()))
 
 
+def test_vit_mlp_in_one_workgroup_equals_fc1_and_fc2_bit_for_bit():
+    """vit_mlp_kernel (round 6: fc1 -> GELU -> fc2 of 128 tokens in one workgroup, the hidden activations never leave the registers) against
+    the two GEMM kernels: the same MFMAs over the same fragments in the same k order, the same epilogues -- identical bits.  Token counts
+    whose last group of four tiles is partial, one layer and twelve, with and without the one-workgroup QKV + attention in front; a width it
+    is not built for (768) takes the two kernels whatever the key says."""
+    from vfmreg import _lib
+    from vfmreg import vit as V
+    for (dim, depth, mlp, B, H, W) in ((384, 2, 1536, 5, 560, 700), (384, 1, 1536, 1, 1200, 1600), (384, 1, 1536, 3, 300, 200),
+                                       (768, 1, 3072, 2, 560, 600), (384, 12, 1536, 13, 1200, 1600), (384, 1, 1536, 7, 1200, 1700)):
+        w = V.random_weights(seed=13, dim=dim, depth=depth, mlp=mlp)
+        imgs = torch.from_numpy(_smooth_images(np.random.default_rng(4), B, H, W)).cuda()
+        model = V.ViTS14(w, H, W, device="cuda")
+        with _lib.using(_lib.Config().set("vit_fused_mlp", -1).set("vit_fused_qkv", -1)):
+            two = model.forward(imgs).clone()
+        for qkv in (-1, 1):
+            with _lib.using(_lib.Config().set("vit_fused_mlp", 1).set("vit_fused_qkv", qkv)):
+                one = model.forward(imgs).clone()
+            torch.cuda.synchronize()
+            assert torch.isfinite(one).all()
+            assert torch.equal(two, one), (dim, B, H, W, qkv, float((two - one).abs().max()))
+
+
 def test_vit_preprocessing_one_workgroup_per_patch_equals_the_per_unit_kernel_bit_for_bit():
     """vit_preprocess_patch_kernel (round 5: a workgroup per 14 x 14 patch, each thread's two source rows read once for the three channels,
     the token's fragment units assembled in the LDS) evaluates the expressions of round 1's kernel in the same order: identical features --

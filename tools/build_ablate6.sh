@@ -10,5 +10,5 @@ for spec in "$@"; do
   /opt/rocm/bin/hipcc $F $defs -c csrc/match_coarse_mx6.hip -o build/match_coarse_mx6_$v.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o vfmreg/lib/libvfmreg_hip_$v.so build/error.cpp.o build/config.cpp.o build/match_api.hip.o build/match_prep.hip.o \
         build/match_coarse_f16.hip.o build/match_coarse_i8.hip.o build/match_coarse_mx6_$v.o build/match_finish.hip.o build/match_l2.hip.o build/ransac.hip.o \
-        build/project.hip.o build/vit.hip.o build/icp.hip.o build/voxel.hip.o
+        build/project.hip.o build/vit.hip.o build/vit_mlp.hip.o build/icp.hip.o build/voxel.hip.o
 done

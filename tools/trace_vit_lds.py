@@ -24,6 +24,8 @@ lib.vfm_debug_set_vit_gemm(-11, C.c_int32(ptr & 0xffffffff).value)
 lib.vfm_debug_set_vit_gemm(-12, C.c_int32((ptr >> 32) & 0xffffffff).value)
 # depth 1: the LAST residual GEMM of the forward is the block's fc2; with VFM_ONLY_PROJ=1 the MLP is skipped by reading after a
 # forward whose weights make fc2 the traced launch anyway -- the two are told apart by the k-steps the kernel records
+if os.environ.get("VFM_ONLY_PROJ") == "1":   # the proj launch instead of fc2 (both are the LDS-tiled residual kernel)
+    _lib.thread_config().set("vit_trace_fused", 2)
 model = V.ViTS14(V.random_weights(0, depth=1), 1200, 1600)
 for _ in range(3):
     buf.zero_()

@@ -27,6 +27,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # with the accumulators in the accumulation file every value the softmax and the epilogues touch was moved across first (936 v_accvgpr_read
 # in 5 900 instructions); the kernels that stay under 256 registers do not change
 FILE_FLAGS = {"vit.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# ... and vit.hip once more for its second part (vit_mlp_kernel: 192 accumulators in the accumulation file), without that option
+EXTRA_OBJECTS = [("vit.hip", ["-DVFM_VIT_PART=1"], "vit_mlp.hip.o")]
 SOURCES = ["error.cpp", "config.cpp", "match_api.hip", "match_prep.hip", "match_coarse_f16.hip", "match_coarse_i8.hip", "match_coarse_mx6.hip", "match_finish.hip",
            "match_l2.hip", "ransac.hip", "project.hip", "vit.hip", "icp.hip", "voxel.hip"]
 
@@ -44,18 +46,23 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     headers = list(CSRC.glob("*.h")) + [HERE.parent / "include" / "vfmreg.h"]
     srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()]
     objs = [OBJ_DIR / (s.name + ".o") for s in srcs]
+    jobs = [(s, o, FILE_FLAGS.get(s.name, [])) for s, o in zip(srcs, objs)]
+    for name, flags, objname in EXTRA_OBJECTS:
+        if (CSRC / name).exists():
+            jobs.append((CSRC / name, OBJ_DIR / objname, flags))
+            objs.append(OBJ_DIR / objname)
 
-    def compile_one(pair):
-        src, obj = pair
+    def compile_one(job):
+        src, obj, extra = job
         if not force and not _stale(obj, [src] + headers):
             return
-        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src.name, []) + (["-x", "hip"] if src.suffix == ".cpp" else []) + ["-c", str(src), "-o", str(obj)]
+        cmd = [HIPCC] + FLAGS + extra + (["-x", "hip"] if src.suffix == ".cpp" else []) + ["-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
     with ThreadPoolExecutor(max_workers=8) as ex:
-        list(ex.map(compile_one, zip(srcs, objs)))
+        list(ex.map(compile_one, jobs))
     if force or _stale(SO, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(SO)] + [str(o) for o in objs]
         if verbose:

@@ -37,7 +37,7 @@ const Field k_fields[] = {
     {"vit_att_lds_min", &VfmConfig::vit_att_lds_min}, {"vit_lds_min_wg", &VfmConfig::vit_lds_min_wg},
     {"vit_astat_min", &VfmConfig::vit_astat_min},    {"vit_astat_two", &VfmConfig::vit_astat_two},
     {"vit_astat_nw", &VfmConfig::vit_astat_nw},      {"vit_fused_qkv", &VfmConfig::vit_fused_qkv},
-    {"vit_trace_fused", &VfmConfig::vit_trace_fused},
+    {"vit_trace_fused", &VfmConfig::vit_trace_fused},  {"vit_fused_mlp", &VfmConfig::vit_fused_mlp},
     {"voxel_replay2", &VfmConfig::voxel_replay2},    {"voxel_one_launch", &VfmConfig::voxel_small},
     {"voxel_trace", &VfmConfig::voxel_trace},        {"voxel_grid_ppt", &VfmConfig::voxel_grid_ppt},
 };

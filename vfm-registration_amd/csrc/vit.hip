@@ -485,6 +485,44 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& g, const floatx16& acc,
     }
 }
 
+// ---- helpers of the LDS-staged kernels
+template <int N>
+__device__ __forceinline__ void vit_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void vit_glds16(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst_uniform)
+        : "memory");
+}
+__device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    half2v h;
+    h[0] = (_Float16)a;
+    h[1] = (_Float16)b;
+    return *reinterpret_cast<unsigned*>(&h);
+}
+
+
+// This file is compiled TWICE (build.py): VFM_VIT_PART 0 -- everything but the fused MLP kernel, with -mllvm -amdgpu-mfma-vgpr-form (MFMA results
+// in architectural registers: vit_qkv_attention_kernel) -- and VFM_VIT_PART 1 -- vit_mlp_kernel alone, WITHOUT that option: its 192 output
+// accumulators live in the accumulation file beside 256 architectural registers of everything else.  The two objects share the code above
+// (internal linkage in each) and meet at vfm_vit_launch_mlp_.
+#ifndef VFM_VIT_PART
+#define VFM_VIT_PART 0
+#endif
+}  // namespace
+extern "C" __attribute__((visibility("hidden"))) int vfm_vit_launch_mlp_(const void* fc1_args, const void* fc2_args, void* stream);
+namespace {
+#if VFM_VIT_PART == 0
+
 // NT = 32-channel tiles per wave (2 for the wide GEMMs, 1 for N = dim so that 66 x 12 = 792 waves
 // cover the chip instead of 396).
 template <int EPI, int NT, int PF>
@@ -570,22 +608,6 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs g) {
 // k-steps (32 KiB: 32 LDS-DMA pieces of one (tile, k-step) fragment row each), two stages in the LDS, one barrier per stage: the
 // pieces of stage i + 1 are issued behind the barrier that ends stage i - 1's reads and land under stage i's 16 MFMAs per wave.
 // At one scan (6 images: 17 x 3 workgroups for N = 384) the direct kernel's spread wins; launch_gemm picks by workgroup count.
-template <int N>
-__device__ __forceinline__ void vit_wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void vit_glds16(const void* gsrc, unsigned lds_dst_uniform) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst_uniform)
-        : "memory");
-}
 // KB k-steps per stage, NS stages in the LDS ring (NS - 1 in flight or in use beside the one being filled): a stage is issued NS - 2
 // stages of MFMAs before it is needed -- an L2 round trip is ~1500 cycles, a stage's MFMAs 128 KB cycles per wave -- and 4 KB x NS KiB
 // of LDS lets several workgroups share a compute unit (KB = 2, NS = 4: 64 KiB, 2 per CU; KB = 2, NS = 3: 48 KiB, 3 per CU).
@@ -1098,14 +1120,6 @@ __global__ __launch_bounds__(256) void vit_final_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 // 4. attention: one wavefront per 32 queries of one (image, head).  NKT = key tiles (Tp / 32).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
-    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-    half2v h;
-    h[0] = (_Float16)a;
-    h[1] = (_Float16)b;
-    return *reinterpret_cast<unsigned*>(&h);
-}
-
 // softmax over the keys of NKT score tiles S^T (rows = keys, column = query = lane & 31; the two half-waves hold a query's other keys):
 // p = exp2((s - max s) scale) with scale = log2(e) / 8 -- the maximum on the raw scores (v_max3), scale and subtraction as ONE packed FMA per
 // pair of scores, the sum by packed adds (round 5: 6 instructions per score were 4 of the kernel's 5 600 VALU cycles per wave; the exponential
@@ -1807,7 +1821,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
         if (wgs >= vfm_cfg().vit_lds_min_wg) {
             GemmArgs gl = g;
             gl.hot_a = vfm_cfg().vit_hot_a;
-            gl.dbg = EPI == EPI_RESID && !vfm_cfg().vit_trace_fused ? vfm_cfg().vit_astat_dbg : nullptr;   // (the trace buffer serves whichever kernel a tool looks at)
+            gl.dbg = EPI == EPI_RESID && (vfm_cfg().vit_trace_fused == 0 || (vfm_cfg().vit_trace_fused == 2 && g.KS * 16 == g.D)) ? vfm_cfg().vit_astat_dbg : nullptr;   // (2: the proj launches only)   // (the trace buffer serves whichever kernel a tool looks at)
             if (EPI == EPI_RESID && g.N == 384 && vfm_cfg().vit_wide_tile && g.KS % 2 == 0) {   // one workgroup per 128 tokens x all 384 channels (NG = 3)
                 const int gridw = 8 * ceil_div(ceil_div(g.M / 32, 4), 8);
                 constexpr int ldsw = 4 * 16 * 2 * 1024;   // NS = 4 stages of (4 + 12) x KB = 2 KiB: 128 KiB
@@ -1943,6 +1957,8 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
         const int k = vfm_cfg().vit_fused_qkv;
         fused_qkv = k > 0 ? d.B >= k : (k == 0 && d.B >= 24 && (rounds >= 3 || rounds == 1 || 4 * last >= 32));
     }
+    // fc1 -> GELU -> fc2 in one workgroup per 128 tokens (vit_mlp_kernel): vfm_cfg().vit_fused_mlp n > 0 from n images on, 0 / -1 never (for now)
+    const bool fused_mlp = vfm_cfg().vit_fused_mlp > 0 && d.B >= vfm_cfg().vit_fused_mlp && d.D == 384 && d.mlp == 1536;
     for (int l = 0; l < d.depth; ++l) {
         const int s0 = SEG_LAYER0 + l * SEGS_PER_LAYER;
         // LayerNorm 1 is inside this GEMM: raw residual stream x folded weight, statistics applied in the epilogue
@@ -1961,7 +1977,7 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
             attr_set |= 1ull << (dev_ & 63);                                                                              \
         }                                                                                                                 \
         GemmArgs gf = g;                                                                                                  \
-        gf.dbg = vfm_cfg().vit_trace_fused ? vfm_cfg().vit_astat_dbg : nullptr;                                                                             \
+        gf.dbg = vfm_cfg().vit_trace_fused == 1 ? vfm_cfg().vit_astat_dbg : nullptr;                                                                             \
         hipLaunchKernelGGL(vit_qkv_attention_kernel<NKT>, dim3(8 * ceil_div(d.B * d.heads, 8)), dim3(256), lds_, st, gf, d.B, w.a);       \
     } while (0)
             switch (d.Tp / 32) {
@@ -2009,6 +2025,14 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
         // LayerNorm 2 likewise
         g.A = reinterpret_cast<const uint4*>(w.xh); g.W = f16(s0 + L_FC1_W); g.bias = f32(s0 + L_FC1_B); g.csum = f32(s0 + L_FC1_C);
         g.N = d.mlp; g.KS = d.D / 16; g.out = w.h;
+        if (fused_mlp) {   // fc1 -> GELU -> fc2 of 128 tokens in one workgroup (vit_mlp_kernel, the file's second compile part)
+            GemmArgs g2 = g;
+            g.dbg = vfm_cfg().vit_trace_fused == 3 ? vfm_cfg().vit_astat_dbg : nullptr;   // (tools: 3 = the trace buffer is vit_mlp_kernel's)
+            g2.A = reinterpret_cast<const uint4*>(w.h); g2.W = f16(s0 + L_FC2_W); g2.bias = f32(s0 + L_FC2_B);
+            g2.gamma = f32(s0 + L_LS2); g2.N = d.D; g2.KS = d.mlp / 16;
+            if ((rc = vfm_vit_launch_mlp_(&g, &g2, st))) return rc;
+            continue;
+        }
         if ((rc = launch_gemm<EPI_GELU>(g, st))) return rc;
         g.A = reinterpret_cast<const uint4*>(w.h); g.W = f16(s0 + L_FC2_W); g.bias = f32(s0 + L_FC2_B);
         g.gamma = f32(s0 + L_LS2); g.N = d.D; g.KS = d.mlp / 16;
@@ -2020,3 +2044,256 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
     VFM_CHECK_LAUNCH("vit_final_kernel");
     return VFM_OK;
 }
+
+#else   // VFM_VIT_PART == 1: the fused MLP kernel, compiled without -amdgpu-mfma-vgpr-form
+
+// ---- fc1 -> GELU -> fc2 (+ LayerScale, residual, fp16 copy, LayerNorm sums) of 128 tokens in ONE workgroup (round 6).  The two kernels it
+// replaces hand the hidden activations (tokens x 1536 fp16) through HBM: 87 MB written and 87 MB read per layer at 84 images, and fc2 runs
+// at the pace of its tiles' staging (545 MB through the L2 -> LDS path per launch).  Here a wave -- one per SIMD, 512 registers -- keeps ONE
+// token tile's 24 fragments of the raw residual copy (96 registers) and its 12 output tiles' accumulators (192) for the whole kernel and
+// walks the 48 chunks of 32 hidden channels: fc1's 24 MFMAs of the chunk (W1 tile from the LDS), the LayerNorm fold + exact GELU on the 16
+// values per lane, the result converted to the B-operand layout in registers (v_permlane32_swap: the q / P conversion), fc2's 24 MFMAs
+// (the chunk's two k-steps of all 12 output tiles of W2 from the LDS).  Weights stream through a ring of two 48 KiB LDS slots by LDS-DMA
+// (2.36 MB per workgroup, from the L2); the hidden activations never exist outside registers.  Every MFMA takes one 1 KiB fragment from
+// the LDS -- the LDS port and the matrix pipes peak together (tools/probe/mfma_lds_probe.hip: ~1.1 PFLOP/s at that ratio) -- against the
+// 0.56 PFLOP/s of fc1 + fc2 as two kernels.
+// Same MFMAs over the same fragments in the same k order (fc2's accumulators take the hidden channels in ascending order), the same epilogue
+// arithmetic (epi_tile): bit-equal to the two kernels (tests/test_gpu_vit.py).  D = 384, mlp = 1536.
+__global__ __launch_bounds__(256, 1) void vit_mlp_kernel(GemmArgs g1, GemmArgs g2) {
+    constexpr int KS = 24, NC = 48, NO = 12, KS2 = 96;
+    constexpr unsigned SLOT = 48u * 1024u, W2OFF = 24u * 1024u, TAB = 3u * SLOT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ml[];   // [3 slots: W1 tile 24 KiB | W2 chunk 24 KiB][bias1 1536 f32][csum1 1536 f32]
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int lane = lane_id(), hi = lane >> 5, lane31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mtiles = g1.M / 32, mg = blockIdx.x;
+    int mt = mg * 4 + wave;
+    const bool live = mt < mtiles;   // wave-uniform (a partial last group: its waves multiply the last tile again and store nothing)
+    if (!live) mt = mtiles - 1;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)ml;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, c_wait = 0;   // (tools: start, loop start, loop end in 100 MHz ticks; shader clocks spent at the loop's waits + barriers)
+    if (g1.dbg) tr0 = wall_clock64();
+    // W1's tile t = 24 consecutive fragment rows -> the W1 half of slot t % 3; W2's chunk u = k-steps 2 u, 2 u + 1 of its 12 row tiles = 24 pieces
+    // of 1 KiB (piece q = 2 j + s2) -> the W2 half of slot u % 3; six pieces per wave each.  Two rings of three: a tile is requested TWO
+    // iterations before it is read (an L2 round trip of the LDS-DMA is ~2 us when 231 workgroups ask together: with one iteration of lead
+    // the loop ran at that latency, 2.5 us per iteration for 1 536 cycles of MFMAs)
+    auto stage_w1 = [&](int tile, int slot) __attribute__((always_inline)) {
+        const unsigned dst = lds_base + (unsigned)slot * SLOT;
+        const uint4* s1 = g1.W + (size_t)tile * KS * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int p = wave + 4 * i;
+            vit_glds16(s1 + (size_t)p * 64, __builtin_amdgcn_readfirstlane(dst + (unsigned)p * 1024u));
+        }
+    };
+    auto stage_w2 = [&](int chunk, int slot) __attribute__((always_inline)) {
+        const unsigned dst = lds_base + (unsigned)slot * SLOT + W2OFF;
+        const uint4* s2p = g2.W + (size_t)(2 * chunk) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int q = wave + 4 * i;
+            vit_glds16(s2p + ((size_t)(q >> 1) * KS2 + (size_t)(q & 1)) * 64, __builtin_amdgcn_readfirstlane(dst + (unsigned)q * 1024u));
+        }
+    };
+    // prologue: W1 tiles 0, 1, 2; W2 chunks 0, 1 -- and chunk 0 once more where chunk "-1" would lie (slot 2): the first iteration's fc2 step
+    // multiplies zeros, its weights must be finite
+    stage_w1(0, 0); stage_w1(1, 1); stage_w1(2, 2);
+    stage_w2(0, 0); stage_w2(1, 1); stage_w2(0, 2);
+    float* tab = reinterpret_cast<float*>(ml + TAB);
+    for (int i = threadIdx.x; i < 1536; i += 256) {
+        tab[i] = g1.bias[i];
+        tab[1536 + i] = g1.csum[i];
+    }
+    u32x4 xf[KS];
+    {
+        const u32x4* Ap = reinterpret_cast<const u32x4*>(g1.A) + (size_t)mt * KS * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xf[s] = Ap[(size_t)s * 64];
+    }
+    const int m = mt * 32 + lane31;
+    float ln_a, ln_nb;
+    ln_stats_load(g1, m, ln_a, ln_nb);
+    const f2 A2 = splat2(ln_a), NB2 = splat2(ln_nb);
+    floatx16 oacc[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[j][r] = 0.f;
+    vit_wait_vmcnt<0>();
+    __syncthreads();
+    constexpr int PF = 6;
+    floatx16 h0, h1;
+    {   // fc1 of chunk 0 on its own
+        const unsigned char* sl = ml + (unsigned)lane * 16u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h0[r] = 0.f;
+        half8 wr[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) wr[i] = *reinterpret_cast<const half8*>(sl + (unsigned)i * 1024u);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[s % PF], *reinterpret_cast<const half8*>(&xf[s]), h0, 0, 0, 0);
+            if (s + PF < KS) wr[s % PF] = *reinterpret_cast<const half8*>(sl + (unsigned)(s + PF) * 1024u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // Iteration c, one wave per SIMD, nothing else to fill a gap: fc1 of chunk c + 1 (-> hn), the LayerNorm fold + GELU of chunk c (hc -> fout)
+    // and fc2 of chunk c - 1 (fin) are independent of one another and go out INTERLEAVED -- k-step k = one fc2 MFMA, one sixth of a
+    // group's GELU (gelu2's arithmetic in six stages: the four groups of the chunk take the 24 k-steps), one fc1 MFMA, the two rings'
+    // reloads; the dependent accumulator chains (fc1's single accumulator, fc2's pairs) are two MFMAs apart.
+    // (r0, r1, r2) = (c, c + 1, c + 2) mod 3, i.e. c - 1 = r2
+    auto body = [&](int c, int r0, int r1, int r2, const floatx16& hc, floatx16& hn, const uint4 (&fin)[2], uint4 (&fout)[2]) __attribute__((always_inline)) {
+        // the pieces this wave requested up to iteration c - 2 have landed (those of iteration c - 1 -- twelve, in the steady state -- may fly on)
+        unsigned long long tw = 0;
+        if (g1.dbg) tw = __builtin_readcyclecounter();
+        if (c >= 2 && c <= NC - 3) vit_wait_vmcnt<12>();
+        else vit_wait_vmcnt<0>();
+        __syncthreads();       // everybody's; everybody has left the regions refilled below
+        if (g1.dbg) c_wait += __builtin_readcyclecounter() - tw;
+#ifndef VFM_MLP_ABL_NODMA
+        if (c + 3 < NC) stage_w1(c + 3, r0);                 // W1[c] was read in iteration c - 1
+        if (c >= 1 && c + 1 < NC) stage_w2(c + 1, r1);       // W2[c - 2] was read in iteration c - 1
+#endif
+        const unsigned char* sl = ml + (unsigned)r1 * SLOT + (unsigned)lane * 16u;             // W1[c + 1]
+        const unsigned char* s2l = ml + (unsigned)r2 * SLOT + W2OFF + (unsigned)lane * 16u;    // W2[c - 1]
+        const float* bt = tab + c * 32 + 4 * hi;
+        half8 w1r[PF], w2r[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            w2r[i] = *reinterpret_cast<const half8*>(s2l + (unsigned)i * 1024u);
+            w1r[i] = *reinterpret_cast<const half8*>(sl + (unsigned)i * 1024u);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hn[r] = 0.f;
+        float4 bias = *reinterpret_cast<const float4*>(bt), csum = *reinterpret_cast<const float4*>(bt + 1536);
+        unsigned pk[8];
+        f2 x0, x1, ax0, ax1, z0, z1, t0, t1, p0, p1, e0, e1;   // the group in flight: its two pairs (x0: values 0, 1; x1: values 2, 3)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            oacc[k >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2r[k % PF], *reinterpret_cast<const half8*>(&fin[k & 1]), oacc[k >> 1], 0, 0, 0);
+            {
+                const int grp = k / 6, st = k % 6;
+                if (st == 0) {          // y = acc a + (nb c + b'): epi_tile<EPI_GELU>'s
+                    x0 = fma2(f2{hc[grp * 4 + 0], hc[grp * 4 + 1]}, A2, fma2(NB2, f2{csum.x, csum.y}, f2{bias.x, bias.y}));
+                    x1 = fma2(f2{hc[grp * 4 + 2], hc[grp * 4 + 3]}, A2, fma2(NB2, f2{csum.z, csum.w}, f2{bias.z, bias.w}));
+                    if (grp < 3) {      // the next group's per-channel operands
+                        bias = *reinterpret_cast<const float4*>(bt + 8 * (grp + 1));
+                        csum = *reinterpret_cast<const float4*>(bt + 1536 + 8 * (grp + 1));
+                    }
+#ifndef VFM_MLP_ABL_NOGELU
+                } else if (st == 1) {   // gelu2, stage by stage
+                    ax0 = f2{fabsf(x0[0]), fabsf(x0[1])};
+                    ax1 = f2{fabsf(x1[0]), fabsf(x1[1])};
+                    z0 = ax0 * splat2(0.70710678118654752440f);
+                    z1 = ax1 * splat2(0.70710678118654752440f);
+                    const f2 d0 = fma2(splat2(0.3275911f), z0, splat2(1.0f)), d1 = fma2(splat2(0.3275911f), z1, splat2(1.0f));
+                    t0 = f2{__builtin_amdgcn_rcpf(d0[0]), __builtin_amdgcn_rcpf(d0[1])};
+                    t1 = f2{__builtin_amdgcn_rcpf(d1[0]), __builtin_amdgcn_rcpf(d1[1])};
+                } else if (st == 2) {
+                    p0 = fma2(splat2(1.061405429f), t0, splat2(-1.453152027f));
+                    p1 = fma2(splat2(1.061405429f), t1, splat2(-1.453152027f));
+                    p0 = fma2(p0, t0, splat2(1.421413741f));
+                    p1 = fma2(p1, t1, splat2(1.421413741f));
+                    p0 = fma2(p0, t0, splat2(-0.284496736f));
+                    p1 = fma2(p1, t1, splat2(-0.284496736f));
+                } else if (st == 3) {
+                    p0 = fma2(p0, t0, splat2(0.254829592f));
+                    p1 = fma2(p1, t1, splat2(0.254829592f));
+                    const f2 a0 = (z0 * z0) * splat2(-1.44269504088896340736f), a1 = (z1 * z1) * splat2(-1.44269504088896340736f);
+                    e0 = f2{__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
+                    e1 = f2{__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
+                } else if (st == 4) {
+                    const f2 r0 = fma2(-(p0 * t0), e0, splat2(1.0f)), r1 = fma2(-(p1 * t1), e1, splat2(1.0f));
+                    x0 = fma2(ax0 * splat2(0.5f), r0, x0 * splat2(0.5f));
+                    x1 = fma2(ax1 * splat2(0.5f), r1, x1 * splat2(0.5f));
+#endif
+                } else if (st == 5) {
+                    pk[grp * 2 + 0] = pack_f16x2(x0[0], x0[1]);
+                    pk[grp * 2 + 1] = pack_f16x2(x1[0], x1[1]);
+                    if (grp & 1) {      // channels 16 s2 .. + 15 of the chunk are complete: to the B-operand layout (the q / P conversion)
+                        const int s2 = grp >> 1;
+                        auto r0 = __builtin_amdgcn_permlane32_swap(pk[4 * s2 + 0], pk[4 * s2 + 2], false, false);
+                        auto r1 = __builtin_amdgcn_permlane32_swap(pk[4 * s2 + 1], pk[4 * s2 + 3], false, false);
+                        fout[s2] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                    }
+                }
+            }
+            hn = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1r[k % PF], *reinterpret_cast<const half8*>(&xf[k]), hn, 0, 0, 0);
+#ifndef VFM_MLP_ABL_NOLDS
+            if (k + PF < KS) {
+                w2r[k % PF] = *reinterpret_cast<const half8*>(s2l + (unsigned)(k + PF) * 1024u);
+                w1r[k % PF] = *reinterpret_cast<const half8*>(sl + (unsigned)(k + PF) * 1024u);
+            }
+#else
+            asm volatile("" : "+v"(w2r[k % PF]), "+v"(w1r[k % PF]));
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    uint4 fa[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)}, fb[2];
+    unsigned long long cy1 = 0, cy2 = 0;
+    if (g1.dbg) { tr1 = wall_clock64(); cy1 = __builtin_readcyclecounter(); }
+    int r0 = 0, r1 = 1, r2 = 2;
+#pragma unroll 1
+    for (int c = 0; c < NC; c += 2) {
+        body(c, r0, r1, r2, h0, h1, fa, fb);
+        body(c + 1, r1, r2, r0, h1, h0, fb, fa);
+        const int n0 = r2, n1 = r0, n2 = r1;   // two iterations on
+        r0 = n0; r1 = n1; r2 = n2;
+    }
+    if (g1.dbg) { tr2 = wall_clock64(); cy2 = __builtin_readcyclecounter(); }
+    vit_wait_vmcnt<0>();
+    __syncthreads();
+    {   // fc2 of the last chunk (47 % 3 = slot 2) on its own
+        const unsigned char* s2l = ml + 2u * SLOT + W2OFF + (unsigned)lane * 16u;
+        half8 wr[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) wr[i] = *reinterpret_cast<const half8*>(s2l + (unsigned)i * 1024u);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 2 * NO; ++q) {
+            oacc[q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[q % PF], *reinterpret_cast<const half8*>(&fa[q & 1]), oacc[q >> 1], 0, 0, 0);
+            if (q + PF < 2 * NO) wr[q % PF] = *reinterpret_cast<const half8*>(s2l + (unsigned)(q + PF) * 1024u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (!live) return;
+    // ---- the residual epilogue of fc2 (bias, LayerScale, the stream's read-modify-write, its fp16 copy, the slices' LayerNorm sums)
+    const int mtu = __builtin_amdgcn_readfirstlane(mt), qtiles = g2.Tp >> 5;
+    const int b = (int)(((unsigned)mtu * g2.qt_magic) >> 20), tq = mtu - b * qtiles, t = tq * 32 + lane31;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        EpiRegs e;
+        epi_load<EPI_RESID>(g2, m, t, hi, j, e);
+        epi_tile<EPI_RESID>(g2, oacc[j], m, mtu, b, tq, t, hi, j, e, 0.f, 0.f);
+    }
+    if (g1.dbg && wave == 0 && lane == 0) {
+        g1.dbg[(size_t)blockIdx.x * 8 + 0] = tr0;
+        g1.dbg[(size_t)blockIdx.x * 8 + 1] = tr1;
+        g1.dbg[(size_t)blockIdx.x * 8 + 2] = tr2;
+        g1.dbg[(size_t)blockIdx.x * 8 + 3] = wall_clock64();
+        g1.dbg[(size_t)blockIdx.x * 8 + 4] = c_wait;
+        g1.dbg[(size_t)blockIdx.x * 8 + 5] = cy2 - cy1;
+    }
+}
+
+}  // namespace
+
+extern "C" __attribute__((visibility("hidden"))) int vfm_vit_launch_mlp_(const void* fc1_args, const void* fc2_args, void* stream) {
+    const GemmArgs& g1 = *static_cast<const GemmArgs*>(fc1_args);
+    const GemmArgs& g2 = *static_cast<const GemmArgs*>(fc2_args);
+    constexpr int lds_ = 144 * 1024 + 2 * 1536 * 4;
+    static std::atomic<unsigned long long> attr_set{0ull};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_set >> (dev & 63)) & 1ull)) {
+        VFM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_));
+        attr_set |= 1ull << (dev & 63);
+    }
+    hipLaunchKernelGGL(vit_mlp_kernel, dim3(ceil_div(g1.M / 32, 4)), dim3(256), lds_, (hipStream_t)stream, g1, g2);
+    VFM_CHECK_LAUNCH("vit_mlp_kernel");
+    return VFM_OK;
+}
+#endif   // VFM_VIT_PART
