@@ -2073,32 +2073,46 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_kernel(GemmArgs g1, GemmArgs g
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)ml;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, c_wait = 0;   // (tools: start, loop start, loop end in 100 MHz ticks; shader clocks spent at the loop's waits + barriers)
     if (g1.dbg) tr0 = wall_clock64();
-    // W1's tile t = 24 consecutive fragment rows -> the W1 half of slot t % 3; W2's chunk u = k-steps 2 u, 2 u + 1 of its 12 row tiles = 24 pieces
-    // of 1 KiB (piece q = 2 j + s2) -> the W2 half of slot u % 3; six pieces per wave each.  Two rings of three: a tile is requested TWO
-    // iterations before it is read (an L2 round trip of the LDS-DMA is ~2 us when 231 workgroups ask together: with one iteration of lead
-    // the loop ran at that latency, 2.5 us per iteration for 1 536 cycles of MFMAs)
-    auto stage_w1 = [&](int tile, int slot) __attribute__((always_inline)) {
+    // The loop works on PAIRS of hidden chunks.  A dependent MFMA (srcC = the previous result) can issue ~97 cycles after its producer -- three
+    // MFMA times -- and fc1 of one chunk is ONE accumulator chain of 24: alone between fc2's MFMAs it set the pace of the whole loop (2 330 cycles
+    // per chunk for 1 536 of MFMA, tools/build_ablate_mlp.sh).  With two chunks' chains side by side the order A_a A_b B B puts four MFMAs
+    // between the links of either.  Iteration i: fc1 of pair i + 1 (chunks 2 i + 2, 2 i + 3 -> hnA, hnB), LayerNorm fold + GELU of pair i
+    // (hcA, hcB -> fout), fc2 of pair i - 1 (fin), interleaved; 96 MFMAs.  Weights by HALVES of an iteration, one 48 KiB slot each, three slots
+    // in flight: half H = 2 i + e holds [k-steps 12 e .. + 11 of W1's tiles 2 i + 2 and 2 i + 3: piece 2 kk + ab][W2's chunk 2 i - 2 + e: piece
+    // 12 s2 + j], is requested two halves ahead (an L2 round trip of the LDS-DMA is ~2 us when 231 workgroups ask together) and waited for
+    // with a counted vmcnt: every half requests exactly twelve pieces per wave (indices past either end are clamped: finite weights nobody's
+    // result depends on -- the first iteration's fc2 multiplies zeros).
+    auto stage_half = [&](int H, int slot) __attribute__((always_inline)) {
+        const int i = H >> 1, e = H & 1;
         const unsigned dst = lds_base + (unsigned)slot * SLOT;
-        const uint4* s1 = g1.W + (size_t)tile * KS * 64 + lane;
+        int ta = 2 * i + 2;
+        ta = ta > NC - 2 ? NC - 2 : ta;
+        int ch = 2 * i - 2 + e;
+        ch = ch < 0 ? 0 : (ch > NC - 1 ? NC - 1 : ch);
+        const uint4* s1 = g1.W + ((size_t)ta * KS + (size_t)(12 * e)) * 64 + lane;
+        const uint4* s2p = g2.W + (size_t)(2 * ch) * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int p = wave + 4 * i;
-            vit_glds16(s1 + (size_t)p * 64, __builtin_amdgcn_readfirstlane(dst + (unsigned)p * 1024u));
+        for (int t = 0; t < 6; ++t) {
+            const int p = wave + 4 * t, kk = p >> 1, ab = p & 1;
+            vit_glds16(s1 + ((size_t)ab * KS + (size_t)kk) * 64, __builtin_amdgcn_readfirstlane(dst + (unsigned)p * 1024u));
+        }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int q = wave + 4 * t, s2 = q >= 12 ? 1 : 0, j = q - 12 * s2;
+            vit_glds16(s2p + ((size_t)j * KS2 + (size_t)s2) * 64, __builtin_amdgcn_readfirstlane(dst + W2OFF + (unsigned)q * 1024u));
         }
     };
-    auto stage_w2 = [&](int chunk, int slot) __attribute__((always_inline)) {
-        const unsigned dst = lds_base + (unsigned)slot * SLOT + W2OFF;
-        const uint4* s2p = g2.W + (size_t)(2 * chunk) * 64 + lane;
+    // prologue: W1's tiles 0 and 1 as they lie (48 consecutive fragment rows) into slot 2, halves 0 and 1 into slots 0 and 1
+    {
+        const uint4* s1 = g1.W + lane;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int q = wave + 4 * i;
-            vit_glds16(s2p + ((size_t)(q >> 1) * KS2 + (size_t)(q & 1)) * 64, __builtin_amdgcn_readfirstlane(dst + (unsigned)q * 1024u));
+        for (int t = 0; t < 12; ++t) {
+            const int p = wave + 4 * t;
+            vit_glds16(s1 + (size_t)p * 64, __builtin_amdgcn_readfirstlane(lds_base + 2u * SLOT + (unsigned)p * 1024u));
         }
-    };
-    // prologue: W1 tiles 0, 1, 2; W2 chunks 0, 1 -- and chunk 0 once more where chunk "-1" would lie (slot 2): the first iteration's fc2 step
-    // multiplies zeros, its weights must be finite
-    stage_w1(0, 0); stage_w1(1, 1); stage_w1(2, 2);
-    stage_w2(0, 0); stage_w2(1, 1); stage_w2(0, 2);
+    }
+    stage_half(0, 0);
+    stage_half(1, 1);
     float* tab = reinterpret_cast<float*>(ml + TAB);
     for (int i = threadIdx.x; i < 1536; i += 256) {
         tab[i] = g1.bias[i];
@@ -2122,141 +2136,159 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_kernel(GemmArgs g1, GemmArgs g
     vit_wait_vmcnt<0>();
     __syncthreads();
     constexpr int PF = 6;
-    floatx16 h0, h1;
-    {   // fc1 of chunk 0 on its own
-        const unsigned char* sl = ml + (unsigned)lane * 16u;
+    floatx16 hA0, hB0, hA1, hB1;
+    {   // fc1 of pair 0 on its own (slot 2: tile t's k-step k at piece 24 t + k)
+        const unsigned char* sl = ml + 2u * SLOT + (unsigned)lane * 16u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h0[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { hA0[r] = 0.f; hB0[r] = 0.f; }
         half8 wr[PF];
 #pragma unroll
-        for (int i = 0; i < PF; ++i) wr[i] = *reinterpret_cast<const half8*>(sl + (unsigned)i * 1024u);
+        for (int i = 0; i < PF; ++i) wr[i] = *reinterpret_cast<const half8*>(sl + (unsigned)((i & 1) * 24 + (i >> 1)) * 1024u);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[s % PF], *reinterpret_cast<const half8*>(&xf[s]), h0, 0, 0, 0);
-            if (s + PF < KS) wr[s % PF] = *reinterpret_cast<const half8*>(sl + (unsigned)(s + PF) * 1024u);
+        for (int p = 0; p < 2 * KS; ++p) {   // p = 2 k + ab
+            const int k = p >> 1;
+            if (p & 1) hB0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[p % PF], *reinterpret_cast<const half8*>(&xf[k]), hB0, 0, 0, 0);
+            else hA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[p % PF], *reinterpret_cast<const half8*>(&xf[k]), hA0, 0, 0, 0);
+            if (p + PF < 2 * KS) wr[p % PF] = *reinterpret_cast<const half8*>(sl + (unsigned)(((p + PF) & 1) * 24 + ((p + PF) >> 1)) * 1024u);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // Iteration c, one wave per SIMD, nothing else to fill a gap: fc1 of chunk c + 1 (-> hn), the LayerNorm fold + GELU of chunk c (hc -> fout)
-    // and fc2 of chunk c - 1 (fin) are independent of one another and go out INTERLEAVED -- k-step k = one fc2 MFMA, one sixth of a
-    // group's GELU (gelu2's arithmetic in six stages: the four groups of the chunk take the 24 k-steps), one fc1 MFMA, the two rings'
-    // reloads; the dependent accumulator chains (fc1's single accumulator, fc2's pairs) are two MFMAs apart.
-    // (r0, r1, r2) = (c, c + 1, c + 2) mod 3, i.e. c - 1 = r2
-    auto body = [&](int c, int r0, int r1, int r2, const floatx16& hc, floatx16& hn, const uint4 (&fin)[2], uint4 (&fout)[2]) __attribute__((always_inline)) {
-        // the pieces this wave requested up to iteration c - 2 have landed (those of iteration c - 1 -- twelve, in the steady state -- may fly on)
+    unsigned long long cy1 = 0, cy2 = 0;
+    if (g1.dbg) { tr1 = wall_clock64(); cy1 = __builtin_readcyclecounter(); }
+    // one half of an iteration: e = 0 / 1 (compile time), i the pair, (sr, sw) = the slot read / the slot half 2 i + e + 2 goes to
+    auto half = [&](auto Ec, int i, int sr, int sw, const floatx16& hc, floatx16& hnA, floatx16& hnB, const uint4 (&fin)[4], uint4 (&fout)[4]) __attribute__((always_inline)) {
+        constexpr int e = decltype(Ec)::value;
         unsigned long long tw = 0;
         if (g1.dbg) tw = __builtin_readcyclecounter();
-        if (c >= 2 && c <= NC - 3) vit_wait_vmcnt<12>();
-        else vit_wait_vmcnt<0>();
-        __syncthreads();       // everybody's; everybody has left the regions refilled below
+        vit_wait_vmcnt<12>();   // everything this wave requested but the last half's twelve pieces has landed
+        __syncthreads();        // everybody's; everybody has left slot sw
         if (g1.dbg) c_wait += __builtin_readcyclecounter() - tw;
 #ifndef VFM_MLP_ABL_NODMA
-        if (c + 3 < NC) stage_w1(c + 3, r0);                 // W1[c] was read in iteration c - 1
-        if (c >= 1 && c + 1 < NC) stage_w2(c + 1, r1);       // W2[c - 2] was read in iteration c - 1
+        if (2 * i + e + 2 < 2 * NC / 2 + 2) stage_half(2 * i + e + 2, sw);
 #endif
-        const unsigned char* sl = ml + (unsigned)r1 * SLOT + (unsigned)lane * 16u;             // W1[c + 1]
-        const unsigned char* s2l = ml + (unsigned)r2 * SLOT + W2OFF + (unsigned)lane * 16u;    // W2[c - 1]
-        const float* bt = tab + c * 32 + 4 * hi;
+        const unsigned char* sl = ml + (unsigned)sr * SLOT + (unsigned)lane * 16u;
+        const unsigned char* s2l = sl + W2OFF;
+        const float* bt = tab + (2 * i + e) * 32 + 4 * hi;
         half8 w1r[PF], w2r[PF];
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            w2r[i] = *reinterpret_cast<const half8*>(s2l + (unsigned)i * 1024u);
-            w1r[i] = *reinterpret_cast<const half8*>(sl + (unsigned)i * 1024u);
+        for (int t = 0; t < PF; ++t) {
+            w1r[t] = *reinterpret_cast<const half8*>(sl + (unsigned)t * 1024u);
+            w2r[t] = *reinterpret_cast<const half8*>(s2l + (unsigned)t * 1024u);
         }
+        if constexpr (e == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hn[r] = 0.f;
+            for (int r = 0; r < 16; ++r) { hnA[r] = 0.f; hnB[r] = 0.f; }
+        }
         float4 bias = *reinterpret_cast<const float4*>(bt), csum = *reinterpret_cast<const float4*>(bt + 1536);
         unsigned pk[8];
         f2 x0, x1, ax0, ax1, z0, z1, t0, t1, p0, p1, e0, e1;   // the group in flight: its two pairs (x0: values 0, 1; x1: values 2, 3)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            oacc[k >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2r[k % PF], *reinterpret_cast<const half8*>(&fin[k & 1]), oacc[k >> 1], 0, 0, 0);
-            {
-                const int grp = k / 6, st = k % 6;
-                if (st == 0) {          // y = acc a + (nb c + b'): epi_tile<EPI_GELU>'s
-                    x0 = fma2(f2{hc[grp * 4 + 0], hc[grp * 4 + 1]}, A2, fma2(NB2, f2{csum.x, csum.y}, f2{bias.x, bias.y}));
-                    x1 = fma2(f2{hc[grp * 4 + 2], hc[grp * 4 + 3]}, A2, fma2(NB2, f2{csum.z, csum.w}, f2{bias.z, bias.w}));
-                    if (grp < 3) {      // the next group's per-channel operands
-                        bias = *reinterpret_cast<const float4*>(bt + 8 * (grp + 1));
-                        csum = *reinterpret_cast<const float4*>(bt + 1536 + 8 * (grp + 1));
-                    }
+        // gelu2's arithmetic in six stages; the chunk's four groups take the half's 24 stage slots (two per k-step)
+        auto gstep = [&](int ms) __attribute__((always_inline)) {
+            const int grp = ms / 6, st = ms % 6;
+            if (st == 0) {          // y = acc a + (nb c + b'): epi_tile<EPI_GELU>'s
+                x0 = fma2(f2{hc[grp * 4 + 0], hc[grp * 4 + 1]}, A2, fma2(NB2, f2{csum.x, csum.y}, f2{bias.x, bias.y}));
+                x1 = fma2(f2{hc[grp * 4 + 2], hc[grp * 4 + 3]}, A2, fma2(NB2, f2{csum.z, csum.w}, f2{bias.z, bias.w}));
+                if (grp < 3) {      // the next group's per-channel operands
+                    bias = *reinterpret_cast<const float4*>(bt + 8 * (grp + 1));
+                    csum = *reinterpret_cast<const float4*>(bt + 1536 + 8 * (grp + 1));
+                }
 #ifndef VFM_MLP_ABL_NOGELU
-                } else if (st == 1) {   // gelu2, stage by stage
-                    ax0 = f2{fabsf(x0[0]), fabsf(x0[1])};
-                    ax1 = f2{fabsf(x1[0]), fabsf(x1[1])};
-                    z0 = ax0 * splat2(0.70710678118654752440f);
-                    z1 = ax1 * splat2(0.70710678118654752440f);
-                    const f2 d0 = fma2(splat2(0.3275911f), z0, splat2(1.0f)), d1 = fma2(splat2(0.3275911f), z1, splat2(1.0f));
-                    t0 = f2{__builtin_amdgcn_rcpf(d0[0]), __builtin_amdgcn_rcpf(d0[1])};
-                    t1 = f2{__builtin_amdgcn_rcpf(d1[0]), __builtin_amdgcn_rcpf(d1[1])};
-                } else if (st == 2) {
-                    p0 = fma2(splat2(1.061405429f), t0, splat2(-1.453152027f));
-                    p1 = fma2(splat2(1.061405429f), t1, splat2(-1.453152027f));
-                    p0 = fma2(p0, t0, splat2(1.421413741f));
-                    p1 = fma2(p1, t1, splat2(1.421413741f));
-                    p0 = fma2(p0, t0, splat2(-0.284496736f));
-                    p1 = fma2(p1, t1, splat2(-0.284496736f));
-                } else if (st == 3) {
-                    p0 = fma2(p0, t0, splat2(0.254829592f));
-                    p1 = fma2(p1, t1, splat2(0.254829592f));
-                    const f2 a0 = (z0 * z0) * splat2(-1.44269504088896340736f), a1 = (z1 * z1) * splat2(-1.44269504088896340736f);
-                    e0 = f2{__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
-                    e1 = f2{__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
-                } else if (st == 4) {
-                    const f2 r0 = fma2(-(p0 * t0), e0, splat2(1.0f)), r1 = fma2(-(p1 * t1), e1, splat2(1.0f));
-                    x0 = fma2(ax0 * splat2(0.5f), r0, x0 * splat2(0.5f));
-                    x1 = fma2(ax1 * splat2(0.5f), r1, x1 * splat2(0.5f));
+            } else if (st == 1) {
+                ax0 = f2{fabsf(x0[0]), fabsf(x0[1])};
+                ax1 = f2{fabsf(x1[0]), fabsf(x1[1])};
+                z0 = ax0 * splat2(0.70710678118654752440f);
+                z1 = ax1 * splat2(0.70710678118654752440f);
+                const f2 d0 = fma2(splat2(0.3275911f), z0, splat2(1.0f)), d1 = fma2(splat2(0.3275911f), z1, splat2(1.0f));
+                t0 = f2{__builtin_amdgcn_rcpf(d0[0]), __builtin_amdgcn_rcpf(d0[1])};
+                t1 = f2{__builtin_amdgcn_rcpf(d1[0]), __builtin_amdgcn_rcpf(d1[1])};
+            } else if (st == 2) {
+                p0 = fma2(splat2(1.061405429f), t0, splat2(-1.453152027f));
+                p1 = fma2(splat2(1.061405429f), t1, splat2(-1.453152027f));
+                p0 = fma2(p0, t0, splat2(1.421413741f));
+                p1 = fma2(p1, t1, splat2(1.421413741f));
+                p0 = fma2(p0, t0, splat2(-0.284496736f));
+                p1 = fma2(p1, t1, splat2(-0.284496736f));
+            } else if (st == 3) {
+                p0 = fma2(p0, t0, splat2(0.254829592f));
+                p1 = fma2(p1, t1, splat2(0.254829592f));
+                const f2 a0 = (z0 * z0) * splat2(-1.44269504088896340736f), a1 = (z1 * z1) * splat2(-1.44269504088896340736f);
+                e0 = f2{__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
+                e1 = f2{__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
+            } else if (st == 4) {
+                const f2 r0 = fma2(-(p0 * t0), e0, splat2(1.0f)), r1 = fma2(-(p1 * t1), e1, splat2(1.0f));
+                x0 = fma2(ax0 * splat2(0.5f), r0, x0 * splat2(0.5f));
+                x1 = fma2(ax1 * splat2(0.5f), r1, x1 * splat2(0.5f));
 #endif
-                } else if (st == 5) {
-                    pk[grp * 2 + 0] = pack_f16x2(x0[0], x0[1]);
-                    pk[grp * 2 + 1] = pack_f16x2(x1[0], x1[1]);
-                    if (grp & 1) {      // channels 16 s2 .. + 15 of the chunk are complete: to the B-operand layout (the q / P conversion)
-                        const int s2 = grp >> 1;
-                        auto r0 = __builtin_amdgcn_permlane32_swap(pk[4 * s2 + 0], pk[4 * s2 + 2], false, false);
-                        auto r1 = __builtin_amdgcn_permlane32_swap(pk[4 * s2 + 1], pk[4 * s2 + 3], false, false);
-                        fout[s2] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-                    }
+            } else if (st == 5) {
+                pk[grp * 2 + 0] = pack_f16x2(x0[0], x0[1]);
+                pk[grp * 2 + 1] = pack_f16x2(x1[0], x1[1]);
+                if (grp & 1) {      // channels 16 s2 .. + 15 of the chunk are complete: to the B-operand layout (the q / P conversion)
+                    const int s2 = grp >> 1;
+                    auto r0 = __builtin_amdgcn_permlane32_swap(pk[4 * s2 + 0], pk[4 * s2 + 2], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(pk[4 * s2 + 1], pk[4 * s2 + 3], false, false);
+                    fout[2 * e + s2] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
                 }
             }
-            hn = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1r[k % PF], *reinterpret_cast<const half8*>(&xf[k]), hn, 0, 0, 0);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 12; ++kk) {
+            const int k = 12 * e + kk, pa = 2 * kk, q0 = 2 * kk, q1 = 2 * kk + 1;
+            hnA = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1r[pa % PF], *reinterpret_cast<const half8*>(&xf[k]), hnA, 0, 0, 0);
+            gstep(2 * kk);
+            hnB = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1r[(pa + 1) % PF], *reinterpret_cast<const half8*>(&xf[k]), hnB, 0, 0, 0);
+            oacc[q0 % 12] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2r[q0 % PF], *reinterpret_cast<const half8*>(&fin[2 * e + q0 / 12]), oacc[q0 % 12], 0, 0, 0);
+            gstep(2 * kk + 1);
+            oacc[q1 % 12] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2r[q1 % PF], *reinterpret_cast<const half8*>(&fin[2 * e + q1 / 12]), oacc[q1 % 12], 0, 0, 0);
 #ifndef VFM_MLP_ABL_NOLDS
-            if (k + PF < KS) {
-                w2r[k % PF] = *reinterpret_cast<const half8*>(s2l + (unsigned)(k + PF) * 1024u);
-                w1r[k % PF] = *reinterpret_cast<const half8*>(sl + (unsigned)(k + PF) * 1024u);
+            if (pa + PF < 24) {
+                w1r[pa % PF] = *reinterpret_cast<const half8*>(sl + (unsigned)(pa + PF) * 1024u);
+                w1r[(pa + 1) % PF] = *reinterpret_cast<const half8*>(sl + (unsigned)(pa + 1 + PF) * 1024u);
+                w2r[q0 % PF] = *reinterpret_cast<const half8*>(s2l + (unsigned)(q0 + PF) * 1024u);
+                w2r[q1 % PF] = *reinterpret_cast<const half8*>(s2l + (unsigned)(q1 + PF) * 1024u);
             }
 #else
-            asm volatile("" : "+v"(w2r[k % PF]), "+v"(w1r[k % PF]));
+            asm volatile("" : "+v"(w1r[pa % PF]), "+v"(w1r[(pa + 1) % PF]), "+v"(w2r[q0 % PF]), "+v"(w2r[q1 % PF]));
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    uint4 fa[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)}, fb[2];
-    unsigned long long cy1 = 0, cy2 = 0;
-    if (g1.dbg) { tr1 = wall_clock64(); cy1 = __builtin_readcyclecounter(); }
-    int r0 = 0, r1 = 1, r2 = 2;
+    uint4 fa[4] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)}, fb[4];
+    int r = 0;   // slot of half 2 i
+    auto nxt = [](int v) { return v + 1 >= 3 ? v - 2 : v + 1; };
 #pragma unroll 1
-    for (int c = 0; c < NC; c += 2) {
-        body(c, r0, r1, r2, h0, h1, fa, fb);
-        body(c + 1, r1, r2, r0, h1, h0, fb, fa);
-        const int n0 = r2, n1 = r0, n2 = r1;   // two iterations on
-        r0 = n0; r1 = n1; r2 = n2;
+    for (int i = 0; i < NC / 2; i += 2) {
+        {   // pair i: reads hA0 / hB0 (its fc1), writes hA1 / hB1 (pair i + 1's), fc2 of pair i - 1 from fa, its own hidden values to fb
+            const int s0 = r, s1 = nxt(s0), s2 = nxt(s1);
+            half(std::integral_constant<int, 0>{}, i, s0, s2, hA0, hA1, hB1, fa, fb);
+            half(std::integral_constant<int, 1>{}, i, s1, s0, hB0, hA1, hB1, fa, fb);
+            r = s2;
+        }
+        {
+            const int s0 = r, s1 = nxt(s0), s2 = nxt(s1);
+            half(std::integral_constant<int, 0>{}, i + 1, s0, s2, hA1, hA0, hB0, fb, fa);
+            half(std::integral_constant<int, 1>{}, i + 1, s1, s0, hB1, hA0, hB0, fb, fa);
+            r = s2;
+        }
     }
     if (g1.dbg) { tr2 = wall_clock64(); cy2 = __builtin_readcyclecounter(); }
     vit_wait_vmcnt<0>();
     __syncthreads();
-    {   // fc2 of the last chunk (47 % 3 = slot 2) on its own
-        const unsigned char* s2l = ml + 2u * SLOT + W2OFF + (unsigned)lane * 16u;
+    {   // fc2 of the last pair on its own: halves 48 and 49 (chunks 46, 47) in slots r and r + 1; its hidden values are in fa (the loop ran an even number of pairs)
         half8 wr[PF];
 #pragma unroll
-        for (int i = 0; i < PF; ++i) wr[i] = *reinterpret_cast<const half8*>(s2l + (unsigned)i * 1024u);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int e = 0; e < 2; ++e) {
+            const unsigned char* s2l = ml + (unsigned)(e ? nxt(r) : r) * SLOT + W2OFF + (unsigned)lane * 16u;
 #pragma unroll
-        for (int q = 0; q < 2 * NO; ++q) {
-            oacc[q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[q % PF], *reinterpret_cast<const half8*>(&fa[q & 1]), oacc[q >> 1], 0, 0, 0);
-            if (q + PF < 2 * NO) wr[q % PF] = *reinterpret_cast<const half8*>(s2l + (unsigned)(q + PF) * 1024u);
+            for (int t = 0; t < PF; ++t) wr[t] = *reinterpret_cast<const half8*>(s2l + (unsigned)t * 1024u);
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 24; ++q) {
+                oacc[q % 12] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[q % PF], *reinterpret_cast<const half8*>(&fa[2 * e + q / 12]), oacc[q % 12], 0, 0, 0);
+                if (q + PF < 24) wr[q % PF] = *reinterpret_cast<const half8*>(s2l + (unsigned)(q + PF) * 1024u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     if (!live) return;
