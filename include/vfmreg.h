@@ -81,8 +81,10 @@ const char *vfm_build_info(void);
  *   "vit_fused_qkv"      QKV product + attention of an (image, head) in one workgroup (vit_qkv_attention_kernel: q, K, V^T never leave the
  *                        compute unit; the same bits as the two kernels): 0 (default) vfm_vit_forward's policy -- ViT-S width, from 24 images per
  *                        call on, unless a second round of workgroups would be less than a quarter full --, n > 0 from n images on, -1 never
- *   "vit_fused_mlp"      fc1 -> GELU -> fc2 of 128 tokens in one workgroup (vit_mlp_kernel; the same bits as the two GEMM kernels): n > 0 from n images
- *                        per call on; 0 (default) / -1 never -- it runs at parity with the two kernels
+ *   "vit_fused_mlp"      fc1 -> GELU -> fc2 of 128 tokens in one workgroup (vit_mlp_kernel; the same bits as the two GEMM kernels): 0 (default)
+ *                        vfm_vit_forward's policy -- from two rounds of workgroups on (~150 images per call) when the last round is at least four
+ *                        fifths full: a single round runs in lockstep and ends level with the two kernels --, n > 0
+ *                        from n images per call on, -1 never
  *   and the single fields behind the codes: "coarse_qsets", "seed_units", "select_variant", "mx6_t4", "mx6_ns3", "prep_form" (0 .. 3),
  *   "finish_short", "rescan_rows", "vit_*", "voxel_replay2", "voxel_one_launch", "voxel_trace", "voxel_grid_ppt" (vfm_config_get reads these;
  *   cfg == NULL there: what the calling thread's entry points would read now). */

@@ -93,7 +93,7 @@ def test_vit_s14_through_the_one_workgroup_qkv_attention_kernel_against_the_fp32
     no multiple of 32 (700 x 820: 289 tokens, keys masked in the last tile)."""
     from vfmreg import _lib
     from vfmreg import vit as V
-    with _lib.using(_lib.Config().set("vit_fused_qkv", 1)):
+    with _lib.using(_lib.Config().set("vit_fused_qkv", 1).set("vit_fused_mlp", 1)):   # (and fc1 -> GELU -> fc2 in vit_mlp_kernel)
         _check(V.random_weights(seed=0), _smooth_images(np.random.default_rng(1), 3, 1200, 1600), atol=1e-2, cos_min=0.99999)
         _check(V.random_weights(seed=2, dim=384, depth=3, mlp=1536), _smooth_images(np.random.default_rng(2), 2, 700, 820), atol=1e-2, cos_min=0.99999)
 
@@ -209,7 +209,7 @@ def test_vit_qkv_and_attention_in_one_workgroup_equal_the_two_kernels_bit_for_bi
         w = V.random_weights(seed=13, dim=dim, depth=depth, mlp=mlp)
         imgs = torch.from_numpy(_smooth_images(np.random.default_rng(4), B, H, W)).cuda()
         model = V.ViTS14(w, H, W, device="cuda")
-        with _lib.using(_lib.Config().set("vit_fused_qkv", -1)):
+        with _lib.using(_lib.Config().set("vit_fused_qkv", -1).set("vit_fused_mlp", -1)):
             two = model.forward(imgs).clone()
         with _lib.using(_lib.Config().set("vit_fused_qkv", 1)):
             one = model.forward(imgs).clone()

@@ -27,7 +27,7 @@ struct VfmConfig {
     int vit_preprocess_patch = 1, vit_xcd = 1, vit_cfg_narrow = 108, vit_cfg_wide = 108, vit_wpw = 0, vit_hot_a = 0, vit_wide_tile = 0,
         vit_lds_shape = 23, vit_att_lds_min = 1, vit_lds_min_wg = 256, vit_astat_min = 0, vit_astat_two = 1, vit_astat_nw = 0,
         vit_trace_fused = 0,   // (tools) whose trace buffer it is: 0 the GEMM kernels', 1 vit_qkv_attention_kernel's, 2 the proj launches' of the LDS-tiled kernel
-        vit_fused_mlp = 0,     // fc1 -> GELU -> fc2 of 128 tokens in one workgroup: n > 0 from n images on
+        vit_fused_mlp = 0,     // fc1 -> GELU -> fc2 of 128 tokens in one workgroup: n > 0 from n images on, -1 never, 0 vfm_vit_forward's policy
         vit_fused_qkv = 0;   // QKV + attention of an (image, head) in one workgroup: n > 0 from n images on, -1 never, 0 vfm_vit_forward's policy
     unsigned long long* vit_astat_dbg = nullptr;   // (tools) device buffer of the token-stationary kernel's placement trace
     // ---- voxel containers (voxel.hip): "voxel_small" codes

@@ -1957,8 +1957,22 @@ VFM_EXPORT int vfm_vit_forward(const vfm_vit_config* cfg, const void* weights, c
         const int k = vfm_cfg().vit_fused_qkv;
         fused_qkv = k > 0 ? d.B >= k : (k == 0 && d.B >= 24 && (rounds >= 3 || rounds == 1 || 4 * last >= 32));
     }
-    // fc1 -> GELU -> fc2 in one workgroup per 128 tokens (vit_mlp_kernel): vfm_cfg().vit_fused_mlp n > 0 from n images on, 0 / -1 never (for now)
-    const bool fused_mlp = vfm_cfg().vit_fused_mlp > 0 && d.B >= vfm_cfg().vit_fused_mlp && d.D == 384 && d.mlp == 1536;
+    // fc1 -> GELU -> fc2 in one workgroup per 128 tokens (vit_mlp_kernel).  vfm_cfg().vit_fused_mlp: n > 0 from n images on, -1 never, 0 (default)
+    // the policy: one workgroup per compute unit whose loop moves nothing through HBM and whose epilogue moves everything -- a single round runs
+    // in lockstep and ends level with the two kernels; from two rounds on the workgroups drift apart and it wins, IF the last round is full
+    // (profiles/r06_ab_vit_fused_mlp_sweep.txt: 84 images 0 %, 144: +1.5 %, 156: -1.9 %, 168: -5.3 %, 180: -6.8 %, 192: +5.4 %, 252: -8.9 %)
+    bool fused_mlp = false;
+    if (d.D == 384 && d.mlp == 1536) {
+        static std::atomic<int> ncu_m{0};
+        if (ncu_m == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            (void)hipGetDevice(&dev);
+            ncu_m = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        const int groups = ceil_div(d.M / 32, 4), rounds = ceil_div(groups, ncu_m), k = vfm_cfg().vit_fused_mlp;
+        fused_mlp = k > 0 ? d.B >= k : (k == 0 && rounds >= 2 && 5 * groups >= 4 * rounds * ncu_m);
+    }
     for (int l = 0; l < d.depth; ++l) {
         const int s0 = SEG_LAYER0 + l * SEGS_PER_LAYER;
         // LayerNorm 1 is inside this GEMM: raw residual stream x folded weight, statistics applied in the epilogue
