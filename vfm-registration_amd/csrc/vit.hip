@@ -2087,10 +2087,11 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_kernel(GemmArgs g1, GemmArgs g
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)ml;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, c_wait = 0;   // (tools: start, loop start, loop end in 100 MHz ticks; shader clocks spent at the loop's waits + barriers)
     if (g1.dbg) tr0 = wall_clock64();
-    // The loop works on PAIRS of hidden chunks.  A dependent MFMA (srcC = the previous result) can issue ~97 cycles after its producer -- three
-    // MFMA times -- and fc1 of one chunk is ONE accumulator chain of 24: alone between fc2's MFMAs it set the pace of the whole loop (2 330 cycles
-    // per chunk for 1 536 of MFMA, tools/build_ablate_mlp.sh).  With two chunks' chains side by side the order A_a A_b B B puts four MFMAs
-    // between the links of either.  Iteration i: fc1 of pair i + 1 (chunks 2 i + 2, 2 i + 3 -> hnA, hnB), LayerNorm fold + GELU of pair i
+    // The loop works on PAIRS of hidden chunks: fc1 of one chunk is ONE accumulator chain of 24 dependent MFMAs, and with two chunks' chains side
+    // by side the order A_a A_b B B puts four MFMAs between the links of either.  (Measured: the MFMA-only skeleton went from 2 335 to 2 222
+    // shader clocks per chunk -- the chain was not what set the pace; a lone wave issues MFMAs at ~46 clocks each in this loop whatever their
+    // order, tools/build_ablate_mlp.sh -- but the halves below are also what lets three 48 KiB slots cover two half-iterations of lead.)
+    // Iteration i: fc1 of pair i + 1 (chunks 2 i + 2, 2 i + 3 -> hnA, hnB), LayerNorm fold + GELU of pair i
     // (hcA, hcB -> fout), fc2 of pair i - 1 (fin), interleaved; 96 MFMAs.  Weights by HALVES of an iteration, one 48 KiB slot each, three slots
     // in flight: half H = 2 i + e holds [k-steps 12 e .. + 11 of W1's tiles 2 i + 2 and 2 i + 3: piece 2 kk + ab][W2's chunk 2 i - 2 + e: piece
     // 12 s2 + j], is requested two halves ahead (an L2 round trip of the LDS-DMA is ~2 us when 231 workgroups ask together) and waited for
