@@ -288,14 +288,14 @@ def extra_configs(dev):
             del e2e
     except Exception as e:  # never lose the line to an auxiliary measurement
         out["C3_pipelined"] = {"error": f"{type(e).__name__}: {e}"}
-    # ---- the ViT on a batch of scans (prepare_scenes.py walks ~170 clouds of a scene: create_descriptors_batch, 14 clouds per call; round 5: 15)
+    # ---- the ViT on a batch of scans (prepare_scenes.py walks ~170 clouds of a scene: create_descriptors_batch, 28 clouds per call; round 5: 15)
     try:
-        for clouds, key in ((14, "ViT_batched"), (15, "at_90_images"), (8, "at_48_images")):
+        for clouds, key in ((28, "ViT_batched"), (14, "at_84_images"), (15, "at_90_images"), (8, "at_48_images")):
             big = imgs.repeat(clouds, 1, 1, 1)
             tb = timed(lambda: model.forward(big), reps=5)
             row = {"workload": f"ViT-S/14 on {6 * clouds} x 1200x1600 images per call ({clouds} clouds of a scene x 6 cameras: prepare_scenes."
-                               "create_descriptors_batch's default is 14); LDS-tiled 128 x 128 GEMMs, QKV + attention per (image, head) in "
-                               "one workgroup where vfm_vit_forward's policy takes it, the token-stationary kernel for fc1 (and QKV otherwise) where "
+                               "create_descriptors_batch's default is 28); LDS-tiled 128 x 128 GEMMs, QKV + attention per (image, head) and fc1 -> GELU -> fc2 "
+                               "per 128 tokens in one workgroup each where vfm_vit_forward's policies take them, the token-stationary kernel for fc1 (and QKV otherwise) where "
                                "its rounds of one workgroup per compute unit are full",
                    "images": 6 * clouds, "ms": tb, "ms_per_scan_of_6": tb / clouds,
                    "roofline": {"bound": "mfma", "flops": clouds * vit_flops, "achieved": clouds * vit_flops / (tb * 1e-3) / 1e12,

@@ -183,7 +183,7 @@ The same pipeline with the coarse pass pinned, other data, other rows (same proc
 {text('r06_time_c3_group.txt')}
 ```
 
-- `extra.ViT_batched`: {vb.get('images')} images per call {vb.get('ms', float('nan')):.2f} ms = {vb.get('ms_per_scan_of_6', float('nan')):.3f} ms per scan of 6 ({vb.get('roofline', {}).get('achieved', float('nan')):.0f} TFLOP/s); 90 images {vb.get('at_90_images', {}).get('ms', float('nan')):.2f} ms, 48 images {vb.get('at_48_images', {}).get('ms', float('nan')):.2f} ms
+- `extra.ViT_batched`: {vb.get('images')} images per call {vb.get('ms', float('nan')):.2f} ms = {vb.get('ms_per_scan_of_6', float('nan')):.3f} ms per scan of 6 ({vb.get('roofline', {}).get('achieved', float('nan')):.0f} TFLOP/s); 84 images {vb.get('at_84_images', {}).get('ms', float('nan')):.2f} ms, 90 images {vb.get('at_90_images', {}).get('ms', float('nan')):.2f} ms, 48 images {vb.get('at_48_images', {}).get('ms', float('nan')):.2f} ms
 - `extra.API_ransac_registration`: {api.get('ms_without_icp', float('nan')):.2f} ms numpy in / numpy out, {api.get('ms_with_icp', float('nan')):.2f} ms with the ICP refinement (scene's map kept between scans)
 - `extra.C5.fp16_descriptor_storage` (the map held in fp16, rows widened on load): {json.dumps(c5.get('fp16_descriptor_storage'))}
 - `extra.stages` RANSAC on executed operations: {json.dumps(ex.get('stages', {}).get('RANSAC + Kabsch (50 000 hypotheses, fp64)', {}).get('executed'))}

@@ -87,13 +87,14 @@ def create_descriptors(image_files, sequence, feature_generator, pcl, images=Non
     return desc.cpu().numpy()
 
 
-def create_descriptors_batch(image_files_list, sequence, feature_generator, pcls, images_list=None, clouds_per_forward: int = 14):
+def create_descriptors_batch(image_files_list, sequence, feature_generator, pcls, images_list=None, clouds_per_forward: int = 28):
     """``create_descriptors`` for a LIST of clouds of one sequence -- what prepare_scenes.main's loops over ~170 map clouds and the
     scans of a scene call one cloud at a time (PS:129-163).  The ViT forward is batched over ``clouds_per_forward`` clouds x their
-    cameras (6 x 14 = 84 images of 1200 x 1600 per call: 0.19 ms per cloud against 0.52 for one cloud per call; the wide GEMMs move to
-    the LDS-tiled kernels, fc1 to the token-stationary one, and QKV + attention to one workgroup per (image, head) -- 504 of them are two
-    full rounds on 256 compute units, csrc/vit.hip; round 5's default of 15 clouds filled the token-stationary GEMMs' single round
-    instead: 32.8 us per image against 31.5 now, profiles/r06_ab_vit_fused_qkv_sweep.txt);
+    cameras (6 x 28 = 168 images of 1200 x 1600 per call: 0.171 ms per cloud against 0.52 for one cloud per call; the wide GEMMs move to
+    the LDS-tiled kernels, QKV + attention to one workgroup per (image, head) and, from two full rounds of workgroups on, fc1 -> GELU -> fc2 to
+    one workgroup per 128 tokens, csrc/vit.hip -- 168 images are 1008 + 462 such workgroups on 256 compute units: 28.5 us per image; 14 clouds
+    (84 images, two rounds of the first kind, one of the second): 29.8; round 5's 15 clouds: 34.7;
+    profiles/r06_ab_vit_fused_qkv_sweep.txt, profiles/r06_ab_vit_fused_mlp_sweep.txt);
     projection and lifting stay per cloud.  A larger batch does not change a single bit of any
     cloud's features (tests/test_gpu_vit.py, tools/time_vit_batch.py), so every returned array equals ``create_descriptors`` of
     that cloud.  Falls back to the per-cloud call for generators without ``patch_features_device`` or cameras of mixed sizes."""
@@ -126,7 +127,7 @@ def create_descriptors_batch(image_files_list, sequence, feature_generator, pcls
 
 
 def prepare_scene(dataset_dir, scene_data: dict, Dataset, feature_generator, date_idx: int, output_filename=None,
-                  clouds_per_forward: int = 14, voxel_down_sample=None):
+                  clouds_per_forward: int = 28, voxel_down_sample=None):
     """prepare_scenes.main without its argument parsing and progress bars (PS:110-171): the map clouds of a scene (voxelised at
     0.2 m, PS:134) and its scans (0.1 m, PS:152) with their lifted descriptors, through ``create_descriptors_batch``; written as the
     reference's HDF5 scene file when ``output_filename`` is given (PS:165-166 -> evaluation.save_scene).  ``Dataset`` is one of
