@@ -43,3 +43,4 @@ timeout 400 python tools/time_c3_group.py 1 2 4 8 1 4 2>&1 | grep -v amdgpu > $O
 # soaks beyond the suite's fixed seeds (the fp6 trial covers record kind 10)
 timeout 600 python tools/soak_mx6.py 40 505 2>&1 | tail -3 > $O/soak_mx6.txt; cat $O/soak_mx6.txt
 timeout 600 python tools/soak_half.py 40 505 2>&1 | tail -3 > $O/soak_half.txt; cat $O/soak_half.txt
+timeout 900 python tools/soak_vit_fused.py 40 606 2>&1 | grep -v amdgpu | tail -4 > $O/soak_vit_fused.txt; cat $O/soak_vit_fused.txt

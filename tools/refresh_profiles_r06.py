@@ -81,7 +81,7 @@ def main():
                    "ab_api_search.txt": "r06_ab_api_search.txt", "ab_vit_wide.txt": "r06_ab_vit_wide.txt", "trace_vit_lds.txt": "r06_trace_vit_lds.txt",
                    "ab_vit_hot_a.txt": "r06_ab_vit_hot_a.txt", "f16_mfma_probe.txt": "r06_f16_mfma_probe.txt", "mfma_lds_probe.txt": "r06_mfma_lds_probe.txt", "l2_lds_probe.txt": "r06_l2_lds_probe.txt"})
     copies.update({"ab_vit_fused_qkv_sweep.txt": "r06_ab_vit_fused_qkv_sweep.txt", "trace_vit_fused.txt": "r06_trace_vit_fused.txt",
-                   "prof_vit_84images.txt": "r06_prof_vit_84images.txt", "pmc_vit_84images.json": "r06_pmc_vit_84images.json"})
+                   "prof_vit_84images.txt": "r06_prof_vit_84images.txt", "soak_vit_fused.txt": "r06_soak_vit_fused.txt", "pmc_vit_84images.json": "r06_pmc_vit_84images.json"})
     for i in range(1, 7):
         copies[f"pmc_vit6_pass{i}_counter_collection.csv"] = f"r06_pmc_vit6_pass{i}_counter_collection.csv"
     for i in range(1, 8):
